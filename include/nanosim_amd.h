@@ -1,0 +1,222 @@
+/*
+ * nanosim_amd.h — C ABI of the MI355X-native read-generation engine.
+ *
+ * The reference (bcgsc/NanoSim v3.2.2, src/simulator.py) has NO FFI/plugin interface: its hot path is
+ * a set of module-level Python functions that share ~30 globals filled by read_profile()
+ * (src/simulator.py:244-591) and are entered through the mp.Process worker targets
+ * (src/simulator.py:1601-1619, 1657-1660).  This header defines the boundary a maintainer would bind
+ * at exactly that worker seam; each entry point cites what it replaces.
+ *
+ * Conventions: plain C, fixed-width little-endian integers, no exceptions across the ABI, every
+ * function returns 0 on success or a negative NS_E* code (message via ns_last_error).  The CALLER owns
+ * host buffers; the LIBRARY owns device buffers.  One context per GPU, used from one host thread.
+ */
+#ifndef NANOSIM_AMD_H
+#define NANOSIM_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NS_ABI_VERSION 1u
+
+/* error codes */
+#define NS_OK 0
+#define NS_EINVAL (-1)   /* bad argument / inconsistent tables */
+#define NS_ENODEV (-2)   /* no HIP device / wrong architecture */
+#define NS_ENOMEM (-3)   /* device or host allocation failed */
+#define NS_EHIP (-4)     /* HIP runtime error (see ns_last_error) */
+#define NS_ESTATE (-5)   /* call order violated (no model / no reference / no batch) */
+
+/* ---- model tables: the flat form of the globals read_profile() fills (src/simulator.py:247-251) ---- */
+
+/* One KDE (sklearn KernelDensity, gaussian): training vector + bandwidth.
+ * Replaces kde.sample() at src/simulator.py:235 (i = floor(U*n); x = N(data[i], bw)). */
+typedef struct ns_kde {
+    const double *data;
+    uint64_t n;
+    double bw;
+} ns_kde;
+
+enum { NS_KDE_ALIGNED = 0,  /* _aligned_region.pkl (or _aligned_reads.pkl with --perfect), S:560,567 */
+       NS_KDE_HT = 1,       /* _ht_length.pkl, log10(len+1), S:552 */
+       NS_KDE_RATIO = 2,    /* _ht_ratio.pkl, S:555 */
+       NS_KDE_UNALIGNED = 3,/* _unaligned_length.pkl, S:545 */
+       NS_KDE_GAP = 4,      /* _gap_length.pkl, log10(len+1), S:577 */
+       NS_KDE_COUNT = 5 };
+
+/* error types / Markov states (trans_error_pr rows, src/simulator.py:486-495) */
+enum { NS_MIS = 0, NS_INS = 1, NS_DEL = 2 };
+enum { NS_ST_START = 0, NS_ST_MIS = 1, NS_ST_INS = 2, NS_ST_DEL = 3, NS_ST_MIS0 = 4, NS_ST_INS0 = 5, NS_ST_DEL0 = 6 };
+
+/* quality classes (lognorm_base_qual keys, src/simulator.py:580-591) */
+enum { NS_Q_MATCH = 0, NS_Q_MIS = 1, NS_Q_INS = 2, NS_Q_HT = 3, NS_Q_UNMAPPED = 4, NS_Q_COUNT = 5 };
+#define NS_QUAL_LEVELS 128u
+#define NS_HP_MAX_BREAKS 4u
+
+typedef struct ns_hp_class {          /* one row (AT or CG) of _hp_lengths_model_parameters.tsv */
+    double konst, alpha1;             /* predict_piecewise, src/model_homopolymer_lengths.py:167-186 */
+    uint32_t n_breaks, _pad;
+    double beta[NS_HP_MAX_BREAKS], breakpoint[NS_HP_MAX_BREAKS];
+    double intercept, slope;          /* predict_lr, src/model_homopolymer_lengths.py:204-209 */
+} ns_hp_class;
+
+typedef struct ns_model_tables {
+    uint32_t abi_version;             /* = NS_ABI_VERSION */
+    uint32_t flags;                   /* NS_MODEL_* */
+
+    /* ECDF of the first match length: read_ecdf(_first_match.hist), src/simulator.py:194-231,497-498.
+     * Segment s covers (hi[s-1], hi[s]] (hi[-1] = 0) and maps linearly onto (vhi[s-1], vhi[s]),
+     * vhi[-1] = fm_vlo0. */
+    uint32_t fm_nseg, _pad0;
+    const double *fm_hi, *fm_vhi;
+    double fm_vlo0;
+
+    /* match Markov model: read_ecdf(_match_markov_model), S:500-501; bins of previous match length */
+    uint32_t mm_nbins, _pad1;
+    const int64_t *mm_bin_lo, *mm_bin_hi;   /* [mm_nbins]  lo <= prev_match < hi, S:1891-1893 */
+    const uint32_t *mm_seg_off;             /* [mm_nbins+1] offsets into mm_hi/mm_vhi */
+    const double *mm_hi, *mm_vhi;
+    const double *mm_vlo0;                  /* [mm_nbins] */
+
+    /* error Markov model rows start,mis,ins,del,mis0,ins0,del0 (S:486-495):
+     * trans[s][0] = a (mis is [0,a)), trans[s][1] = a+b (ins is [a,a+b)), trans[s][2] = 1-c (del is [1-c,1)) */
+    double trans[7][3];
+
+    /* run-length mixtures (error_par, S:473-484; samplers src/mixed_model.py:41-63) as inverse-CDF tables.
+     * mix_cdf[t][0] = first component  (mis: Poisson(lambda)+1;  ins/del: ceil(lambda*Weibull(k)) with 0->1)
+     * mix_cdf[t][1] = second component (mis: Geometric(p);       ins/del: Geometric(p)-1 with 0->1)
+     * cdf[j] = P(value <= j+1); value = 1 + #{j : p > cdf[j]}, capped at mix_n. */
+    double mix_w[3];
+    uint32_t mix_n[3][2];
+    const double *mix_cdf[3][2];
+
+    ns_kde kde[NS_KDE_COUNT];
+
+    double strandness_rate;           /* _strandness_rate or -s, S:270-275 */
+    /* chimeric (S:571-577): number of segments ~ Geometric(1/segment_mean), table as above */
+    uint32_t nseg_n, _pad2;
+    const double *nseg_cdf;
+
+    /* base qualities (src/model_base_qualities.py:9-20,120-130): per class, thr[j] = round(65536*P(q<=j));
+     * q = #{j in [0,126] : h >= thr[j]} for a 16-bit draw h. */
+    uint32_t qual_thr[NS_Q_COUNT][NS_QUAL_LEVELS];
+
+    /* homopolymers (S:504-529; src/model_homopolymer_lengths.py:246-260) */
+    ns_hp_class hp[2];                /* 0 = AT, 1 = CG */
+    double hp_mis_rate;
+} ns_model_tables;
+
+#define NS_MODEL_HAS_ERRORS 1u   /* error tables present (absent with --perfect) */
+#define NS_MODEL_HAS_QUALS 2u
+#define NS_MODEL_HAS_HP 4u
+#define NS_MODEL_HAS_CHIMERIC 8u
+#define NS_MODEL_HAS_UNALIGNED 16u
+
+/* ---- generation parameters: the arguments of the worker targets ------------------------------------
+ * simulation_aligned_genome(dna_type, min_l, max_l, median_l, sd_l, out_reads, out_error, kmer_bias,
+ *                           fastq, num_simulate, per, chimeric)            src/simulator.py:1266-1267
+ * simulation_unaligned(dna_type, min_l, max_l, median_l, sd_l, out_reads, fastq, num_simulate, uracil)
+ *                                                                          src/simulator.py:1482      */
+enum { NS_KIND_ALIGNED = 0, NS_KIND_UNALIGNED = 1, NS_KIND_PERFECT = 2 };
+
+typedef struct ns_params {
+    uint64_t seed;          /* Philox key; (seed, read index) fully determine a read */
+    uint64_t first_read;    /* global index of the first read of this batch (also the number in the name) */
+    uint64_t n_reads;       /* num_simulate for this call */
+    uint32_t kind;          /* NS_KIND_* */
+    uint32_t fastq;         /* emit qualities / FASTQ records */
+    uint32_t kmer_bias;     /* k of -k/--KmerBias; 0 = off (falsy in the reference, S:1413,1920) */
+    uint32_t chimeric;
+    uint32_t use_lognormal; /* -med/-sd given */
+    uint32_t emit_records;  /* 1: format FASTA/FASTQ records on the device */
+    int64_t min_len, max_len;
+    double median_len, sd_len;
+    uint32_t emit_errlog;   /* 1: format the _aligned_error_profile rows on the device (S:2006-2008) */
+    uint32_t _pad;
+} ns_params;
+
+/* ---- device-side result layout (copied out with ns_copy_out) -------------------------------------- */
+
+typedef struct ns_event {   /* one e_dict entry (S:1875-1882): position in un-mutated segment coordinates */
+    uint32_t pos;           /* ceil(key): mis/del at pos, ins before index pos */
+    uint16_t len;
+    uint8_t type;           /* NS_MIS / NS_INS / NS_DEL */
+    uint8_t flags;
+} ns_event;
+
+typedef struct ns_piece {   /* one aligned segment or one chimeric gap / unaligned body */
+    uint64_t ref_gpos;      /* start offset in the concatenated reference */
+    uint64_t ev_off;        /* first event in the event buffer */
+    uint32_t chrom;
+    uint32_t pos;           /* start inside the chromosome (the number in the read name, S:1747,1778) */
+    uint32_t ref_len;       /* middle_ref: reference bases consumed (S:1363) */
+    uint32_t out_len;       /* bases emitted for this piece */
+    uint32_t n_ev;
+    uint32_t kind;          /* 0 aligned segment, 1 gap / unaligned */
+} ns_piece;
+
+typedef struct ns_read {
+    uint64_t rec_off;       /* byte offset of the record in the record buffer */
+    uint32_t piece_off;     /* first piece */
+    uint16_t n_pieces;      /* 2*segments-1 */
+    uint8_t reversed;       /* is_reversed, S:1312 */
+    uint8_t flags;
+    uint32_t head, tail;    /* S:1377-1382 */
+    uint32_t seq_len;       /* emitted bases incl. head/tail */
+    uint32_t attempts;      /* rejected attempts before this one (S:1367) */
+} ns_read;
+
+typedef struct ns_batch_info {
+    uint64_t n_reads, n_pieces, n_events;
+    uint64_t record_bytes;  /* size of the FASTA/FASTQ image */
+    uint64_t errlog_bytes;  /* size of the error-profile image */
+    uint64_t total_bases;   /* sum of seq_len */
+    uint64_t total_ref_bases; /* sum of ref_len over pieces (for the roofline byte count) */
+    uint64_t n_overflow;    /* reads that needed the event-capacity fallback pass */
+    double ms_total;        /* device time of the whole batch (HIP events on the engine stream) */
+    double ms_kernel[8];    /* per-kernel device time: see NS_K_* */
+} ns_batch_info;
+
+enum { NS_K_LENGTHS = 0, NS_K_EVENTS = 1, NS_K_SCAN = 2, NS_K_MATERIALISE = 3, NS_K_HP = 4, NS_K_ERRLOG = 5 };
+enum { NS_BUF_RECORDS = 0, NS_BUF_READS = 1, NS_BUF_PIECES = 2, NS_BUF_EVENTS = 3, NS_BUF_ERRLOG = 4 };
+
+typedef struct ns_ctx ns_ctx;
+
+/* lifecycle */
+int ns_create(int device, ns_ctx **out);
+void ns_destroy(ns_ctx *ctx);
+const char *ns_last_error(const ns_ctx *ctx);
+uint32_t ns_abi_version(void);
+
+/* reference genome: replaces seq_dict/seq_len/genome_len (src/simulator.py:279-353).  `bases` is the
+ * concatenation of all chromosomes as read from the FASTA (any case, IUPAC allowed); chrom_off has
+ * nchrom+1 entries; circular[i] != 0 marks a circular chromosome (-dna_type circular, dict_dna_type);
+ * names is a NUL-separated blob of the (already normalised, S:344-347) chromosome names. */
+int ns_set_reference(ns_ctx *ctx, const uint8_t *bases, uint64_t nbases, const uint64_t *chrom_off,
+                     uint32_t nchrom, const uint8_t *circular, const char *names, uint64_t names_len);
+/* same, but `bases_dev` is already resident in this GPU's HBM (e.g. filled by an RCCL broadcast);
+ * the library does not take ownership of it. */
+int ns_set_reference_device(ns_ctx *ctx, const void *bases_dev, uint64_t nbases, const uint64_t *chrom_off,
+                            uint32_t nchrom, const uint8_t *circular, const char *names, uint64_t names_len);
+
+/* model: replaces the globals filled by read_profile() (src/simulator.py:473-591) */
+int ns_load_model(ns_ctx *ctx, const ns_model_tables *tables);
+
+/* the hot path: replaces one worker call simulation_aligned_genome / simulation_unaligned
+ * (src/simulator.py:1266-1454, 1482-1549).  Results stay in HBM until the next ns_generate. */
+int ns_generate(ns_ctx *ctx, const ns_params *params, ns_batch_info *info);
+
+/* copy a result buffer of the last batch to host memory; nbytes must not exceed the buffer size
+ * (record_bytes, n_reads*sizeof(ns_read), n_pieces*sizeof(ns_piece), n_events*sizeof(ns_event), errlog_bytes) */
+int ns_copy_out(ns_ctx *ctx, int which, void *host_dst, uint64_t offset, uint64_t nbytes);
+/* device address of a result buffer (for zero-copy consumers such as torch / RCCL); NULL if absent */
+const void *ns_device_ptr(ns_ctx *ctx, int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NANOSIM_AMD_H */

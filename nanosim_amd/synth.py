@@ -1,0 +1,224 @@
+"""Synthetic NanoSim model + reference generator.
+
+The reference tree ships no pre-trained models (`.MISSING_LARGE_BLOBS`), so every
+model used by tests and by bench.py is synthesised here in the *on-disk formats* the reference's
+``read_profile`` parses (reference: src/simulator.py:244-591; writers cited per file below).
+
+Nothing here is on the hot path; it only produces inputs.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+IUPAC_AMBIG = "YRWSKMDVHBN"
+
+
+@dataclass
+class SynthModelSpec:
+    """Parameters of the `hg002_like` synthetic model."""
+    n_train: int = 1_000_000
+    seed: int = 20260926
+    aligned_median: float = 7000.0
+    aligned_sigma: float = 0.6
+    ht_median: float = 40.0
+    ht_sigma: float = 0.8
+    ht_zero_frac: float = 0.02          # some reads have no head/tail at all
+    unaligned_median: float = 1500.0
+    unaligned_sigma: float = 0.9
+    gap_median: float = 20.0
+    gap_sigma: float = 1.0
+    alignment_ratio: float = 19.0       # aligned/unaligned
+    strandness: float = 0.5
+    segment_mean: float = 1.05
+    abun_inflation: float = 0.25        # metagenome only ("Shrinkage rate (beta)")
+    # mixture parameters: [lambda, k, prob, weight]  (src/model_fitting.py:136,169,203)
+    mis: tuple = (0.35, 0.0, 0.75, 0.55)
+    ins: tuple = (1.1, 0.9, 0.55, 0.45)
+    dele: tuple = (1.2, 0.95, 0.5, 0.5)
+    # 7x3 error Markov model, rows start,mis,ins,del,mis0,ins0,del0 (src/besthit_to_histogram.py:410-422)
+    trans: tuple = (
+        (0.45, 0.22, 0.33),
+        (0.46, 0.21, 0.33),
+        (0.42, 0.25, 0.33),
+        (0.44, 0.23, 0.33),
+        (0.30, 0.30, 0.40),
+        (0.50, 0.10, 0.40),
+        (0.40, 0.35, 0.25),
+    )
+    ecdf_rows: int = 200
+    # previous-match-length bins for the match Markov model and the mean match length in each
+    mm_bins: tuple = ((0, 1), (1, 3), (3, 6), (6, 10), (10, 18), (18, 30), (30, 60), (60, 200))
+    mm_means: tuple = (24.0, 26.0, 28.0, 30.0, 31.0, 32.0, 34.0, 36.0)
+    mm_zero: tuple = (0.0, 0.02, 0.03, 0.03, 0.03, 0.03, 0.03, 0.03)   # P(match length 0)
+    fm_mean: float = 18.0
+    # base qualities: type -> (sd, loc, mu)   (src/model_base_qualities.py:146-159)
+    quals: dict = field(default_factory=lambda: {
+        "mis": (0.50, 0.0, 2.2), "ins": (0.48, 0.0, 2.3), "match": (0.35, 0.0, 3.2),
+        "ht": (0.45, 0.0, 2.6), "unmapped": (0.42, 0.0, 2.4)})
+    hp_mis_rate: float = 0.03
+    # base -> dict of piecewise (const, beta1, breakpoint1, alpha1, alpha2) + lr (intercept, slope)
+    hp: dict = field(default_factory=lambda: {
+        "AT": dict(const=0.35, beta1=-0.25, breakpoint1=12.0, alpha1=0.92, alpha2=0.67,
+                   intercept=0.0, slope=0.09),
+        "CG": dict(const=0.42, beta1=-0.30, breakpoint1=10.0, alpha1=0.90, alpha2=0.60,
+                   intercept=0.0, slope=0.10)})
+
+
+def _geometric_cdf(n_rows: int, mean: float, p_zero: float, first_nonzero: int = 0) -> np.ndarray:
+    """CDF over integer match lengths 0..n_rows-1 (row i is the bin i-(i+1))."""
+    k = np.arange(n_rows, dtype=np.float64)
+    q = 1.0 / max(mean, 1.0)
+    pmf = q * (1.0 - q) ** k
+    pmf[:first_nonzero] = 0.0
+    if first_nonzero == 0:
+        pmf[0] = 0.0
+        pmf = pmf / pmf.sum() * (1.0 - p_zero)
+        pmf[0] = p_zero
+    else:
+        pmf = pmf / pmf.sum()
+    cdf = np.cumsum(pmf)
+    cdf[-1] = 1.0
+    return cdf
+
+
+def write_model(prefix: str, spec: SynthModelSpec | None = None, *, write_pkl: bool = True,
+                write_npz: bool = True) -> SynthModelSpec:
+    """Write every `<prefix>_*` file of SURVEY.md §5.6.
+
+    KDE training vectors are written both as sklearn/joblib pickles (what the reference loads,
+    src/simulator.py:545-577; writers src/head_align_tail_dist.py:255-278) and as a neutral
+    `<prefix>_kde.npz` that our loader prefers (no sklearn needed on the GPU box).
+    """
+    spec = spec or SynthModelSpec()
+    rng = np.random.Generator(np.random.Philox(spec.seed))
+    d = os.path.dirname(prefix)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    n = spec.n_train
+
+    # --- KDE training vectors --------------------------------------------------------------
+    aligned = np.maximum(1.0, np.rint(rng.lognormal(np.log(spec.aligned_median), spec.aligned_sigma, n)))
+    ht_len = np.rint(rng.lognormal(np.log(spec.ht_median), spec.ht_sigma, n))
+    ht_len[rng.random(n) < spec.ht_zero_frac] = 0.0
+    ht = np.log10(ht_len + 1.0)
+    ratio = rng.beta(2.0, 2.0, n)
+    unaligned = np.maximum(1.0, np.rint(rng.lognormal(np.log(spec.unaligned_median), spec.unaligned_sigma, n)))
+    gap = np.log10(np.rint(rng.lognormal(np.log(spec.gap_median), spec.gap_sigma, n)) + 1.0)
+    # aligned_reads (perfect mode) = whole read length
+    aligned_reads = aligned + ht_len
+    kdes = {
+        "aligned_region": (aligned, 10.0), "aligned_reads": (aligned_reads, 10.0),
+        "unaligned_length": (unaligned, 10.0), "ht_length": (ht, 0.01), "ht_ratio": (ratio, 0.01),
+        "gap_length": (gap, 0.01),
+    }
+    if write_npz:
+        np.savez(prefix + "_kde.npz", **{k + "_data": v[0] for k, v in kdes.items()},
+                 **{k + "_bw": np.float64(v[1]) for k, v in kdes.items()})
+    if write_pkl:
+        import joblib
+        from sklearn.neighbors import KernelDensity
+        for name, (vec, bw) in kdes.items():
+            kde = KernelDensity(bandwidth=bw).fit(vec[:, None])
+            joblib.dump(kde, prefix + "_" + name + ".pkl")
+
+    # --- text tables -----------------------------------------------------------------------
+    with open(prefix + "_model_profile", "w") as f:           # src/model_fitting.py:110,136,169,203
+        f.write("Type\tlambda\tk\tprob\tweight\n")
+        f.write("mismatch\t" + "\t".join(str(x) for x in spec.mis) + "\n")
+        f.write("insertion\t" + "\t".join(str(x) for x in spec.ins) + "\n")
+        f.write("deletion\t" + "\t".join(str(x) for x in spec.dele) + "\n")
+
+    with open(prefix + "_error_markov_model", "w") as f:      # src/besthit_to_histogram.py:410-422
+        f.write("succedent \tmis\tins\tdel\n")
+        names = ["start", "mis", "ins", "del", "mis0", "ins0", "del0"]
+        f.write("\n".join(nm + "\t" + "\t".join(str(x) for x in row) for nm, row in zip(names, spec.trans)))
+
+    rows = spec.ecdf_rows
+    with open(prefix + "_first_match.hist", "w") as f:        # src/besthit_to_histogram.py:479-484
+        f.write("bin\t0-50000\n")
+        cdf = _geometric_cdf(rows, spec.fm_mean, 0.0, first_nonzero=2)
+        for i in range(rows):
+            f.write("%d-%d\t%s\n" % (i, i + 1, str(float(cdf[i]))))
+
+    with open(prefix + "_match_markov_model", "w") as f:      # src/besthit_to_histogram.py:464-474
+        f.write("bins\t" + "\t".join("%d-%d" % b for b in spec.mm_bins) + "\n")
+        cdfs = [_geometric_cdf(rows, m, z) for m, z in zip(spec.mm_means, spec.mm_zero)]
+        for i in range(rows):
+            f.write("%d-%d" % (i, i + 1))
+            for c in cdfs:
+                v = float(c[i])
+                f.write("\t" + ("0" if v == 0.0 else str(v)))
+            f.write("\n")
+
+    with open(prefix + "_reads_alignment_rate", "w") as f:    # src/read_analysis.py:840-851
+        f.write("Aligned / Unaligned ratio:\t" + str(spec.alignment_ratio) + "\n")
+    with open(prefix + "_strandness_rate", "w") as f:         # src/read_analysis.py:833-835
+        f.write("strandness:\t" + str(spec.strandness) + "\n")
+    with open(prefix + "_chimeric_info", "w") as f:           # src/get_primary_sam.py:472-475
+        f.write("Mean segments for each aligned read:\t" + str(spec.segment_mean) + "\n")
+        f.write("Shrinkage rate (beta):\t" + str(spec.abun_inflation) + "\n")
+    with open(prefix + "_base_qualities_model_parameters.tsv", "w") as f:   # src/model_base_qualities.py:146-159
+        f.write("type\tsd\tloc\tmu\n")
+        for t in ("mis", "ins", "match", "ht", "unmapped"):
+            sd, loc, mu = spec.quals[t]
+            f.write("%s\t%s\t%s\t%s\n" % (t, sd, loc, mu))
+    with open(prefix + "_hp_lengths_model_parameters.tsv", "w") as f:       # src/model_homopolymer_lengths.py:236-243
+        f.write("#Homopolymer mismatch rate: " + str(spec.hp_mis_rate) + "\n")
+        cols = ["const", "beta1", "breakpoint1", "alpha1", "alpha2", "intercept", "slope"]
+        f.write("base\t" + "\t".join(cols) + "\n")
+        for base in ("AT", "CG"):
+            f.write(base + "\t" + "\t".join(str(spec.hp[base][c]) for c in cols) + "\n")
+    return spec
+
+
+def synth_sequence(length: int, seed: int, *, n_frac: float = 0.0, iupac_frac: float = 0.0,
+                   lower_frac: float = 0.0, hp_boost: float = 0.0) -> np.ndarray:
+    """Random ASCII DNA (uint8). Optional N runs, sprinkled IUPAC codes, lower-case stretches and
+    homopolymer enrichment so that `case_convert` (src/simulator.py:743-755) and `-k` have work."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seq = lut[rng.integers(0, 4, length, dtype=np.uint8)]
+    if hp_boost > 0 and length > 64:
+        n_runs = int(length * hp_boost / 8)
+        starts = rng.integers(0, length - 32, n_runs)
+        lens = rng.geometric(0.25, n_runs) + 4
+        for s, l in zip(starts, lens):
+            seq[s:s + l] = seq[s]
+    if n_frac > 0 and length > 1000:
+        n_runs = max(1, int(length * n_frac / 200))
+        starts = rng.integers(0, length - 400, n_runs)
+        lens = rng.integers(50, 350, n_runs)
+        for s, l in zip(starts, lens):
+            seq[s:s + l] = ord("N")
+    if iupac_frac > 0:
+        k = int(length * iupac_frac)
+        pos = rng.integers(0, length, k)
+        codes = np.frombuffer(IUPAC_AMBIG.encode(), dtype=np.uint8)
+        seq[pos] = codes[rng.integers(0, len(codes), k)]
+    if lower_frac > 0 and length > 1000:
+        n_runs = max(1, int(length * lower_frac / 300))
+        starts = rng.integers(0, length - 600, n_runs)
+        lens = rng.integers(100, 500, n_runs)
+        for s, l in zip(starts, lens):
+            seq[s:s + l] |= 0x20
+    return seq
+
+
+def write_fasta(path: str, records: list[tuple[str, np.ndarray]], width: int = 80) -> None:
+    with open(path, "wb") as f:
+        for name, seq in records:
+            f.write(b">" + name.encode() + b"\n")
+            b = seq.tobytes()
+            for i in range(0, len(b), width):
+                f.write(b[i:i + width] + b"\n")
+
+
+# Reference sets of SURVEY.md §8d (lengths only; content is seeded random)
+ECOLI_LEN = 4_641_652
+CHR1_LEN = 248_956_422
+GRCH38_LENS = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636,
+               138394717, 133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345,
+               83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415]

@@ -1,0 +1,817 @@
+/*
+ * ns_oracle.c — CPU restatement of NanoSim's per-read generation path.
+ *
+ * >>> TEST INFRASTRUCTURE ONLY. <<<  Nothing in nanosim_amd/ (the product) links, imports or calls
+ * this file.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it, and
+ * only as the checker.
+ *
+ * Every function cites the reference lines it follows (S: = /root/reference/src/simulator.py,
+ * mm: = src/mixed_model.py, hp: = src/model_homopolymer_lengths.py, bq: = src/model_base_qualities.py).
+ *
+ * Two draw sources:
+ *   NSO_PHILOX  counter-based draws with the layout of DESIGN.md §4 — the HIP kernels must reproduce
+ *               these results bit-for-bit;
+ *   NSO_TAPE    uniforms / run lengths / normals are popped from tapes recorded while running the REAL
+ *               reference (tests/golden/make_golden.py) — this is how the restatement is pinned.
+ *
+ * Parity status: pinned against outputs of the imported reference (tests/golden/*.json); the reference
+ * itself has no tests.
+ *
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off; fma() only where written).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/nanosim_amd.h"
+
+/* ------------------------------------------------------------------------------------------------
+ * Philox4x32-10 (Salmon et al. 2011) and the counter layout
+ * ---------------------------------------------------------------------------------------------- */
+enum {
+    ST_NSEG = 1, ST_REFLEN = 2, ST_GAPLEN = 3, ST_HT = 4, ST_RATIO = 5, ST_STRAND = 6, ST_EVENT = 7,
+    ST_UEVENT = 8, ST_POS = 9, ST_IUPAC = 10, ST_SUB = 11, ST_INS = 12, ST_QUAL = 13, ST_HTQ = 14,
+    ST_HEAD = 15, ST_TAIL = 16, ST_HPLEN = 17, ST_HPMIS = 18, ST_HPQ = 19, ST_ULEN = 20
+};
+#define NSO_GAP_SEG 128u          /* gaps use seg ids 128+g */
+#define NSO_MAX_ATTEMPT 1000u
+#define NSO_EPOCH_FAILS 64u
+#define NSO_KDE_RETRY 64u
+#define NSO_POS_RETRY 64u
+
+void nso_philox(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]) {
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+typedef struct nso_draw {
+    int mode;                 /* 0 = Philox, 1 = tape */
+    uint64_t seed, read;
+    const double *tape_u; uint64_t n_u, i_u;      /* uniforms in consumption order */
+    const int64_t *tape_n; uint64_t n_n, i_n;     /* run lengths returned by pois_geom / wei_geom */
+    const double *tape_z; uint64_t n_z, i_z;      /* normal variates */
+    int tape_err;
+} nso_draw;
+
+static void philox_at(const nso_draw *d, uint32_t stream, uint32_t seg, uint32_t attempt, uint32_t idx,
+                      uint32_t sub, uint32_t w[4]) {
+    uint32_t c3 = (uint32_t)((d->read >> 32) & 0xffu) << 24 | (stream & 0x3fu) << 18 | (seg & 0xffu) << 10 |
+                  (attempt & 0x3ffu);
+    nso_philox((uint32_t)d->seed, (uint32_t)(d->seed >> 32), idx, sub, (uint32_t)d->read, c3, w);
+}
+static inline double u32_to_p(uint32_t x) { return ((double)x + 0.5) * 0x1p-32; }
+static inline double u53_to_p(uint32_t a, uint32_t b) {
+    return ((double)(((uint64_t)(a >> 5) << 26) | (uint64_t)(b >> 6)) + 0.5) * 0x1p-53;
+}
+static double tape_u(nso_draw *d) {
+    if (d->i_u >= d->n_u) { d->tape_err = 1; return 0.5; }
+    return d->tape_u[d->i_u++];
+}
+static int64_t tape_n(nso_draw *d) {
+    if (d->i_n >= d->n_n) { d->tape_err = 1; return 1; }
+    return d->tape_n[d->i_n++];
+}
+static double tape_z(nso_draw *d) {
+    if (d->i_z >= d->n_z) { d->tape_err = 1; return 0.0; }
+    return d->tape_z[d->i_z++];
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * exact-operation math (only + - * / sqrt fma and bit moves, so CPU and GPU agree bit-for-bit)
+ * ---------------------------------------------------------------------------------------------- */
+double nso_log(double x) {
+    uint64_t b; memcpy(&b, &x, 8);
+    int e = (int)((b >> 52) & 0x7ff) - 1023;
+    b = (b & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+    double m; memcpy(&m, &b, 8);
+    if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+    double s = (m - 1.0) / (m + 1.0);
+    double z = s * s;
+    double r = 1.0 / 23.0;
+    r = fma(r, z, 1.0 / 21.0); r = fma(r, z, 1.0 / 19.0); r = fma(r, z, 1.0 / 17.0);
+    r = fma(r, z, 1.0 / 15.0); r = fma(r, z, 1.0 / 13.0); r = fma(r, z, 1.0 / 11.0);
+    r = fma(r, z, 1.0 / 9.0);  r = fma(r, z, 1.0 / 7.0);  r = fma(r, z, 1.0 / 5.0);
+    r = fma(r, z, 1.0 / 3.0);  r = fma(r, z, 1.0);
+    return fma((double)e, 0.6931471805599453, 2.0 * s * r);
+}
+
+double nso_exp(double y) {
+    if (y > 700.0) y = 700.0;
+    if (y < -700.0) y = -700.0;
+    double k = floor(fma(y, 1.4426950408889634, 0.5));
+    double r = fma(-k, 6.93147180369123816490e-01, y);
+    r = fma(-k, 1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;                 /* 1/13! */
+    p = fma(p, r, 1.0 / 479001600.0); p = fma(p, r, 1.0 / 39916800.0); p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);    p = fma(p, r, 1.0 / 40320.0);    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);       p = fma(p, r, 1.0 / 120.0);      p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);         p = fma(p, r, 0.5);              p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    uint64_t b = (uint64_t)((int64_t)k + 1023) << 52;
+    double sc; memcpy(&sc, &b, 8);
+    return p * sc;
+}
+
+/* inverse normal CDF, P. J. Acklam's rational approximation (rel. err 1.15e-9) */
+double nso_norminv(double p) {
+    static const double a[6] = {-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02,
+                                1.383577518672690e+02, -3.066479806614716e+01, 2.506628277459239e+00};
+    static const double b[5] = {-5.447609879822406e+01, 1.615858368580409e+02, -1.556989798598866e+02,
+                                6.680131188771972e+01, -1.328068155288572e+01};
+    static const double c[6] = {-7.784894002430293e-03, -3.223964580411365e-01, -2.400758277161838e+00,
+                                -2.549732539343734e+00, 4.374664141464968e+00, 2.938163982698783e+00};
+    static const double dd[4] = {7.784695709041462e-03, 3.224671290700398e-01, 2.445134137142996e+00,
+                                 3.754408661907416e+00};
+    const double plow = 0.02425;
+    if (p < plow || p > 1.0 - plow) {
+        double t = (p < plow) ? p : 1.0 - p;
+        double q = sqrt(-2.0 * nso_log(t));
+        double num = c[0];
+        for (int i = 1; i < 6; ++i) num = fma(num, q, c[i]);
+        double den = dd[0];
+        for (int i = 1; i < 4; ++i) den = fma(den, q, dd[i]);
+        den = fma(den, q, 1.0);
+        double x = num / den;
+        return (p < plow) ? x : -x;
+    }
+    double q = p - 0.5, r = q * q;
+    double num = a[0];
+    for (int i = 1; i < 6; ++i) num = fma(num, r, a[i]);
+    double den = b[0];
+    for (int i = 1; i < 5; ++i) den = fma(den, r, b[i]);
+    den = fma(den, r, 1.0);
+    return num * q / den;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * table look-ups
+ * ---------------------------------------------------------------------------------------------- */
+/* ECDF look-up of S:1845-1849 / S:1895-1898: segment with lo < p <= hi;
+ * value = floor((p-lo)/(hi-lo)*(vhi-vlo)+vlo).  p above the last edge is clamped onto it (the
+ * reference would reuse a stale value or raise; DESIGN.md "conscious fixes"). */
+int64_t nso_ecdf_lookup(const double *hi, const double *vhi, uint32_t n, double vlo0, double p) {
+    uint32_t lo_i = 0, hi_i = n;            /* first s with p <= hi[s] */
+    while (lo_i < hi_i) {
+        uint32_t mid = (lo_i + hi_i) >> 1;
+        if (p <= hi[mid]) hi_i = mid; else lo_i = mid + 1;
+    }
+    uint32_t s = lo_i;
+    if (s >= n) { s = n - 1; p = hi[s]; }
+    double plo = s ? hi[s - 1] : 0.0;
+    double vlo = s ? vhi[s - 1] : vlo0;
+    return (int64_t)floor((p - plo) / (hi[s] - plo) * (vhi[s] - vlo) + vlo);
+}
+
+/* inverse-CDF table: value = 1 + #{j : p > cdf[j]}, capped at n */
+static int64_t table_value(const double *cdf, uint32_t n, double p) {
+    uint32_t lo = 0, hi = n;                /* first j with p <= cdf[j] */
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (p <= cdf[mid]) hi = mid; else lo = mid + 1;
+    }
+    if (lo >= n) lo = n - 1;
+    return (int64_t)lo + 1;
+}
+
+/* transition pick, S:1860-1864: first of mis [0,a), ins [a,a+b), del [1-c,1) with lo <= p < hi.
+ * If no interval matches (rounding gap) the reference keeps a stale variable; we fall to del when
+ * p >= a+b, else ins. */
+static int trans_pick(const double row[3], double p) {
+    if (0.0 <= p && p < row[0]) return NS_MIS;
+    if (row[0] <= p && p < row[1]) return NS_INS;
+    if (row[2] <= p && p < 1.0) return NS_DEL;
+    return (p >= row[1]) ? NS_DEL : NS_INS;
+}
+
+/* mm:41-49 pois_geom / mm:52-63 wei_geom through the inverse-CDF tables */
+static int64_t run_length(const ns_model_tables *t, int type, double p_mix, double p_len) {
+    int comp = (p_mix < t->mix_w[type]) ? 0 : 1;          /* tmp_rand < weight */
+    return table_value(t->mix_cdf[type][comp], t->mix_n[type][comp], p_len);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * error_list (S:1833-1916)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct nso_elist {
+    int64_t l_new, middle_ref;
+    int64_t e_count[3];       /* match, mis, ins (fastq only) */
+    uint64_t n_ev;
+    int overflow;
+} nso_elist;
+
+static void push_event(ns_event *ev, uint64_t cap, nso_elist *r, int64_t pos, int type, int64_t len) {
+    if (ev && r->n_ev < cap) {
+        ev[r->n_ev].pos = (uint32_t)pos; ev[r->n_ev].len = (uint16_t)len;
+        ev[r->n_ev].type = (uint8_t)type; ev[r->n_ev].flags = 0;
+    } else if (ev) r->overflow = 1;
+    r->n_ev++;
+}
+
+void nso_error_list(const ns_model_tables *t, int64_t m_ref, int fastq, nso_draw *d, uint32_t seg,
+                    uint32_t attempt, ns_event *ev, uint64_t cap, nso_elist *r) {
+    uint32_t w[4];
+    memset(r, 0, sizeof *r);
+    int64_t l_new = m_ref, pos = 0, middle_ref = m_ref;
+    int state = NS_ST_START;
+    /* first match from m_ht_list, floored at 2 (S:1843-1850) */
+    double p;
+    if (d->mode) p = tape_u(d); else { philox_at(d, ST_EVENT, seg, attempt, 0, 0, w); p = u32_to_p(w[0]); }
+    int64_t prev_match = nso_ecdf_lookup(t->fm_hi, t->fm_vhi, t->fm_nseg, t->fm_vlo0, p);
+    if (prev_match < 2) prev_match = 2;
+    pos += prev_match;
+    if (fastq) r->e_count[0] += (prev_match > middle_ref) ? middle_ref : prev_match;     /* S:1852-1856 */
+    uint32_t it = 1;
+    int64_t last_ins_pos = -1;          /* collision of two insertions on key pos-0.5 (S:1882) */
+    while (pos < middle_ref) {                                                             /* S:1858 */
+        double p_err, p_mix = 0, p_len = 0, p_match;
+        if (!d->mode) {
+            philox_at(d, ST_EVENT, seg, attempt, it, 0, w);
+            p_err = u32_to_p(w[0]); p_mix = u32_to_p(w[1]); p_len = u32_to_p(w[2]); p_match = u32_to_p(w[3]);
+        } else p_err = tape_u(d);
+        int error = trans_pick(t->trans[state], p_err);                                    /* S:1860-1864 */
+        int64_t step = d->mode ? tape_n(d) : run_length(t, error, p_mix, p_len);           /* S:1866-1873 */
+        if (error == NS_INS) l_new += step; else if (error == NS_DEL) l_new -= step;
+        if (error != NS_INS) {                                                             /* S:1875-1880 */
+            push_event(ev, cap, r, pos, error, step);
+            pos += step;
+            if (pos >= middle_ref) { l_new += pos - middle_ref; middle_ref = pos; }
+        } else {                                                                           /* S:1881-1882 */
+            if (last_ins_pos == pos && r->n_ev > 0) {         /* same dict key: the later entry replaces */
+                if (ev && r->n_ev <= cap) ev[r->n_ev - 1].len = (uint16_t)step;
+            } else push_event(ev, cap, r, pos, NS_INS, step);
+            last_ins_pos = pos;
+        }
+        state = NS_ST_MIS + error;                                                         /* S:1884 */
+        if (fastq) {                                                                       /* S:1886-1888 */
+            if (error == NS_MIS) r->e_count[1] += step; else if (error == NS_INS) r->e_count[2] += step;
+        }
+        /* next match length from the bin of prev_match; falls through to the last bin (S:1891-1893) */
+        uint32_t b = 0;
+        for (; b < t->mm_nbins; ++b)
+            if (t->mm_bin_lo[b] <= prev_match && prev_match < t->mm_bin_hi[b]) break;
+        if (b >= t->mm_nbins) b = t->mm_nbins - 1;
+        if (d->mode) p_match = tape_u(d);
+        uint32_t o = t->mm_seg_off[b];
+        step = nso_ecdf_lookup(t->mm_hi + o, t->mm_vhi + o, t->mm_seg_off[b + 1] - o, t->mm_vlo0[b], p_match);
+        if (prev_match == 0 && step == 0) step = 1;                                        /* S:1900-1901 */
+        prev_match = step;
+        if (fastq) r->e_count[0] += step;
+        if (pos + prev_match > middle_ref) { l_new += pos + prev_match - middle_ref; middle_ref = pos + prev_match; }
+        pos += prev_match;
+        if (prev_match == 0) state += 3;                                                   /* S:1913-1914 */
+        else last_ins_pos = -1;
+        ++it;
+    }
+    r->l_new = l_new; r->middle_ref = middle_ref;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * unaligned_error_list (S:1784-1830) with the event rewrite of DESIGN.md §5.3: an insertion at key
+ * pos+0.1 followed by mis/del at key pos is applied by mutate_read to the ALREADY INSERTED bases
+ * (descending key order, S:1960); the equivalent non-overlapping events are emitted here.
+ * ---------------------------------------------------------------------------------------------- */
+void nso_unaligned_error_list(const ns_model_tables *t, int64_t m_ref, nso_draw *d, uint32_t seg,
+                              uint32_t attempt, ns_event *ev, uint64_t cap, nso_elist *r) {
+    uint32_t w[4];
+    memset(r, 0, sizeof *r);
+    int64_t l_new = m_ref, pos = 0, middle_ref = m_ref;
+    int64_t pend_ins = 0;                 /* merged insertion waiting at pos (last_is_ins) */
+    r->l_new = l_new; r->middle_ref = middle_ref;
+    if (m_ref <= 0) return;               /* S:1793-1794 (negative lengths never enter the loop either) */
+    uint32_t it = 0;
+    while (pos < middle_ref) {
+        double p, p_mix = 0, p_len = 0;
+        if (!d->mode) {
+            philox_at(d, ST_UEVENT, seg, attempt, it, 0, w);
+            p = u32_to_p(w[0]); p_mix = u32_to_p(w[1]); p_len = u32_to_p(w[2]);
+        } else p = tape_u(d);
+        ++it;
+        /* error_rate = {(0,0.4): match, (0.4,0.7): mis, (0.7,0.85): ins, (0.85,1): del}, lo <= p < hi */
+        int type = (p < 0.4) ? 3 : (p < 0.7) ? NS_MIS : (p < 0.85) ? NS_INS : NS_DEL;
+        int64_t step = 1;
+        if (type != 3) step = d->mode ? tape_n(d) : run_length(t, type, p_mix, p_len);
+        if (type == NS_INS) { pend_ins += step; l_new += step; continue; }   /* S:1808-1815 */
+        if (type == NS_DEL) l_new -= step;
+        int64_t L = pend_ins; pend_ins = 0;
+        if (type == 3) {
+            if (L) push_event(ev, cap, r, pos + 1, NS_INS, L);
+        } else if (type == NS_MIS) {
+            if (!L) push_event(ev, cap, r, pos, NS_MIS, step);
+            else {
+                push_event(ev, cap, r, pos, NS_MIS, 1);
+                push_event(ev, cap, r, pos + 1, NS_INS, L);
+                if (step - 1 > L) push_event(ev, cap, r, pos + 1, NS_MIS, step - 1 - L);
+            }
+        } else {
+            if (!L) push_event(ev, cap, r, pos, NS_DEL, step);
+            else {
+                int64_t dl = step - L; if (dl < 1) dl = 1;
+                push_event(ev, cap, r, pos, NS_DEL, dl);
+                if (L - (step - 1) > 0) push_event(ev, cap, r, pos + 1, NS_INS, L - (step - 1));
+            }
+        }
+        pos += step;
+        if (pos > middle_ref) { l_new += pos - middle_ref; middle_ref = pos; }               /* S:1826-1828 */
+    }
+    r->l_new = l_new; r->middle_ref = middle_ref;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * letters
+ * ---------------------------------------------------------------------------------------------- */
+static const char BASES[4] = {'A', 'T', 'C', 'G'};        /* S:49 */
+static int base_rank(uint8_t c) { return c == 'A' ? 0 : c == 'T' ? 1 : c == 'C' ? 2 : c == 'G' ? 3 : -1; }
+
+/* case_convert (S:743-755): members in the reference's list order */
+static int iupac_members(uint8_t c, char out[4]) {
+    const char *m;
+    switch (c) {
+        case 'Y': m = "CT"; break; case 'R': m = "AG"; break; case 'W': m = "AT"; break;
+        case 'S': m = "GC"; break; case 'K': m = "TG"; break; case 'M': m = "CA"; break;
+        case 'D': m = "AGT"; break; case 'V': m = "ACG"; break; case 'H': m = "ACT"; break;
+        case 'B': m = "CGT"; break; case 'N': m = "ATCG"; break; case 'X': m = "ATCG"; break;
+        default: return 0;
+    }
+    int n = (int)strlen(m);
+    memcpy(out, m, (size_t)n);
+    return n;
+}
+/* normalisation the engine applies once at load time: upper-case; anything that is neither ACGT nor an
+ * IUPAC code becomes N */
+uint8_t nso_normalise_base(uint8_t c) {
+    if (c >= 'a' && c <= 'z') c = (uint8_t)(c - 32);
+    char tmp[4];
+    if (base_rank(c) >= 0 || iupac_members(c, tmp)) return c;
+    return 'N';
+}
+static uint8_t resolve_base(uint8_t c, nso_draw *d, uint32_t seg, uint32_t attempt, uint64_t x) {
+    char mem[4];
+    int n = iupac_members(c, mem);
+    if (!n) return c;
+    uint32_t j;
+    if (d->mode) j = (uint32_t)(tape_u(d) * n);
+    else { uint32_t w[4]; philox_at(d, ST_IUPAC, seg, attempt, (uint32_t)(x >> 2), 0, w); j = (uint32_t)(((uint64_t)w[x & 3] * (uint32_t)n) >> 32); }
+    return (uint8_t)mem[j];
+}
+/* S:1968-1972: uniform choice among BASES minus the current base */
+static uint8_t mis_letter(uint8_t cur, nso_draw *d, uint32_t seg, uint32_t attempt, uint64_t x) {
+    uint32_t j;
+    if (d->mode) j = (uint32_t)(tape_u(d) * 3);
+    else { uint32_t w[4]; philox_at(d, ST_SUB, seg, attempt, (uint32_t)(x >> 2), 0, w); j = (uint32_t)(((uint64_t)w[x & 3] * 3u) >> 32); }
+    int rc = base_rank(cur);
+    int rk = (int)j + ((int)j >= rc ? 1 : 0);
+    if (rc < 0) rk = (int)j;                /* cannot happen after resolve_base */
+    return (uint8_t)BASES[rk];
+}
+static uint8_t ins_letter(nso_draw *d, uint32_t seg, uint32_t attempt, uint64_t x, uint32_t i) {   /* S:1990 */
+    uint32_t j;
+    if (d->mode) j = (uint32_t)(tape_u(d) * 4);
+    else { uint32_t w[4]; philox_at(d, ST_INS, seg, attempt, (uint32_t)x, i >> 2, w); j = w[i & 3] >> 30; }
+    return (uint8_t)BASES[j];
+}
+static uint8_t ht_letter(nso_draw *d, uint32_t stream, uint32_t attempt, uint32_t i) {             /* S:1426-1427 */
+    uint32_t w[4];
+    philox_at(d, stream, 0, attempt, i >> 2, 0, w);
+    return (uint8_t)BASES[w[i & 3] >> 30];
+}
+static uint8_t qual_value(const ns_model_tables *t, int cls, uint32_t h) {
+    const uint32_t *thr = t->qual_thr[cls];
+    uint32_t q = 0;
+    for (uint32_t j = 0; j < NS_QUAL_LEVELS - 1; ++j) q += (h >= thr[j]);
+    return (uint8_t)q;
+}
+static uint8_t qual_at(const ns_model_tables *t, int cls, nso_draw *d, uint32_t stream, uint32_t seg,
+                       uint32_t attempt, uint64_t m) {
+    uint32_t w[4];
+    philox_at(d, stream, seg, attempt, (uint32_t)(m >> 3), 0, w);
+    uint32_t h = (w[(m & 7) >> 1] >> (16 * (m & 1))) & 0xffffu;
+    return qual_value(t, cls, h);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * mutate_read (S:1919-2015) — without the -k filter (added by nso_hp_filter below)
+ *   seg_in : case_convert()ed segment (ref_len bases);  events ascending as generated
+ *   out    : mutated bases; cls: quality class of every emitted base (match/mis/ins)
+ *   log    : error-log rows in the reference's (descending) order
+ * Events are walked in DESCENDING key order like the reference so that tape replay pops the letter
+ * draws in the same order; the output is assembled right-to-left.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct nso_logrow { uint32_t pos, len, type, ref_off, new_off; } nso_logrow;   /* offsets into `txt` */
+
+int64_t nso_mutate_read(const uint8_t *seg_in, int64_t ref_len, const ns_event *ev, uint64_t n_ev, nso_draw *d,
+                        uint32_t seg, uint32_t attempt, uint8_t *out, uint8_t *cls, int64_t out_cap,
+                        nso_logrow *log, uint8_t *txt, uint64_t *txt_len) {
+    /* output length */
+    int64_t out_len = ref_len;
+    for (uint64_t j = 0; j < n_ev; ++j) {
+        if (ev[j].type == NS_INS) out_len += ev[j].len; else if (ev[j].type == NS_DEL) out_len -= ev[j].len;
+    }
+    if (out_len > out_cap || out_len < 0) return -1;
+    int64_t w = out_len;                  /* write cursor (exclusive) */
+    int64_t prev = ref_len;               /* S:1958 */
+    uint64_t tl = 0, row = 0;
+    for (uint64_t jj = n_ev; jj-- > 0;) {
+        const ns_event *e = &ev[jj];
+        int64_t key = e->pos, len = e->len;
+        int64_t err_end = (e->type == NS_INS) ? key : key + len;
+        /* match run after the error: read[err_end:prev] */
+        for (int64_t x = prev - 1; x >= err_end; --x) { --w; out[w] = seg_in[x]; if (cls) cls[w] = NS_Q_MATCH; }
+        if (log) { log[row].pos = (uint32_t)key; log[row].len = (uint32_t)len; log[row].type = e->type;
+                   log[row].ref_off = (uint32_t)tl; }
+        if (e->type == NS_MIS) {
+            uint8_t nb[65536];
+            for (int64_t i = 0; i < len; ++i) nb[i] = mis_letter(seg_in[key + i], d, seg, attempt, (uint64_t)(key + i));
+            for (int64_t i = len - 1; i >= 0; --i) { --w; out[w] = nb[i]; if (cls) cls[w] = NS_Q_MIS; }
+            if (txt) { memcpy(txt + tl, seg_in + key, (size_t)len); tl += (uint64_t)len;
+                       if (log) log[row].new_off = (uint32_t)tl;
+                       memcpy(txt + tl, nb, (size_t)len); tl += (uint64_t)len; }
+        } else if (e->type == NS_DEL) {
+            if (txt) { memcpy(txt + tl, seg_in + key, (size_t)len); tl += (uint64_t)len;
+                       if (log) log[row].new_off = (uint32_t)tl;
+                       memset(txt + tl, '-', (size_t)len); tl += (uint64_t)len; }
+        } else {
+            uint8_t nb[65536];
+            for (int64_t i = 0; i < len; ++i) nb[i] = ins_letter(d, seg, attempt, (uint64_t)key, (uint32_t)i);
+            for (int64_t i = len - 1; i >= 0; --i) { --w; out[w] = nb[i]; if (cls) cls[w] = NS_Q_INS; }
+            if (txt) { memset(txt + tl, '-', (size_t)len); tl += (uint64_t)len;
+                       if (log) log[row].new_off = (uint32_t)tl;
+                       memcpy(txt + tl, nb, (size_t)len); tl += (uint64_t)len; }
+        }
+        prev = key;
+        ++row;
+    }
+    for (int64_t x = prev - 1; x >= 0; --x) { --w; out[w] = seg_in[x]; if (cls) cls[w] = NS_Q_MATCH; }
+    if (txt_len) *txt_len = tl;
+    return (w == 0) ? out_len : -2;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * lengths, positions
+ * ---------------------------------------------------------------------------------------------- */
+/* KernelDensity.sample (sklearn, call site S:235): i = floor(U*n); x = N(data[i], bw) */
+static double kde_sample(const ns_kde *k, const uint32_t w[4]) {
+    uint64_t i = (uint64_t)(u53_to_p(w[0], w[1]) * (double)k->n);
+    if (i >= k->n) i = k->n - 1;
+    return fma(k->bw, nso_norminv(u32_to_p(w[2])), k->data[i]);
+}
+static double pow10m1(double x) { return nso_exp(x * 2.302585092994046) - 1.0; }   /* S:236-237 */
+
+/* extract_read, genome branches (S:1750-1781).  Returns 0 and fills chrom/pos on success. */
+static int extract_pos(const uint64_t *chrom_off, uint32_t nchrom, const uint8_t *circular, int64_t length,
+                       nso_draw *d, uint32_t seg, uint32_t attempt, uint32_t *chrom, uint64_t *pos) {
+    uint64_t genome_len = chrom_off[nchrom];
+    for (uint32_t j = 0; j < NSO_POS_RETRY; ++j) {
+        uint32_t w[4];
+        philox_at(d, ST_POS, seg, attempt, j, 0, w);
+        uint64_t ref_pos = (uint64_t)(u53_to_p(w[0], w[1]) * (double)(genome_len + 1));   /* randint(0, genome_len) */
+        if (ref_pos > genome_len) ref_pos = genome_len;
+        if (circular[0]) {                       /* S:1752-1760: first chromosome, wrap-around */
+            *chrom = 0; *pos = ref_pos; return 0;
+        }
+        for (uint32_t c = 0; c < nchrom; ++c) {  /* S:1770-1778 */
+            uint64_t cl = chrom_off[c + 1] - chrom_off[c];
+            if (ref_pos + (uint64_t)length <= cl) {
+                if (length == 0) { *chrom = c; *pos = ref_pos; return 0; }    /* the reference would spin here */
+                *chrom = c; *pos = ref_pos; return 0;
+            } else if (ref_pos < cl) break;
+            else ref_pos -= cl;
+        }
+    }
+    return -1;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * whole-read restatement: simulation_aligned_genome (S:1266-1454), simulation_unaligned (S:1482-1549),
+ * simulation_gap (S:1552-1568)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct nso_ref {
+    const uint8_t *bases;            /* normalised (upper-case, IUPAC) */
+    const uint64_t *chrom_off;
+    uint32_t nchrom;
+    const uint8_t *circular;
+    const char *const *names;
+} nso_ref;
+
+typedef struct nso_out {
+    ns_read *reads; ns_piece *pieces; ns_event *events;
+    uint64_t cap_pieces, cap_events;
+    uint8_t *records; uint64_t cap_records;
+    uint8_t *errlog; uint64_t cap_errlog;
+    uint64_t n_pieces, n_events, record_bytes, errlog_bytes, total_bases, total_ref_bases;
+} nso_out;
+
+#define NSO_MAX_SEG 64
+
+static void fetch_segment(const nso_ref *ref, uint32_t chrom, uint64_t pos, int64_t len, uint8_t *dst) {
+    uint64_t c0 = ref->chrom_off[chrom], cl = ref->chrom_off[chrom + 1] - c0;
+    for (int64_t i = 0; i < len; ++i) {
+        uint64_t x = pos + (uint64_t)i;
+        if (x >= cl) x -= cl;                      /* circular wrap (S:1757-1760); never taken for linear */
+        dst[i] = ref->bases[c0 + x];
+    }
+}
+
+static int u64_digits(uint64_t v, char *buf) { return sprintf(buf, "%llu", (unsigned long long)v); }
+
+/* Generates read `index` of the batch.  Returns 0, or <0 if buffers are too small / attempts exhausted. */
+static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_params *prm, uint64_t index, nso_out *o) {
+    nso_draw d; memset(&d, 0, sizeof d);
+    d.mode = 0; d.seed = prm->seed; d.read = prm->first_read + index;
+    uint32_t w[4];
+    const int kind = (int)prm->kind;
+    uint32_t nseg = 1;
+    if (kind == NS_KIND_ALIGNED && prm->chimeric) {                       /* S:1276-1277 */
+        philox_at(&d, ST_NSEG, 0, 0, 0, 0, w);
+        nseg = (uint32_t)table_value(t->nseg_cdf, t->nseg_n, u32_to_p(w[0]));
+        if (nseg > NSO_MAX_SEG) nseg = NSO_MAX_SEG;
+    }
+    uint32_t epoch = 0, fails = 0;
+    for (uint32_t a = 0; a < NSO_MAX_ATTEMPT; ++a) {
+        int64_t ref_len[NSO_MAX_SEG], gap_len[NSO_MAX_SEG];
+        int ok = 1;
+        /* ---- lengths ---- */
+        if (kind == NS_KIND_UNALIGNED) {                                  /* S:1494-1495,1499 */
+            philox_at(&d, ST_ULEN, 0, a, 0, 0, w);
+            double x = prm->use_lognormal ? nso_exp(fma(prm->sd_len, nso_norminv(u32_to_p(w[2])), nso_log(prm->median_len)))
+                                          : kde_sample(&t->kde[NS_KDE_UNALIGNED], w);
+            ref_len[0] = (int64_t)x;
+        } else {
+            for (uint32_t s = 0; s < nseg && ok; ++s) {                   /* S:1285-1296,1309 */
+                uint32_t j = 0;
+                for (; j < NSO_KDE_RETRY; ++j) {
+                    philox_at(&d, ST_REFLEN, s, epoch, j, 0, w);
+                    double x;
+                    if (!prm->use_lognormal) x = kde_sample(&t->kde[NS_KDE_ALIGNED], w);
+                    else if (kind == NS_KIND_PERFECT)                      /* S:1286-1287 */
+                        x = nso_exp(fma(prm->sd_len, nso_norminv(u32_to_p(w[2])), nso_log(prm->median_len)));
+                    else {                                                 /* S:1293-1295 */
+                        uint32_t w2[4];
+                        philox_at(&d, ST_REFLEN, s, epoch, j, 1, w2);
+                        double tot = nso_exp(fma(prm->sd_len, nso_norminv(u32_to_p(w[2])),
+                                                 nso_log(prm->median_len + prm->sd_len * prm->sd_len / 2)));
+                        double rem = pow10m1(kde_sample(&t->kde[NS_KDE_HT], w2));
+                        if (rem < 0) continue;
+                        x = tot - rem;
+                    }
+                    int keep = (kind == NS_KIND_PERFECT) ? ((double)prm->min_len <= x && x <= (double)prm->max_len)
+                                                         : (0 < x && x <= (double)prm->max_len);
+                    if (keep) { ref_len[s] = (int64_t)x; break; }
+                }
+                if (j == NSO_KDE_RETRY) ok = 0;
+            }
+            for (uint32_t g = 0; g + 1 < nseg; ++g) {                      /* S:1298-1299 */
+                philox_at(&d, ST_GAPLEN, g, epoch, 0, 0, w);
+                double x = pow10m1(kde_sample(&t->kde[NS_KDE_GAP], w));
+                int64_t gi = (int64_t)x; gap_len[g] = gi < 0 ? 0 : gi;
+            }
+        }
+        int64_t remainder = 0; double ratio = 0; int reversed;
+        if (kind == NS_KIND_ALIGNED && ok) {                               /* S:1471-1474,1351-1352 */
+            uint32_t j = 0;
+            for (; j < NSO_KDE_RETRY; ++j) {
+                philox_at(&d, ST_HT, 0, a, j, 0, w);
+                double x = pow10m1(kde_sample(&t->kde[NS_KDE_HT], w));
+                if (x >= 0) { remainder = (int64_t)x; break; }
+            }
+            if (j == NSO_KDE_RETRY) remainder = 0;
+            for (j = 0; j < NSO_KDE_RETRY; ++j) {
+                philox_at(&d, ST_RATIO, 0, a, j, 0, w);
+                double x = kde_sample(&t->kde[NS_KDE_RATIO], w);
+                if (0 <= x && x <= 1) { ratio = x; break; }
+            }
+            if (j == NSO_KDE_RETRY) ratio = 0.5;
+        }
+        philox_at(&d, ST_STRAND, 0, a, 0, 0, w);
+        reversed = u32_to_p(w[0]) > t->strandness_rate;                   /* S:1312, S:1524-1525 */
+        if (!ok) { ++epoch; fails = 0; continue; }
+
+        /* ---- error lists ---- */
+        uint32_t n_pieces = (kind == NS_KIND_ALIGNED) ? 2 * nseg - 1 : 1;
+        if (o->n_pieces + n_pieces > o->cap_pieces) return -10;
+        ns_piece *pc = o->pieces + o->n_pieces;
+        uint64_t ev0 = o->n_events, evn = ev0;
+        int64_t total = remainder;
+        int overflow = 0;
+        for (uint32_t pi = 0; pi < n_pieces; ++pi) {
+            nso_elist r;
+            int is_gap = (kind == NS_KIND_UNALIGNED) || (pi & 1);
+            uint32_t sid = is_gap ? NSO_GAP_SEG + (pi >> 1) : (pi >> 1);
+            int64_t mlen = is_gap ? (kind == NS_KIND_UNALIGNED ? ref_len[0] : gap_len[pi >> 1]) : ref_len[pi >> 1];
+            memset(&pc[pi], 0, sizeof pc[pi]);
+            pc[pi].kind = (uint32_t)is_gap; pc[pi].ev_off = evn;
+            if (kind == NS_KIND_PERFECT) { memset(&r, 0, sizeof r); r.l_new = r.middle_ref = mlen; }
+            else if (is_gap) nso_unaligned_error_list(t, mlen, &d, sid, a, o->events + evn, o->cap_events - evn, &r);
+            else nso_error_list(t, mlen, (int)prm->fastq, &d, sid, a, o->events + evn, o->cap_events - evn, &r);
+            if (r.overflow) overflow = 1;
+            pc[pi].n_ev = (uint32_t)r.n_ev;
+            pc[pi].ref_len = (uint32_t)(r.middle_ref < 0 ? 0 : r.middle_ref);
+            /* emitted length = ref_len + ins - del over the stored events (collisions already folded in) */
+            int64_t ol = r.middle_ref < 0 ? 0 : r.middle_ref;
+            if (!r.overflow) for (uint64_t j = 0; j < r.n_ev; ++j) {
+                const ns_event *e = &o->events[evn + j];
+                if (e->type == NS_INS) ol += e->len; else if (e->type == NS_DEL) ol -= e->len;
+            }
+            pc[pi].out_len = (uint32_t)ol;
+            evn += r.n_ev;
+            if (!is_gap) total += r.l_new;                                  /* S:1362 (gaps are not counted) */
+            if (kind == NS_KIND_UNALIGNED) total = r.middle_ref;            /* S:1503 */
+        }
+        if (overflow) return -11;
+        if (total < prm->min_len || total > prm->max_len) {                 /* S:1367-1368 / S:1503-1504 */
+            if (kind == NS_KIND_UNALIGNED) continue;
+            if (++fails >= NSO_EPOCH_FAILS) { ++epoch; fails = 0; }
+            continue;
+        }
+        /* ---- head / tail (S:1377-1382) ---- */
+        int64_t head = 0, tail = 0;
+        if (kind == NS_KIND_ALIGNED && remainder != 0) {
+            head = (int64_t)nearbyint((double)remainder * ratio);          /* Python round(): half to even */
+            tail = remainder - head;
+        }
+        /* ---- positions (S:1388-1389, 1510, 1557) ---- */
+        int pos_ok = 1;
+        int64_t seq_len = head + tail;
+        for (uint32_t pi = 0; pi < n_pieces; ++pi) {
+            uint32_t sid = pc[pi].kind ? NSO_GAP_SEG + (pi >> 1) : (pi >> 1);
+            uint32_t chrom = 0; uint64_t pos = 0;
+            if (pc[pi].kind && kind == NS_KIND_ALIGNED && gap_len[pi >> 1] == 0) {   /* S:1553-1554 */
+                pc[pi].ref_len = 0; pc[pi].out_len = 0; pc[pi].n_ev = 0;
+            } else if (extract_pos(ref->chrom_off, ref->nchrom, ref->circular, pc[pi].ref_len, &d, sid, a, &chrom, &pos)) {
+                pos_ok = 0; break;
+            }
+            pc[pi].chrom = chrom; pc[pi].pos = (uint32_t)pos;
+            pc[pi].ref_gpos = ref->chrom_off[chrom] + pos;
+            seq_len += pc[pi].out_len;
+        }
+        if (!pos_ok) { ++epoch; fails = 0; continue; }
+        if (seq_len < prm->min_len || seq_len > prm->max_len) { ++epoch; fails = 0; continue; }   /* S:1429-1430, S:1518-1519 */
+
+        /* ---- accepted: materialise ---- */
+        ns_read *rd = &o->reads[index];
+        memset(rd, 0, sizeof *rd);
+        rd->piece_off = (uint32_t)o->n_pieces; rd->n_pieces = (uint16_t)n_pieces; rd->reversed = (uint8_t)reversed;
+        rd->head = (uint32_t)head; rd->tail = (uint32_t)tail; rd->seq_len = (uint32_t)seq_len; rd->attempts = a;
+        rd->rec_off = o->record_bytes;
+        uint64_t gidx = prm->first_read + index;
+
+        /* name (S:1390-1402, 1332-1343, 1511, 1529-1534) */
+        char name[4096]; int nl = 0; char num[32];
+        int first = 1;
+        for (uint32_t pi = 0; pi < n_pieces; ++pi) {
+            if (pc[pi].kind && kind == NS_KIND_ALIGNED) continue;          /* gaps are not named in genome mode */
+            if (!first) name[nl++] = ';';
+            first = 0;
+            const char *cn = ref->names[pc[pi].chrom];
+            size_t l = strlen(cn); memcpy(name + nl, cn, l); nl += (int)l;
+            name[nl++] = '_'; nl += u64_digits(pc[pi].pos, name + nl);
+        }
+        const char *tag = kind == NS_KIND_ALIGNED ? "_aligned_" : kind == NS_KIND_PERFECT ? "_perfect_" : "_unaligned_";
+        memcpy(name + nl, tag, strlen(tag)); nl += (int)strlen(tag);
+        nl += u64_digits(gidx, name + nl);
+        if (kind == NS_KIND_ALIGNED && nseg > 1) { memcpy(name + nl, "_chimeric", 9); nl += 9; }
+        name[nl++] = '_'; name[nl++] = reversed ? 'R' : 'F';
+        name[nl++] = '_'; nl += u64_digits((uint64_t)head, name + nl);
+        name[nl++] = '_';
+        first = 1;
+        for (uint32_t pi = 0; pi < n_pieces; ++pi) {
+            if (pc[pi].kind && kind == NS_KIND_ALIGNED) continue;
+            if (!first) name[nl++] = ';';
+            first = 0;
+            nl += u64_digits(pc[pi].ref_len, name + nl);
+        }
+        name[nl++] = '_'; nl += u64_digits((uint64_t)tail, name + nl);
+        (void)num;
+
+        uint64_t need = (uint64_t)nl + 2 + (uint64_t)seq_len + 1 + (prm->fastq ? (uint64_t)seq_len + 3 : 0);
+        if (o->record_bytes + need > o->cap_records) return -12;
+        uint8_t *rec = o->records + o->record_bytes;
+        rec[0] = prm->fastq ? '@' : '>';
+        memcpy(rec + 1, name, (size_t)nl); rec[1 + nl] = '\n';
+        uint8_t *seq = rec + nl + 2;
+        uint8_t *qual = prm->fastq ? seq + seq_len + 3 : NULL;
+        int64_t wq = 0;                                      /* cursor in pre-revcomp coordinates */
+        for (int64_t i = 0; i < head; ++i) {                 /* S:1426 */
+            seq[wq] = ht_letter(&d, ST_HEAD, a, (uint32_t)i);
+            if (qual) qual[wq] = qual_at(t, NS_Q_HT, &d, ST_HTQ, 0, a, (uint64_t)i);   /* S:1421-1423 */
+            ++wq;
+        }
+        for (uint32_t pi = 0; pi < n_pieces; ++pi) {
+            uint32_t sid = pc[pi].kind ? NSO_GAP_SEG + (pi >> 1) : (pi >> 1);
+            int64_t rl = pc[pi].ref_len;
+            uint8_t *segbuf = (uint8_t *)malloc((size_t)rl + 1);
+            uint8_t *cls = (uint8_t *)malloc((size_t)pc[pi].out_len + 1);
+            uint64_t txt_cap = 0;
+            for (uint32_t j = 0; j < pc[pi].n_ev; ++j) txt_cap += 2u * o->events[pc[pi].ev_off + j].len;
+            int want_log = (!pc[pi].kind && prm->emit_errlog);
+            nso_logrow *rows = want_log ? (nso_logrow *)malloc(sizeof(nso_logrow) * (pc[pi].n_ev + 1)) : NULL;
+            uint8_t *txt = want_log ? (uint8_t *)malloc(txt_cap + 1) : NULL;
+            uint64_t txt_len = 0;
+            fetch_segment(ref, pc[pi].chrom, pc[pi].pos, rl, segbuf);
+            for (int64_t x = 0; x < rl; ++x) segbuf[x] = resolve_base(segbuf[x], &d, sid, a, (uint64_t)x);   /* S:1406 */
+            int64_t ol = nso_mutate_read(segbuf, rl, o->events + pc[pi].ev_off, pc[pi].n_ev, &d, sid, a, seq + wq,
+                                         cls, seq_len - wq - tail, rows, txt, &txt_len);
+            if (ol != (int64_t)pc[pi].out_len) { free(segbuf); free(cls); free(rows); free(txt); return -13; }
+            if (qual) for (int64_t m = 0; m < ol; ++m)
+                qual[wq + m] = qual_at(t, pc[pi].kind ? NS_Q_UNMAPPED : cls[m], &d, ST_QUAL, sid, a, (uint64_t)m);
+            if (want_log) {                                               /* S:2006-2008 */
+                for (uint32_t j = 0; j < pc[pi].n_ev; ++j) {
+                    const char *tn = rows[j].type == NS_MIS ? "mis" : rows[j].type == NS_INS ? "ins" : "del";
+                    uint64_t nb = (uint64_t)nl + 64 + 2u * rows[j].len;
+                    if (o->errlog_bytes + nb > o->cap_errlog) { free(segbuf); free(cls); free(rows); free(txt); return -14; }
+                    uint8_t *p = o->errlog + o->errlog_bytes;
+                    memcpy(p, name, (size_t)nl); p += nl;
+                    p += sprintf((char *)p, "\t%u\t%s\t%u\t", rows[j].pos, tn, rows[j].len);
+                    memcpy(p, txt + rows[j].ref_off, rows[j].len); p += rows[j].len; *p++ = '\t';
+                    memcpy(p, txt + rows[j].new_off, rows[j].len); p += rows[j].len; *p++ = '\n';
+                    o->errlog_bytes = (uint64_t)(p - o->errlog);
+                }
+            }
+            wq += ol;
+            o->total_ref_bases += (uint64_t)rl;
+            free(segbuf); free(cls); free(rows); free(txt);
+        }
+        for (int64_t i = 0; i < tail; ++i) {                  /* S:1427 */
+            seq[wq] = ht_letter(&d, ST_TAIL, a, (uint32_t)i);
+            if (qual) qual[wq] = qual_at(t, NS_Q_HT, &d, ST_HTQ, 0, a, (uint64_t)(head + i));
+            ++wq;
+        }
+        if (wq != seq_len) return -15;
+        if (reversed) {                                       /* S:1433-1435, reverse_complement S:1675-1680 */
+            for (int64_t i = 0, j = seq_len - 1; i <= j; ++i, --j) {
+                uint8_t x = seq[i], y = seq[j];
+                uint8_t cx = x == 'A' ? 'T' : x == 'T' ? 'A' : x == 'C' ? 'G' : x == 'G' ? 'C' : x;
+                uint8_t cy = y == 'A' ? 'T' : y == 'T' ? 'A' : y == 'C' ? 'G' : y == 'G' ? 'C' : y;
+                seq[i] = cy; seq[j] = cx;
+                if (qual) { uint8_t tq = qual[i]; qual[i] = qual[j]; qual[j] = tq; }
+            }
+        }
+        seq[seq_len] = '\n';
+        if (qual) {                                           /* S:1440-1443 */
+            seq[seq_len + 1] = '+'; seq[seq_len + 2] = '\n';
+            for (int64_t i = 0; i < seq_len; ++i) qual[i] = (uint8_t)(qual[i] + 33);
+            qual[seq_len] = '\n';
+        }
+        o->record_bytes += need;
+        o->n_pieces += n_pieces;
+        o->n_events = evn;
+        o->total_bases += (uint64_t)seq_len;
+        return 0;
+    }
+    return -16;
+}
+
+/* Batch entry: same inputs as ns_generate, host buffers for every output. */
+int nso_generate(const ns_model_tables *t, const uint8_t *bases, const uint64_t *chrom_off, uint32_t nchrom,
+                 const uint8_t *circular, const char *names_blob, const ns_params *prm, nso_out *o) {
+    const char **names = (const char **)malloc(sizeof(char *) * (nchrom + 1));
+    const char *p = names_blob;
+    for (uint32_t c = 0; c < nchrom; ++c) { names[c] = p; p += strlen(p) + 1; }
+    nso_ref ref = {bases, chrom_off, nchrom, circular, names};
+    o->n_pieces = o->n_events = o->record_bytes = o->errlog_bytes = o->total_bases = o->total_ref_bases = 0;
+    int rc = 0;
+    for (uint64_t i = 0; i < prm->n_reads && rc == 0; ++i) rc = gen_read(t, &ref, prm, i, o);
+    free((void *)names);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * small exported helpers for the pinning tests
+ * ---------------------------------------------------------------------------------------------- */
+int64_t nso_table_value(const double *cdf, uint32_t n, double p) { return table_value(cdf, n, p); }
+int nso_trans_pick(const double *row, double p) { return trans_pick(row, p); }
+int64_t nso_run_length(const ns_model_tables *t, int type, double p_mix, double p_len) { return run_length(t, type, p_mix, p_len); }
+double nso_kde_sample(const double *data, uint64_t n, double bw, uint32_t w0, uint32_t w1, uint32_t w2) {
+    ns_kde k = {data, n, bw}; uint32_t w[4] = {w0, w1, w2, 0};
+    return kde_sample(&k, w);
+}
+double nso_pow10m1(double x) { return pow10m1(x); }
+uint8_t nso_qual_value(const ns_model_tables *t, int cls, uint32_t h) { return qual_value(t, cls, h); }
+int nso_extract_pos(const uint64_t *chrom_off, uint32_t nchrom, const uint8_t *circular, int64_t length,
+                    uint64_t seed, uint64_t read, uint32_t seg, uint32_t attempt, uint32_t *chrom, uint64_t *pos) {
+    nso_draw d; memset(&d, 0, sizeof d); d.seed = seed; d.read = read;
+    return extract_pos(chrom_off, nchrom, circular, length, &d, seg, attempt, chrom, pos);
+}
+/* extract_read's position walk for a given randint value (S:1767-1780); -1 = redraw */
+int nso_extract_walk(const uint64_t *chrom_off, uint32_t nchrom, uint64_t ref_pos, int64_t length, uint32_t *chrom, uint64_t *pos) {
+    for (uint32_t c = 0; c < nchrom; ++c) {
+        uint64_t cl = chrom_off[c + 1] - chrom_off[c];
+        if (ref_pos + (uint64_t)length <= cl) { *chrom = c; *pos = ref_pos; return 0; }
+        else if (ref_pos < cl) return -1;
+        else ref_pos -= cl;
+    }
+    return -1;
+}
+void nso_case_convert(uint8_t *seq, int64_t n, nso_draw *d, uint32_t seg, uint32_t attempt) {
+    for (int64_t x = 0; x < n; ++x) seq[x] = resolve_base(nso_normalise_base(seq[x]), d, seg, attempt, (uint64_t)x);
+}

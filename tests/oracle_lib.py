@@ -1,0 +1,145 @@
+"""ctypes binding of oracle/libns_oracle.so — TEST INFRASTRUCTURE ONLY (never imported by nanosim_amd)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from nanosim_amd.model import (EVENT_DTYPE, PIECE_DTYPE, READ_DTYPE, NsModelTables, NsParams)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+
+class NsoDraw(C.Structure):
+    _fields_ = [("mode", C.c_int), ("seed", C.c_uint64), ("read", C.c_uint64),
+                ("tape_u", C.POINTER(C.c_double)), ("n_u", C.c_uint64), ("i_u", C.c_uint64),
+                ("tape_n", C.POINTER(C.c_int64)), ("n_n", C.c_uint64), ("i_n", C.c_uint64),
+                ("tape_z", C.POINTER(C.c_double)), ("n_z", C.c_uint64), ("i_z", C.c_uint64),
+                ("tape_err", C.c_int)]
+
+
+class NsoElist(C.Structure):
+    _fields_ = [("l_new", C.c_int64), ("middle_ref", C.c_int64), ("e_count", C.c_int64 * 3),
+                ("n_ev", C.c_uint64), ("overflow", C.c_int)]
+
+
+class NsoOut(C.Structure):
+    _fields_ = [("reads", C.c_void_p), ("pieces", C.c_void_p), ("events", C.c_void_p),
+                ("cap_pieces", C.c_uint64), ("cap_events", C.c_uint64),
+                ("records", C.c_void_p), ("cap_records", C.c_uint64),
+                ("errlog", C.c_void_p), ("cap_errlog", C.c_uint64),
+                ("n_pieces", C.c_uint64), ("n_events", C.c_uint64), ("record_bytes", C.c_uint64),
+                ("errlog_bytes", C.c_uint64), ("total_bases", C.c_uint64), ("total_ref_bases", C.c_uint64)]
+
+
+class NsoLogRow(C.Structure):
+    _fields_ = [("pos", C.c_uint32), ("len", C.c_uint32), ("type", C.c_uint32), ("ref_off", C.c_uint32),
+                ("new_off", C.c_uint32)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(ROOT, "oracle", "libns_oracle.so")
+        src = os.path.join(ROOT, "oracle", "ns_oracle.c")
+        if not os.path.exists(path) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path)):
+            build()
+        L = C.CDLL(path)
+        L.nso_log.restype = C.c_double; L.nso_log.argtypes = [C.c_double]
+        L.nso_exp.restype = C.c_double; L.nso_exp.argtypes = [C.c_double]
+        L.nso_norminv.restype = C.c_double; L.nso_norminv.argtypes = [C.c_double]
+        L.nso_pow10m1.restype = C.c_double; L.nso_pow10m1.argtypes = [C.c_double]
+        L.nso_ecdf_lookup.restype = C.c_int64
+        L.nso_ecdf_lookup.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_uint32, C.c_double, C.c_double]
+        L.nso_table_value.restype = C.c_int64
+        L.nso_table_value.argtypes = [C.POINTER(C.c_double), C.c_uint32, C.c_double]
+        L.nso_trans_pick.restype = C.c_int; L.nso_trans_pick.argtypes = [C.POINTER(C.c_double), C.c_double]
+        L.nso_run_length.restype = C.c_int64
+        L.nso_run_length.argtypes = [C.POINTER(NsModelTables), C.c_int, C.c_double, C.c_double]
+        L.nso_kde_sample.restype = C.c_double
+        L.nso_kde_sample.argtypes = [C.POINTER(C.c_double), C.c_uint64, C.c_double, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.nso_philox.restype = None
+        L.nso_philox.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)]
+        L.nso_error_list.restype = None
+        L.nso_error_list.argtypes = [C.POINTER(NsModelTables), C.c_int64, C.c_int, C.POINTER(NsoDraw), C.c_uint32,
+                                     C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(NsoElist)]
+        L.nso_unaligned_error_list.restype = None
+        L.nso_unaligned_error_list.argtypes = [C.POINTER(NsModelTables), C.c_int64, C.POINTER(NsoDraw), C.c_uint32,
+                                               C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(NsoElist)]
+        L.nso_mutate_read.restype = C.c_int64
+        L.nso_mutate_read.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_uint64, C.POINTER(NsoDraw), C.c_uint32,
+                                      C.c_uint32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                      C.POINTER(C.c_uint64)]
+        L.nso_generate.restype = C.c_int
+        L.nso_generate.argtypes = [C.POINTER(NsModelTables), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                                   C.c_char_p, C.POINTER(NsParams), C.POINTER(NsoOut)]
+        L.nso_qual_value.restype = C.c_uint8
+        L.nso_qual_value.argtypes = [C.POINTER(NsModelTables), C.c_int, C.c_uint32]
+        L.nso_extract_walk.restype = C.c_int
+        L.nso_extract_walk.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_int64, C.POINTER(C.c_uint32),
+                                       C.POINTER(C.c_uint64)]
+        L.nso_normalise_base.restype = C.c_uint8; L.nso_normalise_base.argtypes = [C.c_uint8]
+        L.nso_case_convert.restype = None
+        L.nso_case_convert.argtypes = [C.c_void_p, C.c_int64, C.POINTER(NsoDraw), C.c_uint32, C.c_uint32]
+        _LIB = L
+    return _LIB
+
+
+def make_tape(u=(), n=(), z=()):
+    """Draw source in tape-replay mode; returns (NsoDraw, keepalive)."""
+    ua = np.ascontiguousarray(u, dtype=np.float64)
+    na = np.ascontiguousarray(n, dtype=np.int64)
+    za = np.ascontiguousarray(z, dtype=np.float64)
+    d = NsoDraw()
+    d.mode = 1
+    d.tape_u = ua.ctypes.data_as(C.POINTER(C.c_double)); d.n_u = len(ua)
+    d.tape_n = na.ctypes.data_as(C.POINTER(C.c_int64)); d.n_n = len(na)
+    d.tape_z = za.ctypes.data_as(C.POINTER(C.c_double)); d.n_z = len(za)
+    return d, (ua, na, za)
+
+
+def make_philox(seed, read):
+    d = NsoDraw()
+    d.mode = 0
+    d.seed = seed
+    d.read = read
+    return d
+
+
+def normalise_bases(bases: np.ndarray) -> np.ndarray:
+    """Upper-case; non-IUPAC -> N (what ns_set_reference does on the device)."""
+    L = lib()
+    lut = np.array([L.nso_normalise_base(i) for i in range(256)], dtype=np.uint8)
+    return lut[bases]
+
+
+def generate(model, ref, params: NsParams, *, bytes_per_read=40000, events_per_read=4000):
+    """Run the CPU restatement for one batch; returns dict of numpy arrays like the engine's outputs."""
+    L = lib()
+    t = model.to_c()
+    n = int(params.n_reads)
+    reads = np.zeros(n, dtype=READ_DTYPE)
+    pieces = np.zeros(n * 8 + 64, dtype=PIECE_DTYPE)
+    events = np.zeros(n * events_per_read + 1024, dtype=EVENT_DTYPE)
+    records = np.zeros(n * bytes_per_read + 4096, dtype=np.uint8)
+    errlog = np.zeros((n * bytes_per_read * 3 + 4096) if params.emit_errlog else 16, dtype=np.uint8)
+    o = NsoOut()
+    o.reads = reads.ctypes.data; o.pieces = pieces.ctypes.data; o.events = events.ctypes.data
+    o.cap_pieces = len(pieces); o.cap_events = len(events)
+    o.records = records.ctypes.data; o.cap_records = len(records)
+    o.errlog = errlog.ctypes.data; o.cap_errlog = len(errlog)
+    bases = normalise_bases(ref.bases)
+    rc = L.nso_generate(C.byref(t), bases.ctypes.data, ref.chrom_off.ctypes.data, len(ref.names),
+                        ref.circular.ctypes.data, ref.names_blob(), C.byref(params), C.byref(o))
+    if rc != 0:
+        raise RuntimeError("nso_generate failed: %d" % rc)
+    return dict(reads=reads, pieces=pieces[:o.n_pieces], events=events[:o.n_events],
+                records=records[:o.record_bytes], errlog=errlog[:o.errlog_bytes],
+                total_bases=int(o.total_bases), total_ref_bases=int(o.total_ref_bases))
