@@ -1,0 +1,436 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures under tests/golden/ by running the REAL reference.
+
+Runs only in the build container (needs /root/reference); the fixtures it writes are plain data
+(inputs + the reference's outputs) and are committed.  The reference is imported unmodified with the
+three unused third-party modules stubbed; its random sources are wrapped to RECORD
+the uniforms / run lengths it consumes so that oracle/ns_oracle.c can be replayed on the same tape.
+
+    python tests/golden/make_golden.py [--dist-reads 100000]
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import random
+import shutil
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from nanosim_amd import synth  # noqa: E402
+
+REF_SRC = "/root/reference/src"
+SMALL_SPEC = dict(n_train=2000, seed=7)
+GENOME_SEED = 11
+
+
+def import_reference():
+    for m in ("HTSeq", "pysam", "piecewise_regression"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    sys.dont_write_bytecode = True
+    if REF_SRC not in sys.path:
+        sys.path.insert(0, REF_SRC)
+    import simulator as S
+    return S
+
+
+def build_inputs(workdir):
+    """Small model (text tables + npz committed; pickles only in workdir) and a 2-chromosome genome."""
+    spec = synth.SynthModelSpec(**SMALL_SPEC)
+    committed = os.path.join(HERE, "model_small", "training")
+    synth.write_model(committed, spec, write_pkl=False, write_npz=True)
+    prefix = os.path.join(workdir, "model", "training")
+    synth.write_model(prefix, spec, write_pkl=True, write_npz=False)
+    seq = synth.synth_sequence(180000, GENOME_SEED, n_frac=0.004, iupac_frac=0.002, lower_frac=0.08, hp_boost=0.02)
+    recs = [("chr_A.1 first test chromosome", seq[:110000]), ("chrB", seq[110000:150000]), ("plasmid_c.2", seq[150000:])]
+    fasta = os.path.join(HERE, "genome_small.fa")
+    synth.write_fasta(fasta, recs)
+    circ = os.path.join(HERE, "genome_circ.fa")
+    synth.write_fasta(circ, [("NC_000913.3 synthetic circular", synth.synth_sequence(60000, GENOME_SEED + 1, iupac_frac=0.001))])
+    return prefix, fasta, circ
+
+
+class Recorder:
+    """Wraps the reference's random sources and records what they return."""
+
+    def __init__(self, S):
+        self.S = S
+        self.u, self.n = [], []
+        self._rr = random.random
+        self._pg, self._wg = S.mm.pois_geom, S.mm.wei_geom
+        self._choice = random.choice
+
+    def __enter__(self):
+        S = self.S
+
+        def rr():
+            v = self._rr()
+            self.u.append(v)
+            return v
+
+        def pg(*a):
+            v = int(self._pg(*a))
+            self.n.append(v)
+            return v
+
+        def wg(*a):
+            v = int(self._wg(*a))
+            self.n.append(v)
+            return v
+
+        def choice(seq):
+            v = self._rr()
+            self.u.append(v)
+            return seq[int(v * len(seq))]
+
+        random.random = rr
+        random.choice = choice
+        S.mm.pois_geom, S.mm.wei_geom = pg, wg
+        return self
+
+    def __exit__(self, *exc):
+        random.random = self._rr
+        random.choice = self._choice
+        self.S.mm.pois_geom, self.S.mm.wei_geom = self._pg, self._wg
+
+
+def edict_list(e_dict):
+    return [[float(k), v[0], int(v[1])] for k, v in sorted(e_dict.items())]
+
+
+def fixture_ecdf(S, prefix):
+    out = {}
+    for name in ("_first_match.hist", "_match_markov_model"):
+        with open(prefix + name) as f:
+            d = S.read_ecdf(f)
+        out[name] = [{"bin": list(k1), "segs": [[k2[0], k2[1], v2[0], v2[1]] for k2, v2 in d[k1].items()]}
+                     for k1 in d.keys()]
+    return out
+
+
+def fixture_error_list(S):
+    cases = []
+    seed = 100
+    for m_ref in (1, 5, 60, 300, 3000, 8000):
+        for fastq in (False, True):
+            for rep in range(4):
+                random.seed(seed); np.random.seed(seed); seed += 1
+                with Recorder(S) as r:
+                    l_new, middle_ref, e_dict, e_count = S.error_list(m_ref, S.match_markov_model, S.match_ht_list,
+                                                                      S.error_par, S.trans_error_pr, fastq)
+                cases.append(dict(m_ref=m_ref, fastq=fastq, u=r.u, n=r.n, l_new=int(l_new), middle_ref=int(middle_ref),
+                                  e_dict=edict_list(e_dict),
+                                  e_count=[int(e_count["match"]), int(e_count["mis"]), int(e_count["ins"])]))
+    return cases
+
+
+def fixture_mutate_read(S, genome):
+    """error_list -> mutate_read on real reference sequence, letters driven by the recorded tape."""
+    cases = []
+    seed = 500
+    for m_ref in (40, 300, 2500):
+        for rep in range(4):
+            random.seed(seed); np.random.seed(seed); seed += 1
+            l_new, middle_ref, e_dict, e_count = S.error_list(m_ref, S.match_markov_model, S.match_ht_list,
+                                                              S.error_par, S.trans_error_pr, False)
+            start = 1000 + 37 * seed
+            read = genome[start:start + middle_ref]
+            log = _Log()
+            with Recorder(S) as r:
+                conv = S.case_convert(read)
+                n_conv = len(r.u)
+                out, quals = S.mutate_read(conv, "name", log, dict(e_dict), dict(e_count), False, None)
+            cases.append(dict(read=read, converted=conv, e_dict=edict_list(e_dict), u_convert=r.u[:n_conv],
+                              u_mutate=r.u[n_conv:], out=out, log=log.rows))
+    # the survey's hand-made case
+    read = "ACGTACGTAAAAAAGTCCGTAGCTAGGATC"
+    e_dict = {3: ["mis", 2], 7.5: ["ins", 3], 8: ["del", 2], 15.5: ["ins", 1], 20: ["del", 1], 25: ["mis", 1]}
+    for k in (None, 5):
+        random.seed(9)
+        log = _Log()
+        with Recorder(S) as r:
+            out, _ = S.mutate_read(read, "name", log, {a: list(b) for a, b in e_dict.items()},
+                                   {"mis": 3, "ins": 4, "match": 22}, False, k)
+        cases.append(dict(read=read, converted=read, e_dict=edict_list(e_dict), u_convert=[], u_mutate=r.u, out=out,
+                          log=log.rows, k=k))
+    return cases
+
+
+class _Log:
+    def __init__(self):
+        self.rows = []
+
+    def write(self, s):
+        f = s.rstrip("\n").split("\t")
+        self.rows.append([int(f[1]), f[2], int(f[3]), f[4], f[5]])
+
+
+def fixture_mutate_fastq_classes(S, genome):
+    """Quality CLASS of every emitted base: predict_base_qualities is replaced by a stub returning a
+    per-class constant, so the positions of match/mis/ins qualities are captured exactly."""
+    orig = S.model_base_quals.predict_base_qualities
+    code = {}
+    for cls, name in enumerate(("match", "mis", "ins", "ht", "unmapped")):
+        code[S.lognorm_base_qual[name]["sd"]] = cls
+
+    def stub(sd, loc, scale, n):
+        return [code[sd]] * int(n)
+
+    S.model_base_quals.predict_base_qualities = stub
+    cases = []
+    seed = 900
+    try:
+        for m_ref in (30, 400, 2000):
+            for rep in range(3):
+                random.seed(seed); np.random.seed(seed); seed += 1
+                l_new, middle_ref, e_dict, e_count = S.error_list(m_ref, S.match_markov_model, S.match_ht_list,
+                                                                  S.error_par, S.trans_error_pr, True)
+                start = 2000 + 41 * seed
+                conv = S.case_convert(genome[start:start + middle_ref])
+                out, quals = S.mutate_read(conv, "name", None, dict(e_dict), dict(e_count), True, None)
+                assert len(out) == len(quals)
+                cases.append(dict(converted=conv, e_dict=edict_list(e_dict), classes=[int(q) for q in quals],
+                                  out_len=len(out)))
+    finally:
+        S.model_base_quals.predict_base_qualities = orig
+    return cases
+
+
+def fixture_unaligned(S):
+    """unaligned_error_list + mutate_read STRUCTURE: an all-'A' read and a choice() that never returns 'A'
+    make copied bases ('A') distinguishable from generated ones."""
+    cases = []
+    seed = 1300
+    orig_choice = random.choice
+    for m_ref in (0, 3, 50, 400, 1500):
+        for rep in range(4):
+            random.seed(seed); np.random.seed(seed); seed += 1
+            with Recorder(S) as r:
+                l_new, middle_ref, e_dict, e_count = S.unaligned_error_list(m_ref, S.error_par)
+            read = "A" * middle_ref
+
+            def choice(seq):
+                cand = [c for c in seq if c != "A"]
+                return cand[0]
+
+            random.choice = choice
+            try:
+                out, _ = S.mutate_read(read, "name", None, {a: list(b) for a, b in e_dict.items()}, dict(e_count), False, False)
+            finally:
+                random.choice = orig_choice
+            cases.append(dict(m_ref=m_ref, u=r.u, n=r.n, l_new=int(l_new), middle_ref=int(middle_ref),
+                              e_dict=edict_list(e_dict), copied_mask="".join("1" if c == "A" else "0" for c in out)))
+    return cases
+
+
+def fixture_samplers(S):
+    """Histograms of the reference's own samplers (seeded global numpy RNG)."""
+    out = {}
+    n = 400000
+    np.random.seed(2024)
+    ep = S.error_par
+    v = np.array([S.mm.pois_geom(ep["mis"][0], ep["mis"][2], ep["mis"][3]) for _ in range(n)])
+    out["mis"] = np.bincount(v, minlength=64)[:64].tolist()
+    for ty in ("ins", "del"):
+        v = np.array([S.mm.wei_geom(ep[ty][0], ep[ty][1], ep[ty][2], ep[ty][3]) for _ in range(n)])
+        out[ty] = np.bincount(v, minlength=64)[:64].tolist()
+    out["n"] = n
+    # qualities
+    from scipy.stats import lognorm
+    q = {}
+    for name, par in S.lognorm_base_qual.items():
+        np.random.seed(77)
+        vals = np.array(S.model_base_quals.predict_base_qualities(par["sd"], par["loc"], np.exp(par["mu"]), 200000))
+        fa, fb = lognorm.cdf(1, par["sd"], scale=np.exp(par["mu"])), lognorm.cdf(93, par["sd"], scale=np.exp(par["mu"]))
+        ks = np.arange(1, 94)
+        cdf = (lognorm.cdf(ks, par["sd"], scale=np.exp(par["mu"])) - fa) / (fb - fa)
+        q[name] = dict(hist=np.bincount(vals, minlength=128)[:128].tolist(), pmf_1_92=np.diff(cdf).tolist(), par=par)
+    out["quals"] = q
+    # homopolymer normal parameters (get_nd_par)
+    hp = {}
+    for length in (5, 7, 10, 13, 20, 40):
+        hp[str(length)] = [float(x) for x in S.model_hp_len.get_nd_par(length, S.pw_hp_len, S.lr_hp_len)]
+    out["get_nd_par"] = hp
+    out["hp_mis_rate"] = S.hp_mis_rate
+    return out
+
+
+def fixture_kde(S):
+    out = {}
+    for name, kde, log in (("aligned_region", S.kde_aligned, False), ("ht_length", S.kde_ht, True),
+                           ("ht_ratio", S.kde_ht_ratio, False)):
+        k = 64
+        np.random.seed(31)
+        x = S.get_length_kde(kde, k, log)
+        np.random.seed(31)
+        u = np.random.uniform(0, 1, size=k)
+        g = np.random.standard_normal(k)
+        data = np.asarray(kde.tree_.data)[:, 0]
+        i = (u * data.shape[0]).astype(np.int64)
+        x2 = data[i] + kde.bandwidth_ * g
+        if log:
+            x2 = np.power(10, x2) - 1
+        assert np.allclose(x, x2, rtol=1e-12, atol=1e-12), name
+        out[name] = dict(u=u.tolist(), g=g.tolist(), x=x.tolist(), log=log, bw=float(kde.bandwidth_))
+    return out
+
+
+def fixture_extract(S):
+    """extract_read start positions: (randint value -> chromosome, pos) incl. rejected draws."""
+    cases = []
+    orig = random.randint
+    for dna_type, length in (("linear", 1), ("linear", 500), ("linear", 25000), ("linear", 39990)):
+        random.seed(length)
+        draws = []
+
+        def ri(a, b):
+            v = orig(a, b)
+            draws.append(v)
+            return v
+
+        random.randint = ri
+        try:
+            for _ in range(12):
+                del draws[:]
+                seq, name = S.extract_read(dna_type, length)
+                cases.append(dict(dna_type=dna_type, length=length, draws=list(draws), name=name, seq=seq if length <= 500 else None))
+        finally:
+            random.randint = orig
+    return dict(cases=cases, seq_len=dict(S.seq_len), genome_len=int(S.genome_len))
+
+
+def _dist_worker(args):
+    idx, n_al, n_un, prefix, fasta, workdir, fastq = args
+    S = import_reference()
+    devnull = open(os.devnull, "w")
+    so = sys.stdout
+    sys.stdout = devnull
+    try:
+        S.read_profile(fasta, [n_al + n_un], prefix, False, "genome", None, dna_type="linear", chimeric=False,
+                       homopolymer=False, fastq=fastq)
+    finally:
+        sys.stdout = so
+    S.total_simulated = mp.Value("i", 0, lock=True)
+    random.seed(1000 + idx); np.random.seed(1000 + idx)
+    ext = ".fastq" if fastq else ".fasta"
+    o_reads = os.path.join(workdir, "al%d%s" % (idx, ext))
+    o_err = os.path.join(workdir, "err%d" % idx)
+    o_un = os.path.join(workdir, "un%d%s" % (idx, ext))
+    sys.stdout = devnull
+    try:
+        S.simulation_aligned_genome("linear", 50, S.max_chrom, None, None, o_reads, o_err, None, fastq, n_al, False, False)
+        S.simulation_unaligned("linear", 50, S.max_chrom, None, None, o_un, fastq, n_un, False)
+    finally:
+        sys.stdout = so
+    # per-read metrics
+    lens, heads, tails, refl, rev = [], [], [], [], []
+    names = []
+    qual_hist = np.zeros(128, dtype=np.int64)
+    step = 4 if fastq else 2
+    with open(o_reads) as f:
+        lines = f.read().split("\n")
+    for i in range(0, len(lines) - 1, step):
+        nm = lines[i][1:]
+        parts = nm.split("_")
+        lens.append(len(lines[i + 1])); heads.append(int(parts[-3])); refl.append(int(parts[-2])); tails.append(int(parts[-1]))
+        rev.append(parts[-4] == "R")
+        names.append(nm)
+        if fastq:
+            qual_hist += np.bincount(np.frombuffer(lines[i + 3].encode(), dtype=np.uint8) - 33, minlength=128)[:128]
+    cnt = {nm: [0, 0, 0, 0, 0, 0] for nm in names}
+    tix = {"mis": 0, "ins": 1, "del": 2}
+    with open(o_err) as f:
+        for line in f:
+            p = line.split("\t")
+            c = cnt[p[0]]
+            c[tix[p[2]]] += 1
+            c[3 + tix[p[2]]] += int(p[3])
+    ev = np.array([cnt[nm] for nm in names], dtype=np.int64)
+    ulens, urev = [], []
+    with open(o_un) as f:
+        lines = f.read().split("\n")
+    for i in range(0, len(lines) - 1, step):
+        ulens.append(len(lines[i + 1])); urev.append(lines[i].split("_")[-4] == "R")
+    first = dict(aligned=names[:5], err_rows=open(o_err).read().split("\n")[:5])
+    return dict(lens=lens, heads=heads, tails=tails, refl=refl, rev=rev, ev=ev, ulens=ulens, urev=urev,
+                qual_hist=qual_hist, first=first)
+
+
+def quantiles(x, k=2048):
+    x = np.sort(np.asarray(x, dtype=np.float64))
+    idx = ((np.arange(k) + 0.5) / k * len(x)).astype(np.int64)
+    return x[idx].tolist()
+
+
+def fixture_distributions(prefix, fasta, workdir, n_reads, fastq):
+    n_proc = min(8, os.cpu_count() or 1)
+    n_al = int(round(n_reads * 19.0 / 20.0))
+    n_un = n_reads - n_al
+    args = [(i, n_al // n_proc, max(1, n_un // n_proc), prefix, fasta, workdir, fastq) for i in range(n_proc)]
+    with mp.get_context("fork").Pool(n_proc) as pool:
+        res = pool.map(_dist_worker, args)
+    cat = lambda k: np.concatenate([np.asarray(r[k]) for r in res])
+    ev = np.concatenate([r["ev"] for r in res])
+    out = dict(n_aligned=int(len(cat("lens"))), n_unaligned=int(len(cat("ulens"))), fastq=fastq,
+               q_len=quantiles(cat("lens")), q_head=quantiles(cat("heads")), q_tail=quantiles(cat("tails")),
+               q_ref_len=quantiles(cat("refl")), rev_frac=float(cat("rev").mean()),
+               q_unaligned_len=quantiles(cat("ulens")), unaligned_rev_frac=float(cat("urev").mean()),
+               first=res[0]["first"])
+    for j, nm in enumerate(("mis_events", "ins_events", "del_events", "mis_bases", "ins_bases", "del_bases")):
+        out["q_" + nm] = quantiles(ev[:, j])
+        out["mean_" + nm] = float(ev[:, j].mean())
+    out["mean_len"] = float(cat("lens").mean())
+    if fastq:
+        out["qual_hist"] = np.sum([r["qual_hist"] for r in res], axis=0).tolist()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dist-reads", type=int, default=100000)
+    ap.add_argument("--skip-dist", action="store_true")
+    a = ap.parse_args()
+    workdir = tempfile.mkdtemp(prefix="nsgolden_")
+    try:
+        prefix, fasta, circ = build_inputs(workdir)
+        S = import_reference()
+        so = sys.stdout
+        sys.stdout = open(os.devnull, "w")
+        try:
+            S.read_profile(fasta, [1000], prefix, False, "genome", None, dna_type="linear", chimeric=True,
+                           homopolymer=True, fastq=True)
+        finally:
+            sys.stdout = so
+        genome = "".join(S.seq_dict.values())
+        fx = dict(
+            ecdf=fixture_ecdf(S, prefix),
+            error_list=fixture_error_list(S),
+            mutate_read=fixture_mutate_read(S, genome),
+            mutate_fastq_classes=fixture_mutate_fastq_classes(S, genome),
+            unaligned=fixture_unaligned(S),
+            kde=fixture_kde(S),
+            extract=fixture_extract(S),
+            names=dict(seq_names=list(S.seq_dict.keys())),
+        )
+        with open(os.path.join(HERE, "reference_functions.json"), "w") as f:
+            json.dump(fx, f)
+        with open(os.path.join(HERE, "reference_samplers.json"), "w") as f:
+            json.dump(fixture_samplers(S), f)
+        if not a.skip_dist:
+            d = dict(fasta=fixture_distributions(prefix, fasta, workdir, a.dist_reads, False),
+                     fastq=fixture_distributions(prefix, fasta, workdir, max(2000, a.dist_reads // 10), True))
+            with open(os.path.join(HERE, "reference_distributions.json"), "w") as f:
+                json.dump(d, f)
+    finally:
+        shutil.rmtree(workdir, ignore_errors=True)
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
