@@ -141,12 +141,19 @@ typedef struct ns_params {
 
 /* ---- device-side result layout (copied out with ns_copy_out) -------------------------------------- */
 
-typedef struct ns_event {   /* one e_dict entry (S:1875-1882): position in un-mutated segment coordinates */
+/* one e_dict entry (S:1875-1882), ascending order, position in un-mutated segment coordinates.
+ * info = len[0:12] | type[12:14] | (shift + 2^17)[14:32]; shift = sum(ins - del) over the earlier events of
+ * the same piece, so the payload of the event starts at emitted-segment offset pos + shift. */
+typedef struct ns_event {
     uint32_t pos;           /* ceil(key): mis/del at pos, ins before index pos */
-    uint16_t len;
-    uint8_t type;           /* NS_MIS / NS_INS / NS_DEL */
-    uint8_t flags;
+    uint32_t info;
 } ns_event;
+#define NS_EV_LEN_MAX 4095u
+#define NS_EV_SHIFT_BIAS 131072
+#define NS_EV_LEN(info) ((uint32_t)(info) & 0xfffu)
+#define NS_EV_TYPE(info) (((uint32_t)(info) >> 12) & 3u)
+#define NS_EV_SHIFT(info) ((int32_t)((uint32_t)(info) >> 14) - NS_EV_SHIFT_BIAS)
+#define NS_EV_PACK(len, type, shift) (((uint32_t)(len) & 0xfffu) | ((uint32_t)(type) & 3u) << 12 | (uint32_t)((shift) + NS_EV_SHIFT_BIAS) << 14)
 
 typedef struct ns_piece {   /* one aligned segment or one chimeric gap / unaligned body */
     uint64_t ref_gpos;      /* start offset in the concatenated reference */

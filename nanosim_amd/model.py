@@ -20,7 +20,7 @@ NS_Q_NAMES = ("match", "mis", "ins", "ht", "unmapped")
 NS_QUAL_LEVELS = 128
 NS_HP_MAX_BREAKS = 4
 NS_MODEL_HAS_ERRORS, NS_MODEL_HAS_QUALS, NS_MODEL_HAS_HP, NS_MODEL_HAS_CHIMERIC, NS_MODEL_HAS_UNALIGNED = 1, 2, 4, 8, 16
-MIX_CAP = 4096
+MIX_CAP = 4095
 STATE_NAMES = ("start", "mis", "ins", "del", "mis0", "ins0", "del0")
 
 
@@ -76,12 +76,29 @@ class NsBatchInfo(C.Structure):
                 ("ms_total", C.c_double), ("ms_kernel", C.c_double * 8)]
 
 
-EVENT_DTYPE = np.dtype([("pos", "<u4"), ("len", "<u2"), ("type", "u1"), ("flags", "u1")])
+EVENT_DTYPE = np.dtype([("pos", "<u4"), ("info", "<u4")])
 PIECE_DTYPE = np.dtype([("ref_gpos", "<u8"), ("ev_off", "<u8"), ("chrom", "<u4"), ("pos", "<u4"),
                         ("ref_len", "<u4"), ("out_len", "<u4"), ("n_ev", "<u4"), ("kind", "<u4")])
 READ_DTYPE = np.dtype([("rec_off", "<u8"), ("piece_off", "<u4"), ("n_pieces", "<u2"), ("reversed", "u1"),
                        ("flags", "u1"), ("head", "<u4"), ("tail", "<u4"), ("seq_len", "<u4"), ("attempts", "<u4")])
 assert EVENT_DTYPE.itemsize == 8 and PIECE_DTYPE.itemsize == 40 and READ_DTYPE.itemsize == 32
+NS_EV_SHIFT_BIAS = 131072
+
+
+def ev_len(info):
+    return np.asarray(info, dtype=np.uint32) & 0xFFF
+
+
+def ev_type(info):
+    return (np.asarray(info, dtype=np.uint32) >> 12) & 3
+
+
+def ev_shift(info):
+    return (np.asarray(info, dtype=np.uint32) >> 14).astype(np.int64) - NS_EV_SHIFT_BIAS
+
+
+def ev_pack(length, ty, shift):
+    return (int(length) & 0xFFF) | (int(ty) & 3) << 12 | (int(shift) + NS_EV_SHIFT_BIAS) << 14
 
 
 # --------------------------------------------------------------------------------------------------

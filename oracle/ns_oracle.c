@@ -207,14 +207,17 @@ typedef struct nso_elist {
     int64_t l_new, middle_ref;
     int64_t e_count[3];       /* match, mis, ins (fastq only) */
     uint64_t n_ev;
+    int64_t shift;            /* sum(ins - del) over the stored events */
     int overflow;
 } nso_elist;
 
 static void push_event(ns_event *ev, uint64_t cap, nso_elist *r, int64_t pos, int type, int64_t len) {
+    if (len > (int64_t)NS_EV_LEN_MAX) len = NS_EV_LEN_MAX;
     if (ev && r->n_ev < cap) {
-        ev[r->n_ev].pos = (uint32_t)pos; ev[r->n_ev].len = (uint16_t)len;
-        ev[r->n_ev].type = (uint8_t)type; ev[r->n_ev].flags = 0;
+        ev[r->n_ev].pos = (uint32_t)pos;
+        ev[r->n_ev].info = NS_EV_PACK(len, type, r->shift);
     } else if (ev) r->overflow = 1;
+    if (type == NS_INS) r->shift += len; else if (type == NS_DEL) r->shift -= len;
     r->n_ev++;
 }
 
@@ -248,8 +251,10 @@ void nso_error_list(const ns_model_tables *t, int64_t m_ref, int fastq, nso_draw
             if (pos >= middle_ref) { l_new += pos - middle_ref; middle_ref = pos; }
         } else {                                                                           /* S:1881-1882 */
             if (last_ins_pos == pos && r->n_ev > 0) {         /* same dict key: the later entry replaces */
-                if (ev && r->n_ev <= cap) ev[r->n_ev - 1].len = (uint16_t)step;
-            } else push_event(ev, cap, r, pos, NS_INS, step);
+                r->n_ev--;
+                if (ev && r->n_ev < cap) r->shift -= NS_EV_LEN(ev[r->n_ev].info); else r->overflow = 1;
+            }
+            push_event(ev, cap, r, pos, NS_INS, step);
             last_ins_pos = pos;
         }
         state = NS_ST_MIS + error;                                                         /* S:1884 */
@@ -415,7 +420,8 @@ int64_t nso_mutate_read(const uint8_t *seg_in, int64_t ref_len, const ns_event *
     /* output length */
     int64_t out_len = ref_len;
     for (uint64_t j = 0; j < n_ev; ++j) {
-        if (ev[j].type == NS_INS) out_len += ev[j].len; else if (ev[j].type == NS_DEL) out_len -= ev[j].len;
+        if (NS_EV_TYPE(ev[j].info) == NS_INS) out_len += NS_EV_LEN(ev[j].info);
+        else if (NS_EV_TYPE(ev[j].info) == NS_DEL) out_len -= NS_EV_LEN(ev[j].info);
     }
     if (out_len > out_cap || out_len < 0) return -1;
     int64_t w = out_len;                  /* write cursor (exclusive) */
@@ -423,25 +429,26 @@ int64_t nso_mutate_read(const uint8_t *seg_in, int64_t ref_len, const ns_event *
     uint64_t tl = 0, row = 0;
     for (uint64_t jj = n_ev; jj-- > 0;) {
         const ns_event *e = &ev[jj];
-        int64_t key = e->pos, len = e->len;
-        int64_t err_end = (e->type == NS_INS) ? key : key + len;
+        int64_t key = e->pos, len = NS_EV_LEN(e->info);
+        const int etype = (int)NS_EV_TYPE(e->info);
+        int64_t err_end = (etype == NS_INS) ? key : key + len;
         /* match run after the error: read[err_end:prev] */
         for (int64_t x = prev - 1; x >= err_end; --x) { --w; out[w] = seg_in[x]; if (cls) cls[w] = NS_Q_MATCH; }
-        if (log) { log[row].pos = (uint32_t)key; log[row].len = (uint32_t)len; log[row].type = e->type;
+        if (log) { log[row].pos = (uint32_t)key; log[row].len = (uint32_t)len; log[row].type = (uint32_t)etype;
                    log[row].ref_off = (uint32_t)tl; }
-        if (e->type == NS_MIS) {
-            uint8_t nb[65536];
+        if (etype == NS_MIS) {
+            uint8_t nb[4096];
             for (int64_t i = 0; i < len; ++i) nb[i] = mis_letter(seg_in[key + i], d, seg, attempt, (uint64_t)(key + i));
             for (int64_t i = len - 1; i >= 0; --i) { --w; out[w] = nb[i]; if (cls) cls[w] = NS_Q_MIS; }
             if (txt) { memcpy(txt + tl, seg_in + key, (size_t)len); tl += (uint64_t)len;
                        if (log) log[row].new_off = (uint32_t)tl;
                        memcpy(txt + tl, nb, (size_t)len); tl += (uint64_t)len; }
-        } else if (e->type == NS_DEL) {
+        } else if (etype == NS_DEL) {
             if (txt) { memcpy(txt + tl, seg_in + key, (size_t)len); tl += (uint64_t)len;
                        if (log) log[row].new_off = (uint32_t)tl;
                        memset(txt + tl, '-', (size_t)len); tl += (uint64_t)len; }
         } else {
-            uint8_t nb[65536];
+            uint8_t nb[4096];
             for (int64_t i = 0; i < len; ++i) nb[i] = ins_letter(d, seg, attempt, (uint64_t)key, (uint32_t)i);
             for (int64_t i = len - 1; i >= 0; --i) { --w; out[w] = nb[i]; if (cls) cls[w] = NS_Q_INS; }
             if (txt) { memset(txt + tl, '-', (size_t)len); tl += (uint64_t)len;
@@ -617,11 +624,7 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
             pc[pi].n_ev = (uint32_t)r.n_ev;
             pc[pi].ref_len = (uint32_t)(r.middle_ref < 0 ? 0 : r.middle_ref);
             /* emitted length = ref_len + ins - del over the stored events (collisions already folded in) */
-            int64_t ol = r.middle_ref < 0 ? 0 : r.middle_ref;
-            if (!r.overflow) for (uint64_t j = 0; j < r.n_ev; ++j) {
-                const ns_event *e = &o->events[evn + j];
-                if (e->type == NS_INS) ol += e->len; else if (e->type == NS_DEL) ol -= e->len;
-            }
+            int64_t ol = (r.middle_ref < 0 ? 0 : r.middle_ref) + r.shift;
             pc[pi].out_len = (uint32_t)ol;
             evn += r.n_ev;
             if (!is_gap) total += r.l_new;                                  /* S:1362 (gaps are not counted) */
@@ -712,7 +715,7 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
             uint8_t *segbuf = (uint8_t *)malloc((size_t)rl + 1);
             uint8_t *cls = (uint8_t *)malloc((size_t)pc[pi].out_len + 1);
             uint64_t txt_cap = 0;
-            for (uint32_t j = 0; j < pc[pi].n_ev; ++j) txt_cap += 2u * o->events[pc[pi].ev_off + j].len;
+            for (uint32_t j = 0; j < pc[pi].n_ev; ++j) txt_cap += 2u * NS_EV_LEN(o->events[pc[pi].ev_off + j].info);
             int want_log = (!pc[pi].kind && prm->emit_errlog);
             nso_logrow *rows = want_log ? (nso_logrow *)malloc(sizeof(nso_logrow) * (pc[pi].n_ev + 1)) : NULL;
             uint8_t *txt = want_log ? (uint8_t *)malloc(txt_cap + 1) : NULL;

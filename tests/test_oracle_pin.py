@@ -19,9 +19,22 @@ def expected_events(e_dict):
 
 def events_array(ev):
     a = np.zeros(len(ev), dtype=M.EVENT_DTYPE)
+    shift = 0
     for i, (p, t, n) in enumerate(ev):
-        a[i] = (p, n, t, 0)
+        a[i] = (p, M.ev_pack(n, t, shift))
+        shift += n if t == 1 else -n if t == 2 else 0
     return a
+
+
+def decode_events(ev):
+    """[(pos, type, len)] + check that the packed shift is the running sum(ins - del)."""
+    out, shift = [], 0
+    for e in ev:
+        ty, n = int(M.ev_type(e["info"])), int(M.ev_len(e["info"]))
+        assert int(M.ev_shift(e["info"])) == shift
+        shift += n if ty == 1 else -n if ty == 2 else 0
+        out.append((int(e["pos"]), ty, n))
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -120,8 +133,7 @@ def test_error_list_tape_replay(golden_functions, small_model):
         assert (r.l_new, r.middle_ref) == (case["l_new"], case["middle_ref"])
         exp = expected_events(case["e_dict"])
         assert r.n_ev == len(exp)
-        got = [(int(e["pos"]), int(e["type"]), int(e["len"])) for e in ev[:r.n_ev]]
-        assert got == exp
+        assert decode_events(ev[:r.n_ev]) == exp
         if case["fastq"]:
             assert list(r.e_count) == case["e_count"]
 
@@ -182,7 +194,7 @@ def test_unaligned_error_list_tape_replay_and_structure(golden_functions, small_
         L.nso_unaligned_error_list(C.byref(t), case["m_ref"], C.byref(d), 128, 0, ev.ctypes.data, len(ev), C.byref(r))
         assert not d.tape_err and d.i_u == len(case["u"]) and d.i_n == len(case["n"])
         assert (r.l_new, r.middle_ref) == (case["l_new"], case["middle_ref"])
-        events = [(int(e["pos"]), int(e["type"]), int(e["len"])) for e in ev[:r.n_ev]]
+        events = decode_events(ev[:r.n_ev])
         # events must be ascending and non-overlapping in reference coordinates
         end = 0
         for p, ty, n in events:
