@@ -178,7 +178,9 @@ typedef struct ns_read {
 } ns_read;
 
 typedef struct ns_batch_info {
-    uint64_t n_reads, n_pieces, n_events;
+    uint64_t n_reads, n_pieces;
+    uint64_t n_events;      /* length of the event buffer (pieces index it through ev_off; capacity gaps included) */
+    uint64_t events_used;   /* events actually generated */
     uint64_t record_bytes;  /* size of the FASTA/FASTQ image */
     uint64_t errlog_bytes;  /* size of the error-profile image */
     uint64_t total_bases;   /* sum of seq_len */

@@ -1,0 +1,329 @@
+// ns_device.h — device-side restatement of the per-read generation functions (gfx950).
+// error_list / unaligned_error_list / letters / qualities as __device__ functions shared by the kernels
+// in nanosim_amd.hip.  Reference lines: S: = src/simulator.py of bcgsc/NanoSim v3.2.2.
+#pragma once
+#include "ns_rng.h"
+#include "../../include/nanosim_amd.h"
+
+struct DevModel {
+    uint32_t flags;
+    uint32_t fm_nseg;
+    const double *fm_hi, *fm_vhi;
+    double fm_vlo0;
+    uint32_t mm_nbins;
+    const int64_t *mm_bin_lo, *mm_bin_hi;
+    const uint32_t *mm_seg_off;
+    const double *mm_hi, *mm_vhi, *mm_vlo0;
+    double trans[7][3];
+    double mix_w[3];
+    uint32_t mix_n[3][2];
+    const double *mix_cdf[3][2];
+    ns_kde kde[NS_KDE_COUNT];
+    double strandness_rate;
+    uint32_t nseg_n;
+    const double *nseg_cdf;
+    const uint32_t *qual_thr;     // [NS_Q_COUNT][NS_QUAL_LEVELS]
+    ns_hp_class hp[2];
+    double hp_mis_rate;
+};
+
+struct DevRef {
+    const uint8_t *bases;         // normalised: upper-case ASCII, IUPAC codes kept, everything else N
+    const uint64_t *chrom_off;    // [nchrom+1]
+    const uint8_t *circular;      // [nchrom]
+    const char *names;            // NUL-separated
+    const uint32_t *name_off;     // [nchrom+1] offsets into names
+    uint32_t nchrom;
+};
+
+// ---- table look-ups ------------------------------------------------------------------------------------
+// ECDF look-up of S:1845-1849 / S:1895-1898: segment with lo < p <= hi, linear interpolation, floor.
+__device__ __forceinline__ int64_t ecdf_lookup(const double *__restrict__ hi, const double *__restrict__ vhi,
+                                               uint32_t n, double vlo0, double p) {
+    uint32_t lo_i = 0, hi_i = n;
+    while (lo_i < hi_i) {
+        uint32_t mid = (lo_i + hi_i) >> 1;
+        if (p <= hi[mid]) hi_i = mid; else lo_i = mid + 1;
+    }
+    uint32_t s = lo_i;
+    if (s >= n) { s = n - 1; p = hi[s]; }
+    double plo = s ? hi[s - 1] : 0.0;
+    double vlo = s ? vhi[s - 1] : vlo0;
+    return (int64_t)floor((p - plo) / (hi[s] - plo) * (vhi[s] - vlo) + vlo);
+}
+
+__device__ __forceinline__ int64_t table_value(const double *__restrict__ cdf, uint32_t n, double p) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (p <= cdf[mid]) hi = mid; else lo = mid + 1;
+    }
+    if (lo >= n) lo = n - 1;
+    return (int64_t)lo + 1;
+}
+
+// S:1860-1864
+__device__ __forceinline__ int trans_pick(const double *row, double p) {
+    if (0.0 <= p && p < row[0]) return NS_MIS;
+    if (row[0] <= p && p < row[1]) return NS_INS;
+    if (row[2] <= p && p < 1.0) return NS_DEL;
+    return (p >= row[1]) ? NS_DEL : NS_INS;
+}
+
+// src/mixed_model.py:41-63 through the inverse-CDF tables
+__device__ __forceinline__ int64_t run_length(const DevModel &m, int type, double p_mix, double p_len) {
+    int comp = (p_mix < m.mix_w[type]) ? 0 : 1;
+    return table_value(m.mix_cdf[type][comp], m.mix_n[type][comp], p_len);
+}
+
+// ---- event sink ------------------------------------------------------------------------------------------
+struct EvSink {
+    ns_event *ev;
+    uint32_t cap, n;
+    int32_t shift;
+    uint32_t last_ins_len;
+    bool overflow;
+};
+__device__ __forceinline__ void ev_push(EvSink &s, int64_t pos, uint32_t type, int64_t len) {
+    uint32_t l = len > (int64_t)NS_EV_LEN_MAX ? NS_EV_LEN_MAX : (uint32_t)len;
+    if (s.n < s.cap) {
+        ns_event e; e.pos = (uint32_t)pos; e.info = ns_ev_pack(l, type, s.shift);
+        s.ev[s.n] = e;
+    } else s.overflow = true;
+    if (type == NS_INS) { s.shift += (int32_t)l; s.last_ins_len = l; } else if (type == NS_DEL) s.shift -= (int32_t)l;
+    s.n++;
+}
+
+struct EList { int64_t l_new, middle_ref; };
+
+// error_list, S:1833-1916
+__device__ inline EList dev_error_list(const DevModel &m, int64_t m_ref, const ns_key &key, uint32_t seg,
+                                       uint32_t attempt, EvSink &s) {
+    int64_t l_new = m_ref, pos = 0, middle_ref = m_ref;
+    int state = NS_ST_START;
+    u32x4 w = ns_draw(key, ST_EVENT, seg, attempt, 0, 0);
+    int64_t prev_match = ecdf_lookup(m.fm_hi, m.fm_vhi, m.fm_nseg, m.fm_vlo0, u32_to_p(w.x));   // S:1843-1850
+    if (prev_match < 2) prev_match = 2;
+    pos += prev_match;
+    uint32_t it = 1;
+    int64_t last_ins_pos = -1;
+    while (pos < middle_ref) {                                                                     // S:1858
+        w = ns_draw(key, ST_EVENT, seg, attempt, it, 0);
+        int error = trans_pick(m.trans[state], u32_to_p(w.x));                                    // S:1860-1864
+        int64_t step = run_length(m, error, u32_to_p(w.y), u32_to_p(w.z));                        // S:1866-1873
+        if (error == NS_INS) l_new += step; else if (error == NS_DEL) l_new -= step;
+        if (error != NS_INS) {                                                                     // S:1875-1880
+            ev_push(s, pos, (uint32_t)error, step);
+            pos += step;
+            if (pos >= middle_ref) { l_new += pos - middle_ref; middle_ref = pos; }
+        } else {                                                                                   // S:1881-1882
+            if (last_ins_pos == pos && s.n > 0) {          // same dict key pos-0.5: the later entry replaces
+                s.n--;
+                s.shift -= (int32_t)s.last_ins_len;
+            }
+            ev_push(s, pos, NS_INS, step);
+            last_ins_pos = pos;
+        }
+        state = NS_ST_MIS + error;                                                                 // S:1884
+        uint32_t b = 0;                                                                            // S:1891-1893
+        for (; b < m.mm_nbins; ++b)
+            if (m.mm_bin_lo[b] <= prev_match && prev_match < m.mm_bin_hi[b]) break;
+        if (b >= m.mm_nbins) b = m.mm_nbins - 1;
+        uint32_t o = m.mm_seg_off[b];
+        step = ecdf_lookup(m.mm_hi + o, m.mm_vhi + o, m.mm_seg_off[b + 1] - o, m.mm_vlo0[b], u32_to_p(w.w));
+        if (prev_match == 0 && step == 0) step = 1;                                                // S:1900-1901
+        prev_match = step;
+        if (pos + prev_match > middle_ref) { l_new += pos + prev_match - middle_ref; middle_ref = pos + prev_match; }
+        pos += prev_match;
+        if (prev_match == 0) state += 3;                                                           // S:1913-1914
+        else last_ins_pos = -1;
+        ++it;
+    }
+    return EList{l_new, middle_ref};
+}
+
+// unaligned_error_list, S:1784-1830, with the event rewrite of DESIGN.md §5.3
+__device__ inline EList dev_unaligned_error_list(const DevModel &m, int64_t m_ref, const ns_key &key, uint32_t seg,
+                                                 uint32_t attempt, EvSink &s) {
+    int64_t l_new = m_ref, pos = 0, middle_ref = m_ref;
+    int64_t pend_ins = 0;
+    if (m_ref <= 0) return EList{l_new, middle_ref};
+    uint32_t it = 0;
+    while (pos < middle_ref) {
+        u32x4 w = ns_draw(key, ST_UEVENT, seg, attempt, it, 0);
+        ++it;
+        double p = u32_to_p(w.x);
+        int type = (p < 0.4) ? 3 : (p < 0.7) ? NS_MIS : (p < 0.85) ? NS_INS : NS_DEL;               // S:1787
+        int64_t step = 1;
+        if (type != 3) step = run_length(m, type, u32_to_p(w.y), u32_to_p(w.z));
+        if (type == NS_INS) { pend_ins += step; l_new += step; continue; }                          // S:1808-1815
+        if (type == NS_DEL) l_new -= step;
+        int64_t L = pend_ins; pend_ins = 0;
+        if (type == 3) {
+            if (L) ev_push(s, pos + 1, NS_INS, L);
+        } else if (type == NS_MIS) {
+            if (!L) ev_push(s, pos, NS_MIS, step);
+            else {
+                ev_push(s, pos, NS_MIS, 1);
+                ev_push(s, pos + 1, NS_INS, L);
+                if (step - 1 > L) ev_push(s, pos + 1, NS_MIS, step - 1 - L);
+            }
+        } else {
+            if (!L) ev_push(s, pos, NS_DEL, step);
+            else {
+                int64_t dl = step - L; if (dl < 1) dl = 1;
+                ev_push(s, pos, NS_DEL, dl);
+                if (L - (step - 1) > 0) ev_push(s, pos + 1, NS_INS, L - (step - 1));
+            }
+        }
+        pos += step;
+        if (pos > middle_ref) { l_new += pos - middle_ref; middle_ref = pos; }                       // S:1826-1828
+    }
+    return EList{l_new, middle_ref};
+}
+
+// ---- lengths ---------------------------------------------------------------------------------------------
+// KernelDensity.sample (call site S:235): i = floor(U*n); x = N(data[i], bw)
+__device__ __forceinline__ double kde_sample(const ns_kde &k, const u32x4 &w) {
+    uint64_t i = (uint64_t)(u53_to_p(w.x, w.y) * (double)k.n);
+    if (i >= k.n) i = k.n - 1;
+    return fma(k.bw, ns_norminv(u32_to_p(w.z)), k.data[i]);
+}
+
+// length of aligned segment s in epoch e (S:1285-1296,1309); returns false if no valid draw
+__device__ inline bool seg_length(const DevModel &m, const ns_params &prm, const ns_key &key, uint32_t s,
+                                  uint32_t epoch, int64_t &out) {
+    for (uint32_t j = 0; j < NS_KDE_RETRY; ++j) {
+        u32x4 w = ns_draw(key, ST_REFLEN, s, epoch, j, 0);
+        double x;
+        if (!prm.use_lognormal) x = kde_sample(m.kde[NS_KDE_ALIGNED], w);
+        else if (prm.kind == NS_KIND_PERFECT)                                                       // S:1286-1287
+            x = ns_exp(fma(prm.sd_len, ns_norminv(u32_to_p(w.z)), ns_log(prm.median_len)));
+        else {                                                                                      // S:1293-1295
+            u32x4 w2 = ns_draw(key, ST_REFLEN, s, epoch, j, 1);
+            double tot = ns_exp(fma(prm.sd_len, ns_norminv(u32_to_p(w.z)),
+                                    ns_log(prm.median_len + prm.sd_len * prm.sd_len / 2)));
+            double rem = ns_pow10m1(kde_sample(m.kde[NS_KDE_HT], w2));
+            if (rem < 0) continue;
+            x = tot - rem;
+        }
+        bool keep = (prm.kind == NS_KIND_PERFECT) ? ((double)prm.min_len <= x && x <= (double)prm.max_len)
+                                                  : (0 < x && x <= (double)prm.max_len);
+        if (keep) { out = (int64_t)x; return true; }
+    }
+    return false;
+}
+__device__ inline int64_t gap_length(const DevModel &m, const ns_key &key, uint32_t g, uint32_t epoch) {   // S:1298-1299
+    u32x4 w = ns_draw(key, ST_GAPLEN, g, epoch, 0, 0);
+    int64_t gi = (int64_t)ns_pow10m1(kde_sample(m.kde[NS_KDE_GAP], w));
+    return gi < 0 ? 0 : gi;
+}
+__device__ inline int64_t unaligned_length(const DevModel &m, const ns_params &prm, const ns_key &key, uint32_t a) {
+    u32x4 w = ns_draw(key, ST_ULEN, 0, a, 0, 0);                                                    // S:1494-1495,1499
+    double x = prm.use_lognormal ? ns_exp(fma(prm.sd_len, ns_norminv(u32_to_p(w.z)), ns_log(prm.median_len)))
+                                 : kde_sample(m.kde[NS_KDE_UNALIGNED], w);
+    return (int64_t)x;
+}
+
+// extract_read, genome branches (S:1750-1781)
+__device__ inline bool extract_pos(const DevRef &ref, int64_t length, const ns_key &key, uint32_t seg, uint32_t attempt,
+                                   uint32_t &chrom, uint64_t &pos) {
+    uint64_t genome_len = ref.chrom_off[ref.nchrom];
+    for (uint32_t j = 0; j < NS_POS_RETRY; ++j) {
+        u32x4 w = ns_draw(key, ST_POS, seg, attempt, j, 0);
+        uint64_t ref_pos = (uint64_t)(u53_to_p(w.x, w.y) * (double)(genome_len + 1));
+        if (ref_pos > genome_len) ref_pos = genome_len;
+        if (ref.circular[0]) { chrom = 0; pos = ref_pos; return true; }
+        for (uint32_t c = 0; c < ref.nchrom; ++c) {
+            uint64_t cl = ref.chrom_off[c + 1] - ref.chrom_off[c];
+            if (ref_pos + (uint64_t)length <= cl) { chrom = c; pos = ref_pos; return true; }
+            else if (ref_pos < cl) break;
+            else ref_pos -= cl;
+        }
+    }
+    return false;
+}
+
+// ---- letters ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint8_t bases_atcg(uint32_t j) { return (uint8_t)(0x47435441u >> (8 * j)); }   // BASES, S:49
+__device__ __forceinline__ int base_rank(uint32_t c) { return c == 'A' ? 0 : c == 'T' ? 1 : c == 'C' ? 2 : c == 'G' ? 3 : -1; }
+__device__ __forceinline__ bool is_acgt(uint32_t c) { return ((1u << ((c - 65u) & 31u)) & 0x00080045u) != 0 && (c - 65u) < 26u; }
+
+// case_convert (S:743-755): members in the reference's list order, packed little-endian; count in the top byte index
+__device__ __forceinline__ uint32_t iupac_members(uint32_t c, uint32_t &n) {
+    switch (c) {
+        case 'Y': n = 2; return 'C' | 'T' << 8;
+        case 'R': n = 2; return 'A' | 'G' << 8;
+        case 'W': n = 2; return 'A' | 'T' << 8;
+        case 'S': n = 2; return 'G' | 'C' << 8;
+        case 'K': n = 2; return 'T' | 'G' << 8;
+        case 'M': n = 2; return 'C' | 'A' << 8;
+        case 'D': n = 3; return 'A' | 'G' << 8 | 'T' << 16;
+        case 'V': n = 3; return 'A' | 'C' << 8 | 'G' << 16;
+        case 'H': n = 3; return 'A' | 'C' << 8 | 'T' << 16;
+        case 'B': n = 3; return 'C' | 'G' << 8 | 'T' << 16;
+        case 'N': case 'X': n = 4; return 0x47435441u;
+        default: n = 0; return 0;
+    }
+}
+__device__ __forceinline__ uint8_t normalise_base(uint32_t c) {
+    if (c >= 'a' && c <= 'z') c -= 32;
+    uint32_t n;
+    if (is_acgt(c)) return (uint8_t)c;
+    iupac_members(c, n);
+    return n ? (uint8_t)c : (uint8_t)'N';
+}
+__device__ __forceinline__ uint8_t resolve_base(uint32_t c, const ns_key &key, uint32_t seg, uint32_t attempt, uint32_t x) {
+    if (is_acgt(c)) return (uint8_t)c;
+    uint32_t n, mem = iupac_members(c, n);
+    if (!n) return (uint8_t)c;
+    u32x4 w = ns_draw(key, ST_IUPAC, seg, attempt, x >> 2, 0);
+    uint32_t j = (uint32_t)(((uint64_t)ns_word(w, x & 3) * n) >> 32);
+    return (uint8_t)(mem >> (8 * j));
+}
+// S:1968-1972
+__device__ __forceinline__ uint8_t mis_letter(uint32_t cur, const ns_key &key, uint32_t seg, uint32_t attempt, uint32_t x) {
+    u32x4 w = ns_draw(key, ST_SUB, seg, attempt, x >> 2, 0);
+    uint32_t j = (uint32_t)(((uint64_t)ns_word(w, x & 3) * 3u) >> 32);
+    int rc = base_rank(cur);
+    uint32_t rk = j + ((int)j >= rc ? 1u : 0u);
+    if (rc < 0) rk = j;
+    return bases_atcg(rk);
+}
+__device__ __forceinline__ uint8_t ins_letter(const ns_key &key, uint32_t seg, uint32_t attempt, uint32_t x, uint32_t i) {   // S:1990
+    u32x4 w = ns_draw(key, ST_INS, seg, attempt, x, i >> 2);
+    return bases_atcg(ns_word(w, i & 3) >> 30);
+}
+__device__ __forceinline__ uint8_t ht_letter(const ns_key &key, uint32_t stream, uint32_t attempt, uint32_t i) {             // S:1426-1427
+    u32x4 w = ns_draw(key, stream, 0, attempt, i >> 2, 0);
+    return bases_atcg(ns_word(w, i & 3) >> 30);
+}
+__device__ __forceinline__ uint8_t qual_value(const uint32_t *__restrict__ thr, uint32_t h) {
+    // q = #{j in [0,126] : h >= thr[j]}; thr is non-decreasing -> binary search for the first thr[j] > h
+    uint32_t lo = 0, hi = NS_QUAL_LEVELS - 1;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (h >= thr[mid]) lo = mid + 1; else hi = mid;
+    }
+    return (uint8_t)lo;
+}
+__device__ __forceinline__ uint8_t qual_at(const DevModel &m, int cls, const ns_key &key, uint32_t stream, uint32_t seg,
+                                           uint32_t attempt, uint32_t mpos) {
+    u32x4 w = ns_draw(key, stream, seg, attempt, mpos >> 3, 0);
+    uint32_t h = (ns_word(w, (mpos & 7) >> 1) >> (16 * (mpos & 1))) & 0xffffu;
+    return qual_value(m.qual_thr + cls * NS_QUAL_LEVELS, h);
+}
+
+__device__ __forceinline__ uint32_t dec_digits(uint64_t v) {
+    uint32_t n = 1;
+    while (v >= 10) { v /= 10; ++n; }
+    return n;
+}
+__device__ __forceinline__ uint8_t *put_dec(uint8_t *p, uint64_t v) {
+    uint32_t n = dec_digits(v);
+    for (uint32_t i = 0; i < n; ++i) { p[n - 1 - i] = (uint8_t)('0' + v % 10); v /= 10; }
+    return p + n;
+}
+__device__ __forceinline__ uint8_t complement(uint32_t x) {        // reverse_complement, S:1675-1680
+    return x == 'A' ? 'T' : x == 'T' ? 'A' : x == 'C' ? 'G' : x == 'G' ? 'C' : (uint8_t)x;
+}

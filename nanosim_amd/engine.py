@@ -1,0 +1,156 @@
+"""ctypes binding of the C-ABI (include/nanosim_amd.h) — the only way the Python host reaches the GPU.
+
+There is NO CPU fallback: if libnanosim_amd.so is missing or no MI355X is visible, construction fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .model import (EVENT_DTYPE, PIECE_DTYPE, READ_DTYPE, Model, NsBatchInfo, NsModelTables, NsParams, Reference)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnanosim_amd.so")
+NS_BUF_RECORDS, NS_BUF_READS, NS_BUF_PIECES, NS_BUF_EVENTS, NS_BUF_ERRLOG = 0, 1, 2, 3, 4
+NS_KIND_ALIGNED, NS_KIND_UNALIGNED, NS_KIND_PERFECT = 0, 1, 2
+KERNEL_NAMES = ("k_plan", "k_events", "k_names", "k_materialise", "k_hp", "k_errlog")
+EXPORTS = ("ns_abi_version", "ns_create", "ns_destroy", "ns_last_error", "ns_set_reference",
+           "ns_set_reference_device", "ns_load_model", "ns_generate", "ns_copy_out", "ns_device_ptr")
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen the engine and declare every prototype of include/nanosim_amd.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise EngineError("%s not found — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    L = C.CDLL(path)
+    L.ns_abi_version.restype = C.c_uint32
+    L.ns_create.restype = C.c_int
+    L.ns_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.ns_destroy.restype = None
+    L.ns_destroy.argtypes = [C.c_void_p]
+    L.ns_last_error.restype = C.c_char_p
+    L.ns_last_error.argtypes = [C.c_void_p]
+    ref_args = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_char_p, C.c_uint64]
+    L.ns_set_reference.restype = C.c_int
+    L.ns_set_reference.argtypes = ref_args
+    L.ns_set_reference_device.restype = C.c_int
+    L.ns_set_reference_device.argtypes = ref_args
+    L.ns_load_model.restype = C.c_int
+    L.ns_load_model.argtypes = [C.c_void_p, C.POINTER(NsModelTables)]
+    L.ns_generate.restype = C.c_int
+    L.ns_generate.argtypes = [C.c_void_p, C.POINTER(NsParams), C.POINTER(NsBatchInfo)]
+    L.ns_copy_out.restype = C.c_int
+    L.ns_copy_out.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64]
+    L.ns_device_ptr.restype = C.c_void_p
+    L.ns_device_ptr.argtypes = [C.c_void_p, C.c_int]
+    _lib = L
+    return L
+
+
+class Batch:
+    """Results of one ns_generate call; buffers stay in HBM until the next call on the same engine."""
+
+    def __init__(self, eng: "Engine", info: NsBatchInfo):
+        self.eng = eng
+        self.info = info
+
+    def _copy(self, which, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        if count:
+            self.eng._check(self.eng.L.ns_copy_out(self.eng.ctx, which, out.ctypes.data, 0, out.nbytes))
+        return out
+
+    def reads(self):
+        return self._copy(NS_BUF_READS, READ_DTYPE, int(self.info.n_reads))
+
+    def pieces(self):
+        return self._copy(NS_BUF_PIECES, PIECE_DTYPE, int(self.info.n_pieces))
+
+    def events(self):
+        return self._copy(NS_BUF_EVENTS, EVENT_DTYPE, int(self.info.n_events))
+
+    def records(self, out: np.ndarray | None = None):
+        n = int(self.info.record_bytes)
+        if out is None:
+            return self._copy(NS_BUF_RECORDS, np.uint8, n)
+        if n:
+            self.eng._check(self.eng.L.ns_copy_out(self.eng.ctx, NS_BUF_RECORDS, out.ctypes.data, 0, n))
+        return out[:n]
+
+    def errlog(self):
+        return self._copy(NS_BUF_ERRLOG, np.uint8, int(self.info.errlog_bytes))
+
+    def kernel_ms(self):
+        return {KERNEL_NAMES[i]: float(self.info.ms_kernel[i]) for i in range(len(KERNEL_NAMES))}
+
+
+class Engine:
+    """One context per GPU (single host thread), mirroring the worker seam of src/simulator.py:1601-1619."""
+
+    def __init__(self, device: int = 0):
+        self.L = load_library()
+        self.ctx = C.c_void_p()
+        rc = self.L.ns_create(device, C.byref(self.ctx))
+        if rc != 0:
+            raise EngineError("ns_create(device=%d) failed with %d (no MI355X visible?)" % (device, rc))
+        self._keep = []
+
+    def close(self):
+        if self.ctx:
+            self.L.ns_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError("nanosim_amd error %d: %s" % (rc, self.L.ns_last_error(self.ctx).decode()))
+
+    def set_reference(self, ref: Reference):
+        blob = ref.names_blob()
+        self._check(self.L.ns_set_reference(self.ctx, ref.bases.ctypes.data, len(ref.bases), ref.chrom_off.ctypes.data,
+                                            len(ref.names), ref.circular.ctypes.data, blob, len(blob)))
+
+    def set_reference_device(self, dev_ptr: int, ref: Reference):
+        """`dev_ptr` points at ref.genome_len bytes already resident on this GPU (e.g. after an RCCL
+        broadcast through torch.distributed); the engine normalises them in place and does not own them."""
+        blob = ref.names_blob()
+        self._check(self.L.ns_set_reference_device(self.ctx, dev_ptr, ref.genome_len, ref.chrom_off.ctypes.data,
+                                                   len(ref.names), ref.circular.ctypes.data, blob, len(blob)))
+
+    def load_model(self, model: Model):
+        t = model.to_c()
+        self._check(self.L.ns_load_model(self.ctx, C.byref(t)))
+
+    def generate(self, params: NsParams) -> Batch:
+        info = NsBatchInfo()
+        self._check(self.L.ns_generate(self.ctx, C.byref(params), C.byref(info)))
+        return Batch(self, info)
+
+
+def make_params(*, seed, first_read, n_reads, kind=NS_KIND_ALIGNED, fastq=False, kmer_bias=0, chimeric=False,
+                min_len=50, max_len, median_len=None, sd_len=None, emit_records=True, emit_errlog=False) -> NsParams:
+    p = NsParams()
+    p.seed, p.first_read, p.n_reads, p.kind = seed, first_read, n_reads, kind
+    p.fastq, p.kmer_bias, p.chimeric = int(bool(fastq)), int(kmer_bias or 0), int(bool(chimeric))
+    p.use_lognormal = int(median_len is not None and sd_len is not None)
+    p.emit_records, p.emit_errlog = int(bool(emit_records)), int(bool(emit_errlog))
+    p.min_len, p.max_len = int(min_len), int(max_len)
+    p.median_len, p.sd_len = float(median_len or 0.0), float(sd_len or 0.0)
+    return p

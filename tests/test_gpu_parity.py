@@ -1,0 +1,108 @@
+"""GPU parity: the HIP path (through the C-ABI) must equal the CPU oracle bit-for-bit — same reads,
+same per-read error CIGAR (events), same FASTA/FASTQ bytes, same error-profile rows."""
+import numpy as np
+import pytest
+
+from nanosim_amd import engine as E
+from nanosim_amd import model as M
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng(small_model, small_ref):
+    e = E.Engine(0)
+    e.set_reference(small_ref)
+    e.load_model(small_model)
+    yield e
+    e.close()
+
+
+def compare(batch, exp, params):
+    reads, pieces, events = batch.reads(), batch.pieces(), batch.events()
+    er, ep, ee = exp["reads"], exp["pieces"], exp["events"]
+    assert len(reads) == len(er)
+    for f in ("piece_off", "n_pieces", "reversed", "flags", "head", "tail", "seq_len", "attempts", "rec_off"):
+        assert np.array_equal(reads[f], er[f]), f
+    assert len(pieces) == len(ep)
+    for f in ("ref_gpos", "chrom", "pos", "ref_len", "out_len", "n_ev", "kind"):
+        assert np.array_equal(pieces[f], ep[f]), f
+    # per-piece CIGAR: identical event lists
+    for i in range(len(pieces)):
+        g = events[int(pieces["ev_off"][i]):int(pieces["ev_off"][i]) + int(pieces["n_ev"][i])]
+        x = ee[int(ep["ev_off"][i]):int(ep["ev_off"][i]) + int(ep["n_ev"][i])]
+        assert np.array_equal(g["pos"], x["pos"]) and np.array_equal(g["info"], x["info"]), "events of piece %d" % i
+    assert int(batch.info.events_used) == len(ee)
+    assert int(batch.info.total_bases) == exp["total_bases"]
+    assert int(batch.info.total_ref_bases) == exp["total_ref_bases"]
+    rec = batch.records()
+    assert rec.tobytes() == exp["records"].tobytes()
+    if params.emit_errlog:
+        assert batch.errlog().tobytes() == exp["errlog"].tobytes()
+
+
+CASES = [
+    dict(kind=E.NS_KIND_ALIGNED, n_reads=300, emit_errlog=True),
+    dict(kind=E.NS_KIND_ALIGNED, n_reads=200, fastq=True, emit_errlog=True),
+    dict(kind=E.NS_KIND_ALIGNED, n_reads=300, chimeric=True, fastq=True, emit_errlog=True),
+    dict(kind=E.NS_KIND_UNALIGNED, n_reads=200, fastq=True),
+    dict(kind=E.NS_KIND_UNALIGNED, n_reads=100),
+    dict(kind=E.NS_KIND_PERFECT, n_reads=200, fastq=True),
+    dict(kind=E.NS_KIND_ALIGNED, n_reads=150, min_len=3000, max_len=9000),            # rejections + epochs
+    dict(kind=E.NS_KIND_ALIGNED, n_reads=150, median_len=5000, sd_len=0.4),            # -med/-sd
+    dict(kind=E.NS_KIND_UNALIGNED, n_reads=100, median_len=800, sd_len=0.5),
+    dict(kind=E.NS_KIND_ALIGNED, n_reads=1, first_read=(1 << 33) + 5, emit_errlog=True),
+    dict(kind=E.NS_KIND_ALIGNED, n_reads=0),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_gpu_equals_oracle(eng, small_model, small_ref, case):
+    kw = dict(seed=0x5EED1234ABCD, first_read=0, max_len=small_ref.max_chrom)
+    kw.update(case)
+    p = E.make_params(**kw)
+    b = eng.generate(p)
+    if p.n_reads == 0:
+        assert b.info.record_bytes == 0
+        return
+    exp = O.generate(small_model, small_ref, p)
+    compare(b, exp, p)
+
+
+def test_gpu_circular_reference(small_model, circ_ref):
+    e = E.Engine(0)
+    try:
+        e.set_reference(circ_ref)
+        e.load_model(small_model)
+        p = E.make_params(seed=77, first_read=0, n_reads=200, max_len=circ_ref.max_chrom, emit_errlog=True)
+        b = e.generate(p)
+        exp = O.generate(small_model, circ_ref, p)
+        compare(b, exp, p)
+        # wrap-around reads exist in this sample
+        pc = b.pieces()
+        assert np.any(pc["pos"].astype(np.int64) + pc["ref_len"] > circ_ref.genome_len)
+    finally:
+        e.close()
+
+
+def test_reads_do_not_depend_on_batching(eng, small_ref):
+    """(seed, read index) fully determine a read: a sub-range reproduces the same bytes."""
+    p_all = E.make_params(seed=99, first_read=0, n_reads=300, max_len=small_ref.max_chrom)
+    b = eng.generate(p_all)
+    reads, rec = b.reads(), b.records()
+    p_sub = E.make_params(seed=99, first_read=100, n_reads=100, max_len=small_ref.max_chrom)
+    b2 = eng.generate(p_sub)
+    reads2, rec2 = b2.reads(), b2.records()
+    lo, hi = int(reads["rec_off"][100]), int(reads["rec_off"][200])
+    assert rec2.tobytes() == rec[lo:hi].tobytes()
+    assert np.array_equal(reads2["seq_len"], reads["seq_len"][100:200])
+
+
+def test_error_paths(eng, small_ref):
+    p = E.make_params(seed=1, first_read=0, n_reads=10, max_len=small_ref.max_chrom, kmer_bias=5)
+    with pytest.raises(E.EngineError):
+        eng.generate(p)
+    p = E.make_params(seed=1, first_read=0, n_reads=10, min_len=10 ** 7, max_len=10 ** 8)
+    with pytest.raises(E.EngineError):
+        eng.generate(p)
