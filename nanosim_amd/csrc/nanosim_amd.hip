@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "ns_device.h"
+#include "ns_materialise.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // kernel arguments
@@ -283,167 +284,28 @@ __global__ void __launch_bounds__(256) k_names(GenArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_materialise: one read per wavefront.  Each lane produces 16 consecutive output bytes per tile.
+// k_materialise: one read per wavefront (64-thread workgroup); see ns_materialise.h
 // ---------------------------------------------------------------------------------------------------------
-struct PieceCtx {
-    const ns_event *ev;
-    uint32_t n_ev;
-    uint32_t out_len, ref_len;
-    uint64_t chrom_base;       // offset of the chromosome in the concatenated reference
-    uint64_t chrom_len;
-    uint64_t pos;              // start inside the chromosome
-    uint32_t sid;              // seg id of the Philox counter
-    uint32_t kind;
-};
-
-struct Cursor {
-    // current event (index j-1) and the next boundary
-    uint32_t j;                // number of events whose payload start is <= m
-    uint32_t cur_out, cur_pl, cur_type, cur_pos, cur_rp;
-    uint32_t next_out;
-};
-
-__device__ __forceinline__ uint32_t ev_out_start(const ns_event &e) { return (uint32_t)((int32_t)e.pos + ns_ev_shift(e.info)); }
-
-__device__ __forceinline__ void cursor_load(Cursor &c, const PieceCtx &pc) {
-    if (c.j == 0) { c.cur_out = 0; c.cur_pl = 0; c.cur_type = 3; c.cur_pos = 0; c.cur_rp = 0; }
-    else {
-        ns_event e = pc.ev[c.j - 1];
-        uint32_t len = ns_ev_len(e.info), ty = ns_ev_type(e.info);
-        c.cur_out = ev_out_start(e); c.cur_type = ty; c.cur_pos = e.pos;
-        c.cur_pl = (ty == NS_DEL) ? 0 : len;
-        c.cur_rp = e.pos + ((ty == NS_INS) ? 0 : len);
-    }
-    c.next_out = (c.j < pc.n_ev) ? ev_out_start(pc.ev[c.j]) : 0xffffffffu;
-}
-
-// position the cursor on emitted-segment offset m: j = #{events with out_start <= m}
-__device__ __forceinline__ void cursor_seek(Cursor &c, const PieceCtx &pc, uint32_t m) {
-    uint32_t lo = 0, hi = pc.n_ev;
-    while (lo < hi) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (ev_out_start(pc.ev[mid]) <= m) lo = mid + 1; else hi = mid;
-    }
-    c.j = lo;
-    cursor_load(c, pc);
-    // a deletion (payload 0) or an empty step can share its out_start with the next event: handled by the
-    // while-loop in piece_byte, which always advances to the LAST event with out_start <= m
-}
-
-__device__ __forceinline__ uint8_t ref_base_at(const DevRef &ref, const PieceCtx &pc, uint32_t x) {
-    uint64_t g = pc.pos + x;
-    if (g >= pc.chrom_len) g -= pc.chrom_len;               // circular wrap (S:1757-1760)
-    return ref.bases[pc.chrom_base + g];
-}
-
-// one emitted base of a piece at emitted offset m (cursor must be positioned at or before m)
-__device__ __forceinline__ uint8_t piece_byte(const DevRef &ref, const PieceCtx &pc, Cursor &c, uint32_t m,
-                                              const ns_key &key, uint32_t attempt, int &cls) {
-    while (m >= c.next_out) { c.j++; cursor_load(c, pc); }
-    uint32_t d = m - c.cur_out;
-    if (d < c.cur_pl) {
-        if (c.cur_type == NS_MIS) {                                                  // S:1965-1978
-            cls = NS_Q_MIS;
-            uint32_t x = c.cur_pos + d;
-            uint8_t cur = resolve_base(ref_base_at(ref, pc, x), key, pc.sid, attempt, x);
-            return mis_letter(cur, key, pc.sid, attempt, x);
-        }
-        cls = NS_Q_INS;                                                              // S:1986-1995
-        return ins_letter(key, pc.sid, attempt, c.cur_pos, d);
-    }
-    cls = NS_Q_MATCH;
-    uint32_t x = c.cur_rp + (d - c.cur_pl);
-    return resolve_base(ref_base_at(ref, pc, x), key, pc.sid, attempt, x);           // case_convert, S:743-755
-}
-
-__device__ __forceinline__ PieceCtx load_piece(const GenArgs &A, const ns_piece &p, uint32_t pi) {
-    PieceCtx pc;
-    pc.ev = A.events + p.ev_off; pc.n_ev = p.n_ev; pc.out_len = p.out_len; pc.ref_len = p.ref_len;
-    pc.chrom_base = A.ref.chrom_off[p.chrom];
-    pc.chrom_len = A.ref.chrom_off[p.chrom + 1] - pc.chrom_base;
-    pc.pos = p.pos; pc.kind = p.kind;
-    pc.sid = p.kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
-    return pc;
-}
-
-template <bool QUAL>
-__device__ __forceinline__ void materialise_read(const GenArgs &A, uint64_t r, uint32_t lane) {
+__global__ void __launch_bounds__(64) k_materialise(GenArgs A, uint64_t nbases) {
+    __shared__ TileLds T;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t r = blockIdx.x;
     const ns_read rd = A.reads[r];
     if (rd.flags) return;
     const ns_key key = make_key(A.prm, r);
     const uint32_t a = rd.attempts;
-    const uint32_t seq_len = rd.seq_len;
-    const ns_piece *pieces = A.pieces + rd.piece_off;
-    uint8_t *dst = A.records + rd.rec_off + A.name_len[r] + 2 + (QUAL ? (uint64_t)seq_len + 3 : 0);
-    const uint32_t body_end = seq_len - rd.tail;
-    for (uint32_t o0 = lane * 16; o0 < seq_len; o0 += 64 * 16) {
-        const uint32_t count = min(16u, seq_len - o0);
-        // pre-revcomp coordinates of this chunk: ascending q in [q0, q0+count)
-        const uint32_t q0 = rd.reversed ? seq_len - o0 - count : o0;
-        uint64_t lo = 0, hi = 0;
-        // locate q0
-        uint32_t q = q0;
-        uint32_t pi = 0, pstart = rd.head;          // piece index and its first q
-        PieceCtx pc; Cursor cur;
-        bool in_piece = false;
-        pc.out_len = 0;
-        for (uint32_t i = 0; i < count; ++i, ++q) {
-            uint8_t b;
-            int cls = NS_Q_HT;
-            if (q < rd.head) {
-                if (QUAL) b = qual_at(A.m, NS_Q_HT, key, ST_HTQ, 0, a, q);                          // S:1421-1423
-                else b = ht_letter(key, ST_HEAD, a, q);                                              // S:1426
-            } else if (q >= body_end) {
-                uint32_t t = q - body_end;
-                if (QUAL) b = qual_at(A.m, NS_Q_HT, key, ST_HTQ, 0, a, rd.head + t);
-                else b = ht_letter(key, ST_TAIL, a, t);                                              // S:1427
-            } else {
-                if (!in_piece || q >= pstart + pc.out_len) {
-                    // (re)locate the piece containing q
-                    if (!in_piece) { pi = 0; pstart = rd.head; }
-                    else { pstart += pc.out_len; ++pi; }
-                    for (;;) {
-                        pc = load_piece(A, pieces[pi], pi);
-                        if (q < pstart + pc.out_len) break;
-                        pstart += pc.out_len; ++pi;
-                    }
-                    cursor_seek(cur, pc, q - pstart);
-                    in_piece = true;
-                }
-                uint32_t m = q - pstart;
-                if (QUAL) {
-                    if (pc.kind) cls = NS_Q_UNMAPPED;                                                // S:1521, S:1564
-                    else {
-                        while (m >= cur.next_out) { cur.j++; cursor_load(cur, pc); }
-                        uint32_t d = m - cur.cur_out;
-                        cls = (d < cur.cur_pl) ? (cur.cur_type == NS_MIS ? NS_Q_MIS : NS_Q_INS) : NS_Q_MATCH;
-                    }
-                    b = qual_at(A.m, cls, key, ST_QUAL, pc.sid, a, m);
-                } else {
-                    b = piece_byte(A.ref, pc, cur, m, key, a, cls);
-                }
-            }
-            if (QUAL) b = (uint8_t)(b + 33);                                                          // S:1441
-            else if (rd.reversed) b = complement(b);                                                  // S:1433-1435
-            const uint32_t bi = rd.reversed ? count - 1 - i : i;
-            if (bi < 8) lo |= (uint64_t)b << (8 * bi); else hi |= (uint64_t)b << (8 * (bi - 8));
-        }
-        if (count == 16) {
-            struct __attribute__((packed)) V { uint64_t a, b; } v{lo, hi};
-            __builtin_memcpy(dst + o0, &v, 16);
-        } else {
-            for (uint32_t i = 0; i < count; ++i)
-                dst[o0 + i] = (uint8_t)((i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8))) & 0xff);
-        }
+    ReadOut ro;
+    ro.seq = A.records + rd.rec_off + A.name_len[r] + 2;
+    ro.qual = A.prm.fastq ? ro.seq + rd.seq_len + 3 : nullptr;
+    ro.seq_len = rd.seq_len; ro.reversed = rd.reversed != 0;
+    emit_random_region(A.m, ro, key, a, ST_HEAD, 0, rd.head, 0, lane);                                   // S:1426
+    uint32_t q = rd.head;
+    for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
+        const PieceCtx pc = load_piece(A.events, A.ref, A.pieces[rd.piece_off + pi], pi);
+        materialise_piece(A.m, A.ref, T, ro, key, a, pc, q, lane, nbases);
+        q += pc.out_len;
     }
-}
-
-__global__ void __launch_bounds__(256) k_materialise(GenArgs A) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (r >= A.prm.n_reads) return;
-    materialise_read<false>(A, r, lane);
-    if (A.prm.fastq) materialise_read<true>(A, r, lane);
+    emit_random_region(A.m, ro, key, a, ST_TAIL, rd.seq_len - rd.tail, rd.tail, rd.head, lane);          // S:1427
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -462,7 +324,7 @@ __global__ void __launch_bounds__(256) k_errlog(GenArgs A) {
     uint64_t base = A.err_off[r];
     for (uint32_t pi = 0; pi < rd.n_pieces; pi += 2) {
         const ns_piece p = A.pieces[rd.piece_off + pi];
-        PieceCtx pc = load_piece(A, p, pi);
+        PieceCtx pc = load_piece(A.events, A.ref, p, pi);
         for (uint32_t j0 = 0; j0 < p.n_ev; j0 += 64) {
             // rows are written from the LAST event to the first
             const uint32_t k = j0 + lane;
@@ -492,7 +354,7 @@ __global__ void __launch_bounds__(256) k_errlog(GenArgs A) {
                         uint32_t x = e.pos + i;
                         uint8_t cur = resolve_base(ref_base_at(A.ref, pc, x), key, pc.sid, a, x);
                         q[i] = cur;
-                        q2[i] = (ty == NS_MIS) ? mis_letter(cur, key, pc.sid, a, x) : (uint8_t)'-';
+                        q2[i] = (ty == NS_MIS) ? mis_letter(cur, key, pc.sid, a, e.pos, i) : (uint8_t)'-';
                     }
                 }
                 q[len] = '\t';
@@ -544,6 +406,7 @@ struct ns_ctx {
     void *ref_bases_owned = nullptr;
     std::vector<void *> ref_allocs;
     double cap_rate = 0.1;
+    uint64_t ref_nbases = 0;
     // planning + result buffers
     DevBuf n_pieces, piece_off, ev_cap, ev_off, rec_len, rec_off, err_len, err_off, name_len;
     DevBuf reads, pieces, events, records, errlog, stats, scan_tmp;
@@ -672,6 +535,7 @@ int ns_set_reference(ns_ctx *ctx, const uint8_t *bases, uint64_t nbases, const u
     int rc = set_ref_meta(ctx, chrom_off, nchrom, circular, names, names_len);
     if (rc) return rc;
     if (chrom_off[nchrom] != nbases) return fail(ctx, NS_EINVAL, "chrom_off[nchrom] != nbases");
+    ctx->ref_nbases = nbases;
     ctx->has_ref = true;
     return NS_OK;
 }
@@ -693,6 +557,7 @@ int ns_set_reference_device(ns_ctx *ctx, const void *bases_dev, uint64_t nbases,
     int rc = set_ref_meta(ctx, chrom_off, nchrom, circular, names, names_len);
     if (rc) return rc;
     if (chrom_off[nchrom] != nbases) return fail(ctx, NS_EINVAL, "chrom_off[nchrom] != nbases");
+    ctx->ref_nbases = nbases;
     ctx->has_ref = true;
     return NS_OK;
 }
@@ -866,7 +731,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->evt[6], st));
     if (prm->emit_records) {
-        k_materialise<<<grid_w, blk, 0, st>>>(A);
+        k_materialise<<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->ref_nbases);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ctx->evt[7], st));

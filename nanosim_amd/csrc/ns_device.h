@@ -281,22 +281,27 @@ __device__ __forceinline__ uint8_t resolve_base(uint32_t c, const ns_key &key, u
     uint32_t j = (uint32_t)(((uint64_t)ns_word(w, x & 3) * n) >> 32);
     return (uint8_t)(mem >> (8 * j));
 }
-// S:1968-1972
-__device__ __forceinline__ uint8_t mis_letter(uint32_t cur, const ns_key &key, uint32_t seg, uint32_t attempt, uint32_t x) {
-    u32x4 w = ns_draw(key, ST_SUB, seg, attempt, x >> 2, 0);
-    uint32_t j = (uint32_t)(((uint64_t)ns_word(w, x & 3) * 3u) >> 32);
+// S:1968-1972: 16-bit field i of the block keyed by the event position (8 letters per Philox block)
+__device__ __forceinline__ uint8_t mis_from_h(uint32_t cur, uint32_t h) {
+    uint32_t j = (h * 3u) >> 16;
     int rc = base_rank(cur);
     uint32_t rk = j + ((int)j >= rc ? 1u : 0u);
     if (rc < 0) rk = j;
     return bases_atcg(rk);
 }
-__device__ __forceinline__ uint8_t ins_letter(const ns_key &key, uint32_t seg, uint32_t attempt, uint32_t x, uint32_t i) {   // S:1990
-    u32x4 w = ns_draw(key, ST_INS, seg, attempt, x, i >> 2);
-    return bases_atcg(ns_word(w, i & 3) >> 30);
+__device__ __forceinline__ uint8_t mis_letter(uint32_t cur, const ns_key &key, uint32_t seg, uint32_t attempt, uint32_t x, uint32_t i) {
+    u32x4 w = ns_draw(key, ST_SUB, seg, attempt, x, i >> 3);
+    uint32_t h = (ns_word(w, (i & 7) >> 1) >> (16 * (i & 1))) & 0xffffu;
+    return mis_from_h(cur, h);
+}
+// S:1990: 2-bit field i of the block keyed by the event position (64 letters per Philox block)
+__device__ __forceinline__ uint8_t ins_letter(const ns_key &key, uint32_t seg, uint32_t attempt, uint32_t x, uint32_t i) {
+    u32x4 w = ns_draw(key, ST_INS, seg, attempt, x, i >> 6);
+    return bases_atcg((ns_word(w, (i >> 4) & 3) >> (2 * (i & 15))) & 3u);
 }
 __device__ __forceinline__ uint8_t ht_letter(const ns_key &key, uint32_t stream, uint32_t attempt, uint32_t i) {             // S:1426-1427
-    u32x4 w = ns_draw(key, stream, 0, attempt, i >> 2, 0);
-    return bases_atcg(ns_word(w, i & 3) >> 30);
+    u32x4 w = ns_draw(key, stream, 0, attempt, i >> 6, 0);
+    return bases_atcg((ns_word(w, (i >> 4) & 3) >> (2 * (i & 15))) & 3u);
 }
 __device__ __forceinline__ uint8_t qual_value(const uint32_t *__restrict__ thr, uint32_t h) {
     // q = #{j in [0,126] : h >= thr[j]}; thr is non-decreasing -> binary search for the first thr[j] > h

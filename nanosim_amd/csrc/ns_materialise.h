@@ -1,0 +1,359 @@
+// ns_materialise.h — k_materialise (v2): one read per wavefront (64-thread workgroup), LDS-tiled.
+//
+// Per piece the emitted sequence is produced in tiles of <= 1024 bases:
+//   1. stage the events that start inside the tile (plus the one in force at the tile start) into LDS;
+//   2. stage the reference bytes the tile copies from with coalesced 16-byte loads into LDS, resolving
+//      IUPAC codes on the fly (case_convert, S:743-755: keyed by the segment position, so every tile that
+//      touches a base sees the same letter);
+//   3. phase B — one lane per event: substituted / inserted letters (one Philox block per event) are written
+//      into an LDS payload tile at their output offsets (mutate_read, S:1965-1995);
+//   4. phase A — one lane per 16 output bytes: a histogram + wavefront prefix sum gives every lane the event
+//      in force at its first byte; bytes come from the payload tile or the reference tile; the 16 bytes are
+//      complemented/reversed in registers (S:1433-1435, 1675-1680) and stored with one 16-byte store.
+// Tiles whose reference span does not fit the LDS tile, or that straddle the origin of a circular chromosome,
+// take the generic per-byte path (slow_piece_range).
+#pragma once
+#include "ns_device.h"
+
+#define T_OUT 1024u
+#define T_EV 256u
+#define T_REF 2112u
+
+struct __align__(16) TileLds {
+    uint8_t ref[T_REF];
+    uint8_t pay[T_OUT];
+    uint32_t e_out[T_EV + 1];
+    uint32_t e_rp[T_EV];
+    uint32_t e_pos[T_EV];
+    uint16_t e_pl[T_EV];
+    uint8_t e_ty[T_EV];
+    uint32_t hist[64];
+};
+
+struct ReadOut {
+    uint8_t *seq;        // first base of the record's sequence line
+    uint8_t *qual;       // first quality character, or nullptr
+    uint32_t seq_len;
+    bool reversed;
+};
+
+__device__ __forceinline__ void store16(uint8_t *dst, uint32_t count, uint64_t lo, uint64_t hi) {
+    if (count == 16) {
+        struct __attribute__((packed)) V { uint64_t a, b; } v{lo, hi};
+        __builtin_memcpy(dst, &v, 16);
+    } else {
+        for (uint32_t i = 0; i < count; ++i) dst[i] = (uint8_t)((i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8))) & 0xff);
+    }
+}
+__device__ __forceinline__ void reverse_bytes(uint64_t &lo, uint64_t &hi, uint32_t count) {
+    uint64_t rlo = __builtin_bswap64(hi), rhi = __builtin_bswap64(lo);     // byte i -> 15-i
+    uint32_t s = 8 * (16 - count);
+    if (s == 0) { lo = rlo; hi = rhi; }
+    else if (s < 64) { lo = (rlo >> s) | (rhi << (64 - s)); hi = rhi >> s; }
+    else { lo = rhi >> (s - 64); hi = 0; }
+}
+__device__ __forceinline__ uint64_t complement8(uint64_t x) {              // A<->T, C<->G on 8 packed ASCII bases
+    return x ^ 0x1515151515151515ull ^ (((x >> 1) & 0x0101010101010101ull) * 0x11ull);
+}
+// `count` bytes whose pre-revcomp coordinates are [q0, q0+count), byte i in bits 8i of (lo,hi)
+__device__ __forceinline__ void store_chunk(const ReadOut &ro, uint32_t q0, uint32_t count, uint64_t lo, uint64_t hi,
+                                            uint64_t qlo, uint64_t qhi) {
+    uint32_t o0 = q0;
+    if (ro.reversed) {
+        lo = complement8(lo); hi = complement8(hi);
+        reverse_bytes(lo, hi, count);
+        o0 = ro.seq_len - q0 - count;
+    }
+    store16(ro.seq + o0, count, lo, hi);
+    if (ro.qual) {
+        qlo += 0x2121212121212121ull; qhi += 0x2121212121212121ull;         // chr(q + 33), S:1441
+        if (ro.reversed) reverse_bytes(qlo, qhi, count);
+        store16(ro.qual + o0, count, qlo, qhi);
+    }
+}
+__device__ __forceinline__ void put_byte(uint64_t &lo, uint64_t &hi, uint32_t i, uint32_t b) {
+    if (i < 8) lo |= (uint64_t)b << (8 * i); else hi |= (uint64_t)b << (8 * (i - 8));
+}
+
+// cached 16-bit quality draws: block = mpos >> 3
+struct QualDraw {
+    uint32_t blk; u32x4 w;
+};
+__device__ __forceinline__ uint32_t qual_draw(QualDraw &qd, const DevModel &m, int cls, const ns_key &key, uint32_t stream,
+                                              uint32_t seg, uint32_t attempt, uint32_t mpos) {
+    if ((mpos >> 3) != qd.blk) { qd.blk = mpos >> 3; qd.w = ns_draw(key, stream, seg, attempt, qd.blk, 0); }
+    uint32_t h = (ns_word(qd.w, (mpos & 7) >> 1) >> (16 * (mpos & 1))) & 0xffffu;
+    return qual_value(m.qual_thr + cls * NS_QUAL_LEVELS, h);
+}
+
+// head / tail: uniform bases (S:1426-1427) + 'ht' qualities (S:1421-1423).  One Philox block per 64 letters.
+__device__ inline void emit_random_region(const DevModel &m, const ReadOut &ro, const ns_key &key, uint32_t a,
+                                          uint32_t stream, uint32_t q_start, uint32_t len, uint32_t hq_off, uint32_t lane) {
+    for (uint32_t i0 = lane * 16; i0 < len; i0 += 64 * 16) {
+        const uint32_t count = min(16u, len - i0);
+        u32x4 w = ns_draw(key, stream, 0, a, i0 >> 6, 0);
+        const uint32_t word = ns_word(w, (i0 >> 4) & 3);
+        uint64_t lo = 0, hi = 0, qlo = 0, qhi = 0;
+        QualDraw qd; qd.blk = 0xffffffffu;
+        for (uint32_t i = 0; i < count; ++i) {
+            put_byte(lo, hi, i, bases_atcg((word >> (2 * i)) & 3u));
+            if (ro.qual) put_byte(qlo, qhi, i, qual_draw(qd, m, NS_Q_HT, key, ST_HTQ, 0, a, hq_off + i0 + i));
+        }
+        store_chunk(ro, q_start + i0, count, lo, hi, qlo, qhi);
+    }
+}
+
+// ---- generic per-byte path (global memory, no staging) ---------------------------------------------------
+struct PieceCtx {
+    const ns_event *ev;
+    uint32_t n_ev;
+    uint32_t out_len, ref_len;
+    uint64_t chrom_base;
+    uint64_t chrom_len;
+    uint64_t pos;
+    uint32_t sid;
+    uint32_t kind;
+};
+struct Cursor {
+    uint32_t j;
+    uint32_t cur_out, cur_pl, cur_type, cur_pos, cur_rp;
+    uint32_t next_out;
+};
+__device__ __forceinline__ uint32_t ev_out_start(const ns_event &e) { return (uint32_t)((int32_t)e.pos + ns_ev_shift(e.info)); }
+__device__ __forceinline__ void cursor_load(Cursor &c, const PieceCtx &pc) {
+    if (c.j == 0) { c.cur_out = 0; c.cur_pl = 0; c.cur_type = 3; c.cur_pos = 0; c.cur_rp = 0; }
+    else {
+        ns_event e = pc.ev[c.j - 1];
+        uint32_t len = ns_ev_len(e.info), ty = ns_ev_type(e.info);
+        c.cur_out = ev_out_start(e); c.cur_type = ty; c.cur_pos = e.pos;
+        c.cur_pl = (ty == NS_DEL) ? 0 : len;
+        c.cur_rp = e.pos + ((ty == NS_INS) ? 0 : len);
+    }
+    c.next_out = (c.j < pc.n_ev) ? ev_out_start(pc.ev[c.j]) : 0xffffffffu;
+}
+__device__ __forceinline__ void cursor_seek(Cursor &c, const PieceCtx &pc, uint32_t m) {
+    uint32_t lo = 0, hi = pc.n_ev;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (ev_out_start(pc.ev[mid]) <= m) lo = mid + 1; else hi = mid;
+    }
+    c.j = lo;
+    cursor_load(c, pc);
+}
+__device__ __forceinline__ uint8_t ref_base_at(const DevRef &ref, const PieceCtx &pc, uint32_t x) {
+    uint64_t g = pc.pos + x;
+    if (g >= pc.chrom_len) g -= pc.chrom_len;               // circular wrap (S:1757-1760)
+    return ref.bases[pc.chrom_base + g];
+}
+__device__ __forceinline__ uint8_t piece_byte(const DevRef &ref, const PieceCtx &pc, Cursor &c, uint32_t m,
+                                              const ns_key &key, uint32_t attempt, int &cls) {
+    while (m >= c.next_out) { c.j++; cursor_load(c, pc); }
+    uint32_t d = m - c.cur_out;
+    if (d < c.cur_pl) {
+        if (c.cur_type == NS_MIS) {                                                  // S:1965-1978
+            cls = NS_Q_MIS;
+            uint32_t x = c.cur_pos + d;
+            uint8_t cur = resolve_base(ref_base_at(ref, pc, x), key, pc.sid, attempt, x);
+            return mis_letter(cur, key, pc.sid, attempt, c.cur_pos, d);
+        }
+        cls = NS_Q_INS;                                                              // S:1986-1995
+        return ins_letter(key, pc.sid, attempt, c.cur_pos, d);
+    }
+    cls = NS_Q_MATCH;
+    uint32_t x = c.cur_rp + (d - c.cur_pl);
+    return resolve_base(ref_base_at(ref, pc, x), key, pc.sid, attempt, x);           // case_convert, S:743-755
+}
+__device__ __forceinline__ PieceCtx load_piece(const ns_event *events, const DevRef &ref, const ns_piece &p, uint32_t pi) {
+    PieceCtx pc;
+    pc.ev = events + p.ev_off; pc.n_ev = p.n_ev; pc.out_len = p.out_len; pc.ref_len = p.ref_len;
+    pc.chrom_base = ref.chrom_off[p.chrom];
+    pc.chrom_len = ref.chrom_off[p.chrom + 1] - pc.chrom_base;
+    pc.pos = p.pos; pc.kind = p.kind;
+    pc.sid = p.kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
+    return pc;
+}
+// bytes [m_lo, m_hi) of one piece, 16 per lane, straight from global memory
+__device__ inline void slow_piece_range(const DevModel &m, const DevRef &ref, const ReadOut &ro, const ns_key &key, uint32_t a,
+                                        const PieceCtx &pc, uint32_t pq, uint32_t m_lo, uint32_t m_hi, uint32_t lane) {
+    for (uint32_t m0 = m_lo + lane * 16; m0 < m_hi; m0 += 64 * 16) {
+        const uint32_t count = min(16u, m_hi - m0);
+        Cursor cur;
+        cursor_seek(cur, pc, m0);
+        uint64_t lo = 0, hi = 0, qlo = 0, qhi = 0;
+        QualDraw qd; qd.blk = 0xffffffffu;
+        for (uint32_t i = 0; i < count; ++i) {
+            int cls;
+            uint8_t b = piece_byte(ref, pc, cur, m0 + i, key, a, cls);
+            put_byte(lo, hi, i, b);
+            if (ro.qual) put_byte(qlo, qhi, i, qual_draw(qd, m, pc.kind ? NS_Q_UNMAPPED : cls, key, ST_QUAL, pc.sid, a, m0 + i));
+        }
+        store_chunk(ro, pq + m0, count, lo, hi, qlo, qhi);
+    }
+}
+
+// ---- LDS-tiled path ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t zero_bytes4(uint32_t x) {     // 0x80 in every byte of x that is zero (exact per byte)
+    return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
+}
+__device__ __forceinline__ uint32_t nonacgt_mask4(uint32_t w) {
+    // per byte: 0x80 set if the byte is NOT one of A C G T (upper-case ASCII)
+    uint32_t z = zero_bytes4(w ^ 0x41414141u) | zero_bytes4(w ^ 0x43434343u) | zero_bytes4(w ^ 0x47474747u) |
+                 zero_bytes4(w ^ 0x54545454u);
+    return ~z & 0x80808080u;
+}
+
+__device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, TileLds &T, const ReadOut &ro, const ns_key &key,
+                                         uint32_t a, const PieceCtx &pc, uint32_t pq, uint32_t lane, uint64_t nbases) {
+    uint32_t jb = 0;                       // events with out_start < M0
+    for (uint32_t M0 = 0; M0 < pc.out_len;) {
+        uint32_t M1 = min(M0 + T_OUT, pc.out_len);
+        // ---- 1. stage events: L[0] = the event in force before M0 (or a synthetic start), L[1..] start in [M0, M1)
+        if (lane == 0) {
+            if (jb == 0) { T.e_out[0] = 0; T.e_rp[0] = 0; T.e_pos[0] = 0; T.e_pl[0] = 0; T.e_ty[0] = 3; }
+            else {
+                ns_event e = pc.ev[jb - 1];
+                uint32_t len = ns_ev_len(e.info), ty = ns_ev_type(e.info);
+                T.e_out[0] = ev_out_start(e); T.e_pos[0] = e.pos; T.e_ty[0] = (uint8_t)ty;
+                T.e_pl[0] = (uint16_t)(ty == NS_DEL ? 0 : len);
+                T.e_rp[0] = e.pos + (ty == NS_INS ? 0 : len);
+            }
+        }
+        uint32_t ne = 1;
+        for (uint32_t base = jb;; base += 64) {
+            const uint32_t idx = base + lane;
+            const bool valid = idx < pc.n_ev;
+            ns_event e; e.pos = 0; e.info = 0;
+            if (valid) e = pc.ev[idx];
+            const uint32_t os = ev_out_start(e);
+            const bool take = valid && os < M1;
+            const uint32_t cnt = (uint32_t)__popcll(__ballot(take));
+            const uint32_t slot = ne + lane;
+            if (take && slot < T_EV) {
+                uint32_t len = ns_ev_len(e.info), ty = ns_ev_type(e.info);
+                T.e_out[slot] = os; T.e_pos[slot] = e.pos; T.e_ty[slot] = (uint8_t)ty;
+                T.e_pl[slot] = (uint16_t)(ty == NS_DEL ? 0 : len);
+                T.e_rp[slot] = e.pos + (ty == NS_INS ? 0 : len);
+            }
+            if (ne + cnt > T_EV) {         // more events than LDS slots: end the tile at the first unstaged event
+                M1 = __shfl(os, (int)(T_EV - ne));
+                ne = T_EV;
+                break;
+            }
+            ne += cnt;
+            if (cnt < 64) break;
+        }
+        if (lane == 0) T.e_out[ne] = M1;
+        T.hist[lane] = 0;
+        __syncthreads();
+
+        // ---- 2. reference span of the tile
+        const uint32_t os0 = T.e_out[0], pl0 = T.e_pl[0], rp0 = T.e_rp[0], ty0 = T.e_ty[0], pos0 = T.e_pos[0];
+        const uint32_t d0 = M0 - os0;
+        const uint32_t x0 = d0 < pl0 ? (ty0 == NS_MIS ? pos0 + d0 : rp0) : rp0 + (d0 - pl0);
+        const uint32_t osl = T.e_out[ne - 1], pll = T.e_pl[ne - 1], rpl = T.e_rp[ne - 1];
+        const uint32_t dl = M1 - osl;
+        uint32_t x1 = dl <= pll ? rpl : rpl + (dl - pll);
+        if (x1 < x0) x1 = x0;
+        uint64_t g0 = pc.pos + x0;
+        bool fast = true;
+        if (g0 >= pc.chrom_len) g0 -= pc.chrom_len;                 // whole tile beyond the origin of a circular chromosome
+        if (g0 + (x1 - x0) > pc.chrom_len) fast = false;            // tile straddles the origin
+        const uint64_t gaddr = pc.chrom_base + g0;
+        const uint32_t lead = (uint32_t)(gaddr & 15u);
+        const uint32_t need = lead + (x1 - x0);
+        if (need > T_REF) fast = false;
+        if (!fast) {
+            slow_piece_range(m, ref, ro, key, a, pc, pq, M0, M1, lane);
+            jb += ne - 1; M0 = M1;
+            __syncthreads();
+            continue;
+        }
+        const uint8_t *src = ref.bases + (gaddr - lead);
+        const uint64_t src_off = gaddr - lead;
+        for (uint32_t c = lane * 16; c < need; c += 64 * 16) {
+            uint32_t w[4];
+            if (src_off + c + 16 <= nbases) {
+                uint4 v = *reinterpret_cast<const uint4 *>(src + c);
+                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+            } else {
+                w[0] = w[1] = w[2] = w[3] = 0x41414141u;
+                for (uint32_t b = 0; b < 16 && src_off + c + b < nbases; ++b) {
+                    w[b >> 2] = (w[b >> 2] & ~(0xffu << (8 * (b & 3)))) | (uint32_t)src[c + b] << (8 * (b & 3));
+                }
+            }
+            const uint32_t bad = nonacgt_mask4(w[0]) | nonacgt_mask4(w[1]) | nonacgt_mask4(w[2]) | nonacgt_mask4(w[3]);
+            if (bad) {                                           // case_convert (S:743-755), keyed by segment position
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    if (!nonacgt_mask4(w[k])) continue;
+                    for (uint32_t b = 0; b < 4; ++b) {
+                        uint32_t ch = (w[k] >> (8 * b)) & 0xff;
+                        int64_t x = (int64_t)x0 + (int64_t)(c + 4 * k + b) - (int64_t)lead;
+                        if (!is_acgt(ch) && x >= 0 && x < (int64_t)pc.ref_len) {
+                            uint32_t r = resolve_base(ch, key, pc.sid, a, (uint32_t)x);
+                            w[k] = (w[k] & ~(0xffu << (8 * b))) | r << (8 * b);
+                        }
+                    }
+                }
+            }
+            *reinterpret_cast<uint4 *>(&T.ref[c]) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        __syncthreads();
+        const uint32_t rbase = lead - x0;                         // T.ref index of segment position x is rbase + x
+
+        // ---- 3. phase B: payload letters, one lane per event
+        for (uint32_t k = lane; k < ne; k += 64) {
+            const uint32_t pl = T.e_pl[k];
+            if (!pl) continue;
+            const uint32_t os = T.e_out[k], ty = T.e_ty[k], ep = T.e_pos[k];
+            const uint32_t i_lo = os < M0 ? M0 - os : 0;
+            const uint32_t i_hi = min(pl, M1 - os);
+            uint32_t blk = 0xffffffffu; u32x4 w;
+            for (uint32_t i = i_lo; i < i_hi; ++i) {
+                uint8_t b;
+                if (ty == NS_INS) {
+                    if ((i >> 6) != blk) { blk = i >> 6; w = ns_draw(key, ST_INS, pc.sid, a, ep, blk); }
+                    b = bases_atcg((ns_word(w, (i >> 4) & 3) >> (2 * (i & 15))) & 3u);
+                } else {
+                    if ((i >> 3) != blk) { blk = i >> 3; w = ns_draw(key, ST_SUB, pc.sid, a, ep, blk); }
+                    uint32_t h = (ns_word(w, (i & 7) >> 1) >> (16 * (i & 1))) & 0xffffu;
+                    b = mis_from_h(T.ref[rbase + ep + i], h);
+                }
+                T.pay[os + i - M0] = b;
+            }
+            // histogram for phase A: first 16-byte chunk whose start is >= the event's out_start
+        }
+        for (uint32_t k = 1 + lane; k < ne; k += 64) {
+            uint32_t c = (T.e_out[k] - M0 + 15) >> 4;
+            if (c < 64) atomicAdd(&T.hist[c], 1u);
+        }
+        __syncthreads();
+
+        // ---- 4. phase A: one lane per 16 output bytes
+        uint32_t incl = T.hist[lane];
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t v = __shfl_up(incl, off);
+            if ((int)lane >= off) incl += v;
+        }
+        uint32_t mm = M0 + 16 * lane;
+        if (mm < M1) {
+            const uint32_t count = min(16u, M1 - mm);
+            uint32_t k = incl;                                     // event in force at the chunk's first byte
+            uint32_t os = T.e_out[k], pl = T.e_pl[k], rp = T.e_rp[k], ty = T.e_ty[k], nxt = T.e_out[k + 1];
+            uint64_t lo = 0, hi = 0, qlo = 0, qhi = 0;
+            QualDraw qd; qd.blk = 0xffffffffu;
+            for (uint32_t i = 0; i < count; ++i, ++mm) {
+                while (mm >= nxt) { ++k; os = nxt; pl = T.e_pl[k]; rp = T.e_rp[k]; ty = T.e_ty[k]; nxt = T.e_out[k + 1]; }
+                const uint32_t d = mm - os;
+                uint32_t b; int cls;
+                if (d < pl) { b = T.pay[mm - M0]; cls = (ty == NS_MIS) ? NS_Q_MIS : NS_Q_INS; }
+                else { b = T.ref[rbase + rp + (d - pl)]; cls = NS_Q_MATCH; }
+                put_byte(lo, hi, i, b);
+                if (ro.qual) put_byte(qlo, qhi, i, qual_draw(qd, m, pc.kind ? NS_Q_UNMAPPED : cls, key, ST_QUAL, pc.sid, a, mm));
+            }
+            store_chunk(ro, pq + M0 + 16 * lane, count, lo, hi, qlo, qhi);
+        }
+        jb += ne - 1; M0 = M1;
+        __syncthreads();
+    }
+}

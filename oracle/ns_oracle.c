@@ -369,26 +369,32 @@ static uint8_t resolve_base(uint8_t c, nso_draw *d, uint32_t seg, uint32_t attem
     else { uint32_t w[4]; philox_at(d, ST_IUPAC, seg, attempt, (uint32_t)(x >> 2), 0, w); j = (uint32_t)(((uint64_t)w[x & 3] * (uint32_t)n) >> 32); }
     return (uint8_t)mem[j];
 }
-/* S:1968-1972: uniform choice among BASES minus the current base */
-static uint8_t mis_letter(uint8_t cur, nso_draw *d, uint32_t seg, uint32_t attempt, uint64_t x) {
+/* S:1968-1972: uniform choice among BASES minus the current base.  Draw: 16-bit field i of the block keyed by
+ * the EVENT position x (8 letters per Philox block) */
+static uint8_t mis_letter(uint8_t cur, nso_draw *d, uint32_t seg, uint32_t attempt, uint64_t x, uint32_t i) {
     uint32_t j;
     if (d->mode) j = (uint32_t)(tape_u(d) * 3);
-    else { uint32_t w[4]; philox_at(d, ST_SUB, seg, attempt, (uint32_t)(x >> 2), 0, w); j = (uint32_t)(((uint64_t)w[x & 3] * 3u) >> 32); }
+    else {
+        uint32_t w[4]; philox_at(d, ST_SUB, seg, attempt, (uint32_t)x, i >> 3, w);
+        uint32_t h = (w[(i & 7) >> 1] >> (16 * (i & 1))) & 0xffffu;
+        j = (h * 3u) >> 16;
+    }
     int rc = base_rank(cur);
     int rk = (int)j + ((int)j >= rc ? 1 : 0);
     if (rc < 0) rk = (int)j;                /* cannot happen after resolve_base */
     return (uint8_t)BASES[rk];
 }
-static uint8_t ins_letter(nso_draw *d, uint32_t seg, uint32_t attempt, uint64_t x, uint32_t i) {   /* S:1990 */
+/* S:1990: 2-bit field i of the block keyed by the event position (64 letters per Philox block) */
+static uint8_t ins_letter(nso_draw *d, uint32_t seg, uint32_t attempt, uint64_t x, uint32_t i) {
     uint32_t j;
     if (d->mode) j = (uint32_t)(tape_u(d) * 4);
-    else { uint32_t w[4]; philox_at(d, ST_INS, seg, attempt, (uint32_t)x, i >> 2, w); j = w[i & 3] >> 30; }
+    else { uint32_t w[4]; philox_at(d, ST_INS, seg, attempt, (uint32_t)x, i >> 6, w); j = (w[(i >> 4) & 3] >> (2 * (i & 15))) & 3u; }
     return (uint8_t)BASES[j];
 }
 static uint8_t ht_letter(nso_draw *d, uint32_t stream, uint32_t attempt, uint32_t i) {             /* S:1426-1427 */
     uint32_t w[4];
-    philox_at(d, stream, 0, attempt, i >> 2, 0, w);
-    return (uint8_t)BASES[w[i & 3] >> 30];
+    philox_at(d, stream, 0, attempt, i >> 6, 0, w);
+    return (uint8_t)BASES[(w[(i >> 4) & 3] >> (2 * (i & 15))) & 3u];
 }
 static uint8_t qual_value(const ns_model_tables *t, int cls, uint32_t h) {
     const uint32_t *thr = t->qual_thr[cls];
@@ -438,7 +444,7 @@ int64_t nso_mutate_read(const uint8_t *seg_in, int64_t ref_len, const ns_event *
                    log[row].ref_off = (uint32_t)tl; }
         if (etype == NS_MIS) {
             uint8_t nb[4096];
-            for (int64_t i = 0; i < len; ++i) nb[i] = mis_letter(seg_in[key + i], d, seg, attempt, (uint64_t)(key + i));
+            for (int64_t i = 0; i < len; ++i) nb[i] = mis_letter(seg_in[key + i], d, seg, attempt, (uint64_t)key, (uint32_t)i);
             for (int64_t i = len - 1; i >= 0; --i) { --w; out[w] = nb[i]; if (cls) cls[w] = NS_Q_MIS; }
             if (txt) { memcpy(txt + tl, seg_in + key, (size_t)len); tl += (uint64_t)len;
                        if (log) log[row].new_off = (uint32_t)tl;
