@@ -19,6 +19,7 @@
 
 #include "ns_device.h"
 #include "ns_materialise.h"
+#include "ns_chain.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // kernel arguments
@@ -39,6 +40,11 @@ struct GenArgs {
     uint64_t *err_len;
     uint64_t *err_off;
     uint16_t *name_len;
+    uint32_t *sort_key, *sort_idx;   // k_plan: total reference length per read, read index
+    const uint32_t *list;            // reads this pass visits (pass 0: sorted by descending length)
+    uint32_t list_n, attempt;
+    uint32_t *next_list, *next_n;    // reads rejected in this pass
+    uint32_t *rstate;                // per read: epoch | consecutive first-check failures << 16
     // results
     ns_read *reads;
     ns_piece *pieces;
@@ -61,181 +67,212 @@ __device__ __forceinline__ uint32_t read_nseg(const GenArgs &A, const ns_key &ke
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_plan: pieces per read and event capacity from the epoch-0 lengths
+// k_nseg: pieces per read (S:1276-1279)
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_plan(GenArgs A) {
+__global__ void __launch_bounds__(256) k_nseg(GenArgs A) {
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > A.prm.n_reads) return;
-    if (r == A.prm.n_reads) { A.n_pieces[r] = 0; A.ev_cap[r] = 0; return; }
-    ns_key key = make_key(A.prm, r);
-    uint64_t cap = 0;
-    uint32_t np = 1;
-    if (A.prm.kind == NS_KIND_UNALIGNED) {
-        int64_t l = unaligned_length(A.m, A.prm, key, 0);
-        if (l < 0) l = 0;
-        cap = (uint64_t)l * A.cap_gap_mul + 64;
-    } else if (A.prm.kind == NS_KIND_PERFECT) {
-        cap = 0;
-    } else {
-        uint32_t nseg = read_nseg(A, key);
-        np = 2 * nseg - 1;
-        for (uint32_t s = 0; s < nseg; ++s) {
-            int64_t l = 0;
-            if (!seg_length(A.m, A.prm, key, s, 0, l)) l = 0;
-            cap += (uint64_t)((double)l * A.cap_rate) + 64;
-        }
-        for (uint32_t g = 0; g + 1 < nseg; ++g) cap += (uint64_t)gap_length(A.m, key, g, 0) * A.cap_gap_mul + 64;
-    }
-    A.n_pieces[r] = np;
-    A.ev_cap[r] = cap;
+    if (r == A.prm.n_reads) { A.n_pieces[r] = 0; A.ev_cap[r] = 0; A.rec_len[r] = 0; A.err_len[r] = 0; return; }
+    A.n_pieces[r] = 2 * read_nseg(A, make_key(A.prm, r)) - 1;
+    A.rstate[r] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_events: one thread per read; the whole accept/reject loop of S:1283-1449 with per-read retry counters
+// k_lengths: everything attempt `a` of a read draws BEFORE its error lists — segment / gap lengths
+// (S:1285-1299), head+tail remainder and ratio (S:1471-1474), strand (S:1312).  All the fp64 sampling math
+// (KDE, inverse normal, 10^x) lives here; k_chain is integer/table work only.  Pass 0 visits every read and
+// also sizes the event buffer; later passes visit only the reads whose previous attempt was rejected.
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_events(GenArgs A) {
-    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r > A.prm.n_reads) return;
-    if (r == A.prm.n_reads) { A.rec_len[r] = 0; A.err_len[r] = 0; return; }
+__global__ void __launch_bounds__(256) k_lengths(GenArgs A) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= A.list_n) return;
+    const uint64_t r = A.list ? A.list[tid] : tid;
     const ns_params &prm = A.prm;
     const int kind = (int)prm.kind;
-    ns_key key = make_key(prm, r);
-    const uint32_t nseg = read_nseg(A, key);
-    const uint32_t n_pieces = (kind == NS_KIND_ALIGNED) ? 2 * nseg - 1 : 1;
-    ns_piece *pc = A.pieces + A.piece_off[r];
-    ns_event *ev_base = A.events + A.ev_off[r];
-    const uint64_t ev_cap64 = A.ev_off[r + 1] - A.ev_off[r];
-    const uint32_t ev_cap = ev_cap64 > 0xffffffffull ? 0xffffffffu : (uint32_t)ev_cap64;
-
+    const ns_key key = make_key(prm, r);
+    const uint32_t a = A.attempt;
+    const uint32_t epoch = A.rstate[r] & 0xffffu;
+    const uint32_t piece_off = A.piece_off[r];
+    const uint32_t n_pieces = A.piece_off[r + 1] - piece_off;
+    ns_piece *pc = A.pieces + piece_off;
+    bool ok = true;
+    uint64_t cap = 0, work = 0;
+    for (uint32_t pi = 0; pi < n_pieces; ++pi) {
+        const bool is_gap = (kind == NS_KIND_UNALIGNED) || (pi & 1);
+        int64_t mlen = 0;
+        if (kind == NS_KIND_UNALIGNED) mlen = unaligned_length(A.m, prm, key, a);       // S:1494-1495
+        else if (is_gap) mlen = gap_length(A.m, key, pi >> 1, epoch);                  // S:1298-1299
+        else if (!seg_length(A.m, prm, key, pi >> 1, epoch, mlen)) { ok = false; mlen = 0; }   // S:1285-1296
+        const int32_t m32 = mlen > 0x3fffffff ? 0x3fffffff : mlen < -1 ? -1 : (int32_t)mlen;
+        ns_piece p;
+        p.ref_gpos = 0; p.ev_off = 0; p.chrom = 0; p.pos = 0; p.ref_len = (uint32_t)m32; p.out_len = 0; p.n_ev = 0;
+        p.kind = is_gap ? 1u : 0u;
+        pc[pi] = p;
+        const uint64_t l = m32 > 0 ? (uint64_t)m32 : 0;
+        if (kind == NS_KIND_PERFECT) continue;
+        if (is_gap) { cap += l * A.cap_gap_mul + 64; work += 20 * l; }    // a gap base costs ~20x an aligned base
+        else { cap += (uint64_t)((double)l * A.cap_rate) + 64; work += l; }
+    }
+    int32_t remainder = 0; double ratio = 0;
+    if (kind == NS_KIND_ALIGNED && ok) {                                               // S:1471-1474, 1351-1352
+        uint32_t j = 0;
+        for (; j < NS_KDE_RETRY; ++j) {
+            u32x4 w = ns_draw(key, ST_HT, 0, a, j, 0);
+            double x = ns_pow10m1(kde_sample(A.m.kde[NS_KDE_HT], w));
+            if (x >= 0) { remainder = (int32_t)x; break; }
+        }
+        for (j = 0; j < NS_KDE_RETRY; ++j) {
+            u32x4 w = ns_draw(key, ST_RATIO, 0, a, j, 0);
+            double x = kde_sample(A.m.kde[NS_KDE_RATIO], w);
+            if (0 <= x && x <= 1) { ratio = x; break; }
+        }
+        if (j == NS_KDE_RETRY) ratio = 0.5;
+    }
+    u32x4 ws = ns_draw(key, ST_STRAND, 0, a, 0, 0);
     ns_read rd;
-    rd.rec_off = 0; rd.piece_off = A.piece_off[r]; rd.n_pieces = (uint16_t)n_pieces; rd.reversed = 0; rd.flags = 1;
-    rd.head = rd.tail = rd.seq_len = 0; rd.attempts = 0;
-    uint32_t name_len = 0;
-    uint64_t err_len = 0;
-    bool done = false, overflow = false;
-    uint32_t epoch = 0, fails = 0;
-    for (uint32_t a = 0; a < NS_MAX_ATTEMPT && !done; ++a) {
-        bool ok = true;
-        // lengths are pure functions of (read, seg, epoch): validate them first
-        if (kind != NS_KIND_UNALIGNED) {
-            for (uint32_t s = 0; s < nseg && ok; ++s) { int64_t l; ok = seg_length(A.m, prm, key, s, epoch, l); }
-        }
-        int64_t remainder = 0; double ratio = 0;
-        if (kind == NS_KIND_ALIGNED && ok) {                                         // S:1471-1474, 1351-1352
-            uint32_t j = 0;
-            for (; j < NS_KDE_RETRY; ++j) {
-                u32x4 w = ns_draw(key, ST_HT, 0, a, j, 0);
-                double x = ns_pow10m1(kde_sample(A.m.kde[NS_KDE_HT], w));
-                if (x >= 0) { remainder = (int64_t)x; break; }
-            }
-            for (j = 0; j < NS_KDE_RETRY; ++j) {
-                u32x4 w = ns_draw(key, ST_RATIO, 0, a, j, 0);
-                double x = kde_sample(A.m.kde[NS_KDE_RATIO], w);
-                if (0 <= x && x <= 1) { ratio = x; break; }
-            }
-            if (j == NS_KDE_RETRY) ratio = 0.5;
-        }
-        u32x4 ws = ns_draw(key, ST_STRAND, 0, a, 0, 0);
-        const bool reversed = u32_to_p(ws.x) > A.m.strandness_rate;                  // S:1312, S:1524-1525
-        if (!ok) { ++epoch; fails = 0; continue; }
+    rd.rec_off = 0; rd.piece_off = piece_off; rd.n_pieces = (uint16_t)n_pieces;
+    rd.reversed = (u32_to_p(ws.x) > A.m.strandness_rate) ? 1 : 0;                       // S:1312, S:1524-1525
+    rd.flags = ok ? 1 : 3;                      // bit0: not generated yet, bit1: no valid length draw in this epoch
+    rd.head = 0; rd.tail = 0;
+    if (remainder != 0) {                                                               // S:1377-1382
+        rd.head = (uint32_t)(int64_t)rint((double)remainder * ratio);
+        rd.tail = (uint32_t)remainder - rd.head;
+    }
+    rd.seq_len = 0; rd.attempts = a;
+    A.reads[r] = rd;
+    if (a == 0) {
+        A.ev_cap[r] = cap;
+        A.sort_key[r] = work > 0xffffffffull ? 0xffffffffu : (uint32_t)work;
+        A.sort_idx[r] = (uint32_t)r;
+    }
+}
 
-        // ---- error lists (S:1355-1365, S:1501) ----
-        EvSink sink; sink.ev = ev_base; sink.cap = ev_cap; sink.n = 0; sink.shift = 0; sink.last_ins_len = 0; sink.overflow = false;
-        int64_t total = remainder;
-        uint32_t evn = 0;
-        for (uint32_t pi = 0; pi < n_pieces; ++pi) {
-            const bool is_gap = (kind == NS_KIND_UNALIGNED) || (pi & 1);
-            const uint32_t sid = is_gap ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
-            int64_t mlen;
-            if (kind == NS_KIND_UNALIGNED) mlen = unaligned_length(A.m, prm, key, a);
-            else if (is_gap) mlen = gap_length(A.m, key, pi >> 1, epoch);
-            else seg_length(A.m, prm, key, pi >> 1, epoch, mlen);
-            sink.ev = ev_base + evn; sink.cap = ev_cap > evn ? ev_cap - evn : 0; sink.n = 0; sink.shift = 0;
-            EList e;
-            if (kind == NS_KIND_PERFECT) { e.l_new = e.middle_ref = mlen; }
-            else if (is_gap) e = dev_unaligned_error_list(A.m, mlen, key, sid, a, sink);
-            else e = dev_error_list(A.m, mlen, key, sid, a, sink);
-            ns_piece p;
-            p.ref_gpos = 0; p.ev_off = A.ev_off[r] + evn; p.chrom = 0; p.pos = 0;
-            p.ref_len = (uint32_t)(e.middle_ref < 0 ? 0 : e.middle_ref);
-            p.out_len = (uint32_t)((e.middle_ref < 0 ? 0 : e.middle_ref) + sink.shift);
-            p.n_ev = sink.n; p.kind = is_gap ? 1u : 0u;
-            pc[pi] = p;
-            evn += sink.n;
-            if (!is_gap) total += e.l_new;                                           // S:1362
-            if (kind == NS_KIND_UNALIGNED) total = e.middle_ref;                     // S:1503
-        }
-        if (sink.overflow) { overflow = true; break; }
-        if (total < prm.min_len || total > prm.max_len) {                            // S:1367-1368, S:1503-1504
-            if (kind == NS_KIND_UNALIGNED) continue;
-            if (++fails >= NS_EPOCH_FAILS) { ++epoch; fails = 0; }
-            continue;
-        }
-        int64_t head = 0, tail = 0;                                                  // S:1377-1382
-        if (kind == NS_KIND_ALIGNED && remainder != 0) {
-            head = (int64_t)rint((double)remainder * ratio);
-            tail = remainder - head;
-        }
-        // ---- positions (S:1388-1389, 1510, 1557) ----
-        bool pos_ok = true;
-        int64_t seq_len = head + tail;
-        uint64_t ref_bases = 0;
-        for (uint32_t pi = 0; pi < n_pieces; ++pi) {
-            ns_piece p = pc[pi];
-            const uint32_t sid = p.kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
-            uint32_t chrom = 0; uint64_t pos = 0;
-            if (p.kind && kind == NS_KIND_ALIGNED && gap_length(A.m, key, pi >> 1, epoch) == 0) {    // S:1553-1554
-                p.ref_len = 0; p.out_len = 0; p.n_ev = 0;
-            } else if (!extract_pos(A.ref, p.ref_len, key, sid, a, chrom, pos)) { pos_ok = false; break; }
-            p.chrom = chrom; p.pos = (uint32_t)pos; p.ref_gpos = A.ref.chrom_off[chrom] + pos;
-            pc[pi] = p;
-            seq_len += p.out_len;
-            ref_bases += p.ref_len;
-        }
-        if (!pos_ok) { ++epoch; fails = 0; continue; }
-        if (seq_len < prm.min_len || seq_len > prm.max_len) { ++epoch; fails = 0; continue; }       // S:1429-1430, S:1518-1519
+// ---------------------------------------------------------------------------------------------------------
+// k_chain: one thread per read: the error lists (S:1355-1365, S:1501), the acceptance tests (S:1367, S:1429),
+// the start positions (S:1388-1389) and the record / error-log sizes.  Reads are visited in order of
+// descending length (A.list) so that the 64 chains of a wavefront have similar trip counts; the chain tables
+// live in LDS when they fit.  A rejected read is queued for the next pass (attempt a+1).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
 
-        // ---- accepted ----
-        rd.reversed = reversed ? 1 : 0; rd.flags = 0;
-        rd.head = (uint32_t)head; rd.tail = (uint32_t)tail; rd.seq_len = (uint32_t)seq_len; rd.attempts = a;
-        // name length (S:1390-1402, 1332-1343, 1529-1534)
-        uint32_t nl = 0; bool first = true;
-        for (uint32_t pi = 0; pi < n_pieces; ++pi) {
-            ns_piece p = pc[pi];
-            if (p.kind && kind == NS_KIND_ALIGNED) continue;
-            if (!first) nl += 2;            // ';' in the position list and ';' in the length list
-            first = false;
-            nl += (A.ref.name_off[p.chrom + 1] - A.ref.name_off[p.chrom] - 1) + 1 + dec_digits(p.pos) + dec_digits(p.ref_len);
-        }
-        nl += (kind == NS_KIND_ALIGNED ? 9u : kind == NS_KIND_PERFECT ? 9u : 11u) + dec_digits(prm.first_read + r);
-        if (kind == NS_KIND_ALIGNED && nseg > 1) nl += 9;
-        nl += 2 /*_F*/ + 1 + dec_digits((uint64_t)head) + 1 + 1 + dec_digits((uint64_t)tail);
-        name_len = nl;
-        if (prm.emit_errlog) {
+template <bool LDS_TABLES>
+__global__ void __launch_bounds__(256) k_chain(GenArgs A) {
+    extern __shared__ uint64_t lds_tbl[];
+    Tabs T;
+    if (LDS_TABLES) {
+        for (uint32_t i = threadIdx.x; i < A.m.ct.n_words; i += blockDim.x) lds_tbl[i] = A.m.chain_blob[i];
+        __syncthreads();
+        T.w = lds_tbl;
+    } else T.w = A.m.chain_blob;
+    const ChainTab &ct = A.m.ct;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const ns_params &prm = A.prm;
+    unsigned long long st_over = 0, st_bases = 0, st_ref = 0, st_ev = 0;
+    if (tid < A.list_n) {
+        const uint64_t r = A.list[tid];
+        const int kind = (int)prm.kind;
+        const ns_key key = make_key(prm, r);
+        const uint32_t a = A.attempt;
+        ns_read rd = A.reads[r];
+        const uint32_t n_pieces = rd.n_pieces;
+        ns_piece *pc = A.pieces + rd.piece_off;
+        uint32_t epoch = A.rstate[r] & 0xffffu, fails = A.rstate[r] >> 16;
+        bool accepted = false, overflow = false;
+        do {
+            if (rd.flags & 2) { ++epoch; fails = 0; break; }          // no valid length draw
+            const uint64_t ev_off = A.ev_off[r];
+            const uint64_t ev_cap64 = A.ev_off[r + 1] - ev_off;
+            const uint32_t ev_cap = ev_cap64 > 0xffffffffull ? 0xffffffffu : (uint32_t)ev_cap64;
+            EvSink32 sink; sink.last_ins_len = 0; sink.overflow = false;
+            int64_t total = (int64_t)rd.head + rd.tail;
+            uint32_t evn = 0;
             for (uint32_t pi = 0; pi < n_pieces; ++pi) {
                 ns_piece p = pc[pi];
-                if (p.kind) continue;
-                const ns_event *ev = A.events + p.ev_off;
-                for (uint32_t j = 0; j < p.n_ev; ++j) {
-                    ns_event e = ev[j];
-                    err_len += nl + dec_digits(e.pos) + dec_digits(ns_ev_len(e.info)) + 2u * ns_ev_len(e.info) + 9u;
+                const int32_t m32 = (int32_t)p.ref_len;                // planned length from k_lengths
+                const uint32_t sid = p.kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
+                sink.ev = A.events + ev_off + evn; sink.cap = ev_cap > evn ? ev_cap - evn : 0; sink.n = 0; sink.shift = 0;
+                EList32 e;
+                if (kind == NS_KIND_PERFECT) { e.l_new = e.middle_ref = m32; }
+                else if (p.kind) e = chain_unaligned_error_list(T, ct, m32, key, sid, a, sink);
+                else e = chain_error_list(T, ct, m32, key, sid, a, sink);
+                p.ev_off = ev_off + evn;
+                p.ref_len = (uint32_t)(e.middle_ref < 0 ? 0 : e.middle_ref);
+                p.out_len = (uint32_t)((e.middle_ref < 0 ? 0 : e.middle_ref) + sink.shift);
+                p.n_ev = sink.n;
+                p.chrom = (p.kind && kind == NS_KIND_ALIGNED && m32 == 0) ? 1u : 0u;   // empty gap marker (S:1553-1554)
+                pc[pi] = p;
+                evn += sink.n;
+                if (!p.kind) total += e.l_new;                                           // S:1362
+                if (kind == NS_KIND_UNALIGNED) total = e.middle_ref;                     // S:1503
+            }
+            if (sink.overflow) { overflow = true; break; }
+            if (total < prm.min_len || total > prm.max_len) {                            // S:1367-1368, S:1503-1504
+                if (kind != NS_KIND_UNALIGNED && ++fails >= NS_EPOCH_FAILS) { ++epoch; fails = 0; }
+                break;
+            }
+            // ---- positions (S:1388-1389, 1510, 1557) ----
+            bool pos_ok = true;
+            int64_t seq_len = (int64_t)rd.head + rd.tail;
+            uint64_t ref_bases = 0;
+            for (uint32_t pi = 0; pi < n_pieces; ++pi) {
+                ns_piece p = pc[pi];
+                const uint32_t sid = p.kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
+                uint32_t chrom = 0; uint64_t pos = 0;
+                if (p.chrom == 1u && p.kind) { p.ref_len = 0; p.out_len = 0; p.n_ev = 0; }
+                else if (!extract_pos(A.ref, p.ref_len, key, sid, a, chrom, pos)) { pos_ok = false; break; }
+                p.chrom = chrom; p.pos = (uint32_t)pos; p.ref_gpos = A.ref.chrom_off[chrom] + pos;
+                pc[pi] = p;
+                seq_len += p.out_len;
+                ref_bases += p.ref_len;
+            }
+            if (!pos_ok || seq_len < prm.min_len || seq_len > prm.max_len) { ++epoch; fails = 0; break; }   // S:1429-1430, S:1518-1519
+            // ---- accepted ----
+            rd.flags = 0; rd.seq_len = (uint32_t)seq_len; rd.attempts = a;
+            uint32_t nl = 0; bool first = true;                                          // name length (S:1390-1402, 1332-1343, 1529-1534)
+            for (uint32_t pi = 0; pi < n_pieces; ++pi) {
+                ns_piece p = pc[pi];
+                if (p.kind && kind == NS_KIND_ALIGNED) continue;
+                if (!first) nl += 2;            // ';' in the position list and ';' in the length list
+                first = false;
+                nl += (A.ref.name_off[p.chrom + 1] - A.ref.name_off[p.chrom] - 1) + 1 + dec_digits(p.pos) + dec_digits(p.ref_len);
+            }
+            nl += (kind == NS_KIND_UNALIGNED ? 11u : 9u) + dec_digits(prm.first_read + r);
+            if (kind == NS_KIND_ALIGNED && n_pieces > 1) nl += 9;
+            nl += 2 /*_F*/ + 1 + dec_digits(rd.head) + 1 + 1 + dec_digits(rd.tail);
+            uint64_t err_len = 0;
+            if (prm.emit_errlog) {
+                for (uint32_t pi = 0; pi < n_pieces; ++pi) {
+                    ns_piece p = pc[pi];
+                    if (p.kind) continue;
+                    const ns_event *ev = A.events + p.ev_off;
+                    for (uint32_t j = 0; j < p.n_ev; ++j) {
+                        ns_event e = ev[j];
+                        err_len += nl + dec_digits(e.pos) + dec_digits(ns_ev_len(e.info)) + 2u * ns_ev_len(e.info) + 9u;
+                    }
                 }
             }
+            A.name_len[r] = (uint16_t)nl;
+            A.rec_len[r] = prm.emit_records ? (uint64_t)nl + 2 + (uint64_t)seq_len + 1 + (prm.fastq ? (uint64_t)seq_len + 3 : 0) : 0;
+            A.err_len[r] = err_len;
+            st_bases = (unsigned long long)seq_len; st_ref = ref_bases; st_ev = evn;
+            accepted = true;
+        } while (false);
+        if (overflow) st_over = 1;
+        A.reads[r] = rd;
+        if (!accepted && !overflow) {
+            A.rstate[r] = (epoch & 0xffffu) | fails << 16;
+            A.next_list[atomicAdd(A.next_n, 1u)] = (uint32_t)r;
         }
-        atomicAdd(&A.stats[1], (unsigned long long)seq_len);
-        atomicAdd(&A.stats[2], (unsigned long long)ref_bases);
-        atomicAdd(&A.stats[3], (unsigned long long)evn);
-        done = true;
     }
-    if (overflow) atomicAdd(&A.stats[0], 1ull);
-    else if (!done) atomicAdd(&A.stats[4], 1ull);
-    A.reads[r] = rd;
-    A.name_len[r] = (uint16_t)name_len;
-    uint64_t rl = 0;
-    if (done && prm.emit_records)
-        rl = (uint64_t)name_len + 2 + (uint64_t)rd.seq_len + 1 + (prm.fastq ? (uint64_t)rd.seq_len + 3 : 0);
-    A.rec_len[r] = rl;
-    A.err_len[r] = done ? err_len : 0;
+    // one atomic per wavefront and counter
+    st_over = wave_sum(st_over); st_bases = wave_sum(st_bases); st_ref = wave_sum(st_ref); st_ev = wave_sum(st_ev);
+    if ((threadIdx.x & 63) == 0) {
+        if (st_over) atomicAdd(&A.stats[0], st_over);
+        atomicAdd(&A.stats[1], st_bases); atomicAdd(&A.stats[2], st_ref); atomicAdd(&A.stats[3], st_ev);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -410,6 +447,9 @@ struct ns_ctx {
     // planning + result buffers
     DevBuf n_pieces, piece_off, ev_cap, ev_off, rec_len, rec_off, err_len, err_off, name_len;
     DevBuf reads, pieces, events, records, errlog, stats, scan_tmp;
+    DevBuf sort_key, sort_idx, sort_key_out, order, list_b, rstate;
+    bool lds_tables = false;
+    size_t lds_bytes = 0;
     ns_batch_info last{};
     hipEvent_t evt[16]{};
     bool evt_ok = false;
@@ -485,7 +525,8 @@ void ns_destroy(ns_ctx *ctx) {
     if (ctx->ref_bases_owned) e = hipFree(ctx->ref_bases_owned);
     DevBuf *bufs[] = {&ctx->n_pieces, &ctx->piece_off, &ctx->ev_cap, &ctx->ev_off, &ctx->rec_len, &ctx->rec_off,
                       &ctx->err_len, &ctx->err_off, &ctx->name_len, &ctx->reads, &ctx->pieces, &ctx->events,
-                      &ctx->records, &ctx->errlog, &ctx->stats, &ctx->scan_tmp};
+                      &ctx->records, &ctx->errlog, &ctx->stats, &ctx->scan_tmp, &ctx->sort_key, &ctx->sort_idx,
+                      &ctx->sort_key_out, &ctx->order, &ctx->list_b, &ctx->rstate};
     for (DevBuf *b : bufs)
         if (b->p) e = hipFree(b->p);
     if (ctx->evt_ok)
@@ -607,6 +648,50 @@ int ns_load_model(ns_ctx *ctx, const ns_model_tables *t) {
         }
         double rate = 1.0 / (mean_match_min > 0.5 ? mean_match_min + 0.5 : 1.0);
         ctx->cap_rate = rate * 1.5 > 2.0 ? 2.0 : rate * 1.5;
+
+        // ---- pack the chain tables into one blob of 8-byte words (copied to LDS by k_events) ----
+        std::vector<uint64_t> blob;
+        ChainTab &ct = m.ct;
+        auto put_d = [&](const double *src, size_t n) { uint32_t off = (uint32_t)blob.size(); blob.resize(off + n);
+                                                         memcpy(blob.data() + off, src, n * 8); return off; };
+        auto put_raw = [&](const void *src, size_t bytes) { uint32_t off = (uint32_t)blob.size(); blob.resize(off + (bytes + 7) / 8, 0);
+                                                             memcpy(blob.data() + off, src, bytes); return off; };
+        auto guide = [&](const double *hi, uint32_t n) {          // g[i] = #{s : hi[s] < i/256}: lower bound of the segment of any p >= i/256
+            std::vector<uint16_t> g(256);
+            uint32_t sidx = 0;
+            for (uint32_t i = 0; i < 256; ++i) {
+                double edge = (double)i / 256.0;
+                while (sidx < n && hi[sidx] < edge) ++sidx;
+                g[i] = (uint16_t)(sidx > 65535u ? 65535u : sidx);
+            }
+            return g;
+        };
+        ct.trans = put_d(&t->trans[0][0], 21);
+        ct.mix_w = put_d(t->mix_w, 3);
+        for (int ty = 0; ty < 3; ++ty)
+            for (int c = 0; c < 2; ++c) { ct.mix_n[ty][c] = t->mix_n[ty][c]; ct.mix_cdf[ty][c] = put_d(t->mix_cdf[ty][c], t->mix_n[ty][c]); }
+        ct.fm_n = t->fm_nseg; ct.fm_vlo0 = t->fm_vlo0;
+        ct.fm_hi = put_d(t->fm_hi, t->fm_nseg); ct.fm_vhi = put_d(t->fm_vhi, t->fm_nseg);
+        { auto g = guide(t->fm_hi, t->fm_nseg); ct.fm_guide = put_raw(g.data(), 512); }
+        ct.mm_nbins = t->mm_nbins;
+        std::vector<int32_t> bins(2 * (size_t)t->mm_nbins);
+        for (uint32_t b = 0; b < t->mm_nbins; ++b) {
+            auto clamp = [](int64_t v) { return (int32_t)(v > 0x7fffffff ? 0x7fffffff : v < -0x7fffffff ? -0x7fffffff : v); };
+            bins[2 * b] = clamp(t->mm_bin_lo[b]); bins[2 * b + 1] = clamp(t->mm_bin_hi[b]);
+        }
+        ct.mm_bin = put_raw(bins.data(), bins.size() * 4);
+        ct.mm_seg_off = put_raw(t->mm_seg_off, ((size_t)t->mm_nbins + 1) * 4);
+        ct.mm_hi = put_d(t->mm_hi, nseg); ct.mm_vhi = put_d(t->mm_vhi, nseg); ct.mm_vlo0 = put_d(t->mm_vlo0, t->mm_nbins);
+        std::vector<uint16_t> gall;
+        for (uint32_t b = 0; b < t->mm_nbins; ++b) {
+            auto g = guide(t->mm_hi + t->mm_seg_off[b], t->mm_seg_off[b + 1] - t->mm_seg_off[b]);
+            gall.insert(gall.end(), g.begin(), g.end());
+        }
+        ct.mm_guide = put_raw(gall.data(), gall.size() * 2);
+        ct.n_words = (uint32_t)blob.size();
+        if ((rc = upload(ctx, pool, blob.data(), blob.size(), &m.chain_blob))) return rc;
+        ctx->lds_bytes = blob.size() * 8;
+        ctx->lds_tables = ctx->lds_bytes <= 40 * 1024;     // keep >= 4 workgroups of 256 threads per CU
     }
     for (int k = 0; k < NS_KDE_COUNT; ++k) {
         m.kde[k].n = t->kde[k].n; m.kde[k].bw = t->kde[k].bw;
@@ -666,7 +751,10 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         (rc = ensure(ctx, ctx->rec_len, (n + 1) * 8)) || (rc = ensure(ctx, ctx->rec_off, (n + 1) * 8)) ||
         (rc = ensure(ctx, ctx->err_len, (n + 1) * 8)) || (rc = ensure(ctx, ctx->err_off, (n + 1) * 8)) ||
         (rc = ensure(ctx, ctx->name_len, (n + 1) * 2)) || (rc = ensure(ctx, ctx->reads, n * sizeof(ns_read))) ||
-        (rc = ensure(ctx, ctx->stats, 8 * sizeof(unsigned long long))))
+        (rc = ensure(ctx, ctx->stats, 8 * sizeof(unsigned long long))) ||
+        (rc = ensure(ctx, ctx->sort_key, (n + 1) * 4)) || (rc = ensure(ctx, ctx->sort_idx, (n + 1) * 4)) ||
+        (rc = ensure(ctx, ctx->sort_key_out, (n + 1) * 4)) || (rc = ensure(ctx, ctx->order, (n + 1) * 4)) ||
+        (rc = ensure(ctx, ctx->list_b, (n + 1) * 4)) || (rc = ensure(ctx, ctx->rstate, (n + 1) * 4)))
         return rc;
 
     GenArgs A;
@@ -679,6 +767,10 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     A.err_len = (uint64_t *)ctx->err_len.p; A.err_off = (uint64_t *)ctx->err_off.p;
     A.name_len = (uint16_t *)ctx->name_len.p; A.reads = (ns_read *)ctx->reads.p;
     A.stats = (unsigned long long *)ctx->stats.p;
+    A.sort_key = (uint32_t *)ctx->sort_key.p; A.sort_idx = (uint32_t *)ctx->sort_idx.p;
+    A.rstate = (uint32_t *)ctx->rstate.p;
+    A.next_n = (uint32_t *)((unsigned long long *)ctx->stats.p + 6);
+    uint32_t *list_a = (uint32_t *)ctx->order.p, *list_b = (uint32_t *)ctx->list_b.p;
     const dim3 blk(256);
     const dim3 grid_t((unsigned)((n + 1 + 255) / 256));        // thread-per-read kernels (n+1 for the scan sentinel)
     const dim3 grid_w((unsigned)((n + 3) / 4));                // wave-per-read kernels, 4 waves per block
@@ -686,42 +778,78 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     unsigned long long stats[8];
     uint64_t tot_pieces = 0, tot_cap = 0;
     double cap_rate = ctx->cap_rate;
+    const bool lds = ctx->lds_tables && prm->kind != NS_KIND_PERFECT;
+    float ms = 0;
     HIPCHK(hipEventRecord(ctx->evt[0], st));
-    for (int attempt = 0;; ++attempt) {
+    for (int retry = 0;; ++retry) {
         A.cap_rate = cap_rate;
         HIPCHK(hipMemsetAsync(ctx->stats.p, 0, 8 * sizeof(unsigned long long), st));
+        // ---- plan: pieces, lengths of attempt 0, event capacity, visiting order ----
         HIPCHK(hipEventRecord(ctx->evt[1], st));
-        k_plan<<<grid_t, blk, 0, st>>>(A);
+        k_nseg<<<grid_t, blk, 0, st>>>(A);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(ctx->evt[2], st));
         if ((rc = scan_u32(ctx, A.n_pieces, A.piece_off, n + 1))) return rc;
-        if ((rc = scan_u64(ctx, A.ev_cap, A.ev_off, n + 1))) return rc;
         uint32_t tp32 = 0;
         HIPCHK(hipMemcpyAsync(&tp32, A.piece_off + n, 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(&tot_cap, A.ev_off + n, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         tot_pieces = tp32;
-        if ((rc = ensure(ctx, ctx->pieces, (size_t)tot_pieces * sizeof(ns_piece) + 64)) ||
-            (rc = ensure(ctx, ctx->events, (size_t)tot_cap * sizeof(ns_event) + 64)))
-            return rc;
-        A.pieces = (ns_piece *)ctx->pieces.p; A.events = (ns_event *)ctx->events.p;
-        HIPCHK(hipEventRecord(ctx->evt[3], st));
-        k_events<<<grid_t, blk, 0, st>>>(A);
+        if ((rc = ensure(ctx, ctx->pieces, (size_t)tot_pieces * sizeof(ns_piece) + 64))) return rc;
+        A.pieces = (ns_piece *)ctx->pieces.p;
+        A.list = nullptr; A.list_n = (uint32_t)n; A.attempt = 0;
+        k_lengths<<<grid_t, blk, 0, st>>>(A);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(ctx->evt[4], st));
-        if ((rc = scan_u64(ctx, A.rec_len, A.rec_off, n + 1))) return rc;
-        if (prm->emit_errlog && (rc = scan_u64(ctx, A.err_len, A.err_off, n + 1))) return rc;
-        HIPCHK(hipMemcpyAsync(stats, ctx->stats.p, sizeof stats, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(&info->record_bytes, A.rec_off + n, 8, hipMemcpyDeviceToHost, st));
-        if (prm->emit_errlog) HIPCHK(hipMemcpyAsync(&info->errlog_bytes, A.err_off + n, 8, hipMemcpyDeviceToHost, st));
+        if ((rc = scan_u64(ctx, A.ev_cap, A.ev_off, n + 1))) return rc;
+        {   // visit reads by descending length: the 64 chains of a wavefront then have similar trip counts
+            size_t tmp = 0;
+            HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp, A.sort_key, (uint32_t *)ctx->sort_key_out.p,
+                                                                A.sort_idx, list_a, (int)n, 0, 32, st));
+            if ((rc = ensure(ctx, ctx->scan_tmp, tmp))) return rc;
+            HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(ctx->scan_tmp.p, tmp, A.sort_key, (uint32_t *)ctx->sort_key_out.p,
+                                                                A.sort_idx, list_a, (int)n, 0, 32, st));
+        }
+        HIPCHK(hipEventRecord(ctx->evt[2], st));
+        HIPCHK(hipMemcpyAsync(&tot_cap, A.ev_off + n, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        if ((rc = ensure(ctx, ctx->events, (size_t)tot_cap * sizeof(ns_event) + 64))) return rc;
+        A.events = (ns_event *)ctx->events.p;
+        // ---- passes: pass a generates attempt a of every read still without an accepted attempt ----
+        uint32_t *cur = list_a, *nxt = list_b;
+        uint32_t cur_n = (uint32_t)n;
+        bool overflow = false;
+        double ms_chain = 0;
+        for (uint32_t a = 0;; ++a) {
+            A.list = cur; A.list_n = cur_n; A.attempt = a; A.next_list = nxt;
+            HIPCHK(hipMemsetAsync(A.next_n, 0, 4, st));
+            const dim3 grid_p((cur_n + 255) / 256);
+            if (a > 0) { k_lengths<<<grid_p, blk, 0, st>>>(A); HIPCHK(hipGetLastError()); }
+            HIPCHK(hipEventRecord(ctx->evt[3], st));
+            if (lds) k_chain<true><<<grid_p, blk, ctx->lds_bytes, st>>>(A);
+            else k_chain<false><<<grid_p, blk, 0, st>>>(A);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(ctx->evt[4], st));
+            HIPCHK(hipMemcpyAsync(stats, ctx->stats.p, sizeof stats, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(hipEventElapsedTime(&ms, ctx->evt[3], ctx->evt[4]));
+            ms_chain += ms;
+            if (stats[0]) { overflow = true; break; }
+            cur_n = (uint32_t)(stats[6] & 0xffffffffull);
+            if (!cur_n) break;
+            if (a + 1 >= NS_MAX_ATTEMPT)
+                return fail(ctx, NS_EINVAL, "some reads found no acceptable length within the attempt limit "
+                                            "(min_len/max_len too narrow for this model)");
+            uint32_t *t = cur; cur = nxt; nxt = t;
+        }
+        info->ms_kernel[NS_K_EVENTS] = ms_chain;
+        if (!overflow) break;
         info->n_overflow += stats[0];
-        if (stats[0] == 0) break;
-        if (attempt >= 6) return fail(ctx, NS_ENOMEM, "event capacity overflow persists after 6 retries");
+        if (retry >= 6) return fail(ctx, NS_ENOMEM, "event capacity overflow persists after 6 retries");
         cap_rate *= 2.0; A.cap_gap_mul *= 2;          // rare: re-plan the batch with twice the event capacity
     }
-    if (stats[4]) return fail(ctx, NS_EINVAL, "some reads found no acceptable length within the attempt limit "
-                                              "(min_len/max_len too narrow for this model)");
+    if ((rc = scan_u64(ctx, A.rec_len, A.rec_off, n + 1))) return rc;
+    if (prm->emit_errlog && (rc = scan_u64(ctx, A.err_len, A.err_off, n + 1))) return rc;
+    HIPCHK(hipMemcpyAsync(&info->record_bytes, A.rec_off + n, 8, hipMemcpyDeviceToHost, st));
+    if (prm->emit_errlog) HIPCHK(hipMemcpyAsync(&info->errlog_bytes, A.err_off + n, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     if ((rc = ensure(ctx, ctx->records, (size_t)info->record_bytes + 64)) ||
         (rc = ensure(ctx, ctx->errlog, (size_t)info->errlog_bytes + 64)))
         return rc;
@@ -741,11 +869,9 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     }
     HIPCHK(hipEventRecord(ctx->evt[8], st));
     HIPCHK(hipStreamSynchronize(st));
-    float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, ctx->evt[0], ctx->evt[8])); info->ms_total = ms;
-    HIPCHK(hipEventElapsedTime(&ms, ctx->evt[1], ctx->evt[2])); info->ms_kernel[NS_K_LENGTHS] = ms;
-    HIPCHK(hipEventElapsedTime(&ms, ctx->evt[3], ctx->evt[4])); info->ms_kernel[NS_K_EVENTS] = ms;
-    HIPCHK(hipEventElapsedTime(&ms, ctx->evt[5], ctx->evt[6])); info->ms_kernel[NS_K_SCAN] = ms;   // names/framing
+    HIPCHK(hipEventElapsedTime(&ms, ctx->evt[1], ctx->evt[2])); info->ms_kernel[NS_K_LENGTHS] = ms;   // nseg + lengths + scans + sort
+    HIPCHK(hipEventElapsedTime(&ms, ctx->evt[5], ctx->evt[6])); info->ms_kernel[NS_K_SCAN] = ms;      // names/framing
     HIPCHK(hipEventElapsedTime(&ms, ctx->evt[6], ctx->evt[7])); info->ms_kernel[NS_K_MATERIALISE] = ms;
     HIPCHK(hipEventElapsedTime(&ms, ctx->evt[7], ctx->evt[8])); info->ms_kernel[NS_K_ERRLOG] = ms;
     info->n_reads = n; info->n_pieces = tot_pieces; info->n_events = tot_cap;

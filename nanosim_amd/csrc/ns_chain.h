@@ -1,0 +1,142 @@
+// ns_chain.h — the error-event Markov chains of error_list (S:1833-1916) and unaligned_error_list
+// (S:1784-1830) on tables packed into ONE blob of 8-byte words that k_events copies into LDS.
+// Same arithmetic as the generic functions of ns_device.h (fp64 compares + one fp64 interpolation),
+// but every search starts from a 256-entry guide index instead of a full binary search.
+#pragma once
+#include "ns_device.h"
+
+struct Tabs {
+    const uint64_t *w;
+    __device__ __forceinline__ const double *d(uint32_t off) const { return reinterpret_cast<const double *>(w + off); }
+    __device__ __forceinline__ const uint16_t *h(uint32_t off) const { return reinterpret_cast<const uint16_t *>(w + off); }
+    __device__ __forceinline__ const uint32_t *u(uint32_t off) const { return reinterpret_cast<const uint32_t *>(w + off); }
+    __device__ __forceinline__ const int32_t *i(uint32_t off) const { return reinterpret_cast<const int32_t *>(w + off); }
+};
+
+// first s with p <= hi[s] (guide[u>>24] is a lower bound of s), then the interpolation of S:1847 / S:1897
+__device__ __forceinline__ int32_t ecdf_lookup_g(const double *__restrict__ hi, const double *__restrict__ vhi, uint32_t n,
+                                                 double vlo0, const uint16_t *__restrict__ guide, uint32_t u) {
+    double p = u32_to_p(u);
+    uint32_t s = guide[u >> 24];
+    while (s < n && p > hi[s]) ++s;
+    if (s >= n) { s = n - 1; p = hi[s]; }
+    double plo = s ? hi[s - 1] : 0.0;
+    double vlo = s ? vhi[s - 1] : vlo0;
+    return (int32_t)floor((p - plo) / (hi[s] - plo) * (vhi[s] - vlo) + vlo);
+}
+
+__device__ __forceinline__ int32_t run_length_t(const Tabs &T, const ChainTab &c, int type, uint32_t u_mix, uint32_t u_len) {
+    const int comp = (u32_to_p(u_mix) < T.d(c.mix_w)[type]) ? 0 : 1;        // tmp_rand < weight, mm:44,54
+    const double *cdf = T.d(c.mix_cdf[type][comp]);
+    const uint32_t n = c.mix_n[type][comp];
+    const double p = u32_to_p(u_len);
+    uint32_t v = 0;
+    while (v + 1 < n && p > cdf[v]) ++v;
+    return (int32_t)v + 1;
+}
+
+struct EvSink32 {
+    ns_event *ev;
+    uint32_t cap, n;
+    int32_t shift;
+    uint32_t last_ins_len;
+    bool overflow;
+};
+__device__ __forceinline__ void ev_push32(EvSink32 &s, int32_t pos, uint32_t type, int32_t len) {
+    uint32_t l = len > (int32_t)NS_EV_LEN_MAX ? NS_EV_LEN_MAX : (uint32_t)len;
+    if (s.n < s.cap) {
+        ns_event e; e.pos = (uint32_t)pos; e.info = ns_ev_pack(l, type, s.shift);
+        s.ev[s.n] = e;
+    } else s.overflow = true;
+    if (type == NS_INS) { s.shift += (int32_t)l; s.last_ins_len = l; } else if (type == NS_DEL) s.shift -= (int32_t)l;
+    s.n++;
+}
+
+struct EList32 { int32_t l_new, middle_ref; };
+
+// error_list, S:1833-1916
+__device__ __forceinline__ EList32 chain_error_list(const Tabs &T, const ChainTab &c, int32_t m_ref, const ns_key &key,
+                                                    uint32_t seg, uint32_t attempt, EvSink32 &s) {
+    int32_t l_new = m_ref, pos = 0, middle_ref = m_ref;
+    int state = NS_ST_START;
+    u32x4 w = ns_draw(key, ST_EVENT, seg, attempt, 0, 0);
+    int32_t prev_match = ecdf_lookup_g(T.d(c.fm_hi), T.d(c.fm_vhi), c.fm_n, c.fm_vlo0, T.h(c.fm_guide), w.x);   // S:1843-1850
+    if (prev_match < 2) prev_match = 2;
+    pos += prev_match;
+    uint32_t it = 1;
+    int32_t last_ins_pos = -1;
+    const double *trans = T.d(c.trans);
+    const int32_t *bins = T.i(c.mm_bin);
+    const uint32_t *seg_off = T.u(c.mm_seg_off);
+    while (pos < middle_ref) {                                                                     // S:1858
+        w = ns_draw(key, ST_EVENT, seg, attempt, it, 0);
+        const int error = trans_pick(trans + 3 * state, u32_to_p(w.x));                           // S:1860-1864
+        int32_t step = run_length_t(T, c, error, w.y, w.z);                                       // S:1866-1873
+        if (error == NS_INS) l_new += step; else if (error == NS_DEL) l_new -= step;
+        if (error != NS_INS) {                                                                     // S:1875-1880
+            ev_push32(s, pos, (uint32_t)error, step);
+            pos += step;
+            if (pos >= middle_ref) { l_new += pos - middle_ref; middle_ref = pos; }
+        } else {                                                                                   // S:1881-1882
+            if (last_ins_pos == pos && s.n > 0) { s.n--; s.shift -= (int32_t)s.last_ins_len; }    // dict key collision
+            ev_push32(s, pos, NS_INS, step);
+            last_ins_pos = pos;
+        }
+        state = NS_ST_MIS + error;                                                                 // S:1884
+        uint32_t b = 0;                                                                            // S:1891-1893
+        for (; b < c.mm_nbins; ++b)
+            if (bins[2 * b] <= prev_match && prev_match < bins[2 * b + 1]) break;
+        if (b >= c.mm_nbins) b = c.mm_nbins - 1;
+        const uint32_t o = seg_off[b];
+        step = ecdf_lookup_g(T.d(c.mm_hi) + o, T.d(c.mm_vhi) + o, seg_off[b + 1] - o, T.d(c.mm_vlo0)[b],
+                             T.h(c.mm_guide) + 256 * b, w.w);
+        if (prev_match == 0 && step == 0) step = 1;                                                // S:1900-1901
+        prev_match = step;
+        if (pos + prev_match > middle_ref) { l_new += pos + prev_match - middle_ref; middle_ref = pos + prev_match; }
+        pos += prev_match;
+        if (prev_match == 0) state += 3;                                                           // S:1913-1914
+        else last_ins_pos = -1;
+        ++it;
+    }
+    return EList32{l_new, middle_ref};
+}
+
+// unaligned_error_list, S:1784-1830, with the event rewrite of DESIGN.md §5.3
+__device__ __forceinline__ EList32 chain_unaligned_error_list(const Tabs &T, const ChainTab &c, int32_t m_ref, const ns_key &key,
+                                                              uint32_t seg, uint32_t attempt, EvSink32 &s) {
+    int32_t l_new = m_ref, pos = 0, middle_ref = m_ref;
+    int32_t pend_ins = 0;
+    if (m_ref <= 0) return EList32{l_new, middle_ref};
+    uint32_t it = 0;
+    while (pos < middle_ref) {
+        u32x4 w = ns_draw(key, ST_UEVENT, seg, attempt, it, 0);
+        ++it;
+        const double p = u32_to_p(w.x);
+        const int type = (p < 0.4) ? 3 : (p < 0.7) ? NS_MIS : (p < 0.85) ? NS_INS : NS_DEL;          // S:1787
+        int32_t step = 1;
+        if (type != 3) step = run_length_t(T, c, type, w.y, w.z);
+        if (type == NS_INS) { pend_ins += step; l_new += step; continue; }                          // S:1808-1815
+        if (type == NS_DEL) l_new -= step;
+        const int32_t L = pend_ins; pend_ins = 0;
+        if (type == 3) {
+            if (L) ev_push32(s, pos + 1, NS_INS, L);
+        } else if (type == NS_MIS) {
+            if (!L) ev_push32(s, pos, NS_MIS, step);
+            else {
+                ev_push32(s, pos, NS_MIS, 1);
+                ev_push32(s, pos + 1, NS_INS, L);
+                if (step - 1 > L) ev_push32(s, pos + 1, NS_MIS, step - 1 - L);
+            }
+        } else {
+            if (!L) ev_push32(s, pos, NS_DEL, step);
+            else {
+                int32_t dl = step - L; if (dl < 1) dl = 1;
+                ev_push32(s, pos, NS_DEL, dl);
+                if (L - (step - 1) > 0) ev_push32(s, pos + 1, NS_INS, L - (step - 1));
+            }
+        }
+        pos += step;
+        if (pos > middle_ref) { l_new += pos - middle_ref; middle_ref = pos; }                       // S:1826-1828
+    }
+    return EList32{l_new, middle_ref};
+}

@@ -5,8 +5,20 @@
 #include "ns_rng.h"
 #include "../../include/nanosim_amd.h"
 
+struct ChainTab {                 // offsets are in 8-byte words from the start of the blob
+    uint32_t n_words;
+    uint32_t trans;               // 21 doubles: rows start,mis,ins,del,mis0,ins0,del0 x (a, a+b, 1-c)
+    uint32_t mix_w;               // 3 doubles
+    uint32_t mix_cdf[3][2], mix_n[3][2];
+    uint32_t fm_hi, fm_vhi, fm_n, fm_guide;
+    uint32_t mm_nbins, mm_bin, mm_seg_off, mm_hi, mm_vhi, mm_vlo0, mm_guide;
+    double fm_vlo0;
+};
+
 struct DevModel {
     uint32_t flags;
+    ChainTab ct;                  // packed chain tables (ns_chain.h)
+    const uint64_t *chain_blob;
     uint32_t fm_nseg;
     const double *fm_hi, *fm_vhi;
     double fm_vlo0;

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnanosim_amd.so")
 NS_BUF_RECORDS, NS_BUF_READS, NS_BUF_PIECES, NS_BUF_EVENTS, NS_BUF_ERRLOG = 0, 1, 2, 3, 4
 NS_KIND_ALIGNED, NS_KIND_UNALIGNED, NS_KIND_PERFECT = 0, 1, 2
-KERNEL_NAMES = ("k_plan", "k_events", "k_names", "k_materialise", "k_hp", "k_errlog")
+KERNEL_NAMES = ("plan(k_nseg+k_lengths+scan+sort)", "k_chain", "k_names", "k_materialise", "k_hp", "k_errlog")
 EXPORTS = ("ns_abi_version", "ns_create", "ns_destroy", "ns_last_error", "ns_set_reference",
            "ns_set_reference_device", "ns_load_model", "ns_generate", "ns_copy_out", "ns_device_ptr")
 
