@@ -278,15 +278,19 @@ __device__ __forceinline__ uint32_t iupac_members(uint32_t c, uint32_t &n) {
         default: n = 0; return 0;
     }
 }
+// device form of the reference: upper-case ASCII; IUPAC ambiguity codes (and anything else, as N) carry bit 7
+// so that "needs case_convert's random choice" is one AND per 4 bases
 __device__ __forceinline__ uint8_t normalise_base(uint32_t c) {
+    c &= 0x7fu;
     if (c >= 'a' && c <= 'z') c -= 32;
     uint32_t n;
     if (is_acgt(c)) return (uint8_t)c;
     iupac_members(c, n);
-    return n ? (uint8_t)c : (uint8_t)'N';
+    return (uint8_t)((n ? c : (uint32_t)'N') | 0x80u);
 }
 __device__ __forceinline__ uint8_t resolve_base(uint32_t c, const ns_key &key, uint32_t seg, uint32_t attempt, uint32_t x) {
-    if (is_acgt(c)) return (uint8_t)c;
+    if (!(c & 0x80u)) return (uint8_t)c;
+    c &= 0x7fu;
     uint32_t n, mem = iupac_members(c, n);
     if (!n) return (uint8_t)c;
     u32x4 w = ns_draw(key, ST_IUPAC, seg, attempt, x >> 2, 0);

@@ -19,9 +19,9 @@
 #define T_EV 256u
 #define T_REF 2112u
 
+#define T_GUARD 16u
 struct __align__(16) TileLds {
-    uint8_t ref[T_REF];
-    uint8_t pay[T_OUT];
+    uint8_t ref[T_REF + 2 * T_GUARD];   // [T_GUARD, T_GUARD + T_REF) holds the staged reference bytes
     uint32_t e_out[T_EV + 1];
     uint32_t e_rp[T_EV];
     uint32_t e_pos[T_EV];
@@ -192,19 +192,37 @@ __device__ inline void slow_piece_range(const DevModel &m, const DevRef &ref, co
 }
 
 // ---- LDS-tiled path ---------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t zero_bytes4(uint32_t x) {     // 0x80 in every byte of x that is zero (exact per byte)
-    return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
+// single-wavefront workgroup: DS instructions of one wave execute in issue order, so a compiler-level fence is
+// all that is needed between an LDS write and a cross-lane LDS read (no s_barrier, no vmcnt drain)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
-__device__ __forceinline__ uint32_t nonacgt_mask4(uint32_t w) {
-    // per byte: 0x80 set if the byte is NOT one of A C G T (upper-case ASCII)
-    uint32_t z = zero_bytes4(w ^ 0x41414141u) | zero_bytes4(w ^ 0x43434343u) | zero_bytes4(w ^ 0x47474747u) |
-                 zero_bytes4(w ^ 0x54545454u);
-    return ~z & 0x80808080u;
+
+struct RefPrefetch {          // next tile's reference bytes, in flight in registers while the current tile computes
+    uint64_t off;             // byte offset (16-aligned) in ref.bases of chunk 0; ~0 = nothing prefetched
+    uint4 v0, v1;             // chunks `lane` and `lane + 64`
+};
+__device__ __forceinline__ void ref_prefetch(RefPrefetch &pf, const DevRef &ref, const PieceCtx &pc, uint32_t x0, uint32_t lane,
+                                             uint64_t nbases) {
+    uint64_t g0 = pc.pos + x0;
+    if (g0 >= pc.chrom_len) g0 -= pc.chrom_len;
+    const uint64_t off = (pc.chrom_base + g0) & ~15ull;
+    pf.off = off;
+    const uint64_t o0 = off + 16ull * lane, o1 = o0 + 1024;
+    pf.v0 = make_uint4(0, 0, 0, 0); pf.v1 = make_uint4(0, 0, 0, 0);
+    if (o0 + 16 <= nbases) pf.v0 = *reinterpret_cast<const uint4 *>(ref.bases + o0);
+    if (o1 + 16 <= nbases) pf.v1 = *reinterpret_cast<const uint4 *>(ref.bases + o1);
 }
 
 __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, TileLds &T, const ReadOut &ro, const ns_key &key,
                                          uint32_t a, const PieceCtx &pc, uint32_t pq, uint32_t lane, uint64_t nbases) {
     uint32_t jb = 0;                       // events with out_start < M0
+    // prologue prefetch: first batch of events and the reference bytes of the first tile (x0 = 0)
+    ns_event e_pre; e_pre.pos = 0; e_pre.info = 0;
+    if (lane < pc.n_ev) e_pre = pc.ev[lane];
+    RefPrefetch pf;
+    ref_prefetch(pf, ref, pc, 0, lane, nbases);
     for (uint32_t M0 = 0; M0 < pc.out_len;) {
         uint32_t M1 = min(M0 + T_OUT, pc.out_len);
         // ---- 1. stage events: L[0] = the event in force before M0 (or a synthetic start), L[1..] start in [M0, M1)
@@ -222,8 +240,8 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
         for (uint32_t base = jb;; base += 64) {
             const uint32_t idx = base + lane;
             const bool valid = idx < pc.n_ev;
-            ns_event e; e.pos = 0; e.info = 0;
-            if (valid) e = pc.ev[idx];
+            ns_event e = e_pre;                                   // first batch was prefetched during the previous tile
+            if (base != jb) { e.pos = 0; e.info = 0; if (valid) e = pc.ev[idx]; }
             const uint32_t os = ev_out_start(e);
             const bool take = valid && os < M1;
             const uint32_t cnt = (uint32_t)__popcll(__ballot(take));
@@ -244,16 +262,20 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
         }
         if (lane == 0) T.e_out[ne] = M1;
         T.hist[lane] = 0;
-        __syncthreads();
+        const uint32_t jb_next = jb + ne - 1;
+        e_pre.pos = 0; e_pre.info = 0;
+        if (M1 < pc.out_len && jb_next + lane < pc.n_ev) e_pre = pc.ev[jb_next + lane];   // prefetch for the next tile
+        wave_sync();
 
         // ---- 2. reference span of the tile
         const uint32_t os0 = T.e_out[0], pl0 = T.e_pl[0], rp0 = T.e_rp[0], ty0 = T.e_ty[0], pos0 = T.e_pos[0];
         const uint32_t d0 = M0 - os0;
         const uint32_t x0 = d0 < pl0 ? (ty0 == NS_MIS ? pos0 + d0 : rp0) : rp0 + (d0 - pl0);
-        const uint32_t osl = T.e_out[ne - 1], pll = T.e_pl[ne - 1], rpl = T.e_rp[ne - 1];
+        const uint32_t osl = T.e_out[ne - 1], pll = T.e_pl[ne - 1], rpl = T.e_rp[ne - 1], tyl = T.e_ty[ne - 1], posl = T.e_pos[ne - 1];
         const uint32_t dl = M1 - osl;
         uint32_t x1 = dl <= pll ? rpl : rpl + (dl - pll);
         if (x1 < x0) x1 = x0;
+        const uint32_t x0_next = dl < pll ? (tyl == NS_MIS ? posl + dl : rpl) : rpl + (dl - pll);   // x0 of the tile starting at M1
         uint64_t g0 = pc.pos + x0;
         bool fast = true;
         if (g0 >= pc.chrom_len) g0 -= pc.chrom_len;                 // whole tile beyond the origin of a circular chromosome
@@ -262,46 +284,101 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
         const uint32_t lead = (uint32_t)(gaddr & 15u);
         const uint32_t need = lead + (x1 - x0);
         if (need > T_REF) fast = false;
+        const RefPrefetch cur = pf;                                 // bytes for THIS tile (issued one tile ago)
+        if (M1 < pc.out_len) ref_prefetch(pf, ref, pc, x0_next, lane, nbases);
         if (!fast) {
             slow_piece_range(m, ref, ro, key, a, pc, pq, M0, M1, lane);
-            jb += ne - 1; M0 = M1;
-            __syncthreads();
+            jb = jb_next; M0 = M1;
+            wave_sync();
             continue;
         }
-        const uint8_t *src = ref.bases + (gaddr - lead);
         const uint64_t src_off = gaddr - lead;
-        for (uint32_t c = lane * 16; c < need; c += 64 * 16) {
+        const uint8_t *src = ref.bases + src_off;
+        for (uint32_t c = lane * 16, it = 0; c < need; c += 64 * 16, ++it) {
             uint32_t w[4];
-            if (src_off + c + 16 <= nbases) {
+            if (it < 2 && cur.off == src_off && src_off + c + 16 <= nbases) {
+                const uint4 v = it == 0 ? cur.v0 : cur.v1;
+                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+            } else if (src_off + c + 16 <= nbases) {
                 uint4 v = *reinterpret_cast<const uint4 *>(src + c);
                 w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
             } else {
                 w[0] = w[1] = w[2] = w[3] = 0x41414141u;
-                for (uint32_t b = 0; b < 16 && src_off + c + b < nbases; ++b) {
+                for (uint32_t b = 0; b < 16 && src_off + c + b < nbases; ++b)
                     w[b >> 2] = (w[b >> 2] & ~(0xffu << (8 * (b & 3)))) | (uint32_t)src[c + b] << (8 * (b & 3));
-                }
             }
-            const uint32_t bad = nonacgt_mask4(w[0]) | nonacgt_mask4(w[1]) | nonacgt_mask4(w[2]) | nonacgt_mask4(w[3]);
-            if (bad) {                                           // case_convert (S:743-755), keyed by segment position
+            if ((w[0] | w[1] | w[2] | w[3]) & 0x80808080u) {     // case_convert (S:743-755), keyed by segment position
 #pragma unroll
                 for (uint32_t k = 0; k < 4; ++k) {
-                    if (!nonacgt_mask4(w[k])) continue;
+                    if (!(w[k] & 0x80808080u)) continue;
                     for (uint32_t b = 0; b < 4; ++b) {
                         uint32_t ch = (w[k] >> (8 * b)) & 0xff;
+                        if (!(ch & 0x80u)) continue;
                         int64_t x = (int64_t)x0 + (int64_t)(c + 4 * k + b) - (int64_t)lead;
-                        if (!is_acgt(ch) && x >= 0 && x < (int64_t)pc.ref_len) {
-                            uint32_t r = resolve_base(ch, key, pc.sid, a, (uint32_t)x);
-                            w[k] = (w[k] & ~(0xffu << (8 * b))) | r << (8 * b);
-                        }
+                        uint32_t r = (x >= 0 && x < (int64_t)pc.ref_len) ? resolve_base(ch, key, pc.sid, a, (uint32_t)x) : (uint32_t)'A';
+                        w[k] = (w[k] & ~(0xffu << (8 * b))) | r << (8 * b);
                     }
                 }
             }
-            *reinterpret_cast<uint4 *>(&T.ref[c]) = make_uint4(w[0], w[1], w[2], w[3]);
+            *reinterpret_cast<uint4 *>(&T.ref[T_GUARD + c]) = make_uint4(w[0], w[1], w[2], w[3]);
         }
-        __syncthreads();
-        const uint32_t rbase = lead - x0;                         // T.ref index of segment position x is rbase + x
+        for (uint32_t k = 1 + lane; k < ne; k += 64) {            // histogram: first 16-byte chunk starting at/after the event
+            uint32_t c = (T.e_out[k] - M0 + 15) >> 4;
+            if (c < 64) atomicAdd(&T.hist[c], 1u);
+        }
+        wave_sync();
+        const uint32_t rbase = T_GUARD + lead - x0;               // T.ref index of segment position x is rbase + x
 
-        // ---- 3. phase B: payload letters, one lane per event
+        // ---- 3. phase A: one lane per 16 output bytes; per event sub-run one funnel-shifted 16-byte LDS fetch
+        uint32_t incl = T.hist[lane];
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t v = __shfl_up(incl, off);
+            if ((int)lane >= off) incl += v;
+        }
+        const uint32_t c0 = M0 + 16 * lane;
+        if (c0 < M1) {
+            const uint32_t count = min(16u, M1 - c0);
+            const uint32_t c_end = c0 + count;
+            uint32_t k = incl;                                     // event in force at the chunk's first byte
+            uint32_t os = T.e_out[k], pl = T.e_pl[k], rp = T.e_rp[k], nxt = T.e_out[k + 1];
+            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+            uint32_t mcur = c0;
+            for (;;) {
+                const uint32_t cs = max(mcur, os + pl);            // first copied byte under event k
+                const uint32_t seg_end = min(nxt, c_end);
+                if (cs < seg_end) {
+                    const uint32_t src = rbase + rp + c0 - (os + pl);     // LDS index of chunk byte 0 under this event's shift
+                    const uint32_t al = src & ~15u, sh = src & 15u;
+                    const uint4 va = *reinterpret_cast<const uint4 *>(&T.ref[al]);
+                    const uint4 vb = *reinterpret_cast<const uint4 *>(&T.ref[al + 16]);
+                    uint32_t w0 = va.x, w1 = va.y, w2 = va.z, w3 = va.w, w4 = vb.x, w5 = vb.y;
+                    if (sh & 8u) { w0 = w2; w1 = w3; w2 = w4; w3 = w5; w4 = vb.z; w5 = vb.w; }
+                    if (sh & 4u) { w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; }
+                    const uint32_t bs = sh & 3u;
+                    const uint32_t f0 = __builtin_amdgcn_alignbyte(w1, w0, bs), f1 = __builtin_amdgcn_alignbyte(w2, w1, bs);
+                    const uint32_t f2 = __builtin_amdgcn_alignbyte(w3, w2, bs), f3 = __builtin_amdgcn_alignbyte(w4, w3, bs);
+                    const int i0 = (int)(cs - c0);                 // merge bytes [i0, 16): later events overwrite their own part
+                    const uint32_t m0 = i0 <= 0 ? 0xffffffffu : i0 >= 4 ? 0u : 0xffffffffu << (8 * i0);
+                    const uint32_t m1 = i0 <= 4 ? 0xffffffffu : i0 >= 8 ? 0u : 0xffffffffu << (8 * (i0 - 4));
+                    const uint32_t m2 = i0 <= 8 ? 0xffffffffu : i0 >= 12 ? 0u : 0xffffffffu << (8 * (i0 - 8));
+                    const uint32_t m3 = i0 <= 12 ? 0xffffffffu : 0xffffffffu << (8 * (i0 - 12));
+                    r0 = (f0 & m0) | (r0 & ~m0); r1 = (f1 & m1) | (r1 & ~m1);
+                    r2 = (f2 & m2) | (r2 & ~m2); r3 = (f3 & m3) | (r3 & ~m3);
+                }
+                if (nxt >= c_end) break;
+                mcur = nxt; ++k; os = nxt; pl = T.e_pl[k]; rp = T.e_rp[k]; nxt = T.e_out[k + 1];
+            }
+            const uint64_t lo = (uint64_t)r0 | (uint64_t)r1 << 32, hi = (uint64_t)r2 | (uint64_t)r3 << 32;
+            uint64_t qlo = 0, qhi = 0;
+            if (ro.qual) {                                         // match-class (or unmapped) qualities; payload bytes are redone below
+                QualDraw qd; qd.blk = 0xffffffffu;
+                const int cls = pc.kind ? NS_Q_UNMAPPED : NS_Q_MATCH;
+                for (uint32_t i = 0; i < count; ++i) put_byte(qlo, qhi, i, qual_draw(qd, m, cls, key, ST_QUAL, pc.sid, a, c0 + i));
+            }
+            store_chunk(ro, pq + c0, count, lo, hi, qlo, qhi);
+        }
+
+        // ---- 4. phase B: one lane per event: substituted / inserted letters (S:1965-1995) stored over the copy
         for (uint32_t k = lane; k < ne; k += 64) {
             const uint32_t pl = T.e_pl[k];
             if (!pl) continue;
@@ -309,8 +386,9 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             const uint32_t i_lo = os < M0 ? M0 - os : 0;
             const uint32_t i_hi = min(pl, M1 - os);
             uint32_t blk = 0xffffffffu; u32x4 w;
+            QualDraw qd; qd.blk = 0xffffffffu;
             for (uint32_t i = i_lo; i < i_hi; ++i) {
-                uint8_t b;
+                uint32_t b;
                 if (ty == NS_INS) {
                     if ((i >> 6) != blk) { blk = i >> 6; w = ns_draw(key, ST_INS, pc.sid, a, ep, blk); }
                     b = bases_atcg((ns_word(w, (i >> 4) & 3) >> (2 * (i & 15))) & 3u);
@@ -319,41 +397,16 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
                     uint32_t h = (ns_word(w, (i & 7) >> 1) >> (16 * (i & 1))) & 0xffffu;
                     b = mis_from_h(T.ref[rbase + ep + i], h);
                 }
-                T.pay[os + i - M0] = b;
+                const uint32_t q = pq + os + i;
+                const uint32_t o = ro.reversed ? ro.seq_len - 1 - q : q;
+                ro.seq[o] = ro.reversed ? complement(b) : (uint8_t)b;
+                if (ro.qual) {
+                    const int cls = pc.kind ? NS_Q_UNMAPPED : (ty == NS_MIS ? NS_Q_MIS : NS_Q_INS);
+                    ro.qual[o] = (uint8_t)(qual_draw(qd, m, cls, key, ST_QUAL, pc.sid, a, os + i) + 33);
+                }
             }
-            // histogram for phase A: first 16-byte chunk whose start is >= the event's out_start
         }
-        for (uint32_t k = 1 + lane; k < ne; k += 64) {
-            uint32_t c = (T.e_out[k] - M0 + 15) >> 4;
-            if (c < 64) atomicAdd(&T.hist[c], 1u);
-        }
-        __syncthreads();
-
-        // ---- 4. phase A: one lane per 16 output bytes
-        uint32_t incl = T.hist[lane];
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t v = __shfl_up(incl, off);
-            if ((int)lane >= off) incl += v;
-        }
-        uint32_t mm = M0 + 16 * lane;
-        if (mm < M1) {
-            const uint32_t count = min(16u, M1 - mm);
-            uint32_t k = incl;                                     // event in force at the chunk's first byte
-            uint32_t os = T.e_out[k], pl = T.e_pl[k], rp = T.e_rp[k], ty = T.e_ty[k], nxt = T.e_out[k + 1];
-            uint64_t lo = 0, hi = 0, qlo = 0, qhi = 0;
-            QualDraw qd; qd.blk = 0xffffffffu;
-            for (uint32_t i = 0; i < count; ++i, ++mm) {
-                while (mm >= nxt) { ++k; os = nxt; pl = T.e_pl[k]; rp = T.e_rp[k]; ty = T.e_ty[k]; nxt = T.e_out[k + 1]; }
-                const uint32_t d = mm - os;
-                uint32_t b; int cls;
-                if (d < pl) { b = T.pay[mm - M0]; cls = (ty == NS_MIS) ? NS_Q_MIS : NS_Q_INS; }
-                else { b = T.ref[rbase + rp + (d - pl)]; cls = NS_Q_MATCH; }
-                put_byte(lo, hi, i, b);
-                if (ro.qual) put_byte(qlo, qhi, i, qual_draw(qd, m, pc.kind ? NS_Q_UNMAPPED : cls, key, ST_QUAL, pc.sid, a, mm));
-            }
-            store_chunk(ro, pq + M0 + 16 * lane, count, lo, hi, qlo, qhi);
-        }
-        jb += ne - 1; M0 = M1;
-        __syncthreads();
+        jb = jb_next; M0 = M1;
+        wave_sync();
     }
 }
