@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -323,7 +324,7 @@ __global__ void __launch_bounds__(256) k_names(GenArgs A) {
 // ---------------------------------------------------------------------------------------------------------
 // k_materialise: one read per wavefront (64-thread workgroup); see ns_materialise.h
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_materialise(GenArgs A, uint64_t nbases) {
+__global__ void __launch_bounds__(64) k_materialise(GenArgs A, uint64_t nbases, uint32_t dbg) {
     __shared__ TileLds T;
     const uint32_t lane = threadIdx.x;
     const uint64_t r = blockIdx.x;
@@ -335,14 +336,15 @@ __global__ void __launch_bounds__(64) k_materialise(GenArgs A, uint64_t nbases) 
     ro.seq = A.records + rd.rec_off + A.name_len[r] + 2;
     ro.qual = A.prm.fastq ? ro.seq + rd.seq_len + 3 : nullptr;
     ro.seq_len = rd.seq_len; ro.reversed = rd.reversed != 0;
-    emit_random_region(A.m, ro, key, a, ST_HEAD, 0, rd.head, 0, lane);                                   // S:1426
+    if (!(dbg & 8)) emit_random_region(A.m, ro, key, a, ST_HEAD, 0, rd.head, 0, lane);                                   // S:1426
     uint32_t q = rd.head;
     for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
         const PieceCtx pc = load_piece(A.events, A.ref, A.pieces[rd.piece_off + pi], pi);
-        materialise_piece(A.m, A.ref, T, ro, key, a, pc, q, lane, nbases);
+        materialise_piece(A.m, A.ref, T, ro, key, a, pc, q, lane, nbases, dbg);
+        if (!(dbg & 2)) payload_pass(A.m, A.ref, ro, key, a, pc, q, lane);
         q += pc.out_len;
     }
-    emit_random_region(A.m, ro, key, a, ST_TAIL, rd.seq_len - rd.tail, rd.tail, rd.head, lane);          // S:1427
+    if (!(dbg & 8)) emit_random_region(A.m, ro, key, a, ST_TAIL, rd.seq_len - rd.tail, rd.tail, rd.head, lane);          // S:1427
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -386,12 +388,12 @@ __global__ void __launch_bounds__(256) k_errlog(GenArgs A) {
                 *q++ = '\t'; q = put_dec(q, len); *q++ = '\t';
                 uint8_t *q2 = q + len + 1;
                 for (uint32_t i = 0; i < len; ++i) {
-                    if (ty == NS_INS) { q[i] = '-'; q2[i] = ins_letter(key, pc.sid, a, e.pos, i); }
+                    if (ty == NS_INS) { q[i] = '-'; q2[i] = ins_letter(key, pc.sid, a, p.n_ev - 1 - k, i); }
                     else {
                         uint32_t x = e.pos + i;
                         uint8_t cur = resolve_base(ref_base_at(A.ref, pc, x), key, pc.sid, a, x);
                         q[i] = cur;
-                        q2[i] = (ty == NS_MIS) ? mis_letter(cur, key, pc.sid, a, e.pos, i) : (uint8_t)'-';
+                        q2[i] = (ty == NS_MIS) ? mis_letter(cur, key, pc.sid, a, p.n_ev - 1 - k, i) : (uint8_t)'-';
                     }
                 }
                 q[len] = '\t';
@@ -444,6 +446,7 @@ struct ns_ctx {
     std::vector<void *> ref_allocs;
     double cap_rate = 0.1;
     uint64_t ref_nbases = 0;
+    uint32_t dbg = 0;          // NS_DEBUG_SKIP: phase-ablation bits for profiling only (results are wrong when set)
     // planning + result buffers
     DevBuf n_pieces, piece_off, ev_cap, ev_off, rec_len, rec_off, err_len, err_off, name_len;
     DevBuf reads, pieces, events, records, errlog, stats, scan_tmp;
@@ -507,6 +510,7 @@ int ns_create(int device, ns_ctx **out) {
     for (auto &e : ctx->evt)
         if (hipEventCreate(&e) != hipSuccess) { delete ctx; return NS_EHIP; }
     ctx->evt_ok = true;
+    if (const char *d = getenv("NS_DEBUG_SKIP")) ctx->dbg = (uint32_t)atoi(d);
     *out = ctx;
     return NS_OK;
 }
@@ -859,7 +863,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->evt[6], st));
     if (prm->emit_records) {
-        k_materialise<<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->ref_nbases);
+        k_materialise<<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->ref_nbases, ctx->dbg);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ctx->evt[7], st));

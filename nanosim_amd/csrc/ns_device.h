@@ -297,23 +297,33 @@ __device__ __forceinline__ uint8_t resolve_base(uint32_t c, const ns_key &key, u
     uint32_t j = (uint32_t)(((uint64_t)ns_word(w, x & 3) * n) >> 32);
     return (uint8_t)(mem >> (8 * j));
 }
-// S:1968-1972: 16-bit field i of the block keyed by the event position (8 letters per Philox block)
-__device__ __forceinline__ uint8_t mis_from_h(uint32_t cur, uint32_t h) {
-    uint32_t j = (h * 3u) >> 16;
+// Payload letters of event j of a piece: one 32-bit word per event —
+//   word(j, 0) = Philox(ST_SUB, seg, attempt, idx = j>>2).w[j&3]           (letters 0..15)
+//   word(j, c) = Philox(ST_INS, seg, attempt, idx = j, sub = c>>2).w[c&3]  (letters 16c..16c+15, c >= 1)
+// insertion letter i = 2-bit field (i&15); substitution letter i = (i&15)-th base-3 digit of the word as a fraction.
+__device__ __forceinline__ uint32_t payload_word(const ns_key &key, uint32_t seg, uint32_t attempt, uint32_t j, uint32_t c) {
+    if (c == 0) { u32x4 w = ns_draw(key, ST_SUB, seg, attempt, j >> 2, 0); return ns_word(w, j & 3); }
+    u32x4 w = ns_draw(key, ST_INS, seg, attempt, j, c >> 2);
+    return ns_word(w, c & 3);
+}
+__device__ __forceinline__ uint8_t mis_from_digit(uint32_t cur, uint32_t dg) {      // S:1968-1972
     int rc = base_rank(cur);
-    uint32_t rk = j + ((int)j >= rc ? 1u : 0u);
-    if (rc < 0) rk = j;
+    uint32_t rk = dg + ((int)dg >= rc ? 1u : 0u);
+    if (rc < 0) rk = dg;
     return bases_atcg(rk);
 }
-__device__ __forceinline__ uint8_t mis_letter(uint32_t cur, const ns_key &key, uint32_t seg, uint32_t attempt, uint32_t x, uint32_t i) {
-    u32x4 w = ns_draw(key, ST_SUB, seg, attempt, x, i >> 3);
-    uint32_t h = (ns_word(w, (i & 7) >> 1) >> (16 * (i & 1))) & 0xffffu;
-    return mis_from_h(cur, h);
+__device__ __forceinline__ uint32_t next_digit3(uint32_t &frac) {
+    uint64_t p = (uint64_t)frac * 3u;
+    frac = (uint32_t)p;
+    return (uint32_t)(p >> 32);
 }
-// S:1990: 2-bit field i of the block keyed by the event position (64 letters per Philox block)
-__device__ __forceinline__ uint8_t ins_letter(const ns_key &key, uint32_t seg, uint32_t attempt, uint32_t x, uint32_t i) {
-    u32x4 w = ns_draw(key, ST_INS, seg, attempt, x, i >> 6);
-    return bases_atcg((ns_word(w, (i >> 4) & 3) >> (2 * (i & 15))) & 3u);
+__device__ __forceinline__ uint8_t mis_letter(uint32_t cur, const ns_key &key, uint32_t seg, uint32_t attempt, uint32_t j, uint32_t i) {
+    uint32_t frac = payload_word(key, seg, attempt, j, i >> 4), dg = 0;
+    for (uint32_t t = 0; t <= (i & 15); ++t) dg = next_digit3(frac);
+    return mis_from_digit(cur, dg);
+}
+__device__ __forceinline__ uint8_t ins_letter(const ns_key &key, uint32_t seg, uint32_t attempt, uint32_t j, uint32_t i) {   // S:1990
+    return bases_atcg((payload_word(key, seg, attempt, j, i >> 4) >> (2 * (i & 15))) & 3u);
 }
 __device__ __forceinline__ uint8_t ht_letter(const ns_key &key, uint32_t stream, uint32_t attempt, uint32_t i) {             // S:1426-1427
     u32x4 w = ns_draw(key, stream, 0, attempt, i >> 6, 0);

@@ -154,10 +154,10 @@ __device__ __forceinline__ uint8_t piece_byte(const DevRef &ref, const PieceCtx 
             cls = NS_Q_MIS;
             uint32_t x = c.cur_pos + d;
             uint8_t cur = resolve_base(ref_base_at(ref, pc, x), key, pc.sid, attempt, x);
-            return mis_letter(cur, key, pc.sid, attempt, c.cur_pos, d);
+            return mis_letter(cur, key, pc.sid, attempt, c.j - 1, d);
         }
         cls = NS_Q_INS;                                                              // S:1986-1995
-        return ins_letter(key, pc.sid, attempt, c.cur_pos, d);
+        return ins_letter(key, pc.sid, attempt, c.j - 1, d);
     }
     cls = NS_Q_MATCH;
     uint32_t x = c.cur_rp + (d - c.cur_pl);
@@ -216,7 +216,7 @@ __device__ __forceinline__ void ref_prefetch(RefPrefetch &pf, const DevRef &ref,
 }
 
 __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, TileLds &T, const ReadOut &ro, const ns_key &key,
-                                         uint32_t a, const PieceCtx &pc, uint32_t pq, uint32_t lane, uint64_t nbases) {
+                                         uint32_t a, const PieceCtx &pc, uint32_t pq, uint32_t lane, uint64_t nbases, uint32_t dbg) {
     uint32_t jb = 0;                       // events with out_start < M0
     // prologue prefetch: first batch of events and the reference bytes of the first tile (x0 = 0)
     ns_event e_pre; e_pre.pos = 0; e_pre.info = 0;
@@ -294,7 +294,7 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
         }
         const uint64_t src_off = gaddr - lead;
         const uint8_t *src = ref.bases + src_off;
-        for (uint32_t c = lane * 16, it = 0; c < need; c += 64 * 16, ++it) {
+        for (uint32_t c = lane * 16, it = 0; c < need && !(dbg & 4); c += 64 * 16, ++it) {
             uint32_t w[4];
             if (it < 2 && cur.off == src_off && src_off + c + 16 <= nbases) {
                 const uint4 v = it == 0 ? cur.v0 : cur.v1;
@@ -336,7 +336,7 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             if ((int)lane >= off) incl += v;
         }
         const uint32_t c0 = M0 + 16 * lane;
-        if (c0 < M1) {
+        if (c0 < M1 && !(dbg & 1)) {
             const uint32_t count = min(16u, M1 - c0);
             const uint32_t c_end = c0 + count;
             uint32_t k = incl;                                     // event in force at the chunk's first byte
@@ -375,27 +375,42 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
                 const int cls = pc.kind ? NS_Q_UNMAPPED : NS_Q_MATCH;
                 for (uint32_t i = 0; i < count; ++i) put_byte(qlo, qhi, i, qual_draw(qd, m, cls, key, ST_QUAL, pc.sid, a, c0 + i));
             }
-            store_chunk(ro, pq + c0, count, lo, hi, qlo, qhi);
+            if (!(dbg & 16)) store_chunk(ro, pq + c0, count, lo, hi, qlo, qhi);
         }
 
-        // ---- 4. phase B: one lane per event: substituted / inserted letters (S:1965-1995) stored over the copy
-        for (uint32_t k = lane; k < ne; k += 64) {
-            const uint32_t pl = T.e_pl[k];
-            if (!pl) continue;
-            const uint32_t os = T.e_out[k], ty = T.e_ty[k], ep = T.e_pos[k];
-            const uint32_t i_lo = os < M0 ? M0 - os : 0;
-            const uint32_t i_hi = min(pl, M1 - os);
-            uint32_t blk = 0xffffffffu; u32x4 w;
-            QualDraw qd; qd.blk = 0xffffffffu;
-            for (uint32_t i = i_lo; i < i_hi; ++i) {
+        jb = jb_next; M0 = M1;
+        wave_sync();
+    }
+}
+
+// ---- payload pass: substituted / inserted letters (mutate_read, S:1965-1995) stored over the copied bases -----
+// Runs after all tiles of the piece.  256 events per iteration: each lane owns 4 consecutive events and ONE Philox
+// block (one word per event).  Stores from one wavefront to the same address complete in program order, so these
+// byte stores land after the 16-byte stores of the copy phase.
+__device__ inline void payload_pass(const DevModel &m, const DevRef &ref, const ReadOut &ro, const ns_key &key, uint32_t a,
+                                    const PieceCtx &pc, uint32_t pq, uint32_t lane) {
+    for (uint32_t base = 0; base < pc.n_ev; base += 256) {
+        const uint32_t j0 = base + 4 * lane;
+        if (j0 >= pc.n_ev) continue;
+        const u32x4 w = ns_draw(key, ST_SUB, pc.sid, a, j0 >> 2, 0);
+        QualDraw qd; qd.blk = 0xffffffffu;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t j = j0 + k;
+            if (j >= pc.n_ev) break;
+            const ns_event e = pc.ev[j];
+            const uint32_t ty = ns_ev_type(e.info), len = ns_ev_len(e.info);
+            if (ty == NS_DEL) continue;
+            const uint32_t os = ev_out_start(e);
+            uint32_t word = ns_word(w, k);
+            for (uint32_t i = 0; i < len; ++i) {
+                if (i && !(i & 15)) word = payload_word(key, pc.sid, a, j, i >> 4);
                 uint32_t b;
-                if (ty == NS_INS) {
-                    if ((i >> 6) != blk) { blk = i >> 6; w = ns_draw(key, ST_INS, pc.sid, a, ep, blk); }
-                    b = bases_atcg((ns_word(w, (i >> 4) & 3) >> (2 * (i & 15))) & 3u);
-                } else {
-                    if ((i >> 3) != blk) { blk = i >> 3; w = ns_draw(key, ST_SUB, pc.sid, a, ep, blk); }
-                    uint32_t h = (ns_word(w, (i & 7) >> 1) >> (16 * (i & 1))) & 0xffffu;
-                    b = mis_from_h(T.ref[rbase + ep + i], h);
+                if (ty == NS_INS) b = bases_atcg((word >> (2 * (i & 15))) & 3u);
+                else {
+                    const uint32_t x = e.pos + i;
+                    const uint32_t cur = resolve_base(ref_base_at(ref, pc, x), key, pc.sid, a, x);
+                    b = mis_from_digit(cur, next_digit3(word));
                 }
                 const uint32_t q = pq + os + i;
                 const uint32_t o = ro.reversed ? ro.seq_len - 1 - q : q;
@@ -406,7 +421,5 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
                 }
             }
         }
-        jb = jb_next; M0 = M1;
-        wave_sync();
     }
 }

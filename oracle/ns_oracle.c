@@ -369,27 +369,36 @@ static uint8_t resolve_base(uint8_t c, nso_draw *d, uint32_t seg, uint32_t attem
     else { uint32_t w[4]; philox_at(d, ST_IUPAC, seg, attempt, (uint32_t)(x >> 2), 0, w); j = (uint32_t)(((uint64_t)w[x & 3] * (uint32_t)n) >> 32); }
     return (uint8_t)mem[j];
 }
-/* S:1968-1972: uniform choice among BASES minus the current base.  Draw: 16-bit field i of the block keyed by
- * the EVENT position x (8 letters per Philox block) */
-static uint8_t mis_letter(uint8_t cur, nso_draw *d, uint32_t seg, uint32_t attempt, uint64_t x, uint32_t i) {
-    uint32_t j;
-    if (d->mode) j = (uint32_t)(tape_u(d) * 3);
+/* Payload letters of event j of a piece: one 32-bit word per event —
+ *   word(j, 0) = Philox(ST_SUB, seg, attempt, idx = j>>2).w[j&3]   (letters 0..15)
+ *   word(j, c) = Philox(ST_INS, seg, attempt, idx = j, sub = c>>2).w[c&3]   (letters 16c..16c+15, c >= 1)
+ * insertion letter i: 2-bit field (i&15) of its word; substitution letter i: the (i&15)-th base-3 digit of the
+ * word read as a fraction (digit = (frac*3)>>32, frac = low 32 bits). */
+static uint32_t payload_word(nso_draw *d, uint32_t seg, uint32_t attempt, uint32_t j, uint32_t c) {
+    uint32_t w[4];
+    if (c == 0) { philox_at(d, ST_SUB, seg, attempt, j >> 2, 0, w); return w[j & 3]; }
+    philox_at(d, ST_INS, seg, attempt, j, c >> 2, w);
+    return w[c & 3];
+}
+/* S:1968-1972: uniform choice among BASES minus the current base */
+static uint8_t mis_letter(uint8_t cur, nso_draw *d, uint32_t seg, uint32_t attempt, uint32_t j, uint32_t i) {
+    uint32_t dg = 0;
+    if (d->mode) dg = (uint32_t)(tape_u(d) * 3);
     else {
-        uint32_t w[4]; philox_at(d, ST_SUB, seg, attempt, (uint32_t)x, i >> 3, w);
-        uint32_t h = (w[(i & 7) >> 1] >> (16 * (i & 1))) & 0xffffu;
-        j = (h * 3u) >> 16;
+        uint32_t frac = payload_word(d, seg, attempt, j, i >> 4);
+        for (uint32_t t = 0; t <= (i & 15); ++t) { uint64_t p = (uint64_t)frac * 3u; dg = (uint32_t)(p >> 32); frac = (uint32_t)p; }
     }
     int rc = base_rank(cur);
-    int rk = (int)j + ((int)j >= rc ? 1 : 0);
-    if (rc < 0) rk = (int)j;                /* cannot happen after resolve_base */
+    int rk = (int)dg + ((int)dg >= rc ? 1 : 0);
+    if (rc < 0) rk = (int)dg;               /* cannot happen after resolve_base */
     return (uint8_t)BASES[rk];
 }
-/* S:1990: 2-bit field i of the block keyed by the event position (64 letters per Philox block) */
-static uint8_t ins_letter(nso_draw *d, uint32_t seg, uint32_t attempt, uint64_t x, uint32_t i) {
-    uint32_t j;
-    if (d->mode) j = (uint32_t)(tape_u(d) * 4);
-    else { uint32_t w[4]; philox_at(d, ST_INS, seg, attempt, (uint32_t)x, i >> 6, w); j = (w[(i >> 4) & 3] >> (2 * (i & 15))) & 3u; }
-    return (uint8_t)BASES[j];
+/* S:1990 */
+static uint8_t ins_letter(nso_draw *d, uint32_t seg, uint32_t attempt, uint32_t j, uint32_t i) {
+    uint32_t v;
+    if (d->mode) v = (uint32_t)(tape_u(d) * 4);
+    else v = (payload_word(d, seg, attempt, j, i >> 4) >> (2 * (i & 15))) & 3u;
+    return (uint8_t)BASES[v];
 }
 static uint8_t ht_letter(nso_draw *d, uint32_t stream, uint32_t attempt, uint32_t i) {             /* S:1426-1427 */
     uint32_t w[4];
@@ -444,7 +453,7 @@ int64_t nso_mutate_read(const uint8_t *seg_in, int64_t ref_len, const ns_event *
                    log[row].ref_off = (uint32_t)tl; }
         if (etype == NS_MIS) {
             uint8_t nb[4096];
-            for (int64_t i = 0; i < len; ++i) nb[i] = mis_letter(seg_in[key + i], d, seg, attempt, (uint64_t)key, (uint32_t)i);
+            for (int64_t i = 0; i < len; ++i) nb[i] = mis_letter(seg_in[key + i], d, seg, attempt, (uint32_t)jj, (uint32_t)i);
             for (int64_t i = len - 1; i >= 0; --i) { --w; out[w] = nb[i]; if (cls) cls[w] = NS_Q_MIS; }
             if (txt) { memcpy(txt + tl, seg_in + key, (size_t)len); tl += (uint64_t)len;
                        if (log) log[row].new_off = (uint32_t)tl;
@@ -455,7 +464,7 @@ int64_t nso_mutate_read(const uint8_t *seg_in, int64_t ref_len, const ns_event *
                        memset(txt + tl, '-', (size_t)len); tl += (uint64_t)len; }
         } else {
             uint8_t nb[4096];
-            for (int64_t i = 0; i < len; ++i) nb[i] = ins_letter(d, seg, attempt, (uint64_t)key, (uint32_t)i);
+            for (int64_t i = 0; i < len; ++i) nb[i] = ins_letter(d, seg, attempt, (uint32_t)jj, (uint32_t)i);
             for (int64_t i = len - 1; i >= 0; --i) { --w; out[w] = nb[i]; if (cls) cls[w] = NS_Q_INS; }
             if (txt) { memset(txt + tl, '-', (size_t)len); tl += (uint64_t)len;
                        if (log) log[row].new_off = (uint32_t)tl;
