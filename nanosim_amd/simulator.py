@@ -1,0 +1,280 @@
+#!/usr/bin/env python
+"""Drop-in for the simulation stage of NanoSim: same sub-commands, flags, model files and output files as
+``src/simulator.py`` of bcgsc/NanoSim v3.2.2 (CLI: S:2070-2218, genome driver: S:2226-2320), with the per-read
+loop running on MI355X through the C-ABI (include/nanosim_amd.h).
+
+    python -m nanosim_amd.simulator genome -rg ref.fa -c model/training -o out/simulated -n 100000 [--fastq] ...
+
+Differences a user can see: ``--seed`` is honoured (the reference re-seeds from the OS in
+``simulation()``, S:1591-1592, so its --seed has no effect); read numbers are the read's index (no gaps);
+``-t`` is accepted but GPUs, not processes, do the work (run under ``torch.distributed.run`` for several GPUs).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+from textwrap import dedent
+from time import strftime
+
+import numpy as np
+
+from . import engine as E
+from . import model as M
+from . import shard
+
+VERSION = "3.2.2"
+BATCH_READS = 1_000_000
+ERR_HEADER = b"Seq_name\tSeq_pos\terror_type\terror_length\tref_base\tseq_base\n"      # S:1634
+
+
+def log(msg):
+    sys.stdout.write(strftime("%Y-%m-%d %H:%M:%S") + ": " + msg + "\n")
+    sys.stdout.flush()
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(
+        description=dedent('''
+        Simulation step
+        -----------------------------------------------------------
+        Given error profiles, reference genome, metagenome,
+        and/or transcriptome, simulate ONT DNA or RNA reads
+        '''), formatter_class=argparse.RawDescriptionHelpFormatter)
+    parser.add_argument('-v', '--version', action='version', version='NanoSim ' + VERSION + ' (nanosim_amd, MI355X)')
+    sub = parser.add_subparsers(help="You may run the simulator on genome, transcriptome, or metagenome mode.", dest='mode')
+
+    g = sub.add_parser('genome', help="Run the simulator on genome mode")
+    g.add_argument('-rg', '--ref_g', help='Input reference genome', required=True)
+    g.add_argument('-c', '--model_prefix', default="training",
+                   help='Location and prefix of error profiles generated from characterization step (Default = training)')
+    g.add_argument('-o', '--output', default="simulated", help='Output location and prefix for simulated reads (Default = simulated)')
+    g.add_argument('-n', '--number', type=int, default=20000, help='Number of reads to be simulated (Default = 20000)')
+    g.add_argument('-x', '--coverage', type=float, default=None,
+                   help='Coverage of the simulated reads, Note: Coverage will override the number of reads')
+    g.add_argument('-max', '--max_len', type=int, default=float("inf"), help='The maximum length for simulated reads (Default = Infinity)')
+    g.add_argument('-min', '--min_len', type=int, default=50, help='The minimum length for simulated reads (Default = 50)')
+    g.add_argument('-med', '--median_len', type=int, default=None, help='The median read length (Default = None)')
+    g.add_argument('-sd', '--sd_len', type=float, default=None, help='The standard deviation of read length in log scale (Default = None)')
+    g.add_argument('--seed', type=int, default=None, help='Manually seeds the pseudo-random number generator')
+    g.add_argument('-hp', '--homopolymer', action='store_true', default=False, help='Simulate homopolymer lengths (Default = False)')
+    g.add_argument('-k', '--KmerBias', type=int, default=None,
+                   help='Minimum homopolymer length to simulate homopolymer contraction and expansion events in, a typical k is 5')
+    g.add_argument('-s', '--strandness', type=float, default=None,
+                   help='Proportion of sense sequences. Overrides the value profiled in characterization stage.')
+    g.add_argument('-dna_type', choices=["linear", "circular"], default="linear", help='Specify the dna type: circular OR linear (Default = linear)')
+    g.add_argument('--perfect', action='store_true', default=False, help='Ignore error profiles and simulate perfect reads')
+    g.add_argument('--fastq', action='store_true', default=False, help='Output fastq files instead of fasta files')
+    g.add_argument('--chimeric', action='store_true', default=False, help='Simulate chimeric reads')
+    g.add_argument('-t', '--num_threads', type=int, default=1, help='Number of threads for simulation (Default = 1)')
+
+    t = sub.add_parser('transcriptome', help="Run the simulator on transcriptome mode")
+    t.add_argument('-rt', '--ref_t', required=True)
+    t.add_argument('-rg', '--ref_g', default='')
+    t.add_argument('-e', '--exp', required=True)
+    t.add_argument('-c', '--model_prefix', default="training")
+    t.add_argument('-o', '--output', default="simulated")
+    t.add_argument('-n', '--number', type=int, default=20000)
+    t.add_argument('-x', '--coverage', type=float, default=None)
+    t.add_argument('-max', '--max_len', type=int, default=float("inf"))
+    t.add_argument('-min', '--min_len', type=int, default=50)
+    t.add_argument('--seed', type=int, default=None)
+    t.add_argument('-hp', '--homopolymer', action='store_true', default=False)
+    t.add_argument('-k', '--KmerBias', type=int, default=None)
+    t.add_argument('-b', '--basecaller', choices=["albacore", "guppy"], default=None)
+    t.add_argument('-s', '--strandness', type=float, default=None)
+    t.add_argument('--no_model_ir', action='store_false', default=True)
+    t.add_argument('--perfect', action='store_true', default=False)
+    t.add_argument('--polya', default=None)
+    t.add_argument('--fastq', action='store_true', default=False)
+    t.add_argument('-t', '--num_threads', type=int, default=1)
+    t.add_argument('--uracil', action='store_true', default=False)
+
+    mg = sub.add_parser('metagenome', help="Run the simulator on metagenome mode")
+    mg.add_argument('-gl', '--genome_list', required=True)
+    mg.add_argument('-a', '--abun', required=True)
+    mg.add_argument('-dl', '--dna_type_list', required=True)
+    mg.add_argument('-c', '--model_prefix', default="training")
+    mg.add_argument('-o', '--output', default="simulated")
+    mg.add_argument('-max', '--max_len', type=int, default=float("inf"))
+    mg.add_argument('-min', '--min_len', type=int, default=50)
+    mg.add_argument('-med', '--median_len', type=int, default=None)
+    mg.add_argument('-sd', '--sd_len', type=float, default=None)
+    mg.add_argument('--seed', type=int, default=None)
+    mg.add_argument('-hp', '--homopolymer', action='store_true', default=False)
+    mg.add_argument('-k', '--KmerBias', type=int, default=None)
+    mg.add_argument('-s', '--strandness', type=float, default=None)
+    mg.add_argument('--perfect', action='store_true', default=False)
+    mg.add_argument('--abun_var', nargs='+', type=float, default=None)
+    mg.add_argument('--fastq', action='store_true', default=False)
+    mg.add_argument('--chimeric', action='store_true', default=False)
+    mg.add_argument('-t', '--num_threads', type=int, default=1)
+    return parser, g
+
+
+def calculate_read_number_from_coverage(ref: M.Reference, model_prefix: str, coverage: float) -> int:
+    """S:2024-2068.  The reference estimates the mean read length with 10^7 KDE samples; a Gaussian KDE sample has
+    the mean of its training vector, so the expectation is taken directly."""
+    rate = None
+    with open(model_prefix + "_reads_alignment_rate") as f:
+        rate = float(f.readline().strip().split('\t')[1])
+    npz = np.load(model_prefix + "_kde.npz") if os.path.exists(model_prefix + "_kde.npz") else None
+    al = M._load_kde(model_prefix, "aligned_reads", npz)[0]
+    un = M._load_kde(model_prefix, "unaligned_length", npz)[0]
+    n_est = 10000000
+    n_al = int(n_est * rate / (rate + 1))
+    mean = (n_al * float(al.mean()) + (n_est - n_al) * float(un.mean())) / n_est
+    return int(ref.genome_len / mean * coverage)
+
+
+def validate_genome_args(a, parser_g):
+    """S:2251-2280: same messages, usage on stderr, exit code 1."""
+    def die(msg, to_err=True):
+        (sys.stderr if to_err else sys.stdout).write("\n" + msg + "\n")
+        parser_g.print_help(sys.stderr)
+        sys.exit(1)
+    if a.homopolymer and (a.KmerBias is None or a.KmerBias < 0):
+        die("Please input proper kmer bias value >= 0 to simulate homopolymer contraction and expansion events from", False)
+    if a.strandness and (a.strandness < 0 or a.strandness > 1):
+        die("Please input proper strandness value between 0 and 1", False)
+    if (a.median_len and not a.sd_len) or (a.sd_len and not a.median_len):
+        die("Please provide both mean and standard deviation of read length!")
+    if a.median_len and a.sd_len and a.chimeric:
+        die("Lognormal distributed reads cannot be chimeric!")
+    if a.max_len < a.min_len:
+        die("Maximum read length must be longer than Minimum read length!")
+    if a.perfect and a.chimeric:
+        die("Perfect reads cannot be chimeric", False)
+
+
+def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, chimeric, min_len, max_len, median_len,
+                   sd_len, want_errlog):
+    done = 0
+    with open(out_path, "wb") as fr:
+        fe = open(err_path, "wb") if err_path else None
+        try:
+            while done < count:
+                n = min(BATCH_READS, count - done)
+                p = E.make_params(seed=seed, first_read=first + done, n_reads=n, kind=kind, fastq=fastq, chimeric=chimeric,
+                                  min_len=min_len, max_len=max_len, median_len=median_len, sd_len=sd_len,
+                                  emit_records=True, emit_errlog=bool(fe))
+                b = eng.generate(p)
+                fr.write(memoryview(b.records()))
+                if fe:
+                    fe.write(memoryview(b.errlog()))
+                done += n
+                sys.stdout.write(strftime("%Y-%m-%d %H:%M:%S") + ": Number of reads simulated >> " + str(first + done) + "\r")
+                sys.stdout.flush()
+        finally:
+            if fe:
+                fe.close()
+    sys.stdout.write('\n')
+
+
+def run_genome(a, parser_g):
+    validate_genome_args(a, parser_g)
+    rank, local_rank, world = shard.env_rank_world()
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if a.KmerBias:
+        sys.stderr.write("\n-k/--KmerBias (homopolymer expansion/contraction) is not available in this build yet\n")
+        sys.exit(1)
+    if rank == 0:
+        print("\nrunning the code with following parameters:\n")
+        for k in ("ref_g", "model_prefix"):
+            print(k, getattr(a, k))
+        print("out", a.output); print("number", [a.number]); print("coverage", a.coverage); print("perfect", a.perfect)
+        print("homopolymer", a.homopolymer); print("dna_type", a.dna_type); print("strandness", a.strandness)
+        print("sd_len", a.sd_len); print("median_len", a.median_len); print("max_len", a.max_len); print("min_len", a.min_len)
+        print("fastq", a.fastq); print("chimeric", a.chimeric); print("num_threads", max(a.num_threads, 1))
+        log(' '.join(sys.argv))
+    out = a.output
+    d = os.path.dirname(out)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    if rank == 0:
+        log("Read in reference ")
+    eng = E.Engine(local_rank)
+    ref = M.read_fasta(a.ref_g, a.dna_type) if rank == 0 else None
+    if rank == 0 and len(ref.names) > 1 and a.dna_type == "circular":                       # S:354-356
+        sys.stderr.write("Do not choose circular if there is more than one chromosome in the genome!\n")
+        sys.exit(1)
+    keep = None
+    if dist is not None:
+        import torch
+        ref, keep = shard.broadcast_reference(ref, dist, device=torch.device("cuda", local_rank))
+        eng.set_reference_device(keep.data_ptr(), ref)
+    else:
+        eng.set_reference(ref)
+    if rank == 0:
+        log("Read error profile" if not a.perfect else "Read KDF of aligned reads")
+    mdl = M.load_model(a.model_prefix, perfect=a.perfect, strandness=a.strandness, chimeric=a.chimeric,
+                       homopolymer=a.homopolymer, fastq=a.fastq)
+    eng.load_model(mdl)
+    number = a.number
+    if a.coverage is not None:
+        print("\nCalculating the number of reads to be simulated based on the coverage, if you specified the number of reads "
+              "concurrently with the coverage, coverage will override number of reads.\n")
+        number = calculate_read_number_from_coverage(ref, a.model_prefix, a.coverage)
+    n_al, n_un = mdl.split_counts(number)
+    max_len = int(min(a.max_len, ref.max_chrom))                                            # S:2318
+    seed = a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little") >> 1
+    ext = ".fastq" if a.fastq else ".fasta"
+    kind = E.NS_KIND_PERFECT if a.perfect else E.NS_KIND_ALIGNED
+    if rank == 0:
+        if a.median_len and a.sd_len:
+            log("Simulating read length with log-normal distribution")
+        log("Start simulation of aligned reads")
+    lo, hi = shard.partition(n_al, world)[rank]
+    sub_reads = out + "_aligned_reads%d%s" % (rank, ext)
+    sub_err = out + "_error_profile%d" % rank
+    _write_batches(eng, sub_reads, sub_err, seed=seed, first=lo, count=hi - lo, kind=kind, fastq=a.fastq,
+                   chimeric=a.chimeric, min_len=a.min_len, max_len=max_len, median_len=a.median_len, sd_len=a.sd_len,
+                   want_errlog=True)
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        shard.merge_subfiles(out + "_aligned_reads" + ext, [out + "_aligned_reads%d%s" % (r, ext) for r in range(world)])
+        shard.merge_subfiles(out + "_aligned_error_profile", [out + "_error_profile%d" % r for r in range(world)], ERR_HEADER)
+    if not a.perfect:                                                                       # S:1642-1672
+        if rank == 0:
+            log("Start simulation of random reads")
+        lo, hi = shard.partition(n_un, world)[rank]
+        sub_un = out + "_unaligned_reads%d%s" % (rank, ext)
+        _write_batches(eng, sub_un, None, seed=seed, first=n_al + lo, count=hi - lo, kind=E.NS_KIND_UNALIGNED, fastq=a.fastq,
+                       chimeric=False, min_len=a.min_len, max_len=max_len, median_len=a.median_len, sd_len=a.sd_len,
+                       want_errlog=False)
+        if dist is not None:
+            dist.barrier()
+        if rank == 0:
+            shard.merge_subfiles(out + "_unaligned_reads" + ext, [out + "_unaligned_reads%d%s" % (r, ext) for r in range(world)])
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    if rank == 0:
+        log("Finished!")
+
+
+def main(argv=None):
+    parser, parser_g = build_parser()
+    if len(sys.argv if argv is None else argv) == (1 if argv is None else 0):
+        parser.print_help(sys.stderr)
+        sys.exit(1)
+    a = parser.parse_args(argv)
+    if a.mode == "genome":
+        run_genome(a, parser_g)
+    elif a.mode in ("transcriptome", "metagenome"):
+        sys.stderr.write("\n%s mode is parsed for CLI compatibility but its driver is not part of this build yet "
+                         "(SURVEY.md §8f); use genome mode.\n" % a.mode)
+        sys.exit(2)
+    else:
+        parser.print_help(sys.stderr)
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,150 @@
+"""Distribution parity with the REAL reference (north_star gate: KS distance <= 1 %).
+
+tests/golden/reference_distributions.json holds 2048-point quantile summaries of 114 000 aligned + 6 000
+unaligned reads produced by the imported reference (simulation_aligned_genome / simulation_unaligned) on the
+committed small model.  The same model is run through the CPU oracle (always) and through the HIP engine
+(-m gpu) and compared metric by metric."""
+import numpy as np
+import pytest
+
+from nanosim_amd import engine as E
+from nanosim_amd import model as M
+from tests import oracle_lib as O
+
+KS_GATE = 0.01
+
+
+def ks_vs_quantiles(sample, quantiles):
+    """max |F_sample(v) - F_ref(v)| over the reference's quantile values (F_ref known to 1/len(quantiles))."""
+    q = np.asarray(quantiles, dtype=np.float64)
+    vals = np.unique(q)
+    f_ref = np.searchsorted(q, vals, side="right") / len(q)
+    s = np.sort(np.asarray(sample, dtype=np.float64))
+    f_mine = np.searchsorted(s, vals, side="right") / len(s)
+    f_ref_l = np.searchsorted(q, vals, side="left") / len(q)
+    f_mine_l = np.searchsorted(s, vals, side="left") / len(s)
+    return float(max(np.max(np.abs(f_mine - f_ref)), np.max(np.abs(f_mine_l - f_ref_l))))
+
+
+def per_read_metrics(reads, pieces, events):
+    """length, head, tail, ref_len, strand and per-type event / base counts for every (non-chimeric) read."""
+    n = len(reads)
+    p = pieces[reads["piece_off"]]
+    cnt = np.zeros((n, 6), dtype=np.int64)
+    ev_off, n_ev = p["ev_off"].astype(np.int64), p["n_ev"].astype(np.int64)
+    # flat index of every event -> read id
+    rid = np.repeat(np.arange(n), n_ev)
+    idx = np.concatenate([np.arange(o, o + k) for o, k in zip(ev_off, n_ev)]) if n else np.zeros(0, np.int64)
+    info = events["info"][idx]
+    ty, ln = M.ev_type(info).astype(np.int64), M.ev_len(info).astype(np.int64)
+    for t in range(3):
+        sel = ty == t
+        cnt[:, t] = np.bincount(rid[sel], minlength=n)
+        cnt[:, 3 + t] = np.bincount(rid[sel], weights=ln[sel], minlength=n).astype(np.int64)
+    return dict(len=reads["seq_len"], head=reads["head"], tail=reads["tail"], ref_len=p["ref_len"],
+                rev=reads["reversed"], counts=cnt)
+
+
+def check_aligned(met, fx, tag):
+    rep = {}
+    rep["len"] = ks_vs_quantiles(met["len"], fx["q_len"])
+    rep["head"] = ks_vs_quantiles(met["head"], fx["q_head"])
+    rep["tail"] = ks_vs_quantiles(met["tail"], fx["q_tail"])
+    rep["ref_len"] = ks_vs_quantiles(met["ref_len"], fx["q_ref_len"])
+    for j, nm in enumerate(("mis_events", "ins_events", "del_events", "mis_bases", "ins_bases", "del_bases")):
+        rep[nm] = ks_vs_quantiles(met["counts"][:, j], fx["q_" + nm])
+        assert abs(met["counts"][:, j].mean() / fx["mean_" + nm] - 1.0) < 0.01, (tag, nm)
+    assert abs(float(np.mean(met["rev"])) - fx["rev_frac"]) < 0.01
+    assert abs(float(np.mean(met["len"])) / fx["mean_len"] - 1.0) < 0.01
+    bad = {k: v for k, v in rep.items() if v > KS_GATE}
+    assert not bad, "%s: KS distance above 1 %%: %s (all: %s)" % (tag, bad, rep)
+    return rep
+
+
+def oracle_batch(model, ref, **kw):
+    p = E.make_params(seed=424242, first_read=0, max_len=ref.max_chrom, **kw)
+    out = O.generate(model, ref, p, bytes_per_read=30000)
+    return p, out
+
+
+def test_oracle_aligned_distributions_match_reference(golden_distributions, small_model, small_ref):
+    fx = golden_distributions["fasta"]
+    p, out = oracle_batch(small_model, small_ref, n_reads=60000, emit_records=True)
+    check_aligned(per_read_metrics(out["reads"], out["pieces"], out["events"]), fx, "oracle")
+
+
+def test_oracle_unaligned_distributions_match_reference(golden_distributions, small_model, small_ref):
+    fx = golden_distributions["fasta"]
+    p, out = oracle_batch(small_model, small_ref, n_reads=20000, kind=E.NS_KIND_UNALIGNED)
+    r = out["reads"]
+    assert ks_vs_quantiles(r["seq_len"], fx["q_unaligned_len"]) <= 0.02      # reference sample is only 6 000 reads
+    assert abs(float(np.mean(r["reversed"])) - fx["unaligned_rev_frac"]) < 0.02
+
+
+def qual_hist_from_records(records, reads, name_len_total=None):
+    """quality histogram over all bases of a FASTQ image"""
+    lines = records.tobytes().split(b"\n")
+    h = np.zeros(128, dtype=np.int64)
+    for i in range(3, len(lines), 4):
+        h += np.bincount(np.frombuffer(lines[i], dtype=np.uint8) - 33, minlength=128)[:128]
+    return h
+
+
+def test_oracle_quality_distribution_matches_reference(golden_distributions, small_model, small_ref):
+    fx = golden_distributions["fastq"]
+    p, out = oracle_batch(small_model, small_ref, n_reads=3000, fastq=True)
+    h = qual_hist_from_records(out["records"], out["reads"]).astype(np.float64)
+    ref_h = np.array(fx["qual_hist"], dtype=np.float64)
+    d = np.max(np.abs(np.cumsum(h) / h.sum() - np.cumsum(ref_h) / ref_h.sum()))
+    assert d <= KS_GATE, d
+
+
+def test_record_grammar_matches_reference(golden_distributions, small_model, small_ref):
+    """names / record framing / error-profile rows have the reference's grammar (fixture: first reference records)"""
+    import re
+    fx = golden_distributions["fasta"]["first"]
+    name_re = re.compile(r"^[A-Za-z0-9\-]+_\d+_aligned_\d+_[FR]_\d+_\d+_\d+$")
+    for nm in fx["aligned"]:
+        assert name_re.match(nm), nm
+    p, out = oracle_batch(small_model, small_ref, n_reads=50, emit_errlog=True)
+    lines = out["records"].tobytes().decode().split("\n")
+    assert lines[-1] == ""
+    for i in range(0, len(lines) - 1, 2):
+        assert lines[i][0] == ">" and name_re.match(lines[i][1:]), lines[i]
+        assert set(lines[i + 1]) <= set("ACGT")
+        parts = lines[i][1:].split("_")
+        assert len(lines[i + 1]) == out["reads"]["seq_len"][i // 2]
+        assert int(parts[-3]) == out["reads"]["head"][i // 2] and int(parts[-1]) == out["reads"]["tail"][i // 2]
+    row_re = re.compile(r"^[^\t]+\t\d+\t(mis|ins|del)\t\d+\t[ACGT\-]+\t[ACGT\-]+$")
+    for ref_row in fx["err_rows"]:
+        if ref_row:
+            assert row_re.match(ref_row)
+    rows = out["errlog"].tobytes().decode().split("\n")
+    assert rows[-1] == ""
+    for row in rows[:-1]:
+        assert row_re.match(row), row
+        f = row.split("\t")
+        assert len(f[4]) == len(f[5]) == int(f[3])
+
+
+@pytest.mark.gpu
+def test_gpu_distributions_match_reference(golden_distributions, small_model, small_ref):
+    eng = E.Engine(0)
+    try:
+        eng.set_reference(small_ref)
+        eng.load_model(small_model)
+        p = E.make_params(seed=99991, first_read=0, n_reads=400000, max_len=small_ref.max_chrom, emit_records=False)
+        b = eng.generate(p)
+        rep = check_aligned(per_read_metrics(b.reads(), b.pieces(), b.events()), golden_distributions["fasta"], "gpu")
+        print("KS distances GPU vs reference:", rep)
+        p = E.make_params(seed=99991, first_read=400000, n_reads=100000, kind=E.NS_KIND_UNALIGNED,
+                          max_len=small_ref.max_chrom, emit_records=False)
+        r = eng.generate(p).reads()
+        assert ks_vs_quantiles(r["seq_len"], golden_distributions["fasta"]["q_unaligned_len"]) <= 0.02
+        p = E.make_params(seed=5, first_read=0, n_reads=20000, fastq=True, max_len=small_ref.max_chrom)
+        b = eng.generate(p)
+        h = qual_hist_from_records(b.records(), b.reads()).astype(np.float64)
+        ref_h = np.array(golden_distributions["fastq"]["qual_hist"], dtype=np.float64)
+        assert np.max(np.abs(np.cumsum(h) / h.sum() - np.cumsum(ref_h) / ref_h.sum())) <= KS_GATE
+    finally:
+        eng.close()

@@ -1,0 +1,57 @@
+"""End-to-end drop-in check on the GPU: the CLI writes the reference's file set and the bytes equal the oracle's."""
+import os
+
+import numpy as np
+import pytest
+
+from nanosim_amd import engine as E
+from nanosim_amd import model as M
+from nanosim_amd import simulator
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.mark.parametrize("fastq", [False, True])
+def test_genome_mode_end_to_end(tmp_path, fastq, small_ref):
+    out = str(tmp_path / "run" / "simulated")
+    argv = ["genome", "-rg", os.path.join(GOLDEN, "genome_small.fa"), "-c", os.path.join(GOLDEN, "model_small", "training"),
+            "-o", out, "-n", "400", "--seed", "12345", "--chimeric"] + (["--fastq"] if fastq else [])
+    simulator.main(argv)
+    ext = ".fastq" if fastq else ".fasta"
+    files = sorted(os.listdir(tmp_path / "run"))
+    assert files == sorted(["simulated_aligned_error_profile", "simulated_aligned_reads" + ext, "simulated_unaligned_reads" + ext])
+    mdl = M.load_model(os.path.join(GOLDEN, "model_small", "training"), chimeric=True, fastq=fastq)
+    n_al, n_un = mdl.split_counts(400)
+    assert (n_al, n_un) == (380, 20)
+    p = E.make_params(seed=12345, first_read=0, n_reads=n_al, fastq=fastq, chimeric=True, max_len=small_ref.max_chrom, emit_errlog=True)
+    exp = O.generate(mdl, small_ref, p)
+    assert open(out + "_aligned_reads" + ext, "rb").read() == exp["records"].tobytes()
+    assert open(out + "_aligned_error_profile", "rb").read() == simulator.ERR_HEADER + exp["errlog"].tobytes()
+    p = E.make_params(seed=12345, first_read=n_al, n_reads=n_un, kind=E.NS_KIND_UNALIGNED, fastq=fastq, max_len=small_ref.max_chrom)
+    exp = O.generate(mdl, small_ref, p)
+    got = open(out + "_unaligned_reads" + ext, "rb").read()
+    assert got == exp["records"].tobytes()
+    first = got.split(b"\n")[0].decode()
+    assert "_unaligned_%d_" % n_al in first          # numbering continues after the aligned reads (S:1506-1508)
+
+
+def test_perfect_mode(tmp_path, small_ref):
+    out = str(tmp_path / "perfect")
+    simulator.main(["genome", "-rg", os.path.join(GOLDEN, "genome_small.fa"), "-c", os.path.join(GOLDEN, "model_small", "training"),
+                    "-o", out, "-n", "100", "--seed", "5", "--perfect"])
+    assert not os.path.exists(out + "_unaligned_reads.fasta")       # S:1642: no unaligned phase with --perfect
+    lines = open(out + "_aligned_reads.fasta").read().split("\n")
+    assert len(lines) == 201
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    for i in range(0, 200, 2):
+        f = lines[i][1:].split("_")
+        chrom, pos, strand, ln = f[0], int(f[1]), f[4], int(f[6])
+        ci = small_ref.names.index(chrom)
+        src = O.normalise_bases(small_ref.chrom(ci)[pos:pos + ln])
+        seq = lines[i + 1] if strand == "F" else "".join(comp[c] for c in reversed(lines[i + 1]))
+        assert len(seq) == ln
+        unamb = np.isin(src, np.frombuffer(b"ACGT", dtype=np.uint8))
+        assert np.all(np.frombuffer(seq.encode(), dtype=np.uint8)[unamb] == src[unamb])

@@ -1,0 +1,136 @@
+"""Host-side logic on CPU: CLI surface, counts, sharding over ranks (gloo, world_size 2), sub-file merge."""
+import multiprocessing as mp
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from nanosim_amd import model as M
+from nanosim_amd import shard, simulator
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def test_cli_accepts_the_reference_flag_surface():
+    parser, _ = simulator.build_parser()
+    a = parser.parse_args("genome -rg ref.fa -c m/training -o out/sim -n 1000 -max 20000 -min 100 -med 5000 -sd 0.5 --seed 7 "
+                          "-hp -k 5 -s 0.6 -dna_type circular --fastq --chimeric -t 4".split())
+    assert (a.mode, a.number, a.max_len, a.min_len, a.KmerBias, a.dna_type, a.num_threads) == ("genome", 1000, 20000, 100, 5, "circular", 4)
+    a = parser.parse_args("genome -rg ref.fa".split())
+    assert (a.model_prefix, a.output, a.number, a.min_len, a.max_len) == ("training", "simulated", 20000, 50, float("inf"))
+    parser.parse_args("metagenome -gl g.tsv -a a.tsv -dl d.tsv --abun_var -0.5 0.5 --chimeric".split())
+    parser.parse_args("transcriptome -rt t.fa -e exp.tsv -b guppy --no_model_ir --polya p.txt --uracil".split())
+
+
+@pytest.mark.parametrize("argv", [
+    "genome -rg r.fa -med 5000",                       # S:2262-2265
+    "genome -rg r.fa -sd 0.5",
+    "genome -rg r.fa -med 5000 -sd 0.5 --chimeric",    # S:2267-2270
+    "genome -rg r.fa -max 10 -min 50",                 # S:2272-2275
+    "genome -rg r.fa --perfect --chimeric",            # S:2277-2280
+    "genome -rg r.fa -hp",                             # S:2251-2255
+    "genome -rg r.fa -s 1.5",                          # S:2257-2260
+])
+def test_cli_validation_matches_reference(argv, capsys):
+    parser, pg = simulator.build_parser()
+    a = parser.parse_args(argv.split())
+    with pytest.raises(SystemExit) as e:
+        simulator.validate_genome_args(a, pg)
+    assert e.value.code == 1
+    assert "usage" in capsys.readouterr().err.lower()
+
+
+def test_split_counts_matches_reference_formula(small_model):
+    for n in (1, 10, 19, 20, 21, 1000, 20000, 123457):
+        r = small_model.alignment_rate
+        n_al = int(round(n * r / (r + 1)))                 # S:540
+        assert small_model.split_counts(n) == (n_al, n - n_al)
+    m = M.Model(prefix="x", perfect=True)
+    assert m.split_counts(77) == (77, 0)
+
+
+def test_name_normalisation():
+    assert M.normalise_name("NC_000913.3") == "NC-000913"
+    assert M.normalise_name("chr_A.1") == "chr-A"
+    assert M.normalise_name("plasmid_c.2") == "plasmid-c"
+    assert M.normalise_name("chrB") == "chrB"
+
+
+def test_partition_covers_every_read_once():
+    for n in (0, 1, 7, 100, 1000003):
+        for w in (1, 2, 3, 8):
+            parts = shard.partition(n, w)
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            for (a0, a1), (b0, b1) in zip(parts, parts[1:]):
+                assert a1 == b0 and a0 <= a1
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, tmp, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        sys.path.insert(0, ROOT)
+        import torch.distributed as dist
+        from nanosim_amd import model as M2
+        from nanosim_amd import shard as S2
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ref = M2.read_fasta(os.path.join(GOLDEN, "genome_small.fa")) if rank == 0 else None
+        meta, buf = S2.broadcast_reference(ref, dist)
+        full = M2.read_fasta(os.path.join(GOLDEN, "genome_small.fa"))
+        ok = (meta.names == full.names and np.array_equal(meta.chrom_off, full.chrom_off)
+              and np.array_equal(buf.numpy(), full.bases) and np.array_equal(meta.circular, full.circular))
+        # every rank writes the records of its read-index range; rank 0 merges in rank order (S:1626-1639)
+        n = 1001
+        lo, hi = S2.partition(n, world)[rank]
+        sub = os.path.join(tmp, "reads%d.fasta" % rank)
+        with open(sub, "wb") as f:
+            for i in range(lo, hi):
+                f.write(b">read_%d\nACGT\n" % i)
+        dist.barrier()
+        if rank == 0:
+            S2.merge_subfiles(os.path.join(tmp, "reads.fasta"), [os.path.join(tmp, "reads%d.fasta" % r) for r in range(world)])
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, ok, lo, hi))
+    except Exception as e:      # pragma: no cover
+        q.put((rank, False, repr(e), 0))
+
+
+def test_two_rank_broadcast_and_merge_with_gloo(tmp_path):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert all(r[1] is True for r in res), res
+    assert [(r[2], r[3]) for r in res] == shard.partition(1001, world)
+    lines = open(tmp_path / "reads.fasta").read().split("\n")
+    names = lines[0:-1:2]
+    assert names == [">read_%d" % i for i in range(1001)]
+    assert not (tmp_path / "reads0.fasta").exists()
+
+
+def test_coverage_read_count(small_ref):
+    prefix = os.path.join(GOLDEN, "model_small", "training")
+    n = simulator.calculate_read_number_from_coverage(small_ref, prefix, 30.0)
+    npz = np.load(prefix + "_kde.npz")
+    r = 19.0
+    n_al = int(10000000 * r / (r + 1))
+    mean = (n_al * npz["aligned_reads_data"].mean() + (10000000 - n_al) * npz["unaligned_length_data"].mean()) / 10000000
+    assert n == int(small_ref.genome_len / mean * 30.0)
