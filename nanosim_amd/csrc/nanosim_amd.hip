@@ -324,7 +324,11 @@ __global__ void __launch_bounds__(256) k_names(GenArgs A) {
 // ---------------------------------------------------------------------------------------------------------
 // k_materialise: one read per wavefront (64-thread workgroup); see ns_materialise.h
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_materialise(GenArgs A, uint64_t nbases, uint32_t dbg) {
+#ifndef NS_MAT_WAVES
+#define NS_MAT_WAVES 5
+#endif
+template <bool FASTQ>
+__global__ void __launch_bounds__(64, NS_MAT_WAVES) k_materialise(GenArgs A, uint64_t nbases, uint32_t dbg) {
     __shared__ TileLds T;
     const uint32_t lane = threadIdx.x;
     const uint64_t r = blockIdx.x;
@@ -334,7 +338,7 @@ __global__ void __launch_bounds__(64) k_materialise(GenArgs A, uint64_t nbases, 
     const uint32_t a = rd.attempts;
     ReadOut ro;
     ro.seq = A.records + rd.rec_off + A.name_len[r] + 2;
-    ro.qual = A.prm.fastq ? ro.seq + rd.seq_len + 3 : nullptr;
+    ro.qual = FASTQ ? ro.seq + rd.seq_len + 3 : nullptr;
     ro.seq_len = rd.seq_len; ro.reversed = rd.reversed != 0;
     if (!(dbg & 8)) emit_random_region(A.m, ro, key, a, ST_HEAD, 0, rd.head, 0, lane);                                   // S:1426
     uint32_t q = rd.head;
@@ -863,7 +867,8 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->evt[6], st));
     if (prm->emit_records) {
-        k_materialise<<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->ref_nbases, ctx->dbg);
+        if (prm->fastq) k_materialise<true><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->ref_nbases, ctx->dbg);
+        else k_materialise<false><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->ref_nbases, ctx->dbg);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ctx->evt[7], st));

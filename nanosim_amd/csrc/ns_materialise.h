@@ -389,16 +389,30 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
 // byte stores land after the 16-byte stores of the copy phase.
 __device__ inline void payload_pass(const DevModel &m, const DevRef &ref, const ReadOut &ro, const ns_key &key, uint32_t a,
                                     const PieceCtx &pc, uint32_t pq, uint32_t lane) {
+    const bool wraps = pc.pos + pc.ref_len > pc.chrom_len;          // piece crosses the origin of a circular chromosome
     for (uint32_t base = 0; base < pc.n_ev; base += 256) {
         const uint32_t j0 = base + 4 * lane;
         if (j0 >= pc.n_ev) continue;
+        // the lane's 4 events and, for substitutions, the 4 reference bytes at their position: all loads issued up front
+        ns_event ev4[4];
+        uint32_t cur4[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            ev4[k].pos = 0; ev4[k].info = ns_ev_pack(0, NS_DEL, 0);
+            if (j0 + k < pc.n_ev) ev4[k] = pc.ev[j0 + k];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            cur4[k] = 0;
+            if (ns_ev_type(ev4[k].info) == NS_MIS && !wraps)
+                __builtin_memcpy(&cur4[k], ref.bases + pc.chrom_base + pc.pos + ev4[k].pos, 4);    // bases has 16 bytes of tail padding
+        }
         const u32x4 w = ns_draw(key, ST_SUB, pc.sid, a, j0 >> 2, 0);
         QualDraw qd; qd.blk = 0xffffffffu;
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k) {
             const uint32_t j = j0 + k;
-            if (j >= pc.n_ev) break;
-            const ns_event e = pc.ev[j];
+            const ns_event e = ev4[k];
             const uint32_t ty = ns_ev_type(e.info), len = ns_ev_len(e.info);
             if (ty == NS_DEL) continue;
             const uint32_t os = ev_out_start(e);
@@ -409,8 +423,8 @@ __device__ inline void payload_pass(const DevModel &m, const DevRef &ref, const 
                 if (ty == NS_INS) b = bases_atcg((word >> (2 * (i & 15))) & 3u);
                 else {
                     const uint32_t x = e.pos + i;
-                    const uint32_t cur = resolve_base(ref_base_at(ref, pc, x), key, pc.sid, a, x);
-                    b = mis_from_digit(cur, next_digit3(word));
+                    uint32_t c = (i < 4 && !wraps) ? (cur4[k] >> (8 * i)) & 0xffu : ref_base_at(ref, pc, x);
+                    b = mis_from_digit(resolve_base(c, key, pc.sid, a, x), next_digit3(word));
                 }
                 const uint32_t q = pq + os + i;
                 const uint32_t o = ro.reversed ? ro.seq_len - 1 - q : q;

@@ -12,7 +12,7 @@ import numpy as np
 from .model import (EVENT_DTYPE, PIECE_DTYPE, READ_DTYPE, Model, NsBatchInfo, NsModelTables, NsParams, Reference)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnanosim_amd.so")
+LIB_PATH = os.environ.get("NANOSIM_AMD_LIB") or os.path.join(_HERE, "libnanosim_amd.so")   # override: A/B builds only
 NS_BUF_RECORDS, NS_BUF_READS, NS_BUF_PIECES, NS_BUF_EVENTS, NS_BUF_ERRLOG = 0, 1, 2, 3, 4
 NS_KIND_ALIGNED, NS_KIND_UNALIGNED, NS_KIND_PERFECT = 0, 1, 2
 KERNEL_NAMES = ("plan(k_nseg+k_lengths+scan+sort)", "k_chain", "k_names", "k_materialise", "k_hp", "k_errlog")
