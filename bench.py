@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--errlog", action="store_true", help="also format the error profile on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=40000)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU test of the N>1 path)")
     a = ap.parse_args()
 
     import numpy as np
@@ -54,6 +55,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("NS_BENCH_DEVICE") is not None:          # test aid: several ranks on one GPU (gloo only)
+        local_rank = int(os.environ["NS_BENCH_DEVICE"])
     if not os.path.exists(graft.HIP_OUT):
         if rank == 0:
             graft.build()
@@ -64,7 +67,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl backend == RCCL on ROCm
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl backend == RCCL on ROCm
+        else:
+            dist.init_process_group(a.dist_backend)
     torch.cuda.set_device(local_rank)
 
     # ---- inputs: synthetic hg002-like model (every rank, identical by seed) + E. coli-like reference ----
@@ -78,11 +84,13 @@ def main():
     eng = engine.Engine(local_rank)
     if world > 1:
         # the reference lives on rank 0; ONE broadcast over xGMI puts it in every GPU's HBM
-        buf = torch.empty(glen, dtype=torch.uint8, device="cuda")
+        bdev = "cuda" if a.dist_backend == "nccl" else "cpu"
+        buf = torch.empty(glen, dtype=torch.uint8, device=bdev)
         if rank == 0:
             seq = synth.synth_sequence(glen, SEED, n_frac=0.0005, iupac_frac=0.0002, lower_frac=0.02, hp_boost=0.005)
             buf.copy_(torch.from_numpy(seq))
         dist.broadcast(buf, src=0)
+        buf = buf.cuda()
         torch.cuda.synchronize()
         eng.set_reference_device(buf.data_ptr(), ref_meta)
         ref_host = None
@@ -113,10 +121,11 @@ def main():
     dt = time.perf_counter() - t0
     tot_bases = sum(int(x.total_bases) for x in infos)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        rdev = "cuda" if a.dist_backend == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tb = torch.tensor([tot_bases], dtype=torch.float64, device="cuda")
+        tb = torch.tensor([tot_bases], dtype=torch.float64, device=rdev)
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
         tot_bases = float(tb.item())
 

@@ -171,6 +171,12 @@ __global__ void __launch_bounds__(256) k_chain(GenArgs A) {
     const ChainTab &ct = A.m.ct;
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const ns_params &prm = A.prm;
+    // The list is sorted by descending length, so the first workgroups carry the longest chains and set the makespan
+    // (a 120 kb read is ~3800 dependent iterations): give them issue priority over the short-read waves they share a
+    // SIMD with.
+    if (blockIdx.x < (gridDim.x >> 6)) __builtin_amdgcn_s_setprio(3);
+    else if (blockIdx.x < (gridDim.x >> 4)) __builtin_amdgcn_s_setprio(2);
+    else if (blockIdx.x < (gridDim.x >> 2)) __builtin_amdgcn_s_setprio(1);
     unsigned long long st_over = 0, st_bases = 0, st_ref = 0, st_ev = 0;
     if (tid < A.list_n) {
         const uint64_t r = A.list[tid];
@@ -688,6 +694,16 @@ int ns_load_model(ns_ctx *ctx, const ns_model_tables *t) {
             bins[2 * b] = clamp(t->mm_bin_lo[b]); bins[2 * b + 1] = clamp(t->mm_bin_hi[b]);
         }
         ct.mm_bin = put_raw(bins.data(), bins.size() * 4);
+        {   // direct bin of a previous match length < 256 (first bin with lo <= v < hi, else the last bin, S:1891-1893)
+            std::vector<uint8_t> lut(256);
+            for (int v = 0; v < 256; ++v) {
+                uint32_t b = 0;
+                for (; b < t->mm_nbins; ++b) if (bins[2 * b] <= v && v < bins[2 * b + 1]) break;
+                if (b >= t->mm_nbins) b = t->mm_nbins - 1;
+                lut[v] = (uint8_t)b;
+            }
+            ct.mm_bin_lut = put_raw(lut.data(), 256);
+        }
         ct.mm_seg_off = put_raw(t->mm_seg_off, ((size_t)t->mm_nbins + 1) * 4);
         ct.mm_hi = put_d(t->mm_hi, nseg); ct.mm_vhi = put_d(t->mm_vhi, nseg); ct.mm_vlo0 = put_d(t->mm_vlo0, t->mm_nbins);
         std::vector<uint16_t> gall;

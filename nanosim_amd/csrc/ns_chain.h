@@ -13,16 +13,25 @@ struct Tabs {
     __device__ __forceinline__ const int32_t *i(uint32_t off) const { return reinterpret_cast<const int32_t *>(w + off); }
 };
 
-// first s with p <= hi[s] (guide[u>>24] is a lower bound of s), then the interpolation of S:1847 / S:1897
+// first s with p <= hi[s] (guide[u>>24] is a lower bound of s), then the interpolation of S:1847 / S:1897.
+// hi[s] and hi[s+1] are fetched together: the look-up sits on the chain's critical path.
 __device__ __forceinline__ int32_t ecdf_lookup_g(const double *__restrict__ hi, const double *__restrict__ vhi, uint32_t n,
                                                  double vlo0, const uint16_t *__restrict__ guide, uint32_t u) {
     double p = u32_to_p(u);
     uint32_t s = guide[u >> 24];
-    while (s < n && p > hi[s]) ++s;
+    if (s < n) {
+        const double h0 = hi[s], h1 = hi[min(s + 1, n - 1)];
+        if (p > h0) {
+            ++s;
+            if (s < n && p > h1) { ++s; while (s < n && p > hi[s]) ++s; }
+        }
+    }
     if (s >= n) { s = n - 1; p = hi[s]; }
-    double plo = s ? hi[s - 1] : 0.0;
-    double vlo = s ? vhi[s - 1] : vlo0;
-    return (int32_t)floor((p - plo) / (hi[s] - plo) * (vhi[s] - vlo) + vlo);
+    const uint32_t sm = s ? s - 1 : 0;
+    const double hs = hi[s], hp = hi[sm], vs = vhi[s], vp = vhi[sm];
+    const double plo = s ? hp : 0.0;
+    const double vlo = s ? vp : vlo0;
+    return (int32_t)floor((p - plo) / (hs - plo) * (vs - vlo) + vlo);
 }
 
 __device__ __forceinline__ int32_t run_length_t(const Tabs &T, const ChainTab &c, int type, uint32_t u_mix, uint32_t u_len) {
@@ -30,8 +39,12 @@ __device__ __forceinline__ int32_t run_length_t(const Tabs &T, const ChainTab &c
     const double *cdf = T.d(c.mix_cdf[type][comp]);
     const uint32_t n = c.mix_n[type][comp];
     const double p = u32_to_p(u_len);
-    uint32_t v = 0;
-    while (v + 1 < n && p > cdf[v]) ++v;
+    const double c0 = cdf[0], c1 = cdf[n > 1 ? 1 : 0];
+    uint32_t v = 0;                                          // == while (v + 1 < n && p > cdf[v]) ++v
+    if (n > 1 && p > c0) {
+        v = 1;
+        if (n > 2 && p > c1) { v = 2; while (v + 1 < n && p > cdf[v]) ++v; }
+    }
     return (int32_t)v + 1;
 }
 
@@ -68,8 +81,11 @@ __device__ __forceinline__ EList32 chain_error_list(const Tabs &T, const ChainTa
     const double *trans = T.d(c.trans);
     const int32_t *bins = T.i(c.mm_bin);
     const uint32_t *seg_off = T.u(c.mm_seg_off);
+    const uint8_t *bin_lut = reinterpret_cast<const uint8_t *>(T.w + c.mm_bin_lut);
+    u32x4 w_next = ns_draw(key, ST_EVENT, seg, attempt, 1, 0);
     while (pos < middle_ref) {                                                                     // S:1858
-        w = ns_draw(key, ST_EVENT, seg, attempt, it, 0);
+        w = w_next;
+        w_next = ns_draw(key, ST_EVENT, seg, attempt, it + 1, 0);    // next iteration's draws do not depend on the chain state
         const int error = trans_pick(trans + 3 * state, u32_to_p(w.x));                           // S:1860-1864
         int32_t step = run_length_t(T, c, error, w.y, w.z);                                       // S:1866-1873
         if (error == NS_INS) l_new += step; else if (error == NS_DEL) l_new -= step;
@@ -83,10 +99,13 @@ __device__ __forceinline__ EList32 chain_error_list(const Tabs &T, const ChainTa
             last_ins_pos = pos;
         }
         state = NS_ST_MIS + error;                                                                 // S:1884
-        uint32_t b = 0;                                                                            // S:1891-1893
-        for (; b < c.mm_nbins; ++b)
-            if (bins[2 * b] <= prev_match && prev_match < bins[2 * b + 1]) break;
-        if (b >= c.mm_nbins) b = c.mm_nbins - 1;
+        uint32_t b;                                                                                // S:1891-1893
+        if ((uint32_t)prev_match < 256u) b = bin_lut[prev_match];
+        else {
+            for (b = 0; b < c.mm_nbins; ++b)
+                if (bins[2 * b] <= prev_match && prev_match < bins[2 * b + 1]) break;
+            if (b >= c.mm_nbins) b = c.mm_nbins - 1;
+        }
         const uint32_t o = seg_off[b];
         step = ecdf_lookup_g(T.d(c.mm_hi) + o, T.d(c.mm_vhi) + o, seg_off[b + 1] - o, T.d(c.mm_vlo0)[b],
                              T.h(c.mm_guide) + 256 * b, w.w);
