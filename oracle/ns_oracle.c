@@ -479,6 +479,126 @@ int64_t nso_mutate_read(const uint8_t *seg_in, int64_t ref_len, const ns_event *
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * -k: the homopolymer filter of mutate_read (S:1920-1947) and mutate_homo (S:618-705)
+ * ---------------------------------------------------------------------------------------------- */
+/* is base x of the (converted) segment inside a run of >= k identical bases? */
+static int in_hp_run(const uint8_t *seg, int64_t n, int64_t x, int64_t k) {
+    if (x < 0 || x >= n) return 0;
+    int64_t s = x, e = x + 1;
+    while (s > 0 && seg[s - 1] == seg[x] && e - s < k) --s;
+    while (e < n && seg[e] == seg[x] && e - s < k) ++e;
+    return e - s >= k;
+}
+/* Drops every event whose interval [key, key+len) (float keys: pos for mis/del, pos-0.5 for ins) overlaps a
+ * homopolymer [s,e) of the un-mutated segment: not (e <= key or key+len <= s)  (S:1929-1937).  In integers:
+ * mis/del overlap iff some base in [pos, pos+len) is in a run; ins iff some base in [pos-1, pos+len-1] is.
+ * Kept events are compacted in place with their shifts recomputed.  Returns the new count. */
+uint64_t nso_hp_filter(const uint8_t *seg, int64_t ref_len, ns_event *ev, uint64_t n_ev, int64_t k, int64_t *shift_out) {
+    uint64_t w = 0; int64_t shift = 0;
+    for (uint64_t j = 0; j < n_ev; ++j) {
+        int64_t pos = ev[j].pos, len = NS_EV_LEN(ev[j].info); int ty = (int)NS_EV_TYPE(ev[j].info);
+        int64_t lo = ty == NS_INS ? pos - 1 : pos, hi = ty == NS_INS ? pos + len - 1 : pos + len - 1;
+        int hit = 0;
+        for (int64_t x = lo; x <= hi && !hit; ++x) hit = in_hp_run(seg, ref_len, x, k);
+        if (hit) continue;
+        ev[w].pos = (uint32_t)pos; ev[w].info = NS_EV_PACK(len, ty, shift);
+        if (ty == NS_INS) shift += len; else if (ty == NS_DEL) shift -= len;
+        ++w;
+    }
+    if (shift_out) *shift_out = shift;
+    return w;
+}
+
+/* get_nd_par (hp:246-260): mu = predict_piecewise (hp:167-186), sigma = predict_lr (hp:204-209) */
+static void hp_nd_par(const ns_model_tables *t, uint8_t base, int64_t len, double *mu, double *sigma) {
+    const ns_hp_class *h = &t->hp[(base == 'A' || base == 'T') ? 0 : 1];
+    double x = (double)len;
+    double y = h->konst + h->alpha1 * x;
+    for (uint32_t j = 0; j < h->n_breaks; ++j) {
+        double dlt = x - h->breakpoint[j];
+        y += h->beta[j] * (dlt > 0 ? dlt : 0.0);
+    }
+    *mu = y; *sigma = h->intercept + h->slope * x;
+}
+double nso_hp_mu(const ns_model_tables *t, uint8_t base, int64_t len) { double m, s; hp_nd_par(t, base, len, &m, &s); return m; }
+double nso_hp_sigma(const ns_model_tables *t, uint8_t base, int64_t len) { double m, s; hp_nd_par(t, base, len, &m, &s); return s; }
+
+/* one base of a re-sampled homopolymer (S:671-682): mismatch with prob hp_mis_rate (0 < p <= rate) to a uniform other base */
+static uint8_t hp_base(const ns_model_tables *t, uint8_t base, nso_draw *d, uint32_t seg, uint32_t attempt, uint32_t idx,
+                       uint32_t sub, int *is_mis) {
+    double p; uint32_t j = 0;
+    if (d->mode) {
+        p = tape_u(d);
+        if (0 < p && p <= t->hp_mis_rate) {
+            for (;;) { uint8_t nb = (uint8_t)BASES[(uint32_t)(tape_u(d) * 4)]; if (nb != base) { *is_mis = 1; return nb; } }
+        }
+        *is_mis = 0; return base;
+    }
+    uint32_t w[4]; philox_at(d, ST_HPMIS, seg, attempt, idx, sub, w);
+    p = u32_to_p(w[0]);
+    if (!(0 < p && p <= t->hp_mis_rate)) { *is_mis = 0; return base; }
+    j = (uint32_t)(((uint64_t)w[1] * 3u) >> 32);
+    int rc = base_rank(base);
+    *is_mis = 1;
+    return (uint8_t)BASES[j + ((int)j >= rc ? 1u : 0u)];
+}
+
+/* mutate_homo (S:618-705) on one mutated aligned segment.
+ *   in/in_q: bases and qualities (or NULL) before; out/out_q after; returns the new length (or -1 if out_cap is too small).
+ *   Draw keys: new length of the run starting at s: ST_HPLEN idx=s; kept base (pre-hp position pp): ST_HPMIS idx=pp sub=0;
+ *   j-th appended base of a run ending at e: ST_HPMIS idx=e sub=1+j; appended quality j: ST_HPQ idx=e sub=1+(j>>3), field j&7;
+ *   the single mismatch quality of a run (S:697-700: only the first mismatch gets one): ST_HPQ idx=s sub=0 field 0. */
+int64_t nso_mutate_homo(const ns_model_tables *t, const uint8_t *in, const uint8_t *in_q, int64_t n, int64_t k, nso_draw *d,
+                        uint32_t seg, uint32_t attempt, uint8_t *out, uint8_t *out_q, int64_t out_cap) {
+    int64_t w = 0, p = 0;
+    while (p < n) {
+        int64_t s = p, e = p + 1;
+        while (e < n && in[e] == in[s]) ++e;
+        const int64_t L = e - s;
+        const uint8_t b = in[s];
+        if (L < k || base_rank(b) < 0) {
+            if (w + L > out_cap) return -1;
+            memcpy(out + w, in + s, (size_t)L);
+            if (in_q) memcpy(out_q + w, in_q + s, (size_t)L);
+            w += L; p = e;
+            continue;
+        }
+        double mu, sigma, x;
+        hp_nd_par(t, b, L, &mu, &sigma);
+        if (d->mode) x = tape_z(d);                                   /* np.random.normal(mu, sigma) recorded from the reference */
+        else { uint32_t ww[4]; philox_at(d, ST_HPLEN, seg, attempt, (uint32_t)s, 0, ww); x = fma(sigma, nso_norminv(u32_to_p(ww[0])), mu); }
+        if (x < 0) x = 0;                                             /* S:652-654 */
+        const int64_t size = (int64_t)nearbyint(x);                   /* int(round(.)), S:665 */
+        if (w + size > out_cap) return -1;
+        int64_t first_mis = -1;
+        for (int64_t i = 0; i < size; ++i) {
+            int is_mis; uint8_t nb;
+            if (size <= L || i < L) {
+                const int64_t pp = (size <= L) ? s + (L - size) + i : s + i;          /* kept position (S:688-690: the first |diff| quals go) */
+                nb = hp_base(t, b, d, seg, attempt, (uint32_t)pp, 0, &is_mis);
+                if (in_q) out_q[w + i] = in_q[pp];
+            } else {
+                const int64_t j = i - L;                                                 /* appended base (S:692-695) */
+                nb = hp_base(t, b, d, seg, attempt, (uint32_t)e, (uint32_t)(1 + j), &is_mis);
+                if (in_q) {
+                    uint32_t ww[4]; philox_at(d, ST_HPQ, seg, attempt, (uint32_t)e, (uint32_t)(1 + (j >> 3)), ww);
+                    uint32_t h = (ww[(j & 7) >> 1] >> (16 * (j & 1))) & 0xffffu;
+                    out_q[w + i] = d->mode ? (uint8_t)NS_Q_INS : qual_value(t, NS_Q_INS, h);
+                }
+            }
+            out[w + i] = nb;
+            if (is_mis && first_mis < 0) first_mis = i;
+        }
+        if (in_q && first_mis >= 0) {                                   /* S:697-700 */
+            uint32_t ww[4]; philox_at(d, ST_HPQ, seg, attempt, (uint32_t)s, 0, ww);
+            out_q[w + first_mis] = d->mode ? (uint8_t)NS_Q_MIS : qual_value(t, NS_Q_MIS, ww[0] & 0xffffu);
+        }
+        w += size; p = e;
+    }
+    return w;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * lengths, positions
  * ---------------------------------------------------------------------------------------------- */
 /* KernelDensity.sample (sklearn, call site S:235): i = floor(U*n); x = N(data[i], bw) */

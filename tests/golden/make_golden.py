@@ -202,6 +202,64 @@ def fixture_mutate_fastq_classes(S, genome):
     return cases
 
 
+
+def fixture_homopolymer(S, genome, k=5):
+    """-k: mutate_read's homopolymer filter + mutate_homo, with every random source on tape.  Qualities are replaced by
+    their CLASS (stub), np.random.normal is wrapped so that the sample each run consumed can be listed in run order."""
+    import re as _re
+    orig_q = S.model_base_quals.predict_base_qualities
+    code = {S.lognorm_base_qual[name]["sd"]: cls for cls, name in enumerate(("match", "mis", "ins", "ht", "unmapped"))}
+    S.model_base_quals.predict_base_qualities = lambda sd, loc, scale, n: [code[sd]] * int(n)
+    orig_normal = np.random.normal
+    cases = []
+    seed = 2100
+    pattern = "A{%d,}|C{%d,}|G{%d,}|T{%d,}" % (k, k, k, k)
+    try:
+        for m_ref in (60, 500, 3000, 6000):
+            for rep in range(3):
+                random.seed(seed); np.random.seed(seed); seed += 1
+                l_new, middle_ref, e_dict, e_count = S.error_list(m_ref, S.match_markov_model, S.match_ht_list,
+                                                                  S.error_par, S.trans_error_pr, True)
+                start = 3000 + 53 * seed
+                conv = S.case_convert(genome[start:start + middle_ref])
+                log = _Log()
+                with Recorder(S) as r1:
+                    out1, q1 = S.mutate_read(conv, "name", log, {a: list(b) for a, b in e_dict.items()}, dict(e_count), True, k)
+                calls = []
+
+                def normal(mu, sigma, n):
+                    v = orig_normal(mu, sigma, n)
+                    calls.append((float(mu), float(sigma), [float(x) for x in v]))
+                    return v
+
+                np.random.normal = normal
+                try:
+                    with Recorder(S) as r2:
+                        out2, q2 = S.mutate_homo(out1, list(q1), k)
+                finally:
+                    np.random.normal = orig_normal
+                # which sample did each run use?  groups are created per length (first appearance) then A,T,C,G (S:639-650)
+                runs = [(mt.start(), mt.end(), mt.group()[0]) for mt in _re.finditer(pattern, out1)]
+                order, hist = [], {}
+                for s0, e0, b in runs:
+                    hist.setdefault(e0 - s0, {"A": 0, "T": 0, "C": 0, "G": 0})[b] += 1
+                groups = {}
+                ci = 0
+                for length in hist:
+                    for b in ("A", "T", "C", "G"):
+                        if hist[length][b] > 0:
+                            groups[(length, b)] = list(calls[ci][2]); ci += 1
+                assert ci == len(calls)
+                x_runs = []
+                for s0, e0, b in runs:
+                    x_runs.append(groups[(e0 - s0, b)].pop())          # consumed from the END (S:665-666)
+                cases.append(dict(converted=conv, e_dict=edict_list(e_dict), k=k, u_mutate=r1.u, out1=out1,
+                                  classes1=[int(x) for x in q1], log=log.rows, x_runs=x_runs, u_homo=r2.u, out2=out2,
+                                  classes2=[int(x) for x in q2], runs=[[a, b_, c] for a, b_, c in runs]))
+    finally:
+        S.model_base_quals.predict_base_qualities = orig_q
+    return cases
+
 def fixture_unaligned(S):
     """unaligned_error_list + mutate_read STRUCTURE: an all-'A' read and a choice() that never returns 'A'
     make copied bases ('A') distinguishable from generated ones."""
@@ -417,6 +475,7 @@ def main():
             kde=fixture_kde(S),
             extract=fixture_extract(S),
             names=dict(seq_names=list(S.seq_dict.keys())),
+            homopolymer=fixture_homopolymer(S, genome),
         )
         with open(os.path.join(HERE, "reference_functions.json"), "w") as f:
             json.dump(fx, f)

@@ -77,6 +77,13 @@ def lib():
         L.nso_mutate_read.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_uint64, C.POINTER(NsoDraw), C.c_uint32,
                                       C.c_uint32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                       C.POINTER(C.c_uint64)]
+        L.nso_hp_filter.restype = C.c_uint64
+        L.nso_hp_filter.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_uint64, C.c_int64, C.POINTER(C.c_int64)]
+        L.nso_mutate_homo.restype = C.c_int64
+        L.nso_mutate_homo.argtypes = [C.POINTER(NsModelTables), C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(NsoDraw),
+                                      C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int64]
+        L.nso_hp_mu.restype = C.c_double; L.nso_hp_mu.argtypes = [C.POINTER(NsModelTables), C.c_uint8, C.c_int64]
+        L.nso_hp_sigma.restype = C.c_double; L.nso_hp_sigma.argtypes = [C.POINTER(NsModelTables), C.c_uint8, C.c_int64]
         L.nso_generate.restype = C.c_int
         L.nso_generate.argtypes = [C.POINTER(NsModelTables), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
                                    C.c_char_p, C.POINTER(NsParams), C.POINTER(NsoOut)]
