@@ -793,16 +793,7 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
             seq_len += pc[pi].out_len;
         }
         if (!pos_ok) { ++epoch; fails = 0; continue; }
-        if (seq_len < prm->min_len || seq_len > prm->max_len) { ++epoch; fails = 0; continue; }   /* S:1429-1430, S:1518-1519 */
-
-        /* ---- accepted: materialise ---- */
-        ns_read *rd = &o->reads[index];
-        memset(rd, 0, sizeof *rd);
-        rd->piece_off = (uint32_t)o->n_pieces; rd->n_pieces = (uint16_t)n_pieces; rd->reversed = (uint8_t)reversed;
-        rd->head = (uint32_t)head; rd->tail = (uint32_t)tail; rd->seq_len = (uint32_t)seq_len; rd->attempts = a;
-        rd->rec_off = o->record_bytes;
         uint64_t gidx = prm->first_read + index;
-
         /* name (S:1390-1402, 1332-1343, 1511, 1529-1534) */
         char name[4096]; int nl = 0; char num[32];
         int first = 1;
@@ -831,6 +822,68 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
         name[nl++] = '_'; nl += u64_digits((uint64_t)tail, name + nl);
         (void)num;
 
+        /* ---- -k: homopolymer filter + mutate_homo on every aligned segment (S:1406-1414); lengths change here ---- */
+        uint8_t *hp_seq[2 * NSO_MAX_SEG], *hp_q[2 * NSO_MAX_SEG];
+        uint8_t *hp_log = NULL; uint64_t hp_log_len = 0, hp_log_cap = 0;
+        const int hp_on = (prm->kmer_bias && kind == NS_KIND_ALIGNED);
+        memset(hp_seq, 0, sizeof hp_seq); memset(hp_q, 0, sizeof hp_q);
+        if (hp_on) {
+            for (uint32_t pi = 0; pi < n_pieces; pi += 2) {
+                int64_t rl = pc[pi].ref_len;
+                uint32_t sid = pi >> 1;
+                uint8_t *segbuf = (uint8_t *)malloc((size_t)rl + 1);
+                fetch_segment(ref, pc[pi].chrom, pc[pi].pos, rl, segbuf);
+                for (int64_t x = 0; x < rl; ++x) segbuf[x] = resolve_base(segbuf[x], &d, sid, a, (uint64_t)x);
+                int64_t sh = 0;
+                ns_event *pev = o->events + pc[pi].ev_off;
+                pc[pi].n_ev = (uint32_t)nso_hp_filter(segbuf, rl, pev, pc[pi].n_ev, (int64_t)prm->kmer_bias, &sh);   /* S:1920-1947 */
+                int64_t l1 = rl + sh;
+                uint8_t *s1 = (uint8_t *)malloc((size_t)l1 + 1), *c1 = (uint8_t *)malloc((size_t)l1 + 1);
+                uint64_t txt_cap = 0;
+                for (uint32_t j = 0; j < pc[pi].n_ev; ++j) txt_cap += 2u * NS_EV_LEN(pev[j].info);
+                nso_logrow *rows = prm->emit_errlog ? (nso_logrow *)malloc(sizeof(nso_logrow) * (pc[pi].n_ev + 1)) : NULL;
+                uint8_t *txt = prm->emit_errlog ? (uint8_t *)malloc(txt_cap + 1) : NULL;
+                uint64_t txt_len = 0;
+                int64_t ol = nso_mutate_read(segbuf, rl, pev, pc[pi].n_ev, &d, sid, a, s1, c1, l1, rows, txt, &txt_len);
+                if (ol != l1) return -21;
+                if (prm->emit_errlog) {
+                    for (uint32_t j = 0; j < pc[pi].n_ev; ++j) {
+                        const char *tn = rows[j].type == NS_MIS ? "mis" : rows[j].type == NS_INS ? "ins" : "del";
+                        uint64_t nb = (uint64_t)nl + 64 + 2u * rows[j].len;
+                        if (hp_log_len + nb > hp_log_cap) { hp_log_cap = 2 * (hp_log_cap + nb) + 4096; hp_log = (uint8_t *)realloc(hp_log, hp_log_cap); }
+                        uint8_t *q = hp_log + hp_log_len;
+                        memcpy(q, name, (size_t)nl); q += nl;
+                        q += sprintf((char *)q, "\t%u\t%s\t%u\t", rows[j].pos, tn, rows[j].len);
+                        memcpy(q, txt + rows[j].ref_off, rows[j].len); q += rows[j].len; *q++ = '\t';
+                        memcpy(q, txt + rows[j].new_off, rows[j].len); q += rows[j].len; *q++ = '\n';
+                        hp_log_len = (uint64_t)(q - hp_log);
+                    }
+                }
+                uint8_t *q1 = NULL;
+                if (prm->fastq) {
+                    q1 = (uint8_t *)malloc((size_t)l1 + 1);
+                    for (int64_t mm = 0; mm < l1; ++mm) q1[mm] = qual_at(t, c1[mm], &d, ST_QUAL, sid, a, (uint64_t)mm);
+                }
+                int64_t cap2 = 2 * l1 + 4096;
+                hp_seq[pi] = (uint8_t *)malloc((size_t)cap2);
+                hp_q[pi] = prm->fastq ? (uint8_t *)malloc((size_t)cap2) : NULL;
+                int64_t l2 = nso_mutate_homo(t, s1, q1, l1, (int64_t)prm->kmer_bias, &d, sid, a, hp_seq[pi], hp_q[pi], cap2);   /* S:1413-1414 */
+                free(segbuf); free(s1); free(c1); free(rows); free(txt); free(q1);
+                if (l2 < 0) return -22;
+                seq_len += l2 - (int64_t)pc[pi].out_len;
+                pc[pi].out_len = (uint32_t)l2;
+            }
+        }
+#define NSO_HP_FREE() do { for (uint32_t z_ = 0; z_ < n_pieces; ++z_) { free(hp_seq[z_]); free(hp_q[z_]); } free(hp_log); } while (0)
+        if (seq_len < prm->min_len || seq_len > prm->max_len) { NSO_HP_FREE(); ++epoch; fails = 0; continue; }   /* S:1429-1430, S:1518-1519 */
+
+        /* ---- accepted: materialise ---- */
+        ns_read *rd = &o->reads[index];
+        memset(rd, 0, sizeof *rd);
+        rd->piece_off = (uint32_t)o->n_pieces; rd->n_pieces = (uint16_t)n_pieces; rd->reversed = (uint8_t)reversed;
+        rd->head = (uint32_t)head; rd->tail = (uint32_t)tail; rd->seq_len = (uint32_t)seq_len; rd->attempts = a;
+        rd->rec_off = o->record_bytes;
+
         uint64_t need = (uint64_t)nl + 2 + (uint64_t)seq_len + 1 + (prm->fastq ? (uint64_t)seq_len + 3 : 0);
         if (o->record_bytes + need > o->cap_records) return -12;
         uint8_t *rec = o->records + o->record_bytes;
@@ -847,6 +900,13 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
         for (uint32_t pi = 0; pi < n_pieces; ++pi) {
             uint32_t sid = pc[pi].kind ? NSO_GAP_SEG + (pi >> 1) : (pi >> 1);
             int64_t rl = pc[pi].ref_len;
+            if (hp_on && !pc[pi].kind) {
+                memcpy(seq + wq, hp_seq[pi], pc[pi].out_len);
+                if (qual) memcpy(qual + wq, hp_q[pi], pc[pi].out_len);
+                wq += pc[pi].out_len;
+                o->total_ref_bases += (uint64_t)rl;
+                continue;
+            }
             uint8_t *segbuf = (uint8_t *)malloc((size_t)rl + 1);
             uint8_t *cls = (uint8_t *)malloc((size_t)pc[pi].out_len + 1);
             uint64_t txt_cap = 0;
@@ -879,6 +939,12 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
             o->total_ref_bases += (uint64_t)rl;
             free(segbuf); free(cls); free(rows); free(txt);
         }
+        if (hp_on && hp_log_len) {
+            if (o->errlog_bytes + hp_log_len > o->cap_errlog) { NSO_HP_FREE(); return -14; }
+            memcpy(o->errlog + o->errlog_bytes, hp_log, hp_log_len);
+            o->errlog_bytes += hp_log_len;
+        }
+        NSO_HP_FREE();
         for (int64_t i = 0; i < tail; ++i) {                  /* S:1427 */
             seq[wq] = ht_letter(&d, ST_TAIL, a, (uint32_t)i);
             if (qual) qual[wq] = qual_at(t, NS_Q_HT, &d, ST_HTQ, 0, a, (uint64_t)(head + i));

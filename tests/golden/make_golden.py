@@ -364,14 +364,14 @@ def fixture_extract(S):
 
 
 def _dist_worker(args):
-    idx, n_al, n_un, prefix, fasta, workdir, fastq = args
+    idx, n_al, n_un, prefix, fasta, workdir, fastq, kmer = args
     S = import_reference()
     devnull = open(os.devnull, "w")
     so = sys.stdout
     sys.stdout = devnull
     try:
         S.read_profile(fasta, [n_al + n_un], prefix, False, "genome", None, dna_type="linear", chimeric=False,
-                       homopolymer=False, fastq=fastq)
+                       homopolymer=bool(kmer), fastq=fastq)
     finally:
         sys.stdout = so
     S.total_simulated = mp.Value("i", 0, lock=True)
@@ -382,7 +382,7 @@ def _dist_worker(args):
     o_un = os.path.join(workdir, "un%d%s" % (idx, ext))
     sys.stdout = devnull
     try:
-        S.simulation_aligned_genome("linear", 50, S.max_chrom, None, None, o_reads, o_err, None, fastq, n_al, False, False)
+        S.simulation_aligned_genome("linear", 50, S.max_chrom, None, None, o_reads, o_err, kmer, fastq, n_al, False, False)
         S.simulation_unaligned("linear", 50, S.max_chrom, None, None, o_un, fastq, n_un, False)
     finally:
         sys.stdout = so
@@ -426,11 +426,11 @@ def quantiles(x, k=2048):
     return x[idx].tolist()
 
 
-def fixture_distributions(prefix, fasta, workdir, n_reads, fastq):
+def fixture_distributions(prefix, fasta, workdir, n_reads, fastq, kmer=None):
     n_proc = min(8, os.cpu_count() or 1)
     n_al = int(round(n_reads * 19.0 / 20.0))
     n_un = n_reads - n_al
-    args = [(i, n_al // n_proc, max(1, n_un // n_proc), prefix, fasta, workdir, fastq) for i in range(n_proc)]
+    args = [(i, n_al // n_proc, max(1, n_un // n_proc), prefix, fasta, workdir, fastq, kmer) for i in range(n_proc)]
     with mp.get_context("fork").Pool(n_proc) as pool:
         res = pool.map(_dist_worker, args)
     cat = lambda k: np.concatenate([np.asarray(r[k]) for r in res])
@@ -483,7 +483,8 @@ def main():
             json.dump(fixture_samplers(S), f)
         if not a.skip_dist:
             d = dict(fasta=fixture_distributions(prefix, fasta, workdir, a.dist_reads, False),
-                     fastq=fixture_distributions(prefix, fasta, workdir, max(2000, a.dist_reads // 10), True))
+                     fastq=fixture_distributions(prefix, fasta, workdir, max(2000, a.dist_reads // 10), True),
+                     hp=fixture_distributions(prefix, fasta, workdir, max(2000, a.dist_reads // 5), True, kmer=5))
             with open(os.path.join(HERE, "reference_distributions.json"), "w") as f:
                 json.dump(d, f)
     finally:

@@ -45,18 +45,22 @@ def per_read_metrics(reads, pieces, events):
                 rev=reads["reversed"], counts=cnt)
 
 
-def check_aligned(met, fx, tag):
+def check_aligned(met, fx, tag, gate=KS_GATE, mean_tol=0.01):
     rep = {}
+    ref_rl, my_rl = float(np.mean(fx["q_ref_len"])), float(np.mean(met["ref_len"]))
     rep["len"] = ks_vs_quantiles(met["len"], fx["q_len"])
     rep["head"] = ks_vs_quantiles(met["head"], fx["q_head"])
     rep["tail"] = ks_vs_quantiles(met["tail"], fx["q_tail"])
     rep["ref_len"] = ks_vs_quantiles(met["ref_len"], fx["q_ref_len"])
     for j, nm in enumerate(("mis_events", "ins_events", "del_events", "mis_bases", "ins_bases", "del_bases")):
         rep[nm] = ks_vs_quantiles(met["counts"][:, j], fx["q_" + nm])
-        assert abs(met["counts"][:, j].mean() / fx["mean_" + nm] - 1.0) < 0.01, (tag, nm)
+        assert abs(met["counts"][:, j].mean() / fx["mean_" + nm] - 1.0) < mean_tol, (tag, nm)
+        # events (bases) per reference base: insensitive to the read-length sampling noise of the two samples
+        assert abs((met["counts"][:, j].mean() / my_rl) / (fx["mean_" + nm] / ref_rl) - 1.0) < 0.006, (tag, nm, "rate")
     assert abs(float(np.mean(met["rev"])) - fx["rev_frac"]) < 0.01
-    assert abs(float(np.mean(met["len"])) / fx["mean_len"] - 1.0) < 0.01
-    bad = {k: v for k, v in rep.items() if v > KS_GATE}
+    assert abs(float(np.mean(met["len"])) / fx["mean_len"] - 1.0) < mean_tol
+    assert abs((float(np.mean(met["len"])) / my_rl) / (fx["mean_len"] / ref_rl) - 1.0) < 0.002
+    bad = {k: v for k, v in rep.items() if v > gate}
     assert not bad, "%s: KS distance above 1 %%: %s (all: %s)" % (tag, bad, rep)
     return rep
 
@@ -79,6 +83,16 @@ def test_oracle_unaligned_distributions_match_reference(golden_distributions, sm
     r = out["reads"]
     assert ks_vs_quantiles(r["seq_len"], fx["q_unaligned_len"]) <= 0.02      # reference sample is only 6 000 reads
     assert abs(float(np.mean(r["reversed"])) - fx["unaligned_rev_frac"]) < 0.02
+
+
+def test_oracle_homopolymer_mode_distributions_match_reference(golden_distributions, small_model, small_ref):
+    """--fastq -hp -k 5: the reference sample is 22 800 reads, so the KS noise floor is ~0.009; gate 0.02"""
+    fx = golden_distributions["hp"]
+    p, out = oracle_batch(small_model, small_ref, n_reads=25000, fastq=True, kmer_bias=5)
+    check_aligned(per_read_metrics(out["reads"], out["pieces"], out["events"]), fx, "oracle-hp", gate=0.02, mean_tol=0.03)
+    h = qual_hist_from_records(out["records"], out["reads"]).astype(np.float64)
+    ref_h = np.array(fx["qual_hist"], dtype=np.float64)
+    assert np.max(np.abs(np.cumsum(h) / h.sum() - np.cumsum(ref_h) / ref_h.sum())) <= KS_GATE
 
 
 def qual_hist_from_records(records, reads, name_len_total=None):
