@@ -21,6 +21,7 @@
 #include "ns_device.h"
 #include "ns_materialise.h"
 #include "ns_chain.h"
+#include "ns_hp.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // kernel arguments
@@ -46,6 +47,12 @@ struct GenArgs {
     uint32_t list_n, attempt;
     uint32_t *next_list, *next_n;    // reads rejected in this pass
     uint32_t *rstate;                // per read: epoch | consecutive first-check failures << 16
+    uint32_t *att_base;              // per read: first attempt number of this run (0 unless the batch is re-run in -k mode)
+    uint32_t keep_state;             // k_nseg keeps rstate/att_base (re-run after a failed final length check)
+    uint32_t hp;                     // -k active for this batch
+    uint8_t *scr, *scrq;             // -k: pre-homopolymer reads (forward strand) and their quality characters
+    uint64_t *scr_len, *scr_off;
+    uint32_t *hp_len;                // -k: final emitted length per piece
     // results
     ns_read *reads;
     ns_piece *pieces;
@@ -75,7 +82,7 @@ __global__ void __launch_bounds__(256) k_nseg(GenArgs A) {
     if (r > A.prm.n_reads) return;
     if (r == A.prm.n_reads) { A.n_pieces[r] = 0; A.ev_cap[r] = 0; A.rec_len[r] = 0; A.err_len[r] = 0; return; }
     A.n_pieces[r] = 2 * read_nseg(A, make_key(A.prm, r)) - 1;
-    A.rstate[r] = 0;
+    if (!A.keep_state) { A.rstate[r] = 0; A.att_base[r] = 0; }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -91,7 +98,7 @@ __global__ void __launch_bounds__(256) k_lengths(GenArgs A) {
     const ns_params &prm = A.prm;
     const int kind = (int)prm.kind;
     const ns_key key = make_key(prm, r);
-    const uint32_t a = A.attempt;
+    const uint32_t a = A.att_base[r] + A.attempt;
     const uint32_t epoch = A.rstate[r] & 0xffffu;
     const uint32_t piece_off = A.piece_off[r];
     const uint32_t n_pieces = A.piece_off[r + 1] - piece_off;
@@ -141,7 +148,7 @@ __global__ void __launch_bounds__(256) k_lengths(GenArgs A) {
     }
     rd.seq_len = 0; rd.attempts = a;
     A.reads[r] = rd;
-    if (a == 0) {
+    if (A.attempt == 0) {
         A.ev_cap[r] = cap;
         A.sort_key[r] = work > 0xffffffffull ? 0xffffffffu : (uint32_t)work;
         A.sort_idx[r] = (uint32_t)r;
@@ -182,7 +189,7 @@ __global__ void __launch_bounds__(256) k_chain(GenArgs A) {
         const uint64_t r = A.list[tid];
         const int kind = (int)prm.kind;
         const ns_key key = make_key(prm, r);
-        const uint32_t a = A.attempt;
+        const uint32_t a = A.att_base[r] + A.attempt;
         ns_read rd = A.reads[r];
         const uint32_t n_pieces = rd.n_pieces;
         ns_piece *pc = A.pieces + rd.piece_off;
@@ -235,7 +242,8 @@ __global__ void __launch_bounds__(256) k_chain(GenArgs A) {
                 seq_len += p.out_len;
                 ref_bases += p.ref_len;
             }
-            if (!pos_ok || seq_len < prm.min_len || seq_len > prm.max_len) { ++epoch; fails = 0; break; }   // S:1429-1430, S:1518-1519
+            // final length re-check (S:1429-1430, S:1518-1519); with -k the length is only final after k_hp_count
+            if (!pos_ok || (!A.hp && (seq_len < prm.min_len || seq_len > prm.max_len))) { ++epoch; fails = 0; break; }
             // ---- accepted ----
             rd.flags = 0; rd.seq_len = (uint32_t)seq_len; rd.attempts = a;
             uint32_t nl = 0; bool first = true;                                          // name length (S:1390-1402, 1332-1343, 1529-1534)
@@ -264,11 +272,12 @@ __global__ void __launch_bounds__(256) k_chain(GenArgs A) {
             A.name_len[r] = (uint16_t)nl;
             A.rec_len[r] = prm.emit_records ? (uint64_t)nl + 2 + (uint64_t)seq_len + 1 + (prm.fastq ? (uint64_t)seq_len + 3 : 0) : 0;
             A.err_len[r] = err_len;
-            st_bases = (unsigned long long)seq_len; st_ref = ref_bases; st_ev = evn;
+            st_bases = A.hp ? 0ull : (unsigned long long)seq_len; st_ref = ref_bases; st_ev = evn;
             accepted = true;
         } while (false);
         if (overflow) st_over = 1;
         A.reads[r] = rd;
+        if (accepted) A.att_base[r] = a;            // a re-run of the batch starts every read at its accepted attempt
         if (!accepted && !overflow) {
             A.rstate[r] = (epoch & 0xffffu) | fails << 16;
             A.next_list[atomicAdd(A.next_n, 1u)] = (uint32_t)r;
@@ -346,6 +355,11 @@ __global__ void __launch_bounds__(64, NS_MAT_WAVES) k_materialise(GenArgs A, uin
     ro.seq = A.records + rd.rec_off + A.name_len[r] + 2;
     ro.qual = FASTQ ? ro.seq + rd.seq_len + 3 : nullptr;
     ro.seq_len = rd.seq_len; ro.reversed = rd.reversed != 0;
+    if (A.hp) {                                  // -k: forward-strand pre-homopolymer read into the scratch buffer
+        ro.seq = A.scr + A.scr_off[r];
+        ro.qual = FASTQ ? A.scrq + A.scr_off[r] : nullptr;
+        ro.reversed = false;
+    }
     if (!(dbg & 8)) emit_random_region(A.m, ro, key, a, ST_HEAD, 0, rd.head, 0, lane);                                   // S:1426
     uint32_t q = rd.head;
     for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
@@ -355,6 +369,171 @@ __global__ void __launch_bounds__(64, NS_MAT_WAVES) k_materialise(GenArgs A, uin
         q += pc.out_len;
     }
     if (!(dbg & 8)) emit_random_region(A.m, ro, key, a, ST_TAIL, rd.seq_len - rd.tail, rd.tail, rd.head, lane);          // S:1427
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// -k kernels (ns_hp.h)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_hp_filter(GenArgs A) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > A.prm.n_reads) return;
+    if (r == A.prm.n_reads) { A.scr_len[r] = 0; return; }
+    ns_read rd = A.reads[r];
+    if (rd.flags) { A.scr_len[r] = 0; return; }
+    const ns_key key = make_key(A.prm, r);
+    const uint32_t a = rd.attempts;
+    const int64_t k = (int64_t)A.prm.kmer_bias;
+    const uint32_t nl = A.name_len[r];
+    uint64_t seq_len = (uint64_t)rd.head + rd.tail, err_len = 0;
+    for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
+        ns_piece p = A.pieces[rd.piece_off + pi];
+        if (!p.kind) {
+            const PieceCtx pc = load_piece(A.events, A.ref, p, pi);
+            ns_event *ev = A.events + p.ev_off;
+            uint32_t w = 0; int32_t shift = 0;
+            for (uint32_t j = 0; j < p.n_ev; ++j) {                       // S:1929-1947
+                const ns_event e = ev[j];
+                const int64_t pos = e.pos, len = ns_ev_len(e.info); const uint32_t ty = ns_ev_type(e.info);
+                const int64_t lo = ty == NS_INS ? pos - 1 : pos, hi = pos + len - 1;
+                bool hit = false;
+                for (int64_t x = lo; x <= hi && !hit; ++x) hit = in_hp_run(A.ref, pc, key, a, x, k);
+                if (hit) continue;
+                ns_event o; o.pos = e.pos; o.info = ns_ev_pack((uint32_t)len, ty, shift);
+                ev[w++] = o;
+                if (ty == NS_INS) shift += (int32_t)len; else if (ty == NS_DEL) shift -= (int32_t)len;
+                err_len += nl + dec_digits(e.pos) + dec_digits((uint32_t)len) + 2u * (uint32_t)len + 9u;
+            }
+            p.n_ev = w; p.out_len = (uint32_t)((int32_t)p.ref_len + shift);
+            A.pieces[rd.piece_off + pi] = p;
+        }
+        seq_len += p.out_len;
+    }
+    rd.seq_len = (uint32_t)seq_len;                 // pre-homopolymer length (layout of the scratch read)
+    A.reads[r] = rd;
+    A.scr_len[r] = seq_len;
+    A.err_len[r] = A.prm.emit_errlog ? err_len : 0;
+}
+
+__global__ void __launch_bounds__(256) k_hp_count(GenArgs A) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long st_bases = 0, st_fail = 0;
+    if (r < A.prm.n_reads) {
+        ns_read rd = A.reads[r];
+        if (!rd.flags) {
+            const ns_key key = make_key(A.prm, r);
+            const uint32_t a = rd.attempts, k = A.prm.kmer_bias;
+            const uint8_t *scr = A.scr + A.scr_off[r];
+            uint64_t q = rd.head, final_len = (uint64_t)rd.head + rd.tail;
+            for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
+                const ns_piece p = A.pieces[rd.piece_off + pi];
+                uint32_t flen = p.out_len;
+                if (!p.kind) {
+                    const uint32_t sid = pi >> 1, n = p.out_len;
+                    const uint8_t *sq = scr + q;
+                    int64_t delta = 0;
+                    for (uint32_t s = 0; s < n;) {                        // mutate_homo run scan, S:627-637
+                        const uint8_t b = sq[s];
+                        uint32_t e = s + 1;
+                        while (e < n && sq[e] == b) ++e;
+                        if (e - s >= k) delta += (int64_t)hp_new_size(A.m, key, sid, a, s, e - s, b) - (int64_t)(e - s);
+                        s = e;
+                    }
+                    flen = (uint32_t)((int64_t)n + delta);
+                }
+                A.hp_len[rd.piece_off + pi] = flen;
+                final_len += flen;
+                q += p.out_len;
+            }
+            if ((int64_t)final_len < A.prm.min_len || (int64_t)final_len > A.prm.max_len) {      // S:1429-1430
+                const uint32_t epoch = (A.rstate[r] & 0xffffu) + 1;
+                A.rstate[r] = epoch & 0xffffu;
+                A.att_base[r] = a + 1;
+                st_fail = 1;
+            } else {
+                rd.seq_len = (uint32_t)final_len;
+                A.reads[r] = rd;
+                A.rec_len[r] = A.prm.emit_records ? (uint64_t)A.name_len[r] + 2 + final_len + 1 + (A.prm.fastq ? final_len + 3 : 0) : 0;
+                st_bases = final_len;
+            }
+        }
+    }
+    st_bases = wave_sum(st_bases); st_fail = wave_sum(st_fail);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&A.stats[1], st_bases); if (st_fail) atomicAdd(&A.stats[5], st_fail); }
+}
+
+// scratch (pre-homopolymer, forward) -> final record: runs re-sampled, mismatches, qualities, reverse complement
+__global__ void __launch_bounds__(256) k_hp_write(GenArgs A) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= A.prm.n_reads) return;
+    const ns_read rd = A.reads[r];
+    if (rd.flags) return;
+    if (!A.prm.emit_records) {
+        for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) A.pieces[rd.piece_off + pi].out_len = A.hp_len[rd.piece_off + pi];
+        return;
+    }
+    const ns_key key = make_key(A.prm, r);
+    const uint32_t a = rd.attempts, k = A.prm.kmer_bias;
+    const bool fq = A.prm.fastq != 0, rev = rd.reversed != 0;
+    const uint32_t L = rd.seq_len;                                         // final length
+    uint8_t *seq = A.records + rd.rec_off + A.name_len[r] + 2;
+    uint8_t *qual = fq ? seq + L + 3 : nullptr;
+    const uint8_t *scr = A.scr + A.scr_off[r];
+    const uint8_t *scq = fq ? A.scrq + A.scr_off[r] : nullptr;
+    uint32_t o = 0;                                                        // output cursor, pre-revcomp coordinates
+    auto put = [&](uint32_t b, uint32_t qc) {
+        const uint32_t oo = rev ? L - 1 - o : o;
+        seq[oo] = rev ? complement(b) : (uint8_t)b;
+        if (fq) qual[oo] = (uint8_t)qc;
+        ++o;
+    };
+    uint64_t q = 0;
+    for (uint32_t i = 0; i < rd.head; ++i, ++q) put(scr[q], fq ? scq[q] : 0);
+    for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
+        ns_piece p = A.pieces[rd.piece_off + pi];
+        const uint32_t n = p.out_len;
+        if (p.kind) { for (uint32_t i = 0; i < n; ++i, ++q) put(scr[q], fq ? scq[q] : 0); continue; }
+        const uint32_t sid = pi >> 1;
+        const uint8_t *sq = scr + q;
+        const uint8_t *qq = fq ? scq + q : nullptr;
+        for (uint32_t s = 0; s < n;) {
+            const uint32_t b = sq[s];
+            uint32_t e = s + 1;
+            while (e < n && sq[e] == b) ++e;
+            const uint32_t len = e - s;
+            if (len < k) { for (uint32_t x = s; x < e; ++x) put(sq[x], fq ? qq[x] : 0); s = e; continue; }
+            const uint32_t size = hp_new_size(A.m, key, sid, a, s, len, b);
+            const uint32_t o_run = o;
+            int64_t first_mis = -1;
+            for (uint32_t i = 0; i < size; ++i) {                          // S:668-684, qualities S:686-695
+                bool is_mis; uint32_t nb, qc = 0;
+                if (size <= len || i < len) {
+                    const uint32_t pp = size <= len ? s + (len - size) + i : s + i;
+                    nb = hp_base(A.m, b, key, sid, a, pp, 0, is_mis);
+                    if (fq) qc = qq[pp];
+                } else {
+                    const uint32_t j = i - len;
+                    nb = hp_base(A.m, b, key, sid, a, e, 1 + j, is_mis);
+                    if (fq) {
+                        u32x4 w = ns_draw(key, ST_HPQ, sid, a, e, 1 + (j >> 3));
+                        const uint32_t h = (ns_word(w, (j & 7) >> 1) >> (16 * (j & 1))) & 0xffffu;
+                        qc = qual_value(A.m.qual_thr + NS_Q_INS * NS_QUAL_LEVELS, h) + 33u;
+                    }
+                }
+                if (is_mis && first_mis < 0) first_mis = i;
+                put(nb, qc);
+            }
+            if (fq && first_mis >= 0) {                                    // S:697-700: only the first mismatch gets a 'mis' quality
+                u32x4 w = ns_draw(key, ST_HPQ, sid, a, s, 0);
+                const uint32_t om = o_run + (uint32_t)first_mis;
+                qual[rev ? L - 1 - om : om] = (uint8_t)(qual_value(A.m.qual_thr + NS_Q_MIS * NS_QUAL_LEVELS, w.x & 0xffffu) + 33u);
+            }
+            s = e;
+        }
+        q += n;
+        p.out_len = A.hp_len[rd.piece_off + pi];                           // report the emitted length, like the non -k path
+        A.pieces[rd.piece_off + pi] = p;
+    }
+    for (uint32_t i = 0; i < rd.tail; ++i, ++q) put(scr[q], fq ? scq[q] : 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -460,7 +639,7 @@ struct ns_ctx {
     // planning + result buffers
     DevBuf n_pieces, piece_off, ev_cap, ev_off, rec_len, rec_off, err_len, err_off, name_len;
     DevBuf reads, pieces, events, records, errlog, stats, scan_tmp;
-    DevBuf sort_key, sort_idx, sort_key_out, order, list_b, rstate;
+    DevBuf sort_key, sort_idx, sort_key_out, order, list_b, rstate, att_base, scr, scrq, scr_len, scr_off, hp_len;
     bool lds_tables = false;
     size_t lds_bytes = 0;
     ns_batch_info last{};
@@ -540,7 +719,8 @@ void ns_destroy(ns_ctx *ctx) {
     DevBuf *bufs[] = {&ctx->n_pieces, &ctx->piece_off, &ctx->ev_cap, &ctx->ev_off, &ctx->rec_len, &ctx->rec_off,
                       &ctx->err_len, &ctx->err_off, &ctx->name_len, &ctx->reads, &ctx->pieces, &ctx->events,
                       &ctx->records, &ctx->errlog, &ctx->stats, &ctx->scan_tmp, &ctx->sort_key, &ctx->sort_idx,
-                      &ctx->sort_key_out, &ctx->order, &ctx->list_b, &ctx->rstate};
+                      &ctx->sort_key_out, &ctx->order, &ctx->list_b, &ctx->rstate, &ctx->att_base, &ctx->scr, &ctx->scrq,
+                      &ctx->scr_len, &ctx->scr_off, &ctx->hp_len};
     for (DevBuf *b : bufs)
         if (b->p) e = hipFree(b->p);
     if (ctx->evt_ok)
@@ -761,7 +941,8 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         return fail(ctx, NS_EINVAL, "model has no unaligned-length KDE");
     if (prm->fastq && !(ctx->m.flags & NS_MODEL_HAS_QUALS)) return fail(ctx, NS_EINVAL, "model has no quality tables");
     if (prm->chimeric && !(ctx->m.flags & NS_MODEL_HAS_CHIMERIC)) return fail(ctx, NS_EINVAL, "model has no chimeric tables");
-    if (prm->kmer_bias) return fail(ctx, NS_EINVAL, "homopolymer mode (-k) is not available in this build");
+    const bool hp_on = prm->kmer_bias && prm->kind == NS_KIND_ALIGNED;      // S:1413: only aligned segments; --perfect never
+    if (hp_on && !(ctx->m.flags & NS_MODEL_HAS_HP)) return fail(ctx, NS_EINVAL, "-k needs the homopolymer model (-hp)");
     if (prm->n_reads > 0x7ffffff0ull) return fail(ctx, NS_EINVAL, "batch too large (split into several calls)");
     if (prm->first_read + prm->n_reads >= (1ull << 40)) return fail(ctx, NS_EINVAL, "read index exceeds 2^40");
     HIPCHK(hipSetDevice(ctx->device));
@@ -778,7 +959,9 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         (rc = ensure(ctx, ctx->stats, 8 * sizeof(unsigned long long))) ||
         (rc = ensure(ctx, ctx->sort_key, (n + 1) * 4)) || (rc = ensure(ctx, ctx->sort_idx, (n + 1) * 4)) ||
         (rc = ensure(ctx, ctx->sort_key_out, (n + 1) * 4)) || (rc = ensure(ctx, ctx->order, (n + 1) * 4)) ||
-        (rc = ensure(ctx, ctx->list_b, (n + 1) * 4)) || (rc = ensure(ctx, ctx->rstate, (n + 1) * 4)))
+        (rc = ensure(ctx, ctx->list_b, (n + 1) * 4)) || (rc = ensure(ctx, ctx->rstate, (n + 1) * 4)) ||
+        (rc = ensure(ctx, ctx->att_base, (n + 1) * 4)) || (rc = ensure(ctx, ctx->scr_len, (n + 1) * 8)) ||
+        (rc = ensure(ctx, ctx->scr_off, (n + 1) * 8)))
         return rc;
 
     GenArgs A;
@@ -792,7 +975,9 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     A.name_len = (uint16_t *)ctx->name_len.p; A.reads = (ns_read *)ctx->reads.p;
     A.stats = (unsigned long long *)ctx->stats.p;
     A.sort_key = (uint32_t *)ctx->sort_key.p; A.sort_idx = (uint32_t *)ctx->sort_idx.p;
-    A.rstate = (uint32_t *)ctx->rstate.p;
+    A.rstate = (uint32_t *)ctx->rstate.p; A.att_base = (uint32_t *)ctx->att_base.p;
+    A.scr_len = (uint64_t *)ctx->scr_len.p; A.scr_off = (uint64_t *)ctx->scr_off.p;
+    A.hp = hp_on ? 1u : 0u; A.keep_state = 0;
     A.next_n = (uint32_t *)((unsigned long long *)ctx->stats.p + 6);
     uint32_t *list_a = (uint32_t *)ctx->order.p, *list_b = (uint32_t *)ctx->list_b.p;
     const dim3 blk(256);
@@ -805,6 +990,8 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     const bool lds = ctx->lds_tables && prm->kind != NS_KIND_PERFECT;
     float ms = 0;
     HIPCHK(hipEventRecord(ctx->evt[0], st));
+    double ms_hp = 0;
+    for (int hp_round = 0;; ++hp_round) {
     for (int retry = 0;; ++retry) {
         A.cap_rate = cap_rate;
         HIPCHK(hipMemsetAsync(ctx->stats.p, 0, 8 * sizeof(unsigned long long), st));
@@ -869,6 +1056,37 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         if (retry >= 6) return fail(ctx, NS_ENOMEM, "event capacity overflow persists after 6 retries");
         cap_rate *= 2.0; A.cap_gap_mul *= 2;          // rare: re-plan the batch with twice the event capacity
     }
+    if (!A.hp) break;
+    // ---- -k stage 1: filter events, write the pre-homopolymer reads to scratch, count the final lengths ----
+    HIPCHK(hipEventRecord(ctx->evt[9], st));
+    if ((rc = ensure(ctx, ctx->hp_len, (size_t)tot_pieces * 4 + 64))) return rc;
+    A.hp_len = (uint32_t *)ctx->hp_len.p;
+    k_hp_filter<<<grid_t, blk, 0, st>>>(A);
+    HIPCHK(hipGetLastError());
+    if ((rc = scan_u64(ctx, A.scr_len, A.scr_off, n + 1))) return rc;
+    uint64_t scr_bytes = 0;
+    HIPCHK(hipMemcpyAsync(&scr_bytes, A.scr_off + n, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if ((rc = ensure(ctx, ctx->scr, (size_t)scr_bytes + 64)) || (prm->fastq && (rc = ensure(ctx, ctx->scrq, (size_t)scr_bytes + 64)))) return rc;
+    A.scr = (uint8_t *)ctx->scr.p; A.scrq = (uint8_t *)ctx->scrq.p;
+    if (prm->fastq) k_materialise<true><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->ref_nbases, ctx->dbg);
+    else k_materialise<false><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->ref_nbases, ctx->dbg);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync((unsigned long long *)ctx->stats.p + 1, 0, sizeof(unsigned long long), st));
+    HIPCHK(hipMemsetAsync((unsigned long long *)ctx->stats.p + 5, 0, sizeof(unsigned long long), st));
+    k_hp_count<<<grid_t, blk, 0, st>>>(A);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->evt[10], st));
+    HIPCHK(hipMemcpyAsync(stats, ctx->stats.p, sizeof stats, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipEventElapsedTime(&ms, ctx->evt[9], ctx->evt[10]));
+    ms_hp += ms;
+    if (!stats[5]) break;
+    // some reads failed the final length check (S:1429): they advanced their attempt state; every other read restarts at
+    // its accepted attempt, so re-running the batch reproduces them bit for bit
+    if (hp_round >= (int)NS_MAX_ATTEMPT) return fail(ctx, NS_EINVAL, "reads keep failing the final length check in -k mode");
+    A.keep_state = 1;
+    }
     if ((rc = scan_u64(ctx, A.rec_len, A.rec_off, n + 1))) return rc;
     if (prm->emit_errlog && (rc = scan_u64(ctx, A.err_len, A.err_off, n + 1))) return rc;
     HIPCHK(hipMemcpyAsync(&info->record_bytes, A.rec_off + n, 8, hipMemcpyDeviceToHost, st));
@@ -882,7 +1100,10 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     k_names<<<grid_t, blk, 0, st>>>(A);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->evt[6], st));
-    if (prm->emit_records) {
+    if (A.hp) {
+        k_hp_write<<<grid_t, blk, 0, st>>>(A);
+        HIPCHK(hipGetLastError());
+    } else if (prm->emit_records) {
         if (prm->fastq) k_materialise<true><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->ref_nbases, ctx->dbg);
         else k_materialise<false><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->ref_nbases, ctx->dbg);
         HIPCHK(hipGetLastError());
@@ -899,6 +1120,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     HIPCHK(hipEventElapsedTime(&ms, ctx->evt[5], ctx->evt[6])); info->ms_kernel[NS_K_SCAN] = ms;      // names/framing
     HIPCHK(hipEventElapsedTime(&ms, ctx->evt[6], ctx->evt[7])); info->ms_kernel[NS_K_MATERIALISE] = ms;
     HIPCHK(hipEventElapsedTime(&ms, ctx->evt[7], ctx->evt[8])); info->ms_kernel[NS_K_ERRLOG] = ms;
+    info->ms_kernel[NS_K_HP] = ms_hp;
     info->n_reads = n; info->n_pieces = tot_pieces; info->n_events = tot_cap;
     info->total_bases = stats[1]; info->total_ref_bases = stats[2]; info->events_used = stats[3];
     ctx->last = *info;

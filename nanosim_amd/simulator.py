@@ -148,14 +148,14 @@ def validate_genome_args(a, parser_g):
 
 
 def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, chimeric, min_len, max_len, median_len,
-                   sd_len, want_errlog):
+                   sd_len, want_errlog, kmer_bias=0):
     done = 0
     with open(out_path, "wb") as fr:
         fe = open(err_path, "wb") if err_path else None
         try:
             while done < count:
                 n = min(BATCH_READS, count - done)
-                p = E.make_params(seed=seed, first_read=first + done, n_reads=n, kind=kind, fastq=fastq, chimeric=chimeric,
+                p = E.make_params(seed=seed, first_read=first + done, n_reads=n, kind=kind, fastq=fastq, chimeric=chimeric, kmer_bias=kmer_bias,
                                   min_len=min_len, max_len=max_len, median_len=median_len, sd_len=sd_len,
                                   emit_records=True, emit_errlog=bool(fe))
                 b = eng.generate(p)
@@ -180,8 +180,8 @@ def run_genome(a, parser_g):
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if a.KmerBias:
-        sys.stderr.write("\n-k/--KmerBias (homopolymer expansion/contraction) is not available in this build yet\n")
+    if a.KmerBias and not a.homopolymer:
+        sys.stderr.write("\n-k/--KmerBias needs -hp (the reference crashes on the missing homopolymer parameters, S:504,639)\n")
         sys.exit(1)
     if rank == 0:
         print("\nrunning the code with following parameters:\n")
@@ -234,7 +234,7 @@ def run_genome(a, parser_g):
     sub_err = out + "_error_profile%d" % rank
     _write_batches(eng, sub_reads, sub_err, seed=seed, first=lo, count=hi - lo, kind=kind, fastq=a.fastq,
                    chimeric=a.chimeric, min_len=a.min_len, max_len=max_len, median_len=a.median_len, sd_len=a.sd_len,
-                   want_errlog=True)
+                   want_errlog=True, kmer_bias=a.KmerBias or 0)
     if dist is not None:
         dist.barrier()
     if rank == 0:

@@ -23,7 +23,8 @@ def compare(batch, exp, params):
     reads, pieces, events = batch.reads(), batch.pieces(), batch.events()
     er, ep, ee = exp["reads"], exp["pieces"], exp["events"]
     assert len(reads) == len(er)
-    for f in ("piece_off", "n_pieces", "reversed", "flags", "head", "tail", "seq_len", "attempts", "rec_off"):
+    fields = ("piece_off", "n_pieces", "reversed", "flags", "head", "tail", "seq_len", "attempts")
+    for f in fields + (("rec_off",) if params.emit_records else ()):        # the oracle always formats records
         assert np.array_equal(reads[f], er[f]), f
     assert len(pieces) == len(ep)
     for f in ("ref_gpos", "chrom", "pos", "ref_len", "out_len", "n_ev", "kind"):
@@ -36,6 +37,9 @@ def compare(batch, exp, params):
     assert int(batch.info.events_used) == len(ee)
     assert int(batch.info.total_bases) == exp["total_bases"]
     assert int(batch.info.total_ref_bases) == exp["total_ref_bases"]
+    if not params.emit_records:
+        assert batch.info.record_bytes == 0
+        return
     rec = batch.records()
     assert rec.tobytes() == exp["records"].tobytes()
     if params.emit_errlog:
@@ -54,6 +58,11 @@ CASES = [
     dict(kind=E.NS_KIND_UNALIGNED, n_reads=100, median_len=800, sd_len=0.5),
     dict(kind=E.NS_KIND_ALIGNED, n_reads=1, first_read=(1 << 33) + 5, emit_errlog=True),
     dict(kind=E.NS_KIND_ALIGNED, n_reads=0),
+    dict(kind=E.NS_KIND_ALIGNED, n_reads=200, kmer_bias=5, emit_errlog=True),                      # -hp -k 5
+    dict(kind=E.NS_KIND_ALIGNED, n_reads=200, kmer_bias=5, fastq=True, chimeric=True, emit_errlog=True),
+    dict(kind=E.NS_KIND_ALIGNED, n_reads=4000, kmer_bias=4, fastq=True, min_len=2000, max_len=9000),   # final-length re-check + batch re-run
+    dict(kind=E.NS_KIND_ALIGNED, n_reads=100, kmer_bias=6, emit_records=False),
+    dict(kind=E.NS_KIND_PERFECT, n_reads=50, kmer_bias=5),                                          # -k is ignored with --perfect
 ]
 
 
@@ -100,9 +109,17 @@ def test_reads_do_not_depend_on_batching(eng, small_ref):
 
 
 def test_error_paths(eng, small_ref):
-    p = E.make_params(seed=1, first_read=0, n_reads=10, max_len=small_ref.max_chrom, kmer_bias=5)
-    with pytest.raises(E.EngineError):
-        eng.generate(p)
+    e2 = E.Engine(0)
+    try:
+        e2.set_reference(small_ref)
+        import os
+        from tests.conftest import GOLDEN
+        e2.load_model(M.load_model(os.path.join(GOLDEN, "model_small", "training")))      # no -hp tables
+        p = E.make_params(seed=1, first_read=0, n_reads=10, max_len=small_ref.max_chrom, kmer_bias=5)
+        with pytest.raises(E.EngineError):
+            e2.generate(p)
+    finally:
+        e2.close()
     p = E.make_params(seed=1, first_read=0, n_reads=10, min_len=10 ** 7, max_len=10 ** 8)
     with pytest.raises(E.EngineError):
         eng.generate(p)
