@@ -166,9 +166,11 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     return v;
 }
 
-template <bool LDS_TABLES>
-__global__ void __launch_bounds__(256) k_chain(GenArgs A) {
+template <bool LDS_TABLES, bool COOP>
+__global__ void __launch_bounds__(COOP ? 64 : 256) k_chain(GenArgs A) {
     extern __shared__ uint64_t lds_tbl[];
+    CoopLds *coop = nullptr;
+    if constexpr (COOP) { __shared__ CoopLds coop_lds; coop = &coop_lds; }
     Tabs T;
     if (LDS_TABLES) {
         for (uint32_t i = threadIdx.x; i < A.m.ct.n_words; i += blockDim.x) lds_tbl[i] = A.m.chain_blob[i];
@@ -176,12 +178,15 @@ __global__ void __launch_bounds__(256) k_chain(GenArgs A) {
         T.w = lds_tbl;
     } else T.w = A.m.chain_blob;
     const ChainTab &ct = A.m.ct;
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // COOP: the whole wavefront works on ONE read (blockIdx.x-th entry of the list); lane 0 does the bookkeeping stores
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t tid = COOP ? (uint64_t)blockIdx.x : (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool lead = COOP ? lane == 0 : true;
     const ns_params &prm = A.prm;
     // The list is sorted by descending length, so the first workgroups carry the longest chains and set the makespan
     // (a 120 kb read is ~3800 dependent iterations): give them issue priority over the short-read waves they share a
     // SIMD with.
-    if (blockIdx.x < (gridDim.x >> 6)) __builtin_amdgcn_s_setprio(3);
+    if (COOP || blockIdx.x < (gridDim.x >> 6)) __builtin_amdgcn_s_setprio(3);
     else if (blockIdx.x < (gridDim.x >> 4)) __builtin_amdgcn_s_setprio(2);
     else if (blockIdx.x < (gridDim.x >> 2)) __builtin_amdgcn_s_setprio(1);
     unsigned long long st_over = 0, st_bases = 0, st_ref = 0, st_ev = 0;
@@ -211,13 +216,14 @@ __global__ void __launch_bounds__(256) k_chain(GenArgs A) {
                 EList32 e;
                 if (kind == NS_KIND_PERFECT) { e.l_new = e.middle_ref = m32; }
                 else if (p.kind) e = chain_unaligned_error_list(T, ct, m32, key, sid, a, sink);
+                else if (COOP) e = coop_error_list(T, ct, m32, key, sid, a, sink, *coop, lane);
                 else e = chain_error_list(T, ct, m32, key, sid, a, sink);
                 p.ev_off = ev_off + evn;
                 p.ref_len = (uint32_t)(e.middle_ref < 0 ? 0 : e.middle_ref);
                 p.out_len = (uint32_t)((e.middle_ref < 0 ? 0 : e.middle_ref) + sink.shift);
                 p.n_ev = sink.n;
                 p.chrom = (p.kind && kind == NS_KIND_ALIGNED && m32 == 0) ? 1u : 0u;   // empty gap marker (S:1553-1554)
-                pc[pi] = p;
+                pc[pi] = p;          // COOP: every lane stores the same value (and later reads back its own store)
                 evn += sink.n;
                 if (!p.kind) total += e.l_new;                                           // S:1362
                 if (kind == NS_KIND_UNALIGNED) total = e.middle_ref;                     // S:1503
@@ -269,18 +275,22 @@ __global__ void __launch_bounds__(256) k_chain(GenArgs A) {
                     }
                 }
             }
-            A.name_len[r] = (uint16_t)nl;
-            A.rec_len[r] = prm.emit_records ? (uint64_t)nl + 2 + (uint64_t)seq_len + 1 + (prm.fastq ? (uint64_t)seq_len + 3 : 0) : 0;
-            A.err_len[r] = err_len;
-            st_bases = A.hp ? 0ull : (unsigned long long)seq_len; st_ref = ref_bases; st_ev = evn;
+            if (lead) {
+                A.name_len[r] = (uint16_t)nl;
+                A.rec_len[r] = prm.emit_records ? (uint64_t)nl + 2 + (uint64_t)seq_len + 1 + (prm.fastq ? (uint64_t)seq_len + 3 : 0) : 0;
+                A.err_len[r] = err_len;
+                st_bases = A.hp ? 0ull : (unsigned long long)seq_len; st_ref = ref_bases; st_ev = evn;
+            }
             accepted = true;
         } while (false);
-        if (overflow) st_over = 1;
-        A.reads[r] = rd;
-        if (accepted) A.att_base[r] = a;            // a re-run of the batch starts every read at its accepted attempt
-        if (!accepted && !overflow) {
-            A.rstate[r] = (epoch & 0xffffu) | fails << 16;
-            A.next_list[atomicAdd(A.next_n, 1u)] = (uint32_t)r;
+        if (lead) {
+            if (overflow) st_over = 1;
+            A.reads[r] = rd;
+            if (accepted) A.att_base[r] = a;            // a re-run of the batch starts every read at its accepted attempt
+            if (!accepted && !overflow) {
+                A.rstate[r] = (epoch & 0xffffu) | fails << 16;
+                A.next_list[atomicAdd(A.next_n, 1u)] = (uint32_t)r;
+            }
         }
     }
     // one atomic per wavefront and counter
@@ -625,7 +635,8 @@ struct DevBuf {
 
 struct ns_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: cooperative chain of the longest reads, concurrent with the bulk
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     bool has_model = false, has_ref = false, has_batch = false;
     DevModel m{};
@@ -636,11 +647,12 @@ struct ns_ctx {
     double cap_rate = 0.1;
     uint64_t ref_nbases = 0;
     uint32_t dbg = 0;          // NS_DEBUG_SKIP: phase-ablation bits for profiling only (results are wrong when set)
+    uint32_t coop_min = 16384, coop_shift = 9;   // cooperative chain for the longest n>>shift reads of batches >= min (env: NS_COOP_MIN, NS_COOP_SHIFT)
     // planning + result buffers
     DevBuf n_pieces, piece_off, ev_cap, ev_off, rec_len, rec_off, err_len, err_off, name_len;
     DevBuf reads, pieces, events, records, errlog, stats, scan_tmp;
     DevBuf sort_key, sort_idx, sort_key_out, order, list_b, rstate, att_base, scr, scrq, scr_len, scr_off, hp_len;
-    bool lds_tables = false;
+    bool lds_tables = false, coop_ok = false;
     size_t lds_bytes = 0;
     ns_batch_info last{};
     hipEvent_t evt[16]{};
@@ -698,8 +710,13 @@ int ns_create(int device, ns_ctx **out) {
     }
     for (auto &e : ctx->evt)
         if (hipEventCreate(&e) != hipSuccess) { delete ctx; return NS_EHIP; }
+    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { delete ctx; return NS_EHIP; }
     ctx->evt_ok = true;
     if (const char *d = getenv("NS_DEBUG_SKIP")) ctx->dbg = (uint32_t)atoi(d);
+    if (const char *d = getenv("NS_COOP_MIN")) ctx->coop_min = (uint32_t)atoi(d);
+    if (const char *d = getenv("NS_COOP_SHIFT")) ctx->coop_shift = (uint32_t)atoi(d) & 31u;
     *out = ctx;
     return NS_OK;
 }
@@ -713,6 +730,9 @@ void ns_destroy(ns_ctx *ctx) {
     if (!ctx) return;
     hipError_t e = hipSetDevice(ctx->device); (void)e;
     if (ctx->stream) { e = hipStreamSynchronize(ctx->stream); e = hipStreamDestroy(ctx->stream); }
+    if (ctx->stream2) { e = hipStreamSynchronize(ctx->stream2); e = hipStreamDestroy(ctx->stream2); }
+    if (ctx->ev_fork) e = hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) e = hipEventDestroy(ctx->ev_join);
     free_pool(ctx->model_allocs);
     free_pool(ctx->ref_allocs);
     if (ctx->ref_bases_owned) e = hipFree(ctx->ref_bases_owned);
@@ -896,6 +916,9 @@ int ns_load_model(ns_ctx *ctx, const ns_model_tables *t) {
         if ((rc = upload(ctx, pool, blob.data(), blob.size(), &m.chain_blob))) return rc;
         ctx->lds_bytes = blob.size() * 8;
         ctx->lds_tables = ctx->lds_bytes <= 40 * 1024;     // keep >= 4 workgroups of 256 threads per CU
+        double vmax = 0;
+        for (uint32_t k2 = 0; k2 < nseg; ++k2) if (t->mm_vhi[k2] > vmax) vmax = t->mm_vhi[k2];
+        ctx->coop_ok = t->mm_nbins <= COOP_MAX_BINS && vmax < 65535.0;   // the cooperative chain keeps match lengths in 16 bits
     }
     for (int k = 0; k < NS_KDE_COUNT; ++k) {
         m.kde[k].n = t->kde[k].n; m.kde[k].bw = t->kde[k].bw;
@@ -1034,9 +1057,22 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
             const dim3 grid_p((cur_n + 255) / 256);
             if (a > 0) { k_lengths<<<grid_p, blk, 0, st>>>(A); HIPCHK(hipGetLastError()); }
             HIPCHK(hipEventRecord(ctx->evt[3], st));
-            if (lds) k_chain<true><<<grid_p, blk, ctx->lds_bytes, st>>>(A);
-            else k_chain<false><<<grid_p, blk, 0, st>>>(A);
+            uint32_t n_coop = 0;
+            if (a == 0 && ctx->coop_ok && prm->kind == NS_KIND_ALIGNED && cur_n >= ctx->coop_min) n_coop = cur_n >> ctx->coop_shift;   // longest 0.2 %
+            if (n_coop) {      // wave-per-read for the head of the (length-sorted) list, thread-per-read for the rest
+                GenArgs B = A; B.list_n = n_coop;
+                HIPCHK(hipEventRecord(ctx->ev_fork, st));
+                HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+                k_chain<false, true><<<dim3(n_coop), dim3(64), 0, ctx->stream2>>>(B);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+                A.list = cur + n_coop; A.list_n = cur_n - n_coop;
+            }
+            const dim3 grid_c((A.list_n + 255) / 256);
+            if (lds) k_chain<true, false><<<grid_c, blk, ctx->lds_bytes, st>>>(A);
+            else k_chain<false, false><<<grid_c, blk, 0, st>>>(A);
             HIPCHK(hipGetLastError());
+            if (n_coop) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
             HIPCHK(hipEventRecord(ctx->evt[4], st));
             HIPCHK(hipMemcpyAsync(stats, ctx->stats.p, sizeof stats, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));

@@ -159,3 +159,107 @@ __device__ __forceinline__ EList32 chain_unaligned_error_list(const Tabs &T, con
     }
     return EList32{l_new, middle_ref};
 }
+
+// ---- cooperative error_list: one read per wavefront, for the few longest reads of a batch ---------------------
+// The chain is sequential, but what an iteration draws depends on very little state: the error type on the Markov
+// state (7 rows), the run length on the error type (3), the next match length on the bin of the previous match
+// length (<= 16 columns).  Each lane therefore evaluates ONE future iteration for EVERY possible state / type / bin
+// (its Philox block and all table searches, including the fp64 interpolation) and leaves the results in LDS; the
+// dependent part that remains is a walk over 64 iterations of four small table reads each (~10x shorter critical
+// path than the thread-per-read chain).  Produces exactly the events of chain_error_list.
+#define COOP_MAX_BINS 16u
+struct CoopLds {
+    uint32_t err_tab[64];                 // 2 bits per Markov state
+    uint16_t step_tab[64][4];             // run length per error type
+    uint16_t match_tab[64][COOP_MAX_BINS];
+    ns_event ev_buf[64];
+};
+
+__device__ inline EList32 coop_error_list(const Tabs &T, const ChainTab &c, int32_t m_ref, const ns_key &key, uint32_t seg,
+                                          uint32_t attempt, EvSink32 &s, CoopLds &S, uint32_t lane) {
+    int32_t l_new = m_ref, pos = 0, middle_ref = m_ref;
+    int state = NS_ST_START;
+    u32x4 w = ns_draw(key, ST_EVENT, seg, attempt, 0, 0);
+    int32_t prev_match = ecdf_lookup_g(T.d(c.fm_hi), T.d(c.fm_vhi), c.fm_n, c.fm_vlo0, T.h(c.fm_guide), w.x);   // S:1843-1850
+    if (prev_match < 2) prev_match = 2;
+    pos += prev_match;
+    uint32_t it0 = 1;
+    int32_t last_ins_pos = -1;
+    const double *trans = T.d(c.trans);
+    const int32_t *bins = T.i(c.mm_bin);
+    const uint32_t *seg_off = T.u(c.mm_seg_off);
+    const uint8_t *bin_lut = reinterpret_cast<const uint8_t *>(T.w + c.mm_bin_lut);
+    while (pos < middle_ref) {                                                                     // S:1858
+        // ---- parallel: lane evaluates iteration it0+lane for every state / type / bin
+        {
+            const u32x4 wi = ns_draw(key, ST_EVENT, seg, attempt, it0 + lane, 0);
+            uint32_t eb = 0;
+            const double pe = u32_to_p(wi.x);
+#pragma unroll
+            for (int st = 0; st < 7; ++st) eb |= (uint32_t)trans_pick(trans + 3 * st, pe) << (2 * st);
+            S.err_tab[lane] = eb;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) S.step_tab[lane][t] = (uint16_t)run_length_t(T, c, t, wi.y, wi.z);
+            for (uint32_t b = 0; b < c.mm_nbins; ++b) {
+                const uint32_t o = seg_off[b];
+                S.match_tab[lane][b] = (uint16_t)ecdf_lookup_g(T.d(c.mm_hi) + o, T.d(c.mm_vhi) + o, seg_off[b + 1] - o,
+                                                               T.d(c.mm_vlo0)[b], T.h(c.mm_guide) + 256 * b, wi.w);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- sequential walk (uniform over the wavefront): four small LDS reads per iteration
+        uint32_t nl = 0;                                           // events buffered in this block
+        uint32_t i = 0;
+        for (; i < 64 && pos < middle_ref; ++i) {
+            const int error = (int)((S.err_tab[i] >> (2 * state)) & 3u);                          // S:1860-1864
+            int32_t step = S.step_tab[i][error];                                                  // S:1866-1873
+            if (error == NS_INS) l_new += step; else if (error == NS_DEL) l_new -= step;
+            int32_t epos = pos;
+            if (error != NS_INS) {                                                                 // S:1875-1880
+                pos += step;
+                if (pos >= middle_ref) { l_new += pos - middle_ref; middle_ref = pos; }
+            } else {                                                                               // S:1881-1882
+                if (last_ins_pos == pos && (nl > 0 || s.n > 0)) {                                  // dict key collision
+                    if (nl > 0) --nl; else --s.n;
+                    s.shift -= (int32_t)s.last_ins_len;
+                }
+                last_ins_pos = pos;
+            }
+            {   // ev_push32 into the block buffer
+                const uint32_t l = step > (int32_t)NS_EV_LEN_MAX ? NS_EV_LEN_MAX : (uint32_t)step;
+                ns_event e; e.pos = (uint32_t)epos; e.info = ns_ev_pack(l, (uint32_t)error, s.shift);
+                if (lane == 0) S.ev_buf[nl] = e;
+                ++nl;
+                if (error == NS_INS) { s.shift += (int32_t)l; s.last_ins_len = l; } else if (error == NS_DEL) s.shift -= (int32_t)l;
+            }
+            state = NS_ST_MIS + error;                                                             // S:1884
+            uint32_t b;                                                                            // S:1891-1893
+            if ((uint32_t)prev_match < 256u) b = bin_lut[prev_match];
+            else {
+                for (b = 0; b < c.mm_nbins; ++b)
+                    if (bins[2 * b] <= prev_match && prev_match < bins[2 * b + 1]) break;
+                if (b >= c.mm_nbins) b = c.mm_nbins - 1;
+            }
+            step = S.match_tab[i][b];
+            if (prev_match == 0 && step == 0) step = 1;                                            // S:1900-1901
+            prev_match = step;
+            if (pos + prev_match > middle_ref) { l_new += pos + prev_match - middle_ref; middle_ref = pos + prev_match; }
+            pos += prev_match;
+            if (prev_match == 0) state += 3;                                                       // S:1913-1914
+            else last_ins_pos = -1;
+        }
+        // ---- flush the block's events, one lane per event
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nl) {
+            if (s.n + lane < s.cap) s.ev[s.n + lane] = S.ev_buf[lane];
+        }
+        if (s.n + nl > s.cap) s.overflow = true;
+        s.n += nl;
+        it0 += i;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    return EList32{l_new, middle_ref};
+}

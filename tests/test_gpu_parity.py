@@ -123,3 +123,21 @@ def test_error_paths(eng, small_ref):
     p = E.make_params(seed=1, first_read=0, n_reads=10, min_len=10 ** 7, max_len=10 ** 8)
     with pytest.raises(E.EngineError):
         eng.generate(p)
+
+
+def test_cooperative_chain_equals_oracle(small_model, small_ref, monkeypatch):
+    """The wave-per-read chain used for the longest reads of big batches, forced onto half of a small batch."""
+    monkeypatch.setenv("NS_COOP_MIN", "1")
+    monkeypatch.setenv("NS_COOP_SHIFT", "1")
+    e = E.Engine(0)
+    try:
+        e.set_reference(small_ref)
+        e.load_model(small_model)
+        for kw in (dict(n_reads=500, emit_errlog=True), dict(n_reads=400, chimeric=True, fastq=True, emit_errlog=True),
+                   dict(n_reads=300, min_len=3000, max_len=9000), dict(n_reads=300, kmer_bias=5, fastq=True, emit_errlog=True)):
+            args = dict(seed=31337, first_read=7, max_len=small_ref.max_chrom)
+            args.update(kw)
+            p = E.make_params(**args)
+            compare(e.generate(p), O.generate(small_model, small_ref, p), p)
+    finally:
+        e.close()
