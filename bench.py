@@ -139,6 +139,17 @@ def main():
                               16 * int(x.events_used) + 32 * int(x.n_reads) for x in infos])
         achieved = per_launch / (kms[dom] * 1e-3) / 1e9
         device_ms = float(np.mean([x.ms_total for x in infos]))
+        # HBM traffic of the dominant kernel: rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE) cannot be
+        # collected from inside this process; the per-read figure measured by scripts/profile_round.sh is committed in
+        # profiles/r01/pmc_summary.json and scaled to this launch size.  null when that file has no entry for the kernel.
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")))
+            for kname, kv in pm["kernels"].items():
+                if kname.startswith(dom.split("<")[0]) and "hbm_bytes_per_read" in kv and not a.fastq:
+                    traffic = kv["hbm_bytes_per_read"] * n
+        except (OSError, ValueError, KeyError):
+            traffic = None
         out = {
             "metric": "simulated reads/sec (genome mode, mean 8 kb)", "value": world * n * a.steps / dt, "unit": "reads/s",
             "bases_per_s": tot_bases / dt,
@@ -151,7 +162,8 @@ def main():
                        "parallelism": "read-index sharding x%d, 1 RCCL broadcast of the reference" % world},
             "device_ms_per_step": device_ms, "kernel_ms": kms,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/r01/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per read x reads per launch)",
                          "algorithmic_bytes_per_launch": float(per_launch),
                          "all_kernels_achieved": per_launch / (sum(kms.values()) * 1e-3) / 1e9},
         }
