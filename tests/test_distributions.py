@@ -162,3 +162,18 @@ def test_gpu_distributions_match_reference(golden_distributions, small_model, sm
         assert np.max(np.abs(np.cumsum(h) / h.sum() - np.cumsum(ref_h) / ref_h.sum())) <= KS_GATE
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_gpu_homopolymer_mode_distributions_match_reference(golden_distributions, small_model, small_ref):
+    eng = E.Engine(0)
+    try:
+        eng.set_reference(small_ref)
+        eng.load_model(small_model)
+        p = E.make_params(seed=777, first_read=0, n_reads=200000, fastq=True, kmer_bias=5, max_len=small_ref.max_chrom)
+        b = eng.generate(p)
+        fx = golden_distributions["hp"]
+        rep = check_aligned(per_read_metrics(b.reads(), b.pieces(), b.events()), fx, "gpu-hp", gate=0.02, mean_tol=0.03)
+        print("KS distances GPU (-k 5) vs reference:", rep)
+    finally:
+        eng.close()
