@@ -141,3 +141,30 @@ def test_cooperative_chain_equals_oracle(small_model, small_ref, monkeypatch):
             compare(e.generate(p), O.generate(small_model, small_ref, p), p)
     finally:
         e.close()
+
+
+def test_large_tables_take_the_global_memory_path(tmp_path, small_ref, monkeypatch):
+    """A model shaped like a real trained one (15 previous-match bins, 1500-row ECDFs): the chain tables (~360 KB) do not
+    fit the LDS budget, so k_chain reads them from global memory; the cooperative chain is forced on as well."""
+    from nanosim_amd import synth
+    bins = ((0, 1), (1, 2), (2, 3), (3, 5), (5, 7), (7, 10), (10, 14), (14, 19), (19, 25), (25, 33), (33, 45), (45, 60),
+            (60, 90), (90, 150), (150, 1500))
+    spec = synth.SynthModelSpec(n_train=3000, seed=99, ecdf_rows=1500, mm_bins=bins,
+                                mm_means=tuple(20.0 + 2 * i for i in range(15)), mm_zero=(0.0,) + (0.02,) * 14, fm_mean=25.0)
+    prefix = str(tmp_path / "big" / "training")
+    synth.write_model(prefix, spec, write_pkl=False)
+    mdl = M.load_model(prefix, chimeric=True, homopolymer=True, fastq=True)
+    assert sum(len(c.hi) for c in mdl.match_markov) * 16 > 64 * 1024
+    monkeypatch.setenv("NS_COOP_MIN", "1")
+    monkeypatch.setenv("NS_COOP_SHIFT", "2")
+    e = E.Engine(0)
+    try:
+        e.set_reference(small_ref)
+        e.load_model(mdl)
+        for kw in (dict(n_reads=600, emit_errlog=True), dict(n_reads=300, fastq=True, chimeric=True, kmer_bias=5)):
+            args = dict(seed=4242, first_read=0, max_len=small_ref.max_chrom)
+            args.update(kw)
+            p = E.make_params(**args)
+            compare(e.generate(p), O.generate(mdl, small_ref, p), p)
+    finally:
+        e.close()
