@@ -655,6 +655,130 @@ typedef struct nso_out {
 
 #define NSO_MAX_SEG 64
 
+/* ================================================================================================
+ * metagenome mode
+ * ============================================================================================== */
+enum { ST_SPECIES = 21 };
+
+typedef struct nso_meta {            /* species view of the reference (src/simulator.py:284-339) */
+    uint32_t nspecies;
+    const uint32_t *species_chrom_off;   /* [nspecies+1] */
+    const double *abun;                  /* dict_abun, in species order */
+    const double *abun_inflated;         /* dict_abun_inflated (chimeric) or NULL */
+} nso_meta;
+
+/* assign_species (S:758-811).  lengths/segs are the pass's filtered length list and remaining segment counts;
+ * out_species/out_lengths get one entry per assigned segment, out_segs the sorted segment counts.  Returns the number of
+ * assigned segments.  Draws: tape (u for random.choice -> floor(u*n); random.uniform(0,100) -> 100*u) or Philox keyed
+ * (ST_SPECIES, attempt = pass, idx = segment pointer): word 0 = choice, word 1 = uniform. */
+static int cmp_desc_d(const void *a, const void *b) { double x = *(const double *)a, y = *(const double *)b; return x < y ? 1 : x > y ? -1 : 0; }
+static int cmp_desc_i(const void *a, const void *b) { int32_t x = *(const int32_t *)a, y = *(const int32_t *)b; return x < y ? 1 : x > y ? -1 : 0; }
+
+uint64_t nso_assign_species(const nso_meta *mg, const double *lengths, uint64_t n_len, const int32_t *segs, uint64_t n_reads,
+                            const double *current_bases, nso_draw *d, uint32_t pass, uint16_t *out_species, double *out_lengths,
+                            int32_t *out_segs) {
+    const uint32_t ns = mg->nspecies;
+    memcpy(out_segs, segs, sizeof(int32_t) * n_reads);
+    qsort(out_segs, n_reads, sizeof(int32_t), cmp_desc_i);                      /* S:760 */
+    uint64_t segs_chimera = 0;
+    for (uint64_t i = 0; i < n_reads; ++i) if (segs[i] > 1) segs_chimera += (uint64_t)segs[i];   /* S:761 */
+    if (segs_chimera > n_len) segs_chimera = n_len;
+    memcpy(out_lengths, lengths, sizeof(double) * n_len);
+    qsort(out_lengths + segs_chimera, n_len - segs_chimera, sizeof(double), cmp_desc_d);          /* S:764-765 */
+    double bases_to_add = 0;
+    for (uint64_t i = 0; i < n_len; ++i) bases_to_add += lengths[i];             /* sum(length_list), left to right */
+    double cur_total = 0, total_abun = 0;
+    for (uint32_t s = 0; s < ns; ++s) { cur_total += current_bases[s]; total_abun += mg->abun[s]; }
+    const double total_bases = bases_to_add + cur_total;
+    double quota[256];
+    for (uint32_t s = 0; s < ns; ++s) quota[s] = total_bases * mg->abun[s] / total_abun - current_bases[s];   /* S:772-775 */
+    uint64_t ptr = 0;
+    uint32_t pre = 0;
+    uint32_t avail[256];
+    for (uint64_t r = 0; r < n_reads; ++r) {
+        const int32_t seg = out_segs[r];
+        if (ptr + (uint64_t)seg > n_len) break;                                  /* S:781-782 */
+        for (int32_t each = 0; each < seg; ++each) {
+            const double len = out_lengths[ptr];
+            uint32_t w[4] = {0, 0, 0, 0};
+            if (!d->mode) {
+                uint32_t c3 = (ST_SPECIES & 0x3fu) << 18 | (pass & 0x3ffu);
+                nso_philox((uint32_t)d->seed, (uint32_t)(d->seed >> 32), (uint32_t)ptr, (uint32_t)(ptr >> 32), (uint32_t)d->read,
+                           c3 | (uint32_t)((d->read >> 32) & 0xffu) << 24, w);
+            }
+            uint32_t sp = 0, n = 0;
+#define NSO_CHOOSE() (d->mode ? avail[(uint32_t)(tape_u(d) * n)] : avail[(uint32_t)(((uint64_t)w[0] * n) >> 32)])
+            if (each == 0) {
+                for (uint32_t s = 0; s < ns; ++s) if (quota[s] - len > 0) avail[n++] = s;          /* S:785-788 */
+                if (!n) for (uint32_t s = 0; s < ns; ++s) if (quota[s] > 0) avail[n++] = s;
+                if (!n) return ptr;                     /* random.choice([]) raises in the reference */
+                sp = NSO_CHOOSE();
+            } else {
+                for (uint32_t s = 0; s < ns; ++s) if (quota[s] - len > 0 && s != pre) avail[n++] = s;   /* S:791-792 */
+                const double p = d->mode ? 100.0 * tape_u(d) : 100.0 * u32_to_p(w[1]);                /* S:793 */
+                if (p <= mg->abun_inflated[pre] && quota[pre] > 0) sp = pre;
+                else if (p > mg->abun_inflated[pre] && n > 0) sp = NSO_CHOOSE();
+                else {
+                    n = 0;
+                    for (uint32_t s = 0; s < ns; ++s) if (quota[s] - len > 0) avail[n++] = s;
+                    if (!n) for (uint32_t s = 0; s < ns; ++s) if (quota[s] > 0) avail[n++] = s;
+                    if (!n) return ptr;
+                    sp = NSO_CHOOSE();
+                }
+            }
+            out_species[ptr] = (uint16_t)sp;
+            quota[sp] -= len;
+            ++ptr;
+            pre = sp;
+        }
+    }
+    return ptr;
+}
+
+/* extract_read, metagenome branch (S:1704-1749).  species < 0: random species (S:1705-1706).  Returns 0 and the global
+ * chromosome index + start, 1 additionally when another species had to be used (the reference prints a warning), <0 if no
+ * chromosome is long enough (assert at S:1726).
+ * Draws: tape (choice -> floor(u*n), randint(a,b) -> a + floor(u*(b-a+1))) or Philox (ST_POS, seg, attempt): block idx 0:
+ * word 0 species, word 1 chromosome, word 2 fallback choice; block idx 1: 53-bit position. */
+int nso_extract_meta(const nso_meta *mg, const uint64_t *chrom_off, const uint8_t *circular, int64_t length, int species,
+                     nso_draw *d, uint32_t seg, uint32_t attempt, uint32_t *chrom, uint64_t *pos) {
+    uint32_t wa[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0};
+    if (!d->mode) { philox_at(d, ST_POS, seg, attempt, 0, 0, wa); philox_at(d, ST_POS, seg, attempt, 1, 0, wb); }
+    int warned = 0;
+    uint32_t s;
+    if (species < 0) s = d->mode ? (uint32_t)(tape_u(d) * mg->nspecies) : (uint32_t)(((uint64_t)wa[0] * mg->nspecies) >> 32);
+    else s = (uint32_t)species;
+    uint32_t nch = mg->species_chrom_off[s + 1] - mg->species_chrom_off[s];
+    uint32_t c = mg->species_chrom_off[s] + (d->mode ? (uint32_t)(tape_u(d) * nch) : (uint32_t)(((uint64_t)wa[1] * nch) >> 32));
+    uint64_t clen = chrom_off[c + 1] - chrom_off[c];
+    if ((uint64_t)length > clen) {                                               /* S:1711-1735 */
+        uint32_t total = mg->species_chrom_off[mg->nspecies];
+        uint32_t *target = (uint32_t *)malloc(sizeof(uint32_t) * (total + 1)), *other = (uint32_t *)malloc(sizeof(uint32_t) * (total + 1));
+        uint32_t nt = 0, no = 0;
+        for (uint32_t ts = 0; ts < mg->nspecies; ++ts)
+            for (uint32_t k = mg->species_chrom_off[ts]; k < mg->species_chrom_off[ts + 1]; ++k)
+                if ((uint64_t)length < chrom_off[k + 1] - chrom_off[k]) { if (ts == s) target[nt++] = k; else other[no++] = k; }
+        if (!nt && !no) { free(target); free(other); return -1; }
+        if (nt) c = target[d->mode ? (uint32_t)(tape_u(d) * nt) : (uint32_t)(((uint64_t)wa[2] * nt) >> 32)];
+        else { c = other[d->mode ? (uint32_t)(tape_u(d) * no) : (uint32_t)(((uint64_t)wa[2] * no) >> 32)]; warned = 1; }
+        free(target); free(other);
+        clen = chrom_off[c + 1] - chrom_off[c];
+    }
+    uint64_t span = circular[c] ? clen + 1 : clen - (uint64_t)length + 1;        /* randint(0, len) / randint(0, len - length) */
+    uint64_t rp = d->mode ? (uint64_t)(tape_u(d) * (double)span) : (uint64_t)(u53_to_p(wb[0], wb[1]) * (double)span);
+    if (rp >= span) rp = span - 1;
+    *chrom = c; *pos = rp;
+    return warned;
+}
+
+/* one read of a metagenome pass: lengths / species come from assign_species, the strand from the pass (S:860) */
+typedef struct nso_mread {
+    uint32_t pass, nseg, pos_in_pass, reversed;
+    uint64_t seq_index;                 /* number of the read = reads accepted before it (S:909-911) */
+    const int64_t *ref_len;             /* int(round(.)) of the assigned lengths, S:871 */
+    const uint16_t *species;
+} nso_mread;
+
 static void fetch_segment(const nso_ref *ref, uint32_t chrom, uint64_t pos, int64_t len, uint8_t *dst) {
     uint64_t c0 = ref->chrom_off[chrom], cl = ref->chrom_off[chrom + 1] - c0;
     for (int64_t i = 0; i < len; ++i) {
@@ -667,27 +791,38 @@ static void fetch_segment(const nso_ref *ref, uint32_t chrom, uint64_t pos, int6
 static int u64_digits(uint64_t v, char *buf) { return sprintf(buf, "%llu", (unsigned long long)v); }
 
 /* Generates read `index` of the batch.  Returns 0, or <0 if buffers are too small / attempts exhausted. */
-static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_params *prm, uint64_t index, nso_out *o) {
+static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_params *prm, uint64_t index, nso_out *o,
+                    const nso_mread *mr, const nso_meta *mg) {
     nso_draw d; memset(&d, 0, sizeof d);
-    d.mode = 0; d.seed = prm->seed; d.read = prm->first_read + index;
+    d.mode = 0; d.seed = prm->seed; d.read = prm->first_read + (mr ? mr->pos_in_pass : index);
+    if (mr) index = mr->seq_index;
     uint32_t w[4];
     const int kind = (int)prm->kind;
     uint32_t nseg = 1;
-    if (kind == NS_KIND_ALIGNED && prm->chimeric) {                       /* S:1276-1277 */
+    if (mr) nseg = mr->nseg;
+    else if (kind == NS_KIND_ALIGNED && prm->chimeric) {                       /* S:1276-1277 */
         philox_at(&d, ST_NSEG, 0, 0, 0, 0, w);
         nseg = (uint32_t)table_value(t->nseg_cdf, t->nseg_n, u32_to_p(w[0]));
         if (nseg > NSO_MAX_SEG) nseg = NSO_MAX_SEG;
     }
     uint32_t epoch = 0, fails = 0;
-    for (uint32_t a = 0; a < NSO_MAX_ATTEMPT; ++a) {
+    for (uint32_t a = mr ? mr->pass : 0; a < NSO_MAX_ATTEMPT; ++a) {
         int64_t ref_len[NSO_MAX_SEG], gap_len[NSO_MAX_SEG];
         int ok = 1;
+        if (mr && a != mr->pass) return 1;          /* metagenome: one try per pass; a rejected read is re-planned */
         /* ---- lengths ---- */
         if (kind == NS_KIND_UNALIGNED) {                                  /* S:1494-1495,1499 */
             philox_at(&d, ST_ULEN, 0, a, 0, 0, w);
             double x = prm->use_lognormal ? nso_exp(fma(prm->sd_len, nso_norminv(u32_to_p(w[2])), nso_log(prm->median_len)))
                                           : kde_sample(&t->kde[NS_KDE_UNALIGNED], w);
             ref_len[0] = (int64_t)x;
+        } else if (mr && kind == NS_KIND_ALIGNED) {                       /* S:871-872 */
+            for (uint32_t s = 0; s < nseg; ++s) ref_len[s] = mr->ref_len[s];
+            for (uint32_t g = 0; g + 1 < nseg; ++g) {
+                philox_at(&d, ST_GAPLEN, g, a, 0, 0, w);
+                double x = pow10m1(kde_sample(&t->kde[NS_KDE_GAP], w));
+                int64_t gi = (int64_t)x; gap_len[g] = gi < 0 ? 0 : gi;
+            }
         } else {
             for (uint32_t s = 0; s < nseg && ok; ++s) {                   /* S:1285-1296,1309 */
                 uint32_t j = 0;
@@ -724,7 +859,7 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
             for (; j < NSO_KDE_RETRY; ++j) {
                 philox_at(&d, ST_HT, 0, a, j, 0, w);
                 double x = pow10m1(kde_sample(&t->kde[NS_KDE_HT], w));
-                if (x >= 0) { remainder = (int64_t)x; break; }
+                if (x >= 0) { remainder = mr ? (int64_t)nearbyint(x) : (int64_t)x; break; }      /* S:1351 / S:901 */
             }
             if (j == NSO_KDE_RETRY) remainder = 0;
             for (j = 0; j < NSO_KDE_RETRY; ++j) {
@@ -736,6 +871,7 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
         }
         philox_at(&d, ST_STRAND, 0, a, 0, 0, w);
         reversed = u32_to_p(w[0]) > t->strandness_rate;                   /* S:1312, S:1524-1525 */
+        if (mr && kind == NS_KIND_ALIGNED) reversed = (int)mr->reversed;   /* S:860: one draw per pass */
         if (!ok) { ++epoch; fails = 0; continue; }
 
         /* ---- error lists ---- */
@@ -766,6 +902,13 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
             if (kind == NS_KIND_UNALIGNED) total = r.middle_ref;            /* S:1503 */
         }
         if (overflow) return -11;
+        if (mr && kind == NS_KIND_ALIGNED) {                                /* S:907-946: middle_ref and gap lengths count */
+            int64_t tot = remainder; int restart = 0;
+            for (uint32_t pi = 0; pi < n_pieces && !restart; pi += 2) { if (tot + pc[pi].ref_len > prm->max_len) restart = 1; else tot += pc[pi].ref_len; }
+            for (uint32_t pi = 1; pi < n_pieces && !restart; pi += 2) { if (tot + pc[pi].out_len > prm->max_len) restart = 1; else tot += pc[pi].out_len; }
+            if (restart || tot < prm->min_len || tot > prm->max_len) continue;
+            total = tot;
+        } else
         if (total < prm->min_len || total > prm->max_len) {                 /* S:1367-1368 / S:1503-1504 */
             if (kind == NS_KIND_UNALIGNED) continue;
             if (++fails >= NSO_EPOCH_FAILS) { ++epoch; fails = 0; }
@@ -785,6 +928,9 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
             uint32_t chrom = 0; uint64_t pos = 0;
             if (pc[pi].kind && kind == NS_KIND_ALIGNED && gap_len[pi >> 1] == 0) {   /* S:1553-1554 */
                 pc[pi].ref_len = 0; pc[pi].out_len = 0; pc[pi].n_ev = 0;
+            } else if (mg) {                                              /* extract_read("metagenome", len, species), S:1704-1749 */
+                int sp = (mr && !pc[pi].kind) ? (int)mr->species[pi >> 1] : -1;     /* gaps / unaligned reads: any species (S:1557, 1510) */
+                if (nso_extract_meta(mg, ref->chrom_off, ref->circular, pc[pi].ref_len, sp, &d, sid, a, &chrom, &pos) < 0) { pos_ok = 0; break; }
             } else if (extract_pos(ref->chrom_off, ref->nchrom, ref->circular, pc[pi].ref_len, &d, sid, a, &chrom, &pos)) {
                 pos_ok = 0; break;
             }
@@ -798,7 +944,12 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
         char name[4096]; int nl = 0; char num[32];
         int first = 1;
         for (uint32_t pi = 0; pi < n_pieces; ++pi) {
-            if (pc[pi].kind && kind == NS_KIND_ALIGNED) continue;          /* gaps are not named in genome mode */
+            if (pc[pi].kind && kind == NS_KIND_ALIGNED) {
+                if (!mg) continue;                                         /* gaps are not named in genome mode */
+                memcpy(name + nl, ";gap_", 5); nl += 5;                    /* S:970-971 */
+                nl += u64_digits(pc[pi].out_len, name + nl);
+                continue;
+            }
             if (!first) name[nl++] = ';';
             first = 0;
             const char *cn = ref->names[pc[pi].chrom];
@@ -984,7 +1135,7 @@ int nso_generate(const ns_model_tables *t, const uint8_t *bases, const uint64_t 
     nso_ref ref = {bases, chrom_off, nchrom, circular, names};
     o->n_pieces = o->n_events = o->record_bytes = o->errlog_bytes = o->total_bases = o->total_ref_bases = 0;
     int rc = 0;
-    for (uint64_t i = 0; i < prm->n_reads && rc == 0; ++i) rc = gen_read(t, &ref, prm, i, o);
+    for (uint64_t i = 0; i < prm->n_reads && rc == 0; ++i) rc = gen_read(t, &ref, prm, i, o, NULL, NULL);
     free((void *)names);
     return rc;
 }
@@ -1018,4 +1169,89 @@ int nso_extract_walk(const uint64_t *chrom_off, uint32_t nchrom, uint64_t ref_po
 }
 void nso_case_convert(uint8_t *seq, int64_t n, nso_draw *d, uint32_t seg, uint32_t attempt) {
     for (int64_t x = 0; x < n; ++x) seq[x] = resolve_base(nso_normalise_base(seq[x]), d, seg, attempt, (uint64_t)x);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * metagenome batch: simulation_aligned_metagenome (S:814-1040) / simulation_unaligned("metagenome") (S:1482-1549).
+ * One call = one worker.  Pass p = one iteration of the reference's `while remaining_reads > 0` loop: fresh lengths for
+ * all remaining reads, assign_species with the bases simulated so far, ONE strand draw, then one try per read in the
+ * sorted order; accepted reads are numbered consecutively in that order (S:909-911).
+ * inside a pass the reference hands the lengths of a rejected read to the next loop index; here every
+ * read keeps its own entry of the sorted list and a rejected read simply waits for the next pass.
+ * ---------------------------------------------------------------------------------------------- */
+int nso_generate_meta(const ns_model_tables *t, const uint8_t *bases, const uint64_t *chrom_off, uint32_t nchrom,
+                      const uint8_t *circular, const char *names_blob, const nso_meta *mg, const ns_params *prm, nso_out *o,
+                      double *species_bases_out) {
+    const char **names = (const char **)malloc(sizeof(char *) * (nchrom + 1));
+    const char *pn = names_blob;
+    for (uint32_t c = 0; c < nchrom; ++c) { names[c] = pn; pn += strlen(pn) + 1; }
+    nso_ref ref = {bases, chrom_off, nchrom, circular, names};
+    o->n_pieces = o->n_events = o->record_bytes = o->errlog_bytes = o->total_bases = o->total_ref_bases = 0;
+    const uint64_t n = prm->n_reads;
+    int rc = 0;
+    if (prm->kind == NS_KIND_UNALIGNED) {                /* random species per read, otherwise the genome-mode loop */
+        for (uint64_t i = 0; i < n && rc == 0; ++i) rc = gen_read(t, &ref, prm, i, o, NULL, mg);
+        free((void *)names);
+        return rc;
+    }
+    if (prm->kind != NS_KIND_ALIGNED || prm->use_lognormal) { free((void *)names); return -30; }
+    int32_t *nseg_orig = (int32_t *)malloc(sizeof(int32_t) * (n + 1));
+    for (uint64_t j = 0; j < n; ++j) {                    /* num_segment, S:825-828 */
+        nseg_orig[j] = 1;
+        if (prm->chimeric) {
+            nso_draw dj; memset(&dj, 0, sizeof dj); dj.seed = prm->seed; dj.read = prm->first_read + j;
+            uint32_t w[4]; philox_at(&dj, ST_NSEG, 0, 0, 0, 0, w);
+            int64_t v = table_value(t->nseg_cdf, t->nseg_n, u32_to_p(w[0]));
+            nseg_orig[j] = (int32_t)(v > NSO_MAX_SEG ? NSO_MAX_SEG : v);
+        }
+    }
+    double cur_bases[256]; memset(cur_bases, 0, sizeof cur_bases);
+    nso_draw db; memset(&db, 0, sizeof db); db.seed = prm->seed; db.read = prm->first_read;     /* batch-level draws */
+    uint64_t passed = 0;
+    for (uint32_t p = 0; passed < n && rc == 0; ++p) {
+        if (p >= NSO_MAX_ATTEMPT) { rc = -16; break; }
+        const uint64_t m = n - passed;
+        const int32_t *segs = nseg_orig + passed;                                     /* num_segment[passed:], S:1034 */
+        uint64_t D = 0;
+        for (uint64_t i = 0; i < m; ++i) D += (uint64_t)segs[i];
+        double *lens = (double *)malloc(sizeof(double) * (D + 1));
+        uint64_t V = 0;
+        for (uint64_t j = 0; j < D; ++j) {                                            /* S:852, 857 */
+            uint32_t w[4];
+            philox_at(&db, ST_REFLEN, 0, p, (uint32_t)j, (uint32_t)(j >> 32), w);
+            double x = kde_sample(&t->kde[NS_KDE_ALIGNED], w);
+            if (0 < x && x <= (double)prm->max_len) lens[V++] = x;
+        }
+        if (V == 0) { free(lens); continue; }                                          /* S:858-859 */
+        uint16_t *species = (uint16_t *)malloc(sizeof(uint16_t) * (V + 1));
+        double *lens_sorted = (double *)malloc(sizeof(double) * (V + 1));
+        int32_t *segs_sorted = (int32_t *)malloc(sizeof(int32_t) * (m + 1));
+        const uint64_t P = nso_assign_species(mg, lens, V, segs, m, cur_bases, &db, p, species, lens_sorted, segs_sorted);   /* S:866-867 */
+        uint32_t w[4];
+        philox_at(&db, ST_STRAND, 0, p, 0, 0, w);
+        const uint32_t reversed = u32_to_p(w[0]) > t->strandness_rate;                /* S:860 */
+        uint64_t seg_ptr = 0, accepted = 0;
+        for (uint64_t i = 0; i < m && rc == 0; ++i) {
+            const uint32_t ns = (uint32_t)segs_sorted[i];
+            if (seg_ptr + ns > P) break;                                              /* S:863-865 */
+            int64_t rl[NSO_MAX_SEG];
+            for (uint32_t s2 = 0; s2 < ns; ++s2) rl[s2] = (int64_t)nearbyint(lens_sorted[seg_ptr + s2]);   /* S:871 */
+            nso_mread mr; mr.pass = p; mr.nseg = ns; mr.pos_in_pass = (uint32_t)i; mr.reversed = reversed;
+            mr.seq_index = passed + accepted; mr.ref_len = rl; mr.species = species + seg_ptr;
+            const uint64_t piece0 = o->n_pieces;
+            int r1 = gen_read(t, &ref, prm, i, o, &mr, mg);
+            if (r1 < 0) rc = r1;
+            else if (r1 == 0) {
+                for (uint32_t s2 = 0; s2 < ns; ++s2)                                  /* S:1001-1002 */
+                    cur_bases[species[seg_ptr + s2]] += (double)o->pieces[piece0 + 2 * s2].ref_len;
+                ++accepted;
+            }
+            seg_ptr += ns;
+        }
+        passed += accepted;
+        free(lens); free(species); free(lens_sorted); free(segs_sorted);
+    }
+    if (species_bases_out) for (uint32_t s2 = 0; s2 < mg->nspecies; ++s2) species_bases_out[s2] = cur_bases[s2];
+    free(nseg_orig); free((void *)names);
+    return rc;
 }

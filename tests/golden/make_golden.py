@@ -65,6 +65,8 @@ class Recorder:
         self._rr = random.random
         self._pg, self._wg = S.mm.pois_geom, S.mm.wei_geom
         self._choice = random.choice
+        self._uniform = random.uniform
+        self._randint = random.randint
 
     def __enter__(self):
         S = self.S
@@ -89,14 +91,28 @@ class Recorder:
             self.u.append(v)
             return seq[int(v * len(seq))]
 
+        def uniform(a, b):
+            v = self._rr()
+            self.u.append(v)
+            return a + (b - a) * v
+
+        def randint(a, b):
+            v = self._rr()
+            self.u.append(v)
+            return a + int(v * (b - a + 1))
+
         random.random = rr
         random.choice = choice
+        random.uniform = uniform
+        random.randint = randint
         S.mm.pois_geom, S.mm.wei_geom = pg, wg
         return self
 
     def __exit__(self, *exc):
         random.random = self._rr
         random.choice = self._choice
+        random.uniform = self._uniform
+        random.randint = self._randint
         self.S.mm.pois_geom, self.S.mm.wei_geom = self._pg, self._wg
 
 
@@ -363,6 +379,162 @@ def fixture_extract(S):
     return dict(cases=cases, seq_len=dict(S.seq_len), genome_len=int(S.genome_len))
 
 
+
+META_DIR = os.path.join(HERE, "meta")
+
+
+def build_meta_inputs():
+    """Three synthetic species (committed FASTA files + the three metagenome config files of the CLI)."""
+    os.makedirs(META_DIR, exist_ok=True)
+    synth.write_fasta(os.path.join(META_DIR, "Alpha_one.fa"), [("chrA1 alpha chromosome", synth.synth_sequence(30000, 301, iupac_frac=0.001))])
+    synth.write_fasta(os.path.join(META_DIR, "Beta_two.fa"), [("NC_100.1 beta chromosome 1", synth.synth_sequence(25000, 302, lower_frac=0.1)),
+                                                             ("NC_101.1 beta chromosome 2", synth.synth_sequence(8000, 303))])
+    synth.write_fasta(os.path.join(META_DIR, "Gamma_three.fa"), [("gchr", synth.synth_sequence(15000, 304, n_frac=0.01)),
+                                                                ("plasmid_p1", synth.synth_sequence(3000, 305))])
+    with open(os.path.join(META_DIR, "genome_list.tsv"), "w") as f:
+        f.write("Alpha one\ttests/golden/meta/Alpha_one.fa\nBeta two\ttests/golden/meta/Beta_two.fa\n"
+                "Gamma three\ttests/golden/meta/Gamma_three.fa\n")
+    with open(os.path.join(META_DIR, "dna_type_list.tsv"), "w") as f:
+        f.write("Alpha one\tchrA1 alpha chromosome\tcircular\nBeta two\tNC_100.1 beta chromosome 1\tlinear\n"
+                "Beta two\tNC_101.1 beta chromosome 2\tlinear\nGamma three\tgchr\tcircular\nGamma three\tplasmid_p1\tlinear\n")
+    with open(os.path.join(META_DIR, "abundance.tsv"), "w") as f:
+        f.write("Size\t3000\t500\nAlpha one\t50\t10\nBeta two\t30\t60\nGamma three\t20\t30\n")
+
+
+def _meta_profile(S, prefix, chimeric, fastq=False):
+    os.chdir(ROOT)
+    so = sys.stdout
+    sys.stdout = open(os.devnull, "w")
+    try:
+        S.read_profile(os.path.join(META_DIR, "genome_list.tsv"), [], prefix, False, "metagenome", None,
+                       dna_type=os.path.join(META_DIR, "dna_type_list.tsv"), abun=os.path.join(META_DIR, "abundance.tsv"),
+                       chimeric=chimeric, homopolymer=False, fastq=fastq)
+    finally:
+        sys.stdout = so
+
+
+def fixture_metagenome(S, prefix):
+    build_meta_inputs()
+    _meta_profile(S, prefix, True)
+    out = dict(species=list(S.seq_len.keys()),
+               seq_len={sp: [[k, v] for k, v in S.seq_len[sp].items()] for sp in S.seq_len},
+               dna_type={sp: dict(S.dict_dna_type[sp]) for sp in S.dict_dna_type},
+               abun=S.multi_dict_abun, number_aligned=list(S.number_aligned_l), number_unaligned=list(S.number_unaligned_l),
+               max_chrom=dict(S.max_chrom), abun_inflation=S.abun_inflation, segment_mean=S.segment_mean)
+    S.dict_abun = S.multi_dict_abun["sample0"]
+    S.dict_abun_inflated = {sp: S.inflate_abun(S.dict_abun, sp) for sp in S.dict_abun}
+    out["abun_inflated"] = dict(S.dict_abun_inflated)
+    # assign_species on tape
+    cases = []
+    rng = np.random.default_rng(5)
+    for n_reads, chim in ((40, False), (60, True), (25, True), (300, False)):
+        segs = (rng.geometric(1 / 1.6, n_reads) if chim else np.ones(n_reads, dtype=int)).tolist()
+        lens = rng.lognormal(np.log(3000), 0.7, int(sum(segs))).tolist()
+        if n_reads == 25:
+            lens = lens[:len(lens) - 5]                      # fewer lengths than segments: the loop stops early (S:781-782)
+        cur = {sp: int(rng.integers(0, 20000)) for sp in S.dict_abun}
+        random.seed(n_reads)
+        with Recorder(S) as r:
+            sp_list, len_list, seg_arr = S.assign_species(list(lens), np.array(segs), dict(cur))
+        cases.append(dict(lengths=lens, segs=segs, current=cur, u=r.u, species=list(sp_list), out_lengths=[float(x) for x in len_list],
+                          out_segs=[int(x) for x in seg_arr]))
+    out["assign_species"] = cases
+    # extract_read("metagenome", length, species) on tape
+    ex = []
+    random.seed(77)
+    for sp in list(S.seq_len.keys()) + [None]:
+        for length in (10, 2000, 5000, 12000, 20000, 28000):
+            for rep in range(3):
+                with Recorder(S) as r:
+                    try:
+                        seq, name = S.extract_read("metagenome", length, sp)
+                    except AssertionError:
+                        continue
+                ex.append(dict(species=sp, length=length, u=r.u, name=name, seq_len=len(seq),
+                               head=seq[:30], tail=seq[-30:]))
+    out["extract_read"] = ex
+    # add_abundance_var on tape
+    total_len = {sp: sum(S.seq_len[sp].values()) for sp in S.seq_len}
+    random.seed(3)
+    with Recorder(S) as r:
+        av = S.add_abundance_var(S.multi_dict_abun["sample1"], total_len, -0.5, 0.5)
+    out["abundance_var"] = dict(u=r.u, result=av, total_len=total_len)
+    return out
+
+
+def _meta_worker(args):
+    idx, n_al, n_un, prefix, chimeric, workdir = args
+    S = import_reference()
+    _meta_profile(S, prefix, chimeric)
+    S.dict_abun = S.multi_dict_abun["sample0"]
+    S.dict_abun_inflated = {sp: S.inflate_abun(S.dict_abun, sp) for sp in S.dict_abun} if chimeric else {}
+    S.total_simulated = mp.Value("i", 0, lock=True)
+    random.seed(4000 + idx); np.random.seed(4000 + idx)
+    o_reads = os.path.join(workdir, "m%d_%d.fasta" % (idx, chimeric)); o_err = os.path.join(workdir, "me%d_%d" % (idx, chimeric))
+    o_un = os.path.join(workdir, "mu%d_%d.fasta" % (idx, chimeric))
+    max_l = max(S.max_chrom.values())
+    so = sys.stdout; se = sys.stderr
+    sys.stdout = open(os.devnull, "w"); sys.stderr = open(os.devnull, "w")
+    try:
+        S.simulation_aligned_metagenome(50, max_l, None, None, o_reads, o_err, None, False, n_al, False, chimeric)
+        S.simulation_unaligned("metagenome", 50, max_l, None, None, o_un, False, n_un, False)
+    finally:
+        sys.stdout = so; sys.stderr = se
+    lines = open(o_reads).read().split("\n")
+    names = [x[1:] for x in lines[0:-1:2]]
+    lens = [len(x) for x in lines[1:-1:2]]
+    species = list(S.seq_len.keys())
+
+    def sp_of(comp):
+        for sp in species:
+            if comp.startswith(sp + "-"):
+                return sp
+        raise ValueError(comp)
+
+    bases = {}
+    n_chim = 0
+    n_rev = 0
+    for nm in names:
+        body, _, rest = nm.partition("_aligned_")
+        f = rest.split("_")
+        seg_lens = [int(x) for x in f[-2].split(";")]
+        comps = [c for c in body.split(";") if not c.startswith("gap_")]
+        n_chim += len(comps) > 1
+        n_rev += f[-4] == "R"
+        for c, sl in zip(comps, seg_lens):
+            bases[sp_of(c)] = bases.get(sp_of(c), 0) + sl
+    strands = sorted(set(nm.partition("_aligned_")[2].split("_")[-4] for nm in names))
+    un = [x[1:] for x in open(o_un).read().split("\n")[0:-1:2]]
+    un_sp = {}
+    for nm in un:
+        un_sp[sp_of(nm)] = un_sp.get(sp_of(nm), 0) + 1
+    return dict(names=names[:6], lens=lens, bases=bases, strands=strands, n_chim=n_chim, n=len(names), un_species=un_sp,
+                un_names=un[:3])
+
+
+def fixture_metagenome_runs(prefix, workdir, n_reads=24000):
+    out = {}
+    for chim in (False, True):
+        n_proc = min(8, os.cpu_count() or 1)
+        args = [(i, n_reads // n_proc, 300, prefix, chim, workdir) for i in range(n_proc)]
+        with mp.get_context("fork").Pool(n_proc) as pool:
+            res = pool.map(_meta_worker, args)
+        bases = {}
+        for r in res:
+            for sp, b in r["bases"].items():
+                bases[sp] = bases.get(sp, 0) + b
+        un = {}
+        for r in res:
+            for sp, b in r["un_species"].items():
+                un[sp] = un.get(sp, 0) + b
+        all_lens = np.concatenate([r["lens"] for r in res])
+        out["chimeric" if chim else "plain"] = dict(
+            bases=bases, workers=[dict(strands=r["strands"], n=r["n"], n_chim=r["n_chim"], first_names=r["names"],
+                                       lens_head=r["lens"][:50], sorted_desc_frac=float(np.mean(np.diff(r["lens"]) <= 0)))
+                                  for r in res],
+            q_len=quantiles(all_lens), mean_len=float(all_lens.mean()), unaligned_species=un, un_names=res[0]["un_names"])
+    return out
+
 def _dist_worker(args):
     idx, n_al, n_un, prefix, fasta, workdir, fastq, kmer = args
     S = import_reference()
@@ -481,6 +653,13 @@ def main():
             json.dump(fx, f)
         with open(os.path.join(HERE, "reference_samplers.json"), "w") as f:
             json.dump(fixture_samplers(S), f)
+        mg = fixture_metagenome(import_reference(), prefix)
+        if not a.skip_dist:
+            mg["runs"] = fixture_metagenome_runs(prefix, workdir)
+        elif os.path.exists(os.path.join(HERE, "reference_metagenome.json")):
+            mg["runs"] = json.load(open(os.path.join(HERE, "reference_metagenome.json"))).get("runs")
+        with open(os.path.join(HERE, "reference_metagenome.json"), "w") as f:
+            json.dump(mg, f)
         if not a.skip_dist:
             d = dict(fasta=fixture_distributions(prefix, fasta, workdir, a.dist_reads, False),
                      fastq=fixture_distributions(prefix, fasta, workdir, max(2000, a.dist_reads // 10), True),

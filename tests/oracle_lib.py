@@ -35,6 +35,24 @@ class NsoOut(C.Structure):
                 ("errlog_bytes", C.c_uint64), ("total_bases", C.c_uint64), ("total_ref_bases", C.c_uint64)]
 
 
+class NsoMeta(C.Structure):
+    _fields_ = [("nspecies", C.c_uint32), ("species_chrom_off", C.POINTER(C.c_uint32)), ("abun", C.POINTER(C.c_double)),
+                ("abun_inflated", C.POINTER(C.c_double))]
+
+
+def make_meta(meta_ref, abun: dict, abun_inflated: dict | None):
+    """NsoMeta + keepalive for a MetaReference and per-species abundance dicts (species order of the reference)."""
+    sco = np.ascontiguousarray(meta_ref.species_chrom_off, dtype=np.uint32)
+    ab = np.array([abun[sp] for sp in meta_ref.species], dtype=np.float64)
+    inf = np.array([abun_inflated[sp] for sp in meta_ref.species], dtype=np.float64) if abun_inflated else np.zeros(len(ab))
+    m = NsoMeta()
+    m.nspecies = len(meta_ref.species)
+    m.species_chrom_off = sco.ctypes.data_as(C.POINTER(C.c_uint32))
+    m.abun = ab.ctypes.data_as(C.POINTER(C.c_double))
+    m.abun_inflated = inf.ctypes.data_as(C.POINTER(C.c_double))
+    return m, (sco, ab, inf)
+
+
 class NsoLogRow(C.Structure):
     _fields_ = [("pos", C.c_uint32), ("len", C.c_uint32), ("type", C.c_uint32), ("ref_off", C.c_uint32),
                 ("new_off", C.c_uint32)]
@@ -84,6 +102,12 @@ def lib():
                                       C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int64]
         L.nso_hp_mu.restype = C.c_double; L.nso_hp_mu.argtypes = [C.POINTER(NsModelTables), C.c_uint8, C.c_int64]
         L.nso_hp_sigma.restype = C.c_double; L.nso_hp_sigma.argtypes = [C.POINTER(NsModelTables), C.c_uint8, C.c_int64]
+        L.nso_assign_species.restype = C.c_uint64
+        L.nso_assign_species.argtypes = [C.POINTER(NsoMeta), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
+                                         C.POINTER(NsoDraw), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.nso_extract_meta.restype = C.c_int
+        L.nso_extract_meta.argtypes = [C.POINTER(NsoMeta), C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(NsoDraw),
+                                       C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
         L.nso_generate.restype = C.c_int
         L.nso_generate.argtypes = [C.POINTER(NsModelTables), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
                                    C.c_char_p, C.POINTER(NsParams), C.POINTER(NsoOut)]

@@ -1,0 +1,104 @@
+"""Metagenome mode: host loader + the oracle's assign_species / extract_read restatements pinned by
+tape replay against the reference (tests/golden/reference_metagenome.json)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from nanosim_amd import metagenome as MG
+from nanosim_amd import model as M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+META = os.path.join(ROOT, "tests", "golden", "meta")
+
+
+@pytest.fixture(scope="module")
+def fx():
+    with open(os.path.join(ROOT, "tests", "golden", "reference_metagenome.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def meta_ref():
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        return MG.read_metagenome(os.path.join(META, "genome_list.tsv"), os.path.join(META, "dna_type_list.tsv"))
+    finally:
+        os.chdir(cwd)
+
+
+def test_loader_matches_read_profile(fx, meta_ref):
+    assert meta_ref.species == fx["species"]
+    lens = np.diff(meta_ref.ref.chrom_off.astype(np.int64))
+    ci = 0
+    for si, sp in enumerate(meta_ref.species):
+        assert meta_ref.species_chrom_off[si] == ci
+        for key, ln in fx["seq_len"][sp]:
+            assert meta_ref.ref.names[ci] == sp + "-" + key and lens[ci] == ln
+            assert bool(meta_ref.ref.circular[ci]) == (fx["dna_type"][sp][key] == "circular")
+            ci += 1
+    assert ci == len(meta_ref.ref.names)
+    assert meta_ref.max_chrom == max(fx["max_chrom"].values())
+    assert meta_ref.total_len() == fx["abundance_var"]["total_len"]
+    numbers, samples = MG.read_abundance(os.path.join(META, "abundance.tsv"), meta_ref.species)
+    assert samples == [fx["abun"]["sample0"], fx["abun"]["sample1"]]
+    mdl = M.load_model(os.path.join(ROOT, "tests", "golden", "model_small", "training"), chimeric=True)
+    assert [mdl.split_counts(n) for n in numbers] == list(zip(fx["number_aligned"], fx["number_unaligned"]))
+    assert mdl.abun_inflation == fx["abun_inflation"] and mdl.segment_mean == fx["segment_mean"]
+    for sp, v in fx["abun_inflated"].items():
+        assert MG.inflate_abun(fx["abun"]["sample0"], sp, mdl.abun_inflation) == pytest.approx(v, rel=1e-15)
+
+
+def test_abundance_variation_tape(fx):
+    av = fx["abundance_var"]
+    got = MG.add_abundance_var(fx["abun"]["sample1"], av["total_len"], -0.5, 0.5, iter(av["u"]))
+    assert got.keys() == av["result"].keys()
+    for k in got:
+        assert got[k] == pytest.approx(av["result"][k], rel=1e-14)
+
+
+def test_assign_species_tape_replay(fx, meta_ref):
+    from tests import oracle_lib as O
+    L = O.lib()
+    mg, keep = O.make_meta(meta_ref, fx["abun"]["sample0"], fx["abun_inflated"])
+    for case in fx["assign_species"]:
+        lens = np.array(case["lengths"], dtype=np.float64)
+        segs = np.array(case["segs"], dtype=np.int32)
+        cur = np.array([case["current"][sp] for sp in meta_ref.species], dtype=np.float64)
+        d, k2 = O.make_tape(case["u"])
+        sp_out = np.zeros(len(lens), dtype=np.uint16)
+        len_out = np.zeros(len(lens), dtype=np.float64)
+        seg_out = np.zeros(len(segs), dtype=np.int32)
+        n = L.nso_assign_species(C.byref(mg), lens.ctypes.data, len(lens), segs.ctypes.data, len(segs), cur.ctypes.data, C.byref(d), 0,
+                                 sp_out.ctypes.data, len_out.ctypes.data, seg_out.ctypes.data)
+        assert not d.tape_err and d.i_u == len(case["u"])
+        assert n == len(case["species"])
+        assert [meta_ref.species[i] for i in sp_out[:n]] == case["species"]
+        assert len_out[:n].tolist() == case["out_lengths"]
+        assert seg_out[:n].tolist() == case["out_segs"]            # S:811: the segment list is cut at the segment pointer
+
+
+def test_extract_read_metagenome_tape_replay(fx, meta_ref):
+    from tests import oracle_lib as O
+    L = O.lib()
+    mg, keep = O.make_meta(meta_ref, fx["abun"]["sample0"], None)
+    bases = O.normalise_bases(meta_ref.ref.bases)
+    chrom, pos = C.c_uint32(), C.c_uint64()
+    n_warn = 0
+    for case in fx["extract_read"]:
+        d, k2 = O.make_tape(case["u"])
+        sp = -1 if case["species"] is None else meta_ref.species.index(case["species"])
+        rc = L.nso_extract_meta(C.byref(mg), meta_ref.ref.chrom_off.ctypes.data, meta_ref.ref.circular.ctypes.data, case["length"], sp,
+                                C.byref(d), 0, 0, C.byref(chrom), C.byref(pos))
+        assert rc >= 0 and not d.tape_err and d.i_u == len(case["u"])
+        n_warn += rc
+        assert "%s_%d" % (meta_ref.ref.names[chrom.value], pos.value) == case["name"]
+        # the extracted bases (with wrap-around on circular chromosomes) start / end like the reference's
+        c0, c1 = int(meta_ref.ref.chrom_off[chrom.value]), int(meta_ref.ref.chrom_off[chrom.value + 1])
+        idx = c0 + (pos.value + np.arange(case["length"])) % (c1 - c0)
+        raw = meta_ref.ref.bases[idx]
+        assert bytes(raw[:30]).decode() == case["head"] and bytes(raw[-30:]).decode() == case["tail"]
+    assert n_warn > 0
