@@ -136,7 +136,7 @@ typedef struct ns_params {
     int64_t min_len, max_len;
     double median_len, sd_len;
     uint32_t emit_errlog;   /* 1: format the _aligned_error_profile rows on the device (S:2006-2008) */
-    uint32_t _pad;
+    uint32_t meta;          /* 1: metagenome batch = one worker of simulation_aligned_metagenome (S:814-1040) / simulation_unaligned("metagenome") */
 } ns_params;
 
 /* ---- device-side result layout (copied out with ns_copy_out) -------------------------------------- */
@@ -211,6 +211,14 @@ int ns_set_reference(ns_ctx *ctx, const uint8_t *bases, uint64_t nbases, const u
  * the library does not take ownership of it. */
 int ns_set_reference_device(ns_ctx *ctx, const void *bases_dev, uint64_t nbases, const uint64_t *chrom_off,
                             uint32_t nchrom, const uint8_t *circular, const char *names, uint64_t names_len);
+
+/* metagenome (src/simulator.py:284-339, 357-380): chromosomes of species s are [species_chrom_off[s], species_chrom_off[s+1]) of
+ * the reference set with ns_set_reference (chromosome names are then "<species>-<chrom>", S:1747); abun = dict_abun of the
+ * sample, abun_inflated = dict_abun_inflated (NULL unless chimeric, S:2511-2514).  ns_species_bases returns
+ * current_species_bases (S:835, 1001-1002) of the last metagenome batch. */
+int ns_set_species(ns_ctx *ctx, uint32_t nspecies, const uint32_t *species_chrom_off);
+int ns_set_abundance(ns_ctx *ctx, const double *abun, const double *abun_inflated);
+int ns_species_bases(ns_ctx *ctx, double *out);
 
 /* model: replaces the globals filled by read_profile() (src/simulator.py:473-591) */
 int ns_load_model(ns_ctx *ctx, const ns_model_tables *tables);

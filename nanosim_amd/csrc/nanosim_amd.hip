@@ -15,6 +15,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -53,6 +55,22 @@ struct GenArgs {
     uint8_t *scr, *scrq;             // -k: pre-homopolymer reads (forward strand) and their quality characters
     uint64_t *scr_len, *scr_off;
     uint32_t *hp_len;                // -k: final emitted length per piece
+    // metagenome (one pass = one `while remaining_reads` iteration of S:836-1036)
+    uint32_t meta;                   // 0 genome, 1 metagenome
+    uint32_t nspecies;
+    const uint32_t *species_chrom_off;
+    const uint32_t *key_pos;         // per final read: id of its Philox key inside the pass that accepted it (nullptr: the read index)
+    uint32_t *key_pos_w;
+    uint32_t m_reversed;             // strand of the pass (S:860)
+    uint32_t m_passed, m_pieces_passed;   // reads / pieces accepted by earlier passes
+    const uint32_t *m_segptr;        // per read position of the pass (+1 sentinel): first entry of its segments in m_len / m_species
+    const int32_t *m_len;            // int(round(length)) per assigned segment (S:871)
+    const uint16_t *m_species;
+    uint64_t ev_base;                // first event slot of this pass in the events buffer
+    uint64_t *accept, *accept_scan;  // per pass position: accepted ? 1 | n_pieces << 32 : 0
+    ns_read *f_reads; ns_piece *f_pieces; uint16_t *f_name_len; uint64_t *f_rec_len, *f_err_len;   // final (accepted) arrays
+    double *draw_x; uint64_t draw_n;
+    unsigned long long *species_bases;
     // results
     ns_read *reads;
     ns_piece *pieces;
@@ -66,6 +84,10 @@ __device__ __forceinline__ ns_key make_key(const ns_params &prm, uint64_t r) {
     uint64_t g = prm.first_read + r;
     return ns_key{(uint32_t)prm.seed, (uint32_t)(prm.seed >> 32), (uint32_t)g, (uint32_t)(g >> 32)};
 }
+// key of FINAL read r: in metagenome batches the draws of a read are keyed by its position inside the pass that accepted it
+__device__ __forceinline__ ns_key read_key(const GenArgs &A, uint64_t r);
+
+__device__ __forceinline__ ns_key read_key(const GenArgs &A, uint64_t r) { return make_key(A.prm, A.key_pos ? (uint64_t)A.key_pos[r] : r); }
 
 __device__ __forceinline__ uint32_t read_nseg(const GenArgs &A, const ns_key &key) {
     if (A.prm.kind != NS_KIND_ALIGNED || !A.prm.chimeric) return 1;
@@ -98,8 +120,9 @@ __global__ void __launch_bounds__(256) k_lengths(GenArgs A) {
     const ns_params &prm = A.prm;
     const int kind = (int)prm.kind;
     const ns_key key = make_key(prm, r);
-    const uint32_t a = A.att_base[r] + A.attempt;
-    const uint32_t epoch = A.rstate[r] & 0xffffu;
+    const bool meta_al = A.meta && kind == NS_KIND_ALIGNED;      // r is then the position of the read inside pass A.attempt
+    const uint32_t a = meta_al ? A.attempt : A.att_base[r] + A.attempt;
+    const uint32_t epoch = meta_al ? 0u : A.rstate[r] & 0xffffu;
     const uint32_t piece_off = A.piece_off[r];
     const uint32_t n_pieces = A.piece_off[r + 1] - piece_off;
     ns_piece *pc = A.pieces + piece_off;
@@ -109,7 +132,8 @@ __global__ void __launch_bounds__(256) k_lengths(GenArgs A) {
         const bool is_gap = (kind == NS_KIND_UNALIGNED) || (pi & 1);
         int64_t mlen = 0;
         if (kind == NS_KIND_UNALIGNED) mlen = unaligned_length(A.m, prm, key, a);       // S:1494-1495
-        else if (is_gap) mlen = gap_length(A.m, key, pi >> 1, epoch);                  // S:1298-1299
+        else if (is_gap) mlen = gap_length(A.m, key, pi >> 1, A.meta ? a : epoch);     // S:1298-1299 (S:872: once per pass)
+        else if (A.meta) mlen = A.m_len[A.m_segptr[r] + (pi >> 1)];                    // S:871: assigned by assign_species
         else if (!seg_length(A.m, prm, key, pi >> 1, epoch, mlen)) { ok = false; mlen = 0; }   // S:1285-1296
         const int32_t m32 = mlen > 0x3fffffff ? 0x3fffffff : mlen < -1 ? -1 : (int32_t)mlen;
         ns_piece p;
@@ -127,7 +151,7 @@ __global__ void __launch_bounds__(256) k_lengths(GenArgs A) {
         for (; j < NS_KDE_RETRY; ++j) {
             u32x4 w = ns_draw(key, ST_HT, 0, a, j, 0);
             double x = ns_pow10m1(kde_sample(A.m.kde[NS_KDE_HT], w));
-            if (x >= 0) { remainder = (int32_t)x; break; }
+            if (x >= 0) { remainder = A.meta ? (int32_t)rint(x) : (int32_t)x; break; }      // S:1351 int() / S:901 int(round())
         }
         for (j = 0; j < NS_KDE_RETRY; ++j) {
             u32x4 w = ns_draw(key, ST_RATIO, 0, a, j, 0);
@@ -140,6 +164,7 @@ __global__ void __launch_bounds__(256) k_lengths(GenArgs A) {
     ns_read rd;
     rd.rec_off = 0; rd.piece_off = piece_off; rd.n_pieces = (uint16_t)n_pieces;
     rd.reversed = (u32_to_p(ws.x) > A.m.strandness_rate) ? 1 : 0;                       // S:1312, S:1524-1525
+    if (meta_al) rd.reversed = (uint8_t)A.m_reversed;                                   // S:860: one draw per pass
     rd.flags = ok ? 1 : 3;                      // bit0: not generated yet, bit1: no valid length draw in this epoch
     rd.head = 0; rd.tail = 0;
     if (remainder != 0) {                                                               // S:1377-1382
@@ -148,7 +173,7 @@ __global__ void __launch_bounds__(256) k_lengths(GenArgs A) {
     }
     rd.seq_len = 0; rd.attempts = a;
     A.reads[r] = rd;
-    if (A.attempt == 0) {
+    if (A.attempt == 0 || meta_al) {
         A.ev_cap[r] = cap;
         A.sort_key[r] = work > 0xffffffffull ? 0xffffffffu : (uint32_t)work;
         A.sort_idx[r] = (uint32_t)r;
@@ -191,19 +216,20 @@ __global__ void __launch_bounds__(COOP ? 64 : 256) k_chain(GenArgs A) {
     else if (blockIdx.x < (gridDim.x >> 2)) __builtin_amdgcn_s_setprio(1);
     unsigned long long st_over = 0, st_bases = 0, st_ref = 0, st_ev = 0;
     if (tid < A.list_n) {
-        const uint64_t r = A.list[tid];
+        const uint64_t r = A.list ? A.list[tid] : tid;
         const int kind = (int)prm.kind;
+        const bool meta_al = A.meta && kind == NS_KIND_ALIGNED;
         const ns_key key = make_key(prm, r);
-        const uint32_t a = A.att_base[r] + A.attempt;
+        const uint32_t a = meta_al ? A.attempt : A.att_base[r] + A.attempt;
         ns_read rd = A.reads[r];
         const uint32_t n_pieces = rd.n_pieces;
         ns_piece *pc = A.pieces + rd.piece_off;
-        uint32_t epoch = A.rstate[r] & 0xffffu, fails = A.rstate[r] >> 16;
+        uint32_t epoch = meta_al ? 0u : A.rstate[r] & 0xffffu, fails = meta_al ? 0u : A.rstate[r] >> 16;
         bool accepted = false, overflow = false;
         do {
             if (rd.flags & 2) { ++epoch; fails = 0; break; }          // no valid length draw
-            const uint64_t ev_off = A.ev_off[r];
-            const uint64_t ev_cap64 = A.ev_off[r + 1] - ev_off;
+            const uint64_t ev_off = A.ev_base + A.ev_off[r];
+            const uint64_t ev_cap64 = A.ev_off[r + 1] - A.ev_off[r];
             const uint32_t ev_cap = ev_cap64 > 0xffffffffull ? 0xffffffffu : (uint32_t)ev_cap64;
             EvSink32 sink; sink.last_ins_len = 0; sink.overflow = false;
             int64_t total = (int64_t)rd.head + rd.tail;
@@ -229,6 +255,12 @@ __global__ void __launch_bounds__(COOP ? 64 : 256) k_chain(GenArgs A) {
                 if (kind == NS_KIND_UNALIGNED) total = e.middle_ref;                     // S:1503
             }
             if (sink.overflow) { overflow = true; break; }
+            if (meta_al) {                                   // S:907-946: remainder + middle_ref of the segments, then the gaps
+                int64_t tot = (int64_t)rd.head + rd.tail; bool restart = false;
+                for (uint32_t pi = 0; pi < n_pieces && !restart; pi += 2) { if (tot + pc[pi].ref_len > prm.max_len) restart = true; else tot += pc[pi].ref_len; }
+                for (uint32_t pi = 1; pi < n_pieces && !restart; pi += 2) { if (tot + pc[pi].out_len > prm.max_len) restart = true; else tot += pc[pi].out_len; }
+                if (restart || tot < prm.min_len || tot > prm.max_len) break;
+            } else
             if (total < prm.min_len || total > prm.max_len) {                            // S:1367-1368, S:1503-1504
                 if (kind != NS_KIND_UNALIGNED && ++fails >= NS_EPOCH_FAILS) { ++epoch; fails = 0; }
                 break;
@@ -242,6 +274,10 @@ __global__ void __launch_bounds__(COOP ? 64 : 256) k_chain(GenArgs A) {
                 const uint32_t sid = p.kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
                 uint32_t chrom = 0; uint64_t pos = 0;
                 if (p.chrom == 1u && p.kind) { p.ref_len = 0; p.out_len = 0; p.n_ev = 0; }
+                else if (A.meta) {                                   // species of the segment; gaps / unaligned reads: any species
+                    const int sp = (meta_al && !p.kind) ? (int)A.m_species[A.m_segptr[r] + (pi >> 1)] : -1;
+                    if (!extract_pos_meta(A.ref, A.species_chrom_off, A.nspecies, p.ref_len, sp, key, sid, a, chrom, pos)) { pos_ok = false; break; }
+                }
                 else if (!extract_pos(A.ref, p.ref_len, key, sid, a, chrom, pos)) { pos_ok = false; break; }
                 p.chrom = chrom; p.pos = (uint32_t)pos; p.ref_gpos = A.ref.chrom_off[chrom] + pos;
                 pc[pi] = p;
@@ -255,12 +291,16 @@ __global__ void __launch_bounds__(COOP ? 64 : 256) k_chain(GenArgs A) {
             uint32_t nl = 0; bool first = true;                                          // name length (S:1390-1402, 1332-1343, 1529-1534)
             for (uint32_t pi = 0; pi < n_pieces; ++pi) {
                 ns_piece p = pc[pi];
-                if (p.kind && kind == NS_KIND_ALIGNED) continue;
+                if (p.kind && kind == NS_KIND_ALIGNED) {
+                    if (A.meta) nl += 5 + dec_digits(p.out_len);                        // ";gap_<len>" (S:970-971)
+                    continue;
+                }
                 if (!first) nl += 2;            // ';' in the position list and ';' in the length list
                 first = false;
                 nl += (A.ref.name_off[p.chrom + 1] - A.ref.name_off[p.chrom] - 1) + 1 + dec_digits(p.pos) + dec_digits(p.ref_len);
             }
-            nl += (kind == NS_KIND_UNALIGNED ? 11u : 9u) + dec_digits(prm.first_read + r);
+            // metagenome: the number of the read is only known once the accepted reads of the pass are counted (k_meta_commit)
+            nl += (kind == NS_KIND_UNALIGNED ? 11u : 9u) + (meta_al ? 0u : dec_digits(prm.first_read + r));
             if (kind == NS_KIND_ALIGNED && n_pieces > 1) nl += 9;
             nl += 2 /*_F*/ + 1 + dec_digits(rd.head) + 1 + 1 + dec_digits(rd.tail);
             uint64_t err_len = 0;
@@ -279,6 +319,7 @@ __global__ void __launch_bounds__(COOP ? 64 : 256) k_chain(GenArgs A) {
                 A.name_len[r] = (uint16_t)nl;
                 A.rec_len[r] = prm.emit_records ? (uint64_t)nl + 2 + (uint64_t)seq_len + 1 + (prm.fastq ? (uint64_t)seq_len + 3 : 0) : 0;
                 A.err_len[r] = err_len;
+                if (meta_al) A.accept[r] = 1ull | (uint64_t)n_pieces << 32;
                 st_bases = A.hp ? 0ull : (unsigned long long)seq_len; st_ref = ref_bases; st_ev = evn;
             }
             accepted = true;
@@ -286,8 +327,9 @@ __global__ void __launch_bounds__(COOP ? 64 : 256) k_chain(GenArgs A) {
         if (lead) {
             if (overflow) st_over = 1;
             A.reads[r] = rd;
-            if (accepted) A.att_base[r] = a;            // a re-run of the batch starts every read at its accepted attempt
-            if (!accepted && !overflow) {
+            if (meta_al) { /* a rejected read is re-planned by the next pass */ }
+            else if (accepted) A.att_base[r] = a;       // a re-run of the batch starts every read at its accepted attempt
+            if (!meta_al && !accepted && !overflow) {
                 A.rstate[r] = (epoch & 0xffffu) | fails << 16;
                 A.next_list[atomicAdd(A.next_n, 1u)] = (uint32_t)r;
             }
@@ -299,6 +341,45 @@ __global__ void __launch_bounds__(COOP ? 64 : 256) k_chain(GenArgs A) {
         if (st_over) atomicAdd(&A.stats[0], st_over);
         atomicAdd(&A.stats[1], st_bases); atomicAdd(&A.stats[2], st_ref); atomicAdd(&A.stats[3], st_ev);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// metagenome passes (simulation_aligned_metagenome, S:836-1036)
+//   k_meta_draw    the length list of a pass: one KDE draw per remaining segment (S:852), keyed by the batch
+//   k_meta_commit  numbers the accepted reads of a pass consecutively (S:909-911) and moves them to their final slots
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_meta_draw(GenArgs A) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= A.draw_n) return;
+    const ns_key key = make_key(A.prm, 0);
+    A.draw_x[j] = kde_sample(A.m.kde[NS_KDE_ALIGNED], ns_draw(key, ST_REFLEN, 0, A.attempt, (uint32_t)j, (uint32_t)(j >> 32)));
+}
+
+__global__ void __launch_bounds__(256) k_meta_commit(GenArgs A) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.list_n || !A.accept[i]) return;
+    const uint64_t sc = A.accept_scan[i];
+    const uint64_t slot = A.m_passed + (uint32_t)sc;
+    const uint32_t poff = A.m_pieces_passed + (uint32_t)(sc >> 32);
+    ns_read rd = A.reads[i];
+    const ns_piece *src = A.pieces + rd.piece_off;
+    ns_piece *dst = A.f_pieces + poff;
+    uint64_t rows = 0;
+    for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
+        const ns_piece p = src[pi];
+        dst[pi] = p;
+        if (!p.kind) {
+            rows += p.n_ev;
+            atomicAdd(&A.species_bases[A.m_species[A.m_segptr[i] + (pi >> 1)]], (unsigned long long)p.ref_len);   // S:1001-1002
+        }
+    }
+    rd.piece_off = poff;
+    A.f_reads[slot] = rd;
+    A.key_pos_w[slot] = (uint32_t)i;
+    const uint32_t dg = dec_digits(A.prm.first_read + slot);
+    A.f_name_len[slot] = (uint16_t)(A.name_len[i] + dg);
+    A.f_rec_len[slot] = A.prm.emit_records ? A.rec_len[i] + dg : 0;
+    A.f_err_len[slot] = A.prm.emit_errlog ? A.err_len[i] + rows * dg : 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -317,7 +398,10 @@ __global__ void __launch_bounds__(256) k_names(GenArgs A) {
     *p++ = A.prm.fastq ? '@' : '>';
     bool first = true;
     for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
-        if (pc[pi].kind && kind == NS_KIND_ALIGNED) continue;
+        if (pc[pi].kind && kind == NS_KIND_ALIGNED) {
+            if (A.meta) { const char *g = ";gap_"; while (*g) *p++ = (uint8_t)*g++; p = put_dec(p, pc[pi].out_len); }   // S:970-971
+            continue;
+        }
         if (!first) *p++ = ';';
         first = false;
         const char *cn = A.ref.names + A.ref.name_off[pc[pi].chrom];
@@ -359,7 +443,7 @@ __global__ void __launch_bounds__(64, NS_MAT_WAVES) k_materialise(GenArgs A, uin
     const uint64_t r = blockIdx.x;
     const ns_read rd = A.reads[r];
     if (rd.flags) return;
-    const ns_key key = make_key(A.prm, r);
+    const ns_key key = read_key(A, r);
     const uint32_t a = rd.attempts;
     ReadOut ro;
     ro.seq = A.records + rd.rec_off + A.name_len[r] + 2;
@@ -390,7 +474,7 @@ __global__ void __launch_bounds__(256) k_hp_filter(GenArgs A) {
     if (r == A.prm.n_reads) { A.scr_len[r] = 0; return; }
     ns_read rd = A.reads[r];
     if (rd.flags) { A.scr_len[r] = 0; return; }
-    const ns_key key = make_key(A.prm, r);
+    const ns_key key = read_key(A, r);
     const uint32_t a = rd.attempts;
     const int64_t k = (int64_t)A.prm.kmer_bias;
     const uint32_t nl = A.name_len[r];
@@ -430,7 +514,7 @@ __global__ void __launch_bounds__(256) k_hp_count(GenArgs A) {
     if (r < A.prm.n_reads) {
         ns_read rd = A.reads[r];
         if (!rd.flags) {
-            const ns_key key = make_key(A.prm, r);
+            const ns_key key = read_key(A, r);
             const uint32_t a = rd.attempts, k = A.prm.kmer_bias;
             const uint8_t *scr = A.scr + A.scr_off[r];
             uint64_t q = rd.head, final_len = (uint64_t)rd.head + rd.tail;
@@ -481,7 +565,7 @@ __global__ void __launch_bounds__(256) k_hp_write(GenArgs A) {
         for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) A.pieces[rd.piece_off + pi].out_len = A.hp_len[rd.piece_off + pi];
         return;
     }
-    const ns_key key = make_key(A.prm, r);
+    const ns_key key = read_key(A, r);
     const uint32_t a = rd.attempts, k = A.prm.kmer_bias;
     const bool fq = A.prm.fastq != 0, rev = rd.reversed != 0;
     const uint32_t L = rd.seq_len;                                         // final length
@@ -555,7 +639,7 @@ __global__ void __launch_bounds__(256) k_errlog(GenArgs A) {
     if (r >= A.prm.n_reads) return;
     const ns_read rd = A.reads[r];
     if (rd.flags) return;
-    const ns_key key = make_key(A.prm, r);
+    const ns_key key = read_key(A, r);
     const uint32_t a = rd.attempts;
     const uint32_t nl = A.name_len[r];
     const uint8_t *name = A.records + rd.rec_off + 1;
@@ -652,6 +736,12 @@ struct ns_ctx {
     DevBuf n_pieces, piece_off, ev_cap, ev_off, rec_len, rec_off, err_len, err_off, name_len;
     DevBuf reads, pieces, events, records, errlog, stats, scan_tmp;
     DevBuf sort_key, sort_idx, sort_key_out, order, list_b, rstate, att_base, scr, scrq, scr_len, scr_off, hp_len;
+    // metagenome: species view of the reference, abundances of the sample, per-pass scratch
+    DevBuf species_chrom_off, t_reads, t_pieces, t_name_len, t_rec_len, t_err_len, accept, accept_scan, key_pos, draw_x, m_segptr,
+        m_len, m_species, species_bases;
+    uint32_t nspecies = 0;
+    bool has_abun = false, has_inflated = false, has_key_pos = false;
+    std::vector<double> abun, abun_inflated, last_species_bases;
     bool lds_tables = false, coop_ok = false;
     size_t lds_bytes = 0;
     ns_batch_info last{};
@@ -676,6 +766,23 @@ static int ensure(ns_ctx *ctx, DevBuf &b, size_t bytes) {
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess) { b.p = nullptr; b.cap = 0; return fail(ctx, NS_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     b.cap = want;
+    return NS_OK;
+}
+
+// grows a buffer whose first `keep` bytes must survive
+static int ensure_keep(ns_ctx *ctx, DevBuf &b, size_t bytes, size_t keep) {
+    if (bytes <= b.cap) return NS_OK;
+    size_t want = bytes + bytes / 2 + 4096;
+    void *np = nullptr;
+    hipError_t e = hipMalloc(&np, want);
+    if (e != hipSuccess) return fail(ctx, NS_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    if (b.p && keep) {
+        e = hipMemcpyAsync(np, b.p, keep, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { hipError_t e2 = hipFree(np); (void)e2; return fail(ctx, NS_EHIP, std::string("hipMemcpy: ") + hipGetErrorString(e)); }
+    }
+    if (b.p) { e = hipFree(b.p); (void)e; }
+    b.p = np; b.cap = want;
     return NS_OK;
 }
 
@@ -740,7 +847,9 @@ void ns_destroy(ns_ctx *ctx) {
                       &ctx->err_len, &ctx->err_off, &ctx->name_len, &ctx->reads, &ctx->pieces, &ctx->events,
                       &ctx->records, &ctx->errlog, &ctx->stats, &ctx->scan_tmp, &ctx->sort_key, &ctx->sort_idx,
                       &ctx->sort_key_out, &ctx->order, &ctx->list_b, &ctx->rstate, &ctx->att_base, &ctx->scr, &ctx->scrq,
-                      &ctx->scr_len, &ctx->scr_off, &ctx->hp_len};
+                      &ctx->scr_len, &ctx->scr_off, &ctx->hp_len, &ctx->species_chrom_off, &ctx->t_reads, &ctx->t_pieces,
+                      &ctx->t_name_len, &ctx->t_rec_len, &ctx->t_err_len, &ctx->accept, &ctx->accept_scan, &ctx->key_pos,
+                      &ctx->draw_x, &ctx->m_segptr, &ctx->m_len, &ctx->m_species, &ctx->species_bases};
     for (DevBuf *b : bufs)
         if (b->p) e = hipFree(b->p);
     if (ctx->evt_ok)
@@ -754,6 +863,7 @@ static int set_ref_meta(ns_ctx *ctx, const uint64_t *chrom_off, uint32_t nchrom,
                         const char *names, uint64_t names_len) {
     if (!chrom_off || !nchrom || !circular || !names) return fail(ctx, NS_EINVAL, "reference metadata missing");
     free_pool(ctx->ref_allocs);
+    ctx->nspecies = 0;                           // the species view belongs to the previous reference
     std::vector<uint32_t> noff(nchrom + 1);
     uint64_t p = 0;
     for (uint32_t c = 0; c < nchrom; ++c) {
@@ -954,6 +1064,251 @@ static int scan_u32(ns_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n) {
     return NS_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// metagenome (src/simulator.py:758-811, 814-1040)
+// ---------------------------------------------------------------------------------------------------------
+int ns_set_species(ns_ctx *ctx, uint32_t nspecies, const uint32_t *species_chrom_off) {
+    if (!ctx) return NS_EINVAL;
+    if (!ctx->has_ref) return fail(ctx, NS_ESTATE, "ns_set_species before ns_set_reference");
+    if (!nspecies || nspecies > 65535u || !species_chrom_off) return fail(ctx, NS_EINVAL, "bad species table");
+    if (species_chrom_off[0] != 0 || species_chrom_off[nspecies] != ctx->ref.nchrom) return fail(ctx, NS_EINVAL, "species_chrom_off does not cover the reference");
+    for (uint32_t s = 0; s < nspecies; ++s)
+        if (species_chrom_off[s + 1] <= species_chrom_off[s]) return fail(ctx, NS_EINVAL, "species without chromosomes");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = ensure(ctx, ctx->species_chrom_off, ((size_t)nspecies + 1) * 4);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(ctx->species_chrom_off.p, species_chrom_off, ((size_t)nspecies + 1) * 4, hipMemcpyHostToDevice));
+    ctx->nspecies = nspecies;
+    ctx->has_abun = ctx->has_inflated = false;
+    return NS_OK;
+}
+
+int ns_set_abundance(ns_ctx *ctx, const double *abun, const double *abun_inflated) {
+    if (!ctx) return NS_EINVAL;
+    if (!ctx->nspecies) return fail(ctx, NS_ESTATE, "ns_set_abundance before ns_set_species");
+    if (!abun) return fail(ctx, NS_EINVAL, "null abundance table");
+    ctx->abun.assign(abun, abun + ctx->nspecies);
+    ctx->has_abun = true;
+    ctx->has_inflated = abun_inflated != nullptr;
+    if (abun_inflated) ctx->abun_inflated.assign(abun_inflated, abun_inflated + ctx->nspecies);
+    return NS_OK;
+}
+
+int ns_species_bases(ns_ctx *ctx, double *out) {
+    if (!ctx) return NS_EINVAL;
+    if (!out) return fail(ctx, NS_EINVAL, "null destination");
+    if (!ctx->has_batch || ctx->last_species_bases.size() != ctx->nspecies) return fail(ctx, NS_ESTATE, "no metagenome batch");
+    for (uint32_t s = 0; s < ctx->nspecies; ++s) out[s] = ctx->last_species_bases[s];
+    return NS_OK;
+}
+
+// assign_species (S:758-811): the species of every segment of a pass, by greedy quota.  lens: the filtered length list of the
+// pass (in draw order); on return the list in assignment order (chimeric segments first, the rest descending).  Draws keyed by
+// the batch: Philox(ST_SPECIES, attempt = pass, idx = segment pointer): word 0 = random.choice, word 1 = random.uniform(0, 100).
+static uint64_t assign_species_host(const ns_ctx *ctx, const ns_params *prm, uint32_t pass, std::vector<double> &lens,
+                                    std::vector<int32_t> &segs, const std::vector<double> &cur_bases, std::vector<uint16_t> &species) {
+    const uint32_t ns = ctx->nspecies;
+    const uint64_t n_len = lens.size();
+    uint64_t chim = 0;
+    for (int32_t v : segs) if (v > 1) chim += (uint64_t)v;                       // S:761
+    if (chim > n_len) chim = n_len;
+    double to_add = 0;
+    for (double v : lens) to_add += v;                                           // sum(length_list), in list order
+    std::sort(segs.begin(), segs.end(), std::greater<int32_t>());                // S:760
+    std::sort(lens.begin() + (ptrdiff_t)chim, lens.end(), std::greater<double>());   // S:764-765
+    double have = 0, abun_total = 0;
+    for (uint32_t s = 0; s < ns; ++s) { have += cur_bases[s]; abun_total += ctx->abun[s]; }
+    const double all_bases = to_add + have;
+    std::vector<double> quota(ns);
+    for (uint32_t s = 0; s < ns; ++s) quota[s] = all_bases * ctx->abun[s] / abun_total - cur_bases[s];   // S:772-775
+    const ns_key bkey{(uint32_t)prm->seed, (uint32_t)(prm->seed >> 32), (uint32_t)prm->first_read, (uint32_t)(prm->first_read >> 32)};
+    std::vector<uint32_t> cand(ns);
+    species.assign(n_len, 0);
+    uint64_t ptr = 0;
+    uint32_t prev = 0;
+    auto fitting = [&](double len, int skip) {              // species whose quota still holds `len` (S:785-788: else any with quota left)
+        uint32_t c = 0;
+        for (uint32_t s = 0; s < ns; ++s) if (quota[s] - len > 0 && (int)s != skip) cand[c++] = s;
+        return c;
+    };
+    auto any_left = [&]() { uint32_t c = 0; for (uint32_t s = 0; s < ns; ++s) if (quota[s] > 0) cand[c++] = s; return c; };
+    for (size_t r = 0; r < segs.size(); ++r) {
+        const int32_t seg = segs[r];
+        if (ptr + (uint64_t)seg > n_len) break;                                  // S:781-782
+        for (int32_t k = 0; k < seg; ++k) {
+            const double len = lens[ptr];
+            const u32x4 w = ns_draw(bkey, ST_SPECIES, 0, pass, (uint32_t)ptr, (uint32_t)(ptr >> 32));
+            auto choose = [&](uint32_t c) { return cand[(uint32_t)(((uint64_t)w.x * c) >> 32)]; };
+            uint32_t sp, c;
+            bool fresh = k == 0;
+            if (!fresh) {                                                        // S:791-803: stay with the previous species?
+                c = fitting(len, (int)prev);
+                const double pct = 100.0 * u32_to_p(w.y);
+                if (pct <= ctx->abun_inflated[prev] && quota[prev] > 0) sp = prev;
+                else if (pct > ctx->abun_inflated[prev] && c > 0) sp = choose(c);
+                else fresh = true;
+            }
+            if (fresh) {
+                c = fitting(len, -1);
+                if (!c) c = any_left();
+                if (!c) return ptr;
+                sp = choose(c);
+            }
+            species[ptr] = (uint16_t)sp;
+            quota[sp] -= len;
+            prev = sp;
+            ++ptr;
+        }
+    }
+    return ptr;
+}
+
+// the passes of one metagenome worker: every pass draws fresh lengths for the reads still missing, assigns species and tries
+// each read once; accepted reads take consecutive numbers
+static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, GenArgs &A, uint64_t &tot_pieces, uint64_t &tot_cap,
+                       unsigned long long *stats) {
+    const size_t n = (size_t)prm->n_reads;
+    const uint32_t ns = ctx->nspecies;
+    hipStream_t st = ctx->stream;
+    const dim3 blk(256);
+    int rc;
+    float ms = 0;
+    HIPCHK(hipMemsetAsync(ctx->stats.p, 0, 8 * sizeof(unsigned long long), st));
+    HIPCHK(hipEventRecord(ctx->evt[1], st));
+    k_nseg<<<dim3((unsigned)((n + 1 + 255) / 256)), blk, 0, st>>>(A);       // num_segment (S:825-828); zeroes the scan sentinels
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> npc(n);
+    HIPCHK(hipMemcpyAsync(npc.data(), A.n_pieces, n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<int32_t> nseg(n);
+    tot_pieces = 0;
+    uint64_t tot_seg = 0;
+    for (size_t i = 0; i < n; ++i) { nseg[i] = (int32_t)((npc[i] + 1) / 2); tot_pieces += npc[i]; tot_seg += (uint64_t)nseg[i]; }
+    if ((rc = ensure(ctx, ctx->pieces, tot_pieces * sizeof(ns_piece) + 64)) || (rc = ensure(ctx, ctx->t_pieces, tot_pieces * sizeof(ns_piece) + 64)) ||
+        (rc = ensure(ctx, ctx->t_reads, n * sizeof(ns_read))) || (rc = ensure(ctx, ctx->t_name_len, (n + 1) * 2)) ||
+        (rc = ensure(ctx, ctx->t_rec_len, (n + 1) * 8)) || (rc = ensure(ctx, ctx->t_err_len, (n + 1) * 8)) ||
+        (rc = ensure(ctx, ctx->accept, (n + 1) * 8)) || (rc = ensure(ctx, ctx->accept_scan, (n + 1) * 8)) ||
+        (rc = ensure(ctx, ctx->key_pos, (n + 1) * 4)) || (rc = ensure(ctx, ctx->draw_x, (tot_seg + 1) * 8)) ||
+        (rc = ensure(ctx, ctx->m_segptr, (n + 1) * 4)) || (rc = ensure(ctx, ctx->m_len, (tot_seg + 1) * 4)) ||
+        (rc = ensure(ctx, ctx->m_species, (tot_seg + 1) * 2)) || (rc = ensure(ctx, ctx->species_bases, (size_t)ns * 8)))
+        return rc;
+    HIPCHK(hipMemsetAsync(ctx->species_bases.p, 0, (size_t)ns * 8, st));
+    // final arrays (what the record kernels read) and the per-pass views of the same kernels
+    A.f_reads = (ns_read *)ctx->reads.p; A.f_pieces = (ns_piece *)ctx->pieces.p; A.f_name_len = (uint16_t *)ctx->name_len.p;
+    A.f_rec_len = (uint64_t *)ctx->rec_len.p; A.f_err_len = (uint64_t *)ctx->err_len.p;
+    A.key_pos_w = (uint32_t *)ctx->key_pos.p;
+    A.species_bases = (unsigned long long *)ctx->species_bases.p;
+    GenArgs P = A;
+    P.reads = (ns_read *)ctx->t_reads.p; P.pieces = (ns_piece *)ctx->t_pieces.p; P.name_len = (uint16_t *)ctx->t_name_len.p;
+    P.rec_len = (uint64_t *)ctx->t_rec_len.p; P.err_len = (uint64_t *)ctx->t_err_len.p;
+    P.accept = (uint64_t *)ctx->accept.p; P.accept_scan = (uint64_t *)ctx->accept_scan.p;
+    P.draw_x = (double *)ctx->draw_x.p;
+    P.m_segptr = (const uint32_t *)ctx->m_segptr.p; P.m_len = (const int32_t *)ctx->m_len.p; P.m_species = (const uint16_t *)ctx->m_species.p;
+    P.list = nullptr;
+    P.cap_rate = ctx->cap_rate;
+    const bool lds = ctx->lds_tables;
+    const ns_key bkey{(uint32_t)prm->seed, (uint32_t)(prm->seed >> 32), (uint32_t)prm->first_read, (uint32_t)(prm->first_read >> 32)};
+    std::vector<double> cur_bases(ns, 0.0), draws, lens;
+    std::vector<unsigned long long> sb(ns);
+    std::vector<int32_t> segs, mlen;
+    std::vector<uint16_t> species;
+    std::vector<uint32_t> segptr, pieceoff;
+    uint64_t passed = 0, pieces_passed = 0, ev_base = 0;
+    double ms_chain = 0;
+    unsigned long long good_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // counters after the last complete pass
+    bool first_pass = true;
+    for (uint32_t p = 0; passed < n; ++p) {
+        if (p >= NS_MAX_ATTEMPT)
+            return fail(ctx, NS_EINVAL, "some reads found no acceptable length within the attempt limit "
+                                        "(min_len/max_len too narrow for this model)");
+        const uint64_t m = n - passed;
+        segs.assign(nseg.begin() + (ptrdiff_t)passed, nseg.end());                // num_segment[passed:], S:1034
+        uint64_t D = 0;
+        for (int32_t v : segs) D += (uint64_t)v;
+        P.attempt = p; P.draw_n = D;
+        k_meta_draw<<<dim3((unsigned)((D + 255) / 256)), blk, 0, st>>>(P);         // S:852
+        HIPCHK(hipGetLastError());
+        draws.resize(D);
+        HIPCHK(hipMemcpyAsync(draws.data(), P.draw_x, D * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        lens.clear();
+        for (double x : draws) if (0 < x && x <= (double)prm->max_len) lens.push_back(x);      // S:857
+        if (lens.empty()) continue;                                                // S:858-859
+        const uint64_t P_seg = assign_species_host(ctx, prm, p, lens, segs, cur_bases, species);   // S:866-867
+        P.m_reversed = u32_to_p(ns_draw(bkey, ST_STRAND, 0, p, 0, 0).x) > ctx->m.strandness_rate ? 1u : 0u;   // S:860
+        segptr.clear(); pieceoff.clear();
+        uint64_t sp = 0, po = 0;
+        for (uint64_t i = 0; i < m; ++i) {                                         // S:862-865: reads that still get their lengths
+            const uint64_t k = (uint64_t)segs[i];
+            if (sp + k > P_seg) break;
+            segptr.push_back((uint32_t)sp); pieceoff.push_back((uint32_t)po);
+            sp += k; po += 2 * k - 1;
+        }
+        const size_t np = segptr.size();
+        if (!np) continue;
+        segptr.push_back((uint32_t)sp); pieceoff.push_back((uint32_t)po);
+        mlen.resize(sp);
+        for (uint64_t j = 0; j < sp; ++j) mlen[j] = (int32_t)nearbyint(lens[j]);   // S:871
+        HIPCHK(hipMemcpyAsync(ctx->m_segptr.p, segptr.data(), (np + 1) * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(ctx->piece_off.p, pieceoff.data(), (np + 1) * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(ctx->m_len.p, mlen.data(), sp * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(ctx->m_species.p, species.data(), sp * 2, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(P.accept, 0, (np + 1) * 8, st));
+        HIPCHK(hipMemsetAsync(P.ev_cap + np, 0, 8, st));
+        P.list_n = (uint32_t)np;
+        const dim3 grid_p((unsigned)((np + 255) / 256));
+        uint64_t pass_cap = 0;
+        for (int retry = 0;; ++retry) {
+        k_lengths<<<grid_p, blk, 0, st>>>(P);                                      // gaps, head/tail, planned pieces (S:872, 898-903)
+        HIPCHK(hipGetLastError());
+        if ((rc = scan_u64(ctx, P.ev_cap, P.ev_off, np + 1))) return rc;
+        HIPCHK(hipMemcpyAsync(&pass_cap, P.ev_off + np, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));     // also: the host vectors above are free to change again
+        if ((rc = ensure_keep(ctx, ctx->events, (size_t)(ev_base + pass_cap) * sizeof(ns_event) + 64, (size_t)ev_base * sizeof(ns_event)))) return rc;
+        P.events = (ns_event *)ctx->events.p; P.ev_base = ev_base;
+        P.m_passed = (uint32_t)passed; P.m_pieces_passed = (uint32_t)pieces_passed;
+        HIPCHK(hipEventRecord(ctx->evt[3], st));
+        if (first_pass && retry == 0) { HIPCHK(hipEventRecord(ctx->evt[2], st)); first_pass = false; }
+        if (lds) k_chain<true, false><<<grid_p, blk, ctx->lds_bytes, st>>>(P);
+        else k_chain<false, false><<<grid_p, blk, 0, st>>>(P);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ctx->evt[4], st));
+        HIPCHK(hipMemcpyAsync(stats, ctx->stats.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipEventElapsedTime(&ms, ctx->evt[3], ctx->evt[4])); ms_chain += ms;
+        if (!stats[0]) break;
+        // a read outgrew its event capacity (rare): the pass is repeated with twice the capacity
+        info->n_overflow += stats[0];
+        if (retry >= 6) return fail(ctx, NS_ENOMEM, "event capacity overflow persists after 6 retries");
+        P.cap_rate *= 2.0; P.cap_gap_mul *= 2;
+        HIPCHK(hipMemcpyAsync(ctx->stats.p, good_stats, 8 * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(P.accept, 0, (np + 1) * 8, st));
+        }
+        memcpy(good_stats, stats, sizeof good_stats);
+        if ((rc = scan_u64(ctx, P.accept, P.accept_scan, np + 1))) return rc;
+        k_meta_commit<<<grid_p, blk, 0, st>>>(P);
+        HIPCHK(hipGetLastError());
+        uint64_t acc = 0;
+        HIPCHK(hipMemcpyAsync(&acc, P.accept_scan + np, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(sb.data(), ctx->species_bases.p, (size_t)ns * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (uint32_t s = 0; s < ns; ++s) cur_bases[s] = (double)sb[s];
+        passed += acc & 0xffffffffull; pieces_passed += acc >> 32;
+        ev_base += pass_cap;
+    }
+    if (first_pass) HIPCHK(hipEventRecord(ctx->evt[2], st));
+    A.events = (ns_event *)ctx->events.p;
+    A.pieces = (ns_piece *)ctx->pieces.p;
+    A.key_pos = (const uint32_t *)ctx->key_pos.p;
+    A.m_species = P.m_species; A.m_segptr = P.m_segptr;
+    tot_pieces = pieces_passed;
+    tot_cap = ev_base;
+    ctx->last_species_bases = cur_bases;
+    info->ms_kernel[NS_K_EVENTS] = ms_chain;
+    return NS_OK;
+}
+
 int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     if (!ctx) return NS_EINVAL;
     if (!prm || !info) return fail(ctx, NS_EINVAL, "null params/info");
@@ -966,6 +1321,14 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     if (prm->chimeric && !(ctx->m.flags & NS_MODEL_HAS_CHIMERIC)) return fail(ctx, NS_EINVAL, "model has no chimeric tables");
     const bool hp_on = prm->kmer_bias && prm->kind == NS_KIND_ALIGNED;      // S:1413: only aligned segments; --perfect never
     if (hp_on && !(ctx->m.flags & NS_MODEL_HAS_HP)) return fail(ctx, NS_EINVAL, "-k needs the homopolymer model (-hp)");
+    const bool meta_al = prm->meta && prm->kind == NS_KIND_ALIGNED;
+    if (prm->meta) {
+        if (!ctx->nspecies) return fail(ctx, NS_ESTATE, "metagenome batch before ns_set_species");
+        if (prm->kind == NS_KIND_PERFECT || prm->kmer_bias) return fail(ctx, NS_EINVAL, "metagenome batches support neither --perfect nor -k");
+        if (meta_al && prm->use_lognormal) return fail(ctx, NS_EINVAL, "metagenome batches draw read lengths from the model (no -med/-sd)");
+        if (meta_al && !ctx->has_abun) return fail(ctx, NS_ESTATE, "metagenome batch before ns_set_abundance");
+        if (meta_al && prm->chimeric && !ctx->has_inflated) return fail(ctx, NS_EINVAL, "chimeric metagenome batch needs abun_inflated");
+    }
     if (prm->n_reads > 0x7ffffff0ull) return fail(ctx, NS_EINVAL, "batch too large (split into several calls)");
     if (prm->first_read + prm->n_reads >= (1ull << 40)) return fail(ctx, NS_EINVAL, "read index exceeds 2^40");
     HIPCHK(hipSetDevice(ctx->device));
@@ -1001,6 +1364,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     A.rstate = (uint32_t *)ctx->rstate.p; A.att_base = (uint32_t *)ctx->att_base.p;
     A.scr_len = (uint64_t *)ctx->scr_len.p; A.scr_off = (uint64_t *)ctx->scr_off.p;
     A.hp = hp_on ? 1u : 0u; A.keep_state = 0;
+    A.meta = prm->meta ? 1u : 0u; A.nspecies = ctx->nspecies; A.species_chrom_off = (const uint32_t *)ctx->species_chrom_off.p;
     A.next_n = (uint32_t *)((unsigned long long *)ctx->stats.p + 6);
     uint32_t *list_a = (uint32_t *)ctx->order.p, *list_b = (uint32_t *)ctx->list_b.p;
     const dim3 blk(256);
@@ -1014,7 +1378,8 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     float ms = 0;
     HIPCHK(hipEventRecord(ctx->evt[0], st));
     double ms_hp = 0;
-    for (int hp_round = 0;; ++hp_round) {
+    if (meta_al && (rc = meta_passes(ctx, prm, info, A, tot_pieces, tot_cap, stats))) return rc;
+    for (int hp_round = 0; !meta_al; ++hp_round) {
     for (int retry = 0;; ++retry) {
         A.cap_rate = cap_rate;
         HIPCHK(hipMemsetAsync(ctx->stats.p, 0, 8 * sizeof(unsigned long long), st));

@@ -256,6 +256,40 @@ __device__ inline bool extract_pos(const DevRef &ref, int64_t length, const ns_k
     return false;
 }
 
+// extract_read, metagenome branch (S:1704-1749).  species < 0: any species (gaps, unaligned reads).  Draw layout: block idx 0
+// of (ST_POS, seg, attempt): word 0 species, word 1 chromosome, word 2 fall-back choice; block idx 1: 53-bit position.
+__device__ inline bool extract_pos_meta(const DevRef &ref, const uint32_t *__restrict__ sp_off, uint32_t nspecies, int64_t length,
+                                        int species, const ns_key &key, uint32_t seg, uint32_t attempt, uint32_t &chrom, uint64_t &pos) {
+    const u32x4 wa = ns_draw(key, ST_POS, seg, attempt, 0, 0), wb = ns_draw(key, ST_POS, seg, attempt, 1, 0);
+    const uint32_t s = species < 0 ? (uint32_t)(((uint64_t)wa.x * nspecies) >> 32) : (uint32_t)species;
+    const uint32_t nch = sp_off[s + 1] - sp_off[s];
+    uint32_t c = sp_off[s] + (uint32_t)(((uint64_t)wa.y * nch) >> 32);
+    uint64_t clen = ref.chrom_off[c + 1] - ref.chrom_off[c];
+    if ((uint64_t)length > clen) {                                   // S:1711-1735: a longer chromosome, of this species if any
+        uint32_t nt = 0, no = 0;
+        const uint32_t total = sp_off[nspecies];
+        for (uint32_t ts = 0; ts < nspecies; ++ts)
+            for (uint32_t k = sp_off[ts]; k < sp_off[ts + 1]; ++k)
+                if ((uint64_t)length < ref.chrom_off[k + 1] - ref.chrom_off[k]) { if (ts == s) ++nt; else ++no; }
+        if (!nt && !no) return false;
+        const bool same = nt > 0;
+        uint32_t pick = (uint32_t)(((uint64_t)wa.z * (same ? nt : no)) >> 32), seen = 0;
+        for (uint32_t ts = 0, done = 0; ts < nspecies && !done; ++ts)
+            for (uint32_t k = sp_off[ts]; k < sp_off[ts + 1]; ++k)
+                if ((uint64_t)length < ref.chrom_off[k + 1] - ref.chrom_off[k] && ((ts == s) == same)) {
+                    if (seen == pick) { c = k; done = 1; break; }
+                    ++seen;
+                }
+        (void)total;
+        clen = ref.chrom_off[c + 1] - ref.chrom_off[c];
+    }
+    const uint64_t span = ref.circular[c] ? clen + 1 : clen - (uint64_t)length + 1;     // randint(0, len) / randint(0, len - length)
+    uint64_t rp = (uint64_t)(u53_to_p(wb.x, wb.y) * (double)span);
+    if (rp >= span) rp = span - 1;
+    chrom = c; pos = rp;
+    return true;
+}
+
 // ---- letters ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint8_t bases_atcg(uint32_t j) { return (uint8_t)(0x47435441u >> (8 * j)); }   // BASES, S:49
 __device__ __forceinline__ int base_rank(uint32_t c) { return c == 'A' ? 0 : c == 'T' ? 1 : c == 'C' ? 2 : c == 'G' ? 3 : -1; }

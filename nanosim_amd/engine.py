@@ -17,7 +17,8 @@ NS_BUF_RECORDS, NS_BUF_READS, NS_BUF_PIECES, NS_BUF_EVENTS, NS_BUF_ERRLOG = 0, 1
 NS_KIND_ALIGNED, NS_KIND_UNALIGNED, NS_KIND_PERFECT = 0, 1, 2
 KERNEL_NAMES = ("plan(k_nseg+k_lengths+scan+sort)", "k_chain", "k_names", "k_materialise", "k_hp", "k_errlog")
 EXPORTS = ("ns_abi_version", "ns_create", "ns_destroy", "ns_last_error", "ns_set_reference",
-           "ns_set_reference_device", "ns_load_model", "ns_generate", "ns_copy_out", "ns_device_ptr")
+           "ns_set_reference_device", "ns_load_model", "ns_generate", "ns_copy_out", "ns_device_ptr",
+           "ns_set_species", "ns_set_abundance", "ns_species_bases")
 
 _lib = None
 
@@ -55,6 +56,12 @@ def load_library(path: str = LIB_PATH):
     L.ns_copy_out.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64]
     L.ns_device_ptr.restype = C.c_void_p
     L.ns_device_ptr.argtypes = [C.c_void_p, C.c_int]
+    L.ns_set_species.restype = C.c_int
+    L.ns_set_species.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    L.ns_set_abundance.restype = C.c_int
+    L.ns_set_abundance.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ns_species_bases.restype = C.c_int
+    L.ns_species_bases.argtypes = [C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -134,6 +141,24 @@ class Engine:
         self._check(self.L.ns_set_reference_device(self.ctx, dev_ptr, ref.genome_len, ref.chrom_off.ctypes.data,
                                                    len(ref.names), ref.circular.ctypes.data, blob, len(blob)))
 
+    def set_metagenome(self, meta_ref, abun: dict, abun_inflated: dict | None = None):
+        """meta_ref: nanosim_amd.metagenome.MetaReference; abun/abun_inflated: {species: value} of the sample."""
+        self.set_reference(meta_ref.ref)
+        sco = np.ascontiguousarray(meta_ref.species_chrom_off, dtype=np.uint32)
+        self._check(self.L.ns_set_species(self.ctx, len(meta_ref.species), sco.ctypes.data))
+        self.set_abundance(meta_ref, abun, abun_inflated)
+
+    def set_abundance(self, meta_ref, abun: dict, abun_inflated: dict | None = None):
+        ab = np.array([abun[sp] for sp in meta_ref.species], dtype=np.float64)
+        inf = np.array([abun_inflated[sp] for sp in meta_ref.species], dtype=np.float64) if abun_inflated else None
+        self._check(self.L.ns_set_abundance(self.ctx, ab.ctypes.data, inf.ctypes.data if inf is not None else None))
+        self._nspecies = len(meta_ref.species)
+
+    def species_bases(self) -> np.ndarray:
+        out = np.zeros(self._nspecies, dtype=np.float64)
+        self._check(self.L.ns_species_bases(self.ctx, out.ctypes.data))
+        return out
+
     def load_model(self, model: Model):
         t = model.to_c()
         self._check(self.L.ns_load_model(self.ctx, C.byref(t)))
@@ -145,7 +170,7 @@ class Engine:
 
 
 def make_params(*, seed, first_read, n_reads, kind=NS_KIND_ALIGNED, fastq=False, kmer_bias=0, chimeric=False,
-                min_len=50, max_len, median_len=None, sd_len=None, emit_records=True, emit_errlog=False) -> NsParams:
+                min_len=50, max_len, median_len=None, sd_len=None, emit_records=True, emit_errlog=False, meta=False) -> NsParams:
     p = NsParams()
     p.seed, p.first_read, p.n_reads, p.kind = seed, first_read, n_reads, kind
     p.fastq, p.kmer_bias, p.chimeric = int(bool(fastq)), int(kmer_bias or 0), int(bool(chimeric))
@@ -153,4 +178,5 @@ def make_params(*, seed, first_read, n_reads, kind=NS_KIND_ALIGNED, fastq=False,
     p.emit_records, p.emit_errlog = int(bool(emit_records)), int(bool(emit_errlog))
     p.min_len, p.max_len = int(min_len), int(max_len)
     p.median_len, p.sd_len = float(median_len or 0.0), float(sd_len or 0.0)
+    p.meta = int(bool(meta))
     return p

@@ -66,7 +66,7 @@ class NsParams(C.Structure):
                 ("use_lognormal", C.c_uint32), ("emit_records", C.c_uint32),
                 ("min_len", C.c_int64), ("max_len", C.c_int64),
                 ("median_len", C.c_double), ("sd_len", C.c_double),
-                ("emit_errlog", C.c_uint32), ("_pad", C.c_uint32)]
+                ("emit_errlog", C.c_uint32), ("meta", C.c_uint32)]
 
 
 class NsBatchInfo(C.Structure):

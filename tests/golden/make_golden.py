@@ -386,10 +386,10 @@ META_DIR = os.path.join(HERE, "meta")
 def build_meta_inputs():
     """Three synthetic species (committed FASTA files + the three metagenome config files of the CLI)."""
     os.makedirs(META_DIR, exist_ok=True)
-    synth.write_fasta(os.path.join(META_DIR, "Alpha_one.fa"), [("chrA1 alpha chromosome", synth.synth_sequence(30000, 301, iupac_frac=0.001))])
-    synth.write_fasta(os.path.join(META_DIR, "Beta_two.fa"), [("NC_100.1 beta chromosome 1", synth.synth_sequence(25000, 302, lower_frac=0.1)),
-                                                             ("NC_101.1 beta chromosome 2", synth.synth_sequence(8000, 303))])
-    synth.write_fasta(os.path.join(META_DIR, "Gamma_three.fa"), [("gchr", synth.synth_sequence(15000, 304, n_frac=0.01)),
+    synth.write_fasta(os.path.join(META_DIR, "Alpha_one.fa"), [("chrA1 alpha chromosome", synth.synth_sequence(120000, 301, iupac_frac=0.001))])
+    synth.write_fasta(os.path.join(META_DIR, "Beta_two.fa"), [("NC_100.1 beta chromosome 1", synth.synth_sequence(90000, 302, lower_frac=0.1)),
+                                                             ("NC_101.1 beta chromosome 2", synth.synth_sequence(20000, 303))])
+    synth.write_fasta(os.path.join(META_DIR, "Gamma_three.fa"), [("gchr", synth.synth_sequence(60000, 304, n_frac=0.01)),
                                                                 ("plasmid_p1", synth.synth_sequence(3000, 305))])
     with open(os.path.join(META_DIR, "genome_list.tsv"), "w") as f:
         f.write("Alpha one\ttests/golden/meta/Alpha_one.fa\nBeta two\ttests/golden/meta/Beta_two.fa\n"
@@ -443,7 +443,7 @@ def fixture_metagenome(S, prefix):
     ex = []
     random.seed(77)
     for sp in list(S.seq_len.keys()) + [None]:
-        for length in (10, 2000, 5000, 12000, 20000, 28000):
+        for length in (10, 2000, 5000, 25000, 70000, 100000):
             for rep in range(3):
                 with Recorder(S) as r:
                     try:

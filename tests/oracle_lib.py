@@ -108,6 +108,9 @@ def lib():
         L.nso_extract_meta.restype = C.c_int
         L.nso_extract_meta.argtypes = [C.POINTER(NsoMeta), C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(NsoDraw),
                                        C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        L.nso_generate_meta.restype = C.c_int
+        L.nso_generate_meta.argtypes = [C.POINTER(NsModelTables), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_char_p,
+                                        C.POINTER(NsoMeta), C.POINTER(NsParams), C.POINTER(NsoOut), C.c_void_p]
         L.nso_generate.restype = C.c_int
         L.nso_generate.argtypes = [C.POINTER(NsModelTables), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
                                    C.c_char_p, C.POINTER(NsParams), C.POINTER(NsoOut)]
@@ -174,3 +177,31 @@ def generate(model, ref, params: NsParams, *, bytes_per_read=40000, events_per_r
     return dict(reads=reads, pieces=pieces[:o.n_pieces], events=events[:o.n_events],
                 records=records[:o.record_bytes], errlog=errlog[:o.errlog_bytes],
                 total_bases=int(o.total_bases), total_ref_bases=int(o.total_ref_bases))
+
+
+def generate_meta(model, meta_ref, abun: dict, abun_inflated, params: NsParams, *, bytes_per_read=40000, events_per_read=6000):
+    """Metagenome batch through the CPU restatement (one call = one reference worker)."""
+    L = lib()
+    t = model.to_c()
+    ref = meta_ref.ref
+    n = int(params.n_reads)
+    reads = np.zeros(n, dtype=READ_DTYPE)
+    pieces = np.zeros(n * 8 + 64, dtype=PIECE_DTYPE)
+    events = np.zeros(n * events_per_read + 1024, dtype=EVENT_DTYPE)
+    records = np.zeros(n * bytes_per_read + 4096, dtype=np.uint8)
+    errlog = np.zeros((n * bytes_per_read * 3 + 4096) if params.emit_errlog else 16, dtype=np.uint8)
+    o = NsoOut()
+    o.reads = reads.ctypes.data; o.pieces = pieces.ctypes.data; o.events = events.ctypes.data
+    o.cap_pieces = len(pieces); o.cap_events = len(events)
+    o.records = records.ctypes.data; o.cap_records = len(records)
+    o.errlog = errlog.ctypes.data; o.cap_errlog = len(errlog)
+    bases = normalise_bases(ref.bases)
+    mg, keep = make_meta(meta_ref, abun, abun_inflated)
+    sp_bases = np.zeros(len(meta_ref.species), dtype=np.float64)
+    rc = L.nso_generate_meta(C.byref(t), bases.ctypes.data, ref.chrom_off.ctypes.data, len(ref.names), ref.circular.ctypes.data,
+                             ref.names_blob(), C.byref(mg), C.byref(params), C.byref(o), sp_bases.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("nso_generate_meta failed: %d" % rc)
+    return dict(reads=reads, pieces=pieces[:o.n_pieces], events=events[:o.n_events], records=records[:o.record_bytes],
+                errlog=errlog[:o.errlog_bytes], total_bases=int(o.total_bases), total_ref_bases=int(o.total_ref_bases),
+                species_bases=sp_bases)

@@ -1,0 +1,94 @@
+"""GPU parity for metagenome batches: the HIP path through the C-ABI equals the CPU oracle
+bit for bit — pass structure, species assignment, read numbering, names with gap components, records, error rows and
+the per-species base counts."""
+import os
+
+import numpy as np
+import pytest
+
+from nanosim_amd import engine as E
+from nanosim_amd import metagenome as MG
+from nanosim_amd import model as M
+from tests import oracle_lib as O
+from tests.test_gpu_parity import compare
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+META = os.path.join(ROOT, "tests", "golden", "meta")
+
+
+@pytest.fixture(scope="module")
+def meta_ref():
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        return MG.read_metagenome(os.path.join(META, "genome_list.tsv"), os.path.join(META, "dna_type_list.tsv"))
+    finally:
+        os.chdir(cwd)
+
+
+@pytest.fixture(scope="module")
+def setup(small_model, meta_ref):
+    _, samples = MG.read_abundance(os.path.join(META, "abundance.tsv"), meta_ref.species)
+    abun = samples[0]
+    infl = {sp: MG.inflate_abun(abun, sp, small_model.abun_inflation) for sp in abun}
+    e = E.Engine(0)
+    e.set_metagenome(meta_ref, abun, infl)
+    e.load_model(small_model)
+    yield e, abun, infl
+    e.close()
+
+
+CASES = [
+    dict(n_reads=400, emit_errlog=True),
+    dict(n_reads=300, fastq=True, emit_errlog=True),
+    dict(n_reads=500, chimeric=True, fastq=True, emit_errlog=True),
+    dict(n_reads=600, chimeric=True),
+    dict(n_reads=300, min_len=3000, max_len=9000),                     # many passes: most reads are rejected per pass
+    dict(n_reads=300, chimeric=True, min_len=2000, max_len=20000, emit_errlog=True),
+    dict(n_reads=1, first_read=(1 << 33) + 11),
+    dict(n_reads=250, emit_records=False),
+    dict(n_reads=200, kind=E.NS_KIND_UNALIGNED, fastq=True),
+    dict(n_reads=150, kind=E.NS_KIND_UNALIGNED, median_len=900, sd_len=0.4),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_gpu_metagenome_equals_oracle(setup, small_model, meta_ref, case):
+    eng, abun, infl = setup
+    kw = dict(seed=0xFEED5EED77, first_read=0, max_len=meta_ref.max_chrom, meta=True)
+    kw.update(case)
+    p = E.make_params(**kw)
+    b = eng.generate(p)
+    exp = O.generate_meta(small_model, meta_ref, abun, infl if p.chimeric else None, p)
+    compare(b, exp, p)
+    if p.kind == E.NS_KIND_ALIGNED:
+        assert np.array_equal(eng.species_bases(), exp["species_bases"])
+
+
+def test_metagenome_batches_are_reproducible(setup, meta_ref):
+    eng, abun, infl = setup
+    p = E.make_params(seed=5, first_read=1000, n_reads=2000, chimeric=True, fastq=True, max_len=meta_ref.max_chrom, meta=True)
+    a = eng.generate(p).records().tobytes()
+    assert eng.generate(p).records().tobytes() == a
+    # a genome-mode batch on the same engine afterwards is unaffected by the metagenome state
+    g = E.make_params(seed=5, first_read=0, n_reads=50, max_len=20000)
+    assert eng.generate(g).records().tobytes() == eng.generate(g).records().tobytes()
+
+
+def test_metagenome_error_paths(small_model, small_ref, meta_ref, setup):
+    eng, abun, infl = setup
+    with pytest.raises(E.EngineError):
+        eng.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=9000, meta=True, kmer_bias=5))
+    with pytest.raises(E.EngineError):
+        eng.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=9000, meta=True, kind=E.NS_KIND_PERFECT))
+    with pytest.raises(E.EngineError):
+        eng.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=9000, meta=True, median_len=3000, sd_len=0.3))
+    e2 = E.Engine(0)
+    try:
+        e2.set_reference(small_ref)
+        e2.load_model(small_model)
+        with pytest.raises(E.EngineError):                       # no species view
+            e2.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=9000, meta=True))
+    finally:
+        e2.close()

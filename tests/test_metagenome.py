@@ -102,3 +102,53 @@ def test_extract_read_metagenome_tape_replay(fx, meta_ref):
         raw = meta_ref.ref.bases[idx]
         assert bytes(raw[:30]).decode() == case["head"] and bytes(raw[-30:]).decode() == case["tail"]
     assert n_warn > 0
+
+
+def _species_of_piece(meta_ref, chrom):
+    return np.searchsorted(meta_ref.species_chrom_off, chrom, side="right") - 1
+
+
+@pytest.mark.parametrize("chimeric", [False, True])
+def test_oracle_metagenome_batches_match_reference_runs(fx, meta_ref, chimeric):
+    """8 workers x 3000 reads of the reference vs 8 oracle batches: species base fractions (incl. the fall-back to other
+    species when a chromosome is too short), read lengths, chimeric share, one strand per pass, name grammar."""
+    from nanosim_amd import engine as E
+    from tests import oracle_lib as O
+    from tests.test_distributions import ks_vs_quantiles
+    run = fx["runs"]["chimeric" if chimeric else "plain"]
+    mdl = M.load_model(os.path.join(ROOT, "tests", "golden", "model_small", "training"), chimeric=True)
+    abun = fx["abun"]["sample0"]
+    infl = {sp: MG.inflate_abun(abun, sp, mdl.abun_inflation) for sp in abun} if chimeric else None
+    bases = np.zeros(len(meta_ref.species))
+    lens, n_chim, strands_single = [], 0, 0
+    for w in range(8):
+        p = E.make_params(seed=900 + w, first_read=w * 3000, n_reads=3000, chimeric=chimeric, max_len=meta_ref.max_chrom)
+        out = O.generate_meta(mdl, meta_ref, abun, infl, p)
+        rd, pc = out["reads"], out["pieces"]
+        aligned = pc[pc["kind"] == 0]
+        sp = _species_of_piece(meta_ref, aligned["chrom"])
+        bases += np.bincount(sp, weights=aligned["ref_len"], minlength=len(bases))
+        lens.append(rd["seq_len"])
+        n_chim += int(np.sum(rd["n_pieces"] > 1))
+        strands_single += len(set(rd["reversed"].tolist())) == 1
+        if w == 0:
+            names = [x[1:].decode() for x in out["records"].tobytes().split(b"\n")[0:-1:2]]
+            assert names[0].split("_aligned_")[1].startswith("0_")
+            for nm in names[:200]:
+                body = nm.split("_aligned_")[0]
+                for comp in body.split(";"):
+                    assert comp.startswith("gap_") or any(comp.startswith(s + "-") for s in meta_ref.species), nm
+    frac = bases / bases.sum()
+    ref_tot = sum(run["bases"].values())
+    for i, spn in enumerate(meta_ref.species):
+        assert abs(frac[i] - run["bases"][spn] / ref_tot) < 0.012, (spn, frac[i], run["bases"][spn] / ref_tot)
+    lens = np.concatenate(lens)
+    assert abs(lens.mean() / run["mean_len"] - 1) < 0.02
+    assert ks_vs_quantiles(lens, run["q_len"]) < 0.02
+    ref_chim = sum(wk["n_chim"] for wk in run["workers"])
+    if chimeric:
+        assert 0.5 * ref_chim <= n_chim <= 2.0 * ref_chim + 10, (n_chim, ref_chim)
+    else:
+        assert n_chim == 0
+    # S:860: the strand is drawn once per pass, so workers that finish in one pass have a single strand
+    assert strands_single >= 1 or sum(len(wk["strands"]) == 1 for wk in run["workers"]) == 0
