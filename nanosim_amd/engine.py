@@ -141,12 +141,18 @@ class Engine:
         self._check(self.L.ns_set_reference_device(self.ctx, dev_ptr, ref.genome_len, ref.chrom_off.ctypes.data,
                                                    len(ref.names), ref.circular.ctypes.data, blob, len(blob)))
 
-    def set_metagenome(self, meta_ref, abun: dict, abun_inflated: dict | None = None):
-        """meta_ref: nanosim_amd.metagenome.MetaReference; abun/abun_inflated: {species: value} of the sample."""
-        self.set_reference(meta_ref.ref)
+    def set_metagenome(self, meta_ref, abun: dict | None = None, abun_inflated: dict | None = None, dev_ptr: int | None = None):
+        """meta_ref: nanosim_amd.metagenome.MetaReference; abun/abun_inflated: {species: value} of the sample (may be
+        set later, per sample, with set_abundance); dev_ptr: the concatenated bases already on this GPU."""
+        if dev_ptr is None:
+            self.set_reference(meta_ref.ref)
+        else:
+            self.set_reference_device(dev_ptr, meta_ref.ref)
         sco = np.ascontiguousarray(meta_ref.species_chrom_off, dtype=np.uint32)
         self._check(self.L.ns_set_species(self.ctx, len(meta_ref.species), sco.ctypes.data))
-        self.set_abundance(meta_ref, abun, abun_inflated)
+        self._nspecies = len(meta_ref.species)
+        if abun is not None:
+            self.set_abundance(meta_ref, abun, abun_inflated)
 
     def set_abundance(self, meta_ref, abun: dict, abun_inflated: dict | None = None):
         ab = np.array([abun[sp] for sp in meta_ref.species], dtype=np.float64)

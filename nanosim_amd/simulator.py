@@ -109,7 +109,7 @@ def build_parser():
     mg.add_argument('--fastq', action='store_true', default=False)
     mg.add_argument('--chimeric', action='store_true', default=False)
     mg.add_argument('-t', '--num_threads', type=int, default=1)
-    return parser, g
+    return parser, g, mg
 
 
 def calculate_read_number_from_coverage(ref: M.Reference, model_prefix: str, coverage: float) -> int:
@@ -148,7 +148,7 @@ def validate_genome_args(a, parser_g):
 
 
 def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, chimeric, min_len, max_len, median_len,
-                   sd_len, want_errlog, kmer_bias=0):
+                   sd_len, want_errlog, kmer_bias=0, meta=False):
     done = 0
     with open(out_path, "wb") as fr:
         fe = open(err_path, "wb") if err_path else None
@@ -157,7 +157,7 @@ def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, 
                 n = min(BATCH_READS, count - done)
                 p = E.make_params(seed=seed, first_read=first + done, n_reads=n, kind=kind, fastq=fastq, chimeric=chimeric, kmer_bias=kmer_bias,
                                   min_len=min_len, max_len=max_len, median_len=median_len, sd_len=sd_len,
-                                  emit_records=True, emit_errlog=bool(fe))
+                                  emit_records=True, emit_errlog=bool(fe), meta=meta)
                 b = eng.generate(p)
                 fr.write(memoryview(b.records()))
                 if fe:
@@ -259,15 +259,114 @@ def run_genome(a, parser_g):
         log("Finished!")
 
 
+def run_metagenome(a, parser_mg):
+    """The metagenome branch of main() (S:2416-2527) + simulation("metagenome") (S:1568-1672).  One ns_generate call plays
+    one worker of the reference: it keeps its own per-species base quota (S:835) and numbers its reads consecutively."""
+    from . import metagenome as MG
+    validate_genome_args(a, parser_mg)
+    if a.perfect or a.homopolymer or a.KmerBias or (a.median_len and a.sd_len):
+        sys.stderr.write("\nmetagenome mode of this build simulates model-length reads with errors; --perfect, -hp/-k and "
+                         "-med/-sd are not available here yet (DESIGN.md section 5.7)\n")
+        sys.exit(2)
+    rank, local_rank, world = shard.env_rank_world()
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if rank == 0:
+        print("\nrunning the code with following parameters:\n")
+        for k in ("genome_list", "abun", "dna_type_list", "model_prefix"):
+            print(k, getattr(a, k))
+        print("out", a.output); print("perfect", a.perfect); print("strandness", a.strandness); print("sd_len", a.sd_len)
+        print("median_len", a.median_len); print("max_len", a.max_len); print("min_len", a.min_len); print("abun_var", a.abun_var)
+        print("fastq", a.fastq); print("chimeric", a.chimeric); print("num_threads", max(a.num_threads, 1))
+        log(' '.join(sys.argv))
+    out = a.output
+    d = os.path.dirname(out)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    eng = E.Engine(local_rank)
+    keep = None
+    if rank == 0:
+        log("Read in reference ")
+        mref = MG.read_metagenome(a.genome_list, a.dna_type_list)
+        numbers, samples = MG.read_abundance(a.abun, mref.species)
+    if dist is not None:
+        import torch
+        info = [dict(species=mref.species, off=mref.species_chrom_off.tolist(), keys=mref.chrom_names, numbers=numbers,
+                     samples=samples) if rank == 0 else None]
+        dist.broadcast_object_list(info, src=0)
+        ref, keep = shard.broadcast_reference(mref.ref if rank == 0 else None, dist, device=torch.device("cuda", local_rank))
+        mref = MG.MetaReference(ref, info[0]["species"], np.array(info[0]["off"], dtype=np.uint32), info[0]["keys"])
+        numbers, samples = info[0]["numbers"], info[0]["samples"]
+        eng.set_metagenome(mref, dev_ptr=keep.data_ptr())
+    else:
+        eng.set_metagenome(mref)
+    if rank == 0:
+        log("Read error profile")
+    mdl = M.load_model(a.model_prefix, strandness=a.strandness, chimeric=a.chimeric, fastq=a.fastq)
+    eng.load_model(mdl)
+    seed = a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little") >> 1
+    if dist is not None and a.seed is None:
+        box = [seed]
+        dist.broadcast_object_list(box, src=0)
+        seed = box[0]
+    ext = ".fastq" if a.fastq else ".fasta"
+    max_len = a.max_len
+    total_len = mref.total_len()
+    first = 0
+    for s, abun in enumerate(samples):
+        sample = "sample" + str(s)
+        if a.abun_var:                                                                      # S:2497-2506
+            u = np.random.default_rng([seed & 0xffffffff, seed >> 32, s]).random(len(total_len))
+            abun = MG.add_abundance_var(abun, total_len, float(a.abun_var[0]), float(a.abun_var[1]), iter(u.tolist()))
+        infl = {sp: MG.inflate_abun(abun, sp, mdl.abun_inflation) for sp in abun} if a.chimeric else None   # S:2510-2514
+        eng.set_abundance(mref, abun, infl)
+        if rank == 0:
+            log("Simulating sample " + sample)
+            log("Start simulation of aligned reads")
+        n_al, n_un = mdl.split_counts(numbers[s])
+        max_len = int(min(max_len, mref.max_chrom))                                         # S:2525
+        base = out + "_" + sample
+        lo, hi = shard.partition(n_al, world)[rank]
+        _write_batches(eng, base + "_aligned_reads%d%s" % (rank, ext), base + "_error_profile%d" % rank, seed=seed, first=first + lo,
+                       count=hi - lo, kind=E.NS_KIND_ALIGNED, fastq=a.fastq, chimeric=a.chimeric, min_len=a.min_len, max_len=max_len,
+                       median_len=None, sd_len=None, want_errlog=True, meta=True)
+        if dist is not None:
+            dist.barrier()
+        if rank == 0:
+            shard.merge_subfiles(base + "_aligned_reads" + ext, [base + "_aligned_reads%d%s" % (r, ext) for r in range(world)])
+            shard.merge_subfiles(base + "_aligned_error_profile", [base + "_error_profile%d" % r for r in range(world)], ERR_HEADER)
+            log("Start simulation of random reads")
+        lo, hi = shard.partition(n_un, world)[rank]
+        _write_batches(eng, base + "_unaligned_reads%d%s" % (rank, ext), None, seed=seed, first=first + n_al + lo, count=hi - lo,
+                       kind=E.NS_KIND_UNALIGNED, fastq=a.fastq, chimeric=False, min_len=a.min_len, max_len=max_len, median_len=None,
+                       sd_len=None, want_errlog=False, meta=True)
+        if dist is not None:
+            dist.barrier()
+        if rank == 0:
+            shard.merge_subfiles(base + "_unaligned_reads" + ext, [base + "_unaligned_reads%d%s" % (r, ext) for r in range(world)])
+        first += n_al + n_un            # samples draw from disjoint read-index ranges of the same seed
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    if rank == 0:
+        log("Finished!")
+
+
 def main(argv=None):
-    parser, parser_g = build_parser()
+    parser, parser_g, parser_mg = build_parser()
     if len(sys.argv if argv is None else argv) == (1 if argv is None else 0):
         parser.print_help(sys.stderr)
         sys.exit(1)
     a = parser.parse_args(argv)
     if a.mode == "genome":
         run_genome(a, parser_g)
-    elif a.mode in ("transcriptome", "metagenome"):
+    elif a.mode == "metagenome":
+        run_metagenome(a, parser_mg)
+    elif a.mode == "transcriptome":
         sys.stderr.write("\n%s mode is parsed for CLI compatibility but its driver is not part of this build yet "
                          "(SURVEY.md §8f); use genome mode.\n" % a.mode)
         sys.exit(2)

@@ -55,3 +55,38 @@ def test_perfect_mode(tmp_path, small_ref):
         assert len(seq) == ln
         unamb = np.isin(src, np.frombuffer(b"ACGT", dtype=np.uint8))
         assert np.all(np.frombuffer(seq.encode(), dtype=np.uint8)[unamb] == src[unamb])
+
+
+def test_metagenome_mode_end_to_end(tmp_path, small_model):
+    """Two samples (3000 + 500 reads), chimeric FASTQ: the reference's per-sample file set; every sample equals the oracle's
+    worker for the same (seed, read range, abundances)."""
+    from nanosim_amd import metagenome as MG
+    meta = os.path.join(GOLDEN, "meta")
+    out = str(tmp_path / "mg" / "sim")
+    cwd = os.getcwd()
+    os.chdir(ROOT)                               # the genome list holds paths relative to the repo root
+    try:
+        simulator.main(["metagenome", "-gl", os.path.join(meta, "genome_list.tsv"), "-a", os.path.join(meta, "abundance.tsv"),
+                        "-dl", os.path.join(meta, "dna_type_list.tsv"), "-c", os.path.join(GOLDEN, "model_small", "training"),
+                        "-o", out, "--seed", "777", "--chimeric", "--fastq"])
+        mref = MG.read_metagenome(os.path.join(meta, "genome_list.tsv"), os.path.join(meta, "dna_type_list.tsv"))
+    finally:
+        os.chdir(cwd)
+    files = sorted(os.listdir(tmp_path / "mg"))
+    assert files == sorted("sim_sample%d_%s" % (s, f) for s in (0, 1)
+                           for f in ("aligned_error_profile", "aligned_reads.fastq", "unaligned_reads.fastq"))
+    numbers, samples = MG.read_abundance(os.path.join(meta, "abundance.tsv"), mref.species)
+    mdl = M.load_model(os.path.join(GOLDEN, "model_small", "training"), chimeric=True, fastq=True)
+    first = 0
+    for s, abun in enumerate(samples):
+        n_al, n_un = mdl.split_counts(numbers[s])
+        infl = {sp: MG.inflate_abun(abun, sp, mdl.abun_inflation) for sp in abun}
+        p = E.make_params(seed=777, first_read=first, n_reads=n_al, fastq=True, chimeric=True, max_len=mref.max_chrom, emit_errlog=True, meta=True)
+        exp = O.generate_meta(mdl, mref, abun, infl, p)
+        base = out + "_sample%d" % s
+        assert open(base + "_aligned_reads.fastq", "rb").read() == exp["records"].tobytes()
+        assert open(base + "_aligned_error_profile", "rb").read() == simulator.ERR_HEADER + exp["errlog"].tobytes()
+        p = E.make_params(seed=777, first_read=first + n_al, n_reads=n_un, kind=E.NS_KIND_UNALIGNED, fastq=True, max_len=mref.max_chrom, meta=True)
+        exp = O.generate_meta(mdl, mref, abun, None, p)
+        assert open(base + "_unaligned_reads.fastq", "rb").read() == exp["records"].tobytes()
+        first += n_al + n_un

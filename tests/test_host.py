@@ -15,7 +15,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def test_cli_accepts_the_reference_flag_surface():
-    parser, _ = simulator.build_parser()
+    parser = simulator.build_parser()[0]
     a = parser.parse_args("genome -rg ref.fa -c m/training -o out/sim -n 1000 -max 20000 -min 100 -med 5000 -sd 0.5 --seed 7 "
                           "-hp -k 5 -s 0.6 -dna_type circular --fastq --chimeric -t 4".split())
     assert (a.mode, a.number, a.max_len, a.min_len, a.KmerBias, a.dna_type, a.num_threads) == ("genome", 1000, 20000, 100, 5, "circular", 4)
@@ -35,7 +35,7 @@ def test_cli_accepts_the_reference_flag_surface():
     "genome -rg r.fa -s 1.5",                          # S:2257-2260
 ])
 def test_cli_validation_matches_reference(argv, capsys):
-    parser, pg = simulator.build_parser()
+    parser, pg = simulator.build_parser()[:2]
     a = parser.parse_args(argv.split())
     with pytest.raises(SystemExit) as e:
         simulator.validate_genome_args(a, pg)
