@@ -434,19 +434,24 @@ __global__ void __launch_bounds__(256) k_names(GenArgs A) {
 // k_materialise: one read per wavefront (64-thread workgroup); see ns_materialise.h
 // ---------------------------------------------------------------------------------------------------------
 #ifndef NS_MAT_WAVES
-#define NS_MAT_WAVES 5
+#define NS_MAT_WAVES 6
 #endif
 template <bool FASTQ>
 __global__ void __launch_bounds__(64, NS_MAT_WAVES) k_materialise(GenArgs A, uint64_t nbases, uint32_t dbg) {
     __shared__ TileLds T;
     const uint32_t lane = threadIdx.x;
     const uint64_t r = blockIdx.x;
-    const ns_read rd = A.reads[r];
+    ns_read rd = A.reads[r];
     if (rd.flags) return;
-    const ns_key key = read_key(A, r);
+    rd.rec_off = uni64(rd.rec_off); rd.piece_off = uni(rd.piece_off); rd.n_pieces = (uint16_t)uni(rd.n_pieces);
+    rd.reversed = (uint8_t)uni(rd.reversed); rd.head = uni(rd.head); rd.tail = uni(rd.tail); rd.seq_len = uni(rd.seq_len);
+    rd.attempts = uni(rd.attempts);
+    ns_key key = read_key(A, r);
+    key.r_lo = uni(key.r_lo); key.r_hi = uni(key.r_hi);
     const uint32_t a = rd.attempts;
+    tile_lds_init(T, lane);
     ReadOut ro;
-    ro.seq = A.records + rd.rec_off + A.name_len[r] + 2;
+    ro.seq = A.records + rd.rec_off + uni(A.name_len[r]) + 2;
     ro.qual = FASTQ ? ro.seq + rd.seq_len + 3 : nullptr;
     ro.seq_len = rd.seq_len; ro.reversed = rd.reversed != 0;
     if (A.hp) {                                  // -k: forward-strand pre-homopolymer read into the scratch buffer
@@ -457,7 +462,7 @@ __global__ void __launch_bounds__(64, NS_MAT_WAVES) k_materialise(GenArgs A, uin
     if (!(dbg & 8)) emit_random_region(A.m, ro, key, a, ST_HEAD, 0, rd.head, 0, lane);                                   // S:1426
     uint32_t q = rd.head;
     for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
-        const PieceCtx pc = load_piece(A.events, A.ref, A.pieces[rd.piece_off + pi], pi);
+        const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi);
         materialise_piece(A.m, A.ref, T, ro, key, a, pc, q, lane, nbases, dbg);
         if (!(dbg & 2)) payload_pass(A.m, A.ref, ro, key, a, pc, q, lane);
         q += pc.out_len;

@@ -22,13 +22,34 @@
 #define T_GUARD 16u
 struct __align__(16) TileLds {
     uint8_t ref[T_REF + 2 * T_GUARD];   // [T_GUARD, T_GUARD + T_REF) holds the staged reference bytes
-    uint32_t e_out[T_EV + 1];
-    uint32_t e_rp[T_EV];
-    uint32_t e_pos[T_EV];
-    uint16_t e_pl[T_EV];
-    uint8_t e_ty[T_EV];
+    uint32_t mlut[16][4];               // mlut[i]: 16-byte mask with bytes >= i set (merge of an event sub-run into a chunk)
+    uint32_t e_out[T_EV + 1];           // output offset at which the event starts
+    uint32_t e_rp[T_EV];                // segment position of the first base copied after the event's payload
+    uint16_t e_pt[T_EV];                // payload length (0 for a deletion) | type << 12
     uint32_t hist[64];
 };
+__device__ __forceinline__ void tile_lds_init(TileLds &T, uint32_t lane) {
+    if (lane < 16) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k)
+            T.mlut[lane][k] = lane <= 4 * k ? 0xffffffffu : lane >= 4 * k + 4 ? 0u : 0xffffffffu << (8 * (lane - 4 * k));
+    }
+}
+
+// inclusive prefix sum over the wavefront with DPP row shifts / row broadcasts (6 VALU instructions)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);      // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// wave-uniform values that reach the kernel through vector loads: pin them to SGPRs so that the arithmetic on them is scalar
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v) { return (uint64_t)uni((uint32_t)v) | (uint64_t)uni((uint32_t)(v >> 32)) << 32; }
 
 struct ReadOut {
     uint8_t *seq;        // first base of the record's sequence line
@@ -93,11 +114,17 @@ __device__ inline void emit_random_region(const DevModel &m, const ReadOut &ro, 
         const uint32_t count = min(16u, len - i0);
         u32x4 w = ns_draw(key, stream, 0, a, i0 >> 6, 0);
         const uint32_t word = ns_word(w, (i0 >> 4) & 3);
-        uint64_t lo = 0, hi = 0, qlo = 0, qhi = 0;
-        QualDraw qd; qd.blk = 0xffffffffu;
-        for (uint32_t i = 0; i < count; ++i) {
-            put_byte(lo, hi, i, bases_atcg((word >> (2 * i)) & 3u));
-            if (ro.qual) put_byte(qlo, qhi, i, qual_draw(qd, m, NS_Q_HT, key, ST_HTQ, 0, a, hq_off + i0 + i));
+        uint32_t l4[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {                       // letters 4k..4k+3: 2-bit fields -> byte selectors -> "ATCG"
+            const uint32_t x = (word >> (8 * k)) & 0xffu;
+            const uint32_t t = (x | x << 12) & 0x000f000fu;
+            l4[k] = __builtin_amdgcn_perm(0u, 0x47435441u, (t | t << 6) & 0x03030303u);
+        }
+        uint64_t lo = (uint64_t)l4[0] | (uint64_t)l4[1] << 32, hi = (uint64_t)l4[2] | (uint64_t)l4[3] << 32, qlo = 0, qhi = 0;
+        if (ro.qual) {
+            QualDraw qd; qd.blk = 0xffffffffu;
+            for (uint32_t i = 0; i < count; ++i) put_byte(qlo, qhi, i, qual_draw(qd, m, NS_Q_HT, key, ST_HTQ, 0, a, hq_off + i0 + i));
         }
         store_chunk(ro, q_start + i0, count, lo, hi, qlo, qhi);
     }
@@ -172,6 +199,17 @@ __device__ __forceinline__ PieceCtx load_piece(const ns_event *events, const Dev
     pc.sid = p.kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
     return pc;
 }
+// the same for kernels in which the whole wavefront works on one piece: everything wave-uniform, held in SGPRs
+__device__ __forceinline__ PieceCtx load_piece_uniform(const ns_event *events, const DevRef &ref, const ns_piece &p, uint32_t pi) {
+    PieceCtx pc;
+    pc.ev = events + uni64(p.ev_off); pc.n_ev = uni(p.n_ev); pc.out_len = uni(p.out_len); pc.ref_len = uni(p.ref_len);
+    const uint32_t chrom = uni(p.chrom);
+    pc.chrom_base = uni64(ref.chrom_off[chrom]);
+    pc.chrom_len = uni64(ref.chrom_off[chrom + 1]) - pc.chrom_base;
+    pc.pos = uni(p.pos); pc.kind = uni(p.kind);
+    pc.sid = pc.kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
+    return pc;
+}
 // bytes [m_lo, m_hi) of one piece, 16 per lane, straight from global memory
 __device__ inline void slow_piece_range(const DevModel &m, const DevRef &ref, const ReadOut &ro, const ns_key &key, uint32_t a,
                                         const PieceCtx &pc, uint32_t pq, uint32_t m_lo, uint32_t m_hi, uint32_t lane) {
@@ -218,6 +256,7 @@ __device__ __forceinline__ void ref_prefetch(RefPrefetch &pf, const DevRef &ref,
 __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, TileLds &T, const ReadOut &ro, const ns_key &key,
                                          uint32_t a, const PieceCtx &pc, uint32_t pq, uint32_t lane, uint64_t nbases, uint32_t dbg) {
     uint32_t jb = 0;                       // events with out_start < M0
+    uint32_t L0_out = 0, L0_rp = 0, L0_pt = 3u << 12;     // the event in force at M0 (synthetic start: no payload, copy from 0)
     // prologue prefetch: first batch of events and the reference bytes of the first tile (x0 = 0)
     ns_event e_pre; e_pre.pos = 0; e_pre.info = 0;
     if (lane < pc.n_ev) e_pre = pc.ev[lane];
@@ -226,16 +265,7 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
     for (uint32_t M0 = 0; M0 < pc.out_len;) {
         uint32_t M1 = min(M0 + T_OUT, pc.out_len);
         // ---- 1. stage events: L[0] = the event in force before M0 (or a synthetic start), L[1..] start in [M0, M1)
-        if (lane == 0) {
-            if (jb == 0) { T.e_out[0] = 0; T.e_rp[0] = 0; T.e_pos[0] = 0; T.e_pl[0] = 0; T.e_ty[0] = 3; }
-            else {
-                ns_event e = pc.ev[jb - 1];
-                uint32_t len = ns_ev_len(e.info), ty = ns_ev_type(e.info);
-                T.e_out[0] = ev_out_start(e); T.e_pos[0] = e.pos; T.e_ty[0] = (uint8_t)ty;
-                T.e_pl[0] = (uint16_t)(ty == NS_DEL ? 0 : len);
-                T.e_rp[0] = e.pos + (ty == NS_INS ? 0 : len);
-            }
-        }
+        if (lane == 0) { T.e_out[0] = L0_out; T.e_rp[0] = L0_rp; T.e_pt[0] = (uint16_t)L0_pt; }
         uint32_t ne = 1;
         for (uint32_t base = jb;; base += 64) {
             const uint32_t idx = base + lane;
@@ -248,12 +278,12 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             const uint32_t slot = ne + lane;
             if (take && slot < T_EV) {
                 uint32_t len = ns_ev_len(e.info), ty = ns_ev_type(e.info);
-                T.e_out[slot] = os; T.e_pos[slot] = e.pos; T.e_ty[slot] = (uint8_t)ty;
-                T.e_pl[slot] = (uint16_t)(ty == NS_DEL ? 0 : len);
+                T.e_out[slot] = os;
+                T.e_pt[slot] = (uint16_t)((ty == NS_DEL ? 0 : len) | ty << 12);
                 T.e_rp[slot] = e.pos + (ty == NS_INS ? 0 : len);
             }
             if (ne + cnt > T_EV) {         // more events than LDS slots: end the tile at the first unstaged event
-                M1 = __shfl(os, (int)(T_EV - ne));
+                M1 = (uint32_t)__builtin_amdgcn_readlane((int)os, (int)(T_EV - ne));
                 ne = T_EV;
                 break;
             }
@@ -268,14 +298,18 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
         wave_sync();
 
         // ---- 2. reference span of the tile
-        const uint32_t os0 = T.e_out[0], pl0 = T.e_pl[0], rp0 = T.e_rp[0], ty0 = T.e_ty[0], pos0 = T.e_pos[0];
-        const uint32_t d0 = M0 - os0;
-        const uint32_t x0 = d0 < pl0 ? (ty0 == NS_MIS ? pos0 + d0 : rp0) : rp0 + (d0 - pl0);
-        const uint32_t osl = T.e_out[ne - 1], pll = T.e_pl[ne - 1], rpl = T.e_rp[ne - 1], tyl = T.e_ty[ne - 1], posl = T.e_pos[ne - 1];
+        // (all wave-uniform: kept in SGPRs.  A substitution copies nothing but reads the reference under its payload, so
+        // its span starts at rp - pl; an insertion reads nothing until its payload ends.)
+        const uint32_t pl0 = L0_pt & 0xfffu, ty0 = L0_pt >> 12;
+        const uint32_t d0 = M0 - L0_out;
+        const uint32_t x0 = (d0 < pl0 && ty0 == NS_INS) ? L0_rp : L0_rp + d0 - pl0;
+        const uint32_t osl = uni(T.e_out[ne - 1]), ptl = uni(T.e_pt[ne - 1]), rpl = uni(T.e_rp[ne - 1]);
+        const uint32_t pll = ptl & 0xfffu, tyl = ptl >> 12;
         const uint32_t dl = M1 - osl;
         uint32_t x1 = dl <= pll ? rpl : rpl + (dl - pll);
         if (x1 < x0) x1 = x0;
-        const uint32_t x0_next = dl < pll ? (tyl == NS_MIS ? posl + dl : rpl) : rpl + (dl - pll);   // x0 of the tile starting at M1
+        const uint32_t x0_next = (dl < pll && tyl == NS_INS) ? rpl : rpl + dl - pll;      // x0 of the tile starting at M1
+        L0_out = osl; L0_rp = rpl; L0_pt = ptl;                    // in force at M1: the last event staged for this tile
         uint64_t g0 = pc.pos + x0;
         bool fast = true;
         if (g0 >= pc.chrom_len) g0 -= pc.chrom_len;                 // whole tile beyond the origin of a circular chromosome
@@ -330,17 +364,13 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
         const uint32_t rbase = T_GUARD + lead - x0;               // T.ref index of segment position x is rbase + x
 
         // ---- 3. phase A: one lane per 16 output bytes; per event sub-run one funnel-shifted 16-byte LDS fetch
-        uint32_t incl = T.hist[lane];
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t v = __shfl_up(incl, off);
-            if ((int)lane >= off) incl += v;
-        }
+        const uint32_t incl = wave_incl_scan(T.hist[lane]);
         const uint32_t c0 = M0 + 16 * lane;
         if (c0 < M1 && !(dbg & 1)) {
             const uint32_t count = min(16u, M1 - c0);
             const uint32_t c_end = c0 + count;
             uint32_t k = incl;                                     // event in force at the chunk's first byte
-            uint32_t os = T.e_out[k], pl = T.e_pl[k], rp = T.e_rp[k], nxt = T.e_out[k + 1];
+            uint32_t os = T.e_out[k], pl = T.e_pt[k] & 0xfffu, rp = T.e_rp[k], nxt = T.e_out[k + 1];
             uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
             uint32_t mcur = c0;
             for (;;) {
@@ -348,25 +378,17 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
                 const uint32_t seg_end = min(nxt, c_end);
                 if (cs < seg_end) {
                     const uint32_t src = rbase + rp + c0 - (os + pl);     // LDS index of chunk byte 0 under this event's shift
-                    const uint32_t al = src & ~15u, sh = src & 15u;
-                    const uint4 va = *reinterpret_cast<const uint4 *>(&T.ref[al]);
-                    const uint4 vb = *reinterpret_cast<const uint4 *>(&T.ref[al + 16]);
-                    uint32_t w0 = va.x, w1 = va.y, w2 = va.z, w3 = va.w, w4 = vb.x, w5 = vb.y;
-                    if (sh & 8u) { w0 = w2; w1 = w3; w2 = w4; w3 = w5; w4 = vb.z; w5 = vb.w; }
-                    if (sh & 4u) { w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; }
-                    const uint32_t bs = sh & 3u;
+                    const uint32_t *wp = reinterpret_cast<const uint32_t *>(&T.ref[src & ~3u]);   // 5 dwords from a 4-byte aligned address
+                    const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3], w4 = wp[4];
+                    const uint32_t bs = src & 3u;
                     const uint32_t f0 = __builtin_amdgcn_alignbyte(w1, w0, bs), f1 = __builtin_amdgcn_alignbyte(w2, w1, bs);
                     const uint32_t f2 = __builtin_amdgcn_alignbyte(w3, w2, bs), f3 = __builtin_amdgcn_alignbyte(w4, w3, bs);
-                    const int i0 = (int)(cs - c0);                 // merge bytes [i0, 16): later events overwrite their own part
-                    const uint32_t m0 = i0 <= 0 ? 0xffffffffu : i0 >= 4 ? 0u : 0xffffffffu << (8 * i0);
-                    const uint32_t m1 = i0 <= 4 ? 0xffffffffu : i0 >= 8 ? 0u : 0xffffffffu << (8 * (i0 - 4));
-                    const uint32_t m2 = i0 <= 8 ? 0xffffffffu : i0 >= 12 ? 0u : 0xffffffffu << (8 * (i0 - 8));
-                    const uint32_t m3 = i0 <= 12 ? 0xffffffffu : 0xffffffffu << (8 * (i0 - 12));
-                    r0 = (f0 & m0) | (r0 & ~m0); r1 = (f1 & m1) | (r1 & ~m1);
-                    r2 = (f2 & m2) | (r2 & ~m2); r3 = (f3 & m3) | (r3 & ~m3);
+                    const uint4 mk = *reinterpret_cast<const uint4 *>(&T.mlut[cs - c0][0]);   // merge bytes [cs - c0, 16): later events overwrite their own part
+                    r0 = (f0 & mk.x) | (r0 & ~mk.x); r1 = (f1 & mk.y) | (r1 & ~mk.y);
+                    r2 = (f2 & mk.z) | (r2 & ~mk.z); r3 = (f3 & mk.w) | (r3 & ~mk.w);
                 }
                 if (nxt >= c_end) break;
-                mcur = nxt; ++k; os = nxt; pl = T.e_pl[k]; rp = T.e_rp[k]; nxt = T.e_out[k + 1];
+                mcur = nxt; ++k; os = nxt; pl = T.e_pt[k] & 0xfffu; rp = T.e_rp[k]; nxt = T.e_out[k + 1];
             }
             const uint64_t lo = (uint64_t)r0 | (uint64_t)r1 << 32, hi = (uint64_t)r2 | (uint64_t)r3 << 32;
             uint64_t qlo = 0, qhi = 0;
