@@ -436,38 +436,81 @@ __global__ void __launch_bounds__(256) k_names(GenArgs A) {
 #ifndef NS_MAT_WAVES
 #define NS_MAT_WAVES 6
 #endif
-template <bool FASTQ>
-__global__ void __launch_bounds__(64, NS_MAT_WAVES) k_materialise(GenArgs A, uint64_t nbases, uint32_t dbg) {
-    __shared__ TileLds T;
-    const uint32_t lane = threadIdx.x;
-    const uint64_t r = blockIdx.x;
-    ns_read rd = A.reads[r];
-    if (rd.flags) return;
+// read header of a wave-per-read kernel: everything wave-uniform, pinned to SGPRs
+__device__ __forceinline__ bool load_read_uniform(const GenArgs &A, uint64_t r, bool fastq, ns_read &rd, ns_key &key, ReadOut &ro) {
+    rd = A.reads[r];
+    if (rd.flags) return false;
     rd.rec_off = uni64(rd.rec_off); rd.piece_off = uni(rd.piece_off); rd.n_pieces = (uint16_t)uni(rd.n_pieces);
     rd.reversed = (uint8_t)uni(rd.reversed); rd.head = uni(rd.head); rd.tail = uni(rd.tail); rd.seq_len = uni(rd.seq_len);
     rd.attempts = uni(rd.attempts);
-    ns_key key = read_key(A, r);
+    key = read_key(A, r);
     key.r_lo = uni(key.r_lo); key.r_hi = uni(key.r_hi);
-    const uint32_t a = rd.attempts;
-    tile_lds_init(T, lane);
-    ReadOut ro;
     ro.seq = A.records + rd.rec_off + uni(A.name_len[r]) + 2;
-    ro.qual = FASTQ ? ro.seq + rd.seq_len + 3 : nullptr;
+    ro.qual = fastq ? ro.seq + rd.seq_len + 3 : nullptr;
     ro.seq_len = rd.seq_len; ro.reversed = rd.reversed != 0;
     if (A.hp) {                                  // -k: forward-strand pre-homopolymer read into the scratch buffer
-        ro.seq = A.scr + A.scr_off[r];
-        ro.qual = FASTQ ? A.scrq + A.scr_off[r] : nullptr;
+        const uint64_t so = uni64(A.scr_off[r]);
+        ro.seq = A.scr + so;
+        ro.qual = fastq ? A.scrq + so : nullptr;
         ro.reversed = false;
     }
-    if (!(dbg & 8)) emit_random_region(A.m, ro, key, a, ST_HEAD, 0, rd.head, 0, lane);                                   // S:1426
+    return true;
+}
+
+// copy phase: reference bytes under the event lists -> records (the LDS-tiled path of ns_materialise.h)
+template <bool FASTQ>
+__global__ void __launch_bounds__(64, NS_MAT_WAVES) k_materialise(GenArgs A, uint64_t nbases, uint32_t dbg, SlowQueue sq) {
+    __shared__ TileLds T;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t r = blockIdx.x;
+    ns_read rd; ns_key key; ReadOut ro;
+    if (!load_read_uniform(A, r, FASTQ, rd, key, ro)) return;
+    const uint32_t a = rd.attempts;
+    tile_lds_init(T, lane);
     uint32_t q = rd.head;
     for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
         const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi);
-        materialise_piece(A.m, A.ref, T, ro, key, a, pc, q, lane, nbases, dbg);
-        if (!(dbg & 2)) payload_pass(A.m, A.ref, ro, key, a, pc, q, lane);
+        materialise_piece(A.m, A.ref, T, ro, key, a, pc, q, lane, nbases, dbg, sq, (uint32_t)r, pi);
         q += pc.out_len;
     }
-    if (!(dbg & 8)) emit_random_region(A.m, ro, key, a, ST_TAIL, rd.seq_len - rd.tail, rd.tail, rd.head, lane);          // S:1427
+}
+
+// the tiles k_materialise could not take: generic per-byte path, one wavefront per queued tile
+template <bool FASTQ>
+__global__ void __launch_bounds__(64) k_materialise_slow(GenArgs A, SlowQueue sq) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n = min(*sq.count, sq.cap);
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const SlowTile t = sq.items[i];
+        ns_read rd; ns_key key; ReadOut ro;
+        if (!load_read_uniform(A, t.read, FASTQ, rd, key, ro)) continue;
+        uint32_t q = rd.head;
+        for (uint32_t pi = 0; pi < t.piece; ++pi) q += A.pieces[rd.piece_off + pi].out_len;
+        const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + t.piece], t.piece);
+        slow_piece_range(A.m, A.ref, ro, key, rd.attempts, pc, q, t.m0, t.m1, lane);
+    }
+}
+
+// everything that is not copied from the reference: head / tail bases (S:1426-1427) and the substituted / inserted letters
+// (mutate_read, S:1965-1995).  Runs after k_materialise on the same stream, so its byte stores land on top of the copy.
+template <bool FASTQ>
+__global__ void __launch_bounds__(64) k_payload(GenArgs A, uint32_t dbg) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t r = blockIdx.x;
+    ns_read rd; ns_key key; ReadOut ro;
+    if (!load_read_uniform(A, r, FASTQ, rd, key, ro)) return;
+    const uint32_t a = rd.attempts;
+    if (!(dbg & 8)) {
+        emit_random_region(A.m, ro, key, a, ST_HEAD, 0, rd.head, 0, lane);                                   // S:1426
+        emit_random_region(A.m, ro, key, a, ST_TAIL, rd.seq_len - rd.tail, rd.tail, rd.head, lane);          // S:1427
+    }
+    if (dbg & 2) return;
+    uint32_t q = rd.head;
+    for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
+        const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi);
+        payload_pass(A.m, A.ref, ro, key, a, pc, q, lane);
+        q += pc.out_len;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -740,7 +783,7 @@ struct ns_ctx {
     // planning + result buffers
     DevBuf n_pieces, piece_off, ev_cap, ev_off, rec_len, rec_off, err_len, err_off, name_len;
     DevBuf reads, pieces, events, records, errlog, stats, scan_tmp;
-    DevBuf sort_key, sort_idx, sort_key_out, order, list_b, rstate, att_base, scr, scrq, scr_len, scr_off, hp_len;
+    DevBuf sort_key, sort_idx, sort_key_out, order, list_b, rstate, att_base, scr, scrq, scr_len, scr_off, hp_len, slow_q;
     // metagenome: species view of the reference, abundances of the sample, per-pass scratch
     DevBuf species_chrom_off, t_reads, t_pieces, t_name_len, t_rec_len, t_err_len, accept, accept_scan, key_pos, draw_x, m_segptr,
         m_len, m_species, species_bases;
@@ -852,7 +895,7 @@ void ns_destroy(ns_ctx *ctx) {
                       &ctx->err_len, &ctx->err_off, &ctx->name_len, &ctx->reads, &ctx->pieces, &ctx->events,
                       &ctx->records, &ctx->errlog, &ctx->stats, &ctx->scan_tmp, &ctx->sort_key, &ctx->sort_idx,
                       &ctx->sort_key_out, &ctx->order, &ctx->list_b, &ctx->rstate, &ctx->att_base, &ctx->scr, &ctx->scrq,
-                      &ctx->scr_len, &ctx->scr_off, &ctx->hp_len, &ctx->species_chrom_off, &ctx->t_reads, &ctx->t_pieces,
+                      &ctx->scr_len, &ctx->scr_off, &ctx->hp_len, &ctx->slow_q, &ctx->species_chrom_off, &ctx->t_reads, &ctx->t_pieces,
                       &ctx->t_name_len, &ctx->t_rec_len, &ctx->t_err_len, &ctx->accept, &ctx->accept_scan, &ctx->key_pos,
                       &ctx->draw_x, &ctx->m_segptr, &ctx->m_len, &ctx->m_species, &ctx->species_bases};
     for (DevBuf *b : bufs)
@@ -1073,6 +1116,45 @@ static int scan_u32(ns_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n) {
 // ---------------------------------------------------------------------------------------------------------
 // metagenome (src/simulator.py:758-811, 814-1040)
 // ---------------------------------------------------------------------------------------------------------
+// copy phase, slow tiles, payload: the three kernels that write the sequence (and quality) lines of a batch
+static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fastq) {
+    hipStream_t st = ctx->stream;
+    for (int round = 0;; ++round) {
+        size_t cap = ctx->slow_q.cap >= 16 + sizeof(SlowTile) ? (ctx->slow_q.cap - 16) / sizeof(SlowTile) : 0;
+        if (cap < n / 4 + 4096) {
+            int rc = ensure(ctx, ctx->slow_q, 16 + (n / 4 + 4096) * sizeof(SlowTile));
+            if (rc) return rc;
+            cap = (ctx->slow_q.cap - 16) / sizeof(SlowTile);
+        }
+        SlowQueue sq;
+        sq.count = (uint32_t *)ctx->slow_q.p; sq.items = (SlowTile *)((uint8_t *)ctx->slow_q.p + 16);
+        sq.cap = (uint32_t)(cap > 0xffffffffull ? 0xffffffffull : cap);
+        HIPCHK(hipMemsetAsync(sq.count, 0, 4, st));
+        if (fastq) k_materialise<true><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->ref_nbases, ctx->dbg, sq);
+        else k_materialise<false><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->ref_nbases, ctx->dbg, sq);
+        HIPCHK(hipGetLastError());
+        uint32_t queued = 0;
+        HIPCHK(hipMemcpyAsync(&queued, sq.count, 4, hipMemcpyDeviceToHost, st));
+        if (fastq) k_payload<true><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->dbg);
+        else k_payload<false><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->dbg);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));
+        if (queued > sq.cap) {                   // more slow tiles than queue slots (tiny circular genomes): grow and redo
+            if (round >= 2) return fail(ctx, NS_ENOMEM, "slow-tile queue overflow");
+            int rc = ensure(ctx, ctx->slow_q, 16 + ((size_t)queued + 4096) * sizeof(SlowTile));
+            if (rc) return rc;
+            continue;
+        }
+        if (queued) {
+            const unsigned grid = queued < 16384u ? queued : 16384u;
+            if (fastq) k_materialise_slow<true><<<dim3(grid), dim3(64), 0, st>>>(A, sq);
+            else k_materialise_slow<false><<<dim3(grid), dim3(64), 0, st>>>(A, sq);
+            HIPCHK(hipGetLastError());
+        }
+        return NS_OK;
+    }
+}
+
 int ns_set_species(ns_ctx *ctx, uint32_t nspecies, const uint32_t *species_chrom_off) {
     if (!ctx) return NS_EINVAL;
     if (!ctx->has_ref) return fail(ctx, NS_ESTATE, "ns_set_species before ns_set_reference");
@@ -1475,9 +1557,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     HIPCHK(hipStreamSynchronize(st));
     if ((rc = ensure(ctx, ctx->scr, (size_t)scr_bytes + 64)) || (prm->fastq && (rc = ensure(ctx, ctx->scrq, (size_t)scr_bytes + 64)))) return rc;
     A.scr = (uint8_t *)ctx->scr.p; A.scrq = (uint8_t *)ctx->scrq.p;
-    if (prm->fastq) k_materialise<true><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->ref_nbases, ctx->dbg);
-    else k_materialise<false><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->ref_nbases, ctx->dbg);
-    HIPCHK(hipGetLastError());
+    if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0))) return rc;
     HIPCHK(hipMemsetAsync((unsigned long long *)ctx->stats.p + 1, 0, sizeof(unsigned long long), st));
     HIPCHK(hipMemsetAsync((unsigned long long *)ctx->stats.p + 5, 0, sizeof(unsigned long long), st));
     k_hp_count<<<grid_t, blk, 0, st>>>(A);
@@ -1510,9 +1590,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         k_hp_write<<<grid_t, blk, 0, st>>>(A);
         HIPCHK(hipGetLastError());
     } else if (prm->emit_records) {
-        if (prm->fastq) k_materialise<true><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->ref_nbases, ctx->dbg);
-        else k_materialise<false><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->ref_nbases, ctx->dbg);
-        HIPCHK(hipGetLastError());
+        if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0))) return rc;
     }
     HIPCHK(hipEventRecord(ctx->evt[7], st));
     if (prm->emit_errlog && prm->emit_records) {

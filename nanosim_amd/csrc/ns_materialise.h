@@ -253,8 +253,14 @@ __device__ __forceinline__ void ref_prefetch(RefPrefetch &pf, const DevRef &ref,
     if (o1 + 16 <= nbases) pf.v1 = *reinterpret_cast<const uint4 *>(ref.bases + o1);
 }
 
+// a tile the LDS path cannot take (its reference span straddles the origin of a circular chromosome or exceeds the LDS
+// tile): queued for k_materialise_slow
+struct SlowTile { uint32_t read, piece, m0, m1; };
+struct SlowQueue { SlowTile *items; uint32_t *count; uint32_t cap; };
+
 __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, TileLds &T, const ReadOut &ro, const ns_key &key,
-                                         uint32_t a, const PieceCtx &pc, uint32_t pq, uint32_t lane, uint64_t nbases, uint32_t dbg) {
+                                         uint32_t a, const PieceCtx &pc, uint32_t pq, uint32_t lane, uint64_t nbases, uint32_t dbg,
+                                         const SlowQueue &sq, uint32_t read_idx, uint32_t piece_idx) {
     uint32_t jb = 0;                       // events with out_start < M0
     uint32_t L0_out = 0, L0_rp = 0, L0_pt = 3u << 12;     // the event in force at M0 (synthetic start: no payload, copy from 0)
     // prologue prefetch: first batch of events and the reference bytes of the first tile (x0 = 0)
@@ -321,7 +327,10 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
         const RefPrefetch cur = pf;                                 // bytes for THIS tile (issued one tile ago)
         if (M1 < pc.out_len) ref_prefetch(pf, ref, pc, x0_next, lane, nbases);
         if (!fast) {
-            slow_piece_range(m, ref, ro, key, a, pc, pq, M0, M1, lane);
+            if (lane == 0) {
+                const uint32_t slot = atomicAdd(sq.count, 1u);
+                if (slot < sq.cap) sq.items[slot] = SlowTile{read_idx, piece_idx, M0, M1};
+            }
             jb = jb_next; M0 = M1;
             wave_sync();
             continue;
@@ -342,16 +351,14 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
                     w[b >> 2] = (w[b >> 2] & ~(0xffu << (8 * (b & 3)))) | (uint32_t)src[c + b] << (8 * (b & 3));
             }
             if ((w[0] | w[1] | w[2] | w[3]) & 0x80808080u) {     // case_convert (S:743-755), keyed by segment position
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
-                    if (!(w[k] & 0x80808080u)) continue;
-                    for (uint32_t b = 0; b < 4; ++b) {
-                        uint32_t ch = (w[k] >> (8 * b)) & 0xff;
-                        if (!(ch & 0x80u)) continue;
-                        int64_t x = (int64_t)x0 + (int64_t)(c + 4 * k + b) - (int64_t)lead;
-                        uint32_t r = (x >= 0 && x < (int64_t)pc.ref_len) ? resolve_base(ch, key, pc.sid, a, (uint32_t)x) : (uint32_t)'A';
-                        w[k] = (w[k] & ~(0xffu << (8 * b))) | r << (8 * b);
-                    }
+                for (uint32_t b = 0; b < 16; ++b) {              // rare: one copy of the resolve code, not unrolled
+                    uint32_t wk = b < 8 ? (b < 4 ? w[0] : w[1]) : (b < 12 ? w[2] : w[3]);
+                    const uint32_t ch = (wk >> (8 * (b & 3))) & 0xff;
+                    if (!(ch & 0x80u)) continue;
+                    const int64_t x = (int64_t)x0 + (int64_t)(c + b) - (int64_t)lead;
+                    const uint32_t r = (x >= 0 && x < (int64_t)pc.ref_len) ? resolve_base(ch, key, pc.sid, a, (uint32_t)x) : (uint32_t)'A';
+                    wk = (wk & ~(0xffu << (8 * (b & 3)))) | r << (8 * (b & 3));
+                    if (b < 4) w[0] = wk; else if (b < 8) w[1] = wk; else if (b < 12) w[2] = wk; else w[3] = wk;
                 }
             }
             *reinterpret_cast<uint4 *>(&T.ref[T_GUARD + c]) = make_uint4(w[0], w[1], w[2], w[3]);
