@@ -207,8 +207,8 @@ uint32_t ns_abi_version(void);
  * names is a NUL-separated blob of the (already normalised, S:344-347) chromosome names. */
 int ns_set_reference(ns_ctx *ctx, const uint8_t *bases, uint64_t nbases, const uint64_t *chrom_off,
                      uint32_t nchrom, const uint8_t *circular, const char *names, uint64_t names_len);
-/* same, but `bases_dev` is already resident in this GPU's HBM (e.g. filled by an RCCL broadcast);
- * the library does not take ownership of it. */
+/* same, but `bases_dev` is already resident in this GPU's HBM (e.g. filled by an RCCL broadcast): the library makes a
+ * device-to-device copy (normalised, padded for its unaligned loads); the caller's buffer is neither modified nor kept. */
 int ns_set_reference_device(ns_ctx *ctx, const void *bases_dev, uint64_t nbases, const uint64_t *chrom_off,
                             uint32_t nchrom, const uint8_t *circular, const char *names, uint64_t names_len);
 

@@ -436,6 +436,9 @@ __global__ void __launch_bounds__(256) k_names(GenArgs A) {
 #ifndef NS_MAT_WAVES
 #define NS_MAT_WAVES 6
 #endif
+#ifndef NS_FUSE_PAYLOAD
+#define NS_FUSE_PAYLOAD 1     // 1: head/tail + payload letters inside k_materialise (their lines are still in L2); 0: separate k_payload
+#endif
 // read header of a wave-per-read kernel: everything wave-uniform, pinned to SGPRs
 __device__ __forceinline__ bool load_read_uniform(const GenArgs &A, uint64_t r, bool fastq, ns_read &rd, ns_key &key, ReadOut &ro) {
     rd = A.reads[r];
@@ -467,12 +470,16 @@ __global__ void __launch_bounds__(64, NS_MAT_WAVES) k_materialise(GenArgs A, uin
     if (!load_read_uniform(A, r, FASTQ, rd, key, ro)) return;
     const uint32_t a = rd.attempts;
     tile_lds_init(T, lane);
+    if (NS_FUSE_PAYLOAD && !(dbg & 8)) emit_random_region(A.m, ro, key, a, ST_HEAD, 0, rd.head, 0, lane);          // S:1426
     uint32_t q = rd.head;
     for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
         const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi);
         materialise_piece(A.m, A.ref, T, ro, key, a, pc, q, lane, nbases, dbg, sq, (uint32_t)r, pi);
+        // the byte stores of the payload letters follow the 16-byte stores of the same wavefront in program order
+        if (NS_FUSE_PAYLOAD && !(dbg & 2)) payload_pass(A.m, A.ref, ro, key, a, pc, q, lane);
         q += pc.out_len;
     }
+    if (NS_FUSE_PAYLOAD && !(dbg & 8)) emit_random_region(A.m, ro, key, a, ST_TAIL, rd.seq_len - rd.tail, rd.tail, rd.head, lane);   // S:1427
 }
 
 // the tiles k_materialise could not take: generic per-byte path, one wavefront per queued tile
@@ -930,49 +937,43 @@ static int set_ref_meta(ns_ctx *ctx, const uint64_t *chrom_off, uint32_t nchrom,
     return NS_OK;
 }
 
+// The engine keeps its own normalised copy of the reference with NS_REF_PAD bytes of padding on both sides (the copy kernel
+// issues unaligned 16-byte loads that may start a few bytes before / end a few bytes after a segment).
+static int install_reference(ns_ctx *ctx, const void *src, bool src_on_device, uint64_t nbases, const uint64_t *chrom_off,
+                             uint32_t nchrom, const uint8_t *circular, const char *names, uint64_t names_len) {
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->has_ref = false;
+    if (chrom_off && nchrom && chrom_off[nchrom] != nbases) return fail(ctx, NS_EINVAL, "chrom_off[nchrom] != nbases");
+    if (ctx->ref_bases_owned) { HIPCHK(hipFree(ctx->ref_bases_owned)); ctx->ref_bases_owned = nullptr; }
+    HIPCHK(hipMalloc(&ctx->ref_bases_owned, nbases + 2 * NS_REF_PAD));
+    uint8_t *data = static_cast<uint8_t *>(ctx->ref_bases_owned) + NS_REF_PAD;
+    HIPCHK(hipMemsetAsync(ctx->ref_bases_owned, 'A', NS_REF_PAD, ctx->stream));
+    HIPCHK(hipMemsetAsync(data + nbases, 'A', NS_REF_PAD, ctx->stream));
+    HIPCHK(hipMemcpyAsync(data, src, nbases, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    uint64_t nthreads = (nbases + 15) / 16;
+    k_normalise<<<dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, ctx->stream>>>(data, nbases);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->ref.bases = data;
+    int rc = set_ref_meta(ctx, chrom_off, nchrom, circular, names, names_len);
+    if (rc) return rc;
+    ctx->ref_nbases = nbases;
+    ctx->has_ref = true;
+    return NS_OK;
+}
+
 int ns_set_reference(ns_ctx *ctx, const uint8_t *bases, uint64_t nbases, const uint64_t *chrom_off, uint32_t nchrom,
                      const uint8_t *circular, const char *names, uint64_t names_len) {
     if (!ctx) return NS_EINVAL;
     if (!bases || !nbases) return fail(ctx, NS_EINVAL, "empty reference");
-    HIPCHK(hipSetDevice(ctx->device));
-    ctx->has_ref = false;
-    if (ctx->ref_bases_owned) { HIPCHK(hipFree(ctx->ref_bases_owned)); ctx->ref_bases_owned = nullptr; }
-    HIPCHK(hipMalloc(&ctx->ref_bases_owned, nbases + 16));
-    HIPCHK(hipMemcpy(ctx->ref_bases_owned, bases, nbases, hipMemcpyHostToDevice));
-    uint64_t nthreads = (nbases + 15) / 16;
-    k_normalise<<<dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, ctx->stream>>>(
-        static_cast<uint8_t *>(ctx->ref_bases_owned), nbases);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->ref.bases = static_cast<const uint8_t *>(ctx->ref_bases_owned);
-    int rc = set_ref_meta(ctx, chrom_off, nchrom, circular, names, names_len);
-    if (rc) return rc;
-    if (chrom_off[nchrom] != nbases) return fail(ctx, NS_EINVAL, "chrom_off[nchrom] != nbases");
-    ctx->ref_nbases = nbases;
-    ctx->has_ref = true;
-    return NS_OK;
+    return install_reference(ctx, bases, false, nbases, chrom_off, nchrom, circular, names, names_len);
 }
 
 int ns_set_reference_device(ns_ctx *ctx, const void *bases_dev, uint64_t nbases, const uint64_t *chrom_off,
                             uint32_t nchrom, const uint8_t *circular, const char *names, uint64_t names_len) {
     if (!ctx) return NS_EINVAL;
     if (!bases_dev || !nbases) return fail(ctx, NS_EINVAL, "empty reference");
-    HIPCHK(hipSetDevice(ctx->device));
-    ctx->has_ref = false;
-    if (ctx->ref_bases_owned) { HIPCHK(hipFree(ctx->ref_bases_owned)); ctx->ref_bases_owned = nullptr; }
-    // normalise in place: the caller's buffer becomes the upper-case IUPAC form
-    uint64_t nthreads = (nbases + 15) / 16;
-    k_normalise<<<dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, ctx->stream>>>(
-        static_cast<uint8_t *>(const_cast<void *>(bases_dev)), nbases);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->ref.bases = static_cast<const uint8_t *>(bases_dev);
-    int rc = set_ref_meta(ctx, chrom_off, nchrom, circular, names, names_len);
-    if (rc) return rc;
-    if (chrom_off[nchrom] != nbases) return fail(ctx, NS_EINVAL, "chrom_off[nchrom] != nbases");
-    ctx->ref_nbases = nbases;
-    ctx->has_ref = true;
-    return NS_OK;
+    return install_reference(ctx, bases_dev, true, nbases, chrom_off, nchrom, circular, names, names_len);
 }
 
 int ns_load_model(ns_ctx *ctx, const ns_model_tables *t) {
@@ -1135,9 +1136,11 @@ static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fast
         HIPCHK(hipGetLastError());
         uint32_t queued = 0;
         HIPCHK(hipMemcpyAsync(&queued, sq.count, 4, hipMemcpyDeviceToHost, st));
-        if (fastq) k_payload<true><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->dbg);
-        else k_payload<false><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->dbg);
-        HIPCHK(hipGetLastError());
+        if (!NS_FUSE_PAYLOAD) {
+            if (fastq) k_payload<true><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->dbg);
+            else k_payload<false><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->dbg);
+            HIPCHK(hipGetLastError());
+        }
         HIPCHK(hipStreamSynchronize(st));
         if (queued > sq.cap) {                   // more slow tiles than queue slots (tiny circular genomes): grow and redo
             if (round >= 2) return fail(ctx, NS_ENOMEM, "slow-tile queue overflow");

@@ -17,19 +17,15 @@
 
 #define T_OUT 1024u
 #define T_EV 256u
-#define T_REF 2112u
-
-#define T_GUARD 16u
 struct __align__(16) TileLds {
-    uint8_t ref[T_REF + 2 * T_GUARD];   // [T_GUARD, T_GUARD + T_REF) holds the staged reference bytes
-    uint32_t mlut[16][4];               // mlut[i]: 16-byte mask with bytes >= i set (merge of an event sub-run into a chunk)
+    uint32_t mlut[17][4];               // mlut[i]: 16-byte mask with bytes >= i set (merge of an event sub-run into a chunk); [16] empty
     uint32_t e_out[T_EV + 1];           // output offset at which the event starts
     uint32_t e_rp[T_EV];                // segment position of the first base copied after the event's payload
     uint16_t e_pt[T_EV];                // payload length (0 for a deletion) | type << 12
     uint32_t hist[64];
 };
 __device__ __forceinline__ void tile_lds_init(TileLds &T, uint32_t lane) {
-    if (lane < 16) {
+    if (lane < 17) {
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k)
             T.mlut[lane][k] = lane <= 4 * k ? 0xffffffffu : lane >= 4 * k + 4 ? 0u : 0xffffffffu << (8 * (lane - 4 * k));
@@ -237,37 +233,38 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-struct RefPrefetch {          // next tile's reference bytes, in flight in registers while the current tile computes
-    uint64_t off;             // byte offset (16-aligned) in ref.bases of chunk 0; ~0 = nothing prefetched
-    uint4 v0, v1;             // chunks `lane` and `lane + 64`
-};
-__device__ __forceinline__ void ref_prefetch(RefPrefetch &pf, const DevRef &ref, const PieceCtx &pc, uint32_t x0, uint32_t lane,
-                                             uint64_t nbases) {
-    uint64_t g0 = pc.pos + x0;
-    if (g0 >= pc.chrom_len) g0 -= pc.chrom_len;
-    const uint64_t off = (pc.chrom_base + g0) & ~15ull;
-    pf.off = off;
-    const uint64_t o0 = off + 16ull * lane, o1 = o0 + 1024;
-    pf.v0 = make_uint4(0, 0, 0, 0); pf.v1 = make_uint4(0, 0, 0, 0);
-    if (o0 + 16 <= nbases) pf.v0 = *reinterpret_cast<const uint4 *>(ref.bases + o0);
-    if (o1 + 16 <= nbases) pf.v1 = *reinterpret_cast<const uint4 *>(ref.bases + o1);
-}
-
-// a tile the LDS path cannot take (its reference span straddles the origin of a circular chromosome or exceeds the LDS
-// tile): queued for k_materialise_slow
+// a tile the fast path cannot take (its reference span straddles the origin of a circular chromosome): queued for
+// k_materialise_slow
 struct SlowTile { uint32_t read, piece, m0, m1; };
 struct SlowQueue { SlowTile *items; uint32_t *count; uint32_t cap; };
 
+#define NS_REF_PAD 64u       // bytes allocated before and after the reference bases: any 16-byte load that overlaps a segment is in bounds
+
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {     // (mask & a) | (~mask & b), one instruction
+    uint32_t d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mask), "v"(a), "v"(b));
+    return d;
+}
+
+// Copy phase of one piece (v3: no reference tile).  Per tile of <= 1024 output bases:
+//   1. the events that start inside the tile (plus the one in force at its start) are staged into LDS;
+//   2. a histogram + wavefront prefix sum gives every lane (= 16 output bytes) the event in force at its first byte;
+//   3. per event sub-run of its chunk the lane issues ONE unaligned 16-byte global load at the run's reference offset (the
+//      loads of consecutive sub-runs are in flight together; they hit L1/L2: neighbouring lanes read overlapping bytes)
+//      and merges bytes [run start, 16) into the chunk; IUPAC codes (bit 7) are resolved on the loaded bytes
+//      (case_convert, S:743-755: keyed by the segment position);
+//   4. complement/reverse in registers (S:1433-1435, 1675-1680), one 16-byte store.
+// A tile whose reference span straddles the origin of a circular chromosome goes to the slow-tile queue.
 __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, TileLds &T, const ReadOut &ro, const ns_key &key,
                                          uint32_t a, const PieceCtx &pc, uint32_t pq, uint32_t lane, uint64_t nbases, uint32_t dbg,
                                          const SlowQueue &sq, uint32_t read_idx, uint32_t piece_idx) {
     uint32_t jb = 0;                       // events with out_start < M0
     uint32_t L0_out = 0, L0_rp = 0, L0_pt = 3u << 12;     // the event in force at M0 (synthetic start: no payload, copy from 0)
-    // prologue prefetch: first batch of events and the reference bytes of the first tile (x0 = 0)
+    const uint8_t *seg0 = ref.bases + pc.chrom_base + pc.pos;           // segment position 0
+    const bool wraps = pc.pos + pc.ref_len > pc.chrom_len;
+    const uint32_t wrap_at = wraps ? (uint32_t)(pc.chrom_len - pc.pos) : 0xffffffffu;   // first segment position beyond the origin
     ns_event e_pre; e_pre.pos = 0; e_pre.info = 0;
     if (lane < pc.n_ev) e_pre = pc.ev[lane];
-    RefPrefetch pf;
-    ref_prefetch(pf, ref, pc, 0, lane, nbases);
     for (uint32_t M0 = 0; M0 < pc.out_len;) {
         uint32_t M1 = min(M0 + T_OUT, pc.out_len);
         // ---- 1. stage events: L[0] = the event in force before M0 (or a synthetic start), L[1..] start in [M0, M1)
@@ -303,29 +300,21 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
         if (M1 < pc.out_len && jb_next + lane < pc.n_ev) e_pre = pc.ev[jb_next + lane];   // prefetch for the next tile
         wave_sync();
 
-        // ---- 2. reference span of the tile
-        // (all wave-uniform: kept in SGPRs.  A substitution copies nothing but reads the reference under its payload, so
-        // its span starts at rp - pl; an insertion reads nothing until its payload ends.)
-        const uint32_t pl0 = L0_pt & 0xfffu, ty0 = L0_pt >> 12;
-        const uint32_t d0 = M0 - L0_out;
-        const uint32_t x0 = (d0 < pl0 && ty0 == NS_INS) ? L0_rp : L0_rp + d0 - pl0;
+        // ---- the event in force at M1 (wave-uniform, SGPRs); reference span of the tile only matters next to the origin
         const uint32_t osl = uni(T.e_out[ne - 1]), ptl = uni(T.e_pt[ne - 1]), rpl = uni(T.e_rp[ne - 1]);
-        const uint32_t pll = ptl & 0xfffu, tyl = ptl >> 12;
-        const uint32_t dl = M1 - osl;
-        uint32_t x1 = dl <= pll ? rpl : rpl + (dl - pll);
-        if (x1 < x0) x1 = x0;
-        const uint32_t x0_next = (dl < pll && tyl == NS_INS) ? rpl : rpl + dl - pll;      // x0 of the tile starting at M1
-        L0_out = osl; L0_rp = rpl; L0_pt = ptl;                    // in force at M1: the last event staged for this tile
-        uint64_t g0 = pc.pos + x0;
+        const uint8_t *tb = seg0 - 32;                             // + 32 in the lane offsets: they never go negative
+        uint32_t idle_off = 32;                                    // offset loaded by a sub-run that copies nothing (any valid address)
         bool fast = true;
-        if (g0 >= pc.chrom_len) g0 -= pc.chrom_len;                 // whole tile beyond the origin of a circular chromosome
-        if (g0 + (x1 - x0) > pc.chrom_len) fast = false;            // tile straddles the origin
-        const uint64_t gaddr = pc.chrom_base + g0;
-        const uint32_t lead = (uint32_t)(gaddr & 15u);
-        const uint32_t need = lead + (x1 - x0);
-        if (need > T_REF) fast = false;
-        const RefPrefetch cur = pf;                                 // bytes for THIS tile (issued one tile ago)
-        if (M1 < pc.out_len) ref_prefetch(pf, ref, pc, x0_next, lane, nbases);
+        if (wraps) {
+            const uint32_t pl0 = L0_pt & 0xfffu, ty0 = L0_pt >> 12, d0 = M0 - L0_out;
+            const uint32_t x0 = (d0 < pl0 && ty0 == NS_INS) ? L0_rp : L0_rp + d0 - pl0;
+            const uint32_t pll = ptl & 0xfffu, dl = M1 - osl;
+            uint32_t x1 = dl <= pll ? rpl : rpl + (dl - pll);
+            if (x1 < x0) x1 = x0;
+            if (x0 >= wrap_at) { tb -= pc.chrom_len; idle_off = wrap_at + 32; }   // whole tile beyond the origin
+            else if (x1 > wrap_at) fast = false;                   // tile straddles the origin
+        }
+        L0_out = osl; L0_rp = rpl; L0_pt = ptl;
         if (!fast) {
             if (lane == 0) {
                 const uint32_t slot = atomicAdd(sq.count, 1u);
@@ -335,42 +324,13 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             wave_sync();
             continue;
         }
-        const uint64_t src_off = gaddr - lead;
-        const uint8_t *src = ref.bases + src_off;
-        for (uint32_t c = lane * 16, it = 0; c < need && !(dbg & 4); c += 64 * 16, ++it) {
-            uint32_t w[4];
-            if (it < 2 && cur.off == src_off && src_off + c + 16 <= nbases) {
-                const uint4 v = it == 0 ? cur.v0 : cur.v1;
-                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-            } else if (src_off + c + 16 <= nbases) {
-                uint4 v = *reinterpret_cast<const uint4 *>(src + c);
-                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-            } else {
-                w[0] = w[1] = w[2] = w[3] = 0x41414141u;
-                for (uint32_t b = 0; b < 16 && src_off + c + b < nbases; ++b)
-                    w[b >> 2] = (w[b >> 2] & ~(0xffu << (8 * (b & 3)))) | (uint32_t)src[c + b] << (8 * (b & 3));
-            }
-            if ((w[0] | w[1] | w[2] | w[3]) & 0x80808080u) {     // case_convert (S:743-755), keyed by segment position
-                for (uint32_t b = 0; b < 16; ++b) {              // rare: one copy of the resolve code, not unrolled
-                    uint32_t wk = b < 8 ? (b < 4 ? w[0] : w[1]) : (b < 12 ? w[2] : w[3]);
-                    const uint32_t ch = (wk >> (8 * (b & 3))) & 0xff;
-                    if (!(ch & 0x80u)) continue;
-                    const int64_t x = (int64_t)x0 + (int64_t)(c + b) - (int64_t)lead;
-                    const uint32_t r = (x >= 0 && x < (int64_t)pc.ref_len) ? resolve_base(ch, key, pc.sid, a, (uint32_t)x) : (uint32_t)'A';
-                    wk = (wk & ~(0xffu << (8 * (b & 3)))) | r << (8 * (b & 3));
-                    if (b < 4) w[0] = wk; else if (b < 8) w[1] = wk; else if (b < 12) w[2] = wk; else w[3] = wk;
-                }
-            }
-            *reinterpret_cast<uint4 *>(&T.ref[T_GUARD + c]) = make_uint4(w[0], w[1], w[2], w[3]);
-        }
         for (uint32_t k = 1 + lane; k < ne; k += 64) {            // histogram: first 16-byte chunk starting at/after the event
             uint32_t c = (T.e_out[k] - M0 + 15) >> 4;
             if (c < 64) atomicAdd(&T.hist[c], 1u);
         }
         wave_sync();
-        const uint32_t rbase = T_GUARD + lead - x0;               // T.ref index of segment position x is rbase + x
 
-        // ---- 3. phase A: one lane per 16 output bytes; per event sub-run one funnel-shifted 16-byte LDS fetch
+        // ---- phase A: one lane per 16 output bytes
         const uint32_t incl = wave_incl_scan(T.hist[lane]);
         const uint32_t c0 = M0 + 16 * lane;
         if (c0 < M1 && !(dbg & 1)) {
@@ -380,26 +340,52 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             uint32_t os = T.e_out[k], pl = T.e_pt[k] & 0xfffu, rp = T.e_rp[k], nxt = T.e_out[k + 1];
             uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
             uint32_t mcur = c0;
+            // Branch-free, software-pipelined: the load of sub-run i+1 is issued before sub-run i is merged.  A sub-run that
+            // copies nothing loads from offset 0 and merges with the empty mask mlut[16].
+            // Two register sets (fa / fb) alternate so that a load stays in flight across the merge of the previous one.
+            uint4 fa = make_uint4(0, 0, 0, 0), fb = make_uint4(0, 0, 0, 0);
+            uint32_t ia = 16, ib = 16;
+#define NS_SUBRUN_STEP(FN, IN, FO, IO)                                                                              \
+            {                                                                                                        \
+                const uint32_t cs = max(mcur, os + pl);            /* first copied byte under event k */              \
+                const bool has = cs < min(nxt, c_end);                                                               \
+                const uint32_t xrel = rp + c0 - (os + pl);         /* segment position of chunk byte 0 under this event's shift */ \
+                __builtin_memcpy(&FN, tb + (has ? xrel + 32u : idle_off), 16);                                       \
+                const uint4 mk = *reinterpret_cast<const uint4 *>(&T.mlut[IO][0]);   /* bytes [i0, 16): later sub-runs overwrite their own part */ \
+                r0 = bfi(mk.x, FO.x, r0); r1 = bfi(mk.y, FO.y, r1); r2 = bfi(mk.z, FO.z, r2); r3 = bfi(mk.w, FO.w, r3); \
+                IN = has ? cs - c0 : 16u; IO = 16u;                                                                  \
+            }
             for (;;) {
-                const uint32_t cs = max(mcur, os + pl);            // first copied byte under event k
-                const uint32_t seg_end = min(nxt, c_end);
-                if (cs < seg_end) {
-                    const uint32_t src = rbase + rp + c0 - (os + pl);     // LDS index of chunk byte 0 under this event's shift
-                    const uint32_t *wp = reinterpret_cast<const uint32_t *>(&T.ref[src & ~3u]);   // 5 dwords from a 4-byte aligned address
-                    const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3], w4 = wp[4];
-                    const uint32_t bs = src & 3u;
-                    const uint32_t f0 = __builtin_amdgcn_alignbyte(w1, w0, bs), f1 = __builtin_amdgcn_alignbyte(w2, w1, bs);
-                    const uint32_t f2 = __builtin_amdgcn_alignbyte(w3, w2, bs), f3 = __builtin_amdgcn_alignbyte(w4, w3, bs);
-                    const uint4 mk = *reinterpret_cast<const uint4 *>(&T.mlut[cs - c0][0]);   // merge bytes [cs - c0, 16): later events overwrite their own part
-                    r0 = (f0 & mk.x) | (r0 & ~mk.x); r1 = (f1 & mk.y) | (r1 & ~mk.y);
-                    r2 = (f2 & mk.z) | (r2 & ~mk.z); r3 = (f3 & mk.w) | (r3 & ~mk.w);
-                }
+                NS_SUBRUN_STEP(fa, ia, fb, ib)
+                if (nxt >= c_end) break;
+                mcur = nxt; ++k; os = nxt; pl = T.e_pt[k] & 0xfffu; rp = T.e_rp[k]; nxt = T.e_out[k + 1];
+                NS_SUBRUN_STEP(fb, ib, fa, ia)
                 if (nxt >= c_end) break;
                 mcur = nxt; ++k; os = nxt; pl = T.e_pt[k] & 0xfffu; rp = T.e_rp[k]; nxt = T.e_out[k + 1];
             }
+#undef NS_SUBRUN_STEP
+            {                                                      // at most one of the two is still pending
+                const uint4 ma = *reinterpret_cast<const uint4 *>(&T.mlut[ia][0]), mb = *reinterpret_cast<const uint4 *>(&T.mlut[ib][0]);
+                r0 = bfi(ma.x, fa.x, r0); r1 = bfi(ma.y, fa.y, r1); r2 = bfi(ma.z, fa.z, r2); r3 = bfi(ma.w, fa.w, r3);
+                r0 = bfi(mb.x, fb.x, r0); r1 = bfi(mb.y, fb.y, r1); r2 = bfi(mb.z, fb.z, r2); r3 = bfi(mb.w, fb.w, r3);
+            }
+            if ((r0 | r1 | r2 | r3) & 0x80808080u) {               // case_convert (S:743-755): rare; the segment position of a marked
+                uint32_t kk = incl;                                // byte is found by walking the chunk's events again
+                for (uint32_t b = 0; b < count; ++b) {
+                    uint32_t wk = b < 8 ? (b < 4 ? r0 : r1) : (b < 12 ? r2 : r3);
+                    const uint32_t ch = (wk >> (8 * (b & 3))) & 0xff;
+                    if (!(ch & 0x80u)) continue;
+                    const uint32_t mm = c0 + b;
+                    while (T.e_out[kk + 1] <= mm) ++kk;
+                    const uint32_t x = T.e_rp[kk] + (mm - T.e_out[kk]) - (T.e_pt[kk] & 0xfffu);
+                    const uint32_t r = resolve_base(ch, key, pc.sid, a, x);
+                    wk = (wk & ~(0xffu << (8 * (b & 3)))) | r << (8 * (b & 3));
+                    if (b < 4) r0 = wk; else if (b < 8) r1 = wk; else if (b < 12) r2 = wk; else r3 = wk;
+                }
+            }
             const uint64_t lo = (uint64_t)r0 | (uint64_t)r1 << 32, hi = (uint64_t)r2 | (uint64_t)r3 << 32;
             uint64_t qlo = 0, qhi = 0;
-            if (ro.qual) {                                         // match-class (or unmapped) qualities; payload bytes are redone below
+            if (ro.qual) {                                         // match-class (or unmapped) qualities; payload bytes are redone by k_payload
                 QualDraw qd; qd.blk = 0xffffffffu;
                 const int cls = pc.kind ? NS_Q_UNMAPPED : NS_Q_MATCH;
                 for (uint32_t i = 0; i < count; ++i) put_byte(qlo, qhi, i, qual_draw(qd, m, cls, key, ST_QUAL, pc.sid, a, c0 + i));

@@ -136,7 +136,7 @@ class Engine:
 
     def set_reference_device(self, dev_ptr: int, ref: Reference):
         """`dev_ptr` points at ref.genome_len bytes already resident on this GPU (e.g. after an RCCL
-        broadcast through torch.distributed); the engine normalises them in place and does not own them."""
+        broadcast through torch.distributed); the engine copies them device-to-device (the caller may free its buffer)."""
         blob = ref.names_blob()
         self._check(self.L.ns_set_reference_device(self.ctx, dev_ptr, ref.genome_len, ref.chrom_off.ctypes.data,
                                                    len(ref.names), ref.circular.ctypes.data, blob, len(blob)))
