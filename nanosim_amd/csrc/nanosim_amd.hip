@@ -476,7 +476,7 @@ __global__ void __launch_bounds__(64, NS_MAT_WAVES) k_materialise(GenArgs A, uin
         const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi);
         materialise_piece(A.m, A.ref, T, ro, key, a, pc, q, lane, nbases, dbg, sq, (uint32_t)r, pi);
         // the byte stores of the payload letters follow the 16-byte stores of the same wavefront in program order
-        if (NS_FUSE_PAYLOAD && !(dbg & 2)) payload_pass(A.m, A.ref, ro, key, a, pc, q, lane);
+        if (NS_FUSE_PAYLOAD && !(dbg & 2)) payload_pass(A.m, A.ref, ro, key, a, pc, q, lane, dbg);
         q += pc.out_len;
     }
     if (NS_FUSE_PAYLOAD && !(dbg & 8)) emit_random_region(A.m, ro, key, a, ST_TAIL, rd.seq_len - rd.tail, rd.tail, rd.head, lane);   // S:1427

@@ -16,7 +16,7 @@
 #include "ns_device.h"
 
 #define T_OUT 1024u
-#define T_EV 256u
+#define T_EV 64u            // events staged per tile: slot 0 = the event in force at the tile start, slots 1..63 = lanes 0..62
 struct __align__(16) TileLds {
     uint32_t mlut[17][4];               // mlut[i]: 16-byte mask with bytes >= i set (merge of an event sub-run into a chunk); [16] empty
     uint32_t e_out[T_EV + 1];           // output offset at which the event starts
@@ -267,45 +267,62 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
     if (lane < pc.n_ev) e_pre = pc.ev[lane];
     for (uint32_t M0 = 0; M0 < pc.out_len;) {
         uint32_t M1 = min(M0 + T_OUT, pc.out_len);
-        // ---- 1. stage events: L[0] = the event in force before M0 (or a synthetic start), L[1..] start in [M0, M1)
-        if (lane == 0) { T.e_out[0] = L0_out; T.e_rp[0] = L0_rp; T.e_pt[0] = (uint16_t)L0_pt; }
-        uint32_t ne = 1;
-        for (uint32_t base = jb;; base += 64) {
-            const uint32_t idx = base + lane;
-            const bool valid = idx < pc.n_ev;
-            ns_event e = e_pre;                                   // first batch was prefetched during the previous tile
-            if (base != jb) { e.pos = 0; e.info = 0; if (valid) e = pc.ev[idx]; }
-            const uint32_t os = ev_out_start(e);
-            const bool take = valid && os < M1;
-            const uint32_t cnt = (uint32_t)__popcll(__ballot(take));
-            const uint32_t slot = ne + lane;
-            if (take && slot < T_EV) {
-                uint32_t len = ns_ev_len(e.info), ty = ns_ev_type(e.info);
-                T.e_out[slot] = os;
-                T.e_pt[slot] = (uint16_t)((ty == NS_DEL ? 0 : len) | ty << 12);
-                T.e_rp[slot] = e.pos + (ty == NS_INS ? 0 : len);
-            }
-            if (ne + cnt > T_EV) {         // more events than LDS slots: end the tile at the first unstaged event
-                M1 = (uint32_t)__builtin_amdgcn_readlane((int)os, (int)(T_EV - ne));
-                ne = T_EV;
-                break;
-            }
-            ne += cnt;
-            if (cnt < 64) break;
+        // ---- 1. stage events.  Lane l holds event jb + l (prefetched during the previous tile); the events that start in
+        // [M0, M1) are a prefix of the lanes.  At most 63 are taken: if all 64 start before M1 the tile ends at the last one.
+        const ns_event e = e_pre;
+        const bool valid = jb + lane < pc.n_ev;
+        const uint32_t os = ev_out_start(e), len = ns_ev_len(e.info), ty = ns_ev_type(e.info);
+        const uint32_t e_pt = (ty == NS_DEL ? 0u : len) | ty << 12, e_rp = e.pos + (ty == NS_INS ? 0u : len);
+        if (jb + 63 < pc.n_ev) {
+            const uint32_t os63 = (uint32_t)__builtin_amdgcn_readlane((int)os, 63);
+            if (os63 < M1) M1 = os63;
         }
-        if (lane == 0) T.e_out[ne] = M1;
+        const bool take = valid && os < M1;
+        const uint32_t cnt = (uint32_t)__popcll(__ballot(take));
+        if (M1 <= M0) {                    // 64 events at one output offset (zero-length matches between deletions): not a case
+            M1 = min(M0 + T_OUT, pc.out_len);      // for the tile machinery; the generic path takes the tile
+            uint32_t j2 = jb;
+            while (j2 < pc.n_ev && ev_out_start(pc.ev[j2]) < M1) ++j2;
+            if (lane == 0) {
+                const uint32_t slot = atomicAdd(sq.count, 1u);
+                if (slot < sq.cap) sq.items[slot] = SlowTile{read_idx, piece_idx, M0, M1};
+            }
+            if (j2 > jb) {
+                const ns_event le = pc.ev[j2 - 1];
+                const uint32_t ll = ns_ev_len(le.info), lt = ns_ev_type(le.info);
+                L0_out = ev_out_start(le); L0_pt = (lt == NS_DEL ? 0u : ll) | lt << 12; L0_rp = le.pos + (lt == NS_INS ? 0u : ll);
+                L0_out = uni(L0_out); L0_pt = uni(L0_pt); L0_rp = uni(L0_rp);
+            }
+            jb = uni(j2); M0 = M1;
+            e_pre.pos = 0; e_pre.info = 0;
+            if (jb + lane < pc.n_ev) e_pre = pc.ev[jb + lane];
+            continue;
+        }
+        const uint32_t ne = 1 + cnt;
+        // LDS view for the other lanes (every lane writes slot 0 / the sentinel with the same value: no exec juggling)
+        T.e_out[0] = L0_out; T.e_rp[0] = L0_rp; T.e_pt[0] = (uint16_t)L0_pt;
+        if (take) { T.e_out[1 + lane] = os; T.e_rp[1 + lane] = e_rp; T.e_pt[1 + lane] = (uint16_t)e_pt; }
+        T.e_out[ne] = M1;
         T.hist[lane] = 0;
-        const uint32_t jb_next = jb + ne - 1;
+        const uint32_t jb_next = jb + cnt;
         e_pre.pos = 0; e_pre.info = 0;
         if (M1 < pc.out_len && jb_next + lane < pc.n_ev) e_pre = pc.ev[jb_next + lane];   // prefetch for the next tile
         wave_sync();
-
-        // ---- the event in force at M1 (wave-uniform, SGPRs); reference span of the tile only matters next to the origin
-        const uint32_t osl = uni(T.e_out[ne - 1]), ptl = uni(T.e_pt[ne - 1]), rpl = uni(T.e_rp[ne - 1]);
+        if (take) {                                               // histogram: first 16-byte chunk starting at/after the event
+            const uint32_t c = (os - M0 + 15) >> 4;
+            if (c < 64) atomicAdd(&T.hist[c], 1u);
+        }
+        // ---- the event in force at M1 (wave-uniform): the last one taken, straight from its lane's registers
+        uint32_t osl = L0_out, ptl = L0_pt, rpl = L0_rp;
+        if (cnt) {
+            osl = (uint32_t)__builtin_amdgcn_readlane((int)os, (int)(cnt - 1));
+            ptl = (uint32_t)__builtin_amdgcn_readlane((int)e_pt, (int)(cnt - 1));
+            rpl = (uint32_t)__builtin_amdgcn_readlane((int)e_rp, (int)(cnt - 1));
+        }
         const uint8_t *tb = seg0 - 32;                             // + 32 in the lane offsets: they never go negative
         uint32_t idle_off = 32;                                    // offset loaded by a sub-run that copies nothing (any valid address)
         bool fast = true;
-        if (wraps) {
+        if (wraps) {                                               // reference span of the tile only matters next to the origin
             const uint32_t pl0 = L0_pt & 0xfffu, ty0 = L0_pt >> 12, d0 = M0 - L0_out;
             const uint32_t x0 = (d0 < pl0 && ty0 == NS_INS) ? L0_rp : L0_rp + d0 - pl0;
             const uint32_t pll = ptl & 0xfffu, dl = M1 - osl;
@@ -323,10 +340,6 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             jb = jb_next; M0 = M1;
             wave_sync();
             continue;
-        }
-        for (uint32_t k = 1 + lane; k < ne; k += 64) {            // histogram: first 16-byte chunk starting at/after the event
-            uint32_t c = (T.e_out[k] - M0 + 15) >> 4;
-            if (c < 64) atomicAdd(&T.hist[c], 1u);
         }
         wave_sync();
 
@@ -403,7 +416,7 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
 // block (one word per event).  Stores from one wavefront to the same address complete in program order, so these
 // byte stores land after the 16-byte stores of the copy phase.
 __device__ inline void payload_pass(const DevModel &m, const DevRef &ref, const ReadOut &ro, const ns_key &key, uint32_t a,
-                                    const PieceCtx &pc, uint32_t pq, uint32_t lane) {
+                                    const PieceCtx &pc, uint32_t pq, uint32_t lane, uint32_t dbg = 0) {
     const bool wraps = pc.pos + pc.ref_len > pc.chrom_len;          // piece crosses the origin of a circular chromosome
     for (uint32_t base = 0; base < pc.n_ev; base += 256) {
         const uint32_t j0 = base + 4 * lane;
@@ -443,7 +456,8 @@ __device__ inline void payload_pass(const DevModel &m, const DevRef &ref, const 
                 }
                 const uint32_t q = pq + os + i;
                 const uint32_t o = ro.reversed ? ro.seq_len - 1 - q : q;
-                ro.seq[o] = ro.reversed ? complement(b) : (uint8_t)b;
+                if (!(dbg & 32)) ro.seq[o] = ro.reversed ? complement(b) : (uint8_t)b;
+                else if (b == 0x7fu) ro.seq[o] = 0;          // profiling aid: keep the letter computation alive without the store
                 if (ro.qual) {
                     const int cls = pc.kind ? NS_Q_UNMAPPED : (ty == NS_MIS ? NS_Q_MIS : NS_Q_INS);
                     ro.qual[o] = (uint8_t)(qual_draw(qd, m, cls, key, ST_QUAL, pc.sid, a, os + i) + 33);
