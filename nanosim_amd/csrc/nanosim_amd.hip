@@ -436,9 +436,7 @@ __global__ void __launch_bounds__(256) k_names(GenArgs A) {
 #ifndef NS_MAT_WAVES
 #define NS_MAT_WAVES 6
 #endif
-#ifndef NS_FUSE_PAYLOAD
-#define NS_FUSE_PAYLOAD 1     // 1: head/tail + payload letters inside k_materialise (their lines are still in L2); 0: separate k_payload
-#endif
+
 // read header of a wave-per-read kernel: everything wave-uniform, pinned to SGPRs
 __device__ __forceinline__ bool load_read_uniform(const GenArgs &A, uint64_t r, bool fastq, ns_read &rd, ns_key &key, ReadOut &ro) {
     rd = A.reads[r];
@@ -460,9 +458,28 @@ __device__ __forceinline__ bool load_read_uniform(const GenArgs &A, uint64_t r, 
     return true;
 }
 
-// copy phase: reference bytes under the event lists -> records (the LDS-tiled path of ns_materialise.h)
+// k_words: the letter word of every event, word(j) = Philox(ST_SUB, seg, attempt, idx = j >> 2).w[j & 3]: one
+// Philox block per lane and 4 events, dense; k_materialise reads the word next to the event.
+__global__ void __launch_bounds__(64) k_words(GenArgs A, uint32_t *ev_word) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t r = blockIdx.x;
+    ns_read rd; ns_key key; ReadOut ro;
+    if (!load_read_uniform(A, r, false, rd, key, ro)) return;
+    for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
+        const ns_piece p = A.pieces[rd.piece_off + pi];
+        const uint32_t n_ev = uni(p.n_ev), sid = uni(p.kind) ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
+        uint32_t *dst = ev_word + uni64(p.ev_off);
+        for (uint32_t j0 = 4 * lane; j0 < n_ev; j0 += 256) {
+            const u32x4 w = ns_draw(key, ST_SUB, sid, rd.attempts, j0 >> 2, 0);
+            if (j0 + 4 <= n_ev) { struct __attribute__((packed)) V { uint32_t a, b, c, d; } v{w.x, w.y, w.z, w.w}; __builtin_memcpy(dst + j0, &v, 16); }
+            else for (uint32_t k = 0; j0 + k < n_ev; ++k) dst[j0 + k] = ns_word(w, k);
+        }
+    }
+}
+
+// k_materialise: the sequence (and quality) line of one read per wavefront; see ns_materialise.h
 template <bool FASTQ>
-__global__ void __launch_bounds__(64, NS_MAT_WAVES) k_materialise(GenArgs A, uint64_t nbases, uint32_t dbg, SlowQueue sq) {
+__global__ void __launch_bounds__(64, NS_MAT_WAVES) k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq) {
     __shared__ TileLds T;
     const uint32_t lane = threadIdx.x;
     const uint64_t r = blockIdx.x;
@@ -470,16 +487,14 @@ __global__ void __launch_bounds__(64, NS_MAT_WAVES) k_materialise(GenArgs A, uin
     if (!load_read_uniform(A, r, FASTQ, rd, key, ro)) return;
     const uint32_t a = rd.attempts;
     tile_lds_init(T, lane);
-    if (NS_FUSE_PAYLOAD && !(dbg & 8)) emit_random_region(A.m, ro, key, a, ST_HEAD, 0, rd.head, 0, lane);          // S:1426
+    if (!(dbg & 8)) emit_random_region(A.m, ro, key, a, ST_HEAD, 0, rd.head, 0, lane);                                   // S:1426
     uint32_t q = rd.head;
     for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
-        const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi);
-        materialise_piece(A.m, A.ref, T, ro, key, a, pc, q, lane, nbases, dbg, sq, (uint32_t)r, pi);
-        // the byte stores of the payload letters follow the 16-byte stores of the same wavefront in program order
-        if (NS_FUSE_PAYLOAD && !(dbg & 2)) payload_pass(A.m, A.ref, ro, key, a, pc, q, lane, dbg);
+        const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi, ev_word);
+        materialise_piece(A.m, A.ref, T, ro, key, a, pc, q, lane, ev_word, dbg, sq, (uint32_t)r, pi);
         q += pc.out_len;
     }
-    if (NS_FUSE_PAYLOAD && !(dbg & 8)) emit_random_region(A.m, ro, key, a, ST_TAIL, rd.seq_len - rd.tail, rd.tail, rd.head, lane);   // S:1427
+    if (!(dbg & 8)) emit_random_region(A.m, ro, key, a, ST_TAIL, rd.seq_len - rd.tail, rd.tail, rd.head, lane);          // S:1427
 }
 
 // the tiles k_materialise could not take: generic per-byte path, one wavefront per queued tile
@@ -495,28 +510,6 @@ __global__ void __launch_bounds__(64) k_materialise_slow(GenArgs A, SlowQueue sq
         for (uint32_t pi = 0; pi < t.piece; ++pi) q += A.pieces[rd.piece_off + pi].out_len;
         const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + t.piece], t.piece);
         slow_piece_range(A.m, A.ref, ro, key, rd.attempts, pc, q, t.m0, t.m1, lane);
-    }
-}
-
-// everything that is not copied from the reference: head / tail bases (S:1426-1427) and the substituted / inserted letters
-// (mutate_read, S:1965-1995).  Runs after k_materialise on the same stream, so its byte stores land on top of the copy.
-template <bool FASTQ>
-__global__ void __launch_bounds__(64) k_payload(GenArgs A, uint32_t dbg) {
-    const uint32_t lane = threadIdx.x;
-    const uint64_t r = blockIdx.x;
-    ns_read rd; ns_key key; ReadOut ro;
-    if (!load_read_uniform(A, r, FASTQ, rd, key, ro)) return;
-    const uint32_t a = rd.attempts;
-    if (!(dbg & 8)) {
-        emit_random_region(A.m, ro, key, a, ST_HEAD, 0, rd.head, 0, lane);                                   // S:1426
-        emit_random_region(A.m, ro, key, a, ST_TAIL, rd.seq_len - rd.tail, rd.tail, rd.head, lane);          // S:1427
-    }
-    if (dbg & 2) return;
-    uint32_t q = rd.head;
-    for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
-        const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi);
-        payload_pass(A.m, A.ref, ro, key, a, pc, q, lane);
-        q += pc.out_len;
     }
 }
 
@@ -790,7 +783,7 @@ struct ns_ctx {
     // planning + result buffers
     DevBuf n_pieces, piece_off, ev_cap, ev_off, rec_len, rec_off, err_len, err_off, name_len;
     DevBuf reads, pieces, events, records, errlog, stats, scan_tmp;
-    DevBuf sort_key, sort_idx, sort_key_out, order, list_b, rstate, att_base, scr, scrq, scr_len, scr_off, hp_len, slow_q;
+    DevBuf sort_key, sort_idx, sort_key_out, order, list_b, rstate, att_base, scr, scrq, scr_len, scr_off, hp_len, slow_q, ev_word;
     // metagenome: species view of the reference, abundances of the sample, per-pass scratch
     DevBuf species_chrom_off, t_reads, t_pieces, t_name_len, t_rec_len, t_err_len, accept, accept_scan, key_pos, draw_x, m_segptr,
         m_len, m_species, species_bases;
@@ -902,7 +895,7 @@ void ns_destroy(ns_ctx *ctx) {
                       &ctx->err_len, &ctx->err_off, &ctx->name_len, &ctx->reads, &ctx->pieces, &ctx->events,
                       &ctx->records, &ctx->errlog, &ctx->stats, &ctx->scan_tmp, &ctx->sort_key, &ctx->sort_idx,
                       &ctx->sort_key_out, &ctx->order, &ctx->list_b, &ctx->rstate, &ctx->att_base, &ctx->scr, &ctx->scrq,
-                      &ctx->scr_len, &ctx->scr_off, &ctx->hp_len, &ctx->slow_q, &ctx->species_chrom_off, &ctx->t_reads, &ctx->t_pieces,
+                      &ctx->scr_len, &ctx->scr_off, &ctx->hp_len, &ctx->slow_q, &ctx->ev_word, &ctx->species_chrom_off, &ctx->t_reads, &ctx->t_pieces,
                       &ctx->t_name_len, &ctx->t_rec_len, &ctx->t_err_len, &ctx->accept, &ctx->accept_scan, &ctx->key_pos,
                       &ctx->draw_x, &ctx->m_segptr, &ctx->m_len, &ctx->m_species, &ctx->species_bases};
     for (DevBuf *b : bufs)
@@ -1118,8 +1111,14 @@ static int scan_u32(ns_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n) {
 // metagenome (src/simulator.py:758-811, 814-1040)
 // ---------------------------------------------------------------------------------------------------------
 // copy phase, slow tiles, payload: the three kernels that write the sequence (and quality) lines of a batch
-static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fastq) {
+static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fastq, uint64_t event_slots) {
     hipStream_t st = ctx->stream;
+    {
+        int rc = ensure(ctx, ctx->ev_word, ((size_t)event_slots + 8) * 4);
+        if (rc) return rc;
+        k_words<<<dim3((unsigned)n), dim3(64), 0, st>>>(A, (uint32_t *)ctx->ev_word.p);
+        HIPCHK(hipGetLastError());
+    }
     for (int round = 0;; ++round) {
         size_t cap = ctx->slow_q.cap >= 16 + sizeof(SlowTile) ? (ctx->slow_q.cap - 16) / sizeof(SlowTile) : 0;
         if (cap < n / 4 + 4096) {
@@ -1131,16 +1130,11 @@ static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fast
         sq.count = (uint32_t *)ctx->slow_q.p; sq.items = (SlowTile *)((uint8_t *)ctx->slow_q.p + 16);
         sq.cap = (uint32_t)(cap > 0xffffffffull ? 0xffffffffull : cap);
         HIPCHK(hipMemsetAsync(sq.count, 0, 4, st));
-        if (fastq) k_materialise<true><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->ref_nbases, ctx->dbg, sq);
-        else k_materialise<false><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->ref_nbases, ctx->dbg, sq);
+        if (fastq) k_materialise<true><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, (const uint32_t *)ctx->ev_word.p, ctx->dbg, sq);
+        else k_materialise<false><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, (const uint32_t *)ctx->ev_word.p, ctx->dbg, sq);
         HIPCHK(hipGetLastError());
         uint32_t queued = 0;
         HIPCHK(hipMemcpyAsync(&queued, sq.count, 4, hipMemcpyDeviceToHost, st));
-        if (!NS_FUSE_PAYLOAD) {
-            if (fastq) k_payload<true><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->dbg);
-            else k_payload<false><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, ctx->dbg);
-            HIPCHK(hipGetLastError());
-        }
         HIPCHK(hipStreamSynchronize(st));
         if (queued > sq.cap) {                   // more slow tiles than queue slots (tiny circular genomes): grow and redo
             if (round >= 2) return fail(ctx, NS_ENOMEM, "slow-tile queue overflow");
@@ -1560,7 +1554,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     HIPCHK(hipStreamSynchronize(st));
     if ((rc = ensure(ctx, ctx->scr, (size_t)scr_bytes + 64)) || (prm->fastq && (rc = ensure(ctx, ctx->scrq, (size_t)scr_bytes + 64)))) return rc;
     A.scr = (uint8_t *)ctx->scr.p; A.scrq = (uint8_t *)ctx->scrq.p;
-    if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0))) return rc;
+    if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, tot_cap))) return rc;
     HIPCHK(hipMemsetAsync((unsigned long long *)ctx->stats.p + 1, 0, sizeof(unsigned long long), st));
     HIPCHK(hipMemsetAsync((unsigned long long *)ctx->stats.p + 5, 0, sizeof(unsigned long long), st));
     k_hp_count<<<grid_t, blk, 0, st>>>(A);
@@ -1593,7 +1587,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         k_hp_write<<<grid_t, blk, 0, st>>>(A);
         HIPCHK(hipGetLastError());
     } else if (prm->emit_records) {
-        if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0))) return rc;
+        if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, tot_cap))) return rc;
     }
     HIPCHK(hipEventRecord(ctx->evt[7], st));
     if (prm->emit_errlog && prm->emit_records) {

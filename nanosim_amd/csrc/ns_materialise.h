@@ -23,8 +23,19 @@ struct __align__(16) TileLds {
     uint32_t e_rp[T_EV];                // segment position of the first base copied after the event's payload
     uint16_t e_pt[T_EV];                // payload length (0 for a deletion) | type << 12
     uint32_t hist[64];
+    // substituted / inserted letters of the tile at their output offsets (relative to the tile's aligned origin), the byte mask
+    // that marks them (0xff) and, for FASTQ, their quality class; + a dump area for predicated-off letter slots
+    uint8_t pay[T_OUT + 16 + 64];
+    uint8_t pmask[T_OUT + 16 + 64];
+    uint8_t pcls[T_OUT + 16 + 64];
 };
+#define T_DUMP (T_OUT + 16u)
 __device__ __forceinline__ void tile_lds_init(TileLds &T, uint32_t lane) {
+    for (uint32_t c = lane * 16; c < T_OUT + 16 + 64; c += 64 * 16) {
+        *reinterpret_cast<uint4 *>(&T.pay[c]) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4 *>(&T.pmask[c]) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4 *>(&T.pcls[c]) = make_uint4(0, 0, 0, 0);
+    }
     if (lane < 17) {
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k)
@@ -129,6 +140,7 @@ __device__ inline void emit_random_region(const DevModel &m, const ReadOut &ro, 
 // ---- generic per-byte path (global memory, no staging) ---------------------------------------------------
 struct PieceCtx {
     const ns_event *ev;
+    const uint32_t *wd;      // letter word of every event (k_words); only set by load_piece_uniform
     uint32_t n_ev;
     uint32_t out_len, ref_len;
     uint64_t chrom_base;
@@ -188,7 +200,7 @@ __device__ __forceinline__ uint8_t piece_byte(const DevRef &ref, const PieceCtx 
 }
 __device__ __forceinline__ PieceCtx load_piece(const ns_event *events, const DevRef &ref, const ns_piece &p, uint32_t pi) {
     PieceCtx pc;
-    pc.ev = events + p.ev_off; pc.n_ev = p.n_ev; pc.out_len = p.out_len; pc.ref_len = p.ref_len;
+    pc.ev = events + p.ev_off; pc.wd = nullptr; pc.n_ev = p.n_ev; pc.out_len = p.out_len; pc.ref_len = p.ref_len;
     pc.chrom_base = ref.chrom_off[p.chrom];
     pc.chrom_len = ref.chrom_off[p.chrom + 1] - pc.chrom_base;
     pc.pos = p.pos; pc.kind = p.kind;
@@ -196,9 +208,11 @@ __device__ __forceinline__ PieceCtx load_piece(const ns_event *events, const Dev
     return pc;
 }
 // the same for kernels in which the whole wavefront works on one piece: everything wave-uniform, held in SGPRs
-__device__ __forceinline__ PieceCtx load_piece_uniform(const ns_event *events, const DevRef &ref, const ns_piece &p, uint32_t pi) {
+__device__ __forceinline__ PieceCtx load_piece_uniform(const ns_event *events, const DevRef &ref, const ns_piece &p, uint32_t pi,
+                                                       const uint32_t *ev_word = nullptr) {
     PieceCtx pc;
-    pc.ev = events + uni64(p.ev_off); pc.n_ev = uni(p.n_ev); pc.out_len = uni(p.out_len); pc.ref_len = uni(p.ref_len);
+    const uint64_t eo = uni64(p.ev_off);
+    pc.ev = events + eo; pc.wd = ev_word + eo; pc.n_ev = uni(p.n_ev); pc.out_len = uni(p.out_len); pc.ref_len = uni(p.ref_len);
     const uint32_t chrom = uni(p.chrom);
     pc.chrom_base = uni64(ref.chrom_off[chrom]);
     pc.chrom_len = uni64(ref.chrom_off[chrom + 1]) - pc.chrom_base;
@@ -246,30 +260,35 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
     return d;
 }
 
-// Copy phase of one piece (v3: no reference tile).  Per tile of <= 1024 output bases:
-//   1. the events that start inside the tile (plus the one in force at its start) are staged into LDS;
-//   2. a histogram + wavefront prefix sum gives every lane (= 16 output bytes) the event in force at its first byte;
-//   3. per event sub-run of its chunk the lane issues ONE unaligned 16-byte global load at the run's reference offset (the
-//      loads of consecutive sub-runs are in flight together; they hit L1/L2: neighbouring lanes read overlapping bytes)
-//      and merges bytes [run start, 16) into the chunk; IUPAC codes (bit 7) are resolved on the loaded bytes
-//      (case_convert, S:743-755: keyed by the segment position);
-//   4. complement/reverse in registers (S:1433-1435, 1675-1680), one 16-byte store.
+// One piece of a read (v4).  Per tile of <= 1024 output bases whose 16-byte chunks are ALIGNED in the record buffer:
+//   1. lane l holds event jb + l (prefetched) and its letter word (k_words); the events that start inside the tile are a
+//      prefix of the lanes; they are staged into LDS for the other lanes;
+//   2. lane per event: the substituted / inserted letters (mutate_read, S:1965-1995) are written into an LDS payload tile at
+//      their output offsets, with a byte mask (and the quality class);
+//   3. a histogram + wavefront prefix sum gives every lane (= one aligned 16-byte chunk) the event in force at its first byte;
+//      per event sub-run of the chunk ONE unaligned 16-byte global load at the run's reference offset (software-pipelined,
+//      branch-free; neighbouring lanes hit the same lines in L1/L2), merged into the chunk under a byte mask; then the
+//      payload tile is merged on top; IUPAC codes (bit 7) are resolved afterwards (case_convert, S:743-755);
+//   4. complement/reverse in registers (S:1433-1435, 1675-1680), one aligned 16-byte store.
 // A tile whose reference span straddles the origin of a circular chromosome goes to the slow-tile queue.
 __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, TileLds &T, const ReadOut &ro, const ns_key &key,
-                                         uint32_t a, const PieceCtx &pc, uint32_t pq, uint32_t lane, uint64_t nbases, uint32_t dbg,
-                                         const SlowQueue &sq, uint32_t read_idx, uint32_t piece_idx) {
+                                         uint32_t a, const PieceCtx &pc, uint32_t pq, uint32_t lane, const uint32_t *__restrict__ ev_word,
+                                         uint32_t dbg, const SlowQueue &sq, uint32_t read_idx, uint32_t piece_idx) {
     uint32_t jb = 0;                       // events with out_start < M0
-    uint32_t L0_out = 0, L0_rp = 0, L0_pt = 3u << 12;     // the event in force at M0 (synthetic start: no payload, copy from 0)
+    uint32_t L0_out = 0, L0_rp = 0, L0_pt = 3u << 12, L0_wd = 0, L0_j = 0;   // the event in force at M0 (synthetic start: no payload, copy from 0)
     const uint8_t *seg0 = ref.bases + pc.chrom_base + pc.pos;           // segment position 0
     const bool wraps = pc.pos + pc.ref_len > pc.chrom_len;
     const uint32_t wrap_at = wraps ? (uint32_t)(pc.chrom_len - pc.pos) : 0xffffffffu;   // first segment position beyond the origin
-    ns_event e_pre; e_pre.pos = 0; e_pre.info = 0;
-    if (lane < pc.n_ev) e_pre = pc.ev[lane];
+    // output offsets m with m = phi (mod 16) start an aligned 16-byte group of the record buffer
+    const uint32_t phi = ro.reversed ? ((uint32_t)(uintptr_t)ro.seq + ro.seq_len - pq) & 15u : (0u - ((uint32_t)(uintptr_t)ro.seq + pq)) & 15u;
+    ns_event e_pre; e_pre.pos = 0; e_pre.info = 0; uint32_t w_pre = 0;
+    if (lane < pc.n_ev) { e_pre = pc.ev[lane]; w_pre = pc.wd[lane]; }
     for (uint32_t M0 = 0; M0 < pc.out_len;) {
-        uint32_t M1 = min(M0 + T_OUT, pc.out_len);
-        // ---- 1. stage events.  Lane l holds event jb + l (prefetched during the previous tile); the events that start in
-        // [M0, M1) are a prefix of the lanes.  At most 63 are taken: if all 64 start before M1 the tile ends at the last one.
+        const uint32_t A0 = M0 - ((M0 - phi) & 15u);             // aligned origin of the tile (<= M0; may be "negative" = wrapped)
+        uint32_t M1 = min(A0 + T_OUT, pc.out_len);
+        // ---- 1. events of the tile
         const ns_event e = e_pre;
+        const uint32_t e_wd = w_pre;
         const bool valid = jb + lane < pc.n_ev;
         const uint32_t os = ev_out_start(e), len = ns_ev_len(e.info), ty = ns_ev_type(e.info);
         const uint32_t e_pt = (ty == NS_DEL ? 0u : len) | ty << 12, e_rp = e.pos + (ty == NS_INS ? 0u : len);
@@ -290,12 +309,12 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             if (j2 > jb) {
                 const ns_event le = pc.ev[j2 - 1];
                 const uint32_t ll = ns_ev_len(le.info), lt = ns_ev_type(le.info);
-                L0_out = ev_out_start(le); L0_pt = (lt == NS_DEL ? 0u : ll) | lt << 12; L0_rp = le.pos + (lt == NS_INS ? 0u : ll);
-                L0_out = uni(L0_out); L0_pt = uni(L0_pt); L0_rp = uni(L0_rp);
+                L0_out = uni(ev_out_start(le)); L0_pt = uni((lt == NS_DEL ? 0u : ll) | lt << 12); L0_rp = uni(le.pos + (lt == NS_INS ? 0u : ll));
+                L0_wd = uni(pc.wd[j2 - 1]); L0_j = uni(j2 - 1);
             }
             jb = uni(j2); M0 = M1;
-            e_pre.pos = 0; e_pre.info = 0;
-            if (jb + lane < pc.n_ev) e_pre = pc.ev[jb + lane];
+            e_pre.pos = 0; e_pre.info = 0; w_pre = 0;
+            if (jb + lane < pc.n_ev) { e_pre = pc.ev[jb + lane]; w_pre = pc.wd[jb + lane]; }
             continue;
         }
         const uint32_t ne = 1 + cnt;
@@ -305,19 +324,21 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
         T.e_out[ne] = M1;
         T.hist[lane] = 0;
         const uint32_t jb_next = jb + cnt;
-        e_pre.pos = 0; e_pre.info = 0;
-        if (M1 < pc.out_len && jb_next + lane < pc.n_ev) e_pre = pc.ev[jb_next + lane];   // prefetch for the next tile
+        e_pre.pos = 0; e_pre.info = 0; w_pre = 0;
+        if (M1 < pc.out_len && jb_next + lane < pc.n_ev) { e_pre = pc.ev[jb_next + lane]; w_pre = pc.wd[jb_next + lane]; }   // prefetch for the next tile
         wave_sync();
-        if (take) {                                               // histogram: first 16-byte chunk starting at/after the event
-            const uint32_t c = (os - M0 + 15) >> 4;
+        if (take) {                                               // histogram: first chunk starting at/after the event
+            const uint32_t c = (os - A0 + 15) >> 4;
             if (c < 64) atomicAdd(&T.hist[c], 1u);
         }
         // ---- the event in force at M1 (wave-uniform): the last one taken, straight from its lane's registers
-        uint32_t osl = L0_out, ptl = L0_pt, rpl = L0_rp;
+        uint32_t osl = L0_out, ptl = L0_pt, rpl = L0_rp, wdl = L0_wd, jl = L0_j;
         if (cnt) {
             osl = (uint32_t)__builtin_amdgcn_readlane((int)os, (int)(cnt - 1));
             ptl = (uint32_t)__builtin_amdgcn_readlane((int)e_pt, (int)(cnt - 1));
             rpl = (uint32_t)__builtin_amdgcn_readlane((int)e_rp, (int)(cnt - 1));
+            wdl = (uint32_t)__builtin_amdgcn_readlane((int)e_wd, (int)(cnt - 1));
+            jl = jb + cnt - 1;
         }
         const uint8_t *tb = seg0 - 32;                             // + 32 in the lane offsets: they never go negative
         uint32_t idle_off = 32;                                    // offset loaded by a sub-run that copies nothing (any valid address)
@@ -331,38 +352,66 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             if (x0 >= wrap_at) { tb -= pc.chrom_len; idle_off = wrap_at + 32; }   // whole tile beyond the origin
             else if (x1 > wrap_at) fast = false;                   // tile straddles the origin
         }
-        L0_out = osl; L0_rp = rpl; L0_pt = ptl;
         if (!fast) {
             if (lane == 0) {
                 const uint32_t slot = atomicAdd(sq.count, 1u);
                 if (slot < sq.cap) sq.items[slot] = SlowTile{read_idx, piece_idx, M0, M1};
             }
+            L0_out = osl; L0_rp = rpl; L0_pt = ptl; L0_wd = wdl; L0_j = jl;
             jb = jb_next; M0 = M1;
             wave_sync();
             continue;
         }
+
+        // ---- 2. letters: lane per event; lane 63 (never a taker) continues the payload of the event in force at M0
+        if (!(dbg & 2)) {
+            const bool cont = lane == 63 && L0_out + (L0_pt & 0xfffu) > M0;
+            const uint32_t b_os = cont ? L0_out : os, b_pt = cont ? L0_pt : e_pt, b_rp = cont ? L0_rp : e_rp;
+            const uint32_t b_j = cont ? L0_j : jb + lane;
+            uint32_t frac = cont ? L0_wd : e_wd;
+            const uint32_t b_pl = b_pt & 0xfffu, b_ty = b_pt >> 12;
+            if ((take || cont) && b_pl) {
+                const uint32_t i_lo = b_os < M0 ? M0 - b_os : 0u;
+                const uint32_t i_hi = min(b_pl, M1 - b_os);
+                const uint32_t xs = b_rp - b_pl;                  // segment position under the first substituted base
+                const int cls = pc.kind ? NS_Q_UNMAPPED : (b_ty == NS_MIS ? NS_Q_MIS : NS_Q_INS);
+                for (uint32_t i = 0; i < i_hi; ++i) {
+                    if (i && !(i & 15)) frac = payload_word(key, pc.sid, a, b_j, i >> 4);
+                    uint32_t b;
+                    if (b_ty == NS_INS) b = bases_atcg((frac >> (2 * (i & 15))) & 3u);
+                    else {
+                        const uint32_t x = xs + i;
+                        b = mis_from_digit(resolve_base(ref_base_at(ref, pc, x), key, pc.sid, a, x), next_digit3(frac));
+                    }
+                    if (i >= i_lo) {
+                        const uint32_t o = b_os + i - A0;
+                        T.pay[o] = (uint8_t)b; T.pmask[o] = 0xffu;
+                        if (ro.qual) T.pcls[o] = (uint8_t)cls;
+                    }
+                }
+            }
+        }
+        L0_out = osl; L0_rp = rpl; L0_pt = ptl; L0_wd = wdl; L0_j = jl;
         wave_sync();
 
-        // ---- phase A: one lane per 16 output bytes
+        // ---- 3. one lane per aligned 16-byte chunk
         const uint32_t incl = wave_incl_scan(T.hist[lane]);
-        const uint32_t c0 = M0 + 16 * lane;
-        if (c0 < M1 && !(dbg & 1)) {
-            const uint32_t count = min(16u, M1 - c0);
-            const uint32_t c_end = c0 + count;
+        const uint32_t c0 = A0 + 16 * lane;                        // chunk origin (lane 0 of a piece's first tile may start before M0)
+        const uint32_t lo_m = lane == 0 ? M0 : c0, hi_m = min(c0 + 16, M1);
+        if ((int32_t)(hi_m - lo_m) > 0 && !(dbg & 1)) {
             uint32_t k = incl;                                     // event in force at the chunk's first byte
-            uint32_t os = T.e_out[k], pl = T.e_pt[k] & 0xfffu, rp = T.e_rp[k], nxt = T.e_out[k + 1];
+            uint32_t eos = T.e_out[k], pl = T.e_pt[k] & 0xfffu, rp = T.e_rp[k], nxt = T.e_out[k + 1];
             uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-            uint32_t mcur = c0;
-            // Branch-free, software-pipelined: the load of sub-run i+1 is issued before sub-run i is merged.  A sub-run that
-            // copies nothing loads from offset 0 and merges with the empty mask mlut[16].
-            // Two register sets (fa / fb) alternate so that a load stays in flight across the merge of the previous one.
+            uint32_t mcur = lo_m;
+            // Branch-free, software-pipelined: the load of sub-run i+1 is issued before sub-run i is merged (two register sets
+            // alternate).  A sub-run that copies nothing loads from a fixed valid offset and merges with the empty mask mlut[16].
             uint4 fa = make_uint4(0, 0, 0, 0), fb = make_uint4(0, 0, 0, 0);
             uint32_t ia = 16, ib = 16;
 #define NS_SUBRUN_STEP(FN, IN, FO, IO)                                                                              \
             {                                                                                                        \
-                const uint32_t cs = max(mcur, os + pl);            /* first copied byte under event k */              \
-                const bool has = cs < min(nxt, c_end);                                                               \
-                const uint32_t xrel = rp + c0 - (os + pl);         /* segment position of chunk byte 0 under this event's shift */ \
+                const uint32_t cs = max(mcur, eos + pl);           /* first copied byte under event k */              \
+                const bool has = cs < min(nxt, hi_m);                                                                \
+                const uint32_t xrel = rp + c0 - (eos + pl);        /* segment position of chunk byte 0 under this event's shift */ \
                 __builtin_memcpy(&FN, tb + (has ? xrel + 32u : idle_off), 16);                                       \
                 const uint4 mk = *reinterpret_cast<const uint4 *>(&T.mlut[IO][0]);   /* bytes [i0, 16): later sub-runs overwrite their own part */ \
                 r0 = bfi(mk.x, FO.x, r0); r1 = bfi(mk.y, FO.y, r1); r2 = bfi(mk.z, FO.z, r2); r3 = bfi(mk.w, FO.w, r3); \
@@ -370,13 +419,17 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             }
             for (;;) {
                 NS_SUBRUN_STEP(fa, ia, fb, ib)
-                if (nxt >= c_end) break;
-                mcur = nxt; ++k; os = nxt; pl = T.e_pt[k] & 0xfffu; rp = T.e_rp[k]; nxt = T.e_out[k + 1];
+                if (nxt >= hi_m) break;
+                mcur = nxt; ++k; eos = nxt; pl = T.e_pt[k] & 0xfffu; rp = T.e_rp[k]; nxt = T.e_out[k + 1];
                 NS_SUBRUN_STEP(fb, ib, fa, ia)
-                if (nxt >= c_end) break;
-                mcur = nxt; ++k; os = nxt; pl = T.e_pt[k] & 0xfffu; rp = T.e_rp[k]; nxt = T.e_out[k + 1];
+                if (nxt >= hi_m) break;
+                mcur = nxt; ++k; eos = nxt; pl = T.e_pt[k] & 0xfffu; rp = T.e_rp[k]; nxt = T.e_out[k + 1];
             }
 #undef NS_SUBRUN_STEP
+            const uint32_t lo_off = 16 * lane;                     // chunk offset inside the payload tile
+            const uint4 pv = *reinterpret_cast<const uint4 *>(&T.pay[lo_off]), pm = *reinterpret_cast<const uint4 *>(&T.pmask[lo_off]);
+            uint4 pcl = make_uint4(0, 0, 0, 0);
+            if (ro.qual) pcl = *reinterpret_cast<const uint4 *>(&T.pcls[lo_off]);
             {                                                      // at most one of the two is still pending
                 const uint4 ma = *reinterpret_cast<const uint4 *>(&T.mlut[ia][0]), mb = *reinterpret_cast<const uint4 *>(&T.mlut[ib][0]);
                 r0 = bfi(ma.x, fa.x, r0); r1 = bfi(ma.y, fa.y, r1); r2 = bfi(ma.z, fa.z, r2); r3 = bfi(ma.w, fa.w, r3);
@@ -384,7 +437,7 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             }
             if ((r0 | r1 | r2 | r3) & 0x80808080u) {               // case_convert (S:743-755): rare; the segment position of a marked
                 uint32_t kk = incl;                                // byte is found by walking the chunk's events again
-                for (uint32_t b = 0; b < count; ++b) {
+                for (uint32_t b = lo_m - c0; b < hi_m - c0; ++b) {
                     uint32_t wk = b < 8 ? (b < 4 ? r0 : r1) : (b < 12 ? r2 : r3);
                     const uint32_t ch = (wk >> (8 * (b & 3))) & 0xff;
                     if (!(ch & 0x80u)) continue;
@@ -396,73 +449,32 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
                     if (b < 4) r0 = wk; else if (b < 8) r1 = wk; else if (b < 12) r2 = wk; else r3 = wk;
                 }
             }
-            const uint64_t lo = (uint64_t)r0 | (uint64_t)r1 << 32, hi = (uint64_t)r2 | (uint64_t)r3 << 32;
+            // letters on top of the copied bases; the payload tile is left clean for the next tile
+            r0 = bfi(pm.x, pv.x, r0); r1 = bfi(pm.y, pv.y, r1); r2 = bfi(pm.z, pv.z, r2); r3 = bfi(pm.w, pv.w, r3);
+            *reinterpret_cast<uint4 *>(&T.pay[lo_off]) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4 *>(&T.pmask[lo_off]) = make_uint4(0, 0, 0, 0);
+            uint64_t lo = (uint64_t)r0 | (uint64_t)r1 << 32, hi = (uint64_t)r2 | (uint64_t)r3 << 32;
             uint64_t qlo = 0, qhi = 0;
-            if (ro.qual) {                                         // match-class (or unmapped) qualities; payload bytes are redone by k_payload
+            uint32_t s0 = lo_m - c0, count = hi_m - lo_m;          // bytes [s0, s0 + count) of the chunk are this tile's
+            if (ro.qual) {                                         // one quality per byte, class from the payload tile (S:1421-1423)
+                *reinterpret_cast<uint4 *>(&T.pcls[lo_off]) = make_uint4(0, 0, 0, 0);
                 QualDraw qd; qd.blk = 0xffffffffu;
-                const int cls = pc.kind ? NS_Q_UNMAPPED : NS_Q_MATCH;
-                for (uint32_t i = 0; i < count; ++i) put_byte(qlo, qhi, i, qual_draw(qd, m, cls, key, ST_QUAL, pc.sid, a, c0 + i));
+                const int cls0 = pc.kind ? NS_Q_UNMAPPED : NS_Q_MATCH;
+                for (uint32_t i = s0; i < s0 + count; ++i) {
+                    const uint32_t cw = i < 8 ? (i < 4 ? pcl.x : pcl.y) : (i < 12 ? pcl.z : pcl.w);
+                    const uint32_t cb = (cw >> (8 * (i & 3))) & 0xffu;
+                    put_byte(qlo, qhi, i, qual_draw(qd, m, cb ? (int)cb : cls0, key, ST_QUAL, pc.sid, a, c0 + i));
+                }
             }
-            if (!(dbg & 16)) store_chunk(ro, pq + c0, count, lo, hi, qlo, qhi);
+            if (s0) {                                              // front-partial chunk (first chunk of a piece): shift down
+                const uint32_t sh = 8 * s0;
+                if (sh < 64) { lo = (lo >> sh) | (hi << (64 - sh)); hi >>= sh; qlo = (qlo >> sh) | (qhi << (64 - sh)); qhi >>= sh; }
+                else { lo = hi >> (sh - 64); hi = 0; qlo = qhi >> (sh - 64); qhi = 0; }
+            }
+            if (!(dbg & 16)) store_chunk(ro, pq + lo_m, count, lo, hi, qlo, qhi);
         }
 
         jb = jb_next; M0 = M1;
         wave_sync();
-    }
-}
-
-// ---- payload pass: substituted / inserted letters (mutate_read, S:1965-1995) stored over the copied bases -----
-// Runs after all tiles of the piece.  256 events per iteration: each lane owns 4 consecutive events and ONE Philox
-// block (one word per event).  Stores from one wavefront to the same address complete in program order, so these
-// byte stores land after the 16-byte stores of the copy phase.
-__device__ inline void payload_pass(const DevModel &m, const DevRef &ref, const ReadOut &ro, const ns_key &key, uint32_t a,
-                                    const PieceCtx &pc, uint32_t pq, uint32_t lane, uint32_t dbg = 0) {
-    const bool wraps = pc.pos + pc.ref_len > pc.chrom_len;          // piece crosses the origin of a circular chromosome
-    for (uint32_t base = 0; base < pc.n_ev; base += 256) {
-        const uint32_t j0 = base + 4 * lane;
-        if (j0 >= pc.n_ev) continue;
-        // the lane's 4 events and, for substitutions, the 4 reference bytes at their position: all loads issued up front
-        ns_event ev4[4];
-        uint32_t cur4[4];
-#pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) {
-            ev4[k].pos = 0; ev4[k].info = ns_ev_pack(0, NS_DEL, 0);
-            if (j0 + k < pc.n_ev) ev4[k] = pc.ev[j0 + k];
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) {
-            cur4[k] = 0;
-            if (ns_ev_type(ev4[k].info) == NS_MIS && !wraps)
-                __builtin_memcpy(&cur4[k], ref.bases + pc.chrom_base + pc.pos + ev4[k].pos, 4);    // bases has 16 bytes of tail padding
-        }
-        const u32x4 w = ns_draw(key, ST_SUB, pc.sid, a, j0 >> 2, 0);
-        QualDraw qd; qd.blk = 0xffffffffu;
-#pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) {
-            const uint32_t j = j0 + k;
-            const ns_event e = ev4[k];
-            const uint32_t ty = ns_ev_type(e.info), len = ns_ev_len(e.info);
-            if (ty == NS_DEL) continue;
-            const uint32_t os = ev_out_start(e);
-            uint32_t word = ns_word(w, k);
-            for (uint32_t i = 0; i < len; ++i) {
-                if (i && !(i & 15)) word = payload_word(key, pc.sid, a, j, i >> 4);
-                uint32_t b;
-                if (ty == NS_INS) b = bases_atcg((word >> (2 * (i & 15))) & 3u);
-                else {
-                    const uint32_t x = e.pos + i;
-                    uint32_t c = (i < 4 && !wraps) ? (cur4[k] >> (8 * i)) & 0xffu : ref_base_at(ref, pc, x);
-                    b = mis_from_digit(resolve_base(c, key, pc.sid, a, x), next_digit3(word));
-                }
-                const uint32_t q = pq + os + i;
-                const uint32_t o = ro.reversed ? ro.seq_len - 1 - q : q;
-                if (!(dbg & 32)) ro.seq[o] = ro.reversed ? complement(b) : (uint8_t)b;
-                else if (b == 0x7fu) ro.seq[o] = 0;          // profiling aid: keep the letter computation alive without the store
-                if (ro.qual) {
-                    const int cls = pc.kind ? NS_Q_UNMAPPED : (ty == NS_MIS ? NS_Q_MIS : NS_Q_INS);
-                    ro.qual[o] = (uint8_t)(qual_draw(qd, m, cls, key, ST_QUAL, pc.sid, a, os + i) + 33);
-                }
-            }
-        }
     }
 }
