@@ -403,38 +403,46 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             uint32_t eos = T.e_out[k], pl = T.e_pt[k] & 0xfffu, rp = T.e_rp[k], nxt = T.e_out[k + 1];
             uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
             uint32_t mcur = lo_m;
-            // Branch-free, software-pipelined: the load of sub-run i+1 is issued before sub-run i is merged (two register sets
-            // alternate).  A sub-run that copies nothing loads from a fixed valid offset and merges with the empty mask mlut[16].
-            uint4 fa = make_uint4(0, 0, 0, 0), fb = make_uint4(0, 0, 0, 0);
-            uint32_t ia = 16, ib = 16;
-#define NS_SUBRUN_STEP(FN, IN, FO, IO)                                                                              \
+            // The first four event sub-runs of the chunk are gathered branch-free with all four 16-byte loads in flight (a lane
+            // that has run out of sub-runs loads a fixed valid offset and merges with the empty mask mlut[16]); chunks with
+            // more sub-runs (>= 4 events inside 16 bases) continue in a loop.
+            bool more = true;
+            uint4 f0, f1, f2, f3; uint32_t i0, i1, i2, i3;
+#define NS_SUBRUN_GATHER(FN, IN)                                                                                     \
             {                                                                                                        \
                 const uint32_t cs = max(mcur, eos + pl);           /* first copied byte under event k */              \
-                const bool has = cs < min(nxt, hi_m);                                                                \
+                const bool has = more && cs < min(nxt, hi_m);                                                        \
                 const uint32_t xrel = rp + c0 - (eos + pl);        /* segment position of chunk byte 0 under this event's shift */ \
                 __builtin_memcpy(&FN, tb + (has ? xrel + 32u : idle_off), 16);                                       \
-                const uint4 mk = *reinterpret_cast<const uint4 *>(&T.mlut[IO][0]);   /* bytes [i0, 16): later sub-runs overwrite their own part */ \
+                IN = has ? cs - c0 : 16u;                                                                            \
+                more = more && nxt < hi_m;                                                                           \
+                k += more ? 1u : 0u;                                                                                 \
+                mcur = more ? nxt : mcur; eos = more ? nxt : eos;                                                    \
+                pl = T.e_pt[k] & 0xfffu; rp = T.e_rp[k]; nxt = T.e_out[k + 1];                                       \
+            }
+#define NS_SUBRUN_MERGE(FO, IO)                                                                                      \
+            {                                                                                                        \
+                const uint4 mk = *reinterpret_cast<const uint4 *>(&T.mlut[IO][0]);   /* bytes [i, 16): later sub-runs overwrite their own part */ \
                 r0 = bfi(mk.x, FO.x, r0); r1 = bfi(mk.y, FO.y, r1); r2 = bfi(mk.z, FO.z, r2); r3 = bfi(mk.w, FO.w, r3); \
-                IN = has ? cs - c0 : 16u; IO = 16u;                                                                  \
             }
-            for (;;) {
-                NS_SUBRUN_STEP(fa, ia, fb, ib)
-                if (nxt >= hi_m) break;
-                mcur = nxt; ++k; eos = nxt; pl = T.e_pt[k] & 0xfffu; rp = T.e_rp[k]; nxt = T.e_out[k + 1];
-                NS_SUBRUN_STEP(fb, ib, fa, ia)
-                if (nxt >= hi_m) break;
-                mcur = nxt; ++k; eos = nxt; pl = T.e_pt[k] & 0xfffu; rp = T.e_rp[k]; nxt = T.e_out[k + 1];
+            NS_SUBRUN_GATHER(f0, i0)
+            NS_SUBRUN_GATHER(f1, i1)
+            NS_SUBRUN_GATHER(f2, i2)
+            NS_SUBRUN_GATHER(f3, i3)
+            NS_SUBRUN_MERGE(f0, i0)
+            NS_SUBRUN_MERGE(f1, i1)
+            NS_SUBRUN_MERGE(f2, i2)
+            NS_SUBRUN_MERGE(f3, i3)
+            while (more) {
+                NS_SUBRUN_GATHER(f0, i0)
+                NS_SUBRUN_MERGE(f0, i0)
             }
-#undef NS_SUBRUN_STEP
+#undef NS_SUBRUN_GATHER
+#undef NS_SUBRUN_MERGE
             const uint32_t lo_off = 16 * lane;                     // chunk offset inside the payload tile
             const uint4 pv = *reinterpret_cast<const uint4 *>(&T.pay[lo_off]), pm = *reinterpret_cast<const uint4 *>(&T.pmask[lo_off]);
             uint4 pcl = make_uint4(0, 0, 0, 0);
             if (ro.qual) pcl = *reinterpret_cast<const uint4 *>(&T.pcls[lo_off]);
-            {                                                      // at most one of the two is still pending
-                const uint4 ma = *reinterpret_cast<const uint4 *>(&T.mlut[ia][0]), mb = *reinterpret_cast<const uint4 *>(&T.mlut[ib][0]);
-                r0 = bfi(ma.x, fa.x, r0); r1 = bfi(ma.y, fa.y, r1); r2 = bfi(ma.z, fa.z, r2); r3 = bfi(ma.w, fa.w, r3);
-                r0 = bfi(mb.x, fb.x, r0); r1 = bfi(mb.y, fb.y, r1); r2 = bfi(mb.z, fb.z, r2); r3 = bfi(mb.w, fb.w, r3);
-            }
             if ((r0 | r1 | r2 | r3) & 0x80808080u) {               // case_convert (S:743-755): rare; the segment position of a marked
                 uint32_t kk = incl;                                // byte is found by walking the chunk's events again
                 for (uint32_t b = lo_m - c0; b < hi_m - c0; ++b) {
