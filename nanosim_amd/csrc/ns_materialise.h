@@ -370,11 +370,37 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             const uint32_t b_j = cont ? L0_j : jb + lane;
             uint32_t frac = cont ? L0_wd : e_wd;
             const uint32_t b_pl = b_pt & 0xfffu, b_ty = b_pt >> 12;
-            if ((take || cont) && b_pl) {
+            const bool on = (take || cont) && b_pl;
+            const uint32_t xs = b_rp - b_pl;                      // segment position under the first substituted base
+            const int cls = pc.kind ? NS_Q_UNMAPPED : (b_ty == NS_MIS ? NS_Q_MIS : NS_Q_INS);
+            // fast path (branch-free): up to four letters, all inside the tile, plain bases under a substitution
+            const bool mis = b_ty == NS_MIS;
+            bool fast_l = on && b_pl <= 4 && b_os >= M0 && b_os + b_pl <= M1 && !wraps;
+            uint32_t cur4 = 0x41414141u;
+            if (fast_l && mis) __builtin_memcpy(&cur4, seg0 + xs, 4);
+            fast_l = fast_l && !(cur4 & 0x80808080u);
+            if (fast_l) {
+                // insertion: 2-bit fields of the word -> "ATCG" (S:1990)
+                const uint32_t x8 = frac & 0xffu, t8 = (x8 | x8 << 12) & 0x000f000fu;
+                const uint32_t ins4 = __builtin_amdgcn_perm(0u, 0x47435441u, (t8 | t8 << 6) & 0x03030303u);
+                // substitution: base-3 digits of the word pick among the three other bases (S:1968-1972)
+                uint32_t f3 = frac;
+                const uint32_t d0 = next_digit3(f3), d1 = next_digit3(f3), d2 = next_digit3(f3), d3 = next_digit3(f3);
+                const uint32_t d4 = d0 | d1 << 8 | d2 << 16 | d3 << 24;
+                const uint32_t vv = (cur4 >> 1) & 0x03030303u;                           // A 0, C 1, T 2, G 3
+                const uint32_t rank4 = (vv & 0x01010101u) << 1 | ((vv >> 1) & 0x01010101u);   // rank in "ATCG": A 0, T 1, C 2, G 3
+                const uint32_t ge = ((d4 | 0x80808080u) - rank4) & 0x80808080u;          // per byte: digit >= rank
+                const uint32_t mis4 = __builtin_amdgcn_perm(0u, 0x47435441u, d4 + (ge >> 7));
+                const uint32_t letters = mis ? mis4 : ins4;
+                const uint32_t o = b_os - A0, dump = T_DUMP + lane;
+                const uint32_t o1 = b_pl > 1 ? o + 1 : dump, o2 = b_pl > 2 ? o + 2 : dump, o3 = b_pl > 3 ? o + 3 : dump;
+                T.pay[o] = (uint8_t)letters; T.pay[o1] = (uint8_t)(letters >> 8); T.pay[o2] = (uint8_t)(letters >> 16); T.pay[o3] = (uint8_t)(letters >> 24);
+                T.pmask[o] = 0xffu; T.pmask[o1] = 0xffu; T.pmask[o2] = 0xffu; T.pmask[o3] = 0xffu;
+                if (ro.qual) { T.pcls[o] = (uint8_t)cls; T.pcls[o1] = (uint8_t)cls; T.pcls[o2] = (uint8_t)cls; T.pcls[o3] = (uint8_t)cls; }
+            }
+            if (on && !fast_l) {                                  // long payloads, tile borders, IUPAC under a substitution, the origin
                 const uint32_t i_lo = b_os < M0 ? M0 - b_os : 0u;
                 const uint32_t i_hi = min(b_pl, M1 - b_os);
-                const uint32_t xs = b_rp - b_pl;                  // segment position under the first substituted base
-                const int cls = pc.kind ? NS_Q_UNMAPPED : (b_ty == NS_MIS ? NS_Q_MIS : NS_Q_INS);
                 for (uint32_t i = 0; i < i_hi; ++i) {
                     if (i && !(i & 15)) frac = payload_word(key, pc.sid, a, b_j, i >> 4);
                     uint32_t b;
