@@ -99,6 +99,31 @@ __device__ __forceinline__ void store_chunk(const ReadOut &ro, uint32_t q0, uint
         store16(ro.qual + o0, count, qlo, qhi);
     }
 }
+// the same in two steps: final bytes / record offset now, the store later (k_materialise keeps one chunk per lane pending so
+// that the store is issued behind the next tile's loads and never sits in front of a load the wave waits for)
+struct PendingChunk { uint64_t lo, hi, qlo, qhi; uint32_t o0, count; };
+__device__ __forceinline__ PendingChunk prep_chunk(const ReadOut &ro, uint32_t q0, uint32_t count, uint64_t lo, uint64_t hi,
+                                                   uint64_t qlo, uint64_t qhi) {
+    PendingChunk p; p.count = count; p.o0 = q0;
+    if (ro.reversed) {
+        lo = complement8(lo); hi = complement8(hi);
+        reverse_bytes(lo, hi, count);
+        p.o0 = ro.seq_len - q0 - count;
+    }
+    p.lo = lo; p.hi = hi; p.qlo = 0; p.qhi = 0;
+    if (ro.qual) {
+        qlo += 0x2121212121212121ull; qhi += 0x2121212121212121ull;         // chr(q + 33), S:1441
+        if (ro.reversed) reverse_bytes(qlo, qhi, count);
+        p.qlo = qlo; p.qhi = qhi;
+    }
+    return p;
+}
+__device__ __forceinline__ void flush_chunk(const ReadOut &ro, PendingChunk &p) {
+    if (!p.count) return;
+    store16(ro.seq + p.o0, p.count, p.lo, p.hi);
+    if (ro.qual) store16(ro.qual + p.o0, p.count, p.qlo, p.qhi);
+    p.count = 0;
+}
 __device__ __forceinline__ void put_byte(uint64_t &lo, uint64_t &hi, uint32_t i, uint32_t b) {
     if (i < 8) lo |= (uint64_t)b << (8 * i); else hi |= (uint64_t)b << (8 * (i - 8));
 }
@@ -283,6 +308,7 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
     const uint32_t phi = ro.reversed ? ((uint32_t)(uintptr_t)ro.seq + ro.seq_len - pq) & 15u : (0u - ((uint32_t)(uintptr_t)ro.seq + pq)) & 15u;
     ns_event e_pre; e_pre.pos = 0; e_pre.info = 0; uint32_t w_pre = 0;
     if (lane < pc.n_ev) { e_pre = pc.ev[lane]; w_pre = pc.wd[lane]; }
+    PendingChunk pend; pend.count = 0; pend.o0 = 0; pend.lo = pend.hi = pend.qlo = pend.qhi = 0;
     for (uint32_t M0 = 0; M0 < pc.out_len;) {
         const uint32_t A0 = M0 - ((M0 - phi) & 15u);             // aligned origin of the tile (<= M0; may be "negative" = wrapped)
         uint32_t M1 = min(A0 + T_OUT, pc.out_len);
@@ -455,6 +481,7 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             NS_SUBRUN_GATHER(f1, i1)
             NS_SUBRUN_GATHER(f2, i2)
             NS_SUBRUN_GATHER(f3, i3)
+            flush_chunk(ro, pend);                                 // the previous tile's chunk: behind this tile's loads in the queue
             NS_SUBRUN_MERGE(f0, i0)
             NS_SUBRUN_MERGE(f1, i1)
             NS_SUBRUN_MERGE(f2, i2)
@@ -505,10 +532,11 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
                 if (sh < 64) { lo = (lo >> sh) | (hi << (64 - sh)); hi >>= sh; qlo = (qlo >> sh) | (qhi << (64 - sh)); qhi >>= sh; }
                 else { lo = hi >> (sh - 64); hi = 0; qlo = qhi >> (sh - 64); qhi = 0; }
             }
-            if (!(dbg & 16)) store_chunk(ro, pq + lo_m, count, lo, hi, qlo, qhi);
-        }
+            if (!(dbg & 16)) pend = prep_chunk(ro, pq + lo_m, count, lo, hi, qlo, qhi);
+        } else flush_chunk(ro, pend);
 
         jb = jb_next; M0 = M1;
         wave_sync();
     }
+    flush_chunk(ro, pend);
 }
