@@ -487,14 +487,13 @@ __global__ void __launch_bounds__(64, NS_MAT_WAVES) k_materialise(GenArgs A, con
     if (!load_read_uniform(A, r, FASTQ, rd, key, ro)) return;
     const uint32_t a = rd.attempts;
     tile_lds_init(T, lane);
-    if (!(dbg & 8)) emit_random_region(A.m, ro, key, a, ST_HEAD, 0, rd.head, 0, lane);                                   // S:1426
+    if (!(dbg & 8)) emit_head_tail(A.m, ro, key, a, rd.head, rd.tail, lane);                                             // S:1426-1427
     uint32_t q = rd.head;
     for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
         const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi, ev_word);
         materialise_piece(A.m, A.ref, T, ro, key, a, pc, q, lane, ev_word, dbg, sq, (uint32_t)r, pi);
         q += pc.out_len;
     }
-    if (!(dbg & 8)) emit_random_region(A.m, ro, key, a, ST_TAIL, rd.seq_len - rd.tail, rd.tail, rd.head, lane);          // S:1427
 }
 
 // the tiles k_materialise could not take: generic per-byte path, one wavefront per queued tile

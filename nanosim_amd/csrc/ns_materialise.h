@@ -106,8 +106,17 @@ __device__ __forceinline__ PendingChunk prep_chunk(const ReadOut &ro, uint32_t q
                                                    uint64_t qlo, uint64_t qhi) {
     PendingChunk p; p.count = count; p.o0 = q0;
     if (ro.reversed) {
-        lo = complement8(lo); hi = complement8(hi);
-        reverse_bytes(lo, hi, count);
+        if (count == 16) {              // full group: complement through a byte-permute look-up (A 1, C 3, T 4, G 7 after & 7), then reverse
+            const uint32_t w0 = (uint32_t)lo, w1 = (uint32_t)(lo >> 32), w2 = (uint32_t)hi, w3 = (uint32_t)(hi >> 32);
+            const uint32_t c0 = __builtin_amdgcn_perm(0x43000041u, 0x47005400u, w0 & 0x07070707u), c1 = __builtin_amdgcn_perm(0x43000041u, 0x47005400u, w1 & 0x07070707u);
+            const uint32_t c2 = __builtin_amdgcn_perm(0x43000041u, 0x47005400u, w2 & 0x07070707u), c3 = __builtin_amdgcn_perm(0x43000041u, 0x47005400u, w3 & 0x07070707u);
+            const uint32_t r0 = __builtin_amdgcn_perm(0u, c3, 0x00010203u), r1 = __builtin_amdgcn_perm(0u, c2, 0x00010203u);
+            const uint32_t r2 = __builtin_amdgcn_perm(0u, c1, 0x00010203u), r3 = __builtin_amdgcn_perm(0u, c0, 0x00010203u);
+            lo = (uint64_t)r0 | (uint64_t)r1 << 32; hi = (uint64_t)r2 | (uint64_t)r3 << 32;
+        } else {
+            lo = complement8(lo); hi = complement8(hi);
+            reverse_bytes(lo, hi, count);
+        }
         p.o0 = ro.seq_len - q0 - count;
     }
     p.lo = lo; p.hi = hi; p.qlo = 0; p.qhi = 0;
@@ -139,10 +148,14 @@ __device__ __forceinline__ uint32_t qual_draw(QualDraw &qd, const DevModel &m, i
     return qual_value(m.qual_thr + cls * NS_QUAL_LEVELS, h);
 }
 
-// head / tail: uniform bases (S:1426-1427) + 'ht' qualities (S:1421-1423).  One Philox block per 64 letters.
-__device__ inline void emit_random_region(const DevModel &m, const ReadOut &ro, const ns_key &key, uint32_t a,
-                                          uint32_t stream, uint32_t q_start, uint32_t len, uint32_t hq_off, uint32_t lane) {
-    for (uint32_t i0 = lane * 16; i0 < len; i0 += 64 * 16) {
+// head / tail: uniform bases (S:1426-1427) + 'ht' qualities (S:1421-1423).  One Philox block per 64 letters.  Both regions in
+// one pass: lanes 0..31 take 16-letter groups of the head, lanes 32..63 of the tail (one Philox evaluation for the wavefront).
+__device__ inline void emit_head_tail(const DevModel &m, const ReadOut &ro, const ns_key &key, uint32_t a, uint32_t head, uint32_t tail,
+                                      uint32_t lane) {
+    const bool is_tail = lane >= 32;
+    const uint32_t len = is_tail ? tail : head, stream = is_tail ? ST_TAIL : ST_HEAD;
+    const uint32_t q_start = is_tail ? ro.seq_len - tail : 0u, hq_off = is_tail ? head : 0u;
+    for (uint32_t i0 = (lane & 31u) * 16; i0 < len; i0 += 32 * 16) {
         const uint32_t count = min(16u, len - i0);
         u32x4 w = ns_draw(key, stream, 0, a, i0 >> 6, 0);
         const uint32_t word = ns_word(w, (i0 >> 4) & 3);
