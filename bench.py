@@ -143,11 +143,15 @@ def main():
         # collected from inside this process; the per-read figure measured by scripts/profile_round.sh is committed in
         # profiles/r01/pmc_summary.json and scaled to this launch size.  null when that file has no entry for the kernel.
         traffic = None
+        stage = {"k_materialise": ("k_words", "k_materialise")}.get(dom, (dom,))     # kernels behind the timed stage
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")))
+            tot = 0.0
             for kname, kv in pm["kernels"].items():
-                if kname.startswith(dom.split("<")[0]) and "hbm_bytes_per_read" in kv and not a.fastq:
-                    traffic = kv["hbm_bytes_per_read"] * n
+                if kname.startswith(stage) and "hbm_bytes_per_read" in kv:
+                    tot += kv["hbm_bytes_per_read"]
+            if tot > 0 and not a.fastq:
+                traffic = tot * n
         except (OSError, ValueError, KeyError):
             traffic = None
         out = {
@@ -161,7 +165,7 @@ def main():
                        "reads_per_step_per_gpu": n, "errlog": bool(a.errlog), "seed": SEED,
                        "parallelism": "read-index sharding x%d, 1 RCCL broadcast of the reference" % world},
             "device_ms_per_step": device_ms, "kernel_ms": kms,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": dom + (" (stage: k_words + k_materialise + k_materialise_slow)" if dom == "k_materialise" else ""), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/r01/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, per read x reads per launch)",
                          "algorithmic_bytes_per_launch": float(per_launch),
