@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step")
+    ap.add_argument("--engines", type=int, default=int(os.environ.get("NS_BENCH_ENGINES", "1")),
+                    help="engine contexts per GPU, each driven by its own host thread: the Markov-chain stage of one batch "
+                         "overlaps the record stage of another")
     ap.add_argument("--fastq", action="store_true")
     ap.add_argument("--errlog", action="store_true", help="also format the error profile on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -81,7 +84,8 @@ def main():
     names = ["ecoli-like"]
     glen = synth.ECOLI_LEN
     ref_meta = model.Reference(names, np.zeros(0, np.uint8), np.array([0, glen], dtype=np.uint64), np.array([1], dtype=np.uint8))
-    eng = engine.Engine(local_rank)
+    engs = [engine.Engine(local_rank) for _ in range(max(1, a.engines))]
+    eng = engs[0]
     if world > 1:
         # the reference lives on rank 0; ONE broadcast over xGMI puts it in every GPU's HBM
         bdev = "cuda" if a.dist_backend == "nccl" else "cpu"
@@ -92,29 +96,45 @@ def main():
         dist.broadcast(buf, src=0)
         buf = buf.cuda()
         torch.cuda.synchronize()
-        eng.set_reference_device(buf.data_ptr(), ref_meta)
+        for e in engs:
+            e.set_reference_device(buf.data_ptr(), ref_meta)
         ref_host = None
     else:
         seq = synth.synth_sequence(glen, SEED, n_frac=0.0005, iupac_frac=0.0002, lower_frac=0.02, hp_boost=0.005)
         ref_host = model.Reference(names, seq, ref_meta.chrom_off, ref_meta.circular)
-        eng.set_reference(ref_host)
-    eng.load_model(mdl)
+        for e in engs:
+            e.set_reference(ref_host)
+    for e in engs:
+        e.load_model(mdl)
 
     n = a.reads
-    def step(i):
+    def step(i, e=None):
         p = engine.make_params(seed=SEED, first_read=(i * world + rank) * n, n_reads=n, fastq=a.fastq,
                                max_len=glen, emit_errlog=a.errlog)
-        return eng.generate(p)
+        return (e or eng).generate(p)
 
-    for i in range(a.warmup):
-        step(i)
+    def run_steps(first, count):
+        """`count` steps; with several engines, engine k takes steps k, k + E, ... in its own host thread (the C call releases the GIL)"""
+        if len(engs) == 1:
+            return [step(first + i).info for i in range(count)]
+        import threading
+        infos = [None] * count
+        def work(k):
+            for i in range(k, count, len(engs)):
+                infos[i] = step(first + i, engs[k]).info
+        th = [threading.Thread(target=work, args=(k,)) for k in range(len(engs))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return infos
+
+    run_steps(0, a.warmup)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    infos = []
-    for i in range(a.steps):
-        infos.append(step(a.warmup + i).info)
+    infos = run_steps(a.warmup, a.steps)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -163,7 +183,7 @@ def main():
             "config": {"workload": "configs[1]: ecoli_like 4,641,652 bp circular, hg002_like error model, genome mode, "
                                    "%s, %d reads/GPU/step" % ("FASTQ" if a.fastq else "FASTA", n),
                        "reads_per_step_per_gpu": n, "errlog": bool(a.errlog), "seed": SEED,
-                       "parallelism": "read-index sharding x%d, 1 RCCL broadcast of the reference" % world},
+                       "parallelism": "read-index sharding x%d, 1 RCCL broadcast of the reference" % world, "engines_per_gpu": len(engs)},
             "device_ms_per_step": device_ms, "kernel_ms": kms,
             "roofline": {"bound": "hbm", "kernel": dom + (" (stage: k_words + k_materialise + k_materialise_slow)" if dom == "k_materialise" else ""), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -174,7 +194,8 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(mdl, ref_host, engine, a.cpu_sample)
         print(json.dumps(out))
-    eng.close()
+    for e in engs:
+        e.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) k_lengths(GenArgs A) {
     const ns_params &prm = A.prm;
     const int kind = (int)prm.kind;
     const ns_key key = make_key(prm, r);
-    const bool meta_al = A.meta && kind == NS_KIND_ALIGNED;      // r is then the position of the read inside pass A.attempt
+    const bool meta_al = A.meta && kind != NS_KIND_UNALIGNED;    // r is then the position of the read inside pass A.attempt
     const uint32_t a = meta_al ? A.attempt : A.att_base[r] + A.attempt;
     const uint32_t epoch = meta_al ? 0u : A.rstate[r] & 0xffffu;
     const uint32_t piece_off = A.piece_off[r];
@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
     if (tid < A.list_n) {
         const uint64_t r = A.list ? A.list[tid] : tid;
         const int kind = (int)prm.kind;
-        const bool meta_al = A.meta && kind == NS_KIND_ALIGNED;
+        const bool meta_al = A.meta && kind != NS_KIND_UNALIGNED;
         const ns_key key = make_key(prm, r);
         const uint32_t a = meta_al ? A.attempt : A.att_base[r] + A.attempt;
         ns_read rd = A.reads[r];
@@ -373,7 +373,8 @@ __global__ void __launch_bounds__(256) k_meta_commit(GenArgs A) {
         dst[pi] = p;
         if (!p.kind) {
             rows += p.n_ev;
-            atomicAdd(&A.species_bases[A.m_species[A.m_segptr[i] + (pi >> 1)]], (unsigned long long)p.ref_len);   // S:1001-1002
+            if (A.prm.kind == NS_KIND_ALIGNED)                         // S:1001-1002 (the --perfect branch never updates the quotas)
+                atomicAdd(&A.species_bases[A.m_species[A.m_segptr[i] + (pi >> 1)]], (unsigned long long)p.ref_len);
         }
     }
     rd.piece_off = poff;
@@ -1293,7 +1294,8 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
     P.m_segptr = (const uint32_t *)ctx->m_segptr.p; P.m_len = (const int32_t *)ctx->m_len.p; P.m_species = (const uint16_t *)ctx->m_species.p;
     P.list = nullptr;
     P.cap_rate = ctx->cap_rate;
-    const bool lds = ctx->lds_tables;
+    const bool lds = ctx->lds_tables && prm->kind != NS_KIND_PERFECT;
+    const bool perfect = prm->kind == NS_KIND_PERFECT;      // S:838-842, 879-910: no errors, no head/tail, the quotas are never updated
     const ns_key bkey{(uint32_t)prm->seed, (uint32_t)(prm->seed >> 32), (uint32_t)prm->first_read, (uint32_t)(prm->first_read >> 32)};
     std::vector<double> cur_bases(ns, 0.0), draws, lens;
     std::vector<unsigned long long> sb(ns);
@@ -1319,7 +1321,8 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
         HIPCHK(hipMemcpyAsync(draws.data(), P.draw_x, D * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         lens.clear();
-        for (double x : draws) if (0 < x && x <= (double)prm->max_len) lens.push_back(x);      // S:857
+        for (double x : draws)                                                     // S:857 (--perfect: S:841)
+            if (perfect ? ((double)prm->min_len <= x && x <= (double)prm->max_len) : (0 < x && x <= (double)prm->max_len)) lens.push_back(x);
         if (lens.empty()) continue;                                                // S:858-859
         const uint64_t P_seg = assign_species_host(ctx, prm, p, lens, segs, cur_bases, species);   // S:866-867
         P.m_reversed = u32_to_p(ns_draw(bkey, ST_STRAND, 0, p, 0, 0).x) > ctx->m.strandness_rate ? 1u : 0u;   // S:860
@@ -1380,7 +1383,7 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
         HIPCHK(hipMemcpyAsync(&acc, P.accept_scan + np, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(sb.data(), ctx->species_bases.p, (size_t)ns * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        for (uint32_t s = 0; s < ns; ++s) cur_bases[s] = (double)sb[s];
+        for (uint32_t s = 0; s < ns && !perfect; ++s) cur_bases[s] = (double)sb[s];
         passed += acc & 0xffffffffull; pieces_passed += acc >> 32;
         ev_base += pass_cap;
     }
@@ -1408,10 +1411,11 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     if (prm->chimeric && !(ctx->m.flags & NS_MODEL_HAS_CHIMERIC)) return fail(ctx, NS_EINVAL, "model has no chimeric tables");
     const bool hp_on = prm->kmer_bias && prm->kind == NS_KIND_ALIGNED;      // S:1413: only aligned segments; --perfect never
     if (hp_on && !(ctx->m.flags & NS_MODEL_HAS_HP)) return fail(ctx, NS_EINVAL, "-k needs the homopolymer model (-hp)");
-    const bool meta_al = prm->meta && prm->kind == NS_KIND_ALIGNED;
+    const bool meta_al = prm->meta && prm->kind != NS_KIND_UNALIGNED;       // aligned or --perfect worker of simulation_aligned_metagenome
     if (prm->meta) {
         if (!ctx->nspecies) return fail(ctx, NS_ESTATE, "metagenome batch before ns_set_species");
-        if (prm->kind == NS_KIND_PERFECT || prm->kmer_bias) return fail(ctx, NS_EINVAL, "metagenome batches support neither --perfect nor -k");
+        if (prm->kmer_bias) return fail(ctx, NS_EINVAL, "metagenome batches do not support -k");
+        if (prm->kind == NS_KIND_PERFECT && prm->chimeric) return fail(ctx, NS_EINVAL, "perfect reads cannot be chimeric");
         if (meta_al && prm->use_lognormal) return fail(ctx, NS_EINVAL, "metagenome batches draw read lengths from the model (no -med/-sd)");
         if (meta_al && !ctx->has_abun) return fail(ctx, NS_ESTATE, "metagenome batch before ns_set_abundance");
         if (meta_al && prm->chimeric && !ctx->has_inflated) return fail(ctx, NS_EINVAL, "chimeric metagenome batch needs abun_inflated");

@@ -264,9 +264,9 @@ def run_metagenome(a, parser_mg):
     one worker of the reference: it keeps its own per-species base quota (S:835) and numbers its reads consecutively."""
     from . import metagenome as MG
     validate_genome_args(a, parser_mg)
-    if a.perfect or a.homopolymer or a.KmerBias or (a.median_len and a.sd_len):
-        sys.stderr.write("\nmetagenome mode of this build simulates model-length reads with errors; --perfect, -hp/-k and "
-                         "-med/-sd are not available here yet (DESIGN.md section 5.7)\n")
+    if a.homopolymer or a.KmerBias or (a.median_len and a.sd_len):
+        sys.stderr.write("\nmetagenome mode of this build simulates model-length reads; -hp/-k and -med/-sd are not available "
+                         "here yet (DESIGN.md section 5.7)\n")
         sys.exit(2)
     rank, local_rank, world = shard.env_rank_world()
     dist = None
@@ -305,8 +305,8 @@ def run_metagenome(a, parser_mg):
     else:
         eng.set_metagenome(mref)
     if rank == 0:
-        log("Read error profile")
-    mdl = M.load_model(a.model_prefix, strandness=a.strandness, chimeric=a.chimeric, fastq=a.fastq)
+        log("Read error profile" if not a.perfect else "Read KDF of aligned reads")
+    mdl = M.load_model(a.model_prefix, perfect=a.perfect, strandness=a.strandness, chimeric=a.chimeric, fastq=a.fastq)
     eng.load_model(mdl)
     seed = a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little") >> 1
     if dist is not None and a.seed is None:
@@ -332,22 +332,24 @@ def run_metagenome(a, parser_mg):
         base = out + "_" + sample
         lo, hi = shard.partition(n_al, world)[rank]
         _write_batches(eng, base + "_aligned_reads%d%s" % (rank, ext), base + "_error_profile%d" % rank, seed=seed, first=first + lo,
-                       count=hi - lo, kind=E.NS_KIND_ALIGNED, fastq=a.fastq, chimeric=a.chimeric, min_len=a.min_len, max_len=max_len,
-                       median_len=None, sd_len=None, want_errlog=True, meta=True)
+                       count=hi - lo, kind=E.NS_KIND_PERFECT if a.perfect else E.NS_KIND_ALIGNED, fastq=a.fastq, chimeric=a.chimeric,
+                       min_len=a.min_len, max_len=max_len, median_len=None, sd_len=None, want_errlog=True, meta=True)
         if dist is not None:
             dist.barrier()
         if rank == 0:
             shard.merge_subfiles(base + "_aligned_reads" + ext, [base + "_aligned_reads%d%s" % (r, ext) for r in range(world)])
             shard.merge_subfiles(base + "_aligned_error_profile", [base + "_error_profile%d" % r for r in range(world)], ERR_HEADER)
-            log("Start simulation of random reads")
-        lo, hi = shard.partition(n_un, world)[rank]
-        _write_batches(eng, base + "_unaligned_reads%d%s" % (rank, ext), None, seed=seed, first=first + n_al + lo, count=hi - lo,
-                       kind=E.NS_KIND_UNALIGNED, fastq=a.fastq, chimeric=False, min_len=a.min_len, max_len=max_len, median_len=None,
-                       sd_len=None, want_errlog=False, meta=True)
-        if dist is not None:
-            dist.barrier()
-        if rank == 0:
-            shard.merge_subfiles(base + "_unaligned_reads" + ext, [base + "_unaligned_reads%d%s" % (r, ext) for r in range(world)])
+        if not a.perfect:                                                                   # S:1642
+            if rank == 0:
+                log("Start simulation of random reads")
+            lo, hi = shard.partition(n_un, world)[rank]
+            _write_batches(eng, base + "_unaligned_reads%d%s" % (rank, ext), None, seed=seed, first=first + n_al + lo, count=hi - lo,
+                           kind=E.NS_KIND_UNALIGNED, fastq=a.fastq, chimeric=False, min_len=a.min_len, max_len=max_len, median_len=None,
+                           sd_len=None, want_errlog=False, meta=True)
+            if dist is not None:
+                dist.barrier()
+            if rank == 0:
+                shard.merge_subfiles(base + "_unaligned_reads" + ext, [base + "_unaligned_reads%d%s" % (r, ext) for r in range(world)])
         first += n_al + n_un            # samples draw from disjoint read-index ranges of the same seed
     eng.close()
     if dist is not None:

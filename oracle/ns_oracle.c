@@ -816,7 +816,7 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
             double x = prm->use_lognormal ? nso_exp(fma(prm->sd_len, nso_norminv(u32_to_p(w[2])), nso_log(prm->median_len)))
                                           : kde_sample(&t->kde[NS_KDE_UNALIGNED], w);
             ref_len[0] = (int64_t)x;
-        } else if (mr && kind == NS_KIND_ALIGNED) {                       /* S:871-872 */
+        } else if (mr) {                                                  /* S:871-872 (aligned and --perfect) */
             for (uint32_t s = 0; s < nseg; ++s) ref_len[s] = mr->ref_len[s];
             for (uint32_t g = 0; g + 1 < nseg; ++g) {
                 philox_at(&d, ST_GAPLEN, g, a, 0, 0, w);
@@ -871,7 +871,7 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
         }
         philox_at(&d, ST_STRAND, 0, a, 0, 0, w);
         reversed = u32_to_p(w[0]) > t->strandness_rate;                   /* S:1312, S:1524-1525 */
-        if (mr && kind == NS_KIND_ALIGNED) reversed = (int)mr->reversed;   /* S:860: one draw per pass */
+        if (mr) reversed = (int)mr->reversed;                               /* S:860: one draw per pass */
         if (!ok) { ++epoch; fails = 0; continue; }
 
         /* ---- error lists ---- */
@@ -902,7 +902,7 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
             if (kind == NS_KIND_UNALIGNED) total = r.middle_ref;            /* S:1503 */
         }
         if (overflow) return -11;
-        if (mr && kind == NS_KIND_ALIGNED) {                                /* S:907-946: middle_ref and gap lengths count */
+        if (mr) {                                                           /* S:907-946: middle_ref and gap lengths count; --perfect: S:896-897 */
             int64_t tot = remainder; int restart = 0;
             for (uint32_t pi = 0; pi < n_pieces && !restart; pi += 2) { if (tot + pc[pi].ref_len > prm->max_len) restart = 1; else tot += pc[pi].ref_len; }
             for (uint32_t pi = 1; pi < n_pieces && !restart; pi += 2) { if (tot + pc[pi].out_len > prm->max_len) restart = 1; else tot += pc[pi].out_len; }
@@ -1194,7 +1194,8 @@ int nso_generate_meta(const ns_model_tables *t, const uint8_t *bases, const uint
         free((void *)names);
         return rc;
     }
-    if (prm->kind != NS_KIND_ALIGNED || prm->use_lognormal) { free((void *)names); return -30; }
+    if (prm->use_lognormal) { free((void *)names); return -30; }
+    const int perfect = prm->kind == NS_KIND_PERFECT;                    /* S:838-842, 879-910: no errors, no head/tail, quotas never updated */
     int32_t *nseg_orig = (int32_t *)malloc(sizeof(int32_t) * (n + 1));
     for (uint64_t j = 0; j < n; ++j) {                    /* num_segment, S:825-828 */
         nseg_orig[j] = 1;
@@ -1220,7 +1221,7 @@ int nso_generate_meta(const ns_model_tables *t, const uint8_t *bases, const uint
             uint32_t w[4];
             philox_at(&db, ST_REFLEN, 0, p, (uint32_t)j, (uint32_t)(j >> 32), w);
             double x = kde_sample(&t->kde[NS_KDE_ALIGNED], w);
-            if (0 < x && x <= (double)prm->max_len) lens[V++] = x;
+            if (perfect ? ((double)prm->min_len <= x && x <= (double)prm->max_len) : (0 < x && x <= (double)prm->max_len)) lens[V++] = x;   /* S:841 / S:857 */
         }
         if (V == 0) { free(lens); continue; }                                          /* S:858-859 */
         uint16_t *species = (uint16_t *)malloc(sizeof(uint16_t) * (V + 1));
@@ -1242,7 +1243,7 @@ int nso_generate_meta(const ns_model_tables *t, const uint8_t *bases, const uint
             int r1 = gen_read(t, &ref, prm, i, o, &mr, mg);
             if (r1 < 0) rc = r1;
             else if (r1 == 0) {
-                for (uint32_t s2 = 0; s2 < ns; ++s2)                                  /* S:1001-1002 */
+                for (uint32_t s2 = 0; s2 < ns && !perfect; ++s2)                      /* S:1001-1002 (only in the branch with errors) */
                     cur_bases[species[seg_ptr + s2]] += (double)o->pieces[piece0 + 2 * s2].ref_len;
                 ++accepted;
             }

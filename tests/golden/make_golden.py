@@ -401,12 +401,12 @@ def build_meta_inputs():
         f.write("Size\t3000\t500\nAlpha one\t50\t10\nBeta two\t30\t60\nGamma three\t20\t30\n")
 
 
-def _meta_profile(S, prefix, chimeric, fastq=False):
+def _meta_profile(S, prefix, chimeric, fastq=False, perfect=False):
     os.chdir(ROOT)
     so = sys.stdout
     sys.stdout = open(os.devnull, "w")
     try:
-        S.read_profile(os.path.join(META_DIR, "genome_list.tsv"), [], prefix, False, "metagenome", None,
+        S.read_profile(os.path.join(META_DIR, "genome_list.tsv"), [], prefix, perfect, "metagenome", None,
                        dna_type=os.path.join(META_DIR, "dna_type_list.tsv"), abun=os.path.join(META_DIR, "abundance.tsv"),
                        chimeric=chimeric, homopolymer=False, fastq=fastq)
     finally:
@@ -510,6 +510,60 @@ def _meta_worker(args):
         un_sp[sp_of(nm)] = un_sp.get(sp_of(nm), 0) + 1
     return dict(names=names[:6], lens=lens, bases=bases, strands=strands, n_chim=n_chim, n=len(names), un_species=un_sp,
                 un_names=un[:3])
+
+
+def _meta_perfect_worker(args):
+    idx, n_al, prefix, workdir = args
+    S = import_reference()
+    _meta_profile(S, prefix, False, perfect=True)
+    S.dict_abun = S.multi_dict_abun["sample0"]
+    S.dict_abun_inflated = {}
+    S.total_simulated = mp.Value("i", 0, lock=True)
+    random.seed(7000 + idx); np.random.seed(7000 + idx)
+    o_reads = os.path.join(workdir, "mp%d.fasta" % idx); o_err = os.path.join(workdir, "mpe%d" % idx)
+    max_l = max(S.max_chrom.values())
+    so = sys.stdout; se = sys.stderr
+    sys.stdout = open(os.devnull, "w"); sys.stderr = open(os.devnull, "w")
+    try:
+        S.simulation_aligned_metagenome(50, max_l, None, None, o_reads, o_err, None, False, n_al, True, False)
+    finally:
+        sys.stdout = so; sys.stderr = se
+    lines = open(o_reads).read().split("\n")
+    names = [x[1:] for x in lines[0:-1:2]]
+    seqs = lines[1:-1:2]
+    species = list(S.seq_len.keys())
+    bases = {}
+    for nm, sq in zip(names, seqs):
+        sp = [x for x in species if nm.startswith(x + "-")][0]
+        f = nm.partition("_perfect_")[2].split("_")
+        assert f[2] == "0" and f[4] == "0" and int(f[3]) == len(sq)
+        bases[sp] = bases.get(sp, 0) + len(sq)
+    # the read is the reference substring (or its reverse complement)
+    nm, sq = names[0], seqs[0]
+    sp = [x for x in species if nm.startswith(x + "-")][0]
+    chrom, pos = nm[len(sp) + 1:].partition("_perfect_")[0].rsplit("_", 1)
+    src = S.seq_dict[sp][chrom]
+    seg = (src + src)[int(pos):int(pos) + len(sq)].upper()
+    strand = nm.partition("_perfect_")[2].split("_")[1]
+    fwd = sq if strand == "F" else S.reverse_complement(sq)
+    assert len(fwd) == len(seg) and all(a == b for a, b in zip(seg, fwd) if a in "ACGT"), "perfect read is not the reference substring"
+    return dict(names=names[:5], lens=[len(x) for x in seqs], bases=bases, n=len(names),
+                strands=sorted(set(n.partition("_perfect_")[2].split("_")[1] for n in names)),
+                indices=[int(n.partition("_perfect_")[2].split("_")[0]) for n in names[:50]])
+
+
+def fixture_metagenome_perfect(prefix, workdir, n_reads=8000):
+    n_proc = min(8, os.cpu_count() or 1)
+    with mp.get_context("fork").Pool(n_proc) as pool:
+        res = pool.map(_meta_perfect_worker, [(i, n_reads // n_proc, prefix, workdir) for i in range(n_proc)])
+    bases = {}
+    for r in res:
+        for sp, b in r["bases"].items():
+            bases[sp] = bases.get(sp, 0) + b
+    all_lens = np.concatenate([r["lens"] for r in res])
+    return dict(bases=bases, q_len=quantiles(all_lens), mean_len=float(all_lens.mean()),
+                workers=[dict(strands=r["strands"], n=r["n"], first_names=r["names"], indices=r["indices"],
+                              sorted_desc_frac=float(np.mean(np.diff(r["lens"]) <= 0))) for r in res])
 
 
 def fixture_metagenome_runs(prefix, workdir, n_reads=24000):
@@ -625,10 +679,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dist-reads", type=int, default=100000)
     ap.add_argument("--skip-dist", action="store_true")
+    ap.add_argument("--only-meta-perfect", action="store_true", help="add runs.perfect to reference_metagenome.json, keep the rest")
     a = ap.parse_args()
     workdir = tempfile.mkdtemp(prefix="nsgolden_")
     try:
         prefix, fasta, circ = build_inputs(workdir)
+        if a.only_meta_perfect:
+            mg = json.load(open(os.path.join(HERE, "reference_metagenome.json")))
+            mg["runs"]["perfect"] = fixture_metagenome_perfect(prefix, workdir)
+            with open(os.path.join(HERE, "reference_metagenome.json"), "w") as f:
+                json.dump(mg, f)
+            print("runs.perfect written")
+            return
         S = import_reference()
         so = sys.stdout
         sys.stdout = open(os.devnull, "w")
@@ -656,6 +718,7 @@ def main():
         mg = fixture_metagenome(import_reference(), prefix)
         if not a.skip_dist:
             mg["runs"] = fixture_metagenome_runs(prefix, workdir)
+            mg["runs"]["perfect"] = fixture_metagenome_perfect(prefix, workdir)
         elif os.path.exists(os.path.join(HERE, "reference_metagenome.json")):
             mg["runs"] = json.load(open(os.path.join(HERE, "reference_metagenome.json"))).get("runs")
         with open(os.path.join(HERE, "reference_metagenome.json"), "w") as f:

@@ -50,6 +50,8 @@ CASES = [
     dict(n_reads=250, emit_records=False),
     dict(n_reads=200, kind=E.NS_KIND_UNALIGNED, fastq=True),
     dict(n_reads=150, kind=E.NS_KIND_UNALIGNED, median_len=900, sd_len=0.4),
+    dict(n_reads=300, kind=E.NS_KIND_PERFECT),                             # --perfect worker: no errors, quotas never updated
+    dict(n_reads=200, kind=E.NS_KIND_PERFECT, fastq=True, min_len=4000, max_len=12000),
 ]
 
 
@@ -59,11 +61,19 @@ def test_gpu_metagenome_equals_oracle(setup, small_model, meta_ref, case):
     kw = dict(seed=0xFEED5EED77, first_read=0, max_len=meta_ref.max_chrom, meta=True)
     kw.update(case)
     p = E.make_params(**kw)
-    b = eng.generate(p)
-    exp = O.generate_meta(small_model, meta_ref, abun, infl if p.chimeric else None, p)
-    compare(b, exp, p)
-    if p.kind == E.NS_KIND_ALIGNED:
-        assert np.array_equal(eng.species_bases(), exp["species_bases"])
+    mdl = small_model
+    if p.kind == E.NS_KIND_PERFECT:          # the KDE of whole aligned reads replaces the aligned-region one (S:473-476)
+        mdl = M.load_model(os.path.join(ROOT, "tests", "golden", "model_small", "training"), perfect=True, fastq=True)
+        eng.load_model(mdl)
+    try:
+        b = eng.generate(p)
+        exp = O.generate_meta(mdl, meta_ref, abun, infl if p.chimeric else None, p)
+        compare(b, exp, p)
+        if p.kind != E.NS_KIND_UNALIGNED:
+            assert np.array_equal(eng.species_bases(), exp["species_bases"])
+    finally:
+        if mdl is not small_model:
+            eng.load_model(small_model)
 
 
 def test_metagenome_batches_are_reproducible(setup, meta_ref):
@@ -81,7 +91,7 @@ def test_metagenome_error_paths(small_model, small_ref, meta_ref, setup):
     with pytest.raises(E.EngineError):
         eng.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=9000, meta=True, kmer_bias=5))
     with pytest.raises(E.EngineError):
-        eng.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=9000, meta=True, kind=E.NS_KIND_PERFECT))
+        eng.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=9000, meta=True, kind=E.NS_KIND_PERFECT, chimeric=True))
     with pytest.raises(E.EngineError):
         eng.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=9000, meta=True, median_len=3000, sd_len=0.3))
     e2 = E.Engine(0)

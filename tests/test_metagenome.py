@@ -152,3 +152,39 @@ def test_oracle_metagenome_batches_match_reference_runs(fx, meta_ref, chimeric):
         assert n_chim == 0
     # S:860: the strand is drawn once per pass, so workers that finish in one pass have a single strand
     assert strands_single >= 1 or sum(len(wk["strands"]) == 1 for wk in run["workers"]) == 0
+
+
+def test_oracle_perfect_metagenome_batches_match_reference_runs(fx, meta_ref):
+    """--perfect workers (S:838-842, 879-910): species base fractions, read lengths, one strand per pass, descending lengths,
+    consecutive numbering, quotas that are never updated."""
+    from nanosim_amd import engine as E
+    from tests import oracle_lib as O
+    from tests.test_distributions import ks_vs_quantiles
+    run = fx["runs"]["perfect"]
+    mdl = M.load_model(os.path.join(ROOT, "tests", "golden", "model_small", "training"), perfect=True)
+    abun = fx["abun"]["sample0"]
+    bases = np.zeros(len(meta_ref.species))
+    lens = []
+    for w in range(8):
+        p = E.make_params(seed=300 + w, first_read=w * 1000, n_reads=1000, kind=E.NS_KIND_PERFECT, max_len=meta_ref.max_chrom, meta=True)
+        out = O.generate_meta(mdl, meta_ref, abun, None, p)
+        rd, pc = out["reads"], out["pieces"]
+        assert np.all(pc["n_ev"] == 0) and np.all(rd["head"] == 0) and np.all(rd["tail"] == 0)
+        assert np.all(out["species_bases"] == 0)                              # S:1001-1002 is not reached with --perfect
+        sp = _species_of_piece(meta_ref, pc["chrom"])
+        bases += np.bincount(sp, weights=pc["ref_len"], minlength=len(bases))
+        lens.append(rd["seq_len"])
+        if int(rd["attempts"].max()) == 0:                                    # a single pass: one strand, lengths sorted descending
+            assert len(set(rd["reversed"].tolist())) == 1
+            assert np.all(np.diff(rd["seq_len"].astype(np.int64)) <= 0)
+        names = [x[1:].decode() for x in out["records"].tobytes().split(b"\n")[0:-1:2]]
+        for i, nm in enumerate(names[:50]):
+            f = nm.partition("_perfect_")[2].split("_")
+            assert int(f[0]) == w * 1000 + i and f[2] == "0" and f[4] == "0" and int(f[3]) == rd["seq_len"][i]
+    frac = bases / bases.sum()
+    tot = sum(run["bases"].values())
+    for i, spn in enumerate(meta_ref.species):
+        assert abs(frac[i] - run["bases"][spn] / tot) < 0.005
+    lens = np.concatenate(lens)
+    assert abs(lens.mean() / run["mean_len"] - 1) < 0.02 and ks_vs_quantiles(lens, run["q_len"]) < 0.03
+    assert all(wk["sorted_desc_frac"] == 1.0 and len(wk["strands"]) == 1 and wk["indices"][:3] == [0, 1, 2] for wk in run["workers"])
