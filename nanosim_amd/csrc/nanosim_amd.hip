@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <functional>
 #include <string>
 #include <vector>
@@ -47,6 +48,7 @@ struct GenArgs {
     uint32_t *sort_key, *sort_idx;   // k_plan: total reference length per read, read index
     const uint32_t *list;            // reads this pass visits (pass 0: sorted by descending length)
     uint32_t list_n, attempt;
+    uint32_t list_base;              // list == nullptr: the launch visits reads list_base .. list_base + list_n - 1
     uint32_t *next_list, *next_n;    // reads rejected in this pass
     uint32_t *rstate;                // per read: epoch | consecutive first-check failures << 16
     uint32_t *att_base;              // per read: first attempt number of this run (0 unless the batch is re-run in -k mode)
@@ -219,7 +221,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
     else if (blockIdx.x < (gridDim.x >> 2)) __builtin_amdgcn_s_setprio(1);
     unsigned long long st_over = 0, st_bases = 0, st_ref = 0, st_ev = 0;
     if (tid < A.list_n) {
-        const uint64_t r = A.list ? A.list[tid] : tid;
+        const uint64_t r = A.list ? A.list[tid] : A.list_base + tid;
         const int kind = (int)prm.kind;
         const bool meta_al = A.meta && kind != NS_KIND_UNALIGNED;
         const ns_key key = make_key(prm, r);
@@ -357,6 +359,18 @@ __global__ void __launch_bounds__(256) k_meta_draw(GenArgs A) {
     const ns_key key = make_key(A.prm, 0);
     A.draw_x[j] = kde_sample(A.m.kde[NS_KDE_ALIGNED], ns_draw(key, ST_REFLEN, 0, A.attempt, (uint32_t)j, (uint32_t)(j >> 32)));
 }
+
+// the random.choice / random.uniform words of assign_species for every segment pointer of the pass (S:786-803), keyed by the batch
+__global__ void __launch_bounds__(256) k_meta_words(GenArgs A, uint2 *out, uint64_t n) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const u32x4 w = ns_draw(make_key(A.prm, 0), ST_SPECIES, 0, A.attempt, (uint32_t)j, (uint32_t)(j >> 32));
+    out[j] = make_uint2(w.x, w.y);
+}
+struct MetaLenFilter {           // S:857 (0 < x <= max_l) / S:841 (--perfect: min_l <= x <= max_l)
+    double lo, hi; bool lo_inclusive;
+    __host__ __device__ bool operator()(const double &x) const { return (lo_inclusive ? lo <= x : lo < x) && x <= hi; }
+};
 
 __global__ void __launch_bounds__(256) k_meta_commit(GenArgs A) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -790,6 +804,8 @@ struct ns_ctx {
     // metagenome: species view of the reference, abundances of the sample, per-pass scratch
     DevBuf species_chrom_off, t_reads, t_pieces, t_name_len, t_rec_len, t_err_len, accept, accept_scan, key_pos, draw_x, m_segptr,
         m_len, m_species, species_bases;
+    DevBuf draw_sel, draw_sorted, meta_words, meta_num;
+    struct PinBuf { void *p = nullptr; size_t cap = 0; } pin_a, pin_b, pin_c;     // pinned host staging of the metagenome passes
     uint32_t nspecies = 0;
     bool has_abun = false, has_inflated = false, has_key_pos = false;
     std::vector<double> abun, abun_inflated, last_species_bases;
@@ -816,6 +832,16 @@ static int ensure(ns_ctx *ctx, DevBuf &b, size_t bytes) {
     if (b.p) { hipError_t e = hipFree(b.p); (void)e; b.p = nullptr; b.cap = 0; }
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess) { b.p = nullptr; b.cap = 0; return fail(ctx, NS_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    b.cap = want;
+    return NS_OK;
+}
+
+static int ensure_pin(ns_ctx *ctx, ns_ctx::PinBuf &b, size_t bytes) {
+    if (bytes <= b.cap) return NS_OK;
+    size_t want = bytes + bytes / 8 + 4096;
+    if (b.p) { hipError_t e = hipHostFree(b.p); (void)e; b.p = nullptr; b.cap = 0; }
+    hipError_t e = hipHostMalloc(&b.p, want, hipHostMallocDefault);
+    if (e != hipSuccess) { b.p = nullptr; return fail(ctx, NS_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
     b.cap = want;
     return NS_OK;
 }
@@ -900,7 +926,10 @@ void ns_destroy(ns_ctx *ctx) {
                       &ctx->sort_key_out, &ctx->order, &ctx->list_b, &ctx->rstate, &ctx->att_base, &ctx->scr, &ctx->scrq,
                       &ctx->scr_len, &ctx->scr_off, &ctx->hp_len, &ctx->slow_q, &ctx->ev_word, &ctx->species_chrom_off, &ctx->t_reads, &ctx->t_pieces,
                       &ctx->t_name_len, &ctx->t_rec_len, &ctx->t_err_len, &ctx->accept, &ctx->accept_scan, &ctx->key_pos,
-                      &ctx->draw_x, &ctx->m_segptr, &ctx->m_len, &ctx->m_species, &ctx->species_bases};
+                      &ctx->draw_x, &ctx->m_segptr, &ctx->m_len, &ctx->m_species, &ctx->species_bases, &ctx->draw_sel,
+                      &ctx->draw_sorted, &ctx->meta_words, &ctx->meta_num};
+    for (auto *pb : {&ctx->pin_a, &ctx->pin_b, &ctx->pin_c})
+        if (pb->p) e = hipHostFree(pb->p);
     for (DevBuf *b : bufs)
         if (b->p) e = hipFree(b->p);
     if (ctx->evt_ok)
@@ -1193,25 +1222,24 @@ int ns_species_bases(ns_ctx *ctx, double *out) {
 // assign_species (S:758-811): the species of every segment of a pass, by greedy quota.  lens: the filtered length list of the
 // pass (in draw order); on return the list in assignment order (chimeric segments first, the rest descending).  Draws keyed by
 // the batch: Philox(ST_SPECIES, attempt = pass, idx = segment pointer): word 0 = random.choice, word 1 = random.uniform(0, 100).
-static uint64_t assign_species_host(const ns_ctx *ctx, const ns_params *prm, uint32_t pass, std::vector<double> &lens,
-                                    std::vector<int32_t> &segs, const std::vector<double> &cur_bases, std::vector<uint16_t> &species) {
+// assign_species (S:758-811): the species of every segment of a pass, by greedy quota — a sequential walk, on the host.  `lens`: the
+// filtered length list in assignment order (chimeric segments first in draw order, the rest descending — sorted on the device);
+// `to_add`: sum(length_list) taken left to right over the list in draw order; `words`: the draws of every segment pointer.
+static uint64_t assign_species_host(const ns_ctx *ctx, const double *lens, uint64_t n_len, double to_add, const uint2 *words,
+                                    std::vector<int32_t> &segs, const std::vector<double> &cur_bases, uint16_t *species) {
     const uint32_t ns = ctx->nspecies;
-    const uint64_t n_len = lens.size();
-    uint64_t chim = 0;
-    for (int32_t v : segs) if (v > 1) chim += (uint64_t)v;                       // S:761
-    if (chim > n_len) chim = n_len;
-    double to_add = 0;
-    for (double v : lens) to_add += v;                                           // sum(length_list), in list order
-    std::sort(segs.begin(), segs.end(), std::greater<int32_t>());                // S:760
-    std::sort(lens.begin() + (ptrdiff_t)chim, lens.end(), std::greater<double>());   // S:764-765
+    {                                                                            // S:760: descending counting sort (counts <= NS_MAX_SEG)
+        size_t hist[NS_MAX_SEG + 1] = {0};
+        for (int32_t v : segs) ++hist[v];
+        size_t w = 0;
+        for (int32_t v = (int32_t)NS_MAX_SEG; v >= 1; --v) for (size_t c = 0; c < hist[v]; ++c) segs[w++] = v;
+    }
     double have = 0, abun_total = 0;
     for (uint32_t s = 0; s < ns; ++s) { have += cur_bases[s]; abun_total += ctx->abun[s]; }
     const double all_bases = to_add + have;
     std::vector<double> quota(ns);
     for (uint32_t s = 0; s < ns; ++s) quota[s] = all_bases * ctx->abun[s] / abun_total - cur_bases[s];   // S:772-775
-    const ns_key bkey{(uint32_t)prm->seed, (uint32_t)(prm->seed >> 32), (uint32_t)prm->first_read, (uint32_t)(prm->first_read >> 32)};
     std::vector<uint32_t> cand(ns);
-    species.assign(n_len, 0);
     uint64_t ptr = 0;
     uint32_t prev = 0;
     auto fitting = [&](double len, int skip) {              // species whose quota still holds `len` (S:785-788: else any with quota left)
@@ -1225,9 +1253,9 @@ static uint64_t assign_species_host(const ns_ctx *ctx, const ns_params *prm, uin
         if (ptr + (uint64_t)seg > n_len) break;                                  // S:781-782
         for (int32_t k = 0; k < seg; ++k) {
             const double len = lens[ptr];
-            const u32x4 w = ns_draw(bkey, ST_SPECIES, 0, pass, (uint32_t)ptr, (uint32_t)(ptr >> 32));
+            const uint2 w = words[ptr];                     // Philox(batch, ST_SPECIES, attempt = pass, idx = ptr): .x choice, .y uniform(0, 100)
             auto choose = [&](uint32_t c) { return cand[(uint32_t)(((uint64_t)w.x * c) >> 32)]; };
-            uint32_t sp, c;
+            uint32_t sp = 0, c;
             bool fresh = k == 0;
             if (!fresh) {                                                        // S:791-803: stay with the previous species?
                 c = fitting(len, (int)prev);
@@ -1265,6 +1293,15 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
     HIPCHK(hipEventRecord(ctx->evt[1], st));
     k_nseg<<<dim3((unsigned)((n + 1 + 255) / 256)), blk, 0, st>>>(A);       // num_segment (S:825-828); zeroes the scan sentinels
     HIPCHK(hipGetLastError());
+    const bool trace = getenv("NS_META_TRACE") != nullptr;      // host-side section timing of the passes (stderr)
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto lap = [&](const char *what, std::chrono::steady_clock::time_point &t) {
+        if (!trace) return;
+        auto t2 = now();
+        fprintf(stderr, "[meta] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t2 - t).count());
+        t = t2;
+    };
+    auto tt = now();
     std::vector<uint32_t> npc(n);
     HIPCHK(hipMemcpyAsync(npc.data(), A.n_pieces, n * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -1297,10 +1334,9 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
     const bool lds = ctx->lds_tables && prm->kind != NS_KIND_PERFECT;
     const bool perfect = prm->kind == NS_KIND_PERFECT;      // S:838-842, 879-910: no errors, no head/tail, the quotas are never updated
     const ns_key bkey{(uint32_t)prm->seed, (uint32_t)(prm->seed >> 32), (uint32_t)prm->first_read, (uint32_t)(prm->first_read >> 32)};
-    std::vector<double> cur_bases(ns, 0.0), draws, lens;
+    std::vector<double> cur_bases(ns, 0.0);
     std::vector<unsigned long long> sb(ns);
     std::vector<int32_t> segs, mlen;
-    std::vector<uint16_t> species;
     std::vector<uint32_t> segptr, pieceoff;
     uint64_t passed = 0, pieces_passed = 0, ev_base = 0;
     double ms_chain = 0;
@@ -1317,34 +1353,72 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
         P.attempt = p; P.draw_n = D;
         k_meta_draw<<<dim3((unsigned)((D + 255) / 256)), blk, 0, st>>>(P);         // S:852
         HIPCHK(hipGetLastError());
-        draws.resize(D);
-        HIPCHK(hipMemcpyAsync(draws.data(), P.draw_x, D * 8, hipMemcpyDeviceToHost, st));
+        lap("setup/alloc", tt);
+        if ((rc = ensure_pin(ctx, ctx->pin_a, (D + 1) * 8)) || (rc = ensure_pin(ctx, ctx->pin_b, (D + 1) * 8)) ||
+            (rc = ensure_pin(ctx, ctx->pin_c, (D + 1) * 8)) || (rc = ensure(ctx, ctx->draw_sel, (D + 1) * 8)) ||
+            (rc = ensure(ctx, ctx->draw_sorted, (D + 1) * 8)) || (rc = ensure(ctx, ctx->meta_words, (D + 1) * 8)) ||
+            (rc = ensure(ctx, ctx->meta_num, 16)))
+            return rc;
+        double *h_draw = (double *)ctx->pin_a.p;
+        HIPCHK(hipMemcpyAsync(h_draw, P.draw_x, D * 8, hipMemcpyDeviceToHost, st));
+        // the same filter on the device (order kept), while the host takes sum(length_list) left to right
+        const MetaLenFilter flt{perfect ? (double)prm->min_len : 0.0, (double)prm->max_len, perfect};
+        double *d_sel = (double *)ctx->draw_sel.p, *d_sorted = (double *)ctx->draw_sorted.p;
+        {
+            size_t tmp = 0;
+            HIPCHK(hipcub::DeviceSelect::If(nullptr, tmp, P.draw_x, d_sel, (int *)ctx->meta_num.p, (int)D, flt, st));
+            if ((rc = ensure(ctx, ctx->scan_tmp, tmp))) return rc;
+            HIPCHK(hipcub::DeviceSelect::If(ctx->scan_tmp.p, tmp, P.draw_x, d_sel, (int *)ctx->meta_num.p, (int)D, flt, st));
+        }
         HIPCHK(hipStreamSynchronize(st));
-        lens.clear();
-        for (double x : draws)                                                     // S:857 (--perfect: S:841)
-            if (perfect ? ((double)prm->min_len <= x && x <= (double)prm->max_len) : (0 < x && x <= (double)prm->max_len)) lens.push_back(x);
-        if (lens.empty()) continue;                                                // S:858-859
-        const uint64_t P_seg = assign_species_host(ctx, prm, p, lens, segs, cur_bases, species);   // S:866-867
+        lap("draw + D2H", tt);
+        uint64_t V = 0;
+        double to_add = 0;
+        for (uint64_t j = 0; j < D; ++j) if (flt(h_draw[j])) { to_add += h_draw[j]; ++V; }      // S:857 (--perfect: S:841); S:767
+        if (!V) continue;                                                          // S:858-859
+        uint64_t chim = 0;
+        for (int32_t v : segs) if (v > 1) chim += (uint64_t)v;                     // S:761: the first `chim` lengths keep their order
+        if (chim > V) chim = V;
+        lap("filter", tt);
+        if (chim) HIPCHK(hipMemcpyAsync(d_sorted, d_sel, chim * 8, hipMemcpyDeviceToDevice, st));
+        if (V > chim) {                                                            // S:764-765
+            size_t tmp = 0;
+            HIPCHK(hipcub::DeviceRadixSort::SortKeysDescending(nullptr, tmp, d_sel + chim, d_sorted + chim, (int)(V - chim), 0, 64, st));
+            if ((rc = ensure(ctx, ctx->scan_tmp, tmp))) return rc;
+            HIPCHK(hipcub::DeviceRadixSort::SortKeysDescending(ctx->scan_tmp.p, tmp, d_sel + chim, d_sorted + chim, (int)(V - chim), 0, 64, st));
+        }
+        k_meta_words<<<dim3((unsigned)((V + 255) / 256)), blk, 0, st>>>(P, (uint2 *)ctx->meta_words.p, V);
+        HIPCHK(hipGetLastError());
+        double *h_sorted = (double *)ctx->pin_b.p;
+        uint2 *h_words = (uint2 *)ctx->pin_c.p;
+        HIPCHK(hipMemcpyAsync(h_sorted, d_sorted, V * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h_words, ctx->meta_words.p, V * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        lap("sort + words", tt);
+        uint16_t *h_species = (uint16_t *)h_draw;                                  // the draws are no longer needed: reuse the staging
+        const uint64_t P_seg = assign_species_host(ctx, h_sorted, V, to_add, h_words, segs, cur_bases, h_species);   // S:866-867
+        lap("assign_species", tt);
         P.m_reversed = u32_to_p(ns_draw(bkey, ST_STRAND, 0, p, 0, 0).x) > ctx->m.strandness_rate ? 1u : 0u;   // S:860
-        segptr.clear(); pieceoff.clear();
+        segptr.resize(m + 1); pieceoff.resize(m + 1);
         uint64_t sp = 0, po = 0;
-        for (uint64_t i = 0; i < m; ++i) {                                         // S:862-865: reads that still get their lengths
-            const uint64_t k = (uint64_t)segs[i];
+        size_t np = 0;
+        for (; np < m; ++np) {                                                     // S:862-865: reads that still get their lengths
+            const uint64_t k = (uint64_t)segs[np];
             if (sp + k > P_seg) break;
-            segptr.push_back((uint32_t)sp); pieceoff.push_back((uint32_t)po);
+            segptr[np] = (uint32_t)sp; pieceoff[np] = (uint32_t)po;
             sp += k; po += 2 * k - 1;
         }
-        const size_t np = segptr.size();
         if (!np) continue;
-        segptr.push_back((uint32_t)sp); pieceoff.push_back((uint32_t)po);
+        segptr[np] = (uint32_t)sp; pieceoff[np] = (uint32_t)po;
         mlen.resize(sp);
-        for (uint64_t j = 0; j < sp; ++j) mlen[j] = (int32_t)nearbyint(lens[j]);   // S:871
+        for (uint64_t j = 0; j < sp; ++j) mlen[j] = (int32_t)nearbyint(h_sorted[j]);   // S:871
         HIPCHK(hipMemcpyAsync(ctx->m_segptr.p, segptr.data(), (np + 1) * 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(ctx->piece_off.p, pieceoff.data(), (np + 1) * 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(ctx->m_len.p, mlen.data(), sp * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(ctx->m_species.p, species.data(), sp * 2, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(ctx->m_species.p, h_species, sp * 2, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemsetAsync(P.accept, 0, (np + 1) * 8, st));
         HIPCHK(hipMemsetAsync(P.ev_cap + np, 0, 8, st));
+        lap("arrays + upload", tt);
         P.list_n = (uint32_t)np;
         const dim3 grid_p((unsigned)((np + 255) / 256));
         uint64_t pass_cap = 0;
@@ -1359,10 +1433,24 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
         P.m_passed = (uint32_t)passed; P.m_pieces_passed = (uint32_t)pieces_passed;
         HIPCHK(hipEventRecord(ctx->evt[3], st));
         if (first_pass && retry == 0) { HIPCHK(hipEventRecord(ctx->evt[2], st)); first_pass = false; }
-        const dim3 grid_pc((unsigned)((np + NS_CHAIN_BLOCK - 1) / NS_CHAIN_BLOCK)), blk_c(NS_CHAIN_BLOCK);
-        if (lds) k_chain<true, false><<<grid_pc, blk_c, ctx->lds_bytes, st>>>(P);
-        else k_chain<false, false><<<grid_pc, blk_c, 0, st>>>(P);
+        // the pass positions are (nearly) sorted by descending length: the head of the list goes to the cooperative chain
+        uint32_t n_coop = 0;
+        if (ctx->coop_ok && !perfect && np >= ctx->coop_min) n_coop = (uint32_t)(np >> ctx->coop_shift);
+        GenArgs Q = P;
+        if (n_coop) {
+            GenArgs B = P; B.list_n = n_coop; B.list_base = 0;
+            HIPCHK(hipEventRecord(ctx->ev_fork, st));
+            HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+            k_chain<false, true><<<dim3(n_coop), dim3(64), 0, ctx->stream2>>>(B);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+            Q.list_base = n_coop; Q.list_n = (uint32_t)np - n_coop;
+        }
+        const dim3 grid_pc((unsigned)((Q.list_n + NS_CHAIN_BLOCK - 1) / NS_CHAIN_BLOCK)), blk_c(NS_CHAIN_BLOCK);
+        if (lds) k_chain<true, false><<<grid_pc, blk_c, ctx->lds_bytes, st>>>(Q);
+        else k_chain<false, false><<<grid_pc, blk_c, 0, st>>>(Q);
         HIPCHK(hipGetLastError());
+        if (n_coop) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
         HIPCHK(hipEventRecord(ctx->evt[4], st));
         HIPCHK(hipMemcpyAsync(stats, ctx->stats.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -1383,6 +1471,7 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
         HIPCHK(hipMemcpyAsync(&acc, P.accept_scan + np, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(sb.data(), ctx->species_bases.p, (size_t)ns * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        lap("plan/chain/commit", tt);
         for (uint32_t s = 0; s < ns && !perfect; ++s) cur_bases[s] = (double)sb[s];
         passed += acc & 0xffffffffull; pieces_passed += acc >> 32;
         ev_base += pass_cap;
