@@ -168,3 +168,35 @@ def test_large_tables_take_the_global_memory_path(tmp_path, small_ref, monkeypat
             compare(e.generate(p), O.generate(mdl, small_ref, p), p)
     finally:
         e.close()
+
+
+def test_dense_events_and_long_payloads(tmp_path, small_ref, circ_ref):
+    """A model with an event every ~3 bases, runs of zero-length matches and long insertions: tiles that end early because more
+    than 63 events start inside them, payloads that cross tile borders, letters beyond the first Philox word (> 16 per event),
+    deletion-heavy spans, on a linear and on a circular reference (tiles beyond / across the origin)."""
+    from nanosim_amd import synth
+    spec = synth.SynthModelSpec(n_train=3000, seed=7, aligned_median=2500.0, mis=(3.0, 0.0, 0.3, 0.5), ins=(8.0, 0.9, 0.12, 0.5),
+                                dele=(6.0, 0.95, 0.15, 0.5), mm_means=(2.0, 2.5, 3.0, 3.0, 3.5, 3.5, 4.0, 4.0),
+                                mm_zero=(0.0, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3), fm_mean=3.0)
+    prefix = str(tmp_path / "dense" / "training")
+    synth.write_model(prefix, spec, write_pkl=False)
+    mdl = M.load_model(prefix, chimeric=True, homopolymer=True, fastq=True)
+    for ref in (small_ref, circ_ref):
+        e = E.Engine(0)
+        try:
+            e.set_reference(ref)
+            e.load_model(mdl)
+            for kw in (dict(n_reads=300, emit_errlog=True), dict(n_reads=200, fastq=True, chimeric=True, emit_errlog=True),
+                       dict(n_reads=150, kmer_bias=5, fastq=True), dict(n_reads=100, kind=E.NS_KIND_UNALIGNED, fastq=True)):
+                args = dict(seed=987654321, first_read=3, max_len=ref.max_chrom)
+                args.update(kw)
+                p = E.make_params(**args)
+                b = e.generate(p)
+                exp = O.generate(mdl, ref, p)
+                compare(b, exp, p)
+                ev, pc = b.events(), b.pieces()
+                if kw.get("kind", E.NS_KIND_ALIGNED) == E.NS_KIND_ALIGNED and not kw.get("kmer_bias"):
+                    assert int(pc["n_ev"].sum()) > 0.15 * int(pc["ref_len"].sum())          # an event every few bases
+                    assert int(M.ev_len(ev["info"]).max()) > 20                              # letters beyond the first word
+        finally:
+            e.close()
