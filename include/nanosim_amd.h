@@ -230,6 +230,11 @@ int ns_generate(ns_ctx *ctx, const ns_params *params, ns_batch_info *info);
 /* copy a result buffer of the last batch to host memory; nbytes must not exceed the buffer size
  * (record_bytes, n_reads*sizeof(ns_read), n_pieces*sizeof(ns_piece), n_events*sizeof(ns_event), errlog_bytes) */
 int ns_copy_out(ns_ctx *ctx, int which, void *host_dst, uint64_t offset, uint64_t nbytes);
+/* page-locked host memory for ns_copy_out destinations (the worker's out_reads / out_error writes, src/simulator.py:1437-1443,
+ * 2006-2008, become DMA transfers at PCIe rate into such a buffer followed by plain file writes).  Owned by the caller. */
+int ns_host_alloc(ns_ctx *ctx, uint64_t nbytes, void **out);
+int ns_host_free(ns_ctx *ctx, void *p);
+
 /* device address of a result buffer (for zero-copy consumers such as torch / RCCL); NULL if absent */
 const void *ns_device_ptr(ns_ctx *ctx, int which);
 

@@ -39,6 +39,7 @@ struct GenArgs {
     uint32_t *n_pieces;         // in: count, after scan: offsets (separate array piece_off)
     uint32_t *piece_off;
     uint64_t *ev_cap;
+    uint64_t *ev_need;          // per read: capacity a later attempt asked for (its lengths outgrew the plan of attempt 0), 0 = none
     uint64_t *ev_off;
     uint64_t *rec_len;
     uint64_t *rec_off;
@@ -175,8 +176,9 @@ __global__ void __launch_bounds__(256) k_lengths(GenArgs A) {
     }
     rd.seq_len = 0; rd.attempts = a;
     A.reads[r] = rd;
+    if (A.attempt > 0 && !meta_al && cap > A.ev_off[r + 1] - A.ev_off[r]) A.ev_need[r] = cap;   // re-plan the batch with room for this attempt
     if (A.attempt == 0 || meta_al) {
-        A.ev_cap[r] = cap;
+        A.ev_cap[r] = meta_al ? cap : max(cap, A.ev_need[r]);
         A.sort_key[r] = work > 0xffffffffull ? 0xffffffffu : (uint32_t)work;
         A.sort_idx[r] = (uint32_t)r;
     }
@@ -219,7 +221,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
     if (COOP || blockIdx.x < (gridDim.x >> 6)) __builtin_amdgcn_s_setprio(3);
     else if (blockIdx.x < (gridDim.x >> 4)) __builtin_amdgcn_s_setprio(2);
     else if (blockIdx.x < (gridDim.x >> 2)) __builtin_amdgcn_s_setprio(1);
-    unsigned long long st_over = 0, st_bases = 0, st_ref = 0, st_ev = 0;
+    unsigned long long st_over = 0, st_replan = 0, st_bases = 0, st_ref = 0, st_ev = 0;
     if (tid < A.list_n) {
         const uint64_t r = A.list ? A.list[tid] : A.list_base + tid;
         const int kind = (int)prm.kind;
@@ -330,7 +332,9 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
             accepted = true;
         } while (false);
         if (lead) {
-            if (overflow) st_over = 1;
+            if (overflow) {                     // planned too small for this attempt (stats[7]: re-plan, same rates) or a real overflow (stats[0])
+                if (!meta_al && A.ev_need[r] > A.ev_off[r + 1] - A.ev_off[r]) st_replan = 1; else st_over = 1;
+            }
             A.reads[r] = rd;
             if (meta_al) { /* a rejected read is re-planned by the next pass */ }
             else if (accepted) A.att_base[r] = a;       // a re-run of the batch starts every read at its accepted attempt
@@ -341,9 +345,10 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
         }
     }
     // one atomic per wavefront and counter
-    st_over = wave_sum(st_over); st_bases = wave_sum(st_bases); st_ref = wave_sum(st_ref); st_ev = wave_sum(st_ev);
+    st_over = wave_sum(st_over); st_replan = wave_sum(st_replan); st_bases = wave_sum(st_bases); st_ref = wave_sum(st_ref); st_ev = wave_sum(st_ev);
     if ((threadIdx.x & 63) == 0) {
         if (st_over) atomicAdd(&A.stats[0], st_over);
+        if (st_replan) atomicAdd(&A.stats[7], st_replan);
         atomicAdd(&A.stats[1], st_bases); atomicAdd(&A.stats[2], st_ref); atomicAdd(&A.stats[3], st_ev);
     }
 }
@@ -798,6 +803,7 @@ struct ns_ctx {
     uint32_t dbg = 0;          // NS_DEBUG_SKIP: phase-ablation bits for profiling only (results are wrong when set)
     uint32_t coop_min = 16384, coop_shift = 9;   // cooperative chain for the longest n>>shift reads of batches >= min (env: NS_COOP_MIN, NS_COOP_SHIFT)
     // planning + result buffers
+    DevBuf ev_need;
     DevBuf n_pieces, piece_off, ev_cap, ev_off, rec_len, rec_off, err_len, err_off, name_len;
     DevBuf reads, pieces, events, records, errlog, stats, scan_tmp;
     DevBuf sort_key, sort_idx, sort_key_out, order, list_b, rstate, att_base, scr, scrq, scr_len, scr_off, hp_len, slow_q, ev_word;
@@ -831,7 +837,14 @@ static int ensure(ns_ctx *ctx, DevBuf &b, size_t bytes) {
     size_t want = bytes + bytes / 8 + 4096;
     if (b.p) { hipError_t e = hipFree(b.p); (void)e; b.p = nullptr; b.cap = 0; }
     hipError_t e = hipMalloc(&b.p, want);
-    if (e != hipSuccess) { b.p = nullptr; b.cap = 0; return fail(ctx, NS_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    if (e != hipSuccess) {
+        b.p = nullptr; b.cap = 0;
+        size_t fr = 0, tot = 0;
+        hipError_t e2 = hipMemGetInfo(&fr, &tot); (void)e2;
+        (void)hipGetLastError();             // the failed allocation must not poison the next call
+        return fail(ctx, NS_ENOMEM, std::string("hipMalloc(") + std::to_string(want) + " bytes): " + hipGetErrorString(e) + " (" +
+                                        std::to_string(fr >> 20) + " MiB free of " + std::to_string(tot >> 20) + ")");
+    }
     b.cap = want;
     return NS_OK;
 }
@@ -924,7 +937,7 @@ void ns_destroy(ns_ctx *ctx) {
                       &ctx->err_len, &ctx->err_off, &ctx->name_len, &ctx->reads, &ctx->pieces, &ctx->events,
                       &ctx->records, &ctx->errlog, &ctx->stats, &ctx->scan_tmp, &ctx->sort_key, &ctx->sort_idx,
                       &ctx->sort_key_out, &ctx->order, &ctx->list_b, &ctx->rstate, &ctx->att_base, &ctx->scr, &ctx->scrq,
-                      &ctx->scr_len, &ctx->scr_off, &ctx->hp_len, &ctx->slow_q, &ctx->ev_word, &ctx->species_chrom_off, &ctx->t_reads, &ctx->t_pieces,
+                      &ctx->scr_len, &ctx->scr_off, &ctx->hp_len, &ctx->slow_q, &ctx->ev_word, &ctx->ev_need, &ctx->species_chrom_off, &ctx->t_reads, &ctx->t_pieces,
                       &ctx->t_name_len, &ctx->t_rec_len, &ctx->t_err_len, &ctx->accept, &ctx->accept_scan, &ctx->key_pos,
                       &ctx->draw_x, &ctx->m_segptr, &ctx->m_len, &ctx->m_species, &ctx->species_bases, &ctx->draw_sel,
                       &ctx->draw_sorted, &ctx->meta_words, &ctx->meta_num};
@@ -1518,7 +1531,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     if (!n) { ctx->last = *info; ctx->has_batch = true; return NS_OK; }
     int rc;
     if ((rc = ensure(ctx, ctx->n_pieces, (n + 1) * 4)) || (rc = ensure(ctx, ctx->piece_off, (n + 1) * 4)) ||
-        (rc = ensure(ctx, ctx->ev_cap, (n + 1) * 8)) || (rc = ensure(ctx, ctx->ev_off, (n + 1) * 8)) ||
+        (rc = ensure(ctx, ctx->ev_cap, (n + 1) * 8)) || (rc = ensure(ctx, ctx->ev_off, (n + 1) * 8)) || (rc = ensure(ctx, ctx->ev_need, (n + 1) * 8)) ||
         (rc = ensure(ctx, ctx->rec_len, (n + 1) * 8)) || (rc = ensure(ctx, ctx->rec_off, (n + 1) * 8)) ||
         (rc = ensure(ctx, ctx->err_len, (n + 1) * 8)) || (rc = ensure(ctx, ctx->err_off, (n + 1) * 8)) ||
         (rc = ensure(ctx, ctx->name_len, (n + 1) * 2)) || (rc = ensure(ctx, ctx->reads, n * sizeof(ns_read))) ||
@@ -1535,7 +1548,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     A.prm = *prm; A.m = ctx->m; A.ref = ctx->ref;
     A.cap_gap_mul = 2;
     A.n_pieces = (uint32_t *)ctx->n_pieces.p; A.piece_off = (uint32_t *)ctx->piece_off.p;
-    A.ev_cap = (uint64_t *)ctx->ev_cap.p; A.ev_off = (uint64_t *)ctx->ev_off.p;
+    A.ev_cap = (uint64_t *)ctx->ev_cap.p; A.ev_off = (uint64_t *)ctx->ev_off.p; A.ev_need = (uint64_t *)ctx->ev_need.p;
     A.rec_len = (uint64_t *)ctx->rec_len.p; A.rec_off = (uint64_t *)ctx->rec_off.p;
     A.err_len = (uint64_t *)ctx->err_len.p; A.err_off = (uint64_t *)ctx->err_off.p;
     A.name_len = (uint16_t *)ctx->name_len.p; A.reads = (ns_read *)ctx->reads.p;
@@ -1557,6 +1570,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     const bool lds = ctx->lds_tables && prm->kind != NS_KIND_PERFECT;
     float ms = 0;
     HIPCHK(hipEventRecord(ctx->evt[0], st));
+    HIPCHK(hipMemsetAsync(ctx->ev_need.p, 0, (n + 1) * 8, st));
     double ms_hp = 0;
     if (meta_al && (rc = meta_passes(ctx, prm, info, A, tot_pieces, tot_cap, stats))) return rc;
     for (int hp_round = 0; !meta_al; ++hp_round) {
@@ -1623,7 +1637,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
             HIPCHK(hipStreamSynchronize(st));
             HIPCHK(hipEventElapsedTime(&ms, ctx->evt[3], ctx->evt[4]));
             ms_chain += ms;
-            if (stats[0]) { overflow = true; break; }
+            if (stats[0] || stats[7]) { overflow = true; break; }
             cur_n = (uint32_t)(stats[6] & 0xffffffffull);
             if (!cur_n) break;
             if (a + 1 >= NS_MAX_ATTEMPT)
@@ -1633,9 +1647,11 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         }
         info->ms_kernel[NS_K_EVENTS] = ms_chain;
         if (!overflow) break;
-        info->n_overflow += stats[0];
-        if (retry >= 6) return fail(ctx, NS_ENOMEM, "event capacity overflow persists after 6 retries");
-        cap_rate *= 2.0; A.cap_gap_mul *= 2;          // rare: re-plan the batch with twice the event capacity
+        info->n_overflow += stats[0] + stats[7];
+        if (retry >= 12) return fail(ctx, NS_ENOMEM, "event capacity overflow persists after 12 retries");
+        // rare: re-plan the batch.  stats[7]: reads whose later attempt drew longer segments than attempt 0 (their capacity is now
+        // in ev_need); stats[0]: more events per base than planned -> twice the rates
+        if (stats[0]) { cap_rate *= 2.0; A.cap_gap_mul *= 2; }
     }
     if (!A.hp) break;
     // ---- -k stage 1: filter events, write the pre-homopolymer reads to scratch, count the final lengths ----
@@ -1729,6 +1745,23 @@ int ns_copy_out(ns_ctx *ctx, int which, void *host_dst, uint64_t offset, uint64_
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemcpyAsync(host_dst, static_cast<const uint8_t *>(p) + offset, nbytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return NS_OK;
+}
+
+int ns_host_alloc(ns_ctx *ctx, uint64_t nbytes, void **out) {
+    if (!ctx) return NS_EINVAL;
+    if (!out || !nbytes) return fail(ctx, NS_EINVAL, "ns_host_alloc: null destination / zero size");
+    *out = nullptr;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipError_t e = hipHostMalloc(out, nbytes, hipHostMallocDefault);
+    if (e != hipSuccess) { *out = nullptr; return fail(ctx, NS_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+    return NS_OK;
+}
+
+int ns_host_free(ns_ctx *ctx, void *p) {
+    if (!ctx) return NS_EINVAL;
+    if (!p) return NS_OK;
+    HIPCHK(hipHostFree(p));
     return NS_OK;
 }
 

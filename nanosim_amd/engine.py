@@ -14,11 +14,12 @@ from .model import (EVENT_DTYPE, PIECE_DTYPE, READ_DTYPE, Model, NsBatchInfo, Ns
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NANOSIM_AMD_LIB") or os.path.join(_HERE, "libnanosim_amd.so")   # override: A/B builds only
 NS_BUF_RECORDS, NS_BUF_READS, NS_BUF_PIECES, NS_BUF_EVENTS, NS_BUF_ERRLOG = 0, 1, 2, 3, 4
+NS_EINVAL, NS_ENODEV, NS_ENOMEM, NS_EHIP, NS_ESTATE = -1, -2, -3, -4, -5
 NS_KIND_ALIGNED, NS_KIND_UNALIGNED, NS_KIND_PERFECT = 0, 1, 2
 KERNEL_NAMES = ("plan(k_nseg+k_lengths+scan+sort)", "k_chain", "k_names", "k_materialise", "k_hp", "k_errlog")
 EXPORTS = ("ns_abi_version", "ns_create", "ns_destroy", "ns_last_error", "ns_set_reference",
            "ns_set_reference_device", "ns_load_model", "ns_generate", "ns_copy_out", "ns_device_ptr",
-           "ns_set_species", "ns_set_abundance", "ns_species_bases")
+           "ns_set_species", "ns_set_abundance", "ns_species_bases", "ns_host_alloc", "ns_host_free")
 
 _lib = None
 
@@ -62,6 +63,10 @@ def load_library(path: str = LIB_PATH):
     L.ns_set_abundance.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.ns_species_bases.restype = C.c_int
     L.ns_species_bases.argtypes = [C.c_void_p, C.c_void_p]
+    L.ns_host_alloc.restype = C.c_int
+    L.ns_host_alloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+    L.ns_host_free.restype = C.c_int
+    L.ns_host_free.argtypes = [C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -102,6 +107,12 @@ class Batch:
     def kernel_ms(self):
         return {KERNEL_NAMES[i]: float(self.info.ms_kernel[i]) for i in range(len(KERNEL_NAMES))}
 
+    def copy_range(self, which: int, offset: int, out: np.ndarray, nbytes: int):
+        """bytes [offset, offset + nbytes) of a result buffer into `out` (ideally from Engine.pinned)"""
+        if nbytes:
+            self.eng._check(self.eng.L.ns_copy_out(self.eng.ctx, which, out.ctypes.data, offset, nbytes))
+        return out[:nbytes]
+
 
 class Engine:
     """One context per GPU (single host thread), mirroring the worker seam of src/simulator.py:1601-1619."""
@@ -113,9 +124,13 @@ class Engine:
         if rc != 0:
             raise EngineError("ns_create(device=%d) failed with %d (no MI355X visible?)" % (device, rc))
         self._keep = []
+        self._pinned = []
 
     def close(self):
         if self.ctx:
+            for p in self._pinned:
+                self.L.ns_host_free(self.ctx, p)
+            self._pinned = []
             self.L.ns_destroy(self.ctx)
             self.ctx = C.c_void_p()
 
@@ -127,7 +142,9 @@ class Engine:
 
     def _check(self, rc):
         if rc != 0:
-            raise EngineError("nanosim_amd error %d: %s" % (rc, self.L.ns_last_error(self.ctx).decode()))
+            err = EngineError("nanosim_amd error %d: %s" % (rc, self.L.ns_last_error(self.ctx).decode()))
+            err.code = rc
+            raise err
 
     def set_reference(self, ref: Reference):
         blob = ref.names_blob()
@@ -164,6 +181,13 @@ class Engine:
         out = np.zeros(self._nspecies, dtype=np.float64)
         self._check(self.L.ns_species_bases(self.ctx, out.ctypes.data))
         return out
+
+    def pinned(self, nbytes: int) -> np.ndarray:
+        """uint8 array over page-locked host memory (ns_host_alloc); freed with the engine"""
+        p = C.c_void_p()
+        self._check(self.L.ns_host_alloc(self.ctx, nbytes, C.byref(p)))
+        self._pinned.append(p)
+        return np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(p.value))
 
     def load_model(self, model: Model):
         t = model.to_c()

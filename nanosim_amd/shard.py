@@ -49,7 +49,10 @@ def broadcast_reference(ref: Reference | None, dist, device=None):
 
 
 def merge_subfiles(out_path: str, sub_paths: list[str], header: bytes = b"") -> None:
-    """Concatenate the per-rank sub-files in rank order and remove them (S:1626-1639)."""
+    """Concatenate the per-rank sub-files in rank order and remove them (S:1626-1639); a single sub-file is just renamed."""
+    if len(sub_paths) == 1 and not header:
+        os.replace(sub_paths[0], out_path)
+        return
     with open(out_path, "wb") as out:
         if header:
             out.write(header)

@@ -147,27 +147,104 @@ def validate_genome_args(a, parser_g):
         die("Perfect reads cannot be chimeric", False)
 
 
+class StreamWriter:
+    """Device buffer -> file in a pipeline: 64 MB slices travel by DMA into page-locked staging buffers
+    (ns_host_alloc) while a small pool of threads writes the previous slices at their file offsets (os.pwrite releases the GIL)."""
+    SLICE = 64 << 20
+    DEPTH = 6
+    THREADS = 8
+
+    def __init__(self, eng):
+        import queue
+        import threading
+        self.eng = eng
+        self.free = queue.Queue()
+        self.jobs = queue.Queue()
+        self.err = []
+        for _ in range(self.DEPTH):
+            self.free.put(eng.pinned(self.SLICE))
+        self.threads = [threading.Thread(target=self._work, daemon=True) for _ in range(self.THREADS)]
+        for t in self.threads:
+            t.start()
+
+    def _work(self):
+        while True:
+            job = self.jobs.get()
+            if job is None:
+                return
+            fd, off, buf, n = job
+            try:
+                mv = memoryview(buf)[:n]
+                done = 0
+                while done < n:
+                    done += os.pwrite(fd, mv[done:], off + done)
+            except Exception as ex:                      # surfaces in drain()
+                self.err.append(ex)
+            finally:
+                self.free.put(buf)
+                self.jobs.task_done()
+
+    def stream(self, batch, which, nbytes, fd, file_off):
+        """append bytes [0, nbytes) of result buffer `which` of `batch` to fd at file_off"""
+        pos = 0
+        while pos < nbytes:
+            n = min(self.SLICE, nbytes - pos)
+            buf = self.free.get()
+            batch.copy_range(which, pos, buf, n)
+            self.jobs.put((fd, file_off + pos, buf, n))
+            pos += n
+        return file_off + nbytes
+
+    def drain(self):
+        self.jobs.join()
+        if self.err:
+            raise self.err[0]
+
+    def close(self):
+        self.drain()
+        for _ in self.threads:
+            self.jobs.put(None)
+        for t in self.threads:
+            t.join()
+
+
 def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, chimeric, min_len, max_len, median_len,
-                   sd_len, want_errlog, kmer_bias=0, meta=False):
+                   sd_len, want_errlog, kmer_bias=0, meta=False, err_header=b""):
     done = 0
-    with open(out_path, "wb") as fr:
-        fe = open(err_path, "wb") if err_path else None
-        try:
-            while done < count:
-                n = min(BATCH_READS, count - done)
-                p = E.make_params(seed=seed, first_read=first + done, n_reads=n, kind=kind, fastq=fastq, chimeric=chimeric, kmer_bias=kmer_bias,
-                                  min_len=min_len, max_len=max_len, median_len=median_len, sd_len=sd_len,
-                                  emit_records=True, emit_errlog=bool(fe), meta=meta)
+    w = getattr(eng, "_stream_writer", None)           # one writer (staging buffers + threads) per engine
+    if w is None:
+        w = eng._stream_writer = StreamWriter(eng)
+    fr = os.open(out_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    fe = os.open(err_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644) if err_path else None
+    off_r = off_e = 0
+    if fe is not None and err_header:                  # rank 0 opens the error profile with the column header (S:1634)
+        os.pwrite(fe, err_header, 0)
+        off_e = len(err_header)
+    try:
+        batch = getattr(eng, "_batch_reads", BATCH_READS)
+        while done < count:
+            n = min(batch, count - done)
+            p = E.make_params(seed=seed, first_read=first + done, n_reads=n, kind=kind, fastq=fastq, chimeric=chimeric, kmer_bias=kmer_bias,
+                              min_len=min_len, max_len=max_len, median_len=median_len, sd_len=sd_len,
+                              emit_records=True, emit_errlog=fe is not None, meta=meta)
+            try:
                 b = eng.generate(p)
-                fr.write(memoryview(b.records()))
-                if fe:
-                    fe.write(memoryview(b.errlog()))
-                done += n
-                sys.stdout.write(strftime("%Y-%m-%d %H:%M:%S") + ": Number of reads simulated >> " + str(first + done) + "\r")
-                sys.stdout.flush()
-        finally:
-            if fe:
-                fe.close()
+            except E.EngineError as ex:              # not enough free HBM for this batch size (shared GPU): halve it and go on
+                if getattr(ex, "code", 0) != E.NS_ENOMEM or n <= 1000:
+                    raise
+                batch = eng._batch_reads = max(1000, n // 2)
+                continue
+            off_r = w.stream(b, E.NS_BUF_RECORDS, int(b.info.record_bytes), fr, off_r)
+            if fe is not None:
+                off_e = w.stream(b, E.NS_BUF_ERRLOG, int(b.info.errlog_bytes), fe, off_e)
+            done += n
+            sys.stdout.write(strftime("%Y-%m-%d %H:%M:%S") + ": Number of reads simulated >> " + str(first + done) + "\r")
+            sys.stdout.flush()
+    finally:
+        w.drain()
+        os.close(fr)
+        if fe is not None:
+            os.close(fe)
     sys.stdout.write('\n')
 
 
@@ -234,12 +311,12 @@ def run_genome(a, parser_g):
     sub_err = out + "_error_profile%d" % rank
     _write_batches(eng, sub_reads, sub_err, seed=seed, first=lo, count=hi - lo, kind=kind, fastq=a.fastq,
                    chimeric=a.chimeric, min_len=a.min_len, max_len=max_len, median_len=a.median_len, sd_len=a.sd_len,
-                   want_errlog=True, kmer_bias=a.KmerBias or 0)
+                   want_errlog=True, kmer_bias=a.KmerBias or 0, err_header=ERR_HEADER if rank == 0 else b"")
     if dist is not None:
         dist.barrier()
     if rank == 0:
         shard.merge_subfiles(out + "_aligned_reads" + ext, [out + "_aligned_reads%d%s" % (r, ext) for r in range(world)])
-        shard.merge_subfiles(out + "_aligned_error_profile", [out + "_error_profile%d" % r for r in range(world)], ERR_HEADER)
+        shard.merge_subfiles(out + "_aligned_error_profile", [out + "_error_profile%d" % r for r in range(world)])
     if not a.perfect:                                                                       # S:1642-1672
         if rank == 0:
             log("Start simulation of random reads")
@@ -333,12 +410,13 @@ def run_metagenome(a, parser_mg):
         lo, hi = shard.partition(n_al, world)[rank]
         _write_batches(eng, base + "_aligned_reads%d%s" % (rank, ext), base + "_error_profile%d" % rank, seed=seed, first=first + lo,
                        count=hi - lo, kind=E.NS_KIND_PERFECT if a.perfect else E.NS_KIND_ALIGNED, fastq=a.fastq, chimeric=a.chimeric,
-                       min_len=a.min_len, max_len=max_len, median_len=None, sd_len=None, want_errlog=True, meta=True)
+                       min_len=a.min_len, max_len=max_len, median_len=None, sd_len=None, want_errlog=True, meta=True,
+                       err_header=ERR_HEADER if rank == 0 else b"")
         if dist is not None:
             dist.barrier()
         if rank == 0:
             shard.merge_subfiles(base + "_aligned_reads" + ext, [base + "_aligned_reads%d%s" % (r, ext) for r in range(world)])
-            shard.merge_subfiles(base + "_aligned_error_profile", [base + "_error_profile%d" % r for r in range(world)], ERR_HEADER)
+            shard.merge_subfiles(base + "_aligned_error_profile", [base + "_error_profile%d" % r for r in range(world)])
         if not a.perfect:                                                                   # S:1642
             if rank == 0:
                 log("Start simulation of random reads")

@@ -200,3 +200,25 @@ def test_dense_events_and_long_payloads(tmp_path, small_ref, circ_ref):
                     assert int(M.ev_len(ev["info"]).max()) > 20                              # letters beyond the first word
         finally:
             e.close()
+
+
+def test_later_attempt_outgrows_the_planned_event_capacity(tmp_path, small_ref):
+    """Unaligned reads redraw their length at every attempt: a read whose attempt 0 is tiny (rejected by min_len) and whose next
+    attempt is long needs more event slots than attempt 0 planned; the batch is re-planned with that read's demand."""
+    from nanosim_amd import synth
+    spec = synth.SynthModelSpec(n_train=4000, seed=3, unaligned_median=400.0, unaligned_sigma=1.6)     # wide: many draws below min_len
+    prefix = str(tmp_path / "wide" / "training")
+    synth.write_model(prefix, spec, write_pkl=False)
+    mdl = M.load_model(prefix)
+    e = E.Engine(0)
+    try:
+        e.set_reference(small_ref)
+        e.load_model(mdl)
+        p = E.make_params(seed=11, first_read=0, n_reads=3000, kind=E.NS_KIND_UNALIGNED, min_len=300, max_len=small_ref.max_chrom)
+        b = e.generate(p)
+        exp = O.generate(mdl, small_ref, p)
+        compare(b, exp, p)
+        rd = b.reads()
+        assert int(rd["attempts"].max()) >= 2 and int(b.info.n_overflow) > 0           # the re-plan path ran
+    finally:
+        e.close()
