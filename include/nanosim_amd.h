@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define NS_ABI_VERSION 1u
+#define NS_ABI_VERSION 2u
 
 /* error codes */
 #define NS_OK 0
@@ -108,6 +108,12 @@ typedef struct ns_model_tables {
     /* homopolymers (S:504-529; src/model_homopolymer_lengths.py:246-260) */
     ns_hp_class hp[2];                /* 0 = AT, 1 = CG */
     double hp_mis_rate;
+
+    /* transcriptome: the 2-D KDE of (transcript length, aligned length) (_aligned_region_2d.pkl, S:561-565), training points sorted
+     * by transcript length; select_nearest_kde2d (S:108-111) becomes a draw from the KDE conditioned on the transcript length */
+    const double *kde2d_x, *kde2d_y;
+    uint64_t kde2d_n;
+    double kde2d_bw;
 } ns_model_tables;
 
 #define NS_MODEL_HAS_ERRORS 1u   /* error tables present (absent with --perfect) */
@@ -115,6 +121,7 @@ typedef struct ns_model_tables {
 #define NS_MODEL_HAS_HP 4u
 #define NS_MODEL_HAS_CHIMERIC 8u
 #define NS_MODEL_HAS_UNALIGNED 16u
+#define NS_MODEL_HAS_KDE2D 32u
 
 /* ---- generation parameters: the arguments of the worker targets ------------------------------------
  * simulation_aligned_genome(dna_type, min_l, max_l, median_l, sd_l, out_reads, out_error, kmer_bias,
@@ -137,6 +144,9 @@ typedef struct ns_params {
     double median_len, sd_len;
     uint32_t emit_errlog;   /* 1: format the _aligned_error_profile rows on the device (S:2006-2008) */
     uint32_t meta;          /* 1: metagenome batch = one worker of simulation_aligned_metagenome (S:814-1040) / simulation_unaligned("metagenome") */
+    uint32_t trx;           /* 1: transcriptome batch = one worker of simulation_aligned_transcriptome (S:1043-1263, without intron
+                             * retention) / simulation_unaligned("transcriptome"); needs ns_set_transcriptome */
+    uint32_t uracil;        /* --uracil: T -> U in the emitted sequence (S:1247-1248) */
 } ns_params;
 
 /* ---- device-side result layout (copied out with ns_copy_out) -------------------------------------- */
@@ -191,7 +201,8 @@ typedef struct ns_batch_info {
 } ns_batch_info;
 
 enum { NS_K_LENGTHS = 0, NS_K_EVENTS = 1, NS_K_SCAN = 2, NS_K_MATERIALISE = 3, NS_K_HP = 4, NS_K_ERRLOG = 5 };
-enum { NS_BUF_RECORDS = 0, NS_BUF_READS = 1, NS_BUF_PIECES = 2, NS_BUF_EVENTS = 3, NS_BUF_ERRLOG = 4 };
+enum { NS_BUF_RECORDS = 0, NS_BUF_READS = 1, NS_BUF_PIECES = 2, NS_BUF_EVENTS = 3, NS_BUF_ERRLOG = 4,
+       NS_BUF_POLYA = 5 /* uint16 per read: polyA tail length of a transcriptome batch */ };
 
 typedef struct ns_ctx ns_ctx;
 
@@ -219,6 +230,13 @@ int ns_set_reference_device(ns_ctx *ctx, const void *bases_dev, uint64_t nbases,
 int ns_set_species(ns_ctx *ctx, uint32_t nspecies, const uint32_t *species_chrom_off);
 int ns_set_abundance(ns_ctx *ctx, const double *abun, const double *abun_inflated);
 int ns_species_bases(ns_ctx *ctx, double *out);
+
+/* transcriptome (src/simulator.py:341-350, 382-399, 460-470): the transcripts are the "chromosomes" of the reference set with
+ * ns_set_reference (all linear).  expr_chrom / expr_cum: the transcripts with TPM > 0 in the order of make_cdf (S:69-97, ascending
+ * expression) and the cumulative weights random.choices builds from ecdf_weight_list (S:1084); polya[nchrom] != 0 marks the
+ * transcripts of the --polya list (NULL: none); polya_scale = scale of the exponential tail length (S:1046-1053). */
+int ns_set_transcriptome(ns_ctx *ctx, uint32_t n_expr, const uint32_t *expr_chrom, const double *expr_cum,
+                         const uint8_t *polya, double polya_scale);
 
 /* model: replaces the globals filled by read_profile() (src/simulator.py:473-591) */
 int ns_load_model(ns_ctx *ctx, const ns_model_tables *tables);

@@ -33,6 +33,8 @@ struct GenArgs {
     ns_params prm;
     DevModel m;
     DevRef ref;
+    DevTrx tx;                  // transcriptome batches (prm.trx)
+    uint16_t *polya;            // transcriptome: polyA tail length per read
     double cap_rate;            // event capacity per aligned reference base
     uint32_t cap_gap_mul;       // event capacity per gap/unaligned reference base
     // per-read planning arrays (n+1)
@@ -134,13 +136,21 @@ __global__ void __launch_bounds__(256) k_lengths(GenArgs A) {
     for (uint32_t pi = 0; pi < n_pieces; ++pi) {
         const bool is_gap = (kind == NS_KIND_UNALIGNED) || (pi & 1);
         int64_t mlen = 0;
+        uint32_t plan_chrom = 0;
+        if (prm.trx && kind != NS_KIND_UNALIGNED) {                                     // S:1082-1105: transcript by expression, aligned
+            const u32x4 wt = ns_draw(key, ST_TRX, 0, a, 0, 0);                          // length from the 2-D KDE given its length
+            plan_chrom = A.tx.expr_chrom[trx_pick(A.tx, u53_to_p(wt.x, wt.y))];
+            const int64_t tl = (int64_t)(A.ref.chrom_off[plan_chrom + 1] - A.ref.chrom_off[plan_chrom]);
+            mlen = kde2d_cond(A.m, (double)tl, key, a);
+            if (!(mlen > 0 && mlen < tl)) { ok = false; mlen = 0; }                     // S:1103-1104
+        } else
         if (kind == NS_KIND_UNALIGNED) mlen = unaligned_length(A.m, prm, key, a);       // S:1494-1495
         else if (is_gap) mlen = gap_length(A.m, key, pi >> 1, A.meta ? a : epoch);     // S:1298-1299 (S:872: once per pass)
         else if (A.meta) mlen = A.m_len[A.m_segptr[r] + (pi >> 1)];                    // S:871: assigned by assign_species
         else if (!seg_length(A.m, prm, key, pi >> 1, epoch, mlen)) { ok = false; mlen = 0; }   // S:1285-1296
         const int32_t m32 = mlen > 0x3fffffff ? 0x3fffffff : mlen < -1 ? -1 : (int32_t)mlen;
         ns_piece p;
-        p.ref_gpos = 0; p.ev_off = 0; p.chrom = 0; p.pos = 0; p.ref_len = (uint32_t)m32; p.out_len = 0; p.n_ev = 0;
+        p.ref_gpos = 0; p.ev_off = 0; p.chrom = 0; p.pos = plan_chrom; p.ref_len = (uint32_t)m32; p.out_len = 0; p.n_ev = 0;   // (pos: the planned transcript until k_chain draws the start)
         p.kind = is_gap ? 1u : 0u;
         pc[pi] = p;
         const uint64_t l = m32 > 0 ? (uint64_t)m32 : 0;
@@ -149,6 +159,14 @@ __global__ void __launch_bounds__(256) k_lengths(GenArgs A) {
         else { cap += (uint64_t)((double)l * A.cap_rate) + 64; work += l; }
     }
     int32_t remainder = 0; double ratio = 0;
+    if (prm.trx && kind == NS_KIND_ALIGNED) {                                          // S:1073-1076, 1203-1204: one draw per read, no filter
+        const double x = ns_pow10m1(kde_sample(A.m.kde[NS_KDE_HT], ns_draw(key, ST_HT, 0, 0, 0, 0)));
+        const int64_t r64 = (int64_t)x;
+        remainder = r64 < 0 ? 0 : r64 > 0x3fffffff ? 0x3fffffff : (int32_t)r64;
+        ratio = kde_sample(A.m.kde[NS_KDE_RATIO], ns_draw(key, ST_RATIO, 0, 0, 0, 0));
+        if (ratio > 1) ratio = 1;
+        if (ratio < 0) ratio = 0;
+    } else
     if (kind == NS_KIND_ALIGNED && ok) {                                               // S:1471-1474, 1351-1352
         uint32_t j = 0;
         for (; j < NS_KDE_RETRY; ++j) {
@@ -226,6 +244,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
         const uint64_t r = A.list ? A.list[tid] : A.list_base + tid;
         const int kind = (int)prm.kind;
         const bool meta_al = A.meta && kind != NS_KIND_UNALIGNED;
+        const bool trx_al = prm.trx && kind != NS_KIND_UNALIGNED;
         const ns_key key = make_key(prm, r);
         const uint32_t a = meta_al ? A.attempt : A.att_base[r] + A.attempt;
         ns_read rd = A.reads[r];
@@ -241,6 +260,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
             EvSink32 sink; sink.last_ins_len = 0; sink.overflow = false;
             int64_t total = (int64_t)rd.head + rd.tail;
             uint32_t evn = 0;
+            const uint32_t trx_chrom = trx_al ? pc[0].pos : 0u;      // planned by k_lengths
             for (uint32_t pi = 0; pi < n_pieces; ++pi) {
                 ns_piece p = pc[pi];
                 const int32_t m32 = (int32_t)p.ref_len;                // planned length from k_lengths
@@ -262,13 +282,18 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
                 if (kind == NS_KIND_UNALIGNED) total = e.middle_ref;                     // S:1503
             }
             if (sink.overflow) { overflow = true; break; }
+            int64_t trx_len = 0;
+            if (trx_al) {                                    // S:1143-1144: middle_ref > ref_trx_len -> start over (no length limits)
+                trx_len = (int64_t)(A.ref.chrom_off[trx_chrom + 1] - A.ref.chrom_off[trx_chrom]);
+                if ((int64_t)pc[0].ref_len > trx_len) break;
+            } else
             if (meta_al) {                                   // S:907-946: remainder + middle_ref of the segments, then the gaps
                 int64_t tot = (int64_t)rd.head + rd.tail; bool restart = false;
                 for (uint32_t pi = 0; pi < n_pieces && !restart; pi += 2) { if (tot + pc[pi].ref_len > prm.max_len) restart = true; else tot += pc[pi].ref_len; }
                 for (uint32_t pi = 1; pi < n_pieces && !restart; pi += 2) { if (tot + pc[pi].out_len > prm.max_len) restart = true; else tot += pc[pi].out_len; }
                 if (restart || tot < prm.min_len || tot > prm.max_len) break;
             } else
-            if (total < prm.min_len || total > prm.max_len) {                            // S:1367-1368, S:1503-1504
+            if (!trx_al && (total < prm.min_len || total > prm.max_len)) {               // S:1367-1368, S:1503-1504
                 if (kind != NS_KIND_UNALIGNED && ++fails >= NS_EPOCH_FAILS) { ++epoch; fails = 0; }
                 break;
             }
@@ -281,6 +306,16 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
                 const uint32_t sid = p.kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
                 uint32_t chrom = 0; uint64_t pos = 0;
                 if (p.chrom == 1u && p.kind) { p.ref_len = 0; p.out_len = 0; p.n_ev = 0; }
+                else if (trx_al) {                                   // extract_read_trx (S:1683-1691): uniform start inside the transcript
+                    const u32x4 wp = ns_draw(key, ST_POS, sid, a, 0, 0);
+                    const uint64_t span = (uint64_t)(trx_len - (int64_t)p.ref_len) + 1;
+                    pos = (uint64_t)(u53_to_p(wp.x, wp.y) * (double)span);
+                    if (pos >= span) pos = span - 1;
+                    chrom = trx_chrom;
+                }
+                else if (prm.trx) {                                  // unaligned read: any transcript longer than it (S:1695-1703)
+                    if (!extract_pos_trx_any(A.ref, p.ref_len, key, sid, a, chrom, pos)) { pos_ok = false; break; }
+                }
                 else if (A.meta) {                                   // species of the segment; gaps / unaligned reads: any species
                     const int sp = (meta_al && !p.kind) ? (int)A.m_species[A.m_segptr[r] + (pi >> 1)] : -1;
                     if (!extract_pos_meta(A.ref, A.species_chrom_off, A.nspecies, p.ref_len, sp, key, sid, a, chrom, pos)) { pos_ok = false; break; }
@@ -291,8 +326,15 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
                 seq_len += p.out_len;
                 ref_bases += p.ref_len;
             }
+            uint32_t polya = 0;                                      // S:1046-1053, 1206-1209: exponential tail if the read reaches the 3' end
+            if (trx_al && pos_ok && A.tx.polya && A.tx.polya[trx_chrom] && (int64_t)pc[0].pos + (int64_t)pc[0].ref_len + 10 >= trx_len) {
+                const u32x4 wa = ns_draw(key, ST_TRX, 0, a, 1, 0);
+                const int64_t pl = (int64_t)fma(A.tx.polya_scale, -ns_log(u32_to_p(wa.x)), 2.0);    // int(expon.rvs(loc=2, scale))
+                polya = pl > 65535 ? 65535u : (uint32_t)pl;
+                seq_len += polya;
+            }
             // final length re-check (S:1429-1430, S:1518-1519); with -k the length is only final after k_hp_count
-            if (!pos_ok || (!A.hp && (seq_len < prm.min_len || seq_len > prm.max_len))) { ++epoch; fails = 0; break; }
+            if (!pos_ok || (!A.hp && !trx_al && (seq_len < prm.min_len || seq_len > prm.max_len))) { ++epoch; fails = 0; break; }
             // ---- accepted ----
             rd.flags = 0; rd.seq_len = (uint32_t)seq_len; rd.attempts = a;
             uint32_t nl = 0; bool first = true;                                          // name length (S:1390-1402, 1332-1343, 1529-1534)
@@ -309,7 +351,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
             // metagenome: the number of the read is only known once the accepted reads of the pass are counted (k_meta_commit)
             nl += (kind == NS_KIND_UNALIGNED ? 11u : 9u) + (meta_al ? 0u : dec_digits(prm.first_read + r));
             if (kind == NS_KIND_ALIGNED && n_pieces > 1) nl += 9;
-            nl += 2 /*_F*/ + 1 + dec_digits(rd.head) + 1 + 1 + dec_digits(rd.tail);
+            nl += 2 /*_F*/ + 1 + dec_digits(rd.head) + 1 + 1 + dec_digits(rd.tail + polya);       // S:1211-1213: tail + polya_len
             uint64_t err_len = 0;
             if (prm.emit_errlog) {
                 for (uint32_t pi = 0; pi < n_pieces; ++pi) {
@@ -326,6 +368,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
                 A.name_len[r] = (uint16_t)nl;
                 A.rec_len[r] = prm.emit_records ? (uint64_t)nl + 2 + (uint64_t)seq_len + 1 + (prm.fastq ? (uint64_t)seq_len + 3 : 0) : 0;
                 A.err_len[r] = err_len;
+                if (A.polya) A.polya[r] = (uint16_t)polya;
                 if (meta_al) A.accept[r] = 1ull | (uint64_t)n_pieces << 32;
                 st_bases = A.hp ? 0ull : (unsigned long long)seq_len; st_ref = ref_bases; st_ev = evn;
             }
@@ -446,7 +489,7 @@ __global__ void __launch_bounds__(256) k_names(GenArgs A) {
         first = false;
         p = put_dec(p, pc[pi].ref_len);
     }
-    *p++ = '_'; p = put_dec(p, rd.tail);
+    *p++ = '_'; p = put_dec(p, rd.tail + (A.polya ? A.polya[r] : 0u));
     *p++ = '\n';
     p += rd.seq_len;
     *p++ = '\n';
@@ -471,7 +514,7 @@ __device__ __forceinline__ bool load_read_uniform(const GenArgs &A, uint64_t r, 
     key.r_lo = uni(key.r_lo); key.r_hi = uni(key.r_hi);
     ro.seq = A.records + rd.rec_off + uni(A.name_len[r]) + 2;
     ro.qual = fastq ? ro.seq + rd.seq_len + 3 : nullptr;
-    ro.seq_len = rd.seq_len; ro.reversed = rd.reversed != 0;
+    ro.seq_len = rd.seq_len; ro.reversed = rd.reversed != 0; ro.uracil = A.prm.uracil != 0;
     if (A.hp) {                                  // -k: forward-strand pre-homopolymer read into the scratch buffer
         const uint64_t so = uni64(A.scr_off[r]);
         ro.seq = A.scr + so;
@@ -516,6 +559,10 @@ __global__ void __launch_bounds__(64, NS_MAT_WAVES) k_materialise(GenArgs A, con
         const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi, ev_word);
         materialise_piece(A.m, A.ref, T, ro, key, a, pc, q, lane, ev_word, dbg, sq, (uint32_t)r, pi);
         q += pc.out_len;
+    }
+    if (A.polya) {                                                                          // transcriptome: polyA tail (S:1224-1225)
+        const uint32_t pl = uni(A.polya[r]);
+        if (pl) emit_polya(A.m, ro, key, a, q, pl, rd.head, rd.tail, lane);
     }
 }
 
@@ -811,6 +858,9 @@ struct ns_ctx {
     DevBuf species_chrom_off, t_reads, t_pieces, t_name_len, t_rec_len, t_err_len, accept, accept_scan, key_pos, draw_x, m_segptr,
         m_len, m_species, species_bases;
     DevBuf draw_sel, draw_sorted, meta_words, meta_num;
+    DevBuf trx_chrom, trx_cum, trx_polya, polya;            // transcriptome: expression view of the reference, polyA length per read
+    DevTrx tx{};
+    bool has_trx = false;
     struct PinBuf { void *p = nullptr; size_t cap = 0; } pin_a, pin_b, pin_c;     // pinned host staging of the metagenome passes
     uint32_t nspecies = 0;
     bool has_abun = false, has_inflated = false, has_key_pos = false;
@@ -940,7 +990,7 @@ void ns_destroy(ns_ctx *ctx) {
                       &ctx->scr_len, &ctx->scr_off, &ctx->hp_len, &ctx->slow_q, &ctx->ev_word, &ctx->ev_need, &ctx->species_chrom_off, &ctx->t_reads, &ctx->t_pieces,
                       &ctx->t_name_len, &ctx->t_rec_len, &ctx->t_err_len, &ctx->accept, &ctx->accept_scan, &ctx->key_pos,
                       &ctx->draw_x, &ctx->m_segptr, &ctx->m_len, &ctx->m_species, &ctx->species_bases, &ctx->draw_sel,
-                      &ctx->draw_sorted, &ctx->meta_words, &ctx->meta_num};
+                      &ctx->draw_sorted, &ctx->meta_words, &ctx->meta_num, &ctx->trx_chrom, &ctx->trx_cum, &ctx->trx_polya, &ctx->polya};
     for (auto *pb : {&ctx->pin_a, &ctx->pin_b, &ctx->pin_c})
         if (pb->p) e = hipHostFree(pb->p);
     for (DevBuf *b : bufs)
@@ -956,7 +1006,8 @@ static int set_ref_meta(ns_ctx *ctx, const uint64_t *chrom_off, uint32_t nchrom,
                         const char *names, uint64_t names_len) {
     if (!chrom_off || !nchrom || !circular || !names) return fail(ctx, NS_EINVAL, "reference metadata missing");
     free_pool(ctx->ref_allocs);
-    ctx->nspecies = 0;                           // the species view belongs to the previous reference
+    ctx->nspecies = 0;                           // the species / expression views belong to the previous reference
+    ctx->has_trx = false;
     std::vector<uint32_t> noff(nchrom + 1);
     uint64_t p = 0;
     for (uint32_t c = 0; c < nchrom; ++c) {
@@ -1130,6 +1181,13 @@ int ns_load_model(ns_ctx *ctx, const ns_model_tables *t) {
         if ((rc = upload(ctx, pool, &t->qual_thr[0][0], (size_t)NS_Q_COUNT * NS_QUAL_LEVELS, &m.qual_thr))) return rc;
     memcpy(m.hp, t->hp, sizeof m.hp);
     m.hp_mis_rate = t->hp_mis_rate;
+    if (t->flags & NS_MODEL_HAS_KDE2D) {
+        if (!t->kde2d_n || !(t->kde2d_bw > 0)) return fail(ctx, NS_EINVAL, "empty 2-D KDE");
+        for (uint64_t i = 1; i < t->kde2d_n; ++i)
+            if (t->kde2d_x[i] < t->kde2d_x[i - 1]) return fail(ctx, NS_EINVAL, "kde2d_x must be sorted ascending");
+        if ((rc = upload(ctx, pool, t->kde2d_x, (size_t)t->kde2d_n, &m.kde2d_x)) || (rc = upload(ctx, pool, t->kde2d_y, (size_t)t->kde2d_n, &m.kde2d_y))) return rc;
+        m.kde2d_n = t->kde2d_n; m.kde2d_bw = t->kde2d_bw;
+    }
     ctx->has_model = true;
     return NS_OK;
 }
@@ -1195,6 +1253,32 @@ static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fast
         }
         return NS_OK;
     }
+}
+
+int ns_set_transcriptome(ns_ctx *ctx, uint32_t n_expr, const uint32_t *expr_chrom, const double *expr_cum, const uint8_t *polya,
+                         double polya_scale) {
+    if (!ctx) return NS_EINVAL;
+    if (!ctx->has_ref) return fail(ctx, NS_ESTATE, "ns_set_transcriptome before ns_set_reference");
+    if (!n_expr || !expr_chrom || !expr_cum) return fail(ctx, NS_EINVAL, "empty expression table");
+    for (uint32_t i = 0; i < n_expr; ++i) {
+        if (expr_chrom[i] >= ctx->ref.nchrom) return fail(ctx, NS_EINVAL, "expression table points outside the reference");
+        if (i && expr_cum[i] < expr_cum[i - 1]) return fail(ctx, NS_EINVAL, "expr_cum must be non-decreasing");
+    }
+    if (!(expr_cum[n_expr - 1] > 0)) return fail(ctx, NS_EINVAL, "no expression weight");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->trx_chrom, (size_t)n_expr * 4)) || (rc = ensure(ctx, ctx->trx_cum, (size_t)n_expr * 8))) return rc;
+    HIPCHK(hipMemcpy(ctx->trx_chrom.p, expr_chrom, (size_t)n_expr * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->trx_cum.p, expr_cum, (size_t)n_expr * 8, hipMemcpyHostToDevice));
+    ctx->tx.n_expr = n_expr; ctx->tx.expr_chrom = (const uint32_t *)ctx->trx_chrom.p; ctx->tx.expr_cum = (const double *)ctx->trx_cum.p;
+    ctx->tx.polya = nullptr; ctx->tx.polya_scale = polya_scale;
+    if (polya) {
+        if ((rc = ensure(ctx, ctx->trx_polya, (size_t)ctx->ref.nchrom))) return rc;
+        HIPCHK(hipMemcpy(ctx->trx_polya.p, polya, (size_t)ctx->ref.nchrom, hipMemcpyHostToDevice));
+        ctx->tx.polya = (const uint8_t *)ctx->trx_polya.p;
+    }
+    ctx->has_trx = true;
+    return NS_OK;
 }
 
 int ns_set_species(ns_ctx *ctx, uint32_t nspecies, const uint32_t *species_chrom_off) {
@@ -1522,6 +1606,12 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         if (meta_al && !ctx->has_abun) return fail(ctx, NS_ESTATE, "metagenome batch before ns_set_abundance");
         if (meta_al && prm->chimeric && !ctx->has_inflated) return fail(ctx, NS_EINVAL, "chimeric metagenome batch needs abun_inflated");
     }
+    if (prm->trx) {
+        if (!ctx->has_trx) return fail(ctx, NS_ESTATE, "transcriptome batch before ns_set_transcriptome");
+        if (prm->meta || prm->chimeric || prm->use_lognormal) return fail(ctx, NS_EINVAL, "transcriptome batches are neither metagenome nor chimeric nor log-normal");
+        if (prm->kmer_bias) return fail(ctx, NS_EINVAL, "transcriptome batches do not support -k yet");
+        if (prm->kind != NS_KIND_UNALIGNED && !(ctx->m.flags & NS_MODEL_HAS_KDE2D)) return fail(ctx, NS_EINVAL, "model has no 2-D KDE (_aligned_region_2d)");
+    }
     if (prm->n_reads > 0x7ffffff0ull) return fail(ctx, NS_EINVAL, "batch too large (split into several calls)");
     if (prm->first_read + prm->n_reads >= (1ull << 40)) return fail(ctx, NS_EINVAL, "read index exceeds 2^40");
     HIPCHK(hipSetDevice(ctx->device));
@@ -1557,6 +1647,11 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     A.rstate = (uint32_t *)ctx->rstate.p; A.att_base = (uint32_t *)ctx->att_base.p;
     A.scr_len = (uint64_t *)ctx->scr_len.p; A.scr_off = (uint64_t *)ctx->scr_off.p;
     A.hp = hp_on ? 1u : 0u; A.keep_state = 0;
+    if (prm->trx) {
+        if ((rc = ensure(ctx, ctx->polya, (n + 1) * 2))) return rc;
+        A.tx = ctx->tx; A.polya = (uint16_t *)ctx->polya.p;
+        HIPCHK(hipMemsetAsync(ctx->polya.p, 0, (n + 1) * 2, ctx->stream));
+    }
     A.meta = prm->meta ? 1u : 0u; A.nspecies = ctx->nspecies; A.species_chrom_off = (const uint32_t *)ctx->species_chrom_off.p;
     A.next_n = (uint32_t *)((unsigned long long *)ctx->stats.p + 6);
     uint32_t *list_a = (uint32_t *)ctx->order.p, *list_b = (uint32_t *)ctx->list_b.p;
@@ -1730,6 +1825,7 @@ static int result_buf(ns_ctx *ctx, int which, const void **p, uint64_t *size) {
         case NS_BUF_PIECES: *p = ctx->pieces.p; *size = b.n_pieces * sizeof(ns_piece); return NS_OK;
         case NS_BUF_EVENTS: *p = ctx->events.p; *size = b.n_events * sizeof(ns_event); return NS_OK;
         case NS_BUF_ERRLOG: *p = ctx->errlog.p; *size = b.errlog_bytes; return NS_OK;
+        case NS_BUF_POLYA: *p = ctx->polya.p; *size = ctx->polya.p ? b.n_reads * 2 : 0; return NS_OK;
         default: return NS_EINVAL;
     }
 }

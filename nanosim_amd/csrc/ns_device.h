@@ -37,6 +37,18 @@ struct DevModel {
     const uint32_t *qual_thr;     // [NS_Q_COUNT][NS_QUAL_LEVELS]
     ns_hp_class hp[2];
     double hp_mis_rate;
+    const double *kde2d_x, *kde2d_y;      // transcriptome: 2-D KDE training points sorted by transcript length
+    uint64_t kde2d_n;
+    double kde2d_bw;
+};
+
+// expression view of the reference transcripts (ns_set_transcriptome)
+struct DevTrx {
+    uint32_t n_expr;
+    const uint32_t *expr_chrom;
+    const double *expr_cum;
+    const uint8_t *polya;                 // [nchrom] or nullptr
+    double polya_scale;
 };
 
 struct DevRef {
@@ -251,6 +263,58 @@ __device__ inline bool extract_pos(const DevRef &ref, int64_t length, const ns_k
             if (ref_pos + (uint64_t)length <= cl) { chrom = c; pos = ref_pos; return true; }
             else if (ref_pos < cl) break;
             else ref_pos -= cl;
+        }
+    }
+    return false;
+}
+
+// ---- transcriptome (S:1043-1263 without intron retention) ---------------------------------------------------
+// random.choices(ecdf_length_list, weights) (S:1084): bisect_right over the running sum of the weights, clipped to n - 1
+__device__ inline uint32_t trx_pick(const DevTrx &tx, double u) {
+    const double v = u * tx.expr_cum[tx.n_expr - 1];
+    uint32_t lo = 0, hi = tx.n_expr - 1;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (v < tx.expr_cum[mid]) hi = mid; else lo = mid + 1; }
+    return lo;
+}
+// select_nearest_kde2d (S:108-111) on a fresh, large sample of the 2-D KDE == a draw of the aligned length from the KDE conditioned
+// on the transcript length L: training point i with probability ~ exp(-(L - x_i)^2 / 2h^2), y = y_i + h N(0,1), int().  Rejection
+// sampling inside |x_i - L| <= 5h; no training point there: the nearest one.
+__device__ inline int64_t kde2d_cond(const DevModel &m, double L, const ns_key &key, uint32_t attempt) {
+    const double *__restrict__ x = m.kde2d_x, *__restrict__ y = m.kde2d_y;
+    const double h = m.kde2d_bw;
+    const uint64_t n = m.kde2d_n;
+    uint64_t lo, hi;
+    { uint64_t a = 0, b = n; const double v = L - 5.0 * h; while (a < b) { const uint64_t md = (a + b) >> 1; if (x[md] < v) a = md + 1; else b = md; } lo = a; }
+    { uint64_t a = lo, b = n; const double v = L + 5.0 * h; while (a < b) { const uint64_t md = (a + b) >> 1; if (x[md] <= v) a = md + 1; else b = md; } hi = a; }
+    if (hi > lo) {
+        for (uint32_t j = 0; j < NS_KDE_RETRY; ++j) {
+            const u32x4 w = ns_draw(key, ST_REFLEN, 0, attempt, j, 0);
+            uint64_t i = lo + (uint64_t)(u53_to_p(w.x, w.y) * (double)(hi - lo));
+            if (i >= hi) i = hi - 1;
+            const double dd = (L - x[i]) / h;
+            if (u32_to_p(w.z) <= ns_exp(-0.5 * dd * dd)) return (int64_t)fma(h, ns_norminv(u32_to_p(w.w)), y[i]);
+        }
+    }
+    uint64_t a = 0, b = n;
+    while (a < b) { const uint64_t md = (a + b) >> 1; if (x[md] < L) a = md + 1; else b = md; }
+    uint64_t i = a >= n ? n - 1 : a;
+    if (a > 0 && a < n && L - x[a - 1] <= x[a] - L) i = a - 1;
+    const u32x4 w = ns_draw(key, ST_REFLEN, 0, attempt, NS_KDE_RETRY, 0);
+    return (int64_t)fma(h, ns_norminv(u32_to_p(w.w)), y[i]);
+}
+// extract_read("transcriptome", length) (S:1695-1703): a uniformly drawn transcript that is longer than the read, uniform start
+__device__ inline bool extract_pos_trx_any(const DevRef &ref, int64_t length, const ns_key &key, uint32_t seg, uint32_t attempt,
+                                           uint32_t &chrom, uint64_t &pos) {
+    for (uint32_t j = 0; j < NS_POS_RETRY; ++j) {
+        const u32x4 w = ns_draw(key, ST_POS, seg, attempt, j, 0);
+        const uint32_t c = (uint32_t)(((uint64_t)w.x * ref.nchrom) >> 32);
+        const uint64_t cl = ref.chrom_off[c + 1] - ref.chrom_off[c];
+        if ((uint64_t)length < cl) {
+            const uint64_t span = cl - (uint64_t)length + 1;
+            uint64_t rp = (uint64_t)(u53_to_p(w.y, w.z) * (double)span);
+            if (rp >= span) rp = span - 1;
+            chrom = c; pos = rp;
+            return true;
         }
     }
     return false;

@@ -63,7 +63,14 @@ struct ReadOut {
     uint8_t *qual;       // first quality character, or nullptr
     uint32_t seq_len;
     bool reversed;
+    bool uracil;         // --uracil: T -> U in the emitted bases (S:1247-1248)
 };
+// 'T' (0x54) -> 'U' (0x55) on 8 packed bytes: exact zero-byte detect of x ^ 0x54..54
+__device__ __forceinline__ uint64_t t_to_u8(uint64_t x) {
+    const uint64_t t = x ^ 0x5454545454545454ull;
+    const uint64_t z = ~(((t & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | t) & 0x8080808080808080ull;
+    return x | (z >> 7);
+}
 
 __device__ __forceinline__ void store16(uint8_t *dst, uint32_t count, uint64_t lo, uint64_t hi) {
     if (count == 16) {
@@ -92,6 +99,7 @@ __device__ __forceinline__ void store_chunk(const ReadOut &ro, uint32_t q0, uint
         reverse_bytes(lo, hi, count);
         o0 = ro.seq_len - q0 - count;
     }
+    if (ro.uracil) { lo = t_to_u8(lo); hi = t_to_u8(hi); }
     store16(ro.seq + o0, count, lo, hi);
     if (ro.qual) {
         qlo += 0x2121212121212121ull; qhi += 0x2121212121212121ull;         // chr(q + 33), S:1441
@@ -119,6 +127,7 @@ __device__ __forceinline__ PendingChunk prep_chunk(const ReadOut &ro, uint32_t q
         }
         p.o0 = ro.seq_len - q0 - count;
     }
+    if (ro.uracil) { lo = t_to_u8(lo); hi = t_to_u8(hi); }
     p.lo = lo; p.hi = hi; p.qlo = 0; p.qhi = 0;
     if (ro.qual) {
         qlo += 0x2121212121212121ull; qhi += 0x2121212121212121ull;         // chr(q + 33), S:1441
@@ -172,6 +181,21 @@ __device__ inline void emit_head_tail(const DevModel &m, const ReadOut &ro, cons
             for (uint32_t i = 0; i < count; ++i) put_byte(qlo, qhi, i, qual_draw(qd, m, NS_Q_HT, key, ST_HTQ, 0, a, hq_off + i0 + i));
         }
         store_chunk(ro, q_start + i0, count, lo, hi, qlo, qhi);
+    }
+}
+
+// polyA tail of a transcriptome read (S:1224-1225): `len` A's after the last piece; their qualities are the LAST `len` values of the
+// head/tail quality draw, in reverse order (S:1229-1231: popped from the end and appended)
+__device__ inline void emit_polya(const DevModel &m, const ReadOut &ro, const ns_key &key, uint32_t a, uint32_t q_start, uint32_t len,
+                                  uint32_t head, uint32_t tail, uint32_t lane) {
+    for (uint32_t i0 = lane * 16; i0 < len; i0 += 64 * 16) {
+        const uint32_t count = min(16u, len - i0);
+        uint64_t qlo = 0, qhi = 0;
+        if (ro.qual) {
+            QualDraw qd; qd.blk = 0xffffffffu;
+            for (uint32_t i = 0; i < count; ++i) put_byte(qlo, qhi, i, qual_draw(qd, m, NS_Q_HT, key, ST_HTQ, 0, a, head + tail + len - 1 - (i0 + i)));
+        }
+        store_chunk(ro, q_start + i0, count, 0x4141414141414141ull, 0x4141414141414141ull, qlo, qhi);
     }
 }
 

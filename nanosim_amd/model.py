@@ -14,12 +14,12 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-NS_ABI_VERSION = 1
+NS_ABI_VERSION = 2
 NS_KDE_ALIGNED, NS_KDE_HT, NS_KDE_RATIO, NS_KDE_UNALIGNED, NS_KDE_GAP, NS_KDE_COUNT = 0, 1, 2, 3, 4, 5
 NS_Q_NAMES = ("match", "mis", "ins", "ht", "unmapped")
 NS_QUAL_LEVELS = 128
 NS_HP_MAX_BREAKS = 4
-NS_MODEL_HAS_ERRORS, NS_MODEL_HAS_QUALS, NS_MODEL_HAS_HP, NS_MODEL_HAS_CHIMERIC, NS_MODEL_HAS_UNALIGNED = 1, 2, 4, 8, 16
+NS_MODEL_HAS_ERRORS, NS_MODEL_HAS_QUALS, NS_MODEL_HAS_HP, NS_MODEL_HAS_CHIMERIC, NS_MODEL_HAS_UNALIGNED, NS_MODEL_HAS_KDE2D = 1, 2, 4, 8, 16, 32
 MIX_CAP = 4095
 STATE_NAMES = ("start", "mis", "ins", "del", "mis0", "ins0", "del0")
 
@@ -57,6 +57,7 @@ class NsModelTables(C.Structure):
         ("qual_thr", (C.c_uint32 * NS_QUAL_LEVELS) * 5),
         ("hp", NsHpClass * 2),
         ("hp_mis_rate", C.c_double),
+        ("kde2d_x", C.POINTER(C.c_double)), ("kde2d_y", C.POINTER(C.c_double)), ("kde2d_n", C.c_uint64), ("kde2d_bw", C.c_double),
     ]
 
 
@@ -66,7 +67,7 @@ class NsParams(C.Structure):
                 ("use_lognormal", C.c_uint32), ("emit_records", C.c_uint32),
                 ("min_len", C.c_int64), ("max_len", C.c_int64),
                 ("median_len", C.c_double), ("sd_len", C.c_double),
-                ("emit_errlog", C.c_uint32), ("meta", C.c_uint32)]
+                ("emit_errlog", C.c_uint32), ("meta", C.c_uint32), ("trx", C.c_uint32), ("uracil", C.c_uint32)]
 
 
 class NsBatchInfo(C.Structure):
@@ -248,6 +249,7 @@ class Model:
     qual_thr: np.ndarray | None = None
     hp: dict = field(default_factory=dict)
     hp_mis_rate: float = 0.0
+    kde2d: tuple | None = None                             # transcriptome: (x sorted, y, bandwidth) of _aligned_region_2d
     _keep: list = field(default_factory=list, repr=False)
 
     # -- counts (S:535-542) ---------------------------------------------------
@@ -318,6 +320,10 @@ class Model:
                     t.hp[i].beta[j], t.hp[i].breakpoint[j] = b, bp
                 t.hp[i].intercept, t.hp[i].slope = h["intercept"], h["slope"]
             t.hp_mis_rate = self.hp_mis_rate
+        if self.kde2d is not None:
+            flags |= NS_MODEL_HAS_KDE2D
+            t.kde2d_x, t.kde2d_y = dptr(self.kde2d[0]), dptr(self.kde2d[1])
+            t.kde2d_n, t.kde2d_bw = len(self.kde2d[0]), float(self.kde2d[2])
         t.flags = flags
         return t
 
@@ -339,8 +345,25 @@ def _load_kde(prefix: str, name: str, npz):
     return np.ascontiguousarray(data.reshape(-1)), float(bw)
 
 
+def _load_kde2d(prefix: str, npz):
+    """(x sorted ascending, y in the same order, bandwidth) of the 2-D KDE `_aligned_region_2d` (S:561-565)"""
+    if npz is not None and "aligned_region_2d_data" in npz:
+        data, bw = np.asarray(npz["aligned_region_2d_data"], dtype=np.float64), float(npz["aligned_region_2d_bw"])
+    else:
+        path = prefix + "_aligned_region_2d.pkl"
+        if not os.path.exists(path):
+            return None
+        import joblib
+        kde = joblib.load(path)
+        data = np.asarray(kde.tree_.data, dtype=np.float64)
+        bw = getattr(kde, "bandwidth_", None)
+        bw = float(kde.bandwidth if bw is None else bw)
+    order = np.argsort(data[:, 0], kind="stable")
+    return np.ascontiguousarray(data[order, 0]), np.ascontiguousarray(data[order, 1]), bw
+
+
 def load_model(prefix: str, *, perfect: bool = False, strandness: float | None = None, chimeric: bool = False,
-               homopolymer: bool = False, fastq: bool = False, need_unaligned: bool = True) -> Model:
+               homopolymer: bool = False, fastq: bool = False, need_unaligned: bool = True, transcriptome: bool = False) -> Model:
     """Mirror of read_profile()'s model half for genome/metagenome mode (src/simulator.py:268-275,465-591)."""
     m = Model(prefix=prefix, perfect=perfect)
     if strandness is None:
@@ -414,7 +437,13 @@ def load_model(prefix: str, *, perfect: bool = False, strandness: float | None =
     m.kde[NS_KDE_HT] = _load_kde(prefix, "ht_length", npz)                  # S:552
     m.kde[NS_KDE_RATIO] = _load_kde(prefix, "ht_ratio", npz)                # S:555
     m.kde[NS_KDE_ALIGNED] = _load_kde(prefix, "aligned_reads" if perfect else "aligned_region", npz)  # S:559-567
-    for k in (NS_KDE_HT, NS_KDE_RATIO, NS_KDE_ALIGNED):
+    if transcriptome:                                                       # S:559-565: the 2-D KDE replaces the aligned-length KDE
+        m.kde2d = _load_kde2d(prefix, npz)
+        if m.kde2d is None:
+            raise FileNotFoundError("missing 2-D KDE (_aligned_region_2d) for model prefix " + prefix)
+        if m.kde[NS_KDE_ALIGNED] is None:
+            del m.kde[NS_KDE_ALIGNED]
+    for k in (NS_KDE_HT, NS_KDE_RATIO) + (() if transcriptome else (NS_KDE_ALIGNED,)):
         if m.kde[k] is None:
             raise FileNotFoundError("missing KDE for model prefix " + prefix)
     if chimeric:                                                            # S:571-577

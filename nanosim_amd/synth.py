@@ -32,6 +32,8 @@ class SynthModelSpec:
     gap_sigma: float = 1.0
     alignment_ratio: float = 19.0       # aligned/unaligned
     strandness: float = 0.5
+    trx_median: float = 1400.0          # transcriptome: transcript lengths behind the 2-D KDE (_aligned_region_2d)
+    trx_sigma: float = 0.6
     segment_mean: float = 1.05
     abun_inflation: float = 0.25        # metagenome only ("Shrinkage rate (beta)")
     # mixture parameters: [lambda, k, prob, weight]  (src/model_fitting.py:136,169,203)
@@ -109,6 +111,10 @@ def write_model(prefix: str, spec: SynthModelSpec | None = None, *, write_pkl: b
     gap = np.log10(np.rint(rng.lognormal(np.log(spec.gap_median), spec.gap_sigma, n)) + 1.0)
     # aligned_reads (perfect mode) = whole read length
     aligned_reads = aligned + ht_len
+    # transcriptome: (transcript length, aligned length) pairs; most reads cover most of their transcript
+    trx_len = np.maximum(200.0, np.rint(rng.lognormal(np.log(spec.trx_median), spec.trx_sigma, n)))
+    trx_aligned = np.maximum(50.0, np.rint(trx_len * rng.beta(5.0, 1.5, n)))
+    pairs = np.stack([trx_len, trx_aligned], axis=1)
     kdes = {
         "aligned_region": (aligned, 10.0), "aligned_reads": (aligned_reads, 10.0),
         "unaligned_length": (unaligned, 10.0), "ht_length": (ht, 0.01), "ht_ratio": (ratio, 0.01),
@@ -116,13 +122,15 @@ def write_model(prefix: str, spec: SynthModelSpec | None = None, *, write_pkl: b
     }
     if write_npz:
         np.savez(prefix + "_kde.npz", **{k + "_data": v[0] for k, v in kdes.items()},
-                 **{k + "_bw": np.float64(v[1]) for k, v in kdes.items()})
+                 **{k + "_bw": np.float64(v[1]) for k, v in kdes.items()},
+                 aligned_region_2d_data=pairs, aligned_region_2d_bw=np.float64(10.0))
     if write_pkl:
         import joblib
         from sklearn.neighbors import KernelDensity
         for name, (vec, bw) in kdes.items():
             kde = KernelDensity(bandwidth=bw).fit(vec[:, None])
             joblib.dump(kde, prefix + "_" + name + ".pkl")
+        joblib.dump(KernelDensity(bandwidth=10.0).fit(pairs), prefix + "_aligned_region_2d.pkl")
 
     # --- text tables -----------------------------------------------------------------------
     with open(prefix + "_model_profile", "w") as f:           # src/model_fitting.py:110,136,169,203
@@ -222,3 +230,26 @@ CHR1_LEN = 248_956_422
 GRCH38_LENS = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636,
                138394717, 133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345,
                83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415]
+
+
+def synth_transcriptome(n_trx: int, seed: int, *, median: float = 1400.0, sigma: float = 0.6, polya_frac: float = 0.6,
+                        zero_tpm_frac: float = 0.2):
+    """Synthetic transcriptome: [(name, bases)] with versioned Ensembl-like ids, an expression table (id, est_counts, tpm) in the
+    layout of the -e file (S:382-399) and the ids of the transcripts carrying a polyA tail (--polya, S:460-470)."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    lens = np.clip(np.rint(rng.lognormal(np.log(median), sigma, n_trx)), 150, 30000).astype(np.int64)
+    recs = []
+    for i, l in enumerate(lens):
+        recs.append(("ENST%011d.%d" % (i + 1, 1 + i % 3), synth_sequence(int(l), seed * 1000003 + i, iupac_frac=0.0005 if i % 7 == 0 else 0.0)))
+    tpm = rng.lognormal(1.0, 2.0, n_trx)
+    tpm[rng.random(n_trx) < zero_tpm_frac] = 0.0
+    polya = [recs[i][0] for i in range(n_trx) if rng.random() < polya_frac]
+    expr = [(recs[i][0], float(tpm[i] * 3.0), float(tpm[i])) for i in range(n_trx)]
+    return recs, expr, polya
+
+
+def write_expression(path: str, expr) -> None:
+    with open(path, "w") as f:
+        f.write("target_id\test_counts\ttpm\n")
+        for tid, cnt, tpm in expr:
+            f.write("%s\t%s\t%s\n" % (tid, repr(cnt), repr(tpm)))

@@ -651,6 +651,7 @@ typedef struct nso_out {
     uint8_t *records; uint64_t cap_records;
     uint8_t *errlog; uint64_t cap_errlog;
     uint64_t n_pieces, n_events, record_bytes, errlog_bytes, total_bases, total_ref_bases;
+    uint16_t *polya;                 /* transcriptome: polyA tail length per read (may be NULL) */
 } nso_out;
 
 #define NSO_MAX_SEG 64
@@ -771,6 +772,73 @@ int nso_extract_meta(const nso_meta *mg, const uint64_t *chrom_off, const uint8_
     return warned;
 }
 
+/* ================================================================================================
+ * transcriptome mode (without intron retention)
+ * ============================================================================================== */
+enum { ST_TRX = 22 };
+
+typedef struct nso_trx {             /* expression view of the reference transcripts (src/simulator.py:382-399, 460-470) */
+    uint32_t n_expr;
+    const uint32_t *expr_chrom;          /* transcripts with TPM > 0 in the order of make_cdf (S:69-97) */
+    const double *expr_cum;              /* running sum of ecdf_weight_list, as random.choices accumulates it (S:1084) */
+    const uint8_t *polya;                /* [nchrom] 1 = listed in --polya, or NULL */
+    double polya_scale;                  /* S:1046-1049 */
+} nso_trx;
+
+/* random.choices(population, weights): bisect_right(cum_weights, random() * total, 0, n - 1) */
+uint32_t nso_trx_pick(const nso_trx *tx, double u) {
+    const double v = u * tx->expr_cum[tx->n_expr - 1];
+    uint32_t lo = 0, hi = tx->n_expr - 1;
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (v < tx->expr_cum[mid]) hi = mid; else lo = mid + 1; }
+    return lo;
+}
+
+/* select_nearest_kde2d (S:108-111) on a fresh, large sample of the 2-D KDE == a draw of the aligned length from the KDE
+ * conditioned on the transcript length L: training point i with probability proportional to exp(-(L - x_i)^2 / 2h^2), then
+ * y = y_i + h * N(0,1), int() truncation.  Rejection sampling inside the window |x_i - L| <= 5h; without a training point in the
+ * window: the nearest one.  Draws: Philox (ST_REFLEN, seg 0, attempt, idx = try). */
+int64_t nso_kde2d_cond(const ns_model_tables *t, double L, nso_draw *d, uint32_t attempt) {
+    const double *x = t->kde2d_x, *y = t->kde2d_y, h = t->kde2d_bw;
+    const uint64_t n = t->kde2d_n;
+    uint64_t lo = 0, hi = n;
+    { uint64_t a = 0, b = n; const double v = L - 5.0 * h; while (a < b) { uint64_t m = (a + b) >> 1; if (x[m] < v) a = m + 1; else b = m; } lo = a; }
+    { uint64_t a = lo, b = n; const double v = L + 5.0 * h; while (a < b) { uint64_t m = (a + b) >> 1; if (x[m] <= v) a = m + 1; else b = m; } hi = a; }
+    uint32_t w[4];
+    if (hi > lo) {
+        for (uint32_t j = 0; j < NSO_KDE_RETRY; ++j) {
+            philox_at(d, ST_REFLEN, 0, attempt, j, 0, w);
+            uint64_t i = lo + (uint64_t)(u53_to_p(w[0], w[1]) * (double)(hi - lo));
+            if (i >= hi) i = hi - 1;
+            const double dd = (L - x[i]) / h;
+            if (u32_to_p(w[2]) <= nso_exp(-0.5 * dd * dd)) return (int64_t)fma(h, nso_norminv(u32_to_p(w[3])), y[i]);
+        }
+    }
+    uint64_t a = 0, b = n;
+    while (a < b) { uint64_t m = (a + b) >> 1; if (x[m] < L) a = m + 1; else b = m; }
+    uint64_t i = a >= n ? n - 1 : a;
+    if (a > 0 && a < n && L - x[a - 1] <= x[a] - L) i = a - 1;
+    philox_at(d, ST_REFLEN, 0, attempt, NSO_KDE_RETRY, 0, w);
+    return (int64_t)fma(h, nso_norminv(u32_to_p(w[3])), y[i]);
+}
+
+/* extract_read("transcriptome", length) (S:1695-1703): a uniformly drawn transcript that is longer than the read, uniform start */
+static int extract_trx_unaligned(const uint64_t *chrom_off, uint32_t nchrom, int64_t length, nso_draw *d, uint32_t seg, uint32_t attempt,
+                                 uint32_t *chrom, uint64_t *pos) {
+    uint32_t w[4];
+    for (uint32_t j = 0; j < NSO_POS_RETRY; ++j) {
+        philox_at(d, ST_POS, seg, attempt, j, 0, w);
+        uint32_t c = (uint32_t)(((uint64_t)w[0] * nchrom) >> 32);
+        uint64_t cl = chrom_off[c + 1] - chrom_off[c];
+        if ((uint64_t)length < cl) {
+            uint64_t span = cl - (uint64_t)length + 1, rp = (uint64_t)(u53_to_p(w[1], w[2]) * (double)span);
+            if (rp >= span) rp = span - 1;
+            *chrom = c; *pos = rp;
+            return 0;
+        }
+    }
+    return -1;
+}
+
 /* one read of a metagenome pass: lengths / species come from assign_species, the strand from the pass (S:860) */
 typedef struct nso_mread {
     uint32_t pass, nseg, pos_in_pass, reversed;
@@ -792,7 +860,7 @@ static int u64_digits(uint64_t v, char *buf) { return sprintf(buf, "%llu", (unsi
 
 /* Generates read `index` of the batch.  Returns 0, or <0 if buffers are too small / attempts exhausted. */
 static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_params *prm, uint64_t index, nso_out *o,
-                    const nso_mread *mr, const nso_meta *mg) {
+                    const nso_mread *mr, const nso_meta *mg, const nso_trx *tx) {
     nso_draw d; memset(&d, 0, sizeof d);
     d.mode = 0; d.seed = prm->seed; d.read = prm->first_read + (mr ? mr->pos_in_pass : index);
     if (mr) index = mr->seq_index;
@@ -806,6 +874,7 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
         if (nseg > NSO_MAX_SEG) nseg = NSO_MAX_SEG;
     }
     uint32_t epoch = 0, fails = 0;
+    uint32_t trx_chrom = 0; int64_t trx_len = 0;
     for (uint32_t a = mr ? mr->pass : 0; a < NSO_MAX_ATTEMPT; ++a) {
         int64_t ref_len[NSO_MAX_SEG], gap_len[NSO_MAX_SEG];
         int ok = 1;
@@ -816,6 +885,12 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
             double x = prm->use_lognormal ? nso_exp(fma(prm->sd_len, nso_norminv(u32_to_p(w[2])), nso_log(prm->median_len)))
                                           : kde_sample(&t->kde[NS_KDE_UNALIGNED], w);
             ref_len[0] = (int64_t)x;
+        } else if (tx) {                                                  /* transcriptome, S:1082-1105 */
+            philox_at(&d, ST_TRX, 0, a, 0, 0, w);
+            trx_chrom = tx->expr_chrom[nso_trx_pick(tx, u53_to_p(w[0], w[1]))];
+            trx_len = (int64_t)(ref->chrom_off[trx_chrom + 1] - ref->chrom_off[trx_chrom]);
+            ref_len[0] = nso_kde2d_cond(t, (double)trx_len, &d, a);
+            if (!(ref_len[0] > 0 && ref_len[0] < trx_len)) ok = 0;        /* S:1103-1104: ref_len_aligned < ref_trx_len */
         } else if (mr) {                                                  /* S:871-872 (aligned and --perfect) */
             for (uint32_t s = 0; s < nseg; ++s) ref_len[s] = mr->ref_len[s];
             for (uint32_t g = 0; g + 1 < nseg; ++g) {
@@ -854,6 +929,16 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
             }
         }
         int64_t remainder = 0; double ratio = 0; int reversed;
+        if (tx && kind == NS_KIND_ALIGNED) {                               /* S:1073-1076, 1203-1204: one draw per read, no filter */
+            philox_at(&d, ST_HT, 0, 0, 0, 0, w);
+            double x = pow10m1(kde_sample(&t->kde[NS_KDE_HT], w));
+            remainder = (int64_t)x;                                        /* int(): towards zero */
+            if (remainder < 0) remainder = 0;
+            philox_at(&d, ST_RATIO, 0, 0, 0, 0, w);
+            ratio = kde_sample(&t->kde[NS_KDE_RATIO], w);
+            if (ratio > 1) ratio = 1;
+            if (ratio < 0) ratio = 0;
+        } else
         if (kind == NS_KIND_ALIGNED && ok) {                               /* S:1471-1474,1351-1352 */
             uint32_t j = 0;
             for (; j < NSO_KDE_RETRY; ++j) {
@@ -902,6 +987,10 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
             if (kind == NS_KIND_UNALIGNED) total = r.middle_ref;            /* S:1503 */
         }
         if (overflow) return -11;
+        if (tx && kind != NS_KIND_UNALIGNED) {                              /* S:1143-1144: middle_ref > ref_trx_len -> start over */
+            if ((int64_t)pc[0].ref_len > trx_len) continue;
+            total = remainder + pc[0].out_len;
+        } else
         if (mr) {                                                           /* S:907-946: middle_ref and gap lengths count; --perfect: S:896-897 */
             int64_t tot = remainder; int restart = 0;
             for (uint32_t pi = 0; pi < n_pieces && !restart; pi += 2) { if (tot + pc[pi].ref_len > prm->max_len) restart = 1; else tot += pc[pi].ref_len; }
@@ -928,6 +1017,14 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
             uint32_t chrom = 0; uint64_t pos = 0;
             if (pc[pi].kind && kind == NS_KIND_ALIGNED && gap_len[pi >> 1] == 0) {   /* S:1553-1554 */
                 pc[pi].ref_len = 0; pc[pi].out_len = 0; pc[pi].n_ev = 0;
+            } else if (tx && kind != NS_KIND_UNALIGNED) {                 /* extract_read_trx, S:1683-1691 */
+                philox_at(&d, ST_POS, sid, a, 0, 0, w);
+                uint64_t span = (uint64_t)(trx_len - (int64_t)pc[pi].ref_len) + 1;
+                pos = (uint64_t)(u53_to_p(w[0], w[1]) * (double)span);
+                if (pos >= span) pos = span - 1;
+                chrom = trx_chrom;
+            } else if (tx) {                                              /* extract_read("transcriptome", len), S:1695-1703 */
+                if (extract_trx_unaligned(ref->chrom_off, ref->nchrom, pc[pi].ref_len, &d, sid, a, &chrom, &pos)) { pos_ok = 0; break; }
             } else if (mg) {                                              /* extract_read("metagenome", len, species), S:1704-1749 */
                 int sp = (mr && !pc[pi].kind) ? (int)mr->species[pi >> 1] : -1;     /* gaps / unaligned reads: any species (S:1557, 1510) */
                 if (nso_extract_meta(mg, ref->chrom_off, ref->circular, pc[pi].ref_len, sp, &d, sid, a, &chrom, &pos) < 0) { pos_ok = 0; break; }
@@ -939,6 +1036,14 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
             seq_len += pc[pi].out_len;
         }
         if (!pos_ok) { ++epoch; fails = 0; continue; }
+        int64_t polya_len = 0;                                             /* S:1046-1053, 1206-1209, 1683-1691 */
+        if (tx && kind != NS_KIND_UNALIGNED && tx->polya && tx->polya[trx_chrom] &&
+            (int64_t)pc[0].pos + (int64_t)pc[0].ref_len + 10 >= trx_len) {
+            philox_at(&d, ST_TRX, 0, a, 1, 0, w);
+            polya_len = (int64_t)fma(tx->polya_scale, -nso_log(u32_to_p(w[0])), 2.0);      /* int(expon.rvs(loc=2, scale)) */
+            if (polya_len > 65535) polya_len = 65535;
+            seq_len += polya_len;
+        }
         uint64_t gidx = prm->first_read + index;
         /* name (S:1390-1402, 1332-1343, 1511, 1529-1534) */
         char name[4096]; int nl = 0; char num[32];
@@ -970,7 +1075,7 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
             first = 0;
             nl += u64_digits(pc[pi].ref_len, name + nl);
         }
-        name[nl++] = '_'; nl += u64_digits((uint64_t)tail, name + nl);
+        name[nl++] = '_'; nl += u64_digits((uint64_t)(tail + polya_len), name + nl);      /* S:1211-1213: tail + polya_len */
         (void)num;
 
         /* ---- -k: homopolymer filter + mutate_homo on every aligned segment (S:1406-1414); lengths change here ---- */
@@ -1026,7 +1131,8 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
             }
         }
 #define NSO_HP_FREE() do { for (uint32_t z_ = 0; z_ < n_pieces; ++z_) { free(hp_seq[z_]); free(hp_q[z_]); } free(hp_log); } while (0)
-        if (seq_len < prm->min_len || seq_len > prm->max_len) { NSO_HP_FREE(); ++epoch; fails = 0; continue; }   /* S:1429-1430, S:1518-1519 */
+        if (!(tx && kind != NS_KIND_UNALIGNED) &&                                        /* (no length limits on aligned transcriptome reads) */
+            (seq_len < prm->min_len || seq_len > prm->max_len)) { NSO_HP_FREE(); ++epoch; fails = 0; continue; }   /* S:1429-1430, S:1518-1519 */
 
         /* ---- accepted: materialise ---- */
         ns_read *rd = &o->reads[index];
@@ -1096,6 +1202,12 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
             o->errlog_bytes += hp_log_len;
         }
         NSO_HP_FREE();
+        for (int64_t k2 = 0; k2 < polya_len; ++k2) {          /* S:1224-1225; qualities: popped from the end of the ht draw, S:1229-1231 */
+            seq[wq] = 'A';
+            if (qual) qual[wq] = qual_at(t, NS_Q_HT, &d, ST_HTQ, 0, a, (uint64_t)(head + tail + polya_len - 1 - k2));
+            ++wq;
+        }
+        if (o->polya) o->polya[index] = (uint16_t)polya_len;
         for (int64_t i = 0; i < tail; ++i) {                  /* S:1427 */
             seq[wq] = ht_letter(&d, ST_TAIL, a, (uint32_t)i);
             if (qual) qual[wq] = qual_at(t, NS_Q_HT, &d, ST_HTQ, 0, a, (uint64_t)(head + i));
@@ -1111,6 +1223,7 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
                 if (qual) { uint8_t tq = qual[i]; qual[i] = qual[j]; qual[j] = tq; }
             }
         }
+        if (prm->uracil) for (int64_t i = 0; i < seq_len; ++i) if (seq[i] == 'T') seq[i] = 'U';      /* S:1247-1248 */
         seq[seq_len] = '\n';
         if (qual) {                                           /* S:1440-1443 */
             seq[seq_len + 1] = '+'; seq[seq_len + 2] = '\n';
@@ -1135,7 +1248,21 @@ int nso_generate(const ns_model_tables *t, const uint8_t *bases, const uint64_t 
     nso_ref ref = {bases, chrom_off, nchrom, circular, names};
     o->n_pieces = o->n_events = o->record_bytes = o->errlog_bytes = o->total_bases = o->total_ref_bases = 0;
     int rc = 0;
-    for (uint64_t i = 0; i < prm->n_reads && rc == 0; ++i) rc = gen_read(t, &ref, prm, i, o, NULL, NULL);
+    for (uint64_t i = 0; i < prm->n_reads && rc == 0; ++i) rc = gen_read(t, &ref, prm, i, o, NULL, NULL, NULL);
+    free((void *)names);
+    return rc;
+}
+
+/* transcriptome batch: simulation_aligned_transcriptome (S:1043-1263, no intron retention) / simulation_unaligned("transcriptome") */
+int nso_generate_trx(const ns_model_tables *t, const uint8_t *bases, const uint64_t *chrom_off, uint32_t nchrom,
+                     const uint8_t *circular, const char *names_blob, const nso_trx *tx, const ns_params *prm, nso_out *o) {
+    const char **names = (const char **)malloc(sizeof(char *) * (nchrom + 1));
+    const char *p = names_blob;
+    for (uint32_t c = 0; c < nchrom; ++c) { names[c] = p; p += strlen(p) + 1; }
+    nso_ref ref = {bases, chrom_off, nchrom, circular, names};
+    o->n_pieces = o->n_events = o->record_bytes = o->errlog_bytes = o->total_bases = o->total_ref_bases = 0;
+    int rc = 0;
+    for (uint64_t i = 0; i < prm->n_reads && rc == 0; ++i) rc = gen_read(t, &ref, prm, i, o, NULL, NULL, tx);
     free((void *)names);
     return rc;
 }
@@ -1190,7 +1317,7 @@ int nso_generate_meta(const ns_model_tables *t, const uint8_t *bases, const uint
     const uint64_t n = prm->n_reads;
     int rc = 0;
     if (prm->kind == NS_KIND_UNALIGNED) {                /* random species per read, otherwise the genome-mode loop */
-        for (uint64_t i = 0; i < n && rc == 0; ++i) rc = gen_read(t, &ref, prm, i, o, NULL, mg);
+        for (uint64_t i = 0; i < n && rc == 0; ++i) rc = gen_read(t, &ref, prm, i, o, NULL, mg, NULL);
         free((void *)names);
         return rc;
     }
@@ -1240,7 +1367,7 @@ int nso_generate_meta(const ns_model_tables *t, const uint8_t *bases, const uint
             nso_mread mr; mr.pass = p; mr.nseg = ns; mr.pos_in_pass = (uint32_t)i; mr.reversed = reversed;
             mr.seq_index = passed + accepted; mr.ref_len = rl; mr.species = species + seg_ptr;
             const uint64_t piece0 = o->n_pieces;
-            int r1 = gen_read(t, &ref, prm, i, o, &mr, mg);
+            int r1 = gen_read(t, &ref, prm, i, o, &mr, mg, NULL);
             if (r1 < 0) rc = r1;
             else if (r1 == 0) {
                 for (uint32_t s2 = 0; s2 < ns && !perfect; ++s2)                      /* S:1001-1002 (only in the branch with errors) */

@@ -566,6 +566,125 @@ def fixture_metagenome_perfect(prefix, workdir, n_reads=8000):
                               sorted_desc_frac=float(np.mean(np.diff(r["lens"]) <= 0))) for r in res])
 
 
+TRX_DIR = os.path.join(HERE, "trx")
+
+
+def build_trx_inputs():
+    os.makedirs(TRX_DIR, exist_ok=True)
+    recs, expr, polya = synth.synth_transcriptome(240, 77)
+    synth.write_fasta(os.path.join(TRX_DIR, "transcripts.fa"), recs)
+    synth.write_expression(os.path.join(TRX_DIR, "expression.tsv"), expr)
+    with open(os.path.join(TRX_DIR, "polya.txt"), "w") as f:
+        f.write("\n".join(polya) + "\n")
+
+
+def _trx_profile(S, prefix, perfect=False, fastq=False):
+    so = sys.stdout
+    sys.stdout = open(os.devnull, "w")
+    try:
+        S.read_profile("", [1000], prefix, perfect, "transcriptome", None, ref_t=os.path.join(TRX_DIR, "transcripts.fa"),
+                       polya=os.path.join(TRX_DIR, "polya.txt"), exp=os.path.join(TRX_DIR, "expression.tsv"), model_ir=False,
+                       fastq=fastq)
+    finally:
+        sys.stdout = so
+
+
+def fixture_transcriptome(S, prefix):
+    """make_cdf, random.choices and extract_read_trx pinned by value (S:69-97, 1084, 1683-1691)"""
+    _trx_profile(S, prefix)
+    fx = dict(ecdf_length_list=[[k, int(v)] for k, v in S.ecdf_length_list], ecdf_weight_list=[float(x) for x in S.ecdf_weight_list],
+              seq_len={k: int(v) for k, v in list(S.seq_len.items())[:20]}, n_trx=len(S.seq_len),
+              polya=sorted(S.trx_with_polya.keys())[:20], n_polya=len(S.trx_with_polya))
+    us = [0.0, 1e-9, 0.013, 0.25, 0.5, 0.77, 0.9, 0.99, 0.999999, 0.37, 0.61]
+    picks = []
+    for u in us:                                       # random.choices calls the hidden instance's method, not the module attribute
+        random._inst.random = lambda u=u: u
+        try:
+            picks.append(list(random.choices(S.ecdf_length_list, weights=S.ecdf_weight_list, k=1)[0]))
+        finally:
+            del random._inst.random
+    fx["choices"] = dict(u=us, picks=[[p[0], int(p[1])] for p in picks])
+    ext = []
+    keys = list(S.seq_len.keys())
+    S.trx_with_polya = S.trx_with_polya
+    for i in range(40):
+        key = keys[(i * 7) % len(keys)]
+        length = max(1, S.seq_len[key] - (i * 13) % 60)
+        rec = {}
+        orig_ri = random.randint
+        def ri(a, b, rec=rec):
+            v = orig_ri(a, b)
+            rec.update(a=a, b=b, v=v)
+            return v
+        random.randint = ri
+        try:
+            read, pos, retain = S.extract_read_trx(key, length, key in S.trx_with_polya)
+        finally:
+            random.randint = orig_ri
+        ext.append(dict(key=key, length=length, randint=[rec["a"], rec["b"], rec["v"]], pos=pos, retain=bool(retain), head=read[:12]))
+    fx["extract_read_trx"] = ext
+    samp = np.array([[100.0, 80.2], [250.0, 200.9], [251.0, 10.5], [1000.0, 999.99], [4000.0, 3500.4]])
+    fx["select_nearest"] = [[L, int(S.select_nearest_kde2d(samp, L))] for L in (1, 120, 250.4, 250.6, 2000, 2600, 9999)]
+    return fx
+
+
+def _trx_worker(args):
+    idx, n_al, prefix, workdir, perfect, uracil = args
+    S = import_reference()
+    _trx_profile(S, prefix, perfect=perfect)
+    S.total_simulated = mp.Value("i", 0, lock=True)
+    random.seed(9000 + idx); np.random.seed(9000 + idx)
+    tag = "%d_%d_%d" % (idx, perfect, uracil)
+    o_reads = os.path.join(workdir, "t%s.fasta" % tag); o_err = os.path.join(workdir, "te%s" % tag)
+    so = sys.stdout; se = sys.stderr
+    sys.stdout = open(os.devnull, "w"); sys.stderr = open(os.devnull, "w")
+    try:
+        S.simulation_aligned_transcriptome(False, o_reads, o_err, None, "guppy", n_al, True, False, perfect, uracil)
+    finally:
+        sys.stdout = so; sys.stderr = se
+    lines = open(o_reads).read().split("\n")
+    names = [x[1:] for x in lines[0:-1:2]]
+    seqs = lines[1:-1:2]
+    out = dict(trx=[], pos=[], head=[], mid=[], tailp=[], rev=[], seq_len=[len(x) for x in seqs], names=names[:5],
+               has_t=any("T" in x for x in seqs[:200]), has_u=any("U" in x for x in seqs[:200]))
+    for nm in names:
+        body, _, rest = nm.partition("_perfect_" if perfect else "_aligned_")
+        trx, pos = body.rsplit("_", 1)
+        f = rest.split("_")
+        out["trx"].append(trx); out["pos"].append(int(pos)); out["rev"].append(f[1] == "R")
+        out["head"].append(int(f[2])); out["mid"].append(int(f[3])); out["tailp"].append(int(f[4]))
+    out["seq_lens_of"] = {k: int(v) for k, v in S.seq_len.items()}
+    out["polya_listed"] = sorted(S.trx_with_polya.keys())
+    return out
+
+
+def fixture_transcriptome_runs(prefix, workdir, n_reads=16000):
+    out = {}
+    n_proc = min(8, os.cpu_count() or 1)
+    for name, perfect, uracil in (("aligned", False, False), ("perfect", True, True)):
+        with mp.get_context("fork").Pool(n_proc) as pool:
+            res = pool.map(_trx_worker, [(i, n_reads // n_proc, prefix, workdir, perfect, uracil) for i in range(n_proc)])
+        lens = res[0]["seq_lens_of"]
+        listed = set(res[0]["polya_listed"])
+        trx = [t for r in res for t in r["trx"]]
+        mid = np.array([m for r in res for m in r["mid"]], dtype=np.float64)
+        pos = np.array([m for r in res for m in r["pos"]], dtype=np.float64)
+        tl = np.array([lens[t] for t in trx], dtype=np.float64)
+        tailp = np.array([m for r in res for m in r["tailp"]], dtype=np.float64)
+        head = np.array([m for r in res for m in r["head"]], dtype=np.float64)
+        seq_len = np.array([m for r in res for m in r["seq_len"]], dtype=np.float64)
+        reach = np.array([(t in listed) and (p + m + 10 >= l) for t, p, m, l in zip(trx, pos, mid, tl)])
+        counts = {}
+        for t in trx:
+            counts[t] = counts.get(t, 0) + 1
+        out[name] = dict(n=len(trx), counts=counts, q_mid=quantiles(mid), q_frac=quantiles(mid / tl), q_start_frac=quantiles(pos / np.maximum(1, tl - mid)),
+                         q_tailp=quantiles(tailp), q_head=quantiles(head), q_seq_len=quantiles(seq_len), frac_rev=float(np.mean([x for r in res for x in r["rev"]])),
+                         frac_reach_end=float(reach.mean()), q_tailp_reach=quantiles(tailp[reach]) if reach.any() else [],
+                         q_tailp_noreach=quantiles(tailp[~reach]), first_names=res[0]["names"], has_t=any(r["has_t"] for r in res),
+                         has_u=any(r["has_u"] for r in res))
+    return out
+
+
 def fixture_metagenome_runs(prefix, workdir, n_reads=24000):
     out = {}
     for chim in (False, True):
@@ -680,10 +799,19 @@ def main():
     ap.add_argument("--dist-reads", type=int, default=100000)
     ap.add_argument("--skip-dist", action="store_true")
     ap.add_argument("--only-meta-perfect", action="store_true", help="add runs.perfect to reference_metagenome.json, keep the rest")
+    ap.add_argument("--only-trx", action="store_true", help="write reference_transcriptome.json only")
     a = ap.parse_args()
     workdir = tempfile.mkdtemp(prefix="nsgolden_")
     try:
         prefix, fasta, circ = build_inputs(workdir)
+        if a.only_trx:
+            build_trx_inputs()
+            fx = fixture_transcriptome(import_reference(), prefix)
+            fx["runs"] = fixture_transcriptome_runs(prefix, workdir)
+            with open(os.path.join(HERE, "reference_transcriptome.json"), "w") as f:
+                json.dump(fx, f)
+            print("reference_transcriptome.json written")
+            return
         if a.only_meta_perfect:
             mg = json.load(open(os.path.join(HERE, "reference_metagenome.json")))
             mg["runs"]["perfect"] = fixture_metagenome_perfect(prefix, workdir)

@@ -32,7 +32,13 @@ class NsoOut(C.Structure):
                 ("records", C.c_void_p), ("cap_records", C.c_uint64),
                 ("errlog", C.c_void_p), ("cap_errlog", C.c_uint64),
                 ("n_pieces", C.c_uint64), ("n_events", C.c_uint64), ("record_bytes", C.c_uint64),
-                ("errlog_bytes", C.c_uint64), ("total_bases", C.c_uint64), ("total_ref_bases", C.c_uint64)]
+                ("errlog_bytes", C.c_uint64), ("total_bases", C.c_uint64), ("total_ref_bases", C.c_uint64),
+                ("polya", C.c_void_p)]
+
+
+class NsoTrx(C.Structure):
+    _fields_ = [("n_expr", C.c_uint32), ("expr_chrom", C.POINTER(C.c_uint32)), ("expr_cum", C.POINTER(C.c_double)),
+                ("polya", C.POINTER(C.c_uint8)), ("polya_scale", C.c_double)]
 
 
 class NsoMeta(C.Structure):
@@ -111,6 +117,11 @@ def lib():
         L.nso_generate_meta.restype = C.c_int
         L.nso_generate_meta.argtypes = [C.POINTER(NsModelTables), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_char_p,
                                         C.POINTER(NsoMeta), C.POINTER(NsParams), C.POINTER(NsoOut), C.c_void_p]
+        L.nso_generate_trx.restype = C.c_int
+        L.nso_generate_trx.argtypes = [C.POINTER(NsModelTables), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_char_p,
+                                       C.POINTER(NsoTrx), C.POINTER(NsParams), C.POINTER(NsoOut)]
+        L.nso_trx_pick.restype = C.c_uint32
+        L.nso_trx_pick.argtypes = [C.POINTER(NsoTrx), C.c_double]
         L.nso_generate.restype = C.c_int
         L.nso_generate.argtypes = [C.POINTER(NsModelTables), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
                                    C.c_char_p, C.POINTER(NsParams), C.POINTER(NsoOut)]
@@ -205,3 +216,44 @@ def generate_meta(model, meta_ref, abun: dict, abun_inflated, params: NsParams, 
     return dict(reads=reads, pieces=pieces[:o.n_pieces], events=events[:o.n_events], records=records[:o.record_bytes],
                 errlog=errlog[:o.errlog_bytes], total_bases=int(o.total_bases), total_ref_bases=int(o.total_ref_bases),
                 species_bases=sp_bases)
+
+
+def make_trx(tr):
+    """tr: nanosim_amd.transcriptome.TranscriptomeReference -> (NsoTrx, keep-alive list)"""
+    ec = np.ascontiguousarray(tr.expr_chrom, dtype=np.uint32)
+    cum = np.ascontiguousarray(tr.expr_cum, dtype=np.float64)
+    pa = np.ascontiguousarray(tr.polya, dtype=np.uint8)
+    x = NsoTrx()
+    x.n_expr = len(ec)
+    x.expr_chrom = ec.ctypes.data_as(C.POINTER(C.c_uint32)); x.expr_cum = cum.ctypes.data_as(C.POINTER(C.c_double))
+    x.polya = pa.ctypes.data_as(C.POINTER(C.c_uint8)) if pa.any() else None
+    x.polya_scale = float(tr.polya_scale)
+    return x, [ec, cum, pa]
+
+
+def generate_trx(model, tr, params: NsParams, *, bytes_per_read=40000, events_per_read=4000):
+    """Transcriptome batch through the CPU restatement (aligned / perfect / unaligned by params.kind)."""
+    L = lib()
+    t = model.to_c()
+    ref = tr.ref
+    n = int(params.n_reads)
+    reads = np.zeros(n, dtype=READ_DTYPE)
+    pieces = np.zeros(n * 2 + 64, dtype=PIECE_DTYPE)
+    events = np.zeros(n * events_per_read + 1024, dtype=EVENT_DTYPE)
+    records = np.zeros(n * bytes_per_read + 4096, dtype=np.uint8)
+    errlog = np.zeros((n * bytes_per_read * 3 + 4096) if params.emit_errlog else 16, dtype=np.uint8)
+    polya = np.zeros(n + 1, dtype=np.uint16)
+    o = NsoOut()
+    o.reads = reads.ctypes.data; o.pieces = pieces.ctypes.data; o.events = events.ctypes.data
+    o.cap_pieces = len(pieces); o.cap_events = len(events)
+    o.records = records.ctypes.data; o.cap_records = len(records)
+    o.errlog = errlog.ctypes.data; o.cap_errlog = len(errlog)
+    o.polya = polya.ctypes.data
+    bases = normalise_bases(ref.bases)
+    x, keep = make_trx(tr)
+    rc = L.nso_generate_trx(C.byref(t), bases.ctypes.data, ref.chrom_off.ctypes.data, len(ref.names), ref.circular.ctypes.data,
+                            ref.names_blob(), C.byref(x), C.byref(params), C.byref(o))
+    if rc != 0:
+        raise RuntimeError("nso_generate_trx failed: %d" % rc)
+    return dict(reads=reads, pieces=pieces[:o.n_pieces], events=events[:o.n_events], records=records[:o.record_bytes],
+                errlog=errlog[:o.errlog_bytes], total_bases=int(o.total_bases), total_ref_bases=int(o.total_ref_bases), polya=polya[:n])

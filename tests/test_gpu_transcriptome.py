@@ -1,0 +1,75 @@
+"""GPU parity for transcriptome batches: expression-weighted transcript pick, aligned length from the 2-D KDE
+conditioned on the transcript length, start inside the transcript, polyA tails, --uracil, --perfect, unaligned reads — bit for bit
+against the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from nanosim_amd import engine as E
+from nanosim_amd import model as M
+from nanosim_amd import transcriptome as T
+from tests import oracle_lib as O
+from tests.test_gpu_parity import compare
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TRX = os.path.join(ROOT, "tests", "golden", "trx")
+PREFIX = os.path.join(ROOT, "tests", "golden", "model_small", "training")
+
+
+@pytest.fixture(scope="module")
+def trx_ref():
+    return T.read_transcriptome(os.path.join(TRX, "transcripts.fa"), os.path.join(TRX, "expression.tsv"), os.path.join(TRX, "polya.txt"), "guppy")
+
+
+CASES = [
+    dict(n_reads=500, emit_errlog=True),
+    dict(n_reads=400, fastq=True, emit_errlog=True),
+    dict(n_reads=300, fastq=True, uracil=True),
+    dict(n_reads=300, kind=E.NS_KIND_PERFECT, fastq=True),
+    dict(n_reads=300, kind=E.NS_KIND_PERFECT, uracil=True),
+    dict(n_reads=300, kind=E.NS_KIND_UNALIGNED, fastq=True, min_len=50, max_len=5000),
+    dict(n_reads=200, kind=E.NS_KIND_UNALIGNED, uracil=True, min_len=50, max_len=5000),
+    dict(n_reads=1, first_read=(1 << 34) + 3),
+    dict(n_reads=300, emit_records=False),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_gpu_transcriptome_equals_oracle(trx_ref, case):
+    kw = dict(seed=0xABCD1234, first_read=0, max_len=10 ** 9, trx=True)
+    kw.update(case)
+    p = E.make_params(**kw)
+    mdl = M.load_model(PREFIX, transcriptome=True, perfect=p.kind == E.NS_KIND_PERFECT, fastq=True)
+    e = E.Engine(0)
+    try:
+        e.set_transcriptome(trx_ref)
+        e.load_model(mdl)
+        b = e.generate(p)
+        exp = O.generate_trx(mdl, trx_ref, p)
+        compare(b, exp, p)
+        assert np.array_equal(b.polya(), exp["polya"])
+        if p.kind != E.NS_KIND_UNALIGNED:
+            assert int(b.polya().max()) >= 2 or p.n_reads < 10
+    finally:
+        e.close()
+
+
+def test_transcriptome_error_paths(trx_ref, small_model, small_ref):
+    e = E.Engine(0)
+    try:
+        e.set_reference(small_ref)
+        e.load_model(small_model)
+        with pytest.raises(E.EngineError):                       # no expression view
+            e.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=9000, trx=True))
+        e.set_transcriptome(trx_ref)
+        with pytest.raises(E.EngineError):                       # the genome-mode model has no 2-D KDE
+            e.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=9000, trx=True))
+        e.load_model(M.load_model(PREFIX, transcriptome=True, homopolymer=True))
+        with pytest.raises(E.EngineError):
+            e.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=9000, trx=True, kmer_bias=5))
+        with pytest.raises(E.EngineError):
+            e.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=9000, trx=True, chimeric=True))
+    finally:
+        e.close()

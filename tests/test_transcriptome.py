@@ -1,0 +1,122 @@
+"""Transcriptome mode (without intron retention): host loader and the oracle's transcript pick / conditional
+2-D KDE / polyA restatements pinned against the reference (tests/golden/reference_transcriptome.json: values of make_cdf,
+random.choices and extract_read_trx, and 2 x 16 000 reads of simulation_aligned_transcriptome)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from nanosim_amd import engine as E
+from nanosim_amd import model as M
+from nanosim_amd import transcriptome as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TRX = os.path.join(ROOT, "tests", "golden", "trx")
+
+
+@pytest.fixture(scope="module")
+def fx():
+    with open(os.path.join(ROOT, "tests", "golden", "reference_transcriptome.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def trx_ref():
+    return T.read_transcriptome(os.path.join(TRX, "transcripts.fa"), os.path.join(TRX, "expression.tsv"), os.path.join(TRX, "polya.txt"), "guppy")
+
+
+def test_loader_matches_read_profile(fx, trx_ref):
+    lens = np.diff(trx_ref.ref.chrom_off.astype(np.int64))
+    assert len(trx_ref.ref.names) == fx["n_trx"] and int(trx_ref.polya.sum()) == fx["n_polya"]
+    for k, v in fx["seq_len"].items():
+        assert lens[trx_ref.ref.names.index(k)] == v
+    assert [[trx_ref.ref.names[c], int(lens[c])] for c in trx_ref.expr_chrom] == fx["ecdf_length_list"]        # make_cdf order (S:69-97)
+    assert np.array_equal(trx_ref.expr_weight, np.array(fx["ecdf_weight_list"]))                             # bit-identical weights
+    for k in fx["polya"]:
+        assert trx_ref.polya[trx_ref.ref.names.index(k)] == 1
+    assert trx_ref.polya_scale == 4.168299657168961
+    assert T.read_transcriptome(os.path.join(TRX, "transcripts.fa"), os.path.join(TRX, "expression.tsv"), None, "albacore").polya_scale == 2.409858743694814
+
+
+def test_transcript_pick_is_random_choices(fx, trx_ref):
+    from tests import oracle_lib as O
+    x, keep = O.make_trx(trx_ref)
+    L = O.lib()
+    for u, pk in zip(fx["choices"]["u"], fx["choices"]["picks"]):
+        assert trx_ref.ref.names[trx_ref.expr_chrom[L.nso_trx_pick(x, u)]] == pk[0], u
+    # the same rule in numpy (what random.choices does: bisect_right over the running sum, clipped to n - 1)
+    cum = trx_ref.expr_cum
+    for u, pk in zip(fx["choices"]["u"], fx["choices"]["picks"]):
+        i = min(int(np.searchsorted(cum, u * cum[-1], side="right")), len(cum) - 1)
+        assert trx_ref.ref.names[trx_ref.expr_chrom[i]] == pk[0]
+
+
+def test_extract_read_trx_rule(fx, trx_ref):
+    """S:1683-1691: start uniform in [0, len - length]; the read keeps a polyA tail if its transcript is listed and it ends within
+    10 bases of the 3' end"""
+    lens = np.diff(trx_ref.ref.chrom_off.astype(np.int64))
+    for e in fx["extract_read_trx"]:
+        c = trx_ref.ref.names.index(e["key"])
+        assert e["randint"][:2] == [0, int(lens[c]) - e["length"]] and e["pos"] == e["randint"][2]
+        assert e["retain"] == bool(trx_ref.polya[c] and e["pos"] + e["length"] + 10 >= lens[c])
+        assert trx_ref.ref.chrom(c)[e["pos"]:e["pos"] + 12].tobytes().decode() == e["head"]
+
+
+@pytest.mark.parametrize("name", ["aligned", "perfect"])
+def test_oracle_transcriptome_batches_match_reference_runs(fx, trx_ref, name):
+    from tests import oracle_lib as O
+    from tests.test_distributions import ks_vs_quantiles
+    run = fx["runs"][name]
+    perfect = name == "perfect"
+    mdl = M.load_model(os.path.join(ROOT, "tests", "golden", "model_small", "training"), transcriptome=True, perfect=perfect)
+    lens = np.diff(trx_ref.ref.chrom_off.astype(np.int64))
+    p = E.make_params(seed=2024, first_read=0, n_reads=16000, max_len=10 ** 9, trx=True, kind=E.NS_KIND_PERFECT if perfect else E.NS_KIND_ALIGNED,
+                      uracil=perfect)
+    out = O.generate_trx(mdl, trx_ref, p)
+    rd, pc, pa = out["reads"], out["pieces"], out["polya"].astype(np.int64)
+    tl, mid = lens[pc["chrom"]].astype(np.float64), pc["ref_len"].astype(np.float64)
+    tol = 0.025                                     # two samples of 16 000: KS noise is ~0.015
+    assert ks_vs_quantiles(mid, run["q_mid"]) < tol and ks_vs_quantiles(mid / tl, run["q_frac"]) < tol
+    assert ks_vs_quantiles(pc["pos"] / np.maximum(1, tl - mid), run["q_start_frac"]) < tol
+    assert ks_vs_quantiles(rd["tail"] + pa, run["q_tailp"]) < tol and ks_vs_quantiles(rd["head"], run["q_head"]) < tol
+    assert ks_vs_quantiles(rd["seq_len"], run["q_seq_len"]) < tol
+    assert abs(rd["reversed"].mean() - run["frac_rev"]) < 0.02
+    reach = (trx_ref.polya[pc["chrom"]] > 0) & (pc["pos"].astype(np.int64) + pc["ref_len"] + 10 >= tl)
+    assert abs(reach.mean() - run["frac_reach_end"]) < 0.01
+    assert np.all(pa[~reach] == 0) and np.all(pa[reach] >= 2)                   # int(expon(loc=2)) >= 2
+    assert ks_vs_quantiles((rd["tail"] + pa)[reach], run["q_tailp_reach"]) < 0.06      # ~1 500 reads
+    if perfect:
+        assert np.all(rd["head"] == 0) and np.all(rd["tail"] == 0) and np.all(pc["n_ev"] == 0)
+        recs = out["records"].tobytes().split(b"\n")
+        assert not any(b"T" in s for s in recs[1:400:2]) and any(b"U" in s for s in recs[1:400:2]) and run["has_u"] and not run["has_t"]
+    # expression-weighted pick: every transcript's share within 1 % of the batch, except the one that holds 47 % of the expression —
+    # the reference keeps one 2-D KDE sample until a transcript repeats, so a transcript whose draw failed keeps failing for a few
+    # reads; its share is 3-4 % (relative) lower there
+    cnt = np.bincount(pc["chrom"], minlength=len(lens))
+    for k, v in run["counts"].items():
+        c = int(cnt[trx_ref.ref.names.index(k)])
+        assert abs(c - v) < (0.03 if v > 5000 else 0.01) * run["n"], (k, v, c)
+    # names: <transcript>_<start>_aligned|perfect_<index>_<F|R>_<head>_<middle_ref>_<tail + polyA>
+    first = out["records"].tobytes().split(b"\n")[0][1:].decode()
+    body, _, rest = first.partition("_perfect_" if perfect else "_aligned_")
+    f = rest.split("_")
+    assert body.rsplit("_", 1)[0] == trx_ref.ref.names[pc["chrom"][0]] and int(body.rsplit("_", 1)[1]) == pc["pos"][0]
+    assert (int(f[0]), f[1], int(f[2]), int(f[3]), int(f[4])) == (0, "R" if rd["reversed"][0] else "F", rd["head"][0], pc["ref_len"][0], rd["tail"][0] + pa[0])
+
+
+def test_oracle_unaligned_transcriptome_reads(trx_ref):
+    """simulation_unaligned("transcriptome") (S:1482-1549 with extract_read S:1695-1703): a uniformly drawn transcript that is
+    longer than the read"""
+    from tests import oracle_lib as O
+    mdl = M.load_model(os.path.join(ROOT, "tests", "golden", "model_small", "training"), transcriptome=True)
+    lens = np.diff(trx_ref.ref.chrom_off.astype(np.int64))
+    p = E.make_params(seed=9, first_read=0, n_reads=3000, min_len=50, max_len=int(lens.max()), trx=True, kind=E.NS_KIND_UNALIGNED)
+    out = O.generate_trx(mdl, trx_ref, p)
+    pc = out["pieces"]
+    assert np.all(pc["ref_len"] < lens[pc["chrom"]]) and np.all(pc["pos"] + pc["ref_len"] <= lens[pc["chrom"]])
+    # short reads fit everywhere: transcripts are drawn uniformly, not by length
+    short = pc["ref_len"] < lens.min()
+    share = np.bincount(pc["chrom"][short], minlength=len(lens)) / max(1, short.sum())
+    assert short.sum() >= 50 and share.max() < 0.06 and (share > 0).sum() > 0.3 * min(len(lens), short.sum())
+    assert out["records"].tobytes().split(b"\n")[0].decode().split("_unaligned_")[1].startswith("0_")
