@@ -109,7 +109,7 @@ def build_parser():
     mg.add_argument('--fastq', action='store_true', default=False)
     mg.add_argument('--chimeric', action='store_true', default=False)
     mg.add_argument('-t', '--num_threads', type=int, default=1)
-    return parser, g, mg
+    return parser, g, mg, t
 
 
 def calculate_read_number_from_coverage(ref: M.Reference, model_prefix: str, coverage: float) -> int:
@@ -209,7 +209,7 @@ class StreamWriter:
 
 
 def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, chimeric, min_len, max_len, median_len,
-                   sd_len, want_errlog, kmer_bias=0, meta=False, err_header=b""):
+                   sd_len, want_errlog, kmer_bias=0, meta=False, err_header=b"", trx=False, uracil=False):
     done = 0
     w = getattr(eng, "_stream_writer", None)           # one writer (staging buffers + threads) per engine
     if w is None:
@@ -226,7 +226,7 @@ def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, 
             n = min(batch, count - done)
             p = E.make_params(seed=seed, first_read=first + done, n_reads=n, kind=kind, fastq=fastq, chimeric=chimeric, kmer_bias=kmer_bias,
                               min_len=min_len, max_len=max_len, median_len=median_len, sd_len=sd_len,
-                              emit_records=True, emit_errlog=fe is not None, meta=meta)
+                              emit_records=True, emit_errlog=fe is not None, meta=meta, trx=trx, uracil=uracil)
             try:
                 b = eng.generate(p)
             except E.EngineError as ex:              # not enough free HBM for this batch size (shared GPU): halve it and go on
@@ -436,8 +436,113 @@ def run_metagenome(a, parser_mg):
         log("Finished!")
 
 
+def run_transcriptome(a, parser_t):
+    """The transcriptome branch of main() (S:2322-2414) + simulation("transcriptome") (S:1568-1672), without intron retention."""
+    from . import transcriptome as TR
+
+    def die(msg, to_err=True):
+        (sys.stderr if to_err else sys.stdout).write("\n" + msg + "\n")
+        parser_t.print_help(sys.stderr)
+        sys.exit(1)
+    if a.homopolymer and (a.KmerBias is None or a.KmerBias < 0):                              # S:2350-2354
+        die("Please input proper kmer bias value >= 0 to simulate homopolymer contraction and expansion events from", False)
+    if a.strandness and (a.strandness < 0 or a.strandness > 1):
+        die("Please input proper strandness value between 0 and 1", False)
+    if a.max_len < a.min_len:
+        die("Maximum read length must be longer than Minimum read length!")
+    model_ir = a.no_model_ir                                                                  # store_false: True unless --no_model_ir
+    if model_ir and a.ref_g == '':
+        die("Please provide a reference genome to simulate intron retention events!")
+    if a.polya and a.basecaller is None:
+        die("Please input basecaller to simulate polyA tails from.", False)
+    if model_ir or a.homopolymer or a.KmerBias:
+        sys.stderr.write("\ntranscriptome mode of this build has no intron-retention model and no -hp/-k yet (DESIGN.md section 5.8): "
+                         "pass --no_model_ir\n")
+        sys.exit(2)
+    rank, local_rank, world = shard.env_rank_world()
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if rank == 0:
+        print("\nrunning the code with following parameters:\n")
+        print("ref_g", a.ref_g); print("ref_t", a.ref_t); print("exp", a.exp); print("model_prefix", a.model_prefix); print("out", a.output)
+        print("number", [a.number]); print("coverage", a.coverage); print("perfect", a.perfect); print("homopolymer", a.homopolymer)
+        print("model_ir", model_ir); print("dna_type", "transcriptome"); print("strandness", a.strandness); print("max_len", a.max_len)
+        print("min_len", a.min_len); print("uracil", a.uracil); print("polya", a.polya)
+        if a.polya:
+            print("basecaller", a.basecaller)
+        print("fastq", a.fastq); print("num_threads", max(a.num_threads, 1))
+        log(' '.join(sys.argv))
+    out = a.output
+    d = os.path.dirname(out)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    eng = E.Engine(local_rank)
+    keep = None
+    if rank == 0:
+        log("Read in reference ")
+        tr = TR.read_transcriptome(a.ref_t, a.exp, a.polya, a.basecaller)
+    if dist is not None:
+        import torch
+        info = [dict(ec=tr.expr_chrom, cum=tr.expr_cum, w=tr.expr_weight, pa=tr.polya, sc=tr.polya_scale) if rank == 0 else None]
+        dist.broadcast_object_list(info, src=0)
+        ref, keep = shard.broadcast_reference(tr.ref if rank == 0 else None, dist, device=torch.device("cuda", local_rank))
+        tr = TR.TranscriptomeReference(ref, info[0]["ec"], info[0]["cum"], info[0]["w"], info[0]["pa"], info[0]["sc"])
+        eng.set_transcriptome(tr, dev_ptr=keep.data_ptr())
+    else:
+        eng.set_transcriptome(tr)
+    if rank == 0:
+        log("Read error profile" if not a.perfect else "Read KDF of aligned reads")
+    mdl = M.load_model(a.model_prefix, perfect=a.perfect, strandness=a.strandness, fastq=a.fastq, transcriptome=True)
+    eng.load_model(mdl)
+    number = a.number
+    if a.coverage is not None:
+        print("\nCalculating the number of reads to be simulated based on the coverage, if you specified the number of reads "
+              "concurrently with the coverage, coverage will override number of reads.\n")
+        number = calculate_read_number_from_coverage(tr.ref, a.model_prefix, a.coverage)
+    n_al, n_un = mdl.split_counts(number)
+    max_len = int(min(a.max_len, tr.ref.max_chrom))                                           # S:2411
+    seed = a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little") >> 1
+    if dist is not None and a.seed is None:
+        box = [seed]
+        dist.broadcast_object_list(box, src=0)
+        seed = box[0]
+    ext = ".fastq" if a.fastq else ".fasta"
+    if rank == 0:
+        log("Start simulation of aligned reads")
+    lo, hi = shard.partition(n_al, world)[rank]
+    _write_batches(eng, out + "_aligned_reads%d%s" % (rank, ext), out + "_error_profile%d" % rank, seed=seed, first=lo, count=hi - lo,
+                   kind=E.NS_KIND_PERFECT if a.perfect else E.NS_KIND_ALIGNED, fastq=a.fastq, chimeric=False, min_len=a.min_len,
+                   max_len=max_len, median_len=None, sd_len=None, want_errlog=True, trx=True, uracil=a.uracil,
+                   err_header=ERR_HEADER if rank == 0 else b"")
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        shard.merge_subfiles(out + "_aligned_reads" + ext, [out + "_aligned_reads%d%s" % (r, ext) for r in range(world)])
+        shard.merge_subfiles(out + "_aligned_error_profile", [out + "_error_profile%d" % r for r in range(world)])
+    if not a.perfect:                                                                         # S:1642-1672
+        if rank == 0:
+            log("Start simulation of random reads")
+        lo, hi = shard.partition(n_un, world)[rank]
+        _write_batches(eng, out + "_unaligned_reads%d%s" % (rank, ext), None, seed=seed, first=n_al + lo, count=hi - lo,
+                       kind=E.NS_KIND_UNALIGNED, fastq=a.fastq, chimeric=False, min_len=a.min_len, max_len=max_len, median_len=None,
+                       sd_len=None, want_errlog=False, trx=True, uracil=a.uracil)
+        if dist is not None:
+            dist.barrier()
+        if rank == 0:
+            shard.merge_subfiles(out + "_unaligned_reads" + ext, [out + "_unaligned_reads%d%s" % (r, ext) for r in range(world)])
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    if rank == 0:
+        log("Finished!")
+
+
 def main(argv=None):
-    parser, parser_g, parser_mg = build_parser()
+    parser, parser_g, parser_mg, parser_t = build_parser()
     if len(sys.argv if argv is None else argv) == (1 if argv is None else 0):
         parser.print_help(sys.stderr)
         sys.exit(1)
@@ -447,9 +552,7 @@ def main(argv=None):
     elif a.mode == "metagenome":
         run_metagenome(a, parser_mg)
     elif a.mode == "transcriptome":
-        sys.stderr.write("\n%s mode is parsed for CLI compatibility but its driver is not part of this build yet "
-                         "(SURVEY.md §8f); use genome mode.\n" % a.mode)
-        sys.exit(2)
+        run_transcriptome(a, parser_t)
     else:
         parser.print_help(sys.stderr)
         sys.exit(1)
