@@ -41,7 +41,10 @@ struct GenArgs {
     uint32_t *n_pieces;         // in: count, after scan: offsets (separate array piece_off)
     uint32_t *piece_off;
     uint64_t *ev_cap;
-    uint64_t *ev_need;          // per read: capacity a later attempt asked for (its lengths outgrew the plan of attempt 0), 0 = none
+    // attempts > 0 draw new lengths: every pass gets a fresh region of the event buffer, planned for the reads it visits
+    uint64_t *l_cap;            // [list position] capacity of the read in this pass
+    const uint64_t *l_off;      // exclusive scan of l_cap (nullptr in pass 0: ev_off[r] is used)
+    uint64_t l_base;            // first event slot of this pass's region
     uint64_t *ev_off;
     uint64_t *rec_len;
     uint64_t *rec_off;
@@ -194,9 +197,9 @@ __global__ void __launch_bounds__(256) k_lengths(GenArgs A) {
     }
     rd.seq_len = 0; rd.attempts = a;
     A.reads[r] = rd;
-    if (A.attempt > 0 && !meta_al && cap > A.ev_off[r + 1] - A.ev_off[r]) A.ev_need[r] = cap;   // re-plan the batch with room for this attempt
+    if (A.attempt > 0 && !meta_al) A.l_cap[tid] = cap;
     if (A.attempt == 0 || meta_al) {
-        A.ev_cap[r] = meta_al ? cap : max(cap, A.ev_need[r]);
+        A.ev_cap[r] = cap;
         A.sort_key[r] = work > 0xffffffffull ? 0xffffffffu : (uint32_t)work;
         A.sort_idx[r] = (uint32_t)r;
     }
@@ -239,7 +242,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
     if (COOP || blockIdx.x < (gridDim.x >> 6)) __builtin_amdgcn_s_setprio(3);
     else if (blockIdx.x < (gridDim.x >> 4)) __builtin_amdgcn_s_setprio(2);
     else if (blockIdx.x < (gridDim.x >> 2)) __builtin_amdgcn_s_setprio(1);
-    unsigned long long st_over = 0, st_replan = 0, st_bases = 0, st_ref = 0, st_ev = 0;
+    unsigned long long st_over = 0, st_bases = 0, st_ref = 0, st_ev = 0;
     if (tid < A.list_n) {
         const uint64_t r = A.list ? A.list[tid] : A.list_base + tid;
         const int kind = (int)prm.kind;
@@ -254,8 +257,8 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
         bool accepted = false, overflow = false;
         do {
             if (rd.flags & 2) { ++epoch; fails = 0; break; }          // no valid length draw
-            const uint64_t ev_off = A.ev_base + A.ev_off[r];
-            const uint64_t ev_cap64 = A.ev_off[r + 1] - A.ev_off[r];
+            const uint64_t ev_off = A.l_off ? A.l_base + A.l_off[tid] : A.ev_base + A.ev_off[r];
+            const uint64_t ev_cap64 = A.l_off ? A.l_off[tid + 1] - A.l_off[tid] : A.ev_off[r + 1] - A.ev_off[r];
             const uint32_t ev_cap = ev_cap64 > 0xffffffffull ? 0xffffffffu : (uint32_t)ev_cap64;
             EvSink32 sink; sink.last_ins_len = 0; sink.overflow = false;
             int64_t total = (int64_t)rd.head + rd.tail;
@@ -375,9 +378,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
             accepted = true;
         } while (false);
         if (lead) {
-            if (overflow) {                     // planned too small for this attempt (stats[7]: re-plan, same rates) or a real overflow (stats[0])
-                if (!meta_al && A.ev_need[r] > A.ev_off[r + 1] - A.ev_off[r]) st_replan = 1; else st_over = 1;
-            }
+            if (overflow) st_over = 1;
             A.reads[r] = rd;
             if (meta_al) { /* a rejected read is re-planned by the next pass */ }
             else if (accepted) A.att_base[r] = a;       // a re-run of the batch starts every read at its accepted attempt
@@ -388,10 +389,9 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
         }
     }
     // one atomic per wavefront and counter
-    st_over = wave_sum(st_over); st_replan = wave_sum(st_replan); st_bases = wave_sum(st_bases); st_ref = wave_sum(st_ref); st_ev = wave_sum(st_ev);
+    st_over = wave_sum(st_over); st_bases = wave_sum(st_bases); st_ref = wave_sum(st_ref); st_ev = wave_sum(st_ev);
     if ((threadIdx.x & 63) == 0) {
         if (st_over) atomicAdd(&A.stats[0], st_over);
-        if (st_replan) atomicAdd(&A.stats[7], st_replan);
         atomicAdd(&A.stats[1], st_bases); atomicAdd(&A.stats[2], st_ref); atomicAdd(&A.stats[3], st_ev);
     }
 }
@@ -850,7 +850,7 @@ struct ns_ctx {
     uint32_t dbg = 0;          // NS_DEBUG_SKIP: phase-ablation bits for profiling only (results are wrong when set)
     uint32_t coop_min = 16384, coop_shift = 9;   // cooperative chain for the longest n>>shift reads of batches >= min (env: NS_COOP_MIN, NS_COOP_SHIFT)
     // planning + result buffers
-    DevBuf ev_need;
+    DevBuf l_cap, l_off;
     DevBuf n_pieces, piece_off, ev_cap, ev_off, rec_len, rec_off, err_len, err_off, name_len;
     DevBuf reads, pieces, events, records, errlog, stats, scan_tmp;
     DevBuf sort_key, sort_idx, sort_key_out, order, list_b, rstate, att_base, scr, scrq, scr_len, scr_off, hp_len, slow_q, ev_word;
@@ -987,7 +987,7 @@ void ns_destroy(ns_ctx *ctx) {
                       &ctx->err_len, &ctx->err_off, &ctx->name_len, &ctx->reads, &ctx->pieces, &ctx->events,
                       &ctx->records, &ctx->errlog, &ctx->stats, &ctx->scan_tmp, &ctx->sort_key, &ctx->sort_idx,
                       &ctx->sort_key_out, &ctx->order, &ctx->list_b, &ctx->rstate, &ctx->att_base, &ctx->scr, &ctx->scrq,
-                      &ctx->scr_len, &ctx->scr_off, &ctx->hp_len, &ctx->slow_q, &ctx->ev_word, &ctx->ev_need, &ctx->species_chrom_off, &ctx->t_reads, &ctx->t_pieces,
+                      &ctx->scr_len, &ctx->scr_off, &ctx->hp_len, &ctx->slow_q, &ctx->ev_word, &ctx->l_cap, &ctx->l_off, &ctx->species_chrom_off, &ctx->t_reads, &ctx->t_pieces,
                       &ctx->t_name_len, &ctx->t_rec_len, &ctx->t_err_len, &ctx->accept, &ctx->accept_scan, &ctx->key_pos,
                       &ctx->draw_x, &ctx->m_segptr, &ctx->m_len, &ctx->m_species, &ctx->species_bases, &ctx->draw_sel,
                       &ctx->draw_sorted, &ctx->meta_words, &ctx->meta_num, &ctx->trx_chrom, &ctx->trx_cum, &ctx->trx_polya, &ctx->polya};
@@ -1621,7 +1621,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     if (!n) { ctx->last = *info; ctx->has_batch = true; return NS_OK; }
     int rc;
     if ((rc = ensure(ctx, ctx->n_pieces, (n + 1) * 4)) || (rc = ensure(ctx, ctx->piece_off, (n + 1) * 4)) ||
-        (rc = ensure(ctx, ctx->ev_cap, (n + 1) * 8)) || (rc = ensure(ctx, ctx->ev_off, (n + 1) * 8)) || (rc = ensure(ctx, ctx->ev_need, (n + 1) * 8)) ||
+        (rc = ensure(ctx, ctx->ev_cap, (n + 1) * 8)) || (rc = ensure(ctx, ctx->ev_off, (n + 1) * 8)) || (rc = ensure(ctx, ctx->l_cap, (n + 1) * 8)) || (rc = ensure(ctx, ctx->l_off, (n + 1) * 8)) ||
         (rc = ensure(ctx, ctx->rec_len, (n + 1) * 8)) || (rc = ensure(ctx, ctx->rec_off, (n + 1) * 8)) ||
         (rc = ensure(ctx, ctx->err_len, (n + 1) * 8)) || (rc = ensure(ctx, ctx->err_off, (n + 1) * 8)) ||
         (rc = ensure(ctx, ctx->name_len, (n + 1) * 2)) || (rc = ensure(ctx, ctx->reads, n * sizeof(ns_read))) ||
@@ -1638,7 +1638,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     A.prm = *prm; A.m = ctx->m; A.ref = ctx->ref;
     A.cap_gap_mul = 2;
     A.n_pieces = (uint32_t *)ctx->n_pieces.p; A.piece_off = (uint32_t *)ctx->piece_off.p;
-    A.ev_cap = (uint64_t *)ctx->ev_cap.p; A.ev_off = (uint64_t *)ctx->ev_off.p; A.ev_need = (uint64_t *)ctx->ev_need.p;
+    A.ev_cap = (uint64_t *)ctx->ev_cap.p; A.ev_off = (uint64_t *)ctx->ev_off.p; A.l_cap = (uint64_t *)ctx->l_cap.p;
     A.rec_len = (uint64_t *)ctx->rec_len.p; A.rec_off = (uint64_t *)ctx->rec_off.p;
     A.err_len = (uint64_t *)ctx->err_len.p; A.err_off = (uint64_t *)ctx->err_off.p;
     A.name_len = (uint16_t *)ctx->name_len.p; A.reads = (ns_read *)ctx->reads.p;
@@ -1665,7 +1665,6 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     const bool lds = ctx->lds_tables && prm->kind != NS_KIND_PERFECT;
     float ms = 0;
     HIPCHK(hipEventRecord(ctx->evt[0], st));
-    HIPCHK(hipMemsetAsync(ctx->ev_need.p, 0, (n + 1) * 8, st));
     double ms_hp = 0;
     if (meta_al && (rc = meta_passes(ctx, prm, info, A, tot_pieces, tot_cap, stats))) return rc;
     for (int hp_round = 0; !meta_al; ++hp_round) {
@@ -1705,11 +1704,25 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         uint32_t cur_n = (uint32_t)n;
         bool overflow = false;
         double ms_chain = 0;
+        uint64_t used = tot_cap;                  // event slots handed out so far
         for (uint32_t a = 0;; ++a) {
             A.list = cur; A.list_n = cur_n; A.attempt = a; A.next_list = nxt;
+            A.l_off = nullptr; A.l_base = 0;
             HIPCHK(hipMemsetAsync(A.next_n, 0, 4, st));
             const dim3 grid_p((cur_n + 255) / 256);
-            if (a > 0) { k_lengths<<<grid_p, blk, 0, st>>>(A); HIPCHK(hipGetLastError()); }
+            if (a > 0) {          // new lengths for the reads still open; their events go to a fresh region behind the earlier passes
+                k_lengths<<<grid_p, blk, 0, st>>>(A);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipMemsetAsync(A.l_cap + cur_n, 0, 8, st));
+                if ((rc = scan_u64(ctx, A.l_cap, (uint64_t *)ctx->l_off.p, (size_t)cur_n + 1))) return rc;
+                uint64_t pass_cap = 0;
+                HIPCHK(hipMemcpyAsync(&pass_cap, (uint64_t *)ctx->l_off.p + cur_n, 8, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                if ((rc = ensure_keep(ctx, ctx->events, (size_t)(used + pass_cap) * sizeof(ns_event) + 64, (size_t)used * sizeof(ns_event)))) return rc;
+                A.events = (ns_event *)ctx->events.p;
+                A.l_off = (const uint64_t *)ctx->l_off.p; A.l_base = used;
+                used += pass_cap;
+            }
             HIPCHK(hipEventRecord(ctx->evt[3], st));
             uint32_t n_coop = 0;
             if (a == 0 && ctx->coop_ok && prm->kind == NS_KIND_ALIGNED && cur_n >= ctx->coop_min) n_coop = cur_n >> ctx->coop_shift;   // longest 0.2 %
@@ -1732,9 +1745,9 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
             HIPCHK(hipStreamSynchronize(st));
             HIPCHK(hipEventElapsedTime(&ms, ctx->evt[3], ctx->evt[4]));
             ms_chain += ms;
-            if (stats[0] || stats[7]) { overflow = true; break; }
+            if (stats[0]) { overflow = true; break; }
             cur_n = (uint32_t)(stats[6] & 0xffffffffull);
-            if (!cur_n) break;
+            if (!cur_n) { tot_cap = used; break; }
             if (a + 1 >= NS_MAX_ATTEMPT)
                 return fail(ctx, NS_EINVAL, "some reads found no acceptable length within the attempt limit "
                                             "(min_len/max_len too narrow for this model)");
@@ -1742,11 +1755,9 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         }
         info->ms_kernel[NS_K_EVENTS] = ms_chain;
         if (!overflow) break;
-        info->n_overflow += stats[0] + stats[7];
-        if (retry >= 12) return fail(ctx, NS_ENOMEM, "event capacity overflow persists after 12 retries");
-        // rare: re-plan the batch.  stats[7]: reads whose later attempt drew longer segments than attempt 0 (their capacity is now
-        // in ev_need); stats[0]: more events per base than planned -> twice the rates
-        if (stats[0]) { cap_rate *= 2.0; A.cap_gap_mul *= 2; }
+        info->n_overflow += stats[0];
+        if (retry >= 6) return fail(ctx, NS_ENOMEM, "event capacity overflow persists after 6 retries");
+        cap_rate *= 2.0; A.cap_gap_mul *= 2;          // rare: more events per base than planned -> re-plan the batch with twice the rates
     }
     if (!A.hp) break;
     // ---- -k stage 1: filter events, write the pre-homopolymer reads to scratch, count the final lengths ----

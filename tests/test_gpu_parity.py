@@ -204,7 +204,7 @@ def test_dense_events_and_long_payloads(tmp_path, small_ref, circ_ref):
 
 def test_later_attempt_outgrows_the_planned_event_capacity(tmp_path, small_ref):
     """Unaligned reads redraw their length at every attempt: a read whose attempt 0 is tiny (rejected by min_len) and whose next
-    attempt is long needs more event slots than attempt 0 planned; the batch is re-planned with that read's demand."""
+    attempt is long needs more event slots than attempt 0 planned: every pass plans its own region of the event buffer."""
     from nanosim_amd import synth
     spec = synth.SynthModelSpec(n_train=4000, seed=3, unaligned_median=400.0, unaligned_sigma=1.6)     # wide: many draws below min_len
     prefix = str(tmp_path / "wide" / "training")
@@ -219,6 +219,6 @@ def test_later_attempt_outgrows_the_planned_event_capacity(tmp_path, small_ref):
         exp = O.generate(mdl, small_ref, p)
         compare(b, exp, p)
         rd = b.reads()
-        assert int(rd["attempts"].max()) >= 2 and int(b.info.n_overflow) > 0           # the re-plan path ran
+        assert int(rd["attempts"].max()) >= 2 and int(b.info.n_overflow) == 0          # no re-plan of the batch needed
     finally:
         e.close()
