@@ -519,7 +519,7 @@ __device__ __forceinline__ bool load_read_uniform(const GenArgs &A, uint64_t r, 
         const uint64_t so = uni64(A.scr_off[r]);
         ro.seq = A.scr + so;
         ro.qual = fastq ? A.scrq + so : nullptr;
-        ro.reversed = false;
+        ro.reversed = false; ro.uracil = false;      // (strand and T -> U are applied by k_hp_write)
     }
     return true;
 }
@@ -619,6 +619,7 @@ __global__ void __launch_bounds__(256) k_hp_filter(GenArgs A) {
         }
         seq_len += p.out_len;
     }
+    if (A.polya) seq_len += A.polya[r];             // transcriptome: the polyA tail sits between the segment and the tail
     rd.seq_len = (uint32_t)seq_len;                 // pre-homopolymer length (layout of the scratch read)
     A.reads[r] = rd;
     A.scr_len[r] = seq_len;
@@ -634,7 +635,8 @@ __global__ void __launch_bounds__(256) k_hp_count(GenArgs A) {
             const ns_key key = read_key(A, r);
             const uint32_t a = rd.attempts, k = A.prm.kmer_bias;
             const uint8_t *scr = A.scr + A.scr_off[r];
-            uint64_t q = rd.head, final_len = (uint64_t)rd.head + rd.tail;
+            uint64_t q = rd.head, final_len = (uint64_t)rd.head + rd.tail + (A.polya ? A.polya[r] : 0u);
+            const bool trx_al = A.prm.trx && A.prm.kind != NS_KIND_UNALIGNED;       // no length limits on aligned transcriptome reads
             for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
                 const ns_piece p = A.pieces[rd.piece_off + pi];
                 uint32_t flen = p.out_len;
@@ -655,7 +657,7 @@ __global__ void __launch_bounds__(256) k_hp_count(GenArgs A) {
                 final_len += flen;
                 q += p.out_len;
             }
-            if ((int64_t)final_len < A.prm.min_len || (int64_t)final_len > A.prm.max_len) {      // S:1429-1430
+            if (!trx_al && ((int64_t)final_len < A.prm.min_len || (int64_t)final_len > A.prm.max_len)) {      // S:1429-1430
                 const uint32_t epoch = (A.rstate[r] & 0xffffu) + 1;
                 A.rstate[r] = epoch & 0xffffu;
                 A.att_base[r] = a + 1;
@@ -684,7 +686,7 @@ __global__ void __launch_bounds__(256) k_hp_write(GenArgs A) {
     }
     const ns_key key = read_key(A, r);
     const uint32_t a = rd.attempts, k = A.prm.kmer_bias;
-    const bool fq = A.prm.fastq != 0, rev = rd.reversed != 0;
+    const bool fq = A.prm.fastq != 0, rev = rd.reversed != 0, ura = A.prm.uracil != 0;
     const uint32_t L = rd.seq_len;                                         // final length
     uint8_t *seq = A.records + rd.rec_off + A.name_len[r] + 2;
     uint8_t *qual = fq ? seq + L + 3 : nullptr;
@@ -693,7 +695,9 @@ __global__ void __launch_bounds__(256) k_hp_write(GenArgs A) {
     uint32_t o = 0;                                                        // output cursor, pre-revcomp coordinates
     auto put = [&](uint32_t b, uint32_t qc) {
         const uint32_t oo = rev ? L - 1 - o : o;
-        seq[oo] = rev ? complement(b) : (uint8_t)b;
+        uint8_t ob = rev ? complement(b) : (uint8_t)b;
+        if (ura && ob == 'T') ob = 'U';                                    // --uracil, S:1247-1248
+        seq[oo] = ob;
         if (fq) qual[oo] = (uint8_t)qc;
         ++o;
     };
@@ -744,6 +748,7 @@ __global__ void __launch_bounds__(256) k_hp_write(GenArgs A) {
         p.out_len = A.hp_len[rd.piece_off + pi];                           // report the emitted length, like the non -k path
         A.pieces[rd.piece_off + pi] = p;
     }
+    if (A.polya) for (uint32_t i = 0, n = A.polya[r]; i < n; ++i, ++q) put(scr[q], fq ? scq[q] : 0);      // polyA tail (S:1224-1225)
     for (uint32_t i = 0; i < rd.tail; ++i, ++q) put(scr[q], fq ? scq[q] : 0);
 }
 
@@ -1609,7 +1614,6 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     if (prm->trx) {
         if (!ctx->has_trx) return fail(ctx, NS_ESTATE, "transcriptome batch before ns_set_transcriptome");
         if (prm->meta || prm->chimeric || prm->use_lognormal) return fail(ctx, NS_EINVAL, "transcriptome batches are neither metagenome nor chimeric nor log-normal");
-        if (prm->kmer_bias) return fail(ctx, NS_EINVAL, "transcriptome batches do not support -k yet");
         if (prm->kind != NS_KIND_UNALIGNED && !(ctx->m.flags & NS_MODEL_HAS_KDE2D)) return fail(ctx, NS_EINVAL, "model has no 2-D KDE (_aligned_region_2d)");
     }
     if (prm->n_reads > 0x7ffffff0ull) return fail(ctx, NS_EINVAL, "batch too large (split into several calls)");

@@ -455,10 +455,12 @@ def run_transcriptome(a, parser_t):
         die("Please provide a reference genome to simulate intron retention events!")
     if a.polya and a.basecaller is None:
         die("Please input basecaller to simulate polyA tails from.", False)
-    if model_ir or a.homopolymer or a.KmerBias:
-        sys.stderr.write("\ntranscriptome mode of this build has no intron-retention model and no -hp/-k yet (DESIGN.md section 5.8): "
-                         "pass --no_model_ir\n")
+    if model_ir:
+        sys.stderr.write("\ntranscriptome mode of this build has no intron-retention model (DESIGN.md section 5.8): pass --no_model_ir\n")
         sys.exit(2)
+    if a.KmerBias and not a.homopolymer:
+        sys.stderr.write("\n-k/--KmerBias needs -hp (the reference crashes on the missing homopolymer parameters, S:504,639)\n")
+        sys.exit(1)
     rank, local_rank, world = shard.env_rank_world()
     dist = None
     if world > 1:
@@ -496,7 +498,8 @@ def run_transcriptome(a, parser_t):
         eng.set_transcriptome(tr)
     if rank == 0:
         log("Read error profile" if not a.perfect else "Read KDF of aligned reads")
-    mdl = M.load_model(a.model_prefix, perfect=a.perfect, strandness=a.strandness, fastq=a.fastq, transcriptome=True)
+    mdl = M.load_model(a.model_prefix, perfect=a.perfect, strandness=a.strandness, fastq=a.fastq, transcriptome=True,
+                       homopolymer=a.homopolymer)
     eng.load_model(mdl)
     number = a.number
     if a.coverage is not None:
@@ -516,7 +519,7 @@ def run_transcriptome(a, parser_t):
     lo, hi = shard.partition(n_al, world)[rank]
     _write_batches(eng, out + "_aligned_reads%d%s" % (rank, ext), out + "_error_profile%d" % rank, seed=seed, first=lo, count=hi - lo,
                    kind=E.NS_KIND_PERFECT if a.perfect else E.NS_KIND_ALIGNED, fastq=a.fastq, chimeric=False, min_len=a.min_len,
-                   max_len=max_len, median_len=None, sd_len=None, want_errlog=True, trx=True, uracil=a.uracil,
+                   max_len=max_len, median_len=None, sd_len=None, want_errlog=True, trx=True, uracil=a.uracil, kmer_bias=a.KmerBias or 0,
                    err_header=ERR_HEADER if rank == 0 else b"")
     if dist is not None:
         dist.barrier()

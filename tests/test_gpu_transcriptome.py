@@ -33,6 +33,8 @@ CASES = [
     dict(n_reads=200, kind=E.NS_KIND_UNALIGNED, uracil=True, min_len=50, max_len=5000),
     dict(n_reads=1, first_read=(1 << 34) + 3),
     dict(n_reads=300, emit_records=False),
+    dict(n_reads=300, kmer_bias=5, fastq=True, uracil=True, emit_errlog=True),        # -hp -k 5
+    dict(n_reads=300, kmer_bias=4),
 ]
 
 
@@ -41,7 +43,7 @@ def test_gpu_transcriptome_equals_oracle(trx_ref, case):
     kw = dict(seed=0xABCD1234, first_read=0, max_len=10 ** 9, trx=True)
     kw.update(case)
     p = E.make_params(**kw)
-    mdl = M.load_model(PREFIX, transcriptome=True, perfect=p.kind == E.NS_KIND_PERFECT, fastq=True)
+    mdl = M.load_model(PREFIX, transcriptome=True, perfect=p.kind == E.NS_KIND_PERFECT, fastq=True, homopolymer=p.kind != E.NS_KIND_PERFECT)
     e = E.Engine(0)
     try:
         e.set_transcriptome(trx_ref)
@@ -66,8 +68,8 @@ def test_transcriptome_error_paths(trx_ref, small_model, small_ref):
         e.set_transcriptome(trx_ref)
         with pytest.raises(E.EngineError):                       # the genome-mode model has no 2-D KDE
             e.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=9000, trx=True))
-        e.load_model(M.load_model(PREFIX, transcriptome=True, homopolymer=True))
-        with pytest.raises(E.EngineError):
+        e.load_model(M.load_model(PREFIX, transcriptome=True))
+        with pytest.raises(E.EngineError):                       # -k without the homopolymer model
             e.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=9000, trx=True, kmer_bias=5))
         with pytest.raises(E.EngineError):
             e.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=9000, trx=True, chimeric=True))
