@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
                 A.rec_len[r] = prm.emit_records ? (uint64_t)nl + 2 + (uint64_t)seq_len + 1 + (prm.fastq ? (uint64_t)seq_len + 3 : 0) : 0;
                 A.err_len[r] = err_len;
                 if (A.polya) A.polya[r] = (uint16_t)polya;
-                if (meta_al) A.accept[r] = 1ull | (uint64_t)n_pieces << 32;
+                if (meta_al) { A.accept[r] = 1ull | (uint64_t)n_pieces << 32; A.sort_key[r] = evn; }   // (event count: taken back if -k rejects the read)
                 st_bases = A.hp ? 0ull : (unsigned long long)seq_len; st_ref = ref_bases; st_ev = evn;
             }
             accepted = true;
@@ -657,6 +657,19 @@ __global__ void __launch_bounds__(256) k_hp_count(GenArgs A) {
                 final_len += flen;
                 q += p.out_len;
             }
+            if (A.meta && !A.key_pos && A.prm.kind != NS_KIND_UNALIGNED) {           // a pass of a metagenome worker (S:1023-1024): the
+                if ((int64_t)final_len < A.prm.min_len || (int64_t)final_len > A.prm.max_len) {   // read is not accepted by this pass
+                    A.accept[r] = 0; st_fail = 1;
+                    unsigned long long rb = 0;               // k_chain had counted it as accepted
+                    for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) rb += A.pieces[rd.piece_off + pi].ref_len;
+                    atomicAdd(&A.stats[2], 0ull - rb);
+                    atomicAdd(&A.stats[3], 0ull - (unsigned long long)A.sort_key[r]);
+                } else {
+                    rd.seq_len = (uint32_t)final_len;
+                    A.reads[r] = rd;
+                    A.rec_len[r] = A.prm.emit_records ? (uint64_t)A.name_len[r] + 2 + final_len + 1 + (A.prm.fastq ? final_len + 3 : 0) : 0;
+                }
+            } else
             if (!trx_al && ((int64_t)final_len < A.prm.min_len || (int64_t)final_len > A.prm.max_len)) {      // S:1429-1430
                 const uint32_t epoch = (A.rstate[r] & 0xffffu) + 1;
                 A.rstate[r] = epoch & 0xffffu;
@@ -1260,6 +1273,38 @@ static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fast
     }
 }
 
+// -k stage 1 on the reads of `A` (A.prm.n_reads of them): filter the events inside homopolymers (S:1920-1947), write the pre-homopolymer
+// reads to scratch, count the final lengths (mutate_homo, S:618-706) and apply the final length check (stats[5] = reads that failed it)
+static int hp_stage1(ns_ctx *ctx, const ns_params *prm, GenArgs &A, size_t n, uint64_t tot_pieces, uint64_t event_slots,
+                     unsigned long long *stats, double *ms_hp) {
+    hipStream_t st = ctx->stream;
+    const dim3 blk(256), grid_t((unsigned)((n + 1 + 255) / 256));
+    int rc;
+    float ms = 0;
+    HIPCHK(hipEventRecord(ctx->evt[9], st));
+    if ((rc = ensure(ctx, ctx->hp_len, (size_t)tot_pieces * 4 + 64))) return rc;
+    A.hp_len = (uint32_t *)ctx->hp_len.p;
+    k_hp_filter<<<grid_t, blk, 0, st>>>(A);
+    HIPCHK(hipGetLastError());
+    if ((rc = scan_u64(ctx, A.scr_len, A.scr_off, n + 1))) return rc;
+    uint64_t scr_bytes = 0;
+    HIPCHK(hipMemcpyAsync(&scr_bytes, A.scr_off + n, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if ((rc = ensure(ctx, ctx->scr, (size_t)scr_bytes + 64)) || (prm->fastq && (rc = ensure(ctx, ctx->scrq, (size_t)scr_bytes + 64)))) return rc;
+    A.scr = (uint8_t *)ctx->scr.p; A.scrq = (uint8_t *)ctx->scrq.p;
+    if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, event_slots))) return rc;
+    if (!A.meta || A.key_pos) HIPCHK(hipMemsetAsync((unsigned long long *)ctx->stats.p + 1, 0, sizeof(unsigned long long), st));   // (kept across metagenome passes)
+    HIPCHK(hipMemsetAsync((unsigned long long *)ctx->stats.p + 5, 0, sizeof(unsigned long long), st));
+    k_hp_count<<<grid_t, blk, 0, st>>>(A);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->evt[10], st));
+    HIPCHK(hipMemcpyAsync(stats, ctx->stats.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipEventElapsedTime(&ms, ctx->evt[9], ctx->evt[10]));
+    *ms_hp += ms;
+    return NS_OK;
+}
+
 int ns_set_transcriptome(ns_ctx *ctx, uint32_t n_expr, const uint32_t *expr_chrom, const double *expr_cum, const uint8_t *polya,
                          double polya_scale) {
     if (!ctx) return NS_EINVAL;
@@ -1565,6 +1610,14 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
         HIPCHK(hipMemcpyAsync(ctx->stats.p, good_stats, 8 * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemsetAsync(P.accept, 0, (np + 1) * 8, st));
         }
+        if (P.hp) {            // -k: the homopolymer stage decides the final length, and with it whether the pass accepts the read (S:1023-1024)
+            GenArgs H = P;
+            H.prm.n_reads = np;                      // bound of the thread-per-read kernels of the stage
+            double ms_hp = 0;
+            if ((rc = hp_stage1(ctx, prm, H, np, tot_pieces, ev_base + pass_cap, stats, &ms_hp))) return rc;
+            info->ms_kernel[NS_K_HP] += ms_hp;
+            stats[5] = 0;
+        }
         memcpy(good_stats, stats, sizeof good_stats);
         if ((rc = scan_u64(ctx, P.accept, P.accept_scan, np + 1))) return rc;
         k_meta_commit<<<grid_p, blk, 0, st>>>(P);
@@ -1605,7 +1658,6 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     const bool meta_al = prm->meta && prm->kind != NS_KIND_UNALIGNED;       // aligned or --perfect worker of simulation_aligned_metagenome
     if (prm->meta) {
         if (!ctx->nspecies) return fail(ctx, NS_ESTATE, "metagenome batch before ns_set_species");
-        if (prm->kmer_bias) return fail(ctx, NS_EINVAL, "metagenome batches do not support -k");
         if (prm->kind == NS_KIND_PERFECT && prm->chimeric) return fail(ctx, NS_EINVAL, "perfect reads cannot be chimeric");
         if (meta_al && prm->use_lognormal) return fail(ctx, NS_EINVAL, "metagenome batches draw read lengths from the model (no -med/-sd)");
         if (meta_al && !ctx->has_abun) return fail(ctx, NS_ESTATE, "metagenome batch before ns_set_abundance");
@@ -1671,6 +1723,10 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     HIPCHK(hipEventRecord(ctx->evt[0], st));
     double ms_hp = 0;
     if (meta_al && (rc = meta_passes(ctx, prm, info, A, tot_pieces, tot_cap, stats))) return rc;
+    if (meta_al && A.hp) {         // the passes validated the final lengths; the stage runs once more on the reads in their final order
+        ms_hp = info->ms_kernel[NS_K_HP];
+        if ((rc = hp_stage1(ctx, prm, A, n, tot_pieces, tot_cap, stats, &ms_hp))) return rc;
+    }
     for (int hp_round = 0; !meta_al; ++hp_round) {
     for (int retry = 0;; ++retry) {
         A.cap_rate = cap_rate;
@@ -1764,28 +1820,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         cap_rate *= 2.0; A.cap_gap_mul *= 2;          // rare: more events per base than planned -> re-plan the batch with twice the rates
     }
     if (!A.hp) break;
-    // ---- -k stage 1: filter events, write the pre-homopolymer reads to scratch, count the final lengths ----
-    HIPCHK(hipEventRecord(ctx->evt[9], st));
-    if ((rc = ensure(ctx, ctx->hp_len, (size_t)tot_pieces * 4 + 64))) return rc;
-    A.hp_len = (uint32_t *)ctx->hp_len.p;
-    k_hp_filter<<<grid_t, blk, 0, st>>>(A);
-    HIPCHK(hipGetLastError());
-    if ((rc = scan_u64(ctx, A.scr_len, A.scr_off, n + 1))) return rc;
-    uint64_t scr_bytes = 0;
-    HIPCHK(hipMemcpyAsync(&scr_bytes, A.scr_off + n, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if ((rc = ensure(ctx, ctx->scr, (size_t)scr_bytes + 64)) || (prm->fastq && (rc = ensure(ctx, ctx->scrq, (size_t)scr_bytes + 64)))) return rc;
-    A.scr = (uint8_t *)ctx->scr.p; A.scrq = (uint8_t *)ctx->scrq.p;
-    if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, tot_cap))) return rc;
-    HIPCHK(hipMemsetAsync((unsigned long long *)ctx->stats.p + 1, 0, sizeof(unsigned long long), st));
-    HIPCHK(hipMemsetAsync((unsigned long long *)ctx->stats.p + 5, 0, sizeof(unsigned long long), st));
-    k_hp_count<<<grid_t, blk, 0, st>>>(A);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(ctx->evt[10], st));
-    HIPCHK(hipMemcpyAsync(stats, ctx->stats.p, sizeof stats, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(hipEventElapsedTime(&ms, ctx->evt[9], ctx->evt[10]));
-    ms_hp += ms;
+    if ((rc = hp_stage1(ctx, prm, A, n, tot_pieces, tot_cap, stats, &ms_hp))) return rc;
     if (!stats[5]) break;
     // some reads failed the final length check (S:1429): they advanced their attempt state; every other read restarts at
     // its accepted attempt, so re-running the batch reproduces them bit for bit

@@ -341,10 +341,13 @@ def run_metagenome(a, parser_mg):
     one worker of the reference: it keeps its own per-species base quota (S:835) and numbers its reads consecutively."""
     from . import metagenome as MG
     validate_genome_args(a, parser_mg)
-    if a.homopolymer or a.KmerBias or (a.median_len and a.sd_len):
-        sys.stderr.write("\nmetagenome mode of this build simulates model-length reads; -hp/-k and -med/-sd are not available "
-                         "here yet (DESIGN.md section 5.7)\n")
+    if a.median_len and a.sd_len:
+        sys.stderr.write("\nmetagenome mode of this build simulates model-length reads; -med/-sd is not available here yet "
+                         "(DESIGN.md section 5.7)\n")
         sys.exit(2)
+    if a.KmerBias and not a.homopolymer:
+        sys.stderr.write("\n-k/--KmerBias needs -hp (the reference crashes on the missing homopolymer parameters, S:504,639)\n")
+        sys.exit(1)
     rank, local_rank, world = shard.env_rank_world()
     dist = None
     if world > 1:
@@ -383,7 +386,8 @@ def run_metagenome(a, parser_mg):
         eng.set_metagenome(mref)
     if rank == 0:
         log("Read error profile" if not a.perfect else "Read KDF of aligned reads")
-    mdl = M.load_model(a.model_prefix, perfect=a.perfect, strandness=a.strandness, chimeric=a.chimeric, fastq=a.fastq)
+    mdl = M.load_model(a.model_prefix, perfect=a.perfect, strandness=a.strandness, chimeric=a.chimeric, fastq=a.fastq,
+                       homopolymer=a.homopolymer)
     eng.load_model(mdl)
     seed = a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little") >> 1
     if dist is not None and a.seed is None:
@@ -411,7 +415,7 @@ def run_metagenome(a, parser_mg):
         _write_batches(eng, base + "_aligned_reads%d%s" % (rank, ext), base + "_error_profile%d" % rank, seed=seed, first=first + lo,
                        count=hi - lo, kind=E.NS_KIND_PERFECT if a.perfect else E.NS_KIND_ALIGNED, fastq=a.fastq, chimeric=a.chimeric,
                        min_len=a.min_len, max_len=max_len, median_len=None, sd_len=None, want_errlog=True, meta=True,
-                       err_header=ERR_HEADER if rank == 0 else b"")
+                       kmer_bias=0 if a.perfect else (a.KmerBias or 0), err_header=ERR_HEADER if rank == 0 else b"")
         if dist is not None:
             dist.barrier()
         if rank == 0:

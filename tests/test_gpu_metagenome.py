@@ -52,6 +52,9 @@ CASES = [
     dict(n_reads=150, kind=E.NS_KIND_UNALIGNED, median_len=900, sd_len=0.4),
     dict(n_reads=300, kind=E.NS_KIND_PERFECT),                             # --perfect worker: no errors, quotas never updated
     dict(n_reads=200, kind=E.NS_KIND_PERFECT, fastq=True, min_len=4000, max_len=12000),
+    dict(n_reads=300, kmer_bias=5, fastq=True, emit_errlog=True),                                  # -hp -k 5
+    dict(n_reads=300, kmer_bias=5, chimeric=True, emit_errlog=True),
+    dict(n_reads=2000, kmer_bias=4, min_len=2500, max_len=9000),                                   # final-length check after the homopolymer stage
 ]
 
 
@@ -88,8 +91,6 @@ def test_metagenome_batches_are_reproducible(setup, meta_ref):
 
 def test_metagenome_error_paths(small_model, small_ref, meta_ref, setup):
     eng, abun, infl = setup
-    with pytest.raises(E.EngineError):
-        eng.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=9000, meta=True, kmer_bias=5))
     with pytest.raises(E.EngineError):
         eng.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=9000, meta=True, kind=E.NS_KIND_PERFECT, chimeric=True))
     with pytest.raises(E.EngineError):
