@@ -405,7 +405,18 @@ __global__ void __launch_bounds__(256) k_meta_draw(GenArgs A) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= A.draw_n) return;
     const ns_key key = make_key(A.prm, 0);
-    A.draw_x[j] = kde_sample(A.m.kde[NS_KDE_ALIGNED], ns_draw(key, ST_REFLEN, 0, A.attempt, (uint32_t)j, (uint32_t)(j >> 32)));
+    const uint32_t jl = (uint32_t)j, jh = (uint32_t)(j >> 32) << 1;          // sub = 2 * high part (+ 1 for the second block of a draw)
+    const u32x4 w = ns_draw(key, ST_REFLEN, 0, A.attempt, jl, jh);
+    double x;
+    if (!A.prm.use_lognormal) x = kde_sample(A.m.kde[NS_KDE_ALIGNED], w);                                   // S:852
+    else if (A.prm.kind == NS_KIND_PERFECT)                                                                   // S:840
+        x = ns_exp(fma(A.prm.sd_len, ns_norminv(u32_to_p(w.z)), ns_log(A.prm.median_len)));
+    else {                                                                                                    // S:854-856: total - remainder
+        const double tot = ns_exp(fma(A.prm.sd_len, ns_norminv(u32_to_p(w.z)), ns_log(A.prm.median_len + A.prm.sd_len * A.prm.sd_len / 2)));
+        const double rem = ns_pow10m1(kde_sample(A.m.kde[NS_KDE_HT], ns_draw(key, ST_REFLEN, 0, A.attempt, jl, jh | 1u)));
+        x = rem < 0 ? -1.0 : tot - rem;                                        // (a negative remainder is filtered out, S:846)
+    }
+    A.draw_x[j] = x;
 }
 
 // the random.choice / random.uniform words of assign_species for every segment pointer of the pass (S:786-803), keyed by the batch
@@ -1659,7 +1670,6 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     if (prm->meta) {
         if (!ctx->nspecies) return fail(ctx, NS_ESTATE, "metagenome batch before ns_set_species");
         if (prm->kind == NS_KIND_PERFECT && prm->chimeric) return fail(ctx, NS_EINVAL, "perfect reads cannot be chimeric");
-        if (meta_al && prm->use_lognormal) return fail(ctx, NS_EINVAL, "metagenome batches draw read lengths from the model (no -med/-sd)");
         if (meta_al && !ctx->has_abun) return fail(ctx, NS_ESTATE, "metagenome batch before ns_set_abundance");
         if (meta_al && prm->chimeric && !ctx->has_inflated) return fail(ctx, NS_EINVAL, "chimeric metagenome batch needs abun_inflated");
     }

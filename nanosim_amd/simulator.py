@@ -341,10 +341,6 @@ def run_metagenome(a, parser_mg):
     one worker of the reference: it keeps its own per-species base quota (S:835) and numbers its reads consecutively."""
     from . import metagenome as MG
     validate_genome_args(a, parser_mg)
-    if a.median_len and a.sd_len:
-        sys.stderr.write("\nmetagenome mode of this build simulates model-length reads; -med/-sd is not available here yet "
-                         "(DESIGN.md section 5.7)\n")
-        sys.exit(2)
     if a.KmerBias and not a.homopolymer:
         sys.stderr.write("\n-k/--KmerBias needs -hp (the reference crashes on the missing homopolymer parameters, S:504,639)\n")
         sys.exit(1)
@@ -407,6 +403,8 @@ def run_metagenome(a, parser_mg):
         eng.set_abundance(mref, abun, infl)
         if rank == 0:
             log("Simulating sample " + sample)
+            if a.median_len and a.sd_len:
+                log("Simulating read length from log-normal distribution")
             log("Start simulation of aligned reads")
         n_al, n_un = mdl.split_counts(numbers[s])
         max_len = int(min(max_len, mref.max_chrom))                                         # S:2525
@@ -414,7 +412,7 @@ def run_metagenome(a, parser_mg):
         lo, hi = shard.partition(n_al, world)[rank]
         _write_batches(eng, base + "_aligned_reads%d%s" % (rank, ext), base + "_error_profile%d" % rank, seed=seed, first=first + lo,
                        count=hi - lo, kind=E.NS_KIND_PERFECT if a.perfect else E.NS_KIND_ALIGNED, fastq=a.fastq, chimeric=a.chimeric,
-                       min_len=a.min_len, max_len=max_len, median_len=None, sd_len=None, want_errlog=True, meta=True,
+                       min_len=a.min_len, max_len=max_len, median_len=a.median_len, sd_len=a.sd_len, want_errlog=True, meta=True,
                        kmer_bias=0 if a.perfect else (a.KmerBias or 0), err_header=ERR_HEADER if rank == 0 else b"")
         if dist is not None:
             dist.barrier()
@@ -426,8 +424,8 @@ def run_metagenome(a, parser_mg):
                 log("Start simulation of random reads")
             lo, hi = shard.partition(n_un, world)[rank]
             _write_batches(eng, base + "_unaligned_reads%d%s" % (rank, ext), None, seed=seed, first=first + n_al + lo, count=hi - lo,
-                           kind=E.NS_KIND_UNALIGNED, fastq=a.fastq, chimeric=False, min_len=a.min_len, max_len=max_len, median_len=None,
-                           sd_len=None, want_errlog=False, meta=True)
+                           kind=E.NS_KIND_UNALIGNED, fastq=a.fastq, chimeric=False, min_len=a.min_len, max_len=max_len,
+                           median_len=a.median_len, sd_len=a.sd_len, want_errlog=False, meta=True)
             if dist is not None:
                 dist.barrier()
             if rank == 0:

@@ -1321,7 +1321,6 @@ int nso_generate_meta(const ns_model_tables *t, const uint8_t *bases, const uint
         free((void *)names);
         return rc;
     }
-    if (prm->use_lognormal) { free((void *)names); return -30; }
     const int perfect = prm->kind == NS_KIND_PERFECT;                    /* S:838-842, 879-910: no errors, no head/tail, quotas never updated */
     int32_t *nseg_orig = (int32_t *)malloc(sizeof(int32_t) * (n + 1));
     for (uint64_t j = 0; j < n; ++j) {                    /* num_segment, S:825-828 */
@@ -1346,8 +1345,18 @@ int nso_generate_meta(const ns_model_tables *t, const uint8_t *bases, const uint
         uint64_t V = 0;
         for (uint64_t j = 0; j < D; ++j) {                                            /* S:852, 857 */
             uint32_t w[4];
-            philox_at(&db, ST_REFLEN, 0, p, (uint32_t)j, (uint32_t)(j >> 32), w);
-            double x = kde_sample(&t->kde[NS_KDE_ALIGNED], w);
+            const uint32_t jl = (uint32_t)j, jh = (uint32_t)(j >> 32) << 1;
+            philox_at(&db, ST_REFLEN, 0, p, jl, jh, w);
+            double x;
+            if (!prm->use_lognormal) x = kde_sample(&t->kde[NS_KDE_ALIGNED], w);
+            else if (perfect) x = nso_exp(fma(prm->sd_len, nso_norminv(u32_to_p(w[2])), nso_log(prm->median_len)));      /* S:840 */
+            else {                                                                                                       /* S:854-856 */
+                uint32_t w2[4];
+                double tot = nso_exp(fma(prm->sd_len, nso_norminv(u32_to_p(w[2])), nso_log(prm->median_len + prm->sd_len * prm->sd_len / 2)));
+                philox_at(&db, ST_REFLEN, 0, p, jl, jh | 1u, w2);
+                double rem = pow10m1(kde_sample(&t->kde[NS_KDE_HT], w2));
+                x = rem < 0 ? -1.0 : tot - rem;
+            }
             if (perfect ? ((double)prm->min_len <= x && x <= (double)prm->max_len) : (0 < x && x <= (double)prm->max_len)) lens[V++] = x;   /* S:841 / S:857 */
         }
         if (V == 0) { free(lens); continue; }                                          /* S:858-859 */

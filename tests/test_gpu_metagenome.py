@@ -55,6 +55,8 @@ CASES = [
     dict(n_reads=300, kmer_bias=5, fastq=True, emit_errlog=True),                                  # -hp -k 5
     dict(n_reads=300, kmer_bias=5, chimeric=True, emit_errlog=True),
     dict(n_reads=2000, kmer_bias=4, min_len=2500, max_len=9000),                                   # final-length check after the homopolymer stage
+    dict(n_reads=400, median_len=4000, sd_len=0.5, emit_errlog=True),                              # -med/-sd
+    dict(n_reads=300, median_len=6000, sd_len=0.3, kind=E.NS_KIND_PERFECT),
 ]
 
 
@@ -93,8 +95,6 @@ def test_metagenome_error_paths(small_model, small_ref, meta_ref, setup):
     eng, abun, infl = setup
     with pytest.raises(E.EngineError):
         eng.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=9000, meta=True, kind=E.NS_KIND_PERFECT, chimeric=True))
-    with pytest.raises(E.EngineError):
-        eng.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=9000, meta=True, median_len=3000, sd_len=0.3))
     e2 = E.Engine(0)
     try:
         e2.set_reference(small_ref)
