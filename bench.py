@@ -46,6 +46,7 @@ def main():
                     help="engine contexts per GPU, each driven by its own host thread: the Markov-chain stage of one batch "
                          "overlaps the record stage of another")
     ap.add_argument("--fastq", action="store_true")
+    ap.add_argument("--kmer-bias", type=int, default=0, help="-hp -k K: homopolymer expansion/contraction (configs[2] uses --fastq --kmer-bias 5)")
     ap.add_argument("--errlog", action="store_true", help="also format the error profile on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=40000)
@@ -80,7 +81,7 @@ def main():
     tmp = tempfile.mkdtemp(prefix="nsbench_%d_" % rank)
     prefix = os.path.join(tmp, "hg002_like")
     synth.write_model(prefix, synth.SynthModelSpec(n_train=1_000_000, seed=SEED), write_pkl=False)
-    mdl = model.load_model(prefix, fastq=a.fastq)
+    mdl = model.load_model(prefix, fastq=a.fastq, homopolymer=a.kmer_bias > 0)
     names = ["ecoli-like"]
     glen = synth.ECOLI_LEN
     ref_meta = model.Reference(names, np.zeros(0, np.uint8), np.array([0, glen], dtype=np.uint64), np.array([1], dtype=np.uint8))
@@ -110,7 +111,7 @@ def main():
     n = a.reads
     def step(i, e=None):
         p = engine.make_params(seed=SEED, first_read=(i * world + rank) * n, n_reads=n, fastq=a.fastq,
-                               max_len=glen, emit_errlog=a.errlog)
+                               max_len=glen, emit_errlog=a.errlog, kmer_bias=a.kmer_bias)
         return (e or eng).generate(p)
 
     def run_steps(first, count):
@@ -181,7 +182,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": "configs[1]: ecoli_like 4,641,652 bp circular, hg002_like error model, genome mode, "
-                                   "%s, %d reads/GPU/step" % ("FASTQ" if a.fastq else "FASTA", n),
+                                   "%s%s, %d reads/GPU/step" % ("FASTQ" if a.fastq else "FASTA", ", -hp -k %d" % a.kmer_bias if a.kmer_bias else "", n),
                        "reads_per_step_per_gpu": n, "errlog": bool(a.errlog), "seed": SEED,
                        "parallelism": "read-index sharding x%d, 1 RCCL broadcast of the reference" % world, "engines_per_gpu": len(engs)},
             "device_ms_per_step": device_ms, "kernel_ms": kms,

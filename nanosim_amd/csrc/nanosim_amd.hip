@@ -1206,8 +1206,17 @@ int ns_load_model(ns_ctx *ctx, const ns_model_tables *t) {
         m.nseg_n = t->nseg_n;
         if ((rc = upload(ctx, pool, t->nseg_cdf, t->nseg_n, &m.nseg_cdf))) return rc;
     }
-    if (t->flags & NS_MODEL_HAS_QUALS)
+    if (t->flags & NS_MODEL_HAS_QUALS) {
         if ((rc = upload(ctx, pool, &t->qual_thr[0][0], (size_t)NS_Q_COUNT * NS_QUAL_LEVELS, &m.qual_thr))) return rc;
+        std::vector<uint8_t> lut((size_t)NS_Q_COUNT * 1024);
+        for (int c = 0; c < NS_Q_COUNT; ++c)
+            for (uint32_t b = 0; b < 1024; ++b) {
+                uint32_t q = 0;
+                while (q < NS_QUAL_LEVELS - 1 && t->qual_thr[c][q] <= 64u * b) ++q;      // thresholds at or below the bucket start
+                lut[(size_t)c * 1024 + b] = (uint8_t)q;
+            }
+        if ((rc = upload(ctx, pool, lut.data(), lut.size(), &m.qual_lut))) return rc;
+    }
     memcpy(m.hp, t->hp, sizeof m.hp);
     m.hp_mis_rate = t->hp_mis_rate;
     if (t->flags & NS_MODEL_HAS_KDE2D) {

@@ -35,6 +35,7 @@ struct DevModel {
     uint32_t nseg_n;
     const double *nseg_cdf;
     const uint32_t *qual_thr;     // [NS_Q_COUNT][NS_QUAL_LEVELS]
+    const uint8_t *qual_lut;      // [NS_Q_COUNT][1024]: #{j : thr[j] <= 64 b} for bucket b = h >> 6 (start of the threshold walk)
     ns_hp_class hp[2];
     double hp_mis_rate;
     const double *kde2d_x, *kde2d_y;      // transcriptome: 2-D KDE training points sorted by transcript length
@@ -426,6 +427,12 @@ __device__ __forceinline__ uint8_t ins_letter(const ns_key &key, uint32_t seg, u
 __device__ __forceinline__ uint8_t ht_letter(const ns_key &key, uint32_t stream, uint32_t attempt, uint32_t i) {             // S:1426-1427
     u32x4 w = ns_draw(key, stream, 0, attempt, i >> 6, 0);
     return bases_atcg((ns_word(w, (i >> 4) & 3) >> (2 * (i & 15))) & 3u);
+}
+// the same count through a 1024-bucket look-up table + a short walk (buckets are 64 wide: rarely more than one threshold inside)
+__device__ __forceinline__ uint8_t qual_value_lut(const uint32_t *__restrict__ thr, const uint8_t *__restrict__ lut, uint32_t h) {
+    uint32_t q = lut[h >> 6];
+    while (q < NS_QUAL_LEVELS - 1 && h >= thr[q]) ++q;
+    return (uint8_t)q;
 }
 __device__ __forceinline__ uint8_t qual_value(const uint32_t *__restrict__ thr, uint32_t h) {
     // q = #{j in [0,126] : h >= thr[j]}; thr is non-decreasing -> binary search for the first thr[j] > h

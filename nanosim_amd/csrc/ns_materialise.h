@@ -154,7 +154,7 @@ __device__ __forceinline__ uint32_t qual_draw(QualDraw &qd, const DevModel &m, i
                                               uint32_t seg, uint32_t attempt, uint32_t mpos) {
     if ((mpos >> 3) != qd.blk) { qd.blk = mpos >> 3; qd.w = ns_draw(key, stream, seg, attempt, qd.blk, 0); }
     uint32_t h = (ns_word(qd.w, (mpos & 7) >> 1) >> (16 * (mpos & 1))) & 0xffffu;
-    return qual_value(m.qual_thr + cls * NS_QUAL_LEVELS, h);
+    return qual_value_lut(m.qual_thr + cls * NS_QUAL_LEVELS, m.qual_lut + cls * 1024, h);
 }
 
 // head / tail: uniform bases (S:1426-1427) + 'ht' qualities (S:1421-1423).  One Philox block per 64 letters.  Both regions in
