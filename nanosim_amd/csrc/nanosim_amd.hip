@@ -1252,13 +1252,14 @@ static int scan_u32(ns_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n) {
 // metagenome (src/simulator.py:758-811, 814-1040)
 // ---------------------------------------------------------------------------------------------------------
 // copy phase, slow tiles, payload: the three kernels that write the sequence (and quality) lines of a batch
-static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fastq, uint64_t event_slots) {
+static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fastq, uint64_t event_slots, hipEvent_t names_done = nullptr) {
     hipStream_t st = ctx->stream;
     {
         int rc = ensure(ctx, ctx->ev_word, ((size_t)event_slots + 8) * 4);
         if (rc) return rc;
         k_words<<<dim3((unsigned)n), dim3(64), 0, st>>>(A, (uint32_t *)ctx->ev_word.p);
         HIPCHK(hipGetLastError());
+        if (names_done) HIPCHK(hipStreamWaitEvent(st, names_done, 0));      // k_names ran next to k_words on the second stream
     }
     for (int round = 0;; ++round) {
         size_t cap = ctx->slow_q.cap >= 16 + sizeof(SlowTile) ? (ctx->slow_q.cap - 16) / sizeof(SlowTile) : 0;
@@ -1856,14 +1857,20 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         return rc;
     A.records = (uint8_t *)ctx->records.p; A.errlog = (uint8_t *)ctx->errlog.p;
     HIPCHK(hipEventRecord(ctx->evt[5], st));
-    k_names<<<grid_t, blk, 0, st>>>(A);
+    const bool side_names = !A.hp && prm->emit_records;       // names + framing on the second stream, next to k_words
+    if (side_names) {
+        HIPCHK(hipEventRecord(ctx->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    }
+    k_names<<<grid_t, blk, 0, side_names ? ctx->stream2 : st>>>(A);
     HIPCHK(hipGetLastError());
+    if (side_names) HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
     HIPCHK(hipEventRecord(ctx->evt[6], st));
     if (A.hp) {
         k_hp_write<<<grid_t, blk, 0, st>>>(A);
         HIPCHK(hipGetLastError());
     } else if (prm->emit_records) {
-        if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, tot_cap))) return rc;
+        if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, tot_cap, ctx->ev_join))) return rc;
     }
     HIPCHK(hipEventRecord(ctx->evt[7], st));
     if (prm->emit_errlog && prm->emit_records) {
