@@ -637,6 +637,65 @@ __global__ void __launch_bounds__(256) k_hp_filter(GenArgs A) {
     A.err_len[r] = A.prm.emit_errlog ? err_len : 0;
 }
 
+// the same, one read per wavefront: lane per event (the homopolymer test of an event is independent of the others), ballot /
+// prefix-popcount compaction, exclusive wavefront prefix sum of the length changes for the shift field
+__global__ void __launch_bounds__(256) k_hp_filter_w(GenArgs A) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r > A.prm.n_reads) return;
+    if (r == A.prm.n_reads) { if (lane == 0) A.scr_len[r] = 0; return; }
+    ns_read rd = A.reads[r];
+    if (rd.flags) { if (lane == 0) A.scr_len[r] = 0; return; }
+    const ns_key key = read_key(A, r);
+    const uint32_t a = rd.attempts;
+    const int64_t k = (int64_t)A.prm.kmer_bias;
+    const uint32_t nl = A.name_len[r];
+    uint64_t seq_len = (uint64_t)rd.head + rd.tail, err_len = 0;
+    for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
+        ns_piece p = A.pieces[rd.piece_off + pi];
+        if (!p.kind) {
+            const PieceCtx pc = load_piece(A.events, A.ref, p, pi);
+            ns_event *ev = A.events + p.ev_off;
+            uint32_t w = 0; int32_t shift = 0;                            // kept events / their cumulative length change so far
+            for (uint32_t j0 = 0; j0 < p.n_ev; j0 += 64) {                // S:1929-1947
+                const uint32_t j = j0 + lane;
+                const bool valid = j < p.n_ev;
+                ns_event e; e.pos = 0; e.info = 0;
+                if (valid) e = ev[j];
+                const int64_t pos = e.pos, len = ns_ev_len(e.info); const uint32_t ty = ns_ev_type(e.info);
+                bool keep = valid;
+                if (valid) {
+                    const int64_t lo = ty == NS_INS ? pos - 1 : pos, hi = pos + len - 1;
+                    for (int64_t x = lo; x <= hi && keep; ++x) keep = !in_hp_run(A.ref, pc, key, a, x, k);
+                }
+                const uint64_t km = __ballot(keep);
+                const uint32_t before = (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+                int32_t d = keep ? (ty == NS_INS ? (int32_t)len : ty == NS_DEL ? -(int32_t)len : 0) : 0;
+                int32_t incl = d;                                          // inclusive prefix sum of the length changes
+                for (int off = 1; off < 64; off <<= 1) { const int32_t v = __shfl_up(incl, off); if ((int)lane >= off) incl += v; }
+                if (keep) {
+                    ns_event o; o.pos = e.pos; o.info = ns_ev_pack((uint32_t)len, ty, shift + incl - d);
+                    ev[w + before] = o;                                    // w + before <= j: never ahead of the batch being read
+                    err_len += nl + dec_digits(e.pos) + dec_digits((uint32_t)len) + 2u * (uint32_t)len + 9u;
+                }
+                w += (uint32_t)__popcll(km);
+                shift += __shfl(incl, 63);
+            }
+            p.n_ev = w; p.out_len = (uint32_t)((int32_t)p.ref_len + shift);
+            if (lane == 0) A.pieces[rd.piece_off + pi] = p;
+        }
+        seq_len += p.out_len;
+    }
+    err_len = wave_sum(err_len);
+    if (A.polya) seq_len += A.polya[r];             // transcriptome: the polyA tail sits between the segment and the tail
+    if (lane == 0) {
+        rd.seq_len = (uint32_t)seq_len;             // pre-homopolymer length (layout of the scratch read)
+        A.reads[r] = rd;
+        A.scr_len[r] = seq_len;
+        A.err_len[r] = A.prm.emit_errlog ? err_len : 0;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_hp_count(GenArgs A) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long st_bases = 0, st_fail = 0;
@@ -1305,7 +1364,7 @@ static int hp_stage1(ns_ctx *ctx, const ns_params *prm, GenArgs &A, size_t n, ui
     HIPCHK(hipEventRecord(ctx->evt[9], st));
     if ((rc = ensure(ctx, ctx->hp_len, (size_t)tot_pieces * 4 + 64))) return rc;
     A.hp_len = (uint32_t *)ctx->hp_len.p;
-    k_hp_filter<<<grid_t, blk, 0, st>>>(A);
+    k_hp_filter_w<<<dim3((unsigned)((n + 1 + 3) / 4)), blk, 0, st>>>(A);
     HIPCHK(hipGetLastError());
     if ((rc = scan_u64(ctx, A.scr_len, A.scr_off, n + 1))) return rc;
     uint64_t scr_bytes = 0;
