@@ -696,6 +696,84 @@ __global__ void __launch_bounds__(256) k_hp_filter_w(GenArgs A) {
     }
 }
 
+// final length check after the homopolymer stage (S:1429-1430 / metagenome S:1023-1024) and the record size of an accepted read
+__device__ inline void hp_final_length(const GenArgs &A, uint64_t r, ns_read &rd, uint32_t a, uint64_t final_len, unsigned long long &st_bases,
+                                       unsigned long long &st_fail) {
+    const bool trx_al = A.prm.trx && A.prm.kind != NS_KIND_UNALIGNED;       // no length limits on aligned transcriptome reads
+    if (A.meta && !A.key_pos && A.prm.kind != NS_KIND_UNALIGNED) {           // a pass of a metagenome worker (S:1023-1024): the
+        if ((int64_t)final_len < A.prm.min_len || (int64_t)final_len > A.prm.max_len) {   // read is not accepted by this pass
+            A.accept[r] = 0; st_fail = 1;
+            unsigned long long rb = 0;               // k_chain had counted it as accepted
+            for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) rb += A.pieces[rd.piece_off + pi].ref_len;
+            atomicAdd(&A.stats[2], 0ull - rb);
+            atomicAdd(&A.stats[3], 0ull - (unsigned long long)A.sort_key[r]);
+        } else {
+            rd.seq_len = (uint32_t)final_len;
+            A.reads[r] = rd;
+            A.rec_len[r] = A.prm.emit_records ? (uint64_t)A.name_len[r] + 2 + final_len + 1 + (A.prm.fastq ? final_len + 3 : 0) : 0;
+        }
+    } else
+    if (!trx_al && ((int64_t)final_len < A.prm.min_len || (int64_t)final_len > A.prm.max_len)) {      // S:1429-1430
+        const uint32_t epoch = (A.rstate[r] & 0xffffu) + 1;
+        A.rstate[r] = epoch & 0xffffu;
+        A.att_base[r] = a + 1;
+        st_fail = 1;
+    } else {
+        rd.seq_len = (uint32_t)final_len;
+        A.reads[r] = rd;
+        A.rec_len[r] = A.prm.emit_records ? (uint64_t)A.name_len[r] + 2 + final_len + 1 + (A.prm.fastq ? final_len + 3 : 0) : 0;
+        st_bases = final_len;
+    }
+}
+
+// k_hp_count, one read per wavefront (k <= 16): runs are found 1024 bases at a time (ns_hp.h: hp_tile), a run belongs to the lane
+// that holds its first base, that lane draws the new length
+__global__ void __launch_bounds__(256) k_hp_count_w(GenArgs A) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    unsigned long long st_bases = 0, st_fail = 0;
+    if (r < A.prm.n_reads) {
+        ns_read rd = A.reads[r];
+        if (!rd.flags) {
+            const ns_key key = read_key(A, r);
+            const uint32_t a = rd.attempts, k = A.prm.kmer_bias;
+            const uint8_t *scr = A.scr + A.scr_off[r];
+            uint64_t q = rd.head, final_len = (uint64_t)rd.head + rd.tail + (A.polya ? A.polya[r] : 0u);
+            for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
+                const ns_piece p = A.pieces[rd.piece_off + pi];
+                uint32_t flen = p.out_len;
+                if (!p.kind) {
+                    const uint32_t sid = pi >> 1, n = p.out_len;
+                    const uint8_t *sq = scr + q;
+                    long long delta = 0;
+                    int32_t last_before = -1;
+                    for (uint32_t t0 = 0; t0 < n; t0 += 1024) {
+                        const uint32_t nts = hp_run_end_behind(sq, n, min(t0 + 1024u, n));
+                        const HpTile t = hp_tile(sq, n, t0, lane, k, last_before, nts);
+                        last_before = t.tile_last;
+                        const uint32_t c = t0 + 16 * lane;
+                        for (uint32_t Cm = t.C; Cm; Cm &= Cm - 1) {                     // long runs that start in this lane's chunk
+                            const uint32_t b = (uint32_t)__builtin_ctz(Cm), higher = t.M & ~((2u << b) - 1u);
+                            const uint32_t s0 = c + b, e = higher ? c + (uint32_t)__builtin_ctz(higher) : t.next_start;
+                            const uint32_t wv = b < 8 ? (b < 4 ? t.v.x : t.v.y) : (b < 12 ? t.v.z : t.v.w);
+                            const uint32_t base = (wv >> (8 * (b & 3))) & 0xffu;
+                            delta += (long long)hp_new_size(A.m, key, sid, a, s0, e - s0, base) - (long long)(e - s0);
+                        }
+                    }
+                    unsigned long long du = wave_sum((unsigned long long)delta);
+                    flen = (uint32_t)((long long)n + (long long)du);
+                }
+                if (lane == 0) A.hp_len[rd.piece_off + pi] = flen;
+                final_len += flen;
+                q += p.out_len;
+            }
+            if (lane == 0) hp_final_length(A, r, rd, a, final_len, st_bases, st_fail);
+        }
+    }
+    st_bases = wave_sum(st_bases); st_fail = wave_sum(st_fail);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&A.stats[1], st_bases); if (st_fail) atomicAdd(&A.stats[5], st_fail); }
+}
+
 __global__ void __launch_bounds__(256) k_hp_count(GenArgs A) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long st_bases = 0, st_fail = 0;
@@ -706,7 +784,6 @@ __global__ void __launch_bounds__(256) k_hp_count(GenArgs A) {
             const uint32_t a = rd.attempts, k = A.prm.kmer_bias;
             const uint8_t *scr = A.scr + A.scr_off[r];
             uint64_t q = rd.head, final_len = (uint64_t)rd.head + rd.tail + (A.polya ? A.polya[r] : 0u);
-            const bool trx_al = A.prm.trx && A.prm.kind != NS_KIND_UNALIGNED;       // no length limits on aligned transcriptome reads
             for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
                 const ns_piece p = A.pieces[rd.piece_off + pi];
                 uint32_t flen = p.out_len;
@@ -727,30 +804,7 @@ __global__ void __launch_bounds__(256) k_hp_count(GenArgs A) {
                 final_len += flen;
                 q += p.out_len;
             }
-            if (A.meta && !A.key_pos && A.prm.kind != NS_KIND_UNALIGNED) {           // a pass of a metagenome worker (S:1023-1024): the
-                if ((int64_t)final_len < A.prm.min_len || (int64_t)final_len > A.prm.max_len) {   // read is not accepted by this pass
-                    A.accept[r] = 0; st_fail = 1;
-                    unsigned long long rb = 0;               // k_chain had counted it as accepted
-                    for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) rb += A.pieces[rd.piece_off + pi].ref_len;
-                    atomicAdd(&A.stats[2], 0ull - rb);
-                    atomicAdd(&A.stats[3], 0ull - (unsigned long long)A.sort_key[r]);
-                } else {
-                    rd.seq_len = (uint32_t)final_len;
-                    A.reads[r] = rd;
-                    A.rec_len[r] = A.prm.emit_records ? (uint64_t)A.name_len[r] + 2 + final_len + 1 + (A.prm.fastq ? final_len + 3 : 0) : 0;
-                }
-            } else
-            if (!trx_al && ((int64_t)final_len < A.prm.min_len || (int64_t)final_len > A.prm.max_len)) {      // S:1429-1430
-                const uint32_t epoch = (A.rstate[r] & 0xffffu) + 1;
-                A.rstate[r] = epoch & 0xffffu;
-                A.att_base[r] = a + 1;
-                st_fail = 1;
-            } else {
-                rd.seq_len = (uint32_t)final_len;
-                A.reads[r] = rd;
-                A.rec_len[r] = A.prm.emit_records ? (uint64_t)A.name_len[r] + 2 + final_len + 1 + (A.prm.fastq ? final_len + 3 : 0) : 0;
-                st_bases = final_len;
-            }
+            hp_final_length(A, r, rd, a, final_len, st_bases, st_fail);
         }
     }
     st_bases = wave_sum(st_bases); st_fail = wave_sum(st_fail);
@@ -833,6 +887,130 @@ __global__ void __launch_bounds__(256) k_hp_write(GenArgs A) {
     }
     if (A.polya) for (uint32_t i = 0, n = A.polya[r]; i < n; ++i, ++q) put(scr[q], fq ? scq[q] : 0);      // polyA tail (S:1224-1225)
     for (uint32_t i = 0; i < rd.tail; ++i, ++q) put(scr[q], fq ? scq[q] : 0);
+}
+
+// k_hp_write, one read per wavefront (k <= 16): head / gaps / polyA / tail are plain 16-byte copies; inside an aligned segment a lane
+// copies its 16 bases with one store when no long run touches them, otherwise base by base, re-sampling the runs it owns (mutate_homo,
+// S:657-700).  Output offsets: wavefront prefix sum of the length changes of the runs that start before the lane's chunk.
+__global__ void __launch_bounds__(256) k_hp_write_w(GenArgs A) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= A.prm.n_reads) return;
+    const ns_read rd = A.reads[r];
+    if (rd.flags) return;
+    if (!A.prm.emit_records) {
+        if (lane == 0) for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) A.pieces[rd.piece_off + pi].out_len = A.hp_len[rd.piece_off + pi];
+        return;
+    }
+    const ns_key key = read_key(A, r);
+    const uint32_t a = rd.attempts, k = A.prm.kmer_bias;
+    const bool fq = A.prm.fastq != 0, rev = rd.reversed != 0, ura = A.prm.uracil != 0;
+    const uint32_t L = rd.seq_len;                                         // final length
+    ReadOut ro;
+    ro.seq = A.records + rd.rec_off + A.name_len[r] + 2;
+    ro.qual = fq ? ro.seq + L + 3 : nullptr;
+    ro.seq_len = L; ro.reversed = rev; ro.uracil = ura;
+    const uint8_t *scr = A.scr + A.scr_off[r];
+    const uint8_t *scq = fq ? A.scrq + A.scr_off[r] : nullptr;
+    auto put = [&](uint32_t pos, uint32_t b, uint32_t qc) {                // one base at pre-revcomp position pos of the final read
+        const uint32_t oo = rev ? L - 1 - pos : pos;
+        uint8_t ob = rev ? complement(b) : (uint8_t)b;
+        if (ura && ob == 'T') ob = 'U';
+        ro.seq[oo] = ob;
+        if (fq) ro.qual[oo] = (uint8_t)qc;
+    };
+    auto copy_plain = [&](uint64_t q_in, uint32_t q_out, uint32_t len) {   // scratch [q_in, q_in + len) -> final read [q_out, q_out + len)
+        for (uint32_t i0 = 16 * lane; i0 < len; i0 += 1024) {
+            const uint32_t count = min(16u, len - i0);
+            uint64_t v[2] = {0, 0}, w[2] = {0, 0};
+            __builtin_memcpy(v, scr + q_in + i0, 16);
+            if (fq) __builtin_memcpy(w, scq + q_in + i0, 16);
+            store_chunk(ro, q_out + i0, count, v[0], v[1], w[0], w[1], true);
+        }
+    };
+    uint64_t q_in = 0;
+    uint32_t q_out = 0;
+    copy_plain(q_in, q_out, rd.head); q_in += rd.head; q_out += rd.head;
+    for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
+        const ns_piece p = A.pieces[rd.piece_off + pi];
+        const uint32_t n = p.out_len, flen = A.hp_len[rd.piece_off + pi];
+        if (p.kind) { copy_plain(q_in, q_out, n); q_in += n; q_out += n; continue; }
+        const uint32_t sid = pi >> 1;
+        const uint8_t *sq = scr + q_in;
+        const uint8_t *qq = fq ? scq + q_in : nullptr;
+        long long tileD = 0;                                               // length change of the runs that start before the tile
+        int32_t last_before = -1;
+        for (uint32_t t0 = 0; t0 < n; t0 += 1024) {
+            const uint32_t nts = hp_run_end_behind(sq, n, min(t0 + 1024u, n));
+            const HpTile t = hp_tile(sq, n, t0, lane, k, last_before, nts);
+            last_before = t.tile_last;
+            const uint32_t c = t0 + 16 * lane;
+            const uint32_t valid = c >= n ? 0u : min(16u, n - c);
+            long long lane_delta = 0;
+            for (uint32_t Cm = t.C; Cm; Cm &= Cm - 1) {
+                const uint32_t b = (uint32_t)__builtin_ctz(Cm), higher = t.M & ~((2u << b) - 1u);
+                const uint32_t s0 = c + b, e = higher ? c + (uint32_t)__builtin_ctz(higher) : t.next_start;
+                const uint32_t wv = b < 8 ? (b < 4 ? t.v.x : t.v.y) : (b < 12 ? t.v.z : t.v.w);
+                lane_delta += (long long)hp_new_size(A.m, key, sid, a, s0, e - s0, (wv >> (8 * (b & 3))) & 0xffu) - (long long)(e - s0);
+            }
+            long long incl = lane_delta;                                   // inclusive prefix sum over the lanes
+            for (int off = 1; off < 64; off <<= 1) { const long long o = __shfl_up(incl, off); if ((int)lane >= off) incl += o; }
+            const long long Dlane = tileD + incl - lane_delta;
+            tileD += __shfl(incl, 63);
+            if (!valid) continue;
+            // the run that was open when the chunk begins: if it is long, its bases inside the chunk were re-sampled by its owner
+            const uint32_t older_end = t.M ? c + (uint32_t)__builtin_ctz(t.M) : t.next_start;
+            const bool older_long = t.prev_start >= 0 && older_end > c && older_end - (uint32_t)t.prev_start >= k;
+            if (!older_long && !t.C) {                                     // nothing special: one store
+                uint64_t w[2] = {0, 0};
+                if (fq) __builtin_memcpy(w, qq + c, 16);
+                store_chunk(ro, (uint32_t)((long long)q_out + c + Dlane), valid, (uint64_t)t.v.x | (uint64_t)t.v.y << 32,
+                            (uint64_t)t.v.z | (uint64_t)t.v.w << 32, w[0], w[1], true);
+                continue;
+            }
+            long long Dcur = Dlane;
+            uint32_t i = older_long ? min(older_end, c + 16) - c : 0u;
+            while (i < valid) {
+                const uint32_t wv = i < 8 ? (i < 4 ? t.v.x : t.v.y) : (i < 12 ? t.v.z : t.v.w);
+                const uint32_t base = (wv >> (8 * (i & 3))) & 0xffu;
+                if (!((t.C >> i) & 1u)) { put((uint32_t)((long long)q_out + c + i + Dcur), base, fq ? qq[c + i] : 0u); ++i; continue; }
+                const uint32_t higher = t.M & ~((2u << i) - 1u);
+                const uint32_t s0 = c + i, e = higher ? c + (uint32_t)__builtin_ctz(higher) : t.next_start, len = e - s0;
+                const uint32_t size = hp_new_size(A.m, key, sid, a, s0, len, base);
+                const uint32_t o_run = (uint32_t)((long long)q_out + s0 + Dcur);
+                int64_t first_mis = -1;
+                for (uint32_t x = 0; x < size; ++x) {                      // S:668-684, qualities S:686-695
+                    bool is_mis; uint32_t nb, qc = 0;
+                    if (size <= len || x < len) {
+                        const uint32_t pp = size <= len ? s0 + (len - size) + x : s0 + x;
+                        nb = hp_base(A.m, base, key, sid, a, pp, 0, is_mis);
+                        if (fq) qc = qq[pp];
+                    } else {
+                        const uint32_t j = x - len;
+                        nb = hp_base(A.m, base, key, sid, a, e, 1 + j, is_mis);
+                        if (fq) {
+                            const u32x4 w = ns_draw(key, ST_HPQ, sid, a, e, 1 + (j >> 3));
+                            const uint32_t h = (ns_word(w, (j & 7) >> 1) >> (16 * (j & 1))) & 0xffffu;
+                            qc = qual_value(A.m.qual_thr + NS_Q_INS * NS_QUAL_LEVELS, h) + 33u;
+                        }
+                    }
+                    if (is_mis && first_mis < 0) first_mis = x;
+                    put(o_run + x, nb, qc);
+                }
+                if (fq && first_mis >= 0) {                                // S:697-700: only the first mismatch gets a 'mis' quality
+                    const u32x4 w = ns_draw(key, ST_HPQ, sid, a, s0, 0);
+                    const uint32_t om = o_run + (uint32_t)first_mis;
+                    ro.qual[rev ? L - 1 - om : om] = (uint8_t)(qual_value(A.m.qual_thr + NS_Q_MIS * NS_QUAL_LEVELS, w.x & 0xffffu) + 33u);
+                }
+                Dcur += (long long)size - (long long)len;
+                i = min(e, c + 16) - c;
+            }
+        }
+        q_in += n; q_out += flen;
+        if (lane == 0) { ns_piece pw = p; pw.out_len = flen; A.pieces[rd.piece_off + pi] = pw; }      // report the emitted length, like the non -k path
+    }
+    if (A.polya) { const uint32_t pl = A.polya[r]; copy_plain(q_in, q_out, pl); q_in += pl; q_out += pl; }     // polyA tail (S:1224-1225)
+    copy_plain(q_in, q_out, rd.tail);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1375,7 +1553,8 @@ static int hp_stage1(ns_ctx *ctx, const ns_params *prm, GenArgs &A, size_t n, ui
     if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, event_slots))) return rc;
     if (!A.meta || A.key_pos) HIPCHK(hipMemsetAsync((unsigned long long *)ctx->stats.p + 1, 0, sizeof(unsigned long long), st));   // (kept across metagenome passes)
     HIPCHK(hipMemsetAsync((unsigned long long *)ctx->stats.p + 5, 0, sizeof(unsigned long long), st));
-    k_hp_count<<<grid_t, blk, 0, st>>>(A);
+    if (prm->kmer_bias <= 16) k_hp_count_w<<<dim3((unsigned)((n + 3) / 4)), blk, 0, st>>>(A);
+    else k_hp_count<<<grid_t, blk, 0, st>>>(A);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->evt[10], st));
     HIPCHK(hipMemcpyAsync(stats, ctx->stats.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -1926,7 +2105,8 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     if (side_names) HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
     HIPCHK(hipEventRecord(ctx->evt[6], st));
     if (A.hp) {
-        k_hp_write<<<grid_t, blk, 0, st>>>(A);
+        if (prm->kmer_bias <= 16) k_hp_write_w<<<dim3((unsigned)((n + 3) / 4)), blk, 0, st>>>(A);
+        else k_hp_write<<<grid_t, blk, 0, st>>>(A);
         HIPCHK(hipGetLastError());
     } else if (prm->emit_records) {
         if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, tot_cap, ctx->ev_join))) return rc;

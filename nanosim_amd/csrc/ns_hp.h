@@ -1,13 +1,12 @@
 // ns_hp.h — -k/--KmerBias: the homopolymer filter of mutate_read (S:1920-1947) and mutate_homo (S:618-705).
 //
 // Lengths change AFTER the mutated segment exists, so the mode is count-then-write:
-//   k_hp_filter   thread/read  drop the events that overlap a homopolymer of the un-mutated segment, re-pack the rest
+//   k_hp_filter_w  wave/read   drop the events that overlap a homopolymer of the un-mutated segment, re-pack the rest
 //   k_materialise              (unchanged kernel) writes the pre-homopolymer read, forward strand, into a scratch buffer
-//   k_hp_count    thread/read  scan the scratch segments for runs >= k, draw the new run lengths -> final lengths,
-//                              final length check (S:1429); a failing read bumps its attempt state and the batch is re-run
-//   k_hp_write    thread/read  scratch -> final record with the runs re-sampled, mismatches, qualities, revcomp
-// First implementation: one thread per read for the three hp kernels (sequential like the reference); the main
-// path keeps its wave-per-read kernels.
+//   k_hp_count_w   wave/read   runs >= k of the scratch segments, new run lengths -> final lengths, final length check (S:1429);
+//                              a failing read bumps its attempt state and the batch is re-run
+//   k_hp_write_w   wave/read   scratch -> final record with the runs re-sampled, mismatches, qualities, revcomp
+// (k_hp_filter / k_hp_count / k_hp_write: the sequential thread-per-read versions, still used for k > 16.)
 #pragma once
 #include "ns_materialise.h"
 
@@ -55,4 +54,73 @@ __device__ __forceinline__ uint8_t hp_base(const DevModel &m, uint32_t base, con
     const int rc = base_rank(base);
     is_mis = true;
     return bases_atcg(j + ((int)j >= rc ? 1u : 0u));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// wave-per-read run analysis of a scratch segment (mutate_homo's run scan, S:627-637), 1024 bytes per tile, 16 per lane.
+// A run is owned by the lane whose chunk holds its FIRST base: that lane knows the base, finds the end (the next run start, in
+// its own chunk, in a later lane or behind the tile) and draws the new length (keyed by the start of the run, as the thread
+// version does).  Needs k <= 16.
+// ---------------------------------------------------------------------------------------------------------
+struct HpTile {
+    uint32_t M;            // bit b: a run starts at base c + b of the lane's chunk (c = t0 + 16 lane)
+    uint32_t C;            // subset of M: runs of >= k bases
+    int32_t prev_start;    // last run start before the chunk (-1: none, only for the very first chunk)
+    uint32_t next_start;   // first run start at or behind c + 16 (n = end of the segment counts as one)
+    uint4 v;               // the 16 bases
+    int32_t tile_last;     // last run start inside the tile or before it (wave-uniform): the next tile's carry
+};
+// 0x80 in every byte of x that is not zero
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) { return (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u; }
+__device__ __forceinline__ uint32_t movemask4(uint32_t flags80) { return (((flags80 >> 7) * 0x00204081u) >> 21) & 0xfu; }
+
+// `next_tile_start`: first run start at or behind t0 + 1024 (wave-uniform; found by hp_run_end_behind)
+__device__ inline HpTile hp_tile(const uint8_t *__restrict__ sq, uint32_t n, uint32_t t0, uint32_t lane, uint32_t k, int32_t last_start_before_tile,
+                                 uint32_t next_tile_start) {
+    HpTile t;
+    const uint32_t c = t0 + 16 * lane;
+    t.v = make_uint4(0, 0, 0, 0);
+    uint32_t pb = 0xffu;                                            // base before the chunk (0xff: none -> base 0 starts a run)
+    if (c < n) {
+        __builtin_memcpy(&t.v, sq + c, 16);                        // (the scratch buffer has slack behind the last read)
+        if (c) pb = sq[c - 1];
+    }
+    // starts: base b differs from base b - 1
+    const uint32_t p0 = t.v.x << 8 | pb, p1 = t.v.y << 8 | t.v.x >> 24, p2 = t.v.z << 8 | t.v.y >> 24, p3 = t.v.w << 8 | t.v.z >> 24;
+    uint32_t M = movemask4(nonzero_bytes(t.v.x ^ p0)) | movemask4(nonzero_bytes(t.v.y ^ p1)) << 4 | movemask4(nonzero_bytes(t.v.z ^ p2)) << 8 |
+                 movemask4(nonzero_bytes(t.v.w ^ p3)) << 12;
+    const uint32_t valid = c >= n ? 0u : (n - c >= 16 ? 16u : n - c);      // bases of the chunk inside the segment
+    M &= (1u << valid) - 1u;
+    t.M = M;
+    // last start before the chunk: exclusive prefix "max" of the lanes' last starts (positions grow with the lane)
+    int32_t last = M ? (int32_t)(c + 31u - (uint32_t)__clz((int)M)) : -1;
+    int32_t inc = last;
+    for (int off = 1; off < 64; off <<= 1) { const int32_t o = __shfl_up(inc, off); if ((int)lane >= off) inc = max(inc, o); }
+    int32_t prev = __shfl_up(inc, 1);
+    if (lane == 0) prev = -1;
+    t.prev_start = max(prev, last_start_before_tile);
+    t.tile_last = max(__shfl(inc, 63), last_start_before_tile);
+    // first start behind the chunk: exclusive suffix "min" of the lanes' first starts
+    uint32_t first = M ? c + (uint32_t)__builtin_ctz(M) : 0xffffffffu;
+    uint32_t dec = first;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_down(dec, off); if ((int)lane + off < 64) dec = min(dec, o); }
+    uint32_t nxt = __shfl_down(dec, 1);
+    if (lane == 63) nxt = 0xffffffffu;
+    t.next_start = min(nxt, next_tile_start);
+    // long runs starting in this chunk: no further start among the next k - 1 bases
+    const uint32_t upper = t.next_start - c >= 32u ? 0u : 1u << (t.next_start - c);       // the first start behind the chunk, as a bit of a 32-bit window
+    const uint32_t W = M | upper;
+    uint32_t C = M;
+    for (uint32_t sft = 1; sft < k; ++sft) C &= ~(W >> sft);
+    // a run may also be cut short by the end of the segment: n acts as a start (next_tile_start / next_start carry it)
+    t.C = C;
+    return t;
+}
+// end of the run that holds base p - 1 ... scanning forward from p (wave-uniform helper for the run that is open at a tile end)
+__device__ inline uint32_t hp_run_end_behind(const uint8_t *__restrict__ sq, uint32_t n, uint32_t p) {
+    if (p >= n) return n;
+    const uint8_t b = sq[p - 1];
+    uint32_t e = p;
+    while (e < n && sq[e] == b) ++e;
+    return e;
 }

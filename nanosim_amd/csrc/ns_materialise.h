@@ -92,7 +92,7 @@ __device__ __forceinline__ uint64_t complement8(uint64_t x) {              // A<
 }
 // `count` bytes whose pre-revcomp coordinates are [q0, q0+count), byte i in bits 8i of (lo,hi)
 __device__ __forceinline__ void store_chunk(const ReadOut &ro, uint32_t q0, uint32_t count, uint64_t lo, uint64_t hi,
-                                            uint64_t qlo, uint64_t qhi) {
+                                            uint64_t qlo, uint64_t qhi, bool ascii_quals = false) {
     uint32_t o0 = q0;
     if (ro.reversed) {
         lo = complement8(lo); hi = complement8(hi);
@@ -102,7 +102,7 @@ __device__ __forceinline__ void store_chunk(const ReadOut &ro, uint32_t q0, uint
     if (ro.uracil) { lo = t_to_u8(lo); hi = t_to_u8(hi); }
     store16(ro.seq + o0, count, lo, hi);
     if (ro.qual) {
-        qlo += 0x2121212121212121ull; qhi += 0x2121212121212121ull;         // chr(q + 33), S:1441
+        if (!ascii_quals) { qlo += 0x2121212121212121ull; qhi += 0x2121212121212121ull; }        // chr(q + 33), S:1441
         if (ro.reversed) reverse_bytes(qlo, qhi, count);
         store16(ro.qual + o0, count, qlo, qhi);
     }
