@@ -970,10 +970,20 @@ __global__ void __launch_bounds__(256) k_hp_write_w(GenArgs A) {
             }
             long long Dcur = Dlane;
             uint32_t i = older_long ? min(older_end, c + 16) - c : 0u;
+            uint64_t qv[2] = {0, 0};
+            if (fq) __builtin_memcpy(qv, qq + c, 16);
             while (i < valid) {
+                if (!((t.C >> i) & 1u)) {                                  // plain stretch up to the next long run of the chunk: one (partial) store
+                    const uint32_t rest = t.C >> i;
+                    const uint32_t i1 = rest ? min(valid, i + (uint32_t)__builtin_ctz(rest)) : valid;
+                    uint64_t lo = (uint64_t)t.v.x | (uint64_t)t.v.y << 32, hi = (uint64_t)t.v.z | (uint64_t)t.v.w << 32, ql = qv[0], qh = qv[1];
+                    shift_down_bytes(lo, hi, i); shift_down_bytes(ql, qh, i);
+                    store_chunk(ro, (uint32_t)((long long)q_out + c + i + Dcur), i1 - i, lo, hi, ql, qh, true);
+                    i = i1;
+                    continue;
+                }
                 const uint32_t wv = i < 8 ? (i < 4 ? t.v.x : t.v.y) : (i < 12 ? t.v.z : t.v.w);
                 const uint32_t base = (wv >> (8 * (i & 3))) & 0xffu;
-                if (!((t.C >> i) & 1u)) { put((uint32_t)((long long)q_out + c + i + Dcur), base, fq ? qq[c + i] : 0u); ++i; continue; }
                 const uint32_t higher = t.M & ~((2u << i) - 1u);
                 const uint32_t s0 = c + i, e = higher ? c + (uint32_t)__builtin_ctz(higher) : t.next_start, len = e - s0;
                 const uint32_t size = hp_new_size(A.m, key, sid, a, s0, len, base);

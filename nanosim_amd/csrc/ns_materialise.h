@@ -76,9 +76,19 @@ __device__ __forceinline__ void store16(uint8_t *dst, uint32_t count, uint64_t l
     if (count == 16) {
         struct __attribute__((packed)) V { uint64_t a, b; } v{lo, hi};
         __builtin_memcpy(dst, &v, 16);
-    } else {
-        for (uint32_t i = 0; i < count; ++i) dst[i] = (uint8_t)((i < 8 ? lo >> (8 * i) : hi >> (8 * (i - 8))) & 0xff);
+    } else {                             // 8 + 4 + 2 + 1: at most four (unaligned) stores instead of up to 15 byte stores
+        if (count & 8u) { __builtin_memcpy(dst, &lo, 8); dst += 8; lo = hi; }
+        if (count & 4u) { const uint32_t w = (uint32_t)lo; __builtin_memcpy(dst, &w, 4); dst += 4; lo >>= 32; }
+        if (count & 2u) { const uint16_t w = (uint16_t)lo; __builtin_memcpy(dst, &w, 2); dst += 2; lo >>= 16; }
+        if (count & 1u) *dst = (uint8_t)lo;
     }
+}
+// bytes [i0, 16) of a 16-byte group moved down to byte 0
+__device__ __forceinline__ void shift_down_bytes(uint64_t &lo, uint64_t &hi, uint32_t i0) {
+    const uint32_t sh = 8 * i0;
+    if (sh == 0) return;
+    if (sh < 64) { lo = (lo >> sh) | (hi << (64 - sh)); hi >>= sh; }
+    else { lo = hi >> (sh - 64); hi = 0; }
 }
 __device__ __forceinline__ void reverse_bytes(uint64_t &lo, uint64_t &hi, uint32_t count) {
     uint64_t rlo = __builtin_bswap64(hi), rhi = __builtin_bswap64(lo);     // byte i -> 15-i

@@ -63,6 +63,8 @@ CASES = [
     dict(kind=E.NS_KIND_ALIGNED, n_reads=4000, kmer_bias=4, fastq=True, min_len=2000, max_len=9000),   # final-length re-check + batch re-run
     dict(kind=E.NS_KIND_ALIGNED, n_reads=100, kmer_bias=6, emit_records=False),
     dict(kind=E.NS_KIND_PERFECT, n_reads=50, kmer_bias=5),                                          # -k is ignored with --perfect
+    dict(kind=E.NS_KIND_ALIGNED, n_reads=100, kmer_bias=17, fastq=True),                            # k > 16: the thread-per-read homopolymer kernels
+    dict(kind=E.NS_KIND_ALIGNED, n_reads=300, kmer_bias=3, fastq=True, emit_errlog=True),           # short k: runs everywhere
 ]
 
 
