@@ -556,8 +556,10 @@ __global__ void __launch_bounds__(64) k_words(GenArgs A, uint32_t *ev_word) {
 
 // k_materialise: the sequence (and quality) line of one read per wavefront; see ns_materialise.h
 template <bool FASTQ>
-__global__ void __launch_bounds__(64, NS_MAT_WAVES) k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq) {
+__global__ void __launch_bounds__(64, FASTQ ? 4 : NS_MAT_WAVES) k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq) {
     __shared__ TileLds T;
+    uint8_t *hq = nullptr;
+    if constexpr (FASTQ) { __shared__ __align__(16) uint8_t hq_slots[32 + 64 * 48 + 16]; hq = hq_slots; }   // quality draws of a chunk, per lane
     const uint32_t lane = threadIdx.x;
     const uint64_t r = blockIdx.x;
     ns_read rd; ns_key key; ReadOut ro;
@@ -568,7 +570,7 @@ __global__ void __launch_bounds__(64, NS_MAT_WAVES) k_materialise(GenArgs A, con
     uint32_t q = rd.head;
     for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
         const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi, ev_word);
-        materialise_piece(A.m, A.ref, T, ro, key, a, pc, q, lane, ev_word, dbg, sq, (uint32_t)r, pi);
+        materialise_piece(A.m, A.ref, T, ro, key, a, pc, q, lane, ev_word, dbg, sq, (uint32_t)r, pi, hq);
         q += pc.out_len;
     }
     if (A.polya) {                                                                          // transcriptome: polyA tail (S:1224-1225)

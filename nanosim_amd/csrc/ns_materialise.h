@@ -345,7 +345,7 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
 // A tile whose reference span straddles the origin of a circular chromosome goes to the slow-tile queue.
 __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, TileLds &T, const ReadOut &ro, const ns_key &key,
                                          uint32_t a, const PieceCtx &pc, uint32_t pq, uint32_t lane, const uint32_t *__restrict__ ev_word,
-                                         uint32_t dbg, const SlowQueue &sq, uint32_t read_idx, uint32_t piece_idx) {
+                                         uint32_t dbg, const SlowQueue &sq, uint32_t read_idx, uint32_t piece_idx, uint8_t *hq = nullptr) {
     uint32_t jb = 0;                       // events with out_start < M0
     uint32_t L0_out = 0, L0_rp = 0, L0_pt = 3u << 12, L0_wd = 0, L0_j = 0;   // the event in force at M0 (synthetic start: no payload, copy from 0)
     const uint8_t *seg0 = ref.bases + pc.chrom_base + pc.pos;           // segment position 0
@@ -566,13 +566,54 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             uint32_t s0 = lo_m - c0, count = hi_m - lo_m;          // bytes [s0, s0 + count) of the chunk are this tile's
             if (ro.qual) {                                         // one quality per byte, class from the payload tile (S:1421-1423)
                 *reinterpret_cast<uint4 *>(&T.pcls[lo_off]) = make_uint4(0, 0, 0, 0);
-                QualDraw qd; qd.blk = 0xffffffffu;
-                const int cls0 = pc.kind ? NS_Q_UNMAPPED : NS_Q_MATCH;
-                for (uint32_t i = s0; i < s0 + count; ++i) {
-                    const uint32_t cw = i < 8 ? (i < 4 ? pcl.x : pcl.y) : (i < 12 ? pcl.z : pcl.w);
-                    const uint32_t cb = (cw >> (8 * (i & 3))) & 0xffu;
-                    put_byte(qlo, qhi, i, qual_draw(qd, m, cb ? (int)cb : cls0, key, ST_QUAL, pc.sid, a, c0 + i));
+                const uint32_t cls0 = pc.kind ? NS_Q_UNMAPPED : NS_Q_MATCH;
+                // The 16-bit draws of byte m are halfword m & 7 of Philox block m >> 3: the (up to) three blocks under the chunk go to
+                // the lane's LDS slot, the 16 draws come back with static offsets; then all look-ups of the chunk are issued in
+                // rounds (table bucket, two thresholds) instead of one dependent chain per byte.
+                const uint32_t m0 = c0 + s0, b0 = m0 >> 3;
+                uint8_t *slot = hq + 32 + 48 * lane;
+#pragma unroll
+                for (uint32_t tb = 0; tb < 3; ++tb) {
+                    const u32x4 w = ns_draw(key, ST_QUAL, pc.sid, a, b0 + tb, 0);
+                    *reinterpret_cast<uint4 *>(slot + 16 * tb) = make_uint4(w.x, w.y, w.z, w.w);
                 }
+                const uint8_t *hb = slot + 2 * (int)(m0 & 7u) - 2 * (int)s0;          // halfword i of the chunk at hb + 2 i (i >= s0)
+                const uint32_t pcw[4] = {pcl.x, pcl.y, pcl.z, pcl.w};
+#pragma unroll
+                for (uint32_t half = 0; half < 2; ++half) {
+                    uint32_t h[8], cl[8], q[8], t0[8], t1[8];
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; ++j) {
+                        const uint32_t i = 8 * half + j;
+                        h[j] = *reinterpret_cast<const uint16_t *>(hb + 2 * i);
+                        const uint32_t cb = (pcw[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                        cl[j] = cb ? cb : cls0;
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; ++j) q[j] = m.qual_lut[cl[j] * 1024u + (h[j] >> 6)];
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; ++j) {
+                        const uint32_t *thr = m.qual_thr + cl[j] * NS_QUAL_LEVELS;
+                        t0[j] = thr[min(q[j], (uint32_t)NS_QUAL_LEVELS - 2u)];
+                        t1[j] = thr[min(q[j] + 1u, (uint32_t)NS_QUAL_LEVELS - 2u)];
+                    }
+                    uint64_t acc = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; ++j) {
+                        uint32_t qq = q[j];
+                        if (qq < NS_QUAL_LEVELS - 1 && h[j] >= t0[j]) {
+                            ++qq;
+                            if (qq < NS_QUAL_LEVELS - 1 && h[j] >= t1[j]) {          // rare: more than one threshold inside a 64-wide bucket
+                                ++qq;
+                                const uint32_t *thr = m.qual_thr + cl[j] * NS_QUAL_LEVELS;
+                                while (qq < NS_QUAL_LEVELS - 1 && h[j] >= thr[qq]) ++qq;
+                            }
+                        }
+                        acc |= (uint64_t)qq << (8 * j);
+                    }
+                    if (half) qhi = acc; else qlo = acc;
+                }
+                // bytes outside [s0, s0 + count) hold draws of other positions: they are shifted out / not stored
             }
             if (s0) {                                              // front-partial chunk (first chunk of a piece): shift down
                 const uint32_t sh = 8 * s0;
