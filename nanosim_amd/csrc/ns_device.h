@@ -259,6 +259,14 @@ __device__ inline bool extract_pos(const DevRef &ref, int64_t length, const ns_k
         uint64_t ref_pos = (uint64_t)(u53_to_p(w.x, w.y) * (double)(genome_len + 1));
         if (ref_pos > genome_len) ref_pos = genome_len;
         if (ref.circular[0]) { chrom = 0; pos = ref_pos; return true; }
+        if (length > 0 && ref.nchrom > 8) {
+            // the walk of S:1767-1780 ends at the chromosome that holds ref_pos: found by bisection (many-contig references)
+            uint32_t lo = 0, hi = ref.nchrom;                                  // largest c with chrom_off[c] <= ref_pos
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ref.chrom_off[mid] <= ref_pos) lo = mid; else hi = mid; }
+            const uint64_t local = ref_pos - ref.chrom_off[lo], cl = ref.chrom_off[lo + 1] - ref.chrom_off[lo];
+            if (local + (uint64_t)length <= cl) { chrom = lo; pos = local; return true; }
+            continue;                                                          // does not fit (or ref_pos == genome_len): redraw
+        }
         for (uint32_t c = 0; c < ref.nchrom; ++c) {
             uint64_t cl = ref.chrom_off[c + 1] - ref.chrom_off[c];
             if (ref_pos + (uint64_t)length <= cl) { chrom = c; pos = ref_pos; return true; }

@@ -224,3 +224,27 @@ def test_later_attempt_outgrows_the_planned_event_capacity(tmp_path, small_ref):
         assert int(rd["attempts"].max()) >= 2 and int(b.info.n_overflow) == 0          # no re-plan of the batch needed
     finally:
         e.close()
+
+
+def test_many_contig_reference(small_model):
+    """A fragmented assembly (3 000 contigs of 0.5-40 kb, a few empty): the start-position walk of extract_read (S:1767-1780) is
+    a bisection on the device; reads longer than most contigs are redrawn until they fit."""
+    from nanosim_amd import synth
+    rng = np.random.default_rng(5)
+    lens = np.concatenate([rng.integers(500, 40000, 2996), [0, 0, 1, 90000]]).astype(np.int64)
+    rng.shuffle(lens)
+    seq = synth.synth_sequence(int(lens.sum()), 9, iupac_frac=0.0005)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    ref = M.Reference(["ctg%d" % i for i in range(len(lens))], seq, off, np.zeros(len(lens), dtype=np.uint8))
+    e = E.Engine(0)
+    try:
+        e.set_reference(ref)
+        e.load_model(small_model)
+        for kw in (dict(n_reads=400, emit_errlog=True), dict(n_reads=300, chimeric=True, fastq=True), dict(n_reads=200, kind=E.NS_KIND_UNALIGNED),
+                   dict(n_reads=200, kind=E.NS_KIND_PERFECT)):
+            args = dict(seed=77, first_read=0, max_len=ref.max_chrom)
+            args.update(kw)
+            p = E.make_params(**args)
+            compare(e.generate(p), O.generate(small_model, ref, p), p)
+    finally:
+        e.close()
