@@ -134,3 +134,41 @@ def test_coverage_read_count(small_ref):
     n_al = int(10000000 * r / (r + 1))
     mean = (n_al * npz["aligned_reads_data"].mean() + (10000000 - n_al) * npz["unaligned_length_data"].mean()) / 10000000
     assert n == int(small_ref.genome_len / mean * 30.0)
+
+
+def test_stream_writer_pipelines_slices_in_order(tmp_path):
+    """simulator.StreamWriter with a stand-in engine: many slices per buffer, fewer staging buffers than slices, several writer
+    threads, two files interleaved — the files are the buffers, byte for byte."""
+    rng = np.random.default_rng(3)
+    bufs = {0: rng.integers(0, 256, 1_000_003, dtype=np.uint8), 4: rng.integers(0, 256, 2_345_678, dtype=np.uint8)}
+
+    class FakeEngine:
+        def pinned(self, n):
+            return np.zeros(n, dtype=np.uint8)
+
+    class FakeBatch:
+        def copy_range(self, which, off, out, n):
+            out[:n] = bufs[which][off:off + n]
+            return out[:n]
+
+    class SmallWriter(simulator.StreamWriter):
+        SLICE = 64 << 10
+        DEPTH = 3
+        THREADS = 4
+
+    w = SmallWriter(FakeEngine())
+    f0 = os.open(tmp_path / "a.bin", os.O_WRONLY | os.O_CREAT, 0o644)
+    f1 = os.open(tmp_path / "b.bin", os.O_WRONLY | os.O_CREAT, 0o644)
+    try:
+        os.pwrite(f1, b"HEADER\n", 0)
+        o0 = o1 = 0
+        o1 = 7
+        for _ in range(3):                                   # three "batches" appended back to back
+            o0 = w.stream(FakeBatch(), 0, len(bufs[0]), f0, o0)
+            o1 = w.stream(FakeBatch(), 4, len(bufs[4]), f1, o1)
+        w.drain()
+    finally:
+        w.close()
+        os.close(f0); os.close(f1)
+    assert open(tmp_path / "a.bin", "rb").read() == bufs[0].tobytes() * 3
+    assert open(tmp_path / "b.bin", "rb").read() == b"HEADER\n" + bufs[4].tobytes() * 3
