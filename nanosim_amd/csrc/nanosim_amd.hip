@@ -559,7 +559,7 @@ template <bool FASTQ>
 __global__ void __launch_bounds__(64, FASTQ ? 4 : NS_MAT_WAVES) k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq) {
     __shared__ TileLds T;
     uint8_t *hq = nullptr;
-    if constexpr (FASTQ) { __shared__ __align__(16) uint8_t hq_slots[32 + 64 * 48 + 16]; hq = hq_slots; }   // quality draws of a chunk, per lane
+    if constexpr (FASTQ) { __shared__ __align__(16) uint8_t hq_slots[NS_HQ_LDS]; hq = hq_slots; }   // quality draws of a chunk, per lane
     const uint32_t lane = threadIdx.x;
     const uint64_t r = blockIdx.x;
     ns_read rd; ns_key key; ReadOut ro;

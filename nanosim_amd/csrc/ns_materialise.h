@@ -15,26 +15,28 @@
 #pragma once
 #include "ns_device.h"
 
-#define T_OUT 1024u
+#ifndef NS_TILE_CHUNKS
+#define NS_TILE_CHUNKS 2u                                  // 16-byte chunks per lane and tile
+#endif
+#define T_OUT (1024u * NS_TILE_CHUNKS)
 #define T_EV 64u            // events staged per tile: slot 0 = the event in force at the tile start, slots 1..63 = lanes 0..62
 struct __align__(16) TileLds {
     uint32_t mlut[17][4];               // mlut[i]: 16-byte mask with bytes >= i set (merge of an event sub-run into a chunk); [16] empty
     uint32_t e_out[T_EV + 1];           // output offset at which the event starts
     uint32_t e_rp[T_EV];                // segment position of the first base copied after the event's payload
     uint16_t e_pt[T_EV];                // payload length (0 for a deletion) | type << 12
-    uint32_t hist[64];
+    uint32_t hist[64 * NS_TILE_CHUNKS];
     // substituted / inserted letters of the tile at their output offsets (relative to the tile's aligned origin), the byte mask
     // that marks them (0xff) and, for FASTQ, their quality class; + a dump area for predicated-off letter slots
     uint8_t pay[T_OUT + 16 + 64];
     uint8_t pmask[T_OUT + 16 + 64];
-    uint8_t pcls[T_OUT + 16 + 64];
 };
 #define T_DUMP (T_OUT + 16u)
+#define NS_HQ_LDS (32u + 64u * 48u + 16u)                 // FASTQ only: quality draws of a chunk, per lane
 __device__ __forceinline__ void tile_lds_init(TileLds &T, uint32_t lane) {
     for (uint32_t c = lane * 16; c < T_OUT + 16 + 64; c += 64 * 16) {
         *reinterpret_cast<uint4 *>(&T.pay[c]) = make_uint4(0, 0, 0, 0);
         *reinterpret_cast<uint4 *>(&T.pmask[c]) = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4 *>(&T.pcls[c]) = make_uint4(0, 0, 0, 0);
     }
     if (lane < 17) {
 #pragma unroll
@@ -395,14 +397,15 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
         T.e_out[0] = L0_out; T.e_rp[0] = L0_rp; T.e_pt[0] = (uint16_t)L0_pt;
         if (take) { T.e_out[1 + lane] = os; T.e_rp[1 + lane] = e_rp; T.e_pt[1 + lane] = (uint16_t)e_pt; }
         T.e_out[ne] = M1;
-        T.hist[lane] = 0;
+#pragma unroll
+        for (uint32_t t = 0; t < NS_TILE_CHUNKS; ++t) T.hist[64 * t + lane] = 0;
         const uint32_t jb_next = jb + cnt;
         e_pre.pos = 0; e_pre.info = 0; w_pre = 0;
         if (M1 < pc.out_len && jb_next + lane < pc.n_ev) { e_pre = pc.ev[jb_next + lane]; w_pre = pc.wd[jb_next + lane]; }   // prefetch for the next tile
         wave_sync();
         if (take) {                                               // histogram: first chunk starting at/after the event
             const uint32_t c = (os - A0 + 15) >> 4;
-            if (c < 64) atomicAdd(&T.hist[c], 1u);
+            if (c < 64 * NS_TILE_CHUNKS) atomicAdd(&T.hist[c], 1u);
         }
         // ---- the event in force at M1 (wave-uniform): the last one taken, straight from its lane's registers
         uint32_t osl = L0_out, ptl = L0_pt, rpl = L0_rp, wdl = L0_wd, jl = L0_j;
@@ -445,7 +448,6 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             const uint32_t b_pl = b_pt & 0xfffu, b_ty = b_pt >> 12;
             const bool on = (take || cont) && b_pl;
             const uint32_t xs = b_rp - b_pl;                      // segment position under the first substituted base
-            const int cls = pc.kind ? NS_Q_UNMAPPED : (b_ty == NS_MIS ? NS_Q_MIS : NS_Q_INS);
             // fast path (branch-free): up to four letters, all inside the tile, plain bases under a substitution
             const bool mis = b_ty == NS_MIS;
             bool fast_l = on && b_pl <= 4 && b_os >= M0 && b_os + b_pl <= M1 && !wraps;
@@ -464,12 +466,12 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
                 const uint32_t rank4 = (vv & 0x01010101u) << 1 | ((vv >> 1) & 0x01010101u);   // rank in "ATCG": A 0, T 1, C 2, G 3
                 const uint32_t ge = ((d4 | 0x80808080u) - rank4) & 0x80808080u;          // per byte: digit >= rank
                 const uint32_t mis4 = __builtin_amdgcn_perm(0u, 0x47435441u, d4 + (ge >> 7));
-                const uint32_t letters = mis ? mis4 : ins4;
+                // FASTQ: inserted letters travel in lower case, which is how the chunk pass tells the two quality classes apart
+                const uint32_t letters = mis ? mis4 : (ins4 | (ro.qual ? 0x20202020u : 0u));
                 const uint32_t o = b_os - A0, dump = T_DUMP + lane;
                 const uint32_t o1 = b_pl > 1 ? o + 1 : dump, o2 = b_pl > 2 ? o + 2 : dump, o3 = b_pl > 3 ? o + 3 : dump;
                 T.pay[o] = (uint8_t)letters; T.pay[o1] = (uint8_t)(letters >> 8); T.pay[o2] = (uint8_t)(letters >> 16); T.pay[o3] = (uint8_t)(letters >> 24);
                 T.pmask[o] = 0xffu; T.pmask[o1] = 0xffu; T.pmask[o2] = 0xffu; T.pmask[o3] = 0xffu;
-                if (ro.qual) { T.pcls[o] = (uint8_t)cls; T.pcls[o1] = (uint8_t)cls; T.pcls[o2] = (uint8_t)cls; T.pcls[o3] = (uint8_t)cls; }
             }
             if (on && !fast_l) {                                  // long payloads, tile borders, IUPAC under a substitution, the origin
                 const uint32_t i_lo = b_os < M0 ? M0 - b_os : 0u;
@@ -484,8 +486,7 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
                     }
                     if (i >= i_lo) {
                         const uint32_t o = b_os + i - A0;
-                        T.pay[o] = (uint8_t)b; T.pmask[o] = 0xffu;
-                        if (ro.qual) T.pcls[o] = (uint8_t)cls;
+                        T.pay[o] = (uint8_t)(b | (ro.qual && b_ty == NS_INS ? 0x20u : 0u)); T.pmask[o] = 0xffu;
                     }
                 }
             }
@@ -494,9 +495,16 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
         wave_sync();
 
         // ---- 3. one lane per aligned 16-byte chunk
-        const uint32_t incl = wave_incl_scan(T.hist[lane]);
-        const uint32_t c0 = A0 + 16 * lane;                        // chunk origin (lane 0 of a piece's first tile may start before M0)
-        const uint32_t lo_m = lane == 0 ? M0 : c0, hi_m = min(c0 + 16, M1);
+        uint32_t scan_base = 0;
+#if NS_TILE_CHUNKS > 1
+#pragma nounroll
+#endif
+        for (uint32_t t = 0; t < NS_TILE_CHUNKS; ++t) {
+        const uint32_t ci = 64 * t + lane;                         // chunk of the tile
+        const uint32_t incl = scan_base + wave_incl_scan(T.hist[ci]);
+        scan_base = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t c0 = A0 + 16 * ci;                          // chunk origin (chunk 0 of a piece's first tile may start before M0)
+        const uint32_t lo_m = ci == 0 ? M0 : c0, hi_m = min(c0 + 16, M1);
         if ((int32_t)(hi_m - lo_m) > 0 && !(dbg & 1)) {
             uint32_t k = incl;                                     // event in force at the chunk's first byte
             uint32_t eos = T.e_out[k], pl = T.e_pt[k] & 0xfffu, rp = T.e_rp[k], nxt = T.e_out[k + 1];
@@ -539,10 +547,8 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             }
 #undef NS_SUBRUN_GATHER
 #undef NS_SUBRUN_MERGE
-            const uint32_t lo_off = 16 * lane;                     // chunk offset inside the payload tile
+            const uint32_t lo_off = 16 * ci;                       // chunk offset inside the payload tile
             const uint4 pv = *reinterpret_cast<const uint4 *>(&T.pay[lo_off]), pm = *reinterpret_cast<const uint4 *>(&T.pmask[lo_off]);
-            uint4 pcl = make_uint4(0, 0, 0, 0);
-            if (ro.qual) pcl = *reinterpret_cast<const uint4 *>(&T.pcls[lo_off]);
             if ((r0 | r1 | r2 | r3) & 0x80808080u) {               // case_convert (S:743-755): rare; the segment position of a marked
                 uint32_t kk = incl;                                // byte is found by walking the chunk's events again
                 for (uint32_t b = lo_m - c0; b < hi_m - c0; ++b) {
@@ -559,14 +565,15 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             }
             // letters on top of the copied bases; the payload tile is left clean for the next tile
             r0 = bfi(pm.x, pv.x, r0); r1 = bfi(pm.y, pv.y, r1); r2 = bfi(pm.z, pv.z, r2); r3 = bfi(pm.w, pv.w, r3);
+            if (ro.qual) { r0 &= 0xdfdfdfdfu; r1 &= 0xdfdfdfdfu; r2 &= 0xdfdfdfdfu; r3 &= 0xdfdfdfdfu; }   // back to upper case
             *reinterpret_cast<uint4 *>(&T.pay[lo_off]) = make_uint4(0, 0, 0, 0);
             *reinterpret_cast<uint4 *>(&T.pmask[lo_off]) = make_uint4(0, 0, 0, 0);
             uint64_t lo = (uint64_t)r0 | (uint64_t)r1 << 32, hi = (uint64_t)r2 | (uint64_t)r3 << 32;
             uint64_t qlo = 0, qhi = 0;
             uint32_t s0 = lo_m - c0, count = hi_m - lo_m;          // bytes [s0, s0 + count) of the chunk are this tile's
             if (ro.qual) {                                         // one quality per byte, class from the payload tile (S:1421-1423)
-                *reinterpret_cast<uint4 *>(&T.pcls[lo_off]) = make_uint4(0, 0, 0, 0);
-                const uint32_t cls0 = pc.kind ? NS_Q_UNMAPPED : NS_Q_MATCH;
+                // class per byte: NS_Q_MATCH 0, NS_Q_MIS 1 (payload), NS_Q_INS 2 (lower-case payload); NS_Q_UNMAPPED for unaligned reads
+                static_assert(NS_Q_MATCH == 0 && NS_Q_MIS == 1 && NS_Q_INS == 2, "class arithmetic below");
                 // The 16-bit draws of byte m are halfword m & 7 of Philox block m >> 3: the (up to) three blocks under the chunk go to
                 // the lane's LDS slot, the 16 draws come back with static offsets; then all look-ups of the chunk are issued in
                 // rounds (table bucket, two thresholds) instead of one dependent chain per byte.
@@ -578,7 +585,9 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
                     *reinterpret_cast<uint4 *>(slot + 16 * tb) = make_uint4(w.x, w.y, w.z, w.w);
                 }
                 const uint8_t *hb = slot + 2 * (int)(m0 & 7u) - 2 * (int)s0;          // halfword i of the chunk at hb + 2 i (i >= s0)
-                const uint32_t pcw[4] = {pcl.x, pcl.y, pcl.z, pcl.w};
+#define NS_CLS_WORD(PM, PV) (pc.kind ? 0x01010101u * NS_Q_UNMAPPED : ((PM) & 0x01010101u) + (((PV) >> 5) & 0x01010101u))
+                const uint32_t pcw[4] = {NS_CLS_WORD(pm.x, pv.x), NS_CLS_WORD(pm.y, pv.y), NS_CLS_WORD(pm.z, pv.z), NS_CLS_WORD(pm.w, pv.w)};
+#undef NS_CLS_WORD
 #pragma unroll
                 for (uint32_t half = 0; half < 2; ++half) {
                     uint32_t h[8], cl[8], q[8], t0[8], t1[8];
@@ -586,8 +595,7 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
                     for (uint32_t j = 0; j < 8; ++j) {
                         const uint32_t i = 8 * half + j;
                         h[j] = *reinterpret_cast<const uint16_t *>(hb + 2 * i);
-                        const uint32_t cb = (pcw[i >> 2] >> (8 * (i & 3))) & 0xffu;
-                        cl[j] = cb ? cb : cls0;
+                        cl[j] = (pcw[i >> 2] >> (8 * (i & 3))) & 0xffu;
                     }
 #pragma unroll
                     for (uint32_t j = 0; j < 8; ++j) q[j] = m.qual_lut[cl[j] * 1024u + (h[j] >> 6)];
@@ -622,6 +630,7 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             }
             if (!(dbg & 16)) pend = prep_chunk(ro, pq + lo_m, count, lo, hi, qlo, qhi);
         } else flush_chunk(ro, pend);
+        }
 
         jb = jb_next; M0 = M1;
         wave_sync();
