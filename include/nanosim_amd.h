@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define NS_ABI_VERSION 2u
+#define NS_ABI_VERSION 3u
 
 /* error codes */
 #define NS_OK 0
@@ -144,9 +144,11 @@ typedef struct ns_params {
     double median_len, sd_len;
     uint32_t emit_errlog;   /* 1: format the _aligned_error_profile rows on the device (S:2006-2008) */
     uint32_t meta;          /* 1: metagenome batch = one worker of simulation_aligned_metagenome (S:814-1040) / simulation_unaligned("metagenome") */
-    uint32_t trx;           /* 1: transcriptome batch = one worker of simulation_aligned_transcriptome (S:1043-1263, without intron
-                             * retention) / simulation_unaligned("transcriptome"); needs ns_set_transcriptome */
+    uint32_t trx;           /* 1: transcriptome batch = one worker of simulation_aligned_transcriptome (S:1043-1263) /
+                             * simulation_unaligned("transcriptome"); needs ns_set_transcriptome */
     uint32_t uracil;        /* --uracil: T -> U in the emitted sequence (S:1247-1248) */
+    uint32_t model_ir;      /* transcriptome, aligned reads: intron retention (S:1156-1183); needs ns_set_intron_retention */
+    uint32_t reserved0;
 } ns_params;
 
 /* ---- device-side result layout (copied out with ns_copy_out) -------------------------------------- */
@@ -166,7 +168,8 @@ typedef struct ns_event {
 #define NS_EV_PACK(len, type, shift) (((uint32_t)(len) & 0xfffu) | ((uint32_t)(type) & 3u) << 12 | (uint32_t)((shift) + NS_EV_SHIFT_BIAS) << 14)
 
 typedef struct ns_piece {   /* one aligned segment or one chimeric gap / unaligned body */
-    uint64_t ref_gpos;      /* start offset in the concatenated reference */
+    uint64_t ref_gpos;      /* start offset in the concatenated reference; >= NS_SPLICED_BASE: offset of a spliced pre-mRNA
+                             * stretch (intron retention) in the batch's splice arena (NS_BUF_SPLICED) */
     uint64_t ev_off;        /* first event in the event buffer */
     uint32_t chrom;
     uint32_t pos;           /* start inside the chromosome (the number in the read name, S:1747,1778) */
@@ -198,11 +201,13 @@ typedef struct ns_batch_info {
     uint64_t n_overflow;    /* reads that needed the event-capacity fallback pass */
     double ms_total;        /* device time of the whole batch (HIP events on the engine stream) */
     double ms_kernel[8];    /* per-kernel device time: see NS_K_* */
+    uint64_t spliced_bytes; /* intron retention: size of the splice arena (NS_BUF_SPLICED) */
 } ns_batch_info;
 
 enum { NS_K_LENGTHS = 0, NS_K_EVENTS = 1, NS_K_SCAN = 2, NS_K_MATERIALISE = 3, NS_K_HP = 4, NS_K_ERRLOG = 5 };
 enum { NS_BUF_RECORDS = 0, NS_BUF_READS = 1, NS_BUF_PIECES = 2, NS_BUF_EVENTS = 3, NS_BUF_ERRLOG = 4,
-       NS_BUF_POLYA = 5 /* uint16 per read: polyA tail length of a transcriptome batch */ };
+       NS_BUF_POLYA = 5 /* uint16 per read: polyA tail length of a transcriptome batch */,
+       NS_BUF_SPLICED = 6 /* intron retention: the spliced stretches (transcript orientation, device form of the bases) */ };
 
 typedef struct ns_ctx ns_ctx;
 
@@ -237,6 +242,30 @@ int ns_species_bases(ns_ctx *ctx, double *out);
  * transcripts of the --polya list (NULL: none); polya_scale = scale of the exponential tail length (S:1046-1053). */
 int ns_set_transcriptome(ns_ctx *ctx, uint32_t n_expr, const uint32_t *expr_chrom, const double *expr_cum,
                          const uint8_t *polya, double polya_scale);
+
+/* intron retention (src/simulator.py:403-452: the GFF3 structure of the transcripts, the IR Markov model and the genome FASTA
+ * that pysam serves in the reference).  Items of transcript t (a chromosome of the reference set with ns_set_reference) are
+ * item_off[t] .. item_off[t+1]-1 in GFF3 order; coordinates are HTSeq's (0-based start, length = end - start).  A read of a
+ * transcript in which update_structure (S:114-145) flags at least one intron as retained is cut from the genome by
+ * extract_read_pos (S:148-191, 1159-1177): its piece has pos = the genome coordinate in the read name and
+ * ref_gpos >= NS_SPLICED_BASE.  The host arrays are copied; NULL switches the feature off. */
+typedef struct ns_ir_tables {
+    const uint8_t *genome;          /* bases of the genome FASTA as they are in the file (case matters: S:1675-1680) */
+    const uint64_t *genome_off;     /* [n_gchrom + 1] */
+    uint32_t n_gchrom;
+    uint32_t n_items;
+    const uint32_t *item_off;       /* [n transcripts + 1] */
+    const uint8_t *item_type;       /* NS_IR_EXON / NS_IR_INTRON */
+    const uint8_t *item_minus;      /* 1: strand '-' */
+    const uint32_t *item_chrom;     /* chromosome of the genome FASTA; NS_IR_NO_CHROM: not in the file (S:1167-1169) */
+    const uint32_t *item_start;
+    const uint32_t *item_len;
+    double p_no_ir[3], p_ir[3];     /* rows start / no_IR / IR of <prefix>_IR_markov_model (S:414-422) */
+} ns_ir_tables;
+enum { NS_IR_EXON = 0, NS_IR_INTRON = 1 };
+#define NS_IR_NO_CHROM 0xffffffffu
+#define NS_SPLICED_BASE (1ull << 56)
+int ns_set_intron_retention(ns_ctx *ctx, const ns_ir_tables *tables);
 
 /* model: replaces the globals filled by read_profile() (src/simulator.py:473-591) */
 int ns_load_model(ns_ctx *ctx, const ns_model_tables *tables);

@@ -25,6 +25,7 @@
 #include "ns_materialise.h"
 #include "ns_chain.h"
 #include "ns_hp.h"
+#include "ns_ir.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // kernel arguments
@@ -35,6 +36,8 @@ struct GenArgs {
     DevRef ref;
     DevTrx tx;                  // transcriptome batches (prm.trx)
     uint16_t *polya;            // transcriptome: polyA tail length per read
+    DevIr ir;                   // transcriptome with intron retention (prm.model_ir)
+    uint64_t *ir_need;          // per read: bytes of its slot in the splice arena (0: not spliced)
     double cap_rate;            // event capacity per aligned reference base
     uint32_t cap_gap_mul;       // event capacity per gap/unaligned reference base
     // per-read planning arrays (n+1)
@@ -110,6 +113,7 @@ __device__ __forceinline__ uint32_t read_nseg(const GenArgs &A, const ns_key &ke
 __global__ void __launch_bounds__(256) k_nseg(GenArgs A) {
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > A.prm.n_reads) return;
+    if (A.ir_need) A.ir_need[r] = 0;
     if (r == A.prm.n_reads) { A.n_pieces[r] = 0; A.ev_cap[r] = 0; A.rec_len[r] = 0; A.err_len[r] = 0; return; }
     A.n_pieces[r] = 2 * read_nseg(A, make_key(A.prm, r)) - 1;
     if (!A.keep_state) { A.rstate[r] = 0; A.att_base[r] = 0; }
@@ -304,17 +308,31 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
             bool pos_ok = true;
             int64_t seq_len = (int64_t)rd.head + rd.tail;
             uint64_t ref_bases = 0;
+            bool spliced = false, ir_reach = false;                  // intron retention (S:1156-1177)
+            uint32_t ir_name = 0;
             for (uint32_t pi = 0; pi < n_pieces; ++pi) {
                 ns_piece p = pc[pi];
                 const uint32_t sid = p.kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
                 uint32_t chrom = 0; uint64_t pos = 0;
                 if (p.chrom == 1u && p.kind) { p.ref_len = 0; p.out_len = 0; p.n_ev = 0; }
-                else if (trx_al) {                                   // extract_read_trx (S:1683-1691): uniform start inside the transcript
-                    const u32x4 wp = ns_draw(key, ST_POS, sid, a, 0, 0);
-                    const uint64_t span = (uint64_t)(trx_len - (int64_t)p.ref_len) + 1;
-                    pos = (uint64_t)(u53_to_p(wp.x, wp.y) * (double)span);
-                    if (pos >= span) pos = span - 1;
+                else if (trx_al) {
                     chrom = trx_chrom;
+                    if (prm.model_ir && kind == NS_KIND_ALIGNED) {   // update_structure + extract_read_pos (S:1157-1160)
+                        const IrPlan ip = ir_walk(A.ir, trx_chrom, p.ref_len, (uint32_t)trx_len, key, a,
+                                                  [](uint32_t, uint32_t, uint32_t, uint32_t, bool) {});
+                        if (ip.any) {
+                            if (!ip.chrom_ok) { pos_ok = false; break; }                 // S:1167-1169
+                            spliced = true; pos = ip.first_start;                        // S:1175
+                            ir_reach = ip.last_end + 10u >= ip.struct_end;               // S:186
+                            ir_name = ip.name_extra ? 16u + ip.name_extra : 0u;          // "_RetainedIntron_" + "<start>-<end>;" ... (S:1189-1192)
+                        }
+                    }
+                    if (!spliced) {                                  // extract_read_trx (S:1683-1691): uniform start inside the transcript
+                        const u32x4 wp = ns_draw(key, ST_POS, sid, a, 0, 0);
+                        const uint64_t span = (uint64_t)(trx_len - (int64_t)p.ref_len) + 1;
+                        pos = (uint64_t)(u53_to_p(wp.x, wp.y) * (double)span);
+                        if (pos >= span) pos = span - 1;
+                    }
                 }
                 else if (prm.trx) {                                  // unaligned read: any transcript longer than it (S:1695-1703)
                     if (!extract_pos_trx_any(A.ref, p.ref_len, key, sid, a, chrom, pos)) { pos_ok = false; break; }
@@ -324,13 +342,15 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
                     if (!extract_pos_meta(A.ref, A.species_chrom_off, A.nspecies, p.ref_len, sp, key, sid, a, chrom, pos)) { pos_ok = false; break; }
                 }
                 else if (!extract_pos(A.ref, p.ref_len, key, sid, a, chrom, pos)) { pos_ok = false; break; }
-                p.chrom = chrom; p.pos = (uint32_t)pos; p.ref_gpos = A.ref.chrom_off[chrom] + pos;
+                p.chrom = chrom; p.pos = (uint32_t)pos;
+                p.ref_gpos = spliced ? NS_SPLICED_BASE : A.ref.chrom_off[chrom] + pos;   // (spliced: k_ir_splice fills in the arena offset)
                 pc[pi] = p;
                 seq_len += p.out_len;
                 ref_bases += p.ref_len;
             }
             uint32_t polya = 0;                                      // S:1046-1053, 1206-1209: exponential tail if the read reaches the 3' end
-            if (trx_al && pos_ok && A.tx.polya && A.tx.polya[trx_chrom] && (int64_t)pc[0].pos + (int64_t)pc[0].ref_len + 10 >= trx_len) {
+            if (trx_al && pos_ok && A.tx.polya && A.tx.polya[trx_chrom] &&
+                (spliced ? ir_reach : (int64_t)pc[0].pos + (int64_t)pc[0].ref_len + 10 >= trx_len)) {
                 const u32x4 wa = ns_draw(key, ST_TRX, 0, a, 1, 0);
                 const int64_t pl = (int64_t)fma(A.tx.polya_scale, -ns_log(u32_to_p(wa.x)), 2.0);    // int(expon.rvs(loc=2, scale))
                 polya = pl > 65535 ? 65535u : (uint32_t)pl;
@@ -352,7 +372,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
                 nl += (A.ref.name_off[p.chrom + 1] - A.ref.name_off[p.chrom] - 1) + 1 + dec_digits(p.pos) + dec_digits(p.ref_len);
             }
             // metagenome: the number of the read is only known once the accepted reads of the pass are counted (k_meta_commit)
-            nl += (kind == NS_KIND_UNALIGNED ? 11u : 9u) + (meta_al ? 0u : dec_digits(prm.first_read + r));
+            nl += (kind == NS_KIND_UNALIGNED ? 11u : 9u) + (meta_al ? 0u : dec_digits(prm.first_read + r)) + ir_name;
             if (kind == NS_KIND_ALIGNED && n_pieces > 1) nl += 9;
             nl += 2 /*_F*/ + 1 + dec_digits(rd.head) + 1 + 1 + dec_digits(rd.tail + polya);       // S:1211-1213: tail + polya_len
             uint64_t err_len = 0;
@@ -372,6 +392,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
                 A.rec_len[r] = prm.emit_records ? (uint64_t)nl + 2 + (uint64_t)seq_len + 1 + (prm.fastq ? (uint64_t)seq_len + 3 : 0) : 0;
                 A.err_len[r] = err_len;
                 if (A.polya) A.polya[r] = (uint16_t)polya;
+                if (A.ir_need) A.ir_need[r] = spliced ? ir_slot_bytes(pc[0].ref_len) : 0;
                 if (meta_al) { A.accept[r] = 1ull | (uint64_t)n_pieces << 32; A.sort_key[r] = evn; }   // (event count: taken back if -k rejects the read)
                 st_bases = A.hp ? 0ull : (unsigned long long)seq_len; st_ref = ref_bases; st_ev = evn;
             }
@@ -490,6 +511,16 @@ __global__ void __launch_bounds__(256) k_names(GenArgs A) {
     while (*tag) *p++ = (uint8_t)*tag++;
     p = put_dec(p, A.prm.first_read + r);
     if (kind == NS_KIND_ALIGNED && rd.n_pieces > 1) { const char *c = "_chimeric"; while (*c) *p++ = (uint8_t)*c++; }
+    if (pc[0].ref_gpos >= NS_SPLICED_BASE) {                          // "_RetainedIntron_<start>-<end>;..." (S:1189-1192)
+        const uint32_t trx = pc[0].chrom;
+        const uint32_t trx_len = (uint32_t)(A.ref.chrom_off[trx + 1] - A.ref.chrom_off[trx]);
+        bool open = false;
+        ir_walk(A.ir, trx, pc[0].ref_len, trx_len, read_key(A, r), rd.attempts, [&](uint32_t, uint32_t, uint32_t start, uint32_t end, bool retained) {
+            if (!retained) return;
+            if (!open) { const char *c = "_RetainedIntron_"; while (*c) *p++ = (uint8_t)*c++; open = true; }
+            p = put_dec(p, start); *p++ = '-'; p = put_dec(p, end); *p++ = ';';
+        });
+    }
     *p++ = '_'; *p++ = rd.reversed ? 'R' : 'F';
     *p++ = '_'; p = put_dec(p, rd.head);
     *p++ = '_';
@@ -505,6 +536,40 @@ __global__ void __launch_bounds__(256) k_names(GenArgs A) {
     p += rd.seq_len;
     *p++ = '\n';
     if (A.prm.fastq) { *p++ = '+'; *p++ = '\n'; p += rd.seq_len; *p++ = '\n'; }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_ir_splice: intron retention — one wavefront per read whose structure has a retained intron: the exons / retained introns under
+// the read are copied from the genome into the read's slot of the splice arena (S:1161-1178), in the orientation of the transcript
+// (reverse_complement for strand '-', which only knows upper-case ACGT, S:1675-1680) and in the device form of the bases
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ir_splice(GenArgs A) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= A.prm.n_reads) return;
+    const uint64_t off = A.ir.arena_off[r];
+    if (A.ir.arena_off[r + 1] == off) return;
+    const ns_read rd = A.reads[r];
+    if (rd.flags) return;
+    ns_piece *pp = A.pieces + rd.piece_off;
+    const ns_key key = read_key(A, r);
+    const uint32_t trx = pp->chrom, L = pp->ref_len;
+    const uint32_t trx_len = (uint32_t)(A.ref.chrom_off[trx + 1] - A.ref.chrom_off[trx]);
+    uint8_t *dst = A.ir.arena + off + NS_IR_PAD;
+    const IrPlan ip = ir_walk(A.ir, trx, L, trx_len, key, rd.attempts, [](uint32_t, uint32_t, uint32_t, uint32_t, bool) {});
+    uint32_t done = 0;
+    ir_walk(A.ir, trx, L, trx_len, key, rd.attempts, [&](uint32_t, uint32_t chrom, uint32_t start, uint32_t end, bool) {
+        const uint8_t *src = A.ir.genome + A.ir.genome_off[chrom] + start;
+        for (uint32_t i = lane; i < end - start; i += 64) {
+            uint32_t c = src[i];
+            if (ip.minus) {
+                c = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : c;
+                dst[L - 1 - (done + i)] = normalise_base(c);
+            } else dst[done + i] = normalise_base(c);
+        }
+        done += end - start;
+    });
+    if (lane == 0) pp->ref_gpos = NS_SPLICED_BASE + off + NS_IR_PAD;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1139,6 +1204,11 @@ struct ns_ctx {
     DevBuf trx_chrom, trx_cum, trx_polya, polya;            // transcriptome: expression view of the reference, polyA length per read
     DevTrx tx{};
     bool has_trx = false;
+    DevIr ir{};                                             // intron retention: genome, transcript structures, Markov chain
+    bool has_ir = false;
+    std::vector<void *> ir_allocs;
+    DevBuf ir_need, ir_off, spliced;
+    uint64_t spliced_bytes = 0;
     struct PinBuf { void *p = nullptr; size_t cap = 0; } pin_a, pin_b, pin_c;     // pinned host staging of the metagenome passes
     uint32_t nspecies = 0;
     bool has_abun = false, has_inflated = false, has_key_pos = false;
@@ -1260,6 +1330,7 @@ void ns_destroy(ns_ctx *ctx) {
     if (ctx->ev_join) e = hipEventDestroy(ctx->ev_join);
     free_pool(ctx->model_allocs);
     free_pool(ctx->ref_allocs);
+    free_pool(ctx->ir_allocs);
     if (ctx->ref_bases_owned) e = hipFree(ctx->ref_bases_owned);
     DevBuf *bufs[] = {&ctx->n_pieces, &ctx->piece_off, &ctx->ev_cap, &ctx->ev_off, &ctx->rec_len, &ctx->rec_off,
                       &ctx->err_len, &ctx->err_off, &ctx->name_len, &ctx->reads, &ctx->pieces, &ctx->events,
@@ -1268,7 +1339,8 @@ void ns_destroy(ns_ctx *ctx) {
                       &ctx->scr_len, &ctx->scr_off, &ctx->hp_len, &ctx->slow_q, &ctx->ev_word, &ctx->l_cap, &ctx->l_off, &ctx->species_chrom_off, &ctx->t_reads, &ctx->t_pieces,
                       &ctx->t_name_len, &ctx->t_rec_len, &ctx->t_err_len, &ctx->accept, &ctx->accept_scan, &ctx->key_pos,
                       &ctx->draw_x, &ctx->m_segptr, &ctx->m_len, &ctx->m_species, &ctx->species_bases, &ctx->draw_sel,
-                      &ctx->draw_sorted, &ctx->meta_words, &ctx->meta_num, &ctx->trx_chrom, &ctx->trx_cum, &ctx->trx_polya, &ctx->polya};
+                      &ctx->draw_sorted, &ctx->meta_words, &ctx->meta_num, &ctx->trx_chrom, &ctx->trx_cum, &ctx->trx_polya, &ctx->polya,
+                      &ctx->ir_need, &ctx->ir_off, &ctx->spliced};
     for (auto *pb : {&ctx->pin_a, &ctx->pin_b, &ctx->pin_c})
         if (pb->p) e = hipHostFree(pb->p);
     for (DevBuf *b : bufs)
@@ -1286,6 +1358,7 @@ static int set_ref_meta(ns_ctx *ctx, const uint64_t *chrom_off, uint32_t nchrom,
     free_pool(ctx->ref_allocs);
     ctx->nspecies = 0;                           // the species / expression views belong to the previous reference
     ctx->has_trx = false;
+    ctx->has_ir = false;
     std::vector<uint32_t> noff(nchrom + 1);
     uint64_t p = 0;
     for (uint32_t c = 0; c < nchrom; ++c) {
@@ -1599,6 +1672,50 @@ int ns_set_transcriptome(ns_ctx *ctx, uint32_t n_expr, const uint32_t *expr_chro
         ctx->tx.polya = (const uint8_t *)ctx->trx_polya.p;
     }
     ctx->has_trx = true;
+    return NS_OK;
+}
+
+int ns_set_intron_retention(ns_ctx *ctx, const ns_ir_tables *t) {
+    if (!ctx) return NS_EINVAL;
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->has_ir = false;
+    free_pool(ctx->ir_allocs);
+    ctx->ir = DevIr{};
+    if (!t) return NS_OK;
+    if (!ctx->has_ref) return fail(ctx, NS_ESTATE, "ns_set_intron_retention before ns_set_reference");
+    const uint32_t ntr = ctx->ref.nchrom;
+    if (!t->genome || !t->genome_off || !t->n_gchrom || !t->item_off) return fail(ctx, NS_EINVAL, "intron retention tables missing");
+    if (t->item_off[0] != 0 || t->item_off[ntr] != t->n_items) return fail(ctx, NS_EINVAL, "item_off does not cover n_items");
+    for (uint32_t c = 0; c < ntr; ++c)
+        if (t->item_off[c] > t->item_off[c + 1]) return fail(ctx, NS_EINVAL, "item_off not ascending");
+    for (uint32_t i = 0; i < t->n_items; ++i) {
+        if (t->item_type[i] > NS_IR_INTRON) return fail(ctx, NS_EINVAL, "bad item type");
+        const uint32_t c = t->item_chrom[i];
+        if (c == NS_IR_NO_CHROM) continue;
+        if (c >= t->n_gchrom) return fail(ctx, NS_EINVAL, "item chromosome out of range");
+        if ((uint64_t)t->item_start[i] + t->item_len[i] > t->genome_off[c + 1] - t->genome_off[c])
+            return fail(ctx, NS_EINVAL, "item reaches beyond its chromosome");
+    }
+    for (int k = 0; k < 3; ++k)
+        if (!(t->p_no_ir[k] >= 0 && t->p_ir[k] >= 0 && t->p_no_ir[k] + t->p_ir[k] <= 1.0 + 1e-9))
+            return fail(ctx, NS_EINVAL, "IR Markov model rows must be probabilities");
+    int rc;
+    DevIr d{};
+    const uint64_t glen = t->genome_off[t->n_gchrom];
+    if ((rc = upload(ctx, ctx->ir_allocs, t->genome, (size_t)glen, &d.genome)) ||
+        (rc = upload(ctx, ctx->ir_allocs, t->genome_off, (size_t)t->n_gchrom + 1, &d.genome_off)) ||
+        (rc = upload(ctx, ctx->ir_allocs, t->item_off, (size_t)ntr + 1, &d.item_off)))
+        return rc;
+    if (t->n_items &&
+        ((rc = upload(ctx, ctx->ir_allocs, t->item_type, (size_t)t->n_items, &d.item_type)) ||
+         (rc = upload(ctx, ctx->ir_allocs, t->item_minus, (size_t)t->n_items, &d.item_minus)) ||
+         (rc = upload(ctx, ctx->ir_allocs, t->item_chrom, (size_t)t->n_items, &d.item_chrom)) ||
+         (rc = upload(ctx, ctx->ir_allocs, t->item_start, (size_t)t->n_items, &d.item_start)) ||
+         (rc = upload(ctx, ctx->ir_allocs, t->item_len, (size_t)t->n_items, &d.item_len))))
+        return rc;
+    for (int k = 0; k < 3; ++k) { d.p_no_ir[k] = t->p_no_ir[k]; d.p_ir[k] = t->p_ir[k]; }
+    ctx->ir = d;
+    ctx->has_ir = true;
     return NS_OK;
 }
 
@@ -1938,6 +2055,11 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         if (prm->meta || prm->chimeric || prm->use_lognormal) return fail(ctx, NS_EINVAL, "transcriptome batches are neither metagenome nor chimeric nor log-normal");
         if (prm->kind != NS_KIND_UNALIGNED && !(ctx->m.flags & NS_MODEL_HAS_KDE2D)) return fail(ctx, NS_EINVAL, "model has no 2-D KDE (_aligned_region_2d)");
     }
+    if (prm->model_ir) {
+        if (!prm->trx) return fail(ctx, NS_EINVAL, "model_ir is a transcriptome option");
+        if (!ctx->has_ir) return fail(ctx, NS_ESTATE, "model_ir batch before ns_set_intron_retention");
+    }
+    const bool ir_on = prm->model_ir && prm->kind == NS_KIND_ALIGNED;       // S:1156: not for --perfect, not for unaligned reads
     if (prm->n_reads > 0x7ffffff0ull) return fail(ctx, NS_EINVAL, "batch too large (split into several calls)");
     if (prm->first_read + prm->n_reads >= (1ull << 40)) return fail(ctx, NS_EINVAL, "read index exceeds 2^40");
     HIPCHK(hipSetDevice(ctx->device));
@@ -1977,6 +2099,11 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         if ((rc = ensure(ctx, ctx->polya, (n + 1) * 2))) return rc;
         A.tx = ctx->tx; A.polya = (uint16_t *)ctx->polya.p;
         HIPCHK(hipMemsetAsync(ctx->polya.p, 0, (n + 1) * 2, ctx->stream));
+    }
+    ctx->spliced_bytes = 0;
+    if (ir_on) {
+        if ((rc = ensure(ctx, ctx->ir_need, (n + 1) * 8)) || (rc = ensure(ctx, ctx->ir_off, (n + 1) * 8))) return rc;
+        A.ir = ctx->ir; A.ir_need = (uint64_t *)ctx->ir_need.p;
     }
     A.meta = prm->meta ? 1u : 0u; A.nspecies = ctx->nspecies; A.species_chrom_off = (const uint32_t *)ctx->species_chrom_off.p;
     A.next_n = (uint32_t *)((unsigned long long *)ctx->stats.p + 6);
@@ -2089,6 +2216,20 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         if (retry >= 6) return fail(ctx, NS_ENOMEM, "event capacity overflow persists after 6 retries");
         cap_rate *= 2.0; A.cap_gap_mul *= 2;          // rare: more events per base than planned -> re-plan the batch with twice the rates
     }
+    if (ir_on) {          // splice arena: slot offsets, then the copy from the genome (before anything reads the pieces' bases)
+        if ((rc = scan_u64(ctx, A.ir_need, (uint64_t *)ctx->ir_off.p, n + 1))) return rc;
+        uint64_t arena_bytes = 0;
+        HIPCHK(hipMemcpyAsync(&arena_bytes, (uint64_t *)ctx->ir_off.p + n, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if ((rc = ensure(ctx, ctx->spliced, (size_t)arena_bytes + 64))) return rc;
+        A.ir.arena = (uint8_t *)ctx->spliced.p; A.ir.arena_off = (const uint64_t *)ctx->ir_off.p;
+        A.ref.spliced = (const uint8_t *)ctx->spliced.p;
+        ctx->spliced_bytes = arena_bytes;
+        if (arena_bytes) {
+            k_ir_splice<<<grid_w, blk, 0, st>>>(A);
+            HIPCHK(hipGetLastError());
+        }
+    }
     if (!A.hp) break;
     if ((rc = hp_stage1(ctx, prm, A, n, tot_pieces, tot_cap, stats, &ms_hp))) return rc;
     if (!stats[5]) break;
@@ -2138,6 +2279,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     info->ms_kernel[NS_K_HP] = ms_hp;
     info->n_reads = n; info->n_pieces = tot_pieces; info->n_events = tot_cap;
     info->total_bases = stats[1]; info->total_ref_bases = stats[2]; info->events_used = stats[3];
+    info->spliced_bytes = ctx->spliced_bytes;
     ctx->last = *info;
     ctx->last.n_events = tot_cap;
     ctx->has_batch = true;
@@ -2153,6 +2295,7 @@ static int result_buf(ns_ctx *ctx, int which, const void **p, uint64_t *size) {
         case NS_BUF_EVENTS: *p = ctx->events.p; *size = b.n_events * sizeof(ns_event); return NS_OK;
         case NS_BUF_ERRLOG: *p = ctx->errlog.p; *size = b.errlog_bytes; return NS_OK;
         case NS_BUF_POLYA: *p = ctx->polya.p; *size = ctx->polya.p ? b.n_reads * 2 : 0; return NS_OK;
+        case NS_BUF_SPLICED: *p = ctx->spliced.p; *size = ctx->spliced_bytes; return NS_OK;
         default: return NS_EINVAL;
     }
 }

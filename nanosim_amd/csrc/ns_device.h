@@ -59,6 +59,7 @@ struct DevRef {
     const char *names;            // NUL-separated
     const uint32_t *name_off;     // [nchrom+1] offsets into names
     uint32_t nchrom;
+    const uint8_t *spliced;       // intron retention: the batch's splice arena (pieces with ref_gpos >= NS_SPLICED_BASE read from it)
 };
 
 // ---- table look-ups ------------------------------------------------------------------------------------

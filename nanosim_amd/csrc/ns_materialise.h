@@ -277,6 +277,10 @@ __device__ __forceinline__ PieceCtx load_piece(const ns_event *events, const Dev
     pc.ev = events + p.ev_off; pc.wd = nullptr; pc.n_ev = p.n_ev; pc.out_len = p.out_len; pc.ref_len = p.ref_len;
     pc.chrom_base = ref.chrom_off[p.chrom];
     pc.chrom_len = ref.chrom_off[p.chrom + 1] - pc.chrom_base;
+    if (p.ref_gpos >= NS_SPLICED_BASE) {                    // intron retention: the stretch lies in the splice arena; pos is a genome coordinate
+        pc.chrom_base = (uint64_t)((uintptr_t)ref.spliced - (uintptr_t)ref.bases) + (p.ref_gpos - NS_SPLICED_BASE) - p.pos;
+        pc.chrom_len = ~0ull;
+    }
     pc.pos = p.pos; pc.kind = p.kind;
     pc.sid = p.kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
     return pc;
@@ -291,6 +295,11 @@ __device__ __forceinline__ PieceCtx load_piece_uniform(const ns_event *events, c
     pc.chrom_base = uni64(ref.chrom_off[chrom]);
     pc.chrom_len = uni64(ref.chrom_off[chrom + 1]) - pc.chrom_base;
     pc.pos = uni(p.pos); pc.kind = uni(p.kind);
+    const uint64_t gpos = uni64(p.ref_gpos);
+    if (gpos >= NS_SPLICED_BASE) {
+        pc.chrom_base = (uint64_t)((uintptr_t)ref.spliced - (uintptr_t)ref.bases) + (gpos - NS_SPLICED_BASE) - pc.pos;
+        pc.chrom_len = ~0ull;
+    }
     pc.sid = pc.kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
     return pc;
 }

@@ -11,7 +11,7 @@
 enum : uint32_t {
     ST_NSEG = 1, ST_REFLEN = 2, ST_GAPLEN = 3, ST_HT = 4, ST_RATIO = 5, ST_STRAND = 6, ST_EVENT = 7,
     ST_UEVENT = 8, ST_POS = 9, ST_IUPAC = 10, ST_SUB = 11, ST_INS = 12, ST_QUAL = 13, ST_HTQ = 14,
-    ST_HEAD = 15, ST_TAIL = 16, ST_HPLEN = 17, ST_HPMIS = 18, ST_HPQ = 19, ST_ULEN = 20, ST_SPECIES = 21, ST_TRX = 22
+    ST_HEAD = 15, ST_TAIL = 16, ST_HPLEN = 17, ST_HPMIS = 18, ST_HPQ = 19, ST_ULEN = 20, ST_SPECIES = 21, ST_TRX = 22, ST_IR = 23
 };
 #define NS_GAP_SEG 128u
 #define NS_MAX_ATTEMPT 1000u

@@ -13,14 +13,15 @@ from .model import (EVENT_DTYPE, PIECE_DTYPE, READ_DTYPE, Model, NsBatchInfo, Ns
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NANOSIM_AMD_LIB") or os.path.join(_HERE, "libnanosim_amd.so")   # override: A/B builds only
-NS_BUF_RECORDS, NS_BUF_READS, NS_BUF_PIECES, NS_BUF_EVENTS, NS_BUF_ERRLOG, NS_BUF_POLYA = 0, 1, 2, 3, 4, 5
+NS_BUF_RECORDS, NS_BUF_READS, NS_BUF_PIECES, NS_BUF_EVENTS, NS_BUF_ERRLOG, NS_BUF_POLYA, NS_BUF_SPLICED = 0, 1, 2, 3, 4, 5, 6
+NS_SPLICED_BASE = 1 << 56
 NS_EINVAL, NS_ENODEV, NS_ENOMEM, NS_EHIP, NS_ESTATE = -1, -2, -3, -4, -5
 NS_KIND_ALIGNED, NS_KIND_UNALIGNED, NS_KIND_PERFECT = 0, 1, 2
 KERNEL_NAMES = ("plan(k_nseg+k_lengths+scan+sort)", "k_chain", "k_names", "k_materialise", "k_hp", "k_errlog")
 EXPORTS = ("ns_abi_version", "ns_create", "ns_destroy", "ns_last_error", "ns_set_reference",
            "ns_set_reference_device", "ns_load_model", "ns_generate", "ns_copy_out", "ns_device_ptr",
            "ns_set_species", "ns_set_abundance", "ns_species_bases", "ns_host_alloc", "ns_host_free",
-           "ns_set_transcriptome")
+           "ns_set_transcriptome", "ns_set_intron_retention")
 
 _lib = None
 
@@ -66,6 +67,8 @@ def load_library(path: str = LIB_PATH):
     L.ns_species_bases.argtypes = [C.c_void_p, C.c_void_p]
     L.ns_set_transcriptome.restype = C.c_int
     L.ns_set_transcriptome.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+    L.ns_set_intron_retention.restype = C.c_int
+    L.ns_set_intron_retention.argtypes = [C.c_void_p, C.c_void_p]
     L.ns_host_alloc.restype = C.c_int
     L.ns_host_alloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
     L.ns_host_free.restype = C.c_int
@@ -110,6 +113,10 @@ class Batch:
     def polya(self):
         """polyA tail length per read (transcriptome batches)"""
         return self._copy(NS_BUF_POLYA, np.uint16, int(self.info.n_reads))
+
+    def spliced(self):
+        """intron retention: the splice arena of the batch (pieces with ref_gpos >= NS_SPLICED_BASE point into it)"""
+        return self._copy(NS_BUF_SPLICED, np.uint8, int(self.info.spliced_bytes))
 
     def kernel_ms(self):
         return {KERNEL_NAMES[i]: float(self.info.ms_kernel[i]) for i in range(len(KERNEL_NAMES))}
@@ -190,6 +197,14 @@ class Engine:
         self._check(self.L.ns_set_transcriptome(self.ctx, len(ec), ec.ctypes.data, cum.ctypes.data, pa.ctypes.data if pa.any() else None,
                                                 float(tr.polya_scale)))
 
+    def set_intron_retention(self, ir):
+        """ir: nanosim_amd.intron_retention.IntronRetention for the transcriptome set before (None: off)"""
+        if ir is None:
+            self._check(self.L.ns_set_intron_retention(self.ctx, None))
+            return
+        t = ir.to_c()
+        self._check(self.L.ns_set_intron_retention(self.ctx, C.byref(t)))
+
     def set_abundance(self, meta_ref, abun: dict, abun_inflated: dict | None = None):
         ab = np.array([abun[sp] for sp in meta_ref.species], dtype=np.float64)
         inf = np.array([abun_inflated[sp] for sp in meta_ref.species], dtype=np.float64) if abun_inflated else None
@@ -219,7 +234,8 @@ class Engine:
 
 
 def make_params(*, seed, first_read, n_reads, kind=NS_KIND_ALIGNED, fastq=False, kmer_bias=0, chimeric=False,
-                min_len=50, max_len, median_len=None, sd_len=None, emit_records=True, emit_errlog=False, meta=False, trx=False, uracil=False) -> NsParams:
+                min_len=50, max_len, median_len=None, sd_len=None, emit_records=True, emit_errlog=False, meta=False, trx=False, uracil=False,
+                model_ir=False) -> NsParams:
     p = NsParams()
     p.seed, p.first_read, p.n_reads, p.kind = seed, first_read, n_reads, kind
     p.fastq, p.kmer_bias, p.chimeric = int(bool(fastq)), int(kmer_bias or 0), int(bool(chimeric))
@@ -230,4 +246,5 @@ def make_params(*, seed, first_read, n_reads, kind=NS_KIND_ALIGNED, fastq=False,
     p.meta = int(bool(meta))
     p.trx = int(bool(trx))
     p.uracil = int(bool(uracil))
+    p.model_ir = int(bool(model_ir))
     return p

@@ -14,7 +14,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-NS_ABI_VERSION = 2
+NS_ABI_VERSION = 3
 NS_KDE_ALIGNED, NS_KDE_HT, NS_KDE_RATIO, NS_KDE_UNALIGNED, NS_KDE_GAP, NS_KDE_COUNT = 0, 1, 2, 3, 4, 5
 NS_Q_NAMES = ("match", "mis", "ins", "ht", "unmapped")
 NS_QUAL_LEVELS = 128
@@ -67,14 +67,22 @@ class NsParams(C.Structure):
                 ("use_lognormal", C.c_uint32), ("emit_records", C.c_uint32),
                 ("min_len", C.c_int64), ("max_len", C.c_int64),
                 ("median_len", C.c_double), ("sd_len", C.c_double),
-                ("emit_errlog", C.c_uint32), ("meta", C.c_uint32), ("trx", C.c_uint32), ("uracil", C.c_uint32)]
+                ("emit_errlog", C.c_uint32), ("meta", C.c_uint32), ("trx", C.c_uint32), ("uracil", C.c_uint32),
+                ("model_ir", C.c_uint32), ("reserved0", C.c_uint32)]
+
+
+class NsIrTables(C.Structure):
+    """ns_ir_tables of include/nanosim_amd.h"""
+    _fields_ = [("genome", C.c_void_p), ("genome_off", C.c_void_p), ("n_gchrom", C.c_uint32), ("n_items", C.c_uint32),
+                ("item_off", C.c_void_p), ("item_type", C.c_void_p), ("item_minus", C.c_void_p), ("item_chrom", C.c_void_p),
+                ("item_start", C.c_void_p), ("item_len", C.c_void_p), ("p_no_ir", C.c_double * 3), ("p_ir", C.c_double * 3)]
 
 
 class NsBatchInfo(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_pieces", C.c_uint64), ("n_events", C.c_uint64),
                 ("events_used", C.c_uint64), ("record_bytes", C.c_uint64), ("errlog_bytes", C.c_uint64), ("total_bases", C.c_uint64),
                 ("total_ref_bases", C.c_uint64), ("n_overflow", C.c_uint64),
-                ("ms_total", C.c_double), ("ms_kernel", C.c_double * 8)]
+                ("ms_total", C.c_double), ("ms_kernel", C.c_double * 8), ("spliced_bytes", C.c_uint64)]
 
 
 EVENT_DTYPE = np.dtype([("pos", "<u4"), ("info", "<u4")])
@@ -495,9 +503,9 @@ def normalise_name(header_name: str) -> str:
     return "-".join(info).split(".")[0]                 # S:345-347
 
 
-def read_fasta(path: str, dna_type: str = "linear") -> Reference:
+def read_fasta(path: str, dna_type: str = "linear", raw_names: bool = False) -> Reference:
     """FASTA/FASTQ reader with readfq's record semantics (src/simulator.py:709-740) for FASTA input and
-    the chromosome-name normalisation of S:344-347."""
+    the chromosome-name normalisation of S:344-347 (raw_names: the header up to the first white space instead)."""
     data = np.fromfile(path, dtype=np.uint8)
     if data.size == 0:
         raise ValueError("empty reference file " + path)
@@ -520,7 +528,7 @@ def read_fasta(path: str, dna_type: str = "linear") -> Reference:
         body_end = starts[si + 1] if si + 1 < len(starts) else n
         body = data[e + 1:body_end]
         body = body[(body != 10) & (body != 13)]
-        names.append(normalise_name(name))
+        names.append(hdr.split()[0] if raw_names and hdr.split() else normalise_name(name))
         chunks.append(body)
     if not names:
         raise ValueError("no FASTA records in " + path)

@@ -253,3 +253,83 @@ def write_expression(path: str, expr) -> None:
         f.write("target_id\test_counts\ttpm\n")
         for tid, cnt, tpm in expr:
             f.write("%s\t%s\t%s\n" % (tid, repr(cnt), repr(tpm)))
+
+
+def _revcomp(seq: np.ndarray) -> np.ndarray:
+    lut = np.arange(256, dtype=np.uint8)
+    for a, b in (b"AT", b"TA", b"CG", b"GC", b"at", b"ta", b"cg", b"gc"):
+        lut[a] = b
+    return lut[seq[::-1]]
+
+
+def synth_annotation(recs, seed: int, *, n_chrom: int = 3, chr_prefix: bool = True, max_exons: int = 6,
+                     unannotated_frac: float = 0.1, p_model=((0.8, 0.2), (0.9, 0.1), (0.6, 0.4))):
+    """Genome + GFF3 structure + IR Markov model for the transcripts `recs` of synth_transcriptome, in the layout the
+    transcriptome mode reads with intron retention on (S:403-452): every annotated transcript is cut into exons, random introns
+    (partly soft-masked, a few N) go between them, and the pre-mRNA is laid onto a strand of one of the chromosomes, so that the
+    exons of a transcript add up to its sequence.  A few transcripts are left without structure, one gets exons that do not add
+    up, one sits on a chromosome the genome FASTA lacks — the cases the worker filters (S:1095-1097, 1167-1169).
+    -> (genome records, GFF3 text, Markov model text)"""
+    rng = np.random.Generator(np.random.Philox(seed))
+    chroms = [[] for _ in range(n_chrom)]           # list of arrays per chromosome
+    clen = [0] * n_chrom
+    lines = ["##gff-version 3"]
+
+    def spacer(c, n):
+        s = synth_sequence(n, int(rng.integers(1 << 30)), lower_frac=0.3)
+        chroms[c].append(s); clen[c] += n
+
+    for c in range(n_chrom):
+        spacer(c, 500)
+    for ti, (name, seq) in enumerate(recs):
+        if rng.random() < unannotated_frac:
+            continue
+        L = len(seq)
+        n_ex = int(min(max_exons, max(1, L // 120), 1 + rng.integers(0, max_exons)))
+        cuts = np.sort(rng.choice(np.arange(1, L), size=n_ex - 1, replace=False)) if n_ex > 1 else np.array([], dtype=np.int64)
+        bounds = [0] + [int(x) for x in cuts] + [L]
+        exons = [seq[bounds[i]:bounds[i + 1]] for i in range(n_ex)]
+        introns = []
+        for _ in range(n_ex - 1):
+            il = int(rng.integers(40, 600))
+            s = synth_sequence(il, int(rng.integers(1 << 30)), lower_frac=0.5, iupac_frac=0.002)
+            if rng.random() < 0.3:
+                s[il // 3: il // 3 + 5] = ord("N")
+            introns.append(s)
+        parts, kinds = [], []
+        for i in range(n_ex):
+            parts.append(exons[i]); kinds.append("exon")
+            if i + 1 < n_ex:
+                parts.append(introns[i]); kinds.append("intron")
+        minus = bool(rng.random() < 0.5)
+        if minus:                                       # the genome carries the other strand; GFF3 order = ascending coordinates
+            parts = [_revcomp(p) for p in parts[::-1]]
+            kinds = kinds[::-1]
+        c = int(rng.integers(0, n_chrom))
+        missing_chrom = (ti % 37 == 5)
+        cname = ("chr" if chr_prefix else "") + ("Un9" if missing_chrom else str(c + 1))
+        style = ti % 4
+        tid = name
+        pos = clen[c]
+        bad_sum = (ti % 41 == 7)
+        lines.append("%s\tsynth\tgene\t%d\t%d\t.\t%s\t.\tID=gene:G%d" % (cname, pos + 1, pos + sum(len(p) for p in parts), "-" if minus else "+", ti))
+        for k, (p, kind) in enumerate(zip(parts, kinds)):
+            start1, end1 = pos + 1, pos + len(p)                       # GFF3: 1-based, end included
+            if bad_sum and kind == "exon" and k == 0:
+                end1 -= 1 if len(p) > 1 else 0
+            if style == 0:
+                attr = "transcript_id=%s;exon_number=%d" % (tid, k)
+            elif style == 1:
+                attr = "Parent=transcript:%s" % tid
+            elif style == 2:
+                attr = "Parent=%s;rank=%d" % (tid, k)
+            else:
+                attr = 'ID="%s:%s;%d";transcript_id=%s' % (kind, tid, k, tid)    # quoted value with a ';' inside
+            lines.append("%s\tsynth\t%s\t%d\t%d\t.\t%s\t.\t%s" % (cname, kind, start1, end1, "-" if minus else "+", attr))
+            chroms[c].append(p); clen[c] += len(p); pos += len(p)
+        if ti % 5 == 0:                                # a feature the reader must skip: exon whose first attribute names no transcript
+            lines.append("%s\tsynth\texon\t%d\t%d\t.\t+\t.\tID=exon:X%d;Parent=gene:G%d" % (cname, 1, 10, ti, ti))
+        spacer(c, int(rng.integers(50, 400)))
+    genome = [(("chr" if chr_prefix else "") + str(c + 1) + " synthetic chromosome", np.concatenate(chroms[c])) for c in range(n_chrom)]
+    model = "state\tno_IR\tIR\n" + "".join("%s\t%r\t%r\n" % (st, p[0], p[1]) for st, p in zip(("start", "no_IR", "IR"), p_model))
+    return genome, "\n".join(lines) + "\n", model

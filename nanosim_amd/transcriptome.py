@@ -61,6 +61,19 @@ def make_cdf(dict_exp: dict, dict_len: dict):
     return [(k, dict_len[k]) for k, _ in vals], [float(w) for w in weights]
 
 
+def restrict_expression(tr: TranscriptomeReference, eligible: np.ndarray) -> TranscriptomeReference:
+    """Intron retention on: the worker redraws the transcript until it is annotated with a consistent structure (S:1093-1099);
+    drawing from the weights of the eligible transcripts alone is the same distribution."""
+    keep = np.asarray(eligible, dtype=bool)[tr.expr_chrom]
+    if not keep.any():
+        raise SystemExit("No expressed transcript has a GFF3 structure whose exons add up to its length "
+                         "(intron retention needs <prefix>_added_intron_final.gff3 to match the reference transcriptome)")
+    w = tr.expr_weight[keep]
+    return TranscriptomeReference(ref=tr.ref, expr_chrom=tr.expr_chrom[keep].copy(),
+                                  expr_cum=np.array(list(itertools.accumulate(float(x) for x in w)), dtype=np.float64),
+                                  expr_weight=w.copy(), polya=tr.polya, polya_scale=tr.polya_scale)
+
+
 def read_transcriptome(fasta: str, expression: str, polya: str | None = None, basecaller: str | None = None) -> TranscriptomeReference:
     ref = read_fasta(fasta, "linear")
     lens = np.diff(ref.chrom_off.astype(np.int64))

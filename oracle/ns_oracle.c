@@ -652,6 +652,7 @@ typedef struct nso_out {
     uint8_t *errlog; uint64_t cap_errlog;
     uint64_t n_pieces, n_events, record_bytes, errlog_bytes, total_bases, total_ref_bases;
     uint16_t *polya;                 /* transcriptome: polyA tail length per read (may be NULL) */
+    uint8_t *spliced; uint64_t cap_spliced, spliced_bytes;   /* intron retention: the spliced stretches (may be NULL) */
 } nso_out;
 
 #define NSO_MAX_SEG 64
@@ -773,9 +774,9 @@ int nso_extract_meta(const nso_meta *mg, const uint64_t *chrom_off, const uint8_
 }
 
 /* ================================================================================================
- * transcriptome mode (without intron retention)
+ * transcriptome mode
  * ============================================================================================== */
-enum { ST_TRX = 22 };
+enum { ST_TRX = 22, ST_IR = 23 };
 
 typedef struct nso_trx {             /* expression view of the reference transcripts (src/simulator.py:382-399, 460-470) */
     uint32_t n_expr;
@@ -783,7 +784,69 @@ typedef struct nso_trx {             /* expression view of the reference transcr
     const double *expr_cum;              /* running sum of ecdf_weight_list, as random.choices accumulates it (S:1084) */
     const uint8_t *polya;                /* [nchrom] 1 = listed in --polya, or NULL */
     double polya_scale;                  /* S:1046-1049 */
+    const ns_ir_tables *ir;              /* intron retention (S:403-452) or NULL */
 } nso_trx;
+
+/* ---- intron retention ---------------------------------------------------------------------------
+ * PARITY: nso_ir_states is pinned against the reference's update_structure (tests/golden/reference_ir.json); nso_extract_read_pos
+ * and the splice below are restated from S:148-191 / S:1159-1178 but UNPINNED: the reference's code for them runs through HTSeq
+ * and pysam, which this image lacks. */
+
+/* update_structure (S:114-145): u[k] is the random.random() of intron k; retained[k] = 1 for "IR".  Returns flag_ir.
+ * (A p beyond both intervals of the row — its two probabilities summing to less than 1 — appends nothing in the reference, which
+ * then runs out of list_states; it counts as no_IR here.) */
+int nso_ir_states(const ns_ir_tables *t, uint32_t trx, const double *u, uint8_t *retained) {
+    int prev = 0, flag = 0;
+    uint32_t k = 0;
+    for (uint32_t i = t->item_off[trx]; i < t->item_off[trx + 1]; ++i) {
+        if (t->item_type[i] != NS_IR_INTRON) continue;
+        const double p = u[k];
+        if (0 <= p && p < t->p_no_ir[prev]) { retained[k] = 0; prev = 1; }
+        else if (t->p_no_ir[prev] <= p && p < t->p_no_ir[prev] + t->p_ir[prev]) { retained[k] = 1; prev = 2; flag = 1; }
+        else { retained[k] = 0; prev = 1; }
+        ++k;
+    }
+    return flag;
+}
+
+typedef struct nso_iv { uint32_t chrom, start, end; uint8_t retained, minus; } nso_iv;
+
+/* extract_read_pos (S:148-191) on the structure with the introns of `retained` switched to "retained_intron"; u_start is the
+ * uniform behind random.randint(0, min(ref_len - length, len_before)).  Returns the number of intervals (list_intervals). */
+int nso_extract_read_pos(const ns_ir_tables *t, uint32_t trx, const uint8_t *retained, int64_t length, int64_t ref_len, double u_start,
+                         int polya, nso_iv *iv, uint32_t cap, int *retain_polya) {
+    const uint32_t i0 = t->item_off[trx], i1 = t->item_off[trx + 1];
+    int64_t len_before = 0;
+    uint32_t k = 0;
+    for (uint32_t i = i0; i < i1; ++i) {                                   /* S:153-159 */
+        if (t->item_type[i] == NS_IR_EXON) len_before += t->item_len[i];
+        else if (retained[k++]) break;
+    }
+    int64_t hi = ref_len - length < len_before ? ref_len - length : len_before;
+    int64_t start_pos = (int64_t)(u_start * (double)(hi + 1));
+    if (start_pos > hi) start_pos = hi;
+    uint32_t n = 0;
+    int64_t end = 0;
+    k = 0;
+    for (uint32_t i = i0; i < i1; ++i) {                                   /* S:164-184 */
+        if (length == 0) break;
+        int is_ret = 0;
+        if (t->item_type[i] == NS_IR_INTRON) { is_ret = retained[k++]; if (!is_ret) continue; }
+        const int64_t ilen = t->item_len[i], istart = t->item_start[i], iend = istart + ilen;
+        if (start_pos < ilen) {
+            const int64_t start = start_pos + istart;
+            end = start + length <= iend ? start + length : iend;
+            length -= end - start;
+            start_pos = 0;
+            if (n >= cap) return -1;
+            iv[n].chrom = t->item_chrom[i]; iv[n].start = (uint32_t)start; iv[n].end = (uint32_t)end;
+            iv[n].retained = (uint8_t)is_ret; iv[n].minus = t->item_minus[i];
+            ++n;
+        } else start_pos -= ilen;
+    }
+    *retain_polya = polya && n && end + 10 >= (int64_t)t->item_start[i1 - 1] + (int64_t)t->item_len[i1 - 1];   /* S:186-189 */
+    return (int)n;
+}
 
 /* random.choices(population, weights): bisect_right(cum_weights, random() * total, 0, n - 1) */
 uint32_t nso_trx_pick(const nso_trx *tx, double u) {
@@ -1012,17 +1075,44 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
         /* ---- positions (S:1388-1389, 1510, 1557) ---- */
         int pos_ok = 1;
         int64_t seq_len = head + tail;
+        nso_iv *ir_iv = NULL; int ir_n = 0, ir_polya = 0;                  /* intron retention: the genomic intervals of the read */
         for (uint32_t pi = 0; pi < n_pieces; ++pi) {
             uint32_t sid = pc[pi].kind ? NSO_GAP_SEG + (pi >> 1) : (pi >> 1);
             uint32_t chrom = 0; uint64_t pos = 0;
             if (pc[pi].kind && kind == NS_KIND_ALIGNED && gap_len[pi >> 1] == 0) {   /* S:1553-1554 */
                 pc[pi].ref_len = 0; pc[pi].out_len = 0; pc[pi].n_ev = 0;
-            } else if (tx && kind != NS_KIND_UNALIGNED) {                 /* extract_read_trx, S:1683-1691 */
-                philox_at(&d, ST_POS, sid, a, 0, 0, w);
-                uint64_t span = (uint64_t)(trx_len - (int64_t)pc[pi].ref_len) + 1;
-                pos = (uint64_t)(u53_to_p(w[0], w[1]) * (double)span);
-                if (pos >= span) pos = span - 1;
+            } else if (tx && kind != NS_KIND_UNALIGNED) {
                 chrom = trx_chrom;
+                if (tx->ir && prm->model_ir && kind == NS_KIND_ALIGNED && pc[pi].ref_len) {      /* S:1156-1160 */
+                    const ns_ir_tables *ir = tx->ir;
+                    const uint32_t n_items = ir->item_off[trx_chrom + 1] - ir->item_off[trx_chrom];
+                    double *u = (double *)malloc(sizeof(double) * (n_items + 1));
+                    uint8_t *ret = (uint8_t *)calloc(n_items + 1, 1);
+                    for (uint32_t k2 = 0; k2 < n_items; ++k2) {                /* (at most one draw per item; only the introns use theirs) */
+                        philox_at(&d, ST_IR, 0, a, k2 >> 1, 0, w);
+                        u[k2] = (k2 & 1) ? u53_to_p(w[2], w[3]) : u53_to_p(w[0], w[1]);
+                    }
+                    if (n_items && nso_ir_states(ir, trx_chrom, u, ret)) {
+                        ir_iv = (nso_iv *)malloc(sizeof(nso_iv) * (n_items + 1));
+                        philox_at(&d, ST_POS, sid, a, 0, 0, w);
+                        ir_n = nso_extract_read_pos(ir, trx_chrom, ret, pc[pi].ref_len, trx_len, u53_to_p(w[0], w[1]),
+                                                    tx->polya && tx->polya[trx_chrom], ir_iv, n_items + 1, &ir_polya);
+                        if (ir_n <= 0) { free(ir_iv); ir_iv = NULL; ir_n = 0; }
+                    }
+                    free(u); free(ret);
+                    if (ir_iv) {
+                        int missing = 0;                                       /* S:1167-1169: chromosome not in the genome FASTA */
+                        for (int z = 0; z < ir_n; ++z) if (ir_iv[z].chrom == NS_IR_NO_CHROM) missing = 1;
+                        if (missing) { free(ir_iv); ir_iv = NULL; pos_ok = 0; break; }
+                        pos = ir_iv[0].start;                                  /* S:1175 */
+                    }
+                }
+                if (!ir_iv) {                                              /* extract_read_trx, S:1683-1691 */
+                    philox_at(&d, ST_POS, sid, a, 0, 0, w);
+                    uint64_t span = (uint64_t)(trx_len - (int64_t)pc[pi].ref_len) + 1;
+                    pos = (uint64_t)(u53_to_p(w[0], w[1]) * (double)span);
+                    if (pos >= span) pos = span - 1;
+                }
             } else if (tx) {                                              /* extract_read("transcriptome", len), S:1695-1703 */
                 if (extract_trx_unaligned(ref->chrom_off, ref->nchrom, pc[pi].ref_len, &d, sid, a, &chrom, &pos)) { pos_ok = 0; break; }
             } else if (mg) {                                              /* extract_read("metagenome", len, species), S:1704-1749 */
@@ -1033,12 +1123,38 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
             }
             pc[pi].chrom = chrom; pc[pi].pos = (uint32_t)pos;
             pc[pi].ref_gpos = ref->chrom_off[chrom] + pos;
+            if (ir_iv) pc[pi].ref_gpos = NS_SPLICED_BASE + o->spliced_bytes + 64;      /* slot: 64 bytes of padding, the bases, padding */
             seq_len += pc[pi].out_len;
         }
         if (!pos_ok) { ++epoch; fails = 0; continue; }
+        uint8_t *ir_seq = NULL;                                            /* S:1161-1178: the stretch as the genome has it */
+        if (ir_iv) {
+            const ns_ir_tables *ir = tx->ir;
+            const int64_t rl = pc[0].ref_len;
+            ir_seq = (uint8_t *)malloc((size_t)rl + 1);
+            int64_t got = 0;
+            for (int z = 0; z < ir_n; ++z)
+                for (uint32_t x = ir_iv[z].start; x < ir_iv[z].end; ++x) ir_seq[got++] = ir->genome[ir->genome_off[ir_iv[z].chrom] + x];
+            if (got != rl) { free(ir_seq); free(ir_iv); return -31; }
+            if (ir_iv[ir_n - 1].minus) {                                       /* reverse_complement, S:1675-1680: upper-case ACGT only */
+                for (int64_t i = 0, j = rl - 1; i <= j; ++i, --j) {
+                    uint8_t x = ir_seq[i], y = ir_seq[j];
+                    uint8_t cx = x == 'A' ? 'T' : x == 'T' ? 'A' : x == 'C' ? 'G' : x == 'G' ? 'C' : x;
+                    uint8_t cy = y == 'A' ? 'T' : y == 'T' ? 'A' : y == 'C' ? 'G' : y == 'G' ? 'C' : y;
+                    ir_seq[i] = cy; ir_seq[j] = cx;
+                }
+            }
+            for (int64_t i = 0; i < rl; ++i) ir_seq[i] = nso_normalise_base(ir_seq[i]);
+            const uint64_t slot = 64 + (((uint64_t)rl + 64 + 15) & ~15ull);
+            if (o->spliced) {
+                if (o->spliced_bytes + slot > o->cap_spliced) { free(ir_seq); free(ir_iv); return -32; }
+                memcpy(o->spliced + o->spliced_bytes + 64, ir_seq, (size_t)rl);
+            }
+            o->spliced_bytes += slot;
+        }
         int64_t polya_len = 0;                                             /* S:1046-1053, 1206-1209, 1683-1691 */
         if (tx && kind != NS_KIND_UNALIGNED && tx->polya && tx->polya[trx_chrom] &&
-            (int64_t)pc[0].pos + (int64_t)pc[0].ref_len + 10 >= trx_len) {
+            (ir_iv ? ir_polya : (int64_t)pc[0].pos + (int64_t)pc[0].ref_len + 10 >= trx_len)) {
             philox_at(&d, ST_TRX, 0, a, 1, 0, w);
             polya_len = (int64_t)fma(tx->polya_scale, -nso_log(u32_to_p(w[0])), 2.0);      /* int(expon.rvs(loc=2, scale)) */
             if (polya_len > 65535) polya_len = 65535;
@@ -1065,6 +1181,16 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
         memcpy(name + nl, tag, strlen(tag)); nl += (int)strlen(tag);
         nl += u64_digits(gidx, name + nl);
         if (kind == NS_KIND_ALIGNED && nseg > 1) { memcpy(name + nl, "_chimeric", 9); nl += 9; }
+        if (ir_iv) {                                                       /* S:1189-1192 */
+            int any = 0;
+            for (int z = 0; z < ir_n; ++z) {
+                if (!ir_iv[z].retained) continue;
+                if (nl > 3900) { free(ir_seq); free(ir_iv); return -33; }
+                if (!any) { memcpy(name + nl, "_RetainedIntron_", 16); nl += 16; any = 1; }
+                nl += u64_digits(ir_iv[z].start, name + nl); name[nl++] = '-';
+                nl += u64_digits(ir_iv[z].end, name + nl); name[nl++] = ';';
+            }
+        }
         name[nl++] = '_'; name[nl++] = reversed ? 'R' : 'F';
         name[nl++] = '_'; nl += u64_digits((uint64_t)head, name + nl);
         name[nl++] = '_';
@@ -1088,7 +1214,7 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
                 int64_t rl = pc[pi].ref_len;
                 uint32_t sid = pi >> 1;
                 uint8_t *segbuf = (uint8_t *)malloc((size_t)rl + 1);
-                fetch_segment(ref, pc[pi].chrom, pc[pi].pos, rl, segbuf);
+                if (ir_seq) memcpy(segbuf, ir_seq, (size_t)rl); else fetch_segment(ref, pc[pi].chrom, pc[pi].pos, rl, segbuf);
                 for (int64_t x = 0; x < rl; ++x) segbuf[x] = resolve_base(segbuf[x], &d, sid, a, (uint64_t)x);
                 int64_t sh = 0;
                 ns_event *pev = o->events + pc[pi].ev_off;
@@ -1132,7 +1258,7 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
         }
 #define NSO_HP_FREE() do { for (uint32_t z_ = 0; z_ < n_pieces; ++z_) { free(hp_seq[z_]); free(hp_q[z_]); } free(hp_log); } while (0)
         if (!(tx && kind != NS_KIND_UNALIGNED) &&                                        /* (no length limits on aligned transcriptome reads) */
-            (seq_len < prm->min_len || seq_len > prm->max_len)) { NSO_HP_FREE(); ++epoch; fails = 0; continue; }   /* S:1429-1430, S:1518-1519 */
+            (seq_len < prm->min_len || seq_len > prm->max_len)) { NSO_HP_FREE(); free(ir_seq); free(ir_iv); ++epoch; fails = 0; continue; }   /* S:1429-1430, S:1518-1519 */
 
         /* ---- accepted: materialise ---- */
         ns_read *rd = &o->reads[index];
@@ -1172,7 +1298,7 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
             nso_logrow *rows = want_log ? (nso_logrow *)malloc(sizeof(nso_logrow) * (pc[pi].n_ev + 1)) : NULL;
             uint8_t *txt = want_log ? (uint8_t *)malloc(txt_cap + 1) : NULL;
             uint64_t txt_len = 0;
-            fetch_segment(ref, pc[pi].chrom, pc[pi].pos, rl, segbuf);
+            if (ir_seq) memcpy(segbuf, ir_seq, (size_t)rl); else fetch_segment(ref, pc[pi].chrom, pc[pi].pos, rl, segbuf);
             for (int64_t x = 0; x < rl; ++x) segbuf[x] = resolve_base(segbuf[x], &d, sid, a, (uint64_t)x);   /* S:1406 */
             int64_t ol = nso_mutate_read(segbuf, rl, o->events + pc[pi].ev_off, pc[pi].n_ev, &d, sid, a, seq + wq,
                                          cls, seq_len - wq - tail, rows, txt, &txt_len);
@@ -1234,6 +1360,7 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
         o->n_pieces += n_pieces;
         o->n_events = evn;
         o->total_bases += (uint64_t)seq_len;
+        free(ir_seq); free(ir_iv);
         return 0;
     }
     return -16;
@@ -1261,6 +1388,7 @@ int nso_generate_trx(const ns_model_tables *t, const uint8_t *bases, const uint6
     for (uint32_t c = 0; c < nchrom; ++c) { names[c] = p; p += strlen(p) + 1; }
     nso_ref ref = {bases, chrom_off, nchrom, circular, names};
     o->n_pieces = o->n_events = o->record_bytes = o->errlog_bytes = o->total_bases = o->total_ref_bases = 0;
+    o->spliced_bytes = 0;
     int rc = 0;
     for (uint64_t i = 0; i < prm->n_reads && rc == 0; ++i) rc = gen_read(t, &ref, prm, i, o, NULL, NULL, tx);
     free((void *)names);

@@ -33,12 +33,12 @@ class NsoOut(C.Structure):
                 ("errlog", C.c_void_p), ("cap_errlog", C.c_uint64),
                 ("n_pieces", C.c_uint64), ("n_events", C.c_uint64), ("record_bytes", C.c_uint64),
                 ("errlog_bytes", C.c_uint64), ("total_bases", C.c_uint64), ("total_ref_bases", C.c_uint64),
-                ("polya", C.c_void_p)]
+                ("polya", C.c_void_p), ("spliced", C.c_void_p), ("cap_spliced", C.c_uint64), ("spliced_bytes", C.c_uint64)]
 
 
 class NsoTrx(C.Structure):
     _fields_ = [("n_expr", C.c_uint32), ("expr_chrom", C.POINTER(C.c_uint32)), ("expr_cum", C.POINTER(C.c_double)),
-                ("polya", C.POINTER(C.c_uint8)), ("polya_scale", C.c_double)]
+                ("polya", C.POINTER(C.c_uint8)), ("polya_scale", C.c_double), ("ir", C.c_void_p)]
 
 
 class NsoMeta(C.Structure):
@@ -85,6 +85,7 @@ def lib():
         L.nso_table_value.restype = C.c_int64
         L.nso_table_value.argtypes = [C.POINTER(C.c_double), C.c_uint32, C.c_double]
         L.nso_trans_pick.restype = C.c_int; L.nso_trans_pick.argtypes = [C.POINTER(C.c_double), C.c_double]
+        L.nso_ir_states.restype = C.c_int; L.nso_ir_states.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.nso_run_length.restype = C.c_int64
         L.nso_run_length.argtypes = [C.POINTER(NsModelTables), C.c_int, C.c_double, C.c_double]
         L.nso_kde_sample.restype = C.c_double
@@ -218,8 +219,9 @@ def generate_meta(model, meta_ref, abun: dict, abun_inflated, params: NsParams, 
                 species_bases=sp_bases)
 
 
-def make_trx(tr):
-    """tr: nanosim_amd.transcriptome.TranscriptomeReference -> (NsoTrx, keep-alive list)"""
+def make_trx(tr, ir=None):
+    """tr: nanosim_amd.transcriptome.TranscriptomeReference, ir: nanosim_amd.intron_retention.IntronRetention or None
+    -> (NsoTrx, keep-alive list)"""
     ec = np.ascontiguousarray(tr.expr_chrom, dtype=np.uint32)
     cum = np.ascontiguousarray(tr.expr_cum, dtype=np.float64)
     pa = np.ascontiguousarray(tr.polya, dtype=np.uint8)
@@ -228,10 +230,15 @@ def make_trx(tr):
     x.expr_chrom = ec.ctypes.data_as(C.POINTER(C.c_uint32)); x.expr_cum = cum.ctypes.data_as(C.POINTER(C.c_double))
     x.polya = pa.ctypes.data_as(C.POINTER(C.c_uint8)) if pa.any() else None
     x.polya_scale = float(tr.polya_scale)
-    return x, [ec, cum, pa]
+    keep = [ec, cum, pa]
+    if ir is not None:
+        t = ir.to_c()
+        keep += [t, ir]
+        x.ir = C.addressof(t)
+    return x, keep
 
 
-def generate_trx(model, tr, params: NsParams, *, bytes_per_read=40000, events_per_read=4000):
+def generate_trx(model, tr, params: NsParams, *, ir=None, bytes_per_read=40000, events_per_read=4000):
     """Transcriptome batch through the CPU restatement (aligned / perfect / unaligned by params.kind)."""
     L = lib()
     t = model.to_c()
@@ -249,11 +256,14 @@ def generate_trx(model, tr, params: NsParams, *, bytes_per_read=40000, events_pe
     o.records = records.ctypes.data; o.cap_records = len(records)
     o.errlog = errlog.ctypes.data; o.cap_errlog = len(errlog)
     o.polya = polya.ctypes.data
+    spliced = np.zeros(n * 4096 + 4096 if ir is not None else 16, dtype=np.uint8)
+    o.spliced = spliced.ctypes.data; o.cap_spliced = len(spliced)
     bases = normalise_bases(ref.bases)
-    x, keep = make_trx(tr)
+    x, keep = make_trx(tr, ir)
     rc = L.nso_generate_trx(C.byref(t), bases.ctypes.data, ref.chrom_off.ctypes.data, len(ref.names), ref.circular.ctypes.data,
                             ref.names_blob(), C.byref(x), C.byref(params), C.byref(o))
     if rc != 0:
         raise RuntimeError("nso_generate_trx failed: %d" % rc)
     return dict(reads=reads, pieces=pieces[:o.n_pieces], events=events[:o.n_events], records=records[:o.record_bytes],
-                errlog=errlog[:o.errlog_bytes], total_bases=int(o.total_bases), total_ref_bases=int(o.total_ref_bases), polya=polya[:n])
+                errlog=errlog[:o.errlog_bytes], total_bases=int(o.total_bases), total_ref_bases=int(o.total_ref_bases), polya=polya[:n],
+                spliced=spliced[:o.spliced_bytes])

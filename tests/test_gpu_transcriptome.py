@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from nanosim_amd import engine as E
+from nanosim_amd import intron_retention as IR
 from nanosim_amd import model as M
 from nanosim_amd import transcriptome as T
 from tests import oracle_lib as O
@@ -54,6 +55,73 @@ def test_gpu_transcriptome_equals_oracle(trx_ref, case):
         assert np.array_equal(b.polya(), exp["polya"])
         if p.kind != E.NS_KIND_UNALIGNED:
             assert int(b.polya().max()) >= 2 or p.n_reads < 10
+    finally:
+        e.close()
+
+
+IR_CASES = [
+    dict(n_reads=600, emit_errlog=True),
+    dict(n_reads=500, fastq=True, uracil=True, emit_errlog=True),
+    dict(n_reads=400, kmer_bias=5, fastq=True, emit_errlog=True),                       # -hp -k 5 on spliced stretches
+    dict(n_reads=300, kmer_bias=4),
+    dict(n_reads=300, kind=E.NS_KIND_PERFECT),                                           # S:1117: --perfect never retains introns
+    dict(n_reads=300, kind=E.NS_KIND_UNALIGNED, min_len=50, max_len=5000),
+    dict(n_reads=3000, emit_records=False),
+]
+
+
+@pytest.mark.parametrize("case", IR_CASES)
+def test_gpu_intron_retention_equals_oracle(trx_ref, case):
+    """S:114-191, 1156-1192: structure chain, genomic intervals, splice from the genome (both strands, soft-masked introns),
+    read names with the retained stretches, polyA rule of extract_read_pos"""
+    ir = IR.load(PREFIX, os.path.join(TRX, "genome.fa"), trx_ref.ref)
+    tr = T.restrict_expression(trx_ref, ir.eligible)
+    kw = dict(seed=0x77AB12, first_read=0, max_len=10 ** 9, trx=True, model_ir=True)
+    kw.update(case)
+    p = E.make_params(**kw)
+    mdl = M.load_model(PREFIX, transcriptome=True, perfect=p.kind == E.NS_KIND_PERFECT, fastq=True, homopolymer=p.kind != E.NS_KIND_PERFECT)
+    e = E.Engine(0)
+    try:
+        e.set_transcriptome(tr)
+        e.set_intron_retention(ir)
+        e.load_model(mdl)
+        b = e.generate(p)
+        exp = O.generate_trx(mdl, tr, p, ir=ir)
+        compare(b, exp, p)
+        assert np.array_equal(b.polya(), exp["polya"])
+        n_spliced = int((b.pieces()["ref_gpos"] >= E.NS_SPLICED_BASE).sum())
+        if p.kind == E.NS_KIND_ALIGNED:
+            assert n_spliced > p.n_reads // 10
+            got = b.spliced()
+            assert len(got) == len(exp["spliced"])
+            pcs = b.pieces()
+            for pc in pcs[pcs["ref_gpos"] >= E.NS_SPLICED_BASE]:                          # (the padding between the stretches is not defined)
+                o = int(pc["ref_gpos"] - E.NS_SPLICED_BASE)
+                assert np.array_equal(got[o:o + int(pc["ref_len"])] & 0x7F, exp["spliced"][o:o + int(pc["ref_len"])])   # (bit 7: the engine's IUPAC mark)
+        else:
+            assert n_spliced == 0
+        # the engine keeps working without intron retention afterwards
+        p.model_ir = 0
+        compare(e.generate(p), O.generate_trx(mdl, tr, p), p)
+    finally:
+        e.close()
+
+
+def test_intron_retention_error_paths(trx_ref):
+    e = E.Engine(0)
+    try:
+        e.set_transcriptome(trx_ref)
+        e.load_model(M.load_model(PREFIX, transcriptome=True))
+        with pytest.raises(E.EngineError):                       # no structure tables
+            e.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=10 ** 9, trx=True, model_ir=True))
+        ir = IR.load(PREFIX, os.path.join(TRX, "genome.fa"), trx_ref.ref)
+        e.set_intron_retention(ir)
+        e.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=10 ** 9, trx=True, model_ir=True))
+        e.set_transcriptome(trx_ref)                             # a new reference drops the tables
+        with pytest.raises(E.EngineError):
+            e.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=10 ** 9, trx=True, model_ir=True))
+        with pytest.raises(E.EngineError):                       # not a transcriptome batch
+            e.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=9000, model_ir=True))
     finally:
         e.close()
 

@@ -1,0 +1,201 @@
+"""Intron retention of the transcriptome mode (src/simulator.py:114-191, 403-452, 1156-1192).
+
+Pinned against the reference: update_structure / ref_len_from_structure (tests/golden/reference_ir.json, produced by the
+reference's own functions).  NOT pinned: extract_read_pos and the splice — the reference runs them through HTSeq and pysam,
+which this image lacks; they are checked here against the GFF3 structure and the genome directly (an independent walk in Python
+driven by the read names the oracle prints)."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from nanosim_amd import engine as E
+from nanosim_amd import intron_retention as IR
+from nanosim_amd import model as M
+from nanosim_amd import transcriptome as T
+from tests import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TRX = os.path.join(ROOT, "tests", "golden", "trx")
+PREFIX = os.path.join(ROOT, "tests", "golden", "model_small", "training")
+
+
+@pytest.fixture(scope="module")
+def trx_ref():
+    return T.read_transcriptome(os.path.join(TRX, "transcripts.fa"), os.path.join(TRX, "expression.tsv"), os.path.join(TRX, "polya.txt"), "guppy")
+
+
+@pytest.fixture(scope="module")
+def ir(trx_ref):
+    return IR.load(PREFIX, os.path.join(TRX, "genome.fa"), trx_ref.ref)
+
+
+@pytest.fixture(scope="module")
+def fx():
+    with open(os.path.join(ROOT, "tests", "golden", "reference_ir.json")) as f:
+        return json.load(f)
+
+
+def test_gff_attribute_parsing():
+    d, first = IR.parse_gff_attributes('ID="exon:E1;2";transcript_id=ENST1.2\n')
+    assert d == {"ID": "exon:E1;2", "transcript_id": "ENST1.2"} and first == "exon:E1;2"
+    d, first = IR.parse_gff_attributes("Parent=transcript:ENST7.1;rank=3")
+    assert first == "transcript:ENST7.1" and d["rank"] == "3"
+    d, first = IR.parse_gff_attributes('gene_id "G1"; transcript_id "T1";')                 # GTF style goes through the same expression
+    assert d == {"gene_id": "G1", "transcript_id": "T1"} and first == "G1"
+
+
+def test_structure_reader(tmp_path):
+    gff = tmp_path / "a.gff3"
+    gff.write_text("##gff-version 3\n"
+                   "chr1\tx\tgene\t1\t900\t.\t+\t.\tID=gene:G\n"
+                   "chr1\tx\texon\t101\t200\t.\t+\t.\ttranscript_id=T1.4\n"
+                   "chr1\tx\tintron\t201\t300\t.\t+\t.\tParent=transcript:T1.4\n"
+                   "chr1\tx\texon\t301\t350\t.\t+\t.\tParent=T1\n"
+                   "chr1\tx\texon\t1\t10\t.\t+\t.\tID=exon:E9;Parent=gene:G\n"          # first attribute names no transcript: skipped
+                   "chr1\tx\tCDS\t101\t200\t.\t+\t.\ttranscript_id=T1\n"
+                   "rchr\tx\texon\t5\t9\t.\t-\t.\ttranscript_id=T2\n"                       # str.strip('chr') eats the leading r as well
+                   "\n")
+    s = IR.read_structure(str(gff))
+    assert s["T1"] == [("exon", "1", 100, 200, 100, "+"), ("intron", "1", 200, 300, 100, "+"), ("exon", "1", 300, 350, 50, "+")]
+    assert s["T2"] == [("exon", "", 4, 9, 5, "-")]
+    assert set(s) == {"T1", "T2"}
+
+
+def test_tables_and_eligibility(trx_ref, ir):
+    n = len(trx_ref.ref.names)
+    lens = np.diff(trx_ref.ref.chrom_off.astype(np.int64))
+    assert ir.item_off[0] == 0 and ir.item_off[-1] == len(ir.item_type) and len(ir.item_off) == n + 1
+    assert ir.genome.names == ["chr1", "chr2", "chr3"]                                    # pysam: header up to the first white space
+    n_el = int(ir.eligible.sum())
+    assert 0 < n_el < n
+    for i in range(n):
+        a, b = int(ir.item_off[i]), int(ir.item_off[i + 1])
+        exon = int(ir.item_len[a:b][ir.item_type[a:b] == IR.NS_IR_EXON].sum())
+        assert bool(ir.eligible[i]) == (b > a and exon == lens[i])
+    assert (ir.item_chrom == IR.NS_IR_NO_CHROM).any()                                     # a transcript on a chromosome the FASTA lacks
+    # exons of an eligible '+' transcript spell the transcript
+    g = ir.genome
+    done = 0
+    for i in np.nonzero(ir.eligible)[0]:
+        a, b = int(ir.item_off[i]), int(ir.item_off[i + 1])
+        if ir.item_minus[a] or (ir.item_chrom[a:b] == IR.NS_IR_NO_CHROM).any():
+            continue
+        seq = b"".join(g.chrom(int(ir.item_chrom[k]))[int(ir.item_start[k]):int(ir.item_start[k]) + int(ir.item_len[k])].tobytes()
+                       for k in range(a, b) if ir.item_type[k] == IR.NS_IR_EXON)
+        assert seq == trx_ref.ref.chrom(int(i)).tobytes()
+        done += 1
+    assert done > 20
+    r = T.restrict_expression(trx_ref, ir.eligible)
+    assert ir.eligible[r.expr_chrom].all() and 0 < len(r.expr_chrom) < len(trx_ref.expr_chrom)
+    assert np.isclose(r.expr_cum[-1], trx_ref.expr_weight[ir.eligible[trx_ref.expr_chrom]].sum())
+
+
+def test_ir_states_match_update_structure(fx, trx_ref, ir):
+    """nso_ir_states == update_structure of the reference on the same uniforms (S:114-145)"""
+    L = O.lib()
+    t = ir.to_c()
+    import ctypes as C
+    n_flag = 0
+    for c in fx["cases"]:
+        trx = trx_ref.ref.names.index(c["tid"].split(".")[0]) if c["tid"] in trx_ref.ref.names else None
+        if trx is None:
+            continue
+        a, b = int(ir.item_off[trx]), int(ir.item_off[trx + 1])
+        assert int(ir.item_len[a:b][ir.item_type[a:b] == IR.NS_IR_EXON].sum()) == c["exon_len"]       # ref_len_from_structure
+        u = np.array(c["u"] + [0.0], dtype=np.float64)
+        ret = np.zeros(len(u) + 1, dtype=np.uint8)
+        flag = L.nso_ir_states(C.addressof(t), trx, u.ctypes.data, ret.ctypes.data)
+        assert bool(flag) == c["flag"], c
+        assert [int(x) for x in ret[:len(c["retained"])]] == c["retained"], c
+        n_flag += c["flag"]
+    assert n_flag > 50
+
+
+NAME = re.compile(r"^[>@](?P<trx>[^_]+)_(?P<pos>\d+)_aligned_(?P<idx>\d+)(?:_RetainedIntron_(?P<ir>[0-9;-]+))?_(?P<strand>[RF])_(?P<head>\d+)_(?P<mid>\d+)_(?P<tail>\d+)$")
+
+
+def manual_splice(ir, trx, pos, ref_len, retained_tuples):
+    """the stretch of pre-mRNA a read name describes: exons, plus the introns named in the read, from genome coordinate `pos` on"""
+    a, b = int(ir.item_off[trx]), int(ir.item_off[trx + 1])
+    g = ir.genome
+    out, started, left = [], False, ref_len
+    ret_starts = {s for s, _ in retained_tuples}
+    for k in range(a, b):
+        s0, ln = int(ir.item_start[k]), int(ir.item_len[k])
+        is_intron = ir.item_type[k] == IR.NS_IR_INTRON
+        if not started:
+            if not (s0 <= pos < s0 + ln) or is_intron and pos not in ret_starts and s0 not in ret_starts:
+                continue
+            started = True
+            lo = pos
+        else:
+            if is_intron and s0 not in ret_starts:
+                continue
+            lo = s0
+        hi = min(lo + left, s0 + ln)
+        out.append(g.chrom(int(ir.item_chrom[k]))[lo:hi])
+        left -= hi - lo
+        if left == 0:
+            break
+    assert left == 0
+    seq = np.concatenate(out)
+    if ir.item_minus[b - 1]:
+        lut = np.arange(256, dtype=np.uint8)
+        for x, y in (b"AT", b"TA", b"CG", b"GC"):
+            lut[x] = y
+        seq = lut[seq[::-1]]
+    return O.normalise_bases(seq)
+
+
+@pytest.mark.parametrize("fastq,kmer", [(False, 0), (True, 0), (False, 5)])
+def test_oracle_ir_batch(trx_ref, ir, fastq, kmer):
+    mdl = M.load_model(PREFIX, transcriptome=True, fastq=fastq, homopolymer=bool(kmer))
+    tr = T.restrict_expression(trx_ref, ir.eligible)
+    p = E.make_params(seed=0x1234ABCD, first_read=0, n_reads=600, fastq=fastq, kmer_bias=kmer, max_len=10**9, min_len=1, trx=True, model_ir=True,
+                      emit_errlog=True)
+    out = O.generate_trx(mdl, tr, p, ir=ir)
+    base = O.generate_trx(mdl, tr, E.make_params(seed=0x1234ABCD, first_read=0, n_reads=600, fastq=fastq, kmer_bias=kmer, max_len=10**9, min_len=1,
+                                                 trx=True, emit_errlog=True))
+    pieces, reads = out["pieces"], out["reads"]
+    spliced = pieces["ref_gpos"] >= E.NS_SPLICED_BASE
+    assert 60 < int(spliced.sum()) < 560                      # (P(start -> IR) = 0.2 per intron in the synthetic model)
+    assert ir.eligible[pieces["chrom"]].all()
+    lines = out["records"].tobytes().split(b"\n")
+    names = [ln.decode() for ln in lines if ln[:1] in (b">", b"@") and b"_aligned_" in ln]
+    assert len(names) == 600
+    n_named = 0
+    off = 0
+    for i, nm in enumerate(names):
+        m = NAME.match(nm)
+        assert m, nm
+        pc = pieces[reads["piece_off"][i]]
+        assert int(m.group("pos")) == pc["pos"] and int(m.group("mid")) == pc["ref_len"]
+        if not spliced[reads["piece_off"][i]]:
+            assert m.group("ir") is None
+            assert pc["ref_gpos"] == trx_ref.ref.chrom_off[pc["chrom"]] + pc["pos"]
+            continue
+        tuples = [tuple(int(x) for x in t.split("-")) for t in (m.group("ir") or "").split(";") if t]
+        n_named += bool(tuples)
+        slot = 64 + ((int(pc["ref_len"]) + 64 + 15) & ~15)
+        assert pc["ref_gpos"] == E.NS_SPLICED_BASE + off + 64
+        got = out["spliced"][off + 64: off + 64 + int(pc["ref_len"])]
+        off += slot
+        exp = manual_splice(ir, int(pc["chrom"]), int(pc["pos"]), int(pc["ref_len"]), tuples)
+        assert np.array_equal(got, exp), nm
+        a, b = int(ir.item_off[pc["chrom"]]), int(ir.item_off[pc["chrom"] + 1])
+        for s, e in tuples:                                   # every named stretch lies inside an intron of the transcript
+            assert any(ir.item_type[k] == IR.NS_IR_INTRON and ir.item_start[k] <= s < e <= ir.item_start[k] + ir.item_len[k] for k in range(a, b)), nm
+    assert off == len(out["spliced"]) and n_named > 30
+    # reads whose structure came out without a retained intron are the reads of the run without intron retention
+    same = 0
+    for i in range(600):
+        if not spliced[reads["piece_off"][i]] and reads["attempts"][i] == base["reads"]["attempts"][i]:
+            a0, a1 = int(reads["rec_off"][i]), int(base["reads"]["rec_off"][i])
+            ln = int(reads["seq_len"][i])
+            r0 = out["records"][a0:a0 + ln + 200].tobytes().split(b"\n")[1]
+            r1 = base["records"][a1:a1 + ln + 200].tobytes().split(b"\n")[1]
+            same += r0 == r1
+    assert same > 30
