@@ -209,7 +209,7 @@ class StreamWriter:
 
 
 def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, chimeric, min_len, max_len, median_len,
-                   sd_len, want_errlog, kmer_bias=0, meta=False, err_header=b"", trx=False, uracil=False):
+                   sd_len, want_errlog, kmer_bias=0, meta=False, err_header=b"", trx=False, uracil=False, model_ir=False):
     done = 0
     w = getattr(eng, "_stream_writer", None)           # one writer (staging buffers + threads) per engine
     if w is None:
@@ -226,7 +226,7 @@ def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, 
             n = min(batch, count - done)
             p = E.make_params(seed=seed, first_read=first + done, n_reads=n, kind=kind, fastq=fastq, chimeric=chimeric, kmer_bias=kmer_bias,
                               min_len=min_len, max_len=max_len, median_len=median_len, sd_len=sd_len,
-                              emit_records=True, emit_errlog=fe is not None, meta=meta, trx=trx, uracil=uracil)
+                              emit_records=True, emit_errlog=fe is not None, meta=meta, trx=trx, uracil=uracil, model_ir=model_ir)
             try:
                 b = eng.generate(p)
             except E.EngineError as ex:              # not enough free HBM for this batch size (shared GPU): halve it and go on
@@ -439,7 +439,8 @@ def run_metagenome(a, parser_mg):
 
 
 def run_transcriptome(a, parser_t):
-    """The transcriptome branch of main() (S:2322-2414) + simulation("transcriptome") (S:1568-1672), without intron retention."""
+    """The transcriptome branch of main() (S:2322-2414) + simulation("transcriptome") (S:1568-1672)."""
+    from . import intron_retention as IR
     from . import transcriptome as TR
 
     def die(msg, to_err=True):
@@ -457,9 +458,6 @@ def run_transcriptome(a, parser_t):
         die("Please provide a reference genome to simulate intron retention events!")
     if a.polya and a.basecaller is None:
         die("Please input basecaller to simulate polyA tails from.", False)
-    if model_ir:
-        sys.stderr.write("\ntranscriptome mode of this build has no intron-retention model (DESIGN.md section 5.8): pass --no_model_ir\n")
-        sys.exit(2)
     if a.KmerBias and not a.homopolymer:
         sys.stderr.write("\n-k/--KmerBias needs -hp (the reference crashes on the missing homopolymer parameters, S:504,639)\n")
         sys.exit(1)
@@ -495,9 +493,15 @@ def run_transcriptome(a, parser_t):
         dist.broadcast_object_list(info, src=0)
         ref, keep = shard.broadcast_reference(tr.ref if rank == 0 else None, dist, device=torch.device("cuda", local_rank))
         tr = TR.TranscriptomeReference(ref, info[0]["ec"], info[0]["cum"], info[0]["w"], info[0]["pa"], info[0]["sc"])
-        eng.set_transcriptome(tr, dev_ptr=keep.data_ptr())
-    else:
-        eng.set_transcriptome(tr)
+    ir = None
+    if model_ir:                                                                              # S:403-452
+        if rank == 0:
+            log("Read in reference genome, IR markov model and GFF3 annotation file")
+        ir = IR.load(a.model_prefix, a.ref_g, tr.ref)
+        tr = TR.restrict_expression(tr, ir.eligible)                                          # S:1093-1099
+    eng.set_transcriptome(tr, dev_ptr=keep.data_ptr() if keep is not None else None)
+    if ir is not None:
+        eng.set_intron_retention(ir)
     if rank == 0:
         log("Read error profile" if not a.perfect else "Read KDF of aligned reads")
     mdl = M.load_model(a.model_prefix, perfect=a.perfect, strandness=a.strandness, fastq=a.fastq, transcriptome=True,
@@ -522,7 +526,7 @@ def run_transcriptome(a, parser_t):
     _write_batches(eng, out + "_aligned_reads%d%s" % (rank, ext), out + "_error_profile%d" % rank, seed=seed, first=lo, count=hi - lo,
                    kind=E.NS_KIND_PERFECT if a.perfect else E.NS_KIND_ALIGNED, fastq=a.fastq, chimeric=False, min_len=a.min_len,
                    max_len=max_len, median_len=None, sd_len=None, want_errlog=True, trx=True, uracil=a.uracil, kmer_bias=a.KmerBias or 0,
-                   err_header=ERR_HEADER if rank == 0 else b"")
+                   err_header=ERR_HEADER if rank == 0 else b"", model_ir=model_ir)
     if dist is not None:
         dist.barrier()
     if rank == 0:

@@ -114,8 +114,34 @@ def test_transcriptome_mode_end_to_end(tmp_path):
     assert open(out + "_unaligned_reads.fastq", "rb").read() == O.generate_trx(mdl, tr, p)["records"].tobytes()
     seqs = open(out + "_aligned_reads.fastq").read().split("\n")[1::4]
     assert not any("T" in x for x in seqs) and any("U" in x for x in seqs)
-    # intron retention is not part of this build: asked for (the default), the CLI says so
+    # intron retention (the default): needs the genome
     with pytest.raises(SystemExit) as e:
-        simulator.main(["transcriptome", "-rt", os.path.join(trx, "transcripts.fa"), "-rg", os.path.join(GOLDEN, "genome_small.fa"), "-e",
-                        os.path.join(trx, "expression.tsv"), "-c", os.path.join(GOLDEN, "model_small", "training"), "-o", out])
-    assert e.value.code == 2
+        simulator.main(["transcriptome", "-rt", os.path.join(trx, "transcripts.fa"), "-e", os.path.join(trx, "expression.tsv"), "-c",
+                        os.path.join(GOLDEN, "model_small", "training"), "-o", out])
+    assert e.value.code == 1
+
+
+def test_transcriptome_mode_with_intron_retention(tmp_path):
+    """transcriptome -rg genome.fa (model_ir on): <prefix>_IR_markov_model + <prefix>_added_intron_final.gff3 are read, reads with a
+    retained intron carry it in their name; bytes equal the oracle's"""
+    from nanosim_amd import intron_retention as IR
+    from nanosim_amd import transcriptome as TR
+    trx = os.path.join(GOLDEN, "trx")
+    out = str(tmp_path / "ir" / "sim")
+    prefix = os.path.join(GOLDEN, "model_small", "training")
+    simulator.main(["transcriptome", "-rt", os.path.join(trx, "transcripts.fa"), "-rg", os.path.join(trx, "genome.fa"), "-e",
+                    os.path.join(trx, "expression.tsv"), "--polya", os.path.join(trx, "polya.txt"), "-b", "guppy", "-c", prefix, "-o", out,
+                    "-n", "1200", "--seed", "99"])
+    tr = TR.read_transcriptome(os.path.join(trx, "transcripts.fa"), os.path.join(trx, "expression.tsv"), os.path.join(trx, "polya.txt"), "guppy")
+    ir = IR.load(prefix, os.path.join(trx, "genome.fa"), tr.ref)
+    tr = TR.restrict_expression(tr, ir.eligible)
+    mdl = M.load_model(prefix, transcriptome=True)
+    n_al, n_un = mdl.split_counts(1200)
+    p = E.make_params(seed=99, first_read=0, n_reads=n_al, max_len=tr.ref.max_chrom, emit_errlog=True, trx=True, model_ir=True)
+    exp = O.generate_trx(mdl, tr, p, ir=ir)
+    got = open(out + "_aligned_reads.fasta", "rb").read()
+    assert got == exp["records"].tobytes()
+    assert got.count(b"_RetainedIntron_") > 20
+    assert open(out + "_aligned_error_profile", "rb").read() == simulator.ERR_HEADER + exp["errlog"].tobytes()
+    p = E.make_params(seed=99, first_read=n_al, n_reads=n_un, kind=E.NS_KIND_UNALIGNED, max_len=tr.ref.max_chrom, trx=True)
+    assert open(out + "_unaligned_reads.fasta", "rb").read() == O.generate_trx(mdl, tr, p)["records"].tobytes()
