@@ -795,7 +795,7 @@ __device__ inline void hp_final_length(const GenArgs &A, uint64_t r, ns_read &rd
 
 // k_hp_count, one read per wavefront (k <= 16): runs are found 1024 bases at a time (ns_hp.h: hp_tile), a run belongs to the lane
 // that holds its first base, that lane draws the new length
-__global__ void __launch_bounds__(256) k_hp_count_w(GenArgs A) {
+__global__ void __launch_bounds__(256, 4) k_hp_count_w(GenArgs A) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     unsigned long long st_bases = 0, st_fail = 0;
@@ -956,10 +956,11 @@ __global__ void __launch_bounds__(256) k_hp_write(GenArgs A) {
     for (uint32_t i = 0; i < rd.tail; ++i, ++q) put(scr[q], fq ? scq[q] : 0);
 }
 
-// k_hp_write, one read per wavefront (k <= 16): head / gaps / polyA / tail are plain 16-byte copies; inside an aligned segment a lane
+// k_hp_write, one read per wavefront, first version (still used for k < 4, where a tile can hold more long runs than the run table
+// of k_hp_write_w): head / gaps / polyA / tail are plain 16-byte copies; inside an aligned segment a lane
 // copies its 16 bases with one store when no long run touches them, otherwise base by base, re-sampling the runs it owns (mutate_homo,
 // S:657-700).  Output offsets: wavefront prefix sum of the length changes of the runs that start before the lane's chunk.
-__global__ void __launch_bounds__(256) k_hp_write_w(GenArgs A) {
+__global__ void __launch_bounds__(256, 3) k_hp_write_w_seq(GenArgs A) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= A.prm.n_reads) return;
@@ -1082,6 +1083,171 @@ __global__ void __launch_bounds__(256) k_hp_write_w(GenArgs A) {
                 Dcur += (long long)size - (long long)len;
                 i = min(e, c + 16) - c;
             }
+        }
+        q_in += n; q_out += flen;
+        if (lane == 0) { ns_piece pw = p; pw.out_len = flen; A.pieces[rd.piece_off + pi] = pw; }      // report the emitted length, like the non -k path
+    }
+    if (A.polya) { const uint32_t pl = A.polya[r]; copy_plain(q_in, q_out, pl); q_in += pl; q_out += pl; }     // polyA tail (S:1224-1225)
+    copy_plain(q_in, q_out, rd.tail);
+}
+
+// k_hp_write, one read per wavefront (4 <= k <= 16).  Per tile of 1024 scratch bases:
+//   A  the lane that holds the first base of a long run draws its new length and files the run in an LDS table; wavefront prefix
+//      sums of the length changes / new lengths give every chunk its output offset and every run its slice of the work list;
+//   B  plain stretches (bases outside long runs) leave as (partial) 16-byte stores;
+//   C  the re-sampled runs (mutate_homo, S:657-700) are expanded ONE LANE PER NEW BASE — a run of 9 bases is nine lanes, not nine
+//      iterations of one lane while 63 wait (the first version, k_hp_write_w_seq, spent most of its time there);
+//   the first mismatch of a run gets its 'mis' quality afterwards (S:697-700), found with an LDS atomic min.
+#define NS_HP_MAXRUN 256u        // long runs starting in one tile: <= 1024 / k
+struct HpRunLds {
+    uint32_t s0[NS_HP_MAXRUN], len[NS_HP_MAXRUN], size[NS_HP_MAXRUN], o_run[NS_HP_MAXRUN], fm[NS_HP_MAXRUN], w_off[NS_HP_MAXRUN + 1];
+    uint8_t base[NS_HP_MAXRUN];
+};
+#ifndef NS_HPW_WAVES
+#define NS_HPW_WAVES 4
+#endif
+__global__ void __launch_bounds__(256, NS_HPW_WAVES) k_hp_write_w(GenArgs A) {
+    __shared__ HpRunLds run_lds[4];
+    HpRunLds &R = run_lds[threadIdx.x >> 6];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= A.prm.n_reads) return;
+    const ns_read rd = A.reads[r];
+    if (rd.flags) return;
+    if (!A.prm.emit_records) {
+        if (lane == 0) for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) A.pieces[rd.piece_off + pi].out_len = A.hp_len[rd.piece_off + pi];
+        return;
+    }
+    const ns_key key = read_key(A, r);
+    const uint32_t a = rd.attempts, k = A.prm.kmer_bias;
+    const bool fq = A.prm.fastq != 0, rev = rd.reversed != 0, ura = A.prm.uracil != 0;
+    const uint32_t L = rd.seq_len;                                         // final length
+    ReadOut ro;
+    ro.seq = A.records + rd.rec_off + A.name_len[r] + 2;
+    ro.qual = fq ? ro.seq + L + 3 : nullptr;
+    ro.seq_len = L; ro.reversed = rev; ro.uracil = ura;
+    const uint8_t *scr = A.scr + A.scr_off[r];
+    const uint8_t *scq = fq ? A.scrq + A.scr_off[r] : nullptr;
+    auto copy_plain = [&](uint64_t q_in, uint32_t q_out, uint32_t len) {   // scratch [q_in, q_in + len) -> final read [q_out, q_out + len)
+        for (uint32_t i0 = 16 * lane; i0 < len; i0 += 1024) {
+            const uint32_t count = min(16u, len - i0);
+            uint64_t v[2] = {0, 0}, w[2] = {0, 0};
+            __builtin_memcpy(v, scr + q_in + i0, 16);
+            if (fq) __builtin_memcpy(w, scq + q_in + i0, 16);
+            store_chunk(ro, q_out + i0, count, v[0], v[1], w[0], w[1], true);
+        }
+    };
+    uint64_t q_in = 0;
+    uint32_t q_out = 0;
+    copy_plain(q_in, q_out, rd.head); q_in += rd.head; q_out += rd.head;
+    for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
+        const ns_piece p = A.pieces[rd.piece_off + pi];
+        const uint32_t n = p.out_len, flen = A.hp_len[rd.piece_off + pi];
+        if (p.kind) { copy_plain(q_in, q_out, n); q_in += n; q_out += n; continue; }
+        const uint32_t sid = pi >> 1;
+        const uint8_t *sq = scr + q_in;
+        const uint8_t *qq = fq ? scq + q_in : nullptr;
+        uint32_t tileD = 0;                                                // length change of the runs that start before the tile (mod 2^32)
+        int32_t last_before = -1;
+        for (uint32_t t0 = 0; t0 < n; t0 += 1024) {
+            const uint32_t nts = hp_run_end_behind(sq, n, min(t0 + 1024u, n));
+            const HpTile t = hp_tile(sq, n, t0, lane, k, last_before, nts);
+            last_before = t.tile_last;
+            const uint32_t c = t0 + 16 * lane;
+            const uint32_t valid = c >= n ? 0u : min(16u, n - c);
+            // ---- A: the long runs this lane owns
+            const uint32_t rc = (uint32_t)__builtin_popcount(t.C);
+            const uint32_t rc_incl = wave_incl_scan(rc), slot0 = rc_incl - rc;
+            const uint32_t n_runs = (uint32_t)__builtin_amdgcn_readlane((int)rc_incl, 63);
+            uint32_t lane_delta = 0, lane_new = 0, slot = slot0;
+            for (uint32_t Cm = t.C; Cm; Cm &= Cm - 1) {
+                const uint32_t b = (uint32_t)__builtin_ctz(Cm), higher = t.M & ~((2u << b) - 1u);
+                const uint32_t s0 = c + b, e = higher ? c + (uint32_t)__builtin_ctz(higher) : t.next_start;
+                const uint32_t wv = b < 8 ? (b < 4 ? t.v.x : t.v.y) : (b < 12 ? t.v.z : t.v.w);
+                const uint32_t base = (wv >> (8 * (b & 3))) & 0xffu;
+                const uint32_t size = hp_new_size(A.m, key, sid, a, s0, e - s0, base);
+                R.s0[slot] = s0; R.len[slot] = e - s0; R.size[slot] = size; R.base[slot] = (uint8_t)base; R.fm[slot] = 0xffffffffu;
+                R.o_run[slot] = lane_delta;                                // (length change of the earlier runs of this chunk, for now)
+                lane_delta += size - (e - s0); lane_new += size; ++slot;
+            }
+            const uint32_t d_incl = wave_incl_scan(lane_delta), w_incl = wave_incl_scan(lane_new);
+            const uint32_t Dlane = tileD + d_incl - lane_delta;
+            const uint32_t total_new = (uint32_t)__builtin_amdgcn_readlane((int)w_incl, 63);
+            tileD += (uint32_t)__builtin_amdgcn_readlane((int)d_incl, 63);
+            {
+                uint32_t wb = w_incl - lane_new;
+                for (uint32_t j = slot0; j < slot; ++j) { R.o_run[j] += q_out + R.s0[j] + Dlane; R.w_off[j] = wb; wb += R.size[j]; }
+            }
+            if (lane == 63) R.w_off[n_runs] = total_new;
+            wave_sync();
+            // ---- B: plain stretches of the chunk
+            if (valid) {
+                // the run that was open when the chunk begins: if it is long, its bases inside the chunk belong to its owner
+                const uint32_t older_end = t.M ? c + (uint32_t)__builtin_ctz(t.M) : t.next_start;
+                const bool older_long = t.prev_start >= 0 && older_end > c && older_end - (uint32_t)t.prev_start >= k;
+                uint64_t qv[2] = {0, 0};
+                if (fq) __builtin_memcpy(qv, qq + c, 16);
+                const uint64_t vlo = (uint64_t)t.v.x | (uint64_t)t.v.y << 32, vhi = (uint64_t)t.v.z | (uint64_t)t.v.w << 32;
+                if (!older_long && !t.C) store_chunk(ro, q_out + c + Dlane, valid, vlo, vhi, qv[0], qv[1], true);
+                else {
+                    uint32_t Dcur = Dlane, j = slot0;
+                    uint32_t i = older_long ? min(older_end, c + 16) - c : 0u;
+                    while (i < valid) {
+                        if (!((t.C >> i) & 1u)) {                          // plain stretch up to the next long run of the chunk: one (partial) store
+                            const uint32_t rest = t.C >> i;
+                            const uint32_t i1 = rest ? min(valid, i + (uint32_t)__builtin_ctz(rest)) : valid;
+                            uint64_t lo = vlo, hi = vhi, ql = qv[0], qh = qv[1];
+                            shift_down_bytes(lo, hi, i); shift_down_bytes(ql, qh, i);
+                            store_chunk(ro, q_out + c + i + Dcur, i1 - i, lo, hi, ql, qh, true);
+                            i = i1;
+                            continue;
+                        }
+                        const uint32_t len = R.len[j];
+                        Dcur += R.size[j] - len;
+                        i = len >= 16u - i ? 16u : i + len;
+                        ++j;
+                    }
+                }
+            }
+            // ---- C: the new bases of the runs, one lane each (S:668-684, qualities S:686-695)
+            for (uint32_t w = lane; w < total_new; w += 64) {
+                uint32_t lo = 0, hi = n_runs;                              // run j with w_off[j] <= w < w_off[j + 1]
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (R.w_off[mid] <= w) lo = mid; else hi = mid; }
+                const uint32_t j = lo, x = w - R.w_off[j];
+                const uint32_t s0 = R.s0[j], len = R.len[j], size = R.size[j], base = R.base[j], e = s0 + len;
+                bool is_mis; uint32_t nb, qc = 0;
+                if (size <= len || x < len) {
+                    const uint32_t pp = size <= len ? s0 + (len - size) + x : s0 + x;
+                    nb = hp_base(A.m, base, key, sid, a, pp, 0, is_mis);
+                    if (fq) qc = qq[pp];
+                } else {
+                    const uint32_t jj = x - len;
+                    nb = hp_base(A.m, base, key, sid, a, e, 1 + jj, is_mis);
+                    if (fq) {
+                        const u32x4 wq = ns_draw(key, ST_HPQ, sid, a, e, 1 + (jj >> 3));
+                        const uint32_t h = (ns_word(wq, (jj & 7) >> 1) >> (16 * (jj & 1))) & 0xffffu;
+                        qc = qual_value(A.m.qual_thr + NS_Q_INS * NS_QUAL_LEVELS, h) + 33u;
+                    }
+                }
+                if (fq && is_mis) atomicMin(&R.fm[j], x);
+                const uint32_t pos = R.o_run[j] + x, oo = rev ? L - 1 - pos : pos;
+                uint8_t ob = rev ? complement(nb) : (uint8_t)nb;
+                if (ura && ob == 'T') ob = 'U';
+                ro.seq[oo] = ob;
+                if (fq) ro.qual[oo] = (uint8_t)qc;
+            }
+            if (fq) {                                                      // S:697-700: only the first mismatch of a run gets a 'mis' quality
+                __threadfence_block();                                     // (the quality bytes written above have landed)
+                wave_sync();
+                for (uint32_t j = lane; j < n_runs; j += 64) {
+                    const uint32_t fm = R.fm[j];
+                    if (fm == 0xffffffffu) continue;
+                    const u32x4 wq = ns_draw(key, ST_HPQ, sid, a, R.s0[j], 0);
+                    const uint32_t om = R.o_run[j] + fm;
+                    ro.qual[rev ? L - 1 - om : om] = (uint8_t)(qual_value(A.m.qual_thr + NS_Q_MIS * NS_QUAL_LEVELS, wq.x & 0xffffu) + 33u);
+                }
+            }
+            wave_sync();
         }
         q_in += n; q_out += flen;
         if (lane == 0) { ns_piece pw = p; pw.out_len = flen; A.pieces[rd.piece_off + pi] = pw; }      // report the emitted length, like the non -k path
@@ -2258,7 +2424,8 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     if (side_names) HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
     HIPCHK(hipEventRecord(ctx->evt[6], st));
     if (A.hp) {
-        if (prm->kmer_bias <= 16) k_hp_write_w<<<dim3((unsigned)((n + 3) / 4)), blk, 0, st>>>(A);
+        if (prm->kmer_bias >= 4 && prm->kmer_bias <= 16) k_hp_write_w<<<dim3((unsigned)((n + 3) / 4)), blk, 0, st>>>(A);
+        else if (prm->kmer_bias <= 16) k_hp_write_w_seq<<<dim3((unsigned)((n + 3) / 4)), blk, 0, st>>>(A);
         else k_hp_write<<<grid_t, blk, 0, st>>>(A);
         HIPCHK(hipGetLastError());
     } else if (prm->emit_records) {
