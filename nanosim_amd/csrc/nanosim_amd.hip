@@ -724,6 +724,7 @@ __global__ void __launch_bounds__(256) k_hp_filter_w(GenArgs A) {
             const PieceCtx pc = load_piece(A.events, A.ref, p, pi);
             ns_event *ev = A.events + p.ev_off;
             uint32_t w = 0; int32_t shift = 0;                            // kept events / their cumulative length change so far
+            const bool win = k <= 16 && !(pc.pos + pc.ref_len > pc.chrom_len);   // (a segment across the origin takes the generic walk)
             for (uint32_t j0 = 0; j0 < p.n_ev; j0 += 64) {                // S:1929-1947
                 const uint32_t j = j0 + lane;
                 const bool valid = j < p.n_ev;
@@ -733,7 +734,7 @@ __global__ void __launch_bounds__(256) k_hp_filter_w(GenArgs A) {
                 bool keep = valid;
                 if (valid) {
                     const int64_t lo = ty == NS_INS ? pos - 1 : pos, hi = pos + len - 1;
-                    for (int64_t x = lo; x <= hi && keep; ++x) keep = !in_hp_run(A.ref, pc, key, a, x, k);
+                    for (int64_t x = lo; x <= hi && keep; ++x) keep = win ? !in_hp_run_win(A.ref, pc, key, a, x, k) : !in_hp_run(A.ref, pc, key, a, x, k);
                 }
                 const uint64_t km = __ballot(keep);
                 const uint32_t before = (uint32_t)__popcll(km & ((1ull << lane) - 1ull));

@@ -23,6 +23,32 @@ __device__ inline bool in_hp_run(const DevRef &ref, const PieceCtx &pc, const ns
     return e - s >= k;
 }
 
+// 0x80 in every byte of x that is not zero
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) { return (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u; }
+__device__ __forceinline__ uint32_t movemask4(uint32_t flags80) { return (((flags80 >> 7) * 0x00204081u) >> 21) & 0xfu; }
+
+// The same for k <= 16 on a segment that does not wrap the origin of a circular chromosome: the 32 bases around x come in two
+// 16-byte loads (the engine's copy of the reference and the splice arena are padded), "differs from base x" becomes a bit per base,
+// and the run around x is two bit scans — instead of up to 2k dependent byte loads.  An IUPAC code in the window: the generic walk.
+__device__ inline bool in_hp_run_win(const DevRef &ref, const PieceCtx &pc, const ns_key &key, uint32_t a, int64_t x, int64_t k) {
+    if (x < 0 || x >= (int64_t)pc.ref_len) return false;
+    const uint8_t *p = ref.bases + pc.chrom_base + pc.pos + x - 15;       // window = segment positions [x - 15, x + 16]
+    uint4 lo, hi;
+    __builtin_memcpy(&lo, p, 16); __builtin_memcpy(&hi, p + 16, 16);
+    if ((lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) & 0x80808080u) return in_hp_run(ref, pc, key, a, x, k);
+    const uint32_t bb = (lo.w >> 24) * 0x01010101u;                        // base x in every byte
+    uint32_t ne = movemask4(nonzero_bytes(lo.x ^ bb)) | movemask4(nonzero_bytes(lo.y ^ bb)) << 4 | movemask4(nonzero_bytes(lo.z ^ bb)) << 8 |
+                  movemask4(nonzero_bytes(lo.w ^ bb)) << 12 | movemask4(nonzero_bytes(hi.x ^ bb)) << 16 | movemask4(nonzero_bytes(hi.y ^ bb)) << 20 |
+                  movemask4(nonzero_bytes(hi.z ^ bb)) << 24 | movemask4(nonzero_bytes(hi.w ^ bb)) << 28;
+    if (x < 15) ne |= (1u << (15 - x)) - 1u;                               // positions outside the segment end the run
+    const int64_t top = (int64_t)pc.ref_len - x + 14;                      // highest window bit inside the segment
+    if (top < 31) ne |= 0xffffffffu << (top + 1);
+    const uint32_t up = ne >> 15, dn = ne << 17;
+    const uint32_t r = up ? (uint32_t)__builtin_ctz(up) : 17u;            // base x and the equal bases behind it
+    const uint32_t l = dn ? (uint32_t)__builtin_clz(dn) : 15u;            // equal bases in front of it
+    return (int64_t)(l + r) >= k;
+}
+
 // get_nd_par (src/model_homopolymer_lengths.py:246-260)
 __device__ __forceinline__ void hp_nd_par(const DevModel &m, uint32_t base, uint32_t len, double &mu, double &sigma) {
     const ns_hp_class &h = m.hp[(base == 'A' || base == 'T') ? 0 : 1];
@@ -70,10 +96,6 @@ struct HpTile {
     uint4 v;               // the 16 bases
     int32_t tile_last;     // last run start inside the tile or before it (wave-uniform): the next tile's carry
 };
-// 0x80 in every byte of x that is not zero
-__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) { return (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u; }
-__device__ __forceinline__ uint32_t movemask4(uint32_t flags80) { return (((flags80 >> 7) * 0x00204081u) >> 21) & 0xfu; }
-
 // `next_tile_start`: first run start at or behind t0 + 1024 (wave-uniform; found by hp_run_end_behind)
 __device__ inline HpTile hp_tile(const uint8_t *__restrict__ sq, uint32_t n, uint32_t t0, uint32_t lane, uint32_t k, int32_t last_start_before_tile,
                                  uint32_t next_tile_start) {
@@ -92,21 +114,20 @@ __device__ inline HpTile hp_tile(const uint8_t *__restrict__ sq, uint32_t n, uin
     const uint32_t valid = c >= n ? 0u : (n - c >= 16 ? 16u : n - c);      // bases of the chunk inside the segment
     M &= (1u << valid) - 1u;
     t.M = M;
-    // last start before the chunk: exclusive prefix "max" of the lanes' last starts (positions grow with the lane)
-    int32_t last = M ? (int32_t)(c + 31u - (uint32_t)__clz((int)M)) : -1;
-    int32_t inc = last;
-    for (int off = 1; off < 64; off <<= 1) { const int32_t o = __shfl_up(inc, off); if ((int)lane >= off) inc = max(inc, o); }
-    int32_t prev = __shfl_up(inc, 1);
-    if (lane == 0) prev = -1;
-    t.prev_start = max(prev, last_start_before_tile);
-    t.tile_last = max(__shfl(inc, 63), last_start_before_tile);
-    // first start behind the chunk: exclusive suffix "min" of the lanes' first starts
-    uint32_t first = M ? c + (uint32_t)__builtin_ctz(M) : 0xffffffffu;
-    uint32_t dec = first;
-    for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_down(dec, off); if ((int)lane + off < 64) dec = min(dec, o); }
-    uint32_t nxt = __shfl_down(dec, 1);
-    if (lane == 63) nxt = 0xffffffffu;
-    t.next_start = min(nxt, next_tile_start);
+    // Positions grow with the lane, so "last start before the chunk" is the last start of the nearest lower lane that has one
+    // and "first start behind the chunk" the first start of the nearest higher lane that has one: a ballot, two bit scans and
+    // one cross-lane read each (instead of two 6-step shuffle scans).
+    const int32_t last = M ? (int32_t)(c + 31u - (uint32_t)__clz((int)M)) : -1;
+    const uint32_t first = M ? c + (uint32_t)__builtin_ctz(M) : 0xffffffffu;
+    const uint64_t B = __ballot(M != 0);
+    const uint64_t below = B & ((1ull << lane) - 1ull);
+    const int32_t pv = __shfl(last, below ? 63 - __clzll((long long)below) : (int)lane);
+    t.prev_start = max(below ? pv : -1, last_start_before_tile);
+    const int32_t tl = B ? __shfl(last, 63 - __clzll((long long)B)) : -1;
+    t.tile_last = max(tl, last_start_before_tile);
+    const uint64_t above = lane == 63 ? 0ull : B >> (lane + 1);
+    const uint32_t nx = (uint32_t)__shfl((int)first, above ? (int)lane + 1 + __builtin_ctzll(above) : (int)lane);
+    t.next_start = min(above ? nx : 0xffffffffu, next_tile_start);
     // long runs starting in this chunk: no further start among the next k - 1 bases
     const uint32_t upper = t.next_start - c >= 32u ? 0u : 1u << (t.next_start - c);       // the first start behind the chunk, as a bit of a 32-bit window
     const uint32_t W = M | upper;
