@@ -96,23 +96,43 @@ struct HpTile {
     uint4 v;               // the 16 bases
     int32_t tile_last;     // last run start inside the tile or before it (wave-uniform): the next tile's carry
 };
-// `next_tile_start`: first run start at or behind t0 + 1024 (wave-uniform; found by hp_run_end_behind)
-__device__ inline HpTile hp_tile(const uint8_t *__restrict__ sq, uint32_t n, uint32_t t0, uint32_t lane, uint32_t k, int32_t last_start_before_tile,
-                                 uint32_t next_tile_start) {
+// the lane's 16 bases of a tile and the base in front of them, as loaded (the kernels keep the loads of the next two tiles in flight)
+struct HpRaw { uint4 v; uint32_t pb; };
+__device__ __forceinline__ HpRaw hp_load(const uint8_t *__restrict__ sq, uint32_t n, uint32_t t0, uint32_t lane) {
+    HpRaw r; r.v = make_uint4(0, 0, 0, 0); r.pb = 0xffu;            // base before the chunk (0xff: none -> base 0 starts a run)
+    const uint32_t c = t0 + 16 * lane;
+    if (c < n) {
+        __builtin_memcpy(&r.v, sq + c, 16);                        // (the scratch buffer has slack behind the last read)
+        if (c) r.pb = sq[c - 1];
+    }
+    return r;
+}
+// bit b: a run starts at base b of the chunk (base b differs from base b - 1)
+__device__ __forceinline__ uint32_t hp_starts(const HpRaw &r, uint32_t n, uint32_t t0, uint32_t lane) {
+    const uint32_t c = t0 + 16 * lane;
+    const uint32_t p0 = r.v.x << 8 | r.pb, p1 = r.v.y << 8 | r.v.x >> 24, p2 = r.v.z << 8 | r.v.y >> 24, p3 = r.v.w << 8 | r.v.z >> 24;
+    const uint32_t M = movemask4(nonzero_bytes(r.v.x ^ p0)) | movemask4(nonzero_bytes(r.v.y ^ p1)) << 4 | movemask4(nonzero_bytes(r.v.z ^ p2)) << 8 |
+                       movemask4(nonzero_bytes(r.v.w ^ p3)) << 12;
+    const uint32_t valid = c >= n ? 0u : (n - c >= 16 ? 16u : n - c);      // bases of the chunk inside the segment
+    return M & ((1u << valid) - 1u);
+}
+__device__ inline uint32_t hp_run_end_behind(const uint8_t *__restrict__ sq, uint32_t n, uint32_t p);
+// first run start at or behind t1 = the end of a tile, from the chunk / starts of the NEXT tile (wave-uniform).  Only when a single
+// run fills the whole next tile does the scratch have to be walked.
+__device__ inline uint32_t hp_next_tile_start(uint32_t M_next, const uint8_t *__restrict__ sq, uint32_t n, uint32_t t1, uint32_t lane) {
+    if (t1 >= n) return n;
+    const uint64_t B = __ballot(M_next != 0);
+    if (!B) return hp_run_end_behind(sq, n, min(t1 + 1024u, n));
+    const uint32_t first = t1 + 16 * lane + (M_next ? (uint32_t)__builtin_ctz(M_next) : 0u);
+    return (uint32_t)__shfl((int)first, __builtin_ctzll(B));
+}
+
+// `next_tile_start`: first run start at or behind t0 + 1024 (wave-uniform; hp_next_tile_start / hp_run_end_behind)
+__device__ inline HpTile hp_tile_from(const HpRaw &raw, uint32_t M, uint32_t t0, uint32_t lane, uint32_t k, int32_t last_start_before_tile,
+                                      uint32_t next_tile_start) {
     HpTile t;
     const uint32_t c = t0 + 16 * lane;
-    t.v = make_uint4(0, 0, 0, 0);
-    uint32_t pb = 0xffu;                                            // base before the chunk (0xff: none -> base 0 starts a run)
-    if (c < n) {
-        __builtin_memcpy(&t.v, sq + c, 16);                        // (the scratch buffer has slack behind the last read)
-        if (c) pb = sq[c - 1];
-    }
-    // starts: base b differs from base b - 1
-    const uint32_t p0 = t.v.x << 8 | pb, p1 = t.v.y << 8 | t.v.x >> 24, p2 = t.v.z << 8 | t.v.y >> 24, p3 = t.v.w << 8 | t.v.z >> 24;
-    uint32_t M = movemask4(nonzero_bytes(t.v.x ^ p0)) | movemask4(nonzero_bytes(t.v.y ^ p1)) << 4 | movemask4(nonzero_bytes(t.v.z ^ p2)) << 8 |
-                 movemask4(nonzero_bytes(t.v.w ^ p3)) << 12;
-    const uint32_t valid = c >= n ? 0u : (n - c >= 16 ? 16u : n - c);      // bases of the chunk inside the segment
-    M &= (1u << valid) - 1u;
+    t.v = raw.v;
     t.M = M;
     // Positions grow with the lane, so "last start before the chunk" is the last start of the nearest lower lane that has one
     // and "first start behind the chunk" the first start of the nearest higher lane that has one: a ballot, two bit scans and
@@ -136,6 +156,11 @@ __device__ inline HpTile hp_tile(const uint8_t *__restrict__ sq, uint32_t n, uin
     // a run may also be cut short by the end of the segment: n acts as a start (next_tile_start / next_start carry it)
     t.C = C;
     return t;
+}
+__device__ inline HpTile hp_tile(const uint8_t *__restrict__ sq, uint32_t n, uint32_t t0, uint32_t lane, uint32_t k, int32_t last_start_before_tile,
+                                 uint32_t next_tile_start) {
+    const HpRaw raw = hp_load(sq, n, t0, lane);
+    return hp_tile_from(raw, hp_starts(raw, n, t0, lane), t0, lane, k, last_start_before_tile, next_tile_start);
 }
 // end of the run that holds base p - 1 ... scanning forward from p (wave-uniform helper for the run that is open at a tile end)
 __device__ inline uint32_t hp_run_end_behind(const uint8_t *__restrict__ sq, uint32_t n, uint32_t p) {
