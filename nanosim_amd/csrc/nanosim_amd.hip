@@ -1706,12 +1706,14 @@ int ns_load_model(ns_ctx *ctx, const ns_model_tables *t) {
     }
     if (t->flags & NS_MODEL_HAS_QUALS) {
         if ((rc = upload(ctx, pool, &t->qual_thr[0][0], (size_t)NS_Q_COUNT * NS_QUAL_LEVELS, &m.qual_thr))) return rc;
-        std::vector<uint8_t> lut((size_t)NS_Q_COUNT * 1024);
+        std::vector<uint16_t> lut((size_t)NS_Q_COUNT * 1024);
         for (int c = 0; c < NS_Q_COUNT; ++c)
             for (uint32_t b = 0; b < 1024; ++b) {
                 uint32_t q = 0;
                 while (q < NS_QUAL_LEVELS - 1 && t->qual_thr[c][q] <= 64u * b) ++q;      // thresholds at or below the bucket start
-                lut[(size_t)c * 1024 + b] = (uint8_t)q;
+                uint32_t inside = 0, sub = 64;                                             // thresholds in (64 b, 64 b + 63]
+                for (uint32_t j = q; j < NS_QUAL_LEVELS - 1 && t->qual_thr[c][j] <= 64u * b + 63u; ++j) { if (!inside) sub = t->qual_thr[c][j] - 64u * b; ++inside; }
+                lut[(size_t)c * 1024 + b] = (uint16_t)(q | sub << 8 | (inside > 1 ? 0x8000u : 0u));
             }
         if ((rc = upload(ctx, pool, lut.data(), lut.size(), &m.qual_lut))) return rc;
     }

@@ -599,7 +599,7 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
 #undef NS_CLS_WORD
 #pragma unroll
                 for (uint32_t half = 0; half < 2; ++half) {
-                    uint32_t h[8], cl[8], q[8], t0[8], t1[8];
+                    uint32_t h[8], cl[8], q[8];
 #pragma unroll
                     for (uint32_t j = 0; j < 8; ++j) {
                         const uint32_t i = 8 * half + j;
@@ -607,24 +607,15 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
                         cl[j] = (pcw[i >> 2] >> (8 * (i & 3))) & 0xffu;
                     }
 #pragma unroll
-                    for (uint32_t j = 0; j < 8; ++j) q[j] = m.qual_lut[cl[j] * 1024u + (h[j] >> 6)];
-#pragma unroll
-                    for (uint32_t j = 0; j < 8; ++j) {
-                        const uint32_t *thr = m.qual_thr + cl[j] * NS_QUAL_LEVELS;
-                        t0[j] = thr[min(q[j], (uint32_t)NS_QUAL_LEVELS - 2u)];
-                        t1[j] = thr[min(q[j] + 1u, (uint32_t)NS_QUAL_LEVELS - 2u)];
-                    }
+                    for (uint32_t j = 0; j < 8; ++j) q[j] = m.qual_lut[cl[j] * 1024u + (h[j] >> 6)];     // bucket entry: see qual_value_lut
                     uint64_t acc = 0;
 #pragma unroll
                     for (uint32_t j = 0; j < 8; ++j) {
-                        uint32_t qq = q[j];
-                        if (qq < NS_QUAL_LEVELS - 1 && h[j] >= t0[j]) {
-                            ++qq;
-                            if (qq < NS_QUAL_LEVELS - 1 && h[j] >= t1[j]) {          // rare: more than one threshold inside a 64-wide bucket
-                                ++qq;
-                                const uint32_t *thr = m.qual_thr + cl[j] * NS_QUAL_LEVELS;
-                                while (qq < NS_QUAL_LEVELS - 1 && h[j] >= thr[qq]) ++qq;
-                            }
+                        uint32_t qq = (q[j] & 0xffu) + ((h[j] & 63u) >= ((q[j] >> 8) & 0x7fu) ? 1u : 0u);
+                        if (q[j] & 0x8000u) {                                      // rare: more than one threshold inside the bucket
+                            const uint32_t *thr = m.qual_thr + cl[j] * NS_QUAL_LEVELS;
+                            qq = q[j] & 0xffu;
+                            while (qq < NS_QUAL_LEVELS - 1 && h[j] >= thr[qq]) ++qq;
                         }
                         acc |= (uint64_t)qq << (8 * j);
                     }
