@@ -134,3 +134,50 @@ def test_full_size_structure_and_event_replay(setup):
         assert np.array_equal(body[o:o + run][m], seg[x:][m])
         assert o + run == pc["out_len"]
     assert n_events_checked > 50000
+
+
+def _record_slice(eng, b, reads, r, n):
+    L = E.load_library()
+    lo = int(reads["rec_off"][r])
+    hi = int(reads["rec_off"][r + 1]) if r + 1 < n else int(b.info.record_bytes)
+    rec = np.empty(hi - lo, dtype=np.uint8)
+    eng._check(L.ns_copy_out(eng.ctx, E.NS_BUF_RECORDS, rec.ctypes.data, lo, rec.nbytes))
+    return rec.tobytes()
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(fastq=True, kmer_bias=5)])
+def test_full_size_oracle_spot_checks(setup, tmp_path, cfg):
+    """10^6 reads in one launch (configs[1]; with FASTQ + -hp -k 5: the record path of configs[2]): reads sampled from the big
+    batch are byte-identical to the CPU oracle generating the same read index alone (a read is a pure function of the seed and
+    its index), FASTQ framing and quality range hold for every sampled read, two launches agree."""
+    eng0, mdl0, ref = setup
+    eng, mdl = eng0, mdl0
+    own = None
+    if cfg:
+        prefix = str(tmp_path / "training")
+        synth.write_model(prefix, synth.SynthModelSpec(n_train=1_000_000, seed=SEED), write_pkl=False)
+        mdl = M.load_model(prefix, fastq=True, homopolymer=True)
+        own = eng = E.Engine(0)
+        eng.set_reference(ref)
+        eng.load_model(mdl)
+    try:
+        kw = dict(seed=SEED + 7, max_len=ref.max_chrom, **cfg)
+        b = eng.generate(E.make_params(first_read=0, n_reads=N, **kw))
+        reads = b.reads()
+        assert np.all(reads["flags"] == 0)
+        rng = np.random.default_rng(5)
+        picks = sorted(set(int(x) for x in rng.integers(0, N, 48)) | {0, N - 1})
+        got = {r: _record_slice(eng, b, reads, r, N) for r in picks}
+        c_full = checksum(b.records())
+        for r in picks:
+            exp = O.generate(mdl, ref, E.make_params(first_read=r, n_reads=1, **kw), bytes_per_read=1_000_000, events_per_read=100_000)
+            assert got[r] == exp["records"].tobytes(), r
+            if cfg.get("fastq"):
+                name, seq, plus, qual = got[r].split(b"\n")[:4]
+                assert name[:1] == b"@" and plus == b"+" and len(seq) == len(qual) == reads["seq_len"][r]
+                q = np.frombuffer(qual, dtype=np.uint8)
+                assert q.min() >= 33 + 1 and q.max() <= 33 + 93
+        assert checksum(eng.generate(E.make_params(first_read=0, n_reads=N, **kw)).records()) == c_full
+    finally:
+        if own is not None:
+            own.close()
