@@ -145,9 +145,9 @@ def _record_slice(eng, b, reads, r, n):
     return rec.tobytes()
 
 
-@pytest.mark.parametrize("cfg", [dict(), dict(fastq=True, kmer_bias=5)])
+@pytest.mark.parametrize("cfg", [dict(), dict(fastq=True, kmer_bias=5), dict(chimeric=True, fastq=True)])
 def test_full_size_oracle_spot_checks(setup, tmp_path, cfg):
-    """10^6 reads in one launch (configs[1]; with FASTQ + -hp -k 5: the record path of configs[2]): reads sampled from the big
+    """10^6 reads in one launch (configs[1]; with FASTQ + -hp -k 5: the record path of configs[2]; chimeric: configs[3]): reads sampled from the big
     batch are byte-identical to the CPU oracle generating the same read index alone (a read is a pure function of the seed and
     its index), FASTQ framing and quality range hold for every sampled read, two launches agree."""
     eng0, mdl0, ref = setup
@@ -156,7 +156,7 @@ def test_full_size_oracle_spot_checks(setup, tmp_path, cfg):
     if cfg:
         prefix = str(tmp_path / "training")
         synth.write_model(prefix, synth.SynthModelSpec(n_train=1_000_000, seed=SEED), write_pkl=False)
-        mdl = M.load_model(prefix, fastq=True, homopolymer=True)
+        mdl = M.load_model(prefix, fastq=True, homopolymer=True, chimeric=True)
         own = eng = E.Engine(0)
         eng.set_reference(ref)
         eng.load_model(mdl)
