@@ -27,6 +27,12 @@
 #include "ns_hp.h"
 #include "ns_ir.h"
 
+// Reads per workgroup of the wave-per-read kernels.  One: read lengths vary by an order of magnitude inside a batch, and a wavefront
+// that is done cannot leave before the longest read of its workgroup is.
+#ifndef NS_WPB
+#define NS_WPB 1
+#endif
+
 // ---------------------------------------------------------------------------------------------------------
 // kernel arguments
 // ---------------------------------------------------------------------------------------------------------
@@ -543,7 +549,7 @@ __global__ void __launch_bounds__(256) k_names(GenArgs A) {
 // the read are copied from the genome into the read's slot of the splice arena (S:1161-1178), in the orientation of the transcript
 // (reverse_complement for strand '-', which only knows upper-case ACGT, S:1675-1680) and in the device form of the bases
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_ir_splice(GenArgs A) {
+__global__ void __launch_bounds__(64 * NS_WPB) k_ir_splice(GenArgs A) {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= A.prm.n_reads) return;
@@ -706,7 +712,7 @@ __global__ void __launch_bounds__(256) k_hp_filter(GenArgs A) {
 
 // the same, one read per wavefront: lane per event (the homopolymer test of an event is independent of the others), ballot /
 // prefix-popcount compaction, exclusive wavefront prefix sum of the length changes for the shift field
-__global__ void __launch_bounds__(256) k_hp_filter_w(GenArgs A) {
+__global__ void __launch_bounds__(64 * NS_WPB) k_hp_filter_w(GenArgs A) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r > A.prm.n_reads) return;
@@ -799,8 +805,17 @@ __device__ inline void hp_final_length(const GenArgs &A, uint64_t r, ns_read &rd
 }
 
 // k_hp_count, one read per wavefront (k <= 16): runs are found 1024 bases at a time (ns_hp.h: hp_tile), a run belongs to the lane
-// that holds its first base, that lane draws the new length
-__global__ void __launch_bounds__(256, 4) k_hp_count_w(GenArgs A) {
+// that holds its first base.  The long runs of a segment are collected in an LDS list and their new lengths drawn one lane per run
+// (k >= 4; a tile holds at most 1024 / k of them) — drawn inside the tile loop, the 3-4 runs of a tile cost every lane of the
+// wavefront a Philox block and an inverse normal CDF per tile.
+#define NS_HPC_LIST 512u
+struct HpCountLds { uint32_t s0[NS_HPC_LIST], len[NS_HPC_LIST]; uint8_t base[NS_HPC_LIST]; };
+#ifndef NS_HPC_WAVES
+#define NS_HPC_WAVES 4
+#endif
+__global__ void __launch_bounds__(64 * NS_WPB, NS_HPC_WAVES) k_hp_count_w(GenArgs A) {
+    __shared__ HpCountLds list_lds[NS_WPB];
+    HpCountLds &R = list_lds[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     unsigned long long st_bases = 0, st_fail = 0;
@@ -809,6 +824,7 @@ __global__ void __launch_bounds__(256, 4) k_hp_count_w(GenArgs A) {
         if (!rd.flags) {
             const ns_key key = read_key(A, r);
             const uint32_t a = rd.attempts, k = A.prm.kmer_bias;
+            const bool listed = k >= 4;
             const uint8_t *scr = A.scr + A.scr_off[r];
             uint64_t q = rd.head, final_len = (uint64_t)rd.head + rd.tail + (A.polya ? A.polya[r] : 0u);
             for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
@@ -819,6 +835,14 @@ __global__ void __launch_bounds__(256, 4) k_hp_count_w(GenArgs A) {
                     const uint8_t *sq = scr + q;
                     long long delta = 0;
                     int32_t last_before = -1;
+                    uint32_t n_list = 0;                                                 // runs waiting in the list (wave-uniform)
+                    auto drain = [&]() {
+                        wave_sync();
+                        for (uint32_t j = lane; j < n_list; j += 64)
+                            delta += (long long)hp_new_size(A.m, key, sid, a, R.s0[j], R.len[j], R.base[j]) - (long long)R.len[j];
+                        wave_sync();
+                        n_list = 0;
+                    };
                     HpRaw raw0 = hp_load(sq, n, 0, lane), raw1 = hp_load(sq, n, 1024, lane);     // two tiles ahead
                     uint32_t M0 = hp_starts(raw0, n, 0, lane);
                     for (uint32_t t0 = 0; t0 < n; t0 += 1024) {
@@ -829,14 +853,24 @@ __global__ void __launch_bounds__(256, 4) k_hp_count_w(GenArgs A) {
                         raw0 = raw1; M0 = M1; raw1 = raw2;
                         last_before = t.tile_last;
                         const uint32_t c = t0 + 16 * lane;
+                        uint32_t slot = 0, n_tile = 0;
+                        if (listed) {
+                            const uint32_t rc = (uint32_t)__builtin_popcount(t.C), incl = wave_incl_scan(rc);
+                            slot = n_list + incl - rc;
+                            n_tile = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                        }
                         for (uint32_t Cm = t.C; Cm; Cm &= Cm - 1) {                     // long runs that start in this lane's chunk
                             const uint32_t b = (uint32_t)__builtin_ctz(Cm), higher = t.M & ~((2u << b) - 1u);
                             const uint32_t s0 = c + b, e = higher ? c + (uint32_t)__builtin_ctz(higher) : t.next_start;
                             const uint32_t wv = b < 8 ? (b < 4 ? t.v.x : t.v.y) : (b < 12 ? t.v.z : t.v.w);
                             const uint32_t base = (wv >> (8 * (b & 3))) & 0xffu;
-                            delta += (long long)hp_new_size(A.m, key, sid, a, s0, e - s0, base) - (long long)(e - s0);
+                            if (listed) { R.s0[slot] = s0; R.len[slot] = e - s0; R.base[slot] = (uint8_t)base; ++slot; }
+                            else delta += (long long)hp_new_size(A.m, key, sid, a, s0, e - s0, base) - (long long)(e - s0);
                         }
+                        n_list += n_tile;
+                        if (n_list > NS_HPC_LIST - 256u) drain();                        // (the next tile may bring 1024 / k <= 256 more)
                     }
+                    if (n_list) drain();
                     unsigned long long du = wave_sum((unsigned long long)delta);
                     flen = (uint32_t)((long long)n + (long long)du);
                 }
@@ -846,9 +880,20 @@ __global__ void __launch_bounds__(256, 4) k_hp_count_w(GenArgs A) {
             }
             if (lane == 0) hp_final_length(A, r, rd, a, final_len, st_bases, st_fail);
         }
+        // emitted bases of the read: summed by k_sum_u64 afterwards (one atomic per read on one address costs ~10 ns each: 10 ms per
+        // 10^6 reads, more than the rest of this kernel)
+        if (lane == 0) A.scr_len[r] = st_bases;
     }
-    st_bases = wave_sum(st_bases); st_fail = wave_sum(st_fail);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&A.stats[1], st_bases); if (st_fail) atomicAdd(&A.stats[5], st_fail); }
+    st_fail = wave_sum(st_fail);
+    if ((threadIdx.x & 63) == 0 && st_fail) atomicAdd(&A.stats[5], st_fail);
+}
+
+// sum of v[0 .. n) added to *dst: grid-stride, one atomic per wavefront
+__global__ void __launch_bounds__(256) k_sum_u64(const uint64_t *__restrict__ v, uint64_t n, unsigned long long *dst) {
+    unsigned long long acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) acc += v[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(dst, acc);
 }
 
 __global__ void __launch_bounds__(256) k_hp_count(GenArgs A) {
@@ -970,7 +1015,7 @@ __global__ void __launch_bounds__(256) k_hp_write(GenArgs A) {
 // of k_hp_write_w): head / gaps / polyA / tail are plain 16-byte copies; inside an aligned segment a lane
 // copies its 16 bases with one store when no long run touches them, otherwise base by base, re-sampling the runs it owns (mutate_homo,
 // S:657-700).  Output offsets: wavefront prefix sum of the length changes of the runs that start before the lane's chunk.
-__global__ void __launch_bounds__(256, 3) k_hp_write_w_seq(GenArgs A) {
+__global__ void __launch_bounds__(64 * NS_WPB, 3) k_hp_write_w_seq(GenArgs A) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= A.prm.n_reads) return;
@@ -1116,8 +1161,8 @@ struct HpRunLds {
 #ifndef NS_HPW_WAVES
 #define NS_HPW_WAVES 4
 #endif
-__global__ void __launch_bounds__(256, NS_HPW_WAVES) k_hp_write_w(GenArgs A) {
-    __shared__ HpRunLds run_lds[4];
+__global__ void __launch_bounds__(64 * NS_WPB, NS_HPW_WAVES) k_hp_write_w(GenArgs A) {
+    __shared__ HpRunLds run_lds[NS_WPB];
     HpRunLds &R = run_lds[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -1269,7 +1314,7 @@ __global__ void __launch_bounds__(256, NS_HPW_WAVES) k_hp_write_w(GenArgs A) {
 // ---------------------------------------------------------------------------------------------------------
 // k_errlog: error-profile rows "name\tpos\ttype\tlen\tref\tnew\n" in descending position order (S:1960, 2006-2008)
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_errlog(GenArgs A) {
+__global__ void __launch_bounds__(64 * NS_WPB) k_errlog(GenArgs A) {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= A.prm.n_reads) return;
@@ -1805,7 +1850,7 @@ static int hp_stage1(ns_ctx *ctx, const ns_params *prm, GenArgs &A, size_t n, ui
     HIPCHK(hipEventRecord(ctx->evt[9], st));
     if ((rc = ensure(ctx, ctx->hp_len, (size_t)tot_pieces * 4 + 64))) return rc;
     A.hp_len = (uint32_t *)ctx->hp_len.p;
-    k_hp_filter_w<<<dim3((unsigned)((n + 1 + 3) / 4)), blk, 0, st>>>(A);
+    k_hp_filter_w<<<dim3((unsigned)((n + NS_WPB) / NS_WPB)), dim3(64 * NS_WPB), 0, st>>>(A);
     HIPCHK(hipGetLastError());
     if ((rc = scan_u64(ctx, A.scr_len, A.scr_off, n + 1))) return rc;
     uint64_t scr_bytes = 0;
@@ -1816,8 +1861,10 @@ static int hp_stage1(ns_ctx *ctx, const ns_params *prm, GenArgs &A, size_t n, ui
     if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, event_slots))) return rc;
     if (!A.meta || A.key_pos) HIPCHK(hipMemsetAsync((unsigned long long *)ctx->stats.p + 1, 0, sizeof(unsigned long long), st));   // (kept across metagenome passes)
     HIPCHK(hipMemsetAsync((unsigned long long *)ctx->stats.p + 5, 0, sizeof(unsigned long long), st));
-    if (prm->kmer_bias <= 16) k_hp_count_w<<<dim3((unsigned)((n + 3) / 4)), blk, 0, st>>>(A);
-    else k_hp_count<<<grid_t, blk, 0, st>>>(A);
+    if (prm->kmer_bias <= 16) {
+        k_hp_count_w<<<dim3((unsigned)((n + NS_WPB - 1) / NS_WPB)), dim3(64 * NS_WPB), 0, st>>>(A);
+        k_sum_u64<<<dim3((unsigned)std::min<size_t>(512, (n + 255) / 256)), blk, 0, st>>>(A.scr_len, n, (unsigned long long *)ctx->stats.p + 1);
+    } else k_hp_count<<<grid_t, blk, 0, st>>>(A);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->evt[10], st));
     HIPCHK(hipMemcpyAsync(stats, ctx->stats.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -2288,7 +2335,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     uint32_t *list_a = (uint32_t *)ctx->order.p, *list_b = (uint32_t *)ctx->list_b.p;
     const dim3 blk(256);
     const dim3 grid_t((unsigned)((n + 1 + 255) / 256));        // thread-per-read kernels (n+1 for the scan sentinel)
-    const dim3 grid_w((unsigned)((n + 3) / 4));                // wave-per-read kernels, 4 waves per block
+    const dim3 grid_w((unsigned)((n + NS_WPB - 1) / NS_WPB)), blk_w(64 * NS_WPB);     // wave-per-read kernels
     hipStream_t st = ctx->stream;
     unsigned long long stats[8];
     uint64_t tot_pieces = 0, tot_cap = 0;
@@ -2404,7 +2451,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         A.ref.spliced = (const uint8_t *)ctx->spliced.p;
         ctx->spliced_bytes = arena_bytes;
         if (arena_bytes) {
-            k_ir_splice<<<grid_w, blk, 0, st>>>(A);
+            k_ir_splice<<<grid_w, blk_w, 0, st>>>(A);
             HIPCHK(hipGetLastError());
         }
     }
@@ -2436,8 +2483,8 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     if (side_names) HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
     HIPCHK(hipEventRecord(ctx->evt[6], st));
     if (A.hp) {
-        if (prm->kmer_bias >= 4 && prm->kmer_bias <= 16) k_hp_write_w<<<dim3((unsigned)((n + 3) / 4)), blk, 0, st>>>(A);
-        else if (prm->kmer_bias <= 16) k_hp_write_w_seq<<<dim3((unsigned)((n + 3) / 4)), blk, 0, st>>>(A);
+        if (prm->kmer_bias >= 4 && prm->kmer_bias <= 16) k_hp_write_w<<<grid_w, blk_w, 0, st>>>(A);
+        else if (prm->kmer_bias <= 16) k_hp_write_w_seq<<<grid_w, blk_w, 0, st>>>(A);
         else k_hp_write<<<grid_t, blk, 0, st>>>(A);
         HIPCHK(hipGetLastError());
     } else if (prm->emit_records) {
@@ -2445,7 +2492,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     }
     HIPCHK(hipEventRecord(ctx->evt[7], st));
     if (prm->emit_errlog && prm->emit_records) {
-        k_errlog<<<grid_w, blk, 0, st>>>(A);
+        k_errlog<<<grid_w, blk_w, 0, st>>>(A);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ctx->evt[8], st));
