@@ -453,30 +453,59 @@ __global__ void __launch_bounds__(256) k_meta_words(GenArgs A, uint2 *out, uint6
     const u32x4 w = ns_draw(make_key(A.prm, 0), ST_SPECIES, 0, A.attempt, (uint32_t)j, (uint32_t)(j >> 32));
     out[j] = make_uint2(w.x, w.y);
 }
+// int(round(length)) of the assigned lengths (S:871), on the device copy of the sorted list
+__global__ void __launch_bounds__(256) k_meta_round(const double *__restrict__ x, int32_t *__restrict__ out, uint64_t n) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) out[j] = (int32_t)rint(x[j]);
+}
 struct MetaLenFilter {           // S:857 (0 < x <= max_l) / S:841 (--perfect: min_l <= x <= max_l)
     double lo, hi; bool lo_inclusive;
     __host__ __device__ bool operator()(const double &x) const { return (lo_inclusive ? lo <= x : lo < x) && x <= hi; }
 };
 
+// dst[key] += val for every lane with key != ~0u: one atomic per distinct key and wavefront (the species quotas are ten addresses;
+// one atomic per read on them cost 4 ms per 10^6 reads)
+__device__ inline void wave_add_by_key(unsigned long long *dst, uint32_t key, unsigned long long val) {
+    for (;;) {
+        const uint64_t act = __ballot(key != 0xffffffffu);
+        if (!act) break;
+        const int first = __builtin_ctzll(act);
+        const uint32_t lead = (uint32_t)__shfl((int)key, first);
+        const bool mine = key == lead;
+        const unsigned long long sum = wave_sum(mine ? val : 0ull);
+        if ((int)(threadIdx.x & 63u) == first) atomicAdd(&dst[lead], sum);
+        if (mine) key = 0xffffffffu;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_meta_commit(GenArgs A) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A.list_n || !A.accept[i]) return;
-    const uint64_t sc = A.accept_scan[i];
-    const uint64_t slot = A.m_passed + (uint32_t)sc;
+    const bool on = i < A.list_n && A.accept[i];
+    ns_read rd; rd.n_pieces = 0; rd.piece_off = 0;
+    uint64_t sc = 0;
+    if (on) { rd = A.reads[i]; sc = A.accept_scan[i]; }
     const uint32_t poff = A.m_pieces_passed + (uint32_t)(sc >> 32);
-    ns_read rd = A.reads[i];
     const ns_piece *src = A.pieces + rd.piece_off;
     ns_piece *dst = A.f_pieces + poff;
     uint64_t rows = 0;
-    for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
-        const ns_piece p = src[pi];
-        dst[pi] = p;
-        if (!p.kind) {
-            rows += p.n_ev;
-            if (A.prm.kind == NS_KIND_ALIGNED)                         // S:1001-1002 (the --perfect branch never updates the quotas)
-                atomicAdd(&A.species_bases[A.m_species[A.m_segptr[i] + (pi >> 1)]], (unsigned long long)p.ref_len);
+    uint32_t maxp = on ? rd.n_pieces : 0u;
+    for (int off = 32; off > 0; off >>= 1) maxp = max(maxp, (uint32_t)__shfl_xor((int)maxp, off));
+    for (uint32_t pi = 0; pi < maxp; ++pi) {
+        uint32_t sp = 0xffffffffu; unsigned long long bases = 0;
+        if (on && pi < rd.n_pieces) {
+            const ns_piece p = src[pi];
+            dst[pi] = p;
+            if (!p.kind) {
+                rows += p.n_ev;
+                if (A.prm.kind == NS_KIND_ALIGNED) {                   // S:1001-1002 (the --perfect branch never updates the quotas)
+                    sp = A.m_species[A.m_segptr[i] + (pi >> 1)]; bases = p.ref_len;
+                }
+            }
         }
+        wave_add_by_key(A.species_bases, sp, bases);
     }
+    if (!on) return;
+    const uint64_t slot = A.m_passed + (uint32_t)sc;
     rd.piece_off = poff;
     A.f_reads[slot] = rd;
     A.key_pos_w[slot] = (uint32_t)i;
@@ -2096,7 +2125,7 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
     const ns_key bkey{(uint32_t)prm->seed, (uint32_t)(prm->seed >> 32), (uint32_t)prm->first_read, (uint32_t)(prm->first_read >> 32)};
     std::vector<double> cur_bases(ns, 0.0);
     std::vector<unsigned long long> sb(ns);
-    std::vector<int32_t> segs, mlen;
+    std::vector<int32_t> segs;
     std::vector<uint32_t> segptr, pieceoff;
     uint64_t passed = 0, pieces_passed = 0, ev_base = 0;
     double ms_chain = 0;
@@ -2170,11 +2199,10 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
         }
         if (!np) continue;
         segptr[np] = (uint32_t)sp; pieceoff[np] = (uint32_t)po;
-        mlen.resize(sp);
-        for (uint64_t j = 0; j < sp; ++j) mlen[j] = (int32_t)nearbyint(h_sorted[j]);   // S:871
+        k_meta_round<<<dim3((unsigned)((sp + 255) / 256)), blk, 0, st>>>(d_sorted, (int32_t *)ctx->m_len.p, sp);   // S:871: int(round(length))
+        HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(ctx->m_segptr.p, segptr.data(), (np + 1) * 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(ctx->piece_off.p, pieceoff.data(), (np + 1) * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(ctx->m_len.p, mlen.data(), sp * 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(ctx->m_species.p, h_species, sp * 2, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemsetAsync(P.accept, 0, (np + 1) * 8, st));
         HIPCHK(hipMemsetAsync(P.ev_cap + np, 0, 8, st));
