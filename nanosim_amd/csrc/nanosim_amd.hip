@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
                 sink.ev = A.events + ev_off + evn; sink.cap = ev_cap > evn ? ev_cap - evn : 0; sink.n = 0; sink.shift = 0;
                 EList32 e;
                 if (kind == NS_KIND_PERFECT) { e.l_new = e.middle_ref = m32; }
-                else if (p.kind) e = chain_unaligned_error_list(T, ct, m32, key, sid, a, sink);
+                else if (p.kind) e = COOP ? coop_unaligned_error_list(T, ct, m32, key, sid, a, sink, lane) : chain_unaligned_error_list(T, ct, m32, key, sid, a, sink);
                 else if (COOP) e = coop_error_list(T, ct, m32, key, sid, a, sink, *coop, lane);
                 else e = chain_error_list(T, ct, m32, key, sid, a, sink);
                 p.ev_off = ev_off + evn;
@@ -2435,7 +2435,8 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
             }
             HIPCHK(hipEventRecord(ctx->evt[3], st));
             uint32_t n_coop = 0;
-            if (a == 0 && ctx->coop_ok && prm->kind == NS_KIND_ALIGNED && cur_n >= ctx->coop_min) n_coop = cur_n >> ctx->coop_shift;   // longest 0.2 %
+            if (prm->kind == NS_KIND_UNALIGNED) n_coop = cur_n;          // every unaligned read: its loop is a prefix sum (coop_unaligned_error_list)
+            else if (a == 0 && ctx->coop_ok && prm->kind == NS_KIND_ALIGNED && cur_n >= ctx->coop_min) n_coop = cur_n >> ctx->coop_shift;   // longest 0.2 %
             if (n_coop) {      // wave-per-read for the head of the (length-sorted) list, thread-per-read for the rest
                 GenArgs B = A; B.list_n = n_coop;
                 HIPCHK(hipEventRecord(ctx->ev_fork, st));
@@ -2446,7 +2447,8 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
                 A.list = cur + n_coop; A.list_n = cur_n - n_coop;
             }
             const dim3 grid_c((A.list_n + NS_CHAIN_BLOCK - 1) / NS_CHAIN_BLOCK), blk_c(NS_CHAIN_BLOCK);
-            if (lds) k_chain<true, false><<<grid_c, blk_c, ctx->lds_bytes, st>>>(A);
+            if (!A.list_n) {}
+            else if (lds) k_chain<true, false><<<grid_c, blk_c, ctx->lds_bytes, st>>>(A);
             else k_chain<false, false><<<grid_c, blk_c, 0, st>>>(A);
             HIPCHK(hipGetLastError());
             if (n_coop) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));

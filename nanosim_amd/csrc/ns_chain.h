@@ -160,6 +160,82 @@ __device__ __forceinline__ EList32 chain_unaligned_error_list(const Tabs &T, con
     return EList32{l_new, middle_ref};
 }
 
+// ---- cooperative unaligned_error_list: one read (or gap) per wavefront, lane = loop iteration -------------------------
+// What iteration `it` of S:1797-1829 draws (type, run length) does not depend on the state of the loop, and the state is a running
+// sum: pos(it) = sum of the steps of the earlier non-insertion iterations, the loop runs while pos < m_ref.  So 64 iterations are
+// evaluated at once: wavefront prefix sums give the positions, the pending insertion lengths (consecutive insertion iterations in
+// front of a non-insertion one), the event slots and the cumulative shifts; the events come out exactly as
+// chain_unaligned_error_list produces them.  A 20 kb unaligned read is 20 000 dependent iterations for one thread (tens of
+// milliseconds: it set the duration of the whole batch) and ~320 blocks of a few hundred instructions here.
+__device__ inline EList32 coop_unaligned_error_list(const Tabs &T, const ChainTab &c, int32_t m_ref, const ns_key &key, uint32_t seg,
+                                                    uint32_t attempt, EvSink32 &s, uint32_t lane) {
+    int32_t l_new = m_ref, middle_ref = m_ref;
+    if (m_ref <= 0) return EList32{l_new, middle_ref};
+    uint32_t pos0 = 0, pend0 = 0;                                // position / pending insertion length in front of the block
+    for (uint32_t it0 = 0;; it0 += 64) {
+        const u32x4 w = ns_draw(key, ST_UEVENT, seg, attempt, it0 + lane, 0);
+        const double p = u32_to_p(w.x);
+        int type = (p < 0.4) ? 3 : (p < 0.7) ? NS_MIS : (p < 0.85) ? NS_INS : NS_DEL;                // S:1787
+        uint32_t step = 1;
+        if (type != 3) step = (uint32_t)run_length_t(T, c, type, w.y, w.z);
+        uint32_t adv = type == NS_INS ? 0u : step;
+        const uint32_t adv_all = wave_incl_scan(adv);
+        const bool exec = pos0 + adv_all - adv < (uint32_t)m_ref;                                // the loop is still running (a prefix of the lanes)
+        const uint32_t n_exec = (uint32_t)__popcll(__ballot(exec));
+        if (!exec) { adv = 0; step = 0; type = 3; }
+        const uint32_t adv_incl = wave_incl_scan(adv);
+        const uint32_t pos = pos0 + adv_incl - adv;
+        const uint32_t ins = (exec && type == NS_INS) ? step : 0u, del = (exec && type == NS_DEL) ? step : 0u;
+        const uint32_t ins_incl = wave_incl_scan(ins), del_incl = wave_incl_scan(del);
+        // pending insertion in front of a non-insertion iteration: the insertion steps since the previous non-insertion one
+        const bool nonins = exec && type != NS_INS;
+        const uint64_t NB = __ballot(nonins);
+        const uint64_t below = NB & ((1ull << lane) - 1ull);
+        const uint32_t prev_ins = (uint32_t)__shfl((int)ins_incl, below ? 63 - __clzll((long long)below) : (int)lane);
+        const uint32_t L = nonins ? (below ? ins_incl - prev_ins : pend0 + ins_incl) : 0u;
+        // the events of the iteration, at most three
+        uint32_t ty0 = 0, ty1 = 0, ty2 = 0, ln0 = 0, ln1 = 0, ln2 = 0, ps0 = pos, ps1 = pos + 1, ps2 = pos + 1, n_ev = 0;
+        if (nonins) {
+            if (type == 3) { if (L) { ty0 = NS_INS; ln0 = L; ps0 = pos + 1; n_ev = 1; } }
+            else if (type == NS_MIS) {
+                if (!L) { ty0 = NS_MIS; ln0 = step; n_ev = 1; }
+                else {
+                    ty0 = NS_MIS; ln0 = 1; ty1 = NS_INS; ln1 = L; n_ev = 2;
+                    if (step - 1 > L) { ty2 = NS_MIS; ln2 = step - 1 - L; n_ev = 3; }
+                }
+            } else {
+                if (!L) { ty0 = NS_DEL; ln0 = step; n_ev = 1; }
+                else {
+                    ty0 = NS_DEL; ln0 = step > L ? step - L : 1u; n_ev = 1;
+                    if (L > step - 1) { ty1 = NS_INS; ln1 = L - (step - 1); n_ev = 2; }
+                }
+            }
+        }
+        ln0 = min(ln0, NS_EV_LEN_MAX); ln1 = min(ln1, NS_EV_LEN_MAX); ln2 = min(ln2, NS_EV_LEN_MAX);
+        auto dsh = [](uint32_t ty, uint32_t ln) { return ty == NS_INS ? ln : ty == NS_DEL ? 0u - ln : 0u; };
+        const uint32_t d0 = n_ev > 0 ? dsh(ty0, ln0) : 0u, d1 = n_ev > 1 ? dsh(ty1, ln1) : 0u, d2 = n_ev > 2 ? dsh(ty2, ln2) : 0u;
+        const uint32_t dtot = d0 + d1 + d2;
+        const uint32_t n_incl = wave_incl_scan(n_ev), sh_incl = wave_incl_scan(dtot);
+        const uint32_t slot = s.n + n_incl - n_ev;
+        const uint32_t sh = (uint32_t)s.shift + sh_incl - dtot;
+        if (n_ev > 0) { if (slot < s.cap) { ns_event e; e.pos = ps0; e.info = ns_ev_pack(ln0, ty0, (int32_t)sh); s.ev[slot] = e; } }
+        if (n_ev > 1) { if (slot + 1 < s.cap) { ns_event e; e.pos = ps1; e.info = ns_ev_pack(ln1, ty1, (int32_t)(sh + d0)); s.ev[slot + 1] = e; } }
+        if (n_ev > 2) { if (slot + 2 < s.cap) { ns_event e; e.pos = ps2; e.info = ns_ev_pack(ln2, ty2, (int32_t)(sh + d0 + d1)); s.ev[slot + 2] = e; } }
+        const uint32_t n_blk = (uint32_t)__builtin_amdgcn_readlane((int)n_incl, 63);
+        if (s.n + n_blk > s.cap) s.overflow = true;
+        s.n += n_blk;
+        s.shift = (int32_t)((uint32_t)s.shift + (uint32_t)__builtin_amdgcn_readlane((int)sh_incl, 63));
+        const uint32_t ins_tot = (uint32_t)__builtin_amdgcn_readlane((int)ins_incl, 63);
+        l_new += (int32_t)ins_tot - (int32_t)(uint32_t)__builtin_amdgcn_readlane((int)del_incl, 63);     // S:1808-1815, 1820
+        // pending insertion behind the last non-insertion iteration of the block
+        pend0 = NB ? ins_tot - (uint32_t)__shfl((int)ins_incl, 63 - __clzll((long long)NB)) : pend0 + ins_tot;
+        pos0 += (uint32_t)__builtin_amdgcn_readlane((int)adv_incl, 63);
+        if (n_exec < 64 || pos0 >= (uint32_t)m_ref) break;
+    }
+    if ((int32_t)pos0 > middle_ref) { l_new += (int32_t)pos0 - middle_ref; middle_ref = (int32_t)pos0; }      // S:1826-1828
+    return EList32{l_new, middle_ref};
+}
+
 // ---- cooperative error_list: one read per wavefront, for the few longest reads of a batch ---------------------
 // The chain is sequential, but what an iteration draws depends on very little state: the error type on the Markov
 // state (7 rows), the run length on the error type (3), the next match length on the bin of the previous match
