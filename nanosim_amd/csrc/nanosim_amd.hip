@@ -679,6 +679,25 @@ __global__ void __launch_bounds__(64, FASTQ ? 4 : NS_MAT_WAVES) k_materialise(Ge
     }
 }
 
+// Unaligned reads (S:1482-1549): ~0.55 events per base.  The tiled kernel ends a tile after 63 events — every ~110 bases here, twenty
+// prologues per read — so these reads take the per-byte path: a lane finds the event in force at its 16 bases with a binary search
+// and walks the events from there (12x fewer instructions per read at this density).
+template <bool FASTQ>
+__global__ void __launch_bounds__(64) k_materialise_dense(GenArgs A) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t r = blockIdx.x;
+    ns_read rd; ns_key key; ReadOut ro;
+    if (!load_read_uniform(A, r, FASTQ, rd, key, ro)) return;
+    const uint32_t a = rd.attempts;
+    emit_head_tail(A.m, ro, key, a, rd.head, rd.tail, lane);
+    uint32_t q = rd.head;
+    for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
+        const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi);
+        slow_piece_range(A.m, A.ref, ro, key, a, pc, q, 0, pc.out_len, lane);
+        q += pc.out_len;
+    }
+}
+
 // the tiles k_materialise could not take: generic per-byte path, one wavefront per queued tile
 template <bool FASTQ>
 __global__ void __launch_bounds__(64) k_materialise_slow(GenArgs A, SlowQueue sq) {
@@ -1828,6 +1847,13 @@ static int scan_u32(ns_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n) {
 // copy phase, slow tiles, payload: the three kernels that write the sequence (and quality) lines of a batch
 static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fastq, uint64_t event_slots, hipEvent_t names_done = nullptr) {
     hipStream_t st = ctx->stream;
+    if (A.prm.kind == NS_KIND_UNALIGNED) {
+        if (names_done) HIPCHK(hipStreamWaitEvent(st, names_done, 0));
+        if (fastq) k_materialise_dense<true><<<dim3((unsigned)n), dim3(64), 0, st>>>(A);
+        else k_materialise_dense<false><<<dim3((unsigned)n), dim3(64), 0, st>>>(A);
+        HIPCHK(hipGetLastError());
+        return NS_OK;
+    }
     {
         int rc = ensure(ctx, ctx->ev_word, ((size_t)event_slots + 8) * 4);
         if (rc) return rc;
