@@ -56,6 +56,8 @@ CASES = [
     dict(kind=E.NS_KIND_ALIGNED, n_reads=150, min_len=3000, max_len=9000),            # rejections + epochs
     dict(kind=E.NS_KIND_ALIGNED, n_reads=150, median_len=5000, sd_len=0.4),            # -med/-sd
     dict(kind=E.NS_KIND_UNALIGNED, n_reads=100, median_len=800, sd_len=0.5),
+    dict(kind=E.NS_KIND_UNALIGNED, n_reads=24, median_len=20000, sd_len=0.3, fastq=True),          # hundreds of 64-iteration blocks per read
+    dict(kind=E.NS_KIND_UNALIGNED, n_reads=300, median_len=60, sd_len=0.6, min_len=1),              # reads shorter than one block
     dict(kind=E.NS_KIND_ALIGNED, n_reads=1, first_read=(1 << 33) + 5, emit_errlog=True),
     dict(kind=E.NS_KIND_ALIGNED, n_reads=0),
     dict(kind=E.NS_KIND_ALIGNED, n_reads=200, kmer_bias=5, emit_errlog=True),                      # -hp -k 5
@@ -77,7 +79,8 @@ def test_gpu_equals_oracle(eng, small_model, small_ref, case):
     if p.n_reads == 0:
         assert b.info.record_bytes == 0
         return
-    exp = O.generate(small_model, small_ref, p)
+    big = p.use_lognormal and p.median_len >= 10000
+    exp = O.generate(small_model, small_ref, p, bytes_per_read=400000 if big else 40000, events_per_read=60000 if big else 4000)
     compare(b, exp, p)
 
 
