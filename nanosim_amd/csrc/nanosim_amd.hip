@@ -1393,7 +1393,11 @@ __global__ void __launch_bounds__(64 * NS_WPB) k_errlog(GenArgs A) {
             const uint32_t total = __shfl(incl, 63);
             if (active) {
                 uint8_t *q = A.errlog + base + (incl - row);
-                for (uint32_t i = 0; i < nl; ++i) *q++ = name[i];
+                if (nl >= 16) {                                          // the read name, 16 bytes at a time (the last chunk overlaps)
+                    for (uint32_t i = 0; i + 16 <= nl; i += 16) { uint4 v; __builtin_memcpy(&v, name + i, 16); __builtin_memcpy(q + i, &v, 16); }
+                    if (nl & 15u) { uint4 v; __builtin_memcpy(&v, name + nl - 16, 16); __builtin_memcpy(q + nl - 16, &v, 16); }
+                } else for (uint32_t i = 0; i < nl; ++i) q[i] = name[i];
+                q += nl;
                 *q++ = '\t'; q = put_dec(q, e.pos); *q++ = '\t';
                 const char *tn = ty == NS_MIS ? "mis" : ty == NS_INS ? "ins" : "del";
                 *q++ = (uint8_t)tn[0]; *q++ = (uint8_t)tn[1]; *q++ = (uint8_t)tn[2];
