@@ -5,7 +5,7 @@
 TAG=${1:-r01}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG
 mkdir -p $O; cd /tmp; export TMPDIR=/tmp; ulimit -c 0
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-genome-run > $O/bench_under_rocprof.log 2>&1
 timeout 300 python $R/bench.py --steps 5 --warmup 2 > $O/bench.log 2>&1
 B="python $R/bench.py --steps 1 --warmup 1 --reads 200000 --no-cpu-baseline"
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- $B > /dev/null 2>&1
