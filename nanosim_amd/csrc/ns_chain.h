@@ -172,12 +172,18 @@ __device__ inline EList32 coop_unaligned_error_list(const Tabs &T, const ChainTa
     int32_t l_new = m_ref, middle_ref = m_ref;
     if (m_ref <= 0) return EList32{l_new, middle_ref};
     uint32_t pos0 = 0, pend0 = 0;                                // position / pending insertion length in front of the block
-    for (uint32_t it0 = 0;; it0 += 64) {
-        const u32x4 w = ns_draw(key, ST_UEVENT, seg, attempt, it0 + lane, 0);
+    auto draw = [&](uint32_t it, int &type, uint32_t &step) {    // what iteration `it` does (S:1787, 1799-1818)
+        const u32x4 w = ns_draw(key, ST_UEVENT, seg, attempt, it, 0);
         const double p = u32_to_p(w.x);
-        int type = (p < 0.4) ? 3 : (p < 0.7) ? NS_MIS : (p < 0.85) ? NS_INS : NS_DEL;                // S:1787
-        uint32_t step = 1;
+        type = (p < 0.4) ? 3 : (p < 0.7) ? NS_MIS : (p < 0.85) ? NS_INS : NS_DEL;
+        step = 1;
         if (type != 3) step = (uint32_t)run_length_t(T, c, type, w.y, w.z);
+    };
+    int type_n; uint32_t step_n;
+    draw(lane, type_n, step_n);
+    for (uint32_t it0 = 0;; it0 += 64) {
+        int type = type_n; uint32_t step = step_n;
+        draw(it0 + 64 + lane, type_n, step_n);                   // the next block's draws and table reads run under this block's prefix sums
         uint32_t adv = type == NS_INS ? 0u : step;
         const uint32_t adv_all = wave_incl_scan(adv);
         const bool exec = pos0 + adv_all - adv < (uint32_t)m_ref;                                // the loop is still running (a prefix of the lanes)
