@@ -69,6 +69,7 @@ struct GenArgs {
     uint32_t *att_base;              // per read: first attempt number of this run (0 unless the batch is re-run in -k mode)
     uint32_t keep_state;             // k_nseg keeps rstate/att_base (re-run after a failed final length check)
     uint32_t hp;                     // -k active for this batch
+    uint32_t errlen_later;           // the error-profile size of a read is computed by k_errlen / k_hp_filter_w, not by k_chain
     uint8_t *scr, *scrq;             // -k: pre-homopolymer reads (forward strand) and their quality characters
     uint64_t *scr_len, *scr_off;
     uint32_t *hp_len;                // -k: final emitted length per piece
@@ -382,7 +383,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
             if (kind == NS_KIND_ALIGNED && n_pieces > 1) nl += 9;
             nl += 2 /*_F*/ + 1 + dec_digits(rd.head) + 1 + 1 + dec_digits(rd.tail + polya);       // S:1211-1213: tail + polya_len
             uint64_t err_len = 0;
-            if (prm.emit_errlog) {
+            if (prm.emit_errlog && !A.errlen_later) {
                 for (uint32_t pi = 0; pi < n_pieces; ++pi) {
                     ns_piece p = pc[pi];
                     if (p.kind) continue;
@@ -1357,6 +1358,30 @@ __global__ void __launch_bounds__(64 * NS_WPB, NS_HPW_WAVES) k_hp_write_w(GenArg
     }
     if (A.polya) { const uint32_t pl = A.polya[r]; copy_plain(q_in, q_out, pl); q_in += pl; q_out += pl; }     // polyA tail (S:1224-1225)
     copy_plain(q_in, q_out, rd.tail);
+}
+
+// size of a read's error-profile rows (what k_errlog will write), one read per wavefront, lane per event.  (As a loop over the events
+// inside the thread-per-read chain kernel this cost 4.4 ms per 10^6 reads: every thread walked its own list.)
+__global__ void __launch_bounds__(64 * NS_WPB) k_errlen(GenArgs A) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= A.prm.n_reads) return;
+    const ns_read rd = A.reads[r];
+    unsigned long long sum = 0;
+    if (!rd.flags) {
+        const uint32_t nl = A.name_len[r];
+        for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
+            const ns_piece p = A.pieces[rd.piece_off + pi];
+            if (p.kind) continue;                                    // gaps and unaligned reads have no rows (S:1556, 1501)
+            const ns_event *ev = A.events + p.ev_off;
+            for (uint32_t j = lane; j < p.n_ev; j += 64) {
+                const ns_event e = ev[j];
+                sum += nl + dec_digits(e.pos) + dec_digits(ns_ev_len(e.info)) + 2u * ns_ev_len(e.info) + 9u;
+            }
+        }
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) A.err_len[r] = sum;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2378,6 +2403,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     A.rstate = (uint32_t *)ctx->rstate.p; A.att_base = (uint32_t *)ctx->att_base.p;
     A.scr_len = (uint64_t *)ctx->scr_len.p; A.scr_off = (uint64_t *)ctx->scr_off.p;
     A.hp = hp_on ? 1u : 0u; A.keep_state = 0;
+    A.errlen_later = (prm->emit_errlog && !meta_al) ? 1u : 0u;
     if (prm->trx) {
         if ((rc = ensure(ctx, ctx->polya, (n + 1) * 2))) return rc;
         A.tx = ctx->tx; A.polya = (uint16_t *)ctx->polya.p;
@@ -2522,6 +2548,10 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     // its accepted attempt, so re-running the batch reproduces them bit for bit
     if (hp_round >= (int)NS_MAX_ATTEMPT) return fail(ctx, NS_EINVAL, "reads keep failing the final length check in -k mode");
     A.keep_state = 1;
+    }
+    if (A.errlen_later && !A.hp) {           // (-k: k_hp_filter_w has computed the sizes of the rows that survive the filter)
+        k_errlen<<<dim3((unsigned)((n + NS_WPB - 1) / NS_WPB)), dim3(64 * NS_WPB), 0, st>>>(A);
+        HIPCHK(hipGetLastError());
     }
     if ((rc = scan_u64(ctx, A.rec_len, A.rec_off, n + 1))) return rc;
     if (prm->emit_errlog && (rc = scan_u64(ctx, A.err_len, A.err_off, n + 1))) return rc;
