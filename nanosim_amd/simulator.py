@@ -152,8 +152,8 @@ class StreamWriter:
     (ns_host_alloc) while a small pool of threads writes the previous slices at their file offsets (os.pwrite releases the GIL)."""
     SLICE = int(os.environ.get("NS_WRITER_SLICE_MB", "64")) << 20
     DEPTH = int(os.environ.get("NS_WRITER_DEPTH", "6"))
-    THREADS = int(os.environ.get("NS_WRITER_THREADS", "8"))      # more does not help: writes to ONE file serialise on its inode lock
-                                                                 # (tmpfs: ~2.5 GB/s per file; measured with 24-48 threads and 32-64 slices)
+    THREADS = int(os.environ.get("NS_WRITER_THREADS", "8"))      # measured no faster: 24-48 threads with 32-64 slices in flight, and
+                                                                 # copies into shared mappings of the file ranges instead of pwrite
 
     def __init__(self, eng):
         import queue
