@@ -14,6 +14,7 @@ from __future__ import annotations
 import argparse
 import os
 import sys
+import time
 from textwrap import dedent
 from time import strftime
 
@@ -152,8 +153,12 @@ class StreamWriter:
     (ns_host_alloc) while a small pool of threads writes the previous slices at their file offsets (os.pwrite releases the GIL)."""
     SLICE = int(os.environ.get("NS_WRITER_SLICE_MB", "64")) << 20
     DEPTH = int(os.environ.get("NS_WRITER_DEPTH", "6"))
-    THREADS = int(os.environ.get("NS_WRITER_THREADS", "8"))      # measured no faster: 24-48 threads with 32-64 slices in flight, and
-                                                                 # copies into shared mappings of the file ranges instead of pwrite
+    THREADS = int(os.environ.get("NS_WRITER_THREADS", "8"))
+    # NS_CLI_TRACE shows the main thread waiting for a free staging buffer 90 % of the time: the file writes are the limit
+    # (≈5 GB/s on tmpfs; pwrite()s to one file serialise on its inode lock).  NS_WRITER_MMAP=1 copies into shared mappings of the
+    # file ranges instead (memmove without the GIL, file grown with ftruncate first): 8.6 s instead of 10.1-11.1 s for 48 GB, but a
+    # full file system then ends in SIGBUS instead of ENOSPC, so it is opt-in.  More threads / slices in flight measured slower.
+    MMAP = os.environ.get("NS_WRITER_MMAP", "0") != "0"
 
     def __init__(self, eng):
         import queue
@@ -162,6 +167,7 @@ class StreamWriter:
         self.free = queue.Queue()
         self.jobs = queue.Queue()
         self.err = []
+        self.t_wait = self.t_copy = 0.0                  # time spent waiting for a free staging buffer / in the device-to-host copies
         for _ in range(self.DEPTH):
             self.free.put(eng.pinned(self.SLICE))
         self.threads = [threading.Thread(target=self._work, daemon=True) for _ in range(self.THREADS)]
@@ -175,6 +181,8 @@ class StreamWriter:
                 return
             fd, off, buf, n = job
             try:
+                if self.MMAP and self._copy_mapped(fd, off, buf, n):
+                    continue
                 mv = memoryview(buf)[:n]
                 done = 0
                 while done < n:
@@ -185,13 +193,39 @@ class StreamWriter:
                 self.free.put(buf)
                 self.jobs.task_done()
 
+    @staticmethod
+    def _copy_mapped(fd, off, buf, n):
+        import ctypes
+        import mmap
+        a0 = off - off % mmap.ALLOCATIONGRANULARITY
+        try:
+            mm = mmap.mmap(fd, n + off - a0, flags=mmap.MAP_SHARED, prot=mmap.PROT_READ | mmap.PROT_WRITE, offset=a0)
+        except (OSError, ValueError):                    # descriptor not readable, not a mappable file: pwrite
+            return False
+        try:
+            dst = ctypes.c_char.from_buffer(mm, off - a0)
+            ctypes.memmove(ctypes.addressof(dst), buf.ctypes.data, n)
+            del dst
+        finally:
+            mm.close()
+        return True
+
     def stream(self, batch, which, nbytes, fd, file_off):
         """append bytes [0, nbytes) of result buffer `which` of `batch` to fd at file_off"""
+        if self.MMAP and nbytes:                          # the mapped copies need the file to reach the end of this buffer
+            try:
+                if os.fstat(fd).st_size < file_off + nbytes:
+                    os.ftruncate(fd, file_off + nbytes)
+            except OSError:
+                pass
         pos = 0
         while pos < nbytes:
             n = min(self.SLICE, nbytes - pos)
+            t0 = time.perf_counter()
             buf = self.free.get()
+            t1 = time.perf_counter()
             batch.copy_range(which, pos, buf, n)
+            self.t_wait += t1 - t0; self.t_copy += time.perf_counter() - t1
             self.jobs.put((fd, file_off + pos, buf, n))
             pos += n
         return file_off + nbytes
@@ -212,11 +246,12 @@ class StreamWriter:
 def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, chimeric, min_len, max_len, median_len,
                    sd_len, want_errlog, kmer_bias=0, meta=False, err_header=b"", trx=False, uracil=False, model_ir=False):
     done = 0
+    trace = os.environ.get("NS_CLI_TRACE") is not None       # per-batch host timing on stderr
     w = getattr(eng, "_stream_writer", None)           # one writer (staging buffers + threads) per engine
     if w is None:
         w = eng._stream_writer = StreamWriter(eng)
-    fr = os.open(out_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
-    fe = os.open(err_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644) if err_path else None
+    fr = os.open(out_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)             # (read access: the writer maps the file ranges)
+    fe = os.open(err_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644) if err_path else None
     off_r = off_e = 0
     if fe is not None and err_header:                  # rank 0 opens the error profile with the column header (S:1634)
         os.pwrite(fe, err_header, 0)
@@ -228,6 +263,7 @@ def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, 
             p = E.make_params(seed=seed, first_read=first + done, n_reads=n, kind=kind, fastq=fastq, chimeric=chimeric, kmer_bias=kmer_bias,
                               min_len=min_len, max_len=max_len, median_len=median_len, sd_len=sd_len,
                               emit_records=True, emit_errlog=fe is not None, meta=meta, trx=trx, uracil=uracil, model_ir=model_ir)
+            t0 = time.perf_counter()
             try:
                 b = eng.generate(p)
             except E.EngineError as ex:              # not enough free HBM for this batch size (shared GPU): halve it and go on
@@ -235,9 +271,16 @@ def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, 
                     raise
                 batch = eng._batch_reads = max(1000, n // 2)
                 continue
+            t1 = time.perf_counter()
             off_r = w.stream(b, E.NS_BUF_RECORDS, int(b.info.record_bytes), fr, off_r)
             if fe is not None:
                 off_e = w.stream(b, E.NS_BUF_ERRLOG, int(b.info.errlog_bytes), fe, off_e)
+            if trace:
+                t2 = time.perf_counter()
+                sys.stderr.write("[cli] batch %d reads: generate %.1f ms (device %.1f), stream %.1f ms for %.2f GB (copy %.1f ms, waiting for a staging buffer %.1f ms)\n"
+                                 % (n, (t1 - t0) * 1e3, b.info.ms_total, (t2 - t1) * 1e3, (int(b.info.record_bytes) + int(b.info.errlog_bytes)) / 1e9,
+                                    w.t_copy * 1e3, w.t_wait * 1e3))
+                w.t_copy = w.t_wait = 0.0
             done += n
             sys.stdout.write(strftime("%Y-%m-%d %H:%M:%S") + ": Number of reads simulated >> " + str(first + done) + "\r")
             sys.stdout.flush()

@@ -136,7 +136,8 @@ def test_coverage_read_count(small_ref):
     assert n == int(small_ref.genome_len / mean * 30.0)
 
 
-def test_stream_writer_pipelines_slices_in_order(tmp_path):
+@pytest.mark.parametrize("mapped", [True, False])
+def test_stream_writer_pipelines_slices_in_order(tmp_path, mapped):
     """simulator.StreamWriter with a stand-in engine: many slices per buffer, fewer staging buffers than slices, several writer
     threads, two files interleaved — the files are the buffers, byte for byte."""
     rng = np.random.default_rng(3)
@@ -155,10 +156,11 @@ def test_stream_writer_pipelines_slices_in_order(tmp_path):
         SLICE = 64 << 10
         DEPTH = 3
         THREADS = 4
+        MMAP = mapped
 
     w = SmallWriter(FakeEngine())
-    f0 = os.open(tmp_path / "a.bin", os.O_WRONLY | os.O_CREAT, 0o644)
-    f1 = os.open(tmp_path / "b.bin", os.O_WRONLY | os.O_CREAT, 0o644)
+    f0 = os.open(tmp_path / "a.bin", os.O_RDWR | os.O_CREAT, 0o644)
+    f1 = os.open(tmp_path / "b.bin", (os.O_RDWR if mapped else os.O_WRONLY) | os.O_CREAT, 0o644)
     try:
         os.pwrite(f1, b"HEADER\n", 0)
         o0 = o1 = 0
