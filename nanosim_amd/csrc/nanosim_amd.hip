@@ -1387,7 +1387,9 @@ __global__ void __launch_bounds__(64 * NS_WPB) k_errlen(GenArgs A) {
 // ---------------------------------------------------------------------------------------------------------
 // k_errlog: error-profile rows "name\tpos\ttype\tlen\tref\tnew\n" in descending position order (S:1960, 2006-2008)
 // ---------------------------------------------------------------------------------------------------------
+#define NS_ERR_STAGE 48u          // bytes of a row behind the read name that are staged in LDS (rows with longer payloads: straight to memory)
 __global__ void __launch_bounds__(64 * NS_WPB) k_errlog(GenArgs A) {
+    __shared__ __align__(16) uint8_t stage_lds[NS_WPB][64][NS_ERR_STAGE];
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= A.prm.n_reads) return;
@@ -1397,6 +1399,7 @@ __global__ void __launch_bounds__(64 * NS_WPB) k_errlog(GenArgs A) {
     const uint32_t a = rd.attempts;
     const uint32_t nl = A.name_len[r];
     const uint8_t *name = A.records + rd.rec_off + 1;
+    uint8_t *const stage = stage_lds[threadIdx.x >> 6][lane];
     uint64_t base = A.err_off[r];
     for (uint32_t pi = 0; pi < rd.n_pieces; pi += 2) {
         const ns_piece p = A.pieces[rd.piece_off + pi];
@@ -1408,14 +1411,10 @@ __global__ void __launch_bounds__(64 * NS_WPB) k_errlog(GenArgs A) {
             ns_event e; e.pos = 0; e.info = 0;
             if (active) e = pc.ev[p.n_ev - 1 - k];
             const uint32_t len = ns_ev_len(e.info), ty = ns_ev_type(e.info);
-            uint32_t row = active ? nl + dec_digits(e.pos) + dec_digits(len) + 2u * len + 9u : 0;
-            // exclusive prefix sum over the wavefront
-            uint32_t incl = row;
-            for (int off = 1; off < 64; off <<= 1) {
-                uint32_t v = __shfl_up(incl, off);
-                if ((int)lane >= off) incl += v;
-            }
-            const uint32_t total = __shfl(incl, 63);
+            const uint32_t tail = dec_digits(e.pos) + dec_digits(len) + 2u * len + 9u;      // "\t<pos>\t<type>\t<len>\t<ref>\t<new>\n"
+            const uint32_t row = active ? nl + tail : 0;
+            const uint32_t incl = wave_incl_scan(row);                                      // row offsets: prefix sum over the wavefront
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             if (active) {
                 uint8_t *q = A.errlog + base + (incl - row);
                 if (nl >= 16) {                                          // the read name, 16 bytes at a time (the last chunk overlaps)
@@ -1423,22 +1422,33 @@ __global__ void __launch_bounds__(64 * NS_WPB) k_errlog(GenArgs A) {
                     if (nl & 15u) { uint4 v; __builtin_memcpy(&v, name + nl - 16, 16); __builtin_memcpy(q + nl - 16, &v, 16); }
                 } else for (uint32_t i = 0; i < nl; ++i) q[i] = name[i];
                 q += nl;
-                *q++ = '\t'; q = put_dec(q, e.pos); *q++ = '\t';
-                const char *tn = ty == NS_MIS ? "mis" : ty == NS_INS ? "ins" : "del";
-                *q++ = (uint8_t)tn[0]; *q++ = (uint8_t)tn[1]; *q++ = (uint8_t)tn[2];
-                *q++ = '\t'; q = put_dec(q, len); *q++ = '\t';
-                uint8_t *q2 = q + len + 1;
-                for (uint32_t i = 0; i < len; ++i) {
-                    if (ty == NS_INS) { q[i] = '-'; q2[i] = ins_letter(key, pc.sid, a, p.n_ev - 1 - k, i); }
-                    else {
-                        uint32_t x = e.pos + i;
-                        uint8_t cur = resolve_base(ref_base_at(A.ref, pc, x), key, pc.sid, a, x);
-                        q[i] = cur;
-                        q2[i] = (ty == NS_MIS) ? mis_letter(cur, key, pc.sid, a, p.n_ev - 1 - k, i) : (uint8_t)'-';
+                auto fields = [&](uint8_t *w) {                          // the rest of the row at w
+                    *w++ = '\t'; w = put_dec(w, e.pos); *w++ = '\t';
+                    const char *tn = ty == NS_MIS ? "mis" : ty == NS_INS ? "ins" : "del";
+                    *w++ = (uint8_t)tn[0]; *w++ = (uint8_t)tn[1]; *w++ = (uint8_t)tn[2];
+                    *w++ = '\t'; w = put_dec(w, len); *w++ = '\t';
+                    uint8_t *w2 = w + len + 1;
+                    for (uint32_t i = 0; i < len; ++i) {
+                        if (ty == NS_INS) { w[i] = '-'; w2[i] = ins_letter(key, pc.sid, a, p.n_ev - 1 - k, i); }
+                        else {
+                            uint32_t x = e.pos + i;
+                            uint8_t cur = resolve_base(ref_base_at(A.ref, pc, x), key, pc.sid, a, x);
+                            w[i] = cur;
+                            w2[i] = (ty == NS_MIS) ? mis_letter(cur, key, pc.sid, a, p.n_ev - 1 - k, i) : (uint8_t)'-';
+                        }
                     }
-                }
-                q[len] = '\t';
-                q2[len] = '\n';
+                    w[len] = '\t';
+                    w2[len] = '\n';
+                };
+                if (tail <= NS_ERR_STAGE) {                              // assembled in LDS, then two or three wide stores instead of ~25 byte stores
+                    fields(stage);
+                    uint32_t i = 0;
+                    for (; i + 16 <= tail; i += 16) { const uint4 v = *reinterpret_cast<const uint4 *>(stage + i); __builtin_memcpy(q + i, &v, 16); }
+                    if (tail & 15u) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(stage + i);
+                        store16(q + i, tail & 15u, (uint64_t)v.x | (uint64_t)v.y << 32, (uint64_t)v.z | (uint64_t)v.w << 32);
+                    }
+                } else fields(q);
             }
             base += total;
         }
