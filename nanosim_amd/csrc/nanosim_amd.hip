@@ -2323,6 +2323,11 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
             if ((rc = hp_stage1(ctx, prm, H, np, tot_pieces, ev_base + pass_cap, stats, &ms_hp))) return rc;
             info->ms_kernel[NS_K_HP] += ms_hp;
             stats[5] = 0;
+        } else if (prm->emit_errlog) {     // sizes of the error-profile rows of the reads this pass accepted (k_meta_commit adds the read numbers)
+            GenArgs H = P;
+            H.prm.n_reads = np;
+            k_errlen<<<dim3((unsigned)((np + NS_WPB - 1) / NS_WPB)), dim3(64 * NS_WPB), 0, st>>>(H);
+            HIPCHK(hipGetLastError());
         }
         memcpy(good_stats, stats, sizeof good_stats);
         if ((rc = scan_u64(ctx, P.accept, P.accept_scan, np + 1))) return rc;
@@ -2413,7 +2418,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     A.rstate = (uint32_t *)ctx->rstate.p; A.att_base = (uint32_t *)ctx->att_base.p;
     A.scr_len = (uint64_t *)ctx->scr_len.p; A.scr_off = (uint64_t *)ctx->scr_off.p;
     A.hp = hp_on ? 1u : 0u; A.keep_state = 0;
-    A.errlen_later = (prm->emit_errlog && !meta_al) ? 1u : 0u;
+    A.errlen_later = prm->emit_errlog ? 1u : 0u;
     if (prm->trx) {
         if ((rc = ensure(ctx, ctx->polya, (n + 1) * 2))) return rc;
         A.tx = ctx->tx; A.polya = (uint16_t *)ctx->polya.p;
@@ -2559,7 +2564,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     if (hp_round >= (int)NS_MAX_ATTEMPT) return fail(ctx, NS_EINVAL, "reads keep failing the final length check in -k mode");
     A.keep_state = 1;
     }
-    if (A.errlen_later && !A.hp) {           // (-k: k_hp_filter_w has computed the sizes of the rows that survive the filter)
+    if (A.errlen_later && !A.hp && !meta_al) {   // (-k: k_hp_filter_w has computed the sizes of the rows that survive the filter; metagenome: per pass)
         k_errlen<<<dim3((unsigned)((n + NS_WPB - 1) / NS_WPB)), dim3(64 * NS_WPB), 0, st>>>(A);
         HIPCHK(hipGetLastError());
     }
