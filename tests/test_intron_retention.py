@@ -199,3 +199,35 @@ def test_oracle_ir_batch(trx_ref, ir, fastq, kmer):
             r1 = base["records"][a1:a1 + ln + 200].tobytes().split(b"\n")[1]
             same += r0 == r1
     assert same > 30
+
+
+def test_chromosome_naming_follows_the_worker(tmp_path):
+    """S:448-449 strips the characters c, h, r from both ends of the GFF3 chromosome; S:1066-1070, 1164-1166 put "chr" back in front
+    iff some chromosome of the genome FASTA has it; S:1167-1169: a chromosome the FASTA lacks is skipped at run time"""
+    tr = M.Reference(["T1", "T2", "T3"], np.frombuffer(b"ACGTACGTAC" * 3, dtype=np.uint8).copy(),
+                     np.array([0, 10, 20, 30], dtype=np.uint64), np.zeros(3, dtype=np.uint8))
+    gff = tmp_path / "m_added_intron_final.gff3"
+    gff.write_text("chr1\tx\texon\t1\t10\t.\t+\t.\ttranscript_id=T1.1\n"
+                   "2\tx\texon\t1\t4\t.\t-\t.\ttranscript_id=T2\n"
+                   "2\tx\tintron\t5\t8\t.\t-\t.\ttranscript_id=T2\n"
+                   "2\tx\texon\t9\t14\t.\t-\t.\ttranscript_id=T2\n"
+                   "chrM\tx\texon\t1\t10\t.\t+\t.\ttranscript_id=T3\n")
+    (tmp_path / "m_IR_markov_model").write_text("state\tno_IR\tIR\nstart\t0.5\t0.5\nno_IR\t0.9\t0.1\nIR\t0.2\t0.8\n")
+    for names, exp in ((["chr1 first", "chr2 second"], [0, 1, 1, 1, IR.NS_IR_NO_CHROM]),        # FASTA with "chr": GFF "2" -> "chr2"
+                       (["1", "2"], [0, 1, 1, 1, IR.NS_IR_NO_CHROM])):                          # FASTA without: GFF "chr1" -> "1"
+        fa = tmp_path / "g.fa"
+        fa.write_text("".join(">%s\n%s\n" % (nm, "ACGT" * 10) for nm in names))
+        ir = IR.load(str(tmp_path / "m"), str(fa), tr)
+        assert ir.genome.names == [nm.split()[0] for nm in names]
+        assert list(ir.item_chrom) == exp
+        assert list(ir.item_start) == [0, 0, 4, 8, 0] and list(ir.item_len) == [10, 4, 4, 6, 10]
+        assert list(ir.item_minus) == [0, 1, 1, 1, 0] and list(ir.item_type) == [0, 0, 1, 0, 0]
+        assert list(ir.eligible) == [True, True, True]        # exon sums 10, 4 + 6, 10 (T3 is annotated; its chromosome is only missed at run time)
+        assert ir.p_no_ir == [0.5, 0.9, 0.2] and ir.p_ir == [0.5, 0.1, 0.8]
+    # a feature that reaches beyond its chromosome counts as missing (pysam would hand back a shorter string)
+    fa = tmp_path / "short.fa"
+    fa.write_text(">1\nACGTAC\n>2\n" + "ACGT" * 10 + "\n")
+    assert IR.load(str(tmp_path / "m"), str(fa), tr).item_chrom[0] == IR.NS_IR_NO_CHROM
+    with pytest.raises(SystemExit):                           # a Markov model without the IR row
+        (tmp_path / "m_IR_markov_model").write_text("state\tno_IR\tIR\nstart\t0.5\t0.5\nno_IR\t0.9\t0.1\n")
+        IR.load(str(tmp_path / "m"), str(fa), tr)
