@@ -69,6 +69,7 @@ struct GenArgs {
     uint32_t *att_base;              // per read: first attempt number of this run (0 unless the batch is re-run in -k mode)
     uint32_t keep_state;             // k_nseg keeps rstate/att_base (re-run after a failed final length check)
     uint32_t hp;                     // -k active for this batch
+    uint32_t dbg;                    // NS_DEBUG_SKIP (profiling only)
     uint32_t errlen_later;           // the error-profile size of a read is computed by k_errlen / k_hp_filter_w, not by k_chain
     uint8_t *scr, *scrq;             // -k: pre-homopolymer reads (forward strand) and their quality characters
     uint64_t *scr_len, *scr_off;
@@ -655,23 +656,35 @@ __global__ void __launch_bounds__(64) k_words(GenArgs A, uint32_t *ev_word) {
     }
 }
 
-// k_materialise: the sequence (and quality) line of one read per wavefront; see ns_materialise.h
+// k_materialise: the sequence (and quality) line of one read per wavefront; see ns_materialise.h.  The FASTQ kernel runs NS_MATQ_WAVES
+// reads per workgroup, which share the LDS copy of the quality bucket tables (reads of similar length: `order` is the batch's
+// length-sorted visiting list, so no wavefront idles long behind its workgroup's longest read).
+#ifndef NS_MATQ_WAVES
+#define NS_MATQ_WAVES 4
+#endif
 template <bool FASTQ>
-__global__ void __launch_bounds__(64, FASTQ ? 4 : NS_MAT_WAVES) k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq) {
-    __shared__ TileLds T;
-    uint8_t *hq = nullptr;
-    if constexpr (FASTQ) { __shared__ __align__(16) uint8_t hq_slots[NS_HQ_LDS]; hq = hq_slots; }   // quality draws of a chunk, per lane
-    const uint32_t lane = threadIdx.x;
-    const uint64_t r = blockIdx.x;
+__global__ void __launch_bounds__(FASTQ ? 64 * NS_MATQ_WAVES : 64, FASTQ ? 4 : NS_MAT_WAVES)
+k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, const uint32_t *order) {
+    constexpr uint32_t WAVES = FASTQ ? NS_MATQ_WAVES : 1;
+    __shared__ TileLds Ts[WAVES];
+    __shared__ __align__(16) uint16_t qlut[FASTQ ? NS_QLUT_SLOTS * 1024u : 8u];
+    if constexpr (FASTQ) { qual_lut_load(qlut, A.m, threadIdx.x, 64 * WAVES); __syncthreads(); }
+    const uint32_t wave = WAVES > 1 ? threadIdx.x >> 6 : 0u;
+    TileLds &T = Ts[wave];
+    const uint32_t lane = WAVES > 1 ? threadIdx.x & 63u : threadIdx.x;
+    const uint64_t slot = (uint64_t)blockIdx.x * WAVES + wave;
+    if (slot >= A.prm.n_reads) return;
+    const uint64_t r = order ? (uint64_t)uni(order[slot]) : slot;
     ns_read rd; ns_key key; ReadOut ro;
     if (!load_read_uniform(A, r, FASTQ, rd, key, ro)) return;
     const uint32_t a = rd.attempts;
     tile_lds_init(T, lane);
+    QualState Q; Q.lut = qlut; qual_state_reset(Q);
     if (!(dbg & 8)) emit_head_tail(A.m, ro, key, a, rd.head, rd.tail, lane);                                             // S:1426-1427
     uint32_t q = rd.head;
     for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
         const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi, ev_word);
-        materialise_piece(A.m, A.ref, T, ro, key, a, pc, q, lane, ev_word, dbg, sq, (uint32_t)r, pi, hq);
+        materialise_piece<FASTQ, MAT_REF>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, Q);
         q += pc.out_len;
     }
     if (A.polya) {                                                                          // transcriptome: polyA tail (S:1224-1225)
@@ -1269,7 +1282,7 @@ __global__ void __launch_bounds__(64 * NS_WPB, NS_HPW_WAVES) k_hp_write_w(GenArg
                 const uint32_t s0 = c + b, e = higher ? c + (uint32_t)__builtin_ctz(higher) : t.next_start;
                 const uint32_t wv = b < 8 ? (b < 4 ? t.v.x : t.v.y) : (b < 12 ? t.v.z : t.v.w);
                 const uint32_t base = (wv >> (8 * (b & 3))) & 0xffu;
-                const uint32_t size = hp_new_size(A.m, key, sid, a, s0, e - s0, base);
+                const uint32_t size = (A.dbg & 1024) ? e - s0 : hp_new_size(A.m, key, sid, a, s0, e - s0, base);
                 R.s0[slot] = s0; R.len[slot] = e - s0; R.size[slot] = size; R.base[slot] = (uint8_t)base; R.fm[slot] = 0xffffffffu;
                 R.o_run[slot] = lane_delta;                                // (length change of the earlier runs of this chunk, for now)
                 lane_delta += size - (e - s0); lane_new += size; ++slot;
@@ -1285,7 +1298,7 @@ __global__ void __launch_bounds__(64 * NS_WPB, NS_HPW_WAVES) k_hp_write_w(GenArg
             if (lane == 63) R.w_off[n_runs] = total_new;
             wave_sync();
             // ---- B: plain stretches of the chunk
-            if (valid) {
+            if (valid && !(A.dbg & 512)) {
                 // the run that was open when the chunk begins: if it is long, its bases inside the chunk belong to its owner
                 const uint32_t older_end = t.M ? c + (uint32_t)__builtin_ctz(t.M) : t.next_start;
                 const bool older_long = t.prev_start >= 0 && older_end > c && older_end - (uint32_t)t.prev_start >= k;
@@ -1314,7 +1327,7 @@ __global__ void __launch_bounds__(64 * NS_WPB, NS_HPW_WAVES) k_hp_write_w(GenArg
                 }
             }
             // ---- C: the new bases of the runs, one lane each (S:668-684, qualities S:686-695)
-            for (uint32_t w = lane; w < total_new; w += 64) {
+            for (uint32_t w = lane; w < ((A.dbg & 256) ? 0u : total_new); w += 64) {
                 uint32_t lo = 0, hi = n_runs;                              // run j with w_off[j] <= w < w_off[j + 1]
                 while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (R.w_off[mid] <= w) lo = mid; else hi = mid; }
                 const uint32_t j = lo, x = w - R.w_off[j];
@@ -1504,7 +1517,7 @@ struct ns_ctx {
     DevBuf l_cap, l_off;
     DevBuf n_pieces, piece_off, ev_cap, ev_off, rec_len, rec_off, err_len, err_off, name_len;
     DevBuf reads, pieces, events, records, errlog, stats, scan_tmp;
-    DevBuf sort_key, sort_idx, sort_key_out, order, list_b, rstate, att_base, scr, scrq, scr_len, scr_off, hp_len, slow_q, ev_word;
+    DevBuf sort_key, sort_idx, sort_key_out, order, list_b, list_c, rstate, att_base, scr, scrq, scr_len, scr_off, hp_len, slow_q, ev_word;
     // metagenome: species view of the reference, abundances of the sample, per-pass scratch
     DevBuf species_chrom_off, t_reads, t_pieces, t_name_len, t_rec_len, t_err_len, accept, accept_scan, key_pos, draw_x, m_segptr,
         m_len, m_species, species_bases;
@@ -1643,7 +1656,7 @@ void ns_destroy(ns_ctx *ctx) {
     DevBuf *bufs[] = {&ctx->n_pieces, &ctx->piece_off, &ctx->ev_cap, &ctx->ev_off, &ctx->rec_len, &ctx->rec_off,
                       &ctx->err_len, &ctx->err_off, &ctx->name_len, &ctx->reads, &ctx->pieces, &ctx->events,
                       &ctx->records, &ctx->errlog, &ctx->stats, &ctx->scan_tmp, &ctx->sort_key, &ctx->sort_idx,
-                      &ctx->sort_key_out, &ctx->order, &ctx->list_b, &ctx->rstate, &ctx->att_base, &ctx->scr, &ctx->scrq,
+                      &ctx->sort_key_out, &ctx->order, &ctx->list_b, &ctx->list_c, &ctx->rstate, &ctx->att_base, &ctx->scr, &ctx->scrq,
                       &ctx->scr_len, &ctx->scr_off, &ctx->hp_len, &ctx->slow_q, &ctx->ev_word, &ctx->l_cap, &ctx->l_off, &ctx->species_chrom_off, &ctx->t_reads, &ctx->t_pieces,
                       &ctx->t_name_len, &ctx->t_rec_len, &ctx->t_err_len, &ctx->accept, &ctx->accept_scan, &ctx->key_pos,
                       &ctx->draw_x, &ctx->m_segptr, &ctx->m_len, &ctx->m_species, &ctx->species_bases, &ctx->draw_sel,
@@ -1845,7 +1858,8 @@ int ns_load_model(ns_ctx *ctx, const ns_model_tables *t) {
                 while (q < NS_QUAL_LEVELS - 1 && t->qual_thr[c][q] <= 64u * b) ++q;      // thresholds at or below the bucket start
                 uint32_t inside = 0, sub = 64;                                             // thresholds in (64 b, 64 b + 63]
                 for (uint32_t j = q; j < NS_QUAL_LEVELS - 1 && t->qual_thr[c][j] <= 64u * b + 63u; ++j) { if (!inside) sub = t->qual_thr[c][j] - 64u * b; ++inside; }
-                lut[(size_t)c * 1024 + b] = (uint16_t)(q | sub << 8 | (inside > 1 ? 0x8000u : 0u));
+                // q << 7 | (128 - sub): adding h & 63 carries into the count exactly when h & 63 >= sub (see qual_value_lut)
+                lut[(size_t)c * 1024 + b] = (uint16_t)(q << 7 | (128u - sub) | (inside > 1 ? 0x8000u : 0u));
             }
         if ((rc = upload(ctx, pool, lut.data(), lut.size(), &m.qual_lut))) return rc;
     }
@@ -1884,7 +1898,8 @@ static int scan_u32(ns_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n) {
 // metagenome (src/simulator.py:758-811, 814-1040)
 // ---------------------------------------------------------------------------------------------------------
 // copy phase, slow tiles, payload: the three kernels that write the sequence (and quality) lines of a batch
-static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fastq, uint64_t event_slots, hipEvent_t names_done = nullptr) {
+static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fastq, uint64_t event_slots, hipEvent_t names_done = nullptr,
+                              const uint32_t *order = nullptr) {
     hipStream_t st = ctx->stream;
     if (A.prm.kind == NS_KIND_UNALIGNED) {
         if (names_done) HIPCHK(hipStreamWaitEvent(st, names_done, 0));
@@ -1911,8 +1926,8 @@ static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fast
         sq.count = (uint32_t *)ctx->slow_q.p; sq.items = (SlowTile *)((uint8_t *)ctx->slow_q.p + 16);
         sq.cap = (uint32_t)(cap > 0xffffffffull ? 0xffffffffull : cap);
         HIPCHK(hipMemsetAsync(sq.count, 0, 4, st));
-        if (fastq) k_materialise<true><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, (const uint32_t *)ctx->ev_word.p, ctx->dbg, sq);
-        else k_materialise<false><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, (const uint32_t *)ctx->ev_word.p, ctx->dbg, sq);
+        if (fastq) k_materialise<true><<<dim3((unsigned)((n + NS_MATQ_WAVES - 1) / NS_MATQ_WAVES)), dim3(64 * NS_MATQ_WAVES), 0, st>>>(A, (const uint32_t *)ctx->ev_word.p, ctx->dbg, sq, order);
+        else k_materialise<false><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, (const uint32_t *)ctx->ev_word.p, ctx->dbg, sq, nullptr);
         HIPCHK(hipGetLastError());
         uint32_t queued = 0;
         HIPCHK(hipMemcpyAsync(&queued, sq.count, 4, hipMemcpyDeviceToHost, st));
@@ -2399,7 +2414,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         (rc = ensure(ctx, ctx->stats, 8 * sizeof(unsigned long long))) ||
         (rc = ensure(ctx, ctx->sort_key, (n + 1) * 4)) || (rc = ensure(ctx, ctx->sort_idx, (n + 1) * 4)) ||
         (rc = ensure(ctx, ctx->sort_key_out, (n + 1) * 4)) || (rc = ensure(ctx, ctx->order, (n + 1) * 4)) ||
-        (rc = ensure(ctx, ctx->list_b, (n + 1) * 4)) || (rc = ensure(ctx, ctx->rstate, (n + 1) * 4)) ||
+        (rc = ensure(ctx, ctx->list_b, (n + 1) * 4)) || (rc = ensure(ctx, ctx->list_c, (n + 1) * 4)) || (rc = ensure(ctx, ctx->rstate, (n + 1) * 4)) ||
         (rc = ensure(ctx, ctx->att_base, (n + 1) * 4)) || (rc = ensure(ctx, ctx->scr_len, (n + 1) * 8)) ||
         (rc = ensure(ctx, ctx->scr_off, (n + 1) * 8)))
         return rc;
@@ -2419,6 +2434,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     A.scr_len = (uint64_t *)ctx->scr_len.p; A.scr_off = (uint64_t *)ctx->scr_off.p;
     A.hp = hp_on ? 1u : 0u; A.keep_state = 0;
     A.errlen_later = prm->emit_errlog ? 1u : 0u;
+    A.dbg = ctx->dbg;
     if (prm->trx) {
         if ((rc = ensure(ctx, ctx->polya, (n + 1) * 2))) return rc;
         A.tx = ctx->tx; A.polya = (uint16_t *)ctx->polya.p;
@@ -2431,7 +2447,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     }
     A.meta = prm->meta ? 1u : 0u; A.nspecies = ctx->nspecies; A.species_chrom_off = (const uint32_t *)ctx->species_chrom_off.p;
     A.next_n = (uint32_t *)((unsigned long long *)ctx->stats.p + 6);
-    uint32_t *list_a = (uint32_t *)ctx->order.p, *list_b = (uint32_t *)ctx->list_b.p;
+    uint32_t *list_a = (uint32_t *)ctx->order.p, *list_b = (uint32_t *)ctx->list_b.p, *list_c = (uint32_t *)ctx->list_c.p;
     const dim3 blk(256);
     const dim3 grid_t((unsigned)((n + 1 + 255) / 256));        // thread-per-read kernels (n+1 for the scan sentinel)
     const dim3 grid_w((unsigned)((n + NS_WPB - 1) / NS_WPB)), blk_w(64 * NS_WPB);     // wave-per-read kernels
@@ -2534,7 +2550,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
             if (a + 1 >= NS_MAX_ATTEMPT)
                 return fail(ctx, NS_EINVAL, "some reads found no acceptable length within the attempt limit "
                                             "(min_len/max_len too narrow for this model)");
-            uint32_t *t = cur; cur = nxt; nxt = t;
+            cur = nxt; nxt = cur == list_b ? list_c : list_b;      // (list_a keeps the length-sorted order of the batch for the record kernels)
         }
         info->ms_kernel[NS_K_EVENTS] = ms_chain;
         if (!overflow) break;
@@ -2593,7 +2609,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         else k_hp_write<<<grid_t, blk, 0, st>>>(A);
         HIPCHK(hipGetLastError());
     } else if (prm->emit_records) {
-        if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, tot_cap, ctx->ev_join))) return rc;
+        if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, tot_cap, ctx->ev_join, meta_al ? nullptr : list_a))) return rc;
     }
     HIPCHK(hipEventRecord(ctx->evt[7], st));
     if (prm->emit_errlog && prm->emit_records) {

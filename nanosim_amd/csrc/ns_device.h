@@ -35,8 +35,8 @@ struct DevModel {
     uint32_t nseg_n;
     const double *nseg_cdf;
     const uint32_t *qual_thr;     // [NS_Q_COUNT][NS_QUAL_LEVELS]
-    const uint16_t *qual_lut;     // [NS_Q_COUNT][1024], bucket b = h >> 6: bits 0-7 #{j : thr[j] <= 64 b}; bits 8-14 the offset inside the
-                                  // bucket of its only threshold (64: none); bit 15: several thresholds inside (walk them)
+    const uint16_t *qual_lut;     // [NS_Q_COUNT][1024], bucket b = h >> 6: bits 7-13 #{j : thr[j] <= 64 b}; bits 0-6 = 128 - (offset inside
+                                  // the bucket of its only threshold), 64 if it has none; bit 15: several thresholds inside (walk them)
     ns_hp_class hp[2];
     double hp_mis_rate;
     const double *kde2d_x, *kde2d_y;      // transcriptome: 2-D KDE training points sorted by transcript length
@@ -438,12 +438,13 @@ __device__ __forceinline__ uint8_t ht_letter(const ns_key &key, uint32_t stream,
     u32x4 w = ns_draw(key, stream, 0, attempt, i >> 6, 0);
     return bases_atcg((ns_word(w, (i >> 4) & 3) >> (2 * (i & 15))) & 3u);
 }
-// the same count through a 1024-bucket look-up table: the count at the start of the bucket, plus one if h is at or above the only
-// threshold inside the bucket (buckets are 64 wide; a bucket with several thresholds is walked)
+// the same count through a 1024-bucket look-up table: the count at the start of the bucket in bits 7.., and below it 128 minus the
+// offset of the only threshold inside the bucket — adding h & 63 carries into the count exactly when h is at or above that
+// threshold (buckets are 64 wide; a bucket with several thresholds is walked: the loader's tables have none, model.py)
 __device__ __forceinline__ uint8_t qual_value_lut(const uint32_t *__restrict__ thr, const uint16_t *__restrict__ lut, uint32_t h) {
     const uint32_t e = lut[h >> 6];
-    uint32_t q = e & 0xffu;
-    if (!(e & 0x8000u)) return (uint8_t)(q + ((h & 63u) >= ((e >> 8) & 0x7fu) ? 1u : 0u));
+    if (!(e & 0x8000u)) return (uint8_t)(((e & 0x7fffu) + (h & 63u)) >> 7);
+    uint32_t q = (e >> 7) & 0x7fu;
     while (q < NS_QUAL_LEVELS - 1 && h >= thr[q]) ++q;
     return (uint8_t)q;
 }

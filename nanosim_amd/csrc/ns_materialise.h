@@ -1,17 +1,16 @@
-// ns_materialise.h — k_materialise (v2): one read per wavefront (64-thread workgroup), LDS-tiled.
-//
-// Per piece the emitted sequence is produced in tiles of <= 1024 bases:
-//   1. stage the events that start inside the tile (plus the one in force at the tile start) into LDS;
-//   2. stage the reference bytes the tile copies from with coalesced 16-byte loads into LDS, resolving
-//      IUPAC codes on the fly (case_convert, S:743-755: keyed by the segment position, so every tile that
-//      touches a base sees the same letter);
-//   3. phase B — one lane per event: substituted / inserted letters (one Philox block per event) are written
-//      into an LDS payload tile at their output offsets (mutate_read, S:1965-1995);
-//   4. phase A — one lane per 16 output bytes: a histogram + wavefront prefix sum gives every lane the event
-//      in force at its first byte; bytes come from the payload tile or the reference tile; the 16 bytes are
-//      complemented/reversed in registers (S:1433-1435, 1675-1680) and stored with one 16-byte store.
-// Tiles whose reference span does not fit the LDS tile, or that straddle the origin of a circular chromosome,
-// take the generic per-byte path (slow_piece_range).
+// ns_materialise.h — the record kernels' device code: one read per wavefront, tiles of <= 2 KB of output whose 16-byte chunks are
+// aligned in the destination.  Per tile (materialise_piece below has the details):
+//   1. the events that start inside the tile (<= 63; lane = event, prefetched with their letter words) are staged in LDS;
+//   2. lane per event: substituted / inserted letters (mutate_read, S:1965-1995) go to an LDS payload tile at their output offsets;
+//   3. lane per 16-byte chunk: histogram + wavefront prefix sum -> the event in force at the chunk's first byte; one unaligned
+//      16-byte global load per event sub-run straight from the source (no source tile in LDS: neighbouring lanes hit the same
+//      lines in L1/L2), merged under byte masks; the payload tile on top; IUPAC codes resolved (case_convert, S:743-755);
+//   4. FASTQ: two Philox blocks per lane = the 16-bit quality draws of the chunk (the block that straddles the chunk start comes
+//      from the neighbouring lane by DPP), 16 look-ups in a bucket table held in LDS;
+//   5. complement / reverse in registers (S:1433-1435, 1675-1680), one aligned 16-byte store per line.
+// The SOURCE of a piece is the reference (MAT_REF), or — second pass of -k — the pre-homopolymer read in the scratch buffer with
+// the homopolymer edits as its event list (MAT_HP_FINAL).  Tiles that straddle the origin of a circular chromosome take the generic
+// per-byte path (slow_piece_range).
 #pragma once
 #include "ns_device.h"
 
@@ -32,7 +31,13 @@ struct __align__(16) TileLds {
     uint8_t pmask[T_OUT + 16 + 64];
 };
 #define T_DUMP (T_OUT + 16u)
-#define NS_HQ_LDS (32u + 64u * 48u + 16u)                 // FASTQ only: quality draws of a chunk, per lane
+// quality class of an emitted base travels in two spare bits of its ASCII code (A 41, C 43, G 47, T 54: bits 3 and 5 are free)
+// until the qualities are drawn: bit 3 = substituted ('mis'), bit 5 = inserted ('ins', the base is in lower case)
+#define NS_CLS_MIS_BIT 0x08u
+#define NS_CLS_INS_BIT 0x20u
+#define NS_CLS_STRIP 0xd7d7d7d7u
+// LDS copy of the quality bucket tables: slots 0..2 = match / mis / ins, slot 3 = unmapped (gaps of chimeric reads)
+#define NS_QLUT_SLOTS 4u
 __device__ __forceinline__ void tile_lds_init(TileLds &T, uint32_t lane) {
     for (uint32_t c = lane * 16; c < T_OUT + 16 + 64; c += 64 * 16) {
         *reinterpret_cast<uint4 *>(&T.pay[c]) = make_uint4(0, 0, 0, 0);
@@ -323,7 +328,7 @@ __device__ inline void slow_piece_range(const DevModel &m, const DevRef &ref, co
 }
 
 // ---- LDS-tiled path ---------------------------------------------------------------------------------------
-// single-wavefront workgroup: DS instructions of one wave execute in issue order, so a compiler-level fence is
+// every wavefront works on its own LDS tile: DS instructions of one wave execute in issue order, so a compiler-level fence is
 // all that is needed between an LDS write and a cross-lane LDS read (no s_barrier, no vmcnt drain)
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -342,31 +347,144 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mask), "v"(a), "v"(b));
     return d;
 }
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask, uint32_t c) { return (a & mask) | c; }    // v_and_or_b32
 
-// One piece of a read (v4).  Per tile of <= 1024 output bases whose 16-byte chunks are ALIGNED in the record buffer:
-//   1. lane l holds event jb + l (prefetched) and its letter word (k_words); the events that start inside the tile are a
+// what a piece is copied from
+enum { MAT_REF = 0,          // the reference -> the record (qualities drawn here if FASTQ)
+       MAT_HP_SCRATCH = 1,   // -k, first pass: the reference -> the pre-homopolymer read in the scratch buffer (class bits kept, no qualities)
+       MAT_HP_FINAL = 2 };   // -k, second pass: the scratch read + the homopolymer edits as its event list -> the record
+
+// ---- qualities of one 16-byte chunk (predict_base_qualities, bq:183-193; classes S:1421-1423, 1953-1955) ------------------------
+// The 16-bit draw of emitted piece position m is halfword m & 7 of Philox(ST_QUAL, sid, attempt, idx = m >> 3).  A chunk starts
+// at c0 (any alignment with respect to the blocks, c0 & 7 is wave-uniform): every lane evaluates the two blocks that START inside
+// its chunk, the block that straddles the chunk start is the neighbouring lane's second block (DPP wave_shr:1); for lane 0 it is
+// carried from the previous iteration / tile in SGPRs (or evaluated once, on the scalar unit's operands, when neither candidate fits).
+struct QualState {
+    const uint16_t *lut;                 // LDS: NS_QLUT_SLOTS x 1024 bucket entries (see qual_value_lut)
+    uint32_t a_blk, b_blk;               // block numbers held in a / b (0x80000000: none)
+    u32x4 a, b;
+};
+__device__ __forceinline__ void qual_state_reset(QualState &Q) { Q.a_blk = Q.b_blk = 0x80000000u; Q.a = Q.b = u32x4{0, 0, 0, 0}; }
+
+__device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t lane0_value, uint32_t v) {      // lane l gets v of lane l - 1, lane 0 gets lane0_value
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0_value, (int)v, 0x138, 0xf, 0xf, false);
+}
+// D[k] = the draws of chunk bytes 2k (low half) and 2k + 1 (high half); c0_first = chunk origin of lane 0, n_active = lanes of this
+// iteration that write bytes (a prefix of the wavefront, >= 1).  Executed by ALL lanes.
+__device__ __forceinline__ void qual_draws16(QualState &Q, const ns_key &key, uint32_t sid, uint32_t a, uint32_t c0, uint32_t c0_first,
+                                             uint32_t n_active, bool skip_philox, uint32_t D[8]) {
+    const uint32_t B0 = (uint32_t)((int32_t)c0 >> 3);
+    const uint32_t need = (uint32_t)((int32_t)c0_first >> 3);              // lane 0's straddling block
+    u32x4 k1, k2, p0;
+    if (skip_philox) { k1 = u32x4{B0, 1, c0, 0}; k2 = u32x4{B0, 2, c0, 0}; }
+    else { k1 = ns_draw(key, ST_QUAL, sid, a, B0 + 1u, 0); k2 = ns_draw(key, ST_QUAL, sid, a, B0 + 2u, 0); }
+    if (need == Q.a_blk) p0 = Q.a;
+    else if (need == Q.b_blk) p0 = Q.b;
+    else p0 = ns_draw(key, ST_QUAL, sid, a, need, 0);                      // (wave-uniform operands)
+    uint32_t W[13];
+    W[0] = dpp_wave_shr1(p0.x, k2.x); W[1] = dpp_wave_shr1(p0.y, k2.y); W[2] = dpp_wave_shr1(p0.z, k2.z); W[3] = dpp_wave_shr1(p0.w, k2.w);
+    W[4] = k1.x; W[5] = k1.y; W[6] = k1.z; W[7] = k1.w; W[8] = k2.x; W[9] = k2.y; W[10] = k2.z; W[11] = k2.w; W[12] = 0;
+    // carries: the second block of the last active lane (next iteration starts behind it) and of the one before (the next tile
+    // starts inside the last chunk)
+    const uint32_t la = n_active - 1u;
+    Q.b = p0; Q.b_blk = need + 2u * la;
+    if (la) {
+        Q.b.x = (uint32_t)__builtin_amdgcn_readlane((int)k2.x, (int)(la - 1u)); Q.b.y = (uint32_t)__builtin_amdgcn_readlane((int)k2.y, (int)(la - 1u));
+        Q.b.z = (uint32_t)__builtin_amdgcn_readlane((int)k2.z, (int)(la - 1u)); Q.b.w = (uint32_t)__builtin_amdgcn_readlane((int)k2.w, (int)(la - 1u));
+    }
+    Q.a.x = (uint32_t)__builtin_amdgcn_readlane((int)k2.x, (int)la); Q.a.y = (uint32_t)__builtin_amdgcn_readlane((int)k2.y, (int)la);
+    Q.a.z = (uint32_t)__builtin_amdgcn_readlane((int)k2.z, (int)la); Q.a.w = (uint32_t)__builtin_amdgcn_readlane((int)k2.w, (int)la);
+    Q.a_blk = need + 2u * la + 2u;
+    // byte i of the chunk = halfword g + i of the 24-halfword window W (g = c0 & 7, wave-uniform)
+    const uint32_t g = uni(c0_first & 7u), gd = g >> 1;
+    if (gd & 2u) {
+#pragma unroll
+        for (int i = 0; i < 11; ++i) W[i] = W[i + 2];
+    }
+    if (gd & 1u) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) W[i] = W[i + 1];
+    }
+    if (g & 1u) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) D[i] = __builtin_amdgcn_alignbit(W[i + 1], W[i], 16);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) D[i] = W[i];
+    }
+}
+// 16 qualities from the 16 draws D and the class slot of every byte (cs[k]: slot << 3 in each byte of dword k of the chunk)
+__device__ __forceinline__ void qual_lookup16(const QualState &Q, const DevModel &m, const uint32_t D[8], const uint32_t cs[4], bool skip_lut,
+                                              uint64_t &qlo, uint64_t &qhi) {
+    const uint8_t *lut = reinterpret_cast<const uint8_t *>(Q.lut);
+    uint32_t Q2[8], flags = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k) {
+        const uint32_t d = D[k], cw = cs[k >> 1];
+        // (slot << 3) of byte 2k / 2k + 1 moved to bits 11.. = slot * 2048 bytes
+        const uint32_t o0 = __builtin_amdgcn_perm(0u, cw, (k & 1u) ? 0x0c0c020cu : 0x0c0c000cu);
+        const uint32_t o1 = __builtin_amdgcn_perm(0u, cw, (k & 1u) ? 0x0c0c030cu : 0x0c0c010cu);
+        const uint32_t a0 = and_or(d >> 5, 0x7feu, o0), a1 = and_or(d >> 21, 0x7feu, o1);        // byte address of entry [slot][h >> 6]
+        uint32_t E;
+        if (skip_lut) E = (a0 & 0x3f80u) | (a1 & 0x3f80u) << 16 | 0x00400040u;
+        else E = (uint32_t)*reinterpret_cast<const uint16_t *>(lut + a0) | (uint32_t)*reinterpret_cast<const uint16_t *>(lut + a1) << 16;
+        flags |= E;
+        Q2[k] = (((E & 0x7fff7fffu) + (d & 0x003f003fu)) >> 7) & 0x007f007fu;                   // see qual_value_lut
+    }
+    if (__ballot((flags & 0x80008000u) != 0)) {                        // a bucket with several thresholds (never with the loader's tables)
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t c0 = (cs[k >> 1] >> (16 * (k & 1) + 3)) & 3u, c1 = (cs[k >> 1] >> (16 * (k & 1) + 11)) & 3u;
+            const uint32_t q0 = qual_value(m.qual_thr + (c0 == 3u ? (uint32_t)NS_Q_UNMAPPED : c0) * NS_QUAL_LEVELS, D[k] & 0xffffu);
+            const uint32_t q1 = qual_value(m.qual_thr + (c1 == 3u ? (uint32_t)NS_Q_UNMAPPED : c1) * NS_QUAL_LEVELS, D[k] >> 16);
+            Q2[k] = q0 | q1 << 16;
+        }
+    }
+    const uint32_t b0 = __builtin_amdgcn_perm(Q2[1], Q2[0], 0x06040200u), b1 = __builtin_amdgcn_perm(Q2[3], Q2[2], 0x06040200u);
+    const uint32_t b2 = __builtin_amdgcn_perm(Q2[5], Q2[4], 0x06040200u), b3 = __builtin_amdgcn_perm(Q2[7], Q2[6], 0x06040200u);
+    qlo = (uint64_t)b0 | (uint64_t)b1 << 32; qhi = (uint64_t)b2 | (uint64_t)b3 << 32;
+}
+// the bucket tables of the classes a piece can hold, global -> LDS (all threads of the workgroup; the caller synchronises)
+__device__ __forceinline__ void qual_lut_load(uint16_t *lds, const DevModel &m, uint32_t tid, uint32_t nthreads) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(m.qual_lut);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds);
+    static_assert(NS_Q_MATCH == 0 && NS_Q_MIS == 1 && NS_Q_INS == 2, "slots 0..2 are the first three classes");
+    for (uint32_t i = tid; i < 3u * 128u; i += nthreads) dst[i] = src[i];
+    for (uint32_t i = tid; i < 128u; i += nthreads) dst[3u * 128u + i] = src[(uint32_t)NS_Q_UNMAPPED * 128u + i];
+}
+
+// One piece of a read.  Per tile of <= T_OUT output bases whose 16-byte chunks are ALIGNED in the destination:
+//   1. lane l holds event jb + l (prefetched) and its letter word (k_words / k_hp_events); the events that start inside the tile are a
 //      prefix of the lanes; they are staged into LDS for the other lanes;
 //   2. lane per event: the substituted / inserted letters (mutate_read, S:1965-1995) are written into an LDS payload tile at
-//      their output offsets, with a byte mask (and the quality class);
+//      their output offsets, with a byte mask; FASTQ: the letters carry their quality class in bits 3 / 5;
 //   3. a histogram + wavefront prefix sum gives every lane (= one aligned 16-byte chunk) the event in force at its first byte;
-//      per event sub-run of the chunk ONE unaligned 16-byte global load at the run's reference offset (software-pipelined,
+//      per event sub-run of the chunk ONE unaligned 16-byte global load at the run's source offset (software-pipelined,
 //      branch-free; neighbouring lanes hit the same lines in L1/L2), merged into the chunk under a byte mask; then the
 //      payload tile is merged on top; IUPAC codes (bit 7) are resolved afterwards (case_convert, S:743-755);
-//   4. complement/reverse in registers (S:1433-1435, 1675-1680), one aligned 16-byte store.
+//   4. FASTQ: qual_draws16 + qual_lookup16; complement/reverse in registers (S:1433-1435, 1675-1680), one aligned 16-byte store.
 // A tile whose reference span straddles the origin of a circular chromosome goes to the slow-tile queue.
+// MAT_HP_FINAL: the source is the pre-homopolymer piece in the scratch buffer (its bytes carry the class bits), the events are the
+// homopolymer edits (k_hp_events): a substitution is one base whose word picks the new base with its first base-3 digit and, with
+// bit 0 set, takes the 'mis' class (first mismatch of its run, S:697-700; otherwise the class of the base it replaces); an
+// insertion has <= 15 letters, all of class 'ins' except letter 0 when bit 31 of the word is set.
+template <bool FASTQ, int MODE>
 __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, TileLds &T, const ReadOut &ro, const ns_key &key,
-                                         uint32_t a, const PieceCtx &pc, uint32_t pq, uint32_t lane, const uint32_t *__restrict__ ev_word,
-                                         uint32_t dbg, const SlowQueue &sq, uint32_t read_idx, uint32_t piece_idx, uint8_t *hq = nullptr) {
+                                         uint32_t a, const PieceCtx &pc, uint32_t pq, uint32_t lane, uint32_t dbg, const SlowQueue &sq,
+                                         uint32_t read_idx, uint32_t piece_idx, QualState &Q) {
+    constexpr bool QUALS = FASTQ && MODE != MAT_HP_SCRATCH;            // qualities are drawn in this pass
+    constexpr bool HPF = MODE == MAT_HP_FINAL;
     uint32_t jb = 0;                       // events with out_start < M0
     uint32_t L0_out = 0, L0_rp = 0, L0_pt = 3u << 12, L0_wd = 0, L0_j = 0;   // the event in force at M0 (synthetic start: no payload, copy from 0)
     const uint8_t *seg0 = ref.bases + pc.chrom_base + pc.pos;           // segment position 0
-    const bool wraps = pc.pos + pc.ref_len > pc.chrom_len;
+    const bool wraps = !HPF && pc.pos + pc.ref_len > pc.chrom_len;
     const uint32_t wrap_at = wraps ? (uint32_t)(pc.chrom_len - pc.pos) : 0xffffffffu;   // first segment position beyond the origin
-    // output offsets m with m = phi (mod 16) start an aligned 16-byte group of the record buffer
+    // output offsets m with m = phi (mod 16) start an aligned 16-byte group of the destination
     const uint32_t phi = ro.reversed ? ((uint32_t)(uintptr_t)ro.seq + ro.seq_len - pq) & 15u : (0u - ((uint32_t)(uintptr_t)ro.seq + pq)) & 15u;
     ns_event e_pre; e_pre.pos = 0; e_pre.info = 0; uint32_t w_pre = 0;
     if (lane < pc.n_ev) { e_pre = pc.ev[lane]; w_pre = pc.wd[lane]; }
     PendingChunk pend; pend.count = 0; pend.o0 = 0; pend.lo = pend.hi = pend.qlo = pend.qhi = 0;
+    if constexpr (QUALS) qual_state_reset(Q);
     for (uint32_t M0 = 0; M0 < pc.out_len;) {
         const uint32_t A0 = M0 - ((M0 - phi) & 15u);             // aligned origin of the tile (<= M0; may be "negative" = wrapped)
         uint32_t M1 = min(A0 + T_OUT, pc.out_len);
@@ -444,6 +562,7 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             }
             L0_out = osl; L0_rp = rpl; L0_pt = ptl; L0_wd = wdl; L0_j = jl;
             jb = jb_next; M0 = M1;
+            if constexpr (QUALS) qual_state_reset(Q);
             wave_sync();
             continue;
         }
@@ -462,7 +581,7 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             bool fast_l = on && b_pl <= 4 && b_os >= M0 && b_os + b_pl <= M1 && !wraps;
             uint32_t cur4 = 0x41414141u;
             if (fast_l && mis) __builtin_memcpy(&cur4, seg0 + xs, 4);
-            fast_l = fast_l && !(cur4 & 0x80808080u);
+            if constexpr (!HPF) fast_l = fast_l && !(cur4 & 0x80808080u);
             if (fast_l) {
                 // insertion: 2-bit fields of the word -> "ATCG" (S:1990)
                 const uint32_t x8 = frac & 0xffu, t8 = (x8 | x8 << 12) & 0x000f000fu;
@@ -475,8 +594,15 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
                 const uint32_t rank4 = (vv & 0x01010101u) << 1 | ((vv >> 1) & 0x01010101u);   // rank in "ATCG": A 0, T 1, C 2, G 3
                 const uint32_t ge = ((d4 | 0x80808080u) - rank4) & 0x80808080u;          // per byte: digit >= rank
                 const uint32_t mis4 = __builtin_amdgcn_perm(0u, 0x47435441u, d4 + (ge >> 7));
-                // FASTQ: inserted letters travel in lower case, which is how the chunk pass tells the two quality classes apart
-                const uint32_t letters = mis ? mis4 : (ins4 | (ro.qual ? 0x20202020u : 0u));
+                uint32_t letters = mis ? mis4 : ins4;
+                if constexpr (FASTQ) {                             // the quality class travels with the letter
+                    uint32_t cls4 = mis ? 0x01010101u * NS_CLS_MIS_BIT : 0x01010101u * NS_CLS_INS_BIT;
+                    if constexpr (HPF) {
+                        if (mis) cls4 = (frac & 1u) ? NS_CLS_MIS_BIT : (cur4 & (NS_CLS_MIS_BIT | NS_CLS_INS_BIT));
+                        else if (frac >> 31) cls4 = (cls4 & ~0xffu) | NS_CLS_MIS_BIT;
+                    }
+                    letters |= cls4;
+                }
                 const uint32_t o = b_os - A0, dump = T_DUMP + lane;
                 const uint32_t o1 = b_pl > 1 ? o + 1 : dump, o2 = b_pl > 2 ? o + 2 : dump, o3 = b_pl > 3 ? o + 3 : dump;
                 T.pay[o] = (uint8_t)letters; T.pay[o1] = (uint8_t)(letters >> 8); T.pay[o2] = (uint8_t)(letters >> 16); T.pay[o3] = (uint8_t)(letters >> 24);
@@ -485,17 +611,27 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             if (on && !fast_l) {                                  // long payloads, tile borders, IUPAC under a substitution, the origin
                 const uint32_t i_lo = b_os < M0 ? M0 - b_os : 0u;
                 const uint32_t i_hi = min(b_pl, M1 - b_os);
+                const uint32_t word0 = frac;
                 for (uint32_t i = 0; i < i_hi; ++i) {
                     if (i && !(i & 15)) frac = payload_word(key, pc.sid, a, b_j, i >> 4);
                     uint32_t b;
-                    if (b_ty == NS_INS) b = bases_atcg((frac >> (2 * (i & 15))) & 3u);
-                    else {
+                    if (b_ty == NS_INS) {
+                        b = bases_atcg((frac >> (2 * (i & 15))) & 3u);
+                        if constexpr (FASTQ) b |= (HPF && i == 0 && (word0 >> 31)) ? NS_CLS_MIS_BIT : NS_CLS_INS_BIT;
+                    } else {
                         const uint32_t x = xs + i;
-                        b = mis_from_digit(resolve_base(ref_base_at(ref, pc, x), key, pc.sid, a, x), next_digit3(frac));
+                        const uint32_t src = ref_base_at(ref, pc, x);
+                        if constexpr (HPF) {
+                            b = mis_from_digit(src & ~(NS_CLS_MIS_BIT | NS_CLS_INS_BIT), next_digit3(frac));
+                            if constexpr (FASTQ) b |= (word0 & 1u) ? NS_CLS_MIS_BIT : (src & (NS_CLS_MIS_BIT | NS_CLS_INS_BIT));
+                        } else {
+                            b = mis_from_digit(resolve_base(src, key, pc.sid, a, x), next_digit3(frac));
+                            if constexpr (FASTQ) b |= NS_CLS_MIS_BIT;
+                        }
                     }
                     if (i >= i_lo) {
                         const uint32_t o = b_os + i - A0;
-                        T.pay[o] = (uint8_t)(b | (ro.qual && b_ty == NS_INS ? 0x20u : 0u)); T.pmask[o] = 0xffu;
+                        T.pay[o] = (uint8_t)b; T.pmask[o] = 0xffu;
                     }
                 }
             }
@@ -514,6 +650,12 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
         scan_base = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         const uint32_t c0 = A0 + 16 * ci;                          // chunk origin (chunk 0 of a piece's first tile may start before M0)
         const uint32_t lo_m = ci == 0 ? M0 : c0, hi_m = min(c0 + 16, M1);
+        uint32_t D[8];
+        if constexpr (QUALS) {                                     // the quality draws of the iteration (every lane takes part)
+            const uint32_t c0_first = A0 + 1024u * t;
+            const int32_t span = (int32_t)(M1 - 1u - c0_first);    // >= 0: some lane of this iteration writes bytes
+            if (span >= 0) qual_draws16(Q, key, pc.sid, a, c0, c0_first, min(64u, ((uint32_t)span >> 4) + 1u), (dbg & 128u) != 0, D);
+        }
         if ((int32_t)(hi_m - lo_m) > 0 && !(dbg & 1)) {
             uint32_t k = incl;                                     // event in force at the chunk's first byte
             uint32_t eos = T.e_out[k], pl = T.e_pt[k] & 0xfffu, rp = T.e_rp[k], nxt = T.e_out[k + 1];
@@ -558,6 +700,7 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
 #undef NS_SUBRUN_MERGE
             const uint32_t lo_off = 16 * ci;                       // chunk offset inside the payload tile
             const uint4 pv = *reinterpret_cast<const uint4 *>(&T.pay[lo_off]), pm = *reinterpret_cast<const uint4 *>(&T.pmask[lo_off]);
+            if constexpr (!HPF) {
             if ((r0 | r1 | r2 | r3) & 0x80808080u) {               // case_convert (S:743-755): rare; the segment position of a marked
                 uint32_t kk = incl;                                // byte is found by walking the chunk's events again
                 for (uint32_t b = lo_m - c0; b < hi_m - c0; ++b) {
@@ -572,57 +715,26 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
                     if (b < 4) r0 = wk; else if (b < 8) r1 = wk; else if (b < 12) r2 = wk; else r3 = wk;
                 }
             }
+            }
             // letters on top of the copied bases; the payload tile is left clean for the next tile
             r0 = bfi(pm.x, pv.x, r0); r1 = bfi(pm.y, pv.y, r1); r2 = bfi(pm.z, pv.z, r2); r3 = bfi(pm.w, pv.w, r3);
-            if (ro.qual) { r0 &= 0xdfdfdfdfu; r1 &= 0xdfdfdfdfu; r2 &= 0xdfdfdfdfu; r3 &= 0xdfdfdfdfu; }   // back to upper case
             *reinterpret_cast<uint4 *>(&T.pay[lo_off]) = make_uint4(0, 0, 0, 0);
             *reinterpret_cast<uint4 *>(&T.pmask[lo_off]) = make_uint4(0, 0, 0, 0);
-            uint64_t lo = (uint64_t)r0 | (uint64_t)r1 << 32, hi = (uint64_t)r2 | (uint64_t)r3 << 32;
             uint64_t qlo = 0, qhi = 0;
             uint32_t s0 = lo_m - c0, count = hi_m - lo_m;          // bytes [s0, s0 + count) of the chunk are this tile's
-            if (ro.qual) {                                         // one quality per byte, class from the payload tile (S:1421-1423)
-                // class per byte: NS_Q_MATCH 0, NS_Q_MIS 1 (payload), NS_Q_INS 2 (lower-case payload); NS_Q_UNMAPPED for unaligned reads
-                static_assert(NS_Q_MATCH == 0 && NS_Q_MIS == 1 && NS_Q_INS == 2, "class arithmetic below");
-                // The 16-bit draws of byte m are halfword m & 7 of Philox block m >> 3: the (up to) three blocks under the chunk go to
-                // the lane's LDS slot, the 16 draws come back with static offsets; then all look-ups of the chunk are issued in
-                // rounds (table bucket, two thresholds) instead of one dependent chain per byte.
-                const uint32_t m0 = c0 + s0, b0 = m0 >> 3;
-                uint8_t *slot = hq + 32 + 48 * lane;
-#pragma unroll
-                for (uint32_t tb = 0; tb < 3; ++tb) {
-                    const u32x4 w = ns_draw(key, ST_QUAL, pc.sid, a, b0 + tb, 0);
-                    *reinterpret_cast<uint4 *>(slot + 16 * tb) = make_uint4(w.x, w.y, w.z, w.w);
+            if constexpr (QUALS) {                                 // one quality per byte, class from the bits the base carries (S:1421-1423)
+                // slot << 3 per byte: NS_Q_MATCH 0, NS_Q_MIS 1 (bit 3), NS_Q_INS 2 (bit 5); slot 3 = 'unmapped' for the gaps of chimeric reads
+                uint32_t cs[4];
+                if (pc.kind) cs[0] = cs[1] = cs[2] = cs[3] = 0x18181818u;
+                else {
+                    cs[0] = and_or(r0 >> 1, 0x10101010u, r0 & 0x08080808u); cs[1] = and_or(r1 >> 1, 0x10101010u, r1 & 0x08080808u);
+                    cs[2] = and_or(r2 >> 1, 0x10101010u, r2 & 0x08080808u); cs[3] = and_or(r3 >> 1, 0x10101010u, r3 & 0x08080808u);
                 }
-                const uint8_t *hb = slot + 2 * (int)(m0 & 7u) - 2 * (int)s0;          // halfword i of the chunk at hb + 2 i (i >= s0)
-#define NS_CLS_WORD(PM, PV) (pc.kind ? 0x01010101u * NS_Q_UNMAPPED : ((PM) & 0x01010101u) + (((PV) >> 5) & 0x01010101u))
-                const uint32_t pcw[4] = {NS_CLS_WORD(pm.x, pv.x), NS_CLS_WORD(pm.y, pv.y), NS_CLS_WORD(pm.z, pv.z), NS_CLS_WORD(pm.w, pv.w)};
-#undef NS_CLS_WORD
-#pragma unroll
-                for (uint32_t half = 0; half < 2; ++half) {
-                    uint32_t h[8], cl[8], q[8];
-#pragma unroll
-                    for (uint32_t j = 0; j < 8; ++j) {
-                        const uint32_t i = 8 * half + j;
-                        h[j] = *reinterpret_cast<const uint16_t *>(hb + 2 * i);
-                        cl[j] = (pcw[i >> 2] >> (8 * (i & 3))) & 0xffu;
-                    }
-#pragma unroll
-                    for (uint32_t j = 0; j < 8; ++j) q[j] = m.qual_lut[cl[j] * 1024u + (h[j] >> 6)];     // bucket entry: see qual_value_lut
-                    uint64_t acc = 0;
-#pragma unroll
-                    for (uint32_t j = 0; j < 8; ++j) {
-                        uint32_t qq = (q[j] & 0xffu) + ((h[j] & 63u) >= ((q[j] >> 8) & 0x7fu) ? 1u : 0u);
-                        if (q[j] & 0x8000u) {                                      // rare: more than one threshold inside the bucket
-                            const uint32_t *thr = m.qual_thr + cl[j] * NS_QUAL_LEVELS;
-                            qq = q[j] & 0xffu;
-                            while (qq < NS_QUAL_LEVELS - 1 && h[j] >= thr[qq]) ++qq;
-                        }
-                        acc |= (uint64_t)qq << (8 * j);
-                    }
-                    if (half) qhi = acc; else qlo = acc;
-                }
+                qual_lookup16(Q, m, D, cs, (dbg & 64u) != 0, qlo, qhi);
                 // bytes outside [s0, s0 + count) hold draws of other positions: they are shifted out / not stored
             }
+            if constexpr (FASTQ && MODE != MAT_HP_SCRATCH) { r0 &= NS_CLS_STRIP; r1 &= NS_CLS_STRIP; r2 &= NS_CLS_STRIP; r3 &= NS_CLS_STRIP; }
+            uint64_t lo = (uint64_t)r0 | (uint64_t)r1 << 32, hi = (uint64_t)r2 | (uint64_t)r3 << 32;
             if (s0) {                                              // front-partial chunk (first chunk of a piece): shift down
                 const uint32_t sh = 8 * s0;
                 if (sh < 64) { lo = (lo >> sh) | (hi << (64 - sh)); hi >>= sh; qlo = (qlo >> sh) | (qhi << (64 - sh)); qhi >>= sh; }

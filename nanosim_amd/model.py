@@ -230,6 +230,31 @@ def quality_thresholds(sd: float, loc: float, mu: float) -> np.ndarray:
     return thr
 
 
+def snap_quality_thresholds(thr: np.ndarray) -> np.ndarray:
+    """The engine looks a 16-bit draw h up in 1024 buckets of 64 values (count of thresholds at or below the bucket start, plus
+    ONE compare against the only threshold strictly inside the bucket).  Where several thresholds share a bucket — quality levels
+    of mass < 2^-10 each, in the two tails — all but one are moved to the nearer bucket boundary (CDF displacement <= 32/65536 at
+    those levels only); which one stays is chosen to minimise the total displacement.  Every consumer (engine, oracle) gets the
+    snapped table, so q = #{j : h >= thr[j]} holds exactly for all of them."""
+    thr = np.asarray(thr, dtype=np.int64).copy()
+    b = 0
+    while b < 1024:
+        lo, hi = 64 * b, 64 * b + 63
+        inside = np.nonzero((thr > lo) & (thr <= hi))[0]
+        if len(inside) > 1:
+            t = thr[inside]
+            best, best_cost = 0, None
+            for keep in range(len(inside)):
+                cost = int(np.sum(t[:keep] - lo) + np.sum(lo + 64 - t[keep + 1:]))
+                # thresholds below the kept one go down, those above it go up (monotone)
+                if best_cost is None or cost < best_cost:
+                    best, best_cost = keep, cost
+            thr[inside[:best]] = lo
+            thr[inside[best + 1:]] = lo + 64
+        b += 1
+    return thr.astype(np.uint32)
+
+
 def quality_pmf(sd: float, loc: float, mu: float) -> np.ndarray:
     thr = quality_thresholds(sd, loc, mu).astype(np.float64) / 65536.0
     return np.diff(np.concatenate([[0.0], thr]))
@@ -469,7 +494,7 @@ def load_model(prefix: str, *, perfect: bool = False, strandness: float | None =
                 fields = line.split("\t")
                 if len(fields) >= 4:
                     m.quals[fields[0]] = (float(fields[1]), float(fields[2]), float(fields[3]))
-        m.qual_thr = np.stack([quality_thresholds(*m.quals[nm]) for nm in NS_Q_NAMES])
+        m.qual_thr = np.stack([snap_quality_thresholds(quality_thresholds(*m.quals[nm])) for nm in NS_Q_NAMES])
     return m
 
 

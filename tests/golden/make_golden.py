@@ -759,13 +759,13 @@ def fixture_metagenome_runs(prefix, workdir, n_reads=24000):
     return out
 
 def _dist_worker(args):
-    idx, n_al, n_un, prefix, fasta, workdir, fastq, kmer = args
+    idx, n_al, n_un, prefix, fasta, workdir, fastq, kmer, chimeric = args
     S = import_reference()
     devnull = open(os.devnull, "w")
     so = sys.stdout
     sys.stdout = devnull
     try:
-        S.read_profile(fasta, [n_al + n_un], prefix, False, "genome", None, dna_type="linear", chimeric=False,
+        S.read_profile(fasta, [n_al + n_un], prefix, False, "genome", None, dna_type="linear", chimeric=chimeric,
                        homopolymer=bool(kmer), fastq=fastq)
     finally:
         sys.stdout = so
@@ -777,12 +777,12 @@ def _dist_worker(args):
     o_un = os.path.join(workdir, "un%d%s" % (idx, ext))
     sys.stdout = devnull
     try:
-        S.simulation_aligned_genome("linear", 50, S.max_chrom, None, None, o_reads, o_err, kmer, fastq, n_al, False, False)
+        S.simulation_aligned_genome("linear", 50, S.max_chrom, None, None, o_reads, o_err, kmer, fastq, n_al, False, chimeric)
         S.simulation_unaligned("linear", 50, S.max_chrom, None, None, o_un, fastq, n_un, False)
     finally:
         sys.stdout = so
     # per-read metrics
-    lens, heads, tails, refl, rev = [], [], [], [], []
+    lens, heads, tails, refl, rev, nseg = [], [], [], [], [], []
     names = []
     qual_hist = np.zeros(128, dtype=np.int64)
     step = 4 if fastq else 2
@@ -791,8 +791,9 @@ def _dist_worker(args):
     for i in range(0, len(lines) - 1, step):
         nm = lines[i][1:]
         parts = nm.split("_")
-        lens.append(len(lines[i + 1])); heads.append(int(parts[-3])); refl.append(int(parts[-2])); tails.append(int(parts[-1]))
-        rev.append(parts[-4] == "R")
+        segl = [int(x) for x in parts[-2].split(";")]                   # chimeric: one reference length per segment (S:1399-1401)
+        lens.append(len(lines[i + 1])); heads.append(int(parts[-3])); refl.append(sum(segl)); tails.append(int(parts[-1]))
+        rev.append(parts[-4] == "R"); nseg.append(len(segl))
         names.append(nm)
         if fastq:
             qual_hist += np.bincount(np.frombuffer(lines[i + 3].encode(), dtype=np.uint8) - 33, minlength=128)[:128]
@@ -810,9 +811,10 @@ def _dist_worker(args):
         lines = f.read().split("\n")
     for i in range(0, len(lines) - 1, step):
         ulens.append(len(lines[i + 1])); urev.append(lines[i].split("_")[-4] == "R")
-    first = dict(aligned=names[:5], err_rows=open(o_err).read().split("\n")[:5])
+    first = dict(aligned=names[:5], err_rows=open(o_err).read().split("\n")[:5],
+                 chimeric_names=[nm for nm in names if "_chimeric_" in nm][:8])
     return dict(lens=lens, heads=heads, tails=tails, refl=refl, rev=rev, ev=ev, ulens=ulens, urev=urev,
-                qual_hist=qual_hist, first=first)
+                qual_hist=qual_hist, first=first, nseg=nseg)
 
 
 def quantiles(x, k=2048):
@@ -821,11 +823,11 @@ def quantiles(x, k=2048):
     return x[idx].tolist()
 
 
-def fixture_distributions(prefix, fasta, workdir, n_reads, fastq, kmer=None):
+def fixture_distributions(prefix, fasta, workdir, n_reads, fastq, kmer=None, chimeric=False, n_unaligned=None):
     n_proc = min(8, os.cpu_count() or 1)
     n_al = int(round(n_reads * 19.0 / 20.0))
-    n_un = n_reads - n_al
-    args = [(i, n_al // n_proc, max(1, n_un // n_proc), prefix, fasta, workdir, fastq, kmer) for i in range(n_proc)]
+    n_un = n_reads - n_al if n_unaligned is None else n_unaligned
+    args = [(i, n_al // n_proc, max(1, n_un // n_proc), prefix, fasta, workdir, fastq, kmer, chimeric) for i in range(n_proc)]
     with mp.get_context("fork").Pool(n_proc) as pool:
         res = pool.map(_dist_worker, args)
     cat = lambda k: np.concatenate([np.asarray(r[k]) for r in res])
@@ -839,9 +841,29 @@ def fixture_distributions(prefix, fasta, workdir, n_reads, fastq, kmer=None):
         out["q_" + nm] = quantiles(ev[:, j])
         out["mean_" + nm] = float(ev[:, j].mean())
     out["mean_len"] = float(cat("lens").mean())
+    if chimeric:
+        # segments per read (S:1276-1279), bases contributed by the gaps of a chimeric read (simulation_gap, S:1355-1358, 1552-1568):
+        # read length - head - tail - sum(segment reference lengths) - inserted + deleted bases of the logged events
+        ns = cat("nseg")
+        gap = cat("lens") - cat("heads") - cat("tails") - cat("refl") - ev[:, 4] + ev[:, 5]
+        out["nseg_hist"] = np.bincount(ns, minlength=16).tolist()
+        out["q_gap_bases_chimeric"] = quantiles(gap[ns > 1])
+        out["gap_bases_nonchimeric_max_abs"] = int(np.abs(gap[ns == 1]).max())
+        out["mean_gap_bases_per_gap"] = float(gap[ns > 1].sum() / (ns[ns > 1] - 1).sum())
     if fastq:
         out["qual_hist"] = np.sum([r["qual_hist"] for r in res], axis=0).tolist()
     return out
+
+
+def write_distributions(prefix, fasta, workdir, n):
+    """Every run is large enough for the 1 % KS gate of the north star (noise floor of two 10^5-read samples: ~0.004)."""
+    d = dict(fasta=fixture_distributions(prefix, fasta, workdir, n, False, n_unaligned=n),
+             fastq=fixture_distributions(prefix, fasta, workdir, max(2000, n // 10), True),
+             hp=fixture_distributions(prefix, fasta, workdir, n, True, kmer=5, n_unaligned=8),
+             chimeric=fixture_distributions(prefix, fasta, workdir, n, False, chimeric=True, n_unaligned=8))
+    with open(os.path.join(HERE, "reference_distributions.json"), "w") as f:
+        json.dump(d, f)
+    print("reference_distributions.json written")
 
 
 def main():
@@ -851,6 +873,7 @@ def main():
     ap.add_argument("--only-meta-perfect", action="store_true", help="add runs.perfect to reference_metagenome.json, keep the rest")
     ap.add_argument("--only-trx", action="store_true", help="write reference_transcriptome.json only")
     ap.add_argument("--only-ir", action="store_true", help="write the intron-retention inputs and reference_ir.json only")
+    ap.add_argument("--only-dist", action="store_true", help="write reference_distributions.json only (whole-run distribution pins)")
     a = ap.parse_args()
     workdir = tempfile.mkdtemp(prefix="nsgolden_")
     try:
@@ -868,6 +891,9 @@ def main():
             with open(os.path.join(HERE, "reference_transcriptome.json"), "w") as f:
                 json.dump(fx, f)
             print("reference_transcriptome.json written")
+            return
+        if a.only_dist:
+            write_distributions(prefix, fasta, workdir, a.dist_reads)
             return
         if a.only_meta_perfect:
             mg = json.load(open(os.path.join(HERE, "reference_metagenome.json")))
@@ -909,11 +935,7 @@ def main():
         with open(os.path.join(HERE, "reference_metagenome.json"), "w") as f:
             json.dump(mg, f)
         if not a.skip_dist:
-            d = dict(fasta=fixture_distributions(prefix, fasta, workdir, a.dist_reads, False),
-                     fastq=fixture_distributions(prefix, fasta, workdir, max(2000, a.dist_reads // 10), True),
-                     hp=fixture_distributions(prefix, fasta, workdir, max(2000, a.dist_reads // 5), True, kmer=5))
-            with open(os.path.join(HERE, "reference_distributions.json"), "w") as f:
-                json.dump(d, f)
+            write_distributions(prefix, fasta, workdir, a.dist_reads)
     finally:
         shutil.rmtree(workdir, ignore_errors=True)
     print("golden fixtures written to", HERE)

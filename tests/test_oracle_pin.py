@@ -265,11 +265,22 @@ def test_run_length_tables_vs_reference_samplers(golden_samplers, small_model):
 def test_quality_tables_vs_reference(golden_samplers, small_model):
     for name, fx in golden_samplers["quals"].items():
         cls = M.NS_Q_NAMES.index(name)
-        thr = small_model.qual_thr[cls].astype(np.float64) / 65536.0
-        pmf = np.diff(np.concatenate([[0.0], thr]))         # P(q = j), j = 0..127
         exact = np.zeros(128)
         exact[1:93] = fx["pmf_1_92"]
-        assert np.max(np.abs(np.cumsum(pmf) - np.cumsum(exact))) <= 1.0 / 65536.0 + 1e-12
+        raw = M.quality_thresholds(*small_model.quals[name])          # 16-bit thresholds of the closed form: exact to half a unit
+        assert np.max(np.abs(raw.astype(np.float64) / 65536.0 - np.cumsum(exact))) <= 1.0 / 65536.0 + 1e-12
+        # the table the engine and the oracle use: where several thresholds share a 64-wide bucket of the draw (levels of mass
+        # < 2^-10 in the tails) all but one sit on the nearer bucket boundary — at most 32/65536 away from the closed form
+        snapped = small_model.qual_thr[cls]
+        assert np.array_equal(snapped, M.snap_quality_thresholds(raw)) and np.all(np.diff(snapped.astype(np.int64)) >= 0)
+        moved = np.nonzero(snapped != raw)[0]
+        assert np.max(np.abs(snapped.astype(np.int64) - raw.astype(np.int64))) <= 32
+        assert np.all((raw[moved] < 64 * 8) | (raw[moved] > 65536 - 64 * 8)), "only the tails (mass < 1 %) are touched"
+        for b in range(1024):
+            assert np.sum((snapped > 64 * b) & (snapped <= 64 * b + 63)) <= 1
+        thr = snapped.astype(np.float64) / 65536.0
+        pmf = np.diff(np.concatenate([[0.0], thr]))         # P(q = j), j = 0..127
+        assert np.max(np.abs(np.cumsum(pmf) - np.cumsum(exact))) <= 33.0 / 65536.0
         hist = np.array(fx["hist"], dtype=np.float64)
         n = hist.sum()
         assert np.max(np.abs(np.cumsum(hist) / n - np.cumsum(exact))) < 0.005
