@@ -71,9 +71,13 @@ struct GenArgs {
     uint32_t hp;                     // -k active for this batch
     uint32_t dbg;                    // NS_DEBUG_SKIP (profiling only)
     uint32_t errlen_later;           // the error-profile size of a read is computed by k_errlen / k_hp_filter_w, not by k_chain
-    uint8_t *scr, *scrq;             // -k: pre-homopolymer reads (forward strand) and their quality characters
-    uint64_t *scr_len, *scr_off;
+    uint8_t *scr;                    // -k: the pieces of every read before mutate_homo (forward strand; FASTQ: with their class bits)
+    uint64_t *scr_len, *scr_off;     //     bytes per read / exclusive scan
     uint32_t *hp_len;                // -k: final emitted length per piece
+    ns_event *hp_ev;                 // -k: the homopolymer edits of every aligned piece as an event list over its scratch bytes
+    uint32_t *hp_wd;                 //     (k_hp_events; format: materialise_piece, MAT_HP_FINAL) and the letter word of every event
+    uint32_t *hp_nev;                //     events per piece
+    uint32_t hp_shift, hp_pad;       //     capacity of a piece: (scratch bytes >> hp_shift) + hp_pad events (hp_ev_slot)
     // metagenome (one pass = one `while remaining_reads` iteration of S:836-1036)
     uint32_t meta;                   // 0 genome, 1 metagenome
     uint32_t nspecies;
@@ -628,12 +632,6 @@ __device__ __forceinline__ bool load_read_uniform(const GenArgs &A, uint64_t r, 
     ro.seq = A.records + rd.rec_off + uni(A.name_len[r]) + 2;
     ro.qual = fastq ? ro.seq + rd.seq_len + 3 : nullptr;
     ro.seq_len = rd.seq_len; ro.reversed = rd.reversed != 0; ro.uracil = A.prm.uracil != 0;
-    if (A.hp) {                                  // -k: forward-strand pre-homopolymer read into the scratch buffer
-        const uint64_t so = uni64(A.scr_off[r]);
-        ro.seq = A.scr + so;
-        ro.qual = fastq ? A.scrq + so : nullptr;
-        ro.reversed = false; ro.uracil = false;      // (strand and T -> U are applied by k_hp_write)
-    }
     return true;
 }
 
@@ -662,13 +660,21 @@ __global__ void __launch_bounds__(64) k_words(GenArgs A, uint32_t *ev_word) {
 #ifndef NS_MATQ_WAVES
 #define NS_MATQ_WAVES 4
 #endif
-template <bool FASTQ>
-__global__ void __launch_bounds__(FASTQ ? 64 * NS_MATQ_WAVES : 64, FASTQ ? 4 : NS_MAT_WAVES)
+#ifndef NS_MATQ_MINW
+#define NS_MATQ_MINW 4          // waves per SIMD the FASTQ kernel is compiled for
+#endif
+// first event slot / capacity of the homopolymer edits of the piece whose scratch bytes start at `pos` (bytes from the start of the
+// scratch buffer) and that is piece `piece` of the batch: a monotone function of both, so no scan is needed
+__device__ __forceinline__ uint64_t hp_ev_slot(const GenArgs &A, uint64_t pos, uint32_t piece) { return (pos >> A.hp_shift) + (uint64_t)A.hp_pad * piece; }
+
+template <bool FASTQ, int MODE>
+__global__ void __launch_bounds__((FASTQ && MODE != MAT_HP_SCRATCH) ? 64 * NS_MATQ_WAVES : 64, (FASTQ && MODE != MAT_HP_SCRATCH) ? NS_MATQ_MINW : NS_MAT_WAVES)
 k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, const uint32_t *order) {
-    constexpr uint32_t WAVES = FASTQ ? NS_MATQ_WAVES : 1;
+    constexpr bool QUALS = FASTQ && MODE != MAT_HP_SCRATCH;
+    constexpr uint32_t WAVES = QUALS ? NS_MATQ_WAVES : 1;
     __shared__ TileLds Ts[WAVES];
-    __shared__ __align__(16) uint16_t qlut[FASTQ ? NS_QLUT_SLOTS * 1024u : 8u];
-    if constexpr (FASTQ) { qual_lut_load(qlut, A.m, threadIdx.x, 64 * WAVES); __syncthreads(); }
+    __shared__ __align__(16) uint16_t qlut[QUALS ? NS_QLUT_SLOTS * 1024u : 8u];
+    if constexpr (QUALS) { qual_lut_load(qlut, A.m, threadIdx.x, 64 * WAVES); __syncthreads(); }
     const uint32_t wave = WAVES > 1 ? threadIdx.x >> 6 : 0u;
     TileLds &T = Ts[wave];
     const uint32_t lane = WAVES > 1 ? threadIdx.x & 63u : threadIdx.x;
@@ -676,15 +682,43 @@ k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, co
     if (slot >= A.prm.n_reads) return;
     const uint64_t r = order ? (uint64_t)uni(order[slot]) : slot;
     ns_read rd; ns_key key; ReadOut ro;
-    if (!load_read_uniform(A, r, FASTQ, rd, key, ro)) return;
+    if (!load_read_uniform(A, r, QUALS, rd, key, ro)) return;
     const uint32_t a = rd.attempts;
     tile_lds_init(T, lane);
     QualState Q; Q.lut = qlut; qual_state_reset(Q);
+    if constexpr (MODE == MAT_HP_SCRATCH) {
+        // -k, first pass: the pieces of the read before mutate_homo, forward strand, one after the other in the scratch buffer
+        // (head, tail and polyA are written by the second pass; strand and T -> U are applied there)
+        ro.seq = A.scr + uni64(A.scr_off[r]); ro.qual = nullptr; ro.reversed = false; ro.uracil = false;
+        uint32_t q = 0;
+        for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
+            const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi, ev_word);
+            materialise_piece<FASTQ, MODE>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, Q);
+            q += pc.out_len;
+        }
+        return;
+    }
     if (!(dbg & 8)) emit_head_tail(A.m, ro, key, a, rd.head, rd.tail, lane);                                             // S:1426-1427
     uint32_t q = rd.head;
+    uint64_t q_in = MODE == MAT_HP_FINAL ? uni64(A.scr_off[r]) : 0;
     for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
-        const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi, ev_word);
-        materialise_piece<FASTQ, MAT_REF>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, Q);
+        PieceCtx pc;
+        if constexpr (MODE == MAT_HP_FINAL) {
+            // the source is the scratch piece, the events are the homopolymer edits k_hp_events filed for it (mutate_homo, S:618-705)
+            const uint32_t gp = rd.piece_off + pi;
+            const ns_piece p = A.pieces[gp];
+            const uint64_t eo = hp_ev_slot(A, q_in, gp);
+            pc.kind = uni(p.kind);
+            pc.ev = A.hp_ev + eo; pc.wd = A.hp_wd + eo; pc.n_ev = pc.kind ? 0u : uni(A.hp_nev[gp]);
+            pc.ref_len = uni(p.out_len); pc.out_len = pc.kind ? pc.ref_len : uni(A.hp_len[gp]);
+            pc.chrom_base = (uint64_t)((uintptr_t)A.scr - (uintptr_t)A.ref.bases) + q_in; pc.chrom_len = ~0ull; pc.pos = 0;
+            pc.sid = pc.kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
+            q_in += pc.ref_len;
+        } else pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi, ev_word);
+        materialise_piece<FASTQ, MODE>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, Q);
+        if constexpr (MODE == MAT_HP_FINAL) {            // report the emitted length, like the path without -k
+            if (lane == 0 && !pc.kind) A.pieces[rd.piece_off + pi].out_len = pc.out_len;
+        }
         q += pc.out_len;
     }
     if (A.polya) {                                                                          // transcriptome: polyA tail (S:1224-1225)
@@ -712,67 +746,27 @@ __global__ void __launch_bounds__(64) k_materialise_dense(GenArgs A) {
     }
 }
 
-// the tiles k_materialise could not take: generic per-byte path, one wavefront per queued tile
-template <bool FASTQ>
+// the tiles k_materialise could not take: generic per-byte path, one wavefront per queued tile.  SCRATCH: first record pass of -k
+template <bool FASTQ, bool SCRATCH>
 __global__ void __launch_bounds__(64) k_materialise_slow(GenArgs A, SlowQueue sq) {
     const uint32_t lane = threadIdx.x;
     const uint32_t n = min(*sq.count, sq.cap);
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
         const SlowTile t = sq.items[i];
         ns_read rd; ns_key key; ReadOut ro;
-        if (!load_read_uniform(A, t.read, FASTQ, rd, key, ro)) continue;
-        uint32_t q = rd.head;
+        if (!load_read_uniform(A, t.read, FASTQ && !SCRATCH, rd, key, ro)) continue;
+        uint32_t q = SCRATCH ? 0u : rd.head;
+        if constexpr (SCRATCH) { ro.seq = A.scr + A.scr_off[t.read]; ro.qual = nullptr; ro.reversed = false; ro.uracil = false; }
         for (uint32_t pi = 0; pi < t.piece; ++pi) q += A.pieces[rd.piece_off + pi].out_len;
         const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + t.piece], t.piece);
-        slow_piece_range(A.m, A.ref, ro, key, rd.attempts, pc, q, t.m0, t.m1, lane);
+        slow_piece_range<FASTQ && SCRATCH>(A.m, A.ref, ro, key, rd.attempts, pc, q, t.m0, t.m1, lane);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // -k kernels (ns_hp.h)
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_hp_filter(GenArgs A) {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r > A.prm.n_reads) return;
-    if (r == A.prm.n_reads) { A.scr_len[r] = 0; return; }
-    ns_read rd = A.reads[r];
-    if (rd.flags) { A.scr_len[r] = 0; return; }
-    const ns_key key = read_key(A, r);
-    const uint32_t a = rd.attempts;
-    const int64_t k = (int64_t)A.prm.kmer_bias;
-    const uint32_t nl = A.name_len[r];
-    uint64_t seq_len = (uint64_t)rd.head + rd.tail, err_len = 0;
-    for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
-        ns_piece p = A.pieces[rd.piece_off + pi];
-        if (!p.kind) {
-            const PieceCtx pc = load_piece(A.events, A.ref, p, pi);
-            ns_event *ev = A.events + p.ev_off;
-            uint32_t w = 0; int32_t shift = 0;
-            for (uint32_t j = 0; j < p.n_ev; ++j) {                       // S:1929-1947
-                const ns_event e = ev[j];
-                const int64_t pos = e.pos, len = ns_ev_len(e.info); const uint32_t ty = ns_ev_type(e.info);
-                const int64_t lo = ty == NS_INS ? pos - 1 : pos, hi = pos + len - 1;
-                bool hit = false;
-                for (int64_t x = lo; x <= hi && !hit; ++x) hit = in_hp_run(A.ref, pc, key, a, x, k);
-                if (hit) continue;
-                ns_event o; o.pos = e.pos; o.info = ns_ev_pack((uint32_t)len, ty, shift);
-                ev[w++] = o;
-                if (ty == NS_INS) shift += (int32_t)len; else if (ty == NS_DEL) shift -= (int32_t)len;
-                err_len += nl + dec_digits(e.pos) + dec_digits((uint32_t)len) + 2u * (uint32_t)len + 9u;
-            }
-            p.n_ev = w; p.out_len = (uint32_t)((int32_t)p.ref_len + shift);
-            A.pieces[rd.piece_off + pi] = p;
-        }
-        seq_len += p.out_len;
-    }
-    if (A.polya) seq_len += A.polya[r];             // transcriptome: the polyA tail sits between the segment and the tail
-    rd.seq_len = (uint32_t)seq_len;                 // pre-homopolymer length (layout of the scratch read)
-    A.reads[r] = rd;
-    A.scr_len[r] = seq_len;
-    A.err_len[r] = A.prm.emit_errlog ? err_len : 0;
-}
-
-// the same, one read per wavefront: lane per event (the homopolymer test of an event is independent of the others), ballot /
+// -k filter of mutate_read (S:1929-1947), one read per wavefront: lane per event (the homopolymer test of an event is independent of the others), ballot /
 // prefix-popcount compaction, exclusive wavefront prefix sum of the length changes for the shift field
 __global__ void __launch_bounds__(64 * NS_WPB) k_hp_filter_w(GenArgs A) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -785,7 +779,7 @@ __global__ void __launch_bounds__(64 * NS_WPB) k_hp_filter_w(GenArgs A) {
     const uint32_t a = rd.attempts;
     const int64_t k = (int64_t)A.prm.kmer_bias;
     const uint32_t nl = A.name_len[r];
-    uint64_t seq_len = (uint64_t)rd.head + rd.tail, err_len = 0;
+    uint64_t seq_len = (uint64_t)rd.head + rd.tail, err_len = 0, scr_len = 0;
     for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
         ns_piece p = A.pieces[rd.piece_off + pi];
         if (!p.kind) {
@@ -824,14 +818,14 @@ __global__ void __launch_bounds__(64 * NS_WPB) k_hp_filter_w(GenArgs A) {
             p.n_ev = w; p.out_len = (uint32_t)((int32_t)p.ref_len + shift);
             if (lane == 0) A.pieces[rd.piece_off + pi] = p;
         }
-        seq_len += p.out_len;
+        seq_len += p.out_len; scr_len += p.out_len;
     }
     err_len = wave_sum(err_len);
     if (A.polya) seq_len += A.polya[r];             // transcriptome: the polyA tail sits between the segment and the tail
     if (lane == 0) {
-        rd.seq_len = (uint32_t)seq_len;             // pre-homopolymer length (layout of the scratch read)
+        rd.seq_len = (uint32_t)seq_len;             // length before mutate_homo
         A.reads[r] = rd;
-        A.scr_len[r] = seq_len;
+        A.scr_len[r] = scr_len;                     // the scratch buffer holds the pieces
         A.err_len[r] = A.prm.emit_errlog ? err_len : 0;
     }
 }
@@ -866,88 +860,168 @@ __device__ inline void hp_final_length(const GenArgs &A, uint64_t r, ns_read &rd
     }
 }
 
-// k_hp_count, one read per wavefront (k <= 16): runs are found 1024 bases at a time (ns_hp.h: hp_tile), a run belongs to the lane
-// that holds its first base.  The long runs of a segment are collected in an LDS list and their new lengths drawn one lane per run
-// (k >= 4; a tile holds at most 1024 / k of them) — drawn inside the tile loop, the 3-4 runs of a tile cost every lane of the
-// wavefront a Philox block and an inverse normal CDF per tile.
-#define NS_HPC_LIST 512u
+// k_hp_events — mutate_homo (S:618-705) as an EDIT LIST over the pre-homopolymer read in the scratch buffer, one read per wavefront.
+// The run scan (S:627-637) streams a piece 1024 bases at a time, 16 per lane, and looks BACKWARDS only: a base that differs from its
+// predecessor starts a run and thereby closes the previous one, whose start is the nearest run start before it — in the lane's own
+// chunk, in the nearest lower lane that has one (ballot + one cross-lane read), or carried over from the earlier tiles in an SGPR.  So
+// there is no look-ahead, no dependent load, and the loads of the next tiles are in flight while a tile is scanned.  The runs of >= k
+// bases go to an LDS list, which is drained one lane per run: new length (S:644-665), the mismatches among the new bases
+// (S:668-684), and from them the events the second record pass applies (materialise_piece, MAT_HP_FINAL): a deletion for a
+// contraction, insertions of <= 15 letters for an expansion, one-base substitutions.  Wavefront prefix sums give every run its event
+// slots and its cumulative shift.  Also: the final length of every piece and of the read (checked by k_hp_finalize, S:1429-1430).
+#define NS_HPC_LIST 1088u
 struct HpCountLds { uint32_t s0[NS_HPC_LIST], len[NS_HPC_LIST]; uint8_t base[NS_HPC_LIST]; };
 #ifndef NS_HPC_WAVES
 #define NS_HPC_WAVES 4
 #endif
-__global__ void __launch_bounds__(64 * NS_WPB, NS_HPC_WAVES) k_hp_count_w(GenArgs A) {
+__device__ __forceinline__ uint4 hp_load16(const uint8_t *__restrict__ sq, uint32_t n, uint32_t c) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (c < n) __builtin_memcpy(&v, sq + c, 16);                      // (the scratch buffer has slack behind the last read)
+    return v;
+}
+__global__ void __launch_bounds__(64 * NS_WPB, NS_HPC_WAVES) k_hp_events(GenArgs A, uint64_t *__restrict__ hp_final) {
     __shared__ HpCountLds list_lds[NS_WPB];
     HpCountLds &R = list_lds[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    unsigned long long st_bases = 0, st_fail = 0;
-    if (r < A.prm.n_reads) {
-        ns_read rd = A.reads[r];
-        if (!rd.flags) {
-            const ns_key key = read_key(A, r);
-            const uint32_t a = rd.attempts, k = A.prm.kmer_bias;
-            const bool listed = k >= 4;
-            const uint8_t *scr = A.scr + A.scr_off[r];
-            uint64_t q = rd.head, final_len = (uint64_t)rd.head + rd.tail + (A.polya ? A.polya[r] : 0u);
-            for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
-                const ns_piece p = A.pieces[rd.piece_off + pi];
-                uint32_t flen = p.out_len;
-                if (!p.kind) {
-                    const uint32_t sid = pi >> 1, n = p.out_len;
-                    const uint8_t *sq = scr + q;
-                    long long delta = 0;
-                    int32_t last_before = -1;
-                    uint32_t n_list = 0;                                                 // runs waiting in the list (wave-uniform)
-                    auto drain = [&]() {
-                        wave_sync();
-                        for (uint32_t j = lane; j < n_list; j += 64)
-                            delta += (long long)hp_new_size(A.m, key, sid, a, R.s0[j], R.len[j], R.base[j]) - (long long)R.len[j];
-                        wave_sync();
-                        n_list = 0;
-                    };
-                    HpRaw raw0 = hp_load(sq, n, 0, lane), raw1 = hp_load(sq, n, 1024, lane);     // two tiles ahead
-                    uint32_t M0 = hp_starts(raw0, n, 0, lane);
-                    for (uint32_t t0 = 0; t0 < n; t0 += 1024) {
-                        const HpRaw raw2 = hp_load(sq, n, t0 + 2048, lane);
-                        const uint32_t M1 = hp_starts(raw1, n, t0 + 1024, lane);
-                        const uint32_t nts = hp_next_tile_start(M1, sq, n, t0 + 1024, lane);
-                        const HpTile t = hp_tile_from(raw0, M0, t0, lane, k, last_before, nts);
-                        raw0 = raw1; M0 = M1; raw1 = raw2;
-                        last_before = t.tile_last;
-                        const uint32_t c = t0 + 16 * lane;
-                        uint32_t slot = 0, n_tile = 0;
-                        if (listed) {
-                            const uint32_t rc = (uint32_t)__builtin_popcount(t.C), incl = wave_incl_scan(rc);
-                            slot = n_list + incl - rc;
-                            n_tile = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                        }
-                        for (uint32_t Cm = t.C; Cm; Cm &= Cm - 1) {                     // long runs that start in this lane's chunk
-                            const uint32_t b = (uint32_t)__builtin_ctz(Cm), higher = t.M & ~((2u << b) - 1u);
-                            const uint32_t s0 = c + b, e = higher ? c + (uint32_t)__builtin_ctz(higher) : t.next_start;
-                            const uint32_t wv = b < 8 ? (b < 4 ? t.v.x : t.v.y) : (b < 12 ? t.v.z : t.v.w);
-                            const uint32_t base = (wv >> (8 * (b & 3))) & 0xffu;
-                            if (listed) { R.s0[slot] = s0; R.len[slot] = e - s0; R.base[slot] = (uint8_t)base; ++slot; }
-                            else delta += (long long)hp_new_size(A.m, key, sid, a, s0, e - s0, base) - (long long)(e - s0);
-                        }
-                        n_list += n_tile;
-                        if (n_list > NS_HPC_LIST - 256u) drain();                        // (the next tile may bring 1024 / k <= 256 more)
+    if (r >= A.prm.n_reads) return;
+    const ns_read rd = A.reads[r];
+    if (rd.flags) return;
+    const ns_key key = read_key(A, r);
+    const uint32_t a = rd.attempts, k = A.prm.kmer_bias;
+    const uint64_t scr_off = uni64(A.scr_off[r]);
+    bool over = false;
+    uint64_t q = 0, final_len = (uint64_t)rd.head + rd.tail + (A.polya ? A.polya[r] : 0u);
+    for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
+        const uint32_t gp = rd.piece_off + pi;
+        const ns_piece p = A.pieces[gp];
+        const uint32_t n = uni(p.out_len);
+        uint32_t flen = n;
+        if (!uni(p.kind)) {
+            const uint32_t sid = pi >> 1;
+            const uint8_t *sq = A.scr + scr_off + q;
+            const uint64_t ev0 = hp_ev_slot(A, scr_off + q, gp);
+            const uint64_t cap64 = hp_ev_slot(A, scr_off + q + n, gp + 1) - ev0;
+            const uint32_t cap = cap64 > 0xffffffffull ? 0xffffffffu : (uint32_t)cap64;
+            ns_event *ev = A.hp_ev + ev0;
+            uint32_t *wd = A.hp_wd + ev0;
+            uint32_t n_ev = 0, shift = 0;                                      // events filed / cumulative length change (wave-uniform)
+            uint32_t n_list = 0;                                                 // runs waiting in the list (wave-uniform)
+            // long runs one tile can close: 16 / k + 1 per chunk for k >= 4, one per base below.  The scan loop runs while the list has
+            // room for a tile's worth; the drain sits OUTSIDE it (inside, its registers push the prefetched tiles into scratch memory)
+            const uint32_t tile_max = k >= 4 ? 64u * (16u / k + 1u) : 1024u;
+            uint32_t carry_byte = 0xffu;                                         // base in front of the tile (0xff: none)
+            uint32_t open_start = 0;                                             // start of the run that is open where the tile begins
+            uint32_t t0 = 0;
+            do {
+                uint4 v0 = hp_load16(sq, n, t0 + 16 * lane), v1 = hp_load16(sq, n, t0 + 1024 + 16 * lane), v2 = hp_load16(sq, n, t0 + 2048 + 16 * lane);
+                for (; t0 < n && n_list + tile_max + 1u <= NS_HPC_LIST; t0 += 1024) {
+                    const uint4 v = v0;
+                    v0 = v1; v1 = v2; v2 = hp_load16(sq, n, t0 + 3072 + 16 * lane);   // three tiles ahead
+                    const uint32_t c = t0 + 16 * lane;
+                    const uint32_t valid = c >= n ? 0u : min(16u, n - c);
+                    // base in front of the chunk: the neighbouring lane's last base, for lane 0 the carry
+                    const uint32_t pb = dpp_wave_shr1(carry_byte, v.w >> 24) & 0xffu;
+                    const uint32_t p0 = v.x << 8 | pb, p1 = v.y << 8 | v.x >> 24, p2 = v.z << 8 | v.y >> 24, p3 = v.w << 8 | v.z >> 24;
+                    // bit b: a run starts at base b of the chunk (the class bits of the bases do not take part in the comparison)
+                    uint32_t M = movemask4(nonzero_bytes((v.x ^ p0) & NS_CLS_STRIP)) | movemask4(nonzero_bytes((v.y ^ p1) & NS_CLS_STRIP)) << 4 |
+                                 movemask4(nonzero_bytes((v.z ^ p2) & NS_CLS_STRIP)) << 8 | movemask4(nonzero_bytes((v.w ^ p3) & NS_CLS_STRIP)) << 12;
+                    M &= (1u << valid) - 1u;
+                    // the nearest run start before the chunk: last start of the nearest lower lane that has one, else the carry
+                    const uint64_t B = __ballot(M != 0);
+                    const uint64_t below_l = B & ((1ull << lane) - 1ull);
+                    const uint32_t last_own = c + 31u - (uint32_t)__clz((int)M);      // (garbage when M == 0: never read then)
+                    const uint32_t from = below_l ? 63u - (uint32_t)__clzll((long long)below_l) : lane;
+                    const uint32_t ps_l = (uint32_t)__shfl((int)last_own, (int)from);
+                    const uint32_t ps = below_l ? ps_l : open_start;
+                    const uint32_t back = c - ps;                                   // >= 1 for c > 0 (position 0 always starts a run)
+                    // window: bit 16 + b = base b of the chunk, bits < 16 = the 16 bases in front of it
+                    uint32_t W = M << 16;
+                    if (c && back <= 16u) W |= 1u << (16u - back);
+                    // a run ENDS in front of every start except position 0; it has >= k bases iff no start lies among the k - 1 positions
+                    // before its end (a start further back than the window leaves the test true: the run is then longer than 16)
+                    uint32_t E = M << 16;
+                    if (c == 0) E &= ~(1u << 16);
+                    if (k <= 16) { for (uint32_t sft = 1; sft < k; ++sft) E &= ~(W << sft); }
+                    else E = (M && c && back + (uint32_t)__builtin_ctz(M) >= k) ? (M & (0u - M)) << 16 : 0u;   // only the run closed by the first start
+                    // ---- the long runs that end in front of the window bits E go to the list
+                    const uint32_t rc = (uint32_t)__builtin_popcount(E), incl = wave_incl_scan(rc);
+                    uint32_t slot = n_list + incl - rc;
+                    for (uint32_t Em = E; Em; Em &= Em - 1, ++slot) {
+                        const uint32_t b = (uint32_t)__builtin_ctz(Em);                 // the run ends in front of window bit b
+                        const uint32_t below = W & ((1u << b) - 1u);                      // its start: the nearest start before it —
+                        const uint32_t st = below ? c - 16u + 31u - (uint32_t)__clz((int)below) : ps;   // in the window, or further back
+                        // base of the run = the base in front of bit b: chunk byte b - 17, or the byte in front of the chunk
+                        const uint32_t i = b - 17u;
+                        const uint32_t wv = b == 16u ? pb : (i < 8 ? (i < 4 ? v.x : v.y) : (i < 12 ? v.z : v.w)) >> (8 * (i & 3));
+                        R.s0[slot] = st; R.len[slot] = c - 16u + b - st; R.base[slot] = (uint8_t)(wv & 0xd7u);
                     }
-                    if (n_list) drain();
-                    unsigned long long du = wave_sum((unsigned long long)delta);
-                    flen = (uint32_t)((long long)n + (long long)du);
+                    n_list += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    // carries
+                    if (B) open_start = (uint32_t)__shfl((int)last_own, 63 - __clzll((long long)B));
+                    carry_byte = (uint32_t)__builtin_amdgcn_readlane((int)(v.w >> 24), 63);
                 }
-                if (lane == 0) A.hp_len[rd.piece_off + pi] = flen;
-                final_len += flen;
-                q += p.out_len;
-            }
-            if (lane == 0) hp_final_length(A, r, rd, a, final_len, st_bases, st_fail);
+                if (t0 >= n && n && n - open_start >= k) {                       // the run that is open at the end of the piece
+                    if (lane == 0) { R.s0[n_list] = open_start; R.len[n_list] = n - open_start; R.base[n_list] = (uint8_t)(sq[n - 1] & 0xd7u); }
+                    ++n_list;
+                }
+                // ---- drain: one lane per run
+                wave_sync();
+                for (uint32_t j0 = 0; j0 < n_list; j0 += 64) {
+                    const uint32_t j = j0 + lane;
+                    const bool on = j < n_list;
+                    uint32_t s0 = 0, L = 0, base = 'A', size = 0, ne = 0, slot = 0, sh = 0, d_incl = 0, ne_incl = 0;
+                    if (on) { s0 = R.s0[j]; L = R.len[j]; base = R.base[j]; size = hp_new_size(A.m, key, sid, a, s0, L, base); }
+                    for (uint32_t pass = 0; pass < 2; ++pass) {                 // 0: count the run's events, 1: file them
+                        if (on && (pass == 0 || slot + ne <= cap))
+                            ne = hp_run_events(A.m.hp_mis_rate, key, sid, a, s0, L, size, base, [&](uint32_t pos, uint32_t ty, uint32_t len, uint32_t word) {
+                                if (!pass) return;
+                                ns_event e; e.pos = pos; e.info = ns_ev_pack(len, ty, (int32_t)sh);
+                                ev[slot] = e; wd[slot] = word; ++slot;
+                                if (ty == NS_INS) sh += len; else if (ty == NS_DEL) sh -= len;
+                            });
+                        if (!pass) {
+                            const uint32_t d = on ? size - L : 0u;               // (mod 2^32)
+                            ne_incl = wave_incl_scan(ne); d_incl = wave_incl_scan(d);
+                            slot = n_ev + ne_incl - ne; sh = shift + d_incl - d;
+                        }
+                    }
+                    n_ev += (uint32_t)__builtin_amdgcn_readlane((int)ne_incl, 63);
+                    shift += (uint32_t)__builtin_amdgcn_readlane((int)d_incl, 63);
+                }
+                wave_sync();
+                n_list = 0;
+            } while (t0 < n);
+            if (n_ev > cap) over = true;
+            flen = n + shift;
+            if (lane == 0) A.hp_nev[gp] = min(n_ev, cap);
         }
-        // emitted bases of the read: summed by k_sum_u64 afterwards (one atomic per read on one address costs ~10 ns each: 10 ms per
-        // 10^6 reads, more than the rest of this kernel)
-        if (lane == 0) A.scr_len[r] = st_bases;
+        if (lane == 0) A.hp_len[gp] = flen;
+        final_len += flen;
+        q += n;
+    }
+    if (lane == 0) {
+        hp_final[r] = final_len;                                                // (checked by k_hp_finalize, S:1429-1430)
+        if (over) atomicAdd(&A.stats[7], 1ull);                                 // a piece outgrew its event capacity: the kernel is repeated with more
+    }
+}
+
+// the final length check of every read (S:1429-1430 / metagenome S:1023-1024) once k_hp_events has run without a capacity overflow
+__global__ void __launch_bounds__(256) k_hp_finalize(GenArgs A, const uint64_t *__restrict__ final_len) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long st_bases = 0, st_fail = 0;
+    if (r < A.prm.n_reads && !A.stats[7]) {
+        ns_read rd = A.reads[r];
+        if (!rd.flags) hp_final_length(A, r, rd, rd.attempts, final_len[r], st_bases, st_fail);
+        A.scr_len[r] = st_bases;                    // emitted bases of the read: summed by k_sum_u64 afterwards
     }
     st_fail = wave_sum(st_fail);
     if ((threadIdx.x & 63) == 0 && st_fail) atomicAdd(&A.stats[5], st_fail);
+}
+// batches without records: the pieces report their emitted length, like the path without -k
+__global__ void __launch_bounds__(256) k_hp_report(GenArgs A, uint64_t n_pieces) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_pieces && !A.pieces[i].kind) A.pieces[i].out_len = A.hp_len[i];
 }
 
 // sum of v[0 .. n) added to *dst: grid-stride, one atomic per wavefront
@@ -956,421 +1030,6 @@ __global__ void __launch_bounds__(256) k_sum_u64(const uint64_t *__restrict__ v,
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) acc += v[i];
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0 && acc) atomicAdd(dst, acc);
-}
-
-__global__ void __launch_bounds__(256) k_hp_count(GenArgs A) {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long st_bases = 0, st_fail = 0;
-    if (r < A.prm.n_reads) {
-        ns_read rd = A.reads[r];
-        if (!rd.flags) {
-            const ns_key key = read_key(A, r);
-            const uint32_t a = rd.attempts, k = A.prm.kmer_bias;
-            const uint8_t *scr = A.scr + A.scr_off[r];
-            uint64_t q = rd.head, final_len = (uint64_t)rd.head + rd.tail + (A.polya ? A.polya[r] : 0u);
-            for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
-                const ns_piece p = A.pieces[rd.piece_off + pi];
-                uint32_t flen = p.out_len;
-                if (!p.kind) {
-                    const uint32_t sid = pi >> 1, n = p.out_len;
-                    const uint8_t *sq = scr + q;
-                    int64_t delta = 0;
-                    for (uint32_t s = 0; s < n;) {                        // mutate_homo run scan, S:627-637
-                        const uint8_t b = sq[s];
-                        uint32_t e = s + 1;
-                        while (e < n && sq[e] == b) ++e;
-                        if (e - s >= k) delta += (int64_t)hp_new_size(A.m, key, sid, a, s, e - s, b) - (int64_t)(e - s);
-                        s = e;
-                    }
-                    flen = (uint32_t)((int64_t)n + delta);
-                }
-                A.hp_len[rd.piece_off + pi] = flen;
-                final_len += flen;
-                q += p.out_len;
-            }
-            hp_final_length(A, r, rd, a, final_len, st_bases, st_fail);
-        }
-    }
-    st_bases = wave_sum(st_bases); st_fail = wave_sum(st_fail);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&A.stats[1], st_bases); if (st_fail) atomicAdd(&A.stats[5], st_fail); }
-}
-
-// scratch (pre-homopolymer, forward) -> final record: runs re-sampled, mismatches, qualities, reverse complement
-__global__ void __launch_bounds__(256) k_hp_write(GenArgs A) {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= A.prm.n_reads) return;
-    const ns_read rd = A.reads[r];
-    if (rd.flags) return;
-    if (!A.prm.emit_records) {
-        for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) A.pieces[rd.piece_off + pi].out_len = A.hp_len[rd.piece_off + pi];
-        return;
-    }
-    const ns_key key = read_key(A, r);
-    const uint32_t a = rd.attempts, k = A.prm.kmer_bias;
-    const bool fq = A.prm.fastq != 0, rev = rd.reversed != 0, ura = A.prm.uracil != 0;
-    const uint32_t L = rd.seq_len;                                         // final length
-    uint8_t *seq = A.records + rd.rec_off + A.name_len[r] + 2;
-    uint8_t *qual = fq ? seq + L + 3 : nullptr;
-    const uint8_t *scr = A.scr + A.scr_off[r];
-    const uint8_t *scq = fq ? A.scrq + A.scr_off[r] : nullptr;
-    uint32_t o = 0;                                                        // output cursor, pre-revcomp coordinates
-    auto put = [&](uint32_t b, uint32_t qc) {
-        const uint32_t oo = rev ? L - 1 - o : o;
-        uint8_t ob = rev ? complement(b) : (uint8_t)b;
-        if (ura && ob == 'T') ob = 'U';                                    // --uracil, S:1247-1248
-        seq[oo] = ob;
-        if (fq) qual[oo] = (uint8_t)qc;
-        ++o;
-    };
-    uint64_t q = 0;
-    for (uint32_t i = 0; i < rd.head; ++i, ++q) put(scr[q], fq ? scq[q] : 0);
-    for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
-        ns_piece p = A.pieces[rd.piece_off + pi];
-        const uint32_t n = p.out_len;
-        if (p.kind) { for (uint32_t i = 0; i < n; ++i, ++q) put(scr[q], fq ? scq[q] : 0); continue; }
-        const uint32_t sid = pi >> 1;
-        const uint8_t *sq = scr + q;
-        const uint8_t *qq = fq ? scq + q : nullptr;
-        for (uint32_t s = 0; s < n;) {
-            const uint32_t b = sq[s];
-            uint32_t e = s + 1;
-            while (e < n && sq[e] == b) ++e;
-            const uint32_t len = e - s;
-            if (len < k) { for (uint32_t x = s; x < e; ++x) put(sq[x], fq ? qq[x] : 0); s = e; continue; }
-            const uint32_t size = hp_new_size(A.m, key, sid, a, s, len, b);
-            const uint32_t o_run = o;
-            int64_t first_mis = -1;
-            for (uint32_t i = 0; i < size; ++i) {                          // S:668-684, qualities S:686-695
-                bool is_mis; uint32_t nb, qc = 0;
-                if (size <= len || i < len) {
-                    const uint32_t pp = size <= len ? s + (len - size) + i : s + i;
-                    nb = hp_base(A.m, b, key, sid, a, pp, 0, is_mis);
-                    if (fq) qc = qq[pp];
-                } else {
-                    const uint32_t j = i - len;
-                    nb = hp_base(A.m, b, key, sid, a, e, 1 + j, is_mis);
-                    if (fq) {
-                        u32x4 w = ns_draw(key, ST_HPQ, sid, a, e, 1 + (j >> 3));
-                        const uint32_t h = (ns_word(w, (j & 7) >> 1) >> (16 * (j & 1))) & 0xffffu;
-                        qc = qual_value(A.m.qual_thr + NS_Q_INS * NS_QUAL_LEVELS, h) + 33u;
-                    }
-                }
-                if (is_mis && first_mis < 0) first_mis = i;
-                put(nb, qc);
-            }
-            if (fq && first_mis >= 0) {                                    // S:697-700: only the first mismatch gets a 'mis' quality
-                u32x4 w = ns_draw(key, ST_HPQ, sid, a, s, 0);
-                const uint32_t om = o_run + (uint32_t)first_mis;
-                qual[rev ? L - 1 - om : om] = (uint8_t)(qual_value(A.m.qual_thr + NS_Q_MIS * NS_QUAL_LEVELS, w.x & 0xffffu) + 33u);
-            }
-            s = e;
-        }
-        q += n;
-        p.out_len = A.hp_len[rd.piece_off + pi];                           // report the emitted length, like the non -k path
-        A.pieces[rd.piece_off + pi] = p;
-    }
-    if (A.polya) for (uint32_t i = 0, n = A.polya[r]; i < n; ++i, ++q) put(scr[q], fq ? scq[q] : 0);      // polyA tail (S:1224-1225)
-    for (uint32_t i = 0; i < rd.tail; ++i, ++q) put(scr[q], fq ? scq[q] : 0);
-}
-
-// k_hp_write, one read per wavefront, first version (still used for k < 4, where a tile can hold more long runs than the run table
-// of k_hp_write_w): head / gaps / polyA / tail are plain 16-byte copies; inside an aligned segment a lane
-// copies its 16 bases with one store when no long run touches them, otherwise base by base, re-sampling the runs it owns (mutate_homo,
-// S:657-700).  Output offsets: wavefront prefix sum of the length changes of the runs that start before the lane's chunk.
-__global__ void __launch_bounds__(64 * NS_WPB, 3) k_hp_write_w_seq(GenArgs A) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (r >= A.prm.n_reads) return;
-    const ns_read rd = A.reads[r];
-    if (rd.flags) return;
-    if (!A.prm.emit_records) {
-        if (lane == 0) for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) A.pieces[rd.piece_off + pi].out_len = A.hp_len[rd.piece_off + pi];
-        return;
-    }
-    const ns_key key = read_key(A, r);
-    const uint32_t a = rd.attempts, k = A.prm.kmer_bias;
-    const bool fq = A.prm.fastq != 0, rev = rd.reversed != 0, ura = A.prm.uracil != 0;
-    const uint32_t L = rd.seq_len;                                         // final length
-    ReadOut ro;
-    ro.seq = A.records + rd.rec_off + A.name_len[r] + 2;
-    ro.qual = fq ? ro.seq + L + 3 : nullptr;
-    ro.seq_len = L; ro.reversed = rev; ro.uracil = ura;
-    const uint8_t *scr = A.scr + A.scr_off[r];
-    const uint8_t *scq = fq ? A.scrq + A.scr_off[r] : nullptr;
-    auto put = [&](uint32_t pos, uint32_t b, uint32_t qc) {                // one base at pre-revcomp position pos of the final read
-        const uint32_t oo = rev ? L - 1 - pos : pos;
-        uint8_t ob = rev ? complement(b) : (uint8_t)b;
-        if (ura && ob == 'T') ob = 'U';
-        ro.seq[oo] = ob;
-        if (fq) ro.qual[oo] = (uint8_t)qc;
-    };
-    auto copy_plain = [&](uint64_t q_in, uint32_t q_out, uint32_t len) {   // scratch [q_in, q_in + len) -> final read [q_out, q_out + len)
-        for (uint32_t i0 = 16 * lane; i0 < len; i0 += 1024) {
-            const uint32_t count = min(16u, len - i0);
-            uint64_t v[2] = {0, 0}, w[2] = {0, 0};
-            __builtin_memcpy(v, scr + q_in + i0, 16);
-            if (fq) __builtin_memcpy(w, scq + q_in + i0, 16);
-            store_chunk(ro, q_out + i0, count, v[0], v[1], w[0], w[1], true);
-        }
-    };
-    uint64_t q_in = 0;
-    uint32_t q_out = 0;
-    copy_plain(q_in, q_out, rd.head); q_in += rd.head; q_out += rd.head;
-    for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
-        const ns_piece p = A.pieces[rd.piece_off + pi];
-        const uint32_t n = p.out_len, flen = A.hp_len[rd.piece_off + pi];
-        if (p.kind) { copy_plain(q_in, q_out, n); q_in += n; q_out += n; continue; }
-        const uint32_t sid = pi >> 1;
-        const uint8_t *sq = scr + q_in;
-        const uint8_t *qq = fq ? scq + q_in : nullptr;
-        long long tileD = 0;                                               // length change of the runs that start before the tile
-        int32_t last_before = -1;
-        for (uint32_t t0 = 0; t0 < n; t0 += 1024) {
-            const uint32_t nts = hp_run_end_behind(sq, n, min(t0 + 1024u, n));
-            const HpTile t = hp_tile(sq, n, t0, lane, k, last_before, nts);
-            last_before = t.tile_last;
-            const uint32_t c = t0 + 16 * lane;
-            const uint32_t valid = c >= n ? 0u : min(16u, n - c);
-            long long lane_delta = 0;
-            for (uint32_t Cm = t.C; Cm; Cm &= Cm - 1) {
-                const uint32_t b = (uint32_t)__builtin_ctz(Cm), higher = t.M & ~((2u << b) - 1u);
-                const uint32_t s0 = c + b, e = higher ? c + (uint32_t)__builtin_ctz(higher) : t.next_start;
-                const uint32_t wv = b < 8 ? (b < 4 ? t.v.x : t.v.y) : (b < 12 ? t.v.z : t.v.w);
-                lane_delta += (long long)hp_new_size(A.m, key, sid, a, s0, e - s0, (wv >> (8 * (b & 3))) & 0xffu) - (long long)(e - s0);
-            }
-            long long incl = lane_delta;                                   // inclusive prefix sum over the lanes
-            for (int off = 1; off < 64; off <<= 1) { const long long o = __shfl_up(incl, off); if ((int)lane >= off) incl += o; }
-            const long long Dlane = tileD + incl - lane_delta;
-            tileD += __shfl(incl, 63);
-            if (!valid) continue;
-            // the run that was open when the chunk begins: if it is long, its bases inside the chunk were re-sampled by its owner
-            const uint32_t older_end = t.M ? c + (uint32_t)__builtin_ctz(t.M) : t.next_start;
-            const bool older_long = t.prev_start >= 0 && older_end > c && older_end - (uint32_t)t.prev_start >= k;
-            if (!older_long && !t.C) {                                     // nothing special: one store
-                uint64_t w[2] = {0, 0};
-                if (fq) __builtin_memcpy(w, qq + c, 16);
-                store_chunk(ro, (uint32_t)((long long)q_out + c + Dlane), valid, (uint64_t)t.v.x | (uint64_t)t.v.y << 32,
-                            (uint64_t)t.v.z | (uint64_t)t.v.w << 32, w[0], w[1], true);
-                continue;
-            }
-            long long Dcur = Dlane;
-            uint32_t i = older_long ? min(older_end, c + 16) - c : 0u;
-            uint64_t qv[2] = {0, 0};
-            if (fq) __builtin_memcpy(qv, qq + c, 16);
-            while (i < valid) {
-                if (!((t.C >> i) & 1u)) {                                  // plain stretch up to the next long run of the chunk: one (partial) store
-                    const uint32_t rest = t.C >> i;
-                    const uint32_t i1 = rest ? min(valid, i + (uint32_t)__builtin_ctz(rest)) : valid;
-                    uint64_t lo = (uint64_t)t.v.x | (uint64_t)t.v.y << 32, hi = (uint64_t)t.v.z | (uint64_t)t.v.w << 32, ql = qv[0], qh = qv[1];
-                    shift_down_bytes(lo, hi, i); shift_down_bytes(ql, qh, i);
-                    store_chunk(ro, (uint32_t)((long long)q_out + c + i + Dcur), i1 - i, lo, hi, ql, qh, true);
-                    i = i1;
-                    continue;
-                }
-                const uint32_t wv = i < 8 ? (i < 4 ? t.v.x : t.v.y) : (i < 12 ? t.v.z : t.v.w);
-                const uint32_t base = (wv >> (8 * (i & 3))) & 0xffu;
-                const uint32_t higher = t.M & ~((2u << i) - 1u);
-                const uint32_t s0 = c + i, e = higher ? c + (uint32_t)__builtin_ctz(higher) : t.next_start, len = e - s0;
-                const uint32_t size = hp_new_size(A.m, key, sid, a, s0, len, base);
-                const uint32_t o_run = (uint32_t)((long long)q_out + s0 + Dcur);
-                int64_t first_mis = -1;
-                for (uint32_t x = 0; x < size; ++x) {                      // S:668-684, qualities S:686-695
-                    bool is_mis; uint32_t nb, qc = 0;
-                    if (size <= len || x < len) {
-                        const uint32_t pp = size <= len ? s0 + (len - size) + x : s0 + x;
-                        nb = hp_base(A.m, base, key, sid, a, pp, 0, is_mis);
-                        if (fq) qc = qq[pp];
-                    } else {
-                        const uint32_t j = x - len;
-                        nb = hp_base(A.m, base, key, sid, a, e, 1 + j, is_mis);
-                        if (fq) {
-                            const u32x4 w = ns_draw(key, ST_HPQ, sid, a, e, 1 + (j >> 3));
-                            const uint32_t h = (ns_word(w, (j & 7) >> 1) >> (16 * (j & 1))) & 0xffffu;
-                            qc = qual_value(A.m.qual_thr + NS_Q_INS * NS_QUAL_LEVELS, h) + 33u;
-                        }
-                    }
-                    if (is_mis && first_mis < 0) first_mis = x;
-                    put(o_run + x, nb, qc);
-                }
-                if (fq && first_mis >= 0) {                                // S:697-700: only the first mismatch gets a 'mis' quality
-                    const u32x4 w = ns_draw(key, ST_HPQ, sid, a, s0, 0);
-                    const uint32_t om = o_run + (uint32_t)first_mis;
-                    ro.qual[rev ? L - 1 - om : om] = (uint8_t)(qual_value(A.m.qual_thr + NS_Q_MIS * NS_QUAL_LEVELS, w.x & 0xffffu) + 33u);
-                }
-                Dcur += (long long)size - (long long)len;
-                i = min(e, c + 16) - c;
-            }
-        }
-        q_in += n; q_out += flen;
-        if (lane == 0) { ns_piece pw = p; pw.out_len = flen; A.pieces[rd.piece_off + pi] = pw; }      // report the emitted length, like the non -k path
-    }
-    if (A.polya) { const uint32_t pl = A.polya[r]; copy_plain(q_in, q_out, pl); q_in += pl; q_out += pl; }     // polyA tail (S:1224-1225)
-    copy_plain(q_in, q_out, rd.tail);
-}
-
-// k_hp_write, one read per wavefront (4 <= k <= 16).  Per tile of 1024 scratch bases:
-//   A  the lane that holds the first base of a long run draws its new length and files the run in an LDS table; wavefront prefix
-//      sums of the length changes / new lengths give every chunk its output offset and every run its slice of the work list;
-//   B  plain stretches (bases outside long runs) leave as (partial) 16-byte stores;
-//   C  the re-sampled runs (mutate_homo, S:657-700) are expanded ONE LANE PER NEW BASE — a run of 9 bases is nine lanes, not nine
-//      iterations of one lane while 63 wait (the first version, k_hp_write_w_seq, spent most of its time there);
-//   the first mismatch of a run gets its 'mis' quality afterwards (S:697-700), found with an LDS atomic min.
-#define NS_HP_MAXRUN 256u        // long runs starting in one tile: <= 1024 / k
-struct HpRunLds {
-    uint32_t s0[NS_HP_MAXRUN], len[NS_HP_MAXRUN], size[NS_HP_MAXRUN], o_run[NS_HP_MAXRUN], fm[NS_HP_MAXRUN], w_off[NS_HP_MAXRUN + 1];
-    uint8_t base[NS_HP_MAXRUN];
-};
-#ifndef NS_HPW_WAVES
-#define NS_HPW_WAVES 4
-#endif
-__global__ void __launch_bounds__(64 * NS_WPB, NS_HPW_WAVES) k_hp_write_w(GenArgs A) {
-    __shared__ HpRunLds run_lds[NS_WPB];
-    HpRunLds &R = run_lds[threadIdx.x >> 6];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (r >= A.prm.n_reads) return;
-    const ns_read rd = A.reads[r];
-    if (rd.flags) return;
-    if (!A.prm.emit_records) {
-        if (lane == 0) for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) A.pieces[rd.piece_off + pi].out_len = A.hp_len[rd.piece_off + pi];
-        return;
-    }
-    const ns_key key = read_key(A, r);
-    const uint32_t a = rd.attempts, k = A.prm.kmer_bias;
-    const bool fq = A.prm.fastq != 0, rev = rd.reversed != 0, ura = A.prm.uracil != 0;
-    const uint32_t L = rd.seq_len;                                         // final length
-    ReadOut ro;
-    ro.seq = A.records + rd.rec_off + A.name_len[r] + 2;
-    ro.qual = fq ? ro.seq + L + 3 : nullptr;
-    ro.seq_len = L; ro.reversed = rev; ro.uracil = ura;
-    const uint8_t *scr = A.scr + A.scr_off[r];
-    const uint8_t *scq = fq ? A.scrq + A.scr_off[r] : nullptr;
-    auto copy_plain = [&](uint64_t q_in, uint32_t q_out, uint32_t len) {   // scratch [q_in, q_in + len) -> final read [q_out, q_out + len)
-        for (uint32_t i0 = 16 * lane; i0 < len; i0 += 1024) {
-            const uint32_t count = min(16u, len - i0);
-            uint64_t v[2] = {0, 0}, w[2] = {0, 0};
-            __builtin_memcpy(v, scr + q_in + i0, 16);
-            if (fq) __builtin_memcpy(w, scq + q_in + i0, 16);
-            store_chunk(ro, q_out + i0, count, v[0], v[1], w[0], w[1], true);
-        }
-    };
-    uint64_t q_in = 0;
-    uint32_t q_out = 0;
-    copy_plain(q_in, q_out, rd.head); q_in += rd.head; q_out += rd.head;
-    for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
-        const ns_piece p = A.pieces[rd.piece_off + pi];
-        const uint32_t n = p.out_len, flen = A.hp_len[rd.piece_off + pi];
-        if (p.kind) { copy_plain(q_in, q_out, n); q_in += n; q_out += n; continue; }
-        const uint32_t sid = pi >> 1;
-        const uint8_t *sq = scr + q_in;
-        const uint8_t *qq = fq ? scq + q_in : nullptr;
-        uint32_t tileD = 0;                                                // length change of the runs that start before the tile (mod 2^32)
-        int32_t last_before = -1;
-        for (uint32_t t0 = 0; t0 < n; t0 += 1024) {                       // (keeping the next tiles' loads in flight as k_hp_count_w does
-            const uint32_t nts = hp_run_end_behind(sq, n, min(t0 + 1024u, n));   //  was measured slower here: 39 vs 31 ms)
-            const HpTile t = hp_tile(sq, n, t0, lane, k, last_before, nts);
-            last_before = t.tile_last;
-            const uint32_t c = t0 + 16 * lane;
-            const uint32_t valid = c >= n ? 0u : min(16u, n - c);
-            // ---- A: the long runs this lane owns
-            const uint32_t rc = (uint32_t)__builtin_popcount(t.C);
-            const uint32_t rc_incl = wave_incl_scan(rc), slot0 = rc_incl - rc;
-            const uint32_t n_runs = (uint32_t)__builtin_amdgcn_readlane((int)rc_incl, 63);
-            uint32_t lane_delta = 0, lane_new = 0, slot = slot0;
-            for (uint32_t Cm = t.C; Cm; Cm &= Cm - 1) {
-                const uint32_t b = (uint32_t)__builtin_ctz(Cm), higher = t.M & ~((2u << b) - 1u);
-                const uint32_t s0 = c + b, e = higher ? c + (uint32_t)__builtin_ctz(higher) : t.next_start;
-                const uint32_t wv = b < 8 ? (b < 4 ? t.v.x : t.v.y) : (b < 12 ? t.v.z : t.v.w);
-                const uint32_t base = (wv >> (8 * (b & 3))) & 0xffu;
-                const uint32_t size = (A.dbg & 1024) ? e - s0 : hp_new_size(A.m, key, sid, a, s0, e - s0, base);
-                R.s0[slot] = s0; R.len[slot] = e - s0; R.size[slot] = size; R.base[slot] = (uint8_t)base; R.fm[slot] = 0xffffffffu;
-                R.o_run[slot] = lane_delta;                                // (length change of the earlier runs of this chunk, for now)
-                lane_delta += size - (e - s0); lane_new += size; ++slot;
-            }
-            const uint32_t d_incl = wave_incl_scan(lane_delta), w_incl = wave_incl_scan(lane_new);
-            const uint32_t Dlane = tileD + d_incl - lane_delta;
-            const uint32_t total_new = (uint32_t)__builtin_amdgcn_readlane((int)w_incl, 63);
-            tileD += (uint32_t)__builtin_amdgcn_readlane((int)d_incl, 63);
-            {
-                uint32_t wb = w_incl - lane_new;
-                for (uint32_t j = slot0; j < slot; ++j) { R.o_run[j] += q_out + R.s0[j] + Dlane; R.w_off[j] = wb; wb += R.size[j]; }
-            }
-            if (lane == 63) R.w_off[n_runs] = total_new;
-            wave_sync();
-            // ---- B: plain stretches of the chunk
-            if (valid && !(A.dbg & 512)) {
-                // the run that was open when the chunk begins: if it is long, its bases inside the chunk belong to its owner
-                const uint32_t older_end = t.M ? c + (uint32_t)__builtin_ctz(t.M) : t.next_start;
-                const bool older_long = t.prev_start >= 0 && older_end > c && older_end - (uint32_t)t.prev_start >= k;
-                uint64_t qv[2] = {0, 0};
-                if (fq) __builtin_memcpy(qv, qq + c, 16);
-                const uint64_t vlo = (uint64_t)t.v.x | (uint64_t)t.v.y << 32, vhi = (uint64_t)t.v.z | (uint64_t)t.v.w << 32;
-                if (!older_long && !t.C) store_chunk(ro, q_out + c + Dlane, valid, vlo, vhi, qv[0], qv[1], true);
-                else {
-                    uint32_t Dcur = Dlane, j = slot0;
-                    uint32_t i = older_long ? min(older_end, c + 16) - c : 0u;
-                    while (i < valid) {
-                        if (!((t.C >> i) & 1u)) {                          // plain stretch up to the next long run of the chunk: one (partial) store
-                            const uint32_t rest = t.C >> i;
-                            const uint32_t i1 = rest ? min(valid, i + (uint32_t)__builtin_ctz(rest)) : valid;
-                            uint64_t lo = vlo, hi = vhi, ql = qv[0], qh = qv[1];
-                            shift_down_bytes(lo, hi, i); shift_down_bytes(ql, qh, i);
-                            store_chunk(ro, q_out + c + i + Dcur, i1 - i, lo, hi, ql, qh, true);
-                            i = i1;
-                            continue;
-                        }
-                        const uint32_t len = R.len[j];
-                        Dcur += R.size[j] - len;
-                        i = len >= 16u - i ? 16u : i + len;
-                        ++j;
-                    }
-                }
-            }
-            // ---- C: the new bases of the runs, one lane each (S:668-684, qualities S:686-695)
-            for (uint32_t w = lane; w < ((A.dbg & 256) ? 0u : total_new); w += 64) {
-                uint32_t lo = 0, hi = n_runs;                              // run j with w_off[j] <= w < w_off[j + 1]
-                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (R.w_off[mid] <= w) lo = mid; else hi = mid; }
-                const uint32_t j = lo, x = w - R.w_off[j];
-                const uint32_t s0 = R.s0[j], len = R.len[j], size = R.size[j], base = R.base[j], e = s0 + len;
-                bool is_mis; uint32_t nb, qc = 0;
-                if (size <= len || x < len) {
-                    const uint32_t pp = size <= len ? s0 + (len - size) + x : s0 + x;
-                    nb = hp_base(A.m, base, key, sid, a, pp, 0, is_mis);
-                    if (fq) qc = qq[pp];
-                } else {
-                    const uint32_t jj = x - len;
-                    nb = hp_base(A.m, base, key, sid, a, e, 1 + jj, is_mis);
-                    if (fq) {
-                        const u32x4 wq = ns_draw(key, ST_HPQ, sid, a, e, 1 + (jj >> 3));
-                        const uint32_t h = (ns_word(wq, (jj & 7) >> 1) >> (16 * (jj & 1))) & 0xffffu;
-                        qc = qual_value(A.m.qual_thr + NS_Q_INS * NS_QUAL_LEVELS, h) + 33u;
-                    }
-                }
-                if (fq && is_mis) atomicMin(&R.fm[j], x);
-                const uint32_t pos = R.o_run[j] + x, oo = rev ? L - 1 - pos : pos;
-                uint8_t ob = rev ? complement(nb) : (uint8_t)nb;
-                if (ura && ob == 'T') ob = 'U';
-                ro.seq[oo] = ob;
-                if (fq) ro.qual[oo] = (uint8_t)qc;
-            }
-            if (fq) {                                                      // S:697-700: only the first mismatch of a run gets a 'mis' quality
-                __threadfence_block();                                     // (the quality bytes written above have landed)
-                wave_sync();
-                for (uint32_t j = lane; j < n_runs; j += 64) {
-                    const uint32_t fm = R.fm[j];
-                    if (fm == 0xffffffffu) continue;
-                    const u32x4 wq = ns_draw(key, ST_HPQ, sid, a, R.s0[j], 0);
-                    const uint32_t om = R.o_run[j] + fm;
-                    ro.qual[rev ? L - 1 - om : om] = (uint8_t)(qual_value(A.m.qual_thr + NS_Q_MIS * NS_QUAL_LEVELS, wq.x & 0xffffu) + 33u);
-                }
-            }
-            wave_sync();
-        }
-        q_in += n; q_out += flen;
-        if (lane == 0) { ns_piece pw = p; pw.out_len = flen; A.pieces[rd.piece_off + pi] = pw; }      // report the emitted length, like the non -k path
-    }
-    if (A.polya) { const uint32_t pl = A.polya[r]; copy_plain(q_in, q_out, pl); q_in += pl; q_out += pl; }     // polyA tail (S:1224-1225)
-    copy_plain(q_in, q_out, rd.tail);
 }
 
 // size of a read's error-profile rows (what k_errlog will write), one read per wavefront, lane per event.  (As a loop over the events
@@ -1517,7 +1176,8 @@ struct ns_ctx {
     DevBuf l_cap, l_off;
     DevBuf n_pieces, piece_off, ev_cap, ev_off, rec_len, rec_off, err_len, err_off, name_len;
     DevBuf reads, pieces, events, records, errlog, stats, scan_tmp;
-    DevBuf sort_key, sort_idx, sort_key_out, order, list_b, list_c, rstate, att_base, scr, scrq, scr_len, scr_off, hp_len, slow_q, ev_word;
+    DevBuf sort_key, sort_idx, sort_key_out, order, list_b, list_c, rstate, att_base, scr, scr_len, scr_off, hp_len, hp_nev, hp_ev, hp_wd, slow_q, ev_word;
+    uint32_t hp_shift = 5, hp_pad = 64, hp_cap_k = 0;       // -k: event capacity of a piece (hp_ev_slot), planned for kmer_bias hp_cap_k
     // metagenome: species view of the reference, abundances of the sample, per-pass scratch
     DevBuf species_chrom_off, t_reads, t_pieces, t_name_len, t_rec_len, t_err_len, accept, accept_scan, key_pos, draw_x, m_segptr,
         m_len, m_species, species_bases;
@@ -1656,7 +1316,7 @@ void ns_destroy(ns_ctx *ctx) {
     DevBuf *bufs[] = {&ctx->n_pieces, &ctx->piece_off, &ctx->ev_cap, &ctx->ev_off, &ctx->rec_len, &ctx->rec_off,
                       &ctx->err_len, &ctx->err_off, &ctx->name_len, &ctx->reads, &ctx->pieces, &ctx->events,
                       &ctx->records, &ctx->errlog, &ctx->stats, &ctx->scan_tmp, &ctx->sort_key, &ctx->sort_idx,
-                      &ctx->sort_key_out, &ctx->order, &ctx->list_b, &ctx->list_c, &ctx->rstate, &ctx->att_base, &ctx->scr, &ctx->scrq,
+                      &ctx->sort_key_out, &ctx->order, &ctx->list_b, &ctx->list_c, &ctx->rstate, &ctx->att_base, &ctx->scr, &ctx->hp_nev, &ctx->hp_ev, &ctx->hp_wd,
                       &ctx->scr_len, &ctx->scr_off, &ctx->hp_len, &ctx->slow_q, &ctx->ev_word, &ctx->l_cap, &ctx->l_off, &ctx->species_chrom_off, &ctx->t_reads, &ctx->t_pieces,
                       &ctx->t_name_len, &ctx->t_rec_len, &ctx->t_err_len, &ctx->accept, &ctx->accept_scan, &ctx->key_pos,
                       &ctx->draw_x, &ctx->m_segptr, &ctx->m_len, &ctx->m_species, &ctx->species_bases, &ctx->draw_sel,
@@ -1899,7 +1559,7 @@ static int scan_u32(ns_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n) {
 // ---------------------------------------------------------------------------------------------------------
 // copy phase, slow tiles, payload: the three kernels that write the sequence (and quality) lines of a batch
 static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fastq, uint64_t event_slots, hipEvent_t names_done = nullptr,
-                              const uint32_t *order = nullptr) {
+                              const uint32_t *order = nullptr, int mode = MAT_REF) {
     hipStream_t st = ctx->stream;
     if (A.prm.kind == NS_KIND_UNALIGNED) {
         if (names_done) HIPCHK(hipStreamWaitEvent(st, names_done, 0));
@@ -1908,13 +1568,13 @@ static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fast
         HIPCHK(hipGetLastError());
         return NS_OK;
     }
-    {
+    if (mode != MAT_HP_FINAL) {               // (the second pass of -k takes its letter words from k_hp_events)
         int rc = ensure(ctx, ctx->ev_word, ((size_t)event_slots + 8) * 4);
         if (rc) return rc;
         k_words<<<dim3((unsigned)n), dim3(64), 0, st>>>(A, (uint32_t *)ctx->ev_word.p);
         HIPCHK(hipGetLastError());
-        if (names_done) HIPCHK(hipStreamWaitEvent(st, names_done, 0));      // k_names ran next to k_words on the second stream
     }
+    if (names_done) HIPCHK(hipStreamWaitEvent(st, names_done, 0));      // k_names ran next to k_words on the second stream
     for (int round = 0;; ++round) {
         size_t cap = ctx->slow_q.cap >= 16 + sizeof(SlowTile) ? (ctx->slow_q.cap - 16) / sizeof(SlowTile) : 0;
         if (cap < n / 4 + 4096) {
@@ -1926,12 +1586,24 @@ static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fast
         sq.count = (uint32_t *)ctx->slow_q.p; sq.items = (SlowTile *)((uint8_t *)ctx->slow_q.p + 16);
         sq.cap = (uint32_t)(cap > 0xffffffffull ? 0xffffffffull : cap);
         HIPCHK(hipMemsetAsync(sq.count, 0, 4, st));
-        if (fastq) k_materialise<true><<<dim3((unsigned)((n + NS_MATQ_WAVES - 1) / NS_MATQ_WAVES)), dim3(64 * NS_MATQ_WAVES), 0, st>>>(A, (const uint32_t *)ctx->ev_word.p, ctx->dbg, sq, order);
-        else k_materialise<false><<<dim3((unsigned)n), dim3(64), 0, st>>>(A, (const uint32_t *)ctx->ev_word.p, ctx->dbg, sq, nullptr);
+        const uint32_t *wd = (const uint32_t *)ctx->ev_word.p;
+        const dim3 grid_q((unsigned)((n + NS_MATQ_WAVES - 1) / NS_MATQ_WAVES)), blk_q(64 * NS_MATQ_WAVES), grid_1((unsigned)n), blk_1(64);
+        if (mode == MAT_REF) {
+            if (fastq) k_materialise<true, MAT_REF><<<grid_q, blk_q, 0, st>>>(A, wd, ctx->dbg, sq, order);
+            else k_materialise<false, MAT_REF><<<grid_1, blk_1, 0, st>>>(A, wd, ctx->dbg, sq, nullptr);
+        } else if (mode == MAT_HP_SCRATCH) {
+            if (fastq) k_materialise<true, MAT_HP_SCRATCH><<<grid_1, blk_1, 0, st>>>(A, wd, ctx->dbg, sq, nullptr);
+            else k_materialise<false, MAT_HP_SCRATCH><<<grid_1, blk_1, 0, st>>>(A, wd, ctx->dbg, sq, nullptr);
+        } else {
+            if (fastq) k_materialise<true, MAT_HP_FINAL><<<grid_q, blk_q, 0, st>>>(A, wd, ctx->dbg, sq, order);
+            else k_materialise<false, MAT_HP_FINAL><<<grid_1, blk_1, 0, st>>>(A, wd, ctx->dbg, sq, nullptr);
+        }
         HIPCHK(hipGetLastError());
         uint32_t queued = 0;
         HIPCHK(hipMemcpyAsync(&queued, sq.count, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        if (queued && mode == MAT_HP_FINAL)      // >= 64 homopolymer edits at one output offset (64 adjacent runs re-sampled to nothing)
+            return fail(ctx, NS_EINVAL, "-k: homopolymer edits too dense for the record kernel");
         if (queued > sq.cap) {                   // more slow tiles than queue slots (tiny circular genomes): grow and redo
             if (round >= 2) return fail(ctx, NS_ENOMEM, "slow-tile queue overflow");
             int rc = ensure(ctx, ctx->slow_q, 16 + ((size_t)queued + 4096) * sizeof(SlowTile));
@@ -1940,16 +1612,20 @@ static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fast
         }
         if (queued) {
             const unsigned grid = queued < 16384u ? queued : 16384u;
-            if (fastq) k_materialise_slow<true><<<dim3(grid), dim3(64), 0, st>>>(A, sq);
-            else k_materialise_slow<false><<<dim3(grid), dim3(64), 0, st>>>(A, sq);
+            if (mode == MAT_HP_SCRATCH) {
+                if (fastq) k_materialise_slow<true, true><<<dim3(grid), dim3(64), 0, st>>>(A, sq);
+                else k_materialise_slow<false, true><<<dim3(grid), dim3(64), 0, st>>>(A, sq);
+            } else if (fastq) k_materialise_slow<true, false><<<dim3(grid), dim3(64), 0, st>>>(A, sq);
+            else k_materialise_slow<false, false><<<dim3(grid), dim3(64), 0, st>>>(A, sq);
             HIPCHK(hipGetLastError());
         }
         return NS_OK;
     }
 }
 
-// -k stage 1 on the reads of `A` (A.prm.n_reads of them): filter the events inside homopolymers (S:1920-1947), write the pre-homopolymer
-// reads to scratch, count the final lengths (mutate_homo, S:618-706) and apply the final length check (stats[5] = reads that failed it)
+// -k stage 1 on the reads of `A` (A.prm.n_reads of them): filter the events inside homopolymers (S:1920-1947), write the pieces before
+// mutate_homo to the scratch buffer, turn mutate_homo (S:618-706) into an edit list per piece + final lengths, and apply the final
+// length check (stats[5] = reads that failed it)
 static int hp_stage1(ns_ctx *ctx, const ns_params *prm, GenArgs &A, size_t n, uint64_t tot_pieces, uint64_t event_slots,
                      unsigned long long *stats, double *ms_hp) {
     hipStream_t st = ctx->stream;
@@ -1957,26 +1633,46 @@ static int hp_stage1(ns_ctx *ctx, const ns_params *prm, GenArgs &A, size_t n, ui
     int rc;
     float ms = 0;
     HIPCHK(hipEventRecord(ctx->evt[9], st));
-    if ((rc = ensure(ctx, ctx->hp_len, (size_t)tot_pieces * 4 + 64))) return rc;
-    A.hp_len = (uint32_t *)ctx->hp_len.p;
+    if ((rc = ensure(ctx, ctx->hp_len, (size_t)tot_pieces * 4 + 64)) || (rc = ensure(ctx, ctx->hp_nev, (size_t)tot_pieces * 4 + 64))) return rc;
+    A.hp_len = (uint32_t *)ctx->hp_len.p; A.hp_nev = (uint32_t *)ctx->hp_nev.p;
     k_hp_filter_w<<<dim3((unsigned)((n + NS_WPB) / NS_WPB)), dim3(64 * NS_WPB), 0, st>>>(A);
     HIPCHK(hipGetLastError());
     if ((rc = scan_u64(ctx, A.scr_len, A.scr_off, n + 1))) return rc;
     uint64_t scr_bytes = 0;
     HIPCHK(hipMemcpyAsync(&scr_bytes, A.scr_off + n, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if ((rc = ensure(ctx, ctx->scr, (size_t)scr_bytes + 64)) || (prm->fastq && (rc = ensure(ctx, ctx->scrq, (size_t)scr_bytes + 64)))) return rc;
-    A.scr = (uint8_t *)ctx->scr.p; A.scrq = (uint8_t *)ctx->scrq.p;
-    if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, event_slots))) return rc;
-    if (!A.meta || A.key_pos) HIPCHK(hipMemsetAsync((unsigned long long *)ctx->stats.p + 1, 0, sizeof(unsigned long long), st));   // (kept across metagenome passes)
-    HIPCHK(hipMemsetAsync((unsigned long long *)ctx->stats.p + 5, 0, sizeof(unsigned long long), st));
-    if (prm->kmer_bias <= 16) {
-        k_hp_count_w<<<dim3((unsigned)((n + NS_WPB - 1) / NS_WPB)), dim3(64 * NS_WPB), 0, st>>>(A);
+    // (the second record pass reads the scratch pieces with unaligned 16-byte loads that may start before / end behind a piece)
+    if ((rc = ensure(ctx, ctx->scr, (size_t)scr_bytes + 2 * NS_REF_PAD + 64))) return rc;
+    A.scr = (uint8_t *)ctx->scr.p + NS_REF_PAD;
+    if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, event_slots, nullptr, nullptr, MAT_HP_SCRATCH))) return rc;
+    if (ctx->hp_cap_k != prm->kmer_bias) {      // event capacity per scratch byte: 8x the density of runs >= k in a random sequence
+        double rate = 6.0;
+        for (uint32_t j = 1; j < prm->kmer_bias && rate > 1e-6; ++j) rate *= 0.25;
+        uint32_t sh = 0;
+        while (sh < 16 && rate * (double)(2u << sh) <= 1.0) ++sh;
+        ctx->hp_shift = sh; ctx->hp_pad = 64; ctx->hp_cap_k = prm->kmer_bias;
+    }
+    for (int retry = 0;; ++retry) {
+        A.hp_shift = ctx->hp_shift; A.hp_pad = ctx->hp_pad;
+        const size_t slots = (size_t)(scr_bytes >> A.hp_shift) + (size_t)A.hp_pad * (tot_pieces + 1) + 64;
+        if ((rc = ensure(ctx, ctx->hp_ev, slots * sizeof(ns_event))) || (rc = ensure(ctx, ctx->hp_wd, slots * 4))) return rc;
+        A.hp_ev = (ns_event *)ctx->hp_ev.p; A.hp_wd = (uint32_t *)ctx->hp_wd.p;
+        if (!A.meta || A.key_pos) HIPCHK(hipMemsetAsync((unsigned long long *)ctx->stats.p + 1, 0, sizeof(unsigned long long), st));   // (kept across metagenome passes)
+        HIPCHK(hipMemsetAsync((unsigned long long *)ctx->stats.p + 5, 0, sizeof(unsigned long long), st));
+        HIPCHK(hipMemsetAsync((unsigned long long *)ctx->stats.p + 7, 0, sizeof(unsigned long long), st));
+        k_hp_events<<<dim3((unsigned)((n + NS_WPB - 1) / NS_WPB)), dim3(64 * NS_WPB), 0, st>>>(A, A.l_cap);
+        k_hp_finalize<<<grid_t, blk, 0, st>>>(A, A.l_cap);
         k_sum_u64<<<dim3((unsigned)std::min<size_t>(512, (n + 255) / 256)), blk, 0, st>>>(A.scr_len, n, (unsigned long long *)ctx->stats.p + 1);
-    } else k_hp_count<<<grid_t, blk, 0, st>>>(A);
-    HIPCHK(hipGetLastError());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(stats, ctx->stats.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (!stats[7]) break;
+        // more homopolymer edits per base than planned (low-complexity reference): nothing was finalised; again with twice the capacity
+        if (retry >= 12) return fail(ctx, NS_ENOMEM, "-k: event capacity overflow persists");
+        if (ctx->hp_shift) --ctx->hp_shift;
+        ctx->hp_pad *= 2;
+    }
     HIPCHK(hipEventRecord(ctx->evt[10], st));
-    HIPCHK(hipMemcpyAsync(stats, ctx->stats.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipEventElapsedTime(&ms, ctx->evt[9], ctx->evt[10]));
     *ms_hp += ms;
@@ -2603,11 +2299,13 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     HIPCHK(hipGetLastError());
     if (side_names) HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
     HIPCHK(hipEventRecord(ctx->evt[6], st));
-    if (A.hp) {
-        if (prm->kmer_bias >= 4 && prm->kmer_bias <= 16) k_hp_write_w<<<grid_w, blk_w, 0, st>>>(A);
-        else if (prm->kmer_bias <= 16) k_hp_write_w_seq<<<grid_w, blk_w, 0, st>>>(A);
-        else k_hp_write<<<grid_t, blk, 0, st>>>(A);
-        HIPCHK(hipGetLastError());
+    if (A.hp) {          // second record pass of -k: the scratch read + its homopolymer edits -> the record
+        if (prm->emit_records) {
+            if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, tot_cap, nullptr, meta_al ? nullptr : list_a, MAT_HP_FINAL))) return rc;
+        } else {
+            k_hp_report<<<dim3((unsigned)((tot_pieces + 255) / 256)), blk, 0, st>>>(A, tot_pieces);
+            HIPCHK(hipGetLastError());
+        }
     } else if (prm->emit_records) {
         if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, tot_cap, ctx->ev_join, meta_al ? nullptr : list_a))) return rc;
     }

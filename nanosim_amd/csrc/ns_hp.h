@@ -1,12 +1,13 @@
 // ns_hp.h — -k/--KmerBias: the homopolymer filter of mutate_read (S:1920-1947) and mutate_homo (S:618-705).
 //
-// Lengths change AFTER the mutated segment exists, so the mode is count-then-write:
-//   k_hp_filter_w  wave/read   drop the events that overlap a homopolymer of the un-mutated segment, re-pack the rest
-//   k_materialise              (unchanged kernel) writes the pre-homopolymer read, forward strand, into a scratch buffer
-//   k_hp_count_w   wave/read   runs >= k of the scratch segments, new run lengths -> final lengths, final length check (S:1429);
-//                              a failing read bumps its attempt state and the batch is re-run
-//   k_hp_write_w   wave/read   scratch -> final record with the runs re-sampled, mismatches, qualities, revcomp
-// (k_hp_filter / k_hp_count / k_hp_write: the sequential thread-per-read versions, still used for k > 16.)
+// Lengths change AFTER the mutated segment exists, so the mode has two record passes:
+//   k_hp_filter_w                     wave/read  drop the events that overlap a homopolymer of the un-mutated segment, re-pack the rest
+//   k_materialise<., MAT_HP_SCRATCH>  wave/read  the pieces of the read before mutate_homo, forward strand, into the scratch buffer
+//                                                (FASTQ: every base carries its quality class in bits 3 / 5)
+//   k_hp_events                       wave/read  runs >= k of the scratch segments -> new run lengths, mismatches -> an edit list per
+//                                                piece; final lengths, final length check (S:1429): a failing read bumps its attempt
+//                                                state and the batch is re-run
+//   k_materialise<., MAT_HP_FINAL>    wave/read  scratch + edit list -> the record (qualities drawn here, strand, T -> U)
 #pragma once
 #include "ns_materialise.h"
 
@@ -49,16 +50,22 @@ __device__ inline bool in_hp_run_win(const DevRef &ref, const PieceCtx &pc, cons
     return (int64_t)(l + r) >= k;
 }
 
-// get_nd_par (src/model_homopolymer_lengths.py:246-260)
+// get_nd_par (src/model_homopolymer_lengths.py:246-260).  (The two parameter rows are read with static indices and selected field by
+// field: a dynamic index into the kernel argument would make the compiler keep a copy of the table in scratch memory.)
 __device__ __forceinline__ void hp_nd_par(const DevModel &m, uint32_t base, uint32_t len, double &mu, double &sigma) {
-    const ns_hp_class &h = m.hp[(base == 'A' || base == 'T') ? 0 : 1];
+    const bool at = base == 'A' || base == 'T';
+    const ns_hp_class &h0 = m.hp[0], &h1 = m.hp[1];
     const double x = (double)len;
-    double y = h.konst + h.alpha1 * x;
-    for (uint32_t j = 0; j < h.n_breaks; ++j) {
-        const double d = x - h.breakpoint[j];
-        y += h.beta[j] * (d > 0 ? d : 0.0);
+    double y = (at ? h0.konst : h1.konst) + (at ? h0.alpha1 : h1.alpha1) * x;
+    const uint32_t nb = at ? h0.n_breaks : h1.n_breaks;
+#pragma unroll
+    for (uint32_t j = 0; j < NS_HP_MAX_BREAKS; ++j) {
+        if (j < nb) {
+            const double d = x - (at ? h0.breakpoint[j] : h1.breakpoint[j]);
+            y += (at ? h0.beta[j] : h1.beta[j]) * (d > 0 ? d : 0.0);
+        }
     }
-    mu = y; sigma = h.intercept + h.slope * x;
+    mu = y; sigma = (at ? h0.intercept : h1.intercept) + (at ? h0.slope : h1.slope) * x;
 }
 // new length of the run [s, s+L) of base b (S:644-654, 665)
 __device__ __forceinline__ uint32_t hp_new_size(const DevModel &m, const ns_key &key, uint32_t sid, uint32_t a, uint32_t s,
@@ -70,16 +77,46 @@ __device__ __forceinline__ uint32_t hp_new_size(const DevModel &m, const ns_key 
     if (x < 0) x = 0;
     return (uint32_t)(int64_t)rint(x);
 }
-// one base of a re-sampled run (S:671-682)
-__device__ __forceinline__ uint8_t hp_base(const DevModel &m, uint32_t base, const ns_key &key, uint32_t sid, uint32_t a,
-                                           uint32_t idx, uint32_t sub, bool &is_mis) {
-    u32x4 w = ns_draw(key, ST_HPMIS, sid, a, idx, sub);
-    const double p = u32_to_p(w.x);
-    if (!(0 < p && p <= m.hp_mis_rate)) { is_mis = false; return (uint8_t)base; }
-    const uint32_t j = (uint32_t)(((uint64_t)w.y * 3u) >> 32);
-    const int rc = base_rank(base);
-    is_mis = true;
-    return bases_atcg(j + ((int)j >= rc ? 1u : 0u));
+// The events that turn the run [s0, s0 + L) of `base` into its re-sampled form (mutate_homo, S:657-700), in ascending position,
+// handed to put(pos, type, len, word); returns their number.  New base x of the run (0 <= x < size):
+//   mismatch (S:671-673) iff u32_to_p(Philox(ST_HPMIS, sid, a, idx = s0, sub = x >> 2).word[x & 3]) <= hp_mis_rate;
+//   its letter (S:674-679): choice word c = Philox(ST_HPMIS, sid, a, idx = s0, sub = 0x80000000 | x).word[0], j = (c' * 3) >> 32 picks
+//   among the three other bases in "ATCG" order (kept base: c' = c with bit 0 replaced by the first-mismatch flag; appended base: c' = c).
+// A contraction keeps the run's LAST `size` bases (S:688-690: the first |diff| qualities go): one deletion at s0.  Appended bases
+// (S:692-695, class 'ins') are insertions of <= 15 letters at s0 + L, 2 bits per letter; the run's first mismatch takes the 'mis' class
+// (S:697-700): bit 0 of a substitution's word, bit 31 of an insertion's word (the letter is then letter 0 of its insertion).
+template <typename F>
+__device__ __forceinline__ uint32_t hp_run_events(double hp_mis_rate, const ns_key &key, uint32_t sid, uint32_t a, uint32_t s0, uint32_t L,
+                                                  uint32_t size, uint32_t base, F &&put) {
+    uint32_t n = 0;
+    u32x4 w{0, 0, 0, 0}; uint32_t wblk = 0xffffffffu;
+    auto is_mis = [&](uint32_t x) {
+        if ((x >> 2) != wblk) { wblk = x >> 2; w = ns_draw(key, ST_HPMIS, sid, a, s0, wblk); }
+        return u32_to_p(ns_word(w, x & 3u)) <= hp_mis_rate;
+    };
+    auto choice = [&](uint32_t x) { return ns_draw(key, ST_HPMIS, sid, a, s0, 0x80000000u | x).x; };
+    bool first = true;
+    const uint32_t kept = min(size, L), off = L - kept;
+    for (uint32_t d = L - kept, pos = s0; d;) { const uint32_t c = min(d, NS_EV_LEN_MAX); put(pos, (uint32_t)NS_DEL, c, 0u); pos += c; d -= c; ++n; }
+    for (uint32_t x = 0; x < kept; ++x)
+        if (is_mis(x)) { put(s0 + off + x, (uint32_t)NS_MIS, 1u, (choice(x) & ~1u) | (first ? 1u : 0u)); first = false; ++n; }
+    const uint32_t code_b = (uint32_t)base_rank(base);
+    for (uint32_t x = L; x < size;) {
+        uint32_t word = 0, cnt = 0; bool flag = false;
+        while (x < size && cnt < 15u) {
+            const bool mm = is_mis(x);
+            if (mm && first && cnt) break;                     // the run's first mismatch opens its own insertion
+            uint32_t code = code_b;
+            if (mm) {
+                const uint32_t j = (uint32_t)(((uint64_t)choice(x) * 3u) >> 32);
+                code = j + (j >= code_b ? 1u : 0u);
+                if (first) { flag = true; first = false; }
+            }
+            word |= code << (2u * cnt); ++cnt; ++x;
+        }
+        put(s0 + L, (uint32_t)NS_INS, cnt, word | (flag ? 0x80000000u : 0u)); ++n;
+    }
+    return n;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -111,8 +148,9 @@ __device__ __forceinline__ HpRaw hp_load(const uint8_t *__restrict__ sq, uint32_
 __device__ __forceinline__ uint32_t hp_starts(const HpRaw &r, uint32_t n, uint32_t t0, uint32_t lane) {
     const uint32_t c = t0 + 16 * lane;
     const uint32_t p0 = r.v.x << 8 | r.pb, p1 = r.v.y << 8 | r.v.x >> 24, p2 = r.v.z << 8 | r.v.y >> 24, p3 = r.v.w << 8 | r.v.z >> 24;
-    const uint32_t M = movemask4(nonzero_bytes(r.v.x ^ p0)) | movemask4(nonzero_bytes(r.v.y ^ p1)) << 4 | movemask4(nonzero_bytes(r.v.z ^ p2)) << 8 |
-                       movemask4(nonzero_bytes(r.v.w ^ p3)) << 12;
+    // (the class bits of the bases — NS_CLS_STRIP — do not take part in the comparison)
+    const uint32_t M = movemask4(nonzero_bytes((r.v.x ^ p0) & NS_CLS_STRIP)) | movemask4(nonzero_bytes((r.v.y ^ p1) & NS_CLS_STRIP)) << 4 |
+                       movemask4(nonzero_bytes((r.v.z ^ p2) & NS_CLS_STRIP)) << 8 | movemask4(nonzero_bytes((r.v.w ^ p3) & NS_CLS_STRIP)) << 12;
     const uint32_t valid = c >= n ? 0u : (n - c >= 16 ? 16u : n - c);      // bases of the chunk inside the segment
     return M & ((1u << valid) - 1u);
 }
@@ -152,7 +190,11 @@ __device__ inline HpTile hp_tile_from(const HpRaw &raw, uint32_t M, uint32_t t0,
     const uint32_t upper = t.next_start - c >= 32u ? 0u : 1u << (t.next_start - c);       // the first start behind the chunk, as a bit of a 32-bit window
     const uint32_t W = M | upper;
     uint32_t C = M;
-    for (uint32_t sft = 1; sft < k; ++sft) C &= ~(W >> sft);
+    if (k <= 16) { for (uint32_t sft = 1; sft < k; ++sft) C &= ~(W >> sft); }
+    else {                                 // k > 16: only the last run start of a chunk can open a run of >= k bases
+        C = 0;
+        if (M) { const uint32_t b = 31u - (uint32_t)__clz((int)M); if (t.next_start - (c + b) >= k) C = 1u << b; }
+    }
     // a run may also be cut short by the end of the segment: n acts as a start (next_tile_start / next_start carry it)
     t.C = C;
     return t;
@@ -165,8 +207,8 @@ __device__ inline HpTile hp_tile(const uint8_t *__restrict__ sq, uint32_t n, uin
 // end of the run that holds base p - 1 ... scanning forward from p (wave-uniform helper for the run that is open at a tile end)
 __device__ inline uint32_t hp_run_end_behind(const uint8_t *__restrict__ sq, uint32_t n, uint32_t p) {
     if (p >= n) return n;
-    const uint8_t b = sq[p - 1];
+    const uint8_t b = sq[p - 1] & 0xd7u;
     uint32_t e = p;
-    while (e < n && sq[e] == b) ++e;
+    while (e < n && (sq[e] & 0xd7u) == b) ++e;
     return e;
 }

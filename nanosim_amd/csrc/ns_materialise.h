@@ -308,7 +308,9 @@ __device__ __forceinline__ PieceCtx load_piece_uniform(const ns_event *events, c
     pc.sid = pc.kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
     return pc;
 }
-// bytes [m_lo, m_hi) of one piece, 16 per lane, straight from global memory
+// bytes [m_lo, m_hi) of one piece, 16 per lane, straight from global memory.  CLS_BITS: the bases keep their quality class in bits
+// 3 / 5 (first record pass of -k with FASTQ: the qualities are drawn by the second pass)
+template <bool CLS_BITS = false>
 __device__ inline void slow_piece_range(const DevModel &m, const DevRef &ref, const ReadOut &ro, const ns_key &key, uint32_t a,
                                         const PieceCtx &pc, uint32_t pq, uint32_t m_lo, uint32_t m_hi, uint32_t lane) {
     for (uint32_t m0 = m_lo + lane * 16; m0 < m_hi; m0 += 64 * 16) {
@@ -319,7 +321,8 @@ __device__ inline void slow_piece_range(const DevModel &m, const DevRef &ref, co
         QualDraw qd; qd.blk = 0xffffffffu;
         for (uint32_t i = 0; i < count; ++i) {
             int cls;
-            uint8_t b = piece_byte(ref, pc, cur, m0 + i, key, a, cls);
+            uint32_t b = piece_byte(ref, pc, cur, m0 + i, key, a, cls);
+            if constexpr (CLS_BITS) b |= cls == NS_Q_MIS ? NS_CLS_MIS_BIT : cls == NS_Q_INS ? NS_CLS_INS_BIT : 0u;
             put_byte(lo, hi, i, b);
             if (ro.qual) put_byte(qlo, qhi, i, qual_draw(qd, m, pc.kind ? NS_Q_UNMAPPED : cls, key, ST_QUAL, pc.sid, a, m0 + i));
         }
@@ -650,16 +653,11 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
         scan_base = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         const uint32_t c0 = A0 + 16 * ci;                          // chunk origin (chunk 0 of a piece's first tile may start before M0)
         const uint32_t lo_m = ci == 0 ? M0 : c0, hi_m = min(c0 + 16, M1);
-        uint32_t D[8];
-        if constexpr (QUALS) {                                     // the quality draws of the iteration (every lane takes part)
-            const uint32_t c0_first = A0 + 1024u * t;
-            const int32_t span = (int32_t)(M1 - 1u - c0_first);    // >= 0: some lane of this iteration writes bytes
-            if (span >= 0) qual_draws16(Q, key, pc.sid, a, c0, c0_first, min(64u, ((uint32_t)span >> 4) + 1u), (dbg & 128u) != 0, D);
-        }
-        if ((int32_t)(hi_m - lo_m) > 0 && !(dbg & 1)) {
+        const bool active = (int32_t)(hi_m - lo_m) > 0 && !(dbg & 1);
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        if (active) {
             uint32_t k = incl;                                     // event in force at the chunk's first byte
             uint32_t eos = T.e_out[k], pl = T.e_pt[k] & 0xfffu, rp = T.e_rp[k], nxt = T.e_out[k + 1];
-            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
             uint32_t mcur = lo_m;
             // The first four event sub-runs of the chunk are gathered branch-free with all four 16-byte loads in flight (a lane
             // that has run out of sub-runs loads a fixed valid offset and merges with the empty mask mlut[16]); chunks with
@@ -720,6 +718,14 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             r0 = bfi(pm.x, pv.x, r0); r1 = bfi(pm.y, pv.y, r1); r2 = bfi(pm.z, pv.z, r2); r3 = bfi(pm.w, pv.w, r3);
             *reinterpret_cast<uint4 *>(&T.pay[lo_off]) = make_uint4(0, 0, 0, 0);
             *reinterpret_cast<uint4 *>(&T.pmask[lo_off]) = make_uint4(0, 0, 0, 0);
+        } else flush_chunk(ro, pend);
+        uint32_t D[8];
+        if constexpr (QUALS) {                                     // the quality draws of the iteration (every lane takes part; the
+            const uint32_t c0_first = A0 + 1024u * t;              //  gathered bases wait in four registers meanwhile)
+            const int32_t span = (int32_t)(M1 - 1u - c0_first);    // >= 0: some lane of this iteration writes bytes
+            if (span >= 0) qual_draws16(Q, key, pc.sid, a, c0, c0_first, min(64u, ((uint32_t)span >> 4) + 1u), (dbg & 128u) != 0, D);
+        }
+        if (active) {
             uint64_t qlo = 0, qhi = 0;
             uint32_t s0 = lo_m - c0, count = hi_m - lo_m;          // bytes [s0, s0 + count) of the chunk are this tile's
             if constexpr (QUALS) {                                 // one quality per byte, class from the bits the base carries (S:1421-1423)
@@ -741,7 +747,7 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
                 else { lo = hi >> (sh - 64); hi = 0; qlo = qhi >> (sh - 64); qhi = 0; }
             }
             if (!(dbg & 16)) pend = prep_chunk(ro, pq + lo_m, count, lo, hi, qlo, qhi);
-        } else flush_chunk(ro, pend);
+        }
         }
 
         jb = jb_next; M0 = M1;

@@ -523,9 +523,12 @@ static void hp_nd_par(const ns_model_tables *t, uint8_t base, int64_t len, doubl
 double nso_hp_mu(const ns_model_tables *t, uint8_t base, int64_t len) { double m, s; hp_nd_par(t, base, len, &m, &s); return m; }
 double nso_hp_sigma(const ns_model_tables *t, uint8_t base, int64_t len) { double m, s; hp_nd_par(t, base, len, &m, &s); return s; }
 
-/* one base of a re-sampled homopolymer (S:671-682): mismatch with prob hp_mis_rate (0 < p <= rate) to a uniform other base */
-static uint8_t hp_base(const ns_model_tables *t, uint8_t base, nso_draw *d, uint32_t seg, uint32_t attempt, uint32_t idx,
-                       uint32_t sub, int *is_mis) {
+/* new base x of the re-sampled run that starts at s (S:671-682): mismatch with prob hp_mis_rate (0 < p <= rate) to a uniform other
+ * base.  Draws: p = Philox(ST_HPMIS, idx = s, sub = x >> 2).word[x & 3]; the other base from c = Philox(ST_HPMIS, idx = s,
+ * sub = 0x80000000 | x).word[0] as j = (c' * 3) >> 32 in "ATCG" order — for a KEPT base c' is c with bit 0 replaced by "first mismatch
+ * of the run" (that bit travels in the engine's event word), for an appended base c' = c. */
+static uint8_t hp_base(const ns_model_tables *t, uint8_t base, nso_draw *d, uint32_t seg, uint32_t attempt, uint32_t s, uint32_t x,
+                       int kept, int first, int *is_mis) {
     double p; uint32_t j = 0;
     if (d->mode) {
         p = tape_u(d);
@@ -534,22 +537,25 @@ static uint8_t hp_base(const ns_model_tables *t, uint8_t base, nso_draw *d, uint
         }
         *is_mis = 0; return base;
     }
-    uint32_t w[4]; philox_at(d, ST_HPMIS, seg, attempt, idx, sub, w);
-    p = u32_to_p(w[0]);
+    uint32_t w[4]; philox_at(d, ST_HPMIS, seg, attempt, s, x >> 2, w);
+    p = u32_to_p(w[x & 3u]);
     if (!(0 < p && p <= t->hp_mis_rate)) { *is_mis = 0; return base; }
-    j = (uint32_t)(((uint64_t)w[1] * 3u) >> 32);
+    uint32_t c[4]; philox_at(d, ST_HPMIS, seg, attempt, s, 0x80000000u | x, c);
+    uint32_t cw = c[0];
+    if (kept) cw = (cw & ~1u) | (first ? 1u : 0u);
+    j = (uint32_t)(((uint64_t)cw * 3u) >> 32);
     int rc = base_rank(base);
     *is_mis = 1;
     return (uint8_t)BASES[j + ((int)j >= rc ? 1u : 0u)];
 }
 
 /* mutate_homo (S:618-705) on one mutated aligned segment.
- *   in/in_q: bases and qualities (or NULL) before; out/out_q after; returns the new length (or -1 if out_cap is too small).
- *   Draw keys: new length of the run starting at s: ST_HPLEN idx=s; kept base (pre-hp position pp): ST_HPMIS idx=pp sub=0;
- *   j-th appended base of a run ending at e: ST_HPMIS idx=e sub=1+j; appended quality j: ST_HPQ idx=e sub=1+(j>>3), field j&7;
- *   the single mismatch quality of a run (S:697-700: only the first mismatch gets one): ST_HPQ idx=s sub=0 field 0. */
-int64_t nso_mutate_homo(const ns_model_tables *t, const uint8_t *in, const uint8_t *in_q, int64_t n, int64_t k, nso_draw *d,
-                        uint32_t seg, uint32_t attempt, uint8_t *out, uint8_t *out_q, int64_t out_cap) {
+ *   in/in_c: bases and their quality classes (or NULL) before; out/out_c after; returns the new length (or -1 if out_cap is too small).
+ *   A kept base keeps its class (S:688-690: a contraction drops the FIRST |diff| qualities of the run), an appended base is 'ins'
+ *   (S:692-695), the first mismatch of a run 'mis' (S:697-700).  The qualities themselves are drawn afterwards, by final position.
+ *   Draw keys: new length of the run starting at s: ST_HPLEN idx=s; new base x of the run: hp_base. */
+int64_t nso_mutate_homo(const ns_model_tables *t, const uint8_t *in, const uint8_t *in_c, int64_t n, int64_t k, nso_draw *d,
+                        uint32_t seg, uint32_t attempt, uint8_t *out, uint8_t *out_c, int64_t out_cap) {
     int64_t w = 0, p = 0;
     while (p < n) {
         int64_t s = p, e = p + 1;
@@ -559,7 +565,7 @@ int64_t nso_mutate_homo(const ns_model_tables *t, const uint8_t *in, const uint8
         if (L < k || base_rank(b) < 0) {
             if (w + L > out_cap) return -1;
             memcpy(out + w, in + s, (size_t)L);
-            if (in_q) memcpy(out_q + w, in_q + s, (size_t)L);
+            if (in_c) memcpy(out_c + w, in_c + s, (size_t)L);
             w += L; p = e;
             continue;
         }
@@ -573,26 +579,16 @@ int64_t nso_mutate_homo(const ns_model_tables *t, const uint8_t *in, const uint8
         int64_t first_mis = -1;
         for (int64_t i = 0; i < size; ++i) {
             int is_mis; uint8_t nb;
-            if (size <= L || i < L) {
-                const int64_t pp = (size <= L) ? s + (L - size) + i : s + i;          /* kept position (S:688-690: the first |diff| quals go) */
-                nb = hp_base(t, b, d, seg, attempt, (uint32_t)pp, 0, &is_mis);
-                if (in_q) out_q[w + i] = in_q[pp];
-            } else {
-                const int64_t j = i - L;                                                 /* appended base (S:692-695) */
-                nb = hp_base(t, b, d, seg, attempt, (uint32_t)e, (uint32_t)(1 + j), &is_mis);
-                if (in_q) {
-                    uint32_t ww[4]; philox_at(d, ST_HPQ, seg, attempt, (uint32_t)e, (uint32_t)(1 + (j >> 3)), ww);
-                    uint32_t h = (ww[(j & 7) >> 1] >> (16 * (j & 1))) & 0xffffu;
-                    out_q[w + i] = d->mode ? (uint8_t)NS_Q_INS : qual_value(t, NS_Q_INS, h);
-                }
+            const int kept = (size <= L || i < L);
+            nb = hp_base(t, b, d, seg, attempt, (uint32_t)s, (uint32_t)i, kept, first_mis < 0, &is_mis);
+            if (in_c) {
+                if (kept) out_c[w + i] = in_c[(size <= L) ? s + (L - size) + i : s + i];   /* kept position (S:688-690: the first |diff| quals go) */
+                else out_c[w + i] = (uint8_t)NS_Q_INS;                                        /* appended base (S:692-695) */
             }
             out[w + i] = nb;
             if (is_mis && first_mis < 0) first_mis = i;
         }
-        if (in_q && first_mis >= 0) {                                   /* S:697-700 */
-            uint32_t ww[4]; philox_at(d, ST_HPQ, seg, attempt, (uint32_t)s, 0, ww);
-            out_q[w + first_mis] = d->mode ? (uint8_t)NS_Q_MIS : qual_value(t, NS_Q_MIS, ww[0] & 0xffffu);
-        }
+        if (in_c && first_mis >= 0) out_c[w + first_mis] = (uint8_t)NS_Q_MIS;               /* S:697-700 */
         w += size; p = e;
     }
     return w;
@@ -1241,16 +1237,11 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
                         hp_log_len = (uint64_t)(q - hp_log);
                     }
                 }
-                uint8_t *q1 = NULL;
-                if (prm->fastq) {
-                    q1 = (uint8_t *)malloc((size_t)l1 + 1);
-                    for (int64_t mm = 0; mm < l1; ++mm) q1[mm] = qual_at(t, c1[mm], &d, ST_QUAL, sid, a, (uint64_t)mm);
-                }
                 int64_t cap2 = 2 * l1 + 4096;
                 hp_seq[pi] = (uint8_t *)malloc((size_t)cap2);
-                hp_q[pi] = prm->fastq ? (uint8_t *)malloc((size_t)cap2) : NULL;
-                int64_t l2 = nso_mutate_homo(t, s1, q1, l1, (int64_t)prm->kmer_bias, &d, sid, a, hp_seq[pi], hp_q[pi], cap2);   /* S:1413-1414 */
-                free(segbuf); free(s1); free(c1); free(rows); free(txt); free(q1);
+                hp_q[pi] = prm->fastq ? (uint8_t *)malloc((size_t)cap2) : NULL;                     /* quality CLASS of every final base */
+                int64_t l2 = nso_mutate_homo(t, s1, prm->fastq ? c1 : NULL, l1, (int64_t)prm->kmer_bias, &d, sid, a, hp_seq[pi], hp_q[pi], cap2);   /* S:1413-1414 */
+                free(segbuf); free(s1); free(c1); free(rows); free(txt);
                 if (l2 < 0) return -22;
                 seq_len += l2 - (int64_t)pc[pi].out_len;
                 pc[pi].out_len = (uint32_t)l2;
@@ -1285,7 +1276,8 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
             int64_t rl = pc[pi].ref_len;
             if (hp_on && !pc[pi].kind) {
                 memcpy(seq + wq, hp_seq[pi], pc[pi].out_len);
-                if (qual) memcpy(qual + wq, hp_q[pi], pc[pi].out_len);
+                if (qual) for (int64_t m = 0; m < (int64_t)pc[pi].out_len; ++m)                  /* one draw per FINAL position of the piece */
+                    qual[wq + m] = qual_at(t, hp_q[pi][m], &d, ST_QUAL, sid, a, (uint64_t)m);
                 wq += pc[pi].out_len;
                 o->total_ref_bases += (uint64_t)rl;
                 continue;
