@@ -683,6 +683,8 @@ k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, co
     const uint64_t r = order ? (uint64_t)uni(order[slot]) : slot;
     ns_read rd; ns_key key; ReadOut ro;
     if (!load_read_uniform(A, r, QUALS, rd, key, ro)) return;
+    if (dbg & 512u) ro.qual = nullptr;               // (profiling: no quality line)
+    if ((dbg & 4096u) && ro.qual) ro.qual = (uint8_t *)(((uintptr_t)ro.qual & ~(uintptr_t)15) | ((uintptr_t)ro.seq & 15));   // (profiling: quality line aligned like the bases)
     const uint32_t a = rd.attempts;
     tile_lds_init(T, lane);
     QualState Q; Q.lut = qlut; qual_state_reset(Q);
@@ -1587,10 +1589,11 @@ static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fast
         sq.cap = (uint32_t)(cap > 0xffffffffull ? 0xffffffffull : cap);
         HIPCHK(hipMemsetAsync(sq.count, 0, 4, st));
         const uint32_t *wd = (const uint32_t *)ctx->ev_word.p;
+        if (ctx->dbg & 1024u) order = nullptr;          // (profiling: reads in index order)
         const dim3 grid_q((unsigned)((n + NS_MATQ_WAVES - 1) / NS_MATQ_WAVES)), blk_q(64 * NS_MATQ_WAVES), grid_1((unsigned)n), blk_1(64);
         if (mode == MAT_REF) {
             if (fastq) k_materialise<true, MAT_REF><<<grid_q, blk_q, 0, st>>>(A, wd, ctx->dbg, sq, order);
-            else k_materialise<false, MAT_REF><<<grid_1, blk_1, 0, st>>>(A, wd, ctx->dbg, sq, nullptr);
+            else k_materialise<false, MAT_REF><<<grid_1, blk_1, 0, st>>>(A, wd, ctx->dbg, sq, (ctx->dbg & 2048u) ? order : nullptr);
         } else if (mode == MAT_HP_SCRATCH) {
             if (fastq) k_materialise<true, MAT_HP_SCRATCH><<<grid_1, blk_1, 0, st>>>(A, wd, ctx->dbg, sq, nullptr);
             else k_materialise<false, MAT_HP_SCRATCH><<<grid_1, blk_1, 0, st>>>(A, wd, ctx->dbg, sq, nullptr);

@@ -569,7 +569,6 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             wave_sync();
             continue;
         }
-
         // ---- 2. letters: lane per event; lane 63 (never a taker) continues the payload of the event in force at M0
         if (!(dbg & 2)) {
             const bool cont = lane == 63 && L0_out + (L0_pt & 0xfffu) > M0;
@@ -723,7 +722,7 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
         if constexpr (QUALS) {                                     // the quality draws of the iteration (every lane takes part; the
             const uint32_t c0_first = A0 + 1024u * t;              //  gathered bases wait in four registers meanwhile)
             const int32_t span = (int32_t)(M1 - 1u - c0_first);    // >= 0: some lane of this iteration writes bytes
-            if (span >= 0) qual_draws16(Q, key, pc.sid, a, c0, c0_first, min(64u, ((uint32_t)span >> 4) + 1u), (dbg & 128u) != 0, D);
+            if (span >= 0 && !(dbg & 256u)) qual_draws16(Q, key, pc.sid, a, c0, c0_first, min(64u, ((uint32_t)span >> 4) + 1u), (dbg & 128u) != 0, D);
         }
         if (active) {
             uint64_t qlo = 0, qhi = 0;
@@ -736,7 +735,7 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
                     cs[0] = and_or(r0 >> 1, 0x10101010u, r0 & 0x08080808u); cs[1] = and_or(r1 >> 1, 0x10101010u, r1 & 0x08080808u);
                     cs[2] = and_or(r2 >> 1, 0x10101010u, r2 & 0x08080808u); cs[3] = and_or(r3 >> 1, 0x10101010u, r3 & 0x08080808u);
                 }
-                qual_lookup16(Q, m, D, cs, (dbg & 64u) != 0, qlo, qhi);
+                if (!(dbg & 256u)) qual_lookup16(Q, m, D, cs, (dbg & 64u) != 0, qlo, qhi);
                 // bytes outside [s0, s0 + count) hold draws of other positions: they are shifted out / not stored
             }
             if constexpr (FASTQ && MODE != MAT_HP_SCRATCH) { r0 &= NS_CLS_STRIP; r1 &= NS_CLS_STRIP; r2 &= NS_CLS_STRIP; r3 &= NS_CLS_STRIP; }
