@@ -100,7 +100,8 @@ struct GenArgs {
     ns_event *events;
     uint8_t *records;
     uint8_t *errlog;
-    unsigned long long *stats;  // [0] overflow reads [1] total bases [2] total ref bases [3] events [4] failed reads
+    unsigned long long *stats;  // [0] overflow reads [1] total bases [2] total ref bases [3] events [4] longest accepted read (unaligned batches)
+                                // [5] reads that failed the final length check of -k [6] reads queued for the next pass [7] -k event capacity overflow
 };
 
 __device__ __forceinline__ ns_key make_key(const ns_params &prm, uint64_t r) {
@@ -259,6 +260,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
     else if (blockIdx.x < (gridDim.x >> 4)) __builtin_amdgcn_s_setprio(2);
     else if (blockIdx.x < (gridDim.x >> 2)) __builtin_amdgcn_s_setprio(1);
     unsigned long long st_over = 0, st_bases = 0, st_ref = 0, st_ev = 0;
+    uint32_t st_max = 0;
     if (tid < A.list_n) {
         const uint64_t r = A.list ? A.list[tid] : A.list_base + tid;
         const int kind = (int)prm.kind;
@@ -406,7 +408,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
                 if (A.polya) A.polya[r] = (uint16_t)polya;
                 if (A.ir_need) A.ir_need[r] = spliced ? ir_slot_bytes(pc[0].ref_len) : 0;
                 if (meta_al) { A.accept[r] = 1ull | (uint64_t)n_pieces << 32; A.sort_key[r] = evn; }   // (event count: taken back if -k rejects the read)
-                st_bases = A.hp ? 0ull : (unsigned long long)seq_len; st_ref = ref_bases; st_ev = evn;
+                st_bases = A.hp ? 0ull : (unsigned long long)seq_len; st_ref = ref_bases; st_ev = evn; st_max = (uint32_t)seq_len;
             }
             accepted = true;
         } while (false);
@@ -423,9 +425,11 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
     }
     // one atomic per wavefront and counter
     st_over = wave_sum(st_over); st_bases = wave_sum(st_bases); st_ref = wave_sum(st_ref); st_ev = wave_sum(st_ev);
+    if (A.prm.kind == NS_KIND_UNALIGNED) for (int off = 32; off > 0; off >>= 1) st_max = max(st_max, (uint32_t)__shfl_xor((int)st_max, off));
     if ((threadIdx.x & 63) == 0) {
         if (st_over) atomicAdd(&A.stats[0], st_over);
         atomicAdd(&A.stats[1], st_bases); atomicAdd(&A.stats[2], st_ref); atomicAdd(&A.stats[3], st_ev);
+        if (A.prm.kind == NS_KIND_UNALIGNED && st_max) atomicMax(&A.stats[4], (unsigned long long)st_max);
     }
 }
 
@@ -730,20 +734,29 @@ k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, co
 }
 
 // Unaligned reads (S:1482-1549): ~0.55 events per base.  The tiled kernel ends a tile after 63 events — every ~110 bases here, twenty
-// prologues per read — so these reads take the per-byte path: a lane finds the event in force at its 16 bases with a binary search
-// and walks the events from there (12x fewer instructions per read at this density).
+// prologues per read — so these reads take the lane-per-event path (ns_materialise.h: dense_piece).
+#define NS_DENSE_SEG 4096u        // output bytes of a read one wavefront writes: the longest read of a batch (tens of kb) no longer sets the kernel's duration
 template <bool FASTQ>
 __global__ void __launch_bounds__(64) k_materialise_dense(GenArgs A) {
+    __shared__ DenseLds S;
     const uint32_t lane = threadIdx.x;
     const uint64_t r = blockIdx.x;
+    const uint32_t seg = blockIdx.y;
     ns_read rd; ns_key key; ReadOut ro;
     if (!load_read_uniform(A, r, FASTQ, rd, key, ro)) return;
+    if ((uint64_t)seg * NS_DENSE_SEG >= rd.seq_len && seg) return;
     const uint32_t a = rd.attempts;
-    emit_head_tail(A.m, ro, key, a, rd.head, rd.tail, lane);
+    if (seg == 0) emit_head_tail(A.m, ro, key, a, rd.head, rd.tail, lane);
     uint32_t q = rd.head;
     for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
         const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi);
-        slow_piece_range(A.m, A.ref, ro, key, a, pc, q, 0, pc.out_len, lane);
+        // bytes of the piece that fall into this wavefront's stretch [seg, seg + 1) * NS_DENSE_SEG of the read (head excluded)
+        const uint64_t s_lo = (uint64_t)seg * NS_DENSE_SEG, s_hi = s_lo + NS_DENSE_SEG, p_lo = q - rd.head, p_hi = p_lo + pc.out_len;
+        if (p_hi > s_lo && p_lo < s_hi) {
+            const uint32_t m_lo = (uint32_t)(max(s_lo, p_lo) - p_lo), m_hi = (uint32_t)(min(s_hi, p_hi) - p_lo);
+            if (A.dbg & 16384u) slow_piece_range(A.m, A.ref, ro, key, a, pc, q, m_lo, m_hi, lane);      // (profiling: the per-byte path)
+            else dense_piece<FASTQ>(A.m, A.ref, S, ro, key, a, pc, q, m_lo, m_hi, lane);
+        }
         q += pc.out_len;
     }
 }
@@ -1561,12 +1574,13 @@ static int scan_u32(ns_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n) {
 // ---------------------------------------------------------------------------------------------------------
 // copy phase, slow tiles, payload: the three kernels that write the sequence (and quality) lines of a batch
 static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fastq, uint64_t event_slots, hipEvent_t names_done = nullptr,
-                              const uint32_t *order = nullptr, int mode = MAT_REF) {
+                              const uint32_t *order = nullptr, int mode = MAT_REF, uint64_t max_seq_len = 0) {
     hipStream_t st = ctx->stream;
     if (A.prm.kind == NS_KIND_UNALIGNED) {
         if (names_done) HIPCHK(hipStreamWaitEvent(st, names_done, 0));
-        if (fastq) k_materialise_dense<true><<<dim3((unsigned)n), dim3(64), 0, st>>>(A);
-        else k_materialise_dense<false><<<dim3((unsigned)n), dim3(64), 0, st>>>(A);
+        const unsigned segs = (unsigned)std::min<uint64_t>(65535, (max_seq_len + NS_DENSE_SEG - 1) / NS_DENSE_SEG + 1);
+        if (fastq) k_materialise_dense<true><<<dim3((unsigned)n, segs), dim3(64), 0, st>>>(A);
+        else k_materialise_dense<false><<<dim3((unsigned)n, segs), dim3(64), 0, st>>>(A);
         HIPCHK(hipGetLastError());
         return NS_OK;
     }
@@ -2292,6 +2306,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         (rc = ensure(ctx, ctx->errlog, (size_t)info->errlog_bytes + 64)))
         return rc;
     A.records = (uint8_t *)ctx->records.p; A.errlog = (uint8_t *)ctx->errlog.p;
+    const uint64_t max_unaligned = prm->kind == NS_KIND_UNALIGNED ? stats[4] : 0;      // longest read of the batch (k_chain)
     HIPCHK(hipEventRecord(ctx->evt[5], st));
     const bool side_names = !A.hp && prm->emit_records;       // names + framing on the second stream, next to k_words
     if (side_names) {
@@ -2310,7 +2325,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
             HIPCHK(hipGetLastError());
         }
     } else if (prm->emit_records) {
-        if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, tot_cap, ctx->ev_join, meta_al ? nullptr : list_a))) return rc;
+        if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, tot_cap, ctx->ev_join, meta_al ? nullptr : list_a, MAT_REF, max_unaligned))) return rc;
     }
     HIPCHK(hipEventRecord(ctx->evt[7], st));
     if (prm->emit_errlog && prm->emit_records) {

@@ -330,13 +330,117 @@ __device__ inline void slow_piece_range(const DevModel &m, const DevRef &ref, co
     }
 }
 
-// ---- LDS-tiled path ---------------------------------------------------------------------------------------
 // every wavefront works on its own LDS tile: DS instructions of one wave execute in issue order, so a compiler-level fence is
 // all that is needed between an LDS write and a cross-lane LDS read (no s_barrier, no vmcnt drain)
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+
+// ---- dense pieces: lane per event -----------------------------------------------------------------------------
+// Unaligned reads (S:1482-1549) and the gaps of chimeric reads carry ~0.55 events per base: an event owns two output bytes on
+// average — its letters, then the reference bases copied behind them up to the next event.  One lane per event (item 0 = the stretch
+// in front of the first event): the lane fetches the <= 32 reference bytes its stretch can need with two unaligned 16-byte loads
+// (all of a round's loads are independent: no per-byte chains of dependent loads, which is what the longest read of a batch used to
+// spend its time on), writes its bytes into an LDS tile of 1024 output bytes, and the tile leaves with one 16-byte store per lane.
+#define NS_DENSE_TILE 1024u
+struct __align__(16) DenseLds { uint8_t out[NS_DENSE_TILE]; };
+
+template <bool FASTQ>
+__device__ inline void dense_piece(const DevModel &m, const DevRef &ref, DenseLds &S, const ReadOut &ro, const ns_key &key, uint32_t a,
+                                   const PieceCtx &pc, uint32_t pq, uint32_t m_lo, uint32_t m_hi, uint32_t lane) {
+    if (m_lo & 15u) { slow_piece_range(m, ref, ro, key, a, pc, pq, m_lo, m_hi, lane); return; }   // (the tiles below start on a multiple of 16)
+    const uint32_t n_items = pc.n_ev + 1u;                    // item jj > 0 = event jj - 1; item 0 starts at output offset 0, copies from 0
+    const uint8_t *seg0 = ref.bases + pc.chrom_base + pc.pos;
+    const uint64_t lin = pc.chrom_len - pc.pos;               // segment positions below this lie before the origin of a circular chromosome
+    uint32_t jb = 0;                                          // item in force at the tile start: the last one that starts at or before it
+    if (m_lo) {
+        uint32_t lo = 0, hi = pc.n_ev;                        // events with out_start <= m_lo
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (ev_out_start(pc.ev[mid]) <= m_lo) lo = mid + 1; else hi = mid; }
+        jb = uni(lo);
+    }
+    for (uint32_t M0 = m_lo; M0 < m_hi; M0 += NS_DENSE_TILE) {
+        const uint32_t M1 = min(M0 + NS_DENSE_TILE, m_hi);
+        uint32_t seen = 0;                                    // items with out_start <= M1 met in this tile
+        for (uint32_t jj0 = jb;; jj0 += 64) {
+            const uint32_t jj = jj0 + lane;
+            const bool valid = jj < n_items;
+            uint32_t os = 0, pl = 0, ty = 3, rp = 0, pos = 0, nxt = pc.out_len;
+            if (valid) {
+                if (jj) {
+                    const ns_event e = pc.ev[jj - 1];
+                    const uint32_t len = ns_ev_len(e.info);
+                    ty = ns_ev_type(e.info); os = ev_out_start(e); pos = e.pos;
+                    pl = ty == NS_DEL ? 0u : len; rp = e.pos + (ty == NS_INS ? 0u : len);
+                }
+                if (jj < pc.n_ev) nxt = ev_out_start(pc.ev[jj]);
+            }
+            const uint32_t lo = max(os, M0), hi = min(nxt, M1);
+            if (valid && lo < hi) {
+                // ---- letters of the event (mutate_read, S:1965-1995): letter i = field / digit i & 15 of word i >> 4
+                const uint32_t n_let = min(pl, hi - os);
+                uint32_t word = 0;
+                for (uint32_t i = 0; i < n_let; ++i) {
+                    if (!(i & 15u)) word = payload_word(key, pc.sid, a, jj - 1u, i >> 4);
+                    uint32_t b;
+                    if (ty == NS_INS) b = bases_atcg((word >> (2u * (i & 15u))) & 3u);
+                    else {
+                        const uint32_t x = pos + i;
+                        b = mis_from_digit(resolve_base(ref_base_at(ref, pc, x), key, pc.sid, a, x), next_digit3(word));
+                    }
+                    if (os + i >= lo) S.out[os + i - M0] = (uint8_t)b;
+                }
+                // ---- copied bases: output byte mm <- segment position rp + (mm - os - pl)
+                const uint32_t c_lo = max(lo, os + pl);
+                if (c_lo < hi) {
+                    const uint32_t x0 = rp + (c_lo - os - pl), cn = hi - c_lo;
+                    if (cn <= 32u && (uint64_t)x0 + 32u <= lin) {                      // (not across the origin of a circular chromosome)
+                        uint4 f0, f1;
+                        __builtin_memcpy(&f0, seg0 + x0, 16); __builtin_memcpy(&f1, seg0 + x0 + 16, 16);
+                        const bool marked = ((f0.x | f0.y | f0.z | f0.w | f1.x | f1.y | f1.z | f1.w) & 0x80808080u) != 0;   // IUPAC codes (case_convert, S:743-755)
+                        for (uint32_t i = 0; i < cn; ++i) {
+                            const uint32_t wv = i < 16 ? (i < 8 ? (i < 4 ? f0.x : f0.y) : (i < 12 ? f0.z : f0.w)) : (i < 24 ? (i < 20 ? f1.x : f1.y) : (i < 28 ? f1.z : f1.w));
+                            uint32_t b = (wv >> (8u * (i & 3u))) & 0xffu;
+                            if (marked) b = resolve_base(b, key, pc.sid, a, x0 + i);
+                            S.out[c_lo + i - M0] = (uint8_t)b;
+                        }
+                    } else {
+                        for (uint32_t i = 0; i < cn; ++i) {
+                            const uint32_t x = x0 + i;
+                            S.out[c_lo + i - M0] = resolve_base(ref_base_at(ref, pc, x), key, pc.sid, a, x);
+                        }
+                    }
+                }
+            }
+            seen += (uint32_t)__popcll(__ballot(valid && os <= M1));
+            if (__ballot(valid && os >= M1) || jj0 + 64u >= n_items) break;       // an item behind the tile was met / no items left
+        }
+        jb = jb + seen - 1u;                                  // the last item that starts at or before M1 is in force there
+        wave_sync();
+        // ---- the tile leaves: 16 bytes per lane (+ their qualities: class 'unmapped', S:1521, 1564)
+        const uint32_t m0 = M0 + 16u * lane;
+        if (m0 < M1) {
+            const uint32_t count = min(16u, M1 - m0);
+            const uint4 v = *reinterpret_cast<const uint4 *>(&S.out[16u * lane]);
+            uint64_t qlo = 0, qhi = 0;
+            if constexpr (FASTQ) {
+                const u32x4 w0 = ns_draw(key, ST_QUAL, pc.sid, a, m0 >> 3, 0), w1 = ns_draw(key, ST_QUAL, pc.sid, a, (m0 >> 3) + 1u, 0);
+                const uint32_t cls = pc.kind ? (uint32_t)NS_Q_UNMAPPED : (uint32_t)NS_Q_MATCH;
+                const uint32_t *thr = m.qual_thr + cls * NS_QUAL_LEVELS;
+                const uint16_t *lut = m.qual_lut + cls * 1024u;
+#pragma unroll
+                for (uint32_t i = 0; i < 8; ++i) {
+                    qlo |= (uint64_t)qual_value_lut(thr, lut, (ns_word(w0, i >> 1) >> (16u * (i & 1u))) & 0xffffu) << (8u * i);
+                    qhi |= (uint64_t)qual_value_lut(thr, lut, (ns_word(w1, i >> 1) >> (16u * (i & 1u))) & 0xffffu) << (8u * i);
+                }
+            }
+            store_chunk(ro, pq + m0, count, (uint64_t)v.x | (uint64_t)v.y << 32, (uint64_t)v.z | (uint64_t)v.w << 32, qlo, qhi);
+        }
+        wave_sync();
+    }
+}
+
+// ---- LDS-tiled path ---------------------------------------------------------------------------------------
 
 // a tile the fast path cannot take (its reference span straddles the origin of a circular chromosome): queued for
 // k_materialise_slow

@@ -17,6 +17,7 @@ def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "unaligned"
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
     fastq = len(sys.argv) > 3 and sys.argv[3] == "fastq"
+    max_len = int(sys.argv[4]) if len(sys.argv) > 4 else None          # optional -max (the longest read of a batch sets the tail of the wave-per-read kernels)
     tmp = tempfile.mkdtemp(prefix="nskind_")
     prefix = os.path.join(tmp, "hg002_like")
     synth.write_model(prefix, synth.SynthModelSpec(n_train=1_000_000, seed=SEED), write_pkl=False)
@@ -27,7 +28,7 @@ def main():
     e = E.Engine(0); e.set_reference(ref); e.load_model(mdl)
     kind = {"unaligned": E.NS_KIND_UNALIGNED, "perfect": E.NS_KIND_PERFECT}.get(what, E.NS_KIND_ALIGNED)
     for i in range(4):
-        b = e.generate(E.make_params(seed=SEED, first_read=i * n, n_reads=n, kind=kind, chimeric=what == "chimeric", max_len=ref.max_chrom, fastq=fastq))
+        b = e.generate(E.make_params(seed=SEED, first_read=i * n, n_reads=n, kind=kind, chimeric=what == "chimeric", max_len=max_len or ref.max_chrom, fastq=fastq))
         print(what, "reads", n, "mean len %.0f" % (int(b.info.total_bases) / n), "events/read %.0f" % (int(b.info.events_used) / n),
               "pieces/read %.2f" % (int(b.info.n_pieces) / n), "ms total %.3f" % b.info.ms_total,
               " ".join("%s=%.3f" % (k, v) for k, v in zip(E.KERNEL_NAMES, b.info.ms_kernel)))
