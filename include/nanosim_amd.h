@@ -129,6 +129,7 @@ typedef struct ns_model_tables {
  * simulation_unaligned(dna_type, min_l, max_l, median_l, sd_l, out_reads, fastq, num_simulate, uracil)
  *                                                                          src/simulator.py:1482      */
 enum { NS_KIND_ALIGNED = 0, NS_KIND_UNALIGNED = 1, NS_KIND_PERFECT = 2 };
+#define NS_EMIT_SIZES 2u
 
 typedef struct ns_params {
     uint64_t seed;          /* Philox key; (seed, read index) fully determine a read */
@@ -139,10 +140,12 @@ typedef struct ns_params {
     uint32_t kmer_bias;     /* k of -k/--KmerBias; 0 = off (falsy in the reference, S:1413,1920) */
     uint32_t chimeric;
     uint32_t use_lognormal; /* -med/-sd given */
-    uint32_t emit_records;  /* 1: format FASTA/FASTQ records on the device */
+    uint32_t emit_records;  /* 1: format FASTA/FASTQ records on the device; NS_EMIT_SIZES: compute record_bytes / errlog_bytes of the batch
+                             * without writing the images (sizing pass of a multi-rank run: every rank then writes at its final file offset) */
     int64_t min_len, max_len;
     double median_len, sd_len;
-    uint32_t emit_errlog;   /* 1: format the _aligned_error_profile rows on the device (S:2006-2008) */
+    uint32_t emit_errlog;   /* 1: format the _aligned_error_profile rows on the device (S:2006-2008); needs emit_records != 0 (the rows
+                             * quote the read names of the record image): with emit_records = 0 errlog_bytes is 0 */
     uint32_t meta;          /* 1: metagenome batch = one worker of simulation_aligned_metagenome (S:814-1040) / simulation_unaligned("metagenome") */
     uint32_t trx;           /* 1: transcriptome batch = one worker of simulation_aligned_transcriptome (S:1043-1263) /
                              * simulation_unaligned("transcriptome"); needs ns_set_transcriptome */

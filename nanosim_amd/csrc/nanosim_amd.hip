@@ -534,7 +534,7 @@ __global__ void __launch_bounds__(256) k_names(GenArgs A) {
     ns_read rd = A.reads[r];
     rd.rec_off = A.rec_off[r];
     A.reads[r].rec_off = rd.rec_off;
-    if (rd.flags || !A.prm.emit_records) return;
+    if (rd.flags || A.prm.emit_records != 1u) return;
     const int kind = (int)A.prm.kind;
     const ns_piece *pc = A.pieces + rd.piece_off;
     uint8_t *p = A.records + rd.rec_off;
@@ -2087,6 +2087,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     if (!prm || !info) return fail(ctx, NS_EINVAL, "null params/info");
     if (!ctx->has_model || !ctx->has_ref) return fail(ctx, NS_ESTATE, "ns_generate before ns_load_model/ns_set_reference");
     if (prm->kind > NS_KIND_PERFECT) return fail(ctx, NS_EINVAL, "bad kind");
+    if (prm->emit_records > NS_EMIT_SIZES) return fail(ctx, NS_EINVAL, "bad emit_records");
     if (prm->kind != NS_KIND_PERFECT && !(ctx->m.flags & NS_MODEL_HAS_ERRORS)) return fail(ctx, NS_EINVAL, "model has no error tables");
     if (prm->kind == NS_KIND_UNALIGNED && !prm->use_lognormal && !(ctx->m.flags & NS_MODEL_HAS_UNALIGNED))
         return fail(ctx, NS_EINVAL, "model has no unaligned-length KDE");
@@ -2302,13 +2303,15 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     HIPCHK(hipMemcpyAsync(&info->record_bytes, A.rec_off + n, 8, hipMemcpyDeviceToHost, st));
     if (prm->emit_errlog) HIPCHK(hipMemcpyAsync(&info->errlog_bytes, A.err_off + n, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if ((rc = ensure(ctx, ctx->records, (size_t)info->record_bytes + 64)) ||
-        (rc = ensure(ctx, ctx->errlog, (size_t)info->errlog_bytes + 64)))
+    if (prm->emit_records == 1u && ((rc = ensure(ctx, ctx->records, (size_t)info->record_bytes + 64)) ||
+                                    (rc = ensure(ctx, ctx->errlog, (size_t)info->errlog_bytes + 64))))
         return rc;
+    if (prm->emit_records == 0) info->errlog_bytes = 0;       // (no records: no error-profile image either; NS_EMIT_SIZES keeps the size)
     A.records = (uint8_t *)ctx->records.p; A.errlog = (uint8_t *)ctx->errlog.p;
     const uint64_t max_unaligned = prm->kind == NS_KIND_UNALIGNED ? stats[4] : 0;      // longest read of the batch (k_chain)
     HIPCHK(hipEventRecord(ctx->evt[5], st));
-    const bool side_names = !A.hp && prm->emit_records;       // names + framing on the second stream, next to k_words
+    const bool write_rec = prm->emit_records == 1u;            // (2 = NS_EMIT_SIZES: the sizes of the images only)
+    const bool side_names = !A.hp && write_rec;               // names + framing on the second stream, next to k_words
     if (side_names) {
         HIPCHK(hipEventRecord(ctx->ev_fork, st));
         HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
@@ -2318,17 +2321,17 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     if (side_names) HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
     HIPCHK(hipEventRecord(ctx->evt[6], st));
     if (A.hp) {          // second record pass of -k: the scratch read + its homopolymer edits -> the record
-        if (prm->emit_records) {
+        if (write_rec) {
             if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, tot_cap, nullptr, meta_al ? nullptr : list_a, MAT_HP_FINAL))) return rc;
         } else {
             k_hp_report<<<dim3((unsigned)((tot_pieces + 255) / 256)), blk, 0, st>>>(A, tot_pieces);
             HIPCHK(hipGetLastError());
         }
-    } else if (prm->emit_records) {
+    } else if (write_rec) {
         if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, tot_cap, ctx->ev_join, meta_al ? nullptr : list_a, MAT_REF, max_unaligned))) return rc;
     }
     HIPCHK(hipEventRecord(ctx->evt[7], st));
-    if (prm->emit_errlog && prm->emit_records) {
+    if (prm->emit_errlog && write_rec) {
         k_errlog<<<grid_w, blk_w, 0, st>>>(A);
         HIPCHK(hipGetLastError());
     }
@@ -2345,6 +2348,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     info->spliced_bytes = ctx->spliced_bytes;
     ctx->last = *info;
     ctx->last.n_events = tot_cap;
+    if (prm->emit_records != 1u) { ctx->last.record_bytes = 0; ctx->last.errlog_bytes = 0; }      // nothing to copy out
     ctx->has_batch = true;
     return NS_OK;
 }

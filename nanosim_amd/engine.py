@@ -17,6 +17,7 @@ NS_BUF_RECORDS, NS_BUF_READS, NS_BUF_PIECES, NS_BUF_EVENTS, NS_BUF_ERRLOG, NS_BU
 NS_SPLICED_BASE = 1 << 56
 NS_EINVAL, NS_ENODEV, NS_ENOMEM, NS_EHIP, NS_ESTATE = -1, -2, -3, -4, -5
 NS_KIND_ALIGNED, NS_KIND_UNALIGNED, NS_KIND_PERFECT = 0, 1, 2
+NS_EMIT_SIZES = 2
 KERNEL_NAMES = ("plan(k_nseg+k_lengths+scan+sort)", "k_chain", "k_names", "k_materialise", "k_hp", "k_errlog")
 EXPORTS = ("ns_abi_version", "ns_create", "ns_destroy", "ns_last_error", "ns_set_reference",
            "ns_set_reference_device", "ns_load_model", "ns_generate", "ns_copy_out", "ns_device_ptr",
@@ -240,7 +241,8 @@ def make_params(*, seed, first_read, n_reads, kind=NS_KIND_ALIGNED, fastq=False,
     p.seed, p.first_read, p.n_reads, p.kind = seed, first_read, n_reads, kind
     p.fastq, p.kmer_bias, p.chimeric = int(bool(fastq)), int(kmer_bias or 0), int(bool(chimeric))
     p.use_lognormal = int(median_len is not None and sd_len is not None)
-    p.emit_records, p.emit_errlog = int(bool(emit_records)), int(bool(emit_errlog))
+    p.emit_records = NS_EMIT_SIZES if emit_records == "sizes" else int(bool(emit_records))     # "sizes": record_bytes / errlog_bytes only
+    p.emit_errlog = int(bool(emit_errlog))
     p.min_len, p.max_len = int(min_len), int(max_len)
     p.median_len, p.sd_len = float(median_len or 0.0), float(sd_len or 0.0)
     p.meta = int(bool(meta))

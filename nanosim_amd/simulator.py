@@ -243,32 +243,70 @@ class StreamWriter:
             t.join()
 
 
+def _batch_params(n, first, *, seed, kind, fastq, chimeric, min_len, max_len, median_len, sd_len, want_errlog, kmer_bias, meta, trx, uracil,
+                  model_ir, emit_records=True):
+    return E.make_params(seed=seed, first_read=first, n_reads=n, kind=kind, fastq=fastq, chimeric=chimeric, kmer_bias=kmer_bias, min_len=min_len,
+                         max_len=max_len, median_len=median_len, sd_len=sd_len, emit_records=emit_records, emit_errlog=want_errlog, meta=meta,
+                         trx=trx, uracil=uracil, model_ir=model_ir)
+
+
+def _size_batches(eng, *, first, count, batch, **kw):
+    """Sizing pass of a multi-rank run: bytes of the record image and of the error profile this rank will produce for reads
+    [first, first + count), in the same batches the writing pass uses (ns_params.emit_records = NS_EMIT_SIZES: nothing is formatted)."""
+    rec = err = done = 0
+    while done < count:
+        n = min(batch, count - done)
+        b = eng.generate(_batch_params(n, first + done, emit_records="sizes", **kw))
+        rec += int(b.info.record_bytes); err += int(b.info.errlog_bytes)
+        done += n
+    return rec, err
+
+
 def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, chimeric, min_len, max_len, median_len,
-                   sd_len, want_errlog, kmer_bias=0, meta=False, err_header=b"", trx=False, uracil=False, model_ir=False):
+                   sd_len, want_errlog, kmer_bias=0, meta=False, err_header=b"", trx=False, uracil=False, model_ir=False, dist=None):
+    """Reads [first, first + count) of this rank into out_path (and their error-profile rows into err_path).  One rank: the files are
+    written front to back.  Several ranks (S:1588-1639: the reference's workers write sub-files that are concatenated afterwards): a
+    sizing pass tells every rank where its part starts, and all ranks write into the SAME files at their final offsets — no merge copy."""
     done = 0
     trace = os.environ.get("NS_CLI_TRACE") is not None       # per-batch host timing on stderr
     w = getattr(eng, "_stream_writer", None)           # one writer (staging buffers + threads) per engine
     if w is None:
         w = eng._stream_writer = StreamWriter(eng)
-    fr = os.open(out_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)             # (read access: the writer maps the file ranges)
-    fe = os.open(err_path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644) if err_path else None
+    kw = dict(seed=seed, kind=kind, fastq=fastq, chimeric=chimeric, min_len=min_len, max_len=max_len, median_len=median_len, sd_len=sd_len,
+              want_errlog=err_path is not None, kmer_bias=kmer_bias, meta=meta, trx=trx, uracil=uracil, model_ir=model_ir)
+    batch = getattr(eng, "_batch_reads", BATCH_READS)
+    rank = dist.get_rank() if dist is not None else 0
     off_r = off_e = 0
-    if fe is not None and err_header:                  # rank 0 opens the error profile with the column header (S:1634)
+    expect = None
+    if dist is not None:
+        sizes = _size_batches(eng, first=first, count=count, batch=batch, **kw)
+        (off_r, off_e), (tot_r, tot_e) = shard.file_offsets(dist, sizes)
+        off_e += len(err_header)                       # (every rank is handed the header; rank 0 writes it)
+        expect = (off_r + sizes[0], off_e + sizes[1])
+        if rank == 0:                                  # the files exist at their final size before anybody writes into them
+            for path, size in ((out_path, tot_r), (err_path, tot_e + len(err_header))):
+                if path:
+                    fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
+                    os.ftruncate(fd, size)
+                    os.close(fd)
+        dist.barrier()
+    flags = os.O_RDWR | (os.O_CREAT | os.O_TRUNC if dist is None else 0)
+    fr = os.open(out_path, flags, 0o644)               # (read access: the writer maps the file ranges)
+    fe = os.open(err_path, flags, 0o644) if err_path else None
+    if fe is not None and err_header and rank == 0:    # rank 0 opens the error profile with the column header (S:1634)
         os.pwrite(fe, err_header, 0)
-        off_e = len(err_header)
+        if dist is None:
+            off_e = len(err_header)
     try:
-        batch = getattr(eng, "_batch_reads", BATCH_READS)
         while done < count:
             n = min(batch, count - done)
-            p = E.make_params(seed=seed, first_read=first + done, n_reads=n, kind=kind, fastq=fastq, chimeric=chimeric, kmer_bias=kmer_bias,
-                              min_len=min_len, max_len=max_len, median_len=median_len, sd_len=sd_len,
-                              emit_records=True, emit_errlog=fe is not None, meta=meta, trx=trx, uracil=uracil, model_ir=model_ir)
+            p = _batch_params(n, first + done, **kw)
             t0 = time.perf_counter()
             try:
                 b = eng.generate(p)
             except E.EngineError as ex:              # not enough free HBM for this batch size (shared GPU): halve it and go on
-                if getattr(ex, "code", 0) != E.NS_ENOMEM or n <= 1000:
-                    raise
+                if getattr(ex, "code", 0) != E.NS_ENOMEM or n <= 1000 or dist is not None or meta:
+                    raise                            # (several ranks / metagenome workers: the batches are part of the result)
                 batch = eng._batch_reads = max(1000, n // 2)
                 continue
             t1 = time.perf_counter()
@@ -282,25 +320,25 @@ def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, 
                                     w.t_copy * 1e3, w.t_wait * 1e3))
                 w.t_copy = w.t_wait = 0.0
             done += n
-            sys.stdout.write(strftime("%Y-%m-%d %H:%M:%S") + ": Number of reads simulated >> " + str(first + done) + "\r")
-            sys.stdout.flush()
+            if rank == 0:
+                sys.stdout.write(strftime("%Y-%m-%d %H:%M:%S") + ": Number of reads simulated >> " + str(first + done) + "\r")
+                sys.stdout.flush()
     finally:
         w.drain()
         os.close(fr)
         if fe is not None:
             os.close(fe)
-    sys.stdout.write('\n')
+    if expect is not None and (off_r, off_e if fe is not None else expect[1]) != expect:
+        raise RuntimeError("sizing pass and writing pass disagree: %r != %r" % ((off_r, off_e), expect))
+    if rank == 0:
+        sys.stdout.write('\n')
+    if dist is not None:
+        dist.barrier()
 
 
 def run_genome(a, parser_g):
     validate_genome_args(a, parser_g)
-    rank, local_rank, world = shard.env_rank_world()
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    rank, device, world, dist, bdev = shard.init_dist()
     if a.KmerBias and not a.homopolymer:
         sys.stderr.write("\n-k/--KmerBias needs -hp (the reference crashes on the missing homopolymer parameters, S:504,639)\n")
         sys.exit(1)
@@ -319,16 +357,19 @@ def run_genome(a, parser_g):
         os.makedirs(d, exist_ok=True)
     if rank == 0:
         log("Read in reference ")
-    eng = E.Engine(local_rank)
+    eng = E.Engine(device)
     ref = M.read_fasta(a.ref_g, a.dna_type) if rank == 0 else None
-    if rank == 0 and len(ref.names) > 1 and a.dna_type == "circular":                       # S:354-356
-        sys.stderr.write("Do not choose circular if there is more than one chromosome in the genome!\n")
-        sys.exit(1)
+    # S:354-356; every rank leaves together (a rank that exits alone would leave the others waiting in the broadcast)
+    shard.agree(dist, not (rank == 0 and len(ref.names) > 1 and a.dna_type == "circular"),
+                "Do not choose circular if there is more than one chromosome in the genome!\n")
     keep = None
     if dist is not None:
-        import torch
-        ref, keep = shard.broadcast_reference(ref, dist, device=torch.device("cuda", local_rank))
-        eng.set_reference_device(keep.data_ptr(), ref)
+        ref, keep = shard.broadcast_reference(ref, dist, device=bdev)
+        if bdev is not None:
+            eng.set_reference_device(keep.data_ptr(), ref)
+        else:                                                                               # (gloo: the bases arrived in host memory)
+            ref = M.Reference(ref.names, keep.numpy(), ref.chrom_off, ref.circular)
+            eng.set_reference(ref)
     else:
         eng.set_reference(ref)
     if rank == 0:
@@ -338,12 +379,13 @@ def run_genome(a, parser_g):
     eng.load_model(mdl)
     number = a.number
     if a.coverage is not None:
-        print("\nCalculating the number of reads to be simulated based on the coverage, if you specified the number of reads "
-              "concurrently with the coverage, coverage will override number of reads.\n")
+        if rank == 0:
+            print("\nCalculating the number of reads to be simulated based on the coverage, if you specified the number of reads "
+                  "concurrently with the coverage, coverage will override number of reads.\n")
         number = calculate_read_number_from_coverage(ref, a.model_prefix, a.coverage)
     n_al, n_un = mdl.split_counts(number)
     max_len = int(min(a.max_len, ref.max_chrom))                                            # S:2318
-    seed = a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little") >> 1
+    seed = shard.share_seed(dist, a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little") >> 1)
     ext = ".fastq" if a.fastq else ".fasta"
     kind = E.NS_KIND_PERFECT if a.perfect else E.NS_KIND_ALIGNED
     if rank == 0:
@@ -351,28 +393,16 @@ def run_genome(a, parser_g):
             log("Simulating read length with log-normal distribution")
         log("Start simulation of aligned reads")
     lo, hi = shard.partition(n_al, world)[rank]
-    sub_reads = out + "_aligned_reads%d%s" % (rank, ext)
-    sub_err = out + "_error_profile%d" % rank
-    _write_batches(eng, sub_reads, sub_err, seed=seed, first=lo, count=hi - lo, kind=kind, fastq=a.fastq,
-                   chimeric=a.chimeric, min_len=a.min_len, max_len=max_len, median_len=a.median_len, sd_len=a.sd_len,
-                   want_errlog=True, kmer_bias=a.KmerBias or 0, err_header=ERR_HEADER if rank == 0 else b"")
-    if dist is not None:
-        dist.barrier()
-    if rank == 0:
-        shard.merge_subfiles(out + "_aligned_reads" + ext, [out + "_aligned_reads%d%s" % (r, ext) for r in range(world)])
-        shard.merge_subfiles(out + "_aligned_error_profile", [out + "_error_profile%d" % r for r in range(world)])
+    _write_batches(eng, out + "_aligned_reads" + ext, out + "_aligned_error_profile", seed=seed, first=lo, count=hi - lo, kind=kind,
+                   fastq=a.fastq, chimeric=a.chimeric, min_len=a.min_len, max_len=max_len, median_len=a.median_len, sd_len=a.sd_len,
+                   want_errlog=True, kmer_bias=a.KmerBias or 0, err_header=ERR_HEADER, dist=dist)
     if not a.perfect:                                                                       # S:1642-1672
         if rank == 0:
             log("Start simulation of random reads")
         lo, hi = shard.partition(n_un, world)[rank]
-        sub_un = out + "_unaligned_reads%d%s" % (rank, ext)
-        _write_batches(eng, sub_un, None, seed=seed, first=n_al + lo, count=hi - lo, kind=E.NS_KIND_UNALIGNED, fastq=a.fastq,
-                       chimeric=False, min_len=a.min_len, max_len=max_len, median_len=a.median_len, sd_len=a.sd_len,
-                       want_errlog=False)
-        if dist is not None:
-            dist.barrier()
-        if rank == 0:
-            shard.merge_subfiles(out + "_unaligned_reads" + ext, [out + "_unaligned_reads%d%s" % (r, ext) for r in range(world)])
+        _write_batches(eng, out + "_unaligned_reads" + ext, None, seed=seed, first=n_al + lo, count=hi - lo, kind=E.NS_KIND_UNALIGNED,
+                       fastq=a.fastq, chimeric=False, min_len=a.min_len, max_len=max_len, median_len=a.median_len, sd_len=a.sd_len,
+                       want_errlog=False, dist=dist)
     eng.close()
     if dist is not None:
         dist.destroy_process_group()
@@ -388,13 +418,7 @@ def run_metagenome(a, parser_mg):
     if a.KmerBias and not a.homopolymer:
         sys.stderr.write("\n-k/--KmerBias needs -hp (the reference crashes on the missing homopolymer parameters, S:504,639)\n")
         sys.exit(1)
-    rank, local_rank, world = shard.env_rank_world()
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    rank, device, world, dist, bdev = shard.init_dist()
     if rank == 0:
         print("\nrunning the code with following parameters:\n")
         for k in ("genome_list", "abun", "dna_type_list", "model_prefix"):
@@ -407,21 +431,22 @@ def run_metagenome(a, parser_mg):
     d = os.path.dirname(out)
     if d:
         os.makedirs(d, exist_ok=True)
-    eng = E.Engine(local_rank)
+    eng = E.Engine(device)
     keep = None
     if rank == 0:
         log("Read in reference ")
         mref = MG.read_metagenome(a.genome_list, a.dna_type_list)
         numbers, samples = MG.read_abundance(a.abun, mref.species)
     if dist is not None:
-        import torch
         info = [dict(species=mref.species, off=mref.species_chrom_off.tolist(), keys=mref.chrom_names, numbers=numbers,
                      samples=samples) if rank == 0 else None]
         dist.broadcast_object_list(info, src=0)
-        ref, keep = shard.broadcast_reference(mref.ref if rank == 0 else None, dist, device=torch.device("cuda", local_rank))
+        ref, keep = shard.broadcast_reference(mref.ref if rank == 0 else None, dist, device=bdev)
+        if bdev is None:
+            ref = M.Reference(ref.names, keep.numpy(), ref.chrom_off, ref.circular)
         mref = MG.MetaReference(ref, info[0]["species"], np.array(info[0]["off"], dtype=np.uint32), info[0]["keys"])
         numbers, samples = info[0]["numbers"], info[0]["samples"]
-        eng.set_metagenome(mref, dev_ptr=keep.data_ptr())
+        eng.set_metagenome(mref, dev_ptr=keep.data_ptr() if bdev is not None else None)
     else:
         eng.set_metagenome(mref)
     if rank == 0:
@@ -429,11 +454,7 @@ def run_metagenome(a, parser_mg):
     mdl = M.load_model(a.model_prefix, perfect=a.perfect, strandness=a.strandness, chimeric=a.chimeric, fastq=a.fastq,
                        homopolymer=a.homopolymer)
     eng.load_model(mdl)
-    seed = a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little") >> 1
-    if dist is not None and a.seed is None:
-        box = [seed]
-        dist.broadcast_object_list(box, src=0)
-        seed = box[0]
+    seed = shard.share_seed(dist, a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little") >> 1)
     ext = ".fastq" if a.fastq else ".fasta"
     max_len = a.max_len
     total_len = mref.total_len()
@@ -454,26 +475,17 @@ def run_metagenome(a, parser_mg):
         max_len = int(min(max_len, mref.max_chrom))                                         # S:2525
         base = out + "_" + sample
         lo, hi = shard.partition(n_al, world)[rank]
-        _write_batches(eng, base + "_aligned_reads%d%s" % (rank, ext), base + "_error_profile%d" % rank, seed=seed, first=first + lo,
+        _write_batches(eng, base + "_aligned_reads" + ext, base + "_aligned_error_profile", seed=seed, first=first + lo,
                        count=hi - lo, kind=E.NS_KIND_PERFECT if a.perfect else E.NS_KIND_ALIGNED, fastq=a.fastq, chimeric=a.chimeric,
                        min_len=a.min_len, max_len=max_len, median_len=a.median_len, sd_len=a.sd_len, want_errlog=True, meta=True,
-                       kmer_bias=0 if a.perfect else (a.KmerBias or 0), err_header=ERR_HEADER if rank == 0 else b"")
-        if dist is not None:
-            dist.barrier()
-        if rank == 0:
-            shard.merge_subfiles(base + "_aligned_reads" + ext, [base + "_aligned_reads%d%s" % (r, ext) for r in range(world)])
-            shard.merge_subfiles(base + "_aligned_error_profile", [base + "_error_profile%d" % r for r in range(world)])
+                       kmer_bias=0 if a.perfect else (a.KmerBias or 0), err_header=ERR_HEADER, dist=dist)
         if not a.perfect:                                                                   # S:1642
             if rank == 0:
                 log("Start simulation of random reads")
             lo, hi = shard.partition(n_un, world)[rank]
-            _write_batches(eng, base + "_unaligned_reads%d%s" % (rank, ext), None, seed=seed, first=first + n_al + lo, count=hi - lo,
+            _write_batches(eng, base + "_unaligned_reads" + ext, None, seed=seed, first=first + n_al + lo, count=hi - lo,
                            kind=E.NS_KIND_UNALIGNED, fastq=a.fastq, chimeric=False, min_len=a.min_len, max_len=max_len,
-                           median_len=a.median_len, sd_len=a.sd_len, want_errlog=False, meta=True)
-            if dist is not None:
-                dist.barrier()
-            if rank == 0:
-                shard.merge_subfiles(base + "_unaligned_reads" + ext, [base + "_unaligned_reads%d%s" % (r, ext) for r in range(world)])
+                           median_len=a.median_len, sd_len=a.sd_len, want_errlog=False, meta=True, dist=dist)
         first += n_al + n_un            # samples draw from disjoint read-index ranges of the same seed
     eng.close()
     if dist is not None:
@@ -505,13 +517,7 @@ def run_transcriptome(a, parser_t):
     if a.KmerBias and not a.homopolymer:
         sys.stderr.write("\n-k/--KmerBias needs -hp (the reference crashes on the missing homopolymer parameters, S:504,639)\n")
         sys.exit(1)
-    rank, local_rank, world = shard.env_rank_world()
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    rank, device, world, dist, bdev = shard.init_dist()
     if rank == 0:
         print("\nrunning the code with following parameters:\n")
         print("ref_g", a.ref_g); print("ref_t", a.ref_t); print("exp", a.exp); print("model_prefix", a.model_prefix); print("out", a.output)
@@ -526,16 +532,18 @@ def run_transcriptome(a, parser_t):
     d = os.path.dirname(out)
     if d:
         os.makedirs(d, exist_ok=True)
-    eng = E.Engine(local_rank)
+    eng = E.Engine(device)
     keep = None
     if rank == 0:
         log("Read in reference ")
         tr = TR.read_transcriptome(a.ref_t, a.exp, a.polya, a.basecaller)
     if dist is not None:
-        import torch
         info = [dict(ec=tr.expr_chrom, cum=tr.expr_cum, w=tr.expr_weight, pa=tr.polya, sc=tr.polya_scale) if rank == 0 else None]
         dist.broadcast_object_list(info, src=0)
-        ref, keep = shard.broadcast_reference(tr.ref if rank == 0 else None, dist, device=torch.device("cuda", local_rank))
+        ref, keep = shard.broadcast_reference(tr.ref if rank == 0 else None, dist, device=bdev)
+        if bdev is None:
+            ref = M.Reference(ref.names, keep.numpy(), ref.chrom_off, ref.circular)
+            keep = None
         tr = TR.TranscriptomeReference(ref, info[0]["ec"], info[0]["cum"], info[0]["w"], info[0]["pa"], info[0]["sc"])
     ir = None
     if model_ir:                                                                              # S:403-452
@@ -558,35 +566,22 @@ def run_transcriptome(a, parser_t):
         number = calculate_read_number_from_coverage(tr.ref, a.model_prefix, a.coverage)
     n_al, n_un = mdl.split_counts(number)
     max_len = int(min(a.max_len, tr.ref.max_chrom))                                           # S:2411
-    seed = a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little") >> 1
-    if dist is not None and a.seed is None:
-        box = [seed]
-        dist.broadcast_object_list(box, src=0)
-        seed = box[0]
+    seed = shard.share_seed(dist, a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little") >> 1)
     ext = ".fastq" if a.fastq else ".fasta"
     if rank == 0:
         log("Start simulation of aligned reads")
     lo, hi = shard.partition(n_al, world)[rank]
-    _write_batches(eng, out + "_aligned_reads%d%s" % (rank, ext), out + "_error_profile%d" % rank, seed=seed, first=lo, count=hi - lo,
+    _write_batches(eng, out + "_aligned_reads" + ext, out + "_aligned_error_profile", seed=seed, first=lo, count=hi - lo,
                    kind=E.NS_KIND_PERFECT if a.perfect else E.NS_KIND_ALIGNED, fastq=a.fastq, chimeric=False, min_len=a.min_len,
                    max_len=max_len, median_len=None, sd_len=None, want_errlog=True, trx=True, uracil=a.uracil, kmer_bias=a.KmerBias or 0,
-                   err_header=ERR_HEADER if rank == 0 else b"", model_ir=model_ir)
-    if dist is not None:
-        dist.barrier()
-    if rank == 0:
-        shard.merge_subfiles(out + "_aligned_reads" + ext, [out + "_aligned_reads%d%s" % (r, ext) for r in range(world)])
-        shard.merge_subfiles(out + "_aligned_error_profile", [out + "_error_profile%d" % r for r in range(world)])
+                   err_header=ERR_HEADER, model_ir=model_ir, dist=dist)
     if not a.perfect:                                                                         # S:1642-1672
         if rank == 0:
             log("Start simulation of random reads")
         lo, hi = shard.partition(n_un, world)[rank]
-        _write_batches(eng, out + "_unaligned_reads%d%s" % (rank, ext), None, seed=seed, first=n_al + lo, count=hi - lo,
+        _write_batches(eng, out + "_unaligned_reads" + ext, None, seed=seed, first=n_al + lo, count=hi - lo,
                        kind=E.NS_KIND_UNALIGNED, fastq=a.fastq, chimeric=False, min_len=a.min_len, max_len=max_len, median_len=None,
-                       sd_len=None, want_errlog=False, trx=True, uracil=a.uracil)
-        if dist is not None:
-            dist.barrier()
-        if rank == 0:
-            shard.merge_subfiles(out + "_unaligned_reads" + ext, [out + "_unaligned_reads%d%s" % (r, ext) for r in range(world)])
+                       sd_len=None, want_errlog=False, trx=True, uracil=a.uracil, dist=dist)
     eng.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -145,3 +145,52 @@ def test_transcriptome_mode_with_intron_retention(tmp_path):
     assert open(out + "_aligned_error_profile", "rb").read() == simulator.ERR_HEADER + exp["errlog"].tobytes()
     p = E.make_params(seed=99, first_read=n_al, n_reads=n_un, kind=E.NS_KIND_UNALIGNED, max_len=tr.ref.max_chrom, trx=True)
     assert open(out + "_unaligned_reads.fasta", "rb").read() == O.generate_trx(mdl, tr, p)["records"].tobytes()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_ranks(world, argv, tmp_path):
+    """the CLI under torch.distributed.run with `world` ranks, ALL on GPU 0 (NS_DEVICE), the reference broadcast over gloo"""
+    import subprocess
+    import sys
+    env = dict(os.environ, NS_DIST_BACKEND="gloo", NS_DEVICE="0", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "-m", "nanosim_amd.simulator"] + argv
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("flags", [["--chimeric"], ["--fastq", "-hp", "-k", "5"]])
+def test_genome_output_does_not_depend_on_the_number_of_ranks(tmp_path, flags):
+    """a read is a function of (seed, read index) — 2 and 3 ranks (one process per rank, read-index ranges, one
+    broadcast of the reference, every rank writing at its final file offsets) produce the bytes of the 1-rank run."""
+    base = ["genome", "-rg", os.path.join(GOLDEN, "genome_small.fa"), "-c", os.path.join(GOLDEN, "model_small", "training"),
+            "-n", "1203", "--seed", "424242"] + flags
+    ext = ".fastq" if "--fastq" in flags else ".fasta"
+    one = str(tmp_path / "w1" / "sim")
+    simulator.main(base + ["-o", one])
+    for world in (2, 3):
+        out = str(tmp_path / ("w%d" % world) / "sim")
+        _run_ranks(world, base + ["-o", out], tmp_path)
+        assert sorted(os.listdir(tmp_path / ("w%d" % world))) == sorted(os.listdir(tmp_path / "w1"))      # no sub-files left behind
+        for f in ("_aligned_reads" + ext, "_aligned_error_profile", "_unaligned_reads" + ext):
+            assert open(out + f, "rb").read() == open(one + f, "rb").read(), (world, f)
+
+
+def test_transcriptome_output_does_not_depend_on_the_number_of_ranks(tmp_path):
+    trx = os.path.join(GOLDEN, "trx")
+    base = ["transcriptome", "-rt", os.path.join(trx, "transcripts.fa"), "-e", os.path.join(trx, "expression.tsv"),
+            "-c", os.path.join(GOLDEN, "model_small", "training"), "-n", "900", "--seed", "99", "--no_model_ir", "--fastq"]
+    one = str(tmp_path / "w1" / "sim")
+    simulator.main(base + ["-o", one])
+    out = str(tmp_path / "w2" / "sim")
+    _run_ranks(2, base + ["-o", out], tmp_path)
+    for f in ("_aligned_reads.fastq", "_aligned_error_profile", "_unaligned_reads.fastq"):
+        assert open(out + f, "rb").read() == open(one + f, "rb").read(), f

@@ -91,24 +91,31 @@ def _rank_main(rank, world, port, tmp, q):
         full = M2.read_fasta(os.path.join(GOLDEN, "genome_small.fa"))
         ok = (meta.names == full.names and np.array_equal(meta.chrom_off, full.chrom_off)
               and np.array_equal(buf.numpy(), full.bases) and np.array_equal(meta.circular, full.circular))
-        # every rank writes the records of its read-index range; rank 0 merges in rank order (S:1626-1639)
+        # every rank sizes the records of its read-index range, learns where its part starts (rank order, S:1626-1639) and writes
+        # it at its FINAL offset of the common file; the seed of rank 0 reaches every rank; a failed check ends all ranks together
         n = 1001
         lo, hi = S2.partition(n, world)[rank]
-        sub = os.path.join(tmp, "reads%d.fasta" % rank)
-        with open(sub, "wb") as f:
-            for i in range(lo, hi):
-                f.write(b">read_%d\nACGT\n" % i)
-        dist.barrier()
+        part = b"".join(b">read_%d\nACGT\n" % i for i in range(lo, hi))
+        (off,), (total,) = S2.file_offsets(dist, (len(part),))
+        path = os.path.join(tmp, "reads.fasta")
         if rank == 0:
-            S2.merge_subfiles(os.path.join(tmp, "reads.fasta"), [os.path.join(tmp, "reads%d.fasta" % r) for r in range(world)])
+            fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
+            os.ftruncate(fd, total)
+            os.close(fd)
+        dist.barrier()
+        fd = os.open(path, os.O_RDWR)
+        os.pwrite(fd, part, off)
+        os.close(fd)
+        seed = S2.share_seed(dist, 1234 + rank)
+        S2.agree(dist, True)
         dist.barrier()
         dist.destroy_process_group()
-        q.put((rank, ok, lo, hi))
+        q.put((rank, ok and seed == 1234, lo, hi))
     except Exception as e:      # pragma: no cover
         q.put((rank, False, repr(e), 0))
 
 
-def test_two_rank_broadcast_and_merge_with_gloo(tmp_path):
+def test_two_rank_broadcast_and_final_offsets_with_gloo(tmp_path):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -123,7 +130,33 @@ def test_two_rank_broadcast_and_merge_with_gloo(tmp_path):
     lines = open(tmp_path / "reads.fasta").read().split("\n")
     names = lines[0:-1:2]
     assert names == [">read_%d" % i for i in range(1001)]
-    assert not (tmp_path / "reads0.fasta").exists()
+
+
+def _rank_disagree(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from nanosim_amd import shard as S2
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        S2.agree(dist, rank != 0, "rank 0 failed its check\n")       # rank 0 fails: BOTH ranks must leave with status 1
+    except SystemExit as e:
+        q.put((rank, e.code))
+        return
+    q.put((rank, "no exit"))
+
+
+def test_agree_ends_every_rank_together():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_disagree, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, 1), (1, 1)], res
 
 
 def test_coverage_read_count(small_ref):
