@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
             const uint64_t ev_off = A.l_off ? A.l_base + A.l_off[tid] : A.ev_base + A.ev_off[r];
             const uint64_t ev_cap64 = A.l_off ? A.l_off[tid + 1] - A.l_off[tid] : A.ev_off[r + 1] - A.ev_off[r];
             const uint32_t ev_cap = ev_cap64 > 0xffffffffull ? 0xffffffffu : (uint32_t)ev_cap64;
-            EvSink32 sink; sink.last_ins_len = 0; sink.overflow = false;
+            EvSink32 sink; sink.last_ins_len = 0; sink.overflow = false; sink.range = false;
             int64_t total = (int64_t)rd.head + rd.tail;
             uint32_t evn = 0;
             const uint32_t trx_chrom = trx_al ? pc[0].pos : 0u;      // planned by k_lengths
@@ -302,6 +302,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
                 if (!p.kind) total += e.l_new;                                           // S:1362
                 if (kind == NS_KIND_UNALIGNED) total = e.middle_ref;                     // S:1503
             }
+            if (sink.range) { overflow = true; st_over = 1ull << 40; break; }      // (reported apart from capacity overflows: stats[0] >> 40)
             if (sink.overflow) { overflow = true; break; }
             int64_t trx_len = 0;
             if (trx_al) {                                    // S:1143-1144: middle_ref > ref_trx_len -> start over (no length limits)
@@ -413,7 +414,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
             accepted = true;
         } while (false);
         if (lead) {
-            if (overflow) st_over = 1;
+            if (overflow && !st_over) st_over = 1;
             A.reads[r] = rd;
             if (meta_al) { /* a rejected read is re-planned by the next pass */ }
             else if (accepted) A.att_base[r] = a;       // a re-run of the batch starts every read at its accepted attempt
@@ -1551,6 +1552,8 @@ int ns_load_model(ns_ctx *ctx, const ns_model_tables *t) {
     return NS_OK;
 }
 
+#define NS_RANGE_MSG "a read does not fit the event record (a run of more than 4095 bases, or a net insertion / deletion balance beyond +-131071 " \
+                     "bases inside one segment): lower -max"
 static int scan_u64(ns_ctx *ctx, const uint64_t *in, uint64_t *out, size_t n) {
     size_t tmp = 0;
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, in, out, (int)n, ctx->stream));
@@ -2036,6 +2039,7 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
         HIPCHK(hipMemcpyAsync(stats, ctx->stats.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipEventElapsedTime(&ms, ctx->evt[3], ctx->evt[4])); ms_chain += ms;
+        if (stats[0] >> 40) return fail(ctx, NS_EINVAL, NS_RANGE_MSG);
         if (!stats[0]) break;
         // a read outgrew its event capacity (rare): the pass is repeated with twice the capacity
         info->n_overflow += stats[0];
@@ -2058,6 +2062,10 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
             HIPCHK(hipGetLastError());
         }
         memcpy(good_stats, stats, sizeof good_stats);
+        // the pieces of the reads this pass accepts go behind those of the earlier passes: a pass re-sorts the remaining segment counts, so
+        // the total over all passes can exceed the first plan (sum over the reads in their original order)
+        if ((rc = ensure_keep(ctx, ctx->pieces, (size_t)(pieces_passed + po) * sizeof(ns_piece) + 64, (size_t)pieces_passed * sizeof(ns_piece)))) return rc;
+        A.f_pieces = P.f_pieces = (ns_piece *)ctx->pieces.p;
         if ((rc = scan_u64(ctx, P.accept, P.accept_scan, np + 1))) return rc;
         k_meta_commit<<<grid_p, blk, 0, st>>>(P);
         HIPCHK(hipGetLastError());
@@ -2258,6 +2266,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
             HIPCHK(hipStreamSynchronize(st));
             HIPCHK(hipEventElapsedTime(&ms, ctx->evt[3], ctx->evt[4]));
             ms_chain += ms;
+            if (stats[0] >> 40) return fail(ctx, NS_EINVAL, NS_RANGE_MSG);
             if (stats[0]) { overflow = true; break; }
             cur_n = (uint32_t)(stats[6] & 0xffffffffull);
             if (!cur_n) { tot_cap = used; break; }

@@ -54,9 +54,13 @@ struct EvSink32 {
     int32_t shift;
     uint32_t last_ins_len;
     bool overflow;
+    bool range;          // an event does not fit the 8-byte record: run longer than NS_EV_LEN_MAX, or |shift| >= NS_EV_SHIFT_BIAS
 };
+// does the cumulative shift fit the 18-bit field of ns_event.info?
+__device__ __forceinline__ bool ev_shift_fits(int32_t shift) { return (uint32_t)(shift + NS_EV_SHIFT_BIAS) < 2u * (uint32_t)NS_EV_SHIFT_BIAS; }
 __device__ __forceinline__ void ev_push32(EvSink32 &s, int32_t pos, uint32_t type, int32_t len) {
     uint32_t l = len > (int32_t)NS_EV_LEN_MAX ? NS_EV_LEN_MAX : (uint32_t)len;
+    if (len > (int32_t)NS_EV_LEN_MAX || !ev_shift_fits(s.shift)) s.range = true;
     if (s.n < s.cap) {
         ns_event e; e.pos = (uint32_t)pos; e.info = ns_ev_pack(l, type, s.shift);
         s.ev[s.n] = e;
@@ -217,6 +221,7 @@ __device__ inline EList32 coop_unaligned_error_list(const Tabs &T, const ChainTa
                 }
             }
         }
+        bool bad = ln0 > NS_EV_LEN_MAX || ln1 > NS_EV_LEN_MAX || ln2 > NS_EV_LEN_MAX;       // (a merged insertion of > 4095 bases)
         ln0 = min(ln0, NS_EV_LEN_MAX); ln1 = min(ln1, NS_EV_LEN_MAX); ln2 = min(ln2, NS_EV_LEN_MAX);
         auto dsh = [](uint32_t ty, uint32_t ln) { return ty == NS_INS ? ln : ty == NS_DEL ? 0u - ln : 0u; };
         const uint32_t d0 = n_ev > 0 ? dsh(ty0, ln0) : 0u, d1 = n_ev > 1 ? dsh(ty1, ln1) : 0u, d2 = n_ev > 2 ? dsh(ty2, ln2) : 0u;
@@ -224,6 +229,8 @@ __device__ inline EList32 coop_unaligned_error_list(const Tabs &T, const ChainTa
         const uint32_t n_incl = wave_incl_scan(n_ev), sh_incl = wave_incl_scan(dtot);
         const uint32_t slot = s.n + n_incl - n_ev;
         const uint32_t sh = (uint32_t)s.shift + sh_incl - dtot;
+        if (n_ev && !ev_shift_fits((int32_t)(sh + dtot))) bad = true;
+        if (__ballot(bad)) s.range = true;
         if (n_ev > 0) { if (slot < s.cap) { ns_event e; e.pos = ps0; e.info = ns_ev_pack(ln0, ty0, (int32_t)sh); s.ev[slot] = e; } }
         if (n_ev > 1) { if (slot + 1 < s.cap) { ns_event e; e.pos = ps1; e.info = ns_ev_pack(ln1, ty1, (int32_t)(sh + d0)); s.ev[slot + 1] = e; } }
         if (n_ev > 2) { if (slot + 2 < s.cap) { ns_event e; e.pos = ps2; e.info = ns_ev_pack(ln2, ty2, (int32_t)(sh + d0 + d1)); s.ev[slot + 2] = e; } }
@@ -310,6 +317,7 @@ __device__ inline EList32 coop_error_list(const Tabs &T, const ChainTab &c, int3
             }
             {   // ev_push32 into the block buffer
                 const uint32_t l = step > (int32_t)NS_EV_LEN_MAX ? NS_EV_LEN_MAX : (uint32_t)step;
+                if (step > (int32_t)NS_EV_LEN_MAX || !ev_shift_fits(s.shift)) s.range = true;
                 ns_event e; e.pos = (uint32_t)epos; e.info = ns_ev_pack(l, (uint32_t)error, s.shift);
                 if (lane == 0) S.ev_buf[nl] = e;
                 ++nl;

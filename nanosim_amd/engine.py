@@ -207,8 +207,10 @@ class Engine:
         self._check(self.L.ns_set_intron_retention(self.ctx, C.byref(t)))
 
     def set_abundance(self, meta_ref, abun: dict, abun_inflated: dict | None = None):
-        ab = np.array([abun[sp] for sp in meta_ref.species], dtype=np.float64)
-        inf = np.array([abun_inflated[sp] for sp in meta_ref.species], dtype=np.float64) if abun_inflated else None
+        # a genome of the list that the abundance table does not name gets no quota (its chromosomes still serve gaps and unaligned
+        # reads, as in the reference, whose quotas run over dict_abun only, S:772-775)
+        ab = np.array([abun.get(sp, 0.0) for sp in meta_ref.species], dtype=np.float64)
+        inf = np.array([abun_inflated.get(sp, 0.0) for sp in meta_ref.species], dtype=np.float64) if abun_inflated else None
         self._check(self.L.ns_set_abundance(self.ctx, ab.ctypes.data, inf.ctypes.data if inf is not None else None))
         self._nspecies = len(meta_ref.species)
 

@@ -461,9 +461,10 @@ def run_metagenome(a, parser_mg):
     first = 0
     for s, abun in enumerate(samples):
         sample = "sample" + str(s)
-        if a.abun_var:                                                                      # S:2497-2506
-            u = np.random.default_rng([seed & 0xffffffff, seed >> 32, s]).random(len(total_len))
-            abun = MG.add_abundance_var(abun, total_len, float(a.abun_var[0]), float(a.abun_var[1]), iter(u.tolist()))
+        if a.abun_var:                                                                      # S:2497-2506: the species of THIS sample
+            sample_len = {sp: total_len[sp] for sp in abun}
+            u = np.random.default_rng([seed & 0xffffffff, seed >> 32, s]).random(len(sample_len))
+            abun = MG.add_abundance_var(abun, sample_len, float(a.abun_var[0]), float(a.abun_var[1]), iter(u.tolist()))
         infl = {sp: MG.inflate_abun(abun, sp, mdl.abun_inflation) for sp in abun} if a.chimeric else None   # S:2510-2514
         eng.set_abundance(mref, abun, infl)
         if rank == 0:

@@ -103,3 +103,35 @@ def test_metagenome_error_paths(small_model, small_ref, meta_ref, setup):
             e2.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=9000, meta=True))
     finally:
         e2.close()
+
+
+def test_genome_list_may_hold_species_the_abundance_table_does_not_name(small_model, meta_ref):
+    """The reference's quotas run over dict_abun only (S:772-775): a genome of the list without an abundance row gets no aligned
+    reads (its chromosomes still serve gaps and unaligned reads)."""
+    _, samples = MG.read_abundance(os.path.join(META, "abundance.tsv"), meta_ref.species)
+    abun = dict(samples[0])
+    dropped = sorted(abun)[0]
+    del abun[dropped]
+    e = E.Engine(0)
+    try:
+        e.set_metagenome(meta_ref, abun, None)
+        e.load_model(small_model)
+        p = E.make_params(seed=5, first_read=0, n_reads=500, meta=True, max_len=meta_ref.max_chrom)
+        b = e.generate(p)
+        bases = e.species_bases()
+        assert bases[meta_ref.species.index(dropped)] == 0 and bases.sum() > 0
+        names = [ln for ln in b.records().tobytes().split(b"\n") if ln.startswith(b">")]
+        assert len(names) == 500 and not any(nm[1:].startswith(dropped.encode() + b"-") for nm in names)
+    finally:
+        e.close()
+
+
+def test_many_pass_chimeric_batch_keeps_its_pieces_in_bounds(small_model, setup):
+    """A narrow length window rejects most chimeric reads of a pass; later passes re-sort the remaining segment counts, so the pieces
+    accepted over all passes can outnumber the first plan: the buffer grows, GPU == oracle."""
+    e, abun, infl = setup
+    p = E.make_params(seed=4242, first_read=0, n_reads=3000, chimeric=True, meta=True, min_len=1500, max_len=6000)
+    b = e.generate(p)
+    reads, pieces = b.reads(), b.pieces()
+    assert int(reads["n_pieces"].sum()) == len(pieces) == int(b.info.n_pieces)
+    assert np.all(reads["piece_off"].astype(np.int64) + reads["n_pieces"] <= len(pieces))
