@@ -361,21 +361,67 @@ class Model:
         return t
 
 
+def _kde_pickle_tolerant(path: str):
+    """(training data, bandwidth) of a pickled sklearn KernelDensity WITHOUT building the sklearn objects: the pre-trained NanoSim
+    models were pickled with scikit-learn 0.22 (README.md:41) and do not load under a current scikit-learn (moved modules, changed
+    Cython tree layout).  Every sklearn symbol of the pickle becomes a stub that just keeps its constructor arguments / state; the
+    KDTree's state tuple starts with the training matrix, the estimator's state dict holds `bandwidth` (`bandwidth_` from 1.2 on)."""
+    from joblib.numpy_pickle import NumpyUnpickler
+
+    class _Stub:
+        def __init__(self, *a, **k):
+            self.args, self.state = a, None
+
+        def __setstate__(self, st):
+            self.state = st
+
+    class _Unpickler(NumpyUnpickler):
+        def find_class(self, module, name):
+            if module.split(".")[0] == "sklearn":
+                return type(name, (_Stub,), {})
+            return super().find_class(module, name)
+
+    import inspect
+    with open(path, "rb") as f:
+        if "ensure_native_byte_order" in inspect.signature(NumpyUnpickler.__init__).parameters:      # joblib >= 1.3
+            est = _Unpickler(path, f, True, mmap_mode=None).load()
+        else:
+            est = _Unpickler(path, f, mmap_mode=None).load()
+    st = est.state if isinstance(est.state, dict) else est.__dict__
+    tree = st["tree_"]
+    data = tree.state[0] if isinstance(tree.state, (tuple, list)) else tree.state["data"]
+    bw = st.get("bandwidth_", None)
+    if bw is None:
+        bw = st["bandwidth"]
+    return np.asarray(data, dtype=np.float64), float(bw)
+
+
+def _kde_pickle(path: str):
+    """(training matrix, bandwidth) of `<prefix>_<name>.pkl` (S:545-567): through sklearn when the pickle loads, else tolerant"""
+    if os.environ.get("NS_KDE_TOLERANT") != "1":
+        try:
+            import joblib                      # only needed for genuine trained models (SURVEY.md App. C)
+            kde = joblib.load(path)
+            data = np.asarray(kde.tree_.data, dtype=np.float64)
+            bw = getattr(kde, "bandwidth_", None)
+            if bw is None:
+                bw = kde.bandwidth
+            return data, float(bw)
+        except Exception:                      # wrong scikit-learn for this pickle
+            pass
+    return _kde_pickle_tolerant(path)
+
+
 def _load_kde(prefix: str, name: str, npz):
     if npz is not None and name + "_data" in npz:
         return np.asarray(npz[name + "_data"], dtype=np.float64), float(npz[name + "_bw"])
     path = prefix + "_" + name + ".pkl"
     if not os.path.exists(path):
         return None
-    import joblib                      # only needed for genuine trained models
-    kde = joblib.load(path)
-    data = np.asarray(kde.tree_.data, dtype=np.float64)
+    data, bw = _kde_pickle(path)
     if data.ndim == 2 and data.shape[1] != 1:
         raise ValueError(path + ": only 1-D KDEs are supported on this path")
-    bw = getattr(kde, "bandwidth_", None)
-    if bw is None:
-        bw = kde.bandwidth
-    return np.ascontiguousarray(data.reshape(-1)), float(bw)
+    return np.ascontiguousarray(data.reshape(-1)), bw
 
 
 def _load_kde2d(prefix: str, npz):
@@ -386,11 +432,7 @@ def _load_kde2d(prefix: str, npz):
         path = prefix + "_aligned_region_2d.pkl"
         if not os.path.exists(path):
             return None
-        import joblib
-        kde = joblib.load(path)
-        data = np.asarray(kde.tree_.data, dtype=np.float64)
-        bw = getattr(kde, "bandwidth_", None)
-        bw = float(kde.bandwidth if bw is None else bw)
+        data, bw = _kde_pickle(path)
     order = np.argsort(data[:, 0], kind="stable")
     return np.ascontiguousarray(data[order, 0]), np.ascontiguousarray(data[order, 1]), bw
 

@@ -333,3 +333,49 @@ def synth_annotation(recs, seed: int, *, n_chrom: int = 3, chr_prefix: bool = Tr
     genome = [(("chr" if chr_prefix else "") + str(c + 1) + " synthetic chromosome", np.concatenate(chroms[c])) for c in range(n_chrom)]
     model = "state\tno_IR\tIR\n" + "".join("%s\t%r\t%r\n" % (st, p[0], p[1]) for st, p in zip(("start", "no_IR", "IR"), p_model))
     return genome, "\n".join(lines) + "\n", model
+
+
+# zymo10_like: the ten species of the reference's sample_config_file/ (metagenome_list_for_simulation,
+# dna_type_list.tsv: chromosome counts and topology; genome sizes of the ZymoBIOMICS standard) with the two abundance columns of
+# abundance_for_simulation_multi_sample.tsv (even / log-distributed).  Content is seeded random sequence.
+ZYMO10 = [  # (species, [(chromosome key, length, circular)], even abundance, log abundance)
+    ("Bacillus_subtilis", [("BS-pilon-polished-v3-ST170922", 4_045_677, 1)], 12, 0.89),
+    ("Cryptococcus_neoformans", [("NC-0267%d" % (45 + i), int(19_000_000 / 14 * (1.35 - 0.05 * i)), 0) for i in range(14)] + [("NC-018792", 24_919, 1)], 2, 0.00089),
+    ("Enterococcus_faecalis", [("Enterococcus-faecalis-complete-genome", 2_845_392, 1)], 12, 0.00089),
+    ("Escherichia_coli", [("Escherichia-coli-plasmid", 110_007, 1), ("Escherichia-coli-chromosome", 4_765_434, 1)], 12, 0.089),
+    ("Lactobacillus_fermentum", [("Lactobacillus-fermentum-complete-genome", 1_905_333, 1)], 12, 0.0089),
+    ("Listeria_monocytogenes", [("Listeria-monocytogenes-complete-genome", 2_992_342, 1)], 12, 89.1),
+    ("Pseudomonas_aeruginosa", [("Pseudomonas-aeruginosa-complete-genome", 6_792_330, 1)], 12, 8.9),
+    ("Saccharomyces_cerevisiae", [("NC-0011%d" % (33 + i), n, 0) for i, n in enumerate(
+        [230_218, 813_184, 316_620, 1_531_933, 576_874, 270_161, 1_090_940, 562_643, 439_888, 745_751, 666_816, 1_078_177, 924_431, 784_333,
+         1_091_291, 948_066])] + [("NC-001224", 85_779, 1)], 2, 0.89),
+    ("Salmonella_enterica", [("Salmonella-enterica-plasmid1", 49_572, 1), ("Salmonella-enterica-chromosome", 4_759_746, 1)], 12, 0.089),
+    ("Staphylococcus_aureus", [("Staphylococcus-aureus-chromosome", 2_718_780, 1), ("Staphylococcus-aureus-plasmid1", 6_339, 1),
+                               ("Staphylococcus-aureus-plasmid2", 2_218, 1), ("Staphylococcus-aureus-plasmid3", 2_995, 1)], 12, 0.000089),
+]
+
+
+def zymo10_like(seed: int):
+    """-> (chromosome names '<species>-<key>', concatenated bases, chrom_off, circular flags, species, species_chrom_off, keys per species,
+    [even abundances, log abundances])"""
+    names, chunks, circ, species, sp_off, keys = [], [], [], [], [0], []
+    for si, (sp, chroms, _, _) in enumerate(ZYMO10):
+        species.append(sp)
+        keys.append([k for k, _, _ in chroms])
+        for ci, (k, n, c) in enumerate(chroms):
+            names.append(sp + "-" + k)
+            chunks.append(synth_sequence(int(n), seed + 1000 * si + ci, n_frac=0.0005, iupac_frac=0.0002, lower_frac=0.02, hp_boost=0.005))
+            circ.append(c)
+        sp_off.append(sp_off[-1] + len(chroms))
+    lens = np.array([len(c) for c in chunks], dtype=np.uint64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    abun = [{sp: float(e) for sp, _, e, _ in ZYMO10}, {sp: float(g) for sp, _, _, g in ZYMO10}]
+    return names, np.concatenate(chunks), off, np.array(circ, dtype=np.uint8), species, np.array(sp_off, dtype=np.uint32), keys, abun
+
+
+def grch38_like(seed: int):
+    """24 chromosomes with the GRCh38 primary lengths (3.1 Gb): (names, bases, chrom_off, circular)"""
+    names = ["chr%d" % (i + 1) for i in range(22)] + ["chrX", "chrY"]
+    chunks = [synth_sequence(n, seed + i, n_frac=0.0005, iupac_frac=0.0002, lower_frac=0.02, hp_boost=0.005) for i, n in enumerate(GRCH38_LENS)]
+    off = np.concatenate([[0], np.cumsum(np.array(GRCH38_LENS, dtype=np.uint64))]).astype(np.uint64)
+    return names, np.concatenate(chunks), off, np.zeros(24, dtype=np.uint8)

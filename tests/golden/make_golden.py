@@ -855,6 +855,18 @@ def fixture_distributions(prefix, fasta, workdir, n_reads, fastq, kmer=None, chi
     return out
 
 
+def fixture_coverage(prefix, fasta):
+    """calculate_read_number_from_coverage (S:2024-2068) is a Monte-Carlo estimate (10^7 KDE samples from the global numpy generator):
+    its value for three seeds and two coverages; the build's closed form must land inside their spread."""
+    S = import_reference()
+    out = []
+    for seed in (1, 2, 3):
+        for cov in (30.0, 5000.0):
+            np.random.seed(seed)
+            out.append(dict(seed=seed, coverage=cov, reads=int(S.calculate_read_number_from_coverage(fasta, prefix, cov))))
+    return dict(reference_fasta="genome_small.fa", cases=out)
+
+
 def write_distributions(prefix, fasta, workdir, n):
     """Every run is large enough for the 1 % KS gate of the north star (noise floor of two 10^5-read samples: ~0.004)."""
     d = dict(fasta=fixture_distributions(prefix, fasta, workdir, n, False, n_unaligned=n),
@@ -874,6 +886,8 @@ def main():
     ap.add_argument("--only-trx", action="store_true", help="write reference_transcriptome.json only")
     ap.add_argument("--only-ir", action="store_true", help="write the intron-retention inputs and reference_ir.json only")
     ap.add_argument("--only-dist", action="store_true", help="write reference_distributions.json only (whole-run distribution pins)")
+    ap.add_argument("--only-coverage", action="store_true", help="write reference_coverage.json only (-x / --coverage read counts)")
+    ap.add_argument("--only-meta-runs", action="store_true", help="replace the whole-run part (runs) of reference_metagenome.json: 8 workers x 12 500 reads, plain and chimeric, + 8 x 6 000 perfect reads")
     a = ap.parse_args()
     workdir = tempfile.mkdtemp(prefix="nsgolden_")
     try:
@@ -887,13 +901,27 @@ def main():
         if a.only_trx:
             build_trx_inputs()
             fx = fixture_transcriptome(import_reference(), prefix)
-            fx["runs"] = fixture_transcriptome_runs(prefix, workdir)
+            fx["runs"] = fixture_transcriptome_runs(prefix, workdir, n_reads=96000)
             with open(os.path.join(HERE, "reference_transcriptome.json"), "w") as f:
                 json.dump(fx, f)
             print("reference_transcriptome.json written")
             return
         if a.only_dist:
             write_distributions(prefix, fasta, workdir, a.dist_reads)
+            return
+        if a.only_meta_runs:
+            mg = json.load(open(os.path.join(HERE, "reference_metagenome.json")))
+            mg["runs"] = fixture_metagenome_runs(prefix, workdir, n_reads=100000)
+            mg["runs"]["perfect"] = fixture_metagenome_perfect(prefix, workdir, n_reads=48000)
+            mg["runs"]["reads_per_worker"] = dict(plain=12500, chimeric=12500, perfect=6000)
+            with open(os.path.join(HERE, "reference_metagenome.json"), "w") as f:
+                json.dump(mg, f)
+            print("reference_metagenome.json: runs rewritten")
+            return
+        if a.only_coverage:
+            with open(os.path.join(HERE, "reference_coverage.json"), "w") as f:
+                json.dump(fixture_coverage(prefix, fasta), f)
+            print("reference_coverage.json written")
             return
         if a.only_meta_perfect:
             mg = json.load(open(os.path.join(HERE, "reference_metagenome.json")))

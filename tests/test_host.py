@@ -159,6 +159,19 @@ def test_agree_ends_every_rank_together():
     assert res == [(0, 1), (1, 1)], res
 
 
+def test_coverage_read_count_matches_the_reference_estimate(small_ref):
+    """-x / --coverage (S:2024-2068): the reference averages 10^7 KDE samples; a Gaussian KDE sample has the mean of its training
+    vector, so the build takes the expectation.  Fixture: the reference's own result for three seeds (tests/golden/make_golden.py
+    --only-coverage) — the closed form lies within their Monte-Carlo spread (relative 2e-4 at 10^7 samples)."""
+    import json
+    prefix = os.path.join(GOLDEN, "model_small", "training")
+    fx = json.load(open(os.path.join(GOLDEN, "reference_coverage.json")))
+    for cov in sorted({c["coverage"] for c in fx["cases"]}):
+        ref_counts = [c["reads"] for c in fx["cases"] if c["coverage"] == cov]
+        mine = simulator.calculate_read_number_from_coverage(small_ref, prefix, cov)
+        assert min(ref_counts) - max(2, 1e-3 * mine) <= mine <= max(ref_counts) + max(2, 1e-3 * mine), (cov, mine, ref_counts)
+
+
 def test_coverage_read_count(small_ref):
     prefix = os.path.join(GOLDEN, "model_small", "training")
     n = simulator.calculate_read_number_from_coverage(small_ref, prefix, 30.0)
@@ -207,3 +220,31 @@ def test_stream_writer_pipelines_slices_in_order(tmp_path, mapped):
         os.close(f0); os.close(f1)
     assert open(tmp_path / "a.bin", "rb").read() == bufs[0].tobytes() * 3
     assert open(tmp_path / "b.bin", "rb").read() == b"HEADER\n" + bufs[4].tobytes() * 3
+
+
+def test_trained_pickles_load_like_the_npz(tmp_path, monkeypatch):
+    """a model directory that holds only the reference's own files — sklearn KernelDensity pickles written with
+    joblib (S:545-577) — gives the tables of the neutral .npz form, both through sklearn and through the version-tolerant reader (the
+    pre-trained models were pickled with scikit-learn 0.22, README.md:41, and do not unpickle under a current one)."""
+    from nanosim_amd import synth
+    spec = synth.SynthModelSpec(n_train=3000, seed=19)
+    a, b = str(tmp_path / "npz" / "training"), str(tmp_path / "pkl" / "training")
+    synth.write_model(a, spec, write_pkl=False, write_npz=True)
+    synth.write_model(b, spec, write_pkl=True, write_npz=False)
+    assert not os.path.exists(b + "_kde.npz") and os.path.exists(b + "_aligned_region.pkl") and os.path.exists(b + "_aligned_region_2d.pkl")
+    kw = dict(chimeric=True, homopolymer=True, fastq=True)
+    ref = M.load_model(a, **kw)
+    ref_t = M.load_model(a, transcriptome=True, fastq=True)
+    for tolerant in ("0", "1"):
+        monkeypatch.setenv("NS_KDE_TOLERANT", tolerant)
+        got = M.load_model(b, **kw)
+        assert sorted(got.kde) == sorted(ref.kde)
+        for k in ref.kde:
+            assert np.array_equal(got.kde[k][0], ref.kde[k][0]) and got.kde[k][1] == ref.kde[k][1], (tolerant, k)
+        assert np.array_equal(got.qual_thr, ref.qual_thr) and np.array_equal(got.trans, ref.trans)
+        got_t = M.load_model(b, transcriptome=True, fastq=True)
+        for x, y in zip(got_t.kde2d, ref_t.kde2d):
+            assert np.array_equal(x, y)
+    # --perfect reads the other aligned-length pickle (S:560-567)
+    monkeypatch.setenv("NS_KDE_TOLERANT", "1")
+    assert np.array_equal(M.load_model(b, perfect=True).kde[M.NS_KDE_ALIGNED][0], M.load_model(a, perfect=True).kde[M.NS_KDE_ALIGNED][0])

@@ -110,8 +110,8 @@ def _species_of_piece(meta_ref, chrom):
 
 @pytest.mark.parametrize("chimeric", [False, True])
 def test_oracle_metagenome_batches_match_reference_runs(fx, meta_ref, chimeric):
-    """8 workers x 3000 reads of the reference vs 8 oracle batches: species base fractions (incl. the fall-back to other
-    species when a chromosome is too short), read lengths, chimeric share, one strand per pass, name grammar."""
+    """8 workers x 12 500 reads of the reference vs 8 oracle batches of the same size: species base fractions (incl. the fall-back to
+    other species when a chromosome is too short), read lengths (KS <= 1 %), chimeric share, one strand per pass, name grammar."""
     from nanosim_amd import engine as E
     from tests import oracle_lib as O
     from tests.test_distributions import ks_vs_quantiles
@@ -121,8 +121,9 @@ def test_oracle_metagenome_batches_match_reference_runs(fx, meta_ref, chimeric):
     infl = {sp: MG.inflate_abun(abun, sp, mdl.abun_inflation) for sp in abun} if chimeric else None
     bases = np.zeros(len(meta_ref.species))
     lens, n_chim, strands_single = [], 0, 0
+    per = fx["runs"]["reads_per_worker"]["chimeric" if chimeric else "plain"]
     for w in range(8):
-        p = E.make_params(seed=900 + w, first_read=w * 3000, n_reads=3000, chimeric=chimeric, max_len=meta_ref.max_chrom)
+        p = E.make_params(seed=900 + w, first_read=w * per, n_reads=per, chimeric=chimeric, max_len=meta_ref.max_chrom)
         out = O.generate_meta(mdl, meta_ref, abun, infl, p)
         rd, pc = out["reads"], out["pieces"]
         aligned = pc[pc["kind"] == 0]
@@ -141,10 +142,10 @@ def test_oracle_metagenome_batches_match_reference_runs(fx, meta_ref, chimeric):
     frac = bases / bases.sum()
     ref_tot = sum(run["bases"].values())
     for i, spn in enumerate(meta_ref.species):
-        assert abs(frac[i] - run["bases"][spn] / ref_tot) < 0.012, (spn, frac[i], run["bases"][spn] / ref_tot)
+        assert abs(frac[i] - run["bases"][spn] / ref_tot) < 0.01, (spn, frac[i], run["bases"][spn] / ref_tot)
     lens = np.concatenate(lens)
-    assert abs(lens.mean() / run["mean_len"] - 1) < 0.02
-    assert ks_vs_quantiles(lens, run["q_len"]) < 0.02
+    assert abs(lens.mean() / run["mean_len"] - 1) < 0.01
+    assert ks_vs_quantiles(lens, run["q_len"]) <= 0.01
     ref_chim = sum(wk["n_chim"] for wk in run["workers"])
     if chimeric:
         assert 0.5 * ref_chim <= n_chim <= 2.0 * ref_chim + 10, (n_chim, ref_chim)
@@ -165,8 +166,9 @@ def test_oracle_perfect_metagenome_batches_match_reference_runs(fx, meta_ref):
     abun = fx["abun"]["sample0"]
     bases = np.zeros(len(meta_ref.species))
     lens = []
+    per = fx["runs"]["reads_per_worker"]["perfect"]
     for w in range(8):
-        p = E.make_params(seed=300 + w, first_read=w * 1000, n_reads=1000, kind=E.NS_KIND_PERFECT, max_len=meta_ref.max_chrom, meta=True)
+        p = E.make_params(seed=300 + w, first_read=w * per, n_reads=per, kind=E.NS_KIND_PERFECT, max_len=meta_ref.max_chrom, meta=True)
         out = O.generate_meta(mdl, meta_ref, abun, None, p)
         rd, pc = out["reads"], out["pieces"]
         assert np.all(pc["n_ev"] == 0) and np.all(rd["head"] == 0) and np.all(rd["tail"] == 0)
@@ -180,11 +182,11 @@ def test_oracle_perfect_metagenome_batches_match_reference_runs(fx, meta_ref):
         names = [x[1:].decode() for x in out["records"].tobytes().split(b"\n")[0:-1:2]]
         for i, nm in enumerate(names[:50]):
             f = nm.partition("_perfect_")[2].split("_")
-            assert int(f[0]) == w * 1000 + i and f[2] == "0" and f[4] == "0" and int(f[3]) == rd["seq_len"][i]
+            assert int(f[0]) == w * per + i and f[2] == "0" and f[4] == "0" and int(f[3]) == rd["seq_len"][i]
     frac = bases / bases.sum()
     tot = sum(run["bases"].values())
     for i, spn in enumerate(meta_ref.species):
         assert abs(frac[i] - run["bases"][spn] / tot) < 0.005
     lens = np.concatenate(lens)
-    assert abs(lens.mean() / run["mean_len"] - 1) < 0.02 and ks_vs_quantiles(lens, run["q_len"]) < 0.03
+    assert abs(lens.mean() / run["mean_len"] - 1) < 0.01 and ks_vs_quantiles(lens, run["q_len"]) <= 0.01
     assert all(wk["sorted_desc_frac"] == 1.0 and len(wk["strands"]) == 1 and wk["indices"][:3] == [0, 1, 2] for wk in run["workers"])
