@@ -4,7 +4,7 @@
 A "step" = one genome-mode pass over one batch of read indices of BASELINE.json configs[1]: the aligned worker
 call (src/simulator.py:1266-1454) on 950 000 reads and the unaligned one (S:1482-1549) on 50 000 (the model's
 alignment rate 19:1), E. coli-like 4.64 Mb circular genome, hg002-like error model (mean aligned length ~8.4 kb,
-~265 error events/read), FASTA records, reference + model resident in HBM, outputs left in HBM.  N>1: one
+~265 error events/read), FASTA records, reference + model resident in HBM, outputs left in HBM; the two calls run side by side on two engine contexts of the GPU.  N>1: one
 process per GPU, read-index ranges sharded, ONE RCCL broadcast of the reference before the timed region, no
 collective inside it (weak scaling).
 
@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step (aligned + unaligned)")
+    ap.add_argument("--serial", action="store_true", help="aligned and unaligned worker call of a step one after the other on ONE engine context")
     ap.add_argument("--aligned-only", action="store_true",
                     help="a step = one aligned worker batch only (the path with the Markov error model; profiling / A-B runs)")
     ap.add_argument("--fastq", action="store_true")
@@ -161,6 +162,10 @@ def main():
     ref_meta = model.Reference(names, np.zeros(0, np.uint8), np.array([0, glen], dtype=np.uint64),
                                np.array([1 if a.genome == "ecoli" else 0], dtype=np.uint8))
     eng = engine.Engine(local_rank)
+    # the unaligned worker call of a step runs next to the aligned one on its own engine context (own HIP streams and buffers on the
+    # same GPU, own host thread) — the way the reference runs its workers side by side (-t, S:1588-1605)
+    eng_un = None if (a.aligned_only or a.serial) else engine.Engine(local_rank)
+    engs = [e for e in (eng, eng_un) if e is not None]
     if world > 1:
         # the reference lives on rank 0; ONE broadcast over xGMI puts it in every GPU's HBM
         bdev = "cuda" if a.dist_backend == "nccl" else "cpu"
@@ -171,13 +176,16 @@ def main():
         dist.broadcast(buf, src=0)
         buf = buf.cuda()
         torch.cuda.synchronize()
-        eng.set_reference_device(buf.data_ptr(), ref_meta)
+        for e in engs:
+            e.set_reference_device(buf.data_ptr(), ref_meta)
         ref_host = None
     else:
         seq = synth.synth_sequence(glen, SEED, n_frac=0.0005, iupac_frac=0.0002, lower_frac=0.02, hp_boost=0.005)
         ref_host = model.Reference(names, seq, ref_meta.chrom_off, ref_meta.circular)
-        eng.set_reference(ref_host)
-    eng.load_model(mdl)
+        for e in engs:
+            e.set_reference(ref_host)
+    for e in engs:
+        e.load_model(mdl)
 
     # ---- a step = one genome-mode pass of this GPU over n read indices: the aligned worker call (simulation_aligned_genome,
     # S:1266-1454) on round(n r / (r + 1)) reads, then the unaligned one (simulation_unaligned, S:1482-1549) on the rest
@@ -186,13 +194,27 @@ def main():
     n_al, n_un = (n, 0) if a.aligned_only else mdl.split_counts(n)
     max_len = min(glen, 1 << 30)
 
+    import threading
+
     def step(i):
         base = (i * world + rank) * n
-        out = [eng.generate(engine.make_params(seed=SEED, first_read=base, n_reads=n_al, fastq=a.fastq, max_len=max_len,
-                                               emit_errlog=a.errlog, kmer_bias=a.kmer_bias)).info]
-        if n_un:
-            out.append(eng.generate(engine.make_params(seed=SEED, first_read=base + n_al, n_reads=n_un, kind=engine.NS_KIND_UNALIGNED,
-                                                       fastq=a.fastq, max_len=max_len)).info)
+        out = [None, None]
+
+        def aligned():
+            out[0] = eng.generate(engine.make_params(seed=SEED, first_read=base, n_reads=n_al, fastq=a.fastq, max_len=max_len,
+                                                     emit_errlog=a.errlog, kmer_bias=a.kmer_bias)).info
+
+        def unaligned(e):
+            out[1] = e.generate(engine.make_params(seed=SEED, first_read=base + n_al, n_reads=n_un, kind=engine.NS_KIND_UNALIGNED,
+                                                   fastq=a.fastq, max_len=max_len)).info
+        if not n_un:
+            aligned()
+            return out[:1]
+        if eng_un is None:                                # --serial: one engine, one call after the other
+            aligned(); unaligned(eng)
+            return out
+        t = threading.Thread(target=unaligned, args=(eng_un,))      # (the C call releases the GIL)
+        t.start(); aligned(); t.join()
         return out
 
     for i in range(a.warmup):
@@ -242,7 +264,8 @@ def main():
                        "errlog_note": "the error-profile text (the reference always writes it, S:2006-2008: ~26 KB per read, 3x the reads) is "
                                       "formatted by k_errlog only when asked for (--errlog; the CLI always asks): it is a file-format stage "
                                       "behind the path the metric names (SURVEY section 8 f-1)",
-                       "seed": SEED, "parallelism": "read-index sharding x%d, 1 RCCL broadcast of the reference" % world, "engines_per_gpu": 1},
+                       "seed": SEED, "parallelism": "read-index sharding x%d, 1 RCCL broadcast of the reference" % world, "engines_per_gpu": len(engs),
+                       "engines_note": "aligned and unaligned worker call of a step run side by side on two engine contexts of the GPU (--serial: one after the other on one)"},
             "device_ms_per_step": device_ms,
             "aligned_batch": {"reads": n_al, "device_ms": float(np.mean([x.ms_total for x in al])),
                               "reads_per_s_device": n_al / (float(np.mean([x.ms_total for x in al])) * 1e-3), "kernel_ms": kms},
@@ -260,7 +283,8 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(mdl, ref_host, engine, a.cpu_sample, a.fastq, a.kmer_bias)
         print(json.dumps(out))
-    eng.close()
+    for e in engs:
+        e.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -1476,10 +1476,15 @@ int ns_load_model(ns_ctx *ctx, const ns_model_tables *t) {
             }
             return g;
         };
-        ct.trans = put_d(&t->trans[0][0], 21);
-        ct.mix_w = put_d(t->mix_w, 3);
-        for (int ty = 0; ty < 3; ++ty)
-            for (int c = 0; c < 2; ++c) { ct.mix_n[ty][c] = t->mix_n[ty][c]; ct.mix_cdf[ty][c] = put_d(t->mix_cdf[ty][c], t->mix_n[ty][c]); }
+        // the tables that are only ever COMPARED with a draw are stored as integer thresholds of the 32-bit draw (ns_thr_lt / ns_thr_gt)
+        auto put_thr = [&](const double *src, size_t n, bool gt) {
+            uint32_t off = (uint32_t)blob.size(); blob.resize(off + n);
+            for (size_t i = 0; i < n; ++i) blob[off + i] = gt ? ns_thr_gt(src[i]) : ns_thr_lt(src[i]);
+            return off; };
+        ct.trans = put_thr(&t->trans[0][0], 21, false);          // p < a, p < a + b            (S:1860-1864)
+        ct.mix_w = put_thr(t->mix_w, 3, false);                   // tmp_rand < weight           (mm:44, 54)
+        for (int ty = 0; ty < 3; ++ty)                            // p > cdf[v]: walk of the inverse-CDF tables
+            for (int c = 0; c < 2; ++c) { ct.mix_n[ty][c] = t->mix_n[ty][c]; ct.mix_cdf[ty][c] = put_thr(t->mix_cdf[ty][c], t->mix_n[ty][c], true); }
         ct.fm_n = t->fm_nseg; ct.fm_vlo0 = t->fm_vlo0;
         ct.fm_hi = put_d(t->fm_hi, t->fm_nseg); ct.fm_vhi = put_d(t->fm_vhi, t->fm_nseg);
         { auto g = guide(t->fm_hi, t->fm_nseg); ct.fm_guide = put_raw(g.data(), 512); }

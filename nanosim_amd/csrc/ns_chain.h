@@ -8,6 +8,7 @@
 struct Tabs {
     const uint64_t *w;
     __device__ __forceinline__ const double *d(uint32_t off) const { return reinterpret_cast<const double *>(w + off); }
+    __device__ __forceinline__ const uint64_t *q(uint32_t off) const { return w + off; }
     __device__ __forceinline__ const uint16_t *h(uint32_t off) const { return reinterpret_cast<const uint16_t *>(w + off); }
     __device__ __forceinline__ const uint32_t *u(uint32_t off) const { return reinterpret_cast<const uint32_t *>(w + off); }
     __device__ __forceinline__ const int32_t *i(uint32_t off) const { return reinterpret_cast<const int32_t *>(w + off); }
@@ -34,16 +35,18 @@ __device__ __forceinline__ int32_t ecdf_lookup_g(const double *__restrict__ hi, 
     return (int32_t)floor((p - plo) / (hs - plo) * (vs - vlo) + vlo);
 }
 
+// mixture run length (mm:41-63) on integer thresholds: component by u_mix < T(weight), value = 1 + #{j : p > cdf[j]} by walking
+// G[j] = ns_thr_gt(cdf[j]) — no fp64 on the way
 __device__ __forceinline__ int32_t run_length_t(const Tabs &T, const ChainTab &c, int type, uint32_t u_mix, uint32_t u_len) {
-    const int comp = (u32_to_p(u_mix) < T.d(c.mix_w)[type]) ? 0 : 1;        // tmp_rand < weight, mm:44,54
-    const double *cdf = T.d(c.mix_cdf[type][comp]);
+    const int comp = ((uint64_t)u_mix < T.q(c.mix_w)[type]) ? 0 : 1;         // tmp_rand < weight, mm:44,54
+    const uint64_t *G = T.q(c.mix_cdf[type][comp]);
     const uint32_t n = c.mix_n[type][comp];
-    const double p = u32_to_p(u_len);
-    const double c0 = cdf[0], c1 = cdf[n > 1 ? 1 : 0];
+    const uint64_t u = u_len;
+    const uint64_t g0 = G[0], g1 = G[n > 1 ? 1 : 0];
     uint32_t v = 0;                                          // == while (v + 1 < n && p > cdf[v]) ++v
-    if (n > 1 && p > c0) {
+    if (n > 1 && u >= g0) {
         v = 1;
-        if (n > 2 && p > c1) { v = 2; while (v + 1 < n && p > cdf[v]) ++v; }
+        if (n > 2 && u >= g1) { v = 2; while (v + 1 < n && u >= G[v]) ++v; }
     }
     return (int32_t)v + 1;
 }
@@ -82,7 +85,7 @@ __device__ __forceinline__ EList32 chain_error_list(const Tabs &T, const ChainTa
     pos += prev_match;
     uint32_t it = 1;
     int32_t last_ins_pos = -1;
-    const double *trans = T.d(c.trans);
+    const uint64_t *trans = T.q(c.trans);
     const int32_t *bins = T.i(c.mm_bin);
     const uint32_t *seg_off = T.u(c.mm_seg_off);
     const uint8_t *bin_lut = reinterpret_cast<const uint8_t *>(T.w + c.mm_bin_lut);
@@ -90,7 +93,7 @@ __device__ __forceinline__ EList32 chain_error_list(const Tabs &T, const ChainTa
     while (pos < middle_ref) {                                                                     // S:1858
         w = w_next;
         w_next = ns_draw(key, ST_EVENT, seg, attempt, it + 1, 0);    // next iteration's draws do not depend on the chain state
-        const int error = trans_pick(trans + 3 * state, u32_to_p(w.x));                           // S:1860-1864
+        const int error = trans_pick_u(trans + 3 * state, w.x);                                   // S:1860-1864
         int32_t step = run_length_t(T, c, error, w.y, w.z);                                       // S:1866-1873
         if (error == NS_INS) l_new += step; else if (error == NS_DEL) l_new -= step;
         if (error != NS_INS) {                                                                     // S:1875-1880
@@ -134,8 +137,8 @@ __device__ __forceinline__ EList32 chain_unaligned_error_list(const Tabs &T, con
     while (pos < middle_ref) {
         u32x4 w = ns_draw(key, ST_UEVENT, seg, attempt, it, 0);
         ++it;
-        const double p = u32_to_p(w.x);
-        const int type = (p < 0.4) ? 3 : (p < 0.7) ? NS_MIS : (p < 0.85) ? NS_INS : NS_DEL;          // S:1787
+        const uint64_t ut = w.x;                                                                     // (p < t  <=>  u < ns_thr_lt(t))
+        const int type = (ut < ns_thr_lt(0.4)) ? 3 : (ut < ns_thr_lt(0.7)) ? NS_MIS : (ut < ns_thr_lt(0.85)) ? NS_INS : NS_DEL;   // S:1787
         int32_t step = 1;
         if (type != 3) step = run_length_t(T, c, type, w.y, w.z);
         if (type == NS_INS) { pend_ins += step; l_new += step; continue; }                          // S:1808-1815
@@ -178,8 +181,8 @@ __device__ inline EList32 coop_unaligned_error_list(const Tabs &T, const ChainTa
     uint32_t pos0 = 0, pend0 = 0;                                // position / pending insertion length in front of the block
     auto draw = [&](uint32_t it, int &type, uint32_t &step) {    // what iteration `it` does (S:1787, 1799-1818)
         const u32x4 w = ns_draw(key, ST_UEVENT, seg, attempt, it, 0);
-        const double p = u32_to_p(w.x);
-        type = (p < 0.4) ? 3 : (p < 0.7) ? NS_MIS : (p < 0.85) ? NS_INS : NS_DEL;
+        const uint64_t ut = w.x;                                     // (p < t  <=>  u < ns_thr_lt(t))
+        type = (ut < ns_thr_lt(0.4)) ? 3 : (ut < ns_thr_lt(0.7)) ? NS_MIS : (ut < ns_thr_lt(0.85)) ? NS_INS : NS_DEL;
         step = 1;
         if (type != 3) step = (uint32_t)run_length_t(T, c, type, w.y, w.z);
     };
@@ -274,7 +277,7 @@ __device__ inline EList32 coop_error_list(const Tabs &T, const ChainTab &c, int3
     pos += prev_match;
     uint32_t it0 = 1;
     int32_t last_ins_pos = -1;
-    const double *trans = T.d(c.trans);
+    const uint64_t *trans = T.q(c.trans);
     const int32_t *bins = T.i(c.mm_bin);
     const uint32_t *seg_off = T.u(c.mm_seg_off);
     const uint8_t *bin_lut = reinterpret_cast<const uint8_t *>(T.w + c.mm_bin_lut);
@@ -283,9 +286,8 @@ __device__ inline EList32 coop_error_list(const Tabs &T, const ChainTab &c, int3
         {
             const u32x4 wi = ns_draw(key, ST_EVENT, seg, attempt, it0 + lane, 0);
             uint32_t eb = 0;
-            const double pe = u32_to_p(wi.x);
 #pragma unroll
-            for (int st = 0; st < 7; ++st) eb |= (uint32_t)trans_pick(trans + 3 * st, pe) << (2 * st);
+            for (int st = 0; st < 7; ++st) eb |= (uint32_t)trans_pick_u(trans + 3 * st, wi.x) << (2 * st);
             S.err_tab[lane] = eb;
 #pragma unroll
             for (int t = 0; t < 3; ++t) S.step_tab[lane][t] = (uint16_t)run_length_t(T, c, t, wi.y, wi.z);

@@ -89,124 +89,30 @@ __device__ __forceinline__ int64_t table_value(const double *__restrict__ cdf, u
     return (int64_t)lo + 1;
 }
 
-// S:1860-1864
-__device__ __forceinline__ int trans_pick(const double *row, double p) {
-    if (0.0 <= p && p < row[0]) return NS_MIS;
-    if (row[0] <= p && p < row[1]) return NS_INS;
-    if (row[2] <= p && p < 1.0) return NS_DEL;
-    return (p >= row[1]) ? NS_DEL : NS_INS;
+// Integer form of a probability compare.  A 32-bit draw u stands for p = (u + 0.5) 2^-32, so for a table value t (fp64)
+//   p <  t   <=>   u <  ceil(t 2^32 - 0.5)        =: ns_thr_lt(t)
+//   p >  t   <=>   u >= floor(t 2^32 - 0.5) + 1   =: ns_thr_gt(t)
+// exactly (t 2^32 and the - 0.5 are exact in fp64), with thresholds in [0, 2^32] — hence 64-bit.  The chains compare the draw with
+// these instead of converting it to fp64 first (three fp64 operations per draw and an fp64 compare per table step); the host
+// (ns_load_model) builds them, the oracle keeps the fp64 compares, and the bit-exact parity tests hold the two together.
+__host__ __device__ inline uint64_t ns_thr_lt(double t) {
+    if (!(t > 0.0)) return 0;
+    if (t >= 1.0) return 1ull << 32;
+    const double y = ceil(t * 4294967296.0 - 0.5);
+    return y <= 0.0 ? 0ull : (uint64_t)y;
+}
+__host__ __device__ inline uint64_t ns_thr_gt(double t) {
+    if (t < 0.0) return 0;
+    if (t >= 1.0) return 1ull << 32;
+    const double y = floor(t * 4294967296.0 - 0.5) + 1.0;
+    return y <= 0.0 ? 0ull : (uint64_t)y;
 }
 
-// src/mixed_model.py:41-63 through the inverse-CDF tables
-__device__ __forceinline__ int64_t run_length(const DevModel &m, int type, double p_mix, double p_len) {
-    int comp = (p_mix < m.mix_w[type]) ? 0 : 1;
-    return table_value(m.mix_cdf[type][comp], m.mix_n[type][comp], p_len);
-}
-
-// ---- event sink ------------------------------------------------------------------------------------------
-struct EvSink {
-    ns_event *ev;
-    uint32_t cap, n;
-    int32_t shift;
-    uint32_t last_ins_len;
-    bool overflow;
-};
-__device__ __forceinline__ void ev_push(EvSink &s, int64_t pos, uint32_t type, int64_t len) {
-    uint32_t l = len > (int64_t)NS_EV_LEN_MAX ? NS_EV_LEN_MAX : (uint32_t)len;
-    if (s.n < s.cap) {
-        ns_event e; e.pos = (uint32_t)pos; e.info = ns_ev_pack(l, type, s.shift);
-        s.ev[s.n] = e;
-    } else s.overflow = true;
-    if (type == NS_INS) { s.shift += (int32_t)l; s.last_ins_len = l; } else if (type == NS_DEL) s.shift -= (int32_t)l;
-    s.n++;
-}
-
-struct EList { int64_t l_new, middle_ref; };
-
-// error_list, S:1833-1916
-__device__ inline EList dev_error_list(const DevModel &m, int64_t m_ref, const ns_key &key, uint32_t seg,
-                                       uint32_t attempt, EvSink &s) {
-    int64_t l_new = m_ref, pos = 0, middle_ref = m_ref;
-    int state = NS_ST_START;
-    u32x4 w = ns_draw(key, ST_EVENT, seg, attempt, 0, 0);
-    int64_t prev_match = ecdf_lookup(m.fm_hi, m.fm_vhi, m.fm_nseg, m.fm_vlo0, u32_to_p(w.x));   // S:1843-1850
-    if (prev_match < 2) prev_match = 2;
-    pos += prev_match;
-    uint32_t it = 1;
-    int64_t last_ins_pos = -1;
-    while (pos < middle_ref) {                                                                     // S:1858
-        w = ns_draw(key, ST_EVENT, seg, attempt, it, 0);
-        int error = trans_pick(m.trans[state], u32_to_p(w.x));                                    // S:1860-1864
-        int64_t step = run_length(m, error, u32_to_p(w.y), u32_to_p(w.z));                        // S:1866-1873
-        if (error == NS_INS) l_new += step; else if (error == NS_DEL) l_new -= step;
-        if (error != NS_INS) {                                                                     // S:1875-1880
-            ev_push(s, pos, (uint32_t)error, step);
-            pos += step;
-            if (pos >= middle_ref) { l_new += pos - middle_ref; middle_ref = pos; }
-        } else {                                                                                   // S:1881-1882
-            if (last_ins_pos == pos && s.n > 0) {          // same dict key pos-0.5: the later entry replaces
-                s.n--;
-                s.shift -= (int32_t)s.last_ins_len;
-            }
-            ev_push(s, pos, NS_INS, step);
-            last_ins_pos = pos;
-        }
-        state = NS_ST_MIS + error;                                                                 // S:1884
-        uint32_t b = 0;                                                                            // S:1891-1893
-        for (; b < m.mm_nbins; ++b)
-            if (m.mm_bin_lo[b] <= prev_match && prev_match < m.mm_bin_hi[b]) break;
-        if (b >= m.mm_nbins) b = m.mm_nbins - 1;
-        uint32_t o = m.mm_seg_off[b];
-        step = ecdf_lookup(m.mm_hi + o, m.mm_vhi + o, m.mm_seg_off[b + 1] - o, m.mm_vlo0[b], u32_to_p(w.w));
-        if (prev_match == 0 && step == 0) step = 1;                                                // S:1900-1901
-        prev_match = step;
-        if (pos + prev_match > middle_ref) { l_new += pos + prev_match - middle_ref; middle_ref = pos + prev_match; }
-        pos += prev_match;
-        if (prev_match == 0) state += 3;                                                           // S:1913-1914
-        else last_ins_pos = -1;
-        ++it;
-    }
-    return EList{l_new, middle_ref};
-}
-
-// unaligned_error_list, S:1784-1830, with the event rewrite of DESIGN.md §5.3
-__device__ inline EList dev_unaligned_error_list(const DevModel &m, int64_t m_ref, const ns_key &key, uint32_t seg,
-                                                 uint32_t attempt, EvSink &s) {
-    int64_t l_new = m_ref, pos = 0, middle_ref = m_ref;
-    int64_t pend_ins = 0;
-    if (m_ref <= 0) return EList{l_new, middle_ref};
-    uint32_t it = 0;
-    while (pos < middle_ref) {
-        u32x4 w = ns_draw(key, ST_UEVENT, seg, attempt, it, 0);
-        ++it;
-        double p = u32_to_p(w.x);
-        int type = (p < 0.4) ? 3 : (p < 0.7) ? NS_MIS : (p < 0.85) ? NS_INS : NS_DEL;               // S:1787
-        int64_t step = 1;
-        if (type != 3) step = run_length(m, type, u32_to_p(w.y), u32_to_p(w.z));
-        if (type == NS_INS) { pend_ins += step; l_new += step; continue; }                          // S:1808-1815
-        if (type == NS_DEL) l_new -= step;
-        int64_t L = pend_ins; pend_ins = 0;
-        if (type == 3) {
-            if (L) ev_push(s, pos + 1, NS_INS, L);
-        } else if (type == NS_MIS) {
-            if (!L) ev_push(s, pos, NS_MIS, step);
-            else {
-                ev_push(s, pos, NS_MIS, 1);
-                ev_push(s, pos + 1, NS_INS, L);
-                if (step - 1 > L) ev_push(s, pos + 1, NS_MIS, step - 1 - L);
-            }
-        } else {
-            if (!L) ev_push(s, pos, NS_DEL, step);
-            else {
-                int64_t dl = step - L; if (dl < 1) dl = 1;
-                ev_push(s, pos, NS_DEL, dl);
-                if (L - (step - 1) > 0) ev_push(s, pos + 1, NS_INS, L - (step - 1));
-            }
-        }
-        pos += step;
-        if (pos > middle_ref) { l_new += pos - middle_ref; middle_ref = pos; }                       // S:1826-1828
-    }
-    return EList{l_new, middle_ref};
+// S:1860-1864 on the integer thresholds of a transition row (T0 = ns_thr_lt(a), T1 = ns_thr_lt(a + b)): the intervals are tested in
+// the order mis [0, a), ins [a, a + b), del [1 - c, 1); a draw that falls between a + b and 1 - c (rounding gap) takes del
+// (DESIGN.md section 5.5), so everything that is neither mis nor ins is del
+__device__ __forceinline__ int trans_pick_u(const uint64_t *row, uint32_t u) {
+    return (uint64_t)u < row[0] ? NS_MIS : (uint64_t)u < row[1] ? NS_INS : NS_DEL;
 }
 
 // ---- lengths ---------------------------------------------------------------------------------------------
