@@ -71,21 +71,26 @@ def test_oracle_transcriptome_batches_match_reference_runs(fx, trx_ref, name):
     perfect = name == "perfect"
     mdl = M.load_model(os.path.join(ROOT, "tests", "golden", "model_small", "training"), transcriptome=True, perfect=perfect)
     lens = np.diff(trx_ref.ref.chrom_off.astype(np.int64))
-    p = E.make_params(seed=2024, first_read=0, n_reads=16000, max_len=10 ** 9, trx=True, kind=E.NS_KIND_PERFECT if perfect else E.NS_KIND_ALIGNED,
+    p = E.make_params(seed=2024, first_read=0, n_reads=96000, max_len=10 ** 9, trx=True, kind=E.NS_KIND_PERFECT if perfect else E.NS_KIND_ALIGNED,
                       uracil=perfect)
     out = O.generate_trx(mdl, trx_ref, p)
     rd, pc, pa = out["reads"], out["pieces"], out["polya"].astype(np.int64)
     tl, mid = lens[pc["chrom"]].astype(np.float64), pc["ref_len"].astype(np.float64)
-    tol = 0.025                                     # two samples of 16 000: KS noise is ~0.015
+    # two samples of 96 000 reads.  Start, head, tail + polyA and the aligned fraction sit inside the 1 % gate; the aligned length and the
+    # read length carry the documented deviation (the share of the dominant transcript is 1.7 points lower in the
+    # reference, which keeps its 2-D KDE sample until a transcript repeats) and land at 0.009-0.012
+    tol = 0.015
+    assert ks_vs_quantiles(mid / tl, run["q_frac"]) <= 0.01 and ks_vs_quantiles(pc["pos"] / np.maximum(1, tl - mid), run["q_start_frac"]) <= 0.01
+    assert ks_vs_quantiles(rd["tail"] + pa, run["q_tailp"]) <= 0.01 and ks_vs_quantiles(rd["head"], run["q_head"]) <= 0.01
     assert ks_vs_quantiles(mid, run["q_mid"]) < tol and ks_vs_quantiles(mid / tl, run["q_frac"]) < tol
     assert ks_vs_quantiles(pc["pos"] / np.maximum(1, tl - mid), run["q_start_frac"]) < tol
     assert ks_vs_quantiles(rd["tail"] + pa, run["q_tailp"]) < tol and ks_vs_quantiles(rd["head"], run["q_head"]) < tol
     assert ks_vs_quantiles(rd["seq_len"], run["q_seq_len"]) < tol
-    assert abs(rd["reversed"].mean() - run["frac_rev"]) < 0.02
+    assert abs(rd["reversed"].mean() - run["frac_rev"]) < 0.01
     reach = (trx_ref.polya[pc["chrom"]] > 0) & (pc["pos"].astype(np.int64) + pc["ref_len"] + 10 >= tl)
     assert abs(reach.mean() - run["frac_reach_end"]) < 0.01
     assert np.all(pa[~reach] == 0) and np.all(pa[reach] >= 2)                   # int(expon(loc=2)) >= 2
-    assert ks_vs_quantiles((rd["tail"] + pa)[reach], run["q_tailp_reach"]) < 0.06      # ~1 500 reads
+    assert ks_vs_quantiles((rd["tail"] + pa)[reach], run["q_tailp_reach"]) < 0.03      # ~9 000 reads
     if perfect:
         assert np.all(rd["head"] == 0) and np.all(rd["tail"] == 0) and np.all(pc["n_ev"] == 0)
         recs = out["records"].tobytes().split(b"\n")
@@ -96,7 +101,7 @@ def test_oracle_transcriptome_batches_match_reference_runs(fx, trx_ref, name):
     cnt = np.bincount(pc["chrom"], minlength=len(lens))
     for k, v in run["counts"].items():
         c = int(cnt[trx_ref.ref.names.index(k)])
-        assert abs(c - v) < (0.03 if v > 5000 else 0.01) * run["n"], (k, v, c)
+        assert abs(c - v) < (0.02 if v > 0.3 * run["n"] else 0.01) * run["n"], (k, v, c)
     # names: <transcript>_<start>_aligned|perfect_<index>_<F|R>_<head>_<middle_ref>_<tail + polyA>
     first = out["records"].tobytes().split(b"\n")[0][1:].decode()
     body, _, rest = first.partition("_perfect_" if perfect else "_aligned_")
