@@ -786,13 +786,17 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             }
             NS_SUBRUN_GATHER(f0, i0)
             NS_SUBRUN_GATHER(f1, i1)
-            NS_SUBRUN_GATHER(f2, i2)
-            NS_SUBRUN_GATHER(f3, i3)
+            if constexpr (!HPF) {                                  // (homopolymer edits are sparse — one event per ~250 bases: two sub-runs
+                NS_SUBRUN_GATHER(f2, i2)                           //  cover all but one chunk in a thousand, the loop below takes those)
+                NS_SUBRUN_GATHER(f3, i3)
+            }
             flush_chunk(ro, pend);                                 // the previous tile's chunk: behind this tile's loads in the queue
             NS_SUBRUN_MERGE(f0, i0)
             NS_SUBRUN_MERGE(f1, i1)
-            NS_SUBRUN_MERGE(f2, i2)
-            NS_SUBRUN_MERGE(f3, i3)
+            if constexpr (!HPF) {
+                NS_SUBRUN_MERGE(f2, i2)
+                NS_SUBRUN_MERGE(f3, i3)
+            }
             while (more) {
                 NS_SUBRUN_GATHER(f0, i0)
                 NS_SUBRUN_MERGE(f0, i0)
