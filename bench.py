@@ -45,7 +45,8 @@ def _cpu_worker(args):
             m = min(1000, cnt - done)
             p = eng.make_params(seed=SEED, first_read=first, n_reads=m, kind=kind, max_len=ref.max_chrom, fastq=fastq,
                                 kmer_bias=kmer if kind == eng.NS_KIND_ALIGNED else 0)
-            bases += int(oracle_lib.generate(mdl, ref, p, bytes_per_read=60000)["total_bases"])
+            per = max(120000 if fastq else 60000, 8_000_000 // m)     # a single FASTQ record of a long read needs more than the average
+            bases += int(oracle_lib.generate(mdl, ref, p, bytes_per_read=per)["total_bases"])
             done += m; first += m
     return bases
 
@@ -74,7 +75,7 @@ def cpu_baseline(model, ref, engine_mod, per_core, fastq, kmer):
         pass
     ctx = mp.get_context("fork")
     with ctx.Pool(cores) as pool:
-        pool.map(_cpu_worker, [(i, 1, 0, fastq, kmer) for i in range(cores)])          # start the workers, touch the tables
+        pool.map(_cpu_worker, [(i, 20, 0, fastq, kmer) for i in range(cores)])         # start the workers, touch the tables
         t0 = time.perf_counter()
         bases = pool.map(_cpu_worker, [(i, n_al, n_un, fastq, kmer) for i in range(cores)])
         dt = time.perf_counter() - t0
