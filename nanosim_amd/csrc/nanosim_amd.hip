@@ -622,7 +622,7 @@ __global__ void __launch_bounds__(64 * NS_WPB) k_ir_splice(GenArgs A) {
 // k_materialise: one read per wavefront (64-thread workgroup); see ns_materialise.h
 // ---------------------------------------------------------------------------------------------------------
 #ifndef NS_MAT_WAVES
-#define NS_MAT_WAVES 6
+#define NS_MAT_WAVES 7
 #endif
 
 // read header of a wave-per-read kernel: everything wave-uniform, pinned to SGPRs
@@ -677,11 +677,11 @@ __global__ void __launch_bounds__((FASTQ && MODE != MAT_HP_SCRATCH) ? 64 * NS_MA
 k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, const uint32_t *order) {
     constexpr bool QUALS = FASTQ && MODE != MAT_HP_SCRATCH;
     constexpr uint32_t WAVES = QUALS ? NS_MATQ_WAVES : 1;
-    __shared__ TileLds Ts[WAVES];
+    __shared__ TileLdsT<QUALS> Ts[WAVES];
     __shared__ __align__(16) uint16_t qlut[QUALS ? NS_QLUT_SLOTS * 1024u : 8u];
     if constexpr (QUALS) { qual_lut_load(qlut, A.m, threadIdx.x, 64 * WAVES); __syncthreads(); }
     const uint32_t wave = WAVES > 1 ? threadIdx.x >> 6 : 0u;
-    TileLds &T = Ts[wave];
+    TileLdsT<QUALS> &T = Ts[wave];
     const uint32_t lane = WAVES > 1 ? threadIdx.x & 63u : threadIdx.x;
     const uint64_t slot = (uint64_t)blockIdx.x * WAVES + wave;
     if (slot >= A.prm.n_reads) return;

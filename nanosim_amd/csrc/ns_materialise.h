@@ -19,18 +19,30 @@
 #endif
 #define T_OUT (1024u * NS_TILE_CHUNKS)
 #define T_EV 64u            // events staged per tile: slot 0 = the event in force at the tile start, slots 1..63 = lanes 0..62
-struct __align__(16) TileLds {
+// PMASK: a second tile with the byte mask of the letters (the FASTQ kernels, which have no VALU slots to spare); without it the mask
+// is derived from the letters (every letter is ASCII >= 0x40, an empty slot is 0) and the wavefront needs 2 KB less LDS
+template <bool PMASK>
+struct __align__(16) TileLdsT {
     uint32_t mlut[17][4];               // mlut[i]: 16-byte mask with bytes >= i set (merge of an event sub-run into a chunk); [16] empty
-    uint32_t e_out[T_EV + 1];           // output offset at which the event starts
-    uint32_t e_rp[T_EV];                // segment position of the first base copied after the event's payload
-    uint16_t e_pt[T_EV];                // payload length (0 for a deletion) | type << 12
+    // per staged event, what the copy loop needs in ONE 16-byte read: x = first output offset copied under the event (start + payload
+    // length), y = segment position minus output offset of the bytes copied under it, z = output offset of the NEXT event (the tile
+    // end behind the last one)
+    uint4 ent[T_EV + 1];
     uint32_t hist[64 * NS_TILE_CHUNKS];
     // substituted / inserted letters of the tile at their output offsets (relative to the tile's aligned origin), the byte mask
     // that marks them (0xff) and, for FASTQ, their quality class; + a dump area for predicated-off letter slots
     uint8_t pay[T_OUT + 16 + 64];
-    uint8_t pmask[T_OUT + 16 + 64];
+    uint8_t pmask[PMASK ? T_OUT + 16 + 64 : 16];
 };
 #define T_DUMP (T_OUT + 16u)
+struct Ent3 { uint32_t x, y, z; };
+template <class TL>
+__device__ __forceinline__ Ent3 ent3(const TL &T, uint32_t k) {
+    Ent3 e;
+    const uint2 xy = *reinterpret_cast<const uint2 *>(&T.ent[k]);
+    e.x = xy.x; e.y = xy.y; e.z = T.ent[k].z;
+    return e;
+}
 // quality class of an emitted base travels in two spare bits of its ASCII code (A 41, C 43, G 47, T 54: bits 3 and 5 are free)
 // until the qualities are drawn: bit 3 = substituted ('mis'), bit 5 = inserted ('ins', the base is in lower case)
 #define NS_CLS_MIS_BIT 0x08u
@@ -38,10 +50,11 @@ struct __align__(16) TileLds {
 #define NS_CLS_STRIP 0xd7d7d7d7u
 // LDS copy of the quality bucket tables: slots 0..2 = match / mis / ins, slot 3 = unmapped (gaps of chimeric reads)
 #define NS_QLUT_SLOTS 4u
-__device__ __forceinline__ void tile_lds_init(TileLds &T, uint32_t lane) {
+template <bool PMASK>
+__device__ __forceinline__ void tile_lds_init(TileLdsT<PMASK> &T, uint32_t lane) {
     for (uint32_t c = lane * 16; c < T_OUT + 16 + 64; c += 64 * 16) {
         *reinterpret_cast<uint4 *>(&T.pay[c]) = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4 *>(&T.pmask[c]) = make_uint4(0, 0, 0, 0);
+        if constexpr (PMASK) *reinterpret_cast<uint4 *>(&T.pmask[c]) = make_uint4(0, 0, 0, 0);
     }
     if (lane < 17) {
 #pragma unroll
@@ -576,7 +589,7 @@ __device__ __forceinline__ void qual_lut_load(uint16_t *lds, const DevModel &m, 
 // bit 0 set, takes the 'mis' class (first mismatch of its run, S:697-700; otherwise the class of the base it replaces); an
 // insertion has <= 15 letters, all of class 'ins' except letter 0 when bit 31 of the word is set.
 template <bool FASTQ, int MODE>
-__device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, TileLds &T, const ReadOut &ro, const ns_key &key,
+__device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, TileLdsT<FASTQ && MODE != MAT_HP_SCRATCH> &T, const ReadOut &ro, const ns_key &key,
                                          uint32_t a, const PieceCtx &pc, uint32_t pq, uint32_t lane, uint32_t dbg, const SlowQueue &sq,
                                          uint32_t read_idx, uint32_t piece_idx, QualState &Q) {
     constexpr bool QUALS = FASTQ && MODE != MAT_HP_SCRATCH;            // qualities are drawn in this pass
@@ -628,9 +641,16 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
         }
         const uint32_t ne = 1 + cnt;
         // LDS view for the other lanes (every lane writes slot 0 / the sentinel with the same value: no exec juggling)
-        T.e_out[0] = L0_out; T.e_rp[0] = L0_rp; T.e_pt[0] = (uint16_t)L0_pt;
-        if (take) { T.e_out[1 + lane] = os; T.e_rp[1 + lane] = e_rp; T.e_pt[1 + lane] = (uint16_t)e_pt; }
-        T.e_out[ne] = M1;
+        {
+            const uint32_t s0 = L0_out + (L0_pt & 0xfffu);
+            *reinterpret_cast<uint2 *>(&T.ent[0]) = make_uint2(s0, L0_rp - s0);
+            if (take) {
+                const uint32_t s1 = os + (e_pt & 0xfffu);
+                *reinterpret_cast<uint2 *>(&T.ent[1 + lane]) = make_uint2(s1, e_rp - s1);
+                T.ent[lane].z = os;
+            }
+            T.ent[cnt].z = M1;
+        }
 #pragma unroll
         for (uint32_t t = 0; t < NS_TILE_CHUNKS; ++t) T.hist[64 * t + lane] = 0;
         const uint32_t jb_next = jb + cnt;
@@ -712,7 +732,7 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
                 const uint32_t o = b_os - A0, dump = T_DUMP + lane;
                 const uint32_t o1 = b_pl > 1 ? o + 1 : dump, o2 = b_pl > 2 ? o + 2 : dump, o3 = b_pl > 3 ? o + 3 : dump;
                 T.pay[o] = (uint8_t)letters; T.pay[o1] = (uint8_t)(letters >> 8); T.pay[o2] = (uint8_t)(letters >> 16); T.pay[o3] = (uint8_t)(letters >> 24);
-                T.pmask[o] = 0xffu; T.pmask[o1] = 0xffu; T.pmask[o2] = 0xffu; T.pmask[o3] = 0xffu;
+                if constexpr (QUALS) { T.pmask[o] = 0xffu; T.pmask[o1] = 0xffu; T.pmask[o2] = 0xffu; T.pmask[o3] = 0xffu; }
             }
             if (on && !fast_l) {                                  // long payloads, tile borders, IUPAC under a substitution, the origin
                 const uint32_t i_lo = b_os < M0 ? M0 - b_os : 0u;
@@ -737,7 +757,8 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
                     }
                     if (i >= i_lo) {
                         const uint32_t o = b_os + i - A0;
-                        T.pay[o] = (uint8_t)b; T.pmask[o] = 0xffu;
+                        T.pay[o] = (uint8_t)b;
+                        if constexpr (QUALS) T.pmask[o] = 0xffu;
                     }
                 }
             }
@@ -760,24 +781,30 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         if (active) {
             uint32_t k = incl;                                     // event in force at the chunk's first byte
-            uint32_t eos = T.e_out[k], pl = T.e_pt[k] & 0xfffu, rp = T.e_rp[k], nxt = T.e_out[k + 1];
+            Ent3 E = ent3(T, k);
             uint32_t mcur = lo_m;
             // The first four event sub-runs of the chunk are gathered branch-free with all four 16-byte loads in flight (a lane
             // that has run out of sub-runs loads a fixed valid offset and merges with the empty mask mlut[16]); chunks with
             // more sub-runs (>= 4 events inside 16 bases) continue in a loop.
             bool more = true;
+            const uint32_t c0p = c0 + 32u;
             uint4 f0, f1, f2, f3; uint32_t i0, i1, i2, i3;
+#ifndef NS_GATHER_NOPRED
+#define NS_GATHER_LOAD(FN) FN = make_uint4(0, 0, 0, 0); if (has) __builtin_memcpy(&FN, tb + (E.y + c0p), 16);
+#else
+#define NS_GATHER_LOAD(FN) __builtin_memcpy(&FN, tb + (has ? E.y + c0p : idle_off), 16);
+#endif
 #define NS_SUBRUN_GATHER(FN, IN)                                                                                     \
             {                                                                                                        \
-                const uint32_t cs = max(mcur, eos + pl);           /* first copied byte under event k */              \
-                const bool has = more && cs < min(nxt, hi_m);                                                        \
-                const uint32_t xrel = rp + c0 - (eos + pl);        /* segment position of chunk byte 0 under this event's shift */ \
-                __builtin_memcpy(&FN, tb + (has ? xrel + 32u : idle_off), 16);                                       \
+                const uint32_t cs = max(mcur, E.x);                /* first copied byte under event k */              \
+                const bool has = more && cs < min(E.z, hi_m);                                                        \
+                /* E.y + c0 = segment position of chunk byte 0 under this event's shift */                            \
+                NS_GATHER_LOAD(FN)                                                                                   \
                 IN = has ? cs - c0 : 16u;                                                                            \
-                more = more && nxt < hi_m;                                                                           \
+                more = more && E.z < hi_m;                                                                           \
                 k += more ? 1u : 0u;                                                                                 \
-                mcur = more ? nxt : mcur; eos = more ? nxt : eos;                                                    \
-                pl = T.e_pt[k] & 0xfffu; rp = T.e_rp[k]; nxt = T.e_out[k + 1];                                       \
+                mcur = more ? E.z : mcur;                                                                            \
+                E = ent3(T, k);                                                                                      \
             }
 #define NS_SUBRUN_MERGE(FO, IO)                                                                                      \
             {                                                                                                        \
@@ -804,7 +831,12 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
 #undef NS_SUBRUN_GATHER
 #undef NS_SUBRUN_MERGE
             const uint32_t lo_off = 16 * ci;                       // chunk offset inside the payload tile
-            const uint4 pv = *reinterpret_cast<const uint4 *>(&T.pay[lo_off]), pm = *reinterpret_cast<const uint4 *>(&T.pmask[lo_off]);
+            const uint4 pv = *reinterpret_cast<const uint4 *>(&T.pay[lo_off]);
+            uint4 pm;
+            if constexpr (QUALS) pm = *reinterpret_cast<const uint4 *>(&T.pmask[lo_off]);
+            else                   // every letter is ASCII >= 0x40 (bit 6), an empty slot is 0: the byte mask comes from the letters themselves
+                pm = make_uint4(((pv.x >> 6) & 0x01010101u) * 0xffu, ((pv.y >> 6) & 0x01010101u) * 0xffu,
+                                ((pv.z >> 6) & 0x01010101u) * 0xffu, ((pv.w >> 6) & 0x01010101u) * 0xffu);
             if constexpr (!HPF) {
             if ((r0 | r1 | r2 | r3) & 0x80808080u) {               // case_convert (S:743-755): rare; the segment position of a marked
                 uint32_t kk = incl;                                // byte is found by walking the chunk's events again
@@ -813,8 +845,8 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
                     const uint32_t ch = (wk >> (8 * (b & 3))) & 0xff;
                     if (!(ch & 0x80u)) continue;
                     const uint32_t mm = c0 + b;
-                    while (T.e_out[kk + 1] <= mm) ++kk;
-                    const uint32_t x = T.e_rp[kk] + (mm - T.e_out[kk]) - (T.e_pt[kk] & 0xfffu);
+                    while (T.ent[kk].z <= mm) ++kk;
+                    const uint32_t x = mm + T.ent[kk].y;
                     const uint32_t r = resolve_base(ch, key, pc.sid, a, x);
                     wk = (wk & ~(0xffu << (8 * (b & 3)))) | r << (8 * (b & 3));
                     if (b < 4) r0 = wk; else if (b < 8) r1 = wk; else if (b < 12) r2 = wk; else r3 = wk;
@@ -824,7 +856,7 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
             // letters on top of the copied bases; the payload tile is left clean for the next tile
             r0 = bfi(pm.x, pv.x, r0); r1 = bfi(pm.y, pv.y, r1); r2 = bfi(pm.z, pv.z, r2); r3 = bfi(pm.w, pv.w, r3);
             *reinterpret_cast<uint4 *>(&T.pay[lo_off]) = make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4 *>(&T.pmask[lo_off]) = make_uint4(0, 0, 0, 0);
+            if constexpr (QUALS) *reinterpret_cast<uint4 *>(&T.pmask[lo_off]) = make_uint4(0, 0, 0, 0);
         } else flush_chunk(ro, pend);
         uint32_t D[8];
         if constexpr (QUALS) {                                     // the quality draws of the iteration (every lane takes part; the
