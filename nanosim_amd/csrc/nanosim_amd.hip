@@ -803,6 +803,7 @@ __global__ void __launch_bounds__(64 * NS_WPB) k_hp_filter_w(GenArgs A) {
             ns_event *ev = A.events + p.ev_off;
             uint32_t w = 0; int32_t shift = 0;                            // kept events / their cumulative length change so far
             const bool win = k <= 16 && !(pc.pos + pc.ref_len > pc.chrom_len);   // (a segment across the origin takes the generic walk)
+            const bool win8 = win && k <= 8;
             for (uint32_t j0 = 0; j0 < p.n_ev; j0 += 64) {                // S:1929-1947
                 const uint32_t j = j0 + lane;
                 const bool valid = j < p.n_ev;
@@ -814,22 +815,21 @@ __global__ void __launch_bounds__(64 * NS_WPB) k_hp_filter_w(GenArgs A) {
                     const int64_t lo = ty == NS_INS ? pos - 1 : pos, hi = pos + len - 1;
                     // [lo, hi] overlaps a run of >= k bases iff the run holds lo, hi or — lying strictly inside — one of lo + k, lo + 2k, ...
                     for (int64_t x = lo; keep; x = min(x + k, hi)) {
-                        keep = win ? !in_hp_run_win(A.ref, pc, key, a, x, k) : !in_hp_run(A.ref, pc, key, a, x, k);
+                        keep = win8 ? !in_hp_run_win8(A.ref, pc, key, a, x, k) : win ? !in_hp_run_win(A.ref, pc, key, a, x, k) : !in_hp_run(A.ref, pc, key, a, x, k);
                         if (x >= hi) break;
                     }
                 }
                 const uint64_t km = __ballot(keep);
                 const uint32_t before = (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
                 int32_t d = keep ? (ty == NS_INS ? (int32_t)len : ty == NS_DEL ? -(int32_t)len : 0) : 0;
-                int32_t incl = d;                                          // inclusive prefix sum of the length changes
-                for (int off = 1; off < 64; off <<= 1) { const int32_t v = __shfl_up(incl, off); if ((int)lane >= off) incl += v; }
+                const int32_t incl = (int32_t)wave_incl_scan((uint32_t)d);   // inclusive prefix sum of the length changes
                 if (keep) {
                     ns_event o; o.pos = e.pos; o.info = ns_ev_pack((uint32_t)len, ty, shift + incl - d);
                     ev[w + before] = o;                                    // w + before <= j: never ahead of the batch being read
                     err_len += nl + dec_digits(e.pos) + dec_digits((uint32_t)len) + 2u * (uint32_t)len + 9u;
                 }
                 w += (uint32_t)__popcll(km);
-                shift += __shfl(incl, 63);
+                shift += __builtin_amdgcn_readlane(incl, 63);
             }
             p.n_ev = w; p.out_len = (uint32_t)((int32_t)p.ref_len + shift);
             if (lane == 0) A.pieces[rd.piece_off + pi] = p;

@@ -50,6 +50,26 @@ __device__ inline bool in_hp_run_win(const DevRef &ref, const PieceCtx &pc, cons
     return (int64_t)(l + r) >= k;
 }
 
+// the same for k <= 8 with ONE 16-byte load: window = segment positions [x - 7, x + 8] (7 bases in front of x and 8 behind it decide
+// any run of up to 8; a run that leaves the window is long enough anyway)
+__device__ inline bool in_hp_run_win8(const DevRef &ref, const PieceCtx &pc, const ns_key &key, uint32_t a, int64_t x, int64_t k) {
+    if (x < 0 || x >= (int64_t)pc.ref_len) return false;
+    const uint8_t *p = ref.bases + pc.chrom_base + pc.pos + x - 7;
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    if ((v.x | v.y | v.z | v.w) & 0x80808080u) return in_hp_run(ref, pc, key, a, x, k);
+    const uint32_t bb = (v.y >> 24) * 0x01010101u;                         // base x (byte 7) in every byte
+    uint32_t ne = movemask4(nonzero_bytes(v.x ^ bb)) | movemask4(nonzero_bytes(v.y ^ bb)) << 4 | movemask4(nonzero_bytes(v.z ^ bb)) << 8 |
+                  movemask4(nonzero_bytes(v.w ^ bb)) << 12;
+    if (x < 7) ne |= (1u << (7 - x)) - 1u;                                 // positions outside the segment end the run
+    const int64_t top = (int64_t)pc.ref_len - x + 6;                       // highest window bit inside the segment
+    if (top < 15) ne |= 0xffffu << (top + 1);
+    const uint32_t up = (ne & 0xffffu) >> 7, dn = ne << 25;
+    const uint32_t r = up ? (uint32_t)__builtin_ctz(up) : 9u;             // base x and the equal bases behind it
+    const uint32_t l = dn ? (uint32_t)__builtin_clz(dn) : 7u;             // equal bases in front of it
+    return (int64_t)(l + r) >= k;
+}
+
 // get_nd_par (src/model_homopolymer_lengths.py:246-260).  (The two parameter rows are read with static indices and selected field by
 // field: a dynamic index into the kernel argument would make the compiler keep a copy of the table in scratch memory.)
 __device__ __forceinline__ void hp_nd_par(const DevModel &m, uint32_t base, uint32_t len, double &mu, double &sigma) {
