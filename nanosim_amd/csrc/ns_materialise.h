@@ -357,7 +357,7 @@ __device__ __forceinline__ void wave_sync() {
 // (all of a round's loads are independent: no per-byte chains of dependent loads, which is what the longest read of a batch used to
 // spend its time on), writes its bytes into an LDS tile of 1024 output bytes, and the tile leaves with one 16-byte store per lane.
 #define NS_DENSE_TILE 1024u
-struct __align__(16) DenseLds { uint8_t out[NS_DENSE_TILE]; };
+struct __align__(16) DenseLds { uint8_t out[NS_DENSE_TILE + 64]; };      // + a dump slot per lane for predicated-off letter stores
 
 template <bool FASTQ>
 __device__ inline void dense_piece(const DevModel &m, const DevRef &ref, DenseLds &S, const ReadOut &ro, const ns_key &key, uint32_t a,
@@ -389,39 +389,92 @@ __device__ inline void dense_piece(const DevModel &m, const DevRef &ref, DenseLd
                 if (jj < pc.n_ev) nxt = ev_out_start(pc.ev[jj]);
             }
             const uint32_t lo = max(os, M0), hi = min(nxt, M1);
-            if (valid && lo < hi) {
-                // ---- letters of the event (mutate_read, S:1965-1995): letter i = field / digit i & 15 of word i >> 4
-                const uint32_t n_let = min(pl, hi - os);
-                uint32_t word = 0;
-                for (uint32_t i = 0; i < n_let; ++i) {
-                    if (!(i & 15u)) word = payload_word(key, pc.sid, a, jj - 1u, i >> 4);
-                    uint32_t b;
-                    if (ty == NS_INS) b = bases_atcg((word >> (2u * (i & 15u))) & 3u);
-                    else {
-                        const uint32_t x = pos + i;
-                        b = mis_from_digit(resolve_base(ref_base_at(ref, pc, x), key, pc.sid, a, x), next_digit3(word));
+            const bool act = valid && lo < hi;
+            const uint32_t n_let = act ? min(pl, hi - os) : 0u;                       // letters of the event inside the tile
+            const uint32_t c_lo = max(lo, os + pl);
+            const uint32_t cn = act && c_lo < hi ? hi - c_lo : 0u;                    // copied bases behind them
+            const uint32_t x0 = rp + (c_lo - os - pl);                                // output byte mm <- segment position rp + (mm - os - pl)
+            // ---- straight-line path: the letters four at a time (byte permutes, as the tiled kernel), the copied bases from one
+            // 16-byte load with <= 4 stores into the tile.  Items cut by the tile border, stretches of > 16 bases, IUPAC codes under
+            // the copy and the origin of a circular chromosome take the per-byte walk below.
+            const bool fast_l = n_let && os >= M0 && (ty == NS_INS || (uint64_t)pos + n_let <= lin);
+            bool fast_c = cn && cn <= 16u && (uint64_t)x0 + 16u <= lin;
+            uint4 f = make_uint4(0, 0, 0, 0);
+            if (fast_c) __builtin_memcpy(&f, seg0 + x0, 16);
+            if ((f.x | f.y | f.z | f.w) & 0x80808080u) fast_c = false;             // IUPAC codes (case_convert, S:743-755)
+            {
+                uint32_t nl_max = fast_l ? n_let : 0u;
+                nl_max = max(nl_max, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nl_max, 0x111, 0xf, 0xf, false));   // row_shr:1
+                nl_max = max(nl_max, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nl_max, 0x112, 0xf, 0xf, false));
+                nl_max = max(nl_max, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nl_max, 0x114, 0xf, 0xf, false));
+                nl_max = max(nl_max, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nl_max, 0x118, 0xf, 0xf, false));
+                const uint32_t m01 = max((uint32_t)__builtin_amdgcn_readlane((int)nl_max, 15), (uint32_t)__builtin_amdgcn_readlane((int)nl_max, 31));
+                const uint32_t m23 = max((uint32_t)__builtin_amdgcn_readlane((int)nl_max, 47), (uint32_t)__builtin_amdgcn_readlane((int)nl_max, 63));
+                const uint32_t groups = (max(m01, m23) + 3u) >> 2;                   // wave-uniform: letter groups of four
+                uint32_t frac = 0;
+                const uint32_t o_base = os - M0;
+                for (uint32_t g = 0; g < groups; ++g) {
+                    const uint32_t i0 = 4u * g;
+                    const bool on = fast_l && i0 < n_let;
+                    if (!(g & 3u) && on) frac = payload_word(key, pc.sid, a, jj - 1u, g >> 2);   // letter i = field / digit i & 15 of word i >> 4
+                    uint32_t cur4 = 0x41414141u;
+                    if (on && ty != NS_INS) {
+                        __builtin_memcpy(&cur4, seg0 + pos + i0, 4);
+                        if (cur4 & 0x80808080u) {                                      // IUPAC code under a substitution: case_convert first
+                            uint32_t rs = 0;
+                            for (uint32_t t = 0; t < 4u; ++t) rs |= (uint32_t)resolve_base((cur4 >> (8u * t)) & 0xffu, key, pc.sid, a, pos + i0 + t) << (8u * t);
+                            cur4 = rs;
+                        }
                     }
-                    if (os + i >= lo) S.out[os + i - M0] = (uint8_t)b;
+                    // insertion: 2-bit fields -> "ATCG" (S:1990)
+                    const uint32_t x8 = (frac >> (8u * (g & 3u))) & 0xffu, t8 = (x8 | x8 << 12) & 0x000f000fu;
+                    const uint32_t ins4 = __builtin_amdgcn_perm(0u, 0x47435441u, (t8 | t8 << 6) & 0x03030303u);
+                    // substitution: the next four base-3 digits pick among the three other bases (S:1968-1972)
+                    uint32_t f3 = frac;
+                    const uint32_t d0 = next_digit3(f3), d1 = next_digit3(f3), d2 = next_digit3(f3), d3 = next_digit3(f3);
+                    const uint32_t d4 = d0 | d1 << 8 | d2 << 16 | d3 << 24;
+                    const uint32_t vv = (cur4 >> 1) & 0x03030303u;                           // A 0, C 1, T 2, G 3 (N counts as G: no digit reaches its rank)
+                    const uint32_t rank4 = (vv & 0x01010101u) << 1 | ((vv >> 1) & 0x01010101u);   // rank in "ATCG": A 0, T 1, C 2, G 3
+                    const uint32_t ge = ((d4 | 0x80808080u) - rank4) & 0x80808080u;          // per byte: digit >= rank
+                    const uint32_t mis4 = __builtin_amdgcn_perm(0u, 0x47435441u, d4 + (ge >> 7));
+                    const bool is_ins = ty == NS_INS;
+                    if (!is_ins) frac = f3;
+                    const uint32_t letters = is_ins ? ins4 : mis4;
+                    const uint32_t cnt = on ? n_let - i0 : 0u, dump = NS_DENSE_TILE + lane, o = o_base + i0;
+                    S.out[cnt > 0 ? o : dump] = (uint8_t)letters; S.out[cnt > 1 ? o + 1 : dump] = (uint8_t)(letters >> 8);
+                    S.out[cnt > 2 ? o + 2 : dump] = (uint8_t)(letters >> 16); S.out[cnt > 3 ? o + 3 : dump] = (uint8_t)(letters >> 24);
                 }
-                // ---- copied bases: output byte mm <- segment position rp + (mm - os - pl)
-                const uint32_t c_lo = max(lo, os + pl);
-                if (c_lo < hi) {
-                    const uint32_t x0 = rp + (c_lo - os - pl), cn = hi - c_lo;
-                    if (cn <= 32u && (uint64_t)x0 + 32u <= lin) {                      // (not across the origin of a circular chromosome)
-                        uint4 f0, f1;
-                        __builtin_memcpy(&f0, seg0 + x0, 16); __builtin_memcpy(&f1, seg0 + x0 + 16, 16);
-                        const bool marked = ((f0.x | f0.y | f0.z | f0.w | f1.x | f1.y | f1.z | f1.w) & 0x80808080u) != 0;   // IUPAC codes (case_convert, S:743-755)
-                        for (uint32_t i = 0; i < cn; ++i) {
-                            const uint32_t wv = i < 16 ? (i < 8 ? (i < 4 ? f0.x : f0.y) : (i < 12 ? f0.z : f0.w)) : (i < 24 ? (i < 20 ? f1.x : f1.y) : (i < 28 ? f1.z : f1.w));
-                            uint32_t b = (wv >> (8u * (i & 3u))) & 0xffu;
-                            if (marked) b = resolve_base(b, key, pc.sid, a, x0 + i);
-                            S.out[c_lo + i - M0] = (uint8_t)b;
+            }
+            if (fast_c) {
+                uint8_t *d = &S.out[c_lo - M0];
+                uint64_t w = (uint64_t)f.x | (uint64_t)f.y << 32;
+                if (cn & 16u) { const uint64_t w2 = (uint64_t)f.z | (uint64_t)f.w << 32; __builtin_memcpy(d, &w, 8); __builtin_memcpy(d + 8, &w2, 8); }
+                else {
+                    if (cn & 8u) { __builtin_memcpy(d, &w, 8); d += 8; w = (uint64_t)f.z | (uint64_t)f.w << 32; }
+                    if (cn & 4u) { const uint32_t v = (uint32_t)w; __builtin_memcpy(d, &v, 4); d += 4; w >>= 32; }
+                    if (cn & 2u) { const uint16_t v = (uint16_t)w; __builtin_memcpy(d, &v, 2); d += 2; w >>= 16; }
+                    if (cn & 1u) *d = (uint8_t)w;
+                }
+            }
+            if (act && ((n_let && !fast_l) || (cn && !fast_c))) {
+                // ---- per-byte walk.  Letters (mutate_read, S:1965-1995): letter i = field / digit i & 15 of word i >> 4
+                if (!fast_l) {
+                    uint32_t word = 0;
+                    for (uint32_t i = 0; i < n_let; ++i) {
+                        if (!(i & 15u)) word = payload_word(key, pc.sid, a, jj - 1u, i >> 4);
+                        uint32_t b;
+                        if (ty == NS_INS) b = bases_atcg((word >> (2u * (i & 15u))) & 3u);
+                        else {
+                            const uint32_t x = pos + i;
+                            b = mis_from_digit(resolve_base(ref_base_at(ref, pc, x), key, pc.sid, a, x), next_digit3(word));
                         }
-                    } else {
-                        for (uint32_t i = 0; i < cn; ++i) {
-                            const uint32_t x = x0 + i;
-                            S.out[c_lo + i - M0] = resolve_base(ref_base_at(ref, pc, x), key, pc.sid, a, x);
-                        }
+                        if (os + i >= lo) S.out[os + i - M0] = (uint8_t)b;
+                    }
+                }
+                if (cn && !fast_c) {
+                    for (uint32_t i = 0; i < cn; ++i) {
+                        const uint32_t x = x0 + i;
+                        S.out[c_lo + i - M0] = resolve_base(ref_base_at(ref, pc, x), key, pc.sid, a, x);
                     }
                 }
             }
