@@ -191,15 +191,14 @@ __device__ inline EList32 coop_unaligned_error_list(const Tabs &T, const ChainTa
     for (uint32_t it0 = 0;; it0 += 64) {
         int type = type_n; uint32_t step = step_n;
         draw(it0 + 64 + lane, type_n, step_n);                   // the next block's draws and table reads run under this block's prefix sums
-        uint32_t adv = type == NS_INS ? 0u : step;
-        const uint32_t adv_all = wave_incl_scan(adv);
-        const bool exec = pos0 + adv_all - adv < (uint32_t)m_ref;                                // the loop is still running (a prefix of the lanes)
-        const uint32_t n_exec = (uint32_t)__popcll(__ballot(exec));
-        if (!exec) { adv = 0; step = 0; type = 3; }
+        const uint32_t adv = type == NS_INS ? 0u : step;
         const uint32_t adv_incl = wave_incl_scan(adv);
         const uint32_t pos = pos0 + adv_incl - adv;
+        const bool exec = pos < (uint32_t)m_ref;                                                 // the loop is still running (a prefix of the lanes, >= 1)
+        const uint32_t n_exec = (uint32_t)__popcll(__ballot(exec));
+        if (!exec) { step = 0; type = 3; }
         const uint32_t ins = (exec && type == NS_INS) ? step : 0u, del = (exec && type == NS_DEL) ? step : 0u;
-        const uint32_t ins_incl = wave_incl_scan(ins), del_incl = wave_incl_scan(del);
+        const uint32_t ins_incl = wave_incl_scan(ins);
         // pending insertion in front of a non-insertion iteration: the insertion steps since the previous non-insertion one
         const bool nonins = exec && type != NS_INS;
         const uint64_t NB = __ballot(nonins);
@@ -226,13 +225,16 @@ __device__ inline EList32 coop_unaligned_error_list(const Tabs &T, const ChainTa
         }
         bool bad = ln0 > NS_EV_LEN_MAX || ln1 > NS_EV_LEN_MAX || ln2 > NS_EV_LEN_MAX;       // (a merged insertion of > 4095 bases)
         ln0 = min(ln0, NS_EV_LEN_MAX); ln1 = min(ln1, NS_EV_LEN_MAX); ln2 = min(ln2, NS_EV_LEN_MAX);
+        // one prefix sum for the deleted bases (< 2^24 per block) and the event counts (<= 3 per lane).  The events of a non-insertion
+        // iteration change the length by L - del (every case above), so the cumulative shift in front of them follows from the
+        // insertion and deletion sums: no prefix sum of its own
         auto dsh = [](uint32_t ty, uint32_t ln) { return ty == NS_INS ? ln : ty == NS_DEL ? 0u - ln : 0u; };
-        const uint32_t d0 = n_ev > 0 ? dsh(ty0, ln0) : 0u, d1 = n_ev > 1 ? dsh(ty1, ln1) : 0u, d2 = n_ev > 2 ? dsh(ty2, ln2) : 0u;
-        const uint32_t dtot = d0 + d1 + d2;
-        const uint32_t n_incl = wave_incl_scan(n_ev), sh_incl = wave_incl_scan(dtot);
+        const uint32_t d0 = n_ev > 0 ? dsh(ty0, ln0) : 0u, d1 = n_ev > 1 ? dsh(ty1, ln1) : 0u;
+        const uint32_t dn_incl = wave_incl_scan(del | n_ev << 24);
+        const uint32_t del_incl = dn_incl & 0xffffffu, n_incl = dn_incl >> 24;
         const uint32_t slot = s.n + n_incl - n_ev;
-        const uint32_t sh = (uint32_t)s.shift + sh_incl - dtot;
-        if (n_ev && !ev_shift_fits((int32_t)(sh + dtot))) bad = true;
+        const uint32_t sh = (uint32_t)s.shift + (pend0 + ins_incl - L) - (del_incl - del);       // (used by non-insertion lanes only)
+        if (n_ev && !ev_shift_fits((int32_t)(sh + L - del))) bad = true;
         if (__ballot(bad)) s.range = true;
         if (n_ev > 0) { if (slot < s.cap) { ns_event e; e.pos = ps0; e.info = ns_ev_pack(ln0, ty0, (int32_t)sh); s.ev[slot] = e; } }
         if (n_ev > 1) { if (slot + 1 < s.cap) { ns_event e; e.pos = ps1; e.info = ns_ev_pack(ln1, ty1, (int32_t)(sh + d0)); s.ev[slot + 1] = e; } }
@@ -240,12 +242,14 @@ __device__ inline EList32 coop_unaligned_error_list(const Tabs &T, const ChainTa
         const uint32_t n_blk = (uint32_t)__builtin_amdgcn_readlane((int)n_incl, 63);
         if (s.n + n_blk > s.cap) s.overflow = true;
         s.n += n_blk;
-        s.shift = (int32_t)((uint32_t)s.shift + (uint32_t)__builtin_amdgcn_readlane((int)sh_incl, 63));
         const uint32_t ins_tot = (uint32_t)__builtin_amdgcn_readlane((int)ins_incl, 63);
-        l_new += (int32_t)ins_tot - (int32_t)(uint32_t)__builtin_amdgcn_readlane((int)del_incl, 63);     // S:1808-1815, 1820
+        const uint32_t del_tot = (uint32_t)__builtin_amdgcn_readlane((int)del_incl, 63);
+        l_new += (int32_t)ins_tot - (int32_t)del_tot;                                                      // S:1808-1815, 1820
         // pending insertion behind the last non-insertion iteration of the block
-        pend0 = NB ? ins_tot - (uint32_t)__shfl((int)ins_incl, 63 - __clzll((long long)NB)) : pend0 + ins_tot;
-        pos0 += (uint32_t)__builtin_amdgcn_readlane((int)adv_incl, 63);
+        const uint32_t pend1 = NB ? ins_tot - (uint32_t)__shfl((int)ins_incl, 63 - __clzll((long long)NB)) : pend0 + ins_tot;
+        s.shift = (int32_t)((uint32_t)s.shift + (pend0 + ins_tot - pend1) - del_tot);                     // the insertions filed - the deletions
+        pend0 = pend1;
+        pos0 += (uint32_t)__builtin_amdgcn_readlane((int)adv_incl, (int)(n_exec - 1u));                   // positions advanced by the iterations that ran
         if (n_exec < 64 || pos0 >= (uint32_t)m_ref) break;
     }
     if ((int32_t)pos0 > middle_ref) { l_new += (int32_t)pos0 - middle_ref; middle_ref = (int32_t)pos0; }      // S:1826-1828
