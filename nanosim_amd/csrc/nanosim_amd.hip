@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
                 polya = pl > 65535 ? 65535u : (uint32_t)pl;
                 seq_len += polya;
             }
-            // final length re-check (S:1429-1430, S:1518-1519); with -k the length is only final after k_hp_count
+            // final length re-check (S:1429-1430, S:1518-1519); with -k the length is only final after k_hp_events
             if (!pos_ok || (!A.hp && !trx_al && (seq_len < prm.min_len || seq_len > prm.max_len))) { ++epoch; fails = 0; break; }
             // ---- accepted ----
             rd.flags = 0; rd.seq_len = (uint32_t)seq_len; rd.attempts = a;

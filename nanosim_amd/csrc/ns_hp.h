@@ -139,96 +139,3 @@ __device__ __forceinline__ uint32_t hp_run_events(double hp_mis_rate, const ns_k
     return n;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// wave-per-read run analysis of a scratch segment (mutate_homo's run scan, S:627-637), 1024 bytes per tile, 16 per lane.
-// A run is owned by the lane whose chunk holds its FIRST base: that lane knows the base, finds the end (the next run start, in
-// its own chunk, in a later lane or behind the tile) and draws the new length (keyed by the start of the run, as the thread
-// version does).  Needs k <= 16.
-// ---------------------------------------------------------------------------------------------------------
-struct HpTile {
-    uint32_t M;            // bit b: a run starts at base c + b of the lane's chunk (c = t0 + 16 lane)
-    uint32_t C;            // subset of M: runs of >= k bases
-    int32_t prev_start;    // last run start before the chunk (-1: none, only for the very first chunk)
-    uint32_t next_start;   // first run start at or behind c + 16 (n = end of the segment counts as one)
-    uint4 v;               // the 16 bases
-    int32_t tile_last;     // last run start inside the tile or before it (wave-uniform): the next tile's carry
-};
-// the lane's 16 bases of a tile and the base in front of them, as loaded (the kernels keep the loads of the next two tiles in flight)
-struct HpRaw { uint4 v; uint32_t pb; };
-__device__ __forceinline__ HpRaw hp_load(const uint8_t *__restrict__ sq, uint32_t n, uint32_t t0, uint32_t lane) {
-    HpRaw r; r.v = make_uint4(0, 0, 0, 0); r.pb = 0xffu;            // base before the chunk (0xff: none -> base 0 starts a run)
-    const uint32_t c = t0 + 16 * lane;
-    if (c < n) {
-        __builtin_memcpy(&r.v, sq + c, 16);                        // (the scratch buffer has slack behind the last read)
-        if (c) r.pb = sq[c - 1];
-    }
-    return r;
-}
-// bit b: a run starts at base b of the chunk (base b differs from base b - 1)
-__device__ __forceinline__ uint32_t hp_starts(const HpRaw &r, uint32_t n, uint32_t t0, uint32_t lane) {
-    const uint32_t c = t0 + 16 * lane;
-    const uint32_t p0 = r.v.x << 8 | r.pb, p1 = r.v.y << 8 | r.v.x >> 24, p2 = r.v.z << 8 | r.v.y >> 24, p3 = r.v.w << 8 | r.v.z >> 24;
-    // (the class bits of the bases — NS_CLS_STRIP — do not take part in the comparison)
-    const uint32_t M = movemask4(nonzero_bytes((r.v.x ^ p0) & NS_CLS_STRIP)) | movemask4(nonzero_bytes((r.v.y ^ p1) & NS_CLS_STRIP)) << 4 |
-                       movemask4(nonzero_bytes((r.v.z ^ p2) & NS_CLS_STRIP)) << 8 | movemask4(nonzero_bytes((r.v.w ^ p3) & NS_CLS_STRIP)) << 12;
-    const uint32_t valid = c >= n ? 0u : (n - c >= 16 ? 16u : n - c);      // bases of the chunk inside the segment
-    return M & ((1u << valid) - 1u);
-}
-__device__ inline uint32_t hp_run_end_behind(const uint8_t *__restrict__ sq, uint32_t n, uint32_t p);
-// first run start at or behind t1 = the end of a tile, from the chunk / starts of the NEXT tile (wave-uniform).  Only when a single
-// run fills the whole next tile does the scratch have to be walked.
-__device__ inline uint32_t hp_next_tile_start(uint32_t M_next, const uint8_t *__restrict__ sq, uint32_t n, uint32_t t1, uint32_t lane) {
-    if (t1 >= n) return n;
-    const uint64_t B = __ballot(M_next != 0);
-    if (!B) return hp_run_end_behind(sq, n, min(t1 + 1024u, n));
-    const uint32_t first = t1 + 16 * lane + (M_next ? (uint32_t)__builtin_ctz(M_next) : 0u);
-    return (uint32_t)__shfl((int)first, __builtin_ctzll(B));
-}
-
-// `next_tile_start`: first run start at or behind t0 + 1024 (wave-uniform; hp_next_tile_start / hp_run_end_behind)
-__device__ inline HpTile hp_tile_from(const HpRaw &raw, uint32_t M, uint32_t t0, uint32_t lane, uint32_t k, int32_t last_start_before_tile,
-                                      uint32_t next_tile_start) {
-    HpTile t;
-    const uint32_t c = t0 + 16 * lane;
-    t.v = raw.v;
-    t.M = M;
-    // Positions grow with the lane, so "last start before the chunk" is the last start of the nearest lower lane that has one
-    // and "first start behind the chunk" the first start of the nearest higher lane that has one: a ballot, two bit scans and
-    // one cross-lane read each (instead of two 6-step shuffle scans).
-    const int32_t last = M ? (int32_t)(c + 31u - (uint32_t)__clz((int)M)) : -1;
-    const uint32_t first = M ? c + (uint32_t)__builtin_ctz(M) : 0xffffffffu;
-    const uint64_t B = __ballot(M != 0);
-    const uint64_t below = B & ((1ull << lane) - 1ull);
-    const int32_t pv = __shfl(last, below ? 63 - __clzll((long long)below) : (int)lane);
-    t.prev_start = max(below ? pv : -1, last_start_before_tile);
-    const int32_t tl = B ? __shfl(last, 63 - __clzll((long long)B)) : -1;
-    t.tile_last = max(tl, last_start_before_tile);
-    const uint64_t above = lane == 63 ? 0ull : B >> (lane + 1);
-    const uint32_t nx = (uint32_t)__shfl((int)first, above ? (int)lane + 1 + __builtin_ctzll(above) : (int)lane);
-    t.next_start = min(above ? nx : 0xffffffffu, next_tile_start);
-    // long runs starting in this chunk: no further start among the next k - 1 bases
-    const uint32_t upper = t.next_start - c >= 32u ? 0u : 1u << (t.next_start - c);       // the first start behind the chunk, as a bit of a 32-bit window
-    const uint32_t W = M | upper;
-    uint32_t C = M;
-    if (k <= 16) { for (uint32_t sft = 1; sft < k; ++sft) C &= ~(W >> sft); }
-    else {                                 // k > 16: only the last run start of a chunk can open a run of >= k bases
-        C = 0;
-        if (M) { const uint32_t b = 31u - (uint32_t)__clz((int)M); if (t.next_start - (c + b) >= k) C = 1u << b; }
-    }
-    // a run may also be cut short by the end of the segment: n acts as a start (next_tile_start / next_start carry it)
-    t.C = C;
-    return t;
-}
-__device__ inline HpTile hp_tile(const uint8_t *__restrict__ sq, uint32_t n, uint32_t t0, uint32_t lane, uint32_t k, int32_t last_start_before_tile,
-                                 uint32_t next_tile_start) {
-    const HpRaw raw = hp_load(sq, n, t0, lane);
-    return hp_tile_from(raw, hp_starts(raw, n, t0, lane), t0, lane, k, last_start_before_tile, next_tile_start);
-}
-// end of the run that holds base p - 1 ... scanning forward from p (wave-uniform helper for the run that is open at a tile end)
-__device__ inline uint32_t hp_run_end_behind(const uint8_t *__restrict__ sq, uint32_t n, uint32_t p) {
-    if (p >= n) return n;
-    const uint8_t b = sq[p - 1] & 0xd7u;
-    uint32_t e = p;
-    while (e < n && (sq[e] & 0xd7u) == b) ++e;
-    return e;
-}
