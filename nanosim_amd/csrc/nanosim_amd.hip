@@ -37,6 +37,7 @@
 // kernel arguments
 // ---------------------------------------------------------------------------------------------------------
 struct GenArgs {
+    uint32_t ev_stage;               // k_chain<LDS>: byte offset of the event staging area behind the tables in dynamic LDS (0: none)
     ns_params prm;
     DevModel m;
     DevRef ref;
@@ -214,6 +215,7 @@ __global__ void __launch_bounds__(256) k_lengths(GenArgs A) {
     }
     rd.seq_len = 0; rd.attempts = a;
     A.reads[r] = rd;
+    cap = (cap + 3ull) & ~3ull;                  // whole 32-byte groups of events: k_chain flushes its staged events four at a time
     if (A.attempt > 0 && !meta_al) A.l_cap[tid] = cap;
     if (A.attempt == 0 || meta_al) {
         A.ev_cap[r] = cap;
@@ -243,7 +245,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
     if constexpr (COOP) { __shared__ CoopLds coop_lds; coop = &coop_lds; }
     Tabs T;
     if (LDS_TABLES) {
-        for (uint32_t i = threadIdx.x; i < A.m.ct.n_words; i += blockDim.x) lds_tbl[i] = A.m.chain_blob[i];
+        for (uint32_t i = threadIdx.x; i < A.m.ct.n_words_lds; i += blockDim.x) lds_tbl[i] = A.m.chain_blob[i];
         __syncthreads();
         T.w = lds_tbl;
     } else T.w = A.m.chain_blob;
@@ -287,11 +289,16 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
                 const int32_t m32 = (int32_t)p.ref_len;                // planned length from k_lengths
                 const uint32_t sid = p.kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
                 sink.ev = A.events + ev_off + evn; sink.cap = ev_cap > evn ? ev_cap - evn : 0; sink.n = 0; sink.shift = 0;
+                sink.stg = nullptr;
+                if constexpr (LDS_TABLES && !COOP) {      // single-piece reads: events leave in groups of four (32-byte stores), staged in LDS
+                    if (A.ev_stage && n_pieces == 1) sink.stg = reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(lds_tbl) + A.ev_stage) + threadIdx.x;
+                }
                 EList32 e;
                 if (kind == NS_KIND_PERFECT) { e.l_new = e.middle_ref = m32; }
                 else if (p.kind) e = COOP ? coop_unaligned_error_list(T, ct, m32, key, sid, a, sink, lane) : chain_unaligned_error_list(T, ct, m32, key, sid, a, sink);
                 else if (COOP) e = coop_error_list(T, ct, m32, key, sid, a, sink, *coop, lane);
-                else e = chain_error_list(T, ct, m32, key, sid, a, sink);
+                else e = chain_error_list<LDS_TABLES>(T, ct, m32, key, sid, a, sink);
+                ev_flush_tail(sink);
                 p.ev_off = ev_off + evn;
                 p.ref_len = (uint32_t)(e.middle_ref < 0 ? 0 : e.middle_ref);
                 p.out_len = (uint32_t)((e.middle_ref < 0 ? 0 : e.middle_ref) + sink.shift);
@@ -1486,7 +1493,7 @@ int ns_load_model(ns_ctx *ctx, const ns_model_tables *t) {
         for (int ty = 0; ty < 3; ++ty)                            // p > cdf[v]: walk of the inverse-CDF tables
             for (int c = 0; c < 2; ++c) { ct.mix_n[ty][c] = t->mix_n[ty][c]; ct.mix_cdf[ty][c] = put_thr(t->mix_cdf[ty][c], t->mix_n[ty][c], true); }
         ct.fm_n = t->fm_nseg; ct.fm_vlo0 = t->fm_vlo0;
-        ct.fm_hi = put_d(t->fm_hi, t->fm_nseg); ct.fm_vhi = put_d(t->fm_vhi, t->fm_nseg);
+        ct.fm_hi = put_d(t->fm_hi, t->fm_nseg);
         { auto g = guide(t->fm_hi, t->fm_nseg); ct.fm_guide = put_raw(g.data(), 512); }
         ct.mm_nbins = t->mm_nbins;
         std::vector<int32_t> bins(2 * (size_t)t->mm_nbins);
@@ -1506,17 +1513,27 @@ int ns_load_model(ns_ctx *ctx, const ns_model_tables *t) {
             ct.mm_bin_lut = put_raw(lut.data(), 256);
         }
         ct.mm_seg_off = put_raw(t->mm_seg_off, ((size_t)t->mm_nbins + 1) * 4);
-        ct.mm_hi = put_d(t->mm_hi, nseg); ct.mm_vhi = put_d(t->mm_vhi, nseg); ct.mm_vlo0 = put_d(t->mm_vlo0, t->mm_nbins);
+        ct.mm_hi = put_d(t->mm_hi, nseg); ct.mm_vlo0 = put_d(t->mm_vlo0, t->mm_nbins);
         std::vector<uint16_t> gall;
         for (uint32_t b = 0; b < t->mm_nbins; ++b) {
             auto g = guide(t->mm_hi + t->mm_seg_off[b], t->mm_seg_off[b + 1] - t->mm_seg_off[b]);
             gall.insert(gall.end(), g.begin(), g.end());
         }
         ct.mm_guide = put_raw(gall.data(), gall.size() * 2);
+        // value edges: whole numbers in every model read_analysis.py writes (its bins are "i-(i+1)") -> 32-bit copies for the LDS image;
+        // the fp64 originals follow behind the part that is copied to LDS (the cooperative chain and a model with fractional edges read those)
+        bool whole = true;
+        auto put_u = [&](const double *src, size_t n) {
+            std::vector<uint32_t> v(n);
+            for (size_t i = 0; i < n; ++i) { if (!(src[i] >= 0 && src[i] < 4294967296.0 && src[i] == floor(src[i]))) whole = false; v[i] = (uint32_t)(src[i] < 0 ? 0 : src[i] >= 4294967295.0 ? 4294967295.0 : src[i]); }
+            return put_raw(v.data(), n * 4); };
+        ct.fm_vhi_u = put_u(t->fm_vhi, t->fm_nseg); ct.mm_vhi_u = put_u(t->mm_vhi, nseg);
+        ct.n_words_lds = (uint32_t)blob.size();
+        ct.fm_vhi = put_d(t->fm_vhi, t->fm_nseg); ct.mm_vhi = put_d(t->mm_vhi, nseg);
         ct.n_words = (uint32_t)blob.size();
         if ((rc = upload(ctx, pool, blob.data(), blob.size(), &m.chain_blob))) return rc;
-        ctx->lds_bytes = blob.size() * 8;
-        ctx->lds_tables = ctx->lds_bytes <= 40 * 1024;     // keep >= 4 workgroups of 256 threads per CU
+        ctx->lds_bytes = (size_t)ct.n_words_lds * 8;
+        ctx->lds_tables = whole && ctx->lds_bytes <= 40 * 1024;     // keep >= 4 workgroups of 256 threads per CU
         double vmax = 0;
         for (uint32_t k2 = 0; k2 < nseg; ++k2) if (t->mm_vhi[k2] > vmax) vmax = t->mm_vhi[k2];
         ctx->coop_ok = t->mm_nbins <= COOP_MAX_BINS && vmax < 65535.0;   // the cooperative chain keeps match lengths in 16 bits
@@ -2036,7 +2053,7 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
             Q.list_base = n_coop; Q.list_n = (uint32_t)np - n_coop;
         }
         const dim3 grid_pc((unsigned)((Q.list_n + NS_CHAIN_BLOCK - 1) / NS_CHAIN_BLOCK)), blk_c(NS_CHAIN_BLOCK);
-        if (lds) k_chain<true, false><<<grid_pc, blk_c, ctx->lds_bytes, st>>>(Q);
+        if (lds) k_chain<true, false><<<grid_pc, blk_c, ctx->lds_bytes + (Q.ev_stage ? NS_CHAIN_BLOCK * 32u : 0u), st>>>(Q);
         else k_chain<false, false><<<grid_pc, blk_c, 0, st>>>(Q);
         HIPCHK(hipGetLastError());
         if (n_coop) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
@@ -2150,6 +2167,8 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     memset(&A, 0, sizeof A);
     A.prm = *prm; A.m = ctx->m; A.ref = ctx->ref;
     A.cap_gap_mul = 2;
+    // events of the thread-per-read chain staged four at a time in LDS, when the tables leave room for it next to four workgroups per CU
+    A.ev_stage = (ctx->lds_tables && ctx->lds_bytes + NS_CHAIN_BLOCK * 32u <= 40u * 1024u && !getenv("NS_NO_EV_STAGE")) ? (uint32_t)ctx->lds_bytes : 0u;
     A.n_pieces = (uint32_t *)ctx->n_pieces.p; A.piece_off = (uint32_t *)ctx->piece_off.p;
     A.ev_cap = (uint64_t *)ctx->ev_cap.p; A.ev_off = (uint64_t *)ctx->ev_off.p; A.l_cap = (uint64_t *)ctx->l_cap.p;
     A.rec_len = (uint64_t *)ctx->rec_len.p; A.rec_off = (uint64_t *)ctx->rec_off.p;
@@ -2262,7 +2281,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
             }
             const dim3 grid_c((A.list_n + NS_CHAIN_BLOCK - 1) / NS_CHAIN_BLOCK), blk_c(NS_CHAIN_BLOCK);
             if (!A.list_n) {}
-            else if (lds) k_chain<true, false><<<grid_c, blk_c, ctx->lds_bytes, st>>>(A);
+            else if (lds) k_chain<true, false><<<grid_c, blk_c, ctx->lds_bytes + (A.ev_stage ? NS_CHAIN_BLOCK * 32u : 0u), st>>>(A);
             else k_chain<false, false><<<grid_c, blk_c, 0, st>>>(A);
             HIPCHK(hipGetLastError());
             if (n_coop) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));

@@ -16,7 +16,8 @@ struct Tabs {
 
 // first s with p <= hi[s] (guide[u>>24] is a lower bound of s), then the interpolation of S:1847 / S:1897.
 // hi[s] and hi[s+1] are fetched together: the look-up sits on the chain's critical path.
-__device__ __forceinline__ int32_t ecdf_lookup_g(const double *__restrict__ hi, const double *__restrict__ vhi, uint32_t n,
+template <class V>       // V = double, or uint32_t for the integer copy of the value edges in LDS (same values, converted on the fly)
+__device__ __forceinline__ int32_t ecdf_lookup_g(const double *__restrict__ hi, const V *__restrict__ vhi, uint32_t n,
                                                  double vlo0, const uint16_t *__restrict__ guide, uint32_t u) {
     double p = u32_to_p(u);
     uint32_t s = guide[u >> 24];
@@ -29,7 +30,7 @@ __device__ __forceinline__ int32_t ecdf_lookup_g(const double *__restrict__ hi, 
     }
     if (s >= n) { s = n - 1; p = hi[s]; }
     const uint32_t sm = s ? s - 1 : 0;
-    const double hs = hi[s], hp = hi[sm], vs = vhi[s], vp = vhi[sm];
+    const double hs = hi[s], hp = hi[sm], vs = (double)vhi[s], vp = (double)vhi[sm];
     const double plo = s ? hp : 0.0;
     const double vlo = s ? vp : vlo0;
     return (int32_t)floor((p - plo) / (hs - plo) * (vs - vlo) + vlo);
@@ -58,7 +59,23 @@ struct EvSink32 {
     uint32_t last_ins_len;
     bool overflow;
     bool range;          // an event does not fit the 8-byte record: run longer than NS_EV_LEN_MAX, or |shift| >= NS_EV_SHIFT_BIAS
+    // thread-per-read chain: LDS column of this thread, four slots NS_CHAIN_BLOCK apart (nullptr: events are stored one by one).
+    // A thread's scattered 8-byte stores cost a 32-byte memory write each (WRITE_SIZE 10.3 KB per read for 2.1 KB of events); staged,
+    // four events leave as one aligned 32-byte group (ev and cap are multiples of four events then)
+    uint2 *stg;
 };
+#ifndef NS_CHAIN_BLOCK
+#define NS_CHAIN_BLOCK 256
+#endif
+__device__ __forceinline__ void ev_flush4(EvSink32 &s, uint32_t first) {       // staged slots 0..3 -> events first .. first + 3
+    const uint2 e0 = s.stg[0], e1 = s.stg[NS_CHAIN_BLOCK], e2 = s.stg[2 * NS_CHAIN_BLOCK], e3 = s.stg[3 * NS_CHAIN_BLOCK];
+    uint4 *dst = reinterpret_cast<uint4 *>(s.ev + first);
+    dst[0] = make_uint4(e0.x, e0.y, e1.x, e1.y); dst[1] = make_uint4(e2.x, e2.y, e3.x, e3.y);
+}
+// the events still staged when a piece is complete (slots behind the last event carry stale values: inside the capacity, never read)
+__device__ __forceinline__ void ev_flush_tail(EvSink32 &s) {
+    if (s.stg && (s.n & 3u) && s.n < s.cap) ev_flush4(s, s.n & ~3u);
+}
 // does the cumulative shift fit the 18-bit field of ns_event.info?
 __device__ __forceinline__ bool ev_shift_fits(int32_t shift) { return (uint32_t)(shift + NS_EV_SHIFT_BIAS) < 2u * (uint32_t)NS_EV_SHIFT_BIAS; }
 __device__ __forceinline__ void ev_push32(EvSink32 &s, int32_t pos, uint32_t type, int32_t len) {
@@ -66,7 +83,10 @@ __device__ __forceinline__ void ev_push32(EvSink32 &s, int32_t pos, uint32_t typ
     if (len > (int32_t)NS_EV_LEN_MAX || !ev_shift_fits(s.shift)) s.range = true;
     if (s.n < s.cap) {
         ns_event e; e.pos = (uint32_t)pos; e.info = ns_ev_pack(l, type, s.shift);
-        s.ev[s.n] = e;
+        if (s.stg) {
+            s.stg[(s.n & 3u) * NS_CHAIN_BLOCK] = make_uint2(e.pos, e.info);
+            if ((s.n & 3u) == 3u) ev_flush4(s, s.n - 3u);
+        } else s.ev[s.n] = e;
     } else s.overflow = true;
     if (type == NS_INS) { s.shift += (int32_t)l; s.last_ins_len = l; } else if (type == NS_DEL) s.shift -= (int32_t)l;
     s.n++;
@@ -75,12 +95,15 @@ __device__ __forceinline__ void ev_push32(EvSink32 &s, int32_t pos, uint32_t typ
 struct EList32 { int32_t l_new, middle_ref; };
 
 // error_list, S:1833-1916
+template <bool VU32>     // VU32: T is the LDS copy of the blob (value edges as 32-bit integers)
 __device__ __forceinline__ EList32 chain_error_list(const Tabs &T, const ChainTab &c, int32_t m_ref, const ns_key &key,
                                                     uint32_t seg, uint32_t attempt, EvSink32 &s) {
     int32_t l_new = m_ref, pos = 0, middle_ref = m_ref;
     int state = NS_ST_START;
     u32x4 w = ns_draw(key, ST_EVENT, seg, attempt, 0, 0);
-    int32_t prev_match = ecdf_lookup_g(T.d(c.fm_hi), T.d(c.fm_vhi), c.fm_n, c.fm_vlo0, T.h(c.fm_guide), w.x);   // S:1843-1850
+    int32_t prev_match;                                                                                           // S:1843-1850
+    if constexpr (VU32) prev_match = ecdf_lookup_g(T.d(c.fm_hi), T.u(c.fm_vhi_u), c.fm_n, c.fm_vlo0, T.h(c.fm_guide), w.x);
+    else prev_match = ecdf_lookup_g(T.d(c.fm_hi), T.d(c.fm_vhi), c.fm_n, c.fm_vlo0, T.h(c.fm_guide), w.x);
     if (prev_match < 2) prev_match = 2;
     pos += prev_match;
     uint32_t it = 1;
@@ -114,8 +137,10 @@ __device__ __forceinline__ EList32 chain_error_list(const Tabs &T, const ChainTa
             if (b >= c.mm_nbins) b = c.mm_nbins - 1;
         }
         const uint32_t o = seg_off[b];
-        step = ecdf_lookup_g(T.d(c.mm_hi) + o, T.d(c.mm_vhi) + o, seg_off[b + 1] - o, T.d(c.mm_vlo0)[b],
-                             T.h(c.mm_guide) + 256 * b, w.w);
+        if constexpr (VU32) step = ecdf_lookup_g(T.d(c.mm_hi) + o, T.u(c.mm_vhi_u) + o, seg_off[b + 1] - o, T.d(c.mm_vlo0)[b],
+                                                 T.h(c.mm_guide) + 256 * b, w.w);
+        else step = ecdf_lookup_g(T.d(c.mm_hi) + o, T.d(c.mm_vhi) + o, seg_off[b + 1] - o, T.d(c.mm_vlo0)[b],
+                                  T.h(c.mm_guide) + 256 * b, w.w);
         if (prev_match == 0 && step == 0) step = 1;                                                // S:1900-1901
         prev_match = step;
         if (pos + prev_match > middle_ref) { l_new += pos + prev_match - middle_ref; middle_ref = pos + prev_match; }

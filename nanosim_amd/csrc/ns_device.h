@@ -11,6 +11,8 @@ struct ChainTab {                 // offsets are in 8-byte words from the start 
     uint32_t mix_w;               // 3 doubles
     uint32_t mix_cdf[3][2], mix_n[3][2];
     uint32_t fm_hi, fm_vhi, fm_n, fm_guide;
+    uint32_t fm_vhi_u, mm_vhi_u;     // the value edges once more as 32-bit integers (they are whole numbers in every trained model): what the LDS copy holds
+    uint32_t n_words_lds;            // the blob up to here goes to LDS (k_chain<LDS>); the fp64 value edges behind it stay in global memory
     uint32_t mm_nbins, mm_bin, mm_bin_lut, mm_seg_off, mm_hi, mm_vhi, mm_vlo0, mm_guide;
     double fm_vlo0;
 };
