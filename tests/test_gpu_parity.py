@@ -100,6 +100,30 @@ def test_gpu_circular_reference(small_model, circ_ref):
         e.close()
 
 
+def test_fractional_value_edges_take_the_global_tables():
+    """The LDS image of the chain tables holds the ECDF value edges as 32-bit integers (whole numbers in every model read_analysis.py
+    writes); a table with fractional edges (read_ecdf parses them as floats, S:69-97) keeps fp64 edges and the chain reads them from
+    global memory — same reads as the oracle on the same table."""
+    import copy
+    import os
+    from tests.conftest import GOLDEN
+    mdl = M.load_model(os.path.join(GOLDEN, "model_small", "training"), chimeric=True, homopolymer=True, fastq=True)
+    mdl = copy.deepcopy(mdl)
+    mdl.first_match.vhi = np.asarray(mdl.first_match.vhi, dtype=np.float64) + 0.25
+    for col in mdl.match_markov:
+        col.vhi = np.asarray(col.vhi, dtype=np.float64) + 0.5
+    ref = M.read_fasta(os.path.join(GOLDEN, "genome_small.fa"), "linear")
+    e = E.Engine(0)
+    try:
+        e.set_reference(ref)
+        e.load_model(mdl)
+        for kw in (dict(n_reads=300, emit_errlog=True), dict(n_reads=200, chimeric=True, fastq=True)):
+            p = E.make_params(seed=4242, first_read=0, max_len=ref.max_chrom, **kw)
+            compare(e.generate(p), O.generate(mdl, ref, p), p)
+    finally:
+        e.close()
+
+
 def test_reads_do_not_depend_on_batching(eng, small_ref):
     """(seed, read index) fully determine a read: a sub-range reproduces the same bytes."""
     p_all = E.make_params(seed=99, first_read=0, n_reads=300, max_len=small_ref.max_chrom)
