@@ -1213,6 +1213,7 @@ struct ns_ctx {
     std::vector<void *> ir_allocs;
     DevBuf ir_need, ir_off, spliced;
     uint64_t spliced_bytes = 0;
+    uint8_t *pin_small = nullptr;    // page-locked slots for the scalar read-backs of a call (read_small)
     struct PinBuf { void *p = nullptr; size_t cap = 0; } pin_a, pin_b, pin_c;     // pinned host staging of the metagenome passes
     uint32_t nspecies = 0;
     bool has_abun = false, has_inflated = false, has_key_pos = false;
@@ -1312,11 +1313,25 @@ int ns_create(int device, ns_ctx **out) {
     if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { delete ctx; return NS_EHIP; }
+    if (hipHostMalloc((void **)&ctx->pin_small, 1024, hipHostMallocDefault) != hipSuccess) { ctx->pin_small = nullptr; delete ctx; return NS_ENOMEM; }
     ctx->evt_ok = true;
     if (const char *d = getenv("NS_DEBUG_SKIP")) ctx->dbg = (uint32_t)atoi(d);
     if (const char *d = getenv("NS_COOP_MIN")) ctx->coop_min = (uint32_t)atoi(d);
     if (const char *d = getenv("NS_COOP_SHIFT")) ctx->coop_shift = (uint32_t)atoi(d) & 31u;
     *out = ctx;
+    return NS_OK;
+}
+
+// Scalar read-backs of a call (totals of the scans, the counters): device -> page-locked slot -> destination, with the stream
+// synchronised in between.  (hipMemcpyAsync into pageable memory goes through a staging blit kernel; next to another context's
+// kernels on the same GPU that costs hundreds of microseconds per read-back.)
+static int read_small(ns_ctx *ctx, hipStream_t st, void *dst, const void *src, size_t n, void *dst2 = nullptr, const void *src2 = nullptr, size_t n2 = 0) {
+    if (n > 512 || n2 > 512) return fail(ctx, NS_EINVAL, "read_small: too large");
+    HIPCHK(hipMemcpyAsync(ctx->pin_small, src, n, hipMemcpyDeviceToHost, st));
+    if (dst2) HIPCHK(hipMemcpyAsync(ctx->pin_small + 512, src2, n2, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    memcpy(dst, ctx->pin_small, n);
+    if (dst2) memcpy(dst2, ctx->pin_small + 512, n2);
     return NS_OK;
 }
 
@@ -1347,6 +1362,7 @@ void ns_destroy(ns_ctx *ctx) {
                       &ctx->ir_need, &ctx->ir_off, &ctx->spliced};
     for (auto *pb : {&ctx->pin_a, &ctx->pin_b, &ctx->pin_c})
         if (pb->p) e = hipHostFree(pb->p);
+    if (ctx->pin_small) e = hipHostFree(ctx->pin_small);
     for (DevBuf *b : bufs)
         if (b->p) e = hipFree(b->p);
     if (ctx->evt_ok)
@@ -1642,8 +1658,7 @@ static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fast
         }
         HIPCHK(hipGetLastError());
         uint32_t queued = 0;
-        HIPCHK(hipMemcpyAsync(&queued, sq.count, 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        if (int rc2 = read_small(ctx, st, &queued, sq.count, 4)) return rc2;
         if (queued && mode == MAT_HP_FINAL)      // >= 64 homopolymer edits at one output offset (64 adjacent runs re-sampled to nothing)
             return fail(ctx, NS_EINVAL, "-k: homopolymer edits too dense for the record kernel");
         if (queued > sq.cap) {                   // more slow tiles than queue slots (tiny circular genomes): grow and redo
@@ -1681,8 +1696,7 @@ static int hp_stage1(ns_ctx *ctx, const ns_params *prm, GenArgs &A, size_t n, ui
     HIPCHK(hipGetLastError());
     if ((rc = scan_u64(ctx, A.scr_len, A.scr_off, n + 1))) return rc;
     uint64_t scr_bytes = 0;
-    HIPCHK(hipMemcpyAsync(&scr_bytes, A.scr_off + n, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    if ((rc = read_small(ctx, st, &scr_bytes, A.scr_off + n, 8))) return rc;
     // (the second record pass reads the scratch pieces with unaligned 16-byte loads that may start before / end behind a piece)
     if ((rc = ensure(ctx, ctx->scr, (size_t)scr_bytes + 2 * NS_REF_PAD + 64))) return rc;
     A.scr = (uint8_t *)ctx->scr.p + NS_REF_PAD;
@@ -1706,8 +1720,7 @@ static int hp_stage1(ns_ctx *ctx, const ns_params *prm, GenArgs &A, size_t n, ui
         k_hp_finalize<<<grid_t, blk, 0, st>>>(A, A.l_cap);
         k_sum_u64<<<dim3((unsigned)std::min<size_t>(512, (n + 255) / 256)), blk, 0, st>>>(A.scr_len, n, (unsigned long long *)ctx->stats.p + 1);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(stats, ctx->stats.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        if ((rc = read_small(ctx, st, stats, ctx->stats.p, 8 * sizeof(unsigned long long)))) return rc;
         if (!stats[7]) break;
         // more homopolymer edits per base than planned (low-complexity reference): nothing was finalised; again with twice the capacity
         if (retry >= 12) return fail(ctx, NS_ENOMEM, "-k: event capacity overflow persists");
@@ -2032,8 +2045,7 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
         k_lengths<<<grid_p, blk, 0, st>>>(P);                                      // gaps, head/tail, planned pieces (S:872, 898-903)
         HIPCHK(hipGetLastError());
         if ((rc = scan_u64(ctx, P.ev_cap, P.ev_off, np + 1))) return rc;
-        HIPCHK(hipMemcpyAsync(&pass_cap, P.ev_off + np, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));     // also: the host vectors above are free to change again
+        if ((rc = read_small(ctx, st, &pass_cap, P.ev_off + np, 8))) return rc;     // also: the host vectors above are free to change again
         if ((rc = ensure_keep(ctx, ctx->events, (size_t)(ev_base + pass_cap) * sizeof(ns_event) + 64, (size_t)ev_base * sizeof(ns_event)))) return rc;
         P.events = (ns_event *)ctx->events.p; P.ev_base = ev_base;
         P.m_passed = (uint32_t)passed; P.m_pieces_passed = (uint32_t)pieces_passed;
@@ -2058,8 +2070,7 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
         HIPCHK(hipGetLastError());
         if (n_coop) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
         HIPCHK(hipEventRecord(ctx->evt[4], st));
-        HIPCHK(hipMemcpyAsync(stats, ctx->stats.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        if ((rc = read_small(ctx, st, stats, ctx->stats.p, 8 * sizeof(unsigned long long)))) return rc;
         HIPCHK(hipEventElapsedTime(&ms, ctx->evt[3], ctx->evt[4])); ms_chain += ms;
         if (stats[0] >> 40) return fail(ctx, NS_EINVAL, NS_RANGE_MSG);
         if (!stats[0]) break;
@@ -2220,8 +2231,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         HIPCHK(hipGetLastError());
         if ((rc = scan_u32(ctx, A.n_pieces, A.piece_off, n + 1))) return rc;
         uint32_t tp32 = 0;
-        HIPCHK(hipMemcpyAsync(&tp32, A.piece_off + n, 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        if ((rc = read_small(ctx, st, &tp32, A.piece_off + n, 4))) return rc;
         tot_pieces = tp32;
         if ((rc = ensure(ctx, ctx->pieces, (size_t)tot_pieces * sizeof(ns_piece) + 64))) return rc;
         A.pieces = (ns_piece *)ctx->pieces.p;
@@ -2238,8 +2248,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
                                                                 A.sort_idx, list_a, (int)n, 0, 32, st));
         }
         HIPCHK(hipEventRecord(ctx->evt[2], st));
-        HIPCHK(hipMemcpyAsync(&tot_cap, A.ev_off + n, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        if ((rc = read_small(ctx, st, &tot_cap, A.ev_off + n, 8))) return rc;
         if ((rc = ensure(ctx, ctx->events, (size_t)tot_cap * sizeof(ns_event) + 64))) return rc;
         A.events = (ns_event *)ctx->events.p;
         // ---- passes: pass a generates attempt a of every read still without an accepted attempt ----
@@ -2259,8 +2268,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
                 HIPCHK(hipMemsetAsync(A.l_cap + cur_n, 0, 8, st));
                 if ((rc = scan_u64(ctx, A.l_cap, (uint64_t *)ctx->l_off.p, (size_t)cur_n + 1))) return rc;
                 uint64_t pass_cap = 0;
-                HIPCHK(hipMemcpyAsync(&pass_cap, (uint64_t *)ctx->l_off.p + cur_n, 8, hipMemcpyDeviceToHost, st));
-                HIPCHK(hipStreamSynchronize(st));
+                if ((rc = read_small(ctx, st, &pass_cap, (uint64_t *)ctx->l_off.p + cur_n, 8))) return rc;
                 if ((rc = ensure_keep(ctx, ctx->events, (size_t)(used + pass_cap) * sizeof(ns_event) + 64, (size_t)used * sizeof(ns_event)))) return rc;
                 A.events = (ns_event *)ctx->events.p;
                 A.l_off = (const uint64_t *)ctx->l_off.p; A.l_base = used;
@@ -2286,8 +2294,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
             HIPCHK(hipGetLastError());
             if (n_coop) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
             HIPCHK(hipEventRecord(ctx->evt[4], st));
-            HIPCHK(hipMemcpyAsync(stats, ctx->stats.p, sizeof stats, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
+            if ((rc = read_small(ctx, st, stats, ctx->stats.p, sizeof stats))) return rc;
             HIPCHK(hipEventElapsedTime(&ms, ctx->evt[3], ctx->evt[4]));
             ms_chain += ms;
             if (stats[0] >> 40) return fail(ctx, NS_EINVAL, NS_RANGE_MSG);
@@ -2308,8 +2315,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     if (ir_on) {          // splice arena: slot offsets, then the copy from the genome (before anything reads the pieces' bases)
         if ((rc = scan_u64(ctx, A.ir_need, (uint64_t *)ctx->ir_off.p, n + 1))) return rc;
         uint64_t arena_bytes = 0;
-        HIPCHK(hipMemcpyAsync(&arena_bytes, (uint64_t *)ctx->ir_off.p + n, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        if ((rc = read_small(ctx, st, &arena_bytes, (uint64_t *)ctx->ir_off.p + n, 8))) return rc;
         if ((rc = ensure(ctx, ctx->spliced, (size_t)arena_bytes + 64))) return rc;
         A.ir.arena = (uint8_t *)ctx->spliced.p; A.ir.arena_off = (const uint64_t *)ctx->ir_off.p;
         A.ref.spliced = (const uint8_t *)ctx->spliced.p;
@@ -2333,9 +2339,8 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     }
     if ((rc = scan_u64(ctx, A.rec_len, A.rec_off, n + 1))) return rc;
     if (prm->emit_errlog && (rc = scan_u64(ctx, A.err_len, A.err_off, n + 1))) return rc;
-    HIPCHK(hipMemcpyAsync(&info->record_bytes, A.rec_off + n, 8, hipMemcpyDeviceToHost, st));
-    if (prm->emit_errlog) HIPCHK(hipMemcpyAsync(&info->errlog_bytes, A.err_off + n, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    if ((rc = prm->emit_errlog ? read_small(ctx, st, &info->record_bytes, A.rec_off + n, 8, &info->errlog_bytes, A.err_off + n, 8)
+                               : read_small(ctx, st, &info->record_bytes, A.rec_off + n, 8))) return rc;
     if (prm->emit_records == 1u && ((rc = ensure(ctx, ctx->records, (size_t)info->record_bytes + 64)) ||
                                     (rc = ensure(ctx, ctx->errlog, (size_t)info->errlog_bytes + 64))))
         return rc;

@@ -74,6 +74,20 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     return v;
 }
 
+// inclusive prefix maximum over the wavefront (values >= 0), same DPP pattern
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v) {
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+__device__ __forceinline__ uint32_t dpp_wave_shl1(uint32_t lane63_value, uint32_t v) {     // lane l gets v of lane l + 1, lane 63 gets lane63_value
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)lane63_value, (int)v, 0x130, 0xf, 0xf, false);
+}
+
 // wave-uniform values that reach the kernel through vector loads: pin them to SGPRs so that the arithmetic on them is scalar
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint64_t uni64(uint64_t v) { return (uint64_t)uni((uint32_t)v) | (uint64_t)uni((uint32_t)(v >> 32)) << 32; }
@@ -710,9 +724,12 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
         e_pre.pos = 0; e_pre.info = 0; w_pre = 0;
         if (M1 < pc.out_len && jb_next + lane < pc.n_ev) { e_pre = pc.ev[jb_next + lane]; w_pre = pc.wd[jb_next + lane]; }   // prefetch for the next tile
         wave_sync();
-        if (take) {                                               // histogram: first chunk starting at/after the event
-            const uint32_t c = (os - A0 + 15) >> 4;
-            if (c < 64 * NS_TILE_CHUNKS) atomicAdd(&T.hist[c], 1u);
+        {   // hist[c] = number of the tile's events that start in front of chunk c + 1's first byte... written by the LAST event that
+            // does (the events are sorted: lane l is event l + 1 of the tile), so no two lanes write one slot and nothing is counted
+            // with atomics; the chunks in between inherit the value through a prefix maximum
+            const uint32_t c = take ? (os - A0 + 15) >> 4 : 0xffffffffu;    // first chunk starting at/after the event
+            const uint32_t c_next = dpp_wave_shl1(0xffffffffu, c);
+            if (c < 64 * NS_TILE_CHUNKS && c != c_next) T.hist[c] = lane + 1u;
         }
         // ---- the event in force at M1 (wave-uniform): the last one taken, straight from its lane's registers
         uint32_t osl = L0_out, ptl = L0_pt, rpl = L0_rp, wdl = L0_wd, jl = L0_j;
@@ -826,7 +843,7 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
 #endif
         for (uint32_t t = 0; t < NS_TILE_CHUNKS; ++t) {
         const uint32_t ci = 64 * t + lane;                         // chunk of the tile
-        const uint32_t incl = scan_base + wave_incl_scan(T.hist[ci]);
+        const uint32_t incl = max(scan_base, wave_incl_max(T.hist[ci]));
         scan_base = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         const uint32_t c0 = A0 + 16 * ci;                          // chunk origin (chunk 0 of a piece's first tile may start before M0)
         const uint32_t lo_m = ci == 0 ? M0 : c0, hi_m = min(c0 + 16, M1);
