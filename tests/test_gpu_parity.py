@@ -100,6 +100,24 @@ def test_gpu_circular_reference(small_model, circ_ref):
         e.close()
 
 
+def test_gpu_circular_reference_unaligned_and_gaps(small_model, circ_ref):
+    """unaligned reads and chimeric gaps (the dense record kernel) across the origin of a circular chromosome"""
+    e = E.Engine(0)
+    try:
+        e.set_reference(circ_ref)
+        e.load_model(small_model)
+        for kw in (dict(kind=E.NS_KIND_UNALIGNED, n_reads=400, fastq=True), dict(kind=E.NS_KIND_UNALIGNED, n_reads=300, median_len=9000, sd_len=0.3),
+                   dict(kind=E.NS_KIND_ALIGNED, n_reads=300, chimeric=True, emit_errlog=True)):
+            p = E.make_params(seed=1234, first_read=0, max_len=circ_ref.max_chrom, **kw)
+            b = e.generate(p)
+            compare(b, O.generate(small_model, circ_ref, p, bytes_per_read=100000, events_per_read=20000), p)
+            if kw["kind"] == E.NS_KIND_UNALIGNED:
+                pc = b.pieces()
+                assert np.any(pc["pos"].astype(np.int64) + pc["ref_len"] > circ_ref.genome_len)       # some reads wrap around
+    finally:
+        e.close()
+
+
 def test_fractional_value_edges_take_the_global_tables():
     """The LDS image of the chain tables holds the ECDF value edges as 32-bit integers (whole numbers in every model read_analysis.py
     writes); a table with fractional edges (read_ecdf parses them as floats, S:69-97) keeps fp64 edges and the chain reads them from
