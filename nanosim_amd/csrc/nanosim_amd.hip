@@ -1304,16 +1304,21 @@ int ns_create(int device, ns_ctx **out) {
     if (device < 0 || device >= n) return NS_ENODEV;
     ns_ctx *ctx = new ns_ctx();
     ctx->device = device;
+    // (ns_destroy releases whatever exists of a half-built context: null handles are skipped)
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
-        delete ctx;
+        ctx->stream = nullptr;
+        ns_destroy(ctx);
         return NS_EHIP;
     }
+    for (auto &e : ctx->evt) e = nullptr;
+    bool ok = true;
     for (auto &e : ctx->evt)
-        if (hipEventCreate(&e) != hipSuccess) { delete ctx; return NS_EHIP; }
-    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+        if (ok && hipEventCreate(&e) != hipSuccess) { e = nullptr; ok = false; }
+    ctx->evt_ok = true;              // (the events that exist are destroyed with the context)
+    if (!ok || hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { delete ctx; return NS_EHIP; }
-    if (hipHostMalloc((void **)&ctx->pin_small, 1024, hipHostMallocDefault) != hipSuccess) { ctx->pin_small = nullptr; delete ctx; return NS_ENOMEM; }
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { ns_destroy(ctx); return NS_EHIP; }
+    if (hipHostMalloc((void **)&ctx->pin_small, 1024, hipHostMallocDefault) != hipSuccess) { ctx->pin_small = nullptr; ns_destroy(ctx); return NS_ENOMEM; }
     ctx->evt_ok = true;
     if (const char *d = getenv("NS_DEBUG_SKIP")) ctx->dbg = (uint32_t)atoi(d);
     if (const char *d = getenv("NS_COOP_MIN")) ctx->coop_min = (uint32_t)atoi(d);
@@ -1366,7 +1371,7 @@ void ns_destroy(ns_ctx *ctx) {
     for (DevBuf *b : bufs)
         if (b->p) e = hipFree(b->p);
     if (ctx->evt_ok)
-        for (auto &ev : ctx->evt) e = hipEventDestroy(ev);
+        for (auto &ev : ctx->evt) if (ev) e = hipEventDestroy(ev);
     delete ctx;
 }
 
