@@ -118,8 +118,18 @@ __device__ __forceinline__ uint32_t hp_run_events(double hp_mis_rate, const ns_k
     bool first = true;
     const uint32_t kept = min(size, L), off = L - kept;
     for (uint32_t d = L - kept, pos = s0; d;) { const uint32_t c = min(d, NS_EV_LEN_MAX); put(pos, (uint32_t)NS_DEL, c, 0u); pos += c; d -= c; ++n; }
-    for (uint32_t x = 0; x < kept; ++x)
-        if (is_mis(x)) { put(s0 + off + x, (uint32_t)NS_MIS, 1u, (choice(x) & ~1u) | (first ? 1u : 0u)); first = false; ++n; }
+    // the kept bases four at a time (one Philox block; p <= rate <=> u < ns_thr_gt(rate)): mismatches are rare, the loop over the
+    // bases of the wavefront's longest run is what the drain spends its time on
+    const uint64_t thr = ns_thr_gt(hp_mis_rate);
+    for (uint32_t x0 = 0; x0 < kept; x0 += 4) {
+        wblk = x0 >> 2; w = ns_draw(key, ST_HPMIS, sid, a, s0, wblk);
+        uint32_t m4 = ((uint64_t)w.x < thr ? 1u : 0u) | ((uint64_t)w.y < thr ? 2u : 0u) | ((uint64_t)w.z < thr ? 4u : 0u) | ((uint64_t)w.w < thr ? 8u : 0u);
+        if (kept - x0 < 4u) m4 &= (1u << (kept - x0)) - 1u;
+        for (; m4; m4 &= m4 - 1u) {
+            const uint32_t x = x0 + (uint32_t)__builtin_ctz(m4);
+            put(s0 + off + x, (uint32_t)NS_MIS, 1u, (choice(x) & ~1u) | (first ? 1u : 0u)); first = false; ++n;
+        }
+    }
     const uint32_t code_b = (uint32_t)base_rank(base);
     for (uint32_t x = L; x < size;) {
         uint32_t word = 0, cnt = 0; bool flag = false;
