@@ -1,15 +1,19 @@
 // nanosim_amd.hip — gfx950 kernels + C-ABI host layer of the read-generation engine.
 //
 // Pipeline of one ns_generate() call (one worker call of the reference, S:1266-1454 / S:1482-1549):
-//   k_plan        thread/read   segment count + event capacity                       (S:1276-1299)
-//   scan          rocPRIM       piece / event offsets
-//   k_events      thread/read   lengths, strand, error_list Markov chains, acceptance, positions
-//                                                                                     (S:1283-1402, 1833-1916, 1784-1830, 1694-1781)
-//   scan          rocPRIM       record / error-log offsets
-//   k_names       thread/read   ">name\n", "+\n" framing                              (S:1390-1402, 1437-1443)
-//   k_materialise wave/read     case_convert + mutate_read + head/tail + revcomp (+ qualities)
-//                                                                                     (S:743-755, 1919-2015, 1421-1435)
-//   k_errlog      wave/read     _aligned_error_profile rows                           (S:2006-2008)
+//   k_nseg, k_lengths   thread/read   segment count (S:1276-1299), lengths of the attempt, strand, head / tail, event capacity
+//   scans, radix sort   rocPRIM       piece / event offsets; visiting order by descending length
+//   k_chain             thread/read   error_list / unaligned_error_list, acceptance, positions   (S:1283-1402, 1833-1916, 1784-1830,
+//                       (+ wave/read for the longest reads, the unaligned reads and the gaps)      1694-1781); one pass per attempt
+//   k_ir_splice         wave/read     transcriptome: retained introns spliced into the read's slot of an arena (S:1156-1192)
+//   -k: k_hp_filter_w, k_materialise<., MAT_HP_SCRATCH>, k_hp_events, k_hp_finalize           (ns_hp.h; S:1920-1947, 618-705)
+//   scans               rocPRIM       record / error-profile offsets
+//   k_names             thread/read   ">name\n", "+\n" framing                              (S:1390-1402, 1437-1443)
+//   k_words             wave/read     the letter word of every event
+//   k_materialise       wave/read     case_convert + mutate_read + head/tail + revcomp (+ qualities)   (S:743-755, 1919-2015, 1421-1435)
+//   k_materialise_dense wave/segment  the same for unaligned reads and gaps (0.55 events per base)
+//   k_errlog            wave/read     _aligned_error_profile rows                           (S:2006-2008)
+// Metagenome worker calls run k_lengths / k_chain per PASS of the reference's while loop (S:844-1040) with k_meta_* around them.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdio.h>
@@ -1487,7 +1491,7 @@ int ns_load_model(ns_ctx *ctx, const ns_model_tables *t) {
         double rate = 1.0 / (mean_match_min > 0.5 ? mean_match_min + 0.5 : 1.0);
         ctx->cap_rate = rate * 1.5 > 2.0 ? 2.0 : rate * 1.5;
 
-        // ---- pack the chain tables into one blob of 8-byte words (copied to LDS by k_events) ----
+        // ---- pack the chain tables into one blob of 8-byte words (its first part is copied to LDS by k_chain) ----
         std::vector<uint64_t> blob;
         ChainTab &ct = m.ct;
         auto put_d = [&](const double *src, size_t n) { uint32_t off = (uint32_t)blob.size(); blob.resize(off + n);

@@ -1,5 +1,5 @@
 // ns_chain.h — the error-event Markov chains of error_list (S:1833-1916) and unaligned_error_list
-// (S:1784-1830) on tables packed into ONE blob of 8-byte words that k_events copies into LDS.
+// (S:1784-1830) on tables packed into ONE blob of 8-byte words that k_chain copies into LDS.
 // Same arithmetic as the generic functions of ns_device.h (fp64 compares + one fp64 interpolation),
 // but every search starts from a 256-entry guide index instead of a full binary search.
 #pragma once
