@@ -6,7 +6,7 @@
 //   k_chain             thread/read   error_list / unaligned_error_list, acceptance, positions   (S:1283-1402, 1833-1916, 1784-1830,
 //                       (+ wave/read for the longest reads, the unaligned reads and the gaps)      1694-1781); one pass per attempt
 //   k_ir_splice         wave/read     transcriptome: retained introns spliced into the read's slot of an arena (S:1156-1192)
-//   -k: k_hp_filter_w, k_materialise<., MAT_HP_SCRATCH>, k_hp_events, k_hp_finalize           (ns_hp.h; S:1920-1947, 618-705)
+//   -k: k_hp_filter_w, k_materialise<., MAT_HP_SCRATCH>, k_hp_scan, k_hp_drain, k_hp_finalize  (ns_hp.h; S:1920-1947, 618-705)
 //   scans               rocPRIM       record / error-profile offsets
 //   k_names             thread/read   ">name\n", "+\n" framing                              (S:1390-1402, 1437-1443)
 //   k_words             wave/read     the letter word of every event
@@ -80,7 +80,7 @@ struct GenArgs {
     uint64_t *scr_len, *scr_off;     //     bytes per read / exclusive scan
     uint32_t *hp_len;                // -k: final emitted length per piece
     ns_event *hp_ev;                 // -k: the homopolymer edits of every aligned piece as an event list over its scratch bytes
-    uint32_t *hp_wd;                 //     (k_hp_events; format: materialise_piece, MAT_HP_FINAL) and the letter word of every event
+    uint32_t *hp_wd;                 //     (k_hp_drain; format: materialise_piece, MAT_HP_FINAL) and the letter word of every event
     uint32_t *hp_nev;                //     events per piece
     uint32_t hp_shift, hp_pad;       //     capacity of a piece: (scratch bytes >> hp_shift) + hp_pad events (hp_ev_slot)
     // metagenome (one pass = one `while remaining_reads` iteration of S:836-1036)
@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
                 polya = pl > 65535 ? 65535u : (uint32_t)pl;
                 seq_len += polya;
             }
-            // final length re-check (S:1429-1430, S:1518-1519); with -k the length is only final after k_hp_events
+            // final length re-check (S:1429-1430, S:1518-1519); with -k the length is only final after k_hp_drain
             if (!pos_ok || (!A.hp && !trx_al && (seq_len < prm.min_len || seq_len > prm.max_len))) { ++epoch; fails = 0; break; }
             // ---- accepted ----
             rd.flags = 0; rd.seq_len = (uint32_t)seq_len; rd.attempts = a;
@@ -722,7 +722,7 @@ k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, co
     for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
         PieceCtx pc;
         if constexpr (MODE == MAT_HP_FINAL) {
-            // the source is the scratch piece, the events are the homopolymer edits k_hp_events filed for it (mutate_homo, S:618-705)
+            // the source is the scratch piece, the events are the homopolymer edits k_hp_drain filed for it (mutate_homo, S:618-705)
             const uint32_t gp = rd.piece_off + pi;
             const ns_piece p = A.pieces[gp];
             const uint64_t eo = hp_ev_slot(A, q_in, gp);
@@ -887,26 +887,28 @@ __device__ inline void hp_final_length(const GenArgs &A, uint64_t r, ns_read &rd
     }
 }
 
-// k_hp_events — mutate_homo (S:618-705) as an EDIT LIST over the pre-homopolymer read in the scratch buffer, one read per wavefront.
-// The run scan (S:627-637) streams a piece 1024 bases at a time, 16 per lane, and looks BACKWARDS only: a base that differs from its
-// predecessor starts a run and thereby closes the previous one, whose start is the nearest run start before it — in the lane's own
-// chunk, in the nearest lower lane that has one (ballot + one cross-lane read), or carried over from the earlier tiles in an SGPR.  So
-// there is no look-ahead, no dependent load, and the loads of the next tiles are in flight while a tile is scanned.  The runs of >= k
-// bases go to an LDS list, which is drained one lane per run: new length (S:644-665), the mismatches among the new bases
-// (S:668-684), and from them the events the second record pass applies (materialise_piece, MAT_HP_FINAL): a deletion for a
-// contraction, insertions of <= 15 letters for an expansion, one-base substitutions.  Wavefront prefix sums give every run its event
-// slots and its cumulative shift.  Also: the final length of every piece and of the read (checked by k_hp_finalize, S:1429-1430).
-#define NS_HPC_LIST 1088u
+// mutate_homo (S:618-705) as an EDIT LIST over the pre-homopolymer read in the scratch buffer, one read per wavefront, in two kernels
+// (as one kernel the drain's registers — fp64 norminv, Philox — held the scan at 4 wavefronts per SIMD):
+//
+// k_hp_scan — the run scan (S:627-637) streams a piece 1024 bases at a time, 16 per lane, and looks BACKWARDS only: a base that differs
+// from its predecessor starts a run and thereby closes the previous one, whose start is the nearest run start before it — in the lane's
+// own chunk, in the nearest lower lane that has one (ballot + one cross-lane read), or carried over from the earlier tiles in an SGPR.
+// So there is no look-ahead, no dependent load, and the loads of the next tiles are in flight while a tile is scanned.  The runs of
+// >= k bases are staged in an LDS list and leave for the piece's slots of the run buffer in coalesced groups.
+//
+// k_hp_drain — one lane per run: new length (S:644-665), the mismatches among the new bases (S:668-684), and from them the events the
+// second record pass applies (materialise_piece, MAT_HP_FINAL): a deletion for a contraction, insertions of <= 15 letters for an
+// expansion, one-base substitutions.  Wavefront prefix sums give every run its event slots and its cumulative shift.  Also: the final
+// length of every piece and of the read (checked by k_hp_finalize, S:1429-1430).
+#define NS_HPC_LIST 544u          // 4.9 KB per wavefront: eight wavefronts per SIMD
 struct HpCountLds { uint32_t s0[NS_HPC_LIST], len[NS_HPC_LIST]; uint8_t base[NS_HPC_LIST]; };
-#ifndef NS_HPC_WAVES
-#define NS_HPC_WAVES 4
-#endif
 __device__ __forceinline__ uint4 hp_load16(const uint8_t *__restrict__ sq, uint32_t n, uint32_t c) {
     uint4 v = make_uint4(0, 0, 0, 0);
     if (c < n) __builtin_memcpy(&v, sq + c, 16);                      // (the scratch buffer has slack behind the last read)
     return v;
 }
-__global__ void __launch_bounds__(64 * NS_WPB, NS_HPC_WAVES) k_hp_events(GenArgs A, uint64_t *__restrict__ hp_final) {
+// a run in the run buffer: start in the piece, length << 8 | base
+__global__ void __launch_bounds__(64 * NS_WPB) k_hp_scan(GenArgs A, uint2 *__restrict__ runs, uint32_t *__restrict__ n_runs) {
     __shared__ HpCountLds list_lds[NS_WPB];
     HpCountLds &R = list_lds[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63u;
@@ -914,35 +916,31 @@ __global__ void __launch_bounds__(64 * NS_WPB, NS_HPC_WAVES) k_hp_events(GenArgs
     if (r >= A.prm.n_reads) return;
     const ns_read rd = A.reads[r];
     if (rd.flags) return;
-    const ns_key key = read_key(A, r);
-    const uint32_t a = rd.attempts, k = A.prm.kmer_bias;
+    const uint32_t k = A.prm.kmer_bias;
     const uint64_t scr_off = uni64(A.scr_off[r]);
     bool over = false;
-    uint64_t q = 0, final_len = (uint64_t)rd.head + rd.tail + (A.polya ? A.polya[r] : 0u);
+    uint64_t q = 0;
     for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
         const uint32_t gp = rd.piece_off + pi;
         const ns_piece p = A.pieces[gp];
         const uint32_t n = uni(p.out_len);
-        uint32_t flen = n;
         if (!uni(p.kind)) {
-            const uint32_t sid = pi >> 1;
             const uint8_t *sq = A.scr + scr_off + q;
             const uint64_t ev0 = hp_ev_slot(A, scr_off + q, gp);
             const uint64_t cap64 = hp_ev_slot(A, scr_off + q + n, gp + 1) - ev0;
             const uint32_t cap = cap64 > 0xffffffffull ? 0xffffffffu : (uint32_t)cap64;
-            ns_event *ev = A.hp_ev + ev0;
-            uint32_t *wd = A.hp_wd + ev0;
-            uint32_t n_ev = 0, shift = 0;                                      // events filed / cumulative length change (wave-uniform)
+            uint2 *dst = runs + ev0;
+            uint32_t n_out = 0;                                                  // runs of the piece written so far (wave-uniform)
             uint32_t n_list = 0;                                                 // runs waiting in the list (wave-uniform)
-            // long runs one tile can close: 16 / k + 1 per chunk for k >= 4, one per base below.  The scan loop runs while the list has
-            // room for a tile's worth; the drain sits OUTSIDE it (inside, its registers push the prefetched tiles into scratch memory)
+            // long runs one tile can close: 16 / k + 1 per chunk for k >= 4, one per base below
             const uint32_t tile_max = k >= 4 ? 64u * (16u / k + 1u) : 1024u;
+            const bool direct = tile_max + 1u > NS_HPC_LIST;                    // k < 4: a tile can close more runs than the list holds — they go straight to the run buffer
             uint32_t carry_byte = 0xffu;                                         // base in front of the tile (0xff: none)
             uint32_t open_start = 0;                                             // start of the run that is open where the tile begins
             uint32_t t0 = 0;
             do {
                 uint4 v0 = hp_load16(sq, n, t0 + 16 * lane), v1 = hp_load16(sq, n, t0 + 1024 + 16 * lane), v2 = hp_load16(sq, n, t0 + 2048 + 16 * lane);
-                for (; t0 < n && n_list + tile_max + 1u <= NS_HPC_LIST; t0 += 1024) {
+                for (; t0 < n && (direct || n_list + tile_max + 1u <= NS_HPC_LIST); t0 += 1024) {
                     const uint4 v = v0;
                     v0 = v1; v1 = v2; v2 = hp_load16(sq, n, t0 + 3072 + 16 * lane);   // three tiles ahead
                     const uint32_t c = t0 + 16 * lane;
@@ -973,7 +971,7 @@ __global__ void __launch_bounds__(64 * NS_WPB, NS_HPC_WAVES) k_hp_events(GenArgs
                     else E = (M && c && back + (uint32_t)__builtin_ctz(M) >= k) ? (M & (0u - M)) << 16 : 0u;   // only the run closed by the first start
                     // ---- the long runs that end in front of the window bits E go to the list
                     const uint32_t rc = (uint32_t)__builtin_popcount(E), incl = wave_incl_scan(rc);
-                    uint32_t slot = n_list + incl - rc;
+                    uint32_t slot = (direct ? n_out : n_list) + incl - rc;
                     for (uint32_t Em = E; Em; Em &= Em - 1, ++slot) {
                         const uint32_t b = (uint32_t)__builtin_ctz(Em);                 // the run ends in front of window bit b
                         const uint32_t below = W & ((1u << b) - 1u);                      // its start: the nearest start before it —
@@ -981,44 +979,92 @@ __global__ void __launch_bounds__(64 * NS_WPB, NS_HPC_WAVES) k_hp_events(GenArgs
                         // base of the run = the base in front of bit b: chunk byte b - 17, or the byte in front of the chunk
                         const uint32_t i = b - 17u;
                         const uint32_t wv = b == 16u ? pb : (i < 8 ? (i < 4 ? v.x : v.y) : (i < 12 ? v.z : v.w)) >> (8 * (i & 3));
-                        R.s0[slot] = st; R.len[slot] = c - 16u + b - st; R.base[slot] = (uint8_t)(wv & 0xd7u);
+                        if (direct) { if (slot < cap) dst[slot] = make_uint2(st, (c - 16u + b - st) << 8 | (wv & 0xd7u)); }
+                        else { R.s0[slot] = st; R.len[slot] = c - 16u + b - st; R.base[slot] = (uint8_t)(wv & 0xd7u); }
                     }
-                    n_list += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    if (direct) n_out += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    else n_list += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                     // carries
                     if (B) open_start = (uint32_t)__shfl((int)last_own, 63 - __clzll((long long)B));
                     carry_byte = (uint32_t)__builtin_amdgcn_readlane((int)(v.w >> 24), 63);
                 }
                 if (t0 >= n && n && n - open_start >= k) {                       // the run that is open at the end of the piece
-                    if (lane == 0) { R.s0[n_list] = open_start; R.len[n_list] = n - open_start; R.base[n_list] = (uint8_t)(sq[n - 1] & 0xd7u); }
-                    ++n_list;
-                }
-                // ---- drain: one lane per run
-                wave_sync();
-                for (uint32_t j0 = 0; j0 < n_list; j0 += 64) {
-                    const uint32_t j = j0 + lane;
-                    const bool on = j < n_list;
-                    uint32_t s0 = 0, L = 0, base = 'A', size = 0, ne = 0, slot = 0, sh = 0, d_incl = 0, ne_incl = 0;
-                    if (on) { s0 = R.s0[j]; L = R.len[j]; base = R.base[j]; size = hp_new_size(A.m, key, sid, a, s0, L, base); }
-                    for (uint32_t pass = 0; pass < 2; ++pass) {                 // 0: count the run's events, 1: file them
-                        if (on && (pass == 0 || slot + ne <= cap))
-                            ne = hp_run_events(A.m.hp_mis_rate, key, sid, a, s0, L, size, base, [&](uint32_t pos, uint32_t ty, uint32_t len, uint32_t word) {
-                                if (!pass) return;
-                                ns_event e; e.pos = pos; e.info = ns_ev_pack(len, ty, (int32_t)sh);
-                                ev[slot] = e; wd[slot] = word; ++slot;
-                                if (ty == NS_INS) sh += len; else if (ty == NS_DEL) sh -= len;
-                            });
-                        if (!pass) {
-                            const uint32_t d = on ? size - L : 0u;               // (mod 2^32)
-                            ne_incl = wave_incl_scan(ne); d_incl = wave_incl_scan(d);
-                            slot = n_ev + ne_incl - ne; sh = shift + d_incl - d;
-                        }
+                    if (direct) {
+                        if (lane == 0 && n_out < cap) dst[n_out] = make_uint2(open_start, (n - open_start) << 8 | (uint32_t)(sq[n - 1] & 0xd7u));
+                        ++n_out;
+                    } else {
+                        if (lane == 0) { R.s0[n_list] = open_start; R.len[n_list] = n - open_start; R.base[n_list] = (uint8_t)(sq[n - 1] & 0xd7u); }
+                        ++n_list;
                     }
-                    n_ev += (uint32_t)__builtin_amdgcn_readlane((int)ne_incl, 63);
-                    shift += (uint32_t)__builtin_amdgcn_readlane((int)d_incl, 63);
                 }
+                // ---- the list leaves for the run buffer
+                wave_sync();
+                for (uint32_t j = lane; j < n_list; j += 64)
+                    if (n_out + j < cap) dst[n_out + j] = make_uint2(R.s0[j], R.len[j] << 8 | R.base[j]);
+                n_out += n_list;
                 wave_sync();
                 n_list = 0;
             } while (t0 < n);
+            if (n_out > cap) over = true;
+            if (lane == 0) n_runs[gp] = min(n_out, cap);
+        }
+        q += n;
+    }
+    if (lane == 0 && over) atomicAdd(&A.stats[7], 1ull);                        // a piece outgrew its capacity: the stage is repeated with more
+}
+
+#ifndef NS_HPD_WAVES
+#define NS_HPD_WAVES 4
+#endif
+__global__ void __launch_bounds__(64 * NS_WPB, NS_HPD_WAVES) k_hp_drain(GenArgs A, const uint2 *__restrict__ runs, const uint32_t *__restrict__ n_runs,
+                                                                       uint64_t *__restrict__ hp_final) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= A.prm.n_reads) return;
+    const ns_read rd = A.reads[r];
+    if (rd.flags) return;
+    const ns_key key = read_key(A, r);
+    const uint32_t a = rd.attempts;
+    const uint64_t scr_off = uni64(A.scr_off[r]);
+    bool over = false;
+    uint64_t q = 0, final_len = (uint64_t)rd.head + rd.tail + (A.polya ? A.polya[r] : 0u);
+    for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
+        const uint32_t gp = rd.piece_off + pi;
+        const ns_piece p = A.pieces[gp];
+        const uint32_t n = uni(p.out_len);
+        uint32_t flen = n;
+        if (!uni(p.kind)) {
+            const uint32_t sid = pi >> 1;
+            const uint64_t ev0 = hp_ev_slot(A, scr_off + q, gp);
+            const uint64_t cap64 = hp_ev_slot(A, scr_off + q + n, gp + 1) - ev0;
+            const uint32_t cap = cap64 > 0xffffffffull ? 0xffffffffu : (uint32_t)cap64;
+            ns_event *ev = A.hp_ev + ev0;
+            uint32_t *wd = A.hp_wd + ev0;
+            const uint2 *src = runs + ev0;
+            const uint32_t n_list = uni(n_runs[gp]);
+            uint32_t n_ev = 0, shift = 0;                                      // events filed / cumulative length change (wave-uniform)
+            for (uint32_t j0 = 0; j0 < n_list; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                const bool on = j < n_list;
+                uint32_t s0 = 0, L = 0, base = 'A', size = 0, ne = 0, slot = 0, sh = 0, d_incl = 0, ne_incl = 0;
+                if (on) { const uint2 rn = src[j]; s0 = rn.x; L = rn.y >> 8; base = rn.y & 0xffu; size = hp_new_size(A.m, key, sid, a, s0, L, base); }
+                for (uint32_t pass = 0; pass < 2; ++pass) {                 // 0: count the run's events, 1: file them
+                    if (on && (pass == 0 || slot + ne <= cap))
+                        ne = hp_run_events(A.m.hp_mis_rate, key, sid, a, s0, L, size, base, [&](uint32_t pos, uint32_t ty, uint32_t len, uint32_t word) {
+                            if (!pass) return;
+                            ns_event e; e.pos = pos; e.info = ns_ev_pack(len, ty, (int32_t)sh);
+                            ev[slot] = e; wd[slot] = word; ++slot;
+                            if (ty == NS_INS) sh += len; else if (ty == NS_DEL) sh -= len;
+                        });
+                    if (!pass) {
+                        const uint32_t d = on ? size - L : 0u;               // (mod 2^32)
+                        ne_incl = wave_incl_scan(ne); d_incl = wave_incl_scan(d);
+                        slot = n_ev + ne_incl - ne; sh = shift + d_incl - d;
+                    }
+                }
+                n_ev += (uint32_t)__builtin_amdgcn_readlane((int)ne_incl, 63);
+                shift += (uint32_t)__builtin_amdgcn_readlane((int)d_incl, 63);
+            }
             if (n_ev > cap) over = true;
             flen = n + shift;
             if (lane == 0) A.hp_nev[gp] = min(n_ev, cap);
@@ -1029,11 +1075,11 @@ __global__ void __launch_bounds__(64 * NS_WPB, NS_HPC_WAVES) k_hp_events(GenArgs
     }
     if (lane == 0) {
         hp_final[r] = final_len;                                                // (checked by k_hp_finalize, S:1429-1430)
-        if (over) atomicAdd(&A.stats[7], 1ull);                                 // a piece outgrew its event capacity: the kernel is repeated with more
+        if (over) atomicAdd(&A.stats[7], 1ull);                                 // a piece outgrew its event capacity: the stage is repeated with more
     }
 }
 
-// the final length check of every read (S:1429-1430 / metagenome S:1023-1024) once k_hp_events has run without a capacity overflow
+// the final length check of every read (S:1429-1430 / metagenome S:1023-1024) once k_hp_scan / k_hp_drain have run without a capacity overflow
 __global__ void __launch_bounds__(256) k_hp_finalize(GenArgs A, const uint64_t *__restrict__ final_len) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long st_bases = 0, st_fail = 0;
@@ -1203,7 +1249,7 @@ struct ns_ctx {
     DevBuf l_cap, l_off;
     DevBuf n_pieces, piece_off, ev_cap, ev_off, rec_len, rec_off, err_len, err_off, name_len;
     DevBuf reads, pieces, events, records, errlog, stats, scan_tmp;
-    DevBuf sort_key, sort_idx, sort_key_out, order, list_b, list_c, rstate, att_base, scr, scr_len, scr_off, hp_len, hp_nev, hp_ev, hp_wd, slow_q, ev_word;
+    DevBuf sort_key, sort_idx, sort_key_out, order, list_b, list_c, rstate, att_base, scr, scr_len, scr_off, hp_len, hp_nev, hp_ev, hp_wd, hp_runs, hp_nrun, slow_q, ev_word;
     uint32_t hp_shift = 5, hp_pad = 64, hp_cap_k = 0;       // -k: event capacity of a piece (hp_ev_slot), planned for kmer_bias hp_cap_k
     // metagenome: species view of the reference, abundances of the sample, per-pass scratch
     DevBuf species_chrom_off, t_reads, t_pieces, t_name_len, t_rec_len, t_err_len, accept, accept_scan, key_pos, draw_x, m_segptr,
@@ -1363,7 +1409,7 @@ void ns_destroy(ns_ctx *ctx) {
     DevBuf *bufs[] = {&ctx->n_pieces, &ctx->piece_off, &ctx->ev_cap, &ctx->ev_off, &ctx->rec_len, &ctx->rec_off,
                       &ctx->err_len, &ctx->err_off, &ctx->name_len, &ctx->reads, &ctx->pieces, &ctx->events,
                       &ctx->records, &ctx->errlog, &ctx->stats, &ctx->scan_tmp, &ctx->sort_key, &ctx->sort_idx,
-                      &ctx->sort_key_out, &ctx->order, &ctx->list_b, &ctx->list_c, &ctx->rstate, &ctx->att_base, &ctx->scr, &ctx->hp_nev, &ctx->hp_ev, &ctx->hp_wd,
+                      &ctx->sort_key_out, &ctx->order, &ctx->list_b, &ctx->list_c, &ctx->rstate, &ctx->att_base, &ctx->scr, &ctx->hp_nev, &ctx->hp_ev, &ctx->hp_wd, &ctx->hp_runs, &ctx->hp_nrun,
                       &ctx->scr_len, &ctx->scr_off, &ctx->hp_len, &ctx->slow_q, &ctx->ev_word, &ctx->l_cap, &ctx->l_off, &ctx->species_chrom_off, &ctx->t_reads, &ctx->t_pieces,
                       &ctx->t_name_len, &ctx->t_rec_len, &ctx->t_err_len, &ctx->accept, &ctx->accept_scan, &ctx->key_pos,
                       &ctx->draw_x, &ctx->m_segptr, &ctx->m_len, &ctx->m_species, &ctx->species_bases, &ctx->draw_sel,
@@ -1634,7 +1680,7 @@ static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fast
         HIPCHK(hipGetLastError());
         return NS_OK;
     }
-    if (mode != MAT_HP_FINAL) {               // (the second pass of -k takes its letter words from k_hp_events)
+    if (mode != MAT_HP_FINAL) {               // (the second pass of -k takes its letter words from k_hp_drain)
         int rc = ensure(ctx, ctx->ev_word, ((size_t)event_slots + 8) * 4);
         if (rc) return rc;
         k_words<<<dim3((unsigned)n), dim3(64), 0, st>>>(A, (uint32_t *)ctx->ev_word.p);
@@ -1699,7 +1745,8 @@ static int hp_stage1(ns_ctx *ctx, const ns_params *prm, GenArgs &A, size_t n, ui
     int rc;
     float ms = 0;
     HIPCHK(hipEventRecord(ctx->evt[9], st));
-    if ((rc = ensure(ctx, ctx->hp_len, (size_t)tot_pieces * 4 + 64)) || (rc = ensure(ctx, ctx->hp_nev, (size_t)tot_pieces * 4 + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->hp_len, (size_t)tot_pieces * 4 + 64)) || (rc = ensure(ctx, ctx->hp_nev, (size_t)tot_pieces * 4 + 64)) ||
+        (rc = ensure(ctx, ctx->hp_nrun, (size_t)tot_pieces * 4 + 64))) return rc;
     A.hp_len = (uint32_t *)ctx->hp_len.p; A.hp_nev = (uint32_t *)ctx->hp_nev.p;
     k_hp_filter_w<<<dim3((unsigned)((n + NS_WPB) / NS_WPB)), dim3(64 * NS_WPB), 0, st>>>(A);
     HIPCHK(hipGetLastError());
@@ -1720,12 +1767,13 @@ static int hp_stage1(ns_ctx *ctx, const ns_params *prm, GenArgs &A, size_t n, ui
     for (int retry = 0;; ++retry) {
         A.hp_shift = ctx->hp_shift; A.hp_pad = ctx->hp_pad;
         const size_t slots = (size_t)(scr_bytes >> A.hp_shift) + (size_t)A.hp_pad * (tot_pieces + 1) + 64;
-        if ((rc = ensure(ctx, ctx->hp_ev, slots * sizeof(ns_event))) || (rc = ensure(ctx, ctx->hp_wd, slots * 4))) return rc;
+        if ((rc = ensure(ctx, ctx->hp_ev, slots * sizeof(ns_event))) || (rc = ensure(ctx, ctx->hp_wd, slots * 4)) || (rc = ensure(ctx, ctx->hp_runs, slots * 8))) return rc;
         A.hp_ev = (ns_event *)ctx->hp_ev.p; A.hp_wd = (uint32_t *)ctx->hp_wd.p;
         if (!A.meta || A.key_pos) HIPCHK(hipMemsetAsync((unsigned long long *)ctx->stats.p + 1, 0, sizeof(unsigned long long), st));   // (kept across metagenome passes)
         HIPCHK(hipMemsetAsync((unsigned long long *)ctx->stats.p + 5, 0, sizeof(unsigned long long), st));
         HIPCHK(hipMemsetAsync((unsigned long long *)ctx->stats.p + 7, 0, sizeof(unsigned long long), st));
-        k_hp_events<<<dim3((unsigned)((n + NS_WPB - 1) / NS_WPB)), dim3(64 * NS_WPB), 0, st>>>(A, A.l_cap);
+        k_hp_scan<<<dim3((unsigned)((n + NS_WPB - 1) / NS_WPB)), dim3(64 * NS_WPB), 0, st>>>(A, (uint2 *)ctx->hp_runs.p, (uint32_t *)ctx->hp_nrun.p);
+        k_hp_drain<<<dim3((unsigned)((n + NS_WPB - 1) / NS_WPB)), dim3(64 * NS_WPB), 0, st>>>(A, (const uint2 *)ctx->hp_runs.p, (const uint32_t *)ctx->hp_nrun.p, A.l_cap);
         k_hp_finalize<<<grid_t, blk, 0, st>>>(A, A.l_cap);
         k_sum_u64<<<dim3((unsigned)std::min<size_t>(512, (n + 255) / 256)), blk, 0, st>>>(A.scr_len, n, (unsigned long long *)ctx->stats.p + 1);
         HIPCHK(hipGetLastError());
