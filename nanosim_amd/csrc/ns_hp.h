@@ -4,7 +4,7 @@
 //   k_hp_filter_w                     wave/read  drop the events that overlap a homopolymer of the un-mutated segment, re-pack the rest
 //   k_materialise<., MAT_HP_SCRATCH>  wave/read  the pieces of the read before mutate_homo, forward strand, into the scratch buffer
 //                                                (FASTQ: every base carries its quality class in bits 3 / 5)
-//   k_hp_events                       wave/read  runs >= k of the scratch segments -> new run lengths, mismatches -> an edit list per
+//   k_hp_scan, k_hp_drain             wave/read  runs >= k of the scratch segments -> new run lengths, mismatches -> an edit list per
 //                                                piece; final lengths, final length check (S:1429): a failing read bumps its attempt
 //                                                state and the batch is re-run
 //   k_materialise<., MAT_HP_FINAL>    wave/read  scratch + edit list -> the record (qualities drawn here, strand, T -> U)

@@ -641,7 +641,7 @@ __device__ __forceinline__ void qual_lut_load(uint16_t *lds, const DevModel &m, 
 }
 
 // One piece of a read.  Per tile of <= T_OUT output bases whose 16-byte chunks are ALIGNED in the destination:
-//   1. lane l holds event jb + l (prefetched) and its letter word (k_words / k_hp_events); the events that start inside the tile are a
+//   1. lane l holds event jb + l (prefetched) and its letter word (k_words / k_hp_drain); the events that start inside the tile are a
 //      prefix of the lanes; they are staged into LDS for the other lanes;
 //   2. lane per event: the substituted / inserted letters (mutate_read, S:1965-1995) are written into an LDS payload tile at
 //      their output offsets, with a byte mask; FASTQ: the letters carry their quality class in bits 3 / 5;
@@ -652,7 +652,7 @@ __device__ __forceinline__ void qual_lut_load(uint16_t *lds, const DevModel &m, 
 //   4. FASTQ: qual_draws16 + qual_lookup16; complement/reverse in registers (S:1433-1435, 1675-1680), one aligned 16-byte store.
 // A tile whose reference span straddles the origin of a circular chromosome goes to the slow-tile queue.
 // MAT_HP_FINAL: the source is the pre-homopolymer piece in the scratch buffer (its bytes carry the class bits), the events are the
-// homopolymer edits (k_hp_events): a substitution is one base whose word picks the new base with its first base-3 digit and, with
+// homopolymer edits (k_hp_drain): a substitution is one base whose word picks the new base with its first base-3 digit and, with
 // bit 0 set, takes the 'mis' class (first mismatch of its run, S:697-700; otherwise the class of the base it replaces); an
 // insertion has <= 15 letters, all of class 'ins' except letter 0 when bit 31 of the word is set.
 template <bool FASTQ, int MODE>
