@@ -1018,6 +1018,9 @@ __global__ void __launch_bounds__(64 * NS_WPB) k_hp_scan(GenArgs A, uint2 *__res
 #endif
 __global__ void __launch_bounds__(64 * NS_WPB, NS_HPD_WAVES) k_hp_drain(GenArgs A, const uint2 *__restrict__ runs, const uint32_t *__restrict__ n_runs,
                                                                        uint64_t *__restrict__ hp_final) {
+    struct DrainLds { uint32_t pos[2][64], tl[2][64], wd[2][64]; };
+    __shared__ DrainLds drain_lds[NS_WPB];
+    DrainLds &S = drain_lds[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= A.prm.n_reads) return;
@@ -1048,19 +1051,37 @@ __global__ void __launch_bounds__(64 * NS_WPB, NS_HPD_WAVES) k_hp_drain(GenArgs 
                 const bool on = j < n_list;
                 uint32_t s0 = 0, L = 0, base = 'A', size = 0, ne = 0, slot = 0, sh = 0, d_incl = 0, ne_incl = 0;
                 if (on) { const uint2 rn = src[j]; s0 = rn.x; L = rn.y >> 8; base = rn.y & 0xffu; size = hp_new_size(A.m, key, sid, a, s0, L, base); }
-                for (uint32_t pass = 0; pass < 2; ++pass) {                 // 0: count the run's events, 1: file them
-                    if (on && (pass == 0 || slot + ne <= cap))
-                        ne = hp_run_events(A.m.hp_mis_rate, key, sid, a, s0, L, size, base, [&](uint32_t pos, uint32_t ty, uint32_t len, uint32_t word) {
-                            if (!pass) return;
+                // the run's edits: evaluated once — the first two (all that all but a few runs in a thousand have) wait in the lane's LDS
+                // slots while wavefront prefix sums give the event slots and shifts — then filed; a run with more is evaluated again
+                if (on) {
+                    uint32_t seen = 0;
+                    ne = hp_run_events(A.m.hp_mis_rate, key, sid, a, s0, L, size, base, [&](uint32_t pos, uint32_t ty, uint32_t len, uint32_t word) {
+                        if (seen < 2u) { S.pos[seen][lane] = pos; S.tl[seen][lane] = ty << 12 | len; S.wd[seen][lane] = word; }
+                        ++seen;
+                    });
+                }
+                {
+                    const uint32_t d = on ? size - L : 0u;                   // (mod 2^32)
+                    ne_incl = wave_incl_scan(ne); d_incl = wave_incl_scan(d);
+                    slot = n_ev + ne_incl - ne; sh = shift + d_incl - d;
+                }
+                if (on && ne && slot + ne <= cap) {
+                    if (ne <= 2u) {
+                        const uint32_t tl0 = S.tl[0][lane];
+                        ns_event e; e.pos = S.pos[0][lane]; e.info = ns_ev_pack(tl0 & 0xfffu, tl0 >> 12, (int32_t)sh);
+                        ev[slot] = e; wd[slot] = S.wd[0][lane];
+                        if (ne == 2u) {
+                            const uint32_t ty0 = tl0 >> 12, l0 = tl0 & 0xfffu, tl1 = S.tl[1][lane];
+                            const uint32_t sh1 = ty0 == NS_INS ? sh + l0 : ty0 == NS_DEL ? sh - l0 : sh;
+                            e.pos = S.pos[1][lane]; e.info = ns_ev_pack(tl1 & 0xfffu, tl1 >> 12, (int32_t)sh1);
+                            ev[slot + 1] = e; wd[slot + 1] = S.wd[1][lane];
+                        }
+                    } else
+                        hp_run_events(A.m.hp_mis_rate, key, sid, a, s0, L, size, base, [&](uint32_t pos, uint32_t ty, uint32_t len, uint32_t word) {
                             ns_event e; e.pos = pos; e.info = ns_ev_pack(len, ty, (int32_t)sh);
                             ev[slot] = e; wd[slot] = word; ++slot;
                             if (ty == NS_INS) sh += len; else if (ty == NS_DEL) sh -= len;
                         });
-                    if (!pass) {
-                        const uint32_t d = on ? size - L : 0u;               // (mod 2^32)
-                        ne_incl = wave_incl_scan(ne); d_incl = wave_incl_scan(d);
-                        slot = n_ev + ne_incl - ne; sh = shift + d_incl - d;
-                    }
                 }
                 n_ev += (uint32_t)__builtin_amdgcn_readlane((int)ne_incl, 63);
                 shift += (uint32_t)__builtin_amdgcn_readlane((int)d_incl, 63);
