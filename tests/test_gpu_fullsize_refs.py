@@ -72,6 +72,20 @@ def test_chr1_like_fastq_homopolymer_2m_reads(hg002_model):
                 ra = eng.generate(E.make_params(first_read=n, n_reads=h, **kw)).records()
                 assert checksum(ra) == checksum(rec[:int(reads["rec_off"][h])])
         assert sums[0] != sums[1]
+        # the unaligned reads of the same run (S:1482-1549: the dense record kernel), 10^5 of them behind the aligned ones
+        nu = 100_000
+        ku = dict(seed=SEED + 3, fastq=True, kind=E.NS_KIND_UNALIGNED, max_len=ref.max_chrom)
+        b = eng.generate(E.make_params(first_read=2 * n, n_reads=nu, **ku))
+        reads, pieces = b.reads(), b.pieces()
+        assert np.all(reads["flags"] == 0) and np.all(reads["n_pieces"] == 1) and np.all(pieces["kind"] == 1)
+        assert np.all(pieces["pos"].astype(np.int64) + pieces["ref_len"] <= synth.CHR1_LEN)
+        assert np.array_equal(reads["seq_len"], pieces["out_len"]) and int(b.info.total_bases) == int(reads["seq_len"].astype(np.int64).sum())
+        rec = b.records()
+        _fastq_structure(rec, reads)
+        longest = int(np.argmax(reads["seq_len"]))
+        for r in sorted({0, nu - 1, longest} | set(int(x) for x in np.random.default_rng(5).integers(0, nu, 6))):
+            exp = O.generate(mdl, ref, E.make_params(first_read=2 * n + r, n_reads=1, **ku), bytes_per_read=2_000_000, events_per_read=600_000)
+            assert _record_slice(eng, b, reads, r, nu) == exp["records"].tobytes(), ("unaligned", r)
     finally:
         eng.close()
 
