@@ -1,4 +1,4 @@
 #!/bin/bash
-# k_materialise time per ablated phase (NS_DEBUG_SKIP bits: 1 phase A, 2 payload pass, 8 head/tail, 16 the 16-byte stores,
-# 32 payload byte stores).  Profiling aid only: results are wrong when a bit is set.
-for d in ${@:-0 2 8 10 16 32 31}; do echo -n "skip=$d "; NS_DEBUG_SKIP=$d timeout 60 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['kernel_ms']['k_materialise'],2))"; done
+# k_materialise time per ablated phase (NS_DEBUG_SKIP bits: 1 the copy loop, 2 the letters, 8 head/tail, 16 the 16-byte stores,
+# 64 no quality table look-ups, 128 no quality Philox, 256 no qualities).  Profiling aid only: results are wrong when a bit is set.
+for d in ${@:-0 1 2 8 16}; do echo -n "skip=$d "; NS_DEBUG_SKIP=$d timeout 60 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['kernel_ms']['k_materialise'],2))"; done

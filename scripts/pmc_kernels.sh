@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-read PMC counters of the record-writing kernels (k_materialise, k_payload), 200k-read launch.
+# per-read PMC counters of the record-writing kernels (k_materialise*, k_hp_*), 200k-read launch.
 # usage: pmc_kernels.sh "<counter list>" [NS_DEBUG_SKIP] [extra bench.py arguments, e.g. "--kmer-bias 5 --fastq"]
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmck
 mkdir -p $O; cd /tmp; export TMPDIR=/tmp
