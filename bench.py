@@ -166,6 +166,8 @@ def main():
     # the unaligned worker call of a step runs next to the aligned one on its own engine context (own HIP streams and buffers on the
     # same GPU, own host thread) — the way the reference runs its workers side by side (-t, S:1588-1605)
     eng_un = None if (a.aligned_only or a.serial) else engine.Engine(local_rank)
+    if eng_un is not None:
+        eng_un.set_background(True)     # its kernels share the GPU with the aligned call's: few issue slots matter more than a short latency
     engs = [e for e in (eng, eng_un) if e is not None]
     if world > 1:
         # the reference lives on rank 0; ONE broadcast over xGMI puts it in every GPU's HBM
@@ -266,7 +268,7 @@ def main():
                                       "formatted by k_errlog only when asked for (--errlog; the CLI always asks): it is a file-format stage "
                                       "behind the path the metric names (SURVEY section 8 f-1)",
                        "seed": SEED, "parallelism": "read-index sharding x%d, 1 RCCL broadcast of the reference" % world, "engines_per_gpu": len(engs),
-                       "engines_note": "aligned and unaligned worker call of a step run side by side on two engine contexts of the GPU (--serial: one after the other on one)"},
+                       "engines_note": "aligned and unaligned worker call of a step run side by side on two engine contexts of the GPU, the unaligned one as a background context (ns_set_background); --serial: one after the other on one"},
             "device_ms_per_step": device_ms,
             "aligned_batch": {"reads": n_al, "device_ms": float(np.mean([x.ms_total for x in al])),
                               "reads_per_s_device": n_al / (float(np.mean([x.ms_total for x in al])) * 1e-3), "kernel_ms": kms},

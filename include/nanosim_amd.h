@@ -219,6 +219,12 @@ int ns_create(int device, ns_ctx **out);
 void ns_destroy(ns_ctx *ctx);
 const char *ns_last_error(const ns_ctx *ctx);
 uint32_t ns_abi_version(void);
+/* A context whose worker calls run NEXT TO another context's on the same GPU (the reference runs its workers side by side, -t,
+ * S:1588-1605; bench.py runs the unaligned worker call of a step like that): with on != 0 the engine prefers kernels that
+ * take few issue slots over kernels with a short latency — only the longest eighth of a batch of unaligned reads goes through
+ * the wave-per-read error list, the rest through the thread-per-read one (six times fewer instructions, several times the latency).
+ * The reads are the same either way. */
+int ns_set_background(ns_ctx *ctx, int on);
 
 /* reference genome: replaces seq_dict/seq_len/genome_len (src/simulator.py:279-353).  `bases` is the
  * concatenation of all chromosomes as read from the FASTA (any case, IUPAC allowed); chrom_off has

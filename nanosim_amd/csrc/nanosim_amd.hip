@@ -1266,6 +1266,7 @@ struct ns_ctx {
     uint64_t ref_nbases = 0;
     uint32_t dbg = 0;          // NS_DEBUG_SKIP: phase-ablation bits for profiling only (results are wrong when set)
     uint32_t coop_min = 16384, coop_shift = 9;   // cooperative chain for the longest n>>shift reads of batches >= min (env: NS_COOP_MIN, NS_COOP_SHIFT)
+    uint32_t ucoop_shift = 0;                    // unaligned reads: the longest n>>shift of a batch take the wave-per-read list, the rest the thread-per-read one (env: NS_UCOOP_SHIFT; 0: all)
     // planning + result buffers
     DevBuf l_cap, l_off;
     DevBuf n_pieces, piece_off, ev_cap, ev_off, rec_len, rec_off, err_len, err_off, name_len;
@@ -1367,6 +1368,13 @@ extern "C" {
 
 uint32_t ns_abi_version(void) { return NS_ABI_VERSION; }
 
+int ns_set_background(ns_ctx *ctx, int on) {
+    if (!ctx) return NS_EINVAL;
+    ctx->ucoop_shift = on ? 3u : 0u;
+    if (const char *d = getenv("NS_UCOOP_SHIFT")) ctx->ucoop_shift = (uint32_t)atoi(d) & 31u;
+    return NS_OK;
+}
+
 int ns_create(int device, ns_ctx **out) {
     if (!out) return NS_EINVAL;
     *out = nullptr;
@@ -1394,6 +1402,7 @@ int ns_create(int device, ns_ctx **out) {
     if (const char *d = getenv("NS_DEBUG_SKIP")) ctx->dbg = (uint32_t)atoi(d);
     if (const char *d = getenv("NS_COOP_MIN")) ctx->coop_min = (uint32_t)atoi(d);
     if (const char *d = getenv("NS_COOP_SHIFT")) ctx->coop_shift = (uint32_t)atoi(d) & 31u;
+    if (const char *d = getenv("NS_UCOOP_SHIFT")) ctx->ucoop_shift = (uint32_t)atoi(d) & 31u;
     *out = ctx;
     return NS_OK;
 }
@@ -2354,7 +2363,8 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
             }
             HIPCHK(hipEventRecord(ctx->evt[3], st));
             uint32_t n_coop = 0;
-            if (prm->kind == NS_KIND_UNALIGNED) n_coop = cur_n;          // every unaligned read: its loop is a prefix sum (coop_unaligned_error_list)
+            if (prm->kind == NS_KIND_UNALIGNED)                           // its loop is a prefix sum (coop_unaligned_error_list); pass 0 visits the reads longest first
+                n_coop = (a == 0 && lds && cur_n >= ctx->coop_min) ? std::max(cur_n >> ctx->ucoop_shift, 1u) : cur_n;
             else if (a == 0 && ctx->coop_ok && prm->kind == NS_KIND_ALIGNED && cur_n >= ctx->coop_min) n_coop = cur_n >> ctx->coop_shift;   // longest 0.2 %
             if (n_coop) {      // wave-per-read for the head of the (length-sorted) list, thread-per-read for the rest
                 GenArgs B = A; B.list_n = n_coop;

@@ -22,7 +22,7 @@ KERNEL_NAMES = ("plan(k_nseg+k_lengths+scan+sort)", "k_chain", "k_names", "k_mat
 EXPORTS = ("ns_abi_version", "ns_create", "ns_destroy", "ns_last_error", "ns_set_reference",
            "ns_set_reference_device", "ns_load_model", "ns_generate", "ns_copy_out", "ns_device_ptr",
            "ns_set_species", "ns_set_abundance", "ns_species_bases", "ns_host_alloc", "ns_host_free",
-           "ns_set_transcriptome", "ns_set_intron_retention")
+           "ns_set_transcriptome", "ns_set_intron_retention", "ns_set_background")
 
 _lib = None
 
@@ -64,6 +64,8 @@ def load_library(path: str = LIB_PATH):
     L.ns_set_species.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     L.ns_set_abundance.restype = C.c_int
     L.ns_set_abundance.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ns_set_background.restype = C.c_int
+    L.ns_set_background.argtypes = [C.c_void_p, C.c_int]
     L.ns_species_bases.restype = C.c_int
     L.ns_species_bases.argtypes = [C.c_void_p, C.c_void_p]
     L.ns_set_transcriptome.restype = C.c_int
@@ -140,6 +142,10 @@ class Engine:
             raise EngineError("ns_create(device=%d) failed with %d (no MI355X visible?)" % (device, rc))
         self._keep = []
         self._pinned = []
+
+    def set_background(self, on: bool = True):
+        """this context's worker calls run next to another context's on the same GPU (ns_set_background)"""
+        self._check(self.L.ns_set_background(self.ctx, 1 if on else 0))
 
     def close(self):
         if self.ctx:

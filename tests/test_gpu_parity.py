@@ -190,6 +190,23 @@ def test_cooperative_chain_equals_oracle(small_model, small_ref, monkeypatch):
         e.close()
 
 
+def test_background_context_gives_the_same_unaligned_reads(small_model, small_ref, circ_ref, monkeypatch):
+    """ns_set_background: all but the longest eighth of a batch of unaligned reads take the thread-per-read error list instead of
+    the wave-per-read one — same reads, byte for byte"""
+    monkeypatch.setenv("NS_COOP_MIN", "1")
+    for ref in (small_ref, circ_ref):
+        e = E.Engine(0)
+        try:
+            e.set_background(True)
+            e.set_reference(ref)
+            e.load_model(small_model)
+            for kw in (dict(n_reads=700, fastq=True), dict(n_reads=300, median_len=7000, sd_len=0.6), dict(n_reads=400, min_len=500, max_len=4000)):
+                p = E.make_params(seed=2718, first_read=3, kind=E.NS_KIND_UNALIGNED, **{**dict(max_len=ref.max_chrom), **kw})
+                compare(e.generate(p), O.generate(small_model, ref, p, bytes_per_read=200000, events_per_read=40000), p)
+        finally:
+            e.close()
+
+
 def test_large_tables_take_the_global_memory_path(tmp_path, small_ref, monkeypatch):
     """A model shaped like a real trained one (15 previous-match bins, 1500-row ECDFs): the chain tables (~360 KB) do not
     fit the LDS budget, so k_chain reads them from global memory; the cooperative chain is forced on as well."""
