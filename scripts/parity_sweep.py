@@ -27,6 +27,7 @@ MODES = [
     ("circular chimeric fastq", "circ", dict(fastq=True, chimeric=True)),
     ("circular unaligned", "circ", dict(kind=E.NS_KIND_UNALIGNED)),
     ("narrow window", "lin", dict(min_len=3000, max_len=9000, fastq=True)),
+    ("unaligned, background ctx", "lin", dict(kind=E.NS_KIND_UNALIGNED, fastq=True, median_len=3000, sd_len=0.7, _background=True)),
 ]
 _CTX = {}
 
@@ -54,7 +55,7 @@ def oracle_chunk(args):
     mdl, refs = _CTX["mdl"], _CTX["refs"]
     ref = refs[refk]
     p = E.make_params(seed=0xC0FFEE + mode_i, first_read=first, n_reads=CHUNK, max_len=kw.get("max_len", ref.max_chrom),
-                      **{k: v for k, v in kw.items() if k != "max_len"})
+                      **{k: v for k, v in kw.items() if k != "max_len" and not k.startswith("_")})
     return digest(O.generate(mdl, ref, p, bytes_per_read=120000, events_per_read=24000))
 
 
@@ -72,16 +73,21 @@ def main():
         got = {}
         for refk in ("lin", "circ"):
             eng = E.Engine(0); eng.set_reference(refs[refk]); eng.load_model(mdl)
+            os.environ["NS_COOP_MIN"] = "1"            # (read at ns_create: the background context routes small batches too)
+            eng_bg = E.Engine(0); eng_bg.set_background(True); eng_bg.set_reference(refs[refk]); eng_bg.load_model(mdl)
+            os.environ.pop("NS_COOP_MIN")
+            fg = eng
             for mi, (name, rk, kw) in enumerate(MODES):
                 if rk != refk:
                     continue
+                eng = eng_bg if kw.get("_background") else fg
                 for f in range(0, n, CHUNK):
                     p = E.make_params(seed=0xC0FFEE + mi, first_read=f, n_reads=CHUNK, max_len=kw.get("max_len", refs[rk].max_chrom),
-                                      **{k: v for k, v in kw.items() if k != "max_len"})
+                                      **{k: v for k, v in kw.items() if k != "max_len" and not k.startswith("_")})
                     b = eng.generate(p)
                     got[(mi, f)] = digest(dict(records=b.records(), errlog=b.errlog() if p.emit_errlog else np.zeros(0, np.uint8),
                                                reads=b.reads(), pieces=b.pieces(), events=b.events()))
-            eng.close()
+            fg.close(); eng_bg.close()
         exp = dict(zip(jobs, res.get()))
     bad = [k for k in jobs if got[k] != exp[k]]
     for mi, (name, _, _) in enumerate(MODES):
