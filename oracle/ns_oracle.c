@@ -237,7 +237,7 @@ void nso_error_list(const ns_model_tables *t, int64_t m_ref, int fastq, nso_draw
     uint32_t it = 1;
     int64_t last_ins_pos = -1;          /* collision of two insertions on key pos-0.5 (S:1882) */
     while (pos < middle_ref) {                                                             /* S:1858 */
-        double p_err, p_mix = 0, p_len = 0, p_match;
+        double p_err, p_mix = 0, p_len = 0, p_match = 0;
         if (!d->mode) {
             philox_at(d, ST_EVENT, seg, attempt, it, 0, w);
             p_err = u32_to_p(w[0]); p_mix = u32_to_p(w[1]); p_len = u32_to_p(w[2]); p_match = u32_to_p(w[3]);
