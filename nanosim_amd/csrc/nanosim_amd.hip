@@ -1265,7 +1265,8 @@ struct ns_ctx {
     double cap_rate = 0.1;
     uint64_t ref_nbases = 0;
     uint32_t dbg = 0;          // NS_DEBUG_SKIP: phase-ablation bits for profiling only (results are wrong when set)
-    uint32_t coop_min = 16384, coop_shift = 9;   // cooperative chain for the longest n>>shift reads of batches >= min (env: NS_COOP_MIN, NS_COOP_SHIFT)
+    uint32_t coop_min = 16384, coop_shift = 10;  // cooperative chain for the longest n>>shift reads of batches >= min (env: NS_COOP_MIN, NS_COOP_SHIFT);
+                                                 // 10^6 reads, chain ms at shift 9 / 10 / 11 / 12: 4.18 / 3.63 / 3.90 / 4.32
     uint32_t ucoop_shift = 0;                    // unaligned reads: the longest n>>shift of a batch take the wave-per-read list, the rest the thread-per-read one (env: NS_UCOOP_SHIFT; 0: all)
     // planning + result buffers
     DevBuf l_cap, l_off;
@@ -2365,7 +2366,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
             uint32_t n_coop = 0;
             if (prm->kind == NS_KIND_UNALIGNED)                           // its loop is a prefix sum (coop_unaligned_error_list); pass 0 visits the reads longest first
                 n_coop = (a == 0 && lds && cur_n >= ctx->coop_min) ? std::max(cur_n >> ctx->ucoop_shift, 1u) : cur_n;
-            else if (a == 0 && ctx->coop_ok && prm->kind == NS_KIND_ALIGNED && cur_n >= ctx->coop_min) n_coop = cur_n >> ctx->coop_shift;   // longest 0.2 %
+            else if (a == 0 && ctx->coop_ok && prm->kind == NS_KIND_ALIGNED && cur_n >= ctx->coop_min) n_coop = cur_n >> ctx->coop_shift;   // longest 0.1 %
             if (n_coop) {      // wave-per-read for the head of the (length-sorted) list, thread-per-read for the rest
                 GenArgs B = A; B.list_n = n_coop;
                 HIPCHK(hipEventRecord(ctx->ev_fork, st));
