@@ -784,9 +784,10 @@ typedef struct nso_trx {             /* expression view of the reference transcr
 } nso_trx;
 
 /* ---- intron retention ---------------------------------------------------------------------------
- * PARITY: nso_ir_states is pinned against the reference's update_structure (tests/golden/reference_ir.json); nso_extract_read_pos
- * and the splice below are restated from S:148-191 / S:1159-1178 but UNPINNED: the reference's code for them runs through HTSeq
- * and pysam, which this image lacks. */
+ * PARITY: nso_ir_states is pinned against the reference's update_structure and nso_extract_read_pos against its extract_read_pos
+ * (tests/golden/reference_ir.json: 400 + 496 recorded calls; HTSeq.GenomicInterval, which extract_read_pos only constructs, is a
+ * four-field record in the fixture generator).  The splice below is restated from S:1159-1178 but UNPINNED: the reference fetches
+ * the intervals through pysam, which this image lacks. */
 
 /* update_structure (S:114-145): u[k] is the random.random() of intron k; retained[k] = 1 for "IR".  Returns flag_ir.
  * (A p beyond both intervals of the row — its two probabilities summing to less than 1 — appends nothing in the reference, which

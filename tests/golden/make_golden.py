@@ -30,9 +30,19 @@ SMALL_SPEC = dict(n_train=2000, seed=7)
 GENOME_SEED = 11
 
 
+class _GenomicIntervalRecord:
+    """What the hot path uses of HTSeq.GenomicInterval: extract_read_pos constructs it from (chrom, start, end, strand) (S:178) and the
+    worker reads those four attributes back (S:1162-1174).  A record with the same constructor lets the reference's own
+    extract_read_pos run here (HTSeq itself is not in the image)."""
+    def __init__(self, chrom, start, end, strand):
+        self.chrom, self.start, self.end, self.strand = chrom, start, end, strand
+
+
 def import_reference():
     for m in ("HTSeq", "pysam", "piecewise_regression"):
         sys.modules.setdefault(m, types.ModuleType(m))
+    if not hasattr(sys.modules["HTSeq"], "GenomicInterval"):
+        sys.modules["HTSeq"].GenomicInterval = _GenomicIntervalRecord
     sys.dont_write_bytecode = True
     if REF_SRC not in sys.path:
         sys.path.insert(0, REF_SRC)
@@ -595,8 +605,10 @@ def build_ir_inputs():
 def fixture_ir(S):
     """update_structure / ref_len_from_structure (S:100-145) pinned by value.  The structures are read with the repo's GFF3 reader
     (the reference reads them through HTSeq, which this image lacks) and handed over in the reference's tuple layout
-    (type, chrom, start, end, length, strand); IR_markov_model is laid out as S:414-422 builds it.  extract_read_pos (S:148-191)
-    constructs HTSeq.GenomicInterval objects and is therefore NOT run here."""
+    (type, chrom, start, end, length, strand); IR_markov_model is laid out as S:414-422 builds it.  extract_read_pos (S:148-191) runs on
+    the structures update_structure returned, with random.randint on tape and HTSeq.GenomicInterval replaced by a four-field record
+    (_GenomicIntervalRecord): `extract` lists, per case, the calls made (aligned length, polyA flag, uniform behind the randint) and what
+    came back (intervals, retain_polya, ir_list)."""
     import random as pyrandom
     from nanosim_amd import intron_retention as IR
     structure = IR.read_structure(IR_PREFIX + "_added_intron_final.gff3")
@@ -610,6 +622,7 @@ def fixture_ir(S):
     tids = sorted(structure.keys())
     cases = []
     real = pyrandom.random
+    real_randint = pyrandom.randint
     try:
         for ci in range(400):
             tid = tids[int(rng.integers(0, len(tids)))]
@@ -621,10 +634,34 @@ def fixture_ir(S):
             it = iter(tape)
             pyrandom.random = lambda: next(it)
             flag, new = S.update_structure(items, model)
+            exon_len = int(S.ref_len_from_structure(items))
+            extract = []
+            if flag:                                        # S:1157-1160: extract_read_pos(middle_ref, ref_trx_len, structure_new, trx_has_polya)
+                len_before, ret_total = 0, sum(x[4] for x in new if x[0] == "retained_intron")
+                for x in new:
+                    if x[0] == "exon":
+                        len_before += x[4]
+                    elif x[0] == "retained_intron":
+                        break
+                for k in range(4):
+                    length = int(rng.integers(1, exon_len + 1)) if k else exon_len          # (middle_ref <= ref_trx_len, S:1143-1144)
+                    polya = bool(rng.integers(0, 2))
+                    u = float(rng.random()) if (ci + k) % 5 else [0.0, 0.9999999999999999][k % 2]
+                    if k == 3:                              # a read that starts late enough to reach the 3' end through the retained introns
+                        s_ = min(len_before, ret_total + int(rng.integers(0, 12)) - 6, exon_len - 1)
+                        if s_ < 0:
+                            continue
+                        length, polya, u = exon_len - s_, True, 0.9999999999999999
+                    pyrandom.randint = lambda a_, b_, u=u: a_ + min(int(u * (b_ - a_ + 1)), b_ - a_)
+                    ivs, retain_polya, ir_list = S.extract_read_pos(length, exon_len, new, polya)
+                    extract.append(dict(length=length, polya=polya, u=u, retain_polya=bool(retain_polya),
+                                        intervals=[[str(iv.chrom), int(iv.start), int(iv.end), str(iv.strand)] for iv in ivs],
+                                        ir_list=[[int(a_), int(b_)] for a_, b_ in ir_list]))
             cases.append(dict(tid=tid, u=tape, flag=bool(flag), retained=[1 if x[0] == "retained_intron" else 0 for x in new if x[0] != "exon"],
-                              exon_len=int(S.ref_len_from_structure(items))))
+                              exon_len=exon_len, extract=extract))
     finally:
         pyrandom.random = real
+        pyrandom.randint = real_randint
     return dict(cases=cases)
 
 

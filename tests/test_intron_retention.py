@@ -114,6 +114,49 @@ def test_ir_states_match_update_structure(fx, trx_ref, ir):
     assert n_flag > 50
 
 
+def test_extract_read_pos_matches_the_reference(fx, trx_ref, ir):
+    """nso_extract_read_pos == extract_read_pos of the reference (S:148-191) on the structures update_structure returned: the same
+    intervals (chromosome, start, end, strand), the same retain_polya flag, the same list of retained-intron stretches, for the
+    recorded aligned length, polyA flag and the uniform behind random.randint (make_golden.py, fixture_ir)"""
+    import ctypes as C
+
+    class Iv(C.Structure):
+        _fields_ = [("chrom", C.c_uint32), ("start", C.c_uint32), ("end", C.c_uint32), ("retained", C.c_uint8), ("minus", C.c_uint8)]
+
+    L = O.lib()
+    L.nso_extract_read_pos.restype = C.c_int
+    L.nso_extract_read_pos.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
+    t = ir.to_c()
+    flag_chrom = any("chr" in nm for nm in ir.genome.names)
+    n_calls = n_multi = n_polya = 0
+    for c in fx["cases"]:
+        if not c["extract"] or c["tid"] not in trx_ref.ref.names:
+            continue
+        trx = trx_ref.ref.names.index(c["tid"])
+        ret = np.array(c["retained"] + [0], dtype=np.uint8)
+        for e in c["extract"]:
+            iv = (Iv * 64)()
+            rp = C.c_int(0)
+            n = L.nso_extract_read_pos(C.addressof(t), trx, ret.ctypes.data, e["length"], c["exon_len"], e["u"], int(e["polya"]), iv, 64, C.byref(rp))
+            assert n == len(e["intervals"]), (c["tid"], e)
+            got = []
+            for k in range(n):
+                if iv[k].chrom == IR.NS_IR_NO_CHROM:                             # a chromosome the genome FASTA lacks (the worker skips the read, S:1167-1169)
+                    name = e["intervals"][k][0]
+                    assert name not in ir.genome.names and "chr" + name not in ir.genome.names
+                else:
+                    name = ir.genome.names[iv[k].chrom]
+                    if flag_chrom and name.startswith("chr"):
+                        name = name[3:]                                        # (the structure holds the name without the prefix, S:448-449)
+                got.append([name, int(iv[k].start), int(iv[k].end), "-" if iv[k].minus else "+"])
+            assert got == e["intervals"], (c["tid"], e, got)
+            assert bool(rp.value) == e["retain_polya"], (c["tid"], e)
+            assert [[int(iv[k].start), int(iv[k].end)] for k in range(n) if iv[k].retained] == e["ir_list"], (c["tid"], e)
+            n_calls += 1; n_multi += n > 1; n_polya += e["retain_polya"]
+    # (retain_polya is False throughout: a read with a retained intron ends that intron's length short of the 3' end, S:186-189)
+    assert n_calls > 350 and n_multi > 300 and n_polya == sum(e["retain_polya"] for c in fx["cases"] for e in c["extract"])
+
+
 NAME = re.compile(r"^[>@](?P<trx>[^_]+)_(?P<pos>\d+)_aligned_(?P<idx>\d+)(?:_RetainedIntron_(?P<ir>[0-9;-]+))?_(?P<strand>[RF])_(?P<head>\d+)_(?P<mid>\d+)_(?P<tail>\d+)$")
 
 
