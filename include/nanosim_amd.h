@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define NS_ABI_VERSION 3u
+#define NS_ABI_VERSION 4u
 
 /* error codes */
 #define NS_OK 0
@@ -30,6 +30,7 @@ extern "C" {
 #define NS_ENOMEM (-3)   /* device or host allocation failed */
 #define NS_EHIP (-4)     /* HIP runtime error (see ns_last_error) */
 #define NS_ESTATE (-5)   /* call order violated (no model / no reference / no batch) */
+#define NS_EIO (-6)      /* a file write of an output sink failed (ENOSPC, EBADF ...; see ns_last_error) */
 
 /* ---- model tables: the flat form of the globals read_profile() fills (src/simulator.py:247-251) ---- */
 
@@ -280,7 +281,8 @@ int ns_set_intron_retention(ns_ctx *ctx, const ns_ir_tables *tables);
 int ns_load_model(ns_ctx *ctx, const ns_model_tables *tables);
 
 /* the hot path: replaces one worker call simulation_aligned_genome / simulation_unaligned
- * (src/simulator.py:1266-1454, 1482-1549).  Results stay in HBM until the next ns_generate. */
+ * (src/simulator.py:1266-1454, 1482-1549).  Results stay in HBM until the next ns_generate; the record and error-profile images
+ * live in one of TWO result slots, so that a batch queued with ns_sink_write leaves the device while the next one is generated. */
 int ns_generate(ns_ctx *ctx, const ns_params *params, ns_batch_info *info);
 
 /* copy a result buffer of the last batch to host memory; nbytes must not exceed the buffer size
@@ -290,6 +292,32 @@ int ns_copy_out(ns_ctx *ctx, int which, void *host_dst, uint64_t offset, uint64_
  * 2006-2008, become DMA transfers at PCIe rate into such a buffer followed by plain file writes).  Owned by the caller. */
 int ns_host_alloc(ns_ctx *ctx, uint64_t nbytes, void **out);
 int ns_host_free(ns_ctx *ctx, void *p);
+
+/* ---- output sinks: the worker's out_reads.write(...) / out_error.write(...) (src/simulator.py:1437-1443, 2006-2008) ----------------
+ * A sink is an open file (descriptor owned by the caller) that the library appends result buffers to: ns_sink_write queues the record
+ * image (NS_BUF_RECORDS) or the error-profile image (NS_BUF_ERRLOG) of the LAST batch and returns at once.  The bytes travel in
+ * slices over the context's copy stream (DMA, concurrent with the kernels of the next ns_generate) into page-locked staging memory
+ * and from there to the file with pwrite() at their final offsets, on the library's writer threads.  The next ns_generate fills the
+ * other result slot; the one after it waits until the queued copies have left the device.  fd < 0: the bytes are copied to the host
+ * and dropped.  ns_sink_put appends host bytes (the header line of the error profile, S:1634) in order with the queued buffers.
+ * ns_sink_drain waits until everything queued is in the file and reports the first write error (NS_EIO); file_off (optional)
+ * receives the offset behind the last byte.  Tuning (environment, read by the first ns_sink_open of a context): NS_IO_SLICE_MB
+ * (16), NS_IO_SLICES (16), NS_IO_THREADS (8). */
+typedef struct ns_sink ns_sink;
+int ns_sink_open(ns_ctx *ctx, int fd, uint64_t file_off, ns_sink **out);
+int ns_sink_put(ns_ctx *ctx, ns_sink *sink, const void *host_src, uint64_t nbytes);
+int ns_sink_write(ns_ctx *ctx, ns_sink *sink, int which);
+int ns_sink_drain(ns_ctx *ctx, ns_sink *sink, uint64_t *file_off);
+int ns_sink_close(ns_ctx *ctx, ns_sink *sink);
+typedef struct ns_io_stats {
+    uint64_t bytes;          /* bytes copied device -> host through the sinks of this context */
+    double dma_ms;           /* sum of the slices' copy durations (HIP events on the copy stream): bytes / dma_ms = the DMA rate */
+    double wait_staging_s;   /* time the copier waited for a free staging slice (the file writes are the limit when this is large) */
+    double write_s;          /* sum of the writer threads' time in pwrite() */
+    uint64_t slice_bytes;
+    uint32_t n_slices, n_threads;
+} ns_io_stats;
+int ns_io_counters(ns_ctx *ctx, ns_io_stats *out, int reset);
 
 /* device address of a result buffer (for zero-copy consumers such as torch / RCCL); NULL if absent */
 const void *ns_device_ptr(ns_ctx *ctx, int which);

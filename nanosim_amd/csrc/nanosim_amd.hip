@@ -30,6 +30,7 @@
 #include "ns_chain.h"
 #include "ns_hp.h"
 #include "ns_ir.h"
+#include "ns_io.h"
 
 // Reads per workgroup of the wave-per-read kernels.  One: read lengths vary by an order of magnitude inside a batch, and a wavefront
 // that is done cannot leave before the longest read of its workgroup is.
@@ -1271,7 +1272,11 @@ struct ns_ctx {
     // planning + result buffers
     DevBuf l_cap, l_off;
     DevBuf n_pieces, piece_off, ev_cap, ev_off, rec_len, rec_off, err_len, err_off, name_len;
-    DevBuf reads, pieces, events, records, errlog, stats, scan_tmp;
+    DevBuf reads, pieces, events, stats, scan_tmp;
+    DevBuf rec_slot[2], err_slot[2];   // two result slots: the record / error-profile images of the last batch and of the one before (ns_io.h)
+    int slot = 0;                      // slot of the last batch
+    IoEngine *io = nullptr;            // copy stream, staging slices, writer threads (created by the first ns_sink_open)
+    std::vector<ns_sink *> sinks;
     DevBuf sort_key, sort_idx, sort_key_out, order, list_b, list_c, rstate, att_base, scr, scr_len, scr_off, hp_len, hp_nev, hp_ev, hp_wd, hp_runs, hp_nrun, slow_q, ev_word;
     uint32_t hp_shift = 5, hp_pad = 64, hp_cap_k = 0;       // -k: event capacity of a piece (hp_ev_slot), planned for kmer_bias hp_cap_k
     // metagenome: species view of the reference, abundances of the sample, per-pass scratch
@@ -1429,6 +1434,9 @@ static void free_pool(std::vector<void *> &pool) {
 void ns_destroy(ns_ctx *ctx) {
     if (!ctx) return;
     hipError_t e = hipSetDevice(ctx->device); (void)e;
+    if (ctx->io) { ctx->io->wait_all(); ctx->io->shutdown(); delete ctx->io; ctx->io = nullptr; }
+    for (ns_sink *s : ctx->sinks) delete s;
+    ctx->sinks.clear();
     if (ctx->stream) { e = hipStreamSynchronize(ctx->stream); e = hipStreamDestroy(ctx->stream); }
     if (ctx->stream2) { e = hipStreamSynchronize(ctx->stream2); e = hipStreamDestroy(ctx->stream2); }
     if (ctx->ev_fork) e = hipEventDestroy(ctx->ev_fork);
@@ -1439,7 +1447,7 @@ void ns_destroy(ns_ctx *ctx) {
     if (ctx->ref_bases_owned) e = hipFree(ctx->ref_bases_owned);
     DevBuf *bufs[] = {&ctx->n_pieces, &ctx->piece_off, &ctx->ev_cap, &ctx->ev_off, &ctx->rec_len, &ctx->rec_off,
                       &ctx->err_len, &ctx->err_off, &ctx->name_len, &ctx->reads, &ctx->pieces, &ctx->events,
-                      &ctx->records, &ctx->errlog, &ctx->stats, &ctx->scan_tmp, &ctx->sort_key, &ctx->sort_idx,
+                      &ctx->rec_slot[0], &ctx->rec_slot[1], &ctx->err_slot[0], &ctx->err_slot[1], &ctx->stats, &ctx->scan_tmp, &ctx->sort_key, &ctx->sort_idx,
                       &ctx->sort_key_out, &ctx->order, &ctx->list_b, &ctx->list_c, &ctx->rstate, &ctx->att_base, &ctx->scr, &ctx->hp_nev, &ctx->hp_ev, &ctx->hp_wd, &ctx->hp_runs, &ctx->hp_nrun,
                       &ctx->scr_len, &ctx->scr_off, &ctx->hp_len, &ctx->slow_q, &ctx->ev_word, &ctx->l_cap, &ctx->l_off, &ctx->species_chrom_off, &ctx->t_reads, &ctx->t_pieces,
                       &ctx->t_name_len, &ctx->t_rec_len, &ctx->t_err_len, &ctx->accept, &ctx->accept_scan, &ctx->key_pos,
@@ -2430,11 +2438,18 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     if (prm->emit_errlog && (rc = scan_u64(ctx, A.err_len, A.err_off, n + 1))) return rc;
     if ((rc = prm->emit_errlog ? read_small(ctx, st, &info->record_bytes, A.rec_off + n, 8, &info->errlog_bytes, A.err_off + n, 8)
                                : read_small(ctx, st, &info->record_bytes, A.rec_off + n, 8))) return rc;
-    if (prm->emit_records == 1u && ((rc = ensure(ctx, ctx->records, (size_t)info->record_bytes + 64)) ||
-                                    (rc = ensure(ctx, ctx->errlog, (size_t)info->errlog_bytes + 64))))
+    // result slot of this batch: the other one while the last batch is still being copied out (ns_sink_write); a slot is reused
+    // once its copies have left the device
+    int slot = ctx->slot;
+    if (prm->emit_records == 1u && ctx->io) {
+        if (ctx->io->slot_busy(slot)) slot ^= 1;
+        ctx->io->wait_slot(slot);
+    }
+    if (prm->emit_records == 1u && ((rc = ensure(ctx, ctx->rec_slot[slot], (size_t)info->record_bytes + 64)) ||
+                                    (rc = ensure(ctx, ctx->err_slot[slot], (size_t)info->errlog_bytes + 64))))
         return rc;
     if (prm->emit_records == 0) info->errlog_bytes = 0;       // (no records: no error-profile image either; NS_EMIT_SIZES keeps the size)
-    A.records = (uint8_t *)ctx->records.p; A.errlog = (uint8_t *)ctx->errlog.p;
+    A.records = (uint8_t *)ctx->rec_slot[slot].p; A.errlog = (uint8_t *)ctx->err_slot[slot].p;
     const uint64_t max_unaligned = prm->kind == NS_KIND_UNALIGNED ? stats[4] : 0;      // longest read of the batch (k_chain)
     HIPCHK(hipEventRecord(ctx->evt[5], st));
     const bool write_rec = prm->emit_records == 1u;            // (2 = NS_EMIT_SIZES: the sizes of the images only)
@@ -2476,6 +2491,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     ctx->last = *info;
     ctx->last.n_events = tot_cap;
     if (prm->emit_records != 1u) { ctx->last.record_bytes = 0; ctx->last.errlog_bytes = 0; }      // nothing to copy out
+    ctx->slot = slot;
     ctx->has_batch = true;
     return NS_OK;
 }
@@ -2483,11 +2499,11 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
 static int result_buf(ns_ctx *ctx, int which, const void **p, uint64_t *size) {
     const ns_batch_info &b = ctx->last;
     switch (which) {
-        case NS_BUF_RECORDS: *p = ctx->records.p; *size = b.record_bytes; return NS_OK;
+        case NS_BUF_RECORDS: *p = ctx->rec_slot[ctx->slot].p; *size = b.record_bytes; return NS_OK;
         case NS_BUF_READS: *p = ctx->reads.p; *size = b.n_reads * sizeof(ns_read); return NS_OK;
         case NS_BUF_PIECES: *p = ctx->pieces.p; *size = b.n_pieces * sizeof(ns_piece); return NS_OK;
         case NS_BUF_EVENTS: *p = ctx->events.p; *size = b.n_events * sizeof(ns_event); return NS_OK;
-        case NS_BUF_ERRLOG: *p = ctx->errlog.p; *size = b.errlog_bytes; return NS_OK;
+        case NS_BUF_ERRLOG: *p = ctx->err_slot[ctx->slot].p; *size = b.errlog_bytes; return NS_OK;
         case NS_BUF_POLYA: *p = ctx->polya.p; *size = ctx->polya.p ? b.n_reads * 2 : 0; return NS_OK;
         case NS_BUF_SPLICED: *p = ctx->spliced.p; *size = ctx->spliced_bytes; return NS_OK;
         default: return NS_EINVAL;
@@ -2522,6 +2538,84 @@ int ns_host_free(ns_ctx *ctx, void *p) {
     if (!ctx) return NS_EINVAL;
     if (!p) return NS_OK;
     HIPCHK(hipHostFree(p));
+    return NS_OK;
+}
+
+// ---- output sinks (ns_io.h): the worker's out_reads.write / out_error.write (S:1437-1443, 2006-2008) as an asynchronous pipeline ----
+int ns_sink_open(ns_ctx *ctx, int fd, uint64_t file_off, ns_sink **out) {
+    if (!ctx) return NS_EINVAL;
+    if (!out) return fail(ctx, NS_EINVAL, "ns_sink_open: null destination");
+    *out = nullptr;
+    if (!ctx->io) {
+        IoEngine *io = new IoEngine();
+        std::string msg;
+        if (io->start(ctx->device, msg)) { io->shutdown(); delete io; return fail(ctx, NS_ENOMEM, msg); }
+        ctx->io = io;
+    }
+    ns_sink *s = new ns_sink();
+    s->fd = fd; s->off = file_off;
+    ctx->sinks.push_back(s);
+    *out = s;
+    return NS_OK;
+}
+
+static bool own_sink(ns_ctx *ctx, ns_sink *s) { return s && std::find(ctx->sinks.begin(), ctx->sinks.end(), s) != ctx->sinks.end(); }
+
+int ns_sink_put(ns_ctx *ctx, ns_sink *s, const void *host, uint64_t n) {
+    if (!ctx) return NS_EINVAL;
+    if (!own_sink(ctx, s)) return fail(ctx, NS_EINVAL, "unknown sink");
+    if (n && !host) return fail(ctx, NS_EINVAL, "ns_sink_put: null source");
+    uint64_t done = 0;
+    while (s->fd >= 0 && done < n) {
+        const ssize_t w = pwrite(s->fd, static_cast<const uint8_t *>(host) + done, (size_t)(n - done), (off_t)(s->off + done));
+        if (w < 0 && errno == EINTR) continue;
+        if (w <= 0) return fail(ctx, NS_EIO, std::string("write: ") + strerror(w < 0 ? errno : ENOSPC));
+        done += (uint64_t)w;
+    }
+    s->off += n; s->queued += n; s->written += n;
+    return NS_OK;
+}
+
+int ns_sink_write(ns_ctx *ctx, ns_sink *s, int which) {
+    if (!ctx) return NS_EINVAL;
+    if (!own_sink(ctx, s)) return fail(ctx, NS_EINVAL, "unknown sink");
+    if (!ctx->has_batch) return fail(ctx, NS_ESTATE, "no batch to write");
+    if (which != NS_BUF_RECORDS && which != NS_BUF_ERRLOG) return fail(ctx, NS_EINVAL, "ns_sink_write: records or error profile only");
+    const void *p; uint64_t size;
+    if (result_buf(ctx, which, &p, &size)) return fail(ctx, NS_EINVAL, "unknown buffer id");
+    ctx->io->enqueue(s, p, size, ctx->slot);
+    return NS_OK;
+}
+
+int ns_sink_drain(ns_ctx *ctx, ns_sink *s, uint64_t *file_off) {
+    if (!ctx) return NS_EINVAL;
+    if (!own_sink(ctx, s)) return fail(ctx, NS_EINVAL, "unknown sink");
+    ctx->io->wait_sink(s);
+    if (file_off) *file_off = s->off;
+    { std::lock_guard<std::mutex> g(ctx->io->mu); if (!ctx->io->err.empty()) return fail(ctx, NS_EHIP, ctx->io->err); }
+    if (const int e = s->err.load()) return fail(ctx, NS_EIO, std::string("write: ") + strerror(e));
+    return NS_OK;
+}
+
+int ns_sink_close(ns_ctx *ctx, ns_sink *s) {
+    if (!ctx) return NS_EINVAL;
+    if (!s) return NS_OK;
+    const int rc = ns_sink_drain(ctx, s, nullptr);
+    if (rc == NS_EINVAL) return rc;
+    ctx->sinks.erase(std::find(ctx->sinks.begin(), ctx->sinks.end(), s));
+    delete s;
+    return rc;
+}
+
+int ns_io_counters(ns_ctx *ctx, ns_io_stats *out, int reset) {
+    if (!ctx) return NS_EINVAL;
+    if (!out) return fail(ctx, NS_EINVAL, "null destination");
+    memset(out, 0, sizeof *out);
+    if (!ctx->io) return NS_OK;
+    std::lock_guard<std::mutex> g(ctx->io->mu);
+    out->bytes = ctx->io->bytes; out->dma_ms = ctx->io->dma_ms; out->wait_staging_s = ctx->io->wait_free_s; out->write_s = ctx->io->write_s;
+    out->slice_bytes = ctx->io->slice_bytes; out->n_slices = (uint32_t)ctx->io->slices.size(); out->n_threads = (uint32_t)ctx->io->writers.size();
+    if (reset) { ctx->io->bytes = 0; ctx->io->dma_ms = ctx->io->wait_free_s = ctx->io->write_s = 0; }
     return NS_OK;
 }
 

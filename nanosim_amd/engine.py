@@ -15,14 +15,20 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NANOSIM_AMD_LIB") or os.path.join(_HERE, "libnanosim_amd.so")   # override: A/B builds only
 NS_BUF_RECORDS, NS_BUF_READS, NS_BUF_PIECES, NS_BUF_EVENTS, NS_BUF_ERRLOG, NS_BUF_POLYA, NS_BUF_SPLICED = 0, 1, 2, 3, 4, 5, 6
 NS_SPLICED_BASE = 1 << 56
-NS_EINVAL, NS_ENODEV, NS_ENOMEM, NS_EHIP, NS_ESTATE = -1, -2, -3, -4, -5
+NS_EINVAL, NS_ENODEV, NS_ENOMEM, NS_EHIP, NS_ESTATE, NS_EIO = -1, -2, -3, -4, -5, -6
 NS_KIND_ALIGNED, NS_KIND_UNALIGNED, NS_KIND_PERFECT = 0, 1, 2
 NS_EMIT_SIZES = 2
 KERNEL_NAMES = ("plan(k_nseg+k_lengths+scan+sort)", "k_chain", "k_names", "k_materialise", "k_hp", "k_errlog")
 EXPORTS = ("ns_abi_version", "ns_create", "ns_destroy", "ns_last_error", "ns_set_reference",
            "ns_set_reference_device", "ns_load_model", "ns_generate", "ns_copy_out", "ns_device_ptr",
            "ns_set_species", "ns_set_abundance", "ns_species_bases", "ns_host_alloc", "ns_host_free",
-           "ns_set_transcriptome", "ns_set_intron_retention", "ns_set_background")
+           "ns_set_transcriptome", "ns_set_intron_retention", "ns_set_background",
+           "ns_sink_open", "ns_sink_put", "ns_sink_write", "ns_sink_drain", "ns_sink_close", "ns_io_counters")
+
+
+class NsIoStats(C.Structure):
+    _fields_ = [("bytes", C.c_uint64), ("dma_ms", C.c_double), ("wait_staging_s", C.c_double), ("write_s", C.c_double),
+                ("slice_bytes", C.c_uint64), ("n_slices", C.c_uint32), ("n_threads", C.c_uint32)]
 
 _lib = None
 
@@ -76,8 +82,48 @@ def load_library(path: str = LIB_PATH):
     L.ns_host_alloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
     L.ns_host_free.restype = C.c_int
     L.ns_host_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.ns_sink_open.restype = C.c_int
+    L.ns_sink_open.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]
+    L.ns_sink_put.restype = C.c_int
+    L.ns_sink_put.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint64]
+    L.ns_sink_write.restype = C.c_int
+    L.ns_sink_write.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.ns_sink_drain.restype = C.c_int
+    L.ns_sink_drain.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.ns_sink_close.restype = C.c_int
+    L.ns_sink_close.argtypes = [C.c_void_p, C.c_void_p]
+    L.ns_io_counters.restype = C.c_int
+    L.ns_io_counters.argtypes = [C.c_void_p, C.POINTER(NsIoStats), C.c_int]
     _lib = L
     return L
+
+
+class Sink:
+    """An output file the engine appends result buffers to (ns_sink_*): the out_reads / out_error handle of a worker
+    (src/simulator.py:1437-1443, 2006-2008).  write() queues a buffer of the LAST batch and returns at once; the bytes leave the GPU
+    on the engine's copy stream while the next batch is generated."""
+
+    def __init__(self, eng: "Engine", fd: int, file_off: int = 0):
+        self.eng = eng
+        self.h = C.c_void_p()
+        eng._check(eng.L.ns_sink_open(eng.ctx, fd, file_off, C.byref(self.h)))
+
+    def put(self, data: bytes):
+        self.eng._check(self.eng.L.ns_sink_put(self.eng.ctx, self.h, data, len(data)))
+
+    def write(self, which: int):
+        self.eng._check(self.eng.L.ns_sink_write(self.eng.ctx, self.h, which))
+
+    def drain(self) -> int:
+        """wait until everything queued is in the file; returns the file offset behind the last byte"""
+        off = C.c_uint64()
+        self.eng._check(self.eng.L.ns_sink_drain(self.eng.ctx, self.h, C.byref(off)))
+        return int(off.value)
+
+    def close(self):
+        if self.h:
+            h, self.h = self.h, C.c_void_p()
+            self.eng._check(self.eng.L.ns_sink_close(self.eng.ctx, h))
 
 
 class Batch:
@@ -231,6 +277,16 @@ class Engine:
         self._check(self.L.ns_host_alloc(self.ctx, nbytes, C.byref(p)))
         self._pinned.append(p)
         return np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(p.value))
+
+    def sink(self, fd: int, file_off: int = 0) -> Sink:
+        return Sink(self, fd, file_off)
+
+    def io_counters(self, reset: bool = False) -> dict:
+        st = NsIoStats()
+        self._check(self.L.ns_io_counters(self.ctx, C.byref(st), 1 if reset else 0))
+        return dict(bytes=int(st.bytes), dma_ms=float(st.dma_ms), wait_staging_s=float(st.wait_staging_s), write_s=float(st.write_s),
+                    d2h_gbs=(st.bytes / (st.dma_ms * 1e-3) / 1e9) if st.dma_ms > 0 else None,
+                    slice_bytes=int(st.slice_bytes), n_slices=int(st.n_slices), n_threads=int(st.n_threads))
 
     def load_model(self, model: Model):
         t = model.to_c()

@@ -2,14 +2,21 @@
 
 The reference's only parallelism is a fork fan-out that splits the read count and concatenates the workers'
 sub-files in worker order (src/simulator.py:1588-1639, 1642-1672).  Here: read-index ranges are partitioned
-across ranks, the reference genome is broadcast ONCE from rank 0, and there is no further data-path collective — a
-read is a pure function of (seed, read index), so the result does not depend on the number of GPUs.  The ranks
-write into the SAME output files at their final offsets (a sizing pass + one small all-gather of byte counts
-tells every rank where its part starts), so there is no merge copy either.
+across ranks, and the reference genome is broadcast ONCE from rank 0 — the run's single collective: the
+chromosome table, the seed and the mode's small tables ride behind the bases in the same buffer, and the size of that
+buffer is published through the rendezvous key-value store, which is not a collective.  A read is a pure function of
+(seed, read index), so the result does not depend on the number of GPUs.  Output follows the reference (S:1626-1639):
+rank 0 writes the head of every output file, every other rank a sub-file `<file>.part<rank>`, and rank 0 appends the
+sub-files in rank order as they appear.  Completion and failure travel through the file system (a finished sub-file is
+renamed into place, a failed rank leaves `<file>.part<rank>.failed`), so no rank ever waits inside a collective for a
+peer that has died.
 """
 from __future__ import annotations
 
 import os
+import pickle
+import sys
+import time
 
 import numpy as np
 
@@ -49,14 +56,13 @@ def init_dist():
 
 def agree(dist, ok: bool, message: str = "") -> None:
     """Every rank calls this before the next collective: if any rank failed its checks, ALL ranks exit with status 1 (a rank that
-    exits alone leaves the others waiting in the collective until the RCCL timeout)."""
+    exits alone leaves the others waiting in the collective until the RCCL timeout).  The CLI no longer needs it — rank 0's checks
+    travel in the header of the reference broadcast — it stays for callers that validate on every rank."""
     if dist is None:
         if not ok:
-            import sys
             sys.stderr.write(message)
             sys.exit(1)
         return
-    import sys
     flags = [None] * dist.get_world_size()
     dist.all_gather_object(flags, (bool(ok), message))
     bad = [m for o, m in flags if not o]
@@ -67,45 +73,141 @@ def agree(dist, ok: bool, message: str = "") -> None:
         sys.exit(1)
 
 
-def share_seed(dist, seed):
-    """rank 0's seed for every rank: a read is a function of (seed, read index), so all ranks must draw from the same seed"""
-    if dist is None:
-        return seed
-    box = [seed]
-    dist.broadcast_object_list(box, src=0)
-    return box[0]
+def _publish_header(dist, key: str, payload: bytes | None) -> bytes:
+    """rank 0's `payload` for every rank through the rendezvous store of the process group (a TCP key-value store: set / blocking get,
+    no collective); falls back to a 2-step object broadcast when the store is not reachable"""
+    try:
+        from torch.distributed import distributed_c10d as c10d
+        store = c10d._get_default_store()
+        if dist.get_rank() == 0:
+            store.set(key, payload)
+            return payload
+        return bytes(store.get(key))
+    except Exception:
+        box = [payload]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
 
 
-def file_offsets(dist, sizes: tuple[int, ...]) -> tuple[tuple[int, ...], tuple[int, ...]]:
-    """(first byte of this rank's part, total size) per file, from every rank's part sizes: ranks write in rank order (S:1626-1639)"""
-    if dist is None:
-        return tuple(0 for _ in sizes), tuple(sizes)
-    all_sizes = [None] * dist.get_world_size()
-    dist.all_gather_object(all_sizes, tuple(int(x) for x in sizes))
-    r = dist.get_rank()
-    return (tuple(sum(a[k] for a in all_sizes[:r]) for k in range(len(sizes))),
-            tuple(sum(a[k] for a in all_sizes) for k in range(len(sizes))))
+_BCAST_SEQ = [0]
 
 
-def broadcast_reference(ref: Reference | None, dist, device=None):
-    """Rank 0 holds `ref`; every rank returns (Reference metadata, bases tensor on `device`).
+def broadcast_reference(ref: Reference | None, dist, device=None, extra=None, error: str | None = None):
+    """Rank 0 holds `ref` (and `extra`, any picklable control data: the seed, the species / expression tables ...); every rank
+    returns (Reference metadata, bases tensor on `device`, extra).
 
-    One broadcast of the concatenated genome bytes (the only data-path collective of a run) plus one small
-    object broadcast for the chromosome table.  With device=None the tensor stays on the CPU (gloo tests).
-    """
+    ONE broadcast: the buffer is [bases | pickle(names, chrom_off, circular, extra)]; its two lengths reach the other ranks
+    through the rendezvous store.  `error` (rank 0): a failed check — every rank prints nothing, rank 0 the message, and ALL ranks
+    exit with status 1 together (S:354-356 & co: the reference exits before it forks).  device=None: the tensor stays on the CPU (gloo)."""
     import torch
     rank = dist.get_rank()
-    meta = [None]
+    _BCAST_SEQ[0] += 1
+    key = "ns_ref_header_%d" % _BCAST_SEQ[0]
+    blob = b""
     if rank == 0:
-        meta = [dict(names=ref.names, chrom_off=ref.chrom_off.tolist(), circular=ref.circular.tolist())]
-    dist.broadcast_object_list(meta, src=0)
-    m = meta[0]
-    n = int(m["chrom_off"][-1])
+        if error is None:
+            blob = pickle.dumps(dict(names=ref.names, chrom_off=np.asarray(ref.chrom_off), circular=np.asarray(ref.circular), extra=extra),
+                                protocol=pickle.HIGHEST_PROTOCOL)
+        hdr = pickle.dumps(dict(n=0 if error else int(ref.chrom_off[-1]), m=len(blob), error=error))
+    hdr = pickle.loads(_publish_header(dist, key, hdr if rank == 0 else None))
+    if hdr["error"] is not None:
+        if rank == 0:
+            sys.stderr.write(hdr["error"])
+        dist.destroy_process_group()
+        sys.exit(1)
+    n, m = int(hdr["n"]), int(hdr["m"])
     dev = device if device is not None else "cpu"
-    buf = torch.empty(n, dtype=torch.uint8, device=dev)
+    buf = torch.empty(n + m, dtype=torch.uint8, device=dev)
     if rank == 0:
-        buf.copy_(torch.from_numpy(np.ascontiguousarray(ref.bases)))
-    dist.broadcast(buf, src=0)
-    out = Reference(list(m["names"]), ref.bases if rank == 0 else np.zeros(0, np.uint8),
-                    np.array(m["chrom_off"], dtype=np.uint64), np.array(m["circular"], dtype=np.uint8))
-    return out, buf
+        buf[:n].copy_(torch.from_numpy(np.ascontiguousarray(ref.bases)))
+        buf[n:].copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+    dist.broadcast(buf, src=0)                                   # the run's one collective: RCCL over xGMI
+    meta = pickle.loads(buf[n:].cpu().numpy().tobytes())
+    out = Reference(list(meta["names"]), ref.bases if rank == 0 else np.zeros(0, np.uint8),
+                    np.asarray(meta["chrom_off"], dtype=np.uint64), np.asarray(meta["circular"], dtype=np.uint8))
+    return out, buf[:n], meta["extra"]
+
+
+# ---- output files of a multi-rank run (S:1626-1639) ------------------------------------------------------------------------------
+
+def part_path(path: str, rank: int) -> str:
+    """the file rank `rank` writes: rank 0 the final file itself (its records are the head of it), the others a sub-file"""
+    return path if rank == 0 else "%s.part%d" % (path, rank)
+
+
+def clean_parts(paths, rank: int) -> None:
+    """before the run's broadcast: no sub-file, temporary or failure marker of an earlier run may be mistaken for this run's"""
+    if rank == 0:
+        return
+    for p in paths:
+        for q in (part_path(p, rank), part_path(p, rank) + ".tmp", part_path(p, rank) + ".failed"):
+            try:
+                os.unlink(q)
+            except FileNotFoundError:
+                pass
+
+
+def mark_failed(path: str, rank: int, message: str) -> None:
+    try:
+        with open("%s.part%d.failed" % (path, rank), "w") as f:
+            f.write(message + "\n")
+    except OSError:
+        pass
+
+
+def _append_file(dst_fd: int, src_path: str) -> int:
+    """the bytes of src_path appended to dst_fd inside the kernel (copy_file_range: a reflink where the file system has one), falling
+    back to sendfile / read + write"""
+    total = 0
+    with open(src_path, "rb") as src:
+        size = os.fstat(src.fileno()).st_size
+        mode = "cfr" if hasattr(os, "copy_file_range") else "sendfile"
+        while total < size:
+            want = min(1 << 30, size - total)
+            try:
+                if mode == "cfr":
+                    n = os.copy_file_range(src.fileno(), dst_fd, want)
+                elif mode == "sendfile":
+                    n = os.sendfile(dst_fd, src.fileno(), None, want)
+                else:
+                    chunk = src.read(min(want, 64 << 20))
+                    n = len(chunk)
+                    view = memoryview(chunk)
+                    while view:
+                        w = os.write(dst_fd, view)
+                        view = view[w:]
+            except OSError:
+                if mode == "rw":
+                    raise
+                mode = "sendfile" if mode == "cfr" else "rw"       # EXDEV / EINVAL / ENOSYS: next method, same position
+                if mode == "rw":
+                    src.seek(total)
+                continue
+            if n == 0:
+                break
+            total += n
+    return total
+
+
+def collect_parts(path: str, world: int, timeout_s: float | None = None, poll_s: float = 0.02) -> None:
+    """Rank 0, after its own records are in `path`: append the sub-files of ranks 1 .. world-1 in rank order as they appear and remove
+    them.  A `.failed` marker of any rank (or the timeout, NS_PART_TIMEOUT seconds, default one day) ends the run with status 1."""
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("NS_PART_TIMEOUT", "86400"))
+    deadline = time.monotonic() + timeout_s
+    fd = os.open(path, os.O_WRONLY)                # (no O_APPEND: copy_file_range refuses such a descriptor)
+    os.lseek(fd, 0, os.SEEK_END)
+    try:
+        for r in range(1, world):
+            part = part_path(path, r)
+            while not os.path.exists(part):
+                bad = [q for q in (part_path(path, k) + ".failed" for k in range(1, world)) if os.path.exists(q)]
+                if bad or time.monotonic() > deadline:
+                    msg = open(bad[0]).read().strip() if bad else "timed out waiting for " + part
+                    sys.stderr.write("\nrank failure while writing %s: %s\n" % (path, msg))
+                    sys.exit(1)
+                time.sleep(poll_s)
+            _append_file(fd, part)
+            os.unlink(part)
+    finally:
+        os.close(fd)

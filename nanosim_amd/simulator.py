@@ -148,101 +148,6 @@ def validate_genome_args(a, parser_g):
         die("Perfect reads cannot be chimeric", False)
 
 
-class StreamWriter:
-    """Device buffer -> file in a pipeline: 64 MB slices travel by DMA into page-locked staging buffers
-    (ns_host_alloc) while a small pool of threads writes the previous slices at their file offsets (os.pwrite releases the GIL)."""
-    SLICE = int(os.environ.get("NS_WRITER_SLICE_MB", "64")) << 20
-    DEPTH = int(os.environ.get("NS_WRITER_DEPTH", "6"))
-    THREADS = int(os.environ.get("NS_WRITER_THREADS", "8"))
-    # NS_CLI_TRACE shows the main thread waiting for a free staging buffer 90 % of the time: the file writes are the limit
-    # (≈5 GB/s on tmpfs; pwrite()s to one file serialise on its inode lock).  NS_WRITER_MMAP=1 copies into shared mappings of the
-    # file ranges instead (memmove without the GIL, file grown with ftruncate first): 8.6 s instead of 10.1-11.1 s for 48 GB, but a
-    # full file system then ends in SIGBUS instead of ENOSPC, so it is opt-in.  More threads / slices in flight measured slower.
-    MMAP = os.environ.get("NS_WRITER_MMAP", "0") != "0"
-
-    def __init__(self, eng):
-        import queue
-        import threading
-        self.eng = eng
-        self.free = queue.Queue()
-        self.jobs = queue.Queue()
-        self.err = []
-        self.t_wait = self.t_copy = 0.0                  # time spent waiting for a free staging buffer / in the device-to-host copies
-        for _ in range(self.DEPTH):
-            self.free.put(eng.pinned(self.SLICE))
-        self.threads = [threading.Thread(target=self._work, daemon=True) for _ in range(self.THREADS)]
-        for t in self.threads:
-            t.start()
-
-    def _work(self):
-        while True:
-            job = self.jobs.get()
-            if job is None:
-                return
-            fd, off, buf, n = job
-            try:
-                if self.MMAP and self._copy_mapped(fd, off, buf, n):
-                    continue
-                mv = memoryview(buf)[:n]
-                done = 0
-                while done < n:
-                    done += os.pwrite(fd, mv[done:], off + done)
-            except Exception as ex:                      # surfaces in drain()
-                self.err.append(ex)
-            finally:
-                self.free.put(buf)
-                self.jobs.task_done()
-
-    @staticmethod
-    def _copy_mapped(fd, off, buf, n):
-        import ctypes
-        import mmap
-        a0 = off - off % mmap.ALLOCATIONGRANULARITY
-        try:
-            mm = mmap.mmap(fd, n + off - a0, flags=mmap.MAP_SHARED, prot=mmap.PROT_READ | mmap.PROT_WRITE, offset=a0)
-        except (OSError, ValueError):                    # descriptor not readable, not a mappable file: pwrite
-            return False
-        try:
-            dst = ctypes.c_char.from_buffer(mm, off - a0)
-            ctypes.memmove(ctypes.addressof(dst), buf.ctypes.data, n)
-            del dst
-        finally:
-            mm.close()
-        return True
-
-    def stream(self, batch, which, nbytes, fd, file_off):
-        """append bytes [0, nbytes) of result buffer `which` of `batch` to fd at file_off"""
-        if self.MMAP and nbytes:                          # the mapped copies need the file to reach the end of this buffer
-            try:
-                if os.fstat(fd).st_size < file_off + nbytes:
-                    os.ftruncate(fd, file_off + nbytes)
-            except OSError:
-                pass
-        pos = 0
-        while pos < nbytes:
-            n = min(self.SLICE, nbytes - pos)
-            t0 = time.perf_counter()
-            buf = self.free.get()
-            t1 = time.perf_counter()
-            batch.copy_range(which, pos, buf, n)
-            self.t_wait += t1 - t0; self.t_copy += time.perf_counter() - t1
-            self.jobs.put((fd, file_off + pos, buf, n))
-            pos += n
-        return file_off + nbytes
-
-    def drain(self):
-        self.jobs.join()
-        if self.err:
-            raise self.err[0]
-
-    def close(self):
-        self.drain()
-        for _ in self.threads:
-            self.jobs.put(None)
-        for t in self.threads:
-            t.join()
-
-
 def _batch_params(n, first, *, seed, kind, fastq, chimeric, min_len, max_len, median_len, sd_len, want_errlog, kmer_bias, meta, trx, uracil,
                   model_ir, emit_records=True):
     return E.make_params(seed=seed, first_read=first, n_reads=n, kind=kind, fastq=fastq, chimeric=chimeric, kmer_bias=kmer_bias, min_len=min_len,
@@ -250,90 +155,76 @@ def _batch_params(n, first, *, seed, kind, fastq, chimeric, min_len, max_len, me
                          trx=trx, uracil=uracil, model_ir=model_ir)
 
 
-def _size_batches(eng, *, first, count, batch, **kw):
-    """Sizing pass of a multi-rank run: bytes of the record image and of the error profile this rank will produce for reads
-    [first, first + count), in the same batches the writing pass uses (ns_params.emit_records = NS_EMIT_SIZES: nothing is formatted)."""
-    rec = err = done = 0
-    while done < count:
-        n = min(batch, count - done)
-        b = eng.generate(_batch_params(n, first + done, emit_records="sizes", **kw))
-        rec += int(b.info.record_bytes); err += int(b.info.errlog_bytes)
-        done += n
-    return rec, err
-
-
 def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, chimeric, min_len, max_len, median_len,
                    sd_len, want_errlog, kmer_bias=0, meta=False, err_header=b"", trx=False, uracil=False, model_ir=False, dist=None):
-    """Reads [first, first + count) of this rank into out_path (and their error-profile rows into err_path).  One rank: the files are
-    written front to back.  Several ranks (S:1588-1639: the reference's workers write sub-files that are concatenated afterwards): a
-    sizing pass tells every rank where its part starts, and all ranks write into the SAME files at their final offsets — no merge copy."""
-    done = 0
+    """Reads [first, first + count) of this rank into out_path (and their error-profile rows into err_path), through the engine's output
+    sinks (include/nanosim_amd.h: ns_sink_*): the images of batch i leave the GPU and reach the files while batch i + 1 is generated.
+    Several ranks (S:1588-1639: the reference's workers write sub-files that are concatenated afterwards): rank 0 writes the head of
+    the final files, every other rank a sub-file `<path>.part<rank>`; rank 0 appends them in rank order as they appear
+    (shard.collect_parts) — no collective, and a rank that fails leaves a marker instead of a hanging peer."""
+    rank = dist.get_rank() if dist is not None else 0
+    world = dist.get_world_size() if dist is not None else 1
     trace = os.environ.get("NS_CLI_TRACE") is not None       # per-batch host timing on stderr
-    w = getattr(eng, "_stream_writer", None)           # one writer (staging buffers + threads) per engine
-    if w is None:
-        w = eng._stream_writer = StreamWriter(eng)
     kw = dict(seed=seed, kind=kind, fastq=fastq, chimeric=chimeric, min_len=min_len, max_len=max_len, median_len=median_len, sd_len=sd_len,
               want_errlog=err_path is not None, kmer_bias=kmer_bias, meta=meta, trx=trx, uracil=uracil, model_ir=model_ir)
     batch = getattr(eng, "_batch_reads", BATCH_READS)
-    rank = dist.get_rank() if dist is not None else 0
-    off_r = off_e = 0
-    expect = None
-    if dist is not None:
-        sizes = _size_batches(eng, first=first, count=count, batch=batch, **kw)
-        (off_r, off_e), (tot_r, tot_e) = shard.file_offsets(dist, sizes)
-        off_e += len(err_header)                       # (every rank is handed the header; rank 0 writes it)
-        expect = (off_r + sizes[0], off_e + sizes[1])
-        if rank == 0:                                  # the files exist at their final size before anybody writes into them
-            for path, size in ((out_path, tot_r), (err_path, tot_e + len(err_header))):
-                if path:
-                    fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
-                    os.ftruncate(fd, size)
-                    os.close(fd)
-        dist.barrier()
-    flags = os.O_RDWR | (os.O_CREAT | os.O_TRUNC if dist is None else 0)
-    fr = os.open(out_path, flags, 0o644)               # (read access: the writer maps the file ranges)
-    fe = os.open(err_path, flags, 0o644) if err_path else None
-    if fe is not None and err_header and rank == 0:    # rank 0 opens the error profile with the column header (S:1634)
-        os.pwrite(fe, err_header, 0)
-        if dist is None:
-            off_e = len(err_header)
+    paths = [p for p in (out_path, err_path) if p]
+    mine = {p: shard.part_path(p, rank) for p in paths}                 # rank 0: the final file itself
+    work = {p: mine[p] + (".tmp" if rank else "") for p in paths}       # sub-files appear under their name only when complete
+    fds, sinks = {}, {}
+    done = 0
     try:
+        for p in paths:
+            fds[p] = os.open(work[p], os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+            sinks[p] = eng.sink(fds[p])
+        if err_path and err_header and rank == 0:       # rank 0 opens the error profile with the column header (S:1634)
+            sinks[err_path].put(err_header)
         while done < count:
             n = min(batch, count - done)
-            p = _batch_params(n, first + done, **kw)
             t0 = time.perf_counter()
             try:
-                b = eng.generate(p)
+                b = eng.generate(_batch_params(n, first + done, **kw))
             except E.EngineError as ex:              # not enough free HBM for this batch size (shared GPU): halve it and go on
-                if getattr(ex, "code", 0) != E.NS_ENOMEM or n <= 1000 or dist is not None or meta:
-                    raise                            # (several ranks / metagenome workers: the batches are part of the result)
+                if getattr(ex, "code", 0) != E.NS_ENOMEM or n <= 1000 or meta:
+                    raise                            # (metagenome workers: the batches are part of the result)
                 batch = eng._batch_reads = max(1000, n // 2)
                 continue
             t1 = time.perf_counter()
-            off_r = w.stream(b, E.NS_BUF_RECORDS, int(b.info.record_bytes), fr, off_r)
-            if fe is not None:
-                off_e = w.stream(b, E.NS_BUF_ERRLOG, int(b.info.errlog_bytes), fe, off_e)
+            sinks[out_path].write(E.NS_BUF_RECORDS)
+            if err_path:
+                sinks[err_path].write(E.NS_BUF_ERRLOG)
             if trace:
-                t2 = time.perf_counter()
-                sys.stderr.write("[cli] batch %d reads: generate %.1f ms (device %.1f), stream %.1f ms for %.2f GB (copy %.1f ms, waiting for a staging buffer %.1f ms)\n"
-                                 % (n, (t1 - t0) * 1e3, b.info.ms_total, (t2 - t1) * 1e3, (int(b.info.record_bytes) + int(b.info.errlog_bytes)) / 1e9,
-                                    w.t_copy * 1e3, w.t_wait * 1e3))
-                w.t_copy = w.t_wait = 0.0
+                c = eng.io_counters()
+                sys.stderr.write("[cli] batch %d reads: generate %.1f ms (device %.1f), %.2f GB queued; so far %.2f GB copied at %s GB/s (DMA), copier waited "
+                                 "%.2f s for staging, writers %.2f s in pwrite\n"
+                                 % (n, (t1 - t0) * 1e3, b.info.ms_total, (int(b.info.record_bytes) + int(b.info.errlog_bytes)) / 1e9, c["bytes"] / 1e9,
+                                    "%.1f" % c["d2h_gbs"] if c["d2h_gbs"] else "-", c["wait_staging_s"], c["write_s"]))
             done += n
             if rank == 0:
                 sys.stdout.write(strftime("%Y-%m-%d %H:%M:%S") + ": Number of reads simulated >> " + str(first + done) + "\r")
                 sys.stdout.flush()
-    finally:
-        w.drain()
-        os.close(fr)
-        if fe is not None:
-            os.close(fe)
-    if expect is not None and (off_r, off_e if fe is not None else expect[1]) != expect:
-        raise RuntimeError("sizing pass and writing pass disagree: %r != %r" % ((off_r, off_e), expect))
+        for p in paths:
+            sinks.pop(p).close()                     # waits for the file writes; raises on ENOSPC & co
+            os.close(fds.pop(p))
+            if rank:
+                os.rename(work[p], mine[p])
+    except BaseException as ex:
+        for sk in sinks.values():
+            try:
+                sk.close()
+            except Exception:
+                pass
+        for fd in fds.values():
+            os.close(fd)
+        if world > 1:
+            for p in paths:
+                shard.mark_failed(p, rank, repr(ex))
+        raise
     if rank == 0:
         sys.stdout.write('\n')
-    if dist is not None:
-        dist.barrier()
+        if world > 1:
+            for p in paths:
+                shard.collect_parts(p, world)
 
 
 def run_genome(a, parser_g):
@@ -359,18 +250,22 @@ def run_genome(a, parser_g):
         log("Read in reference ")
     eng = E.Engine(device)
     ref = M.read_fasta(a.ref_g, a.dna_type) if rank == 0 else None
-    # S:354-356; every rank leaves together (a rank that exits alone would leave the others waiting in the broadcast)
-    shard.agree(dist, not (rank == 0 and len(ref.names) > 1 and a.dna_type == "circular"),
-                "Do not choose circular if there is more than one chromosome in the genome!\n")
+    ext = ".fastq" if a.fastq else ".fasta"
+    seed = a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little") >> 1
+    # S:354-356; every rank leaves together (the verdict of rank 0's check travels in the header of the broadcast)
+    bad = "Do not choose circular if there is more than one chromosome in the genome!\n" if (rank == 0 and len(ref.names) > 1 and a.dna_type == "circular") else None
     keep = None
     if dist is not None:
-        ref, keep = shard.broadcast_reference(ref, dist, device=bdev)
+        shard.clean_parts([out + "_aligned_reads" + ext, out + "_aligned_error_profile", out + "_unaligned_reads" + ext], rank)
+        ref, keep, extra = shard.broadcast_reference(ref, dist, device=bdev, extra=dict(seed=seed), error=bad)
+        seed = extra["seed"]               # rank 0's: a read is a function of (seed, read index)
         if bdev is not None:
             eng.set_reference_device(keep.data_ptr(), ref)
         else:                                                                               # (gloo: the bases arrived in host memory)
             ref = M.Reference(ref.names, keep.numpy(), ref.chrom_off, ref.circular)
             eng.set_reference(ref)
     else:
+        shard.agree(None, bad is None, bad or "")
         eng.set_reference(ref)
     if rank == 0:
         log("Read error profile" if not a.perfect else "Read KDF of aligned reads")
@@ -385,8 +280,6 @@ def run_genome(a, parser_g):
         number = calculate_read_number_from_coverage(ref, a.model_prefix, a.coverage)
     n_al, n_un = mdl.split_counts(number)
     max_len = int(min(a.max_len, ref.max_chrom))                                            # S:2318
-    seed = shard.share_seed(dist, a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little") >> 1)
-    ext = ".fastq" if a.fastq else ".fasta"
     kind = E.NS_KIND_PERFECT if a.perfect else E.NS_KIND_ALIGNED
     if rank == 0:
         if a.median_len and a.sd_len:
@@ -437,15 +330,20 @@ def run_metagenome(a, parser_mg):
         log("Read in reference ")
         mref = MG.read_metagenome(a.genome_list, a.dna_type_list)
         numbers, samples = MG.read_abundance(a.abun, mref.species)
+    seed = a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little") >> 1
+    ext = ".fastq" if a.fastq else ".fasta"
     if dist is not None:
-        info = [dict(species=mref.species, off=mref.species_chrom_off.tolist(), keys=mref.chrom_names, numbers=numbers,
-                     samples=samples) if rank == 0 else None]
-        dist.broadcast_object_list(info, src=0)
-        ref, keep = shard.broadcast_reference(mref.ref if rank == 0 else None, dist, device=bdev)
+        info = dict(species=mref.species, off=mref.species_chrom_off.tolist(), keys=mref.chrom_names, numbers=numbers,
+                    samples=samples, seed=seed) if rank == 0 else None
+        # (sub-files of every sample this rank may write: the sample count is only known after the broadcast, so by pattern)
+        import glob
+        for q in glob.glob(glob.escape(a.output) + "_sample*.part%d*" % rank) if rank else ():
+            os.unlink(q)
+        ref, keep, info = shard.broadcast_reference(mref.ref if rank == 0 else None, dist, device=bdev, extra=info)
         if bdev is None:
             ref = M.Reference(ref.names, keep.numpy(), ref.chrom_off, ref.circular)
-        mref = MG.MetaReference(ref, info[0]["species"], np.array(info[0]["off"], dtype=np.uint32), info[0]["keys"])
-        numbers, samples = info[0]["numbers"], info[0]["samples"]
+        mref = MG.MetaReference(ref, info["species"], np.array(info["off"], dtype=np.uint32), info["keys"])
+        numbers, samples, seed = info["numbers"], info["samples"], info["seed"]
         eng.set_metagenome(mref, dev_ptr=keep.data_ptr() if bdev is not None else None)
     else:
         eng.set_metagenome(mref)
@@ -454,8 +352,6 @@ def run_metagenome(a, parser_mg):
     mdl = M.load_model(a.model_prefix, perfect=a.perfect, strandness=a.strandness, chimeric=a.chimeric, fastq=a.fastq,
                        homopolymer=a.homopolymer)
     eng.load_model(mdl)
-    seed = shard.share_seed(dist, a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little") >> 1)
-    ext = ".fastq" if a.fastq else ".fasta"
     max_len = a.max_len
     total_len = mref.total_len()
     first = 0
@@ -538,14 +434,17 @@ def run_transcriptome(a, parser_t):
     if rank == 0:
         log("Read in reference ")
         tr = TR.read_transcriptome(a.ref_t, a.exp, a.polya, a.basecaller)
+    seed = a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little") >> 1
+    ext = ".fastq" if a.fastq else ".fasta"
     if dist is not None:
-        info = [dict(ec=tr.expr_chrom, cum=tr.expr_cum, w=tr.expr_weight, pa=tr.polya, sc=tr.polya_scale) if rank == 0 else None]
-        dist.broadcast_object_list(info, src=0)
-        ref, keep = shard.broadcast_reference(tr.ref if rank == 0 else None, dist, device=bdev)
+        info = dict(ec=tr.expr_chrom, cum=tr.expr_cum, w=tr.expr_weight, pa=tr.polya, sc=tr.polya_scale, seed=seed) if rank == 0 else None
+        shard.clean_parts([out + "_aligned_reads" + ext, out + "_aligned_error_profile", out + "_unaligned_reads" + ext], rank)
+        ref, keep, info = shard.broadcast_reference(tr.ref if rank == 0 else None, dist, device=bdev, extra=info)
         if bdev is None:
             ref = M.Reference(ref.names, keep.numpy(), ref.chrom_off, ref.circular)
             keep = None
-        tr = TR.TranscriptomeReference(ref, info[0]["ec"], info[0]["cum"], info[0]["w"], info[0]["pa"], info[0]["sc"])
+        tr = TR.TranscriptomeReference(ref, info["ec"], info["cum"], info["w"], info["pa"], info["sc"])
+        seed = info["seed"]
     ir = None
     if model_ir:                                                                              # S:403-452
         if rank == 0:
@@ -567,8 +466,6 @@ def run_transcriptome(a, parser_t):
         number = calculate_read_number_from_coverage(tr.ref, a.model_prefix, a.coverage)
     n_al, n_un = mdl.split_counts(number)
     max_len = int(min(a.max_len, tr.ref.max_chrom))                                           # S:2411
-    seed = shard.share_seed(dist, a.seed if a.seed is not None else int.from_bytes(os.urandom(8), "little") >> 1)
-    ext = ".fastq" if a.fastq else ".fasta"
     if rank == 0:
         log("Start simulation of aligned reads")
     lo, hi = shard.partition(n_al, world)[rank]

@@ -665,6 +665,82 @@ def fixture_ir(S):
     return dict(cases=cases)
 
 
+class _FastafileStandIn:
+    """What the transcriptome worker uses of pysam.Fastafile (S:1066-1070, 1164-1171): `.references` (the sequence names up to the first
+    white space, in file order) and `.fetch(chrom, start, end)` = bases [start, end) of that sequence, 0-based, half open, in the case of
+    the file — pysam's documented semantics.  pysam is not in the image; with this record in its place the reference's own splice
+    (fetch of every interval, concatenation, reverse_complement on strand '-') runs here on the committed trx/genome.fa."""
+    def __init__(self, path):
+        self.seqs, name, chunks = {}, None, []
+        with open(path) as f:
+            for line in f:
+                if line.startswith(">"):
+                    if name is not None:
+                        self.seqs[name] = "".join(chunks)
+                    name, chunks = line[1:].split()[0], []
+                else:
+                    chunks.append(line.strip())
+        if name is not None:
+            self.seqs[name] = "".join(chunks)
+        self.references = list(self.seqs.keys())
+
+    def fetch(self, chrom, start, end):
+        return self.seqs[chrom][start:end]
+
+
+def fixture_ir_splice(S, prefix, n_reads=1500):
+    """The intron splice of simulation_aligned_transcriptome(model_ir=True) (S:1156-1178) pinned by value: the reference's worker runs
+    on the committed transcriptome + GFF3 structure + IR Markov model with `genome_fai` = _FastafileStandIn(trx/genome.fa); for every
+    read that went through extract_read_pos the fixture keeps the intervals it returned and the string the worker built from them
+    (what it hands to case_convert: fetches concatenated, reverse-complemented when the last interval is on strand '-') — as length,
+    SHA-1 and both ends.  dict_ref_structure is read with the repo's GFF3 reader in the reference's tuple layout (HTSeq is absent)."""
+    import hashlib
+    from nanosim_amd import intron_retention as IR
+    _trx_profile(S, prefix)
+    S.dict_ref_structure = IR.read_structure(IR_PREFIX + "_added_intron_final.gff3")
+    S.IR_markov_model = {}
+    with open(IR_PREFIX + "_IR_markov_model") as f:                      # S:414-422
+        f.readline()
+        for line in f:
+            info = line.strip().split()
+            S.IR_markov_model[info[0]] = {(0, float(info[1])): "no_IR", (float(info[1]), float(info[1]) + float(info[2])): "IR"}
+    S.genome_fai = _FastafileStandIn(os.path.join(TRX_DIR, "genome.fa"))
+    S.total_simulated = mp.Value("i", 0, lock=True)
+    random.seed(4711); np.random.seed(4711)
+    last = {"iv": None}
+    records = []
+    o_erp, o_ert, o_cc = S.extract_read_pos, S.extract_read_trx, S.case_convert
+
+    def erp(*a, **k):
+        out = o_erp(*a, **k)
+        last["iv"] = out
+        return out
+
+    def ert(*a, **k):
+        last["iv"] = None
+        return o_ert(*a, **k)
+
+    def cc(seq):
+        if last["iv"] is not None:
+            ivs, retain_polya, ir_list = last["iv"]
+            last["iv"] = None
+            records.append(dict(intervals=[[str(iv.chrom), int(iv.start), int(iv.end), str(iv.strand)] for iv in ivs],
+                                ir_list=[[int(a_), int(b_)] for a_, b_ in ir_list], length=len(seq),
+                                sha1=hashlib.sha1(seq.encode()).hexdigest(), head=seq[:24], tail=seq[-24:]))
+        return o_cc(seq)
+    S.extract_read_pos, S.extract_read_trx, S.case_convert = erp, ert, cc
+    workdir = tempfile.mkdtemp(prefix="nsgolden_ir_")
+    so, se = sys.stdout, sys.stderr
+    sys.stdout = open(os.devnull, "w"); sys.stderr = open(os.devnull, "w")
+    try:
+        S.simulation_aligned_transcriptome(True, os.path.join(workdir, "r.fasta"), os.path.join(workdir, "e"), None, "guppy", n_reads, True, False)
+    finally:
+        sys.stdout, sys.stderr = so, se
+        S.extract_read_pos, S.extract_read_trx, S.case_convert = o_erp, o_ert, o_cc
+        shutil.rmtree(workdir, ignore_errors=True)
+    return dict(n_reads=n_reads, references=S.genome_fai.references, spliced=records)
+
+
 def _trx_profile(S, prefix, perfect=False, fastq=False):
     so = sys.stdout
     sys.stdout = open(os.devnull, "w")
@@ -922,6 +998,7 @@ def main():
     ap.add_argument("--only-meta-perfect", action="store_true", help="add runs.perfect to reference_metagenome.json, keep the rest")
     ap.add_argument("--only-trx", action="store_true", help="write reference_transcriptome.json only")
     ap.add_argument("--only-ir", action="store_true", help="write the intron-retention inputs and reference_ir.json only")
+    ap.add_argument("--only-ir-splice", action="store_true", help="write reference_ir_splice.json only (the intron splice of the transcriptome worker)")
     ap.add_argument("--only-dist", action="store_true", help="write reference_distributions.json only (whole-run distribution pins)")
     ap.add_argument("--only-coverage", action="store_true", help="write reference_coverage.json only (-x / --coverage read counts)")
     ap.add_argument("--only-meta-runs", action="store_true", help="replace the whole-run part (runs) of reference_metagenome.json: 8 workers x 12 500 reads, plain and chimeric, + 8 x 6 000 perfect reads")
@@ -935,6 +1012,11 @@ def main():
             print("reference_ir.json written")
             return
         prefix, fasta, circ = build_inputs(workdir)
+        if a.only_ir_splice:
+            with open(os.path.join(HERE, "reference_ir_splice.json"), "w") as f:
+                json.dump(fixture_ir_splice(import_reference(), prefix), f)
+            print("reference_ir_splice.json written")
+            return
         if a.only_trx:
             build_trx_inputs()
             fx = fixture_transcriptome(import_reference(), prefix)

@@ -194,3 +194,41 @@ def test_transcriptome_output_does_not_depend_on_the_number_of_ranks(tmp_path):
     _run_ranks(2, base + ["-o", out], tmp_path)
     for f in ("_aligned_reads.fastq", "_aligned_error_profile", "_unaligned_reads.fastq"):
         assert open(out + f, "rb").read() == open(one + f, "rb").read(), f
+
+
+def test_configs0_ecoli_circular_perfect_10k_reads(tmp_path):
+    """BASELINE configs[0] as stated: E. coli-size CIRCULAR genome x --perfect x 10 000 reads x FASTA (S:1321-1343, 1750-1781).  The file
+    equals the oracle's bytes, and every read — also those across the origin — is a substring of the doubled genome (or of its reverse
+    complement) at the position its name gives."""
+    from nanosim_amd import synth
+    prefix = str(tmp_path / "model" / "hg002_like")
+    os.makedirs(os.path.dirname(prefix))
+    synth.write_model(prefix, synth.SynthModelSpec(n_train=200_000, seed=11), write_pkl=False)
+    seq = synth.synth_sequence(synth.ECOLI_LEN, 11, n_frac=0.0, iupac_frac=0.0, lower_frac=0.02, hp_boost=0.005)
+    fa = str(tmp_path / "ecoli_like.fa")
+    synth.write_fasta(fa, [("ecoli-like", seq)])
+    out = str(tmp_path / "run" / "simulated")
+    simulator.main(["genome", "-rg", fa, "-c", prefix, "-o", out, "-n", "10000", "--seed", "2026", "-dna_type", "circular", "--perfect"])
+    assert sorted(os.listdir(tmp_path / "run")) == ["simulated_aligned_error_profile", "simulated_aligned_reads.fasta"]
+    assert open(out + "_aligned_error_profile", "rb").read() == simulator.ERR_HEADER           # S:1634: header only
+    ref = M.read_fasta(fa, "circular")
+    mdl = M.load_model(prefix, perfect=True)
+    assert mdl.split_counts(10000) == (10000, 0)                                                # S:465-467
+    p = E.make_params(seed=2026, first_read=0, n_reads=10000, kind=E.NS_KIND_PERFECT, max_len=ref.max_chrom, emit_errlog=True)
+    exp = O.generate(mdl, ref, p, bytes_per_read=60000)
+    got = open(out + "_aligned_reads.fasta", "rb").read()
+    assert got == exp["records"].tobytes()
+    lines = got.split(b"\n")
+    assert len(lines) == 20001
+    genome = O.normalise_bases(ref.chrom(0))
+    doubled = np.concatenate([genome, genome]).tobytes()
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    wraps = 0
+    for i in range(0, 20000, 2):
+        f = lines[i][1:].split(b"_")                 # ecoli-like_<pos>_perfect_<n>_<F|R>_0_<len>_0
+        assert f[2] == b"perfect" and int(f[3]) == i // 2 and f[5] == b"0" and f[7] == b"0"
+        pos, ln = int(f[1]), int(f[6])
+        s = lines[i + 1] if f[4] == b"F" else lines[i + 1].translate(comp)[::-1]
+        assert len(s) == ln and doubled[pos:pos + ln] == s, lines[i]
+        wraps += pos + ln > len(genome)
+    assert wraps >= 5                                # reads across the origin exist in this sample (expected ~18)

@@ -78,7 +78,7 @@ def _free_port():
     return p
 
 
-def _rank_main(rank, world, port, tmp, q):
+def _rank_main(rank, world, port, tmp, q, fail_rank):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
         sys.path.insert(0, ROOT)
@@ -86,50 +86,94 @@ def _rank_main(rank, world, port, tmp, q):
         from nanosim_amd import model as M2
         from nanosim_amd import shard as S2
         dist.init_process_group("gloo", rank=rank, world_size=world)
+        path = os.path.join(tmp, "reads.fasta")
+        if rank:                                  # leftovers of an "earlier run" must not be taken for this run's sub-files
+            open(S2.part_path(path, rank), "w").write("stale")
+            open(S2.part_path(path, rank) + ".failed", "w").write("stale")
+        S2.clean_parts([path], rank)
         ref = M2.read_fasta(os.path.join(GOLDEN, "genome_small.fa")) if rank == 0 else None
-        meta, buf = S2.broadcast_reference(ref, dist)
+        # ONE collective: the bases, the chromosome table and the control data (here the seed of rank 0) in one broadcast
+        meta, buf, extra = S2.broadcast_reference(ref, dist, extra=dict(seed=1234 + rank, table=np.arange(5)))
         full = M2.read_fasta(os.path.join(GOLDEN, "genome_small.fa"))
         ok = (meta.names == full.names and np.array_equal(meta.chrom_off, full.chrom_off)
-              and np.array_equal(buf.numpy(), full.bases) and np.array_equal(meta.circular, full.circular))
-        # every rank sizes the records of its read-index range, learns where its part starts (rank order, S:1626-1639) and writes
-        # it at its FINAL offset of the common file; the seed of rank 0 reaches every rank; a failed check ends all ranks together
+              and np.array_equal(buf.numpy(), full.bases) and np.array_equal(meta.circular, full.circular)
+              and extra["seed"] == 1234 and np.array_equal(extra["table"], np.arange(5)))
+        # every rank writes the records of its read-index range: rank 0 the head of the final file, the others sub-files that appear
+        # under their name only when complete; rank 0 appends them in rank order (S:1626-1639) — no collective
         n = 1001
         lo, hi = S2.partition(n, world)[rank]
         part = b"".join(b">read_%d\nACGT\n" % i for i in range(lo, hi))
-        (off,), (total,) = S2.file_offsets(dist, (len(part),))
-        path = os.path.join(tmp, "reads.fasta")
-        if rank == 0:
-            fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
-            os.ftruncate(fd, total)
-            os.close(fd)
-        dist.barrier()
-        fd = os.open(path, os.O_RDWR)
-        os.pwrite(fd, part, off)
-        os.close(fd)
-        seed = S2.share_seed(dist, 1234 + rank)
-        S2.agree(dist, True)
-        dist.barrier()
+        code = 0
+        if rank == fail_rank:
+            S2.mark_failed(path, rank, "RuntimeError('disk full')")
+        else:
+            if rank:
+                import time as _t
+                _t.sleep(0.2 * (world - rank))        # the last rank finishes first: order must come from the rank, not from time
+            mine = S2.part_path(path, rank)
+            with open(mine + (".tmp" if rank else ""), "wb") as f:
+                f.write(part)
+            if rank:
+                os.rename(mine + ".tmp", mine)
+            else:
+                try:
+                    S2.collect_parts(path, world, timeout_s=60)
+                except SystemExit as e:
+                    code = e.code
         dist.destroy_process_group()
-        q.put((rank, ok and seed == 1234, lo, hi))
+        q.put((rank, ok, lo, hi, code))
     except Exception as e:      # pragma: no cover
-        q.put((rank, False, repr(e), 0))
+        q.put((rank, False, repr(e), 0, -1))
 
 
-def test_two_rank_broadcast_and_final_offsets_with_gloo(tmp_path):
-    world, port = 2, _free_port()
+def _run_ranks(tmp_path, world, fail_rank=-1):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, str(tmp_path), q, fail_rank)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=180) for _ in procs)
     for p in procs:
         p.join(60)
-    assert all(r[1] is True for r in res), res
+    return res
+
+
+def test_three_rank_broadcast_and_sub_files_with_gloo(tmp_path):
+    world = 3
+    res = _run_ranks(tmp_path, world)
+    assert all(r[1] is True and r[4] == 0 for r in res), res
     assert [(r[2], r[3]) for r in res] == shard.partition(1001, world)
     lines = open(tmp_path / "reads.fasta").read().split("\n")
     names = lines[0:-1:2]
     assert names == [">read_%d" % i for i in range(1001)]
+    assert sorted(os.listdir(tmp_path)) == ["reads.fasta"]          # sub-files are gone
+
+
+def test_failed_rank_ends_the_merge_with_status_1(tmp_path):
+    """a rank that fails leaves a marker: rank 0 exits with status 1 instead of waiting for a sub-file that never comes"""
+    res = _run_ranks(tmp_path, 2, fail_rank=1)
+    assert res[0][4] == 1 and res[1][4] == 0, res
+
+
+def test_append_file_methods_agree(tmp_path, monkeypatch):
+    """shard._append_file: copy_file_range, sendfile and read + write produce the same bytes (the fallbacks are taken on EXDEV & co)"""
+    data = np.random.default_rng(5).integers(0, 256, 3_000_001, dtype=np.uint8).tobytes()
+    (tmp_path / "src").write_bytes(data)
+    for drop in ((), ("copy_file_range",), ("copy_file_range", "sendfile")):
+        with monkeypatch.context() as m:
+            for name in drop:
+                if name == "copy_file_range":
+                    m.delattr(os, "copy_file_range", raising=False)
+                else:
+                    m.setattr(os, "sendfile", lambda *a, **k: (_ for _ in ()).throw(OSError(22, "no sendfile")))
+            dst = tmp_path / ("dst%d" % len(drop))
+            dst.write_bytes(b"HEAD")
+            fd = os.open(dst, os.O_WRONLY)
+            os.lseek(fd, 0, os.SEEK_END)
+            assert shard._append_file(fd, str(tmp_path / "src")) == len(data)
+            os.close(fd)
+            assert dst.read_bytes() == b"HEAD" + data
 
 
 def _rank_disagree(rank, world, port, q):
@@ -180,46 +224,6 @@ def test_coverage_read_count(small_ref):
     n_al = int(10000000 * r / (r + 1))
     mean = (n_al * npz["aligned_reads_data"].mean() + (10000000 - n_al) * npz["unaligned_length_data"].mean()) / 10000000
     assert n == int(small_ref.genome_len / mean * 30.0)
-
-
-@pytest.mark.parametrize("mapped", [True, False])
-def test_stream_writer_pipelines_slices_in_order(tmp_path, mapped):
-    """simulator.StreamWriter with a stand-in engine: many slices per buffer, fewer staging buffers than slices, several writer
-    threads, two files interleaved — the files are the buffers, byte for byte."""
-    rng = np.random.default_rng(3)
-    bufs = {0: rng.integers(0, 256, 1_000_003, dtype=np.uint8), 4: rng.integers(0, 256, 2_345_678, dtype=np.uint8)}
-
-    class FakeEngine:
-        def pinned(self, n):
-            return np.zeros(n, dtype=np.uint8)
-
-    class FakeBatch:
-        def copy_range(self, which, off, out, n):
-            out[:n] = bufs[which][off:off + n]
-            return out[:n]
-
-    class SmallWriter(simulator.StreamWriter):
-        SLICE = 64 << 10
-        DEPTH = 3
-        THREADS = 4
-        MMAP = mapped
-
-    w = SmallWriter(FakeEngine())
-    f0 = os.open(tmp_path / "a.bin", os.O_RDWR | os.O_CREAT, 0o644)
-    f1 = os.open(tmp_path / "b.bin", (os.O_RDWR if mapped else os.O_WRONLY) | os.O_CREAT, 0o644)
-    try:
-        os.pwrite(f1, b"HEADER\n", 0)
-        o0 = o1 = 0
-        o1 = 7
-        for _ in range(3):                                   # three "batches" appended back to back
-            o0 = w.stream(FakeBatch(), 0, len(bufs[0]), f0, o0)
-            o1 = w.stream(FakeBatch(), 4, len(bufs[4]), f1, o1)
-        w.drain()
-    finally:
-        w.close()
-        os.close(f0); os.close(f1)
-    assert open(tmp_path / "a.bin", "rb").read() == bufs[0].tobytes() * 3
-    assert open(tmp_path / "b.bin", "rb").read() == b"HEADER\n" + bufs[4].tobytes() * 3
 
 
 def test_trained_pickles_load_like_the_npz(tmp_path, monkeypatch):
