@@ -786,7 +786,7 @@ typedef struct nso_trx {             /* expression view of the reference transcr
 /* ---- intron retention ---------------------------------------------------------------------------
  * PARITY: nso_ir_states is pinned against the reference's update_structure and nso_extract_read_pos against its extract_read_pos
  * (tests/golden/reference_ir.json: 400 + 496 recorded calls; HTSeq.GenomicInterval, which extract_read_pos only constructs, is a
- * four-field record in the fixture generator).  The splice below is restated from S:1159-1178 but UNPINNED: the reference fetches
+ * four-field record in the fixture generator).  The splice (nso_splice) is restated from S:1159-1178 and pinned the same way (it was UNPINNED until round 3): the reference fetches
  * the intervals through pysam, which this image lacks. */
 
 /* update_structure (S:114-145): u[k] is the random.random() of intron k; retained[k] = 1 for "IR".  Returns flag_ir.
@@ -807,6 +807,28 @@ int nso_ir_states(const ns_ir_tables *t, uint32_t trx, const double *u, uint8_t 
 }
 
 typedef struct nso_iv { uint32_t chrom, start, end; uint8_t retained, minus; } nso_iv;
+
+/* The splice of the transcriptome worker (S:1161-1178): genome_fai.fetch(chrom, start, end) of every interval extract_read_pos returned,
+ * concatenated, and reverse_complement (S:1675-1680: upper-case A, C, G, T only; everything else stays) when the LAST interval is on
+ * strand '-'.  The bases are the file's (case kept; the device form is applied by the caller).  Returns the length, -1 if it exceeds cap.
+ * PARITY: pinned against the reference's worker run with a FASTA record in place of pysam.Fastafile (tests/golden/reference_ir_splice.json). */
+int64_t nso_splice(const ns_ir_tables *t, const nso_iv *iv, int n, uint8_t *out, int64_t cap) {
+    int64_t got = 0;
+    for (int z = 0; z < n; ++z)
+        for (uint32_t x = iv[z].start; x < iv[z].end; ++x) {
+            if (got >= cap) return -1;
+            out[got++] = t->genome[t->genome_off[iv[z].chrom] + x];
+        }
+    if (n > 0 && iv[n - 1].minus) {
+        for (int64_t i = 0, j = got - 1; i <= j; ++i, --j) {
+            uint8_t x = out[i], y = out[j];
+            uint8_t cx = x == 'A' ? 'T' : x == 'T' ? 'A' : x == 'C' ? 'G' : x == 'G' ? 'C' : x;
+            uint8_t cy = y == 'A' ? 'T' : y == 'T' ? 'A' : y == 'C' ? 'G' : y == 'G' ? 'C' : y;
+            out[i] = cy; out[j] = cx;
+        }
+    }
+    return got;
+}
 
 /* extract_read_pos (S:148-191) on the structure with the introns of `retained` switched to "retained_intron"; u_start is the
  * uniform behind random.randint(0, min(ref_len - length, len_before)).  Returns the number of intervals (list_intervals). */
@@ -1129,18 +1151,7 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
             const ns_ir_tables *ir = tx->ir;
             const int64_t rl = pc[0].ref_len;
             ir_seq = (uint8_t *)malloc((size_t)rl + 1);
-            int64_t got = 0;
-            for (int z = 0; z < ir_n; ++z)
-                for (uint32_t x = ir_iv[z].start; x < ir_iv[z].end; ++x) ir_seq[got++] = ir->genome[ir->genome_off[ir_iv[z].chrom] + x];
-            if (got != rl) { free(ir_seq); free(ir_iv); return -31; }
-            if (ir_iv[ir_n - 1].minus) {                                       /* reverse_complement, S:1675-1680: upper-case ACGT only */
-                for (int64_t i = 0, j = rl - 1; i <= j; ++i, --j) {
-                    uint8_t x = ir_seq[i], y = ir_seq[j];
-                    uint8_t cx = x == 'A' ? 'T' : x == 'T' ? 'A' : x == 'C' ? 'G' : x == 'G' ? 'C' : x;
-                    uint8_t cy = y == 'A' ? 'T' : y == 'T' ? 'A' : y == 'C' ? 'G' : y == 'G' ? 'C' : y;
-                    ir_seq[i] = cy; ir_seq[j] = cx;
-                }
-            }
+            if (nso_splice(ir, ir_iv, ir_n, ir_seq, rl) != rl) { free(ir_seq); free(ir_iv); return -31; }
             for (int64_t i = 0; i < rl; ++i) ir_seq[i] = nso_normalise_base(ir_seq[i]);
             const uint64_t slot = 64 + (((uint64_t)rl + 64 + 15) & ~15ull);
             if (o->spliced) {

@@ -1,9 +1,10 @@
 """Intron retention of the transcriptome mode (src/simulator.py:114-191, 403-452, 1156-1192).
 
-Pinned against the reference: update_structure / ref_len_from_structure (tests/golden/reference_ir.json, produced by the
-reference's own functions).  NOT pinned: extract_read_pos and the splice — the reference runs them through HTSeq and pysam,
-which this image lacks; they are checked here against the GFF3 structure and the genome directly (an independent walk in Python
-driven by the read names the oracle prints)."""
+Pinned against the reference: update_structure / ref_len_from_structure and extract_read_pos (tests/golden/reference_ir.json, produced
+by the reference's own functions, HTSeq.GenomicInterval as a four-field record), and the splice itself
+(tests/golden/reference_ir_splice.json: the reference's worker run with a FASTA record in place of pysam.Fastafile).  On top of that the
+oracle's batches are checked against the GFF3 structure and the genome directly (an independent walk in Python driven by the read
+names the oracle prints)."""
 import json
 import os
 import re
@@ -155,6 +156,43 @@ def test_extract_read_pos_matches_the_reference(fx, trx_ref, ir):
             n_calls += 1; n_multi += n > 1; n_polya += e["retain_polya"]
     # (retain_polya is False throughout: a read with a retained intron ends that intron's length short of the 3' end, S:186-189)
     assert n_calls > 350 and n_multi > 300 and n_polya == sum(e["retain_polya"] for c in fx["cases"] for e in c["extract"])
+
+
+def test_splice_matches_the_reference(trx_ref, ir):
+    """nso_splice == the string simulation_aligned_transcriptome(model_ir=True) builds from the intervals extract_read_pos returned
+    (S:1161-1178: genome_fai.fetch of every interval, concatenated, reverse_complement when the last interval is on strand '-'), for
+    every spliced read of a reference run (make_golden.py --only-ir-splice: pysam.Fastafile replaced by a record that serves
+    references / fetch from the committed trx/genome.fa) — same length, same SHA-1, same ends.  The chromosome of an interval is
+    resolved the way the worker does ("chr" + name when the FASTA's names carry the prefix, S:1066-1070, 1164-1166)."""
+    import ctypes as C
+    import hashlib
+
+    class Iv(C.Structure):
+        _fields_ = [("chrom", C.c_uint32), ("start", C.c_uint32), ("end", C.c_uint32), ("retained", C.c_uint8), ("minus", C.c_uint8)]
+
+    with open(os.path.join(ROOT, "tests", "golden", "reference_ir_splice.json")) as f:
+        fxs = json.load(f)
+    L = O.lib()
+    L.nso_splice.restype = C.c_int64
+    L.nso_splice.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
+    t = ir.to_c()
+    assert fxs["references"] == ir.genome.names
+    flag_chrom = any("chr" in nm for nm in fxs["references"])
+    n_minus = n_multi = 0
+    assert len(fxs["spliced"]) > 200
+    for rec in fxs["spliced"]:
+        iv = (Iv * len(rec["intervals"]))()
+        for k, (chrom, start, end, strand) in enumerate(rec["intervals"]):
+            name = "chr" + chrom if flag_chrom else chrom
+            iv[k].chrom, iv[k].start, iv[k].end, iv[k].minus = ir.genome.names.index(name), start, end, int(strand == "-")
+            iv[k].retained = int([start, end] in rec["ir_list"])
+        out = np.zeros(rec["length"] + 8, dtype=np.uint8)
+        n = L.nso_splice(C.addressof(t), iv, len(rec["intervals"]), out.ctypes.data, len(out))
+        got = out[:n].tobytes()
+        assert n == rec["length"] and got[:24].decode() == rec["head"] and got[-24:].decode() == rec["tail"], rec
+        assert hashlib.sha1(got).hexdigest() == rec["sha1"], rec
+        n_minus += rec["intervals"][-1][3] == "-"; n_multi += len(rec["intervals"]) > 1
+    assert n_minus > 50 and n_multi > 150 and len(fxs["spliced"]) - n_minus > 50         # both strands, several intervals per read
 
 
 NAME = re.compile(r"^[>@](?P<trx>[^_]+)_(?P<pos>\d+)_aligned_(?P<idx>\d+)(?:_RetainedIntron_(?P<ir>[0-9;-]+))?_(?P<strand>[RF])_(?P<head>\d+)_(?P<mid>\d+)_(?P<tail>\d+)$")
