@@ -269,10 +269,13 @@ def summarise(w, a, infos, dt, n, n_al, n_un, steps, warmup, world, tot_bases, e
     return out
 
 
-def e2e_legs(w, n, steps, shm_dir):
+def e2e_legs(w, n, steps, shm_dir, stripes=16):
     """SURVEY section 8(d) "timing protocol": end to end = generation + device-to-host + file writes.  Every leg: one untimed step (it
     sizes the second result slot), then `steps` steps whose record image (and error-profile image) are queued for their files right
-    after each worker call (ns_sink_write), then a drain.  reads/s = reads of the timed steps / wall time incl. the drain."""
+    after each worker call (ns_sink_write), then a drain.  reads/s = reads of the timed steps / wall time incl. the drain.
+    Destinations: null = /dev/null; shm = ONE file per output on /dev/shm (what the CLI does by default; writes into one inode
+    serialise in the kernel); shm<K> = every worker call's images cut at read boundaries into K sub-files per output (the CLI's -t K
+    with NS_KEEP_SUBFILES=1: the reference's sub-file layout, S:1588-1639, without the final concatenation)."""
     E = w.engine
     n_al, n_un = w.split(n, False)
     res = {}
@@ -282,49 +285,78 @@ def e2e_legs(w, n, steps, shm_dir):
         free = sv.f_bavail * sv.f_frsize
     except OSError:
         pass
-    for dest in ("null", "shm"):
+    for dest in ("null", "shm", "shm%d" % stripes):
         for errlog in (False, True):
             name = "%s_%s%s" % (dest, "fastq" if w.fastq else "fasta", "_errlog" if errlog else "")
             need = (steps + 1) * n * (36_000 if errlog else 9_000) * (2 if w.fastq else 1)
-            if dest == "shm" and (free is None or free < 3 * need):
+            if dest != "null" and (free is None or free < 3 * need):
                 res[name] = {"skipped": "needs %.0f GB on %s" % (need / 1e9, shm_dir)}
                 continue
-            d = tempfile.mkdtemp(prefix="nsbench_e2e_", dir=shm_dir) if dest == "shm" else None
+            d = tempfile.mkdtemp(prefix="nsbench_e2e_", dir=shm_dir) if dest != "null" else None
+            K = stripes if dest.startswith("shm") and dest != "shm" else 1
             fds, sinks = [], {}
+            live = {"al": [], "un": []}            # K > 1: (sink, fd) of the worker call being copied / of the one before it
+            counter = [0]
             try:
                 def open_sink(eng, fname):
                     fd = os.open("/dev/null" if d is None else os.path.join(d, fname), os.O_WRONLY | (0 if d is None else os.O_CREAT | os.O_TRUNC), 0o644)
-                    fds.append(fd)
-                    return eng.sink(fd)
-                sinks["al"] = open_sink(w.eng, "aligned_reads")
-                if errlog:
-                    sinks["err"] = open_sink(w.eng, "aligned_error_profile")
-                sinks["un"] = open_sink(w.eng_un or w.eng, "unaligned_reads")
+                    return eng.sink(fd), fd
+                if K == 1:
+                    for key, eng, fname in (("al", w.eng, "aligned_reads"), ("err", w.eng, "aligned_error_profile"), ("un", w.eng_un or w.eng, "unaligned_reads")):
+                        if key != "err" or errlog:
+                            sinks[key], fd = open_sink(eng, fname)
+                            fds.append(fd)
+
+                def striped(b, eng, key, with_err):
+                    nr = int(b.info.n_reads)
+                    cuts = sorted({k * nr // K for k in range(K + 1)})
+                    ro, eo = b.record_offsets(cuts)
+                    mine = []
+                    for lo, hi in zip(range(len(cuts) - 1), range(1, len(cuts))):
+                        counter[0] += 1
+                        sk, fd = open_sink(eng, "%s_reads%d" % (key, counter[0]))
+                        sk.write(E.NS_BUF_RECORDS, int(ro[lo]), int(ro[hi] - ro[lo])); mine.append((sk, fd))
+                        if with_err:
+                            sk, fd = open_sink(eng, "error_profile%d" % counter[0])
+                            sk.write(E.NS_BUF_ERRLOG, int(eo[lo]), int(eo[hi] - eo[lo])); mine.append((sk, fd))
+                    for sk, fd in live[key]:             # the worker call before this one is in its files by now (or soon)
+                        sk.close(); os.close(fd)
+                    live[key] = mine
 
                 def after_al(b):
+                    if K > 1:
+                        return striped(b, w.eng, "al", errlog)
                     sinks["al"].write(E.NS_BUF_RECORDS)
                     if errlog:
                         sinks["err"].write(E.NS_BUF_ERRLOG)
 
                 def after_un(b):
+                    if K > 1:
+                        return striped(b, w.eng_un or w.eng, "un", False)
                     sinks["un"].write(E.NS_BUF_RECORDS)
+
+                def drain():
+                    for s in sinks.values():
+                        s.drain()
+                    for key in live:
+                        for sk, fd in live[key]:
+                            sk.close(); os.close(fd)
+                        live[key] = []
                 w.step(1000, n, n_al, n_un, errlog=errlog, after_aligned=after_al, after_unaligned=after_un)
-                for s in sinks.values():
-                    s.drain()
+                drain()
                 for e in w.engs:
                     e.io_counters(reset=True)
                 t0 = time.perf_counter()
                 for i in range(steps):
                     w.step(1001 + i, n, n_al, n_un, errlog=errlog, after_aligned=after_al, after_unaligned=after_un)
                 t_gen = time.perf_counter() - t0
-                for s in sinks.values():
-                    s.drain()
+                drain()
                 dt = time.perf_counter() - t0
                 io = [e.io_counters() for e in w.engs]
                 moved = sum(c["bytes"] for c in io)
                 dma_ms = sum(c["dma_ms"] for c in io)
                 res[name] = {"reads_per_s": n * steps / dt, "file_gb_per_s": moved / dt / 1e9, "seconds": dt, "bytes": moved,
-                             "host_returned_after_s": t_gen,
+                             "files": max(counter[0] * (2 if errlog else 1), len(sinks)), "host_returned_after_s": t_gen,
                              "d2h_gb_per_s_while_copying": moved / (dma_ms * 1e-3) / 1e9 if dma_ms else None,
                              "copier_waited_for_staging_s": sum(c["wait_staging_s"] for c in io), "writers_in_pwrite_s": sum(c["write_s"] for c in io)}
             finally:
@@ -333,15 +365,23 @@ def e2e_legs(w, n, steps, shm_dir):
                         s.close()
                     except Exception:
                         pass
+                for key in live:
+                    for sk, fd in live[key]:
+                        try:
+                            sk.close()
+                        except Exception:
+                            pass
+                        os.close(fd)
                 for fd in fds:
                     os.close(fd)
                 if d is not None:
                     shutil.rmtree(d, ignore_errors=True)
     c = w.eng.io_counters()
     res["protocol"] = ("%d steps of %d reads (= %d aligned + %d unaligned) per leg after one untimed step; record image (+ error-profile image) of every "
-                       "worker call queued with ns_sink_write, wall time incl. the final drain; %d staging slices of %d MB, %d writer threads per engine context; "
-                       "null = /dev/null, shm = one file per output on %s (pwrite into ONE inode is what bounds those legs)"
-                       % (steps, n, n_al, n_un, c["n_slices"], c["slice_bytes"] >> 20, c["n_threads"], shm_dir))
+                       "worker call queued with ns_sink_write / ns_sink_write_range, wall time incl. the final drain; %d staging slices of %d MB, %d writer "
+                       "threads per engine context, one writer per file at a time; null = /dev/null, shm = one file per output on %s (writes into ONE "
+                       "inode serialise in the kernel: that bounds those legs), shm%d = %d sub-files per worker call and output, cut at read boundaries"
+                       % (steps, n, n_al, n_un, c["n_slices"], c["slice_bytes"] >> 20, c["n_threads"], shm_dir, stripes, stripes))
     return res
 
 

@@ -302,11 +302,17 @@ int ns_host_free(ns_ctx *ctx, void *p);
  * and dropped.  ns_sink_put appends host bytes (the header line of the error profile, S:1634) in order with the queued buffers.
  * ns_sink_drain waits until everything queued is in the file and reports the first write error (NS_EIO); file_off (optional)
  * receives the offset behind the last byte.  Tuning (environment, read by the first ns_sink_open of a context): NS_IO_SLICE_MB
- * (16), NS_IO_SLICES (16), NS_IO_THREADS (8). */
+ * (16), NS_IO_SLICES (24), NS_IO_THREADS (16; at most one of them writes into a given file at a time). */
 typedef struct ns_sink ns_sink;
 int ns_sink_open(ns_ctx *ctx, int fd, uint64_t file_off, ns_sink **out);
 int ns_sink_put(ns_ctx *ctx, ns_sink *sink, const void *host_src, uint64_t nbytes);
 int ns_sink_write(ns_ctx *ctx, ns_sink *sink, int which);
+/* the same for bytes [offset, offset + nbytes) of the buffer: one batch spread over several files (the reference's workers write
+ * sub-files that are concatenated afterwards, S:1588-1639; several inodes are what lets the file writes run in parallel).
+ * ns_record_offsets gives the cut points: for read indices of the last batch (0 .. n_reads; n_reads = the end) the byte offset of
+ * the read's record in the record image and of its first row in the error-profile image (err_off may be NULL). */
+int ns_sink_write_range(ns_ctx *ctx, ns_sink *sink, int which, uint64_t offset, uint64_t nbytes);
+int ns_record_offsets(ns_ctx *ctx, const uint64_t *read_index, uint32_t n, uint64_t *rec_off, uint64_t *err_off);
 int ns_sink_drain(ns_ctx *ctx, ns_sink *sink, uint64_t *file_off);
 int ns_sink_close(ns_ctx *ctx, ns_sink *sink);
 typedef struct ns_io_stats {

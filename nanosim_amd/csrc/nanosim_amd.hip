@@ -2576,14 +2576,48 @@ int ns_sink_put(ns_ctx *ctx, ns_sink *s, const void *host, uint64_t n) {
     return NS_OK;
 }
 
-int ns_sink_write(ns_ctx *ctx, ns_sink *s, int which) {
+int ns_sink_write_range(ns_ctx *ctx, ns_sink *s, int which, uint64_t offset, uint64_t nbytes) {
     if (!ctx) return NS_EINVAL;
     if (!own_sink(ctx, s)) return fail(ctx, NS_EINVAL, "unknown sink");
     if (!ctx->has_batch) return fail(ctx, NS_ESTATE, "no batch to write");
     if (which != NS_BUF_RECORDS && which != NS_BUF_ERRLOG) return fail(ctx, NS_EINVAL, "ns_sink_write: records or error profile only");
     const void *p; uint64_t size;
     if (result_buf(ctx, which, &p, &size)) return fail(ctx, NS_EINVAL, "unknown buffer id");
-    ctx->io->enqueue(s, p, size, ctx->slot);
+    if (offset > size || nbytes > size - offset) return fail(ctx, NS_EINVAL, "ns_sink_write_range: range exceeds the buffer");
+    ctx->io->enqueue(s, static_cast<const uint8_t *>(p) + offset, nbytes, ctx->slot);
+    return NS_OK;
+}
+
+int ns_sink_write(ns_ctx *ctx, ns_sink *s, int which) {
+    if (!ctx) return NS_EINVAL;
+    if (!ctx->has_batch) return fail(ctx, NS_ESTATE, "no batch to write");
+    const void *p; uint64_t size;
+    if (result_buf(ctx, which, &p, &size)) return fail(ctx, NS_EINVAL, "unknown buffer id");
+    return ns_sink_write_range(ctx, s, which, 0, size);
+}
+
+int ns_record_offsets(ns_ctx *ctx, const uint64_t *read_index, uint32_t n, uint64_t *rec_off, uint64_t *err_off) {
+    if (!ctx) return NS_EINVAL;
+    if (!ctx->has_batch) return fail(ctx, NS_ESTATE, "no batch");
+    if (n && (!read_index || !rec_off)) return fail(ctx, NS_EINVAL, "ns_record_offsets: null argument");
+    const uint64_t nr = ctx->last.n_reads;
+    for (uint32_t i = 0; i < n; ++i) if (read_index[i] > nr) return fail(ctx, NS_EINVAL, "ns_record_offsets: read index beyond the batch");
+    if (!nr || !ctx->last.record_bytes) {              // empty batch / no record image
+        for (uint32_t i = 0; i < n; ++i) { rec_off[i] = 0; if (err_off) err_off[i] = 0; }
+        return NS_OK;
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    const bool with_err = err_off && ctx->last.errlog_bytes;
+    uint64_t *slots = reinterpret_cast<uint64_t *>(ctx->pin_small);            // 1 KB of page-locked memory: 64 + 64 values per round
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+        const uint32_t m = std::min<uint32_t>(64u, n - i0);
+        for (uint32_t i = 0; i < m; ++i) {
+            HIPCHK(hipMemcpyAsync(slots + i, (const uint64_t *)ctx->rec_off.p + read_index[i0 + i], 8, hipMemcpyDeviceToHost, ctx->stream));
+            if (with_err) HIPCHK(hipMemcpyAsync(slots + 64 + i, (const uint64_t *)ctx->err_off.p + read_index[i0 + i], 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (uint32_t i = 0; i < m; ++i) { rec_off[i0 + i] = slots[i]; if (err_off) err_off[i0 + i] = with_err ? slots[64 + i] : 0; }
+    }
     return NS_OK;
 }
 

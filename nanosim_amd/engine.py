@@ -23,7 +23,8 @@ EXPORTS = ("ns_abi_version", "ns_create", "ns_destroy", "ns_last_error", "ns_set
            "ns_set_reference_device", "ns_load_model", "ns_generate", "ns_copy_out", "ns_device_ptr",
            "ns_set_species", "ns_set_abundance", "ns_species_bases", "ns_host_alloc", "ns_host_free",
            "ns_set_transcriptome", "ns_set_intron_retention", "ns_set_background",
-           "ns_sink_open", "ns_sink_put", "ns_sink_write", "ns_sink_drain", "ns_sink_close", "ns_io_counters")
+           "ns_sink_open", "ns_sink_put", "ns_sink_write", "ns_sink_write_range", "ns_record_offsets", "ns_sink_drain",
+           "ns_sink_close", "ns_io_counters")
 
 
 class NsIoStats(C.Structure):
@@ -88,6 +89,10 @@ def load_library(path: str = LIB_PATH):
     L.ns_sink_put.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint64]
     L.ns_sink_write.restype = C.c_int
     L.ns_sink_write.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.ns_sink_write_range.restype = C.c_int
+    L.ns_sink_write_range.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]
+    L.ns_record_offsets.restype = C.c_int
+    L.ns_record_offsets.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.ns_sink_drain.restype = C.c_int
     L.ns_sink_drain.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
     L.ns_sink_close.restype = C.c_int
@@ -111,8 +116,12 @@ class Sink:
     def put(self, data: bytes):
         self.eng._check(self.eng.L.ns_sink_put(self.eng.ctx, self.h, data, len(data)))
 
-    def write(self, which: int):
-        self.eng._check(self.eng.L.ns_sink_write(self.eng.ctx, self.h, which))
+    def write(self, which: int, offset: int = 0, nbytes: int | None = None):
+        """queue the whole buffer `which` of the last batch, or its bytes [offset, offset + nbytes)"""
+        if offset == 0 and nbytes is None:
+            self.eng._check(self.eng.L.ns_sink_write(self.eng.ctx, self.h, which))
+        else:
+            self.eng._check(self.eng.L.ns_sink_write_range(self.eng.ctx, self.h, which, offset, nbytes))
 
     def drain(self) -> int:
         """wait until everything queued is in the file; returns the file offset behind the last byte"""
@@ -166,6 +175,13 @@ class Batch:
     def spliced(self):
         """intron retention: the splice arena of the batch (pieces with ref_gpos >= NS_SPLICED_BASE point into it)"""
         return self._copy(NS_BUF_SPLICED, np.uint8, int(self.info.spliced_bytes))
+
+    def record_offsets(self, read_index):
+        """(record offsets, error-profile offsets) of the given read indices of this batch (n_reads = the end of the images)"""
+        idx = np.ascontiguousarray(read_index, dtype=np.uint64)
+        rec, err = np.zeros(len(idx), dtype=np.uint64), np.zeros(len(idx), dtype=np.uint64)
+        self.eng._check(self.eng.L.ns_record_offsets(self.eng.ctx, idx.ctypes.data, len(idx), rec.ctypes.data, err.ctypes.data))
+        return rec, err
 
     def kernel_ms(self):
         return {KERNEL_NAMES[i]: float(self.info.ms_kernel[i]) for i in range(len(KERNEL_NAMES))}

@@ -135,16 +135,33 @@ def part_path(path: str, rank: int) -> str:
     return path if rank == 0 else "%s.part%d" % (path, rank)
 
 
+def subfile_path(path: str, tag) -> str:
+    """sub-file `tag` of an output file, named as the reference names its workers' sub-files (S:1594-1595, 1650):
+    <out>_aligned_reads<i>.fasta, <out>_error_profile<i> (without "aligned_"), <out>_unaligned_reads<i>.fasta"""
+    head, ext = (path[:-6], path[-6:]) if path.endswith((".fasta", ".fastq")) else (path, "")
+    if head.endswith("_aligned_error_profile"):
+        head = head[:-len("_aligned_error_profile")] + "_error_profile"
+    return "%s%s%s" % (head, tag, ext)
+
+
 def clean_parts(paths, rank: int) -> None:
-    """before the run's broadcast: no sub-file, temporary or failure marker of an earlier run may be mistaken for this run's"""
+    """before the run's broadcast: no sub-file list, temporary or failure marker of an earlier run may be mistaken for this run's"""
     if rank == 0:
         return
     for p in paths:
-        for q in (part_path(p, rank), part_path(p, rank) + ".tmp", part_path(p, rank) + ".failed"):
+        for q in (part_path(p, rank), part_path(p, rank) + ".subfiles", part_path(p, rank) + ".subfiles.tmp", part_path(p, rank) + ".failed"):
             try:
                 os.unlink(q)
             except FileNotFoundError:
                 pass
+
+
+def publish_parts(path: str, rank: int, files) -> None:
+    """rank > 0 is done with `path`: the names of the files that hold its bytes, in order, appear atomically as <path>.part<rank>.subfiles"""
+    tmp = part_path(path, rank) + ".subfiles.tmp"
+    with open(tmp, "w") as f:
+        f.write("".join(os.path.abspath(x) + "\n" for x in files))
+    os.rename(tmp, part_path(path, rank) + ".subfiles")
 
 
 def mark_failed(path: str, rank: int, message: str) -> None:
@@ -189,25 +206,48 @@ def _append_file(dst_fd: int, src_path: str) -> int:
     return total
 
 
-def collect_parts(path: str, world: int, timeout_s: float | None = None, poll_s: float = 0.02) -> None:
-    """Rank 0, after its own records are in `path`: append the sub-files of ranks 1 .. world-1 in rank order as they appear and remove
-    them.  A `.failed` marker of any rank (or the timeout, NS_PART_TIMEOUT seconds, default one day) ends the run with status 1."""
+def collect_parts(path: str, world: int, own=None, keep: bool = False, timeout_s: float | None = None, poll_s: float = 0.02) -> None:
+    """Rank 0, once its own bytes of `path` are written (`own`: the files that hold them, in order — [path] itself when it wrote the final
+    file directly): append everything else in order — its own sub-files, then those of ranks 1 .. world-1 as their lists appear
+    (publish_parts) — and remove the sub-files.  keep: nothing is copied; <path>.subfiles lists the files in order instead.
+    A `.failed` marker of any rank (or the timeout, NS_PART_TIMEOUT seconds, default one day) ends the run with status 1."""
     if timeout_s is None:
         timeout_s = float(os.environ.get("NS_PART_TIMEOUT", "86400"))
     deadline = time.monotonic() + timeout_s
-    fd = os.open(path, os.O_WRONLY)                # (no O_APPEND: copy_file_range refuses such a descriptor)
-    os.lseek(fd, 0, os.SEEK_END)
+    own = [os.path.abspath(x) for x in (own if own is not None else [path])]
+    final = os.path.abspath(path)
+    order = list(own)
+    fd = None
     try:
+        if not keep:
+            fd = os.open(path, os.O_WRONLY | os.O_CREAT, 0o644)          # (no O_APPEND: copy_file_range refuses such a descriptor)
+            if final not in own:
+                os.ftruncate(fd, 0)
+            os.lseek(fd, 0, os.SEEK_END)
+            for x in own:
+                if x != final:
+                    _append_file(fd, x)
+                    os.unlink(x)
         for r in range(1, world):
-            part = part_path(path, r)
-            while not os.path.exists(part):
+            lst = part_path(path, r) + ".subfiles"
+            while not os.path.exists(lst):
                 bad = [q for q in (part_path(path, k) + ".failed" for k in range(1, world)) if os.path.exists(q)]
                 if bad or time.monotonic() > deadline:
-                    msg = open(bad[0]).read().strip() if bad else "timed out waiting for " + part
+                    msg = open(bad[0]).read().strip() if bad else "timed out waiting for " + lst
                     sys.stderr.write("\nrank failure while writing %s: %s\n" % (path, msg))
                     sys.exit(1)
                 time.sleep(poll_s)
-            _append_file(fd, part)
-            os.unlink(part)
+            names = [x for x in open(lst).read().split("\n") if x]
+            for x in names:
+                if keep:
+                    order.append(x)
+                else:
+                    _append_file(fd, x)
+                    os.unlink(x)
+            os.unlink(lst)
+        if keep and order != [final]:
+            with open(path + ".subfiles", "w") as f:
+                f.write("".join(x + "\n" for x in order))
     finally:
-        os.close(fd)
+        if fd is not None:
+            os.close(fd)

@@ -7,7 +7,8 @@ loop running on MI355X through the C-ABI (include/nanosim_amd.h).
 
 Differences a user can see: ``--seed`` is honoured (the reference re-seeds from the OS in
 ``simulation()``, S:1591-1592, so its --seed has no effect); read numbers are the read's index (no gaps);
-``-t`` is accepted but GPUs, not processes, do the work (run under ``torch.distributed.run`` for several GPUs).
+``-t K`` keeps the reference's meaning for the OUTPUT (K sub-files written side by side, then concatenated, S:1588-1639) while GPUs,
+not processes, do the work (run under ``torch.distributed.run`` for several GPUs).
 """
 from __future__ import annotations
 
@@ -156,29 +157,48 @@ def _batch_params(n, first, *, seed, kind, fastq, chimeric, min_len, max_len, me
 
 
 def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, chimeric, min_len, max_len, median_len,
-                   sd_len, want_errlog, kmer_bias=0, meta=False, err_header=b"", trx=False, uracil=False, model_ir=False, dist=None):
+                   sd_len, want_errlog, kmer_bias=0, meta=False, err_header=b"", trx=False, uracil=False, model_ir=False, dist=None, stripes=1):
     """Reads [first, first + count) of this rank into out_path (and their error-profile rows into err_path), through the engine's output
     sinks (include/nanosim_amd.h: ns_sink_*): the images of batch i leave the GPU and reach the files while batch i + 1 is generated.
-    Several ranks (S:1588-1639: the reference's workers write sub-files that are concatenated afterwards): rank 0 writes the head of
-    the final files, every other rank a sub-file `<path>.part<rank>`; rank 0 appends them in rank order as they appear
-    (shard.collect_parts) — no collective, and a rank that fails leaves a marker instead of a hanging peer."""
+
+    stripes == 1: rank 0 writes the final files front to back, every other rank one sub-file per output.
+    stripes > 1 (-t K; the reference's workers write K sub-files that are concatenated afterwards, S:1588-1639): every batch is cut at read
+    boundaries into K sub-files `<out>_aligned_reads<i>.fasta` / `<out>_error_profile<i>` / `<out>_unaligned_reads<i>.fasta` that are written in
+    parallel — writes into ONE file serialise on its inode, K files do not — and appended to the final file at the end, in order.
+    NS_KEEP_SUBFILES=1 skips that merge: the sub-files stay and `<file>.subfiles` lists them in order (cat $(cat x.subfiles) = x).
+    Several ranks: a rank that is done publishes the list of its sub-files (shard.publish_parts); rank 0 appends them in rank order as they
+    appear (shard.collect_parts) — no collective, and a rank that fails leaves a marker instead of a hanging peer."""
     rank = dist.get_rank() if dist is not None else 0
     world = dist.get_world_size() if dist is not None else 1
     trace = os.environ.get("NS_CLI_TRACE") is not None       # per-batch host timing on stderr
+    keep = os.environ.get("NS_KEEP_SUBFILES", "0") != "0"
     kw = dict(seed=seed, kind=kind, fastq=fastq, chimeric=chimeric, min_len=min_len, max_len=max_len, median_len=median_len, sd_len=sd_len,
               want_errlog=err_path is not None, kmer_bias=kmer_bias, meta=meta, trx=trx, uracil=uracil, model_ir=model_ir)
     batch = getattr(eng, "_batch_reads", BATCH_READS)
     paths = [p for p in (out_path, err_path) if p]
-    mine = {p: shard.part_path(p, rank) for p in paths}                 # rank 0: the final file itself
-    work = {p: mine[p] + (".tmp" if rank else "") for p in paths}       # sub-files appear under their name only when complete
-    fds, sinks = {}, {}
-    done = 0
+    which = {out_path: E.NS_BUF_RECORDS, err_path: E.NS_BUF_ERRLOG}
+    files = {p: [] for p in paths}                           # what holds this rank's bytes of p, in order
+    open_now, prev = [], []                                  # (sink, fd) of the batch being queued / of the batch before it
+    single = {}                                              # stripes == 1: the one sink per output
+    done = n_sub = 0
+
+    def close_all(lst):
+        for sk, fd in lst:
+            try:
+                sk.close()                               # waits for the file writes; raises on ENOSPC & co
+            finally:
+                os.close(fd)
+        del lst[:]
     try:
-        for p in paths:
-            fds[p] = os.open(work[p], os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
-            sinks[p] = eng.sink(fds[p])
-        if err_path and err_header and rank == 0:       # rank 0 opens the error profile with the column header (S:1634)
-            sinks[err_path].put(err_header)
+        if stripes == 1:
+            for p in paths:
+                name = shard.part_path(p, rank)
+                fd = os.open(name, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+                single[p] = eng.sink(fd)
+                open_now.append((single[p], fd))
+                files[p].append(name)
+            if err_path and err_header and rank == 0:   # rank 0 opens the error profile with the column header (S:1634)
+                single[err_path].put(err_header)
         while done < count:
             n = min(batch, count - done)
             t0 = time.perf_counter()
@@ -190,9 +210,25 @@ def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, 
                 batch = eng._batch_reads = max(1000, n // 2)
                 continue
             t1 = time.perf_counter()
-            sinks[out_path].write(E.NS_BUF_RECORDS)
-            if err_path:
-                sinks[err_path].write(E.NS_BUF_ERRLOG)
+            if stripes == 1:
+                for p in paths:
+                    single[p].write(which[p])
+            else:
+                cuts = sorted({k * n // stripes for k in range(stripes + 1)})
+                offs = dict(zip(paths, b.record_offsets(cuts)))
+                for lo, hi in zip(range(len(cuts) - 1), range(1, len(cuts))):
+                    for p in paths:
+                        name = shard.subfile_path(p, n_sub if world == 1 else "%d_%d" % (rank, n_sub))
+                        fd = os.open(name, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+                        sk = eng.sink(fd)
+                        open_now.append((sk, fd))
+                        files[p].append(name)
+                        if p == err_path and err_header and rank == 0 and n_sub == 0:
+                            sk.put(err_header)
+                        sk.write(which[p], int(offs[p][lo]), int(offs[p][hi] - offs[p][lo]))
+                    n_sub += 1
+                close_all(prev)                      # the batch before this one is in its files; this one's copies are under way
+                prev, open_now = open_now, []
             if trace:
                 c = eng.io_counters()
                 sys.stderr.write("[cli] batch %d reads: generate %.1f ms (device %.1f), %.2f GB queued; so far %.2f GB copied at %s GB/s (DMA), copier waited "
@@ -203,28 +239,30 @@ def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, 
             if rank == 0:
                 sys.stdout.write(strftime("%Y-%m-%d %H:%M:%S") + ": Number of reads simulated >> " + str(first + done) + "\r")
                 sys.stdout.flush()
-        for p in paths:
-            sinks.pop(p).close()                     # waits for the file writes; raises on ENOSPC & co
-            os.close(fds.pop(p))
-            if rank:
-                os.rename(work[p], mine[p])
+        close_all(prev)
+        close_all(open_now)
+        if stripes > 1 and err_path and err_header and rank == 0 and not files[err_path]:     # no reads at all: the header alone
+            name = shard.subfile_path(err_path, 0 if world == 1 else "0_0")
+            with open(name, "wb") as f:
+                f.write(err_header)
+            files[err_path].append(name)
+        if rank:
+            for p in paths:
+                shard.publish_parts(p, rank, files[p])
     except BaseException as ex:
-        for sk in sinks.values():
+        for lst in (prev, open_now):
             try:
-                sk.close()
+                close_all(lst)
             except Exception:
                 pass
-        for fd in fds.values():
-            os.close(fd)
         if world > 1:
             for p in paths:
                 shard.mark_failed(p, rank, repr(ex))
         raise
     if rank == 0:
         sys.stdout.write('\n')
-        if world > 1:
-            for p in paths:
-                shard.collect_parts(p, world)
+        for p in paths:
+            shard.collect_parts(p, world, files[p], keep=keep)
 
 
 def run_genome(a, parser_g):
@@ -288,14 +326,14 @@ def run_genome(a, parser_g):
     lo, hi = shard.partition(n_al, world)[rank]
     _write_batches(eng, out + "_aligned_reads" + ext, out + "_aligned_error_profile", seed=seed, first=lo, count=hi - lo, kind=kind,
                    fastq=a.fastq, chimeric=a.chimeric, min_len=a.min_len, max_len=max_len, median_len=a.median_len, sd_len=a.sd_len,
-                   want_errlog=True, kmer_bias=a.KmerBias or 0, err_header=ERR_HEADER, dist=dist)
+                   want_errlog=True, kmer_bias=a.KmerBias or 0, err_header=ERR_HEADER, dist=dist, stripes=max(a.num_threads, 1))
     if not a.perfect:                                                                       # S:1642-1672
         if rank == 0:
             log("Start simulation of random reads")
         lo, hi = shard.partition(n_un, world)[rank]
         _write_batches(eng, out + "_unaligned_reads" + ext, None, seed=seed, first=n_al + lo, count=hi - lo, kind=E.NS_KIND_UNALIGNED,
                        fastq=a.fastq, chimeric=False, min_len=a.min_len, max_len=max_len, median_len=a.median_len, sd_len=a.sd_len,
-                       want_errlog=False, dist=dist)
+                       want_errlog=False, dist=dist, stripes=max(a.num_threads, 1))
     eng.close()
     if dist is not None:
         dist.destroy_process_group()
@@ -472,14 +510,14 @@ def run_transcriptome(a, parser_t):
     _write_batches(eng, out + "_aligned_reads" + ext, out + "_aligned_error_profile", seed=seed, first=lo, count=hi - lo,
                    kind=E.NS_KIND_PERFECT if a.perfect else E.NS_KIND_ALIGNED, fastq=a.fastq, chimeric=False, min_len=a.min_len,
                    max_len=max_len, median_len=None, sd_len=None, want_errlog=True, trx=True, uracil=a.uracil, kmer_bias=a.KmerBias or 0,
-                   err_header=ERR_HEADER, model_ir=model_ir, dist=dist)
+                   err_header=ERR_HEADER, model_ir=model_ir, dist=dist, stripes=max(a.num_threads, 1))
     if not a.perfect:                                                                         # S:1642-1672
         if rank == 0:
             log("Start simulation of random reads")
         lo, hi = shard.partition(n_un, world)[rank]
         _write_batches(eng, out + "_unaligned_reads" + ext, None, seed=seed, first=n_al + lo, count=hi - lo,
                        kind=E.NS_KIND_UNALIGNED, fastq=a.fastq, chimeric=False, min_len=a.min_len, max_len=max_len, median_len=None,
-                       sd_len=None, want_errlog=False, trx=True, uracil=a.uracil, dist=dist)
+                       sd_len=None, want_errlog=False, trx=True, uracil=a.uracil, dist=dist, stripes=max(a.num_threads, 1))
     eng.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -28,6 +28,7 @@ from nanosim_amd import synth  # noqa: E402
 REF_SRC = "/root/reference/src"
 SMALL_SPEC = dict(n_train=2000, seed=7)
 GENOME_SEED = 11
+CHIMERIC_DENSE_MEAN = 2.0
 
 
 class _GenomicIntervalRecord:
@@ -915,7 +916,9 @@ def _dist_worker(args):
     with open(o_err) as f:
         for line in f:
             p = line.split("\t")
-            c = cnt[p[0]]
+            c = cnt.get(p[0])
+            if c is None:           # rows of a read that failed the final length check AFTER mutate_read had logged them (S:1429-1430 behind
+                continue            # S:2006-2008): the reference leaves them in the profile; the read itself was never written
             c[tix[p[2]]] += 1
             c[3 + tix[p[2]]] += int(p[3])
     ev = np.array([cnt[nm] for nm in names], dtype=np.int64)
@@ -999,6 +1002,9 @@ def main():
     ap.add_argument("--only-trx", action="store_true", help="write reference_transcriptome.json only")
     ap.add_argument("--only-ir", action="store_true", help="write the intron-retention inputs and reference_ir.json only")
     ap.add_argument("--only-ir-splice", action="store_true", help="write reference_ir_splice.json only (the intron splice of the transcriptome worker)")
+    ap.add_argument("--only-chimeric-dense", action="store_true",
+                    help="write reference_chimeric_dense.json only: genome mode --chimeric with the small model at 2 segments per read on average, "
+                         "so that the fixture holds > 10^5 chimeric reads (gap lengths and segment counts at the 1 %% gate)")
     ap.add_argument("--only-dist", action="store_true", help="write reference_distributions.json only (whole-run distribution pins)")
     ap.add_argument("--only-coverage", action="store_true", help="write reference_coverage.json only (-x / --coverage read counts)")
     ap.add_argument("--only-meta-runs", action="store_true", help="replace the whole-run part (runs) of reference_metagenome.json: 8 workers x 12 500 reads, plain and chimeric, + 8 x 6 000 perfect reads")
@@ -1016,6 +1022,16 @@ def main():
             with open(os.path.join(HERE, "reference_ir_splice.json"), "w") as f:
                 json.dump(fixture_ir_splice(import_reference(), prefix), f)
             print("reference_ir_splice.json written")
+            return
+        if a.only_chimeric_dense:
+            spec = synth.SynthModelSpec(**SMALL_SPEC, segment_mean=CHIMERIC_DENSE_MEAN)       # the committed small model but for _chimeric_info
+            prefix2 = os.path.join(workdir, "model_dense", "training")
+            synth.write_model(prefix2, spec, write_pkl=True, write_npz=False)
+            fx = fixture_distributions(prefix2, fasta, workdir, a.dist_reads, False, chimeric=True, n_unaligned=8)
+            fx["segment_mean"] = CHIMERIC_DENSE_MEAN
+            with open(os.path.join(HERE, "reference_chimeric_dense.json"), "w") as f:
+                json.dump(fx, f)
+            print("reference_chimeric_dense.json written:", fx["n_aligned"], "aligned reads,", sum(fx["nseg_hist"][2:]), "chimeric")
             return
         if a.only_trx:
             build_trx_inputs()

@@ -151,3 +151,38 @@ def test_eight_ranks_on_one_gpu_metagenome(tmp_path, small_model):
         assert open(base + "_aligned_reads.fasta", "rb").read() == b"".join(recs)
         assert open(base + "_aligned_error_profile", "rb").read() == b"".join(errs)
         first += n_al + n_un
+
+
+@pytest.mark.parametrize("flags", [["--chimeric"], ["--fastq", "-hp", "-k", "5"]])
+def test_sub_files_of_minus_t_give_the_same_files(tmp_path, monkeypatch, flags):
+    """-t K (S:1588-1639): every batch is cut at read boundaries into K sub-files written side by side and appended in order — the final
+    files are those of -t 1; NS_KEEP_SUBFILES=1 keeps the sub-files and lists them; 2 ranks x -t 3 the same"""
+    monkeypatch.setattr(simulator, "BATCH_READS", 500)           # several batches: sub-files of batch i close while batch i + 1 is copied
+    base = ["genome", "-rg", os.path.join(GOLDEN, "genome_small.fa"), "-c", os.path.join(GOLDEN, "model_small", "training"),
+            "-n", "1703", "--seed", "99"] + flags
+    ext = ".fastq" if "--fastq" in flags else ".fasta"
+    tails = ("_aligned_reads" + ext, "_aligned_error_profile", "_unaligned_reads" + ext)
+    one = str(tmp_path / "t1" / "sim")
+    simulator.main(base + ["-o", one])
+    four = str(tmp_path / "t4" / "sim")
+    simulator.main(base + ["-o", four, "-t", "4"])
+    assert sorted(os.listdir(tmp_path / "t4")) == sorted(os.listdir(tmp_path / "t1"))           # sub-files merged and removed
+    for f in tails:
+        assert open(four + f, "rb").read() == open(one + f, "rb").read(), f
+    monkeypatch.setenv("NS_KEEP_SUBFILES", "1")
+    kept = str(tmp_path / "keep" / "sim")
+    simulator.main(base + ["-o", kept, "-t", "4"])
+    names = os.listdir(tmp_path / "keep")
+    assert "sim_aligned_reads0" + ext in names and "sim_error_profile0" in names and "sim_aligned_reads" + ext not in names
+    for f in tails:
+        listed = open(kept + f + ".subfiles").read().split()
+        assert len(listed) >= 4
+        assert b"".join(open(x, "rb").read() for x in listed) == open(one + f, "rb").read(), f
+        head = open(listed[1], "rb").read(1)
+        assert head in (b"", b">", b"@") or f == "_aligned_error_profile"                          # cut at read boundaries
+    monkeypatch.delenv("NS_KEEP_SUBFILES")
+    out = str(tmp_path / "w2" / "sim")
+    _run_ranks(2, base + ["-o", out, "-t", "3"])
+    assert sorted(os.listdir(tmp_path / "w2")) == sorted(os.listdir(tmp_path / "t1"))
+    for f in tails:
+        assert open(out + f, "rb").read() == open(one + f, "rb").read(), f

@@ -89,6 +89,7 @@ def _rank_main(rank, world, port, tmp, q, fail_rank):
         path = os.path.join(tmp, "reads.fasta")
         if rank:                                  # leftovers of an "earlier run" must not be taken for this run's sub-files
             open(S2.part_path(path, rank), "w").write("stale")
+            open(S2.part_path(path, rank) + ".subfiles", "w").write(S2.part_path(path, rank) + "\n")
             open(S2.part_path(path, rank) + ".failed", "w").write("stale")
         S2.clean_parts([path], rank)
         ref = M2.read_fasta(os.path.join(GOLDEN, "genome_small.fa")) if rank == 0 else None
@@ -111,10 +112,10 @@ def _rank_main(rank, world, port, tmp, q, fail_rank):
                 import time as _t
                 _t.sleep(0.2 * (world - rank))        # the last rank finishes first: order must come from the rank, not from time
             mine = S2.part_path(path, rank)
-            with open(mine + (".tmp" if rank else ""), "wb") as f:
+            with open(mine, "wb") as f:
                 f.write(part)
             if rank:
-                os.rename(mine + ".tmp", mine)
+                S2.publish_parts(path, rank, [mine])       # the list of its sub-files appears atomically when the rank is done
             else:
                 try:
                     S2.collect_parts(path, world, timeout_s=60)
@@ -154,6 +155,28 @@ def test_failed_rank_ends_the_merge_with_status_1(tmp_path):
     """a rank that fails leaves a marker: rank 0 exits with status 1 instead of waiting for a sub-file that never comes"""
     res = _run_ranks(tmp_path, 2, fail_rank=1)
     assert res[0][4] == 1 and res[1][4] == 0, res
+
+
+def test_collect_parts_merges_own_sub_files_or_lists_them(tmp_path):
+    """-t K on one rank: the sub-files of the batches are appended to the final file in order and removed; NS_KEEP_SUBFILES: nothing is
+    copied, <file>.subfiles lists them (cat of the list = the file)"""
+    names = [shard.subfile_path(str(tmp_path / "sim_aligned_error_profile"), i) for i in range(5)]
+    assert os.path.basename(names[3]) == "sim_error_profile3"                  # S:1595
+    assert os.path.basename(shard.subfile_path("x/sim_aligned_reads.fastq", 12)) == "sim_aligned_reads12.fastq"      # S:1594
+    data = [os.urandom(1000 + 137 * i) for i in range(5)]
+    final = str(tmp_path / "sim_aligned_error_profile")
+    for keep in (True, False):
+        for nm, d in zip(names, data):
+            open(nm, "wb").write(d)
+        open(final, "wb").write(b"stale bytes of an earlier run")
+        shard.collect_parts(final, 1, names, keep=keep)
+        if keep:
+            listed = open(final + ".subfiles").read().split()
+            assert listed == [os.path.abspath(x) for x in names]
+            assert b"".join(open(x, "rb").read() for x in listed) == b"".join(data)
+        else:
+            assert open(final, "rb").read() == b"".join(data)
+            assert not any(os.path.exists(x) for x in names)
 
 
 def test_append_file_methods_agree(tmp_path, monkeypatch):
