@@ -159,7 +159,8 @@ typedef struct ns_params {
 
 /* one e_dict entry (S:1875-1882), ascending order, position in un-mutated segment coordinates.
  * info = len[0:12] | type[12:14] | (shift + 2^17)[14:32]; shift = sum(ins - del) over the earlier events of
- * the same piece, so the payload of the event starts at emitted-segment offset pos + shift. */
+ * the same piece, so the payload of the event starts at emitted-segment offset pos + shift.  An attempt of a read with an event
+ * outside these fields (multi-megabase reads only) is dropped and the read redrawn: ns_batch_info.n_range_redraws. */
 typedef struct ns_event {
     uint32_t pos;           /* ceil(key): mis/del at pos, ins before index pos */
     uint32_t info;
@@ -206,6 +207,8 @@ typedef struct ns_batch_info {
     double ms_total;        /* device time of the whole batch (HIP events on the engine stream) */
     double ms_kernel[8];    /* per-kernel device time: see NS_K_* */
     uint64_t spliced_bytes; /* intron retention: size of the splice arena (NS_BUF_SPLICED) */
+    uint64_t n_range_redraws; /* attempts dropped because an event did not fit the 8-byte record (NS_EV_LEN_MAX / the shift field): the
+                               * read drew new lengths, as after a failed final length check (S:1429-1430) */
 } ns_batch_info;
 
 enum { NS_K_LENGTHS = 0, NS_K_EVENTS = 1, NS_K_SCAN = 2, NS_K_MATERIALISE = 3, NS_K_HP = 4, NS_K_ERRLOG = 5 };

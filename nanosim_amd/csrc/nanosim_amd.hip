@@ -60,6 +60,8 @@ struct GenArgs {
     uint64_t *l_cap;            // [list position] capacity of the read in this pass
     const uint64_t *l_off;      // exclusive scan of l_cap (nullptr in pass 0: ev_off[r] is used)
     uint64_t l_base;            // first event slot of this pass's region
+    const uint32_t *p_need, *p_off;   // passes > 0 of a chimeric batch (k_replan): pieces a re-planned read needs / exclusive scan
+    uint32_t p_base;                  // first piece slot of this pass's region
     uint64_t *ev_off;
     uint64_t *rec_len;
     uint64_t *rec_off;
@@ -119,9 +121,12 @@ __device__ __forceinline__ ns_key read_key(const GenArgs &A, uint64_t r);
 
 __device__ __forceinline__ ns_key read_key(const GenArgs &A, uint64_t r) { return make_key(A.prm, A.key_pos ? (uint64_t)A.key_pos[r] : r); }
 
-__device__ __forceinline__ uint32_t read_nseg(const GenArgs &A, const ns_key &key) {
+// Segments of a read (S:1276-1277).  The reference draws num_segment once per worker and hands the counts out by POSITION among the reads
+// still missing (remaining_segments = num_segment[passed:], S:1447), so a count that no draw of lengths can satisfy is not retried for
+// ever.  Here the count belongs to the EPOCH of the read: it is drawn again whenever the read draws new segment lengths.
+__device__ __forceinline__ uint32_t read_nseg(const GenArgs &A, const ns_key &key, uint32_t epoch) {
     if (A.prm.kind != NS_KIND_ALIGNED || !A.prm.chimeric) return 1;
-    u32x4 w = ns_draw(key, ST_NSEG, 0, 0, 0, 0);                                     // S:1276-1277
+    u32x4 w = ns_draw(key, ST_NSEG, 0, epoch, 0, 0);
     uint32_t nseg = (uint32_t)table_value(A.m.nseg_cdf, A.m.nseg_n, u32_to_p(w.x));
     return nseg > NS_MAX_SEG ? NS_MAX_SEG : nseg;
 }
@@ -134,8 +139,19 @@ __global__ void __launch_bounds__(256) k_nseg(GenArgs A) {
     if (r > A.prm.n_reads) return;
     if (A.ir_need) A.ir_need[r] = 0;
     if (r == A.prm.n_reads) { A.n_pieces[r] = 0; A.ev_cap[r] = 0; A.rec_len[r] = 0; A.err_len[r] = 0; return; }
-    A.n_pieces[r] = 2 * read_nseg(A, make_key(A.prm, r)) - 1;
+    A.n_pieces[r] = 2 * read_nseg(A, make_key(A.prm, r), (A.keep_state && !A.meta) ? A.rstate[r] & 0xffffu : 0u) - 1;
     if (!A.keep_state) { A.rstate[r] = 0; A.att_base[r] = 0; }
+}
+
+// passes > 0 of a chimeric batch: a read whose epoch advanced draws its segment count again; if the count changed, the read moves to
+// fresh piece slots behind the planned ones (need[tid] = pieces to allocate, 0: it keeps its slots)
+__global__ void __launch_bounds__(256) k_replan(GenArgs A, uint32_t *need) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid > A.list_n) return;
+    if (tid == A.list_n) { need[tid] = 0; return; }
+    const uint64_t r = A.list[tid];
+    const uint32_t np = 2 * read_nseg(A, make_key(A.prm, r), A.rstate[r] & 0xffffu) - 1;
+    need[tid] = np != A.reads[r].n_pieces ? np : 0u;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -154,8 +170,12 @@ __global__ void __launch_bounds__(256) k_lengths(GenArgs A) {
     const bool meta_al = A.meta && kind != NS_KIND_UNALIGNED;    // r is then the position of the read inside pass A.attempt
     const uint32_t a = meta_al ? A.attempt : A.att_base[r] + A.attempt;
     const uint32_t epoch = meta_al ? 0u : A.rstate[r] & 0xffffu;
-    const uint32_t piece_off = A.piece_off[r];
-    const uint32_t n_pieces = A.piece_off[r + 1] - piece_off;
+    uint32_t piece_off, n_pieces;
+    if (A.attempt == 0 || meta_al) { piece_off = A.piece_off[r]; n_pieces = A.piece_off[r + 1] - piece_off; }
+    else {                                           // a later pass: the read's slots, unless k_replan gave it new ones
+        piece_off = A.reads[r].piece_off; n_pieces = A.reads[r].n_pieces;
+        if (A.p_need && A.p_need[tid]) { n_pieces = A.p_need[tid]; piece_off = A.p_base + A.p_off[tid]; }
+    }
     ns_piece *pc = A.pieces + piece_off;
     bool ok = true;
     uint64_t cap = 0, work = 0;
@@ -314,7 +334,11 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
                 if (!p.kind) total += e.l_new;                                           // S:1362
                 if (kind == NS_KIND_UNALIGNED) total = e.middle_ref;                     // S:1503
             }
-            if (sink.range) { overflow = true; st_over = 1ull << 40; break; }      // (reported apart from capacity overflows: stats[0] >> 40)
+            // An event that does not fit the 8-byte record (a run of more than NS_EV_LEN_MAX bases, a net insertion / deletion balance
+            // beyond the 18-bit shift field: multi-megabase reads only): this ATTEMPT is dropped like one that fails the final length
+            // check (S:1429-1430) and the read draws new lengths; counted in stats[0] >> 40 (ns_batch_info.n_range_redraws).  The
+            // reference keeps Python integers (S:1875-1882) and would emit the read: a documented limit of the record format.
+            if (sink.range) { if (lead) st_over = 1ull << 40; if (!meta_al) { ++epoch; fails = 0; } break; }
             if (sink.overflow) { overflow = true; break; }
             int64_t trx_len = 0;
             if (trx_al) {                                    // S:1143-1144: middle_ref > ref_trx_len -> start over (no length limits)
@@ -426,7 +450,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
             accepted = true;
         } while (false);
         if (lead) {
-            if (overflow && !st_over) st_over = 1;
+            if (overflow) st_over += 1;
             A.reads[r] = rd;
             if (meta_al) { /* a rejected read is re-planned by the next pass */ }
             else if (accepted) A.att_base[r] = a;       // a re-run of the batch starts every read at its accepted attempt
@@ -749,15 +773,28 @@ k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, co
 // Unaligned reads (S:1482-1549): ~0.55 events per base.  The tiled kernel ends a tile after 63 events — every ~110 bases here, twenty
 // prologues per read — so these reads take the lane-per-event path (ns_materialise.h: dense_piece).
 #define NS_DENSE_SEG 4096u        // output bytes of a read one wavefront writes: the longest read of a batch (tens of kb) no longer sets the kernel's duration
+// work list of the dense kernel: stretches of NS_DENSE_SEG output bytes per read (at least one: an empty read still has its framing), then
+// an exclusive scan — workgroup w finds its (read, stretch) by binary search.  (A grid of n x ceil(longest read / NS_DENSE_SEG) made
+// nine workgroups in ten exit at once on a 2 kb batch, and one 1 Mb read in a batch multiplied the launch by 245.)
+__global__ void __launch_bounds__(256) k_dense_plan(GenArgs A, uint32_t *cnt) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > A.prm.n_reads) return;
+    uint32_t c = 0;
+    if (r < A.prm.n_reads) { const ns_read rd = A.reads[r]; c = rd.flags ? 0u : max(1u, (rd.seq_len + NS_DENSE_SEG - 1u) / NS_DENSE_SEG); }
+    cnt[r] = c;
+}
 template <bool FASTQ>
-__global__ void __launch_bounds__(64) k_materialise_dense(GenArgs A) {
+__global__ void __launch_bounds__(64) k_materialise_dense(GenArgs A, const uint32_t *__restrict__ seg_off) {
     __shared__ DenseLds S;
     const uint32_t lane = threadIdx.x;
-    const uint64_t r = blockIdx.x;
-    const uint32_t seg = blockIdx.y;
+    const uint32_t w = blockIdx.x, n = (uint32_t)A.prm.n_reads;
+    if (w >= seg_off[n]) return;
+    uint32_t lo = 0, hi = n;                                   // the read whose stretches hold w: last r with seg_off[r] <= w
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (seg_off[mid] <= w) lo = mid; else hi = mid; }
+    const uint64_t r = uni(lo);
+    const uint32_t seg = uni(w - seg_off[lo]);
     ns_read rd; ns_key key; ReadOut ro;
     if (!load_read_uniform(A, r, FASTQ, rd, key, ro)) return;
-    if ((uint64_t)seg * NS_DENSE_SEG >= rd.seq_len && seg) return;
     const uint32_t a = rd.attempts;
     if (seg == 0) emit_head_tail(A.m, ro, key, a, rd.head, rd.tail, lane);
     uint32_t q = rd.head;
@@ -1270,7 +1307,7 @@ struct ns_ctx {
                                                  // 10^6 reads, chain ms at shift 9 / 10 / 11 / 12: 4.18 / 3.63 / 3.90 / 4.32
     uint32_t ucoop_shift = 0;                    // unaligned reads: the longest n>>shift of a batch take the wave-per-read list, the rest the thread-per-read one (env: NS_UCOOP_SHIFT; 0: all)
     // planning + result buffers
-    DevBuf l_cap, l_off;
+    DevBuf l_cap, l_off, p_need, p_off;
     DevBuf n_pieces, piece_off, ev_cap, ev_off, rec_len, rec_off, err_len, err_off, name_len;
     DevBuf reads, pieces, events, stats, scan_tmp;
     DevBuf rec_slot[2], err_slot[2];   // two result slots: the record / error-profile images of the last batch and of the one before (ns_io.h)
@@ -1453,7 +1490,7 @@ void ns_destroy(ns_ctx *ctx) {
                       &ctx->t_name_len, &ctx->t_rec_len, &ctx->t_err_len, &ctx->accept, &ctx->accept_scan, &ctx->key_pos,
                       &ctx->draw_x, &ctx->m_segptr, &ctx->m_len, &ctx->m_species, &ctx->species_bases, &ctx->draw_sel,
                       &ctx->draw_sorted, &ctx->meta_words, &ctx->meta_num, &ctx->trx_chrom, &ctx->trx_cum, &ctx->trx_polya, &ctx->polya,
-                      &ctx->ir_need, &ctx->ir_off, &ctx->spliced};
+                      &ctx->ir_need, &ctx->ir_off, &ctx->spliced, &ctx->p_need, &ctx->p_off};
     for (auto *pb : {&ctx->pin_a, &ctx->pin_b, &ctx->pin_c})
         if (pb->p) e = hipHostFree(pb->p);
     if (ctx->pin_small) e = hipHostFree(ctx->pin_small);
@@ -1684,8 +1721,7 @@ int ns_load_model(ns_ctx *ctx, const ns_model_tables *t) {
     return NS_OK;
 }
 
-#define NS_RANGE_MSG "a read does not fit the event record (a run of more than 4095 bases, or a net insertion / deletion balance beyond +-131071 " \
-                     "bases inside one segment): lower -max"
+#define NS_OVER_MASK ((1ull << 40) - 1)          // stats[0]: capacity overflows in the low bits, attempts dropped for the event-record range above
 static int scan_u64(ns_ctx *ctx, const uint64_t *in, uint64_t *out, size_t n) {
     size_t tmp = 0;
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, in, out, (int)n, ctx->stream));
@@ -1709,13 +1745,20 @@ static int scan_u32(ns_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n) {
 // ---------------------------------------------------------------------------------------------------------
 // copy phase, slow tiles, payload: the three kernels that write the sequence (and quality) lines of a batch
 static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fastq, uint64_t event_slots, hipEvent_t names_done = nullptr,
-                              const uint32_t *order = nullptr, int mode = MAT_REF, uint64_t max_seq_len = 0) {
+                              const uint32_t *order = nullptr, int mode = MAT_REF, uint64_t total_bases = 0) {
     hipStream_t st = ctx->stream;
     if (A.prm.kind == NS_KIND_UNALIGNED) {
+        // work list: stretches per read + scan (list_b / list_c are free once the passes are done); the grid is bounded from the batch's
+        // total: every read adds at most one partial stretch
+        uint32_t *cnt = (uint32_t *)ctx->list_b.p, *seg_off = (uint32_t *)ctx->list_c.p;
+        k_dense_plan<<<dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st>>>(A, cnt);
+        HIPCHK(hipGetLastError());
+        if (int rc = scan_u32(ctx, cnt, seg_off, n + 1)) return rc;
+        const uint64_t bound = total_bases / NS_DENSE_SEG + n + 1;
+        if (bound > 0x7fffffffull) return fail(ctx, NS_EINVAL, "unaligned batch too large for one launch of the record kernel (split it)");
         if (names_done) HIPCHK(hipStreamWaitEvent(st, names_done, 0));
-        const unsigned segs = (unsigned)std::min<uint64_t>(65535, (max_seq_len + NS_DENSE_SEG - 1) / NS_DENSE_SEG + 1);
-        if (fastq) k_materialise_dense<true><<<dim3((unsigned)n, segs), dim3(64), 0, st>>>(A);
-        else k_materialise_dense<false><<<dim3((unsigned)n, segs), dim3(64), 0, st>>>(A);
+        if (fastq) k_materialise_dense<true><<<dim3((unsigned)bound), dim3(64), 0, st>>>(A, seg_off);
+        else k_materialise_dense<false><<<dim3((unsigned)bound), dim3(64), 0, st>>>(A, seg_off);
         HIPCHK(hipGetLastError());
         return NS_OK;
     }
@@ -2061,7 +2104,8 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
     for (uint32_t p = 0; passed < n; ++p) {
         if (p >= NS_MAX_ATTEMPT)
             return fail(ctx, NS_EINVAL, "some reads found no acceptable length within the attempt limit "
-                                        "(min_len/max_len too narrow for this model)");
+                                        "(min_len/max_len too narrow for this model, or its reads do not fit the event record: runs <= 4095 bases, "
+                                            "insertion / deletion balance within +-131071 bases per segment)");
         const uint64_t m = n - passed;
         segs.assign(nseg.begin() + (ptrdiff_t)passed, nseg.end());                // num_segment[passed:], S:1034
         uint64_t D = 0;
@@ -2168,10 +2212,9 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
         HIPCHK(hipEventRecord(ctx->evt[4], st));
         if ((rc = read_small(ctx, st, stats, ctx->stats.p, 8 * sizeof(unsigned long long)))) return rc;
         HIPCHK(hipEventElapsedTime(&ms, ctx->evt[3], ctx->evt[4])); ms_chain += ms;
-        if (stats[0] >> 40) return fail(ctx, NS_EINVAL, NS_RANGE_MSG);
-        if (!stats[0]) break;
+        if (!(stats[0] & NS_OVER_MASK)) break;
         // a read outgrew its event capacity (rare): the pass is repeated with twice the capacity
-        info->n_overflow += stats[0];
+        info->n_overflow += stats[0] & NS_OVER_MASK;
         if (retry >= 6) return fail(ctx, NS_ENOMEM, "event capacity overflow persists after 6 retries");
         P.cap_rate *= 2.0; P.cap_gap_mul *= 2;
         HIPCHK(hipMemcpyAsync(ctx->stats.p, good_stats, 8 * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
@@ -2358,7 +2401,22 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
             A.l_off = nullptr; A.l_base = 0;
             HIPCHK(hipMemsetAsync(A.next_n, 0, 4, st));
             const dim3 grid_p((cur_n + 255) / 256);
+            A.p_need = nullptr; A.p_off = nullptr; A.p_base = 0;
             if (a > 0) {          // new lengths for the reads still open; their events go to a fresh region behind the earlier passes
+                if (prm->kind == NS_KIND_ALIGNED && prm->chimeric) {     // ... and a new segment count with a new epoch (read_nseg)
+                    if ((rc = ensure(ctx, ctx->p_need, ((size_t)cur_n + 1) * 4)) || (rc = ensure(ctx, ctx->p_off, ((size_t)cur_n + 1) * 4))) return rc;
+                    k_replan<<<dim3((cur_n + 1 + 255) / 256), blk, 0, st>>>(A, (uint32_t *)ctx->p_need.p);
+                    HIPCHK(hipGetLastError());
+                    if ((rc = scan_u32(ctx, (const uint32_t *)ctx->p_need.p, (uint32_t *)ctx->p_off.p, (size_t)cur_n + 1))) return rc;
+                    uint32_t extra = 0;
+                    if ((rc = read_small(ctx, st, &extra, (uint32_t *)ctx->p_off.p + cur_n, 4))) return rc;
+                    if (extra) {
+                        if ((rc = ensure_keep(ctx, ctx->pieces, (size_t)(tot_pieces + extra) * sizeof(ns_piece) + 64, (size_t)tot_pieces * sizeof(ns_piece)))) return rc;
+                        A.pieces = (ns_piece *)ctx->pieces.p;
+                        A.p_need = (const uint32_t *)ctx->p_need.p; A.p_off = (const uint32_t *)ctx->p_off.p; A.p_base = (uint32_t)tot_pieces;
+                        tot_pieces += extra;
+                    }
+                }
                 k_lengths<<<grid_p, blk, 0, st>>>(A);
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipMemsetAsync(A.l_cap + cur_n, 0, 8, st));
@@ -2394,18 +2452,18 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
             if ((rc = read_small(ctx, st, stats, ctx->stats.p, sizeof stats))) return rc;
             HIPCHK(hipEventElapsedTime(&ms, ctx->evt[3], ctx->evt[4]));
             ms_chain += ms;
-            if (stats[0] >> 40) return fail(ctx, NS_EINVAL, NS_RANGE_MSG);
-            if (stats[0]) { overflow = true; break; }
+            if (stats[0] & NS_OVER_MASK) { overflow = true; break; }
             cur_n = (uint32_t)(stats[6] & 0xffffffffull);
             if (!cur_n) { tot_cap = used; break; }
             if (a + 1 >= NS_MAX_ATTEMPT)
                 return fail(ctx, NS_EINVAL, "some reads found no acceptable length within the attempt limit "
-                                            "(min_len/max_len too narrow for this model)");
+                                            "(min_len/max_len too narrow for this model, or its reads do not fit the event record: runs <= 4095 bases, "
+                                            "insertion / deletion balance within +-131071 bases per segment)");
             cur = nxt; nxt = cur == list_b ? list_c : list_b;      // (list_a keeps the length-sorted order of the batch for the record kernels)
         }
         info->ms_kernel[NS_K_EVENTS] = ms_chain;
         if (!overflow) break;
-        info->n_overflow += stats[0];
+        info->n_overflow += stats[0] & NS_OVER_MASK;
         if (retry >= 6) return fail(ctx, NS_ENOMEM, "event capacity overflow persists after 6 retries");
         cap_rate *= 2.0; A.cap_gap_mul *= 2;          // rare: more events per base than planned -> re-plan the batch with twice the rates
     }
@@ -2450,7 +2508,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         return rc;
     if (prm->emit_records == 0) info->errlog_bytes = 0;       // (no records: no error-profile image either; NS_EMIT_SIZES keeps the size)
     A.records = (uint8_t *)ctx->rec_slot[slot].p; A.errlog = (uint8_t *)ctx->err_slot[slot].p;
-    const uint64_t max_unaligned = prm->kind == NS_KIND_UNALIGNED ? stats[4] : 0;      // longest read of the batch (k_chain)
+    const uint64_t max_unaligned = prm->kind == NS_KIND_UNALIGNED ? stats[1] : 0;      // emitted bases of the batch (k_chain): bounds the dense kernel's grid
     HIPCHK(hipEventRecord(ctx->evt[5], st));
     const bool write_rec = prm->emit_records == 1u;            // (2 = NS_EMIT_SIZES: the sizes of the images only)
     const bool side_names = !A.hp && write_rec;               // names + framing on the second stream, next to k_words
@@ -2487,6 +2545,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     info->ms_kernel[NS_K_HP] = ms_hp;
     info->n_reads = n; info->n_pieces = tot_pieces; info->n_events = tot_cap;
     info->total_bases = stats[1]; info->total_ref_bases = stats[2]; info->events_used = stats[3];
+    info->n_range_redraws = stats[0] >> 40;
     info->spliced_bytes = ctx->spliced_bytes;
     ctx->last = *info;
     ctx->last.n_events = tot_cap;

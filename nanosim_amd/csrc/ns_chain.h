@@ -259,7 +259,8 @@ __device__ inline EList32 coop_unaligned_error_list(const Tabs &T, const ChainTa
         const uint32_t del_incl = dn_incl & 0xffffffu, n_incl = dn_incl >> 24;
         const uint32_t slot = s.n + n_incl - n_ev;
         const uint32_t sh = (uint32_t)s.shift + (pend0 + ins_incl - L) - (del_incl - del);       // (used by non-insertion lanes only)
-        if (n_ev && !ev_shift_fits((int32_t)(sh + L - del))) bad = true;
+        // (the shift in FRONT of every event must fit its field, as ev_push32 checks it)
+        if ((n_ev > 0 && !ev_shift_fits((int32_t)sh)) || (n_ev > 1 && !ev_shift_fits((int32_t)(sh + d0))) || (n_ev > 2 && !ev_shift_fits((int32_t)(sh + d0 + d1)))) bad = true;
         if (__ballot(bad)) s.range = true;
         if (n_ev > 0) { if (slot < s.cap) { ns_event e; e.pos = ps0; e.info = ns_ev_pack(ln0, ty0, (int32_t)sh); s.ev[slot] = e; } }
         if (n_ev > 1) { if (slot + 1 < s.cap) { ns_event e; e.pos = ps1; e.info = ns_ev_pack(ln1, ty1, (int32_t)(sh + d0)); s.ev[slot + 1] = e; } }

@@ -82,7 +82,8 @@ class NsBatchInfo(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_pieces", C.c_uint64), ("n_events", C.c_uint64),
                 ("events_used", C.c_uint64), ("record_bytes", C.c_uint64), ("errlog_bytes", C.c_uint64), ("total_bases", C.c_uint64),
                 ("total_ref_bases", C.c_uint64), ("n_overflow", C.c_uint64),
-                ("ms_total", C.c_double), ("ms_kernel", C.c_double * 8), ("spliced_bytes", C.c_uint64)]
+                ("ms_total", C.c_double), ("ms_kernel", C.c_double * 8), ("spliced_bytes", C.c_uint64),
+                ("n_range_redraws", C.c_uint64)]
 
 
 EVENT_DTYPE = np.dtype([("pos", "<u4"), ("info", "<u4")])

@@ -209,9 +209,11 @@ typedef struct nso_elist {
     uint64_t n_ev;
     int64_t shift;            /* sum(ins - del) over the stored events */
     int overflow;
+    int range;                /* an event outside the fields of ns_event (NS_EV_LEN_MAX, the 18-bit shift): the attempt is dropped */
 } nso_elist;
 
 static void push_event(ns_event *ev, uint64_t cap, nso_elist *r, int64_t pos, int type, int64_t len) {
+    if (len > (int64_t)NS_EV_LEN_MAX || r->shift < -(int64_t)NS_EV_SHIFT_BIAS || r->shift >= (int64_t)NS_EV_SHIFT_BIAS) r->range = 1;
     if (len > (int64_t)NS_EV_LEN_MAX) len = NS_EV_LEN_MAX;
     if (ev && r->n_ev < cap) {
         ev[r->n_ev].pos = (uint32_t)pos;
@@ -950,16 +952,20 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
     const int kind = (int)prm->kind;
     uint32_t nseg = 1;
     if (mr) nseg = mr->nseg;
-    else if (kind == NS_KIND_ALIGNED && prm->chimeric) {                       /* S:1276-1277 */
-        philox_at(&d, ST_NSEG, 0, 0, 0, 0, w);
-        nseg = (uint32_t)table_value(t->nseg_cdf, t->nseg_n, u32_to_p(w[0]));
-        if (nseg > NSO_MAX_SEG) nseg = NSO_MAX_SEG;
-    }
     uint32_t epoch = 0, fails = 0;
     uint32_t trx_chrom = 0; int64_t trx_len = 0;
     for (uint32_t a = mr ? mr->pass : 0; a < NSO_MAX_ATTEMPT; ++a) {
         int64_t ref_len[NSO_MAX_SEG], gap_len[NSO_MAX_SEG];
         int ok = 1;
+        if (!mr && kind == NS_KIND_ALIGNED && prm->chimeric) {
+            /* S:1276-1277.  The reference draws num_segment once per worker and hands the segment counts out by POSITION among the
+             * reads still missing (remaining_segments = num_segment[passed:], S:1447): a count that no draw of lengths can satisfy is
+             * not retried for ever, the next while-iteration pairs the slot with other counts.  Here the count belongs to the epoch
+             * of the read: it is drawn again whenever the read draws new lengths. */
+            philox_at(&d, ST_NSEG, 0, epoch, 0, 0, w);
+            nseg = (uint32_t)table_value(t->nseg_cdf, t->nseg_n, u32_to_p(w[0]));
+            if (nseg > NSO_MAX_SEG) nseg = NSO_MAX_SEG;
+        }
         if (mr && a != mr->pass) return 1;          /* metagenome: one try per pass; a rejected read is re-planned */
         /* ---- lengths ---- */
         if (kind == NS_KIND_UNALIGNED) {                                  /* S:1494-1495,1499 */
@@ -1047,7 +1053,7 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
         ns_piece *pc = o->pieces + o->n_pieces;
         uint64_t ev0 = o->n_events, evn = ev0;
         int64_t total = remainder;
-        int overflow = 0;
+        int overflow = 0, range = 0;
         for (uint32_t pi = 0; pi < n_pieces; ++pi) {
             nso_elist r;
             int is_gap = (kind == NS_KIND_UNALIGNED) || (pi & 1);
@@ -1059,6 +1065,7 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
             else if (is_gap) nso_unaligned_error_list(t, mlen, &d, sid, a, o->events + evn, o->cap_events - evn, &r);
             else nso_error_list(t, mlen, (int)prm->fastq, &d, sid, a, o->events + evn, o->cap_events - evn, &r);
             if (r.overflow) overflow = 1;
+            if (kind != NS_KIND_PERFECT && r.range) range = 1;
             pc[pi].n_ev = (uint32_t)r.n_ev;
             pc[pi].ref_len = (uint32_t)(r.middle_ref < 0 ? 0 : r.middle_ref);
             /* emitted length = ref_len + ins - del over the stored events (collisions already folded in) */
@@ -1068,6 +1075,7 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
             if (!is_gap) total += r.l_new;                                  /* S:1362 (gaps are not counted) */
             if (kind == NS_KIND_UNALIGNED) total = r.middle_ref;            /* S:1503 */
         }
+        if (range) { if (!mr) { ++epoch; fails = 0; } continue; }       /* the attempt is dropped, new lengths (a limit of the 8-byte event record) */
         if (overflow) return -11;
         if (tx && kind != NS_KIND_UNALIGNED) {                              /* S:1143-1144: middle_ref > ref_trx_len -> start over */
             if ((int64_t)pc[0].ref_len > trx_len) continue;

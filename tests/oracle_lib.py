@@ -23,7 +23,7 @@ class NsoDraw(C.Structure):
 
 class NsoElist(C.Structure):
     _fields_ = [("l_new", C.c_int64), ("middle_ref", C.c_int64), ("e_count", C.c_int64 * 3),
-                ("n_ev", C.c_uint64), ("overflow", C.c_int)]
+                ("n_ev", C.c_uint64), ("shift", C.c_int64), ("overflow", C.c_int), ("range", C.c_int)]
 
 
 class NsoOut(C.Structure):

@@ -115,16 +115,18 @@ def chimeric_metrics(reads, pieces, events):
     return dict(nseg=nseg, gap=total - reads["head"] - reads["tail"] - seg_out, refl=refl)
 
 
-def check_chimeric(reads, pieces, events, fx, tag):
+def check_chimeric(reads, pieces, events, fx, tag, gap_gate=0.03, gap_mean_tol=0.06):
     cm = chimeric_metrics(reads, pieces, events)
-    hist = np.bincount(cm["nseg"], minlength=16)[:16].astype(np.float64)
-    ref_h = np.array(fx["nseg_hist"], dtype=np.float64)
+    nbin = max(len(fx["nseg_hist"]), int(cm["nseg"].max()) + 1)
+    hist = np.bincount(cm["nseg"], minlength=nbin).astype(np.float64)
+    ref_h = np.zeros(nbin); ref_h[:len(fx["nseg_hist"])] = fx["nseg_hist"]
     assert np.max(np.abs(np.cumsum(hist) / hist.sum() - np.cumsum(ref_h) / ref_h.sum())) <= KS_GATE, (tag, hist, ref_h)      # S:1276-1279
     ch = cm["nseg"] > 1
     assert fx["gap_bases_nonchimeric_max_abs"] == 0 and np.all(cm["gap"][~ch] == 0)
-    assert ks_vs_quantiles(cm["gap"][ch], fx["q_gap_bases_chimeric"]) <= 0.03, tag      # ~5 800 chimeric reads on either side: noise floor 0.02
+    # (the 1.05-segment fixture holds ~5 800 chimeric reads: noise floor 0.02; the dense one > 10^5: the 1 % gate)
+    assert ks_vs_quantiles(cm["gap"][ch], fx["q_gap_bases_chimeric"]) <= gap_gate, (tag, ks_vs_quantiles(cm["gap"][ch], fx["q_gap_bases_chimeric"]))
     mine = cm["gap"][ch].sum() / (cm["nseg"][ch] - 1).sum()
-    assert abs(mine / fx["mean_gap_bases_per_gap"] - 1.0) < 0.06, (tag, mine, fx["mean_gap_bases_per_gap"])
+    assert abs(mine / fx["mean_gap_bases_per_gap"] - 1.0) < gap_mean_tol, (tag, mine, fx["mean_gap_bases_per_gap"])
     assert ks_vs_quantiles(reads["seq_len"], fx["q_len"]) <= KS_GATE, tag
     assert ks_vs_quantiles(cm["refl"], fx["q_ref_len"]) <= KS_GATE, tag
     assert ks_vs_quantiles(reads["head"], fx["q_head"]) <= KS_GATE and ks_vs_quantiles(reads["tail"], fx["q_tail"]) <= KS_GATE, tag
@@ -155,6 +157,35 @@ def test_oracle_genome_chimeric_matches_reference(golden_distributions, small_mo
         else:
             assert ";" not in nm
     assert seen > 5
+
+
+def dense_chimeric_model(small_model, fx):
+    """the committed small model with the segment mean of tests/golden/reference_chimeric_dense.json (its only difference: the line of
+    <prefix>_chimeric_info that S:571-575 reads; make_golden.py --only-chimeric-dense)"""
+    import copy
+    m = copy.deepcopy(small_model)
+    m.segment_mean = float(fx["segment_mean"])
+    m.nseg_cdf = M.geometric_cdf(1.0 / m.segment_mean, 0)                 # np.random.geometric(1 / segment_mean), S:1277
+    return m
+
+
+@pytest.fixture(scope="module")
+def golden_chimeric_dense():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_chimeric_dense.json")) as f:
+        return json.load(f)
+
+
+def test_oracle_dense_chimeric_matches_reference_at_the_1_percent_gate(golden_chimeric_dense, small_model, small_ref):
+    """genome mode --chimeric with 2 segments per read on average: 247 000 reference reads, 123 603 of them chimeric — segment counts,
+    gap bases per chimeric read (simulation_gap, S:1552-1568) and lengths at KS <= 1 % (the 1.05-segment fixture above has too few
+    chimeric reads for that gate)"""
+    fx = golden_chimeric_dense
+    assert sum(fx["nseg_hist"][2:]) > 100000
+    m = dense_chimeric_model(small_model, fx)
+    p, out = oracle_batch(m, small_ref, n_reads=120000, chimeric=True, emit_records=False)
+    check_chimeric(out["reads"], out["pieces"], out["events"], fx, "oracle-chimeric-dense", gap_gate=KS_GATE, gap_mean_tol=0.01)
 
 
 def qual_hist_from_records(records, reads, name_len_total=None):
@@ -250,5 +281,18 @@ def test_gpu_genome_chimeric_matches_reference(golden_distributions, small_model
         p = E.make_params(seed=31337, first_read=0, n_reads=300000, chimeric=True, max_len=small_ref.max_chrom, emit_records=False)
         b = eng.generate(p)
         check_chimeric(b.reads(), b.pieces(), b.events(), golden_distributions["chimeric"], "gpu-chimeric")
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_gpu_dense_chimeric_matches_reference_at_the_1_percent_gate(golden_chimeric_dense, small_model, small_ref):
+    eng = E.Engine(0)
+    try:
+        eng.set_reference(small_ref)
+        eng.load_model(dense_chimeric_model(small_model, golden_chimeric_dense))
+        p = E.make_params(seed=271828, first_read=0, n_reads=300000, chimeric=True, max_len=small_ref.max_chrom, emit_records=False)
+        b = eng.generate(p)
+        check_chimeric(b.reads(), b.pieces(), b.events(), golden_chimeric_dense, "gpu-chimeric-dense", gap_gate=KS_GATE, gap_mean_tol=0.01)
     finally:
         eng.close()

@@ -23,16 +23,23 @@ def compare(batch, exp, params):
     reads, pieces, events = batch.reads(), batch.pieces(), batch.events()
     er, ep, ee = exp["reads"], exp["pieces"], exp["events"]
     assert len(reads) == len(er)
-    fields = ("piece_off", "n_pieces", "reversed", "flags", "head", "tail", "seq_len", "attempts")
+    fields = ("n_pieces", "reversed", "flags", "head", "tail", "seq_len", "attempts")
     for f in fields + (("rec_off",) if params.emit_records else ()):        # the oracle always formats records
         assert np.array_equal(reads[f], er[f]), f
-    assert len(pieces) == len(ep)
+    # the pieces of every read, through the read's own piece_off (a chimeric read that drew a new segment count in a later pass sits in
+    # fresh slots behind the planned ones on the GPU; the oracle files its pieces one read after the other)
+    def gather(rd, pc):
+        k = rd["n_pieces"].astype(np.int64)
+        idx = np.repeat(rd["piece_off"].astype(np.int64) - np.concatenate([[0], np.cumsum(k)[:-1]]), k) + np.arange(int(k.sum()))
+        return pc[idx]
+    gp, xp = gather(reads, pieces), gather(er, ep)
+    assert len(gp) == len(xp) == len(ep)
     for f in ("ref_gpos", "chrom", "pos", "ref_len", "out_len", "n_ev", "kind"):
-        assert np.array_equal(pieces[f], ep[f]), f
+        assert np.array_equal(gp[f], xp[f]), f
     # per-piece CIGAR: identical event lists
-    for i in range(len(pieces)):
-        g = events[int(pieces["ev_off"][i]):int(pieces["ev_off"][i]) + int(pieces["n_ev"][i])]
-        x = ee[int(ep["ev_off"][i]):int(ep["ev_off"][i]) + int(ep["n_ev"][i])]
+    for i in range(len(gp)):
+        g = events[int(gp["ev_off"][i]):int(gp["ev_off"][i]) + int(gp["n_ev"][i])]
+        x = ee[int(xp["ev_off"][i]):int(xp["ev_off"][i]) + int(xp["n_ev"][i])]
         assert np.array_equal(g["pos"], x["pos"]) and np.array_equal(g["info"], x["info"]), "events of piece %d" % i
     assert int(batch.info.events_used) == len(ee)
     assert int(batch.info.total_bases) == exp["total_bases"]
@@ -308,5 +315,44 @@ def test_many_contig_reference(small_model):
             args.update(kw)
             p = E.make_params(**args)
             compare(e.generate(p), O.generate(small_model, ref, p), p)
+    finally:
+        e.close()
+
+
+def _long_insertion_model(small_model, mean):
+    """the small model with insertion runs ~ Geometric(1 / mean) (table capped at 4095, include/nanosim_amd.h): reads whose net insertion
+    balance leaves the 18-bit shift field of ns_event become likely"""
+    import copy
+    m = copy.deepcopy(small_model)
+    cdf = 1.0 - (1.0 - 1.0 / mean) ** np.arange(1, 4096)
+    cdf[-1] = 1.0
+    m.mix_cdf[1] = [cdf.copy(), cdf.copy()]            # NS_INS
+    return m
+
+
+def test_reads_that_do_not_fit_the_event_record_are_redrawn(small_model, small_ref):
+    """An event outside the fields of the 8-byte record (shift beyond +-131071) used to fail the whole batch with NS_EINVAL; now that ATTEMPT
+    of the read is dropped and the read draws new lengths (like a failed final length check, S:1429-1430).  Same reads as the oracle,
+    which applies the same rule; thread-per-read and wave-per-read error lists agree."""
+    e = E.Engine(0)
+    try:
+        e.set_reference(small_ref)
+        m = _long_insertion_model(small_model, 150)
+        e.load_model(m)
+        p = E.make_params(seed=7, first_read=0, n_reads=150, kind=E.NS_KIND_UNALIGNED, max_len=10**7)
+        exp = O.generate(m, small_ref, p, bytes_per_read=600000, events_per_read=40000)
+        assert int((exp["reads"]["attempts"] > 0).sum()) >= 3            # (no length limit in reach: every redraw is a range redraw)
+        for background in (False, True):
+            e.set_background(background)
+            b = e.generate(p)
+            compare(b, exp, p)
+            assert 3 <= int(b.info.n_range_redraws) <= int(exp["reads"]["attempts"].sum())
+        e.set_background(False)
+        m = _long_insertion_model(small_model, 2500)
+        e.load_model(m)
+        p = E.make_params(seed=7, first_read=0, n_reads=200, max_len=small_ref.max_chrom, emit_errlog=True)
+        b = e.generate(p)
+        assert int(b.info.n_range_redraws) > 0
+        compare(b, O.generate(m, small_ref, p, bytes_per_read=400000, events_per_read=8000), p)
     finally:
         e.close()
