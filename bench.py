@@ -164,6 +164,7 @@ class Workload:
         for e in self.engs:
             e.load_model(self.mdl)
         self.max_len = min(glen, 1 << 30)
+        self.unaligned_delay_s = max(0.0, getattr(a, "unaligned_delay_ms", 0.0)) * 1e-3
 
     def split(self, n, aligned_only):
         return (n, 0) if aligned_only else self.mdl.split_counts(n)
@@ -196,7 +197,11 @@ class Workload:
         if self.eng_un is None:                                # --serial: one engine, one call after the other
             aligned(); unaligned(self.eng)
             return out
-        t = threading.Thread(target=unaligned, args=(self.eng_un,))      # (the C call releases the GIL)
+        def late_unaligned():
+            if self.unaligned_delay_s > 0:
+                time.sleep(self.unaligned_delay_s)
+            unaligned(self.eng_un)
+        t = threading.Thread(target=late_unaligned)      # (the C call releases the GIL)
         t.start(); aligned(); t.join()
         return out
 
@@ -423,6 +428,7 @@ def main():
     ap.add_argument("--no-genome-run", action="store_true", help="same as --aligned-only (kept for the profiling scripts)")
     ap.add_argument("--cpu-sample", type=int, default=5000, help="reads PER CORE of the CPU baseline sample (about 10 s with every core busy)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU test of the N>1 path)")
+    ap.add_argument("--unaligned-delay-ms", type=float, default=0.0, help="start the unaligned worker call of a step this long after the aligned one")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end legs (generation + D2H + file writes)")
     ap.add_argument("--e2e-steps", type=int, default=3)
     ap.add_argument("--e2e-dir", default="/dev/shm")

@@ -713,11 +713,18 @@ __global__ void __launch_bounds__((FASTQ && MODE != MAT_HP_SCRATCH) ? 64 * NS_MA
 k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, const uint32_t *order) {
     constexpr bool QUALS = FASTQ && MODE != MAT_HP_SCRATCH;
     constexpr uint32_t WAVES = QUALS ? NS_MATQ_WAVES : 1;
+#if NS_MAT_V6
+    __shared__ TileLds6 Ts[WAVES];
+#define NS_MAT_PIECE materialise_piece6
+    TileLds6 &T = Ts[WAVES > 1 ? threadIdx.x >> 6 : 0u];
+#else
     __shared__ TileLdsT<QUALS> Ts[WAVES];
+#define NS_MAT_PIECE materialise_piece
+    TileLdsT<QUALS> &T = Ts[WAVES > 1 ? threadIdx.x >> 6 : 0u];
+#endif
     __shared__ __align__(16) uint16_t qlut[QUALS ? NS_QLUT_SLOTS * 1024u : 8u];
     if constexpr (QUALS) { qual_lut_load(qlut, A.m, threadIdx.x, 64 * WAVES); __syncthreads(); }
     const uint32_t wave = WAVES > 1 ? threadIdx.x >> 6 : 0u;
-    TileLdsT<QUALS> &T = Ts[wave];
     const uint32_t lane = WAVES > 1 ? threadIdx.x & 63u : threadIdx.x;
     const uint64_t slot = (uint64_t)blockIdx.x * WAVES + wave;
     if (slot >= A.prm.n_reads) return;
@@ -736,7 +743,7 @@ k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, co
         uint32_t q = 0;
         for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
             const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi, ev_word);
-            materialise_piece<FASTQ, MODE>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, Q);
+            NS_MAT_PIECE<FASTQ, MODE>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, Q);
             q += pc.out_len;
         }
         return;
@@ -758,7 +765,7 @@ k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, co
             pc.sid = pc.kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
             q_in += pc.ref_len;
         } else pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi, ev_word);
-        materialise_piece<FASTQ, MODE>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, Q);
+        NS_MAT_PIECE<FASTQ, MODE>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, Q);
         if constexpr (MODE == MAT_HP_FINAL) {            // report the emitted length, like the path without -k
             if (lane == 0 && !pc.kind) A.pieces[rd.piece_off + pi].out_len = pc.out_len;
         }
@@ -1638,7 +1645,22 @@ int ns_load_model(ns_ctx *ctx, const ns_model_tables *t) {
         ct.trans = put_thr(&t->trans[0][0], 21, false);          // p < a, p < a + b            (S:1860-1864)
         ct.mix_w = put_thr(t->mix_w, 3, false);                   // tmp_rand < weight           (mm:44, 54)
         for (int ty = 0; ty < 3; ++ty)                            // p > cdf[v]: walk of the inverse-CDF tables
-            for (int c = 0; c < 2; ++c) { ct.mix_n[ty][c] = t->mix_n[ty][c]; ct.mix_cdf[ty][c] = put_thr(t->mix_cdf[ty][c], t->mix_n[ty][c], true); }
+            for (int c = 0; c < 2; ++c) {
+                ct.mix_n[ty][c] = t->mix_n[ty][c]; ct.mix_cdf[ty][c] = put_thr(t->mix_cdf[ty][c], t->mix_n[ty][c], true);
+                // guide of the walk by the number of leading one bits of the draw (the tail of a run-length CDF is geometric: a constant
+                // number of thresholds per halving of 1 - p): g[l] = thresholds at or below the smallest draw with l leading ones — a
+                // lower bound of the walk's result for every draw of that class, so the walk starts there instead of at 0
+                uint8_t g2[40] = {0};
+                const uint64_t *G = blob.data() + ct.mix_cdf[ty][c];
+                const uint32_t nn = t->mix_n[ty][c];
+                for (uint32_t l = 0; l <= 32; ++l) {
+                    const uint64_t lo_u = l == 0 ? 0ull : (0xffffffffull << (32 - l)) & 0xffffffffull;
+                    uint32_t v = 0;
+                    while (v + 1 < nn && lo_u >= G[v]) ++v;
+                    g2[l] = (uint8_t)(v > 255u ? 255u : v);
+                }
+                ct.mix_g2[ty][c] = put_raw(g2, 40);
+            }
         ct.fm_n = t->fm_nseg; ct.fm_vlo0 = t->fm_vlo0;
         ct.fm_hi = put_d(t->fm_hi, t->fm_nseg);
         { auto g = guide(t->fm_hi, t->fm_nseg); ct.fm_guide = put_raw(g.data(), 512); }

@@ -43,12 +43,11 @@ __device__ __forceinline__ int32_t run_length_t(const Tabs &T, const ChainTab &c
     const uint64_t *G = T.q(c.mix_cdf[type][comp]);
     const uint32_t n = c.mix_n[type][comp];
     const uint64_t u = u_len;
-    const uint64_t g0 = G[0], g1 = G[n > 1 ? 1 : 0];
-    uint32_t v = 0;                                          // == while (v + 1 < n && p > cdf[v]) ++v
-    if (n > 1 && u >= g0) {
-        v = 1;
-        if (n > 2 && u >= g1) { v = 2; while (v + 1 < n && u >= G[v]) ++v; }
-    }
+    // == v = 0; while (v + 1 < n && p > cdf[v]) ++v — started at the guide's lower bound for draws with this many leading one bits
+    // (every threshold below it is <= the smallest such draw): zero to two steps instead of (run length - 1) dependent LDS reads
+    const uint8_t *g2 = reinterpret_cast<const uint8_t *>(T.w + c.mix_g2[type][comp]);
+    uint32_t v = g2[(uint32_t)__clz((int)~u_len)];                             // (__clz(0) == 32: the draw 0xffffffff)
+    while (v + 1 < n && u >= G[v]) ++v;
     return (int32_t)v + 1;
 }
 
@@ -159,9 +158,13 @@ __device__ __forceinline__ EList32 chain_unaligned_error_list(const Tabs &T, con
     int32_t pend_ins = 0;
     if (m_ref <= 0) return EList32{l_new, middle_ref};
     uint32_t it = 0;
+    // what iteration `it` draws does not depend on the state of the loop: the Philox block of the NEXT iteration is evaluated under this
+    // iteration's table walk, off the critical path (as thread-per-read work the loop is pure latency: ~2 000 dependent iterations per read)
+    u32x4 w_next = ns_draw(key, ST_UEVENT, seg, attempt, 0, 0);
     while (pos < middle_ref) {
-        u32x4 w = ns_draw(key, ST_UEVENT, seg, attempt, it, 0);
+        const u32x4 w = w_next;
         ++it;
+        w_next = ns_draw(key, ST_UEVENT, seg, attempt, it, 0);
         const uint64_t ut = w.x;                                                                     // (p < t  <=>  u < ns_thr_lt(t))
         const int type = (ut < ns_thr_lt(0.4)) ? 3 : (ut < ns_thr_lt(0.7)) ? NS_MIS : (ut < ns_thr_lt(0.85)) ? NS_INS : NS_DEL;   // S:1787
         int32_t step = 1;

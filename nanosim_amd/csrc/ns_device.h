@@ -10,6 +10,7 @@ struct ChainTab {                 // offsets are in 8-byte words from the start 
     uint32_t trans;               // 21 doubles: rows start,mis,ins,del,mis0,ins0,del0 x (a, a+b, 1-c)
     uint32_t mix_w;               // 3 doubles
     uint32_t mix_cdf[3][2], mix_n[3][2];
+    uint32_t mix_g2[3][2];        // per table: 33 bytes, guide of the threshold walk by the leading one bits of the draw (run_length_t)
     uint32_t fm_hi, fm_vhi, fm_n, fm_guide;
     uint32_t fm_vhi_u, mm_vhi_u;     // the value edges once more as 32-bit integers (they are whole numbers in every trained model): what the LDS copy holds
     uint32_t n_words_lds;            // the blob up to here goes to LDS (k_chain<LDS>); the fp64 value edges behind it stay in global memory

@@ -964,3 +964,339 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
     }
     flush_chunk(ro, pend);
 }
+
+// ================================================================================================================================
+// Version 6 of the tile (round 3).  Same tiles, same events, same letters — a different COPY: instead of one lane per 16-byte chunk
+// that walks the events crossing its chunk (four predicated gathers per lane and iteration, paid by the whole wavefront whenever one
+// lane needs them), the tile's copy is cut into SUB-RUNS — maximal stretches of output bytes that lie in one chunk AND under one
+// event — and one lane copies one sub-run:
+//   * the sorted merge of the chunk starts and the event starts is never searched: chunk c is element c + (events that start at or
+//     before it), event k is element k + (chunks that start before it) — both counts fall out of the staging of the events;
+//   * element j covers [start_j, cut_{j+1}): ONE unaligned 16-byte load at the chunk's source position under the element's shift,
+//     masked to the sub-run's bytes and OR-ed into the zeroed output tile in LDS (ds_or_b64: no two sub-runs share a byte, so the
+//     OR is a store that needs no ordering); <= 128 + 63 elements = three passes of the wavefront per 2 KB tile;
+//   * the letters are byte stores into the same tile (no copy ever lies under a letter), so the final pass is: read the chunk,
+//     resolve IUPAC codes (rare), qualities, complement / reverse, one aligned 16-byte store.
+// Per tile ~250 wavefront instructions of copy machinery instead of ~590 (ablation of round 3: the copy loop was 53 % of the kernel).
+// ================================================================================================================================
+#ifndef NS_MAT_V6
+#define NS_MAT_V6 1
+#endif
+#define T6_NEL (64u * NS_TILE_CHUNKS + T_EV + 3u)
+struct __align__(16) TileLds6 {
+    uint32_t mlut[17][4];                       // mlut[i]: 16-byte mask with bytes >= i set; [16] empty
+    uint2 ent[T_EV + 1];                        // per staged event (0: the event in force at the tile start): x = first output offset copied
+                                                // under it, y = segment position minus output offset of those bytes
+    uint32_t hist[64 * NS_TILE_CHUNKS];         // build: last event at or before chunk c (+1); afterwards: the number of events at or before it
+    uint2 desc[T6_NEL];                         // elements: .x = (start - A0) | (cut - A0) << 16, .y = y
+    __align__(16) uint8_t out[T_OUT + 16 + 64]; // the tile's output bytes (zero where nothing has been written) + dump slots
+};
+__device__ __forceinline__ void tile_lds_init(TileLds6 &T, uint32_t lane) {
+    for (uint32_t c = lane * 16; c < T_OUT + 16 + 64; c += 64 * 16) *reinterpret_cast<uint4 *>(&T.out[c]) = make_uint4(0, 0, 0, 0);
+    if (lane < 17) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k)
+            T.mlut[lane][k] = lane <= 4 * k ? 0xffffffffu : lane >= 4 * k + 4 ? 0u : 0xffffffffu << (8 * (lane - 4 * k));
+    }
+}
+__device__ __forceinline__ void lds_or64(uint8_t *p, uint64_t v) {
+    __hip_atomic_fetch_or(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+template <bool FASTQ, int MODE>
+__device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, TileLds6 &T, const ReadOut &ro, const ns_key &key,
+                                          uint32_t a, const PieceCtx &pc, uint32_t pq, uint32_t lane, uint32_t dbg, const SlowQueue &sq,
+                                          uint32_t read_idx, uint32_t piece_idx, QualState &Q) {
+    constexpr bool QUALS = FASTQ && MODE != MAT_HP_SCRATCH;            // qualities are drawn in this pass
+    constexpr bool HPF = MODE == MAT_HP_FINAL;
+    uint32_t jb = 0;                       // events with out_start < M0
+    uint32_t L0_out = 0, L0_rp = 0, L0_pt = 3u << 12, L0_wd = 0, L0_j = 0;   // the event in force at M0 (synthetic start: no payload, copy from 0)
+    const uint8_t *seg0 = ref.bases + pc.chrom_base + pc.pos;           // segment position 0
+    const bool wraps = !HPF && pc.pos + pc.ref_len > pc.chrom_len;
+    const uint32_t wrap_at = wraps ? (uint32_t)(pc.chrom_len - pc.pos) : 0xffffffffu;   // first segment position beyond the origin
+    // output offsets m with m = phi (mod 16) start an aligned 16-byte group of the destination
+    const uint32_t phi = ro.reversed ? ((uint32_t)(uintptr_t)ro.seq + ro.seq_len - pq) & 15u : (0u - ((uint32_t)(uintptr_t)ro.seq + pq)) & 15u;
+    ns_event e_pre; e_pre.pos = 0; e_pre.info = 0; uint32_t w_pre = 0;
+    if (lane < pc.n_ev) { e_pre = pc.ev[lane]; w_pre = pc.wd[lane]; }
+    if constexpr (QUALS) qual_state_reset(Q);
+    // The tile whose bytes are complete in T.out and wait for their final pass (step 4): it runs UNDER the loads of the next tile
+    bool have_prev = false;
+    uint32_t A0p = 0, M0p = 0, M1p = 0;
+    // ---- 4. one lane per aligned 16-byte chunk of the tile [M0p, M1p): qualities, complement / reverse, one aligned 16-byte store
+    auto final_pass = [&]() {
+        if (!have_prev) return;
+        have_prev = false;
+#if NS_TILE_CHUNKS > 1
+#pragma nounroll
+#endif
+        for (uint32_t t = 0; t < NS_TILE_CHUNKS; ++t) {
+            const uint32_t ci = 64 * t + lane;
+            const uint32_t c0 = A0p + 16 * ci;                         // chunk origin (chunk 0 of a piece's first tile may start before M0)
+            const uint32_t lo_m = ci == 0 ? M0p : c0, hi_m = min(c0 + 16, M1p);
+            const bool active = (int32_t)(hi_m - lo_m) > 0 && !(dbg & 1);
+            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+            if (active) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(&T.out[16 * ci]);
+                *reinterpret_cast<uint4 *>(&T.out[16 * ci]) = make_uint4(0, 0, 0, 0);      // the tile is left clean for the next one
+                r0 = v.x; r1 = v.y; r2 = v.z; r3 = v.w;
+            }
+            uint32_t D[8];
+            if constexpr (QUALS) {                                     // the quality draws of the iteration (every lane takes part)
+                const uint32_t c0_first = A0p + 1024u * t;
+                const int32_t span = (int32_t)(M1p - 1u - c0_first);   // >= 0: some lane of this iteration writes bytes
+                if (span >= 0 && !(dbg & 256u)) qual_draws16(Q, key, pc.sid, a, c0, c0_first, min(64u, ((uint32_t)span >> 4) + 1u), (dbg & 128u) != 0, D);
+            }
+            if (active) {
+                uint64_t qlo = 0, qhi = 0;
+                uint32_t s0 = lo_m - c0, count = hi_m - lo_m;          // bytes [s0, s0 + count) of the chunk are this tile's
+                if constexpr (QUALS) {
+                    uint32_t cs[4];
+                    if (pc.kind) cs[0] = cs[1] = cs[2] = cs[3] = 0x18181818u;
+                    else {
+                        cs[0] = and_or(r0 >> 1, 0x10101010u, r0 & 0x08080808u); cs[1] = and_or(r1 >> 1, 0x10101010u, r1 & 0x08080808u);
+                        cs[2] = and_or(r2 >> 1, 0x10101010u, r2 & 0x08080808u); cs[3] = and_or(r3 >> 1, 0x10101010u, r3 & 0x08080808u);
+                    }
+                    if (!(dbg & 256u)) qual_lookup16(Q, m, D, cs, (dbg & 64u) != 0, qlo, qhi);
+                }
+                if constexpr (FASTQ && MODE != MAT_HP_SCRATCH) { r0 &= NS_CLS_STRIP; r1 &= NS_CLS_STRIP; r2 &= NS_CLS_STRIP; r3 &= NS_CLS_STRIP; }
+                uint64_t lo = (uint64_t)r0 | (uint64_t)r1 << 32, hi = (uint64_t)r2 | (uint64_t)r3 << 32;
+                if (s0) {                                              // front-partial chunk (first chunk of a piece): shift down
+                    const uint32_t sh = 8 * s0;
+                    if (sh < 64) { lo = (lo >> sh) | (hi << (64 - sh)); hi >>= sh; qlo = (qlo >> sh) | (qhi << (64 - sh)); qhi >>= sh; }
+                    else { lo = hi >> (sh - 64); hi = 0; qlo = qhi >> (sh - 64); qhi = 0; }
+                }
+                if (!(dbg & 16)) { PendingChunk pd = prep_chunk(ro, pq + lo_m, count, lo, hi, qlo, qhi); flush_chunk(ro, pd); }
+            }
+        }
+    };
+    for (uint32_t M0 = 0; M0 < pc.out_len;) {
+        const uint32_t A0 = M0 - ((M0 - phi) & 15u);             // aligned origin of the tile (<= M0; may be "negative" = wrapped)
+        uint32_t M1 = min(A0 + T_OUT, pc.out_len);
+        // ---- 1. events of the tile
+        const ns_event e = e_pre;
+        const uint32_t e_wd = w_pre;
+        const bool valid = jb + lane < pc.n_ev;
+        const uint32_t os = ev_out_start(e), len = ns_ev_len(e.info), ty = ns_ev_type(e.info);
+        const uint32_t e_pt = (ty == NS_DEL ? 0u : len) | ty << 12, e_rp = e.pos + (ty == NS_INS ? 0u : len);
+        if (jb + 63 < pc.n_ev) {
+            const uint32_t os63 = (uint32_t)__builtin_amdgcn_readlane((int)os, 63);
+            if (os63 < M1) M1 = os63;
+        }
+        const bool take = valid && os < M1;
+        const uint32_t cnt = (uint32_t)__popcll(__ballot(take));
+        if (M1 <= M0) {                    // 64 events at one output offset (zero-length matches between deletions): not a case
+            final_pass();                  // for the tile machinery; the generic path takes the tile
+            wave_sync();
+            M1 = min(M0 + T_OUT, pc.out_len);
+            uint32_t j2 = jb;
+            while (j2 < pc.n_ev && ev_out_start(pc.ev[j2]) < M1) ++j2;
+            if (lane == 0) {
+                const uint32_t slot = atomicAdd(sq.count, 1u);
+                if (slot < sq.cap) sq.items[slot] = SlowTile{read_idx, piece_idx, M0, M1};
+            }
+            if (j2 > jb) {
+                const ns_event le = pc.ev[j2 - 1];
+                const uint32_t ll = ns_ev_len(le.info), lt = ns_ev_type(le.info);
+                L0_out = uni(ev_out_start(le)); L0_pt = uni((lt == NS_DEL ? 0u : ll) | lt << 12); L0_rp = uni(le.pos + (lt == NS_INS ? 0u : ll));
+                L0_wd = uni(pc.wd[j2 - 1]); L0_j = uni(j2 - 1);
+            }
+            jb = uni(j2); M0 = M1;
+            if constexpr (QUALS) qual_state_reset(Q);
+            e_pre.pos = 0; e_pre.info = 0; w_pre = 0;
+            if (jb + lane < pc.n_ev) { e_pre = pc.ev[jb + lane]; w_pre = pc.wd[jb + lane]; }
+            continue;
+        }
+        const uint32_t nc = (M1 - A0 + 15u) >> 4;                 // chunks of the tile (chunk 0 starts at M0, chunk c > 0 at A0 + 16 c)
+        const uint32_t nel = nc + cnt;                            // elements: chunk starts + event starts
+        // chunk an event sorts in front of: the first one that starts at or after it (an event AT a chunk start comes first, so the
+        // chunk already copies under it)
+        const uint32_t ekey = take ? (os <= M0 ? 0u : (os - A0 + 15u) >> 4) : 0xffffffffu;
+        {
+            const uint32_t s0 = L0_out + (L0_pt & 0xfffu);
+            T.ent[0] = make_uint2(s0, L0_rp - s0);                // (every lane, same value)
+            if (take) {
+                const uint32_t s1 = os + (e_pt & 0xfffu), y1 = e_rp - s1;
+                T.ent[1 + lane] = make_uint2(s1, y1);
+                T.desc[lane + ekey] = make_uint2((min(s1, M1) - A0) | (os - A0) << 16, y1);
+            }
+            T.desc[nel] = make_uint2((M1 - A0) | (M1 - A0) << 16, 0u);          // sentinel: the last sub-run ends at M1
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < NS_TILE_CHUNKS; ++t) T.hist[64 * t + lane] = 0;
+        const uint32_t jb_next = jb + cnt;
+        e_pre.pos = 0; e_pre.info = 0; w_pre = 0;
+        if (M1 < pc.out_len && jb_next + lane < pc.n_ev) { e_pre = pc.ev[jb_next + lane]; w_pre = pc.wd[jb_next + lane]; }   // prefetch for the next tile
+        wave_sync();
+        {   // hist[c] = number of the tile's events sorted in front of chunk c — written by the LAST one (sorted events: lane l is event l + 1
+            // of the tile), the chunks in between inherit it through a prefix maximum
+            const uint32_t c_next = dpp_wave_shl1(0xffffffffu, ekey);
+            if (ekey < 64 * NS_TILE_CHUNKS && ekey != c_next) T.hist[ekey] = lane + 1u;
+        }
+        // ---- the event in force at M1 (wave-uniform): the last one taken, straight from its lane's registers
+        uint32_t osl = L0_out, ptl = L0_pt, rpl = L0_rp, wdl = L0_wd, jl = L0_j;
+        if (cnt) {
+            osl = (uint32_t)__builtin_amdgcn_readlane((int)os, (int)(cnt - 1));
+            ptl = (uint32_t)__builtin_amdgcn_readlane((int)e_pt, (int)(cnt - 1));
+            rpl = (uint32_t)__builtin_amdgcn_readlane((int)e_rp, (int)(cnt - 1));
+            wdl = (uint32_t)__builtin_amdgcn_readlane((int)e_wd, (int)(cnt - 1));
+            jl = jb + cnt - 1;
+        }
+        const uint8_t *tb = seg0 - 32;                             // + 32 in the lane offsets: they never go negative
+        bool fast = true;
+        if (wraps) {                                               // reference span of the tile only matters next to the origin
+            const uint32_t pl0 = L0_pt & 0xfffu, ty0 = L0_pt >> 12, d0 = M0 - L0_out;
+            const uint32_t x0 = (d0 < pl0 && ty0 == NS_INS) ? L0_rp : L0_rp + d0 - pl0;
+            const uint32_t pll = ptl & 0xfffu, dl = M1 - osl;
+            uint32_t x1 = dl <= pll ? rpl : rpl + (dl - pll);
+            if (x1 < x0) x1 = x0;
+            if (x0 >= wrap_at) tb -= pc.chrom_len;                 // whole tile beyond the origin
+            else if (x1 > wrap_at) fast = false;                   // tile straddles the origin
+        }
+        if (!fast) {
+            final_pass();
+            if (lane == 0) {
+                const uint32_t slot = atomicAdd(sq.count, 1u);
+                if (slot < sq.cap) sq.items[slot] = SlowTile{read_idx, piece_idx, M0, M1};
+            }
+            L0_out = osl; L0_rp = rpl; L0_pt = ptl; L0_wd = wdl; L0_j = jl;
+            jb = jb_next; M0 = M1;
+            if constexpr (QUALS) qual_state_reset(Q);
+            wave_sync();
+            continue;
+        }
+        wave_sync();
+        // ---- 3a. the chunk elements: chunk c is element c + (events in front of it), it copies under the last of those events
+        {
+            uint32_t scan_base = 0;
+#pragma unroll
+            for (uint32_t t = 0; t < NS_TILE_CHUNKS; ++t) {
+                const uint32_t ci = 64 * t + lane;
+                const uint32_t incl = max(scan_base, wave_incl_max(T.hist[ci]));
+                scan_base = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                if (ci < nc) {
+                    const uint32_t p = ci == 0 ? M0 : A0 + 16u * ci;
+                    const uint2 E = T.ent[incl];
+                    T.desc[ci + incl] = make_uint2((min(max(p, E.x), M1) - A0) | (p - A0) << 16, E.y);
+                }
+            }
+        }
+        wave_sync();
+        // ---- 3b. one lane per sub-run: element j copies [start_j, cut_(j+1)).  All loads of the tile are issued here; they travel while
+        // the PREVIOUS tile gets its final pass and this tile its letters
+        uint4 f[3]; uint32_t i0[3], i1[3], oc[3];
+#pragma unroll
+        for (uint32_t ps = 0; ps < 3; ++ps) {
+            const uint32_t j = 64u * ps + lane;
+            f[ps] = make_uint4(0, 0, 0, 0); i0[ps] = 16; i1[ps] = 16; oc[ps] = 0;
+            if (!(dbg & 1) && 64u * ps < nel && j < nel) {
+                const uint2 d0 = T.desc[j];
+                const uint32_t nx = T.desc[j + 1].x;
+                const uint32_t st = d0.x & 0xffffu, en = nx >> 16;
+                if (en > st) {
+                    const uint32_t c = st >> 4;                          // (relative to A0: the chunk of the sub-run)
+                    oc[ps] = 16u * c; i0[ps] = st - 16u * c; i1[ps] = en - 16u * c;
+                    __builtin_memcpy(&f[ps], tb + (d0.y + A0 + 16u * c + 32u), 16);
+                }
+            }
+        }
+        final_pass();                                              // the previous tile: reads and clears T.out
+        wave_sync();
+        // ---- 2. letters: lane per event; lane 63 (never a taker) continues the payload of the event in force at M0
+        if (!(dbg & 2)) {
+            const bool cont = lane == 63 && L0_out + (L0_pt & 0xfffu) > M0;
+            const uint32_t b_os = cont ? L0_out : os, b_pt = cont ? L0_pt : e_pt, b_rp = cont ? L0_rp : e_rp;
+            const uint32_t b_j = cont ? L0_j : jb + lane;
+            uint32_t frac = cont ? L0_wd : e_wd;
+            const uint32_t b_pl = b_pt & 0xfffu, b_ty = b_pt >> 12;
+            const bool on = (take || cont) && b_pl;
+            const uint32_t xs = b_rp - b_pl;                      // segment position under the first substituted base
+            // fast path (branch-free): up to four letters, all inside the tile, plain bases under a substitution
+            const bool mis = b_ty == NS_MIS;
+            bool fast_l = on && b_pl <= 4 && b_os >= M0 && b_os + b_pl <= M1 && !wraps;
+            uint32_t cur4 = 0x41414141u;
+            if (fast_l && mis) __builtin_memcpy(&cur4, seg0 + xs, 4);
+            if constexpr (!HPF) fast_l = fast_l && !(cur4 & 0x80808080u);
+            if (fast_l) {
+                const uint32_t x8 = frac & 0xffu, t8 = (x8 | x8 << 12) & 0x000f000fu;
+                const uint32_t ins4 = __builtin_amdgcn_perm(0u, 0x47435441u, (t8 | t8 << 6) & 0x03030303u);          // S:1990
+                uint32_t f3 = frac;
+                const uint32_t d0 = next_digit3(f3), d1 = next_digit3(f3), d2 = next_digit3(f3), d3 = next_digit3(f3);
+                const uint32_t d4 = d0 | d1 << 8 | d2 << 16 | d3 << 24;
+                const uint32_t vv = (cur4 >> 1) & 0x03030303u;                           // A 0, C 1, T 2, G 3
+                const uint32_t rank4 = (vv & 0x01010101u) << 1 | ((vv >> 1) & 0x01010101u);   // rank in "ATCG": A 0, T 1, C 2, G 3
+                const uint32_t ge = ((d4 | 0x80808080u) - rank4) & 0x80808080u;          // per byte: digit >= rank
+                const uint32_t mis4 = __builtin_amdgcn_perm(0u, 0x47435441u, d4 + (ge >> 7));                        // S:1968-1972
+                uint32_t letters = mis ? mis4 : ins4;
+                if constexpr (FASTQ) {                             // the quality class travels with the letter
+                    uint32_t cls4 = mis ? 0x01010101u * NS_CLS_MIS_BIT : 0x01010101u * NS_CLS_INS_BIT;
+                    if constexpr (HPF) {
+                        if (mis) cls4 = (frac & 1u) ? NS_CLS_MIS_BIT : (cur4 & (NS_CLS_MIS_BIT | NS_CLS_INS_BIT));
+                        else if (frac >> 31) cls4 = (cls4 & ~0xffu) | NS_CLS_MIS_BIT;
+                    }
+                    letters |= cls4;
+                }
+                const uint32_t o = b_os - A0, dump = T_DUMP + lane;
+                const uint32_t o1 = b_pl > 1 ? o + 1 : dump, o2 = b_pl > 2 ? o + 2 : dump, o3 = b_pl > 3 ? o + 3 : dump;
+                T.out[o] = (uint8_t)letters; T.out[o1] = (uint8_t)(letters >> 8); T.out[o2] = (uint8_t)(letters >> 16); T.out[o3] = (uint8_t)(letters >> 24);
+            }
+            if (on && !fast_l) {                                  // long payloads, tile borders, IUPAC under a substitution, the origin
+                const uint32_t i_lo = b_os < M0 ? M0 - b_os : 0u;
+                const uint32_t i_hi = min(b_pl, M1 - b_os);
+                const uint32_t word0 = frac;
+                for (uint32_t i = 0; i < i_hi; ++i) {
+                    if (i && !(i & 15)) frac = payload_word(key, pc.sid, a, b_j, i >> 4);
+                    uint32_t b;
+                    if (b_ty == NS_INS) {
+                        b = bases_atcg((frac >> (2 * (i & 15))) & 3u);
+                        if constexpr (FASTQ) b |= (HPF && i == 0 && (word0 >> 31)) ? NS_CLS_MIS_BIT : NS_CLS_INS_BIT;
+                    } else {
+                        const uint32_t x = xs + i;
+                        const uint32_t src = ref_base_at(ref, pc, x);
+                        if constexpr (HPF) {
+                            b = mis_from_digit(src & ~(NS_CLS_MIS_BIT | NS_CLS_INS_BIT), next_digit3(frac));
+                            if constexpr (FASTQ) b |= (word0 & 1u) ? NS_CLS_MIS_BIT : (src & (NS_CLS_MIS_BIT | NS_CLS_INS_BIT));
+                        } else {
+                            b = mis_from_digit(resolve_base(src, key, pc.sid, a, x), next_digit3(frac));
+                            if constexpr (FASTQ) b |= NS_CLS_MIS_BIT;
+                        }
+                    }
+                    if (i >= i_lo) T.out[b_os + i - A0] = (uint8_t)b;
+                }
+            }
+            // the dump slots collect predicated-off letter bytes: cleared so that the tile stays zero outside its bytes
+        }
+        // ---- 3c. the sub-runs arrive: masked to their bytes, IUPAC codes resolved (case_convert, S:743-755: rare), OR-ed into the tile
+#pragma unroll
+        for (uint32_t ps = 0; ps < 3; ++ps) {
+            if (64u * ps < nel && i0[ps] < 16u) {
+                const uint4 m0 = *reinterpret_cast<const uint4 *>(&T.mlut[i0[ps]][0]), m1 = *reinterpret_cast<const uint4 *>(&T.mlut[i1[ps]][0]);
+                uint32_t a0 = f[ps].x & m0.x & ~m1.x, a1 = f[ps].y & m0.y & ~m1.y, a2 = f[ps].z & m0.z & ~m1.z, a3 = f[ps].w & m0.w & ~m1.w;
+                if constexpr (!HPF) {
+                    if ((a0 | a1 | a2 | a3) & 0x80808080u) {
+                        const uint32_t y = T.desc[64u * ps + lane].y;
+                        for (uint32_t b = i0[ps]; b < i1[ps]; ++b) {
+                            uint32_t wk = b < 8 ? (b < 4 ? a0 : a1) : (b < 12 ? a2 : a3);
+                            const uint32_t ch = (wk >> (8 * (b & 3))) & 0xff;
+                            if (!(ch & 0x80u)) continue;
+                            const uint32_t x = A0 + oc[ps] + b + y;              // segment position of the byte
+                            const uint32_t r = resolve_base(ch, key, pc.sid, a, x);
+                            wk = (wk & ~(0xffu << (8 * (b & 3)))) | r << (8 * (b & 3));
+                            if (b < 4) a0 = wk; else if (b < 8) a1 = wk; else if (b < 12) a2 = wk; else a3 = wk;
+                        }
+                    }
+                }
+                lds_or64(&T.out[oc[ps]], (uint64_t)a0 | (uint64_t)a1 << 32);
+                lds_or64(&T.out[oc[ps] + 8], (uint64_t)a2 | (uint64_t)a3 << 32);
+            }
+        }
+        L0_out = osl; L0_rp = rpl; L0_pt = ptl; L0_wd = wdl; L0_j = jl;
+        have_prev = true; A0p = A0; M0p = M0; M1p = M1;
+        jb = jb_next; M0 = M1;
+        wave_sync();
+        // the kernels that draw qualities have no registers to carry a tile's loads across the final pass of the tile before (they
+        // spill: FASTQ 15.8 -> 16.4 ms): their final pass follows at once
+        if constexpr (QUALS) { final_pass(); wave_sync(); }
+    }
+    final_pass();
+    wave_sync();
+}
