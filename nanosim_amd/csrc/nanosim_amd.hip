@@ -1784,12 +1784,16 @@ static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fast
         HIPCHK(hipGetLastError());
         return NS_OK;
     }
+#if !NS_MAT_V6
     if (mode != MAT_HP_FINAL) {               // (the second pass of -k takes its letter words from k_hp_drain)
         int rc = ensure(ctx, ctx->ev_word, ((size_t)event_slots + 8) * 4);
         if (rc) return rc;
         k_words<<<dim3((unsigned)n), dim3(64), 0, st>>>(A, (uint32_t *)ctx->ev_word.p);
         HIPCHK(hipGetLastError());
     }
+#else
+    (void)event_slots;                        // (v6 draws the letter words in the tile prologue: event_word)
+#endif
     if (names_done) HIPCHK(hipStreamWaitEvent(st, names_done, 0));      // k_names ran next to k_words on the second stream
     for (int round = 0;; ++round) {
         size_t cap = ctx->slow_q.cap >= 16 + sizeof(SlowTile) ? (ctx->slow_q.cap - 16) / sizeof(SlowTile) : 0;

@@ -1003,6 +1003,14 @@ __device__ __forceinline__ void lds_or64(uint8_t *p, uint64_t v) {
     __hip_atomic_fetch_or(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
+// letter word of event j of the piece: word(j) = Philox(ST_SUB, seg, attempt, idx = j >> 2).w[j & 3].  The record
+// kernel draws it where it stages the events (one block per lane and tile: a k_words pass that wrote the words for the next kernel to
+// read back cost 0.65 ms and 1.4 KB of traffic per read); the second pass of -k takes the words k_hp_drain filed with its edits.
+template <int MODE>
+__device__ __forceinline__ uint32_t event_word(const PieceCtx &pc, const ns_key &key, uint32_t a, uint32_t j) {
+    if constexpr (MODE == MAT_HP_FINAL) return pc.wd[j];
+    else { const u32x4 w = ns_draw(key, ST_SUB, pc.sid, a, j >> 2, 0); return ns_word(w, j & 3u); }
+}
 template <bool FASTQ, int MODE>
 __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, TileLds6 &T, const ReadOut &ro, const ns_key &key,
                                           uint32_t a, const PieceCtx &pc, uint32_t pq, uint32_t lane, uint32_t dbg, const SlowQueue &sq,
@@ -1017,7 +1025,8 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
     // output offsets m with m = phi (mod 16) start an aligned 16-byte group of the destination
     const uint32_t phi = ro.reversed ? ((uint32_t)(uintptr_t)ro.seq + ro.seq_len - pq) & 15u : (0u - ((uint32_t)(uintptr_t)ro.seq + pq)) & 15u;
     ns_event e_pre; e_pre.pos = 0; e_pre.info = 0; uint32_t w_pre = 0;
-    if (lane < pc.n_ev) { e_pre = pc.ev[lane]; w_pre = pc.wd[lane]; }
+    if (lane < pc.n_ev) e_pre = pc.ev[lane];
+    w_pre = event_word<MODE>(pc, key, a, lane < pc.n_ev ? lane : 0u);
     if constexpr (QUALS) qual_state_reset(Q);
     // The tile whose bytes are complete in T.out and wait for their final pass (step 4): it runs UNDER the loads of the next tile
     bool have_prev = false;
@@ -1078,9 +1087,12 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
         const bool valid = jb + lane < pc.n_ev;
         const uint32_t os = ev_out_start(e), len = ns_ev_len(e.info), ty = ns_ev_type(e.info);
         const uint32_t e_pt = (ty == NS_DEL ? 0u : len) | ty << 12, e_rp = e.pos + (ty == NS_INS ? 0u : len);
-        if (jb + 63 < pc.n_ev) {
-            const uint32_t os63 = (uint32_t)__builtin_amdgcn_readlane((int)os, 63);
-            if (os63 < M1) M1 = os63;
+        if (jb + 63 < pc.n_ev) {           // more events than lanes: the tile ends early — on a CHUNK boundary, so that the next tile starts on one
+            const uint32_t os63 = (uint32_t)__builtin_amdgcn_readlane((int)os, 63);     // (a tile cut inside a chunk gives this tile a partial last
+            if (os63 < M1) {                                                             // chunk and the next one a partial first chunk: the partial
+                const uint32_t cut = A0 + ((os63 - A0) & ~15u);                          // store path then runs in every iteration of the final pass)
+                M1 = cut > M0 ? cut : os63;
+            }
         }
         const bool take = valid && os < M1;
         const uint32_t cnt = (uint32_t)__popcll(__ballot(take));
@@ -1098,12 +1110,13 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
                 const ns_event le = pc.ev[j2 - 1];
                 const uint32_t ll = ns_ev_len(le.info), lt = ns_ev_type(le.info);
                 L0_out = uni(ev_out_start(le)); L0_pt = uni((lt == NS_DEL ? 0u : ll) | lt << 12); L0_rp = uni(le.pos + (lt == NS_INS ? 0u : ll));
-                L0_wd = uni(pc.wd[j2 - 1]); L0_j = uni(j2 - 1);
+                L0_wd = uni(event_word<MODE>(pc, key, a, j2 - 1)); L0_j = uni(j2 - 1);
             }
             jb = uni(j2); M0 = M1;
             if constexpr (QUALS) qual_state_reset(Q);
             e_pre.pos = 0; e_pre.info = 0; w_pre = 0;
-            if (jb + lane < pc.n_ev) { e_pre = pc.ev[jb + lane]; w_pre = pc.wd[jb + lane]; }
+            if (jb + lane < pc.n_ev) e_pre = pc.ev[jb + lane];
+            w_pre = event_word<MODE>(pc, key, a, jb + lane < pc.n_ev ? jb + lane : 0u);
             continue;
         }
         const uint32_t nc = (M1 - A0 + 15u) >> 4;                 // chunks of the tile (chunk 0 starts at M0, chunk c > 0 at A0 + 16 c)
@@ -1125,7 +1138,8 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
         for (uint32_t t = 0; t < NS_TILE_CHUNKS; ++t) T.hist[64 * t + lane] = 0;
         const uint32_t jb_next = jb + cnt;
         e_pre.pos = 0; e_pre.info = 0; w_pre = 0;
-        if (M1 < pc.out_len && jb_next + lane < pc.n_ev) { e_pre = pc.ev[jb_next + lane]; w_pre = pc.wd[jb_next + lane]; }   // prefetch for the next tile
+        if (M1 < pc.out_len && jb_next + lane < pc.n_ev) e_pre = pc.ev[jb_next + lane];       // prefetch for the next tile
+        if (M1 < pc.out_len) w_pre = event_word<MODE>(pc, key, a, jb_next + lane < pc.n_ev ? jb_next + lane : 0u);
         wave_sync();
         {   // hist[c] = number of the tile's events sorted in front of chunk c — written by the LAST one (sorted events: lane l is event l + 1
             // of the tile), the chunks in between inherit it through a prefix maximum
@@ -1173,7 +1187,7 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
                 const uint32_t ci = 64 * t + lane;
                 const uint32_t incl = max(scan_base, wave_incl_max(T.hist[ci]));
                 scan_base = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                if (ci < nc) {
+                if (ci < nc && !(dbg & 8192u)) {
                     const uint32_t p = ci == 0 ? M0 : A0 + 16u * ci;
                     const uint2 E = T.ent[incl];
                     T.desc[ci + incl] = make_uint2((min(max(p, E.x), M1) - A0) | (p - A0) << 16, E.y);
@@ -1210,34 +1224,40 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
             const uint32_t b_pl = b_pt & 0xfffu, b_ty = b_pt >> 12;
             const bool on = (take || cont) && b_pl;
             const uint32_t xs = b_rp - b_pl;                      // segment position under the first substituted base
-            // fast path (branch-free): up to four letters, all inside the tile, plain bases under a substitution
+            // fast path (branch-free): up to EIGHT letters, all inside the tile, plain bases under a substitution (with four, two tiles in
+            // five had an event for the per-byte loop below; run lengths beyond eight are one event in three hundred)
             const bool mis = b_ty == NS_MIS;
-            bool fast_l = on && b_pl <= 4 && b_os >= M0 && b_os + b_pl <= M1 && !wraps;
-            uint32_t cur4 = 0x41414141u;
-            if (fast_l && mis) __builtin_memcpy(&cur4, seg0 + xs, 4);
-            if constexpr (!HPF) fast_l = fast_l && !(cur4 & 0x80808080u);
+            bool fast_l = on && b_pl <= 8 && b_os >= M0 && b_os + b_pl <= M1 && !wraps;
+            uint2 cur8 = make_uint2(0x41414141u, 0x41414141u);
+            if (fast_l && mis) __builtin_memcpy(&cur8, seg0 + xs, 8);
+            if constexpr (!HPF) fast_l = fast_l && !((cur8.x | cur8.y) & 0x80808080u);
             if (fast_l) {
-                const uint32_t x8 = frac & 0xffu, t8 = (x8 | x8 << 12) & 0x000f000fu;
-                const uint32_t ins4 = __builtin_amdgcn_perm(0u, 0x47435441u, (t8 | t8 << 6) & 0x03030303u);          // S:1990
                 uint32_t f3 = frac;
-                const uint32_t d0 = next_digit3(f3), d1 = next_digit3(f3), d2 = next_digit3(f3), d3 = next_digit3(f3);
-                const uint32_t d4 = d0 | d1 << 8 | d2 << 16 | d3 << 24;
-                const uint32_t vv = (cur4 >> 1) & 0x03030303u;                           // A 0, C 1, T 2, G 3
-                const uint32_t rank4 = (vv & 0x01010101u) << 1 | ((vv >> 1) & 0x01010101u);   // rank in "ATCG": A 0, T 1, C 2, G 3
-                const uint32_t ge = ((d4 | 0x80808080u) - rank4) & 0x80808080u;          // per byte: digit >= rank
-                const uint32_t mis4 = __builtin_amdgcn_perm(0u, 0x47435441u, d4 + (ge >> 7));                        // S:1968-1972
-                uint32_t letters = mis ? mis4 : ins4;
-                if constexpr (FASTQ) {                             // the quality class travels with the letter
-                    uint32_t cls4 = mis ? 0x01010101u * NS_CLS_MIS_BIT : 0x01010101u * NS_CLS_INS_BIT;
-                    if constexpr (HPF) {
-                        if (mis) cls4 = (frac & 1u) ? NS_CLS_MIS_BIT : (cur4 & (NS_CLS_MIS_BIT | NS_CLS_INS_BIT));
-                        else if (frac >> 31) cls4 = (cls4 & ~0xffu) | NS_CLS_MIS_BIT;
-                    }
-                    letters |= cls4;
-                }
                 const uint32_t o = b_os - A0, dump = T_DUMP + lane;
-                const uint32_t o1 = b_pl > 1 ? o + 1 : dump, o2 = b_pl > 2 ? o + 2 : dump, o3 = b_pl > 3 ? o + 3 : dump;
-                T.out[o] = (uint8_t)letters; T.out[o1] = (uint8_t)(letters >> 8); T.out[o2] = (uint8_t)(letters >> 16); T.out[o3] = (uint8_t)(letters >> 24);
+#pragma unroll
+                for (uint32_t g = 0; g < 2; ++g) {
+                    const uint32_t cur4 = g ? cur8.y : cur8.x;
+                    const uint32_t x8 = (frac >> (8u * g)) & 0xffu, t8 = (x8 | x8 << 12) & 0x000f000fu;
+                    const uint32_t ins4 = __builtin_amdgcn_perm(0u, 0x47435441u, (t8 | t8 << 6) & 0x03030303u);          // S:1990
+                    const uint32_t d0 = next_digit3(f3), d1 = next_digit3(f3), d2 = next_digit3(f3), d3 = next_digit3(f3);
+                    const uint32_t d4 = d0 | d1 << 8 | d2 << 16 | d3 << 24;
+                    const uint32_t vv = (cur4 >> 1) & 0x03030303u;                           // A 0, C 1, T 2, G 3
+                    const uint32_t rank4 = (vv & 0x01010101u) << 1 | ((vv >> 1) & 0x01010101u);   // rank in "ATCG": A 0, T 1, C 2, G 3
+                    const uint32_t ge = ((d4 | 0x80808080u) - rank4) & 0x80808080u;          // per byte: digit >= rank
+                    const uint32_t mis4 = __builtin_amdgcn_perm(0u, 0x47435441u, d4 + (ge >> 7));                        // S:1968-1972
+                    uint32_t letters = mis ? mis4 : ins4;
+                    if constexpr (FASTQ) {                             // the quality class travels with the letter
+                        uint32_t cls4 = mis ? 0x01010101u * NS_CLS_MIS_BIT : 0x01010101u * NS_CLS_INS_BIT;
+                        if constexpr (HPF) {
+                            if (mis) cls4 = (frac & 1u) ? NS_CLS_MIS_BIT : (cur4 & (NS_CLS_MIS_BIT | NS_CLS_INS_BIT));
+                            else if (g == 0 && (frac >> 31)) cls4 = (cls4 & ~0xffu) | NS_CLS_MIS_BIT;
+                        }
+                        letters |= cls4;
+                    }
+                    const uint32_t q0 = 4u * g;
+                    const uint32_t p0 = b_pl > q0 ? o + q0 : dump, p1 = b_pl > q0 + 1 ? o + q0 + 1 : dump, p2 = b_pl > q0 + 2 ? o + q0 + 2 : dump, p3 = b_pl > q0 + 3 ? o + q0 + 3 : dump;
+                    T.out[p0] = (uint8_t)letters; T.out[p1] = (uint8_t)(letters >> 8); T.out[p2] = (uint8_t)(letters >> 16); T.out[p3] = (uint8_t)(letters >> 24);
+                }
             }
             if (on && !fast_l) {                                  // long payloads, tile borders, IUPAC under a substitution, the origin
                 const uint32_t i_lo = b_os < M0 ? M0 - b_os : 0u;
@@ -1268,7 +1288,7 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
         // ---- 3c. the sub-runs arrive: masked to their bytes, IUPAC codes resolved (case_convert, S:743-755: rare), OR-ed into the tile
 #pragma unroll
         for (uint32_t ps = 0; ps < 3; ++ps) {
-            if (64u * ps < nel && i0[ps] < 16u) {
+            if (64u * ps < nel && i0[ps] < 16u && !(dbg & 32u)) {
                 const uint4 m0 = *reinterpret_cast<const uint4 *>(&T.mlut[i0[ps]][0]), m1 = *reinterpret_cast<const uint4 *>(&T.mlut[i1[ps]][0]);
                 uint32_t a0 = f[ps].x & m0.x & ~m1.x, a1 = f[ps].y & m0.y & ~m1.y, a2 = f[ps].z & m0.z & ~m1.z, a3 = f[ps].w & m0.w & ~m1.w;
                 if constexpr (!HPF) {
