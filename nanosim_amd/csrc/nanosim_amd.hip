@@ -9,7 +9,6 @@
 //   -k: k_hp_filter_w, k_materialise<., MAT_HP_SCRATCH>, k_hp_scan, k_hp_drain, k_hp_finalize  (ns_hp.h; S:1920-1947, 618-705)
 //   scans               rocPRIM       record / error-profile offsets
 //   k_names             thread/read   ">name\n", "+\n" framing                              (S:1390-1402, 1437-1443)
-//   k_words             wave/read     the letter word of every event
 //   k_materialise       wave/read     case_convert + mutate_read + head/tail + revcomp (+ qualities)   (S:743-755, 1919-2015, 1421-1435)
 //   k_materialise_dense wave/segment  the same for unaligned reads and gaps (0.55 events per base)
 //   k_errlog            wave/read     _aligned_error_profile rows                           (S:2006-2008)
@@ -665,7 +664,8 @@ __global__ void __launch_bounds__(64 * NS_WPB) k_ir_splice(GenArgs A) {
 __device__ __forceinline__ bool load_read_uniform(const GenArgs &A, uint64_t r, bool fastq, ns_read &rd, ns_key &key, ReadOut &ro) {
     rd = A.reads[r];
     if (rd.flags) return false;
-    rd.rec_off = uni64(rd.rec_off); rd.piece_off = uni(rd.piece_off); rd.n_pieces = (uint16_t)uni(rd.n_pieces);
+    rd.rec_off = uni64(A.rec_off[r]);        // (the scan's value: k_names, which files it in the read, may still be running)
+    rd.piece_off = uni(rd.piece_off); rd.n_pieces = (uint16_t)uni(rd.n_pieces);
     rd.reversed = (uint8_t)uni(rd.reversed); rd.head = uni(rd.head); rd.tail = uni(rd.tail); rd.seq_len = uni(rd.seq_len);
     rd.attempts = uni(rd.attempts);
     key = read_key(A, r);
@@ -674,25 +674,6 @@ __device__ __forceinline__ bool load_read_uniform(const GenArgs &A, uint64_t r, 
     ro.qual = fastq ? ro.seq + rd.seq_len + 3 : nullptr;
     ro.seq_len = rd.seq_len; ro.reversed = rd.reversed != 0; ro.uracil = A.prm.uracil != 0;
     return true;
-}
-
-// k_words: the letter word of every event, word(j) = Philox(ST_SUB, seg, attempt, idx = j >> 2).w[j & 3]: one
-// Philox block per lane and 4 events, dense; k_materialise reads the word next to the event.
-__global__ void __launch_bounds__(64) k_words(GenArgs A, uint32_t *ev_word) {
-    const uint32_t lane = threadIdx.x;
-    const uint64_t r = blockIdx.x;
-    ns_read rd; ns_key key; ReadOut ro;
-    if (!load_read_uniform(A, r, false, rd, key, ro)) return;
-    for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
-        const ns_piece p = A.pieces[rd.piece_off + pi];
-        const uint32_t n_ev = uni(p.n_ev), sid = uni(p.kind) ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
-        uint32_t *dst = ev_word + uni64(p.ev_off);
-        for (uint32_t j0 = 4 * lane; j0 < n_ev; j0 += 256) {
-            const u32x4 w = ns_draw(key, ST_SUB, sid, rd.attempts, j0 >> 2, 0);
-            if (j0 + 4 <= n_ev) { struct __attribute__((packed)) V { uint32_t a, b, c, d; } v{w.x, w.y, w.z, w.w}; __builtin_memcpy(dst + j0, &v, 16); }
-            else for (uint32_t k = 0; j0 + k < n_ev; ++k) dst[j0 + k] = ns_word(w, k);
-        }
-    }
 }
 
 // k_materialise: the sequence (and quality) line of one read per wavefront; see ns_materialise.h.  The FASTQ kernel runs NS_MATQ_WAVES
@@ -713,15 +694,8 @@ __global__ void __launch_bounds__((FASTQ && MODE != MAT_HP_SCRATCH) ? 64 * NS_MA
 k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, const uint32_t *order) {
     constexpr bool QUALS = FASTQ && MODE != MAT_HP_SCRATCH;
     constexpr uint32_t WAVES = QUALS ? NS_MATQ_WAVES : 1;
-#if NS_MAT_V6
     __shared__ TileLds6 Ts[WAVES];
-#define NS_MAT_PIECE materialise_piece6
     TileLds6 &T = Ts[WAVES > 1 ? threadIdx.x >> 6 : 0u];
-#else
-    __shared__ TileLdsT<QUALS> Ts[WAVES];
-#define NS_MAT_PIECE materialise_piece
-    TileLdsT<QUALS> &T = Ts[WAVES > 1 ? threadIdx.x >> 6 : 0u];
-#endif
     __shared__ __align__(16) uint16_t qlut[QUALS ? NS_QLUT_SLOTS * 1024u : 8u];
     if constexpr (QUALS) { qual_lut_load(qlut, A.m, threadIdx.x, 64 * WAVES); __syncthreads(); }
     const uint32_t wave = WAVES > 1 ? threadIdx.x >> 6 : 0u;
@@ -743,7 +717,7 @@ k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, co
         uint32_t q = 0;
         for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
             const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi, ev_word);
-            NS_MAT_PIECE<FASTQ, MODE>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, Q);
+            materialise_piece6<FASTQ, MODE>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, Q);
             q += pc.out_len;
         }
         return;
@@ -765,7 +739,7 @@ k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, co
             pc.sid = pc.kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
             q_in += pc.ref_len;
         } else pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi, ev_word);
-        NS_MAT_PIECE<FASTQ, MODE>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, Q);
+        materialise_piece6<FASTQ, MODE>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, Q);
         if constexpr (MODE == MAT_HP_FINAL) {            // report the emitted length, like the path without -k
             if (lane == 0 && !pc.kind) A.pieces[rd.piece_off + pi].out_len = pc.out_len;
         }
@@ -1321,7 +1295,7 @@ struct ns_ctx {
     int slot = 0;                      // slot of the last batch
     IoEngine *io = nullptr;            // copy stream, staging slices, writer threads (created by the first ns_sink_open)
     std::vector<ns_sink *> sinks;
-    DevBuf sort_key, sort_idx, sort_key_out, order, list_b, list_c, rstate, att_base, scr, scr_len, scr_off, hp_len, hp_nev, hp_ev, hp_wd, hp_runs, hp_nrun, slow_q, ev_word;
+    DevBuf sort_key, sort_idx, sort_key_out, order, list_b, list_c, rstate, att_base, scr, scr_len, scr_off, hp_len, hp_nev, hp_ev, hp_wd, hp_runs, hp_nrun, slow_q;
     uint32_t hp_shift = 5, hp_pad = 64, hp_cap_k = 0;       // -k: event capacity of a piece (hp_ev_slot), planned for kmer_bias hp_cap_k
     // metagenome: species view of the reference, abundances of the sample, per-pass scratch
     DevBuf species_chrom_off, t_reads, t_pieces, t_name_len, t_rec_len, t_err_len, accept, accept_scan, key_pos, draw_x, m_segptr,
@@ -1493,7 +1467,7 @@ void ns_destroy(ns_ctx *ctx) {
                       &ctx->err_len, &ctx->err_off, &ctx->name_len, &ctx->reads, &ctx->pieces, &ctx->events,
                       &ctx->rec_slot[0], &ctx->rec_slot[1], &ctx->err_slot[0], &ctx->err_slot[1], &ctx->stats, &ctx->scan_tmp, &ctx->sort_key, &ctx->sort_idx,
                       &ctx->sort_key_out, &ctx->order, &ctx->list_b, &ctx->list_c, &ctx->rstate, &ctx->att_base, &ctx->scr, &ctx->hp_nev, &ctx->hp_ev, &ctx->hp_wd, &ctx->hp_runs, &ctx->hp_nrun,
-                      &ctx->scr_len, &ctx->scr_off, &ctx->hp_len, &ctx->slow_q, &ctx->ev_word, &ctx->l_cap, &ctx->l_off, &ctx->species_chrom_off, &ctx->t_reads, &ctx->t_pieces,
+                      &ctx->scr_len, &ctx->scr_off, &ctx->hp_len, &ctx->slow_q, &ctx->l_cap, &ctx->l_off, &ctx->species_chrom_off, &ctx->t_reads, &ctx->t_pieces,
                       &ctx->t_name_len, &ctx->t_rec_len, &ctx->t_err_len, &ctx->accept, &ctx->accept_scan, &ctx->key_pos,
                       &ctx->draw_x, &ctx->m_segptr, &ctx->m_len, &ctx->m_species, &ctx->species_bases, &ctx->draw_sel,
                       &ctx->draw_sorted, &ctx->meta_words, &ctx->meta_num, &ctx->trx_chrom, &ctx->trx_cum, &ctx->trx_polya, &ctx->polya,
@@ -1784,17 +1758,8 @@ static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fast
         HIPCHK(hipGetLastError());
         return NS_OK;
     }
-#if !NS_MAT_V6
-    if (mode != MAT_HP_FINAL) {               // (the second pass of -k takes its letter words from k_hp_drain)
-        int rc = ensure(ctx, ctx->ev_word, ((size_t)event_slots + 8) * 4);
-        if (rc) return rc;
-        k_words<<<dim3((unsigned)n), dim3(64), 0, st>>>(A, (uint32_t *)ctx->ev_word.p);
-        HIPCHK(hipGetLastError());
-    }
-#else
-    (void)event_slots;                        // (v6 draws the letter words in the tile prologue: event_word)
-#endif
-    if (names_done) HIPCHK(hipStreamWaitEvent(st, names_done, 0));      // k_names ran next to k_words on the second stream
+    (void)event_slots;                        // (the letter words are drawn in the tile prologue: event_word, ns_materialise.h)
+    if (names_done) HIPCHK(hipStreamWaitEvent(st, names_done, 0));
     for (int round = 0;; ++round) {
         size_t cap = ctx->slow_q.cap >= 16 + sizeof(SlowTile) ? (ctx->slow_q.cap - 16) / sizeof(SlowTile) : 0;
         if (cap < n / 4 + 4096) {
@@ -1806,7 +1771,7 @@ static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fast
         sq.count = (uint32_t *)ctx->slow_q.p; sq.items = (SlowTile *)((uint8_t *)ctx->slow_q.p + 16);
         sq.cap = (uint32_t)(cap > 0xffffffffull ? 0xffffffffull : cap);
         HIPCHK(hipMemsetAsync(sq.count, 0, 4, st));
-        const uint32_t *wd = (const uint32_t *)ctx->ev_word.p;
+        const uint32_t *wd = nullptr;               // (MAT_HP_FINAL reads A.hp_wd; the other modes draw the letter words: event_word)
         if (ctx->dbg & 1024u) order = nullptr;          // (profiling: reads in index order)
         const dim3 grid_q((unsigned)((n + NS_MATQ_WAVES - 1) / NS_MATQ_WAVES)), blk_q(64 * NS_MATQ_WAVES), grid_1((unsigned)n), blk_1(64);
         if (mode == MAT_REF) {
@@ -2537,7 +2502,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     const uint64_t max_unaligned = prm->kind == NS_KIND_UNALIGNED ? stats[1] : 0;      // emitted bases of the batch (k_chain): bounds the dense kernel's grid
     HIPCHK(hipEventRecord(ctx->evt[5], st));
     const bool write_rec = prm->emit_records == 1u;            // (2 = NS_EMIT_SIZES: the sizes of the images only)
-    const bool side_names = !A.hp && write_rec;               // names + framing on the second stream, next to k_words
+    const bool side_names = !A.hp && write_rec;               // names + framing on the second stream, next to the record kernel
     if (side_names) {
         HIPCHK(hipEventRecord(ctx->ev_fork, st));
         HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
@@ -2554,8 +2519,10 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
             HIPCHK(hipGetLastError());
         }
     } else if (write_rec) {
-        if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, tot_cap, ctx->ev_join, meta_al ? nullptr : list_a, MAT_REF, max_unaligned))) return rc;
+        // (k_names runs NEXT to the record kernels on the second stream: they write different bytes of the image)
+        if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, tot_cap, nullptr, meta_al ? nullptr : list_a, MAT_REF, max_unaligned))) return rc;
     }
+    if (side_names) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
     HIPCHK(hipEventRecord(ctx->evt[7], st));
     if (prm->emit_errlog && write_rec) {
         k_errlog<<<grid_w, blk_w, 0, st>>>(A);

@@ -19,30 +19,7 @@
 #endif
 #define T_OUT (1024u * NS_TILE_CHUNKS)
 #define T_EV 64u            // events staged per tile: slot 0 = the event in force at the tile start, slots 1..63 = lanes 0..62
-// PMASK: a second tile with the byte mask of the letters (the FASTQ kernels, which have no VALU slots to spare); without it the mask
-// is derived from the letters (every letter is ASCII >= 0x40, an empty slot is 0) and the wavefront needs 2 KB less LDS
-template <bool PMASK>
-struct __align__(16) TileLdsT {
-    uint32_t mlut[17][4];               // mlut[i]: 16-byte mask with bytes >= i set (merge of an event sub-run into a chunk); [16] empty
-    // per staged event, what the copy loop needs in ONE 16-byte read: x = first output offset copied under the event (start + payload
-    // length), y = segment position minus output offset of the bytes copied under it, z = output offset of the NEXT event (the tile
-    // end behind the last one)
-    uint4 ent[T_EV + 1];
-    uint32_t hist[64 * NS_TILE_CHUNKS];
-    // substituted / inserted letters of the tile at their output offsets (relative to the tile's aligned origin), the byte mask
-    // that marks them (0xff) and, for FASTQ, their quality class; + a dump area for predicated-off letter slots
-    uint8_t pay[T_OUT + 16 + 64];
-    uint8_t pmask[PMASK ? T_OUT + 16 + 64 : 16];
-};
 #define T_DUMP (T_OUT + 16u)
-struct Ent3 { uint32_t x, y, z; };
-template <class TL>
-__device__ __forceinline__ Ent3 ent3(const TL &T, uint32_t k) {
-    Ent3 e;
-    const uint2 xy = *reinterpret_cast<const uint2 *>(&T.ent[k]);
-    e.x = xy.x; e.y = xy.y; e.z = T.ent[k].z;
-    return e;
-}
 // quality class of an emitted base travels in two spare bits of its ASCII code (A 41, C 43, G 47, T 54: bits 3 and 5 are free)
 // until the qualities are drawn: bit 3 = substituted ('mis'), bit 5 = inserted ('ins', the base is in lower case)
 #define NS_CLS_MIS_BIT 0x08u
@@ -50,19 +27,6 @@ __device__ __forceinline__ Ent3 ent3(const TL &T, uint32_t k) {
 #define NS_CLS_STRIP 0xd7d7d7d7u
 // LDS copy of the quality bucket tables: slots 0..2 = match / mis / ins, slot 3 = unmapped (gaps of chimeric reads)
 #define NS_QLUT_SLOTS 4u
-template <bool PMASK>
-__device__ __forceinline__ void tile_lds_init(TileLdsT<PMASK> &T, uint32_t lane) {
-    for (uint32_t c = lane * 16; c < T_OUT + 16 + 64; c += 64 * 16) {
-        *reinterpret_cast<uint4 *>(&T.pay[c]) = make_uint4(0, 0, 0, 0);
-        if constexpr (PMASK) *reinterpret_cast<uint4 *>(&T.pmask[c]) = make_uint4(0, 0, 0, 0);
-    }
-    if (lane < 17) {
-#pragma unroll
-        for (uint32_t k = 0; k < 4; ++k)
-            T.mlut[lane][k] = lane <= 4 * k ? 0xffffffffu : lane >= 4 * k + 4 ? 0u : 0xffffffffu << (8 * (lane - 4 * k));
-    }
-}
-
 // inclusive prefix sum over the wavefront with DPP row shifts / row broadcasts (6 VALU instructions)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);      // row_shr:1
@@ -246,7 +210,7 @@ __device__ inline void emit_polya(const DevModel &m, const ReadOut &ro, const ns
 // ---- generic per-byte path (global memory, no staging) ---------------------------------------------------
 struct PieceCtx {
     const ns_event *ev;
-    const uint32_t *wd;      // letter word of every event (k_words); only set by load_piece_uniform
+    const uint32_t *wd;      // -k, second pass: the letter word of every homopolymer edit (k_hp_drain); else unused (event_word)
     uint32_t n_ev;
     uint32_t out_len, ref_len;
     uint64_t chrom_base;
@@ -640,331 +604,6 @@ __device__ __forceinline__ void qual_lut_load(uint16_t *lds, const DevModel &m, 
     for (uint32_t i = tid; i < 128u; i += nthreads) dst[3u * 128u + i] = src[(uint32_t)NS_Q_UNMAPPED * 128u + i];
 }
 
-// One piece of a read.  Per tile of <= T_OUT output bases whose 16-byte chunks are ALIGNED in the destination:
-//   1. lane l holds event jb + l (prefetched) and its letter word (k_words / k_hp_drain); the events that start inside the tile are a
-//      prefix of the lanes; they are staged into LDS for the other lanes;
-//   2. lane per event: the substituted / inserted letters (mutate_read, S:1965-1995) are written into an LDS payload tile at
-//      their output offsets, with a byte mask; FASTQ: the letters carry their quality class in bits 3 / 5;
-//   3. a histogram + wavefront prefix sum gives every lane (= one aligned 16-byte chunk) the event in force at its first byte;
-//      per event sub-run of the chunk ONE unaligned 16-byte global load at the run's source offset (software-pipelined,
-//      branch-free; neighbouring lanes hit the same lines in L1/L2), merged into the chunk under a byte mask; then the
-//      payload tile is merged on top; IUPAC codes (bit 7) are resolved afterwards (case_convert, S:743-755);
-//   4. FASTQ: qual_draws16 + qual_lookup16; complement/reverse in registers (S:1433-1435, 1675-1680), one aligned 16-byte store.
-// A tile whose reference span straddles the origin of a circular chromosome goes to the slow-tile queue.
-// MAT_HP_FINAL: the source is the pre-homopolymer piece in the scratch buffer (its bytes carry the class bits), the events are the
-// homopolymer edits (k_hp_drain): a substitution is one base whose word picks the new base with its first base-3 digit and, with
-// bit 0 set, takes the 'mis' class (first mismatch of its run, S:697-700; otherwise the class of the base it replaces); an
-// insertion has <= 15 letters, all of class 'ins' except letter 0 when bit 31 of the word is set.
-template <bool FASTQ, int MODE>
-__device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, TileLdsT<FASTQ && MODE != MAT_HP_SCRATCH> &T, const ReadOut &ro, const ns_key &key,
-                                         uint32_t a, const PieceCtx &pc, uint32_t pq, uint32_t lane, uint32_t dbg, const SlowQueue &sq,
-                                         uint32_t read_idx, uint32_t piece_idx, QualState &Q) {
-    constexpr bool QUALS = FASTQ && MODE != MAT_HP_SCRATCH;            // qualities are drawn in this pass
-    constexpr bool HPF = MODE == MAT_HP_FINAL;
-    uint32_t jb = 0;                       // events with out_start < M0
-    uint32_t L0_out = 0, L0_rp = 0, L0_pt = 3u << 12, L0_wd = 0, L0_j = 0;   // the event in force at M0 (synthetic start: no payload, copy from 0)
-    const uint8_t *seg0 = ref.bases + pc.chrom_base + pc.pos;           // segment position 0
-    const bool wraps = !HPF && pc.pos + pc.ref_len > pc.chrom_len;
-    const uint32_t wrap_at = wraps ? (uint32_t)(pc.chrom_len - pc.pos) : 0xffffffffu;   // first segment position beyond the origin
-    // output offsets m with m = phi (mod 16) start an aligned 16-byte group of the destination
-    const uint32_t phi = ro.reversed ? ((uint32_t)(uintptr_t)ro.seq + ro.seq_len - pq) & 15u : (0u - ((uint32_t)(uintptr_t)ro.seq + pq)) & 15u;
-    ns_event e_pre; e_pre.pos = 0; e_pre.info = 0; uint32_t w_pre = 0;
-    if (lane < pc.n_ev) { e_pre = pc.ev[lane]; w_pre = pc.wd[lane]; }
-    PendingChunk pend; pend.count = 0; pend.o0 = 0; pend.lo = pend.hi = pend.qlo = pend.qhi = 0;
-    if constexpr (QUALS) qual_state_reset(Q);
-    for (uint32_t M0 = 0; M0 < pc.out_len;) {
-        const uint32_t A0 = M0 - ((M0 - phi) & 15u);             // aligned origin of the tile (<= M0; may be "negative" = wrapped)
-        uint32_t M1 = min(A0 + T_OUT, pc.out_len);
-        // ---- 1. events of the tile
-        const ns_event e = e_pre;
-        const uint32_t e_wd = w_pre;
-        const bool valid = jb + lane < pc.n_ev;
-        const uint32_t os = ev_out_start(e), len = ns_ev_len(e.info), ty = ns_ev_type(e.info);
-        const uint32_t e_pt = (ty == NS_DEL ? 0u : len) | ty << 12, e_rp = e.pos + (ty == NS_INS ? 0u : len);
-        if (jb + 63 < pc.n_ev) {
-            const uint32_t os63 = (uint32_t)__builtin_amdgcn_readlane((int)os, 63);
-            if (os63 < M1) M1 = os63;
-        }
-        const bool take = valid && os < M1;
-        const uint32_t cnt = (uint32_t)__popcll(__ballot(take));
-        if (M1 <= M0) {                    // 64 events at one output offset (zero-length matches between deletions): not a case
-            M1 = min(M0 + T_OUT, pc.out_len);      // for the tile machinery; the generic path takes the tile
-            uint32_t j2 = jb;
-            while (j2 < pc.n_ev && ev_out_start(pc.ev[j2]) < M1) ++j2;
-            if (lane == 0) {
-                const uint32_t slot = atomicAdd(sq.count, 1u);
-                if (slot < sq.cap) sq.items[slot] = SlowTile{read_idx, piece_idx, M0, M1};
-            }
-            if (j2 > jb) {
-                const ns_event le = pc.ev[j2 - 1];
-                const uint32_t ll = ns_ev_len(le.info), lt = ns_ev_type(le.info);
-                L0_out = uni(ev_out_start(le)); L0_pt = uni((lt == NS_DEL ? 0u : ll) | lt << 12); L0_rp = uni(le.pos + (lt == NS_INS ? 0u : ll));
-                L0_wd = uni(pc.wd[j2 - 1]); L0_j = uni(j2 - 1);
-            }
-            jb = uni(j2); M0 = M1;
-            e_pre.pos = 0; e_pre.info = 0; w_pre = 0;
-            if (jb + lane < pc.n_ev) { e_pre = pc.ev[jb + lane]; w_pre = pc.wd[jb + lane]; }
-            continue;
-        }
-        const uint32_t ne = 1 + cnt;
-        // LDS view for the other lanes (every lane writes slot 0 / the sentinel with the same value: no exec juggling)
-        {
-            const uint32_t s0 = L0_out + (L0_pt & 0xfffu);
-            *reinterpret_cast<uint2 *>(&T.ent[0]) = make_uint2(s0, L0_rp - s0);
-            if (take) {
-                const uint32_t s1 = os + (e_pt & 0xfffu);
-                *reinterpret_cast<uint2 *>(&T.ent[1 + lane]) = make_uint2(s1, e_rp - s1);
-                T.ent[lane].z = os;
-            }
-            T.ent[cnt].z = M1;
-        }
-#pragma unroll
-        for (uint32_t t = 0; t < NS_TILE_CHUNKS; ++t) T.hist[64 * t + lane] = 0;
-        const uint32_t jb_next = jb + cnt;
-        e_pre.pos = 0; e_pre.info = 0; w_pre = 0;
-        if (M1 < pc.out_len && jb_next + lane < pc.n_ev) { e_pre = pc.ev[jb_next + lane]; w_pre = pc.wd[jb_next + lane]; }   // prefetch for the next tile
-        wave_sync();
-        {   // hist[c] = number of the tile's events that start in front of chunk c + 1's first byte... written by the LAST event that
-            // does (the events are sorted: lane l is event l + 1 of the tile), so no two lanes write one slot and nothing is counted
-            // with atomics; the chunks in between inherit the value through a prefix maximum
-            const uint32_t c = take ? (os - A0 + 15) >> 4 : 0xffffffffu;    // first chunk starting at/after the event
-            const uint32_t c_next = dpp_wave_shl1(0xffffffffu, c);
-            if (c < 64 * NS_TILE_CHUNKS && c != c_next) T.hist[c] = lane + 1u;
-        }
-        // ---- the event in force at M1 (wave-uniform): the last one taken, straight from its lane's registers
-        uint32_t osl = L0_out, ptl = L0_pt, rpl = L0_rp, wdl = L0_wd, jl = L0_j;
-        if (cnt) {
-            osl = (uint32_t)__builtin_amdgcn_readlane((int)os, (int)(cnt - 1));
-            ptl = (uint32_t)__builtin_amdgcn_readlane((int)e_pt, (int)(cnt - 1));
-            rpl = (uint32_t)__builtin_amdgcn_readlane((int)e_rp, (int)(cnt - 1));
-            wdl = (uint32_t)__builtin_amdgcn_readlane((int)e_wd, (int)(cnt - 1));
-            jl = jb + cnt - 1;
-        }
-        const uint8_t *tb = seg0 - 32;                             // + 32 in the lane offsets: they never go negative
-        uint32_t idle_off = 32;                                    // offset loaded by a sub-run that copies nothing (any valid address)
-        bool fast = true;
-        if (wraps) {                                               // reference span of the tile only matters next to the origin
-            const uint32_t pl0 = L0_pt & 0xfffu, ty0 = L0_pt >> 12, d0 = M0 - L0_out;
-            const uint32_t x0 = (d0 < pl0 && ty0 == NS_INS) ? L0_rp : L0_rp + d0 - pl0;
-            const uint32_t pll = ptl & 0xfffu, dl = M1 - osl;
-            uint32_t x1 = dl <= pll ? rpl : rpl + (dl - pll);
-            if (x1 < x0) x1 = x0;
-            if (x0 >= wrap_at) { tb -= pc.chrom_len; idle_off = wrap_at + 32; }   // whole tile beyond the origin
-            else if (x1 > wrap_at) fast = false;                   // tile straddles the origin
-        }
-        if (!fast) {
-            if (lane == 0) {
-                const uint32_t slot = atomicAdd(sq.count, 1u);
-                if (slot < sq.cap) sq.items[slot] = SlowTile{read_idx, piece_idx, M0, M1};
-            }
-            L0_out = osl; L0_rp = rpl; L0_pt = ptl; L0_wd = wdl; L0_j = jl;
-            jb = jb_next; M0 = M1;
-            if constexpr (QUALS) qual_state_reset(Q);
-            wave_sync();
-            continue;
-        }
-        // ---- 2. letters: lane per event; lane 63 (never a taker) continues the payload of the event in force at M0
-        if (!(dbg & 2)) {
-            const bool cont = lane == 63 && L0_out + (L0_pt & 0xfffu) > M0;
-            const uint32_t b_os = cont ? L0_out : os, b_pt = cont ? L0_pt : e_pt, b_rp = cont ? L0_rp : e_rp;
-            const uint32_t b_j = cont ? L0_j : jb + lane;
-            uint32_t frac = cont ? L0_wd : e_wd;
-            const uint32_t b_pl = b_pt & 0xfffu, b_ty = b_pt >> 12;
-            const bool on = (take || cont) && b_pl;
-            const uint32_t xs = b_rp - b_pl;                      // segment position under the first substituted base
-            // fast path (branch-free): up to four letters, all inside the tile, plain bases under a substitution
-            const bool mis = b_ty == NS_MIS;
-            bool fast_l = on && b_pl <= 4 && b_os >= M0 && b_os + b_pl <= M1 && !wraps;
-            uint32_t cur4 = 0x41414141u;
-            if (fast_l && mis) __builtin_memcpy(&cur4, seg0 + xs, 4);
-            if constexpr (!HPF) fast_l = fast_l && !(cur4 & 0x80808080u);
-            if (fast_l) {
-                // insertion: 2-bit fields of the word -> "ATCG" (S:1990)
-                const uint32_t x8 = frac & 0xffu, t8 = (x8 | x8 << 12) & 0x000f000fu;
-                const uint32_t ins4 = __builtin_amdgcn_perm(0u, 0x47435441u, (t8 | t8 << 6) & 0x03030303u);
-                // substitution: base-3 digits of the word pick among the three other bases (S:1968-1972)
-                uint32_t f3 = frac;
-                const uint32_t d0 = next_digit3(f3), d1 = next_digit3(f3), d2 = next_digit3(f3), d3 = next_digit3(f3);
-                const uint32_t d4 = d0 | d1 << 8 | d2 << 16 | d3 << 24;
-                const uint32_t vv = (cur4 >> 1) & 0x03030303u;                           // A 0, C 1, T 2, G 3
-                const uint32_t rank4 = (vv & 0x01010101u) << 1 | ((vv >> 1) & 0x01010101u);   // rank in "ATCG": A 0, T 1, C 2, G 3
-                const uint32_t ge = ((d4 | 0x80808080u) - rank4) & 0x80808080u;          // per byte: digit >= rank
-                const uint32_t mis4 = __builtin_amdgcn_perm(0u, 0x47435441u, d4 + (ge >> 7));
-                uint32_t letters = mis ? mis4 : ins4;
-                if constexpr (FASTQ) {                             // the quality class travels with the letter
-                    uint32_t cls4 = mis ? 0x01010101u * NS_CLS_MIS_BIT : 0x01010101u * NS_CLS_INS_BIT;
-                    if constexpr (HPF) {
-                        if (mis) cls4 = (frac & 1u) ? NS_CLS_MIS_BIT : (cur4 & (NS_CLS_MIS_BIT | NS_CLS_INS_BIT));
-                        else if (frac >> 31) cls4 = (cls4 & ~0xffu) | NS_CLS_MIS_BIT;
-                    }
-                    letters |= cls4;
-                }
-                const uint32_t o = b_os - A0, dump = T_DUMP + lane;
-                const uint32_t o1 = b_pl > 1 ? o + 1 : dump, o2 = b_pl > 2 ? o + 2 : dump, o3 = b_pl > 3 ? o + 3 : dump;
-                T.pay[o] = (uint8_t)letters; T.pay[o1] = (uint8_t)(letters >> 8); T.pay[o2] = (uint8_t)(letters >> 16); T.pay[o3] = (uint8_t)(letters >> 24);
-                if constexpr (QUALS) { T.pmask[o] = 0xffu; T.pmask[o1] = 0xffu; T.pmask[o2] = 0xffu; T.pmask[o3] = 0xffu; }
-            }
-            if (on && !fast_l) {                                  // long payloads, tile borders, IUPAC under a substitution, the origin
-                const uint32_t i_lo = b_os < M0 ? M0 - b_os : 0u;
-                const uint32_t i_hi = min(b_pl, M1 - b_os);
-                const uint32_t word0 = frac;
-                for (uint32_t i = 0; i < i_hi; ++i) {
-                    if (i && !(i & 15)) frac = payload_word(key, pc.sid, a, b_j, i >> 4);
-                    uint32_t b;
-                    if (b_ty == NS_INS) {
-                        b = bases_atcg((frac >> (2 * (i & 15))) & 3u);
-                        if constexpr (FASTQ) b |= (HPF && i == 0 && (word0 >> 31)) ? NS_CLS_MIS_BIT : NS_CLS_INS_BIT;
-                    } else {
-                        const uint32_t x = xs + i;
-                        const uint32_t src = ref_base_at(ref, pc, x);
-                        if constexpr (HPF) {
-                            b = mis_from_digit(src & ~(NS_CLS_MIS_BIT | NS_CLS_INS_BIT), next_digit3(frac));
-                            if constexpr (FASTQ) b |= (word0 & 1u) ? NS_CLS_MIS_BIT : (src & (NS_CLS_MIS_BIT | NS_CLS_INS_BIT));
-                        } else {
-                            b = mis_from_digit(resolve_base(src, key, pc.sid, a, x), next_digit3(frac));
-                            if constexpr (FASTQ) b |= NS_CLS_MIS_BIT;
-                        }
-                    }
-                    if (i >= i_lo) {
-                        const uint32_t o = b_os + i - A0;
-                        T.pay[o] = (uint8_t)b;
-                        if constexpr (QUALS) T.pmask[o] = 0xffu;
-                    }
-                }
-            }
-        }
-        L0_out = osl; L0_rp = rpl; L0_pt = ptl; L0_wd = wdl; L0_j = jl;
-        wave_sync();
-
-        // ---- 3. one lane per aligned 16-byte chunk
-        uint32_t scan_base = 0;
-#if NS_TILE_CHUNKS > 1
-#pragma nounroll
-#endif
-        for (uint32_t t = 0; t < NS_TILE_CHUNKS; ++t) {
-        const uint32_t ci = 64 * t + lane;                         // chunk of the tile
-        const uint32_t incl = max(scan_base, wave_incl_max(T.hist[ci]));
-        scan_base = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        const uint32_t c0 = A0 + 16 * ci;                          // chunk origin (chunk 0 of a piece's first tile may start before M0)
-        const uint32_t lo_m = ci == 0 ? M0 : c0, hi_m = min(c0 + 16, M1);
-        const bool active = (int32_t)(hi_m - lo_m) > 0 && !(dbg & 1);
-        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-        if (active) {
-            uint32_t k = incl;                                     // event in force at the chunk's first byte
-            Ent3 E = ent3(T, k);
-            uint32_t mcur = lo_m;
-            // The first four event sub-runs of the chunk are gathered branch-free with all four 16-byte loads in flight (a lane
-            // that has run out of sub-runs loads a fixed valid offset and merges with the empty mask mlut[16]); chunks with
-            // more sub-runs (>= 4 events inside 16 bases) continue in a loop.
-            bool more = true;
-            const uint32_t c0p = c0 + 32u;
-            uint4 f0, f1, f2, f3; uint32_t i0, i1, i2, i3;
-#ifndef NS_GATHER_NOPRED
-#define NS_GATHER_LOAD(FN) FN = make_uint4(0, 0, 0, 0); if (has) __builtin_memcpy(&FN, tb + (E.y + c0p), 16);
-#else
-#define NS_GATHER_LOAD(FN) __builtin_memcpy(&FN, tb + (has ? E.y + c0p : idle_off), 16);
-#endif
-#define NS_SUBRUN_GATHER(FN, IN)                                                                                     \
-            {                                                                                                        \
-                const uint32_t cs = max(mcur, E.x);                /* first copied byte under event k */              \
-                const bool has = more && cs < min(E.z, hi_m);                                                        \
-                /* E.y + c0 = segment position of chunk byte 0 under this event's shift */                            \
-                NS_GATHER_LOAD(FN)                                                                                   \
-                IN = has ? cs - c0 : 16u;                                                                            \
-                more = more && E.z < hi_m;                                                                           \
-                k += more ? 1u : 0u;                                                                                 \
-                mcur = more ? E.z : mcur;                                                                            \
-                E = ent3(T, k);                                                                                      \
-            }
-#define NS_SUBRUN_MERGE(FO, IO)                                                                                      \
-            {                                                                                                        \
-                const uint4 mk = *reinterpret_cast<const uint4 *>(&T.mlut[IO][0]);   /* bytes [i, 16): later sub-runs overwrite their own part */ \
-                r0 = bfi(mk.x, FO.x, r0); r1 = bfi(mk.y, FO.y, r1); r2 = bfi(mk.z, FO.z, r2); r3 = bfi(mk.w, FO.w, r3); \
-            }
-            NS_SUBRUN_GATHER(f0, i0)
-            NS_SUBRUN_GATHER(f1, i1)
-            if constexpr (!HPF) {                                  // (homopolymer edits are sparse — one event per ~250 bases: two sub-runs
-                NS_SUBRUN_GATHER(f2, i2)                           //  cover all but one chunk in a thousand, the loop below takes those)
-                NS_SUBRUN_GATHER(f3, i3)
-            }
-            flush_chunk(ro, pend);                                 // the previous tile's chunk: behind this tile's loads in the queue
-            NS_SUBRUN_MERGE(f0, i0)
-            NS_SUBRUN_MERGE(f1, i1)
-            if constexpr (!HPF) {
-                NS_SUBRUN_MERGE(f2, i2)
-                NS_SUBRUN_MERGE(f3, i3)
-            }
-            while (more) {
-                NS_SUBRUN_GATHER(f0, i0)
-                NS_SUBRUN_MERGE(f0, i0)
-            }
-#undef NS_SUBRUN_GATHER
-#undef NS_SUBRUN_MERGE
-            const uint32_t lo_off = 16 * ci;                       // chunk offset inside the payload tile
-            const uint4 pv = *reinterpret_cast<const uint4 *>(&T.pay[lo_off]);
-            uint4 pm;
-            if constexpr (QUALS) pm = *reinterpret_cast<const uint4 *>(&T.pmask[lo_off]);
-            else                   // every letter is ASCII >= 0x40 (bit 6), an empty slot is 0: the byte mask comes from the letters themselves
-                pm = make_uint4(((pv.x >> 6) & 0x01010101u) * 0xffu, ((pv.y >> 6) & 0x01010101u) * 0xffu,
-                                ((pv.z >> 6) & 0x01010101u) * 0xffu, ((pv.w >> 6) & 0x01010101u) * 0xffu);
-            if constexpr (!HPF) {
-            if ((r0 | r1 | r2 | r3) & 0x80808080u) {               // case_convert (S:743-755): rare; the segment position of a marked
-                uint32_t kk = incl;                                // byte is found by walking the chunk's events again
-                for (uint32_t b = lo_m - c0; b < hi_m - c0; ++b) {
-                    uint32_t wk = b < 8 ? (b < 4 ? r0 : r1) : (b < 12 ? r2 : r3);
-                    const uint32_t ch = (wk >> (8 * (b & 3))) & 0xff;
-                    if (!(ch & 0x80u)) continue;
-                    const uint32_t mm = c0 + b;
-                    while (T.ent[kk].z <= mm) ++kk;
-                    const uint32_t x = mm + T.ent[kk].y;
-                    const uint32_t r = resolve_base(ch, key, pc.sid, a, x);
-                    wk = (wk & ~(0xffu << (8 * (b & 3)))) | r << (8 * (b & 3));
-                    if (b < 4) r0 = wk; else if (b < 8) r1 = wk; else if (b < 12) r2 = wk; else r3 = wk;
-                }
-            }
-            }
-            // letters on top of the copied bases; the payload tile is left clean for the next tile
-            r0 = bfi(pm.x, pv.x, r0); r1 = bfi(pm.y, pv.y, r1); r2 = bfi(pm.z, pv.z, r2); r3 = bfi(pm.w, pv.w, r3);
-            *reinterpret_cast<uint4 *>(&T.pay[lo_off]) = make_uint4(0, 0, 0, 0);
-            if constexpr (QUALS) *reinterpret_cast<uint4 *>(&T.pmask[lo_off]) = make_uint4(0, 0, 0, 0);
-        } else flush_chunk(ro, pend);
-        uint32_t D[8];
-        if constexpr (QUALS) {                                     // the quality draws of the iteration (every lane takes part; the
-            const uint32_t c0_first = A0 + 1024u * t;              //  gathered bases wait in four registers meanwhile)
-            const int32_t span = (int32_t)(M1 - 1u - c0_first);    // >= 0: some lane of this iteration writes bytes
-            if (span >= 0 && !(dbg & 256u)) qual_draws16(Q, key, pc.sid, a, c0, c0_first, min(64u, ((uint32_t)span >> 4) + 1u), (dbg & 128u) != 0, D);
-        }
-        if (active) {
-            uint64_t qlo = 0, qhi = 0;
-            uint32_t s0 = lo_m - c0, count = hi_m - lo_m;          // bytes [s0, s0 + count) of the chunk are this tile's
-            if constexpr (QUALS) {                                 // one quality per byte, class from the bits the base carries (S:1421-1423)
-                // slot << 3 per byte: NS_Q_MATCH 0, NS_Q_MIS 1 (bit 3), NS_Q_INS 2 (bit 5); slot 3 = 'unmapped' for the gaps of chimeric reads
-                uint32_t cs[4];
-                if (pc.kind) cs[0] = cs[1] = cs[2] = cs[3] = 0x18181818u;
-                else {
-                    cs[0] = and_or(r0 >> 1, 0x10101010u, r0 & 0x08080808u); cs[1] = and_or(r1 >> 1, 0x10101010u, r1 & 0x08080808u);
-                    cs[2] = and_or(r2 >> 1, 0x10101010u, r2 & 0x08080808u); cs[3] = and_or(r3 >> 1, 0x10101010u, r3 & 0x08080808u);
-                }
-                if (!(dbg & 256u)) qual_lookup16(Q, m, D, cs, (dbg & 64u) != 0, qlo, qhi);
-                // bytes outside [s0, s0 + count) hold draws of other positions: they are shifted out / not stored
-            }
-            if constexpr (FASTQ && MODE != MAT_HP_SCRATCH) { r0 &= NS_CLS_STRIP; r1 &= NS_CLS_STRIP; r2 &= NS_CLS_STRIP; r3 &= NS_CLS_STRIP; }
-            uint64_t lo = (uint64_t)r0 | (uint64_t)r1 << 32, hi = (uint64_t)r2 | (uint64_t)r3 << 32;
-            if (s0) {                                              // front-partial chunk (first chunk of a piece): shift down
-                const uint32_t sh = 8 * s0;
-                if (sh < 64) { lo = (lo >> sh) | (hi << (64 - sh)); hi >>= sh; qlo = (qlo >> sh) | (qhi << (64 - sh)); qhi >>= sh; }
-                else { lo = hi >> (sh - 64); hi = 0; qlo = qhi >> (sh - 64); qhi = 0; }
-            }
-            if (!(dbg & 16)) pend = prep_chunk(ro, pq + lo_m, count, lo, hi, qlo, qhi);
-        }
-        }
-
-        jb = jb_next; M0 = M1;
-        wave_sync();
-    }
-    flush_chunk(ro, pend);
-}
-
 // ================================================================================================================================
 // Version 6 of the tile (round 3).  Same tiles, same events, same letters — a different COPY: instead of one lane per 16-byte chunk
 // that walks the events crossing its chunk (four predicated gathers per lane and iteration, paid by the whole wavefront whenever one
@@ -979,9 +618,6 @@ __device__ inline void materialise_piece(const DevModel &m, const DevRef &ref, T
 //     resolve IUPAC codes (rare), qualities, complement / reverse, one aligned 16-byte store.
 // Per tile ~250 wavefront instructions of copy machinery instead of ~590 (ablation of round 3: the copy loop was 53 % of the kernel).
 // ================================================================================================================================
-#ifndef NS_MAT_V6
-#define NS_MAT_V6 1
-#endif
 #define T6_NEL (64u * NS_TILE_CHUNKS + T_EV + 3u)
 struct __align__(16) TileLds6 {
     uint32_t mlut[17][4];                       // mlut[i]: 16-byte mask with bytes >= i set; [16] empty
