@@ -1310,7 +1310,8 @@ struct ns_ctx {
     DevBuf ir_need, ir_off, spliced;
     uint64_t spliced_bytes = 0;
     uint8_t *pin_small = nullptr;    // page-locked slots for the scalar read-backs of a call (read_small)
-    struct PinBuf { void *p = nullptr; size_t cap = 0; } pin_a, pin_b, pin_c;     // pinned host staging of the metagenome passes
+    struct PinBuf { void *p = nullptr; size_t cap = 0; } pin_a, pin_b, pin_c, pin_d;     // pinned host staging of the metagenome passes
+    std::vector<uint8_t> h_nseg;                               // metagenome: num_segment of the batch (S:825-828)
     uint32_t nspecies = 0;
     bool has_abun = false, has_inflated = false, has_key_pos = false;
     std::vector<double> abun, abun_inflated, last_species_bases;
@@ -1472,7 +1473,7 @@ void ns_destroy(ns_ctx *ctx) {
                       &ctx->draw_x, &ctx->m_segptr, &ctx->m_len, &ctx->m_species, &ctx->species_bases, &ctx->draw_sel,
                       &ctx->draw_sorted, &ctx->meta_words, &ctx->meta_num, &ctx->trx_chrom, &ctx->trx_cum, &ctx->trx_polya, &ctx->polya,
                       &ctx->ir_need, &ctx->ir_off, &ctx->spliced, &ctx->p_need, &ctx->p_off};
-    for (auto *pb : {&ctx->pin_a, &ctx->pin_b, &ctx->pin_c})
+    for (auto *pb : {&ctx->pin_a, &ctx->pin_b, &ctx->pin_c, &ctx->pin_d})
         if (pb->p) e = hipHostFree(pb->p);
     if (ctx->pin_small) e = hipHostFree(ctx->pin_small);
     for (DevBuf *b : bufs)
@@ -1975,15 +1976,17 @@ int ns_species_bases(ns_ctx *ctx, double *out) {
 // assign_species (S:758-811): the species of every segment of a pass, by greedy quota — a sequential walk, on the host.  `lens`: the
 // filtered length list in assignment order (chimeric segments first in draw order, the rest descending — sorted on the device);
 // `to_add`: sum(length_list) taken left to right over the list in draw order; `words`: the draws of every segment pointer.
+// `hist[v]`: how many of the reads still missing have v segments — the reads are taken in descending order of v (S:760: a descending sort of
+// num_segment).  Returns the segments assigned; `reads_done`: the reads whose segments were all assigned.
+// The walk is sequential by definition (every assignment lowers a quota).  Chimeric reads (their lengths are in draw order) take the
+// loop over all species as the reference writes it.  The single-segment reads — nine in ten — come by DESCENDING length (S:764-765), so
+// "quota - len > 0" can only become true for a species as the walk goes on, and false only for the species just charged: the candidate
+// list is kept up to date with O(1) work per read instead of being rebuilt from all species (same comparisons, same order of the
+// candidates, same arithmetic).
 static uint64_t assign_species_host(const ns_ctx *ctx, const double *lens, uint64_t n_len, double to_add, const uint2 *words,
-                                    std::vector<int32_t> &segs, const std::vector<double> &cur_bases, uint16_t *species) {
+                                    const uint64_t *hist, const std::vector<double> &cur_bases, uint16_t *species, uint64_t *reads_done) {
     const uint32_t ns = ctx->nspecies;
-    {                                                                            // S:760: descending counting sort (counts <= NS_MAX_SEG)
-        size_t hist[NS_MAX_SEG + 1] = {0};
-        for (int32_t v : segs) ++hist[v];
-        size_t w = 0;
-        for (int32_t v = (int32_t)NS_MAX_SEG; v >= 1; --v) for (size_t c = 0; c < hist[v]; ++c) segs[w++] = v;
-    }
+    *reads_done = 0;
     double have = 0, abun_total = 0;
     for (uint32_t s = 0; s < ns; ++s) { have += cur_bases[s]; abun_total += ctx->abun[s]; }
     const double all_bases = to_add + have;
@@ -1998,35 +2001,99 @@ static uint64_t assign_species_host(const ns_ctx *ctx, const double *lens, uint6
         return c;
     };
     auto any_left = [&]() { uint32_t c = 0; for (uint32_t s = 0; s < ns; ++s) if (quota[s] > 0) cand[c++] = s; return c; };
-    for (size_t r = 0; r < segs.size(); ++r) {
-        const int32_t seg = segs[r];
-        if (ptr + (uint64_t)seg > n_len) break;                                  // S:781-782
-        for (int32_t k = 0; k < seg; ++k) {
-            const double len = lens[ptr];
-            const uint2 w = words[ptr];                     // Philox(batch, ST_SPECIES, attempt = pass, idx = ptr): .x choice, .y uniform(0, 100)
-            auto choose = [&](uint32_t c) { return cand[(uint32_t)(((uint64_t)w.x * c) >> 32)]; };
-            uint32_t sp = 0, c;
-            bool fresh = k == 0;
-            if (!fresh) {                                                        // S:791-803: stay with the previous species?
-                c = fitting(len, (int)prev);
-                const double pct = 100.0 * u32_to_p(w.y);
-                if (pct <= ctx->abun_inflated[prev] && quota[prev] > 0) sp = prev;
-                else if (pct > ctx->abun_inflated[prev] && c > 0) sp = choose(c);
-                else fresh = true;
+    for (int32_t seg = (int32_t)NS_MAX_SEG; seg >= 2; --seg) {                  // ---- chimeric reads
+        for (uint64_t r = 0; r < hist[seg]; ++r) {
+            if (ptr + (uint64_t)seg > n_len) return ptr;                         // S:781-782
+            for (int32_t k = 0; k < seg; ++k) {
+                const double len = lens[ptr];
+                const uint2 w = words[ptr];                 // Philox(batch, ST_SPECIES, attempt = pass, idx = ptr): .x choice, .y uniform(0, 100)
+                auto choose = [&](uint32_t c) { return cand[(uint32_t)(((uint64_t)w.x * c) >> 32)]; };
+                uint32_t sp = 0, c;
+                bool fresh = k == 0;
+                if (!fresh) {                                                    // S:791-803: stay with the previous species?
+                    c = fitting(len, (int)prev);
+                    const double pct = 100.0 * u32_to_p(w.y);
+                    if (pct <= ctx->abun_inflated[prev] && quota[prev] > 0) sp = prev;
+                    else if (pct > ctx->abun_inflated[prev] && c > 0) sp = choose(c);
+                    else fresh = true;
+                }
+                if (fresh) {
+                    c = fitting(len, -1);
+                    if (!c) c = any_left();
+                    if (!c) return ptr;
+                    sp = choose(c);
+                }
+                species[ptr] = (uint16_t)sp;
+                quota[sp] -= len;
+                prev = sp;
+                ++ptr;
             }
-            if (fresh) {
-                c = fitting(len, -1);
-                if (!c) c = any_left();
-                if (!c) return ptr;
-                sp = choose(c);
-            }
-            species[ptr] = (uint16_t)sp;
-            quota[sp] -= len;
-            prev = sp;
-            ++ptr;
+            ++*reads_done;
         }
     }
+    // ---- single-segment reads, lengths descending: fit = {s : quota[s] - len > 0} in species order, marg = {s : 0 < quota[s], not fitting}
+    std::vector<uint32_t> fit(ns), marg(ns);
+    uint32_t n_fit = 0, n_marg = 0;
+    const uint64_t n1 = hist[1];
+    if (n1 && ptr < n_len) {
+        const double len0 = lens[ptr];
+        for (uint32_t s = 0; s < ns; ++s) { if (quota[s] - len0 > 0) fit[n_fit++] = s; else if (quota[s] > 0) marg[n_marg++] = s; }
+    }
+    uint32_t last = 0xffffffffu;                            // the species charged by the previous read (the only one that can leave `fit`)
+    for (uint64_t r = 0; r < n1; ++r) {
+        if (ptr + 1 > n_len) return ptr;                                         // S:781-782
+        const double len = lens[ptr];
+        const uint2 w = words[ptr];
+        if (last != 0xffffffffu && !(quota[last] - len > 0)) {                   // ... it no longer holds this length
+            uint32_t i = 0;
+            while (i < n_fit && fit[i] != last) ++i;
+            if (i < n_fit) { for (; i + 1 < n_fit; ++i) fit[i] = fit[i + 1]; --n_fit; if (quota[last] > 0) marg[n_marg++] = last; }
+        }
+        for (uint32_t i = 0; i < n_marg;) {                                      // a species with little quota left fits the shorter reads again
+            const uint32_t s = marg[i];
+            if (quota[s] - len > 0) {
+                uint32_t j = n_fit++;
+                while (j > 0 && fit[j - 1] > s) { fit[j] = fit[j - 1]; --j; }
+                fit[j] = s;
+                marg[i] = marg[--n_marg];
+            } else ++i;
+        }
+        uint32_t sp;
+        if (n_fit) sp = fit[(uint32_t)(((uint64_t)w.x * n_fit) >> 32)];
+        else {                                                                   // S:787-788: any species with quota left, in species order
+            const uint32_t c = any_left();
+            if (!c) return ptr;
+            sp = cand[(uint32_t)(((uint64_t)w.x * c) >> 32)];
+        }
+        species[ptr] = (uint16_t)sp;
+        quota[sp] -= len;
+        if (!(quota[sp] > 0)) {                                                  // used up: out of both lists
+            for (uint32_t i = 0; i < n_marg; ++i) if (marg[i] == sp) { marg[i] = marg[--n_marg]; break; }
+            uint32_t i = 0;
+            while (i < n_fit && fit[i] != sp) ++i;
+            if (i < n_fit) { for (; i + 1 < n_fit; ++i) fit[i] = fit[i + 1]; --n_fit; }
+            last = 0xffffffffu;
+        } else last = sp;
+        prev = sp;
+        ++ptr;
+        ++*reads_done;
+    }
     return ptr;
+}
+
+// positions of a pass in assignment order -> first segment / first piece of the read: the reads are sorted by descending segment count,
+// so both are closed forms of the histogram (S:862-865)
+struct MetaHist { uint32_t cnt[NS_MAX_SEG + 1]; };
+__global__ void __launch_bounds__(256) k_meta_layout(MetaHist H, uint32_t np, uint32_t *__restrict__ segptr, uint32_t *__restrict__ pieceoff) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > np) return;
+    uint32_t start = 0, sbase = 0, pbase = 0;
+    for (int v = (int)NS_MAX_SEG; v >= 1; --v) {
+        const uint32_t c = H.cnt[v];
+        if (i < start + c) { segptr[i] = sbase + (i - start) * (uint32_t)v; pieceoff[i] = pbase + (i - start) * (2u * (uint32_t)v - 1u); return; }
+        start += c; sbase += c * (uint32_t)v; pbase += c * (2u * (uint32_t)v - 1u);
+    }
+    segptr[i] = sbase; pieceoff[i] = pbase;                 // i == the number of reads: the totals
 }
 
 // the passes of one metagenome worker: every pass draws fresh lengths for the reads still missing, assigns species and tries
@@ -2052,13 +2119,17 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
         t = t2;
     };
     auto tt = now();
-    std::vector<uint32_t> npc(n);
-    HIPCHK(hipMemcpyAsync(npc.data(), A.n_pieces, n * 4, hipMemcpyDeviceToHost, st));
+    // num_segment comes back through page-locked memory (4 MB at PCIe rate; into a std::vector it was a staged copy of milliseconds)
+    if ((rc = ensure_pin(ctx, ctx->pin_d, (n + 1) * 4))) return rc;
+    const uint32_t *npc = (const uint32_t *)ctx->pin_d.p;
+    HIPCHK(hipMemcpyAsync(ctx->pin_d.p, A.n_pieces, n * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    std::vector<int32_t> nseg(n);
+    lap("k_nseg + D2H", tt);
+    std::vector<uint8_t> &nseg = ctx->h_nseg;                  // (kept across calls: no allocation, no zero-fill per batch)
+    if (nseg.size() < n) nseg.resize(n);
     tot_pieces = 0;
     uint64_t tot_seg = 0;
-    for (size_t i = 0; i < n; ++i) { nseg[i] = (int32_t)((npc[i] + 1) / 2); tot_pieces += npc[i]; tot_seg += (uint64_t)nseg[i]; }
+    for (size_t i = 0; i < n; ++i) { const uint32_t v = (npc[i] + 1) / 2; nseg[i] = (uint8_t)v; tot_pieces += npc[i]; tot_seg += v; }
     if ((rc = ensure(ctx, ctx->pieces, tot_pieces * sizeof(ns_piece) + 64)) || (rc = ensure(ctx, ctx->t_pieces, tot_pieces * sizeof(ns_piece) + 64)) ||
         (rc = ensure(ctx, ctx->t_reads, n * sizeof(ns_read))) || (rc = ensure(ctx, ctx->t_name_len, (n + 1) * 2)) ||
         (rc = ensure(ctx, ctx->t_rec_len, (n + 1) * 8)) || (rc = ensure(ctx, ctx->t_err_len, (n + 1) * 8)) ||
@@ -2068,6 +2139,7 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
         (rc = ensure(ctx, ctx->m_species, (tot_seg + 1) * 2)) || (rc = ensure(ctx, ctx->species_bases, (size_t)ns * 8)))
         return rc;
     HIPCHK(hipMemsetAsync(ctx->species_bases.p, 0, (size_t)ns * 8, st));
+    lap("nseg loop + buffers", tt);
     // final arrays (what the record kernels read) and the per-pass views of the same kernels
     A.f_reads = (ns_read *)ctx->reads.p; A.f_pieces = (ns_piece *)ctx->pieces.p; A.f_name_len = (uint16_t *)ctx->name_len.p;
     A.f_rec_len = (uint64_t *)ctx->rec_len.p; A.f_err_len = (uint64_t *)ctx->err_len.p;
@@ -2086,8 +2158,6 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
     const ns_key bkey{(uint32_t)prm->seed, (uint32_t)(prm->seed >> 32), (uint32_t)prm->first_read, (uint32_t)(prm->first_read >> 32)};
     std::vector<double> cur_bases(ns, 0.0);
     std::vector<unsigned long long> sb(ns);
-    std::vector<int32_t> segs;
-    std::vector<uint32_t> segptr, pieceoff;
     uint64_t passed = 0, pieces_passed = 0, ev_base = 0;
     double ms_chain = 0;
     unsigned long long good_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // counters after the last complete pass
@@ -2098,9 +2168,11 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
                                         "(min_len/max_len too narrow for this model, or its reads do not fit the event record: runs <= 4095 bases, "
                                             "insertion / deletion balance within +-131071 bases per segment)");
         const uint64_t m = n - passed;
-        segs.assign(nseg.begin() + (ptrdiff_t)passed, nseg.end());                // num_segment[passed:], S:1034
+        uint64_t hist[NS_MAX_SEG + 1] = {0};                                       // num_segment[passed:], S:1034 — as a histogram: the reads
+        for (size_t i = passed; i < n; ++i) ++hist[nseg[i]];                       // are taken by descending segment count (S:760)
         uint64_t D = 0;
-        for (int32_t v : segs) D += (uint64_t)v;
+        for (uint32_t v = 1; v <= NS_MAX_SEG; ++v) D += (uint64_t)v * hist[v];
+        lap("histogram", tt);
         P.attempt = p; P.draw_n = D;
         k_meta_draw<<<dim3((unsigned)((D + 255) / 256)), blk, 0, st>>>(P);         // S:852
         HIPCHK(hipGetLastError());
@@ -2128,7 +2200,7 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
         for (uint64_t j = 0; j < D; ++j) if (flt(h_draw[j])) { to_add += h_draw[j]; ++V; }      // S:857 (--perfect: S:841); S:767
         if (!V) continue;                                                          // S:858-859
         uint64_t chim = 0;
-        for (int32_t v : segs) if (v > 1) chim += (uint64_t)v;                     // S:761: the first `chim` lengths keep their order
+        for (uint32_t v = 2; v <= NS_MAX_SEG; ++v) chim += (uint64_t)v * hist[v];  // S:761: the first `chim` lengths keep their order
         if (chim > V) chim = V;
         lap("filter", tt);
         if (chim) HIPCHK(hipMemcpyAsync(d_sorted, d_sel, chim * 8, hipMemcpyDeviceToDevice, st));
@@ -2147,24 +2219,26 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
         HIPCHK(hipStreamSynchronize(st));
         lap("sort + words", tt);
         uint16_t *h_species = (uint16_t *)h_draw;                                  // the draws are no longer needed: reuse the staging
-        const uint64_t P_seg = assign_species_host(ctx, h_sorted, V, to_add, h_words, segs, cur_bases, h_species);   // S:866-867
+        uint64_t np64 = 0;
+        const uint64_t P_seg = assign_species_host(ctx, h_sorted, V, to_add, h_words, hist, cur_bases, h_species, &np64);   // S:866-867
         lap("assign_species", tt);
         P.m_reversed = u32_to_p(ns_draw(bkey, ST_STRAND, 0, p, 0, 0).x) > ctx->m.strandness_rate ? 1u : 0u;   // S:860
-        segptr.resize(m + 1); pieceoff.resize(m + 1);
-        uint64_t sp = 0, po = 0;
-        size_t np = 0;
-        for (; np < m; ++np) {                                                     // S:862-865: reads that still get their lengths
-            const uint64_t k = (uint64_t)segs[np];
-            if (sp + k > P_seg) break;
-            segptr[np] = (uint32_t)sp; pieceoff[np] = (uint32_t)po;
-            sp += k; po += 2 * k - 1;
-        }
+        // S:862-865: the reads that still get their lengths are the first np of the descending order; their first segment / first piece
+        // are closed forms of the histogram (k_meta_layout): no host loop over the reads, no upload of two 4 MB arrays
+        size_t np = (size_t)std::min<uint64_t>(np64, m);
         if (!np) continue;
-        segptr[np] = (uint32_t)sp; pieceoff[np] = (uint32_t)po;
+        MetaHist H;
+        uint64_t left = np, sp = 0, po = 0;
+        H.cnt[0] = 0;
+        for (int v = (int)NS_MAX_SEG; v >= 1; --v) {
+            const uint64_t c = std::min<uint64_t>(hist[v], left);
+            H.cnt[v] = (uint32_t)c; left -= c; sp += c * (uint64_t)v; po += c * (2ull * (uint64_t)v - 1ull);
+        }
+        (void)P_seg;
+        k_meta_layout<<<dim3((unsigned)((np + 1 + 255) / 256)), blk, 0, st>>>(H, (uint32_t)np, (uint32_t *)ctx->m_segptr.p, (uint32_t *)ctx->piece_off.p);
+        HIPCHK(hipGetLastError());
         k_meta_round<<<dim3((unsigned)((sp + 255) / 256)), blk, 0, st>>>(d_sorted, (int32_t *)ctx->m_len.p, sp);   // S:871: int(round(length))
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(ctx->m_segptr.p, segptr.data(), (np + 1) * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(ctx->piece_off.p, pieceoff.data(), (np + 1) * 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(ctx->m_species.p, h_species, sp * 2, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemsetAsync(P.accept, 0, (np + 1) * 8, st));
         HIPCHK(hipMemsetAsync(P.ev_cap + np, 0, 8, st));
