@@ -40,7 +40,7 @@ def init_dist():
     NS_DEVICE=<index> exist for tests that run several ranks on ONE GPU: the reference then travels through host memory."""
     rank, local_rank, world = env_rank_world()
     device = int(os.environ.get("NS_DEVICE", local_rank))
-    if world == 1:
+    if world == 1 and os.environ.get("NS_FORCE_DIST", "0") == "0":      # (NS_FORCE_DIST=1: a process group of one rank — the RCCL path on a 1-GPU box)
         return rank, device, world, None, None
     import torch
     import torch.distributed as dist

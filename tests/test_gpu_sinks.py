@@ -186,3 +186,21 @@ def test_sub_files_of_minus_t_give_the_same_files(tmp_path, monkeypatch, flags):
     assert sorted(os.listdir(tmp_path / "w2")) == sorted(os.listdir(tmp_path / "t1"))
     for f in tails:
         assert open(out + f, "rb").read() == open(one + f, "rb").read(), f
+
+
+def test_one_rank_process_group_over_rccl(tmp_path):
+    """the multi-GPU code path with the REAL backend on the one GPU of the box: a process group of one rank over RCCL ("nccl"), the
+    reference broadcast into a HIP tensor, ns_set_reference_device from its pointer — the bytes of the plain run"""
+    base = ["genome", "-rg", os.path.join(GOLDEN, "genome_small.fa"), "-c", os.path.join(GOLDEN, "model_small", "training"),
+            "-n", "903", "--seed", "777", "--chimeric", "--fastq"]
+    one = str(tmp_path / "plain" / "sim")
+    simulator.main(base + ["-o", one])
+    out = str(tmp_path / "rccl" / "sim")
+    env = dict(os.environ, NS_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("NS_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "-m", "nanosim_amd.simulator"] + base + ["-o", out]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    for f in ("_aligned_reads.fastq", "_aligned_error_profile", "_unaligned_reads.fastq"):
+        assert open(out + f, "rb").read() == open(one + f, "rb").read(), f
