@@ -740,10 +740,7 @@ k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, co
             q_in += pc.ref_len;
         } else pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi, ev_word);
         materialise_piece6<FASTQ, MODE>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, Q);
-        if constexpr (MODE == MAT_HP_FINAL) {            // report the emitted length, like the path without -k
-            if (lane == 0 && !pc.kind) A.pieces[rd.piece_off + pi].out_len = pc.out_len;
-        }
-        q += pc.out_len;
+        q += pc.out_len;                                 // (-k: k_hp_report files the emitted length in the piece once the record kernels are done)
     }
     if (A.polya) {                                                                          // transcriptome: polyA tail (S:1224-1225)
         const uint32_t pl = uni(A.polya[r]);
@@ -806,6 +803,75 @@ __global__ void __launch_bounds__(64) k_materialise_slow(GenArgs A, SlowQueue sq
         for (uint32_t pi = 0; pi < t.piece; ++pi) q += A.pieces[rd.piece_off + pi].out_len;
         const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + t.piece], t.piece);
         slow_piece_range<FASTQ && SCRATCH>(A.m, A.ref, ro, key, rd.attempts, pc, q, t.m0, t.m1, lane);
+    }
+}
+
+// the tiles of the SECOND record pass of -k that k_materialise<., MAT_HP_FINAL> could not take (>= 64 homopolymer edits at one output
+// offset: a stretch of adjacent runs all re-sampled to nothing): generic per-byte path over the scratch piece and its edit list, one
+// wavefront per queued tile.  (Until round 2 such a tile failed the batch with NS_EINVAL: the condition depends on the reference — a
+// low-complexity stretch — not on the caller.)
+template <bool FASTQ>
+__global__ void __launch_bounds__(64) k_materialise_slow_hpf(GenArgs A, SlowQueue sq) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n = min(*sq.count, sq.cap);
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const SlowTile t = sq.items[i];
+        ns_read rd; ns_key key; ReadOut ro;
+        if (!load_read_uniform(A, t.read, FASTQ, rd, key, ro)) continue;
+        uint32_t q = rd.head;                                    // output offset of the piece in the read / of its scratch bytes
+        uint64_t q_in = A.scr_off[t.read];
+        for (uint32_t pi = 0; pi < t.piece; ++pi) {
+            const uint32_t gp = rd.piece_off + pi;
+            const ns_piece p = A.pieces[gp];
+            q += p.kind ? p.out_len : A.hp_len[gp];
+            q_in += p.out_len;
+        }
+        const uint32_t gp = rd.piece_off + t.piece;
+        const ns_piece p = A.pieces[gp];
+        const uint64_t eo = hp_ev_slot(A, q_in, gp);
+        const ns_event *ev = A.hp_ev + eo;
+        const uint32_t *wd = A.hp_wd + eo;
+        const uint32_t n_ev = p.kind ? 0u : A.hp_nev[gp], sid = p.kind ? NS_GAP_SEG + (t.piece >> 1) : (t.piece >> 1);
+        const uint8_t *src = A.scr + q_in;
+        for (uint32_t m0 = t.m0 + lane * 16; m0 < t.m1; m0 += 64 * 16) {
+            const uint32_t count = min(16u, t.m1 - m0);
+            uint32_t lo = 0, hi = n_ev;                          // events with out_start <= m0
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (ev_out_start(ev[mid]) <= m0) lo = mid + 1; else hi = mid; }
+            uint32_t j = lo;                                     // event in force: j - 1 (none: copy from the start of the piece)
+            uint64_t blo = 0, bhi = 0, qlo = 0, qhi = 0;
+            QualDraw qd; qd.blk = 0xffffffffu;
+            for (uint32_t i2 = 0; i2 < count; ++i2) {
+                const uint32_t m = m0 + i2;
+                while (j < n_ev && ev_out_start(ev[j]) <= m) ++j;
+                uint32_t b, cls_bits;
+                if (j == 0) { const uint32_t c = src[m]; b = c & ~(NS_CLS_MIS_BIT | NS_CLS_INS_BIT); cls_bits = c & (NS_CLS_MIS_BIT | NS_CLS_INS_BIT); }
+                else {
+                    const ns_event e = ev[j - 1];
+                    const uint32_t len = ns_ev_len(e.info), ty = ns_ev_type(e.info), os = ev_out_start(e), d = m - os, w = wd[j - 1];
+                    const uint32_t pl = ty == NS_DEL ? 0u : len;
+                    if (d < pl) {
+                        if (ty == NS_INS) {                      // inserted letters: 2-bit fields of the edit's word; letter 0 may be the run's first mismatch
+                            b = bases_atcg((w >> (2 * (d & 15))) & 3u);
+                            cls_bits = (d == 0 && (w >> 31)) ? NS_CLS_MIS_BIT : NS_CLS_INS_BIT;
+                        } else {                                 // one substituted base: the first base-3 digit of the word picks among the other three
+                            const uint32_t c = src[e.pos + d];
+                            uint32_t f = w;
+                            b = mis_from_digit(c & ~(NS_CLS_MIS_BIT | NS_CLS_INS_BIT), next_digit3(f));
+                            cls_bits = (w & 1u) ? NS_CLS_MIS_BIT : (c & (NS_CLS_MIS_BIT | NS_CLS_INS_BIT));
+                        }
+                    } else {
+                        const uint32_t c = src[e.pos + (ty == NS_INS ? 0u : len) + (d - pl)];
+                        b = c & ~(NS_CLS_MIS_BIT | NS_CLS_INS_BIT); cls_bits = c & (NS_CLS_MIS_BIT | NS_CLS_INS_BIT);
+                    }
+                }
+                put_byte(blo, bhi, i2, b);
+                if (ro.qual) {
+                    const int cls = p.kind ? NS_Q_UNMAPPED : (cls_bits & NS_CLS_MIS_BIT) ? NS_Q_MIS : (cls_bits & NS_CLS_INS_BIT) ? NS_Q_INS : NS_Q_MATCH;
+                    put_byte(qlo, qhi, i2, qual_draw(qd, A.m, cls, key, ST_QUAL, sid, rd.attempts, m));
+                }
+            }
+            store_chunk(ro, q + m0, count, blo, bhi, qlo, qhi);
+        }
     }
 }
 
@@ -1788,8 +1854,6 @@ static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fast
         HIPCHK(hipGetLastError());
         uint32_t queued = 0;
         if (int rc2 = read_small(ctx, st, &queued, sq.count, 4)) return rc2;
-        if (queued && mode == MAT_HP_FINAL)      // >= 64 homopolymer edits at one output offset (64 adjacent runs re-sampled to nothing)
-            return fail(ctx, NS_EINVAL, "-k: homopolymer edits too dense for the record kernel");
         if (queued > sq.cap) {                   // more slow tiles than queue slots (tiny circular genomes): grow and redo
             if (round >= 2) return fail(ctx, NS_ENOMEM, "slow-tile queue overflow");
             int rc = ensure(ctx, ctx->slow_q, 16 + ((size_t)queued + 4096) * sizeof(SlowTile));
@@ -1798,6 +1862,10 @@ static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fast
         }
         if (queued) {
             const unsigned grid = queued < 16384u ? queued : 16384u;
+            if (mode == MAT_HP_FINAL) {          // >= 64 homopolymer edits at one output offset (adjacent runs all re-sampled to nothing)
+                if (fastq) k_materialise_slow_hpf<true><<<dim3(grid), dim3(64), 0, st>>>(A, sq);
+                else k_materialise_slow_hpf<false><<<dim3(grid), dim3(64), 0, st>>>(A, sq);
+            } else
             if (mode == MAT_HP_SCRATCH) {
                 if (fastq) k_materialise_slow<true, true><<<dim3(grid), dim3(64), 0, st>>>(A, sq);
                 else k_materialise_slow<false, true><<<dim3(grid), dim3(64), 0, st>>>(A, sq);
@@ -2586,12 +2654,9 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     if (side_names) HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
     HIPCHK(hipEventRecord(ctx->evt[6], st));
     if (A.hp) {          // second record pass of -k: the scratch read + its homopolymer edits -> the record
-        if (write_rec) {
-            if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, tot_cap, nullptr, meta_al ? nullptr : list_a, MAT_HP_FINAL))) return rc;
-        } else {
-            k_hp_report<<<dim3((unsigned)((tot_pieces + 255) / 256)), blk, 0, st>>>(A, tot_pieces);
-            HIPCHK(hipGetLastError());
-        }
+        if (write_rec && (rc = launch_materialise(ctx, A, n, prm->fastq != 0, tot_cap, nullptr, meta_al ? nullptr : list_a, MAT_HP_FINAL))) return rc;
+        k_hp_report<<<dim3((unsigned)((tot_pieces + 255) / 256)), blk, 0, st>>>(A, tot_pieces);      // the pieces report their emitted length,
+        HIPCHK(hipGetLastError());                                                                    // like the path without -k
     } else if (write_rec) {
         // (k_names runs NEXT to the record kernels on the second stream: they write different bytes of the image)
         if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, tot_cap, nullptr, meta_al ? nullptr : list_a, MAT_REF, max_unaligned))) return rc;

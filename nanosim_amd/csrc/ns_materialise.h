@@ -727,7 +727,7 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
             const uint32_t os63 = (uint32_t)__builtin_amdgcn_readlane((int)os, 63);     // (a tile cut inside a chunk gives this tile a partial last
             if (os63 < M1) {                                                             // chunk and the next one a partial first chunk: the partial
                 const uint32_t cut = A0 + ((os63 - A0) & ~15u);                          // store path then runs in every iteration of the final pass)
-                M1 = cut > M0 ? cut : os63;
+                M1 = (int32_t)(cut - M0) > 0 ? cut : os63;                                // (A0, and with it cut, may be "negative": wrapped)
             }
         }
         const bool take = valid && os < M1;

@@ -356,3 +356,32 @@ def test_reads_that_do_not_fit_the_event_record_are_redrawn(small_model, small_r
         compare(b, O.generate(m, small_ref, p, bytes_per_read=400000, events_per_read=8000), p)
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("fastq", [False, True])
+def test_dense_homopolymer_edits_take_the_slow_tiles(small_model, fastq):
+    """-k on a reference that is nothing but runs of five, with a homopolymer model that re-samples every run to nothing: hundreds of
+    adjacent deletions at ONE output offset — more than the 63 events a tile of the record kernel stages.  Until round 2 the second
+    record pass failed the batch with NS_EINVAL ("edits too dense"); now those tiles take a per-byte kernel (k_materialise_slow_hpf).
+    Same bytes as the oracle."""
+    import copy
+    m = copy.deepcopy(small_model)
+    for base in ("AT", "CG"):                       # mu = -50 whatever the run length, sigma 0.1: int(round(max(0, x))) == 0 (S:644-666)
+        m.hp[base] = dict(m.hp[base], const=-50.0, alpha1=0.0, betas=[0.0] * len(m.hp[base]["betas"]), intercept=0.1, slope=0.0)
+    seq = np.frombuffer((b"AAAAACCCCCGGGGGTTTTT" * 3000), dtype=np.uint8).copy()
+    ref = M.Reference(["runs"], seq, np.array([0, len(seq)], dtype=np.uint64), np.array([0], dtype=np.uint8))
+    e = E.Engine(0)
+    try:
+        e.set_reference(ref)
+        e.load_model(m)
+        p = E.make_params(seed=11, first_read=0, n_reads=120, fastq=fastq, kmer_bias=5, min_len=1, max_len=ref.max_chrom, emit_errlog=True)
+        b = e.generate(p)
+        exp = O.generate(m, ref, p, bytes_per_read=60000, events_per_read=8000)
+        assert b.records().tobytes() == exp["records"].tobytes()
+        assert b.errlog().tobytes() == exp["errlog"].tobytes()
+        rd, er = b.reads(), exp["reads"]
+        assert np.array_equal(rd["seq_len"], er["seq_len"]) and np.array_equal(rd["attempts"], er["attempts"])
+        pc = b.pieces()[rd["piece_off"]]
+        assert int(np.max(pc["ref_len"].astype(np.int64) - pc["out_len"])) > 2000        # thousands of bases deleted inside one piece
+    finally:
+        e.close()
