@@ -107,6 +107,7 @@ struct GenArgs {
     ns_event *events;
     uint8_t *records;
     uint8_t *errlog;
+    uint32_t *cls;              // FASTQ: the class of every base of the aligned pieces, 2 bits each (k_materialise -> k_qualities; cls_word0)
     unsigned long long *stats;  // [0] overflow reads [1] total bases [2] total ref bases [3] events [4] longest accepted read (unaligned batches)
                                 // [5] reads that failed the final length check of -k [6] reads queued for the next pass [7] -k event capacity overflow
 };
@@ -676,40 +677,34 @@ __device__ __forceinline__ bool load_read_uniform(const GenArgs &A, uint64_t r, 
     return true;
 }
 
-// k_materialise: the sequence (and quality) line of one read per wavefront; see ns_materialise.h.  The FASTQ kernel runs NS_MATQ_WAVES
-// reads per workgroup, which share the LDS copy of the quality bucket tables (reads of similar length: `order` is the batch's
-// length-sorted visiting list, so no wavefront idles long behind its workgroup's longest read).
+// k_materialise: the sequence line of one read per wavefront; see ns_materialise.h.  k_qualities: its quality line, NS_MATQ_WAVES reads
+// per workgroup, which share the LDS copy of the quality bucket tables (reads of similar length: `order` is the batch's length-sorted
+// visiting list, so no wavefront idles long behind its workgroup's longest read).
 #ifndef NS_MATQ_WAVES
 #define NS_MATQ_WAVES 4
 #endif
 #ifndef NS_MATQ_MINW
-#define NS_MATQ_MINW 4          // waves per SIMD the FASTQ kernel is compiled for
+#define NS_MATQ_MINW 6          // waves per SIMD k_qualities is compiled for (80 VGPRs; for 8 it spills: 11.25 against 11.0 ms per FASTQ batch)
 #endif
 // first event slot / capacity of the homopolymer edits of the piece whose scratch bytes start at `pos` (bytes from the start of the
 // scratch buffer) and that is piece `piece` of the batch: a monotone function of both, so no scan is needed
 __device__ __forceinline__ uint64_t hp_ev_slot(const GenArgs &A, uint64_t pos, uint32_t piece) { return (pos >> A.hp_shift) + (uint64_t)A.hp_pad * piece; }
 
 template <bool FASTQ, int MODE>
-__global__ void __launch_bounds__((FASTQ && MODE != MAT_HP_SCRATCH) ? 64 * NS_MATQ_WAVES : 64, (FASTQ && MODE != MAT_HP_SCRATCH) ? NS_MATQ_MINW : NS_MAT_WAVES)
+__global__ void __launch_bounds__(64, NS_MAT_WAVES)
 k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, const uint32_t *order) {
-    constexpr bool QUALS = FASTQ && MODE != MAT_HP_SCRATCH;
-    constexpr uint32_t WAVES = QUALS ? NS_MATQ_WAVES : 1;
-    __shared__ TileLds6 Ts[WAVES];
-    TileLds6 &T = Ts[WAVES > 1 ? threadIdx.x >> 6 : 0u];
-    __shared__ __align__(16) uint16_t qlut[QUALS ? NS_QLUT_SLOTS * 1024u : 8u];
-    if constexpr (QUALS) { qual_lut_load(qlut, A.m, threadIdx.x, 64 * WAVES); __syncthreads(); }
-    const uint32_t wave = WAVES > 1 ? threadIdx.x >> 6 : 0u;
-    const uint32_t lane = WAVES > 1 ? threadIdx.x & 63u : threadIdx.x;
-    const uint64_t slot = (uint64_t)blockIdx.x * WAVES + wave;
+    constexpr bool CLSOUT = FASTQ && MODE != MAT_HP_SCRATCH;           // FASTQ: the bases here, the quality line in k_qualities
+    __shared__ TileLds6 T;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t slot = blockIdx.x;
     if (slot >= A.prm.n_reads) return;
     const uint64_t r = order ? (uint64_t)uni(order[slot]) : slot;
     ns_read rd; ns_key key; ReadOut ro;
-    if (!load_read_uniform(A, r, QUALS, rd, key, ro)) return;
-    if (dbg & 512u) ro.qual = nullptr;               // (profiling: no quality line)
-    if ((dbg & 4096u) && ro.qual) ro.qual = (uint8_t *)(((uintptr_t)ro.qual & ~(uintptr_t)15) | ((uintptr_t)ro.seq & 15));   // (profiling: quality line aligned like the bases)
+    if (!load_read_uniform(A, r, false, rd, key, ro)) return;
     const uint32_t a = rd.attempts;
     tile_lds_init(T, lane);
-    QualState Q; Q.lut = qlut; qual_state_reset(Q);
+    uint32_t *cls = nullptr;
+    if constexpr (CLSOUT) cls = A.cls + cls_word0(rd.rec_off, rd.piece_off, 0, 0);
     if constexpr (MODE == MAT_HP_SCRATCH) {
         // -k, first pass: the pieces of the read before mutate_homo, forward strand, one after the other in the scratch buffer
         // (head, tail and polyA are written by the second pass; strand and T -> U are applied there)
@@ -717,7 +712,7 @@ k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, co
         uint32_t q = 0;
         for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
             const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi, ev_word);
-            materialise_piece6<FASTQ, MODE>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, Q);
+            materialise_piece6<FASTQ, MODE>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, nullptr);
             q += pc.out_len;
         }
         return;
@@ -739,12 +734,44 @@ k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, co
             pc.sid = pc.kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
             q_in += pc.ref_len;
         } else pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi, ev_word);
-        materialise_piece6<FASTQ, MODE>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, Q);
+        materialise_piece6<FASTQ, MODE>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, CLSOUT ? cls + (q >> 4) + 2u * pi : nullptr);
         q += pc.out_len;                                 // (-k: k_hp_report files the emitted length in the piece once the record kernels are done)
     }
     if (A.polya) {                                                                          // transcriptome: polyA tail (S:1224-1225)
         const uint32_t pl = uni(A.polya[r]);
         if (pl) emit_polya(A.m, ro, key, a, q, pl, rd.head, rd.tail, lane);
+    }
+}
+
+// k_qualities: the quality line of one read per wavefront (predict_base_qualities per class, bq:183-193; classes S:1421-1423, 1953-1955,
+// 1564), from the class words k_materialise<true, .> left.  HPF: second record pass of -k (piece lengths after mutate_homo).
+template <bool HPF>
+__global__ void __launch_bounds__(64 * NS_MATQ_WAVES, NS_MATQ_MINW) k_qualities(GenArgs A, const uint32_t *order) {
+    __shared__ __align__(16) uint16_t qlut[NS_QLUT_SLOTS * 1024u];
+    qual_lut_load(qlut, A.m, threadIdx.x, 64 * NS_MATQ_WAVES);
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t slot = (uint64_t)blockIdx.x * NS_MATQ_WAVES + (threadIdx.x >> 6);
+    if (slot >= A.prm.n_reads) return;
+    const uint64_t r = order ? (uint64_t)uni(order[slot]) : slot;
+    ns_read rd; ns_key key; ReadOut ro;
+    if (!load_read_uniform(A, r, true, rd, key, ro)) return;
+    const uint32_t a = rd.attempts;
+    QualState Q; Q.lut = qlut;
+    qualities_head_tail(A.m, Q, ro, key, a, rd.head, rd.tail, lane);                         // S:1421-1423
+    const uint32_t *cls = A.cls + cls_word0(rd.rec_off, rd.piece_off, 0, 0);
+    uint32_t q = rd.head;
+    for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
+        const uint32_t gp = rd.piece_off + pi;
+        const ns_piece p = A.pieces[gp];
+        const uint32_t kind = uni(p.kind);
+        const uint32_t out_len = (HPF && !kind) ? uni(A.hp_len[gp]) : uni(p.out_len);
+        qualities_piece(A.m, Q, ro, key, a, kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1), kind, out_len, q, cls + (q >> 4) + 2u * pi, lane);
+        q += out_len;
+    }
+    if (A.polya) {
+        const uint32_t pl = uni(A.polya[r]);
+        if (pl) emit_polya_quals(A.m, ro, key, a, q, pl, rd.head, rd.tail, lane);
     }
 }
 
@@ -1361,7 +1388,7 @@ struct ns_ctx {
     int slot = 0;                      // slot of the last batch
     IoEngine *io = nullptr;            // copy stream, staging slices, writer threads (created by the first ns_sink_open)
     std::vector<ns_sink *> sinks;
-    DevBuf sort_key, sort_idx, sort_key_out, order, list_b, list_c, rstate, att_base, scr, scr_len, scr_off, hp_len, hp_nev, hp_ev, hp_wd, hp_runs, hp_nrun, slow_q;
+    DevBuf sort_key, sort_idx, sort_key_out, order, list_b, list_c, rstate, att_base, scr, scr_len, scr_off, hp_len, hp_nev, hp_ev, hp_wd, hp_runs, hp_nrun, slow_q, cls;
     uint32_t hp_shift = 5, hp_pad = 64, hp_cap_k = 0;       // -k: event capacity of a piece (hp_ev_slot), planned for kmer_bias hp_cap_k
     // metagenome: species view of the reference, abundances of the sample, per-pass scratch
     DevBuf species_chrom_off, t_reads, t_pieces, t_name_len, t_rec_len, t_err_len, accept, accept_scan, key_pos, draw_x, m_segptr,
@@ -1538,7 +1565,7 @@ void ns_destroy(ns_ctx *ctx) {
                       &ctx->t_name_len, &ctx->t_rec_len, &ctx->t_err_len, &ctx->accept, &ctx->accept_scan, &ctx->key_pos,
                       &ctx->draw_x, &ctx->m_segptr, &ctx->m_len, &ctx->m_species, &ctx->species_bases, &ctx->draw_sel,
                       &ctx->draw_sorted, &ctx->meta_words, &ctx->meta_num, &ctx->trx_chrom, &ctx->trx_cum, &ctx->trx_polya, &ctx->polya,
-                      &ctx->ir_need, &ctx->ir_off, &ctx->spliced, &ctx->p_need, &ctx->p_off};
+                      &ctx->ir_need, &ctx->ir_off, &ctx->spliced, &ctx->p_need, &ctx->p_off, &ctx->cls};
     for (auto *pb : {&ctx->pin_a, &ctx->pin_b, &ctx->pin_c, &ctx->pin_d})
         if (pb->p) e = hipHostFree(pb->p);
     if (ctx->pin_small) e = hipHostFree(ctx->pin_small);
@@ -1841,17 +1868,25 @@ static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fast
         const uint32_t *wd = nullptr;               // (MAT_HP_FINAL reads A.hp_wd; the other modes draw the letter words: event_word)
         if (ctx->dbg & 1024u) order = nullptr;          // (profiling: reads in index order)
         const dim3 grid_q((unsigned)((n + NS_MATQ_WAVES - 1) / NS_MATQ_WAVES)), blk_q(64 * NS_MATQ_WAVES), grid_1((unsigned)n), blk_1(64);
+        const uint32_t *order_b = (ctx->dbg & 2048u) ? order : nullptr;      // (the record kernel: reads in index order)
         if (mode == MAT_REF) {
-            if (fastq) k_materialise<true, MAT_REF><<<grid_q, blk_q, 0, st>>>(A, wd, ctx->dbg, sq, order);
-            else k_materialise<false, MAT_REF><<<grid_1, blk_1, 0, st>>>(A, wd, ctx->dbg, sq, (ctx->dbg & 2048u) ? order : nullptr);
+            if (fastq) k_materialise<true, MAT_REF><<<grid_1, blk_1, 0, st>>>(A, wd, ctx->dbg, sq, order_b);
+            else k_materialise<false, MAT_REF><<<grid_1, blk_1, 0, st>>>(A, wd, ctx->dbg, sq, order_b);
         } else if (mode == MAT_HP_SCRATCH) {
             if (fastq) k_materialise<true, MAT_HP_SCRATCH><<<grid_1, blk_1, 0, st>>>(A, wd, ctx->dbg, sq, nullptr);
             else k_materialise<false, MAT_HP_SCRATCH><<<grid_1, blk_1, 0, st>>>(A, wd, ctx->dbg, sq, nullptr);
         } else {
-            if (fastq) k_materialise<true, MAT_HP_FINAL><<<grid_q, blk_q, 0, st>>>(A, wd, ctx->dbg, sq, order);
+            if (fastq) k_materialise<true, MAT_HP_FINAL><<<grid_1, blk_1, 0, st>>>(A, wd, ctx->dbg, sq, order_b);
             else k_materialise<false, MAT_HP_FINAL><<<grid_1, blk_1, 0, st>>>(A, wd, ctx->dbg, sq, nullptr);
         }
         HIPCHK(hipGetLastError());
+        // FASTQ: the quality lines, from the class words the record kernel left (before the generic kernel below: a tile queued for it
+        // has no class words, and its qualities are that kernel's)
+        if (fastq && mode != MAT_HP_SCRATCH && round == 0) {
+            if (mode == MAT_HP_FINAL) k_qualities<true><<<grid_q, blk_q, 0, st>>>(A, order);
+            else k_qualities<false><<<grid_q, blk_q, 0, st>>>(A, order);
+            HIPCHK(hipGetLastError());
+        }
         uint32_t queued = 0;
         if (int rc2 = read_small(ctx, st, &queued, sq.count, 4)) return rc2;
         if (queued > sq.cap) {                   // more slow tiles than queue slots (tiny circular genomes): grow and redo
@@ -2641,6 +2676,11 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         return rc;
     if (prm->emit_records == 0) info->errlog_bytes = 0;       // (no records: no error-profile image either; NS_EMIT_SIZES keeps the size)
     A.records = (uint8_t *)ctx->rec_slot[slot].p; A.errlog = (uint8_t *)ctx->err_slot[slot].p;
+    A.cls = nullptr;
+    if (prm->emit_records == 1u && prm->fastq && prm->kind != NS_KIND_UNALIGNED) {      // class words: k_materialise -> k_qualities (cls_word0)
+        if ((rc = ensure(ctx, ctx->cls, (((size_t)info->record_bytes >> 4) + 2 * (size_t)tot_pieces + 64) * 4))) return rc;
+        A.cls = (uint32_t *)ctx->cls.p;
+    }
     const uint64_t max_unaligned = prm->kind == NS_KIND_UNALIGNED ? stats[1] : 0;      // emitted bases of the batch (k_chain): bounds the dense kernel's grid
     HIPCHK(hipEventRecord(ctx->evt[5], st));
     const bool write_rec = prm->emit_records == 1u;            // (2 = NS_EMIT_SIZES: the sizes of the images only)

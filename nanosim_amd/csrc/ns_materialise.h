@@ -26,7 +26,7 @@
 #define NS_CLS_INS_BIT 0x20u
 #define NS_CLS_STRIP 0xd7d7d7d7u
 // LDS copy of the quality bucket tables: slots 0..2 = match / mis / ins, slot 3 = unmapped (gaps of chimeric reads)
-#define NS_QLUT_SLOTS 4u
+#define NS_QLUT_SLOTS 5u
 // inclusive prefix sum over the wavefront with DPP row shifts / row broadcasts (6 VALU instructions)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);      // row_shr:1
@@ -204,6 +204,29 @@ __device__ inline void emit_polya(const DevModel &m, const ReadOut &ro, const ns
             for (uint32_t i = 0; i < count; ++i) put_byte(qlo, qhi, i, qual_draw(qd, m, NS_Q_HT, key, ST_HTQ, 0, a, head + tail + len - 1 - (i0 + i)));
         }
         store_chunk(ro, q_start + i0, count, 0x4141414141414141ull, 0x4141414141414141ull, qlo, qhi);
+    }
+}
+
+// `count` quality values whose pre-revcomp coordinates are [q0, q0 + count)
+__device__ __forceinline__ void store_qual_chunk(const ReadOut &ro, uint32_t q0, uint32_t count, uint64_t qlo, uint64_t qhi) {
+    uint32_t o0 = q0;
+    qlo += 0x2121212121212121ull; qhi += 0x2121212121212121ull;             // chr(q + 33), S:1441
+    if (ro.reversed) {
+        if (count == 16) { const uint64_t t = __builtin_bswap64(qhi); qhi = __builtin_bswap64(qlo); qlo = t; }
+        else reverse_bytes(qlo, qhi, count);
+        o0 = ro.seq_len - q0 - count;
+    }
+    store16(ro.qual + o0, count, qlo, qhi);
+}
+// the quality half of emit_polya (k_qualities: the record kernel of a FASTQ batch writes the bases only)
+__device__ inline void emit_polya_quals(const DevModel &m, const ReadOut &ro, const ns_key &key, uint32_t a, uint32_t q_start, uint32_t len,
+                                        uint32_t head, uint32_t tail, uint32_t lane) {
+    for (uint32_t i0 = lane * 16; i0 < len; i0 += 64 * 16) {
+        const uint32_t count = min(16u, len - i0);
+        uint64_t qlo = 0, qhi = 0;
+        QualDraw qd; qd.blk = 0xffffffffu;
+        for (uint32_t i = 0; i < count; ++i) put_byte(qlo, qhi, i, qual_draw(qd, m, NS_Q_HT, key, ST_HTQ, 0, a, head + tail + len - 1 - (i0 + i)));
+        store_qual_chunk(ro, q_start + i0, count, qlo, qhi);
     }
 }
 
@@ -505,65 +528,15 @@ enum { MAT_REF = 0,          // the reference -> the record (qualities drawn her
        MAT_HP_SCRATCH = 1,   // -k, first pass: the reference -> the pre-homopolymer read in the scratch buffer (class bits kept, no qualities)
        MAT_HP_FINAL = 2 };   // -k, second pass: the scratch read + the homopolymer edits as its event list -> the record
 
-// ---- qualities of one 16-byte chunk (predict_base_qualities, bq:183-193; classes S:1421-1423, 1953-1955) ------------------------
-// The 16-bit draw of emitted piece position m is halfword m & 7 of Philox(ST_QUAL, sid, attempt, idx = m >> 3).  A chunk starts
-// at c0 (any alignment with respect to the blocks, c0 & 7 is wave-uniform): every lane evaluates the two blocks that START inside
-// its chunk, the block that straddles the chunk start is the neighbouring lane's second block (DPP wave_shr:1); for lane 0 it is
-// carried from the previous iteration / tile in SGPRs (or evaluated once, on the scalar unit's operands, when neither candidate fits).
-struct QualState {
-    const uint16_t *lut;                 // LDS: NS_QLUT_SLOTS x 1024 bucket entries (see qual_value_lut)
-    uint32_t a_blk, b_blk;               // block numbers held in a / b (0x80000000: none)
-    u32x4 a, b;
-};
-__device__ __forceinline__ void qual_state_reset(QualState &Q) { Q.a_blk = Q.b_blk = 0x80000000u; Q.a = Q.b = u32x4{0, 0, 0, 0}; }
-
+// ---- qualities (predict_base_qualities, bq:183-193; classes S:1421-1423, 1953-1955) --------------------------------------------------
+// The 16-bit draw of emitted piece position m is halfword m & 7 of Philox(ST_QUAL, sid, attempt, idx = m >> 3).
 __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t lane0_value, uint32_t v) {      // lane l gets v of lane l - 1, lane 0 gets lane0_value
     return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0_value, (int)v, 0x138, 0xf, 0xf, false);
 }
-// D[k] = the draws of chunk bytes 2k (low half) and 2k + 1 (high half); c0_first = chunk origin of lane 0, n_active = lanes of this
-// iteration that write bytes (a prefix of the wavefront, >= 1).  Executed by ALL lanes.
-__device__ __forceinline__ void qual_draws16(QualState &Q, const ns_key &key, uint32_t sid, uint32_t a, uint32_t c0, uint32_t c0_first,
-                                             uint32_t n_active, bool skip_philox, uint32_t D[8]) {
-    const uint32_t B0 = (uint32_t)((int32_t)c0 >> 3);
-    const uint32_t need = (uint32_t)((int32_t)c0_first >> 3);              // lane 0's straddling block
-    u32x4 k1, k2, p0;
-    if (skip_philox) { k1 = u32x4{B0, 1, c0, 0}; k2 = u32x4{B0, 2, c0, 0}; }
-    else { k1 = ns_draw(key, ST_QUAL, sid, a, B0 + 1u, 0); k2 = ns_draw(key, ST_QUAL, sid, a, B0 + 2u, 0); }
-    if (need == Q.a_blk) p0 = Q.a;
-    else if (need == Q.b_blk) p0 = Q.b;
-    else p0 = ns_draw(key, ST_QUAL, sid, a, need, 0);                      // (wave-uniform operands)
-    uint32_t W[13];
-    W[0] = dpp_wave_shr1(p0.x, k2.x); W[1] = dpp_wave_shr1(p0.y, k2.y); W[2] = dpp_wave_shr1(p0.z, k2.z); W[3] = dpp_wave_shr1(p0.w, k2.w);
-    W[4] = k1.x; W[5] = k1.y; W[6] = k1.z; W[7] = k1.w; W[8] = k2.x; W[9] = k2.y; W[10] = k2.z; W[11] = k2.w; W[12] = 0;
-    // carries: the second block of the last active lane (next iteration starts behind it) and of the one before (the next tile
-    // starts inside the last chunk)
-    const uint32_t la = n_active - 1u;
-    Q.b = p0; Q.b_blk = need + 2u * la;
-    if (la) {
-        Q.b.x = (uint32_t)__builtin_amdgcn_readlane((int)k2.x, (int)(la - 1u)); Q.b.y = (uint32_t)__builtin_amdgcn_readlane((int)k2.y, (int)(la - 1u));
-        Q.b.z = (uint32_t)__builtin_amdgcn_readlane((int)k2.z, (int)(la - 1u)); Q.b.w = (uint32_t)__builtin_amdgcn_readlane((int)k2.w, (int)(la - 1u));
-    }
-    Q.a.x = (uint32_t)__builtin_amdgcn_readlane((int)k2.x, (int)la); Q.a.y = (uint32_t)__builtin_amdgcn_readlane((int)k2.y, (int)la);
-    Q.a.z = (uint32_t)__builtin_amdgcn_readlane((int)k2.z, (int)la); Q.a.w = (uint32_t)__builtin_amdgcn_readlane((int)k2.w, (int)la);
-    Q.a_blk = need + 2u * la + 2u;
-    // byte i of the chunk = halfword g + i of the 24-halfword window W (g = c0 & 7, wave-uniform)
-    const uint32_t g = uni(c0_first & 7u), gd = g >> 1;
-    if (gd & 2u) {
-#pragma unroll
-        for (int i = 0; i < 11; ++i) W[i] = W[i + 2];
-    }
-    if (gd & 1u) {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) W[i] = W[i + 1];
-    }
-    if (g & 1u) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) D[i] = __builtin_amdgcn_alignbit(W[i + 1], W[i], 16);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) D[i] = W[i];
-    }
-}
+struct QualState {
+    const uint16_t *lut;                 // LDS: NS_QLUT_SLOTS x 1024 bucket entries (see qual_value_lut), slot = class
+};
+
 // 16 qualities from the 16 draws D and the class slot of every byte (cs[k]: slot << 3 in each byte of dword k of the chunk)
 __device__ __forceinline__ void qual_lookup16(const QualState &Q, const DevModel &m, const uint32_t D[8], const uint32_t cs[4], bool skip_lut,
                                               uint64_t &qlo, uint64_t &qhi) {
@@ -585,9 +558,9 @@ __device__ __forceinline__ void qual_lookup16(const QualState &Q, const DevModel
     if (__ballot((flags & 0x80008000u) != 0)) {                        // a bucket with several thresholds (never with the loader's tables)
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k) {
-            const uint32_t c0 = (cs[k >> 1] >> (16 * (k & 1) + 3)) & 3u, c1 = (cs[k >> 1] >> (16 * (k & 1) + 11)) & 3u;
-            const uint32_t q0 = qual_value(m.qual_thr + (c0 == 3u ? (uint32_t)NS_Q_UNMAPPED : c0) * NS_QUAL_LEVELS, D[k] & 0xffffu);
-            const uint32_t q1 = qual_value(m.qual_thr + (c1 == 3u ? (uint32_t)NS_Q_UNMAPPED : c1) * NS_QUAL_LEVELS, D[k] >> 16);
+            const uint32_t c0 = (cs[k >> 1] >> (16 * (k & 1) + 3)) & 7u, c1 = (cs[k >> 1] >> (16 * (k & 1) + 11)) & 7u;      // slot = class
+            const uint32_t q0 = qual_value(m.qual_thr + min(c0, (uint32_t)NS_Q_COUNT - 1u) * NS_QUAL_LEVELS, D[k] & 0xffffu);
+            const uint32_t q1 = qual_value(m.qual_thr + min(c1, (uint32_t)NS_Q_COUNT - 1u) * NS_QUAL_LEVELS, D[k] >> 16);
             Q2[k] = q0 | q1 << 16;
         }
     }
@@ -595,13 +568,38 @@ __device__ __forceinline__ void qual_lookup16(const QualState &Q, const DevModel
     const uint32_t b2 = __builtin_amdgcn_perm(Q2[5], Q2[4], 0x06040200u), b3 = __builtin_amdgcn_perm(Q2[7], Q2[6], 0x06040200u);
     qlo = (uint64_t)b0 | (uint64_t)b1 << 32; qhi = (uint64_t)b2 | (uint64_t)b3 << 32;
 }
+// ---- the class stream between the record kernel and k_qualities --------------------------------------------------------------------
+// The record kernel of a FASTQ batch writes the bases; the class of every base (match / substituted / inserted: which quality model
+// applies, S:1953-1955) is on the bytes of its LDS tile as two bits (NS_CLS_MIS_BIT, NS_CLS_INS_BIT) and leaves as ONE 32-bit word per
+// 16-byte chunk: byte i of the chunk in bits 2i (substituted) and 2i + 1 (inserted).  k_qualities reads the words back and draws the
+// quality line.  (As ONE kernel the quality draws — two Philox blocks in flight per lane, sixteen table reads — held the record kernel
+// at 124 VGPRs = 4 wavefronts per SIMD, where it issued 52 % of the time: FASTQ 14.2 ms per 950 000 reads against 5.4 for FASTA.)
+__device__ __forceinline__ uint32_t cls_pack16(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3) {
+    auto field = [](uint32_t r) {            // the four 2-bit fields of a dword gathered into its top byte (no two terms of the product meet)
+        const uint32_t t = and_or(r >> 4, 0x02020202u, (r >> 3) & 0x01010101u);
+        return t * 0x01041040u;
+    };
+    const uint32_t p0 = field(r0), p1 = field(r1), p2 = field(r2), p3 = field(r3);
+    return __builtin_amdgcn_perm(p1, p0, 0x0c0c0703u) | __builtin_amdgcn_perm(p3, p2, 0x07030c0cu);
+}
+// dword k of the chunk: the table slot of every byte as slot << 3 (the form qual_lookup16 takes)
+__device__ __forceinline__ uint32_t cls_unpack4(uint32_t w, uint32_t k) {
+    const uint32_t e = (w >> (8u * k)) & 0xffu;
+    uint32_t t = e << 3;
+    t |= e << 9; t |= e << 15; t |= e << 21;
+    return t & 0x18181818u;
+}
+// class words of a read: first word of the read / of piece pi, which starts at output offset q of the read.  A piece of n bytes has at
+// most n / 16 + 2 chunks (its first and last may be partial), a FASTQ record is longer than twice its bases: no two pieces share a word
+__device__ __forceinline__ uint64_t cls_word0(uint64_t rec_off, uint32_t piece_off, uint32_t q, uint32_t pi) {
+    return (rec_off >> 4) + 2ull * piece_off + (q >> 4) + 2u * pi;
+}
+
 // the bucket tables of the classes a piece can hold, global -> LDS (all threads of the workgroup; the caller synchronises)
 __device__ __forceinline__ void qual_lut_load(uint16_t *lds, const DevModel &m, uint32_t tid, uint32_t nthreads) {
     const uint4 *src = reinterpret_cast<const uint4 *>(m.qual_lut);
     uint4 *dst = reinterpret_cast<uint4 *>(lds);
-    static_assert(NS_Q_MATCH == 0 && NS_Q_MIS == 1 && NS_Q_INS == 2, "slots 0..2 are the first three classes");
-    for (uint32_t i = tid; i < 3u * 128u; i += nthreads) dst[i] = src[i];
-    for (uint32_t i = tid; i < 128u; i += nthreads) dst[3u * 128u + i] = src[(uint32_t)NS_Q_UNMAPPED * 128u + i];
+    for (uint32_t i = tid; i < NS_QLUT_SLOTS * 128u; i += nthreads) dst[i] = src[i];      // slot = class (NS_Q_*)
 }
 
 // ================================================================================================================================
@@ -650,8 +648,8 @@ __device__ __forceinline__ uint32_t event_word(const PieceCtx &pc, const ns_key 
 template <bool FASTQ, int MODE>
 __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, TileLds6 &T, const ReadOut &ro, const ns_key &key,
                                           uint32_t a, const PieceCtx &pc, uint32_t pq, uint32_t lane, uint32_t dbg, const SlowQueue &sq,
-                                          uint32_t read_idx, uint32_t piece_idx, QualState &Q) {
-    constexpr bool QUALS = FASTQ && MODE != MAT_HP_SCRATCH;            // qualities are drawn in this pass
+                                          uint32_t read_idx, uint32_t piece_idx, uint32_t *__restrict__ cls) {
+    constexpr bool CLSOUT = FASTQ && MODE != MAT_HP_SCRATCH;           // the class of every base leaves as 2 bits for k_qualities (cls: the piece's words)
     constexpr bool HPF = MODE == MAT_HP_FINAL;
     uint32_t jb = 0;                       // events with out_start < M0
     uint32_t L0_out = 0, L0_rp = 0, L0_pt = 3u << 12, L0_wd = 0, L0_j = 0;   // the event in force at M0 (synthetic start: no payload, copy from 0)
@@ -663,10 +661,10 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
     ns_event e_pre; e_pre.pos = 0; e_pre.info = 0; uint32_t w_pre = 0;
     if (lane < pc.n_ev) e_pre = pc.ev[lane];
     w_pre = event_word<MODE>(pc, key, a, lane < pc.n_ev ? lane : 0u);
-    if constexpr (QUALS) qual_state_reset(Q);
     // The tile whose bytes are complete in T.out and wait for their final pass (step 4): it runs UNDER the loads of the next tile
     bool have_prev = false;
     uint32_t A0p = 0, M0p = 0, M1p = 0;
+    uint32_t cls_carry = 0;                // class bits of the chunk the last tile ended in (tiles queued for the generic path: none)
     // ---- 4. one lane per aligned 16-byte chunk of the tile [M0p, M1p): qualities, complement / reverse, one aligned 16-byte store
     auto final_pass = [&]() {
         if (!have_prev) return;
@@ -679,31 +677,21 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
             const uint32_t c0 = A0p + 16 * ci;                         // chunk origin (chunk 0 of a piece's first tile may start before M0)
             const uint32_t lo_m = ci == 0 ? M0p : c0, hi_m = min(c0 + 16, M1p);
             const bool active = (int32_t)(hi_m - lo_m) > 0 && !(dbg & 1);
-            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, cw = 0;
             if (active) {
                 const uint4 v = *reinterpret_cast<const uint4 *>(&T.out[16 * ci]);
                 *reinterpret_cast<uint4 *>(&T.out[16 * ci]) = make_uint4(0, 0, 0, 0);      // the tile is left clean for the next one
                 r0 = v.x; r1 = v.y; r2 = v.z; r3 = v.w;
             }
-            uint32_t D[8];
-            if constexpr (QUALS) {                                     // the quality draws of the iteration (every lane takes part)
-                const uint32_t c0_first = A0p + 1024u * t;
-                const int32_t span = (int32_t)(M1p - 1u - c0_first);   // >= 0: some lane of this iteration writes bytes
-                if (span >= 0 && !(dbg & 256u)) qual_draws16(Q, key, pc.sid, a, c0, c0_first, min(64u, ((uint32_t)span >> 4) + 1u), (dbg & 128u) != 0, D);
-            }
             if (active) {
                 uint64_t qlo = 0, qhi = 0;
                 uint32_t s0 = lo_m - c0, count = hi_m - lo_m;          // bytes [s0, s0 + count) of the chunk are this tile's
-                if constexpr (QUALS) {
-                    uint32_t cs[4];
-                    if (pc.kind) cs[0] = cs[1] = cs[2] = cs[3] = 0x18181818u;
-                    else {
-                        cs[0] = and_or(r0 >> 1, 0x10101010u, r0 & 0x08080808u); cs[1] = and_or(r1 >> 1, 0x10101010u, r1 & 0x08080808u);
-                        cs[2] = and_or(r2 >> 1, 0x10101010u, r2 & 0x08080808u); cs[3] = and_or(r3 >> 1, 0x10101010u, r3 & 0x08080808u);
-                    }
-                    if (!(dbg & 256u)) qual_lookup16(Q, m, D, cs, (dbg & 64u) != 0, qlo, qhi);
+                if constexpr (CLSOUT) {                                // chunk k of the piece covers its positions [16 k - g, 16 k - g + 16), g = -phi mod 16
+                    cw = cls_pack16(r0, r1, r2, r3);
+                    if (ci == 0) cw |= cls_carry;                      // (a tile cut inside a chunk: the bits of the part the last tile wrote)
+                    if (!pc.kind) cls[(c0 + ((0u - phi) & 15u)) >> 4] = cw;
+                    r0 &= NS_CLS_STRIP; r1 &= NS_CLS_STRIP; r2 &= NS_CLS_STRIP; r3 &= NS_CLS_STRIP;
                 }
-                if constexpr (FASTQ && MODE != MAT_HP_SCRATCH) { r0 &= NS_CLS_STRIP; r1 &= NS_CLS_STRIP; r2 &= NS_CLS_STRIP; r3 &= NS_CLS_STRIP; }
                 uint64_t lo = (uint64_t)r0 | (uint64_t)r1 << 32, hi = (uint64_t)r2 | (uint64_t)r3 << 32;
                 if (s0) {                                              // front-partial chunk (first chunk of a piece): shift down
                     const uint32_t sh = 8 * s0;
@@ -711,6 +699,10 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
                     else { lo = hi >> (sh - 64); hi = 0; qlo = qhi >> (sh - 64); qhi = 0; }
                 }
                 if (!(dbg & 16)) { PendingChunk pd = prep_chunk(ro, pq + lo_m, count, lo, hi, qlo, qhi); flush_chunk(ro, pd); }
+            }
+            if constexpr (CLSOUT) {                                    // the tile ends inside a chunk: its word goes on in the next tile's chunk 0
+                const uint32_t cl = (M1p - 1u - A0p) >> 4;
+                if (t == (cl >> 6)) cls_carry = (M1p < pc.out_len && ((M1p - A0p) & 15u)) ? (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)(cl & 63u)) : 0u;
             }
         }
     };
@@ -734,6 +726,7 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
         const uint32_t cnt = (uint32_t)__popcll(__ballot(take));
         if (M1 <= M0) {                    // 64 events at one output offset (zero-length matches between deletions): not a case
             final_pass();                  // for the tile machinery; the generic path takes the tile
+            cls_carry = 0;
             wave_sync();
             M1 = min(M0 + T_OUT, pc.out_len);
             uint32_t j2 = jb;
@@ -749,7 +742,6 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
                 L0_wd = uni(event_word<MODE>(pc, key, a, j2 - 1)); L0_j = uni(j2 - 1);
             }
             jb = uni(j2); M0 = M1;
-            if constexpr (QUALS) qual_state_reset(Q);
             e_pre.pos = 0; e_pre.info = 0; w_pre = 0;
             if (jb + lane < pc.n_ev) e_pre = pc.ev[jb + lane];
             w_pre = event_word<MODE>(pc, key, a, jb + lane < pc.n_ev ? jb + lane : 0u);
@@ -804,13 +796,13 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
         }
         if (!fast) {
             final_pass();
+            cls_carry = 0;
             if (lane == 0) {
                 const uint32_t slot = atomicAdd(sq.count, 1u);
                 if (slot < sq.cap) sq.items[slot] = SlowTile{read_idx, piece_idx, M0, M1};
             }
             L0_out = osl; L0_rp = rpl; L0_pt = ptl; L0_wd = wdl; L0_j = jl;
             jb = jb_next; M0 = M1;
-            if constexpr (QUALS) qual_state_reset(Q);
             wave_sync();
             continue;
         }
@@ -949,10 +941,57 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
         have_prev = true; A0p = A0; M0p = M0; M1p = M1;
         jb = jb_next; M0 = M1;
         wave_sync();
-        // the kernels that draw qualities have no registers to carry a tile's loads across the final pass of the tile before (they
-        // spill: FASTQ 15.8 -> 16.4 ms): their final pass follows at once
-        if constexpr (QUALS) { final_pass(); wave_sync(); }
     }
     final_pass();
     wave_sync();
+}
+
+// ---- the quality lines (k_qualities) ----------------------------------------------------------------------------------------------
+// One lane per 16 positions of a quality stream, [16 j, 16 j + 16): exactly its Philox blocks 2 j and 2 j + 1 (the 16-bit draw of position
+// m is halfword m & 7 of block m >> 3), sixteen bucket look-ups in LDS, one 16-byte store (the quality line starts wherever the sequence
+// line ends: no grid is aligned with it).
+__device__ __forceinline__ void quals16(const QualState &Q, const DevModel &m, const ns_key &key, uint32_t stream, uint32_t sid, uint32_t a,
+                                        uint32_t j, const uint32_t cs[4], uint64_t &qlo, uint64_t &qhi) {
+    const u32x4 k1 = ns_draw(key, stream, sid, a, 2u * j, 0), k2 = ns_draw(key, stream, sid, a, 2u * j + 1u, 0);
+    const uint32_t D[8] = {k1.x, k1.y, k1.z, k1.w, k2.x, k2.y, k2.z, k2.w};
+    qual_lookup16(Q, m, D, cs, false, qlo, qhi);
+}
+// A piece: the class words lie on the record kernel's chunk grid, g positions ahead of the piece's positions — two neighbouring words,
+// funnel-shifted; the next iteration's words are in flight during this one's draws.  kind != 0 (the gap of a chimeric read): every base
+// is of class `unmapped` (S:1564), no class words.
+__device__ inline void qualities_piece(const DevModel &m, const QualState &Q, const ReadOut &ro, const ns_key &key, uint32_t a, uint32_t sid,
+                                       uint32_t kind, uint32_t out_len, uint32_t pq, const uint32_t *__restrict__ cls, uint32_t lane) {
+    const uint32_t phi = ro.reversed ? ((uint32_t)(uintptr_t)ro.seq + ro.seq_len - pq) & 15u : (0u - ((uint32_t)(uintptr_t)ro.seq + pq)) & 15u;
+    const uint32_t g2 = 2u * ((0u - phi) & 15u);               // word k of the piece: positions [16 k - g, 16 k - g + 16)
+    const uint32_t nchunks = (out_len + 15u) >> 4;
+    uint32_t wl = 0, wh = 0;
+    if (!kind && lane < nchunks) { wl = cls[lane]; wh = cls[lane + 1u]; }      // (the word behind the piece's last: allocated, any value)
+    for (uint32_t j = lane; j < nchunks; j += 64) {
+        const uint32_t w = __builtin_amdgcn_alignbit(wh, wl, g2);
+        if (!kind && j + 64u < nchunks) { wl = cls[j + 64u]; wh = cls[j + 65u]; }
+        uint32_t cs[4];
+        if (kind) cs[0] = cs[1] = cs[2] = cs[3] = 0x08080808u * (uint32_t)NS_Q_UNMAPPED;
+        else { cs[0] = cls_unpack4(w, 0); cs[1] = cls_unpack4(w, 1); cs[2] = cls_unpack4(w, 2); cs[3] = cls_unpack4(w, 3); }
+        uint64_t qlo, qhi;
+        quals16(Q, m, key, ST_QUAL, sid, a, j, cs, qlo, qhi);
+        store_qual_chunk(ro, pq + 16u * j, min(16u, out_len - 16u * j), qlo, qhi);
+    }
+}
+// head and tail (S:1421-1423): ONE stream of head + tail draws of class `ht`; the first `head` go to the start of the read, the rest to its
+// end — the chunk that holds both is stored in two parts
+__device__ inline void qualities_head_tail(const DevModel &m, const QualState &Q, const ReadOut &ro, const ns_key &key, uint32_t a,
+                                           uint32_t head, uint32_t tail, uint32_t lane) {
+    const uint32_t total = head + tail;
+    for (uint32_t j = lane; 16u * j < total; j += 64) {
+        const uint32_t cs[4] = {0x08080808u * (uint32_t)NS_Q_HT, 0x08080808u * (uint32_t)NS_Q_HT, 0x08080808u * (uint32_t)NS_Q_HT, 0x08080808u * (uint32_t)NS_Q_HT};
+        uint64_t qlo, qhi;
+        quals16(Q, m, key, ST_HTQ, 0, a, j, cs, qlo, qhi);
+        const uint32_t m0 = 16u * j, m1 = min(m0 + 16u, total);
+        if (m0 < head) store_qual_chunk(ro, m0, min(m1, head) - m0, qlo, qhi);
+        if (m1 > head) {
+            const uint32_t lo = max(m0, head);
+            shift_down_bytes(qlo, qhi, lo - m0);
+            store_qual_chunk(ro, ro.seq_len - tail + (lo - head), m1 - lo, qlo, qhi);
+        }
+    }
 }
