@@ -107,6 +107,7 @@ struct GenArgs {
     ns_event *events;
     uint8_t *records;
     uint8_t *errlog;
+    const uint8_t *hp_bm;       // -k: two bits per reference base (k_hp_bitmap), nullptr: none
     uint32_t *cls;              // FASTQ: the class of every base of the aligned pieces, 2 bits each (k_materialise -> k_qualities; cls_word0)
     unsigned long long *stats;  // [0] overflow reads [1] total bases [2] total ref bases [3] events [4] longest accepted read (unaligned batches)
                                 // [5] reads that failed the final length check of -k [6] reads queued for the next pass [7] -k event capacity overflow
@@ -905,6 +906,34 @@ __global__ void __launch_bounds__(64) k_materialise_slow_hpf(GenArgs A, SlowQueu
 // ---------------------------------------------------------------------------------------------------------
 // -k kernels (ns_hp.h)
 // ---------------------------------------------------------------------------------------------------------
+// Homopolymer bitmap of the reference for one k, two bits per base (position p: bits 2p and 2p + 1 of the byte array):
+//   bit 0: p lies in a run of >= k identical unambiguous bases of the reference as stored (runs are not cut at chromosome ends: a
+//          segment never crosses one, and a run a segment cuts is looked at again — k_hp_filter_w);
+//   bit 1: an IUPAC code within k - 1 bases of p: what case_convert (S:743-755) makes of it is the read's own draw, so the runs around
+//          it are, and the filter walks the bases.
+// Built once per (reference, k); the filter then tests an event with one 8-byte load instead of a 16-byte window of the reference
+// per k bases of the event (13.2 KB of reference per 8.4 kb read, 3.6 ms per 950 000 reads).
+__global__ void __launch_bounds__(256) k_hp_bitmap(const uint8_t *__restrict__ bases, uint64_t n, uint32_t k, uint8_t *__restrict__ bm) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t * 4 >= n) return;
+    uint32_t out = 0;
+    for (uint32_t i = 0; i < 4; ++i) {
+        const uint64_t p = t * 4 + i;
+        if (p >= n) break;
+        const uint8_t b = bases[p];
+        bool amb = (b & 0x80u) != 0;
+        uint32_t l = 0, r = 0;
+        bool lrun = !amb, rrun = !amb;
+        for (uint32_t j = 1; j < k; ++j) {
+            if (p >= j) { const uint8_t c = bases[p - j]; if (c & 0x80u) amb = true; if (lrun && c == b) ++l; else lrun = false; } else lrun = false;
+            if (p + j < n) { const uint8_t c = bases[p + j]; if (c & 0x80u) amb = true; if (rrun && c == b) ++r; else rrun = false; } else rrun = false;
+        }
+        if (!(b & 0x80u) && l + r + 1 >= k) out |= 1u << (2 * i);
+        if (amb) out |= 2u << (2 * i);
+    }
+    bm[t] = (uint8_t)out;
+}
+
 // -k filter of mutate_read (S:1929-1947), one read per wavefront: lane per event (the homopolymer test of an event is independent of the others), ballot /
 // prefix-popcount compaction, exclusive wavefront prefix sum of the length changes for the shift field
 __global__ void __launch_bounds__(64 * NS_WPB) k_hp_filter_w(GenArgs A) {
@@ -927,14 +956,33 @@ __global__ void __launch_bounds__(64 * NS_WPB) k_hp_filter_w(GenArgs A) {
             uint32_t w = 0; int32_t shift = 0;                            // kept events / their cumulative length change so far
             const bool win = k <= 16 && !(pc.pos + pc.ref_len > pc.chrom_len);   // (a segment across the origin takes the generic walk)
             const bool win8 = win && k <= 8;
+            const uint8_t *bm = (win && pc.chrom_len != ~0ull) ? A.hp_bm : nullptr;   // (not for spliced stretches: they lie in the arena)
             for (uint32_t j0 = 0; j0 < p.n_ev; j0 += 64) {                // S:1929-1947
                 const uint32_t j = j0 + lane;
                 const bool valid = j < p.n_ev;
                 ns_event e; e.pos = 0; e.info = 0;
                 if (valid) e = ev[j];
                 const int64_t pos = e.pos, len = ns_ev_len(e.info); const uint32_t ty = ns_ev_type(e.info);
-                bool keep = valid;
-                if (valid) {
+                bool keep = valid, walk = valid;
+                if (valid && bm) {                  // the bitmap decides unless an IUPAC code is near, or the run it shows may be cut by the segment's ends
+                    const int64_t lo = max((int64_t)(ty == NS_INS ? pos - 1 : pos), (int64_t)0), hi = min(pos + len - 1, (int64_t)pc.ref_len - 1);
+                    walk = false;
+                    for (int64_t x = lo; x <= hi; x += 28) {
+                        const uint64_t gb = 2ull * (pc.chrom_base + pc.pos + (uint64_t)x);
+                        uint64_t v;
+                        __builtin_memcpy(&v, bm + (gb >> 3), 8);
+                        v >>= (gb & 7u);
+                        const uint32_t nb = (uint32_t)min((int64_t)28, hi - x + 1);
+                        v &= (1ull << (2u * nb)) - 1ull;
+                        if (v & 0xaaaaaaaaaaaaaaaaull) { walk = true; break; }
+                        if (v) {
+                            const int64_t xs = x + (__builtin_ctzll(v) >> 1);          // first base of the event inside a run of the reference
+                            if (xs >= k - 1 && xs + k <= (int64_t)pc.ref_len) keep = false; else walk = true;
+                            break;
+                        }
+                    }
+                }
+                if (walk) {
                     const int64_t lo = ty == NS_INS ? pos - 1 : pos, hi = pos + len - 1;
                     // [lo, hi] overlaps a run of >= k bases iff the run holds lo, hi or — lying strictly inside — one of lo + k, lo + 2k, ...
                     for (int64_t x = lo; keep; x = min(x + k, hi)) {
@@ -1388,7 +1436,7 @@ struct ns_ctx {
     int slot = 0;                      // slot of the last batch
     IoEngine *io = nullptr;            // copy stream, staging slices, writer threads (created by the first ns_sink_open)
     std::vector<ns_sink *> sinks;
-    DevBuf sort_key, sort_idx, sort_key_out, order, list_b, list_c, rstate, att_base, scr, scr_len, scr_off, hp_len, hp_nev, hp_ev, hp_wd, hp_runs, hp_nrun, slow_q, cls;
+    DevBuf sort_key, sort_idx, sort_key_out, order, list_b, list_c, rstate, att_base, scr, scr_len, scr_off, hp_len, hp_nev, hp_ev, hp_wd, hp_runs, hp_nrun, slow_q, cls, hp_bm;
     uint32_t hp_shift = 5, hp_pad = 64, hp_cap_k = 0;       // -k: event capacity of a piece (hp_ev_slot), planned for kmer_bias hp_cap_k
     // metagenome: species view of the reference, abundances of the sample, per-pass scratch
     DevBuf species_chrom_off, t_reads, t_pieces, t_name_len, t_rec_len, t_err_len, accept, accept_scan, key_pos, draw_x, m_segptr,
@@ -1410,6 +1458,7 @@ struct ns_ctx {
     std::vector<double> abun, abun_inflated, last_species_bases;
     bool lds_tables = false, coop_ok = false;
     size_t lds_bytes = 0;
+    uint32_t hp_bm_k = 0;                // -k: the k the bitmap hp_bm was built for (0: none)
     ns_batch_info last{};
     hipEvent_t evt[16]{};
     bool evt_ok = false;
@@ -1565,7 +1614,7 @@ void ns_destroy(ns_ctx *ctx) {
                       &ctx->t_name_len, &ctx->t_rec_len, &ctx->t_err_len, &ctx->accept, &ctx->accept_scan, &ctx->key_pos,
                       &ctx->draw_x, &ctx->m_segptr, &ctx->m_len, &ctx->m_species, &ctx->species_bases, &ctx->draw_sel,
                       &ctx->draw_sorted, &ctx->meta_words, &ctx->meta_num, &ctx->trx_chrom, &ctx->trx_cum, &ctx->trx_polya, &ctx->polya,
-                      &ctx->ir_need, &ctx->ir_off, &ctx->spliced, &ctx->p_need, &ctx->p_off, &ctx->cls};
+                      &ctx->ir_need, &ctx->ir_off, &ctx->spliced, &ctx->p_need, &ctx->p_off, &ctx->cls, &ctx->hp_bm};
     for (auto *pb : {&ctx->pin_a, &ctx->pin_b, &ctx->pin_c, &ctx->pin_d})
         if (pb->p) e = hipHostFree(pb->p);
     if (ctx->pin_small) e = hipHostFree(ctx->pin_small);
@@ -1624,6 +1673,7 @@ static int install_reference(ns_ctx *ctx, const void *src, bool src_on_device, u
     int rc = set_ref_meta(ctx, chrom_off, nchrom, circular, names, names_len);
     if (rc) return rc;
     ctx->ref_nbases = nbases;
+    ctx->hp_bm_k = 0;                    // (the homopolymer bitmap of the last reference)
     ctx->has_ref = true;
     return NS_OK;
 }
@@ -1925,6 +1975,18 @@ static int hp_stage1(ns_ctx *ctx, const ns_params *prm, GenArgs &A, size_t n, ui
     if ((rc = ensure(ctx, ctx->hp_len, (size_t)tot_pieces * 4 + 64)) || (rc = ensure(ctx, ctx->hp_nev, (size_t)tot_pieces * 4 + 64)) ||
         (rc = ensure(ctx, ctx->hp_nrun, (size_t)tot_pieces * 4 + 64))) return rc;
     A.hp_len = (uint32_t *)ctx->hp_len.p; A.hp_nev = (uint32_t *)ctx->hp_nev.p;
+    A.hp_bm = nullptr;
+    if (prm->kmer_bias >= 2 && prm->kmer_bias <= 16 && !getenv("NS_NO_HP_BITMAP")) {
+        if (ctx->hp_bm_k != prm->kmer_bias) {           // once per (reference, k)
+            const uint64_t nb = ctx->ref_nbases, nthreads = (nb + 3) / 4;
+            if ((rc = ensure(ctx, ctx->hp_bm, (size_t)nthreads + 64))) return rc;
+            HIPCHK(hipMemsetAsync((uint8_t *)ctx->hp_bm.p + nthreads, 0, 64, st));       // (8-byte loads may run past the last base)
+            k_hp_bitmap<<<dim3((unsigned)((nthreads + 255) / 256)), blk, 0, st>>>(ctx->ref.bases, nb, prm->kmer_bias, (uint8_t *)ctx->hp_bm.p);
+            HIPCHK(hipGetLastError());
+            ctx->hp_bm_k = prm->kmer_bias;
+        }
+        A.hp_bm = (const uint8_t *)ctx->hp_bm.p;
+    }
     k_hp_filter_w<<<dim3((unsigned)((n + NS_WPB) / NS_WPB)), dim3(64 * NS_WPB), 0, st>>>(A);
     HIPCHK(hipGetLastError());
     if ((rc = scan_u64(ctx, A.scr_len, A.scr_off, n + 1))) return rc;
