@@ -264,8 +264,11 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #ifndef NS_CHAIN_BLOCK
 #define NS_CHAIN_BLOCK 256     // threads per block of the thread-per-read chain (320 was measured slower: 4.56 vs 4.09 ms)
 #endif
+#ifndef NS_CHAIN_MINW
+#define NS_CHAIN_MINW 4
+#endif
 template <bool LDS_TABLES, bool COOP>
-__global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A) {
+__global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK, COOP ? 4 : NS_CHAIN_MINW) k_chain(GenArgs A) {
     extern __shared__ uint64_t lds_tbl[];
     CoopLds *coop = nullptr;
     if constexpr (COOP) { __shared__ CoopLds coop_lds; coop = &coop_lds; }
@@ -323,7 +326,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK) k_chain(GenArgs A)
                 if (kind == NS_KIND_PERFECT) { e.l_new = e.middle_ref = m32; }
                 else if (p.kind) e = COOP ? coop_unaligned_error_list(T, ct, m32, key, sid, a, sink, lane) : chain_unaligned_error_list(T, ct, m32, key, sid, a, sink);
                 else if (COOP) e = coop_error_list(T, ct, m32, key, sid, a, sink, *coop, lane);
-                else e = chain_error_list<LDS_TABLES>(T, ct, m32, key, sid, a, sink);
+                else e = chain_error_list<LDS_TABLES>(T, Tabs{A.m.chain_blob}, ct, m32, key, sid, a, sink);
                 ev_flush_tail(sink);
                 p.ev_off = ev_off + evn;
                 p.ref_len = (uint32_t)(e.middle_ref < 0 ? 0 : e.middle_ref);
@@ -1780,7 +1783,7 @@ int ns_load_model(ns_ctx *ctx, const ns_model_tables *t) {
                 ct.mix_g2[ty][c] = put_raw(g2, 40);
             }
         ct.fm_n = t->fm_nseg; ct.fm_vlo0 = t->fm_vlo0;
-        ct.fm_hi = put_d(t->fm_hi, t->fm_nseg);
+        ct.fm_g = put_thr(t->fm_hi, t->fm_nseg, true);           // p > hi[s]: the segment search of the ECDF look-ups (ecdf_lookup_u)
         { auto g = guide(t->fm_hi, t->fm_nseg); ct.fm_guide = put_raw(g.data(), 512); }
         ct.mm_nbins = t->mm_nbins;
         std::vector<int32_t> bins(2 * (size_t)t->mm_nbins);
@@ -1800,7 +1803,7 @@ int ns_load_model(ns_ctx *ctx, const ns_model_tables *t) {
             ct.mm_bin_lut = put_raw(lut.data(), 256);
         }
         ct.mm_seg_off = put_raw(t->mm_seg_off, ((size_t)t->mm_nbins + 1) * 4);
-        ct.mm_hi = put_d(t->mm_hi, nseg); ct.mm_vlo0 = put_d(t->mm_vlo0, t->mm_nbins);
+        ct.mm_g = put_thr(t->mm_hi, nseg, true); ct.mm_vlo0 = put_d(t->mm_vlo0, t->mm_nbins);
         std::vector<uint16_t> gall;
         for (uint32_t b = 0; b < t->mm_nbins; ++b) {
             auto g = guide(t->mm_hi + t->mm_seg_off[b], t->mm_seg_off[b + 1] - t->mm_seg_off[b]);
@@ -1810,12 +1813,48 @@ int ns_load_model(ns_ctx *ctx, const ns_model_tables *t) {
         // value edges: whole numbers in every model read_analysis.py writes (its bins are "i-(i+1)") -> 32-bit copies for the LDS image;
         // the fp64 originals follow behind the part that is copied to LDS (the cooperative chain and a model with fractional edges read those)
         bool whole = true;
-        auto put_u = [&](const double *src, size_t n) {
-            std::vector<uint32_t> v(n);
-            for (size_t i = 0; i < n; ++i) { if (!(src[i] >= 0 && src[i] < 4294967296.0 && src[i] == floor(src[i]))) whole = false; v[i] = (uint32_t)(src[i] < 0 ? 0 : src[i] >= 4294967295.0 ? 4294967295.0 : src[i]); }
-            return put_raw(v.data(), n * 4); };
-        ct.fm_vhi_u = put_u(t->fm_vhi, t->fm_nseg); ct.mm_vhi_u = put_u(t->mm_vhi, nseg);
+        // The steps of the interpolation floor((p - plo) / (hs - plo) * (vs - vlo) + vlo) inside a segment, found with the arithmetic of
+        // the fp64 formula (this file is compiled with -ffp-contract=off, like the device code and the oracle) — ecdf_lookup_u:
+        // bit 31 of a value edge: one unit wide and every draw gives vlo; else, up to 15 units wide: thresholds in `sub`, their number
+        // and position in the upper bits of the segment's G word
+        std::vector<uint64_t> sub;
+        auto put_u = [&](uint32_t g_off, const double *hi, const double *src, size_t n, double vlo0, std::vector<uint32_t> &v) {
+            for (size_t i = 0; i < n; ++i) {
+                if (!(src[i] >= 0 && src[i] < 2147483648.0 && src[i] == floor(src[i]))) whole = false;
+                uint32_t e = (uint32_t)(src[i] < 0 ? 0 : src[i] >= 2147483647.0 ? 2147483647.0 : src[i]);
+                const double hs = hi[i], plo = i ? hi[i - 1] : 0.0, vs = src[i], vlo = i ? src[i - 1] : vlo0;
+                const double w = vs - vlo;
+                if (w >= 1.0 && w <= 15.0 && w == floor(w) && hs > plo && vlo == floor(vlo) && vlo >= 0) {
+                    auto f = [&](uint64_t u) { const double pp = u32_to_p((uint32_t)u); return floor((pp - plo) / (hs - plo) * (vs - vlo) + vlo); };
+                    const uint64_t u0 = i ? ns_thr_gt(plo) : 0ull, u1 = ns_thr_gt(hs);     // the draws of the segment: [u0, u1)
+                    uint64_t thr[15];
+                    for (uint32_t k = 1; k <= (uint32_t)w; ++k) {                          // smallest draw of the segment that gives >= vlo + k
+                        uint64_t lo = u0, hi2 = u1;                                         // (f is non-decreasing in the draw)
+                        while (lo < hi2) { const uint64_t mid = lo + ((hi2 - lo) >> 1); if (f(mid) >= vlo + (double)k) hi2 = mid; else lo = mid + 1; }
+                        thr[k - 1] = lo >= u1 ? (1ull << 32) : lo;
+                    }
+                    if (w == 1.0 && thr[0] == (1ull << 32)) e |= 0x80000000u;
+                    else {
+                        blob[g_off + i] |= (uint64_t)(uint32_t)w << 36 | (uint64_t)sub.size() << 40;
+                        sub.insert(sub.end(), thr, thr + (uint32_t)w);
+                    }
+                }
+                v.push_back(e);
+            } };
+        { std::vector<uint32_t> v; put_u(ct.fm_g, t->fm_hi, t->fm_vhi, t->fm_nseg, t->fm_vlo0, v); ct.fm_vhi_u = put_raw(v.data(), v.size() * 4); }
+        {
+            std::vector<uint32_t> v;                               // per column: its first segment starts at the column's vlo0
+            for (uint32_t b = 0; b < t->mm_nbins; ++b) {
+                const uint32_t o = t->mm_seg_off[b];
+                put_u(ct.mm_g + o, t->mm_hi + o, t->mm_vhi + o, t->mm_seg_off[b + 1] - o, t->mm_vlo0[b], v);
+            }
+            ct.mm_vhi_u = put_raw(v.data(), v.size() * 4);
+        }
+        if (sub.size() >= (1u << 24)) whole = false;
+        sub.push_back(0);
+        ct.sub = put_raw(sub.data(), sub.size() * 8);
         ct.n_words_lds = (uint32_t)blob.size();
+        ct.fm_hi = put_d(t->fm_hi, t->fm_nseg); ct.mm_hi = put_d(t->mm_hi, nseg);      // fp64 tables: global memory (wide segments, cooperative chain)
         ct.fm_vhi = put_d(t->fm_vhi, t->fm_nseg); ct.mm_vhi = put_d(t->mm_vhi, nseg);
         ct.n_words = (uint32_t)blob.size();
         if ((rc = upload(ctx, pool, blob.data(), blob.size(), &m.chain_blob))) return rc;

@@ -36,6 +36,46 @@ __device__ __forceinline__ int32_t ecdf_lookup_g(const double *__restrict__ hi, 
     return (int32_t)floor((p - plo) / (hs - plo) * (vs - vlo) + vlo);
 }
 
+// The same look-up without floating point, for the LDS image (k_chain<LDS>).  The segment search compares the draw with integer
+// thresholds (bits 0..32 of G[s] = ns_thr_gt(hi[s]): p > hi[s] <=> u >= G[s], exactly).  Inside a segment (vlo, vhi] the interpolation
+// floor(frac * (vhi - vlo) + vlo) is a non-decreasing step function of the draw, and the host (ns_load_model) finds its steps with the
+// arithmetic of the fp64 formula:
+//   * bit 31 of the 32-bit value edge: the segment is one unit wide and every draw inside it gives vlo (the histograms read_analysis.py
+//     writes have bins one unit wide: all but the sparse tails and the first segment of a column, which S:216-221 stretches down);
+//   * else bits 36..39 of G[s]: w = vhi - vlo <= 15 and bits 40.. point at w thresholds t_1..t_w in `sub` (t_k: the smallest draw that
+//     gives vlo + k; 2^32: none): the result is vlo + #{k : u >= t_k};
+//   * else (wider segments: empty bins merged) the fp64 formula on the global tables.
+// A draw above the last edge is clamped to it (the reference would keep a stale value): frac = 1 exactly -> vhi.
+#define NS_G_THR(g) ((g) & 0x1ffffffffull)
+__device__ __forceinline__ int32_t ecdf_lookup_u(const uint64_t *__restrict__ G, const uint32_t *__restrict__ vhi_u, uint32_t n,
+                                                 const uint16_t *__restrict__ guide, uint32_t u, const uint64_t *__restrict__ sub,
+                                                 const double *__restrict__ hi_g, const double *__restrict__ vhi_g, double vlo0) {
+    uint32_t s = guide[u >> 24];
+    const uint64_t uu = u;
+    if (s < n) {
+        const uint64_t g0 = G[s], g1 = G[min(s + 1, n - 1)];
+        if (uu >= NS_G_THR(g0)) {
+            ++s;
+            if (s < n && uu >= NS_G_THR(g1)) { ++s; while (s < n && uu >= NS_G_THR(G[s])) ++s; }
+        }
+    }
+    if (s >= n) return (int32_t)(vhi_u[n - 1] & 0x7fffffffu);
+    const uint32_t v = vhi_u[s];
+    if (v & 0x80000000u) return (int32_t)(v & 0x7fffffffu) - 1;
+    const uint64_t g = G[s];
+    const uint32_t nt = (uint32_t)(g >> 36) & 15u;
+    if (nt) {
+        const uint64_t *t = sub + (g >> 40);
+        int32_t r = (int32_t)v - (int32_t)nt;
+        for (uint32_t k = 0; k < nt; ++k) r += uu >= t[k] ? 1 : 0;
+        return r;
+    }
+    const double p = u32_to_p(u);
+    const uint32_t sm = s ? s - 1 : 0;
+    const double hs = hi_g[s], plo = s ? hi_g[sm] : 0.0, vs = vhi_g[s], vlo = s ? vhi_g[sm] : vlo0;
+    return (int32_t)floor((p - plo) / (hs - plo) * (vs - vlo) + vlo);
+}
+
 // mixture run length (mm:41-63) on integer thresholds: component by u_mix < T(weight), value = 1 + #{j : p > cdf[j]} by walking
 // G[j] = ns_thr_gt(cdf[j]) — no fp64 on the way
 __device__ __forceinline__ int32_t run_length_t(const Tabs &T, const ChainTab &c, int type, uint32_t u_mix, uint32_t u_len) {
@@ -94,14 +134,14 @@ __device__ __forceinline__ void ev_push32(EvSink32 &s, int32_t pos, uint32_t typ
 struct EList32 { int32_t l_new, middle_ref; };
 
 // error_list, S:1833-1916
-template <bool VU32>     // VU32: T is the LDS copy of the blob (value edges as 32-bit integers)
-__device__ __forceinline__ EList32 chain_error_list(const Tabs &T, const ChainTab &c, int32_t m_ref, const ns_key &key,
+template <bool VU32>     // VU32: T is the LDS copy of the blob (integer thresholds, value edges as 32-bit integers); TG: the whole blob in global memory
+__device__ __forceinline__ EList32 chain_error_list(const Tabs &T, const Tabs &TG, const ChainTab &c, int32_t m_ref, const ns_key &key,
                                                     uint32_t seg, uint32_t attempt, EvSink32 &s) {
     int32_t l_new = m_ref, pos = 0, middle_ref = m_ref;
     int state = NS_ST_START;
     u32x4 w = ns_draw(key, ST_EVENT, seg, attempt, 0, 0);
     int32_t prev_match;                                                                                           // S:1843-1850
-    if constexpr (VU32) prev_match = ecdf_lookup_g(T.d(c.fm_hi), T.u(c.fm_vhi_u), c.fm_n, c.fm_vlo0, T.h(c.fm_guide), w.x);
+    if constexpr (VU32) prev_match = ecdf_lookup_u(T.q(c.fm_g), T.u(c.fm_vhi_u), c.fm_n, T.h(c.fm_guide), w.x, T.q(c.sub), TG.d(c.fm_hi), TG.d(c.fm_vhi), c.fm_vlo0);
     else prev_match = ecdf_lookup_g(T.d(c.fm_hi), T.d(c.fm_vhi), c.fm_n, c.fm_vlo0, T.h(c.fm_guide), w.x);
     if (prev_match < 2) prev_match = 2;
     pos += prev_match;
@@ -136,8 +176,8 @@ __device__ __forceinline__ EList32 chain_error_list(const Tabs &T, const ChainTa
             if (b >= c.mm_nbins) b = c.mm_nbins - 1;
         }
         const uint32_t o = seg_off[b];
-        if constexpr (VU32) step = ecdf_lookup_g(T.d(c.mm_hi) + o, T.u(c.mm_vhi_u) + o, seg_off[b + 1] - o, T.d(c.mm_vlo0)[b],
-                                                 T.h(c.mm_guide) + 256 * b, w.w);
+        if constexpr (VU32) step = ecdf_lookup_u(T.q(c.mm_g) + o, T.u(c.mm_vhi_u) + o, seg_off[b + 1] - o, T.h(c.mm_guide) + 256 * b, w.w, T.q(c.sub),
+                                                 TG.d(c.mm_hi) + o, TG.d(c.mm_vhi) + o, T.d(c.mm_vlo0)[b]);
         else step = ecdf_lookup_g(T.d(c.mm_hi) + o, T.d(c.mm_vhi) + o, seg_off[b + 1] - o, T.d(c.mm_vlo0)[b],
                                   T.h(c.mm_guide) + 256 * b, w.w);
         if (prev_match == 0 && step == 0) step = 1;                                                // S:1900-1901

@@ -12,7 +12,10 @@ struct ChainTab {                 // offsets are in 8-byte words from the start 
     uint32_t mix_cdf[3][2], mix_n[3][2];
     uint32_t mix_g2[3][2];        // per table: 33 bytes, guide of the threshold walk by the leading one bits of the draw (run_length_t)
     uint32_t fm_hi, fm_vhi, fm_n, fm_guide;
-    uint32_t fm_vhi_u, mm_vhi_u;     // the value edges once more as 32-bit integers (they are whole numbers in every trained model): what the LDS copy holds
+    uint32_t fm_vhi_u, mm_vhi_u;     // the value edges once more as 32-bit integers (they are whole numbers in every trained model): what the LDS copy holds;
+                                     // bit 31: the segment is one unit wide and no draw inside it rounds up to its upper edge (ecdf_lookup_u)
+    uint32_t fm_g, mm_g;             // the probability edges as integer thresholds of the 32-bit draw (ns_thr_gt), 8 bytes each: LDS copy
+    uint32_t sub;                    // the steps of the interpolation inside the narrow segments that are not flagged (ecdf_lookup_u)
     uint32_t n_words_lds;            // the blob up to here goes to LDS (k_chain<LDS>); the fp64 value edges behind it stay in global memory
     uint32_t mm_nbins, mm_bin, mm_bin_lut, mm_seg_off, mm_hi, mm_vhi, mm_vlo0, mm_guide;
     double fm_vlo0;
