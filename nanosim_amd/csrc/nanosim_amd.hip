@@ -1455,7 +1455,6 @@ struct ns_ctx {
     uint64_t spliced_bytes = 0;
     uint8_t *pin_small = nullptr;    // page-locked slots for the scalar read-backs of a call (read_small)
     struct PinBuf { void *p = nullptr; size_t cap = 0; } pin_a, pin_b, pin_c, pin_d;     // pinned host staging of the metagenome passes
-    std::vector<uint8_t> h_nseg;                               // metagenome: num_segment of the batch (S:825-828)
     uint32_t nspecies = 0;
     bool has_abun = false, has_inflated = false, has_key_pos = false;
     std::vector<double> abun, abun_inflated, last_species_bases;
@@ -1581,7 +1580,7 @@ int ns_create(int device, ns_ctx **out) {
 // synchronised in between.  (hipMemcpyAsync into pageable memory goes through a staging blit kernel; next to another context's
 // kernels on the same GPU that costs hundreds of microseconds per read-back.)
 static int read_small(ns_ctx *ctx, hipStream_t st, void *dst, const void *src, size_t n, void *dst2 = nullptr, const void *src2 = nullptr, size_t n2 = 0) {
-    if (n > 512 || n2 > 512) return fail(ctx, NS_EINVAL, "read_small: too large");
+    if (n > (dst2 ? 512u : 1024u) || n2 > 512) return fail(ctx, NS_EINVAL, "read_small: too large");
     HIPCHK(hipMemcpyAsync(ctx->pin_small, src, n, hipMemcpyDeviceToHost, st));
     if (dst2) HIPCHK(hipMemcpyAsync(ctx->pin_small + 512, src2, n2, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -2285,6 +2284,18 @@ static uint64_t assign_species_host(const ns_ctx *ctx, const double *lens, uint6
     return ptr;
 }
 
+// histogram of num_segment over the reads [lo, n) of a metagenome batch (n_pieces = 2 * num_segment - 1): what the passes need of
+// remaining_segments (S:1034) — the reads are taken by descending segment count, so the counts per value say everything
+__global__ void __launch_bounds__(256) k_meta_hist(const uint32_t *__restrict__ n_pieces, uint64_t lo, uint64_t n, unsigned long long *__restrict__ hist) {
+    __shared__ uint32_t h[NS_MAX_SEG + 1];
+    if (threadIdx.x <= NS_MAX_SEG) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t i = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        atomicAdd(&h[min((n_pieces[i] + 1u) / 2u, (uint32_t)NS_MAX_SEG)], 1u);
+    __syncthreads();
+    if (threadIdx.x <= NS_MAX_SEG && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
 // positions of a pass in assignment order -> first segment / first piece of the read: the reads are sorted by descending segment count,
 // so both are closed forms of the histogram (S:862-865)
 struct MetaHist { uint32_t cnt[NS_MAX_SEG + 1]; };
@@ -2323,17 +2334,21 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
         t = t2;
     };
     auto tt = now();
-    // num_segment comes back through page-locked memory (4 MB at PCIe rate; into a std::vector it was a staged copy of milliseconds)
-    if ((rc = ensure_pin(ctx, ctx->pin_d, (n + 1) * 4))) return rc;
-    const uint32_t *npc = (const uint32_t *)ctx->pin_d.p;
-    HIPCHK(hipMemcpyAsync(ctx->pin_d.p, A.n_pieces, n * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    lap("k_nseg + D2H", tt);
-    std::vector<uint8_t> &nseg = ctx->h_nseg;                  // (kept across calls: no allocation, no zero-fill per batch)
-    if (nseg.size() < n) nseg.resize(n);
+    // num_segment (k_nseg) stays on the device: the passes need its histogram over the reads still missing, 65 counters per pass
+    if ((rc = ensure(ctx, ctx->meta_num, 16 + (NS_MAX_SEG + 1) * 8))) return rc;
+    unsigned long long *d_hist = (unsigned long long *)((uint8_t *)ctx->meta_num.p + 16);
+    uint64_t hist[NS_MAX_SEG + 1];
+    auto seg_hist = [&](uint64_t lo) -> int {
+        HIPCHK(hipMemsetAsync(d_hist, 0, (NS_MAX_SEG + 1) * 8, st));
+        k_meta_hist<<<dim3((unsigned)std::min<uint64_t>(1024, (n - lo + 255) / 256 + 1)), blk, 0, st>>>(A.n_pieces, lo, n, d_hist);
+        HIPCHK(hipGetLastError());
+        return read_small(ctx, st, hist, d_hist, (NS_MAX_SEG + 1) * 8);
+    };
+    if ((rc = seg_hist(0))) return rc;
+    lap("k_nseg + histogram", tt);
     tot_pieces = 0;
     uint64_t tot_seg = 0;
-    for (size_t i = 0; i < n; ++i) { const uint32_t v = (npc[i] + 1) / 2; nseg[i] = (uint8_t)v; tot_pieces += npc[i]; tot_seg += v; }
+    for (uint32_t v = 1; v <= NS_MAX_SEG; ++v) { tot_pieces += (2ull * v - 1ull) * hist[v]; tot_seg += (uint64_t)v * hist[v]; }
     if ((rc = ensure(ctx, ctx->pieces, tot_pieces * sizeof(ns_piece) + 64)) || (rc = ensure(ctx, ctx->t_pieces, tot_pieces * sizeof(ns_piece) + 64)) ||
         (rc = ensure(ctx, ctx->t_reads, n * sizeof(ns_read))) || (rc = ensure(ctx, ctx->t_name_len, (n + 1) * 2)) ||
         (rc = ensure(ctx, ctx->t_rec_len, (n + 1) * 8)) || (rc = ensure(ctx, ctx->t_err_len, (n + 1) * 8)) ||
@@ -2372,8 +2387,8 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
                                         "(min_len/max_len too narrow for this model, or its reads do not fit the event record: runs <= 4095 bases, "
                                             "insertion / deletion balance within +-131071 bases per segment)");
         const uint64_t m = n - passed;
-        uint64_t hist[NS_MAX_SEG + 1] = {0};                                       // num_segment[passed:], S:1034 — as a histogram: the reads
-        for (size_t i = passed; i < n; ++i) ++hist[nseg[i]];                       // are taken by descending segment count (S:760)
+        if (p && (rc = seg_hist(passed))) return rc;                               // num_segment[passed:], S:1034 — as a histogram: the reads
+                                                                                   // are taken by descending segment count (S:760)
         uint64_t D = 0;
         for (uint32_t v = 1; v <= NS_MAX_SEG; ++v) D += (uint64_t)v * hist[v];
         lap("histogram", tt);
@@ -2384,11 +2399,11 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
         if ((rc = ensure_pin(ctx, ctx->pin_a, (D + 1) * 8)) || (rc = ensure_pin(ctx, ctx->pin_b, (D + 1) * 8)) ||
             (rc = ensure_pin(ctx, ctx->pin_c, (D + 1) * 8)) || (rc = ensure(ctx, ctx->draw_sel, (D + 1) * 8)) ||
             (rc = ensure(ctx, ctx->draw_sorted, (D + 1) * 8)) || (rc = ensure(ctx, ctx->meta_words, (D + 1) * 8)) ||
-            (rc = ensure(ctx, ctx->meta_num, 16)))
+            false)
             return rc;
         double *h_draw = (double *)ctx->pin_a.p;
-        HIPCHK(hipMemcpyAsync(h_draw, P.draw_x, D * 8, hipMemcpyDeviceToHost, st));
-        // the same filter on the device (order kept), while the host takes sum(length_list) left to right
+        // the filter (S:857; --perfect: S:841) on the device, order kept; sum(length_list) (S:767) is taken left to right, as Python
+        // does, by the host — over the filtered values, while the device sorts them
         const MetaLenFilter flt{perfect ? (double)prm->min_len : 0.0, (double)prm->max_len, perfect};
         double *d_sel = (double *)ctx->draw_sel.p, *d_sorted = (double *)ctx->draw_sorted.p;
         {
@@ -2397,16 +2412,16 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
             if ((rc = ensure(ctx, ctx->scan_tmp, tmp))) return rc;
             HIPCHK(hipcub::DeviceSelect::If(ctx->scan_tmp.p, tmp, P.draw_x, d_sel, (int *)ctx->meta_num.p, (int)D, flt, st));
         }
-        HIPCHK(hipStreamSynchronize(st));
-        lap("draw + D2H", tt);
-        uint64_t V = 0;
-        double to_add = 0;
-        for (uint64_t j = 0; j < D; ++j) if (flt(h_draw[j])) { to_add += h_draw[j]; ++V; }      // S:857 (--perfect: S:841); S:767
+        int v_sel = 0;
+        if ((rc = read_small(ctx, st, &v_sel, ctx->meta_num.p, 4))) return rc;
+        lap("draw + filter", tt);
+        const uint64_t V = (uint64_t)v_sel;
         if (!V) continue;                                                          // S:858-859
         uint64_t chim = 0;
         for (uint32_t v = 2; v <= NS_MAX_SEG; ++v) chim += (uint64_t)v * hist[v];  // S:761: the first `chim` lengths keep their order
         if (chim > V) chim = V;
-        lap("filter", tt);
+        HIPCHK(hipMemcpyAsync(h_draw, d_sel, V * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(ctx->ev_fork, st));
         if (chim) HIPCHK(hipMemcpyAsync(d_sorted, d_sel, chim * 8, hipMemcpyDeviceToDevice, st));
         if (V > chim) {                                                            // S:764-765
             size_t tmp = 0;
@@ -2420,6 +2435,10 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
         uint2 *h_words = (uint2 *)ctx->pin_c.p;
         HIPCHK(hipMemcpyAsync(h_sorted, d_sorted, V * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(h_words, ctx->meta_words.p, V * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventSynchronize(ctx->ev_fork));
+        double to_add = 0;
+        for (uint64_t j = 0; j < V; ++j) to_add += h_draw[j];                      // S:767 (one dependent add per value: ~1 ms per 10^6)
+        lap("sum(length_list)", tt);
         HIPCHK(hipStreamSynchronize(st));
         lap("sort + words", tt);
         uint16_t *h_species = (uint16_t *)h_draw;                                  // the draws are no longer needed: reuse the staging
