@@ -708,7 +708,7 @@ k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, co
     const uint32_t a = rd.attempts;
     tile_lds_init(T, lane);
     uint32_t *cls = nullptr;
-    if constexpr (CLSOUT) cls = A.cls + cls_word0(rd.rec_off, rd.piece_off, 0, 0);
+    if constexpr (CLSOUT) cls = A.cls + cls_word0(rd.rec_off, r, cls_per_read(A.prm));
     if constexpr (MODE == MAT_HP_SCRATCH) {
         // -k, first pass: the pieces of the read before mutate_homo, forward strand, one after the other in the scratch buffer
         // (head, tail and polyA are written by the second pass; strand and T -> U are applied there)
@@ -763,7 +763,7 @@ __global__ void __launch_bounds__(64 * NS_MATQ_WAVES, NS_MATQ_MINW) k_qualities(
     const uint32_t a = rd.attempts;
     QualState Q; Q.lut = qlut;
     qualities_head_tail(A.m, Q, ro, key, a, rd.head, rd.tail, lane);                         // S:1421-1423
-    const uint32_t *cls = A.cls + cls_word0(rd.rec_off, rd.piece_off, 0, 0);
+    const uint32_t *cls = A.cls + cls_word0(rd.rec_off, r, cls_per_read(A.prm));
     uint32_t q = rd.head;
     for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
         const uint32_t gp = rd.piece_off + pi;
@@ -2798,7 +2798,8 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     A.records = (uint8_t *)ctx->rec_slot[slot].p; A.errlog = (uint8_t *)ctx->err_slot[slot].p;
     A.cls = nullptr;
     if (prm->emit_records == 1u && prm->fastq && prm->kind != NS_KIND_UNALIGNED) {      // class words: k_materialise -> k_qualities (cls_word0)
-        if ((rc = ensure(ctx, ctx->cls, (((size_t)info->record_bytes >> 4) + 2 * (size_t)tot_pieces + 64) * 4))) return rc;
+        const size_t per_read = prm->chimeric ? 2u * (2u * NS_MAX_SEG - 1u) : 2u;          // cls_per_read
+        if ((rc = ensure(ctx, ctx->cls, (((size_t)info->record_bytes >> 4) + per_read * (n + 1) + 64) * 4))) return rc;
         A.cls = (uint32_t *)ctx->cls.p;
     }
     const uint64_t max_unaligned = prm->kind == NS_KIND_UNALIGNED ? stats[1] : 0;      // emitted bases of the batch (k_chain): bounds the dense kernel's grid

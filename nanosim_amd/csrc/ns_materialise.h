@@ -589,11 +589,12 @@ __device__ __forceinline__ uint32_t cls_unpack4(uint32_t w, uint32_t k) {
     t |= e << 9; t |= e << 15; t |= e << 21;
     return t & 0x18181818u;
 }
-// class words of a read: first word of the read / of piece pi, which starts at output offset q of the read.  A piece of n bytes has at
-// most n / 16 + 2 chunks (its first and last may be partial), a FASTQ record is longer than twice its bases: no two pieces share a word
-__device__ __forceinline__ uint64_t cls_word0(uint64_t rec_off, uint32_t piece_off, uint32_t q, uint32_t pi) {
-    return (rec_off >> 4) + 2ull * piece_off + (q >> 4) + 2u * pi;
-}
+// class words of read r: a piece of n bytes has at most n / 16 + 2 chunks (its first and last may be partial) and a FASTQ record is
+// longer than twice its bases, so the words of a read fit behind (its record offset) / 16 once every read brings two words per piece it
+// can have (per_read = 2, chimeric batches 2 * (2 * NS_MAX_SEG - 1)); piece pi starts at output offset q of the read.  (Not the read's
+// piece_off: a chimeric read that was planned again lies behind the others, out of read order.)
+__device__ __forceinline__ uint64_t cls_word0(uint64_t rec_off, uint64_t r, uint32_t per_read) { return (rec_off >> 4) + r * per_read; }
+__device__ __forceinline__ uint32_t cls_per_read(const ns_params &prm) { return prm.chimeric ? 2u * (2u * NS_MAX_SEG - 1u) : 2u; }
 
 // the bucket tables of the classes a piece can hold, global -> LDS (all threads of the workgroup; the caller synchronises)
 __device__ __forceinline__ void qual_lut_load(uint16_t *lds, const DevModel &m, uint32_t tid, uint32_t nthreads) {

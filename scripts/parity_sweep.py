@@ -27,6 +27,8 @@ MODES = [
     ("circular chimeric fastq", "circ", dict(fastq=True, chimeric=True)),
     ("circular unaligned", "circ", dict(kind=E.NS_KIND_UNALIGNED)),
     ("narrow window", "lin", dict(min_len=3000, max_len=9000, fastq=True)),
+    ("circular chimeric fastq -k5", "circ", dict(fastq=True, chimeric=True, kmer_bias=5, emit_errlog=True)),
+    ("perfect fastq", "circ", dict(kind=E.NS_KIND_PERFECT, fastq=True)),
     ("unaligned, background ctx", "lin", dict(kind=E.NS_KIND_UNALIGNED, fastq=True, median_len=3000, sd_len=0.7, _background=True)),
 ]
 _CTX = {}
@@ -39,7 +41,10 @@ def digest(d):
     r = d["reads"]
     for f in ("n_pieces", "reversed", "flags", "head", "tail", "seq_len", "attempts"):
         h.update(np.ascontiguousarray(r[f]).tobytes())
-    p = d["pieces"]
+    # the pieces of every read through its piece_off (a chimeric read whose segment count changed with its epoch moved to fresh slots
+    # behind the planned ones: the arrays of engine and oracle differ in their unused slots, not in what the reads point at)
+    idx = np.concatenate([np.arange(int(o), int(o) + int(c)) for o, c in zip(r["piece_off"], r["n_pieces"])]) if len(r) else np.zeros(0, np.int64)
+    p = d["pieces"][idx]
     for f in ("ref_gpos", "pos", "ref_len", "out_len", "n_ev", "kind"):
         h.update(np.ascontiguousarray(p[f]).tobytes())
     ev = d["events"]

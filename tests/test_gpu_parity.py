@@ -385,3 +385,28 @@ def test_dense_homopolymer_edits_take_the_slow_tiles(small_model, fastq):
         assert int(np.max(pc["ref_len"].astype(np.int64) - pc["out_len"])) > 2000        # thousands of bases deleted inside one piece
     finally:
         e.close()
+
+
+def test_chimeric_fastq_with_reads_planned_again(small_model, circ_ref):
+    """FASTQ, chimeric, many segments per read (segment mean 2.5): reads whose segment count changes with their epoch move to piece slots
+    behind the planned ones, so piece_off is not in read order — the class words between the record kernel and k_qualities must not be
+    placed by it (round 3: a read's words were overwritten by a re-planned read's; found by scripts/parity_sweep.py, 1 chunk in 120)."""
+    import copy
+    m = copy.deepcopy(small_model)
+    m.segment_mean = 2.5
+    m.nseg_cdf = M.geometric_cdf(1.0 / m.segment_mean, 0)
+    e = E.Engine(0)
+    try:
+        e.set_reference(circ_ref)
+        e.load_model(m)
+        moved = 0
+        for first in (0, 3000):
+            p = E.make_params(seed=0xC0FFEE, first_read=first, n_reads=3000, fastq=True, chimeric=True, max_len=circ_ref.max_chrom)
+            b = e.generate(p)
+            compare(b, O.generate(m, circ_ref, p, bytes_per_read=160000, events_per_read=24000), p)
+            rd = b.reads()
+            po = rd["piece_off"].astype(np.int64)
+            moved += int(np.sum(po[1:] < po[:-1]))
+        assert moved > 0                       # some reads lie out of order in the piece array
+    finally:
+        e.close()
