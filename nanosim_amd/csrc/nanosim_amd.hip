@@ -85,6 +85,8 @@ struct GenArgs {
     uint32_t *hp_wd;                 //     (k_hp_drain; format: materialise_piece, MAT_HP_FINAL) and the letter word of every event
     uint32_t *hp_nev;                //     events per piece
     uint32_t hp_shift, hp_pad;       //     capacity of a piece: (scratch bytes >> hp_shift) + hp_pad events (hp_ev_slot)
+    uint32_t *hp_pcnt;               //     pieces per read / their exclusive scan: the ordinal of a piece in READ order (piece_off is not:
+    const uint32_t *hp_pord;         //     a chimeric read that was planned again lies behind the others)
     // metagenome (one pass = one `while remaining_reads` iteration of S:836-1036)
     uint32_t meta;                   // 0 genome, 1 metagenome
     uint32_t nspecies;
@@ -691,7 +693,8 @@ __device__ __forceinline__ bool load_read_uniform(const GenArgs &A, uint64_t r, 
 #define NS_MATQ_MINW 6          // waves per SIMD k_qualities is compiled for (80 VGPRs; for 8 it spills: 11.25 against 11.0 ms per FASTQ batch)
 #endif
 // first event slot / capacity of the homopolymer edits of the piece whose scratch bytes start at `pos` (bytes from the start of the
-// scratch buffer) and that is piece `piece` of the batch: a monotone function of both, so no scan is needed
+// scratch buffer) and that is the `piece`-th piece of the batch IN READ ORDER (A.hp_pord[read] + its number in the read — the order of
+// the scratch buffer): a monotone function of both, so the slots of no two pieces overlap
 __device__ __forceinline__ uint64_t hp_ev_slot(const GenArgs &A, uint64_t pos, uint32_t piece) { return (pos >> A.hp_shift) + (uint64_t)A.hp_pad * piece; }
 
 template <bool FASTQ, int MODE>
@@ -730,7 +733,7 @@ k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, co
             // the source is the scratch piece, the events are the homopolymer edits k_hp_drain filed for it (mutate_homo, S:618-705)
             const uint32_t gp = rd.piece_off + pi;
             const ns_piece p = A.pieces[gp];
-            const uint64_t eo = hp_ev_slot(A, q_in, gp);
+            const uint64_t eo = hp_ev_slot(A, q_in, uni(A.hp_pord[r]) + pi);
             pc.kind = uni(p.kind);
             pc.ev = A.hp_ev + eo; pc.wd = A.hp_wd + eo; pc.n_ev = pc.kind ? 0u : uni(A.hp_nev[gp]);
             pc.ref_len = uni(p.out_len); pc.out_len = pc.kind ? pc.ref_len : uni(A.hp_len[gp]);
@@ -859,7 +862,7 @@ __global__ void __launch_bounds__(64) k_materialise_slow_hpf(GenArgs A, SlowQueu
         }
         const uint32_t gp = rd.piece_off + t.piece;
         const ns_piece p = A.pieces[gp];
-        const uint64_t eo = hp_ev_slot(A, q_in, gp);
+        const uint64_t eo = hp_ev_slot(A, q_in, A.hp_pord[t.read] + t.piece);
         const ns_event *ev = A.hp_ev + eo;
         const uint32_t *wd = A.hp_wd + eo;
         const uint32_t n_ev = p.kind ? 0u : A.hp_nev[gp], sid = p.kind ? NS_GAP_SEG + (t.piece >> 1) : (t.piece >> 1);
@@ -943,9 +946,10 @@ __global__ void __launch_bounds__(64 * NS_WPB) k_hp_filter_w(GenArgs A) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r > A.prm.n_reads) return;
-    if (r == A.prm.n_reads) { if (lane == 0) A.scr_len[r] = 0; return; }
+    if (r == A.prm.n_reads) { if (lane == 0) { A.scr_len[r] = 0; A.hp_pcnt[r] = 0; } return; }
     ns_read rd = A.reads[r];
-    if (rd.flags) { if (lane == 0) A.scr_len[r] = 0; return; }
+    if (rd.flags) { if (lane == 0) { A.scr_len[r] = 0; A.hp_pcnt[r] = 0; } return; }
+    if (lane == 0) A.hp_pcnt[r] = rd.n_pieces;
     const ns_key key = read_key(A, r);
     const uint32_t a = rd.attempts;
     const int64_t k = (int64_t)A.prm.kmer_bias;
@@ -1089,8 +1093,9 @@ __global__ void __launch_bounds__(64 * NS_WPB) k_hp_scan(GenArgs A, uint2 *__res
         const uint32_t n = uni(p.out_len);
         if (!uni(p.kind)) {
             const uint8_t *sq = A.scr + scr_off + q;
-            const uint64_t ev0 = hp_ev_slot(A, scr_off + q, gp);
-            const uint64_t cap64 = hp_ev_slot(A, scr_off + q + n, gp + 1) - ev0;
+            const uint32_t ord = uni(A.hp_pord[r]) + pi;
+            const uint64_t ev0 = hp_ev_slot(A, scr_off + q, ord);
+            const uint64_t cap64 = hp_ev_slot(A, scr_off + q + n, ord + 1) - ev0;
             const uint32_t cap = cap64 > 0xffffffffull ? 0xffffffffu : (uint32_t)cap64;
             uint2 *dst = runs + ev0;
             uint32_t n_out = 0;                                                  // runs of the piece written so far (wave-uniform)
@@ -1201,8 +1206,9 @@ __global__ void __launch_bounds__(64 * NS_WPB, NS_HPD_WAVES) k_hp_drain(GenArgs 
         uint32_t flen = n;
         if (!uni(p.kind)) {
             const uint32_t sid = pi >> 1;
-            const uint64_t ev0 = hp_ev_slot(A, scr_off + q, gp);
-            const uint64_t cap64 = hp_ev_slot(A, scr_off + q + n, gp + 1) - ev0;
+            const uint32_t ord = uni(A.hp_pord[r]) + pi;
+            const uint64_t ev0 = hp_ev_slot(A, scr_off + q, ord);
+            const uint64_t cap64 = hp_ev_slot(A, scr_off + q + n, ord + 1) - ev0;
             const uint32_t cap = cap64 > 0xffffffffull ? 0xffffffffu : (uint32_t)cap64;
             ns_event *ev = A.hp_ev + ev0;
             uint32_t *wd = A.hp_wd + ev0;
@@ -1439,7 +1445,7 @@ struct ns_ctx {
     int slot = 0;                      // slot of the last batch
     IoEngine *io = nullptr;            // copy stream, staging slices, writer threads (created by the first ns_sink_open)
     std::vector<ns_sink *> sinks;
-    DevBuf sort_key, sort_idx, sort_key_out, order, list_b, list_c, rstate, att_base, scr, scr_len, scr_off, hp_len, hp_nev, hp_ev, hp_wd, hp_runs, hp_nrun, slow_q, cls, hp_bm;
+    DevBuf sort_key, sort_idx, sort_key_out, order, list_b, list_c, rstate, att_base, scr, scr_len, scr_off, hp_len, hp_nev, hp_ev, hp_wd, hp_runs, hp_nrun, slow_q, cls, hp_bm, hp_pcnt, hp_pord;
     uint32_t hp_shift = 5, hp_pad = 64, hp_cap_k = 0;       // -k: event capacity of a piece (hp_ev_slot), planned for kmer_bias hp_cap_k
     // metagenome: species view of the reference, abundances of the sample, per-pass scratch
     DevBuf species_chrom_off, t_reads, t_pieces, t_name_len, t_rec_len, t_err_len, accept, accept_scan, key_pos, draw_x, m_segptr,
@@ -1616,7 +1622,7 @@ void ns_destroy(ns_ctx *ctx) {
                       &ctx->t_name_len, &ctx->t_rec_len, &ctx->t_err_len, &ctx->accept, &ctx->accept_scan, &ctx->key_pos,
                       &ctx->draw_x, &ctx->m_segptr, &ctx->m_len, &ctx->m_species, &ctx->species_bases, &ctx->draw_sel,
                       &ctx->draw_sorted, &ctx->meta_words, &ctx->meta_num, &ctx->trx_chrom, &ctx->trx_cum, &ctx->trx_polya, &ctx->polya,
-                      &ctx->ir_need, &ctx->ir_off, &ctx->spliced, &ctx->p_need, &ctx->p_off, &ctx->cls, &ctx->hp_bm};
+                      &ctx->ir_need, &ctx->ir_off, &ctx->spliced, &ctx->p_need, &ctx->p_off, &ctx->cls, &ctx->hp_bm, &ctx->hp_pcnt, &ctx->hp_pord};
     for (auto *pb : {&ctx->pin_a, &ctx->pin_b, &ctx->pin_c, &ctx->pin_d})
         if (pb->p) e = hipHostFree(pb->p);
     if (ctx->pin_small) e = hipHostFree(ctx->pin_small);
@@ -2013,6 +2019,8 @@ static int hp_stage1(ns_ctx *ctx, const ns_params *prm, GenArgs &A, size_t n, ui
     if ((rc = ensure(ctx, ctx->hp_len, (size_t)tot_pieces * 4 + 64)) || (rc = ensure(ctx, ctx->hp_nev, (size_t)tot_pieces * 4 + 64)) ||
         (rc = ensure(ctx, ctx->hp_nrun, (size_t)tot_pieces * 4 + 64))) return rc;
     A.hp_len = (uint32_t *)ctx->hp_len.p; A.hp_nev = (uint32_t *)ctx->hp_nev.p;
+    if ((rc = ensure(ctx, ctx->hp_pcnt, (n + 1) * 4)) || (rc = ensure(ctx, ctx->hp_pord, (n + 1) * 4))) return rc;
+    A.hp_pcnt = (uint32_t *)ctx->hp_pcnt.p; A.hp_pord = (const uint32_t *)ctx->hp_pord.p;
     A.hp_bm = nullptr;
     if (prm->kmer_bias >= 2 && prm->kmer_bias <= 16 && !getenv("NS_NO_HP_BITMAP")) {
         if (ctx->hp_bm_k != prm->kmer_bias) {           // once per (reference, k)
@@ -2027,7 +2035,7 @@ static int hp_stage1(ns_ctx *ctx, const ns_params *prm, GenArgs &A, size_t n, ui
     }
     k_hp_filter_w<<<dim3((unsigned)((n + NS_WPB) / NS_WPB)), dim3(64 * NS_WPB), 0, st>>>(A);
     HIPCHK(hipGetLastError());
-    if ((rc = scan_u64(ctx, A.scr_len, A.scr_off, n + 1))) return rc;
+    if ((rc = scan_u64(ctx, A.scr_len, A.scr_off, n + 1)) || (rc = scan_u32(ctx, A.hp_pcnt, (uint32_t *)ctx->hp_pord.p, n + 1))) return rc;
     uint64_t scr_bytes = 0;
     if ((rc = read_small(ctx, st, &scr_bytes, A.scr_off + n, 8))) return rc;
     // (the second record pass reads the scratch pieces with unaligned 16-byte loads that may start before / end behind a piece)

@@ -13,6 +13,10 @@ import parity_sweep as PS  # noqa: E402
 
 mi, first = int(sys.argv[1]), int(sys.argv[2])
 name, rk, kw = PS.MODES[mi]
+kw = dict(kw)
+for item in os.environ.get("PC_SET", "").split(","):            # e.g. PC_SET=fastq=0,kmer_bias=0
+    if item:
+        k_, v_ = item.split("="); kw[k_] = type(kw.get(k_, 0))(int(v_))
 mdl = M.load_model(os.path.join(PS.GOLDEN, "model_small", "training"), chimeric=True, homopolymer=True, fastq=True)
 ref = M.read_fasta(os.path.join(PS.GOLDEN, "genome_small.fa" if rk == "lin" else "genome_circ.fa"), "linear" if rk == "lin" else "circular")
 p = E.make_params(seed=0xC0FFEE + mi, first_read=first, n_reads=PS.CHUNK, max_len=kw.get("max_len", ref.max_chrom),
@@ -70,3 +74,24 @@ if len(rec) == len(erec) and len(d):
     print("pieces (kind, chrom, pos, ref_len, out_len, n_ev):", [(int(q["kind"]), int(q["chrom"]), int(q["pos"]), int(q["ref_len"]), int(q["out_len"]), int(q["n_ev"])) for q in pcs])
     print("differing quality positions (in line order):", (dd - q0)[:200], "count", len(dd), "other reads affected:", len(d) - len(dd))
     print("chrom lens", [int(x) for x in np.diff(ref.chrom_off)])
+for fld in ("out_len",):
+    w = np.nonzero(pg[fld] != pe[fld])[0]
+    for i in w[:3]:
+        print("piece", int(i), {k: int(pg[k][i]) for k in ("kind", "chrom", "pos", "ref_len", "out_len", "n_ev")}, "oracle out_len", int(pe["out_len"][i]), "n_ev", int(pe["n_ev"][i]),
+              "wraps" if int(pg["pos"][i]) + int(pg["ref_len"][i]) > int(np.diff(ref.chrom_off)[int(pg["chrom"][i])]) else "")
+        r = int(np.searchsorted(np.cumsum(rd["n_pieces"]), i, side="right"))
+        print(" read", r, {k: int(rd[k][r]) for k in ("n_pieces", "reversed", "head", "tail", "seq_len", "attempts")}, "oracle seq_len", int(er["seq_len"][r]))
+        o, n_ = int(rd["rec_off"][r]), int(rd["rec_off"][r + 1]) if r + 1 < len(rd) else len(rec)
+        oo = int(er["rec_off"][r]); on_ = int(er["rec_off"][r + 1]) if r + 1 < len(er) else len(erec)
+        a, c = bytes(rec[o:n_]).split(b"\n"), bytes(erec[oo:on_]).split(b"\n")
+        print(" name", a[0][:120])
+        sa, sc = a[1], c[1]
+        k = next((j for j in range(min(len(sa), len(sc))) if sa[j] != sc[j]), None)
+        print(" first differing base at", k, "gpu", sa[max(0, k - 30):k + 30], "exp", sc[max(0, k - 30):k + 30])
+        ev = eg[int(pg["ev_off"][i]):int(pg["ev_off"][i]) + int(pg["n_ev"][i])]
+        pos_ = ev["pos"].astype(np.int64); info = ev["info"].astype(np.uint32)
+        ln = info & 0xfff; ty = (info >> 12) & 3; sh = (info >> 14).astype(np.int64) - 131072
+        os_ = pos_ + sh
+        sel = np.nonzero((os_ > k - int(rd["head"][r]) - 120) & (os_ < k - int(rd["head"][r]) + 60))[0]
+        print(" events near (idx, pos, out_start, type, len):", [(int(j), int(pos_[j]), int(os_[j]), int(ty[j]), int(ln[j])) for j in sel])
+        print(" n events with out_start < that:", int(np.sum(os_ < k - int(rd["head"][r]))))
