@@ -275,8 +275,9 @@ def summarise(w, a, infos, dt, n, n_al, n_un, steps, warmup, world, tot_bases, e
 
 
 def e2e_legs(w, n, steps, shm_dir, stripes=16):
-    """SURVEY section 8(d) "timing protocol": end to end = generation + device-to-host + file writes.  Every leg: one untimed step (it
-    sizes the second result slot), then `steps` steps whose record image (and error-profile image) are queued for their files right
+    """SURVEY section 8(d) "timing protocol": end to end = generation + device-to-host + file writes.  Every leg: two untimed steps back
+    to back (they size both result slots: a 25 GB hipMalloc inside the timed steps cost the first error-profile leg a quarter of its
+    rate), then `steps` steps whose record image (and error-profile image) are queued for their files right
     after each worker call (ns_sink_write), then a drain.  reads/s = reads of the timed steps / wall time incl. the drain.
     Destinations: null = /dev/null; shm = ONE file per output on /dev/shm (what the CLI does by default; writes into one inode
     serialise in the kernel); shm<K> = every worker call's images cut at read boundaries into K sub-files per output (the CLI's -t K
@@ -293,7 +294,7 @@ def e2e_legs(w, n, steps, shm_dir, stripes=16):
     for dest in ("null", "shm", "shm%d" % stripes):
         for errlog in (False, True):
             name = "%s_%s%s" % (dest, "fastq" if w.fastq else "fasta", "_errlog" if errlog else "")
-            need = (steps + 1) * n * (36_000 if errlog else 9_000) * (2 if w.fastq else 1)
+            need = (steps + 2) * n * (36_000 if errlog else 9_000) * (2 if w.fastq else 1)
             if dest != "null" and (free is None or free < 3 * need):
                 res[name] = {"skipped": "needs %.0f GB on %s" % (need / 1e9, shm_dir)}
                 continue
@@ -347,7 +348,8 @@ def e2e_legs(w, n, steps, shm_dir, stripes=16):
                         for sk, fd in live[key]:
                             sk.close(); os.close(fd)
                         live[key] = []
-                w.step(1000, n, n_al, n_un, errlog=errlog, after_aligned=after_al, after_unaligned=after_un)
+                for i in range(2):         # two untimed steps back to back: the second one lands in (and sizes) the second result slot
+                    w.step(998 + i, n, n_al, n_un, errlog=errlog, after_aligned=after_al, after_unaligned=after_un)
                 drain()
                 for e in w.engs:
                     e.io_counters(reset=True)
@@ -382,7 +384,7 @@ def e2e_legs(w, n, steps, shm_dir, stripes=16):
                 if d is not None:
                     shutil.rmtree(d, ignore_errors=True)
     c = w.eng.io_counters()
-    res["protocol"] = ("%d steps of %d reads (= %d aligned + %d unaligned) per leg after one untimed step; record image (+ error-profile image) of every "
+    res["protocol"] = ("%d steps of %d reads (= %d aligned + %d unaligned) per leg after two untimed steps; record image (+ error-profile image) of every "
                        "worker call queued with ns_sink_write / ns_sink_write_range, wall time incl. the final drain; %d staging slices of %d MB, %d writer "
                        "threads per engine context, one writer per file at a time; null = /dev/null, shm = one file per output on %s (writes into ONE "
                        "inode serialise in the kernel: that bounds those legs), shm%d = %d sub-files per worker call and output, cut at read boundaries"
