@@ -412,3 +412,36 @@ def test_chimeric_fastq_with_reads_planned_again(small_model, circ_ref):
         assert moved > 0                       # some reads lie out of order in the piece array
     finally:
         e.close()
+
+
+def test_ecdf_segments_of_every_width(small_ref):
+    """The LDS image of the chain answers an ECDF look-up without floating point where it can (ns_chain.h: ecdf_lookup_u): unit-wide
+    segments by a flag, segments up to 15 units wide by a threshold list the host derives from the fp64 formula, wider ones (empty
+    histogram bins merged, S:216-221) by the formula itself.  A model whose match-length columns mix all three, with edges that sit on
+    and next to the 2^-32 grid of the draws: same reads as the oracle (which only knows the fp64 formula)."""
+    import copy
+    import os
+    from tests.conftest import GOLDEN
+    mdl = copy.deepcopy(M.load_model(os.path.join(GOLDEN, "model_small", "training"), chimeric=True, homopolymer=True, fastq=True))
+    rng = np.random.default_rng(5)
+    widths = [1, 1, 2, 1, 3, 1, 1, 7, 1, 15, 1, 16, 1, 1, 40, 2, 1, 1, 9, 1]
+    for ci, col in enumerate(mdl.match_markov):
+        w = np.array(widths[ci % 5:] + widths[:ci % 5], dtype=np.float64)
+        mass = rng.random(len(w)) + 0.05
+        hi = np.cumsum(mass / mass.sum())
+        # some edges exactly on a draw's probability (u + 0.5) 2^-32 and one ulp beside it: where fp64 rounding decides the last step
+        for k in range(0, len(hi) - 1, 3):
+            u = np.floor(hi[k] * 4294967296.0)
+            hi[k] = (u + 0.5) * 2.0 ** -32 if k % 2 == 0 else np.nextafter((u + 0.5) * 2.0 ** -32, 1.0)
+        hi[-1] = 1.0
+        col.hi = hi
+        col.vhi = float(col.vlo0) + np.cumsum(w)
+    e = E.Engine(0)
+    try:
+        e.set_reference(small_ref)
+        e.load_model(mdl)
+        for kw in (dict(n_reads=1500, emit_errlog=True), dict(n_reads=500, chimeric=True, fastq=True)):
+            p = E.make_params(seed=99, first_read=0, max_len=small_ref.max_chrom, **kw)
+            compare(e.generate(p), O.generate(mdl, small_ref, p, bytes_per_read=200000, events_per_read=40000), p)
+    finally:
+        e.close()
