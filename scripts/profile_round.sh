@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 evidence for the bench lines of a round: for every configuration (ecoli_fasta = the default bench command, chr1_fasta,
-# chr1_fastq_k5 = BASELINE configs[2]) the bench line, the same command under --kernel-trace --stats, and separate PMC passes
+# chr1_fastq_k5 = BASELINE configs[2], ecoli_fastq = configs[1] with --fastq) the bench line, the same command under --kernel-trace --stats, and separate PMC passes
 # (FETCH_SIZE / WRITE_SIZE / SQ counters; never together with the trace domains) on a 200k-read aligned launch.
 # Run on the GPU box through gpurun; outputs go to gpurun_out/<tag>/; afterwards, here: python scripts/summarise_pmc.py <tag>.
 TAG=${1:-r03}
@@ -17,8 +17,11 @@ run_cfg() {
   timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM --kernel-trace --output-format csv -d $O/pmc_${key}/sq2 -o p -- $B > /dev/null 2>&1
   grep -h "^{" $O/bench_$key.log | tail -1 | cut -c1-200
 }
+CFGS=${CFGS:-"ecoli_fasta chr1_fasta chr1_fastq_k5 ecoli_fastq"}      # CFGS="ecoli_fastq" bash scripts/profile_round.sh r03: one configuration only
+want() { case " $CFGS " in *" $1 "*) return 0;; esac; return 1; }
 EXTRA=""                      # the default command: the line the driver records (with its e2e legs and its configs2 object)
-run_cfg ecoli_fasta
-EXTRA="--no-e2e"
-run_cfg chr1_fasta --genome chr1
-run_cfg chr1_fastq_k5 --genome chr1 --fastq --kmer-bias 5
+want ecoli_fasta && run_cfg ecoli_fasta
+EXTRA="--no-e2e --no-configs2"
+want chr1_fasta && run_cfg chr1_fasta --genome chr1
+want chr1_fastq_k5 && run_cfg chr1_fastq_k5 --genome chr1 --fastq --kmer-bias 5
+want ecoli_fastq && run_cfg ecoli_fastq --fastq
