@@ -19,12 +19,12 @@ for item in os.environ.get("PC_SET", "").split(","):            # e.g. PC_SET=fa
         k_, v_ = item.split("="); kw[k_] = type(kw.get(k_, 0))(int(v_))
 mdl = M.load_model(os.path.join(PS.GOLDEN, "model_small", "training"), chimeric=True, homopolymer=True, fastq=True)
 ref = M.read_fasta(os.path.join(PS.GOLDEN, "genome_small.fa" if rk == "lin" else "genome_circ.fa"), "linear" if rk == "lin" else "circular")
-p = E.make_params(seed=0xC0FFEE + mi, first_read=first, n_reads=PS.CHUNK, max_len=kw.get("max_len", ref.max_chrom),
+p = E.make_params(seed=PS.SEED0 + mi, first_read=first, n_reads=PS.CHUNK, max_len=kw.get("max_len", ref.max_chrom),
                   **{k: v for k, v in kw.items() if k != "max_len" and not k.startswith("_")})
 eng = E.Engine(0); eng.set_reference(ref); eng.load_model(mdl)
 start = int(sys.argv[3]) if len(sys.argv) > 3 else first
 for f in range(start, first + 1, PS.CHUNK):
-    p = E.make_params(seed=0xC0FFEE + mi, first_read=f, n_reads=PS.CHUNK, max_len=kw.get("max_len", ref.max_chrom),
+    p = E.make_params(seed=PS.SEED0 + mi, first_read=f, n_reads=PS.CHUNK, max_len=kw.get("max_len", ref.max_chrom),
                       **{k: v for k, v in kw.items() if k != "max_len" and not k.startswith("_")})
     b = eng.generate(p)
     got = dict(records=b.records(), errlog=b.errlog() if p.emit_errlog else np.zeros(0, np.uint8), reads=b.reads(), pieces=b.pieces(), events=b.events())

@@ -16,6 +16,7 @@ from tests import oracle_lib as O  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 CHUNK = 500
+SEED0 = int(os.environ.get("NS_SWEEP_SEED", str(0xC0FFEE)), 0)      # NS_SWEEP_SEED=...: other reads
 MODES = [
     ("fasta+errlog", "lin", dict(emit_errlog=True)),
     ("fastq", "lin", dict(fastq=True)),
@@ -59,7 +60,7 @@ def oracle_chunk(args):
     name, refk, kw = MODES[mode_i]
     mdl, refs = _CTX["mdl"], _CTX["refs"]
     ref = refs[refk]
-    p = E.make_params(seed=0xC0FFEE + mode_i, first_read=first, n_reads=CHUNK, max_len=kw.get("max_len", ref.max_chrom),
+    p = E.make_params(seed=SEED0 + mode_i, first_read=first, n_reads=CHUNK, max_len=kw.get("max_len", ref.max_chrom),
                       **{k: v for k, v in kw.items() if k != "max_len" and not k.startswith("_")})
     return digest(O.generate(mdl, ref, p, bytes_per_read=120000, events_per_read=24000))
 
@@ -87,7 +88,7 @@ def main():
                     continue
                 eng = eng_bg if kw.get("_background") else fg
                 for f in range(0, n, CHUNK):
-                    p = E.make_params(seed=0xC0FFEE + mi, first_read=f, n_reads=CHUNK, max_len=kw.get("max_len", refs[rk].max_chrom),
+                    p = E.make_params(seed=SEED0 + mi, first_read=f, n_reads=CHUNK, max_len=kw.get("max_len", refs[rk].max_chrom),
                                       **{k: v for k, v in kw.items() if k != "max_len" and not k.startswith("_")})
                     b = eng.generate(p)
                     got[(mi, f)] = digest(dict(records=b.records(), errlog=b.errlog() if p.emit_errlog else np.zeros(0, np.uint8),
