@@ -795,6 +795,7 @@ __global__ void __launch_bounds__(256) k_dense_plan(GenArgs A, uint32_t *cnt) {
     if (r < A.prm.n_reads) { const ns_read rd = A.reads[r]; c = rd.flags ? 0u : max(1u, (rd.seq_len + NS_DENSE_SEG - 1u) / NS_DENSE_SEG); }
     cnt[r] = c;
 }
+// (FASTQ = true draws the qualities in place through the per-value look-up; launch_materialise uses <false> + k_qualities since round 3)
 template <bool FASTQ>
 __global__ void __launch_bounds__(64) k_materialise_dense(GenArgs A, const uint32_t *__restrict__ seg_off) {
     __shared__ DenseLds S;
