@@ -8,7 +8,14 @@ alignment rate 19:1), E. coli-like 4.64 Mb circular genome, hg002-like error mod
 process per GPU, read-index ranges sharded, ONE RCCL broadcast of the reference before the timed region, no
 collective inside it (weak scaling).
 
+Other workloads (not the headline; one line each): --genome chr1 --fastq --kmer-bias 5 = configs[2]; --genome grch38 --chimeric =
+configs[3] (3.1 Gb reference, chimeric reads: the 8-GPU genome split); --metagenome = configs[4] (zymo10-like community of 10 species,
+one metagenome worker call per step).  --gpus N without a launcher starts the N ranks itself (torch.distributed.run on 127.0.0.1).
+
 The same JSON line also carries (N = 1):
+  "serial"    the same steps with both worker calls one after the other on ONE engine context (NS_SERIAL=1 of the CLI);
+  "errlog_on" the same steps with the error profile the reference always writes (S:2006-2008) formatted on the device as well — what
+              the CLI's worker calls cost on the device — and k_errlog's own store rate as a fraction of HBM peak;
   "configs2"  BASELINE configs[2] — chr1-size reference, FASTQ, -hp -k 5 — a few steps of the same protocol, with its own roofline;
   "e2e"       the END-TO-END legs of SURVEY section 8(d): generation + device-to-host copy + file writes through the engine's output
               sinks (include/nanosim_amd.h: ns_sink_*), to /dev/null and to files on /dev/shm, with and without the error profile
@@ -31,7 +38,7 @@ if ROOT not in sys.path:
 
 SEED = 20260926
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_ROUNDS = ("r03", "r02")
+PROFILE_ROUNDS = ("r04", "r03", "r02")
 
 
 REFERENCE_PYTHON = {        # the reference itself (bcgsc/NanoSim v3.2.2, simulator.py -t 8), measured in the build container
@@ -43,7 +50,7 @@ REFERENCE_PYTHON = {        # the reference itself (bcgsc
 
 def _cpu_worker(args):
     """one host core: its share of the sample through the C restatement of the reference (oracle/ns_oracle.c)"""
-    idx, n_al, n_un, fastq, kmer = args
+    idx, n_al, n_un, fastq, kmer, chimeric = args
     from tests import oracle_lib
     mdl, ref, eng = _CPU_CTX
     bases = 0
@@ -53,7 +60,7 @@ def _cpu_worker(args):
         while done < cnt:                            # 1 000 reads per call: the buffers of a call stay below ~50 MB per process
             m = min(1000, cnt - done)
             p = eng.make_params(seed=SEED, first_read=first, n_reads=m, kind=kind, max_len=ref.max_chrom, fastq=fastq,
-                                kmer_bias=kmer if kind == eng.NS_KIND_ALIGNED else 0)
+                                kmer_bias=kmer if kind == eng.NS_KIND_ALIGNED else 0, chimeric=chimeric and kind == eng.NS_KIND_ALIGNED)
             per = max(120000 if fastq else 60000, 8_000_000 // m)     # a single FASTQ record of a long read needs more than the average
             bases += int(oracle_lib.generate(mdl, ref, p, bytes_per_read=per)["total_bases"])
             done += m; first += m
@@ -63,7 +70,7 @@ def _cpu_worker(args):
 _CPU_CTX = None
 
 
-def cpu_baseline(model, ref, engine_mod, per_core, fastq, kmer):
+def cpu_baseline(model, ref, engine_mod, per_core, fastq, kmer, chimeric=False):
     """The CPU restatement (oracle, kind="port") on ALL host cores — one process per core, as the reference's -t fan-out
     (src/simulator.py:1588-1605) — on a bounded sample of the same workload: per core `per_core` reads in the model's
     aligned : unaligned proportion."""
@@ -84,9 +91,9 @@ def cpu_baseline(model, ref, engine_mod, per_core, fastq, kmer):
         pass
     ctx = mp.get_context("fork")
     with ctx.Pool(cores) as pool:
-        pool.map(_cpu_worker, [(i, 20, 0, fastq, kmer) for i in range(cores)])         # start the workers, touch the tables
+        pool.map(_cpu_worker, [(i, 20, 0, fastq, kmer, chimeric) for i in range(cores)])         # start the workers, touch the tables
         t0 = time.perf_counter()
-        bases = pool.map(_cpu_worker, [(i, n_al, n_un, fastq, kmer) for i in range(cores)])
+        bases = pool.map(_cpu_worker, [(i, n_al, n_un, fastq, kmer, chimeric) for i in range(cores)])
         dt = time.perf_counter() - t0
     return dict(value=cores * per_core / dt, unit="reads/s", cores=cores, kind="port", cpu=cpu,
                 sample="%d cores x %d reads (%d aligned + %d unaligned each) of the same workload through oracle/ns_oracle.c, one process "
@@ -114,37 +121,78 @@ def measured_traffic(genome, fastq, kmer, kernels):
     return None, None
 
 
+WORKLOADS = {
+    "ecoli": "configs[1]: ecoli_like 4,641,652 bp circular",
+    "chr1": "configs[2]: chr1_like 248,956,422 bp linear",
+    "grch38": "configs[3]: grch38_like 24 chromosomes, 3,088,269,832 bp linear",
+    "zymo10": "configs[4]: zymo10_like community (10 species, 44 chromosomes, 8 circular bacteria + 2 yeasts), even abundances, metagenome mode",
+}
+
+
+def reference_layout(genome):
+    """(names, chrom_off, circular) of a synthetic reference — every rank knows the layout, only rank 0 makes the bases"""
+    import numpy as np
+    from nanosim_amd import synth
+    if genome == "ecoli":
+        return ["ecoli-like"], np.array([0, synth.ECOLI_LEN], dtype=np.uint64), np.array([1], dtype=np.uint8)
+    if genome == "chr1":
+        return ["chr1-like"], np.array([0, synth.CHR1_LEN], dtype=np.uint64), np.array([0], dtype=np.uint8)
+    if genome == "grch38":
+        names = ["chr%d" % (i + 1) for i in range(22)] + ["chrX", "chrY"]
+        off = np.concatenate([[0], np.cumsum(np.array(synth.GRCH38_LENS, dtype=np.uint64))]).astype(np.uint64)
+        return names, off, np.zeros(24, dtype=np.uint8)
+    names, lens, circ = [], [], []
+    for sp, chroms, _, _ in synth.ZYMO10:
+        for k, n, c in chroms:
+            names.append(sp + "-" + k); lens.append(int(n)); circ.append(c)
+    off = np.concatenate([[0], np.cumsum(np.array(lens, dtype=np.uint64))]).astype(np.uint64)
+    return names, off, np.array(circ, dtype=np.uint8)
+
+
+def reference_bases(genome):
+    from nanosim_amd import synth
+    kw = dict(n_frac=0.0005, iupac_frac=0.0002, lower_frac=0.02, hp_boost=0.005)
+    if genome == "ecoli":
+        return synth.synth_sequence(synth.ECOLI_LEN, SEED, **kw)
+    if genome == "chr1":
+        return synth.synth_sequence(synth.CHR1_LEN, SEED, **kw)
+    if genome == "grch38":
+        return synth.grch38_like(SEED)[1]
+    return synth.zymo10_like(SEED)[1]
+
+
 class Workload:
     """one configuration resident on this rank's GPU: engines (aligned + background unaligned context), model, reference"""
 
-    def __init__(self, a, genome, fastq, kmer, local_rank, rank, world, dist, serial, aligned_only, tmp):
+    def __init__(self, a, genome, fastq, kmer, local_rank, rank, world, dist, serial, aligned_only, tmp, chimeric=False):
         import numpy as np
         import torch
         from nanosim_amd import engine, model, synth
         self.engine, self.genome, self.fastq, self.kmer, self.rank, self.world = engine, genome, fastq, kmer, rank, world
+        self.meta = genome == "zymo10"
+        self.chimeric = bool(chimeric)
         prefix = os.path.join(tmp, "hg002_like")
         if not os.path.exists(prefix + "_kde.npz"):
             synth.write_model(prefix, synth.SynthModelSpec(n_train=1_000_000, seed=SEED), write_pkl=False)
-        self.mdl = model.load_model(prefix, fastq=fastq, homopolymer=kmer > 0)
-        names = ["ecoli-like"] if genome == "ecoli" else ["chr1-like"]
-        self.glen = glen = synth.ECOLI_LEN if genome == "ecoli" else synth.CHR1_LEN
-        ref_meta = model.Reference(names, np.zeros(0, np.uint8), np.array([0, glen], dtype=np.uint64),
-                                   np.array([1 if genome == "ecoli" else 0], dtype=np.uint8))
+        self.mdl = model.load_model(prefix, fastq=fastq, homopolymer=kmer > 0, chimeric=self.chimeric)
+        names, chrom_off, circular = reference_layout(genome)
+        self.glen = glen = int(chrom_off[-1])
+        ref_meta = model.Reference(names, np.zeros(0, np.uint8), chrom_off, circular)
         self.eng = engine.Engine(local_rank)
         # the unaligned worker call of a step runs next to the aligned one on its own engine context (own HIP streams and buffers on the
-        # same GPU, own host thread) — the way the reference runs its workers side by side (-t, S:1588-1605)
+        # same GPU, own host thread): the schedule of the CLI (nanosim_amd/simulator.py: _run_phases)
         self.eng_un = None if (aligned_only or serial) else engine.Engine(local_rank)
         if self.eng_un is not None:
             self.eng_un.set_background(True)     # its kernels share the GPU with the aligned call's: few issue slots matter more than a short latency
         self.engs = [e for e in (self.eng, self.eng_un) if e is not None]
         self.broadcast_ms = None
+        dev_ptr, self._keep = None, None
         if world > 1:
             # the reference lives on rank 0; ONE broadcast over xGMI puts it in every GPU's HBM
             bdev = "cuda" if a.dist_backend == "nccl" else "cpu"
             buf = torch.empty(glen, dtype=torch.uint8, device=bdev)
             if rank == 0:
-                seq = synth.synth_sequence(glen, SEED, n_frac=0.0005, iupac_frac=0.0002, lower_frac=0.02, hp_boost=0.005)
-                buf.copy_(torch.from_numpy(seq))
+                buf.copy_(torch.from_numpy(reference_bases(genome)))
             dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -153,48 +201,68 @@ class Workload:
             self.broadcast_ms = (time.perf_counter() - t0) * 1e3
             buf = buf.cuda()
             torch.cuda.synchronize()
-            for e in self.engs:
-                e.set_reference_device(buf.data_ptr(), ref_meta)
+            dev_ptr, self._keep = buf.data_ptr(), buf
             self.ref_host = None
+            ref = ref_meta
         else:
-            seq = synth.synth_sequence(glen, SEED, n_frac=0.0005, iupac_frac=0.0002, lower_frac=0.02, hp_boost=0.005)
-            self.ref_host = model.Reference(names, seq, ref_meta.chrom_off, ref_meta.circular)
+            self.ref_host = ref = model.Reference(names, reference_bases(genome), chrom_off, circular)
+        if self.meta:
+            from nanosim_amd import metagenome as MG
+            sp_off = np.concatenate([[0], np.cumsum([len(c) for _, c, _, _ in synth.ZYMO10])]).astype(np.uint32)
+            self.mref = MG.MetaReference(ref, [sp for sp, _, _, _ in synth.ZYMO10], sp_off, [[k for k, _, _ in c] for _, c, _, _ in synth.ZYMO10])
+            abun = {sp: float(e) for sp, _, e, _ in synth.ZYMO10}                  # the "even" column of the abundance table
+            infl = {sp: MG.inflate_abun(abun, sp, self.mdl.abun_inflation) for sp in abun} if self.chimeric else None
+            self.eng.set_metagenome(self.mref, abun, infl, dev_ptr=dev_ptr)
+            if self.eng_un is not None:
+                self.eng_un.set_metagenome(self.mref, dev_ptr=dev_ptr)
+        else:
             for e in self.engs:
-                e.set_reference(self.ref_host)
+                if dev_ptr is not None:
+                    e.set_reference_device(dev_ptr, ref_meta)
+                else:
+                    e.set_reference(ref)
+        self._keep = None                          # (the engines hold their own normalised copies)
         for e in self.engs:
             e.load_model(self.mdl)
-        self.max_len = min(glen, 1 << 30)
+        self.max_len = min(int(np.diff(chrom_off.astype(np.int64)).max()), 1 << 30)
         self.unaligned_delay_s = max(0.0, getattr(a, "unaligned_delay_ms", 0.0)) * 1e-3
+
+    def describe(self):
+        mode = "metagenome mode" if self.meta else "genome mode"
+        return (WORKLOADS[self.genome] + ", hg002_like error model" + ("" if self.meta else ", " + mode) + ", " + ("FASTQ" if self.fastq else "FASTA") +
+                (", -hp -k %d" % self.kmer if self.kmer else "") + (", --chimeric" if self.chimeric else ""))
 
     def split(self, n, aligned_only):
         return (n, 0) if aligned_only else self.mdl.split_counts(n)
 
-    def step(self, i, n, n_al, n_un, errlog=False, records=True, after_aligned=None, after_unaligned=None):
-        """a step = one genome-mode pass of this GPU over n read indices: the aligned worker call (simulation_aligned_genome,
-        S:1266-1454) on round(n r / (r + 1)) reads and the unaligned one (simulation_unaligned, S:1482-1549) on the rest (the model's
-        alignment rate r = 19), as simulation() runs them (S:1571-1672).  after_*: called with the batch right after its worker call
-        (the end-to-end legs queue the result buffers for their files there)."""
+    def step(self, i, n, n_al, n_un, errlog=False, records=True, after_aligned=None, after_unaligned=None, serial=False):
+        """a step = one pass of this GPU over n read indices: the aligned worker call (simulation_aligned_genome, S:1266-1454;
+        --metagenome: simulation_aligned_metagenome, S:814-1040) on round(n r / (r + 1)) reads and the unaligned one
+        (simulation_unaligned, S:1482-1549) on the rest (the model's alignment rate r = 19), as simulation() runs them (S:1571-1672).
+        after_*: called with the batch right after its worker call (the end-to-end legs queue the result buffers for their files there).
+        serial: both calls on the first engine context, one after the other."""
         engine = self.engine
         base = (i * self.world + self.rank) * n
         out = [None, None]
 
         def aligned():
             b = self.eng.generate(engine.make_params(seed=SEED, first_read=base, n_reads=n_al, fastq=self.fastq, max_len=self.max_len,
-                                                     emit_errlog=errlog, kmer_bias=self.kmer, emit_records=records))
+                                                     emit_errlog=errlog, kmer_bias=self.kmer, emit_records=records, chimeric=self.chimeric,
+                                                     meta=self.meta))
             out[0] = b.info
             if after_aligned:
                 after_aligned(b)
 
         def unaligned(e):
             b = e.generate(engine.make_params(seed=SEED, first_read=base + n_al, n_reads=n_un, kind=engine.NS_KIND_UNALIGNED,
-                                              fastq=self.fastq, max_len=self.max_len, emit_records=records))
+                                              fastq=self.fastq, max_len=self.max_len, emit_records=records, meta=self.meta))
             out[1] = b.info
             if after_unaligned:
                 after_unaligned(b)
         if not n_un:
             aligned()
             return out[:1]
-        if self.eng_un is None:                                # --serial: one engine, one call after the other
+        if self.eng_un is None or serial:                      # one engine, one call after the other
             aligned(); unaligned(self.eng)
             return out
         def late_unaligned():
@@ -210,15 +278,15 @@ class Workload:
             e.close()
 
 
-def timed_steps(w, a, n, n_al, n_un, steps, warmup, dist, errlog):
+def timed_steps(w, a, n, n_al, n_un, steps, warmup, dist, errlog, serial=False, first_step=0):
     import torch
     for i in range(warmup):
-        w.step(i, n, n_al, n_un, errlog=errlog)
+        w.step(first_step + i, n, n_al, n_un, errlog=errlog, serial=serial)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    infos = [w.step(warmup + i, n, n_al, n_un, errlog=errlog) for i in range(steps)]
+    infos = [w.step(first_step + warmup + i, n, n_al, n_un, errlog=errlog, serial=serial) for i in range(steps)]
     torch.cuda.synchronize()
     dt_local = time.perf_counter() - t0
     if dist is not None:
@@ -242,30 +310,39 @@ def summarise(w, a, infos, dt, n, n_al, n_un, steps, warmup, world, tot_bases, e
     device_ms = float(np.mean([sum(x.ms_total for x in st) for st in infos]))
     stage = {"k_materialise": ("k_materialise",), "k_hp": ("k_hp", "k_materialise<true, 1>", "k_materialise<false, 1>")}.get(dom, (dom,))
     per_read, traffic_src = measured_traffic(w.genome, w.fastq, w.kmer, stage)
+    # the same duration priced three ways, so that the line cannot flatter itself: SURVEY 8(d) bytes (incl. the 8 B per event the CHAIN
+    # kernel writes), the bytes this stage itself moves (without them), and the bytes the PMC counters saw
+    ev_write = float(np.mean([8 * int(x.events_used) for x in al]))
+    t_dom = kms[dom] * 1e-3
     out = {
         "metric": "simulated reads/sec (genome mode, mean 8 kb)", "value": world * n * steps / dt, "unit": "reads/s",
         "bases_per_s": tot_bases / dt,
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
         "data": "synthetic",
-        "config": {"workload": ("configs[1]: ecoli_like 4,641,652 bp circular" if w.genome == "ecoli" else "configs[2]: chr1_like 248,956,422 bp linear") +
-                               ", hg002_like error model, genome mode, %s%s, %d reads/GPU/step = %d aligned + %d unaligned (alignment rate 19:1)"
-                               % ("FASTQ" if w.fastq else "FASTA", ", -hp -k %d" % w.kmer if w.kmer else "", n, n_al, n_un),
+        "config": {"workload": w.describe() + ", %d reads/GPU/step = %d aligned + %d unaligned (alignment rate 19:1)" % (n, n_al, n_un),
                    "reads_per_step_per_gpu": n, "aligned_per_step": n_al, "unaligned_per_step": n_un, "errlog": bool(errlog),
                    "errlog_note": "the error-profile text (the reference always writes it, S:2006-2008: ~26 KB per read, 3x the reads) is "
                                   "formatted by k_errlog only when asked for (--errlog; the CLI always asks): it is a file-format stage "
                                   "behind the path the metric names (SURVEY section 8 f-1); the e2e legs below time it",
                    "seed": SEED, "parallelism": "read-index sharding x%d, 1 RCCL broadcast of the reference" % world, "engines_per_gpu": len(w.engs),
-                   "engines_note": "aligned and unaligned worker call of a step run side by side on two engine contexts of the GPU, the unaligned one as a background context (ns_set_background); --serial: one after the other on one"},
+                   "engines_note": "aligned and unaligned worker call of a step run side by side on two engine contexts of the GPU, the unaligned one as a background context (ns_set_background) - the schedule of the CLI (nanosim_amd/simulator.py: _run_phases); the `serial` object / --serial: one after the other on one context (the CLI with NS_SERIAL=1)"},
         "device_ms_per_step": device_ms,
         "aligned_batch": {"reads": n_al, "device_ms": float(np.mean([x.ms_total for x in al])),
                           "reads_per_s_device": n_al / (float(np.mean([x.ms_total for x in al])) * 1e-3), "kernel_ms": kms},
         "kernel_ms": kms,
         "roofline": {"bound": "hbm", "kernel": dom + (" (stage: k_materialise + k_materialise_slow; k_names runs next to it on a second stream)" if dom == "k_materialise" else ""), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": per_read * n_al if per_read else None,
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "frac_kernel_only_bytes": (per_launch - ev_write) / t_dom / 1e9 / HBM_PEAK_GBS,
+                     "frac_counter_bytes": (per_read * n_al / t_dom / 1e9 / HBM_PEAK_GBS) if per_read else None,
+                     "frac_note": "frac: SURVEY 8(d) algorithmic bytes (L_ref + L_out [+ L_out qualities] + 16 E + 32) / stage time / 8 TB/s; "
+                                  "frac_kernel_only_bytes: without the 8 B per event the chain kernel writes; frac_counter_bytes: PMC bytes "
+                                  "(2 x FETCH_SIZE + WRITE_SIZE of the profiled launch) / stage time / 8 TB/s",
+                     "traffic": per_read * n_al if per_read else None,
                      "traffic_source": (traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this configuration, per read x reads per launch)") if per_read else None,
                      "algorithmic_bytes_per_launch": float(per_launch),
-                     "all_kernels_achieved": per_launch / (sum(kms.values()) * 1e-3) / 1e9},
+                     "all_kernels_achieved": per_launch / (sum(kms.values()) * 1e-3) / 1e9,
+                     "whole_aligned_batch_frac": per_launch / (float(np.mean([x.ms_total for x in al])) * 1e-3) / 1e9 / HBM_PEAK_GBS},
     }
     if n_un:
         un = [st[1] for st in infos]
@@ -412,6 +489,62 @@ def d2h_rate(w, nbytes=2 << 30):
     return {"wall_gb_per_s": c["bytes"] / dt / 1e9, "dma_gb_per_s": c["d2h_gbs"], "bytes": c["bytes"]}
 
 
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def self_launch(a):
+    """--gpus N without a launcher: start the N ranks here — one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1 —
+    with the same arguments; rank 0's JSON line is this process's output."""
+    import subprocess
+    if a.dist_backend == "nccl" and os.environ.get("NS_BENCH_DEVICE") is None:
+        import torch
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            sys.stderr.write("bench.py --gpus %d: %d GPU(s) visible (NS_BENCH_DEVICE=0 with --dist-backend gloo runs the %d ranks on one GPU)\n"
+                             % (a.gpus, have, a.gpus))
+            sys.exit(2)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL between processes)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def extra_legs(w, a, n, n_al, n_un, steps):
+    """N = 1: what the headline schedule leaves out.  serial: both worker calls of a step on ONE engine context, one after the other
+    (S:1621-1622 joins the aligned workers before S:1642-1663 starts the unaligned ones; the CLI with NS_SERIAL=1).  errlog_on: the
+    headline schedule with the error profile formatted on the device too (emit_errlog = 1: k_errlen + k_errlog), as every worker call of
+    the CLI runs — the device-side rate of the CLI — with k_errlog's own store rate against the HBM peak."""
+    import numpy as np
+    out = {}
+    infos, dt, _ = timed_steps(w, a, n, n_al, n_un, steps, 1, None, False, serial=True, first_step=2000)
+    out["serial"] = {"value": n * steps / dt, "unit": "reads/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+                     "aligned_device_ms": float(np.mean([st[0].ms_total for st in infos])),
+                     "unaligned_device_ms": float(np.mean([st[1].ms_total for st in infos])) if n_un else None,
+                     "note": "one engine context, aligned then unaligned worker call (CLI: NS_SERIAL=1)"}
+    infos, dt, _ = timed_steps(w, a, n, n_al, n_un, steps, 2, None, True, first_step=3000)    # (two warm-ups: both error-profile slots sized)
+    al = [st[0] for st in infos]
+    k_err = w.engine.KERNEL_NAMES.index("k_errlog")
+    ms_err = float(np.mean([x.ms_kernel[k_err] for x in al]))
+    eb = float(np.mean([int(x.errlog_bytes) for x in al]))
+    out["errlog_on"] = {"value": n * steps / dt, "unit": "reads/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+                        "aligned_device_ms": float(np.mean([x.ms_total for x in al])),
+                        "unaligned_device_ms": float(np.mean([st[1].ms_total for st in infos])) if n_un else None,
+                        "k_errlog_ms": ms_err, "errlog_bytes_per_read": eb / max(1, n_al),
+                        "k_errlog_store_gb_per_s": eb / (ms_err * 1e-3) / 1e9 if ms_err > 0 else None,
+                        "k_errlog_frac": eb / (ms_err * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_err > 0 else None,
+                        "note": "two engine contexts as the headline, emit_errlog = 1 on the aligned worker call (k_errlen + k_errlog); "
+                                "k_errlog_frac = error-profile bytes stored / k_errlog time / 8 TB/s"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -423,8 +556,11 @@ def main():
                     help="a step = one aligned worker batch only (the path with the Markov error model; profiling / A-B runs)")
     ap.add_argument("--fastq", action="store_true")
     ap.add_argument("--kmer-bias", type=int, default=0, help="-hp -k K: homopolymer expansion/contraction (configs[2] uses --fastq --kmer-bias 5)")
-    ap.add_argument("--genome", choices=("ecoli", "chr1"), default="ecoli",
-                    help="ecoli: 4.64 Mb circular (configs[1], the default and the headline); chr1: 248.96 Mb linear (configs[2], with --fastq --kmer-bias 5)")
+    ap.add_argument("--genome", choices=("ecoli", "chr1", "grch38"), default="ecoli",
+                    help="ecoli: 4.64 Mb circular (configs[1], the default and the headline); chr1: 248.96 Mb linear (configs[2], with --fastq "
+                         "--kmer-bias 5); grch38: 24 chromosomes, 3.1 Gb (configs[3], with --chimeric)")
+    ap.add_argument("--chimeric", action="store_true", help="chimeric reads (S:1276-1299; configs[3] and, optionally, configs[4])")
+    ap.add_argument("--metagenome", action="store_true", help="configs[4]: zymo10-like community, one metagenome worker call per step (S:814-1040)")
     ap.add_argument("--errlog", action="store_true", help="also format the error profile on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-genome-run", action="store_true", help="same as --aligned-only (kept for the profiling scripts)")
@@ -436,9 +572,14 @@ def main():
     ap.add_argument("--e2e-dir", default="/dev/shm")
     ap.add_argument("--no-configs2", action="store_true", help="skip the configs[2] object (chr1-size reference, FASTQ, -hp -k 5)")
     ap.add_argument("--configs2-steps", type=int, default=3)
+    ap.add_argument("--no-extras", action="store_true", help="skip the `serial` and `errlog_on` objects")
+    ap.add_argument("--extras-steps", type=int, default=3)
     a = ap.parse_args()
     a.aligned_only = a.aligned_only or a.no_genome_run
-    default_cfg = a.genome == "ecoli" and not a.fastq and not a.kmer_bias and not a.aligned_only and not a.serial
+    genome = "zymo10" if a.metagenome else a.genome
+    default_cfg = genome == "ecoli" and not a.fastq and not a.kmer_bias and not a.aligned_only and not a.serial and not a.chimeric
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)                                         # (does not return)
 
     import fcntl
     import numpy as np
@@ -470,9 +611,9 @@ def main():
             dist.init_process_group(a.dist_backend)
     torch.cuda.set_device(local_rank)
 
-    # ---- inputs: synthetic hg002-like model (every rank, identical by seed) + E. coli-like reference ----
+    # ---- inputs: synthetic hg002-like model (every rank, identical by seed) + the synthetic reference (rank 0) ----
     tmp = tempfile.mkdtemp(prefix="nsbench_%d_" % rank)
-    w = Workload(a, a.genome, a.fastq, a.kmer_bias, local_rank, rank, world, dist, a.serial, a.aligned_only, tmp)
+    w = Workload(a, genome, a.fastq, a.kmer_bias, local_rank, rank, world, dist, a.serial, a.aligned_only, tmp, chimeric=a.chimeric)
     n = a.reads
     n_al, n_un = w.split(n, a.aligned_only)
     infos, dt, dt_local = timed_steps(w, a, n, n_al, n_un, a.steps, a.warmup, dist, a.errlog)
@@ -495,15 +636,22 @@ def main():
         out = summarise(w, a, infos, dt, n, n_al, n_un, a.steps, a.warmup, world, tot_bases, a.errlog)
         if world > 1:
             out["multi_gpu"] = {"world_size": dist.get_world_size(), "backend": "RCCL (torch.distributed nccl)" if a.dist_backend == "nccl" else a.dist_backend,
-                                "reference_broadcast_ms": w.broadcast_ms, "reference_bytes": w.glen, "per_rank": per_rank,
-                                "collectives_in_timed_region": 0}
-        if world == 1 and not a.no_e2e and w.eng_un is not None:
+                                "reference_broadcast_ms": w.broadcast_ms, "reference_bytes": w.glen,
+                                "reference_broadcast_gb_per_s": w.glen / (w.broadcast_ms * 1e-3) / 1e9 if w.broadcast_ms else None,
+                                "per_rank": per_rank, "collectives_in_timed_region": 0,
+                                "ranks_on_one_gpu": os.environ.get("NS_BENCH_DEVICE") is not None}
+        if world == 1 and not a.no_extras and w.eng_un is not None and n_un:
+            try:
+                out.update(extra_legs(w, a, n, n_al, n_un, a.extras_steps))
+            except Exception as ex:
+                out["serial"] = {"error": repr(ex)}
+        if world == 1 and not a.no_e2e and w.eng_un is not None and not w.meta:
             try:
                 out["e2e"] = {"d2h_pinned": d2h_rate(w), **e2e_legs(w, n, a.e2e_steps, a.e2e_dir)}
             except Exception as ex:                 # the headline must not depend on the state of /dev/shm
                 out["e2e"] = {"error": repr(ex)}
-        if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(w.mdl, w.ref_host, engine, a.cpu_sample, a.fastq, a.kmer_bias)
+        if not a.no_cpu_baseline and world == 1 and not w.meta:
+            out["cpu_baseline"] = cpu_baseline(w.mdl, w.ref_host, engine, a.cpu_sample, a.fastq, a.kmer_bias, w.chimeric)
     w.close()
     if rank == 0 and world == 1 and default_cfg and not a.no_configs2:
         # BASELINE configs[2] on the same GPU, same protocol: chr1-size linear reference, FASTQ + base qualities + homopolymers
@@ -518,6 +666,7 @@ def main():
             out["configs2"] = {"error": repr(ex)}
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     shutil.rmtree(tmp, ignore_errors=True)
     if dist is not None:
         dist.destroy_process_group()

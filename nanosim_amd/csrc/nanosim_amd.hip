@@ -77,6 +77,7 @@ struct GenArgs {
     uint32_t keep_state;             // k_nseg keeps rstate/att_base (re-run after a failed final length check)
     uint32_t hp;                     // -k active for this batch
     uint32_t dbg;                    // NS_DEBUG_SKIP (profiling only)
+    uint32_t bg_prio;                // background context (ns_set_background): issue priority of ALL its chain waves (0: the graded default)
     uint32_t errlen_later;           // the error-profile size of a read is computed by k_errlen / k_hp_filter_w, not by k_chain
     uint8_t *scr;                    // -k: the pieces of every read before mutate_homo (forward strand; FASTQ: with their class bits)
     uint64_t *scr_len, *scr_off;     //     bytes per read / exclusive scan
@@ -289,7 +290,9 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK, COOP ? 4 : NS_CHAI
     // The list is sorted by descending length, so the first workgroups carry the longest chains and set the makespan
     // (a 120 kb read is ~3800 dependent iterations): give them issue priority over the short-read waves they share a
     // SIMD with.
-    if (COOP || blockIdx.x < (gridDim.x >> 6)) __builtin_amdgcn_s_setprio(3);
+    // A background context's chain is a few hundred latency-bound wavefronts next to another context's full grids: all of them take
+    // the issue slots they can use (priority outranks age; a wave that issues one instruction in four cycles leaves the rest).
+    if (COOP || A.bg_prio || blockIdx.x < (gridDim.x >> 6)) __builtin_amdgcn_s_setprio(3);
     else if (blockIdx.x < (gridDim.x >> 4)) __builtin_amdgcn_s_setprio(2);
     else if (blockIdx.x < (gridDim.x >> 2)) __builtin_amdgcn_s_setprio(1);
     unsigned long long st_over = 0, st_bases = 0, st_ref = 0, st_ev = 0;
@@ -1364,13 +1367,17 @@ __global__ void __launch_bounds__(64 * NS_WPB) k_errlog(GenArgs A) {
                     *w++ = (uint8_t)tn[0]; *w++ = (uint8_t)tn[1]; *w++ = (uint8_t)tn[2];
                     *w++ = '\t'; w = put_dec(w, len); *w++ = '\t';
                     uint8_t *w2 = w + len + 1;
+                    // the letters of the event come from ONE word per 16 (payload_word: 2-bit fields / successive base-3 digits) — drawn
+                    // once per word here, not once per letter (ins_letter / mis_letter evaluate a Philox block per call)
+                    uint32_t frac = 0;
                     for (uint32_t i = 0; i < len; ++i) {
-                        if (ty == NS_INS) { w[i] = '-'; w2[i] = ins_letter(key, pc.sid, a, p.n_ev - 1 - k, i); }
+                        if (ty != NS_DEL && !(i & 15u)) frac = payload_word(key, pc.sid, a, p.n_ev - 1 - k, i >> 4);
+                        if (ty == NS_INS) { w[i] = '-'; w2[i] = bases_atcg((frac >> (2u * (i & 15u))) & 3u); }
                         else {
                             uint32_t x = e.pos + i;
                             uint8_t cur = resolve_base(ref_base_at(A.ref, pc, x), key, pc.sid, a, x);
                             w[i] = cur;
-                            w2[i] = (ty == NS_MIS) ? mis_letter(cur, key, pc.sid, a, p.n_ev - 1 - k, i) : (uint8_t)'-';
+                            w2[i] = (ty == NS_MIS) ? mis_from_digit(cur, next_digit3(frac)) : (uint8_t)'-';
                         }
                     }
                     w[len] = '\t';
@@ -1437,6 +1444,7 @@ struct ns_ctx {
     uint32_t dbg = 0;          // NS_DEBUG_SKIP: phase-ablation bits for profiling only (results are wrong when set)
     uint32_t coop_min = 16384, coop_shift = 10;  // cooperative chain for the longest n>>shift reads of batches >= min (env: NS_COOP_MIN, NS_COOP_SHIFT);
                                                  // 10^6 reads, chain ms at shift 9 / 10 / 11 / 12: 4.18 / 3.63 / 3.90 / 4.32
+    uint32_t bg_prio = 0;                        // background context: all chain waves at s_setprio 3 (env NS_BG_PRIO overrides)
     uint32_t ucoop_shift = 0;                    // unaligned reads: the longest n>>shift of a batch take the wave-per-read list, the rest the thread-per-read one (env: NS_UCOOP_SHIFT; 0: all)
     // planning + result buffers
     DevBuf l_cap, l_off, p_need, p_off;
@@ -1547,7 +1555,9 @@ uint32_t ns_abi_version(void) { return NS_ABI_VERSION; }
 int ns_set_background(ns_ctx *ctx, int on) {
     if (!ctx) return NS_EINVAL;
     ctx->ucoop_shift = on ? 3u : 0u;
+    ctx->bg_prio = on ? 1u : 0u;
     if (const char *d = getenv("NS_UCOOP_SHIFT")) ctx->ucoop_shift = (uint32_t)atoi(d) & 31u;
+    if (const char *d = getenv("NS_BG_PRIO")) ctx->bg_prio = on ? (uint32_t)atoi(d) : 0u;
     return NS_OK;
 }
 
@@ -2633,6 +2643,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     A.hp = hp_on ? 1u : 0u; A.keep_state = 0;
     A.errlen_later = prm->emit_errlog ? 1u : 0u;
     A.dbg = ctx->dbg;
+    A.bg_prio = ctx->bg_prio;
     if (prm->trx) {
         if ((rc = ensure(ctx, ctx->polya, (n + 1) * 2))) return rc;
         A.tx = ctx->tx; A.polya = (uint16_t *)ctx->polya.p;

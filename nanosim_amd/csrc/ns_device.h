@@ -376,6 +376,17 @@ __device__ __forceinline__ uint8_t qual_at(const DevModel &m, int cls, const ns_
     return qual_value(m.qual_thr + cls * NS_QUAL_LEVELS, h);
 }
 
+// (32-bit values — positions, run lengths, lengths — take the 32-bit forms: a division of a 64-bit value by ten is a multi-instruction
+// sequence on this target, and k_errlen / k_errlog / the names format millions of numbers per batch)
+__device__ __forceinline__ uint32_t dec_digits(uint32_t v) {
+    return v < 10u ? 1u : v < 100u ? 2u : v < 1000u ? 3u : v < 10000u ? 4u : v < 100000u ? 5u : v < 1000000u ? 6u : v < 10000000u ? 7u :
+           v < 100000000u ? 8u : v < 1000000000u ? 9u : 10u;
+}
+__device__ __forceinline__ uint8_t *put_dec(uint8_t *p, uint32_t v) {
+    const uint32_t n = dec_digits(v);
+    for (uint32_t i = 0; i < n; ++i) { const uint32_t q = v / 10u; p[n - 1 - i] = (uint8_t)('0' + (v - 10u * q)); v = q; }
+    return p + n;
+}
 __device__ __forceinline__ uint32_t dec_digits(uint64_t v) {
     uint32_t n = 1;
     while (v >= 10) { v /= 10; ++n; }

@@ -192,11 +192,13 @@ struct IoEngine {
                 }
             }
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            j.sink->written += j.n;
             {
+                // `written` is published LAST and under the lock: ns_sink_close -> wait_sink tests written == queued under the same
+                // lock and then deletes the sink, so nothing may touch it after that update becomes visible
                 std::lock_guard<std::mutex> g(mu);
                 free_slices.push_back(j.slice); --jobs_open; write_s += dt;
                 j.sink->writing = false;
+                j.sink->written += j.n;
             }
             cv_free.notify_one(); cv_idle.notify_all(); cv_write.notify_one();
         }

@@ -73,20 +73,30 @@ def agree(dist, ok: bool, message: str = "") -> None:
         sys.exit(1)
 
 
-def _publish_header(dist, key: str, payload: bytes | None) -> bytes:
-    """rank 0's `payload` for every rank through the rendezvous store of the process group (a TCP key-value store: set / blocking get,
-    no collective); falls back to a 2-step object broadcast when the store is not reachable"""
+def _default_store():
+    """the rendezvous store of the default process group, or None when this torch has no such accessor.  Whether it exists depends on the
+    torch build and on how the group was created — the same on every rank — so every rank takes the same transport below."""
     try:
         from torch.distributed import distributed_c10d as c10d
-        store = c10d._get_default_store()
-        if dist.get_rank() == 0:
-            store.set(key, payload)
-            return payload
-        return bytes(store.get(key))
-    except Exception:
+        return c10d._get_default_store()
+    except (ImportError, AttributeError):
+        return None
+
+
+def _publish_header(dist, key: str, payload: bytes | None) -> bytes:
+    """rank 0's `payload` for every rank through the rendezvous store of the process group (a TCP key-value store: set / blocking get,
+    no collective).  Only a torch WITHOUT the store accessor takes the fallback, an object broadcast — decided before any rank
+    publishes, identically on all ranks; an error of set / get itself propagates (a rank that fell back on its own would sit in a
+    collective its peers never enter)."""
+    store = _default_store()
+    if store is None:
         box = [payload]
         dist.broadcast_object_list(box, src=0)
         return box[0]
+    if dist.get_rank() == 0:
+        store.set(key, payload)
+        return payload
+    return bytes(store.get(key))
 
 
 _BCAST_SEQ = [0]
@@ -172,6 +182,25 @@ def mark_failed(path: str, rank: int, message: str) -> None:
         pass
 
 
+class failure_markers:
+    """`with failure_markers(outputs, rank, world):` around everything a rank > 0 does after the broadcast: whatever ends the block with
+    an exception — a model that does not load, an engine that cannot be created, ENOMEM in a later batch, a failed write — leaves
+    `<file>.part<rank>.failed` for EVERY output, so rank 0 (collect_parts) ends with status 1 at once instead of polling for a sub-file
+    list that never comes.  (A rank killed by a signal leaves nothing: the launcher tears the job down, and NS_PART_TIMEOUT bounds the wait.)"""
+
+    def __init__(self, paths, rank: int, world: int):
+        self.paths, self.rank, self.world = list(paths), rank, world
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is not None and self.rank > 0 and self.world > 1 and not (et is SystemExit and ev.code in (0, None)):
+            for p in self.paths:
+                mark_failed(p, self.rank, repr(ev))
+        return False
+
+
 def _append_file(dst_fd: int, src_path: str) -> int:
     """the bytes of src_path appended to dst_fd inside the kernel (copy_file_range: a reflink where the file system has one), falling
     back to sendfile / read + write"""
@@ -210,9 +239,10 @@ def collect_parts(path: str, world: int, own=None, keep: bool = False, timeout_s
     """Rank 0, once its own bytes of `path` are written (`own`: the files that hold them, in order — [path] itself when it wrote the final
     file directly): append everything else in order — its own sub-files, then those of ranks 1 .. world-1 as their lists appear
     (publish_parts) — and remove the sub-files.  keep: nothing is copied; <path>.subfiles lists the files in order instead.
-    A `.failed` marker of any rank (or the timeout, NS_PART_TIMEOUT seconds, default one day) ends the run with status 1."""
+    A `.failed` marker of any rank (or the timeout, NS_PART_TIMEOUT seconds, default one hour — counted from the moment rank 0 is
+    done with its own share: the ranks have equal shares and finish together) ends the run with status 1."""
     if timeout_s is None:
-        timeout_s = float(os.environ.get("NS_PART_TIMEOUT", "86400"))
+        timeout_s = float(os.environ.get("NS_PART_TIMEOUT", "3600"))
     deadline = time.monotonic() + timeout_s
     own = [os.path.abspath(x) for x in (own if own is not None else [path])]
     final = os.path.abspath(path)

@@ -149,6 +149,77 @@ def validate_genome_args(a, parser_g):
         die("Perfect reads cannot be chimeric", False)
 
 
+def _cap_stripes(stripes: int, n_outputs: int) -> int:
+    """-t K opens 2 x K descriptors per output (two batches in flight): K is capped at 64 and by RLIMIT_NOFILE"""
+    k = max(1, min(int(stripes), 64))
+    try:
+        import resource
+        soft = resource.getrlimit(resource.RLIMIT_NOFILE)[0]
+        if soft != resource.RLIM_INFINITY:
+            k = max(1, min(k, (int(soft) - 64) // max(1, 4 * n_outputs)))
+    except (ImportError, ValueError, OSError):
+        pass
+    return k
+
+
+def _step_batches(n_al: int, n_un: int) -> tuple[int, int]:
+    """reads per worker call of the two phases: one STEP of BATCH_READS reads = an aligned call on its share and an unaligned call on
+    the rest (950 000 + 50 000 at the usual 19:1), so that the two contexts of _run_phases work through the run in lockstep — the step
+    bench.py times — instead of the unaligned phase racing ahead in one big batch"""
+    tot = max(1, n_al + n_un)
+    al = max(1000, min(BATCH_READS, int(round(BATCH_READS * n_al / tot))))
+    return al, max(1000, BATCH_READS - al)
+
+
+def _serial_schedule() -> bool:
+    """NS_SERIAL=1: aligned and unaligned worker calls one after the other on ONE engine context (A/B runs, GPUs short of memory)"""
+    return os.environ.get("NS_SERIAL", "0") != "0"
+
+
+def _background_engine(device, setup):
+    """The second engine context of this GPU: the unaligned worker calls run on it NEXT TO the aligned ones (ns_set_background: its
+    kernels are chosen for few issue slots, not for a short latency).  `setup(engine)` installs reference, mode tables and model."""
+    eng = E.Engine(device)
+    try:
+        eng.set_background(True)
+        setup(eng)
+    except BaseException:
+        eng.close()
+        raise
+    return eng
+
+
+def _run_phases(aligned, unaligned, rank, n_done):
+    """simulation() (S:1588-1672) starts the unaligned workers once the aligned ones are joined.  That order constrains the FILES only —
+    the two phases write different files and a read is a function of (seed, read index) — so here `unaligned` (a closure over the
+    background engine context) runs in a second host thread NEXT TO `aligned`: one GPU, two contexts, the schedule bench.py times.
+    unaligned is None: nothing to run (--perfect).  The log keeps the reference's order."""
+    import threading
+    err = []
+
+    def bg():
+        try:
+            unaligned()
+        except BaseException as ex:                      # (SystemExit of a failed merge included: threading would swallow it)
+            err.append(ex)
+    t = None
+    if unaligned is not None:
+        t = threading.Thread(target=bg, name="ns-unaligned")
+        t.start()
+    try:
+        aligned()
+    finally:
+        if t is not None:
+            if rank == 0:
+                log("Start simulation of random reads")
+            t.join()
+    if err:
+        raise err[0]
+    if t is not None and rank == 0:
+        sys.stdout.write(strftime("%Y-%m-%d %H:%M:%S") + ": Number of reads simulated >> " + str(n_done) + "\n")
+        sys.stdout.flush()
+
+
 def _batch_params(n, first, *, seed, kind, fastq, chimeric, min_len, max_len, median_len, sd_len, want_errlog, kmer_bias, meta, trx, uracil,
                   model_ir, emit_records=True):
     return E.make_params(seed=seed, first_read=first, n_reads=n, kind=kind, fastq=fastq, chimeric=chimeric, kmer_bias=kmer_bias, min_len=min_len,
@@ -157,7 +228,8 @@ def _batch_params(n, first, *, seed, kind, fastq, chimeric, min_len, max_len, me
 
 
 def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, chimeric, min_len, max_len, median_len,
-                   sd_len, want_errlog, kmer_bias=0, meta=False, err_header=b"", trx=False, uracil=False, model_ir=False, dist=None, stripes=1):
+                   sd_len, want_errlog, kmer_bias=0, meta=False, err_header=b"", trx=False, uracil=False, model_ir=False, dist=None, stripes=1,
+                   quiet=False, tag="", batch_reads=None):
     """Reads [first, first + count) of this rank into out_path (and their error-profile rows into err_path), through the engine's output
     sinks (include/nanosim_amd.h: ns_sink_*): the images of batch i leave the GPU and reach the files while batch i + 1 is generated.
 
@@ -167,14 +239,16 @@ def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, 
     parallel — writes into ONE file serialise on its inode, K files do not — and appended to the final file at the end, in order.
     NS_KEEP_SUBFILES=1 skips that merge: the sub-files stay and `<file>.subfiles` lists them in order (cat $(cat x.subfiles) = x).
     Several ranks: a rank that is done publishes the list of its sub-files (shard.publish_parts); rank 0 appends them in rank order as they
-    appear (shard.collect_parts) — no collective, and a rank that fails leaves a marker instead of a hanging peer."""
+    appear (shard.collect_parts) — no collective, and a rank that fails leaves a marker instead of a hanging peer.
+    quiet: no progress line on stdout (the worker call that runs on the background context, _run_phases)."""
     rank = dist.get_rank() if dist is not None else 0
+    stripes = _cap_stripes(stripes, len([p for p in (out_path, err_path) if p]))
     world = dist.get_world_size() if dist is not None else 1
     trace = os.environ.get("NS_CLI_TRACE") is not None       # per-batch host timing on stderr
     keep = os.environ.get("NS_KEEP_SUBFILES", "0") != "0"
     kw = dict(seed=seed, kind=kind, fastq=fastq, chimeric=chimeric, min_len=min_len, max_len=max_len, median_len=median_len, sd_len=sd_len,
               want_errlog=err_path is not None, kmer_bias=kmer_bias, meta=meta, trx=trx, uracil=uracil, model_ir=model_ir)
-    batch = getattr(eng, "_batch_reads", BATCH_READS)
+    batch = min(getattr(eng, "_batch_reads", BATCH_READS), batch_reads or BATCH_READS)
     paths = [p for p in (out_path, err_path) if p]
     which = {out_path: E.NS_BUF_RECORDS, err_path: E.NS_BUF_ERRLOG}
     files = {p: [] for p in paths}                           # what holds this rank's bytes of p, in order
@@ -183,12 +257,21 @@ def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, 
     done = n_sub = 0
 
     def close_all(lst):
-        for sk, fd in lst:
+        """every (sink, fd) of the list is closed exactly once, whatever fails on the way; the first error is raised at the end"""
+        first_err = None
+        while lst:
+            sk, fd = lst.pop(0)
             try:
                 sk.close()                               # waits for the file writes; raises on ENOSPC & co
+            except Exception as ex:
+                first_err = first_err or ex
             finally:
-                os.close(fd)
-        del lst[:]
+                try:
+                    os.close(fd)
+                except OSError as ex:
+                    first_err = first_err or ex
+        if first_err is not None:
+            raise first_err
     try:
         if stripes == 1:
             for p in paths:
@@ -231,12 +314,12 @@ def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, 
                 prev, open_now = open_now, []
             if trace:
                 c = eng.io_counters()
-                sys.stderr.write("[cli] batch %d reads: generate %.1f ms (device %.1f), %.2f GB queued; so far %.2f GB copied at %s GB/s (DMA), copier waited "
+                sys.stderr.write("[cli%s] batch %d reads: generate %.1f ms (device %.1f), %.2f GB queued; so far %.2f GB copied at %s GB/s (DMA), copier waited "
                                  "%.2f s for staging, writers %.2f s in pwrite\n"
-                                 % (n, (t1 - t0) * 1e3, b.info.ms_total, (int(b.info.record_bytes) + int(b.info.errlog_bytes)) / 1e9, c["bytes"] / 1e9,
+                                 % (tag, n, (t1 - t0) * 1e3, b.info.ms_total, (int(b.info.record_bytes) + int(b.info.errlog_bytes)) / 1e9, c["bytes"] / 1e9,
                                     "%.1f" % c["d2h_gbs"] if c["d2h_gbs"] else "-", c["wait_staging_s"], c["write_s"]))
             done += n
-            if rank == 0:
+            if rank == 0 and not quiet:
                 sys.stdout.write(strftime("%Y-%m-%d %H:%M:%S") + ": Number of reads simulated >> " + str(first + done) + "\r")
                 sys.stdout.flush()
         close_all(prev)
@@ -260,7 +343,8 @@ def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, 
                 shard.mark_failed(p, rank, repr(ex))
         raise
     if rank == 0:
-        sys.stdout.write('\n')
+        if not quiet:
+            sys.stdout.write('\n')
         for p in paths:
             shard.collect_parts(p, world, files[p], keep=keep)
 
@@ -293,48 +377,73 @@ def run_genome(a, parser_g):
     # S:354-356; every rank leaves together (the verdict of rank 0's check travels in the header of the broadcast)
     bad = "Do not choose circular if there is more than one chromosome in the genome!\n" if (rank == 0 and len(ref.names) > 1 and a.dna_type == "circular") else None
     keep = None
+    outputs = [out + "_aligned_reads" + ext, out + "_aligned_error_profile", out + "_unaligned_reads" + ext]
     if dist is not None:
-        shard.clean_parts([out + "_aligned_reads" + ext, out + "_aligned_error_profile", out + "_unaligned_reads" + ext], rank)
+        shard.clean_parts(outputs, rank)
         ref, keep, extra = shard.broadcast_reference(ref, dist, device=bdev, extra=dict(seed=seed), error=bad)
         seed = extra["seed"]               # rank 0's: a read is a function of (seed, read index)
-        if bdev is not None:
-            eng.set_reference_device(keep.data_ptr(), ref)
-        else:                                                                               # (gloo: the bases arrived in host memory)
+        if bdev is None:                                                                    # (gloo: the bases arrived in host memory)
             ref = M.Reference(ref.names, keep.numpy(), ref.chrom_off, ref.circular)
-            eng.set_reference(ref)
     else:
         shard.agree(None, bad is None, bad or "")
-        eng.set_reference(ref)
-    if rank == 0:
-        log("Read error profile" if not a.perfect else "Read KDF of aligned reads")
-    mdl = M.load_model(a.model_prefix, perfect=a.perfect, strandness=a.strandness, chimeric=a.chimeric,
-                       homopolymer=a.homopolymer, fastq=a.fastq)
-    eng.load_model(mdl)
-    number = a.number
-    if a.coverage is not None:
+    with shard.failure_markers(outputs, rank, world):
         if rank == 0:
-            print("\nCalculating the number of reads to be simulated based on the coverage, if you specified the number of reads "
-                  "concurrently with the coverage, coverage will override number of reads.\n")
-        number = calculate_read_number_from_coverage(ref, a.model_prefix, a.coverage)
-    n_al, n_un = mdl.split_counts(number)
-    max_len = int(min(a.max_len, ref.max_chrom))                                            # S:2318
-    kind = E.NS_KIND_PERFECT if a.perfect else E.NS_KIND_ALIGNED
-    if rank == 0:
-        if a.median_len and a.sd_len:
-            log("Simulating read length with log-normal distribution")
-        log("Start simulation of aligned reads")
-    lo, hi = shard.partition(n_al, world)[rank]
-    _write_batches(eng, out + "_aligned_reads" + ext, out + "_aligned_error_profile", seed=seed, first=lo, count=hi - lo, kind=kind,
-                   fastq=a.fastq, chimeric=a.chimeric, min_len=a.min_len, max_len=max_len, median_len=a.median_len, sd_len=a.sd_len,
-                   want_errlog=True, kmer_bias=a.KmerBias or 0, err_header=ERR_HEADER, dist=dist, stripes=max(a.num_threads, 1))
-    if not a.perfect:                                                                       # S:1642-1672
+            log("Read error profile" if not a.perfect else "Read KDF of aligned reads")
+        mdl = M.load_model(a.model_prefix, perfect=a.perfect, strandness=a.strandness, chimeric=a.chimeric,
+                           homopolymer=a.homopolymer, fastq=a.fastq)
+
+        def setup(e):
+            if dist is not None and bdev is not None:
+                e.set_reference_device(keep.data_ptr(), ref)
+            else:
+                e.set_reference(ref)
+            e.load_model(mdl)
+        setup(eng)
+        number = a.number
+        if a.coverage is not None:
+            if rank == 0:
+                print("\nCalculating the number of reads to be simulated based on the coverage, if you specified the number of reads "
+                      "concurrently with the coverage, coverage will override number of reads.\n")
+            number = calculate_read_number_from_coverage(ref, a.model_prefix, a.coverage)
+        n_al, n_un = mdl.split_counts(number)
+        max_len = int(min(a.max_len, ref.max_chrom))                                            # S:2318
+        kind = E.NS_KIND_PERFECT if a.perfect else E.NS_KIND_ALIGNED
         if rank == 0:
-            log("Start simulation of random reads")
-        lo, hi = shard.partition(n_un, world)[rank]
-        _write_batches(eng, out + "_unaligned_reads" + ext, None, seed=seed, first=n_al + lo, count=hi - lo, kind=E.NS_KIND_UNALIGNED,
-                       fastq=a.fastq, chimeric=False, min_len=a.min_len, max_len=max_len, median_len=a.median_len, sd_len=a.sd_len,
-                       want_errlog=False, dist=dist, stripes=max(a.num_threads, 1))
-    eng.close()
+            if a.median_len and a.sd_len:
+                log("Simulating read length with log-normal distribution")
+            log("Start simulation of aligned reads")
+        lo, hi = shard.partition(n_al, world)[rank]
+        ulo, uhi = shard.partition(n_un, world)[rank]
+        stripes = max(a.num_threads, 1)
+        eng_un = eng
+        if not a.perfect and not _serial_schedule():
+            eng_un = _background_engine(device, setup)
+        b_al, b_un = _step_batches(n_al, n_un) if eng_un is not eng else (None, None)
+
+        def aligned():
+            _write_batches(eng, outputs[0], outputs[1], seed=seed, first=lo, count=hi - lo, kind=kind,
+                           fastq=a.fastq, chimeric=a.chimeric, min_len=a.min_len, max_len=max_len, median_len=a.median_len, sd_len=a.sd_len,
+                           want_errlog=True, kmer_bias=a.KmerBias or 0, err_header=ERR_HEADER, dist=dist, stripes=stripes, tag=" aligned",
+                           batch_reads=b_al)
+
+        def unaligned(quiet):                                                                   # S:1642-1672
+            _write_batches(eng_un, outputs[2], None, seed=seed, first=n_al + ulo, count=uhi - ulo, kind=E.NS_KIND_UNALIGNED,
+                           fastq=a.fastq, chimeric=False, min_len=a.min_len, max_len=max_len, median_len=a.median_len, sd_len=a.sd_len,
+                           want_errlog=False, dist=dist, stripes=stripes, quiet=quiet, tag=" unaligned", batch_reads=b_un)
+        try:
+            if a.perfect:
+                aligned()
+            elif eng_un is eng:
+                aligned()
+                if rank == 0:
+                    log("Start simulation of random reads")
+                unaligned(False)
+            else:
+                _run_phases(aligned, lambda: unaligned(True), rank, n_al + uhi)
+        finally:
+            if eng_un is not eng:
+                eng_un.close()
+            eng.close()
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:
@@ -373,56 +482,81 @@ def run_metagenome(a, parser_mg):
     if dist is not None:
         info = dict(species=mref.species, off=mref.species_chrom_off.tolist(), keys=mref.chrom_names, numbers=numbers,
                     samples=samples, seed=seed) if rank == 0 else None
-        # (sub-files of every sample this rank may write: the sample count is only known after the broadcast, so by pattern)
+        # (sub-files of every sample this rank may write: the sample count is only known after the broadcast, so by pattern —
+        # ".part<rank>" followed by the end of the name or a dot, so that rank 1 does not take rank 10's files)
         import glob
+        import re
+        tail = re.compile(r"\.part%d(\.|$)" % rank)
         for q in glob.glob(glob.escape(a.output) + "_sample*.part%d*" % rank) if rank else ():
-            os.unlink(q)
+            if tail.search(q):
+                os.unlink(q)
         ref, keep, info = shard.broadcast_reference(mref.ref if rank == 0 else None, dist, device=bdev, extra=info)
         if bdev is None:
             ref = M.Reference(ref.names, keep.numpy(), ref.chrom_off, ref.circular)
         mref = MG.MetaReference(ref, info["species"], np.array(info["off"], dtype=np.uint32), info["keys"])
         numbers, samples, seed = info["numbers"], info["samples"], info["seed"]
-        eng.set_metagenome(mref, dev_ptr=keep.data_ptr() if bdev is not None else None)
-    else:
-        eng.set_metagenome(mref)
-    if rank == 0:
-        log("Read error profile" if not a.perfect else "Read KDF of aligned reads")
-    mdl = M.load_model(a.model_prefix, perfect=a.perfect, strandness=a.strandness, chimeric=a.chimeric, fastq=a.fastq,
-                       homopolymer=a.homopolymer)
-    eng.load_model(mdl)
-    max_len = a.max_len
-    total_len = mref.total_len()
-    first = 0
-    for s, abun in enumerate(samples):
-        sample = "sample" + str(s)
-        if a.abun_var:                                                                      # S:2497-2506: the species of THIS sample
-            sample_len = {sp: total_len[sp] for sp in abun}
-            u = np.random.default_rng([seed & 0xffffffff, seed >> 32, s]).random(len(sample_len))
-            abun = MG.add_abundance_var(abun, sample_len, float(a.abun_var[0]), float(a.abun_var[1]), iter(u.tolist()))
-        infl = {sp: MG.inflate_abun(abun, sp, mdl.abun_inflation) for sp in abun} if a.chimeric else None   # S:2510-2514
-        eng.set_abundance(mref, abun, infl)
+    tails = ("_aligned_reads" + ext, "_aligned_error_profile", "_unaligned_reads" + ext)
+    outputs = [out + "_sample%d%s" % (s, t) for s in range(len(samples)) for t in tails]
+    with shard.failure_markers(outputs, rank, world):
         if rank == 0:
-            log("Simulating sample " + sample)
-            if a.median_len and a.sd_len:
-                log("Simulating read length from log-normal distribution")
-            log("Start simulation of aligned reads")
-        n_al, n_un = mdl.split_counts(numbers[s])
-        max_len = int(min(max_len, mref.max_chrom))                                         # S:2525
-        base = out + "_" + sample
-        lo, hi = shard.partition(n_al, world)[rank]
-        _write_batches(eng, base + "_aligned_reads" + ext, base + "_aligned_error_profile", seed=seed, first=first + lo,
-                       count=hi - lo, kind=E.NS_KIND_PERFECT if a.perfect else E.NS_KIND_ALIGNED, fastq=a.fastq, chimeric=a.chimeric,
-                       min_len=a.min_len, max_len=max_len, median_len=a.median_len, sd_len=a.sd_len, want_errlog=True, meta=True,
-                       kmer_bias=0 if a.perfect else (a.KmerBias or 0), err_header=ERR_HEADER, dist=dist)
-        if not a.perfect:                                                                   # S:1642
-            if rank == 0:
-                log("Start simulation of random reads")
-            lo, hi = shard.partition(n_un, world)[rank]
-            _write_batches(eng, base + "_unaligned_reads" + ext, None, seed=seed, first=first + n_al + lo, count=hi - lo,
-                           kind=E.NS_KIND_UNALIGNED, fastq=a.fastq, chimeric=False, min_len=a.min_len, max_len=max_len,
-                           median_len=a.median_len, sd_len=a.sd_len, want_errlog=False, meta=True, dist=dist)
-        first += n_al + n_un            # samples draw from disjoint read-index ranges of the same seed
-    eng.close()
+            log("Read error profile" if not a.perfect else "Read KDF of aligned reads")
+        mdl = M.load_model(a.model_prefix, perfect=a.perfect, strandness=a.strandness, chimeric=a.chimeric, fastq=a.fastq,
+                           homopolymer=a.homopolymer)
+
+        def setup(e):
+            e.set_metagenome(mref, dev_ptr=keep.data_ptr() if (dist is not None and bdev is not None) else None)
+            e.load_model(mdl)
+        setup(eng)
+        eng_un = eng
+        if not a.perfect and not _serial_schedule():
+            eng_un = _background_engine(device, setup)       # (unaligned reads and gaps take any species: no abundances needed, S:1708)
+        max_len = a.max_len
+        total_len = mref.total_len()
+        first = 0
+        try:
+            for s, abun in enumerate(samples):
+                sample = "sample" + str(s)
+                if a.abun_var:                                                                  # S:2497-2506: the species of THIS sample
+                    sample_len = {sp: total_len[sp] for sp in abun}
+                    u = np.random.default_rng([seed & 0xffffffff, seed >> 32, s]).random(len(sample_len))
+                    abun = MG.add_abundance_var(abun, sample_len, float(a.abun_var[0]), float(a.abun_var[1]), iter(u.tolist()))
+                infl = {sp: MG.inflate_abun(abun, sp, mdl.abun_inflation) for sp in abun} if a.chimeric else None   # S:2510-2514
+                eng.set_abundance(mref, abun, infl)
+                if rank == 0:
+                    log("Simulating sample " + sample)
+                    if a.median_len and a.sd_len:
+                        log("Simulating read length from log-normal distribution")
+                    log("Start simulation of aligned reads")
+                n_al, n_un = mdl.split_counts(numbers[s])
+                max_len = int(min(max_len, mref.max_chrom))                                     # S:2525
+                base = out + "_" + sample
+                lo, hi = shard.partition(n_al, world)[rank]
+                ulo, uhi = shard.partition(n_un, world)[rank]
+
+                def aligned(base=base, first=first, lo=lo, hi=hi, max_len=max_len):
+                    _write_batches(eng, base + "_aligned_reads" + ext, base + "_aligned_error_profile", seed=seed, first=first + lo,
+                                   count=hi - lo, kind=E.NS_KIND_PERFECT if a.perfect else E.NS_KIND_ALIGNED, fastq=a.fastq, chimeric=a.chimeric,
+                                   min_len=a.min_len, max_len=max_len, median_len=a.median_len, sd_len=a.sd_len, want_errlog=True, meta=True,
+                                   kmer_bias=0 if a.perfect else (a.KmerBias or 0), err_header=ERR_HEADER, dist=dist, tag=" aligned")
+
+                def unaligned(quiet, base=base, first=first, n_al=n_al, ulo=ulo, uhi=uhi, max_len=max_len):     # S:1642
+                    _write_batches(eng_un, base + "_unaligned_reads" + ext, None, seed=seed, first=first + n_al + ulo, count=uhi - ulo,
+                                   kind=E.NS_KIND_UNALIGNED, fastq=a.fastq, chimeric=False, min_len=a.min_len, max_len=max_len,
+                                   median_len=a.median_len, sd_len=a.sd_len, want_errlog=False, meta=True, dist=dist, quiet=quiet, tag=" unaligned")
+                if a.perfect:
+                    aligned()
+                elif eng_un is eng:
+                    aligned()
+                    if rank == 0:
+                        log("Start simulation of random reads")
+                    unaligned(False)
+                else:
+                    _run_phases(aligned, lambda: unaligned(True), rank, first + n_al + uhi)
+                first += n_al + n_un            # samples draw from disjoint read-index ranges of the same seed
+        finally:
+            if eng_un is not eng:
+                eng_un.close()
+            eng.close()
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:
@@ -489,36 +623,61 @@ def run_transcriptome(a, parser_t):
             log("Read in reference genome, IR markov model and GFF3 annotation file")
         ir = IR.load(a.model_prefix, a.ref_g, tr.ref)
         tr = TR.restrict_expression(tr, ir.eligible)                                          # S:1093-1099
-    eng.set_transcriptome(tr, dev_ptr=keep.data_ptr() if keep is not None else None)
-    if ir is not None:
-        eng.set_intron_retention(ir)
-    if rank == 0:
-        log("Read error profile" if not a.perfect else "Read KDF of aligned reads")
-    mdl = M.load_model(a.model_prefix, perfect=a.perfect, strandness=a.strandness, fastq=a.fastq, transcriptome=True,
-                       homopolymer=a.homopolymer)
-    eng.load_model(mdl)
-    number = a.number
-    if a.coverage is not None:
-        print("\nCalculating the number of reads to be simulated based on the coverage, if you specified the number of reads "
-              "concurrently with the coverage, coverage will override number of reads.\n")
-        number = calculate_read_number_from_coverage(tr.ref, a.model_prefix, a.coverage)
-    n_al, n_un = mdl.split_counts(number)
-    max_len = int(min(a.max_len, tr.ref.max_chrom))                                           # S:2411
-    if rank == 0:
-        log("Start simulation of aligned reads")
-    lo, hi = shard.partition(n_al, world)[rank]
-    _write_batches(eng, out + "_aligned_reads" + ext, out + "_aligned_error_profile", seed=seed, first=lo, count=hi - lo,
-                   kind=E.NS_KIND_PERFECT if a.perfect else E.NS_KIND_ALIGNED, fastq=a.fastq, chimeric=False, min_len=a.min_len,
-                   max_len=max_len, median_len=None, sd_len=None, want_errlog=True, trx=True, uracil=a.uracil, kmer_bias=a.KmerBias or 0,
-                   err_header=ERR_HEADER, model_ir=model_ir, dist=dist, stripes=max(a.num_threads, 1))
-    if not a.perfect:                                                                         # S:1642-1672
+    outputs = [out + "_aligned_reads" + ext, out + "_aligned_error_profile", out + "_unaligned_reads" + ext]
+    with shard.failure_markers(outputs, rank, world):
         if rank == 0:
-            log("Start simulation of random reads")
-        lo, hi = shard.partition(n_un, world)[rank]
-        _write_batches(eng, out + "_unaligned_reads" + ext, None, seed=seed, first=n_al + lo, count=hi - lo,
-                       kind=E.NS_KIND_UNALIGNED, fastq=a.fastq, chimeric=False, min_len=a.min_len, max_len=max_len, median_len=None,
-                       sd_len=None, want_errlog=False, trx=True, uracil=a.uracil, dist=dist, stripes=max(a.num_threads, 1))
-    eng.close()
+            log("Read error profile" if not a.perfect else "Read KDF of aligned reads")
+        mdl = M.load_model(a.model_prefix, perfect=a.perfect, strandness=a.strandness, fastq=a.fastq, transcriptome=True,
+                           homopolymer=a.homopolymer)
+
+        def setup(e, with_ir=True):
+            e.set_transcriptome(tr, dev_ptr=keep.data_ptr() if keep is not None else None)
+            if ir is not None and with_ir:
+                e.set_intron_retention(ir)
+            e.load_model(mdl)
+        setup(eng)
+        number = a.number
+        if a.coverage is not None:
+            print("\nCalculating the number of reads to be simulated based on the coverage, if you specified the number of reads "
+                  "concurrently with the coverage, coverage will override number of reads.\n")
+            number = calculate_read_number_from_coverage(tr.ref, a.model_prefix, a.coverage)
+        n_al, n_un = mdl.split_counts(number)
+        max_len = int(min(a.max_len, tr.ref.max_chrom))                                           # S:2411
+        if rank == 0:
+            log("Start simulation of aligned reads")
+        lo, hi = shard.partition(n_al, world)[rank]
+        ulo, uhi = shard.partition(n_un, world)[rank]
+        stripes = max(a.num_threads, 1)
+        eng_un = eng
+        if not a.perfect and not _serial_schedule():
+            eng_un = _background_engine(device, lambda e: setup(e, with_ir=False))     # (S:1156: unaligned reads are never spliced)
+        b_al, b_un = _step_batches(n_al, n_un) if eng_un is not eng else (None, None)
+
+        def aligned():
+            _write_batches(eng, outputs[0], outputs[1], seed=seed, first=lo, count=hi - lo,
+                           kind=E.NS_KIND_PERFECT if a.perfect else E.NS_KIND_ALIGNED, fastq=a.fastq, chimeric=False, min_len=a.min_len,
+                           max_len=max_len, median_len=None, sd_len=None, want_errlog=True, trx=True, uracil=a.uracil, kmer_bias=a.KmerBias or 0,
+                           err_header=ERR_HEADER, model_ir=model_ir, dist=dist, stripes=stripes, tag=" aligned", batch_reads=b_al)
+
+        def unaligned(quiet):                                                                     # S:1642-1672
+            _write_batches(eng_un, outputs[2], None, seed=seed, first=n_al + ulo, count=uhi - ulo,
+                           kind=E.NS_KIND_UNALIGNED, fastq=a.fastq, chimeric=False, min_len=a.min_len, max_len=max_len, median_len=None,
+                           sd_len=None, want_errlog=False, trx=True, uracil=a.uracil, dist=dist, stripes=stripes, quiet=quiet, tag=" unaligned",
+                           batch_reads=b_un)
+        try:
+            if a.perfect:
+                aligned()
+            elif eng_un is eng:
+                aligned()
+                if rank == 0:
+                    log("Start simulation of random reads")
+                unaligned(False)
+            else:
+                _run_phases(aligned, lambda: unaligned(True), rank, n_al + uhi)
+        finally:
+            if eng_un is not eng:
+                eng_un.close()
+            eng.close()
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:

@@ -880,8 +880,8 @@ uint32_t nso_trx_pick(const nso_trx *tx, double u) {
 /* select_nearest_kde2d (S:108-111) on a fresh, large sample of the 2-D KDE == a draw of the aligned length from the KDE
  * conditioned on the transcript length L: training point i with probability proportional to exp(-(L - x_i)^2 / 2h^2), then
  * y = y_i + h * N(0,1), int() truncation.  Rejection sampling inside the window |x_i - L| <= 5h; without a training point in the
- * window: the nearest one.  Draws: Philox (ST_REFLEN, seg 0, attempt, idx = try). */
-int64_t nso_kde2d_cond(const ns_model_tables *t, double L, nso_draw *d, uint32_t attempt) {
+ * window: the nearest one.  Draws: Philox (ST_REFLEN, seg 0, attempt, idx = try, sub). */
+int64_t nso_kde2d_cond(const ns_model_tables *t, double L, nso_draw *d, uint32_t attempt, uint32_t sub) {
     const double *x = t->kde2d_x, *y = t->kde2d_y, h = t->kde2d_bw;
     const uint64_t n = t->kde2d_n;
     uint64_t lo = 0, hi = n;
@@ -890,7 +890,7 @@ int64_t nso_kde2d_cond(const ns_model_tables *t, double L, nso_draw *d, uint32_t
     uint32_t w[4];
     if (hi > lo) {
         for (uint32_t j = 0; j < NSO_KDE_RETRY; ++j) {
-            philox_at(d, ST_REFLEN, 0, attempt, j, 0, w);
+            philox_at(d, ST_REFLEN, 0, attempt, j, sub, w);
             uint64_t i = lo + (uint64_t)(u53_to_p(w[0], w[1]) * (double)(hi - lo));
             if (i >= hi) i = hi - 1;
             const double dd = (L - x[i]) / h;
@@ -901,7 +901,7 @@ int64_t nso_kde2d_cond(const ns_model_tables *t, double L, nso_draw *d, uint32_t
     while (a < b) { uint64_t m = (a + b) >> 1; if (x[m] < L) a = m + 1; else b = m; }
     uint64_t i = a >= n ? n - 1 : a;
     if (a > 0 && a < n && L - x[a - 1] <= x[a] - L) i = a - 1;
-    philox_at(d, ST_REFLEN, 0, attempt, NSO_KDE_RETRY, 0, w);
+    philox_at(d, ST_REFLEN, 0, attempt, NSO_KDE_RETRY, sub, w);
     return (int64_t)fma(h, nso_norminv(u32_to_p(w[3])), y[i]);
 }
 
@@ -931,6 +931,16 @@ typedef struct nso_mread {
     const uint16_t *species;
 } nso_mread;
 
+/* one CANDIDATE read of a transcriptome block (trx_block below): transcript and aligned length come from the block's pick walk, every
+ * other draw of the read is keyed by the candidate (key read index, attempt); one try — a candidate that fails is dropped */
+typedef struct nso_tread {
+    uint64_t key_read;                  /* absolute read index of the Philox key */
+    uint32_t attempt;
+    uint32_t chrom;                     /* the transcript */
+    int64_t ref_len;                    /* ref_len_aligned (S:1098-1104) */
+    uint64_t seq_index;                 /* slot of the read in the batch = its number - first_read */
+} nso_tread;
+
 static void fetch_segment(const nso_ref *ref, uint32_t chrom, uint64_t pos, int64_t len, uint8_t *dst) {
     uint64_t c0 = ref->chrom_off[chrom], cl = ref->chrom_off[chrom + 1] - c0;
     for (int64_t i = 0; i < len; ++i) {
@@ -944,17 +954,18 @@ static int u64_digits(uint64_t v, char *buf) { return sprintf(buf, "%llu", (unsi
 
 /* Generates read `index` of the batch.  Returns 0, or <0 if buffers are too small / attempts exhausted. */
 static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_params *prm, uint64_t index, nso_out *o,
-                    const nso_mread *mr, const nso_meta *mg, const nso_trx *tx) {
+                    const nso_mread *mr, const nso_meta *mg, const nso_trx *tx, const nso_tread *tr) {
     nso_draw d; memset(&d, 0, sizeof d);
-    d.mode = 0; d.seed = prm->seed; d.read = prm->first_read + (mr ? mr->pos_in_pass : index);
+    d.mode = 0; d.seed = prm->seed; d.read = tr ? tr->key_read : prm->first_read + (mr ? mr->pos_in_pass : index);
     if (mr) index = mr->seq_index;
+    if (tr) index = tr->seq_index;
     uint32_t w[4];
     const int kind = (int)prm->kind;
     uint32_t nseg = 1;
     if (mr) nseg = mr->nseg;
     uint32_t epoch = 0, fails = 0;
     uint32_t trx_chrom = 0; int64_t trx_len = 0;
-    for (uint32_t a = mr ? mr->pass : 0; a < NSO_MAX_ATTEMPT; ++a) {
+    for (uint32_t a = mr ? mr->pass : tr ? tr->attempt : 0; a < NSO_MAX_ATTEMPT; ++a) {
         int64_t ref_len[NSO_MAX_SEG], gap_len[NSO_MAX_SEG];
         int ok = 1;
         if (!mr && kind == NS_KIND_ALIGNED && prm->chimeric) {
@@ -967,18 +978,18 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
             if (nseg > NSO_MAX_SEG) nseg = NSO_MAX_SEG;
         }
         if (mr && a != mr->pass) return 1;          /* metagenome: one try per pass; a rejected read is re-planned */
+        if (tr && a != tr->attempt) return 1;       /* transcriptome: one try per candidate of the block's pick walk */
         /* ---- lengths ---- */
         if (kind == NS_KIND_UNALIGNED) {                                  /* S:1494-1495,1499 */
             philox_at(&d, ST_ULEN, 0, a, 0, 0, w);
             double x = prm->use_lognormal ? nso_exp(fma(prm->sd_len, nso_norminv(u32_to_p(w[2])), nso_log(prm->median_len)))
                                           : kde_sample(&t->kde[NS_KDE_UNALIGNED], w);
             ref_len[0] = (int64_t)x;
-        } else if (tx) {                                                  /* transcriptome, S:1082-1105 */
-            philox_at(&d, ST_TRX, 0, a, 0, 0, w);
-            trx_chrom = tx->expr_chrom[nso_trx_pick(tx, u53_to_p(w[0], w[1]))];
+        } else if (tx) {                                                  /* transcriptome, S:1082-1105: planned by trx_block */
+            if (!tr) return -40;
+            trx_chrom = tr->chrom;
             trx_len = (int64_t)(ref->chrom_off[trx_chrom + 1] - ref->chrom_off[trx_chrom]);
-            ref_len[0] = nso_kde2d_cond(t, (double)trx_len, &d, a);
-            if (!(ref_len[0] > 0 && ref_len[0] < trx_len)) ok = 0;        /* S:1103-1104: ref_len_aligned < ref_trx_len */
+            ref_len[0] = tr->ref_len;
         } else if (mr) {                                                  /* S:871-872 (aligned and --perfect) */
             for (uint32_t s = 0; s < nseg; ++s) ref_len[s] = mr->ref_len[s];
             for (uint32_t g = 0; g + 1 < nseg; ++g) {
@@ -1018,11 +1029,11 @@ static int gen_read(const ns_model_tables *t, const nso_ref *ref, const ns_param
         }
         int64_t remainder = 0; double ratio = 0; int reversed;
         if (tx && kind == NS_KIND_ALIGNED) {                               /* S:1073-1076, 1203-1204: one draw per read, no filter */
-            philox_at(&d, ST_HT, 0, 0, 0, 0, w);
+            philox_at(&d, ST_HT, 0, a, 0, 0, w);
             double x = pow10m1(kde_sample(&t->kde[NS_KDE_HT], w));
             remainder = (int64_t)x;                                        /* int(): towards zero */
             if (remainder < 0) remainder = 0;
-            philox_at(&d, ST_RATIO, 0, 0, 0, 0, w);
+            philox_at(&d, ST_RATIO, 0, a, 0, 0, w);
             ratio = kde_sample(&t->kde[NS_KDE_RATIO], w);
             if (ratio > 1) ratio = 1;
             if (ratio < 0) ratio = 0;
@@ -1387,12 +1398,69 @@ int nso_generate(const ns_model_tables *t, const uint8_t *bases, const uint64_t 
     nso_ref ref = {bases, chrom_off, nchrom, circular, names};
     o->n_pieces = o->n_events = o->record_bytes = o->errlog_bytes = o->total_bases = o->total_ref_bases = 0;
     int rc = 0;
-    for (uint64_t i = 0; i < prm->n_reads && rc == 0; ++i) rc = gen_read(t, &ref, prm, i, o, NULL, NULL, NULL);
+    for (uint64_t i = 0; i < prm->n_reads && rc == 0; ++i) rc = gen_read(t, &ref, prm, i, o, NULL, NULL, NULL, NULL);
     free((void *)names);
     return rc;
 }
 
-/* transcriptome batch: simulation_aligned_transcriptome (S:1043-1263, no intron retention) / simulation_unaligned("transcriptome") */
+/* transcriptome batch: simulation_aligned_transcriptome (S:1043-1263) / simulation_unaligned("transcriptome").
+ *
+ * Transcript and aligned length of the aligned reads (S:1080-1104).  The reference worker keeps ONE sample of num_simulate points of the
+ * 2-D KDE (transcript length, aligned length), takes for every picked transcript the point whose first coordinate is nearest
+ * (select_nearest_kde2d, S:108-111) — so inside one sample a transcript always gets the SAME aligned length — remembers the transcripts
+ * it has used (trx_sampled) and draws a new sample as soon as one of them is picked again (S:1087-1092).  A transcript whose length failed
+ * `ref_len_aligned < ref_trx_len` is NOT remembered: it keeps failing until some other transcript repeats.  That couples the reads of a
+ * worker: restated here per BLOCK of NSO_TRX_BLOCK read indices (a "virtual worker": block b holds the reads b * W .. b * W + W - 1 of
+ * the run, whatever batch or rank generates them), as a walk over the block's own pick sequence:
+ *   pick j: transcript = random.choices by Philox(key read b * W, ST_TRX, idx = j, sub = 2); its aligned length under the current
+ *           sample = the conditional draw nso_kde2d_cond(sub = 1 + j) of the FIRST pick of that transcript inside the sample (the nearest
+ *           point of a fresh, large sample is a draw from the KDE conditioned on the transcript length);
+ *   a pick of a transcript that succeeded earlier in the sample starts a new sample and is evaluated under it (S:1087-1092);
+ *   a successful pick is candidate c of the block: its read is generated with the key (b * W + c mod W, attempt c / W), one try; a
+ *   candidate whose error list overshoots the transcript (S:1143-1144), or that cannot be placed, is dropped; the block's reads are
+ *   its first W surviving candidates, in order.
+ * A batch that starts inside a block walks the block from its start (dry runs for the reads in front of the batch). */
+#define NSO_TRX_BLOCK 1024u
+#define NSO_TRX_MAX_PICKS (1u << 22)
+
+static int trx_block(const ns_model_tables *t, const nso_ref *ref, const ns_params *prm, const nso_trx *tx, uint64_t b, nso_out *o,
+                     nso_out *dry, uint32_t *seen_epoch, uint8_t *ok_epoch, uint32_t *epoch_io) {
+    const uint64_t W = NSO_TRX_BLOCK, g0 = prm->first_read, g1 = g0 + prm->n_reads;
+    nso_draw db; memset(&db, 0, sizeof db); db.seed = prm->seed; db.read = b * W;
+    uint32_t epoch = ++*epoch_io, w[4];
+    uint64_t acc = 0, c = 0;
+    for (uint32_t j = 0; acc < W && b * W + acc < g1; ++j) {
+        if (j >= NSO_TRX_MAX_PICKS) return -41;
+        philox_at(&db, ST_TRX, 0, 0, j, 2, w);
+        const uint32_t e = nso_trx_pick(tx, u53_to_p(w[0], w[1]));
+        const uint32_t chrom = tx->expr_chrom[e];
+        const int64_t L = (int64_t)(ref->chrom_off[chrom + 1] - ref->chrom_off[chrom]);
+        int in_epoch = seen_epoch[e] == epoch;
+        if (in_epoch && ok_epoch[e]) { epoch = ++*epoch_io; in_epoch = 0; }          /* S:1087-1092: new sample, trx_sampled = set() */
+        if (in_epoch) continue;                          /* failed before under this sample: the same nearest point, the same failure */
+        const int64_t y = nso_kde2d_cond(t, (double)L, &db, 0, 1u + j);
+        const int good = y > 0 && y < L;                 /* S:1103-1104 */
+        seen_epoch[e] = epoch; ok_epoch[e] = (uint8_t)good;
+        if (!good) continue;
+        if (c >= 2 * W) return -42;
+        nso_tread tr; tr.key_read = b * W + c % W; tr.attempt = (uint32_t)(c / W); tr.chrom = chrom; tr.ref_len = y;
+        ++c;
+        const uint64_t g = b * W + acc;
+        int r1;
+        if (g < g0) {                                    /* a read of an earlier batch: only whether it survives matters */
+            dry->n_pieces = dry->n_events = dry->record_bytes = dry->errlog_bytes = dry->total_bases = dry->spliced_bytes = 0;
+            tr.seq_index = 0;
+            r1 = gen_read(t, ref, prm, 0, dry, NULL, NULL, tx, &tr);
+        } else {
+            tr.seq_index = g - g0;
+            r1 = gen_read(t, ref, prm, g - g0, o, NULL, NULL, tx, &tr);
+        }
+        if (r1 < 0) return r1;
+        if (r1 == 0) ++acc;
+    }
+    return 0;
+}
+
 int nso_generate_trx(const ns_model_tables *t, const uint8_t *bases, const uint64_t *chrom_off, uint32_t nchrom,
                      const uint8_t *circular, const char *names_blob, const nso_trx *tx, const ns_params *prm, nso_out *o) {
     const char **names = (const char **)malloc(sizeof(char *) * (nchrom + 1));
@@ -1402,7 +1470,27 @@ int nso_generate_trx(const ns_model_tables *t, const uint8_t *bases, const uint6
     o->n_pieces = o->n_events = o->record_bytes = o->errlog_bytes = o->total_bases = o->total_ref_bases = 0;
     o->spliced_bytes = 0;
     int rc = 0;
-    for (uint64_t i = 0; i < prm->n_reads && rc == 0; ++i) rc = gen_read(t, &ref, prm, i, o, NULL, NULL, tx);
+    if (prm->kind == NS_KIND_UNALIGNED) {
+        for (uint64_t i = 0; i < prm->n_reads && rc == 0; ++i) rc = gen_read(t, &ref, prm, i, o, NULL, NULL, tx, NULL);
+    } else if (prm->n_reads) {
+        uint64_t longest = 0;
+        for (uint32_t c = 0; c < nchrom; ++c) if (chrom_off[c + 1] - chrom_off[c] > longest) longest = chrom_off[c + 1] - chrom_off[c];
+        nso_out dry; memset(&dry, 0, sizeof dry);          /* scratch outputs for the dry runs in front of the batch */
+        ns_read dry_read; uint16_t dry_polya;
+        dry.reads = &dry_read; dry.polya = &dry_polya;
+        dry.cap_pieces = 8; dry.pieces = (ns_piece *)malloc(sizeof(ns_piece) * dry.cap_pieces);
+        dry.cap_events = 4 * longest + 4096; dry.events = (ns_event *)malloc(sizeof(ns_event) * dry.cap_events);
+        dry.cap_records = 8 * longest + 65536; dry.records = (uint8_t *)malloc(dry.cap_records);
+        dry.cap_errlog = 64 * (4 * longest + 4096) + 65536; dry.errlog = prm->emit_errlog ? (uint8_t *)malloc(dry.cap_errlog) : NULL;
+        dry.spliced = NULL; dry.cap_spliced = 0;
+        uint32_t *seen = (uint32_t *)calloc(tx->n_expr + 1, sizeof(uint32_t));
+        uint8_t *okf = (uint8_t *)calloc(tx->n_expr + 1, 1);
+        uint32_t epoch = 0;
+        const uint64_t W = NSO_TRX_BLOCK;
+        for (uint64_t b = prm->first_read / W; b * W < prm->first_read + prm->n_reads && rc == 0; ++b)
+            rc = trx_block(t, &ref, prm, tx, b, o, &dry, seen, okf, &epoch);
+        free(dry.pieces); free(dry.events); free(dry.records); free(dry.errlog); free(seen); free(okf);
+    }
     free((void *)names);
     return rc;
 }
@@ -1457,7 +1545,7 @@ int nso_generate_meta(const ns_model_tables *t, const uint8_t *bases, const uint
     const uint64_t n = prm->n_reads;
     int rc = 0;
     if (prm->kind == NS_KIND_UNALIGNED) {                /* random species per read, otherwise the genome-mode loop */
-        for (uint64_t i = 0; i < n && rc == 0; ++i) rc = gen_read(t, &ref, prm, i, o, NULL, mg, NULL);
+        for (uint64_t i = 0; i < n && rc == 0; ++i) rc = gen_read(t, &ref, prm, i, o, NULL, mg, NULL, NULL);
         free((void *)names);
         return rc;
     }
@@ -1516,7 +1604,7 @@ int nso_generate_meta(const ns_model_tables *t, const uint8_t *bases, const uint
             nso_mread mr; mr.pass = p; mr.nseg = ns; mr.pos_in_pass = (uint32_t)i; mr.reversed = reversed;
             mr.seq_index = passed + accepted; mr.ref_len = rl; mr.species = species + seg_ptr;
             const uint64_t piece0 = o->n_pieces;
-            int r1 = gen_read(t, &ref, prm, i, o, &mr, mg, NULL);
+            int r1 = gen_read(t, &ref, prm, i, o, &mr, mg, NULL, NULL);
             if (r1 < 0) rc = r1;
             else if (r1 == 0) {
                 for (uint32_t s2 = 0; s2 < ns && !perfect; ++s2)                      /* S:1001-1002 (only in the branch with errors) */

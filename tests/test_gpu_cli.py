@@ -232,3 +232,67 @@ def test_configs0_ecoli_circular_perfect_10k_reads(tmp_path):
         assert len(s) == ln and doubled[pos:pos + ln] == s, lines[i]
         wraps += pos + ln > len(genome)
     assert wraps >= 5                                # reads across the origin exist in this sample (expected ~18)
+
+
+@pytest.mark.parametrize("mode", ["genome", "metagenome", "transcriptome"])
+def test_two_context_schedule_writes_the_files_of_the_serial_one(tmp_path, monkeypatch, mode):
+    """the CLI runs the unaligned worker calls on a background engine context NEXT TO the aligned ones (the schedule
+    bench.py times); the phase order of S:1588-1672 constrains the FILE CONTENT only — the files equal those of NS_SERIAL=1 (one
+    context, aligned then unaligned), byte for byte, over several batches per phase."""
+    monkeypatch.setattr(simulator, "BATCH_READS", 700)
+    prefix = os.path.join(GOLDEN, "model_small", "training")
+    if mode == "genome":
+        argv = ["genome", "-rg", os.path.join(GOLDEN, "genome_small.fa"), "-c", prefix, "-n", "3000", "--seed", "8", "--chimeric", "--fastq", "-hp", "-k", "5"]
+    elif mode == "metagenome":
+        meta = os.path.join(GOLDEN, "meta")
+        argv = ["metagenome", "-gl", os.path.join(meta, "genome_list.tsv"), "-a", os.path.join(meta, "abundance.tsv"),
+                "-dl", os.path.join(meta, "dna_type_list.tsv"), "-c", prefix, "--seed", "8", "--chimeric"]
+    else:
+        trx = os.path.join(GOLDEN, "trx")
+        argv = ["transcriptome", "-rt", os.path.join(trx, "transcripts.fa"), "-rg", os.path.join(trx, "genome.fa"), "-e",
+                os.path.join(trx, "expression.tsv"), "-c", prefix, "-n", "2500", "--seed", "8", "--fastq"]
+    cwd = os.getcwd()
+    os.chdir(ROOT)                               # (the metagenome genome list holds paths relative to the repo root)
+    try:
+        simulator.main(argv + ["-o", str(tmp_path / "two" / "sim")])
+        monkeypatch.setenv("NS_SERIAL", "1")
+        simulator.main(argv + ["-o", str(tmp_path / "one" / "sim")])
+    finally:
+        os.chdir(cwd)
+    names = sorted(os.listdir(tmp_path / "one"))
+    assert names == sorted(os.listdir(tmp_path / "two")) and len(names) >= 3
+    for f in names:
+        a, b = open(tmp_path / "one" / f, "rb").read(), open(tmp_path / "two" / f, "rb").read()
+        assert a == b and (len(a) > 0 or "unaligned" in f), f
+
+
+def _bench_line(args, env_extra=None, timeout=900):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("WORLD_SIZE", None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.split("\n") if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_launches_its_own_ranks_on_one_gpu():
+    """`bench.py --gpus N` WITHOUT torchrun starts N ranks itself; here 2 ranks on the one GPU of the box over gloo"""
+    d = _bench_line(["--gpus", "2", "--dist-backend", "gloo", "--steps", "2", "--warmup", "1", "--reads", "100000"], {"NS_BENCH_DEVICE": "0"})
+    assert d["n_gpus"] == 2 and d["multi_gpu"]["world_size"] == 2 and d["multi_gpu"]["collectives_in_timed_region"] == 0
+    assert len(d["multi_gpu"]["per_rank"]) == 2 and d["multi_gpu"]["reference_broadcast_ms"] > 0
+    assert d["value"] > 0 and d["scaling"] == "weak" and d["config"]["reads_per_step_per_gpu"] == 100000
+
+
+def test_bench_metagenome_and_extras_objects():
+    """configs[4] as a bench workload, and the `serial` / `errlog_on` objects of the default line (here at a reduced size)"""
+    d = _bench_line(["--metagenome", "--steps", "2", "--warmup", "1", "--reads", "200000", "--no-cpu-baseline", "--no-e2e"])
+    assert "zymo10_like" in d["config"]["workload"] and d["value"] > 0 and d["n_gpus"] == 1
+    assert d["serial"]["value"] > 0 and d["errlog_on"]["value"] > 0 and d["errlog_on"]["k_errlog_ms"] > 0
+    assert 0 < d["errlog_on"]["k_errlog_frac"] < 1 and d["errlog_on"]["errlog_bytes_per_read"] > 1000
+    r = d["roofline"]
+    assert r["frac_kernel_only_bytes"] < r["frac"] < 1

@@ -275,3 +275,187 @@ def test_trained_pickles_load_like_the_npz(tmp_path, monkeypatch):
     # --perfect reads the other aligned-length pickle (S:560-567)
     monkeypatch.setenv("NS_KDE_TOLERANT", "1")
     assert np.array_equal(M.load_model(b, perfect=True).kde[M.NS_KDE_ALIGNED][0], M.load_model(a, perfect=True).kde[M.NS_KDE_ALIGNED][0])
+
+
+# ---- the CLI's batch / sink / phase logic without a GPU: a stand-in engine with the methods _write_batches uses -------------------------
+class _FakeInfo:
+    def __init__(self, n, rec, err):
+        self.n_reads, self.record_bytes, self.errlog_bytes, self.ms_total = n, rec, err, 0.0
+
+
+class _FakeBatch:
+    def __init__(self, first, n, with_err):
+        self.rec = [b">read_%d\nACGT\n" % i for i in range(first, first + n)]
+        self.err = [b"read_%d\t0\tmis\t1\tA\tC\n" % i for i in range(first, first + n)] if with_err else []
+        self.info = _FakeInfo(n, sum(map(len, self.rec)), sum(map(len, self.err)))
+
+    def record_offsets(self, cuts):
+        ro = np.array([sum(map(len, self.rec[:c])) for c in cuts], dtype=np.uint64)
+        eo = np.array([sum(map(len, self.err[:c])) for c in cuts], dtype=np.uint64)
+        return ro, eo
+
+
+class _FakeSink:
+    def __init__(self, eng, fd):
+        self.eng, self.fd, self.closed = eng, fd, 0
+
+    def put(self, data):
+        os.write(self.fd, data)
+
+    def write(self, which, offset=0, nbytes=None):
+        b = self.eng.last
+        img = b"".join(b.rec if which == 0 else b.err)
+        os.write(self.fd, img[offset:] if nbytes is None else img[offset:offset + nbytes])
+
+    def drain(self):
+        return 0
+
+    def close(self):
+        self.closed += 1
+        assert self.closed == 1, "a sink was closed twice"
+        if self.eng.fail_close:
+            raise OSError(28, "No space left on device")
+
+
+class _FakeEngine:
+    def __init__(self, fail_close=False, fail_generate_at=None):
+        self.fail_close, self.fail_generate_at, self.sinks, self.calls = fail_close, fail_generate_at, [], 0
+
+    def generate(self, p):
+        self.calls += 1
+        if self.fail_generate_at is not None and self.calls >= self.fail_generate_at:
+            raise RuntimeError("device lost")
+        self.last = _FakeBatch(int(p.first_read), int(p.n_reads), bool(p.emit_errlog))
+        return self.last
+
+    def sink(self, fd):
+        s = _FakeSink(self, fd)
+        self.sinks.append(s)
+        return s
+
+    def io_counters(self):
+        return dict(bytes=0, d2h_gbs=None, wait_staging_s=0.0, write_s=0.0)
+
+
+_KW = dict(seed=1, kind=0, fastq=False, chimeric=False, min_len=50, max_len=1000, median_len=None, sd_len=None, want_errlog=True)
+
+
+@pytest.mark.parametrize("stripes", [1, 3])
+def test_write_batches_cuts_batches_and_sub_files_at_read_boundaries(tmp_path, monkeypatch, stripes):
+    monkeypatch.setattr(simulator, "BATCH_READS", 100)
+    eng = _FakeEngine()
+    out, err = str(tmp_path / "sim_aligned_reads.fasta"), str(tmp_path / "sim_aligned_error_profile")
+    simulator._write_batches(eng, out, err, first=7, count=333, err_header=simulator.ERR_HEADER, stripes=stripes, quiet=True, **_KW)
+    assert open(out, "rb").read() == b"".join(b">read_%d\nACGT\n" % i for i in range(7, 340))
+    assert open(err, "rb").read() == simulator.ERR_HEADER + b"".join(b"read_%d\t0\tmis\t1\tA\tC\n" % i for i in range(7, 340))
+    assert sorted(os.listdir(tmp_path)) == ["sim_aligned_error_profile", "sim_aligned_reads.fasta"]
+    assert all(s.closed == 1 for s in eng.sinks)
+
+
+def test_write_batches_closes_every_sink_once_when_a_close_fails(tmp_path, monkeypatch):
+    """a close() that raises (ENOSPC) must not leave the list behind for the error handler to close a second time"""
+    monkeypatch.setattr(simulator, "BATCH_READS", 50)
+    eng = _FakeEngine(fail_close=True)
+    with pytest.raises(OSError):
+        simulator._write_batches(eng, str(tmp_path / "a.fasta"), str(tmp_path / "a_err"), first=0, count=120, stripes=4, quiet=True, **_KW)
+    assert eng.sinks and all(s.closed == 1 for s in eng.sinks)        # (_FakeSink.close asserts on a second call)
+
+
+def test_cap_stripes():
+    assert simulator._cap_stripes(1, 2) == 1 and simulator._cap_stripes(16, 2) == 16
+    assert simulator._cap_stripes(100000, 2) <= 64
+    import resource
+    soft, hard = resource.getrlimit(resource.RLIMIT_NOFILE)
+    try:
+        resource.setrlimit(resource.RLIMIT_NOFILE, (128, hard))
+        assert 1 <= simulator._cap_stripes(64, 2) <= (128 - 64) // 8
+    finally:
+        resource.setrlimit(resource.RLIMIT_NOFILE, (soft, hard))
+
+
+def test_run_phases_runs_both_worker_calls_side_by_side_and_reports_failures(capsys):
+    import threading
+    both = threading.Barrier(2, timeout=20)
+    seen = []
+    simulator._run_phases(lambda: (both.wait(), seen.append("al")), lambda: (both.wait(), seen.append("un")), 0, 1000)
+    assert sorted(seen) == ["al", "un"]                   # the barrier only opens when the two calls overlap
+    lines = capsys.readouterr().out
+    assert "Start simulation of random reads" in lines and "Number of reads simulated >> 1000" in lines
+
+    def boom():
+        raise SystemExit(1)                               # e.g. shard.collect_parts of the unaligned file on rank 0
+    with pytest.raises(SystemExit):
+        simulator._run_phases(lambda: None, boom, 0, 10)
+    done = []
+    with pytest.raises(RuntimeError):                     # the aligned call fails: the background call is still joined
+        simulator._run_phases(lambda: (_ for _ in ()).throw(RuntimeError("x")), lambda: done.append(1), 1, 10)
+    assert done == [1]
+    simulator._run_phases(lambda: done.append(2), None, 0, 10)       # --perfect: no second phase
+    assert done == [1, 2]
+
+
+def test_failure_markers_cover_every_output_of_a_rank(tmp_path):
+    """a rank > 0 that dies OUTSIDE _write_batches (engine, model, a later file) leaves a marker for every output"""
+    outs = [str(tmp_path / "sim_aligned_reads.fasta"), str(tmp_path / "sim_unaligned_reads.fasta")]
+    with pytest.raises(RuntimeError):
+        with shard.failure_markers(outs, 2, 4):
+            raise RuntimeError("ns_load_model failed")
+    assert sorted(os.listdir(tmp_path)) == ["sim_aligned_reads.fasta.part2.failed", "sim_unaligned_reads.fasta.part2.failed"]
+    assert "ns_load_model failed" in open(outs[0] + ".part2.failed").read()
+    for q in os.listdir(tmp_path):
+        os.unlink(tmp_path / q)
+    with pytest.raises(RuntimeError):
+        with shard.failure_markers(outs, 0, 4):           # rank 0 has nobody to tell
+            raise RuntimeError("x")
+    with shard.failure_markers(outs, 1, 4):
+        pass
+    with pytest.raises(SystemExit):
+        with shard.failure_markers(outs, 1, 4):
+            sys.exit(0)
+    assert os.listdir(tmp_path) == []
+
+
+def test_publish_header_takes_the_same_transport_on_every_rank(monkeypatch):
+    """the fallback (object broadcast) is chosen by what the torch build offers, never by an error of one rank's get/set"""
+    class Store:
+        def __init__(self): self.kv = {}
+        def set(self, k, v): self.kv[k] = v
+        def get(self, k): raise TimeoutError("store timeout")
+
+    class Dist:
+        def __init__(self, rank): self.rank, self.bcast = rank, 0
+        def get_rank(self): return self.rank
+        def broadcast_object_list(self, box, src=0): self.bcast += 1
+    st = Store()
+    monkeypatch.setattr(shard, "_default_store", lambda: st)
+    d0, d1 = Dist(0), Dist(1)
+    assert shard._publish_header(d0, "k", b"hdr") == b"hdr" and st.kv["k"] == b"hdr"
+    with pytest.raises(TimeoutError):                     # rank 1's failed get propagates: no lone fallback into a collective
+        shard._publish_header(d1, "k", None)
+    assert d0.bcast == 0 and d1.bcast == 0
+    monkeypatch.setattr(shard, "_default_store", lambda: None)
+    shard._publish_header(d0, "k", b"hdr"); shard._publish_header(d1, "k", None)
+    assert d0.bcast == 1 and d1.bcast == 1
+
+
+def test_bench_gpus_n_launches_its_own_ranks(monkeypatch):
+    """`bench.py --gpus N` without a launcher starts N ranks under torch.distributed.run on 127.0.0.1"""
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setenv("NS_BENCH_DEVICE", "0")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--dist-backend", "gloo", "--steps", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
+    assert cmd[-6:] == ["--gpus", "2", "--dist-backend", "gloo", "--steps", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -1,6 +1,6 @@
-"""Transcriptome mode (without intron retention): host loader and the oracle's transcript pick / conditional
-2-D KDE / polyA restatements pinned against the reference (tests/golden/reference_transcriptome.json: values of make_cdf,
-random.choices and extract_read_trx, and 2 x 16 000 reads of simulation_aligned_transcriptome)."""
+"""Transcriptome mode (without intron retention): host loader and the oracle's transcript pick / 2-D KDE sample
+kept until a transcript repeats / polyA restatements pinned against the reference (tests/golden/reference_transcriptome.json: values of
+make_cdf, random.choices and extract_read_trx, and 2 x 96 000 reads of simulation_aligned_transcriptome)."""
 import json
 import os
 
@@ -76,12 +76,11 @@ def test_oracle_transcriptome_batches_match_reference_runs(fx, trx_ref, name):
     out = O.generate_trx(mdl, trx_ref, p)
     rd, pc, pa = out["reads"], out["pieces"], out["polya"].astype(np.int64)
     tl, mid = lens[pc["chrom"]].astype(np.float64), pc["ref_len"].astype(np.float64)
-    # two samples of 96 000 reads.  Start, head, tail + polyA and the aligned fraction sit inside the 1 % gate; the aligned length and the
-    # read length carry the documented deviation (the share of the dominant transcript is 1.7 points lower in the
-    # reference, which keeps its 2-D KDE sample until a transcript repeats) and land at 0.009-0.012
-    tol = 0.015
-    assert ks_vs_quantiles(mid / tl, run["q_frac"]) <= 0.01 and ks_vs_quantiles(pc["pos"] / np.maximum(1, tl - mid), run["q_start_frac"]) <= 0.01
-    assert ks_vs_quantiles(rd["tail"] + pa, run["q_tailp"]) <= 0.01 and ks_vs_quantiles(rd["head"], run["q_head"]) <= 0.01
+    # 96 000 reads against 8 reference workers x 12 000.  Every distribution sits inside the 1 % gate of the north star since the
+    # oracle restates S:1080-1104 as it is — ONE 2-D KDE sample kept until a transcript repeats (trx_sampled), per block of 1 024 read
+    # indices (oracle/ns_oracle.c: trx_block).  (Until round 3 every attempt drew from the conditional KDE on its
+    # own: aligned length at KS 0.009-0.012, the dominant transcript's share 1.7 points off.)
+    tol = 0.01
     assert ks_vs_quantiles(mid, run["q_mid"]) < tol and ks_vs_quantiles(mid / tl, run["q_frac"]) < tol
     assert ks_vs_quantiles(pc["pos"] / np.maximum(1, tl - mid), run["q_start_frac"]) < tol
     assert ks_vs_quantiles(rd["tail"] + pa, run["q_tailp"]) < tol and ks_vs_quantiles(rd["head"], run["q_head"]) < tol
@@ -95,13 +94,12 @@ def test_oracle_transcriptome_batches_match_reference_runs(fx, trx_ref, name):
         assert np.all(rd["head"] == 0) and np.all(rd["tail"] == 0) and np.all(pc["n_ev"] == 0)
         recs = out["records"].tobytes().split(b"\n")
         assert not any(b"T" in s for s in recs[1:400:2]) and any(b"U" in s for s in recs[1:400:2]) and run["has_u"] and not run["has_t"]
-    # expression-weighted pick: every transcript's share within 1 % of the batch, except the one that holds 47 % of the expression —
-    # the reference keeps one 2-D KDE sample until a transcript repeats, so a transcript whose draw failed keeps failing for a few
-    # reads; its share is 3-4 % (relative) lower there
+    # expression-weighted pick (S:1084) under the sample-until-repeat rule: every transcript's share within 1 % of the batch — also the one
+    # that holds 47 % of the expression (measured: 0.1-0.2 %)
     cnt = np.bincount(pc["chrom"], minlength=len(lens))
     for k, v in run["counts"].items():
         c = int(cnt[trx_ref.ref.names.index(k)])
-        assert abs(c - v) < (0.02 if v > 0.3 * run["n"] else 0.01) * run["n"], (k, v, c)
+        assert abs(c - v) < 0.01 * run["n"], (k, v, c)
     # names: <transcript>_<start>_aligned|perfect_<index>_<F|R>_<head>_<middle_ref>_<tail + polyA>
     first = out["records"].tobytes().split(b"\n")[0][1:].decode()
     body, _, rest = first.partition("_perfect_" if perfect else "_aligned_")
@@ -125,3 +123,22 @@ def test_oracle_unaligned_transcriptome_reads(trx_ref):
     share = np.bincount(pc["chrom"][short], minlength=len(lens)) / max(1, short.sum())
     assert short.sum() >= 50 and share.max() < 0.06 and (share > 0).sum() > 0.3 * min(len(lens), short.sum())
     assert out["records"].tobytes().split(b"\n")[0].decode().split("_unaligned_")[1].startswith("0_")
+
+
+def test_oracle_transcriptome_reads_do_not_depend_on_the_batch(trx_ref):
+    """The sample-until-repeat rule couples the reads of one BLOCK of 1 024 read indices, not of a batch: a batch that starts inside a
+    block walks the block from its start (dry runs), so any split of the run gives the same reads."""
+    from tests import oracle_lib as O
+    mdl = M.load_model(os.path.join(ROOT, "tests", "golden", "model_small", "training"), transcriptome=True, fastq=True)
+    kw = dict(seed=77, max_len=10 ** 9, trx=True, fastq=True, emit_errlog=True)
+    whole = O.generate_trx(mdl, trx_ref, E.make_params(first_read=0, n_reads=3000, **kw))
+    recs, errs = [], []
+    for lo, hi in ((0, 700), (700, 1024), (1024, 2500), (2500, 3000)):
+        part = O.generate_trx(mdl, trx_ref, E.make_params(first_read=lo, n_reads=hi - lo, **kw))
+        recs.append(part["records"].tobytes()); errs.append(part["errlog"].tobytes())
+    assert b"".join(recs) == whole["records"].tobytes() and b"".join(errs) == whole["errlog"].tobytes()
+    # inside a sample a transcript is used once: the dominant transcript (47 % of the expression) never fills two neighbouring reads
+    # from one sample, yet still holds its share
+    names = [ln.split(b"_")[0] for ln in whole["records"].tobytes().split(b"\n")[0::4] if ln]
+    top = max(set(names), key=names.count)
+    assert 0.40 < names.count(top) / len(names) < 0.50
