@@ -104,6 +104,15 @@ struct GenArgs {
     ns_read *f_reads; ns_piece *f_pieces; uint16_t *f_name_len; uint64_t *f_rec_len, *f_err_len;   // final (accepted) arrays
     double *draw_x; uint64_t draw_n;
     unsigned long long *species_bases;
+    // keys and numbers: read r of a batch draws with the key (seed, key_first + r) and is called name_first + r.  Both are
+    // prm.first_read, except in the candidate table of a transcriptome batch (below), whose keys count from the batch's first BLOCK
+    uint64_t key_first, name_first;
+    // transcriptome, aligned / --perfect batches (S:1080-1104 per block of NS_TRX_BLOCK read indices; k_trx_walk): the candidate table —
+    // position i = candidate i % trx_C of block i / trx_C of the batch; 0: no table
+    uint32_t trx_C, trx_M;
+    const uint32_t *trx_cand;        // [position] pick that became the candidate, 0xffffffff: none
+    const uint32_t *trx_pick_e;      // [block * trx_M + pick] transcript (index of the expression view)
+    const int32_t *trx_pick_y;       //                        its aligned length under a fresh sample, -1: fails S:1103-1104
     // results
     ns_read *reads;
     ns_piece *pieces;
@@ -116,14 +125,20 @@ struct GenArgs {
                                 // [5] reads that failed the final length check of -k [6] reads queued for the next pass [7] -k event capacity overflow
 };
 
-__device__ __forceinline__ ns_key make_key(const ns_params &prm, uint64_t r) {
-    uint64_t g = prm.first_read + r;
-    return ns_key{(uint32_t)prm.seed, (uint32_t)(prm.seed >> 32), (uint32_t)g, (uint32_t)(g >> 32)};
+__device__ __forceinline__ ns_key make_key(const GenArgs &A, uint64_t r) {
+    uint64_t g = A.key_first + r;
+    return ns_key{(uint32_t)A.prm.seed, (uint32_t)(A.prm.seed >> 32), (uint32_t)g, (uint32_t)(g >> 32)};
 }
-// key of FINAL read r: in metagenome batches the draws of a read are keyed by its position inside the pass that accepted it
-__device__ __forceinline__ ns_key read_key(const GenArgs &A, uint64_t r);
-
-__device__ __forceinline__ ns_key read_key(const GenArgs &A, uint64_t r) { return make_key(A.prm, A.key_pos ? (uint64_t)A.key_pos[r] : r); }
+// key of FINAL read r: in metagenome batches the draws of a read are keyed by its position inside the pass that accepted it, in
+// transcriptome batches by its candidate (k_trx_commit)
+__device__ __forceinline__ ns_key read_key(const GenArgs &A, uint64_t r) { return make_key(A, A.key_pos ? (uint64_t)A.key_pos[r] : r); }
+// candidate table of a transcriptome batch: position -> key index (relative to key_first = the first read of the batch's first
+// block) and attempt: candidate c of a block draws with the key of read (block start + c mod W), attempt c / W
+__device__ __forceinline__ uint64_t trx_key_rel(const GenArgs &A, uint64_t pos) {
+    const uint64_t blk = pos / A.trx_C, c = pos % A.trx_C;
+    return blk * NS_TRX_BLOCK + c % NS_TRX_BLOCK;
+}
+__device__ __forceinline__ uint32_t trx_attempt(const GenArgs &A, uint64_t pos) { return (uint32_t)((pos % A.trx_C) / NS_TRX_BLOCK); }
 
 // Segments of a read (S:1276-1277).  The reference draws num_segment once per worker and hands the counts out by POSITION among the reads
 // still missing (remaining_segments = num_segment[passed:], S:1447), so a count that no draw of lengths can satisfy is not retried for
@@ -143,7 +158,7 @@ __global__ void __launch_bounds__(256) k_nseg(GenArgs A) {
     if (r > A.prm.n_reads) return;
     if (A.ir_need) A.ir_need[r] = 0;
     if (r == A.prm.n_reads) { A.n_pieces[r] = 0; A.ev_cap[r] = 0; A.rec_len[r] = 0; A.err_len[r] = 0; return; }
-    A.n_pieces[r] = 2 * read_nseg(A, make_key(A.prm, r), (A.keep_state && !A.meta) ? A.rstate[r] & 0xffffu : 0u) - 1;
+    A.n_pieces[r] = 2 * read_nseg(A, make_key(A, r), (A.keep_state && !A.meta) ? A.rstate[r] & 0xffffu : 0u) - 1;
     if (!A.keep_state) { A.rstate[r] = 0; A.att_base[r] = 0; }
 }
 
@@ -154,7 +169,7 @@ __global__ void __launch_bounds__(256) k_replan(GenArgs A, uint32_t *need) {
     if (tid > A.list_n) return;
     if (tid == A.list_n) { need[tid] = 0; return; }
     const uint64_t r = A.list[tid];
-    const uint32_t np = 2 * read_nseg(A, make_key(A.prm, r), A.rstate[r] & 0xffffu) - 1;
+    const uint32_t np = 2 * read_nseg(A, make_key(A, r), A.rstate[r] & 0xffffu) - 1;
     need[tid] = np != A.reads[r].n_pieces ? np : 0u;
 }
 
@@ -170,12 +185,14 @@ __global__ void __launch_bounds__(256) k_lengths(GenArgs A) {
     const uint64_t r = A.list ? A.list[tid] : tid;
     const ns_params &prm = A.prm;
     const int kind = (int)prm.kind;
-    const ns_key key = make_key(prm, r);
     const bool meta_al = A.meta && kind != NS_KIND_UNALIGNED;    // r is then the position of the read inside pass A.attempt
-    const uint32_t a = meta_al ? A.attempt : A.att_base[r] + A.attempt;
-    const uint32_t epoch = meta_al ? 0u : A.rstate[r] & 0xffffu;
+    const bool trx_tab = A.trx_C != 0;                           // r is a position of the candidate table
+    const ns_key key = make_key(A, trx_tab ? trx_key_rel(A, r) : r);
+    const uint32_t a = meta_al ? A.attempt : trx_tab ? trx_attempt(A, r) : A.att_base[r] + A.attempt;
+    const uint32_t epoch = (meta_al || trx_tab) ? 0u : A.rstate[r] & 0xffffu;
     uint32_t piece_off, n_pieces;
-    if (A.attempt == 0 || meta_al) { piece_off = A.piece_off[r]; n_pieces = A.piece_off[r + 1] - piece_off; }
+    if (trx_tab) { piece_off = (uint32_t)r; n_pieces = 1; }
+    else if (A.attempt == 0 || meta_al) { piece_off = A.piece_off[r]; n_pieces = A.piece_off[r + 1] - piece_off; }
     else {                                           // a later pass: the read's slots, unless k_replan gave it new ones
         piece_off = A.reads[r].piece_off; n_pieces = A.reads[r].n_pieces;
         if (A.p_need && A.p_need[tid]) { n_pieces = A.p_need[tid]; piece_off = A.p_base + A.p_off[tid]; }
@@ -187,12 +204,14 @@ __global__ void __launch_bounds__(256) k_lengths(GenArgs A) {
         const bool is_gap = (kind == NS_KIND_UNALIGNED) || (pi & 1);
         int64_t mlen = 0;
         uint32_t plan_chrom = 0;
-        if (prm.trx && kind != NS_KIND_UNALIGNED) {                                     // S:1082-1105: transcript by expression, aligned
-            const u32x4 wt = ns_draw(key, ST_TRX, 0, a, 0, 0);                          // length from the 2-D KDE given its length
-            plan_chrom = A.tx.expr_chrom[trx_pick(A.tx, u53_to_p(wt.x, wt.y))];
-            const int64_t tl = (int64_t)(A.ref.chrom_off[plan_chrom + 1] - A.ref.chrom_off[plan_chrom]);
-            mlen = kde2d_cond(A.m, (double)tl, key, a);
-            if (!(mlen > 0 && mlen < tl)) { ok = false; mlen = 0; }                     // S:1103-1104
+        if (prm.trx && kind != NS_KIND_UNALIGNED) {                                     // S:1082-1105: transcript and aligned length of
+            const uint32_t pk = A.trx_cand[r];                                          // the candidate, planned by k_trx_walk
+            if (pk == 0xffffffffu) ok = false;
+            else {
+                const uint64_t pi2 = (r / A.trx_C) * (uint64_t)A.trx_M + pk;
+                plan_chrom = A.tx.expr_chrom[A.trx_pick_e[pi2]];
+                mlen = A.trx_pick_y[pi2];
+            }
         } else
         if (kind == NS_KIND_UNALIGNED) mlen = unaligned_length(A.m, prm, key, a);       // S:1494-1495
         else if (is_gap) mlen = gap_length(A.m, key, pi >> 1, A.meta ? a : epoch);     // S:1298-1299 (S:872: once per pass)
@@ -210,10 +229,10 @@ __global__ void __launch_bounds__(256) k_lengths(GenArgs A) {
     }
     int32_t remainder = 0; double ratio = 0;
     if (prm.trx && kind == NS_KIND_ALIGNED) {                                          // S:1073-1076, 1203-1204: one draw per read, no filter
-        const double x = ns_pow10m1(kde_sample(A.m.kde[NS_KDE_HT], ns_draw(key, ST_HT, 0, 0, 0, 0)));
+        const double x = ns_pow10m1(kde_sample(A.m.kde[NS_KDE_HT], ns_draw(key, ST_HT, 0, a, 0, 0)));
         const int64_t r64 = (int64_t)x;
         remainder = r64 < 0 ? 0 : r64 > 0x3fffffff ? 0x3fffffff : (int32_t)r64;
-        ratio = kde_sample(A.m.kde[NS_KDE_RATIO], ns_draw(key, ST_RATIO, 0, 0, 0, 0));
+        ratio = kde_sample(A.m.kde[NS_KDE_RATIO], ns_draw(key, ST_RATIO, 0, a, 0, 0));
         if (ratio > 1) ratio = 1;
         if (ratio < 0) ratio = 0;
     } else
@@ -245,8 +264,8 @@ __global__ void __launch_bounds__(256) k_lengths(GenArgs A) {
     rd.seq_len = 0; rd.attempts = a;
     A.reads[r] = rd;
     cap = (cap + 3ull) & ~3ull;                  // whole 32-byte groups of events: k_chain flushes its staged events four at a time
-    if (A.attempt > 0 && !meta_al) A.l_cap[tid] = cap;
-    if (A.attempt == 0 || meta_al) {
+    if (A.attempt > 0 && !meta_al && !trx_tab) A.l_cap[tid] = cap;
+    if (A.attempt == 0 || meta_al || trx_tab) {
         A.ev_cap[r] = cap;
         A.sort_key[r] = work > 0xffffffffull ? 0xffffffffu : (uint32_t)work;
         A.sort_idx[r] = (uint32_t)r;
@@ -300,10 +319,10 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK, COOP ? 4 : NS_CHAI
     if (tid < A.list_n) {
         const uint64_t r = A.list ? A.list[tid] : A.list_base + tid;
         const int kind = (int)prm.kind;
-        const bool meta_al = A.meta && kind != NS_KIND_UNALIGNED;
-        const bool trx_al = prm.trx && kind != NS_KIND_UNALIGNED;
-        const ns_key key = make_key(prm, r);
-        const uint32_t a = meta_al ? A.attempt : A.att_base[r] + A.attempt;
+        const bool trx_al = prm.trx && kind != NS_KIND_UNALIGNED;       // r is then a position of the candidate table (one try each)
+        const bool meta_al = (A.meta && kind != NS_KIND_UNALIGNED) || trx_al;      // ... or of a metagenome pass
+        const ns_key key = make_key(A, trx_al ? trx_key_rel(A, r) : r);
+        const uint32_t a = trx_al ? trx_attempt(A, r) : meta_al ? A.attempt : A.att_base[r] + A.attempt;
         ns_read rd = A.reads[r];
         const uint32_t n_pieces = rd.n_pieces;
         ns_piece *pc = A.pieces + rd.piece_off;
@@ -354,7 +373,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK, COOP ? 4 : NS_CHAI
                 trx_len = (int64_t)(A.ref.chrom_off[trx_chrom + 1] - A.ref.chrom_off[trx_chrom]);
                 if ((int64_t)pc[0].ref_len > trx_len) break;
             } else
-            if (meta_al) {                                   // S:907-946: remainder + middle_ref of the segments, then the gaps
+            if (meta_al && !trx_al) {                        // S:907-946: remainder + middle_ref of the segments, then the gaps
                 int64_t tot = (int64_t)rd.head + rd.tail; bool restart = false;
                 for (uint32_t pi = 0; pi < n_pieces && !restart; pi += 2) { if (tot + pc[pi].ref_len > prm.max_len) restart = true; else tot += pc[pi].ref_len; }
                 for (uint32_t pi = 1; pi < n_pieces && !restart; pi += 2) { if (tot + pc[pi].out_len > prm.max_len) restart = true; else tot += pc[pi].out_len; }
@@ -432,7 +451,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK, COOP ? 4 : NS_CHAI
                 nl += (A.ref.name_off[p.chrom + 1] - A.ref.name_off[p.chrom] - 1) + 1 + dec_digits(p.pos) + dec_digits(p.ref_len);
             }
             // metagenome: the number of the read is only known once the accepted reads of the pass are counted (k_meta_commit)
-            nl += (kind == NS_KIND_UNALIGNED ? 11u : 9u) + (meta_al ? 0u : dec_digits(prm.first_read + r)) + ir_name;
+            nl += (kind == NS_KIND_UNALIGNED ? 11u : 9u) + (meta_al ? 0u : dec_digits(A.name_first + r)) + ir_name;
             if (kind == NS_KIND_ALIGNED && n_pieces > 1) nl += 9;
             nl += 2 /*_F*/ + 1 + dec_digits(rd.head) + 1 + 1 + dec_digits(rd.tail + polya);       // S:1211-1213: tail + polya_len
             uint64_t err_len = 0;
@@ -455,6 +474,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK, COOP ? 4 : NS_CHAI
                 if (A.ir_need) A.ir_need[r] = spliced ? ir_slot_bytes(pc[0].ref_len) : 0;
                 if (meta_al) { A.accept[r] = 1ull | (uint64_t)n_pieces << 32; A.sort_key[r] = evn; }   // (event count: taken back if -k rejects the read)
                 st_bases = A.hp ? 0ull : (unsigned long long)seq_len; st_ref = ref_bases; st_ev = evn; st_max = (uint32_t)seq_len;
+                if (trx_al) st_bases = st_ref = st_ev = 0;       // (a candidate is not a read yet: k_trx_commit counts those it takes)
             }
             accepted = true;
         } while (false);
@@ -487,7 +507,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK, COOP ? 4 : NS_CHAI
 __global__ void __launch_bounds__(256) k_meta_draw(GenArgs A) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= A.draw_n) return;
-    const ns_key key = make_key(A.prm, 0);
+    const ns_key key = make_key(A, 0);
     const uint32_t jl = (uint32_t)j, jh = (uint32_t)(j >> 32) << 1;          // sub = 2 * high part (+ 1 for the second block of a draw)
     const u32x4 w = ns_draw(key, ST_REFLEN, 0, A.attempt, jl, jh);
     double x;
@@ -506,7 +526,7 @@ __global__ void __launch_bounds__(256) k_meta_draw(GenArgs A) {
 __global__ void __launch_bounds__(256) k_meta_words(GenArgs A, uint2 *out, uint64_t n) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    const u32x4 w = ns_draw(make_key(A.prm, 0), ST_SPECIES, 0, A.attempt, (uint32_t)j, (uint32_t)(j >> 32));
+    const u32x4 w = ns_draw(make_key(A, 0), ST_SPECIES, 0, A.attempt, (uint32_t)j, (uint32_t)(j >> 32));
     out[j] = make_uint2(w.x, w.y);
 }
 // int(round(length)) of the assigned lengths (S:871), on the device copy of the sorted list
@@ -565,10 +585,115 @@ __global__ void __launch_bounds__(256) k_meta_commit(GenArgs A) {
     rd.piece_off = poff;
     A.f_reads[slot] = rd;
     A.key_pos_w[slot] = (uint32_t)i;
-    const uint32_t dg = dec_digits(A.prm.first_read + slot);
+    const uint32_t dg = dec_digits(A.name_first + slot);
     A.f_name_len[slot] = (uint16_t)(A.name_len[i] + dg);
     A.f_rec_len[slot] = A.prm.emit_records ? A.rec_len[i] + dg : 0;
     A.f_err_len[slot] = A.prm.emit_errlog ? A.err_len[i] + rows * dg : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// transcriptome, aligned / --perfect batches: which transcript, which aligned length (S:1080-1104)
+// The reference worker keeps ONE sample of the 2-D KDE until a transcript it has used is picked again (trx_sampled, S:1087-1092); inside
+// a sample a transcript always gets the same aligned length (the nearest point, S:108-111), so one whose length failed S:1103-1104 keeps
+// failing until some other transcript repeats.  Restated per BLOCK of NS_TRX_BLOCK read indices (whatever batch or rank generates
+// them) as a walk over the block's own sequence of picks — the oracle's trx_block:
+//   k_trx_picks   pick j of a block: transcript by expression (random.choices, S:1084) and the aligned length it gets under a FRESH
+//                 sample (a draw from the KDE conditioned on the transcript length: kde2d_cond) — thread per pick
+//   (radix sort)  by (block, transcript, pick): the previous pick of the same transcript
+//   k_trx_walk    the sequential part, one wavefront per block: pick j is inside the current sample if its transcript was picked since
+//                 the sample started; it starts a new sample if that earlier pick succeeded, fails like it if it failed, and is
+//                 evaluated with its own draw otherwise; a successful pick is the block's next CANDIDATE
+//   k_lengths / k_chain over the candidate table (one try per candidate, key = (block start + c mod W, attempt c / W))
+//   k_trx_commit  the reads of a block = its first NS_TRX_BLOCK surviving candidates; those of the batch move to their slots
+// ---------------------------------------------------------------------------------------------------------
+#define NS_TRX_PICK_BITS 20u       // picks per block (< 2^20) and transcripts (< 2^22) in the sort key: block[21] | transcript[22] | pick[20]
+__global__ void __launch_bounds__(256) k_trx_picks(GenArgs A, uint64_t n_picks, uint32_t M, uint64_t block0, uint32_t *__restrict__ pick_e,
+                                                   int32_t *__restrict__ pick_y, uint64_t *__restrict__ keys) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_picks) return;
+    const uint64_t blk = i / M; const uint32_t j = (uint32_t)(i % M);
+    const uint64_t g = (block0 + blk) * NS_TRX_BLOCK;
+    const ns_key key{(uint32_t)A.prm.seed, (uint32_t)(A.prm.seed >> 32), (uint32_t)g, (uint32_t)(g >> 32)};
+    const u32x4 w = ns_draw(key, ST_TRX, 0, 0, j, 2);
+    const uint32_t e = trx_pick(A.tx, u53_to_p(w.x, w.y));                                // S:1084
+    const uint32_t chrom = A.tx.expr_chrom[e];
+    const int64_t L = (int64_t)(A.ref.chrom_off[chrom + 1] - A.ref.chrom_off[chrom]);
+    const int64_t y = kde2d_cond(A.m, (double)L, key, 0, 1u + j);                          // S:1098-1102
+    pick_e[i] = e;
+    pick_y[i] = (y > 0 && y < L) ? (int32_t)y : -1;                                        // S:1103-1104
+    keys[i] = blk << (22u + NS_TRX_PICK_BITS) | (uint64_t)e << NS_TRX_PICK_BITS | j;
+}
+// sorted keys -> the previous pick of the same transcript in the same block (-1: none)
+__global__ void __launch_bounds__(256) k_trx_prev(const uint64_t *__restrict__ keys, uint64_t n_picks, uint32_t M, int32_t *__restrict__ prev) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_picks) return;
+    const uint64_t k = keys[i], blk = k >> (22u + NS_TRX_PICK_BITS);
+    const uint32_t j = (uint32_t)k & ((1u << NS_TRX_PICK_BITS) - 1u);
+    int32_t p = -1;
+    if (i) { const uint64_t q = keys[i - 1]; if ((q >> NS_TRX_PICK_BITS) == (k >> NS_TRX_PICK_BITS)) p = (int32_t)((uint32_t)q & ((1u << NS_TRX_PICK_BITS) - 1u)); }
+    prev[blk * M + j] = p;
+}
+// the walk: one wavefront per block; the state is the first pick of the current sample and, per pick, whether its transcript's length
+// holds under the sample it belongs to (ok[], one byte per pick in LDS); 64 picks are fetched at a time and handed over by readlane
+__global__ void __launch_bounds__(64) k_trx_walk(uint32_t M, uint32_t C, const int32_t *__restrict__ prev, const int32_t *__restrict__ pick_y,
+                                                 uint32_t *__restrict__ cand, unsigned long long *__restrict__ n_short) {
+    extern __shared__ uint8_t ok_lds[];
+    volatile uint8_t *ok = ok_lds;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t blk = blockIdx.x;
+    const int32_t *pv = prev + blk * M, *py = pick_y + blk * M;
+    uint32_t *out = cand + blk * C;
+    uint32_t c = 0;
+    int32_t start = 0;                                     // first pick of the current sample
+    for (uint32_t j0 = 0; j0 < M && c < C; j0 += 64) {
+        const int32_t p_l = j0 + lane < M ? pv[j0 + lane] : -1, y_l = j0 + lane < M ? py[j0 + lane] : -1;
+        const uint32_t kn = min(64u, M - j0);
+        for (uint32_t k = 0; k < kn && c < C; ++k) {
+            const int32_t p = __builtin_amdgcn_readlane(p_l, (int)k), y = __builtin_amdgcn_readlane(y_l, (int)k);
+            const int32_t j = (int32_t)(j0 + k);
+            bool inside = p >= start;                      // the transcript was picked before under this sample
+            if (inside && ok[p]) { start = j; inside = false; }        // ... and used: a new sample starts with this pick (S:1087-1092)
+            const bool good = !inside && y >= 0;           // (inside: it failed before, the same nearest point fails again)
+            if (lane == 0) ok[j] = good ? 1 : 0;
+            if (good) { if (lane == 0) out[c] = (uint32_t)j; ++c; }
+            wave_sync();
+        }
+    }
+    for (uint32_t q = c + lane; q < C; q += 64) out[q] = 0xffffffffu;
+    if (lane == 0 && c < C) atomicAdd(n_short, 1ull);      // the picks ran out before the table was full: the host asks for more picks
+}
+// the candidates that survived (k_chain: accept) -> the reads of their blocks, those of the batch [g0, g0 + n) -> their final slots
+__global__ void __launch_bounds__(256) k_trx_commit(GenArgs A, uint64_t n_pos, uint64_t block0, uint64_t g0, uint64_t n, uint16_t *__restrict__ polya_out,
+                                                    uint64_t *__restrict__ ir_need_out, unsigned long long *__restrict__ n_short) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long st_bases = 0, st_ref = 0, st_ev = 0;
+    if (i < n_pos) {
+        const uint64_t blk = i / A.trx_C, c = i % A.trx_C;
+        const uint64_t acc = A.accept[i] & 1ull, before = (A.accept_scan[i] & 0xffffffffull) - (A.accept_scan[blk * A.trx_C] & 0xffffffffull);
+        const uint64_t gb = (block0 + blk) * NS_TRX_BLOCK, g = gb + before;
+        if (acc && before < NS_TRX_BLOCK && g >= g0 && g < g0 + n) {
+            const uint64_t slot = g - g0;
+            ns_read rd = A.reads[i];
+            ns_piece p = A.pieces[rd.piece_off];
+            rd.piece_off = (uint32_t)slot;
+            A.f_reads[slot] = rd; A.f_pieces[slot] = p;
+            A.key_pos_w[slot] = (uint32_t)(blk * NS_TRX_BLOCK + c % NS_TRX_BLOCK);
+            const uint32_t dg = dec_digits(A.name_first + slot);
+            A.f_name_len[slot] = (uint16_t)(A.name_len[i] + dg);
+            A.f_rec_len[slot] = A.prm.emit_records ? A.rec_len[i] + dg : 0;
+            A.f_err_len[slot] = 0;                              // (k_errlen / k_hp_filter_w size the rows of the final reads)
+            if (polya_out) polya_out[slot] = A.polya[i];
+            if (ir_need_out) ir_need_out[slot] = A.ir_need[i];
+            st_bases = A.hp ? 0ull : rd.seq_len; st_ref = p.ref_len; st_ev = p.n_ev;
+        }
+        if (c == A.trx_C - 1u) {                                // the block's census: enough survivors for the reads the batch needs of it?
+            const uint64_t total = before + acc, end = g0 + n;
+            const uint64_t need = gb >= end ? 0ull : min((uint64_t)NS_TRX_BLOCK, end - gb);
+            if (total < need) atomicAdd(n_short, 1ull);
+        }
+    }
+    st_bases = wave_sum(st_bases); st_ref = wave_sum(st_ref); st_ev = wave_sum(st_ev);
+    if ((threadIdx.x & 63) == 0 && (st_bases | st_ref | st_ev)) { atomicAdd(&A.stats[1], st_bases); atomicAdd(&A.stats[2], st_ref); atomicAdd(&A.stats[3], st_ev); }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -600,7 +725,7 @@ __global__ void __launch_bounds__(256) k_names(GenArgs A) {
     }
     const char *tag = kind == NS_KIND_ALIGNED ? "_aligned_" : kind == NS_KIND_PERFECT ? "_perfect_" : "_unaligned_";
     while (*tag) *p++ = (uint8_t)*tag++;
-    p = put_dec(p, A.prm.first_read + r);
+    p = put_dec(p, A.name_first + r);
     if (kind == NS_KIND_ALIGNED && rd.n_pieces > 1) { const char *c = "_chimeric"; while (*c) *p++ = (uint8_t)*c++; }
     if (pc[0].ref_gpos >= NS_SPLICED_BASE) {                          // "_RetainedIntron_<start>-<end>;..." (S:1189-1192)
         const uint32_t trx = pc[0].chrom;
@@ -1461,6 +1586,8 @@ struct ns_ctx {
         m_len, m_species, species_bases;
     DevBuf draw_sel, draw_sorted, meta_words, meta_num;
     DevBuf trx_chrom, trx_cum, trx_polya, polya;            // transcriptome: expression view of the reference, polyA length per read
+    DevBuf trx_pick_e, trx_pick_y, trx_keys, trx_keys2, trx_prev, trx_cand, t_polya, t_ir_need;   // ... the pick walk of its aligned batches (trx_passes)
+    uint32_t trx_margin = 128, trx_pick_pct = 125;          // candidates per block beyond NS_TRX_BLOCK / picks per candidate in percent: grown on demand, kept
     DevTrx tx{};
     bool has_trx = false;
     DevIr ir{};                                             // intron retention: genome, transcript structures, Markov chain
@@ -1633,7 +1760,8 @@ void ns_destroy(ns_ctx *ctx) {
                       &ctx->t_name_len, &ctx->t_rec_len, &ctx->t_err_len, &ctx->accept, &ctx->accept_scan, &ctx->key_pos,
                       &ctx->draw_x, &ctx->m_segptr, &ctx->m_len, &ctx->m_species, &ctx->species_bases, &ctx->draw_sel,
                       &ctx->draw_sorted, &ctx->meta_words, &ctx->meta_num, &ctx->trx_chrom, &ctx->trx_cum, &ctx->trx_polya, &ctx->polya,
-                      &ctx->ir_need, &ctx->ir_off, &ctx->spliced, &ctx->p_need, &ctx->p_off, &ctx->cls, &ctx->hp_bm, &ctx->hp_pcnt, &ctx->hp_pord};
+                      &ctx->ir_need, &ctx->ir_off, &ctx->spliced, &ctx->p_need, &ctx->p_off, &ctx->cls, &ctx->hp_bm, &ctx->hp_pcnt, &ctx->hp_pord,
+                      &ctx->trx_pick_e, &ctx->trx_pick_y, &ctx->trx_keys, &ctx->trx_keys2, &ctx->trx_prev, &ctx->trx_cand, &ctx->t_polya, &ctx->t_ir_need};
     for (auto *pb : {&ctx->pin_a, &ctx->pin_b, &ctx->pin_c, &ctx->pin_d})
         if (pb->p) e = hipHostFree(pb->p);
     if (ctx->pin_small) e = hipHostFree(ctx->pin_small);
@@ -2574,6 +2702,151 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
     return NS_OK;
 }
 
+// The aligned / --perfect reads of a transcriptome batch (S:1080-1104; kernels: k_trx_picks ... k_trx_commit above): the blocks of
+// NS_TRX_BLOCK read indices that overlap the batch are walked from their starts, every candidate is tried once (k_lengths + k_chain over
+// the candidate table), and the survivors that belong to the batch move to their slots.  Too few picks for a full table, or too few
+// survivors in a block, repeats the planning with more picks / a longer table (deterministic: a pick is keyed by (block, pick), a
+// candidate by (block, candidate)).
+static int trx_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, GenArgs &A, uint64_t &tot_pieces, uint64_t &tot_cap,
+                      unsigned long long *stats) {
+    const size_t n = (size_t)prm->n_reads;
+    hipStream_t st = ctx->stream;
+    const dim3 blk(256);
+    const uint64_t W = NS_TRX_BLOCK, g0 = prm->first_read, b0 = g0 / W, nb = (g0 + n - 1) / W - b0 + 1;
+    int rc;
+    float ms = 0;
+    if (ctx->tx.n_expr >= (1u << 22)) return fail(ctx, NS_EINVAL, "transcriptome: more than 2^22 expressed transcripts");
+    HIPCHK(hipEventRecord(ctx->evt[1], st));
+    A.key_first = b0 * W;                                   // the keys of the candidate table count from the first block
+    double ms_chain = 0;
+    bool planned = false;
+    for (int round = 0;; ++round) {
+        if (round >= 24) return fail(ctx, NS_EINVAL, "transcriptome: no aligned length below the transcript length within the pick limit "
+                                                     "(2-D KDE and transcript lengths do not match)");
+        const uint32_t C = (uint32_t)std::min<uint64_t>(2 * W, W + ctx->trx_margin);
+        uint64_t M64 = ((uint64_t)C * ctx->trx_pick_pct / 100 + 64 + 63) & ~63ull;
+        if (M64 >= (1ull << NS_TRX_PICK_BITS)) M64 = (1ull << NS_TRX_PICK_BITS) - 64;
+        const uint32_t M = (uint32_t)M64;
+        const uint64_t n_picks = nb * M, np = nb * C;
+        if (np > 0x7ffffff0ull || n_picks > 0x7ffffff0ull) return fail(ctx, NS_EINVAL, "transcriptome batch too large (split into several calls)");
+        if ((rc = ensure(ctx, ctx->trx_pick_e, n_picks * 4 + 64)) || (rc = ensure(ctx, ctx->trx_pick_y, n_picks * 4 + 64)) ||
+            (rc = ensure(ctx, ctx->trx_keys, n_picks * 8 + 64)) || (rc = ensure(ctx, ctx->trx_keys2, n_picks * 8 + 64)) ||
+            (rc = ensure(ctx, ctx->trx_prev, n_picks * 4 + 64)) || (rc = ensure(ctx, ctx->trx_cand, np * 4 + 64)) ||
+            (rc = ensure(ctx, ctx->meta_num, 64)))
+            return rc;
+        unsigned long long *d_short = (unsigned long long *)ctx->meta_num.p;
+        HIPCHK(hipMemsetAsync(d_short, 0, 16, st));
+        k_trx_picks<<<dim3((unsigned)((n_picks + 255) / 256)), blk, 0, st>>>(A, n_picks, M, b0, (uint32_t *)ctx->trx_pick_e.p, (int32_t *)ctx->trx_pick_y.p,
+                                                                              (uint64_t *)ctx->trx_keys.p);
+        HIPCHK(hipGetLastError());
+        {
+            int end_bit = 22 + (int)NS_TRX_PICK_BITS;
+            for (uint64_t v = nb - 1; v; v >>= 1) ++end_bit;
+            size_t tmp = 0;
+            HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp, (const uint64_t *)ctx->trx_keys.p, (uint64_t *)ctx->trx_keys2.p, (int)n_picks, 0, end_bit, st));
+            if ((rc = ensure(ctx, ctx->scan_tmp, tmp))) return rc;
+            HIPCHK(hipcub::DeviceRadixSort::SortKeys(ctx->scan_tmp.p, tmp, (const uint64_t *)ctx->trx_keys.p, (uint64_t *)ctx->trx_keys2.p, (int)n_picks, 0, end_bit, st));
+        }
+        k_trx_prev<<<dim3((unsigned)((n_picks + 255) / 256)), blk, 0, st>>>((const uint64_t *)ctx->trx_keys2.p, n_picks, M, (int32_t *)ctx->trx_prev.p);
+        k_trx_walk<<<dim3((unsigned)nb), dim3(64), M, st>>>(M, C, (const int32_t *)ctx->trx_prev.p, (const int32_t *)ctx->trx_pick_y.p,
+                                                            (uint32_t *)ctx->trx_cand.p, d_short);
+        HIPCHK(hipGetLastError());
+        unsigned long long n_short = 0;
+        if ((rc = read_small(ctx, st, &n_short, d_short, 8))) return rc;
+        if (n_short) {                                       // picks ran out before the table of some block was full: more picks per candidate
+            if (M64 + 64 >= (1ull << NS_TRX_PICK_BITS)) return fail(ctx, NS_EINVAL, "transcriptome: pick limit reached (almost no pick gives an aligned length below its transcript)");
+            ctx->trx_pick_pct *= 2;
+            continue;
+        }
+        // ---- the candidate table: one try per position
+        if ((rc = ensure(ctx, ctx->pieces, np * sizeof(ns_piece) + 64)) || (rc = ensure(ctx, ctx->t_pieces, np * sizeof(ns_piece) + 64)) ||
+            (rc = ensure(ctx, ctx->t_reads, np * sizeof(ns_read))) || (rc = ensure(ctx, ctx->t_name_len, (np + 1) * 2)) ||
+            (rc = ensure(ctx, ctx->t_rec_len, (np + 1) * 8)) || (rc = ensure(ctx, ctx->t_err_len, (np + 1) * 8)) ||
+            (rc = ensure(ctx, ctx->accept, (np + 1) * 8)) || (rc = ensure(ctx, ctx->accept_scan, (np + 1) * 8)) ||
+            (rc = ensure(ctx, ctx->key_pos, (n + 1) * 4)) || (rc = ensure(ctx, ctx->t_polya, (np + 1) * 2)) ||
+            (rc = ensure(ctx, ctx->ev_cap, (np + 1) * 8)) || (rc = ensure(ctx, ctx->ev_off, (np + 1) * 8)) ||
+            (rc = ensure(ctx, ctx->sort_key, (np + 1) * 4)) || (rc = ensure(ctx, ctx->sort_idx, (np + 1) * 4)) ||
+            (rc = ensure(ctx, ctx->sort_key_out, (np + 1) * 4)) || (rc = ensure(ctx, ctx->list_b, (np + 1) * 4)) ||
+            (A.ir_need && (rc = ensure(ctx, ctx->t_ir_need, (np + 1) * 8))))
+            return rc;
+        A.ev_cap = (uint64_t *)ctx->ev_cap.p; A.ev_off = (uint64_t *)ctx->ev_off.p;
+        A.sort_key = (uint32_t *)ctx->sort_key.p; A.sort_idx = (uint32_t *)ctx->sort_idx.p;
+        A.f_reads = (ns_read *)ctx->reads.p; A.f_pieces = (ns_piece *)ctx->pieces.p; A.f_name_len = (uint16_t *)ctx->name_len.p;
+        A.f_rec_len = (uint64_t *)ctx->rec_len.p; A.f_err_len = (uint64_t *)ctx->err_len.p;
+        A.key_pos_w = (uint32_t *)ctx->key_pos.p;
+        GenArgs P = A;
+        P.reads = (ns_read *)ctx->t_reads.p; P.pieces = (ns_piece *)ctx->t_pieces.p; P.name_len = (uint16_t *)ctx->t_name_len.p;
+        P.rec_len = (uint64_t *)ctx->t_rec_len.p; P.err_len = (uint64_t *)ctx->t_err_len.p;
+        P.accept = (uint64_t *)ctx->accept.p; P.accept_scan = (uint64_t *)ctx->accept_scan.p;
+        P.polya = (uint16_t *)ctx->t_polya.p;
+        if (A.ir_need) P.ir_need = (uint64_t *)ctx->t_ir_need.p;
+        P.trx_C = C; P.trx_M = M; P.trx_cand = (const uint32_t *)ctx->trx_cand.p;
+        P.trx_pick_e = (const uint32_t *)ctx->trx_pick_e.p; P.trx_pick_y = (const int32_t *)ctx->trx_pick_y.p;
+        P.list = nullptr; P.list_n = (uint32_t)np; P.list_base = 0; P.attempt = 0; P.l_off = nullptr; P.ev_base = 0;
+        P.cap_rate = ctx->cap_rate;
+        const bool lds = ctx->lds_tables && prm->kind != NS_KIND_PERFECT;
+        const dim3 grid_p((unsigned)((np + 255) / 256));
+        uint64_t cap = 0;
+        for (int retry = 0;; ++retry) {
+            HIPCHK(hipMemsetAsync(ctx->stats.p, 0, 8 * sizeof(unsigned long long), st));
+            HIPCHK(hipMemsetAsync(P.accept, 0, (np + 1) * 8, st));
+            HIPCHK(hipMemsetAsync(P.polya, 0, (np + 1) * 2, st));
+            if (P.ir_need) HIPCHK(hipMemsetAsync(P.ir_need, 0, (np + 1) * 8, st));
+            HIPCHK(hipMemsetAsync(P.ev_cap + np, 0, 8, st));
+            P.list = nullptr;
+            k_lengths<<<grid_p, blk, 0, st>>>(P);
+            HIPCHK(hipGetLastError());
+            if ((rc = scan_u64(ctx, P.ev_cap, P.ev_off, np + 1))) return rc;
+            {   // candidates by descending length: the 64 chains of a wavefront then have similar trip counts
+                size_t tmp = 0;
+                HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp, P.sort_key, (uint32_t *)ctx->sort_key_out.p, P.sort_idx,
+                                                                    (uint32_t *)ctx->list_b.p, (int)np, 0, 32, st));
+                if ((rc = ensure(ctx, ctx->scan_tmp, tmp))) return rc;
+                HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(ctx->scan_tmp.p, tmp, P.sort_key, (uint32_t *)ctx->sort_key_out.p, P.sort_idx,
+                                                                    (uint32_t *)ctx->list_b.p, (int)np, 0, 32, st));
+            }
+            if (!planned) { HIPCHK(hipEventRecord(ctx->evt[2], st)); planned = true; }
+            if ((rc = read_small(ctx, st, &cap, P.ev_off + np, 8))) return rc;
+            if ((rc = ensure(ctx, ctx->events, (size_t)cap * sizeof(ns_event) + 64))) return rc;
+            A.events = P.events = (ns_event *)ctx->events.p;
+            P.list = (const uint32_t *)ctx->list_b.p;
+            HIPCHK(hipEventRecord(ctx->evt[3], st));
+            const dim3 grid_c((unsigned)((np + NS_CHAIN_BLOCK - 1) / NS_CHAIN_BLOCK)), blk_c(NS_CHAIN_BLOCK);
+            if (lds) k_chain<true, false><<<grid_c, blk_c, ctx->lds_bytes + (P.ev_stage ? NS_CHAIN_BLOCK * 32u : 0u), st>>>(P);
+            else k_chain<false, false><<<grid_c, blk_c, 0, st>>>(P);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(ctx->evt[4], st));
+            if ((rc = read_small(ctx, st, stats, ctx->stats.p, 8 * sizeof(unsigned long long)))) return rc;
+            HIPCHK(hipEventElapsedTime(&ms, ctx->evt[3], ctx->evt[4])); ms_chain += ms;
+            if (!(stats[0] & NS_OVER_MASK)) break;
+            info->n_overflow += stats[0] & NS_OVER_MASK;         // a read outgrew its event capacity (rare): again with twice the capacity
+            if (retry >= 6) return fail(ctx, NS_ENOMEM, "event capacity overflow persists after 6 retries");
+            P.cap_rate *= 2.0; P.cap_gap_mul *= 2;
+        }
+        if ((rc = scan_u64(ctx, P.accept, P.accept_scan, np + 1))) return rc;
+        if (A.ir_need) HIPCHK(hipMemsetAsync(A.ir_need, 0, (n + 1) * 8, st));
+        HIPCHK(hipMemsetAsync(A.rec_len + n, 0, 8, st));     // the sentinels of the scans over the final reads
+        HIPCHK(hipMemsetAsync(A.err_len + n, 0, 8, st));
+        HIPCHK(hipMemsetAsync(d_short, 0, 16, st));
+        HIPCHK(hipMemsetAsync((unsigned long long *)ctx->stats.p + 1, 0, 3 * sizeof(unsigned long long), st));
+        k_trx_commit<<<grid_p, blk, 0, st>>>(P, np, b0, g0, (uint64_t)n, (uint16_t *)ctx->polya.p, A.ir_need, d_short);
+        HIPCHK(hipGetLastError());
+        if ((rc = read_small(ctx, st, &n_short, d_short, 8, stats, ctx->stats.p, 8 * sizeof(unsigned long long)))) return rc;
+        if (n_short) {                                       // a block lost more candidates than the table has to spare: a longer table
+            if (C >= 2 * W) return fail(ctx, NS_EINVAL, "transcriptome: more than half of the candidates of a block overshoot their transcript");
+            ctx->trx_margin = (uint32_t)std::min<uint64_t>(W, 2ull * ctx->trx_margin);
+            continue;
+        }
+        tot_cap = cap;
+        break;
+    }
+    A.pieces = (ns_piece *)ctx->pieces.p;
+    A.key_pos = (const uint32_t *)ctx->key_pos.p;
+    tot_pieces = n;
+    info->ms_kernel[NS_K_EVENTS] = ms_chain;
+    return NS_OK;
+}
+
 int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     if (!ctx) return NS_EINVAL;
     if (!prm || !info) return fail(ctx, NS_EINVAL, "null params/info");
@@ -2628,6 +2901,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     GenArgs A;
     memset(&A, 0, sizeof A);
     A.prm = *prm; A.m = ctx->m; A.ref = ctx->ref;
+    A.key_first = A.name_first = prm->first_read;
     A.cap_gap_mul = 2;
     // events of the thread-per-read chain staged four at a time in LDS, when the tables leave room for it next to four workgroups per CU
     A.ev_stage = (ctx->lds_tables && ctx->lds_bytes + NS_CHAIN_BLOCK * 32u <= 40u * 1024u && !getenv("NS_NO_EV_STAGE")) ? (uint32_t)ctx->lds_bytes : 0u;
@@ -2668,12 +2942,32 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     float ms = 0;
     HIPCHK(hipEventRecord(ctx->evt[0], st));
     double ms_hp = 0;
+    const bool trx_tab = prm->trx && prm->kind != NS_KIND_UNALIGNED;        // transcript + aligned length per block walk (trx_passes)
     if (meta_al && (rc = meta_passes(ctx, prm, info, A, tot_pieces, tot_cap, stats))) return rc;
     if (meta_al && A.hp) {         // the passes validated the final lengths; the stage runs once more on the reads in their final order
         ms_hp = info->ms_kernel[NS_K_HP];
         if ((rc = hp_stage1(ctx, prm, A, n, tot_pieces, tot_cap, stats, &ms_hp))) return rc;
     }
-    for (int hp_round = 0; !meta_al; ++hp_round) {
+    auto ir_splice = [&]() -> int {          // splice arena: slot offsets, then the copy from the genome (before anything reads the pieces' bases)
+        if ((rc = scan_u64(ctx, A.ir_need, (uint64_t *)ctx->ir_off.p, n + 1))) return rc;
+        uint64_t arena_bytes = 0;
+        if ((rc = read_small(ctx, st, &arena_bytes, (uint64_t *)ctx->ir_off.p + n, 8))) return rc;
+        if ((rc = ensure(ctx, ctx->spliced, (size_t)arena_bytes + 64))) return rc;
+        A.ir.arena = (uint8_t *)ctx->spliced.p; A.ir.arena_off = (const uint64_t *)ctx->ir_off.p;
+        A.ref.spliced = (const uint8_t *)ctx->spliced.p;
+        ctx->spliced_bytes = arena_bytes;
+        if (arena_bytes) {
+            k_ir_splice<<<grid_w, blk_w, 0, st>>>(A);
+            HIPCHK(hipGetLastError());
+        }
+        return NS_OK;
+    };
+    if (trx_tab) {
+        if ((rc = trx_passes(ctx, prm, info, A, tot_pieces, tot_cap, stats))) return rc;
+        if (ir_on && (rc = ir_splice())) return rc;
+        if (A.hp && (rc = hp_stage1(ctx, prm, A, n, tot_pieces, tot_cap, stats, &ms_hp))) return rc;    // (no length limits on these reads: nothing fails S:1429)
+    }
+    for (int hp_round = 0; !meta_al && !trx_tab; ++hp_round) {
     for (int retry = 0;; ++retry) {
         A.cap_rate = cap_rate;
         HIPCHK(hipMemsetAsync(ctx->stats.p, 0, 8 * sizeof(unsigned long long), st));
@@ -2780,19 +3074,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         if (retry >= 6) return fail(ctx, NS_ENOMEM, "event capacity overflow persists after 6 retries");
         cap_rate *= 2.0; A.cap_gap_mul *= 2;          // rare: more events per base than planned -> re-plan the batch with twice the rates
     }
-    if (ir_on) {          // splice arena: slot offsets, then the copy from the genome (before anything reads the pieces' bases)
-        if ((rc = scan_u64(ctx, A.ir_need, (uint64_t *)ctx->ir_off.p, n + 1))) return rc;
-        uint64_t arena_bytes = 0;
-        if ((rc = read_small(ctx, st, &arena_bytes, (uint64_t *)ctx->ir_off.p + n, 8))) return rc;
-        if ((rc = ensure(ctx, ctx->spliced, (size_t)arena_bytes + 64))) return rc;
-        A.ir.arena = (uint8_t *)ctx->spliced.p; A.ir.arena_off = (const uint64_t *)ctx->ir_off.p;
-        A.ref.spliced = (const uint8_t *)ctx->spliced.p;
-        ctx->spliced_bytes = arena_bytes;
-        if (arena_bytes) {
-            k_ir_splice<<<grid_w, blk_w, 0, st>>>(A);
-            HIPCHK(hipGetLastError());
-        }
-    }
+    if (ir_on && (rc = ir_splice())) return rc;
     if (!A.hp) break;
     if ((rc = hp_stage1(ctx, prm, A, n, tot_pieces, tot_cap, stats, &ms_hp))) return rc;
     if (!stats[5]) break;
@@ -2840,12 +3122,12 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     if (side_names) HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
     HIPCHK(hipEventRecord(ctx->evt[6], st));
     if (A.hp) {          // second record pass of -k: the scratch read + its homopolymer edits -> the record
-        if (write_rec && (rc = launch_materialise(ctx, A, n, prm->fastq != 0, tot_cap, nullptr, meta_al ? nullptr : list_a, MAT_HP_FINAL))) return rc;
+        if (write_rec && (rc = launch_materialise(ctx, A, n, prm->fastq != 0, tot_cap, nullptr, (meta_al || trx_tab) ? nullptr : list_a, MAT_HP_FINAL))) return rc;
         k_hp_report<<<dim3((unsigned)((tot_pieces + 255) / 256)), blk, 0, st>>>(A, tot_pieces);      // the pieces report their emitted length,
         HIPCHK(hipGetLastError());                                                                    // like the path without -k
     } else if (write_rec) {
         // (k_names runs NEXT to the record kernels on the second stream: they write different bytes of the image)
-        if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, tot_cap, nullptr, meta_al ? nullptr : list_a, MAT_REF, max_unaligned))) return rc;
+        if ((rc = launch_materialise(ctx, A, n, prm->fastq != 0, tot_cap, nullptr, (meta_al || trx_tab) ? nullptr : list_a, MAT_REF, max_unaligned))) return rc;
     }
     if (side_names) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
     HIPCHK(hipEventRecord(ctx->evt[7], st));

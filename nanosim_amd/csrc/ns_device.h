@@ -201,8 +201,8 @@ __device__ inline uint32_t trx_pick(const DevTrx &tx, double u) {
 }
 // select_nearest_kde2d (S:108-111) on a fresh, large sample of the 2-D KDE == a draw of the aligned length from the KDE conditioned
 // on the transcript length L: training point i with probability ~ exp(-(L - x_i)^2 / 2h^2), y = y_i + h N(0,1), int().  Rejection
-// sampling inside |x_i - L| <= 5h; no training point there: the nearest one.
-__device__ inline int64_t kde2d_cond(const DevModel &m, double L, const ns_key &key, uint32_t attempt) {
+// sampling inside |x_i - L| <= 5h; no training point there: the nearest one.  Draws: (ST_REFLEN, seg 0, attempt, idx = try, sub).
+__device__ inline int64_t kde2d_cond(const DevModel &m, double L, const ns_key &key, uint32_t attempt, uint32_t sub) {
     const double *__restrict__ x = m.kde2d_x, *__restrict__ y = m.kde2d_y;
     const double h = m.kde2d_bw;
     const uint64_t n = m.kde2d_n;
@@ -211,7 +211,7 @@ __device__ inline int64_t kde2d_cond(const DevModel &m, double L, const ns_key &
     { uint64_t a = lo, b = n; const double v = L + 5.0 * h; while (a < b) { const uint64_t md = (a + b) >> 1; if (x[md] <= v) a = md + 1; else b = md; } hi = a; }
     if (hi > lo) {
         for (uint32_t j = 0; j < NS_KDE_RETRY; ++j) {
-            const u32x4 w = ns_draw(key, ST_REFLEN, 0, attempt, j, 0);
+            const u32x4 w = ns_draw(key, ST_REFLEN, 0, attempt, j, sub);
             uint64_t i = lo + (uint64_t)(u53_to_p(w.x, w.y) * (double)(hi - lo));
             if (i >= hi) i = hi - 1;
             const double dd = (L - x[i]) / h;
@@ -222,7 +222,7 @@ __device__ inline int64_t kde2d_cond(const DevModel &m, double L, const ns_key &
     while (a < b) { const uint64_t md = (a + b) >> 1; if (x[md] < L) a = md + 1; else b = md; }
     uint64_t i = a >= n ? n - 1 : a;
     if (a > 0 && a < n && L - x[a - 1] <= x[a] - L) i = a - 1;
-    const u32x4 w = ns_draw(key, ST_REFLEN, 0, attempt, NS_KDE_RETRY, 0);
+    const u32x4 w = ns_draw(key, ST_REFLEN, 0, attempt, NS_KDE_RETRY, sub);
     return (int64_t)fma(h, ns_norminv(u32_to_p(w.w)), y[i]);
 }
 // extract_read("transcriptome", length) (S:1695-1703): a uniformly drawn transcript that is longer than the read, uniform start

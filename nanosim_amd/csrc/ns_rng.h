@@ -19,6 +19,7 @@ enum : uint32_t {
 #define NS_KDE_RETRY 64u
 #define NS_POS_RETRY 64u
 #define NS_MAX_SEG 64u
+#define NS_TRX_BLOCK 1024u      // transcriptome: read indices per block of the sample-until-repeat walk (k_trx_walk)
 
 struct ns_key {           // per-read part of the counter
     uint32_t k0, k1;      // seed

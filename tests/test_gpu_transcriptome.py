@@ -1,6 +1,6 @@
 """GPU parity for transcriptome batches: expression-weighted transcript pick, aligned length from the 2-D KDE
-conditioned on the transcript length, start inside the transcript, polyA tails, --uracil, --perfect, unaligned reads — bit for bit
-against the CPU oracle."""
+sample kept until a transcript repeats (S:1080-1104, per block of 1 024 read indices), start inside the transcript, polyA tails,
+--uracil, --perfect, unaligned reads — bit for bit against the CPU oracle."""
 import os
 
 import numpy as np
@@ -36,6 +36,9 @@ CASES = [
     dict(n_reads=300, emit_records=False),
     dict(n_reads=300, kmer_bias=5, fastq=True, uracil=True, emit_errlog=True),        # -hp -k 5
     dict(n_reads=300, kmer_bias=4),
+    dict(n_reads=2500, fastq=True, emit_errlog=True),                                  # three blocks of the sample-until-repeat walk
+    dict(n_reads=1500, first_read=700, emit_errlog=True),                              # starts and ends inside a block (dry runs in front)
+    dict(n_reads=1100, first_read=5 * 1024, kind=E.NS_KIND_PERFECT),
 ]
 
 
@@ -67,6 +70,7 @@ IR_CASES = [
     dict(n_reads=300, kind=E.NS_KIND_PERFECT),                                           # S:1117: --perfect never retains introns
     dict(n_reads=300, kind=E.NS_KIND_UNALIGNED, min_len=50, max_len=5000),
     dict(n_reads=3000, emit_records=False),
+    dict(n_reads=1300, first_read=1000, fastq=True, emit_errlog=True),                  # a batch that starts inside a block
 ]
 
 
@@ -141,5 +145,24 @@ def test_transcriptome_error_paths(trx_ref, small_model, small_ref):
             e.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=9000, trx=True, kmer_bias=5))
         with pytest.raises(E.EngineError):
             e.generate(E.make_params(seed=1, first_read=0, n_reads=10, max_len=9000, trx=True, chimeric=True))
+    finally:
+        e.close()
+
+
+def test_gpu_transcriptome_batches_do_not_depend_on_the_split(trx_ref):
+    """the sample-until-repeat rule couples the reads of a BLOCK of read indices, not of a batch: any split of a run gives its bytes"""
+    mdl = M.load_model(PREFIX, transcriptome=True, fastq=True)
+    kw = dict(seed=0xFEED, max_len=10 ** 9, trx=True, fastq=True, emit_errlog=True)
+    e = E.Engine(0)
+    try:
+        e.set_transcriptome(trx_ref)
+        e.load_model(mdl)
+        b = e.generate(E.make_params(first_read=0, n_reads=3100, **kw))
+        whole, whole_err = b.records().tobytes(), b.errlog().tobytes()
+        recs, errs = [], []
+        for lo, hi in ((0, 1), (1, 1023), (1023, 1024), (1024, 2500), (2500, 3100)):
+            b = e.generate(E.make_params(first_read=lo, n_reads=hi - lo, **kw))
+            recs.append(b.records().tobytes()); errs.append(b.errlog().tobytes())
+        assert b"".join(recs) == whole and b"".join(errs) == whole_err
     finally:
         e.close()
