@@ -77,7 +77,6 @@ struct GenArgs {
     uint32_t keep_state;             // k_nseg keeps rstate/att_base (re-run after a failed final length check)
     uint32_t hp;                     // -k active for this batch
     uint32_t dbg;                    // NS_DEBUG_SKIP (profiling only)
-    uint32_t bg_prio;                // background context (ns_set_background): issue priority of ALL its chain waves (0: the graded default)
     uint32_t errlen_later;           // the error-profile size of a read is computed by k_errlen / k_hp_filter_w, not by k_chain
     uint8_t *scr;                    // -k: the pieces of every read before mutate_homo (forward strand; FASTQ: with their class bits)
     uint64_t *scr_len, *scr_off;     //     bytes per read / exclusive scan
@@ -309,9 +308,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK, COOP ? 4 : NS_CHAI
     // The list is sorted by descending length, so the first workgroups carry the longest chains and set the makespan
     // (a 120 kb read is ~3800 dependent iterations): give them issue priority over the short-read waves they share a
     // SIMD with.
-    // A background context's chain is a few hundred latency-bound wavefronts next to another context's full grids: all of them take
-    // the issue slots they can use (priority outranks age; a wave that issues one instruction in four cycles leaves the rest).
-    if (COOP || A.bg_prio || blockIdx.x < (gridDim.x >> 6)) __builtin_amdgcn_s_setprio(3);
+    if (COOP || blockIdx.x < (gridDim.x >> 6)) __builtin_amdgcn_s_setprio(3);
     else if (blockIdx.x < (gridDim.x >> 4)) __builtin_amdgcn_s_setprio(2);
     else if (blockIdx.x < (gridDim.x >> 2)) __builtin_amdgcn_s_setprio(1);
     unsigned long long st_over = 0, st_bases = 0, st_ref = 0, st_ev = 0;
@@ -350,6 +347,9 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK, COOP ? 4 : NS_CHAI
                 if (kind == NS_KIND_PERFECT) { e.l_new = e.middle_ref = m32; }
                 else if (p.kind) e = COOP ? coop_unaligned_error_list(T, ct, m32, key, sid, a, sink, lane) : chain_unaligned_error_list(T, ct, m32, key, sid, a, sink);
                 else if (COOP) e = coop_error_list(T, ct, m32, key, sid, a, sink, *coop, lane);
+#ifdef NS_CHAIN_MLP          // (round 4: measured SLOWER than the one-question-at-a-time chain, 3.76 against 3.28 ms — ns_chain.h)
+                else if constexpr (LDS_TABLES) e = chain_error_list_mlp(T, Tabs{A.m.chain_blob}, ct, m32, key, sid, a, sink);
+#endif
                 else e = chain_error_list<LDS_TABLES>(T, Tabs{A.m.chain_blob}, ct, m32, key, sid, a, sink);
                 ev_flush_tail(sink);
                 p.ev_off = ev_off + evn;
@@ -1569,7 +1569,6 @@ struct ns_ctx {
     uint32_t dbg = 0;          // NS_DEBUG_SKIP: phase-ablation bits for profiling only (results are wrong when set)
     uint32_t coop_min = 16384, coop_shift = 10;  // cooperative chain for the longest n>>shift reads of batches >= min (env: NS_COOP_MIN, NS_COOP_SHIFT);
                                                  // 10^6 reads, chain ms at shift 9 / 10 / 11 / 12: 4.18 / 3.63 / 3.90 / 4.32
-    uint32_t bg_prio = 0;                        // background context: all chain waves at s_setprio 3 (env NS_BG_PRIO overrides)
     uint32_t ucoop_shift = 0;                    // unaligned reads: the longest n>>shift of a batch take the wave-per-read list, the rest the thread-per-read one (env: NS_UCOOP_SHIFT; 0: all)
     // planning + result buffers
     DevBuf l_cap, l_off, p_need, p_off;
@@ -1682,9 +1681,7 @@ uint32_t ns_abi_version(void) { return NS_ABI_VERSION; }
 int ns_set_background(ns_ctx *ctx, int on) {
     if (!ctx) return NS_EINVAL;
     ctx->ucoop_shift = on ? 3u : 0u;
-    ctx->bg_prio = on ? 1u : 0u;
     if (const char *d = getenv("NS_UCOOP_SHIFT")) ctx->ucoop_shift = (uint32_t)atoi(d) & 31u;
-    if (const char *d = getenv("NS_BG_PRIO")) ctx->bg_prio = on ? (uint32_t)atoi(d) : 0u;
     return NS_OK;
 }
 
@@ -2917,7 +2914,6 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     A.hp = hp_on ? 1u : 0u; A.keep_state = 0;
     A.errlen_later = prm->emit_errlog ? 1u : 0u;
     A.dbg = ctx->dbg;
-    A.bg_prio = ctx->bg_prio;
     if (prm->trx) {
         if ((rc = ensure(ctx, ctx->polya, (n + 1) * 2))) return rc;
         A.tx = ctx->tx; A.polya = (uint16_t *)ctx->polya.p;

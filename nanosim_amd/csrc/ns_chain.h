@@ -91,6 +91,19 @@ __device__ __forceinline__ int32_t run_length_t(const Tabs &T, const ChainTab &c
     return (int32_t)v + 1;
 }
 
+// the same with the mixture weight handed in (the callers keep the three weights in registers) and the first TWO thresholds of the walk
+// fetched together: the walk starts at the guide's lower bound and almost always ends within two steps
+__device__ __forceinline__ int32_t run_length_w(const Tabs &T, const ChainTab &c, int type, uint64_t weight_thr, uint32_t u_mix, uint32_t u_len) {
+    const uint32_t comp = ((uint64_t)u_mix < weight_thr) ? 0u : 1u;                        // tmp_rand < weight, mm:44,54
+    const uint32_t go = comp ? c.mix_cdf[type][1] : c.mix_cdf[type][0], n = comp ? c.mix_n[type][1] : c.mix_n[type][0];
+    const uint32_t h = comp ? c.mix_g2[type][1] : c.mix_g2[type][0];
+    const uint64_t u = u_len;
+    uint32_t v = reinterpret_cast<const uint8_t *>(T.w)[8u * h + (uint32_t)__clz((int)~u_len)];
+    const uint64_t a = T.w[go + v], b = T.w[go + min(v + 1u, n - 1u)];
+    if (v + 1u < n && u >= a) { ++v; if (v + 1u < n && u >= b) { ++v; while (v + 1u < n && u >= T.w[go + v]) ++v; } }
+    return (int32_t)v + 1;
+}
+
 struct EvSink32 {
     ns_event *ev;
     uint32_t cap, n;
@@ -191,6 +204,107 @@ __device__ __forceinline__ EList32 chain_error_list(const Tabs &T, const Tabs &T
     return EList32{l_new, middle_ref};
 }
 
+// ---- error_list with its table look-ups side by side (round 4; -DNS_CHAIN_MLP: an experiment that did NOT pay) -------------------------
+// Measured on configs[1] (950 000 reads, same box): 3.76 ms against 3.28 ms for chain_error_list — the three-fold run-length look-ups and
+// the wider match look-up cost more LDS bandwidth and issue slots than the shorter dependency chain gives back; the chain is closer to
+// LDS- / issue-throughput bound than its serial shape suggests.  Kept as the documented negative result.
+// chain_error_list above asks the tables one question at a time: transition row -> run-length mixture -> guide -> threshold walk ->
+// event -> bin -> segment offsets -> guide -> thresholds -> value edge, each an LDS round trip the next one waits for — about fourteen per
+// event, ~3 000 dependent cycles, with four wavefronts per SIMD to hide them.  But an iteration's questions hardly depend on each other:
+//   * the next match length depends on the PREVIOUS match length (its bin) and on the draw, not on this iteration's error;
+//   * the run length depends on the error type only through which of three tables is asked — all three are asked;
+//   * a walk that starts at the guide's lower bound almost always ends within two steps — both thresholds are fetched at once.
+// So the look-ups are issued in three waves of independent LDS reads (straight-line code: the compiler batches them under one wait)
+// and the answers are selected afterwards; whatever does not fit the pattern (a walk of more than two steps, a draw beyond the last
+// edge, a segment that is not one unit wide, a previous match >= 256) falls back to the functions above.  Same events, bit for bit.
+struct RunPick { uint32_t v; bool more; uint32_t g_off, n; };
+__device__ __forceinline__ EList32 chain_error_list_mlp(const Tabs &T, const Tabs &TG, const ChainTab &c, int32_t m_ref, const ns_key &key,
+                                                        uint32_t seg, uint32_t attempt, EvSink32 &s) {
+    int32_t l_new = m_ref, pos = 0, middle_ref = m_ref;
+    int state = NS_ST_START;
+    u32x4 w = ns_draw(key, ST_EVENT, seg, attempt, 0, 0);
+    int32_t prev_match = ecdf_lookup_u(T.q(c.fm_g), T.u(c.fm_vhi_u), c.fm_n, T.h(c.fm_guide), w.x, T.q(c.sub), TG.d(c.fm_hi), TG.d(c.fm_vhi), c.fm_vlo0);   // S:1843-1850
+    if (prev_match < 2) prev_match = 2;
+    pos += prev_match;
+    uint32_t it = 1;
+    int32_t last_ins_pos = -1;
+    const uint64_t *trans = T.q(c.trans);
+    const int32_t *bins = T.i(c.mm_bin);
+    const uint32_t *seg_off = T.u(c.mm_seg_off);
+    const uint8_t *bin_lut = reinterpret_cast<const uint8_t *>(T.w + c.mm_bin_lut);
+    const uint64_t *mmG = T.q(c.mm_g);
+    const uint32_t *mmV = T.u(c.mm_vhi_u);
+    const uint16_t *mmGuide = T.h(c.mm_guide);
+    const uint8_t *wbytes = reinterpret_cast<const uint8_t *>(T.w);
+    // the three mixture weights are the same for every iteration: registers
+    const uint64_t mw0 = T.q(c.mix_w)[0], mw1 = T.q(c.mix_w)[1], mw2 = T.q(c.mix_w)[2];
+    u32x4 w_next = ns_draw(key, ST_EVENT, seg, attempt, 1, 0);
+    while (pos < middle_ref) {                                                                     // S:1858
+        w = w_next;
+        w_next = ns_draw(key, ST_EVENT, seg, attempt, it + 1, 0);    // next iteration's draws do not depend on the chain state
+        const uint64_t ux = w.x, uy = w.y, uz = w.z, uw = w.w;
+        // ---- wave 1: transition row, bin of the previous match, the walk's lower bound for each error type
+        const uint64_t t0 = trans[3 * state], t1 = trans[3 * state + 1];
+        const bool small = (uint32_t)prev_match < 256u;
+        const uint32_t b_l = bin_lut[small ? prev_match : 0];
+        const uint32_t lz = (uint32_t)__clz((int)~w.z);
+        const uint32_t c0 = uy < mw0 ? 0u : 1u, c1 = uy < mw1 ? 0u : 1u, c2 = uy < mw2 ? 0u : 1u;
+        const uint32_t go0 = c0 ? c.mix_cdf[0][1] : c.mix_cdf[0][0], go1 = c1 ? c.mix_cdf[1][1] : c.mix_cdf[1][0], go2 = c2 ? c.mix_cdf[2][1] : c.mix_cdf[2][0];
+        const uint32_t n0 = c0 ? c.mix_n[0][1] : c.mix_n[0][0], n1 = c1 ? c.mix_n[1][1] : c.mix_n[1][0], n2 = c2 ? c.mix_n[2][1] : c.mix_n[2][0];
+        const uint32_t h0 = c0 ? c.mix_g2[0][1] : c.mix_g2[0][0], h1 = c1 ? c.mix_g2[1][1] : c.mix_g2[1][0], h2 = c2 ? c.mix_g2[2][1] : c.mix_g2[2][0];
+        const uint32_t v0 = wbytes[8u * h0 + lz], v1 = wbytes[8u * h1 + lz], v2 = wbytes[8u * h2 + lz];
+        uint32_t b = b_l;
+        if (!small) {                                                                              // S:1891-1893 (rare: a match of >= 256 bases)
+            for (b = 0; b < c.mm_nbins; ++b)
+                if (bins[2 * b] <= prev_match && prev_match < bins[2 * b + 1]) break;
+            if (b >= c.mm_nbins) b = c.mm_nbins - 1;
+        }
+        // ---- wave 2: two thresholds of every run-length walk; segment range and guide of the match column
+        const uint64_t a0 = T.w[go0 + v0], b0 = T.w[go0 + min(v0 + 1u, n0 - 1u)];
+        const uint64_t a1 = T.w[go1 + v1], b1 = T.w[go1 + min(v1 + 1u, n1 - 1u)];
+        const uint64_t a2 = T.w[go2 + v2], b2 = T.w[go2 + min(v2 + 1u, n2 - 1u)];
+        const uint32_t o = seg_off[b], ncol = seg_off[b + 1] - o;
+        const uint32_t s0 = mmGuide[256u * b + (w.w >> 24)];
+        // ---- wave 3: three thresholds / value edges of the match column from the guide's segment on
+        const uint32_t sa = min(s0, ncol - 1u), sb = min(s0 + 1u, ncol - 1u), sc = min(s0 + 2u, ncol - 1u);
+        const uint64_t ga = mmG[o + sa], gb = mmG[o + sb], gc = mmG[o + sc];
+        const uint32_t va = mmV[o + sa], vb = mmV[o + sb], vc = mmV[o + sc];
+        // ---- the answers
+        const int error = ux < t0 ? NS_MIS : ux < t1 ? NS_INS : NS_DEL;                           // S:1860-1864 (trans_pick_u)
+        const uint32_t rv = error == NS_MIS ? v0 : error == NS_INS ? v1 : v2, rn = error == NS_MIS ? n0 : error == NS_INS ? n1 : n2;
+        const uint64_t ra = error == NS_MIS ? a0 : error == NS_INS ? a1 : a2, rb = error == NS_MIS ? b0 : error == NS_INS ? b1 : b2;
+        const uint32_t rg = error == NS_MIS ? go0 : error == NS_INS ? go1 : go2;
+        uint32_t rw = rv;                                                                          // == run_length_t's walk (S:1866-1873)
+        if (rw + 1u < rn && uz >= ra) { ++rw; if (rw + 1u < rn && uz >= rb) { ++rw; while (rw + 1u < rn && uz >= T.w[rg + rw]) ++rw; } }
+        int32_t step = (int32_t)rw + 1;
+        if (error == NS_INS) l_new += step; else if (error == NS_DEL) l_new -= step;
+        if (error != NS_INS) {                                                                     // S:1875-1880
+            ev_push32(s, pos, (uint32_t)error, step);
+            pos += step;
+            if (pos >= middle_ref) { l_new += pos - middle_ref; middle_ref = pos; }
+        } else {                                                                                   // S:1881-1882
+            if (last_ins_pos == pos && s.n > 0) { s.n--; s.shift -= (int32_t)s.last_ins_len; }    // dict key collision
+            ev_push32(s, pos, NS_INS, step);
+            last_ins_pos = pos;
+        }
+        state = NS_ST_MIS + error;                                                                 // S:1884
+        // next match length (S:1895-1898): the segment is the guide's, or one or two further on, and one unit wide — else the full look-up
+        const bool k0 = s0 < ncol && uw >= NS_G_THR(ga), k1 = k0 && s0 + 1u < ncol && uw >= NS_G_THR(gb), k2 = k1 && s0 + 2u < ncol && uw >= NS_G_THR(gc);
+        const uint32_t sv = k1 ? vc : k0 ? vb : va;
+        const bool in_col = (k1 ? s0 + 2u : k0 ? s0 + 1u : s0) < ncol;
+        if (!k2 && in_col && (sv & 0x80000000u)) step = (int32_t)(sv & 0x7fffffffu) - 1;
+        else step = ecdf_lookup_u(mmG + o, mmV + o, ncol, mmGuide + 256u * b, w.w, T.q(c.sub), TG.d(c.mm_hi) + o, TG.d(c.mm_vhi) + o, T.d(c.mm_vlo0)[b]);
+        if (prev_match == 0 && step == 0) step = 1;                                                // S:1900-1901
+        prev_match = step;
+        if (pos + prev_match > middle_ref) { l_new += pos + prev_match - middle_ref; middle_ref = pos + prev_match; }
+        pos += prev_match;
+        if (prev_match == 0) state += 3;                                                           // S:1913-1914
+        else last_ins_pos = -1;
+        ++it;
+    }
+    return EList32{l_new, middle_ref};
+}
+
 // unaligned_error_list, S:1784-1830, with the event rewrite of DESIGN.md §5.3
 __device__ __forceinline__ EList32 chain_unaligned_error_list(const Tabs &T, const ChainTab &c, int32_t m_ref, const ns_key &key,
                                                               uint32_t seg, uint32_t attempt, EvSink32 &s) {
@@ -201,6 +315,7 @@ __device__ __forceinline__ EList32 chain_unaligned_error_list(const Tabs &T, con
     // what iteration `it` draws does not depend on the state of the loop: the Philox block of the NEXT iteration is evaluated under this
     // iteration's table walk, off the critical path (as thread-per-read work the loop is pure latency: ~2 000 dependent iterations per read)
     u32x4 w_next = ns_draw(key, ST_UEVENT, seg, attempt, 0, 0);
+    const uint64_t mw0 = T.q(c.mix_w)[0], mw1 = T.q(c.mix_w)[1], mw2 = T.q(c.mix_w)[2];            // the mixture weights: registers
     while (pos < middle_ref) {
         const u32x4 w = w_next;
         ++it;
@@ -208,7 +323,7 @@ __device__ __forceinline__ EList32 chain_unaligned_error_list(const Tabs &T, con
         const uint64_t ut = w.x;                                                                     // (p < t  <=>  u < ns_thr_lt(t))
         const int type = (ut < ns_thr_lt(0.4)) ? 3 : (ut < ns_thr_lt(0.7)) ? NS_MIS : (ut < ns_thr_lt(0.85)) ? NS_INS : NS_DEL;   // S:1787
         int32_t step = 1;
-        if (type != 3) step = run_length_t(T, c, type, w.y, w.z);
+        if (type != 3) step = run_length_w(T, c, type, type == NS_MIS ? mw0 : type == NS_INS ? mw1 : mw2, w.y, w.z);
         if (type == NS_INS) { pend_ins += step; l_new += step; continue; }                          // S:1808-1815
         if (type == NS_DEL) l_new -= step;
         const int32_t L = pend_ins; pend_ins = 0;

@@ -661,7 +661,11 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
     const uint32_t phi = ro.reversed ? ((uint32_t)(uintptr_t)ro.seq + ro.seq_len - pq) & 15u : (0u - ((uint32_t)(uintptr_t)ro.seq + pq)) & 15u;
     ns_event e_pre; e_pre.pos = 0; e_pre.info = 0; uint32_t w_pre = 0;
     if (lane < pc.n_ev) e_pre = pc.ev[lane];
-    w_pre = event_word<MODE>(pc, key, a, lane < pc.n_ev ? lane : 0u);
+    // (round 4: caching the letter words of 256 events per Philox evaluation — lane l keeps block l, tiles fetch theirs by ds_bpermute or
+    // from 1 KB of LDS — was SLOWER in every variant: record kernel 5.72 ms without, 6.40 / 5.93 / 6.06 with (registers at 7 / 6 waves per
+    // SIMD, LDS): the spills and cross-lane reads cost more than the Philox they save.  The word is drawn per tile: event_word.)
+    auto cached_word = [&](uint32_t j0) -> uint32_t { const uint32_t j = j0 + lane; return event_word<MODE>(pc, key, a, j < pc.n_ev ? j : 0u); };
+    w_pre = cached_word(0u);
     // The tile whose bytes are complete in T.out and wait for their final pass (step 4): it runs UNDER the loads of the next tile
     bool have_prev = false;
     uint32_t A0p = 0, M0p = 0, M1p = 0;
@@ -745,7 +749,7 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
             jb = uni(j2); M0 = M1;
             e_pre.pos = 0; e_pre.info = 0; w_pre = 0;
             if (jb + lane < pc.n_ev) e_pre = pc.ev[jb + lane];
-            w_pre = event_word<MODE>(pc, key, a, jb + lane < pc.n_ev ? jb + lane : 0u);
+            w_pre = cached_word(jb);
             continue;
         }
         const uint32_t nc = (M1 - A0 + 15u) >> 4;                 // chunks of the tile (chunk 0 starts at M0, chunk c > 0 at A0 + 16 c)
@@ -768,7 +772,7 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
         const uint32_t jb_next = jb + cnt;
         e_pre.pos = 0; e_pre.info = 0; w_pre = 0;
         if (M1 < pc.out_len && jb_next + lane < pc.n_ev) e_pre = pc.ev[jb_next + lane];       // prefetch for the next tile
-        if (M1 < pc.out_len) w_pre = event_word<MODE>(pc, key, a, jb_next + lane < pc.n_ev ? jb_next + lane : 0u);
+        if (M1 < pc.out_len) w_pre = cached_word(jb_next);
         wave_sync();
         {   // hist[c] = number of the tile's events sorted in front of chunk c — written by the LAST one (sorted events: lane l is event l + 1
             // of the tile), the chunks in between inherit it through a prefix maximum

@@ -14,3 +14,5 @@ timeout 900 python bench.py --genome grch38 --chimeric --no-e2e --cpu-sample 200
 for f in pytest_trx_parity pytest_cli_trx parity_trx_big sweep_bg bench_transcriptome; do echo "== $f"; tail -12 $O/$f.log; done
 tail -4 $O/bench_cli_default.log
 for f in bench_ecoli_noextra bench_zymo10_metagenome bench_grch38_chimeric; do echo "== $f"; cut -c1-260 $O/$f.json; tail -2 $O/${f%%_*}*.err 2>/dev/null | head -3; done
+echo "== A/B record kernel variants (aligned-only, configs[1])"; bash scripts/ab_run.sh --no-e2e --no-configs2 --no-extras 2>&1 | tee $O/ab_wordcache.log
+echo "== A/B FASTQ -k5 chr1"; VARIANTS="base wc7" bash scripts/ab_run.sh --no-e2e --no-configs2 --no-extras --genome chr1 --fastq --kmer-bias 5 2>&1 | tee $O/ab_wordcache_k5.log
