@@ -1451,11 +1451,19 @@ __global__ void __launch_bounds__(64 * NS_WPB) k_errlen(GenArgs A) {
 // ---------------------------------------------------------------------------------------------------------
 // k_errlog: error-profile rows "name\tpos\ttype\tlen\tref\tnew\n" in descending position order (S:1960, 2006-2008)
 // ---------------------------------------------------------------------------------------------------------
-#define NS_ERR_STAGE 48u          // bytes of a row behind the read name that are staged in LDS (rows with longer payloads: straight to memory)
-__global__ void __launch_bounds__(64 * NS_WPB) k_errlog(GenArgs A) {
-    __shared__ __align__(16) uint8_t stage_lds[NS_WPB][64][NS_ERR_STAGE];
+// Round 4: the 64 rows of an iteration are assembled side by side in ONE LDS buffer and leave as aligned 16-byte stores, lane l the
+// l-th chunk of the block — until then every lane stored its own ~67-byte row with five unaligned 16-byte stores, each instruction
+// touching 64 different cache lines: the kernel was bound by the memory pipeline's address handling (11.5 ms per 950 000 reads for
+// 17.7 KB of text per read = 0.18 of HBM), not by HBM.  A block of rows that does not fit the buffer (names beyond ~60 characters with
+// long payloads) takes the row-per-lane stores.
+#define NS_ERR_BUF 8192u          // bytes of rows staged per iteration
+#define NS_ERR_PAD 16u            // in front of the buffer: the copy-out reads 16 bytes from up to 15 bytes before the first row
+#define NS_ERR_NAME 256u          // the read name, once per read
+__global__ void __launch_bounds__(64) k_errlog(GenArgs A) {
+    __shared__ __align__(16) uint8_t buf_lds[NS_ERR_PAD + NS_ERR_BUF + 16];
+    __shared__ __align__(16) uint8_t name_lds[NS_ERR_NAME];
     const uint32_t lane = threadIdx.x & 63;
-    const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t r = blockIdx.x;
     if (r >= A.prm.n_reads) return;
     const ns_read rd = A.reads[r];
     if (rd.flags) return;
@@ -1463,7 +1471,16 @@ __global__ void __launch_bounds__(64 * NS_WPB) k_errlog(GenArgs A) {
     const uint32_t a = rd.attempts;
     const uint32_t nl = A.name_len[r];
     const uint8_t *name = A.records + rd.rec_off + 1;
-    uint8_t *const stage = stage_lds[threadIdx.x >> 6][lane];
+    uint8_t *const buf = buf_lds + NS_ERR_PAD;
+    const bool name_in_lds = nl <= NS_ERR_NAME;
+    if (name_in_lds) {                                              // (k_names is done: ns_generate orders the kernels)
+        for (uint32_t i = lane * 4; i < nl; i += 256) {
+            uint32_t v = 0;
+            for (uint32_t b = 0; b < 4 && i + b < nl; ++b) v |= (uint32_t)name[i + b] << (8 * b);
+            *reinterpret_cast<uint32_t *>(name_lds + i) = v;
+        }
+        wave_sync();
+    }
     uint64_t base = A.err_off[r];
     for (uint32_t pi = 0; pi < rd.n_pieces; pi += 2) {
         const ns_piece p = A.pieces[rd.piece_off + pi];
@@ -1479,44 +1496,67 @@ __global__ void __launch_bounds__(64 * NS_WPB) k_errlog(GenArgs A) {
             const uint32_t row = active ? nl + tail : 0;
             const uint32_t incl = wave_incl_scan(row);                                      // row offsets: prefix sum over the wavefront
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            if (active) {
+            const bool staged = name_in_lds && total <= NS_ERR_BUF;                         // wave-uniform
+            auto fields = [&](uint8_t *w) {                          // the rest of the row at w
+                *w++ = '\t'; w = put_dec(w, e.pos); *w++ = '\t';
+                const char *tn = ty == NS_MIS ? "mis" : ty == NS_INS ? "ins" : "del";
+                *w++ = (uint8_t)tn[0]; *w++ = (uint8_t)tn[1]; *w++ = (uint8_t)tn[2];
+                *w++ = '\t'; w = put_dec(w, len); *w++ = '\t';
+                uint8_t *w2 = w + len + 1;
+                // the letters of the event come from ONE word per 16 (payload_word: 2-bit fields / successive base-3 digits) — drawn
+                // once per word here, not once per letter (ins_letter / mis_letter evaluate a Philox block per call)
+                uint32_t frac = 0;
+                // the reference bases under a substitution / deletion of <= 8 bases: ONE 8-byte load in front of the loop (the engine's
+                // copy of the reference is padded) instead of a dependent byte load per base; across the origin: the byte loads
+                uint64_t ref8 = 0;
+                const bool ref_fast = ty != NS_INS && len <= 8u && pc.pos + e.pos + 8ull <= pc.chrom_len;
+                if (ref_fast) __builtin_memcpy(&ref8, A.ref.bases + pc.chrom_base + pc.pos + e.pos, 8);
+                for (uint32_t i = 0; i < len; ++i) {
+                    if (ty != NS_DEL && !(i & 15u)) frac = payload_word(key, pc.sid, a, p.n_ev - 1 - k, i >> 4);
+                    if (ty == NS_INS) { w[i] = '-'; w2[i] = bases_atcg((frac >> (2u * (i & 15u))) & 3u); }
+                    else {
+                        uint32_t x = e.pos + i;
+                        uint8_t cur = resolve_base(ref_fast ? (uint32_t)(ref8 >> (8u * i)) & 0xffu : (uint32_t)ref_base_at(A.ref, pc, x), key, pc.sid, a, x);
+                        w[i] = cur;
+                        w2[i] = (ty == NS_MIS) ? mis_from_digit(cur, next_digit3(frac)) : (uint8_t)'-';
+                    }
+                }
+                w[len] = '\t';
+                w2[len] = '\n';
+            };
+            if (staged) {
+                if (active) {
+                    uint8_t *q = buf + (incl - row);
+                    // the name: 8 bytes at a time from its LDS copy (every lane reads the same address: a broadcast), the last group
+                    // overlapping; the row starts at any byte
+                    if (nl >= 8) {
+                        for (uint32_t i = 0; i + 8 <= nl; i += 8) { uint64_t v; __builtin_memcpy(&v, name_lds + i, 8); __builtin_memcpy(q + i, &v, 8); }
+                        if (nl & 7u) { uint64_t v; __builtin_memcpy(&v, name_lds + nl - 8, 8); __builtin_memcpy(q + nl - 8, &v, 8); }
+                    } else for (uint32_t i = 0; i < nl; ++i) q[i] = name_lds[i];
+                    fields(q + nl);
+                }
+                wave_sync();
+                // the block leaves: chunk c = the 16 bytes at errlog address (dst0 & ~15) + 16 c, i.e. buffer bytes [16 c - mis, 16 c - mis + 16)
+                uint8_t *const dst0 = A.errlog + base;
+                const uint32_t mis = (uint32_t)(uintptr_t)dst0 & 15u;
+                uint8_t *const dstA = dst0 - mis;
+                for (uint32_t c = lane; 16u * c < mis + total; c += 64) {
+                    const int32_t lo = (int32_t)(16u * c) - (int32_t)mis;                      // >= -15: inside the pad
+                    uint64_t v0, v1;
+                    __builtin_memcpy(&v0, buf + lo, 8); __builtin_memcpy(&v1, buf + lo + 8, 8);
+                    const uint32_t s0 = lo < 0 ? (uint32_t)(-lo) : 0u;                          // bytes of the chunk in front of the block
+                    const uint32_t e0 = min(16u, mis + total - 16u * c);                        // ... and where the block ends inside it
+                    if (s0 == 0 && e0 == 16u) { struct __attribute__((packed)) V { uint64_t a, b; } v{v0, v1}; __builtin_memcpy(dstA + 16u * c, &v, 16); }
+                    else { shift_down_bytes(v0, v1, s0); store16(dstA + 16u * c + s0, e0 - s0, v0, v1); }
+                }
+                wave_sync();
+            } else if (active) {
                 uint8_t *q = A.errlog + base + (incl - row);
                 if (nl >= 16) {                                          // the read name, 16 bytes at a time (the last chunk overlaps)
                     for (uint32_t i = 0; i + 16 <= nl; i += 16) { uint4 v; __builtin_memcpy(&v, name + i, 16); __builtin_memcpy(q + i, &v, 16); }
                     if (nl & 15u) { uint4 v; __builtin_memcpy(&v, name + nl - 16, 16); __builtin_memcpy(q + nl - 16, &v, 16); }
                 } else for (uint32_t i = 0; i < nl; ++i) q[i] = name[i];
-                q += nl;
-                auto fields = [&](uint8_t *w) {                          // the rest of the row at w
-                    *w++ = '\t'; w = put_dec(w, e.pos); *w++ = '\t';
-                    const char *tn = ty == NS_MIS ? "mis" : ty == NS_INS ? "ins" : "del";
-                    *w++ = (uint8_t)tn[0]; *w++ = (uint8_t)tn[1]; *w++ = (uint8_t)tn[2];
-                    *w++ = '\t'; w = put_dec(w, len); *w++ = '\t';
-                    uint8_t *w2 = w + len + 1;
-                    // the letters of the event come from ONE word per 16 (payload_word: 2-bit fields / successive base-3 digits) — drawn
-                    // once per word here, not once per letter (ins_letter / mis_letter evaluate a Philox block per call)
-                    uint32_t frac = 0;
-                    for (uint32_t i = 0; i < len; ++i) {
-                        if (ty != NS_DEL && !(i & 15u)) frac = payload_word(key, pc.sid, a, p.n_ev - 1 - k, i >> 4);
-                        if (ty == NS_INS) { w[i] = '-'; w2[i] = bases_atcg((frac >> (2u * (i & 15u))) & 3u); }
-                        else {
-                            uint32_t x = e.pos + i;
-                            uint8_t cur = resolve_base(ref_base_at(A.ref, pc, x), key, pc.sid, a, x);
-                            w[i] = cur;
-                            w2[i] = (ty == NS_MIS) ? mis_from_digit(cur, next_digit3(frac)) : (uint8_t)'-';
-                        }
-                    }
-                    w[len] = '\t';
-                    w2[len] = '\n';
-                };
-                if (tail <= NS_ERR_STAGE) {                              // assembled in LDS, then two or three wide stores instead of ~25 byte stores
-                    fields(stage);
-                    uint32_t i = 0;
-                    for (; i + 16 <= tail; i += 16) { const uint4 v = *reinterpret_cast<const uint4 *>(stage + i); __builtin_memcpy(q + i, &v, 16); }
-                    if (tail & 15u) {
-                        const uint4 v = *reinterpret_cast<const uint4 *>(stage + i);
-                        store16(q + i, tail & 15u, (uint64_t)v.x | (uint64_t)v.y << 32, (uint64_t)v.z | (uint64_t)v.w << 32);
-                    }
-                } else fields(q);
+                fields(q + nl);
             }
             base += total;
         }
@@ -3128,7 +3168,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     if (side_names) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
     HIPCHK(hipEventRecord(ctx->evt[7], st));
     if (prm->emit_errlog && write_rec) {
-        k_errlog<<<grid_w, blk_w, 0, st>>>(A);
+        k_errlog<<<dim3((unsigned)n), dim3(64), 0, st>>>(A);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ctx->evt[8], st));

@@ -3,7 +3,7 @@
 # chr1_fastq_k5 = BASELINE configs[2], ecoli_fastq = configs[1] with --fastq) the bench line, the same command under --kernel-trace --stats, and separate PMC passes
 # (FETCH_SIZE / WRITE_SIZE / SQ counters; never together with the trace domains) on a 200k-read aligned launch.
 # Run on the GPU box through gpurun; outputs go to gpurun_out/<tag>/; afterwards, here: python scripts/summarise_pmc.py <tag>.
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG
 mkdir -p $O; cd /tmp; export TMPDIR=/tmp; ulimit -c 0
 run_cfg() {
@@ -19,7 +19,7 @@ run_cfg() {
 }
 CFGS=${CFGS:-"ecoli_fasta chr1_fasta chr1_fastq_k5 ecoli_fastq"}      # CFGS="ecoli_fastq" bash scripts/profile_round.sh r03: one configuration only
 want() { case " $CFGS " in *" $1 "*) return 0;; esac; return 1; }
-EXTRA=""                      # the default command: the line the driver records (with its e2e legs and its configs2 object)
+EXTRA="${EXTRA_FIRST:-}"       # the default command: the line the driver records (with its e2e legs and its configs2 object); EXTRA_FIRST="--no-e2e" skips the /dev/shm legs
 want ecoli_fasta && run_cfg ecoli_fasta
 EXTRA="--no-e2e --no-configs2"
 want chr1_fasta && run_cfg chr1_fasta --genome chr1
