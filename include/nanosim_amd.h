@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define NS_ABI_VERSION 4u
+#define NS_ABI_VERSION 5u
 
 /* error codes */
 #define NS_OK 0
@@ -327,6 +327,32 @@ typedef struct ns_io_stats {
     uint32_t n_slices, n_threads;
 } ns_io_stats;
 int ns_io_counters(ns_ctx *ctx, ns_io_stats *out, int reset);
+
+/* ---- training side: the histograms of the characterisation stage ---------------------------------------------------------------------
+ * replaces the counting loop of src/besthit_to_histogram.py:hist() (B:308-355 over parse_cs, B:42-72): from the cs strings of the primary
+ * alignments (minimap2's short form: `:N` match, `*xy` mismatch, `+seq` insertion, `-seq` deletion) to
+ *   dic[0..4]    run-length histograms of add_dict (B:14-22; values above 1000 are not counted): matches between errors, the first
+ *                match of every alignment, mismatch runs, insertions, deletions           -> _match.hist, _first_match.hist, _mis/_ins/_del.hist
+ *   match_list   (previous match, next match) counts of add_match (B:25-39; no upper limit) -> _match_markov_model
+ *   error_list   error transitions, row = mis, ins, del, mis0, ins0, del0 (the previous error, "0": no match in between), column = mis,
+ *                ins, del; first_error: the first error of every alignment                   -> _error_markov_model
+ * cs: the strings back to back, aln_off[n_aln + 1] their offsets (host memory; copied to the device).  The tables the reference writes
+ * from these counts are text formatting on the host (nanosim_amd/characterize.py).  match_list is a dense cap x cap matrix in caller-owned
+ * host memory: an add_match with an index >= cap is counted in n_match2d_overflow and max_match says how large the matrix has to be. */
+typedef struct ns_cs_hist {
+    uint32_t cap_match2d;         /* in */
+    uint32_t _pad;
+    uint64_t *match_list;         /* in: host buffer of cap_match2d * cap_match2d counters (row = previous match length), or NULL */
+    uint64_t dic[5][1001];        /* out: NS_CSH_MATCH, NS_CSH_FIRST_MATCH, NS_CSH_MIS, NS_CSH_INS, NS_CSH_DEL */
+    uint64_t error_list[18];
+    uint64_t first_error[3];
+    uint64_t max_match;           /* largest length handed to add_match */
+    uint64_t n_match2d_overflow;
+    uint64_t n_skip;              /* `=` items (long-form cs): the reference's two lists fall out of step on them — refuse the input */
+    double ms_kernel;
+} ns_cs_hist;
+enum { NS_CSH_MATCH = 0, NS_CSH_FIRST_MATCH = 1, NS_CSH_MIS = 2, NS_CSH_INS = 3, NS_CSH_DEL = 4 };
+int ns_cs_histograms(ns_ctx *ctx, const uint8_t *cs, uint64_t nbytes, const uint64_t *aln_off, uint32_t n_aln, ns_cs_hist *h);
 
 /* device address of a result buffer (for zero-copy consumers such as torch / RCCL); NULL if absent */
 const void *ns_device_ptr(ns_ctx *ctx, int which);

@@ -30,6 +30,7 @@
 #include "ns_hp.h"
 #include "ns_ir.h"
 #include "ns_io.h"
+#include "ns_cs_hist.h"
 
 // Reads per workgroup of the wave-per-read kernels.  One: read lengths vary by an order of magnitude inside a batch, and a wavefront
 // that is done cannot leave before the longest read of its workgroup is.
@@ -1560,6 +1561,60 @@ __global__ void __launch_bounds__(64) k_errlog(GenArgs A) {
             }
             base += total;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_cs_hist: the counting loop of the characterisation stage (ns_cs_hist.h; src/besthit_to_histogram.py:308-355), one alignment per
+// thread.  The 1-D histograms and the transition counters are privatised per workgroup in LDS (their hot bins — one-base mismatches,
+// short matches — would serialise millions of atomics on a few addresses) and flushed once; the (previous match, next match) matrix is
+// large and sparse: global atomics.
+// ---------------------------------------------------------------------------------------------------------
+struct CsHistDev {
+    unsigned long long *dic;          // [5][1001]
+    unsigned long long *err;          // [18] error_list, [3] first_error behind it
+    unsigned long long *misc;         // [0] max_match [1] match_list overflow [2] `=` items
+    unsigned long long *m2; uint32_t cap2;
+};
+#define NS_CSH_LDS_WORDS (5u * 1001u + 24u + 1u)
+struct CsAccDev {
+    uint32_t *l;                      // the workgroup's LDS counters: dic[5][1001], err[18], first[3], (3 spare), the largest match
+    const CsHistDev *H;
+    uint32_t mx;                      // largest length this thread handed to add_match
+    __device__ __forceinline__ void d1(uint32_t which, uint32_t v) { if (v <= NS_CS_DICT_MAX) atomicAdd(&l[which * 1001u + v], 1u); }
+    __device__ __forceinline__ void m2(uint32_t p, uint32_t s) {
+        const uint32_t m = p > s ? p : s;
+        mx = mx > m ? mx : m;
+        if (H->m2 && m < H->cap2) atomicAdd(&H->m2[(uint64_t)p * H->cap2 + s], 1ull);
+        else atomicAdd(&H->misc[1], 1ull);
+    }
+    __device__ __forceinline__ void err(uint32_t i) { atomicAdd(&l[5u * 1001u + i], 1u); }
+    __device__ __forceinline__ void first(uint32_t i) { atomicAdd(&l[5u * 1001u + 18u + i], 1u); }
+    __device__ __forceinline__ void skip() { atomicAdd(&H->misc[2], 1ull); }
+};
+__global__ void __launch_bounds__(256) k_cs_hist(const uint8_t *__restrict__ cs, const uint64_t *__restrict__ off, uint32_t n_aln, CsHistDev H) {
+    __shared__ uint32_t cnt[NS_CSH_LDS_WORDS];
+    for (uint32_t i = threadIdx.x; i < NS_CSH_LDS_WORDS; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
+    const uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < n_aln) {
+        const uint8_t *s = cs + off[a];
+        const uint64_t n = off[a + 1] - off[a];
+        // prev_match is only read before this alignment assigns it when its first op is an error: then it is what the alignments in
+        // front of it left (the reference never resets it between alignments)
+        uint32_t pm = 0;
+        { CsCursor c; cs_cursor_init(c); int t; uint32_t l; if (cs_next_op(s, n, c, t, l) && t != CS_MATCH) pm = cs_carry_in(cs, off, a); }
+        CsAccDev acc{cnt, &H, 0u};
+        cs_hist_alignment(s, n, pm, nullptr, acc);
+        if (acc.mx) atomicMax(&cnt[NS_CSH_LDS_WORDS - 1u], acc.mx);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < NS_CSH_LDS_WORDS; i += blockDim.x) {
+        const uint32_t v = cnt[i];
+        if (!v) continue;
+        if (i < 5u * 1001u) atomicAdd(&H.dic[i], (unsigned long long)v);
+        else if (i < NS_CSH_LDS_WORDS - 1u) atomicAdd(&H.err[i - 5u * 1001u], (unsigned long long)v);
+        else atomicMax(&H.misc[0], (unsigned long long)v);          // one atomic per workgroup for the largest match
     }
 }
 
@@ -3345,6 +3400,57 @@ int ns_io_counters(ns_ctx *ctx, ns_io_stats *out, int reset) {
     out->bytes = ctx->io->bytes; out->dma_ms = ctx->io->dma_ms; out->wait_staging_s = ctx->io->wait_free_s; out->write_s = ctx->io->write_s;
     out->slice_bytes = ctx->io->slice_bytes; out->n_slices = (uint32_t)ctx->io->slices.size(); out->n_threads = (uint32_t)ctx->io->writers.size();
     if (reset) { ctx->io->bytes = 0; ctx->io->dma_ms = ctx->io->wait_free_s = ctx->io->write_s = 0; }
+    return NS_OK;
+}
+
+// the characterisation stage's counting loop (include/nanosim_amd.h: ns_cs_hist; src/besthit_to_histogram.py:308-355)
+int ns_cs_histograms(ns_ctx *ctx, const uint8_t *cs, uint64_t nbytes, const uint64_t *aln_off, uint32_t n_aln, ns_cs_hist *h) {
+    if (!ctx) return NS_EINVAL;
+    if (!h || (n_aln && (!aln_off || (!cs && nbytes)))) return fail(ctx, NS_EINVAL, "ns_cs_histograms: null argument");
+    for (uint32_t a = 0; a < n_aln; ++a)
+        if (aln_off[a] > aln_off[a + 1] || aln_off[a + 1] > nbytes) return fail(ctx, NS_EINVAL, "ns_cs_histograms: offsets not ascending / beyond the strings");
+    const uint32_t cap = h->cap_match2d;
+    if (h->match_list && (!cap || cap > 65536u)) return fail(ctx, NS_EINVAL, "ns_cs_histograms: cap_match2d must be 1 .. 65536");
+    HIPCHK(hipSetDevice(ctx->device));
+    uint64_t *m2_host = h->match_list;
+    memset(h->dic, 0, sizeof h->dic); memset(h->error_list, 0, sizeof h->error_list); memset(h->first_error, 0, sizeof h->first_error);
+    h->max_match = h->n_match2d_overflow = h->n_skip = 0; h->ms_kernel = 0;
+    if (!n_aln) { if (m2_host) memset(m2_host, 0, (size_t)cap * cap * 8); return NS_OK; }
+    const size_t n_small = 5 * 1001 + 24 + 8;
+    void *d_cs = nullptr, *d_off = nullptr, *d_small = nullptr, *d_m2 = nullptr;
+    auto release = [&]() { for (void *p : {d_cs, d_off, d_small, d_m2}) if (p) { hipError_t e = hipFree(p); (void)e; } };
+    hipError_t e = hipMalloc(&d_cs, (size_t)nbytes + 16);
+    if (e == hipSuccess) e = hipMalloc(&d_off, ((size_t)n_aln + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc(&d_small, n_small * 8);
+    if (e == hipSuccess && m2_host) e = hipMalloc(&d_m2, (size_t)cap * cap * 8);
+    if (e != hipSuccess) { release(); (void)hipGetLastError(); return fail(ctx, NS_ENOMEM, std::string("ns_cs_histograms: hipMalloc: ") + hipGetErrorString(e)); }
+    hipStream_t st = ctx->stream;
+    e = hipMemcpyAsync(d_cs, cs, (size_t)nbytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, aln_off, ((size_t)n_aln + 1) * 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_small, 0, n_small * 8, st);
+    if (e == hipSuccess && d_m2) e = hipMemsetAsync(d_m2, 0, (size_t)cap * cap * 8, st);
+    if (e == hipSuccess) e = hipEventRecord(ctx->evt[14], st);
+    if (e == hipSuccess) {
+        CsHistDev H;
+        H.dic = (unsigned long long *)d_small; H.err = H.dic + 5 * 1001; H.misc = H.err + 24;
+        H.m2 = (unsigned long long *)d_m2; H.cap2 = cap;
+        k_cs_hist<<<dim3((n_aln + 255u) / 256u), dim3(256), 0, st>>>((const uint8_t *)d_cs, (const uint64_t *)d_off, n_aln, H);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipEventRecord(ctx->evt[15], st);
+    std::vector<unsigned long long> small(n_small);
+    if (e == hipSuccess) e = hipMemcpyAsync(small.data(), d_small, n_small * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && d_m2) e = hipMemcpyAsync(m2_host, d_m2, (size_t)cap * cap * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    float ms = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ctx->evt[14], ctx->evt[15]);
+    release();
+    if (e != hipSuccess) return fail(ctx, NS_EHIP, std::string("ns_cs_histograms: ") + hipGetErrorString(e));
+    for (int w = 0; w < 5; ++w) for (int v = 0; v <= 1000; ++v) h->dic[w][v] = small[(size_t)w * 1001 + v];
+    for (int i = 0; i < 18; ++i) h->error_list[i] = small[5 * 1001 + i];
+    for (int i = 0; i < 3; ++i) h->first_error[i] = small[5 * 1001 + 18 + i];
+    h->max_match = small[5 * 1001 + 24]; h->n_match2d_overflow = small[5 * 1001 + 25]; h->n_skip = small[5 * 1001 + 26];
+    h->ms_kernel = ms;
     return NS_OK;
 }
 

@@ -1,0 +1,120 @@
+// ns_cs_hist.h — training-side histogramming (second half): what src/besthit_to_histogram.py:hist() (B:148-486)
+// counts from the cs strings of the primary alignments — match / mismatch / insertion / deletion run lengths, the first match of every
+// alignment, the (previous match, next match) matrix behind _match_markov_model, and the error transitions behind _error_markov_model —
+// as ONE streaming pass per alignment.  B: = src/besthit_to_histogram.py of bcgsc/NanoSim v3.2.2.
+//
+// The reference works in two steps: parse_cs (B:42-72) turns the string into two lists (one entry per op, a run of `*xy` items folded
+// into one "mis" op that carries its count), then hist() walks the list with a little state (B:308-355): `flag` (no error seen yet in
+// this alignment), prev_error, prev_match, and two looks sideways — the op BEFORE an error (Python's list[i - 1]: for the first op
+// that is the LAST op of the alignment) and whether a match is the last op.  Both looks are local, so the walk streams: the items are
+// tokenised on the fly (the regex of B:45), folded, and an op is accounted for when the op behind it is known.
+// The code below compiles for the device (k_cs_hist) and, unchanged, for the host (tests/cs_hist_host.cpp: the CPU tests run the very
+// same walk against the oracle's two-list restatement and the reference's files).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define NS_CSH __host__ __device__ __forceinline__
+#else
+#define NS_CSH static inline
+#endif
+
+enum { CS_MATCH = 0, CS_MIS = 1, CS_INS = 2, CS_DEL = 3, CS_SKIP = 4 };         // conv_op_to_word (B:133-143)
+enum { CSH_MATCH = 0, CSH_FIRST = 1, CSH_MIS = 2, CSH_INS = 3, CSH_DEL = 4 };    // the five 1-D histograms (add_dict, B:14-22)
+#define NS_CS_DICT_MAX 1000u      // add_dict ignores values above it (B:15-16)
+
+// the next item of the cs string at or after i — re.findall('(:[0-9]+|\*[a-z][a-z]|[=\+\-][A-Za-z]+)') of B:45: what matches nothing
+// is skipped one character at a time
+NS_CSH bool cs_next_item(const uint8_t *s, uint64_t n, uint64_t &i, int &type, uint32_t &len) {
+    while (i < n) {
+        const uint8_t c = s[i];
+        if (c == ':') {
+            uint64_t j = i + 1, v = 0;
+            while (j < n && s[j] >= '0' && s[j] <= '9') { v = v * 10 + (uint64_t)(s[j] - '0'); if (v > 0xffffffffull) v = 0xffffffffull; ++j; }
+            if (j > i + 1) { type = CS_MATCH; len = (uint32_t)v; i = j; return true; }
+        } else if (c == '*') {
+            if (i + 2 < n && s[i + 1] >= 'a' && s[i + 1] <= 'z' && s[i + 2] >= 'a' && s[i + 2] <= 'z') { type = CS_MIS; len = 1; i += 3; return true; }
+        } else if (c == '+' || c == '-' || c == '=') {
+            uint64_t j = i + 1;
+            while (j < n && ((s[j] >= 'a' && s[j] <= 'z') || (s[j] >= 'A' && s[j] <= 'Z'))) ++j;
+            if (j > i + 1) { type = c == '+' ? CS_INS : c == '-' ? CS_DEL : CS_SKIP; len = (uint32_t)(j - i - 1); i = j; return true; }
+        }
+        ++i;
+    }
+    return false;
+}
+
+// the next op of the FOLDED list (list_op / list_hist of parse_cs): a run of mismatch items is one op whose length is their number
+struct CsCursor { uint64_t i; bool have; int type; uint32_t len; };
+NS_CSH void cs_cursor_init(CsCursor &c) { c.i = 0; c.have = false; c.type = CS_SKIP; c.len = 0; }
+NS_CSH bool cs_next_op(const uint8_t *s, uint64_t n, CsCursor &c, int &type, uint32_t &len) {
+    int t; uint32_t l;
+    if (!c.have) { if (!cs_next_item(s, n, c.i, t, l)) return false; c.have = true; c.type = t; c.len = l; }
+    type = c.type; len = c.len;
+    c.have = false;
+    if (type == CS_MIS) {                                       // fold the mismatch items that follow (B:50-53, 66-67)
+        while (cs_next_item(s, n, c.i, t, l)) {
+            if (t != CS_MIS) { c.have = true; c.type = t; c.len = l; break; }
+            ++len;
+        }
+    }
+    return true;
+}
+
+// the walk of hist() over one alignment (B:320-355).  prev_match: in = the value the previous alignments left (the reference never
+// resets it), out = what this one leaves; *assigned: the alignment assigned it.  n_skip counts `=` items (long-form cs): the reference's
+// two lists fall out of step on them, the caller refuses such input.
+template <class Acc>
+NS_CSH void cs_hist_alignment(const uint8_t *s, uint64_t n, uint32_t &prev_match, bool *assigned, Acc &acc) {
+    // the type of the last op: what list_op_unique[i - 1] is for i = 0 (B:324)
+    int last_type = CS_SKIP;
+    { CsCursor c; cs_cursor_init(c); int t; uint32_t l; while (cs_next_op(s, n, c, t, l)) last_type = t; }
+    CsCursor c; cs_cursor_init(c);
+    bool flag = true;
+    int prev_type = last_type, prev_error = CS_MIS;             // (prev_error: only read after an error of this alignment has set it)
+    int t; uint32_t l;
+    bool more = cs_next_op(s, n, c, t, l);
+    while (more) {
+        int tn = CS_SKIP; uint32_t ln = 0;
+        const bool has_next = cs_next_op(s, n, c, tn, ln);
+        if (t == CS_SKIP) acc.skip();
+        else if (t != CS_MATCH) {                               // B:323-343
+            const bool zero = prev_type != CS_MATCH;            // exact_prev_op != "match": prev_error += "0"
+            if (flag) { flag = false; acc.first((uint32_t)(t - CS_MIS)); }
+            else acc.err((uint32_t)((prev_error - CS_MIS) + (zero ? 3 : 0)) * 3u + (uint32_t)(t - CS_MIS));
+            prev_error = t;
+            if (t == CS_MIS) {
+                acc.d1(CSH_MIS, l);
+                if (zero) { acc.d1(CSH_MATCH, 0); acc.m2(prev_match, 0); prev_match = 0; if (assigned) *assigned = true; }
+            } else if (t == CS_DEL) acc.d1(CSH_DEL, l);
+            else acc.d1(CSH_INS, l);
+        } else {                                                // B:344-355
+            if (flag) { acc.d1(CSH_FIRST, l); prev_match = l; if (assigned) *assigned = true; }
+            else if (!has_next) acc.m2(prev_match, l);
+            else { acc.d1(CSH_MATCH, l); acc.m2(prev_match, l); prev_match = l; if (assigned) *assigned = true; }
+        }
+        if (t != CS_SKIP) prev_type = t;                        // (a `skip` op is not looked at by conv_op_to_word's callers: B:322)
+        else prev_type = CS_SKIP;
+        t = tn; l = ln; more = has_next;
+    }
+}
+
+// an accumulator that counts nothing: what an alignment leaves in prev_match
+struct CsAccNull {
+    NS_CSH void d1(uint32_t, uint32_t) {}
+    NS_CSH void m2(uint32_t, uint32_t) {}
+    NS_CSH void err(uint32_t) {}
+    NS_CSH void first(uint32_t) {}
+    NS_CSH void skip() {}
+};
+// prev_match in front of alignment a: the last value an earlier alignment assigned (0 in front of all of them: the reference would
+// stop with an UnboundLocalError there)
+NS_CSH uint32_t cs_carry_in(const uint8_t *cs, const uint64_t *off, uint64_t a) {
+    while (a > 0) {
+        --a;
+        uint32_t pm = 0; bool assigned = false; CsAccNull z;
+        cs_hist_alignment(cs + off[a], off[a + 1] - off[a], pm, &assigned, z);
+        if (assigned) return pm;
+    }
+    return 0;
+}

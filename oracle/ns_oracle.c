@@ -1620,3 +1620,104 @@ int nso_generate_meta(const ns_model_tables *t, const uint8_t *bases, const uint
     free(nseg_orig); free((void *)names);
     return rc;
 }
+
+/* ================================================================================================
+ * training side (second half): the counting loop of src/besthit_to_histogram.py:hist()
+ * B: = src/besthit_to_histogram.py.  PARITY: pinned against the files the reference's hist() writes for the
+ * alignments of tests/golden/reference_hist.json.gz (generated by tests/golden/make_hist_golden.py, which imports the
+ * module with a pysam stand-in that serves the cs strings).  Restated the way the reference does it — parse_cs builds
+ * two lists, hist() walks them with Python's list[i - 1] — so that it checks the engine's one-pass walk
+ * (nanosim_amd/csrc/ns_cs_hist.h) independently.
+ * ============================================================================================== */
+typedef struct { int64_t *hist; char *op; size_t n_hist, n_op, cap; } nso_cs_lists;
+static void cs_push_hist(nso_cs_lists *l, int64_t v) { if (l->n_hist + 1 > l->cap) { l->cap = 2 * l->cap + 64; l->hist = (int64_t *)realloc(l->hist, l->cap * sizeof(int64_t)); l->op = (char *)realloc(l->op, l->cap); } l->hist[l->n_hist++] = v; }
+static void cs_push_op(nso_cs_lists *l, char c) { if (l->n_op + 1 > l->cap) { l->cap = 2 * l->cap + 64; l->hist = (int64_t *)realloc(l->hist, l->cap * sizeof(int64_t)); l->op = (char *)realloc(l->op, l->cap); } l->op[l->n_op++] = c; }
+static int cs_is_alpha(uint8_t c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); }
+
+/* parse_cs (B:42-72): items of re.findall('(:[0-9]+|\*[a-z][a-z]|[=\+\-][A-Za-z]+)') */
+static void nso_parse_cs(const uint8_t *s, uint64_t n, nso_cs_lists *l) {
+    int64_t mis = 0;
+    int prev_mis = 0;                                  /* prev_op == "mis" (prev_op starts as "start") */
+    l->n_hist = l->n_op = 0;
+    uint64_t i = 0;
+    while (i < n) {
+        uint8_t c = s[i];
+        uint64_t j = i + 1;
+        int ok = 0;
+        if (c == ':') { while (j < n && s[j] >= '0' && s[j] <= '9') ++j; ok = j > i + 1; }
+        else if (c == '*') { ok = i + 2 < n && s[i + 1] >= 'a' && s[i + 1] <= 'z' && s[i + 2] >= 'a' && s[i + 2] <= 'z'; j = i + 3; }
+        else if (c == '+' || c == '-' || c == '=') { while (j < n && cs_is_alpha(s[j])) ++j; ok = j > i + 1; }
+        if (!ok) { ++i; continue; }
+        const int is_mis = c == '*';
+        if (!is_mis) cs_push_op(l, (char)c);                                   /* B:50-51 */
+        else if (!prev_mis) cs_push_op(l, (char)c);                            /* B:52-53 */
+        prev_mis = is_mis;
+        if (c == '+' || c == '-') {                                            /* B:55-59 */
+            if (mis != 0) { cs_push_hist(l, mis); mis = 0; }
+            cs_push_hist(l, (int64_t)(j - i - 1));
+        } else if (c == ':') {                                                 /* B:60-64 */
+            if (mis != 0) { cs_push_hist(l, mis); mis = 0; }
+            int64_t v = 0;
+            for (uint64_t k = i + 1; k < j; ++k) { v = v * 10 + (s[k] - '0'); if (v > 0xffffffffll) v = 0xffffffffll; }
+            cs_push_hist(l, v);
+        } else if (is_mis) mis += 1;                                           /* B:65-66 ("skip" items add nothing) */
+        i = j;
+    }
+    if (mis != 0) cs_push_hist(l, mis);                                        /* B:68-69 */
+}
+int nso_parse_cs_lists(const uint8_t *s, uint64_t n, int64_t *hist, char *op, uint32_t cap, uint32_t *n_hist, uint32_t *n_op) {
+    nso_cs_lists l; memset(&l, 0, sizeof l);
+    nso_parse_cs(s, n, &l);
+    *n_hist = (uint32_t)l.n_hist; *n_op = (uint32_t)l.n_op;
+    int rc = (l.n_hist > cap || l.n_op > cap) ? -1 : 0;
+    if (!rc) { memcpy(hist, l.hist, l.n_hist * sizeof(int64_t)); memcpy(op, l.op, l.n_op); }
+    free(l.hist); free(l.op);
+    return rc;
+}
+
+static int cs_word(char op) { return op == ':' ? 0 : op == '*' ? 1 : op == '+' ? 2 : op == '-' ? 3 : 4; }   /* conv_op_to_word: match mis ins del skip */
+
+/* hist(), the bam branch (B:308-355).  dic: [5][1001] = dic_match, dic_first_match, dic_mis, dic_ins, dic_del (add_dict, B:14-22);
+ * match_list: dense cap2 x cap2 (add_match, B:25-39); error_list: rows mis, ins, del, mis0, ins0, del0 x columns mis, ins, del.
+ * Returns 0; -2: list_hist shorter than list_op (an `=` item: the reference raises IndexError or counts garbage). */
+int nso_cs_hist(const uint8_t *cs, const uint64_t *off, uint32_t n_aln, uint32_t cap2, uint64_t *dic, uint64_t *match_list,
+                uint64_t *error_list, uint64_t *first_error, uint64_t *max_match, uint64_t *overflow) {
+    nso_cs_lists l; memset(&l, 0, sizeof l);
+    int64_t prev_match = 0;                            /* (the reference leaves it unbound in front of the first alignment) */
+    int prev_error = 1, rc = 0;
+    *max_match = 0; *overflow = 0;
+#define NSO_ADD_DICT(w, v) do { int64_t v_ = (v); if (v_ <= 1000) dic[(w) * 1001 + v_] += 1; } while (0)                 /* B:14-22 */
+#define NSO_ADD_MATCH(p, q) do { int64_t p_ = (p), q_ = (q), m_ = p_ > q_ ? p_ : q_; if ((uint64_t)m_ > *max_match) *max_match = (uint64_t)m_; \
+        if (match_list && m_ < (int64_t)cap2) match_list[(uint64_t)p_ * cap2 + (uint64_t)q_] += 1; else *overflow += 1; } while (0)
+    for (uint32_t a = 0; a < n_aln && !rc; ++a) {
+        nso_parse_cs(cs + off[a], off[a + 1] - off[a], &l);                    /* B:316 */
+        int flag = 1;                                                          /* B:318 */
+        for (size_t i = 0; i < l.n_op; ++i) {
+            const int curr = cs_word(l.op[i]);                                 /* B:320 */
+            if (curr == 4) continue;                                           /* B:321 */
+            if (i >= l.n_hist) { rc = -2; break; }
+            if (curr != 0) {                                                   /* B:322-343 */
+                const int exact_prev = cs_word(l.op[(i + l.n_op - 1) % l.n_op]);   /* list_op_unique[i - 1]: Python wraps for i = 0 */
+                int pe = prev_error;
+                if (exact_prev != 0) pe += 3;                                  /* prev_error += "0" */
+                if (flag) { flag = 0; first_error[curr - 1] += 1; }
+                else error_list[(pe - 1) * 3 + (curr - 1)] += 1;
+                prev_error = curr;
+                if (curr == 1) {
+                    NSO_ADD_DICT(2, l.hist[i]);
+                    if (exact_prev != 0) { NSO_ADD_DICT(0, 0); NSO_ADD_MATCH(prev_match, 0); prev_match = 0; }
+                } else if (curr == 3) NSO_ADD_DICT(4, l.hist[i]);
+                else NSO_ADD_DICT(3, l.hist[i]);
+            } else {                                                           /* B:344-355 */
+                const int64_t match = l.hist[i];
+                if (flag) { NSO_ADD_DICT(1, match); prev_match = match; }
+                else if (i == l.n_op - 1) NSO_ADD_MATCH(prev_match, match);
+                else { NSO_ADD_DICT(0, match); NSO_ADD_MATCH(prev_match, match); prev_match = match; }
+            }
+        }
+    }
+#undef NSO_ADD_DICT
+#undef NSO_ADD_MATCH
+    free(l.hist); free(l.op);
+    return rc;
+}

@@ -267,3 +267,43 @@ def generate_trx(model, tr, params: NsParams, *, ir=None, bytes_per_read=40000, 
     return dict(reads=reads, pieces=pieces[:o.n_pieces], events=events[:o.n_events], records=records[:o.record_bytes],
                 errlog=errlog[:o.errlog_bytes], total_bases=int(o.total_bases), total_ref_bases=int(o.total_ref_bases), polya=polya[:n],
                 spliced=spliced[:o.spliced_bytes])
+
+
+def _pack_cs(cs_list):
+    blobs = [c.encode() if isinstance(c, str) else bytes(c) for c in cs_list]
+    off = np.zeros(len(blobs) + 1, dtype=np.uint64)
+    np.cumsum([len(b) for b in blobs], out=off[1:])
+    return np.frombuffer(b"".join(blobs) + b"\0", dtype=np.uint8), off
+
+
+def cs_hist(cs_list, cap=2048):
+    """The counting loop of src/besthit_to_histogram.py:hist() through the oracle's two-list restatement (nso_cs_hist); same dict as
+    nanosim_amd.characterize.count"""
+    L = lib()
+    L.nso_cs_hist.restype = C.c_int
+    L.nso_cs_hist.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 6
+    data, off = _pack_cs(cs_list)
+    while True:
+        dic = np.zeros((5, 1001), dtype=np.uint64); m2 = np.zeros((cap, cap), dtype=np.uint64)
+        err = np.zeros(18, dtype=np.uint64); first = np.zeros(3, dtype=np.uint64); mx = np.zeros(2, dtype=np.uint64)
+        rc = L.nso_cs_hist(data.ctypes.data, off.ctypes.data, len(cs_list), cap, dic.ctypes.data, m2.ctypes.data, err.ctypes.data,
+                           first.ctypes.data, mx[0:].ctypes.data, mx[1:].ctypes.data)
+        if rc:
+            raise RuntimeError("nso_cs_hist failed: %d" % rc)
+        if not mx[1]:
+            break
+        cap = 1 << int(mx[0]).bit_length()
+    return dict(dic=dic, match_list=m2, error_list=err.reshape(6, 3), first_error=first, max_match=int(mx[0]))
+
+
+def parse_cs(cs):
+    """(list_hist, list_op) of the oracle's parse_cs restatement"""
+    L = lib()
+    L.nso_parse_cs_lists.restype = C.c_int
+    L.nso_parse_cs_lists.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_char_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    b = cs.encode()
+    cap = len(b) + 8
+    hist = np.zeros(cap, dtype=np.int64); op = C.create_string_buffer(cap)
+    nh, no = C.c_uint32(), C.c_uint32()
+    assert L.nso_parse_cs_lists(b, len(b), hist.ctypes.data, op, cap, C.byref(nh), C.byref(no)) == 0
+    return [int(x) for x in hist[:nh.value]], [chr(c) for c in op.raw[:no.value]]

@@ -1,0 +1,105 @@
+"""Training-side histogramming (second half) on CPU: the oracle's restatement of parse_cs / hist()'s counting loop,
+the host formatting of the reference's tables, and the engine's one-pass walk (compiled for the host) — all pinned against what the REAL
+src/besthit_to_histogram.py:hist() wrote for the same alignments (tests/golden/reference_hist.json.gz, tests/golden/make_hist_golden.py)."""
+import ctypes as C
+import gzip
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from nanosim_amd import characterize
+from tests import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def fx():
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "reference_hist.json.gz"), "rt") as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def host_walk():
+    """the engine's walk (nanosim_amd/csrc/ns_cs_hist.h) compiled for the host"""
+    out = os.path.join(ROOT, "tests", "_tmp")
+    os.makedirs(out, exist_ok=True)
+    so = os.path.join(out, "libcs_hist_host.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(ROOT, "tests", "cs_hist_host.cpp")])
+    L = C.CDLL(so)
+    L.csh_host_count.restype = C.c_int
+    L.csh_host_count.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 5
+
+    def run(cs_list, cap=2048):
+        data, off = O._pack_cs(cs_list)
+        while True:
+            dic = np.zeros((5, 1001), dtype=np.uint64); m2 = np.zeros((cap, cap), dtype=np.uint64)
+            err = np.zeros(18, dtype=np.uint64); first = np.zeros(3, dtype=np.uint64); misc = np.zeros(4, dtype=np.uint64)
+            L.csh_host_count(data.ctypes.data, off.ctypes.data, len(cs_list), cap, dic.ctypes.data, m2.ctypes.data, err.ctypes.data,
+                             first.ctypes.data, misc.ctypes.data)
+            if not misc[1]:
+                break
+            cap = 1 << int(misc[0]).bit_length()
+        return dict(dic=dic, match_list=m2, error_list=err.reshape(6, 3), first_error=first, max_match=int(misc[0]), n_skip=int(misc[2]))
+    return run
+
+
+def same_counts(a, b):
+    k = min(a["match_list"].shape[0], b["match_list"].shape[0])
+    assert np.array_equal(a["dic"], b["dic"]) and np.array_equal(a["error_list"], b["error_list"])
+    assert np.array_equal(a["first_error"], b["first_error"]) and a["max_match"] == b["max_match"] < k
+    assert np.array_equal(a["match_list"][:k, :k], b["match_list"][:k, :k])
+
+
+def test_parse_cs_matches_the_reference(fx):
+    for cs, (hist, op) in zip(fx["cs"][-8:], fx["parse_cs_tail"]):
+        assert O.parse_cs(cs) == (hist, op), cs
+
+
+def test_oracle_counts_give_the_reference_files(fx):
+    """oracle (two lists, Python's list[i - 1]) -> counts -> the host's formatting == every file hist() wrote, text for text"""
+    t = O.cs_hist(fx["cs"])
+    got = characterize.format_tables(t)
+    assert sorted(got) == sorted(fx["files"])
+    for name, text in fx["files"].items():
+        assert got[name] == text, name
+
+
+def test_one_pass_walk_equals_the_two_list_restatement(fx, host_walk):
+    """the code k_cs_hist runs per thread, on the host: same counts as the oracle, hence the reference's files"""
+    w = host_walk(fx["cs"])
+    same_counts(w, O.cs_hist(fx["cs"]))
+    assert w["n_skip"] == 0
+    got = characterize.format_tables(w)
+    for name, text in fx["files"].items():
+        assert got[name] == text, name
+
+
+def test_walk_edge_cases(host_walk):
+    """what the fixture's reads do not do: an alignment that starts with an error takes prev_match from the alignments in front of it
+    (the reference never resets it), also across alignments that assign nothing; errors only; empty strings; junk; `=` items are counted"""
+    cases = [[":5*ag:3", "*ac:7", ":2"],                       # 2nd starts with mis after a match-ending alignment: list_op[-1] is a match
+             [":9-a", "+g:4", "-t", "*ac*gt", ":3+a:2"],        # errors at the ends: the wrap of list_op[i - 1], carries through "-t"
+             ["", "*ag", "", "+a-c*gt", ":1"],
+             ["garbage", ":12", "::7*a1*ab:3"],
+             [":1200*ct:2300-a:5", ":4+c:2500"]]
+    for cs in cases:
+        same_counts(host_walk(cs, cap=64), O.cs_hist(cs, cap=64))
+    assert host_walk([":4=ACG:2"])["n_skip"] == 1
+
+
+def test_get_cs_and_sam_reader(fx, tmp_path):
+    """cs from CIGAR + MD (B:79-130) — against the reference's own get_cs on recorded inputs — and the SAM reader"""
+    for cigar, md, cs in fx["get_cs"]:
+        assert characterize.get_cs(cigar, md) == cs, (cigar, md)
+    assert characterize.get_cs("10M", "10") == ":10"
+    assert characterize.get_cs("5M2I5M", "10") == ":5+II:5"
+    assert characterize.get_cs("4M1D6M", "4^A6") == ":4-A:6"
+    assert characterize.get_cs("3S7M", "3C3") == ":3*ab:3"
+    sam = tmp_path / "a.sam"
+    sam.write_text("@HD\tVN:1.6\nr1\t0\tchr\t1\t60\t10M\t*\t0\t0\tACGTACGTAC\t*\tcs:Z::4*ag:5\nr2\t0\tchr\t1\t60\t5M2I5M\t*\t0\t0\tACGTACGTACGT\t*\tMD:Z:10\n"
+                   "r3\t4\t*\t0\t0\t*\t*\t0\t0\tACGT\t*\n")
+    assert characterize.cs_from_sam(str(sam)) == [":4*ag:5", ":5+II:5"]

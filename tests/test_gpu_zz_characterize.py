@@ -1,0 +1,53 @@
+"""GPU parity of the training-side histogramming (second half): ns_cs_histograms (k_cs_hist, one alignment per thread)
+against the oracle's two-list restatement of src/besthit_to_histogram.py:hist() and against the files the reference itself wrote
+(tests/golden/reference_hist.json.gz).  (The file sorts behind the other -m gpu files on purpose: it is the newest kernel of the engine.)"""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+from nanosim_amd import characterize
+from nanosim_amd import engine as E
+from tests import oracle_lib as O
+from tests.test_characterize import same_counts
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def fx():
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "reference_hist.json.gz"), "rt") as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = E.Engine(0)
+    yield e
+    e.close()
+
+
+def test_gpu_counts_equal_the_oracle_and_the_reference_files(fx, eng, tmp_path):
+    t = characterize.count(eng, fx["cs"], cap=256)            # (256 < the fixture's longest match: the matrix is sized again)
+    same_counts(t, O.cs_hist(fx["cs"]))
+    prefix = str(tmp_path / "training_genome")
+    characterize.hist(prefix, fx["cs"], eng)                  # B:150-151: "_genome" is cut off the prefix
+    for name, text in fx["files"].items():
+        assert open(str(tmp_path / "training") + name).read() == text, name
+
+
+def test_gpu_edge_cases_and_many_alignments(fx, eng):
+    for cs in ([":5*ag:3", "*ac:7", ":2"], [":9-a", "+g:4", "-t", "*ac*gt", ":3+a:2"], ["", "*ag", "", "+a-c*gt", ":1"], ["garbage", ":12", "::7*a1*ab:3"]):
+        same_counts(characterize.count(eng, cs, cap=64), O.cs_hist(cs, cap=64))
+    with pytest.raises(ValueError):
+        characterize.count(eng, [":4=ACG:2"])
+    assert characterize.count(eng, [])["dic"].sum() == 0
+    # 40 x the fixture, shuffled: several workgroups, the carry of prev_match across alignments that start with an error
+    rng = np.random.default_rng(3)
+    many = [fx["cs"][i] for i in rng.integers(0, len(fx["cs"]), 40 * len(fx["cs"]))] + ["*ag:3", "+c", "-g*ac:9"]
+    t = characterize.count(eng, many)
+    same_counts(t, O.cs_hist(many))
+    assert t["ms_kernel"] > 0
