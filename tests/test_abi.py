@@ -46,6 +46,8 @@ int main(void) {
          sizeof(ns_event), sizeof(ns_piece), sizeof(ns_read), sizeof(ns_hp_class));
   printf("%zu %zu %zu %zu %zu\n", offsetof(ns_model_tables, trans), offsetof(ns_model_tables, kde),
          offsetof(ns_model_tables, qual_thr), offsetof(ns_model_tables, hp), offsetof(ns_params, min_len));
+  printf("%zu %zu %zu %zu %zu\n", sizeof(ns_cs_hist), offsetof(ns_cs_hist, dic), offsetof(ns_cs_hist, error_list),
+         offsetof(ns_cs_hist, max_match), offsetof(ns_cs_hist, ms_kernel));
   return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "t.c")
@@ -58,7 +60,9 @@ int main(void) {
     assert sizes[:7] == [C.sizeof(T), C.sizeof(model.NsParams), C.sizeof(model.NsBatchInfo),
                          model.EVENT_DTYPE.itemsize, model.PIECE_DTYPE.itemsize, model.READ_DTYPE.itemsize,
                          C.sizeof(model.NsHpClass)]
-    assert sizes[7:] == [T.trans.offset, T.kde.offset, T.qual_thr.offset, T.hp.offset, model.NsParams.min_len.offset]
+    assert sizes[7:12] == [T.trans.offset, T.kde.offset, T.qual_thr.offset, T.hp.offset, model.NsParams.min_len.offset]
+    from nanosim_amd.characterize import NsCsHist as H
+    assert sizes[12:] == [C.sizeof(H), H.dic.offset, H.error_list.offset, H.max_match.offset, H.ms_kernel.offset]
 
 
 def test_no_gpu_means_loud_failure(lib):
