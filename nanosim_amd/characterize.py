@@ -31,38 +31,50 @@ class NsCsHist(C.Structure):
                 ("n_match2d_overflow", C.c_uint64), ("n_skip", C.c_uint64), ("ms_kernel", C.c_double)]
 
 
+_MD_TOKEN = re.compile(r'(\d+)|(\^[A-Za-z]+)|([A-Za-z])')
+_CIGAR_TOKEN = re.compile(r'(\d+)([MIDSHX=])')          # (no N: introns are not looked for, as in the reference)
+
+
 def get_cs(cigar_str: str, md_str: str) -> str:
-    """the cs string of an alignment that carries only CIGAR + MD (B:79-130); arbitrary bases stand for the real ones, as there"""
-    cs = []
-    k = cx = cy = mx = my = 0
-    md = re.findall(r'(\d+)|(\^[A-Za-z]+)|([A-Za-z])', md_str)
-    cigar = re.findall(r'(\d+)([MIDSHX=])', cigar_str)
-    for m in md:
-        if m[1] != "":
-            ln = len(m[1]) - 1
-            cs.extend(["-", m[1][1:]])
-            mx += ln; cx += ln; k += 1
-        else:
-            ml = int(m[0]) if m[0] != "" else 1
-            while k < len(cigar) and cigar[k][1] != 'D':
-                cl, op = int(cigar[k][0]), cigar[k][1]
-                if op == "M":
-                    if my + ml < cy + cl:
-                        if ml > 0:
-                            cs.extend(['*', 'a', 'b'] if m[2] != "" else [':', ml])
-                        mx += ml; my += ml; ml = 0
-                        break
-                    dl = cy + cl - my
-                    cs.extend([':', dl])
-                    cx += cl; cy += cl; k += 1; mx += dl; my += dl; ml -= dl
-                elif op == 'I':
-                    cs.extend(['+', 'I' * cl])
-                    cy += cl; my += cl; k += 1
-                elif op == 'S':
-                    cy += cl; my += cl; k += 1
-                else:                                       # (H, X, = : the reference spins for ever on these; minimap2 -a emits M/I/D/S)
-                    raise ValueError("CIGAR operation %r is not handled by get_cs (src/besthit_to_histogram.py:99-127)" % op)
-    return "".join(str(x) for x in cs)
+    """The cs string the reference derives for an alignment that carries only CIGAR + MD (B:79-130).  It models indels and mismatches,
+    not bases: a mismatch is always `*ab`, an inserted base `I`.  Written as a walk of the MD items over a cursor into the CIGAR; the
+    reference's corner behaviour is kept because its histograms depend on it: an MD item that ends exactly where an M block ends closes
+    the block as a MATCH of the remaining length (so a mismatch in the last column of a block counts as `:1`, and an item that starts at
+    a block end leaves a `:0`), and the items behind an insertion start with whatever is left of the MD count."""
+    blocks = [(int(n), op) for n, op in _CIGAR_TOKEN.findall(cigar_str)]
+    out = []
+    at = 0              # cursor into `blocks`
+    block_end = 0       # query-side end of the blocks consumed so far (M, I and S advance it)
+    md_pos = 0          # how far the MD items have come on the same axis
+    for count, deleted, base in _MD_TOKEN.findall(md_str):
+        if deleted:
+            out.append("-" + deleted[1:])
+            at += 1                                         # the D block that carries it
+            continue
+        left = int(count) if count else 1
+        while at < len(blocks) and blocks[at][1] != 'D':
+            size, op = blocks[at]
+            if op == 'I':
+                out.append("+" + "I" * size)
+            elif op == 'M':
+                if md_pos + left < block_end + size:        # the item ends inside this block
+                    if left > 0:
+                        out.append("*ab" if base else ":%d" % left)
+                    md_pos += left
+                    break
+                rest = block_end + size - md_pos            # ... or runs to its end: the rest of the block is a match
+                out.append(":%d" % rest)
+                md_pos += rest
+                left -= rest
+                block_end += size
+                at += 1
+                continue
+            elif op != 'S':                                 # (H, X, = : the reference never advances on these; minimap2 -a writes M/I/D/S)
+                raise ValueError("CIGAR operation %r is not handled by get_cs (src/besthit_to_histogram.py:99-127)" % op)
+            block_end += size
+            md_pos += size
+            at += 1
+    return "".join(out)
 
 
 def cs_from_sam(path: str):
@@ -148,46 +160,41 @@ def format_tables(t: dict) -> dict:
         for c in range(3):
             s += "\t" + ("0" if pred == 0 else str(int(err[r][c]) * 1.0 / pred))
     out["_error_markov_model"] = s
-    # match Markov model (B:411-466): 15 bins of the previous match length with about count / 15 events each
+    # match Markov model (B:411-466).  The previous-match lengths are cut into <= 15 consecutive bins of about total / 15 pairs each:
+    # a bin takes rows while it is below the target and stops in front of a row that would carry it further from the target than it is
+    # (never in front of its first row); rows left over behind the 15th bin are added to its counts (its label keeps the old end)
     n = max(150, t["max_match"] + 1)
-    ml = np.zeros((n, n), dtype=np.int64)
+    pairs = np.zeros((n, n), dtype=np.int64)
     k = min(n, m2.shape[0])
-    ml[:k, :k] = m2[:k, :k]
-    row_sum = [int(x) for x in ml.sum(axis=1)]
-    total = sum(row_sum)
-    bin_size = total / 15
-    k_of_bin = k_of_ml = last_k = 0
-    count_each_bin, match_bin = {}, {}
-    while k_of_bin < 15:
-        if k_of_ml >= n:
-            break
-        match_bin[k_of_bin] = np.zeros(n, dtype=np.int64)
-        tmp = 0
-        while tmp < bin_size and k_of_ml < n:
-            new_added = row_sum[k_of_ml]
-            if abs(tmp + new_added - bin_size) > abs(tmp - bin_size) and tmp != 0:
+    pairs[:k, :k] = m2[:k, :k]
+    per_row = [int(x) for x in pairs.sum(axis=1)]
+    target = sum(per_row) / 15
+    edges, sizes = [], []                 # (first row, one past the last row) and the pairs of every bin
+    row = 0
+    while len(edges) < 15 and row < n:
+        start, got = row, 0
+        while got < target and row < n:
+            if got != 0 and abs(got + per_row[row] - target) > abs(got - target):
                 break
-            tmp += new_added
-            k_of_ml += 1
-        if k_of_ml > last_k:
-            match_bin[k_of_bin] += ml[last_k:k_of_ml].sum(axis=0)
-        count_each_bin[k_of_bin] = [(last_k, k_of_ml), tmp]
-        last_k = k_of_ml
-        k_of_bin += 1
-    if k_of_ml < n:
-        match_bin[k_of_bin - 1] += ml[last_k:n].sum(axis=0)
-        count_each_bin[k_of_bin - 1][1] += sum(row_sum[last_k:n])
-    count_prob = [0] * len(match_bin)
-    lines = ["bins\t" + "\t".join("%s-%s" % tup[0] for tup in count_each_bin.values()) + '\n']
+            got += per_row[row]
+            row += 1
+        edges.append((start, row))
+        sizes.append(got)
+    cols = [pairs[lo:hi].sum(axis=0) if hi > lo else np.zeros(n, dtype=np.int64) for lo, hi in edges]
+    if row < n:
+        cols[-1] = cols[-1] + pairs[row:n].sum(axis=0)
+        sizes[-1] += sum(per_row[row:n])
+    running = [0] * len(edges)
+    lines = ["bins\t" + "\t".join("%s-%s" % e for e in edges) + '\n']
     for i in range(n):
-        row = [str(i) + "-" + str(i + 1)]
-        for kb in match_bin:
-            if count_each_bin[kb][1] == 0:
-                row.append("\t" + "0")
+        cells = [str(i) + "-" + str(i + 1)]
+        for j in range(len(edges)):
+            if sizes[j] == 0:
+                cells.append("0")
             else:
-                count_prob[kb] += int(match_bin[kb][i]) * 1.0 / count_each_bin[kb][1]
-                row.append("\t" + str(count_prob[kb]))
-        lines.append("".join(row) + '\n')
+                running[j] += int(cols[j][i]) * 1.0 / sizes[j]
+                cells.append(str(running[j]))
+        lines.append("\t".join(cells) + '\n')
     out["_match_markov_model"] = "".join(lines)
     # first match profile (B:468-476)
     nf = _dict_len(dic[1], 150)

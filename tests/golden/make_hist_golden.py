@@ -96,6 +96,40 @@ def run_reference(cs_list, workdir):
     parsed = [list(map(list, B.parse_cs(c))) for c in cs_list[-8:]]          # parse_cs of the hand-made cases: (list_hist, list_op)
     cigar_md = [("10M", "10"), ("5M2I5M", "10"), ("4M1D6M", "4^A6"), ("3S7M", "3C3"), ("20M3I10M2D15M5S", "12A7T9^CG3G11"),
                 ("2S8M1I4M1D9M", "3T4G3^A0C8"), ("50M", "0A48C0"), ("6M2D6M2I6M", "6^TT1A10")]
+    # ... and 300 random alignments (soft clips at the ends; matches with mismatches inside, insertions, deletions in between; the MD
+    # string derived the way aligners write it: match counts, mismatched reference bases, ^deleted bases, a 0 between two non-matches)
+    rng = np.random.default_rng(99)
+    for _ in range(300):
+        ops, md, run = [], [], 0
+        if rng.random() < 0.3:
+            ops.append("%dS" % rng.integers(1, 30))
+        n_blocks = int(rng.integers(1, 8))
+        prev = None
+        for b in range(n_blocks):
+            kind = "M" if b % 2 == 0 or prev != "M" else ("I" if rng.random() < 0.5 else "D")
+            if kind == "M":
+                ln = int(rng.integers(1, 60))
+                ops.append("%dM" % ln)
+                i = 0
+                while i < ln:
+                    if rng.random() < 0.08:
+                        md.append(str(run)); md.append("ACGT"[int(rng.integers(0, 4))]); run = 0
+                    else:
+                        run += 1
+                    i += 1
+            elif kind == "I":
+                ops.append("%dI" % rng.integers(1, 6))
+            else:
+                ln = int(rng.integers(1, 6))
+                ops.append("%dD" % ln)
+                md.append(str(run)); md.append("^" + "".join("ACGT"[int(x)] for x in rng.integers(0, 4, ln))); run = 0
+            prev = kind
+        if prev != "M":
+            ln = int(rng.integers(1, 40)); ops.append("%dM" % ln); run += ln
+        md.append(str(run))
+        if rng.random() < 0.3:
+            ops.append("%dS" % rng.integers(1, 30))
+        cigar_md.append(("".join(ops), "".join(md)))
     getcs = [[c, m, B.get_cs(c, m)] for c, m in cigar_md]                      # get_cs (B:79-130) by value
     return files, parsed, getcs
 
