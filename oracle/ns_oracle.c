@@ -6,7 +6,8 @@
  * only as the checker.
  *
  * Every function cites the reference lines it follows (S: = /root/reference/src/simulator.py,
- * mm: = src/mixed_model.py, hp: = src/model_homopolymer_lengths.py, bq: = src/model_base_qualities.py).
+ * mm: = src/mixed_model.py, hp: = src/model_homopolymer_lengths.py, bq: = src/model_base_qualities.py,
+ * B: = src/besthit_to_histogram.py — the training side's counting loop, at the end of the file).
  *
  * Two draw sources:
  *   NSO_PHILOX  counter-based draws with the layout of DESIGN.md §4 — the HIP kernels must reproduce
@@ -14,8 +15,8 @@
  *   NSO_TAPE    uniforms / run lengths / normals are popped from tapes recorded while running the REAL
  *               reference (tests/golden/make_golden.py) — this is how the restatement is pinned.
  *
- * Parity status: pinned against outputs of the imported reference (tests/golden/*.json); the reference
- * itself has no tests.
+ * Parity status: pinned against outputs of the imported reference (tests/golden/*.json, reference_hist.json.gz);
+ * the reference itself has no tests.
  *
  * Build: make -C oracle   (gcc -O2 -ffp-contract=off; fma() only where written).
  */
