@@ -1424,11 +1424,32 @@ int nso_generate(const ns_model_tables *t, const uint8_t *bases, const uint64_t 
 #define NSO_TRX_BLOCK 1024u
 #define NSO_TRX_MAX_PICKS (1u << 22)
 
+/* the state of the walk: which KDE sample ("epoch") is current, and for every transcript the last sample it was looked up under and
+ * whether that look-up passed S:1103-1104 */
+typedef struct trx_walk {
+    uint32_t *seen_epoch; uint8_t *ok_epoch;      /* per entry of the expression list */
+    uint32_t *epoch_io;                           /* sample counter of the run (never reused, so the arrays need no clearing) */
+    uint32_t epoch;
+} trx_walk;
+static void trx_walk_start(trx_walk *wk) { wk->epoch = ++*wk->epoch_io; }
+/* pick of transcript e.  Returns 1 when the pick needs a look-up (first pick of e under the current sample — which is a NEW sample when e
+ * passed earlier under the old one, S:1087-1092: *redraw = 1), 0 when e failed before under this sample (the same nearest point, the same
+ * failure: S:1098-1104 with an unchanged sampled_2d_lengths) */
+static int trx_walk_visit(trx_walk *wk, uint32_t e, int *redraw) {
+    int in_epoch = wk->seen_epoch[e] == wk->epoch;
+    *redraw = 0;
+    if (in_epoch && wk->ok_epoch[e]) { wk->epoch = ++*wk->epoch_io; in_epoch = 0; *redraw = 1; }      /* new sample, trx_sampled = set() */
+    return !in_epoch;
+}
+static void trx_walk_record(trx_walk *wk, uint32_t e, int good) { wk->seen_epoch[e] = wk->epoch; wk->ok_epoch[e] = (uint8_t)good; }
+
 static int trx_block(const ns_model_tables *t, const nso_ref *ref, const ns_params *prm, const nso_trx *tx, uint64_t b, nso_out *o,
                      nso_out *dry, uint32_t *seen_epoch, uint8_t *ok_epoch, uint32_t *epoch_io) {
     const uint64_t W = NSO_TRX_BLOCK, g0 = prm->first_read, g1 = g0 + prm->n_reads;
     nso_draw db; memset(&db, 0, sizeof db); db.seed = prm->seed; db.read = b * W;
-    uint32_t epoch = ++*epoch_io, w[4];
+    trx_walk wk = {seen_epoch, ok_epoch, epoch_io, 0};
+    trx_walk_start(&wk);
+    uint32_t w[4];
     uint64_t acc = 0, c = 0;
     for (uint32_t j = 0; acc < W && b * W + acc < g1; ++j) {
         if (j >= NSO_TRX_MAX_PICKS) return -41;
@@ -1436,12 +1457,11 @@ static int trx_block(const ns_model_tables *t, const nso_ref *ref, const ns_para
         const uint32_t e = nso_trx_pick(tx, u53_to_p(w[0], w[1]));
         const uint32_t chrom = tx->expr_chrom[e];
         const int64_t L = (int64_t)(ref->chrom_off[chrom + 1] - ref->chrom_off[chrom]);
-        int in_epoch = seen_epoch[e] == epoch;
-        if (in_epoch && ok_epoch[e]) { epoch = ++*epoch_io; in_epoch = 0; }          /* S:1087-1092: new sample, trx_sampled = set() */
-        if (in_epoch) continue;                          /* failed before under this sample: the same nearest point, the same failure */
+        int redraw;
+        if (!trx_walk_visit(&wk, e, &redraw)) continue;
         const int64_t y = nso_kde2d_cond(t, (double)L, &db, 0, 1u + j);
         const int good = y > 0 && y < L;                 /* S:1103-1104 */
-        seen_epoch[e] = epoch; ok_epoch[e] = (uint8_t)good;
+        trx_walk_record(&wk, e, good);
         if (!good) continue;
         if (c >= 2 * W) return -42;
         nso_tread tr; tr.key_read = b * W + c % W; tr.attempt = (uint32_t)(c / W); tr.chrom = chrom; tr.ref_len = y;
@@ -1494,6 +1514,35 @@ int nso_generate_trx(const ns_model_tables *t, const uint8_t *bases, const uint6
     }
     free((void *)names);
     return rc;
+}
+
+/* The walk of trx_block over a TAPE of the reference's own picks (tests/golden/reference_trx_walk.json): pick j is transcript pick_e[j] of
+ * length L[pick_e[j]], and pick_y[j] is the ref_len_aligned the reference looked up for it.  Where the walk needs a look-up it takes the
+ * tape's value; where it says "failed before under this sample" it reports the pick whose look-up it relies on (memo_of[j]; -1
+ * otherwise) so that the test can check that the reference saw the same value there.  accept[j] / redraw[j] are what the reference
+ * recorded as "left the inner loop" (S:1103-1104) / "drew a new sample" (S:1087-1092).  Returns the number of samples used. */
+uint32_t nso_trx_walk_tape(uint32_t n_picks, const uint32_t *pick_e, const int64_t *pick_y, uint32_t n_expr, const int64_t *L,
+                           uint8_t *accept, uint8_t *redraw, int64_t *memo_of) {
+    uint32_t *seen = (uint32_t *)calloc(n_expr + 1, sizeof(uint32_t));
+    uint8_t *okf = (uint8_t *)calloc(n_expr + 1, 1);
+    int64_t *last = (int64_t *)malloc(sizeof(int64_t) * (n_expr + 1));
+    uint32_t epoch = 0;
+    trx_walk wk = {seen, okf, &epoch, 0};
+    trx_walk_start(&wk);
+    for (uint32_t j = 0; j < n_picks; ++j) {
+        const uint32_t e = pick_e[j];
+        int rd;
+        accept[j] = 0; memo_of[j] = -1;
+        const int look = trx_walk_visit(&wk, e, &rd);
+        redraw[j] = (uint8_t)rd;
+        if (!look) { memo_of[j] = last[e]; continue; }
+        const int good = pick_y[j] > 0 && pick_y[j] < L[e];
+        trx_walk_record(&wk, e, good);
+        last[e] = (int64_t)j;
+        accept[j] = (uint8_t)good;
+    }
+    free(seen); free(okf); free(last);
+    return epoch;
 }
 
 /* ------------------------------------------------------------------------------------------------

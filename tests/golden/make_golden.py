@@ -792,6 +792,54 @@ def fixture_transcriptome(S, prefix):
     return fx
 
 
+def fixture_trx_walk(S, prefix, n_reads=4000):
+    """The transcript pick walk of simulation_aligned_transcriptome (S:1080-1104) as a TAPE: the reference's worker runs with
+    random.choices, get_length_kde(kde_aligned_2d) and select_nearest_kde2d wrapped, and the fixture keeps, for every pick in order,
+    [index of the transcript in ecdf_length_list, the ref_len_aligned the reference looked up, 1 if a new KDE sample was drawn before the
+    look-up (S:1087-1092), 1 if the pick ended the inner loop (S:1103-1104)] — plus the transcripts of the reads the worker wrote, which
+    must be the accepted picks in order.  tests/test_transcriptome.py replays the picks and look-ups through the oracle's walk."""
+    _trx_profile(S, prefix, perfect=True)
+    S.total_simulated = mp.Value("i", 0, lock=True)
+    random.seed(2718); np.random.seed(2718)
+    index_of = {name: i for i, (name, _) in enumerate(S.ecdf_length_list)}
+    st = {"sample": 0, "at_pick": 0}
+    picks = []
+    o_choices, o_glk, o_near = random.choices, S.get_length_kde, S.select_nearest_kde2d
+
+    def choices(population, *a, **k):
+        out = o_choices(population, *a, **k)
+        if population is S.ecdf_length_list:
+            st["at_pick"] = st["sample"]
+            picks.append([index_of[out[0][0]], None, None, None])
+        return out
+
+    def glk(kde, *a, **k):
+        if kde is S.kde_aligned_2d:
+            st["sample"] += 1
+        return o_glk(kde, *a, **k)
+
+    def near(sampled, ref_len_total):
+        y = o_near(sampled, ref_len_total)
+        pk = picks[-1]
+        pk[1], pk[2], pk[3] = int(y), int(st["sample"] != st["at_pick"]), int(y < ref_len_total)
+        return y
+    random.choices, S.get_length_kde, S.select_nearest_kde2d = choices, glk, near
+    workdir = tempfile.mkdtemp(prefix="nsgolden_walk_")
+    so, se = sys.stdout, sys.stderr
+    sys.stdout = open(os.devnull, "w"); sys.stderr = open(os.devnull, "w")
+    try:
+        S.simulation_aligned_transcriptome(False, os.path.join(workdir, "r.fasta"), os.path.join(workdir, "e"), None, "guppy", n_reads, True,
+                                           False, True, False)
+        lines = open(os.path.join(workdir, "r.fasta")).read().split("\n")
+    finally:
+        sys.stdout, sys.stderr = so, se
+        random.choices, S.get_length_kde, S.select_nearest_kde2d = o_choices, o_glk, o_near
+        shutil.rmtree(workdir, ignore_errors=True)
+    written = [index_of[x[1:].partition("_perfect_")[0].rsplit("_", 1)[0]] for x in lines[0:-1:2]]
+    assert all(p[1] is not None for p in picks)
+    return dict(n_reads=n_reads, n_samples=st["sample"], lengths=[int(v) for _, v in S.ecdf_length_list], picks=picks, written=written)
+
+
 def _trx_worker(args):
     idx, n_al, prefix, workdir, perfect, uracil = args
     S = import_reference()
@@ -1002,6 +1050,7 @@ def main():
     ap.add_argument("--only-trx", action="store_true", help="write reference_transcriptome.json only")
     ap.add_argument("--only-ir", action="store_true", help="write the intron-retention inputs and reference_ir.json only")
     ap.add_argument("--only-ir-splice", action="store_true", help="write reference_ir_splice.json only (the intron splice of the transcriptome worker)")
+    ap.add_argument("--only-trx-walk", action="store_true", help="write reference_trx_walk.json only (the pick walk of the transcriptome worker as a tape)")
     ap.add_argument("--only-chimeric-dense", action="store_true",
                     help="write reference_chimeric_dense.json only: genome mode --chimeric with the small model at 2 segments per read on average, "
                          "so that the fixture holds > 10^5 chimeric reads (gap lengths and segment counts at the 1 %% gate)")
@@ -1022,6 +1071,13 @@ def main():
             with open(os.path.join(HERE, "reference_ir_splice.json"), "w") as f:
                 json.dump(fixture_ir_splice(import_reference(), prefix), f)
             print("reference_ir_splice.json written")
+            return
+        if a.only_trx_walk:
+            build_trx_inputs()
+            fx = fixture_trx_walk(import_reference(), prefix)
+            with open(os.path.join(HERE, "reference_trx_walk.json"), "w") as f:
+                json.dump(fx, f, separators=(",", ":"))
+            print("reference_trx_walk.json written:", len(fx["picks"]), "picks,", fx["n_samples"], "KDE samples,", len(fx["written"]), "reads")
             return
         if a.only_chimeric_dense:
             spec = synth.SynthModelSpec(**SMALL_SPEC, segment_mean=CHIMERIC_DENSE_MEAN)       # the committed small model but for _chimeric_info

@@ -307,3 +307,15 @@ def parse_cs(cs):
     nh, no = C.c_uint32(), C.c_uint32()
     assert L.nso_parse_cs_lists(b, len(b), hist.ctypes.data, op, cap, C.byref(nh), C.byref(no)) == 0
     return [int(x) for x in hist[:nh.value]], [chr(c) for c in op.raw[:no.value]]
+
+
+def trx_walk_tape(pick_e, pick_y, lengths):
+    """nso_trx_walk_tape: the oracle's pick walk over the reference's own picks and look-ups -> (accept, redraw, memo_of, n_samples)"""
+    L = lib()
+    L.nso_trx_walk_tape.restype = C.c_uint32
+    L.nso_trx_walk_tape.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    e = np.ascontiguousarray(pick_e, dtype=np.uint32); y = np.ascontiguousarray(pick_y, dtype=np.int64)
+    ln = np.ascontiguousarray(lengths, dtype=np.int64)
+    accept = np.zeros(len(e), np.uint8); redraw = np.zeros(len(e), np.uint8); memo = np.zeros(len(e), np.int64)
+    n = L.nso_trx_walk_tape(len(e), e.ctypes.data, y.ctypes.data, len(ln), ln.ctypes.data, accept.ctypes.data, redraw.ctypes.data, memo.ctypes.data)
+    return accept, redraw, memo, int(n)

@@ -142,3 +142,28 @@ def test_oracle_transcriptome_reads_do_not_depend_on_the_batch(trx_ref):
     names = [ln.split(b"_")[0] for ln in whole["records"].tobytes().split(b"\n")[0::4] if ln]
     top = max(set(names), key=names.count)
     assert 0.40 < names.count(top) / len(names) < 0.50
+
+
+def test_oracle_pick_walk_replays_the_reference_tape():
+    """The walk itself (which pick draws a new KDE sample, which pick leaves the inner loop, S:1080-1104), exactly: the reference's worker
+    was run with random.choices, get_length_kde(kde_aligned_2d) and select_nearest_kde2d wrapped (tests/golden/make_golden.py
+    --only-trx-walk: 4 000 reads, every pick with the length the reference looked up).  The oracle's walk over those picks and look-ups
+    must draw a new sample at exactly the reference's picks and accept exactly the reference's picks; where it skips a look-up ("failed
+    before under this sample") the reference must have seen the value of the pick the walk relies on."""
+    from tests import oracle_lib as O
+    with open(os.path.join(ROOT, "tests", "golden", "reference_trx_walk.json")) as f:
+        tape = json.load(f)
+    picks = np.array(tape["picks"], dtype=np.int64)
+    e, y, ref_redraw, ref_accept = picks[:, 0], picks[:, 1], picks[:, 2], picks[:, 3]
+    accept, redraw, memo, n_samples = O.trx_walk_tape(e, y, tape["lengths"])
+    assert np.array_equal(redraw, ref_redraw) and np.array_equal(accept, ref_accept)
+    assert n_samples == tape["n_samples"] and n_samples > 1000               # 1 + the redraws; the fixture is dominated by one transcript
+    assert e[accept == 1].tolist() == tape["written"] and len(tape["written"]) == tape["n_reads"]
+    skipped = np.flatnonzero(memo >= 0)
+    assert len(skipped) > 0 and not accept[skipped].any()
+    assert np.array_equal(y[skipped], y[memo[skipped]]) and np.array_equal(e[skipped], e[memo[skipped]])
+    # and a walk that forgot the rule is caught: never drawing a new sample accepts a different pick set on this tape
+    lens = np.array(tape["lengths"], dtype=np.int64)
+    first_y = {}
+    naive = np.array([int(first_y.setdefault(int(t), int(v)) < lens[t]) for t, v in zip(e, y)])
+    assert not np.array_equal(naive, ref_accept) or not np.array_equal(y, [first_y[int(t)] for t in e])
