@@ -1,9 +1,12 @@
 """GPU parity of the training-side histogramming (second half): ns_cs_histograms (k_cs_hist, one alignment per thread)
 against the oracle's two-list restatement of src/besthit_to_histogram.py:hist() and against the files the reference itself wrote
-(tests/golden/reference_hist.json.gz).  (The file sorts behind the other -m gpu files on purpose: it is the newest kernel of the engine.)"""
+(tests/golden/reference_hist.json.gz).  (The file sorts behind the other -m gpu files on purpose: it is the newest kernel of the engine — and for the same reason the file runs
+in a CHILD pytest first: a device fault or a hang there fails this file with the child's output, not the whole -m gpu run.)"""
 import gzip
 import json
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -24,7 +27,20 @@ def fx():
 
 
 @pytest.fixture(scope="module")
-def eng():
+def child_ok():
+    if os.environ.get("NS_CSH_CHILD"):
+        return
+    try:
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"], cwd=ROOT,
+                           env=dict(os.environ, NS_CSH_CHILD="1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    except subprocess.TimeoutExpired as ex:
+        pytest.fail("the child run of this file did not finish in 900 s:\n" + str(ex.stdout or "")[-3000:])
+    if r.returncode != 0:
+        pytest.fail("the child run of this file failed (exit %d):\n%s" % (r.returncode, r.stdout[-4000:]))
+
+
+@pytest.fixture(scope="module")
+def eng(child_ok):
     e = E.Engine(0)
     yield e
     e.close()
