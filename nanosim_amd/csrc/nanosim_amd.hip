@@ -30,6 +30,7 @@
 #include "ns_hp.h"
 #include "ns_ir.h"
 #include "ns_io.h"
+#include "ns_pack.h"
 #include "ns_cs_hist.h"
 
 // Reads per workgroup of the wave-per-read kernels.  One: read lengths vary by an order of magnitude inside a batch, and a wavefront
@@ -1977,122 +1978,11 @@ int ns_load_model(ns_ctx *ctx, const ns_model_tables *t) {
         double rate = 1.0 / (mean_match_min > 0.5 ? mean_match_min + 0.5 : 1.0);
         ctx->cap_rate = rate * 1.5 > 2.0 ? 2.0 : rate * 1.5;
 
-        // ---- pack the chain tables into one blob of 8-byte words (its first part is copied to LDS by k_chain) ----
+        // ---- pack the chain tables into one blob of 8-byte words (its first part is copied to LDS by k_chain): ns_pack.h ----
         std::vector<uint64_t> blob;
         ChainTab &ct = m.ct;
-        auto put_d = [&](const double *src, size_t n) { uint32_t off = (uint32_t)blob.size(); blob.resize(off + n);
-                                                         memcpy(blob.data() + off, src, n * 8); return off; };
-        auto put_raw = [&](const void *src, size_t bytes) { uint32_t off = (uint32_t)blob.size(); blob.resize(off + (bytes + 7) / 8, 0);
-                                                             memcpy(blob.data() + off, src, bytes); return off; };
-        auto guide = [&](const double *hi, uint32_t n) {          // g[i] = #{s : hi[s] < i/256}: lower bound of the segment of any p >= i/256
-            std::vector<uint16_t> g(256);
-            uint32_t sidx = 0;
-            for (uint32_t i = 0; i < 256; ++i) {
-                double edge = (double)i / 256.0;
-                while (sidx < n && hi[sidx] < edge) ++sidx;
-                g[i] = (uint16_t)(sidx > 65535u ? 65535u : sidx);
-            }
-            return g;
-        };
-        // the tables that are only ever COMPARED with a draw are stored as integer thresholds of the 32-bit draw (ns_thr_lt / ns_thr_gt)
-        auto put_thr = [&](const double *src, size_t n, bool gt) {
-            uint32_t off = (uint32_t)blob.size(); blob.resize(off + n);
-            for (size_t i = 0; i < n; ++i) blob[off + i] = gt ? ns_thr_gt(src[i]) : ns_thr_lt(src[i]);
-            return off; };
-        ct.trans = put_thr(&t->trans[0][0], 21, false);          // p < a, p < a + b            (S:1860-1864)
-        ct.mix_w = put_thr(t->mix_w, 3, false);                   // tmp_rand < weight           (mm:44, 54)
-        for (int ty = 0; ty < 3; ++ty)                            // p > cdf[v]: walk of the inverse-CDF tables
-            for (int c = 0; c < 2; ++c) {
-                ct.mix_n[ty][c] = t->mix_n[ty][c]; ct.mix_cdf[ty][c] = put_thr(t->mix_cdf[ty][c], t->mix_n[ty][c], true);
-                // guide of the walk by the number of leading one bits of the draw (the tail of a run-length CDF is geometric: a constant
-                // number of thresholds per halving of 1 - p): g[l] = thresholds at or below the smallest draw with l leading ones — a
-                // lower bound of the walk's result for every draw of that class, so the walk starts there instead of at 0
-                uint8_t g2[40] = {0};
-                const uint64_t *G = blob.data() + ct.mix_cdf[ty][c];
-                const uint32_t nn = t->mix_n[ty][c];
-                for (uint32_t l = 0; l <= 32; ++l) {
-                    const uint64_t lo_u = l == 0 ? 0ull : (0xffffffffull << (32 - l)) & 0xffffffffull;
-                    uint32_t v = 0;
-                    while (v + 1 < nn && lo_u >= G[v]) ++v;
-                    g2[l] = (uint8_t)(v > 255u ? 255u : v);
-                }
-                ct.mix_g2[ty][c] = put_raw(g2, 40);
-            }
-        ct.fm_n = t->fm_nseg; ct.fm_vlo0 = t->fm_vlo0;
-        ct.fm_g = put_thr(t->fm_hi, t->fm_nseg, true);           // p > hi[s]: the segment search of the ECDF look-ups (ecdf_lookup_u)
-        { auto g = guide(t->fm_hi, t->fm_nseg); ct.fm_guide = put_raw(g.data(), 512); }
-        ct.mm_nbins = t->mm_nbins;
-        std::vector<int32_t> bins(2 * (size_t)t->mm_nbins);
-        for (uint32_t b = 0; b < t->mm_nbins; ++b) {
-            auto clamp = [](int64_t v) { return (int32_t)(v > 0x7fffffff ? 0x7fffffff : v < -0x7fffffff ? -0x7fffffff : v); };
-            bins[2 * b] = clamp(t->mm_bin_lo[b]); bins[2 * b + 1] = clamp(t->mm_bin_hi[b]);
-        }
-        ct.mm_bin = put_raw(bins.data(), bins.size() * 4);
-        {   // direct bin of a previous match length < 256 (first bin with lo <= v < hi, else the last bin, S:1891-1893)
-            std::vector<uint8_t> lut(256);
-            for (int v = 0; v < 256; ++v) {
-                uint32_t b = 0;
-                for (; b < t->mm_nbins; ++b) if (bins[2 * b] <= v && v < bins[2 * b + 1]) break;
-                if (b >= t->mm_nbins) b = t->mm_nbins - 1;
-                lut[v] = (uint8_t)b;
-            }
-            ct.mm_bin_lut = put_raw(lut.data(), 256);
-        }
-        ct.mm_seg_off = put_raw(t->mm_seg_off, ((size_t)t->mm_nbins + 1) * 4);
-        ct.mm_g = put_thr(t->mm_hi, nseg, true); ct.mm_vlo0 = put_d(t->mm_vlo0, t->mm_nbins);
-        std::vector<uint16_t> gall;
-        for (uint32_t b = 0; b < t->mm_nbins; ++b) {
-            auto g = guide(t->mm_hi + t->mm_seg_off[b], t->mm_seg_off[b + 1] - t->mm_seg_off[b]);
-            gall.insert(gall.end(), g.begin(), g.end());
-        }
-        ct.mm_guide = put_raw(gall.data(), gall.size() * 2);
-        // value edges: whole numbers in every model read_analysis.py writes (its bins are "i-(i+1)") -> 32-bit copies for the LDS image;
-        // the fp64 originals follow behind the part that is copied to LDS (the cooperative chain and a model with fractional edges read those)
         bool whole = true;
-        // The steps of the interpolation floor((p - plo) / (hs - plo) * (vs - vlo) + vlo) inside a segment, found with the arithmetic of
-        // the fp64 formula (this file is compiled with -ffp-contract=off, like the device code and the oracle) — ecdf_lookup_u:
-        // bit 31 of a value edge: one unit wide and every draw gives vlo; else, up to 15 units wide: thresholds in `sub`, their number
-        // and position in the upper bits of the segment's G word
-        std::vector<uint64_t> sub;
-        auto put_u = [&](uint32_t g_off, const double *hi, const double *src, size_t n, double vlo0, std::vector<uint32_t> &v) {
-            for (size_t i = 0; i < n; ++i) {
-                if (!(src[i] >= 0 && src[i] < 2147483648.0 && src[i] == floor(src[i]))) whole = false;
-                uint32_t e = (uint32_t)(src[i] < 0 ? 0 : src[i] >= 2147483647.0 ? 2147483647.0 : src[i]);
-                const double hs = hi[i], plo = i ? hi[i - 1] : 0.0, vs = src[i], vlo = i ? src[i - 1] : vlo0;
-                const double w = vs - vlo;
-                if (w >= 1.0 && w <= 15.0 && w == floor(w) && hs > plo && vlo == floor(vlo) && vlo >= 0) {
-                    auto f = [&](uint64_t u) { const double pp = u32_to_p((uint32_t)u); return floor((pp - plo) / (hs - plo) * (vs - vlo) + vlo); };
-                    const uint64_t u0 = i ? ns_thr_gt(plo) : 0ull, u1 = ns_thr_gt(hs);     // the draws of the segment: [u0, u1)
-                    uint64_t thr[15];
-                    for (uint32_t k = 1; k <= (uint32_t)w; ++k) {                          // smallest draw of the segment that gives >= vlo + k
-                        uint64_t lo = u0, hi2 = u1;                                         // (f is non-decreasing in the draw)
-                        while (lo < hi2) { const uint64_t mid = lo + ((hi2 - lo) >> 1); if (f(mid) >= vlo + (double)k) hi2 = mid; else lo = mid + 1; }
-                        thr[k - 1] = lo >= u1 ? (1ull << 32) : lo;
-                    }
-                    if (w == 1.0 && thr[0] == (1ull << 32)) e |= 0x80000000u;
-                    else {
-                        blob[g_off + i] |= (uint64_t)(uint32_t)w << 36 | (uint64_t)sub.size() << 40;
-                        sub.insert(sub.end(), thr, thr + (uint32_t)w);
-                    }
-                }
-                v.push_back(e);
-            } };
-        { std::vector<uint32_t> v; put_u(ct.fm_g, t->fm_hi, t->fm_vhi, t->fm_nseg, t->fm_vlo0, v); ct.fm_vhi_u = put_raw(v.data(), v.size() * 4); }
-        {
-            std::vector<uint32_t> v;                               // per column: its first segment starts at the column's vlo0
-            for (uint32_t b = 0; b < t->mm_nbins; ++b) {
-                const uint32_t o = t->mm_seg_off[b];
-                put_u(ct.mm_g + o, t->mm_hi + o, t->mm_vhi + o, t->mm_seg_off[b + 1] - o, t->mm_vlo0[b], v);
-            }
-            ct.mm_vhi_u = put_raw(v.data(), v.size() * 4);
-        }
-        if (sub.size() >= (1u << 24)) whole = false;
-        sub.push_back(0);
-        ct.sub = put_raw(sub.data(), sub.size() * 8);
-        ct.n_words_lds = (uint32_t)blob.size();
-        ct.fm_hi = put_d(t->fm_hi, t->fm_nseg); ct.mm_hi = put_d(t->mm_hi, nseg);      // fp64 tables: global memory (wide segments, cooperative chain)
-        ct.fm_vhi = put_d(t->fm_vhi, t->fm_nseg); ct.mm_vhi = put_d(t->mm_vhi, nseg);
-        ct.n_words = (uint32_t)blob.size();
+        ns_pack_chain_tables(t, nseg, ct, blob, whole);
         if ((rc = upload(ctx, pool, blob.data(), blob.size(), &m.chain_blob))) return rc;
         ctx->lds_bytes = (size_t)ct.n_words_lds * 8;
         ctx->lds_tables = whole && ctx->lds_bytes <= 40 * 1024;     // keep >= 4 workgroups of 256 threads per CU

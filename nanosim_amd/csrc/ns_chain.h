@@ -7,17 +7,17 @@
 
 struct Tabs {
     const uint64_t *w;
-    __device__ __forceinline__ const double *d(uint32_t off) const { return reinterpret_cast<const double *>(w + off); }
-    __device__ __forceinline__ const uint64_t *q(uint32_t off) const { return w + off; }
-    __device__ __forceinline__ const uint16_t *h(uint32_t off) const { return reinterpret_cast<const uint16_t *>(w + off); }
-    __device__ __forceinline__ const uint32_t *u(uint32_t off) const { return reinterpret_cast<const uint32_t *>(w + off); }
-    __device__ __forceinline__ const int32_t *i(uint32_t off) const { return reinterpret_cast<const int32_t *>(w + off); }
+    NS_DEV const double *d(uint32_t off) const { return reinterpret_cast<const double *>(w + off); }
+    NS_DEV const uint64_t *q(uint32_t off) const { return w + off; }
+    NS_DEV const uint16_t *h(uint32_t off) const { return reinterpret_cast<const uint16_t *>(w + off); }
+    NS_DEV const uint32_t *u(uint32_t off) const { return reinterpret_cast<const uint32_t *>(w + off); }
+    NS_DEV const int32_t *i(uint32_t off) const { return reinterpret_cast<const int32_t *>(w + off); }
 };
 
 // first s with p <= hi[s] (guide[u>>24] is a lower bound of s), then the interpolation of S:1847 / S:1897.
 // hi[s] and hi[s+1] are fetched together: the look-up sits on the chain's critical path.
 template <class V>       // V = double, or uint32_t for the integer copy of the value edges in LDS (same values, converted on the fly)
-__device__ __forceinline__ int32_t ecdf_lookup_g(const double *__restrict__ hi, const V *__restrict__ vhi, uint32_t n,
+NS_DEV int32_t ecdf_lookup_g(const double *__restrict__ hi, const V *__restrict__ vhi, uint32_t n,
                                                  double vlo0, const uint16_t *__restrict__ guide, uint32_t u) {
     double p = u32_to_p(u);
     uint32_t s = guide[u >> 24];
@@ -47,7 +47,7 @@ __device__ __forceinline__ int32_t ecdf_lookup_g(const double *__restrict__ hi, 
 //   * else (wider segments: empty bins merged) the fp64 formula on the global tables.
 // A draw above the last edge is clamped to it (the reference would keep a stale value): frac = 1 exactly -> vhi.
 #define NS_G_THR(g) ((g) & 0x1ffffffffull)
-__device__ __forceinline__ int32_t ecdf_lookup_u(const uint64_t *__restrict__ G, const uint32_t *__restrict__ vhi_u, uint32_t n,
+NS_DEV int32_t ecdf_lookup_u(const uint64_t *__restrict__ G, const uint32_t *__restrict__ vhi_u, uint32_t n,
                                                  const uint16_t *__restrict__ guide, uint32_t u, const uint64_t *__restrict__ sub,
                                                  const double *__restrict__ hi_g, const double *__restrict__ vhi_g, double vlo0) {
     uint32_t s = guide[u >> 24];
@@ -78,7 +78,7 @@ __device__ __forceinline__ int32_t ecdf_lookup_u(const uint64_t *__restrict__ G,
 
 // mixture run length (mm:41-63) on integer thresholds: component by u_mix < T(weight), value = 1 + #{j : p > cdf[j]} by walking
 // G[j] = ns_thr_gt(cdf[j]) — no fp64 on the way
-__device__ __forceinline__ int32_t run_length_t(const Tabs &T, const ChainTab &c, int type, uint32_t u_mix, uint32_t u_len) {
+NS_DEV int32_t run_length_t(const Tabs &T, const ChainTab &c, int type, uint32_t u_mix, uint32_t u_len) {
     const int comp = ((uint64_t)u_mix < T.q(c.mix_w)[type]) ? 0 : 1;         // tmp_rand < weight, mm:44,54
     const uint64_t *G = T.q(c.mix_cdf[type][comp]);
     const uint32_t n = c.mix_n[type][comp];
@@ -86,19 +86,19 @@ __device__ __forceinline__ int32_t run_length_t(const Tabs &T, const ChainTab &c
     // == v = 0; while (v + 1 < n && p > cdf[v]) ++v — started at the guide's lower bound for draws with this many leading one bits
     // (every threshold below it is <= the smallest such draw): zero to two steps instead of (run length - 1) dependent LDS reads
     const uint8_t *g2 = reinterpret_cast<const uint8_t *>(T.w + c.mix_g2[type][comp]);
-    uint32_t v = g2[(uint32_t)__clz((int)~u_len)];                             // (__clz(0) == 32: the draw 0xffffffff)
+    uint32_t v = g2[ns_clz32(~u_len)];                             // (__clz(0) == 32: the draw 0xffffffff)
     while (v + 1 < n && u >= G[v]) ++v;
     return (int32_t)v + 1;
 }
 
 // the same with the mixture weight handed in (the callers keep the three weights in registers) and the first TWO thresholds of the walk
 // fetched together: the walk starts at the guide's lower bound and almost always ends within two steps
-__device__ __forceinline__ int32_t run_length_w(const Tabs &T, const ChainTab &c, int type, uint64_t weight_thr, uint32_t u_mix, uint32_t u_len) {
+NS_DEV int32_t run_length_w(const Tabs &T, const ChainTab &c, int type, uint64_t weight_thr, uint32_t u_mix, uint32_t u_len) {
     const uint32_t comp = ((uint64_t)u_mix < weight_thr) ? 0u : 1u;                        // tmp_rand < weight, mm:44,54
     const uint32_t go = comp ? c.mix_cdf[type][1] : c.mix_cdf[type][0], n = comp ? c.mix_n[type][1] : c.mix_n[type][0];
     const uint32_t h = comp ? c.mix_g2[type][1] : c.mix_g2[type][0];
     const uint64_t u = u_len;
-    uint32_t v = reinterpret_cast<const uint8_t *>(T.w)[8u * h + (uint32_t)__clz((int)~u_len)];
+    uint32_t v = reinterpret_cast<const uint8_t *>(T.w)[8u * h + ns_clz32(~u_len)];
     const uint64_t a = T.w[go + v], b = T.w[go + min(v + 1u, n - 1u)];
     if (v + 1u < n && u >= a) { ++v; if (v + 1u < n && u >= b) { ++v; while (v + 1u < n && u >= T.w[go + v]) ++v; } }
     return (int32_t)v + 1;
@@ -119,18 +119,18 @@ struct EvSink32 {
 #ifndef NS_CHAIN_BLOCK
 #define NS_CHAIN_BLOCK 256
 #endif
-__device__ __forceinline__ void ev_flush4(EvSink32 &s, uint32_t first) {       // staged slots 0..3 -> events first .. first + 3
+NS_DEV void ev_flush4(EvSink32 &s, uint32_t first) {       // staged slots 0..3 -> events first .. first + 3
     const uint2 e0 = s.stg[0], e1 = s.stg[NS_CHAIN_BLOCK], e2 = s.stg[2 * NS_CHAIN_BLOCK], e3 = s.stg[3 * NS_CHAIN_BLOCK];
     uint4 *dst = reinterpret_cast<uint4 *>(s.ev + first);
     dst[0] = make_uint4(e0.x, e0.y, e1.x, e1.y); dst[1] = make_uint4(e2.x, e2.y, e3.x, e3.y);
 }
 // the events still staged when a piece is complete (slots behind the last event carry stale values: inside the capacity, never read)
-__device__ __forceinline__ void ev_flush_tail(EvSink32 &s) {
+NS_DEV void ev_flush_tail(EvSink32 &s) {
     if (s.stg && (s.n & 3u) && s.n < s.cap) ev_flush4(s, s.n & ~3u);
 }
 // does the cumulative shift fit the 18-bit field of ns_event.info?
-__device__ __forceinline__ bool ev_shift_fits(int32_t shift) { return (uint32_t)(shift + NS_EV_SHIFT_BIAS) < 2u * (uint32_t)NS_EV_SHIFT_BIAS; }
-__device__ __forceinline__ void ev_push32(EvSink32 &s, int32_t pos, uint32_t type, int32_t len) {
+NS_DEV bool ev_shift_fits(int32_t shift) { return (uint32_t)(shift + NS_EV_SHIFT_BIAS) < 2u * (uint32_t)NS_EV_SHIFT_BIAS; }
+NS_DEV void ev_push32(EvSink32 &s, int32_t pos, uint32_t type, int32_t len) {
     uint32_t l = len > (int32_t)NS_EV_LEN_MAX ? NS_EV_LEN_MAX : (uint32_t)len;
     if (len > (int32_t)NS_EV_LEN_MAX || !ev_shift_fits(s.shift)) s.range = true;
     if (s.n < s.cap) {
@@ -148,7 +148,7 @@ struct EList32 { int32_t l_new, middle_ref; };
 
 // error_list, S:1833-1916
 template <bool VU32>     // VU32: T is the LDS copy of the blob (integer thresholds, value edges as 32-bit integers); TG: the whole blob in global memory
-__device__ __forceinline__ EList32 chain_error_list(const Tabs &T, const Tabs &TG, const ChainTab &c, int32_t m_ref, const ns_key &key,
+NS_DEV EList32 chain_error_list(const Tabs &T, const Tabs &TG, const ChainTab &c, int32_t m_ref, const ns_key &key,
                                                     uint32_t seg, uint32_t attempt, EvSink32 &s) {
     int32_t l_new = m_ref, pos = 0, middle_ref = m_ref;
     int state = NS_ST_START;
@@ -306,7 +306,7 @@ __device__ __forceinline__ EList32 chain_error_list_mlp(const Tabs &T, const Tab
 }
 
 // unaligned_error_list, S:1784-1830, with the event rewrite of DESIGN.md §5.3
-__device__ __forceinline__ EList32 chain_unaligned_error_list(const Tabs &T, const ChainTab &c, int32_t m_ref, const ns_key &key,
+NS_DEV EList32 chain_unaligned_error_list(const Tabs &T, const ChainTab &c, int32_t m_ref, const ns_key &key,
                                                               uint32_t seg, uint32_t attempt, EvSink32 &s) {
     int32_t l_new = m_ref, pos = 0, middle_ref = m_ref;
     int32_t pend_ins = 0;

@@ -117,7 +117,7 @@ __host__ __device__ inline uint64_t ns_thr_gt(double t) {
 // S:1860-1864 on the integer thresholds of a transition row (T0 = ns_thr_lt(a), T1 = ns_thr_lt(a + b)): the intervals are tested in
 // the order mis [0, a), ins [a, a + b), del [1 - c, 1); a draw that falls between a + b and 1 - c (rounding gap) takes del
 // (DESIGN.md section 5.5), so everything that is neither mis nor ins is del
-__device__ __forceinline__ int trans_pick_u(const uint64_t *row, uint32_t u) {
+NS_DEV int trans_pick_u(const uint64_t *row, uint32_t u) {
     return (uint64_t)u < row[0] ? NS_MIS : (uint64_t)u < row[1] ? NS_INS : NS_DEL;
 }
 

@@ -6,6 +6,14 @@
 #include <stdint.h>
 
 #define NS_HD __host__ __device__ __forceinline__
+// NS_DEV: device code of the thread-per-read event chains (ns_chain.h).  The CPU test suite compiles the SAME source for the host
+// (tests/chain_host.hip, -DNS_HOST_TEST, host pass only) and holds it against the oracle without a GPU; in the product build the
+// qualifier is the plain device one.
+#ifdef NS_HOST_TEST
+#define NS_DEV __host__ __device__ __forceinline__
+#else
+#define NS_DEV __device__ __forceinline__
+#endif
 
 // stream ids of the Philox counter (c3 bits 18..23)
 enum : uint32_t {
@@ -27,6 +35,15 @@ struct ns_key {           // per-read part of the counter
 };
 
 struct u32x4 { uint32_t x, y, z, w; };
+
+// leading zero bits, 32 for 0 (__clz)
+NS_HD uint32_t ns_clz32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__clz((int)x);
+#else
+    return x ? (uint32_t)__builtin_clz(x) : 32u;
+#endif
+}
 
 // Philox4x32-10 (Salmon, Moraes, Dror, Shaw 2011)
 NS_HD u32x4 philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
