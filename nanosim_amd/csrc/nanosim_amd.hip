@@ -347,12 +347,15 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK, COOP ? 4 : NS_CHAI
                 }
                 EList32 e;
                 if (kind == NS_KIND_PERFECT) { e.l_new = e.middle_ref = m32; }
-                else if (p.kind) e = COOP ? coop_unaligned_error_list(T, ct, m32, key, sid, a, sink, lane) : chain_unaligned_error_list(T, ct, m32, key, sid, a, sink);
+                else if (p.kind) e = COOP ? coop_unaligned_error_list(T, ct, m32, key, sid, a, sink, lane) : chain_unaligned_error_list<NS_MIX_REC>(T, ct, m32, key, sid, a, sink);
                 else if (COOP) e = coop_error_list(T, ct, m32, key, sid, a, sink, *coop, lane);
 #ifdef NS_CHAIN_MLP          // (round 4: measured SLOWER than the one-question-at-a-time chain, 3.76 against 3.28 ms — ns_chain.h)
                 else if constexpr (LDS_TABLES) e = chain_error_list_mlp(T, Tabs{A.m.chain_blob}, ct, m32, key, sid, a, sink);
 #endif
-                else e = chain_error_list<LDS_TABLES>(T, Tabs{A.m.chain_blob}, ct, m32, key, sid, a, sink);
+#if NS_CHAIN_VAR & 32       // (round 4: prepared and checked against the oracle on the CPU, not yet timed — ns_chain.h)
+                else if constexpr (LDS_TABLES) e = chain_error_list_v2(T, Tabs{A.m.chain_blob}, ct, m32, key, sid, a, sink);
+#endif
+                else e = chain_error_list<LDS_TABLES, (NS_CHAIN_VAR & 15)>(T, Tabs{A.m.chain_blob}, ct, m32, key, sid, a, sink);
                 ev_flush_tail(sink);
                 p.ev_off = ev_off + evn;
                 p.ref_len = (uint32_t)(e.middle_ref < 0 ? 0 : e.middle_ref);
@@ -1982,7 +1985,7 @@ int ns_load_model(ns_ctx *ctx, const ns_model_tables *t) {
         std::vector<uint64_t> blob;
         ChainTab &ct = m.ct;
         bool whole = true;
-        ns_pack_chain_tables(t, nseg, ct, blob, whole);
+        ns_pack_chain_tables(t, nseg, ct, blob, whole, NS_CHAIN_LAYOUT);
         if ((rc = upload(ctx, pool, blob.data(), blob.size(), &m.chain_blob))) return rc;
         ctx->lds_bytes = (size_t)ct.n_words_lds * 8;
         ctx->lds_tables = whole && ctx->lds_bytes <= 40 * 1024;     // keep >= 4 workgroups of 256 threads per CU

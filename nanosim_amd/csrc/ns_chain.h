@@ -78,8 +78,29 @@ NS_DEV int32_t ecdf_lookup_u(const uint64_t *__restrict__ G, const uint32_t *__r
 
 // mixture run length (mm:41-63) on integer thresholds: component by u_mix < T(weight), value = 1 + #{j : p > cdf[j]} by walking
 // G[j] = ns_thr_gt(cdf[j]) — no fp64 on the way
+// MR (NS_CHAIN_VAR & 8): offset, length and guide of the table come from the record 2 * type + component in the blob (one LDS read)
+// instead of ChainTab — indexed by a per-thread type, those are three vector loads from the kernel-argument segment per event
+#ifdef NS_CHAIN_TABS2
+NS_DEV void mix_record(const Tabs &T, const ChainTab &c, uint32_t type, uint32_t comp, uint32_t &go, uint32_t &n, uint32_t &h) {
+    const uint64_t *r = T.w + c.mix_rec + 2u * (2u * type + comp);
+    const uint64_t r0 = r[0], r1 = r[1];
+    go = (uint32_t)r0; n = (uint32_t)(r0 >> 32); h = (uint32_t)r1;
+}
+#endif
+constexpr bool NS_MIX_REC = (NS_CHAIN_VAR & (8 | 32)) != 0;
+template <bool MR = false>
 NS_DEV int32_t run_length_t(const Tabs &T, const ChainTab &c, int type, uint32_t u_mix, uint32_t u_len) {
     const int comp = ((uint64_t)u_mix < T.q(c.mix_w)[type]) ? 0 : 1;         // tmp_rand < weight, mm:44,54
+#ifdef NS_CHAIN_TABS2
+    if constexpr (MR) {
+        uint32_t go, n, h;
+        mix_record(T, c, (uint32_t)type, (uint32_t)comp, go, n, h);
+        const uint64_t u = u_len;
+        uint32_t v = reinterpret_cast<const uint8_t *>(T.w)[8u * h + ns_clz32(~u_len)];
+        while (v + 1 < n && u >= T.w[go + v]) ++v;
+        return (int32_t)v + 1;
+    }
+#endif
     const uint64_t *G = T.q(c.mix_cdf[type][comp]);
     const uint32_t n = c.mix_n[type][comp];
     const uint64_t u = u_len;
@@ -93,10 +114,18 @@ NS_DEV int32_t run_length_t(const Tabs &T, const ChainTab &c, int type, uint32_t
 
 // the same with the mixture weight handed in (the callers keep the three weights in registers) and the first TWO thresholds of the walk
 // fetched together: the walk starts at the guide's lower bound and almost always ends within two steps
+template <bool MR = false>
 NS_DEV int32_t run_length_w(const Tabs &T, const ChainTab &c, int type, uint64_t weight_thr, uint32_t u_mix, uint32_t u_len) {
     const uint32_t comp = ((uint64_t)u_mix < weight_thr) ? 0u : 1u;                        // tmp_rand < weight, mm:44,54
-    const uint32_t go = comp ? c.mix_cdf[type][1] : c.mix_cdf[type][0], n = comp ? c.mix_n[type][1] : c.mix_n[type][0];
-    const uint32_t h = comp ? c.mix_g2[type][1] : c.mix_g2[type][0];
+    uint32_t go, n, h;
+#ifdef NS_CHAIN_TABS2
+    if constexpr (MR) mix_record(T, c, (uint32_t)type, comp, go, n, h);
+    else
+#endif
+    {
+        go = comp ? c.mix_cdf[type][1] : c.mix_cdf[type][0]; n = comp ? c.mix_n[type][1] : c.mix_n[type][0];
+        h = comp ? c.mix_g2[type][1] : c.mix_g2[type][0];
+    }
     const uint64_t u = u_len;
     uint32_t v = reinterpret_cast<const uint8_t *>(T.w)[8u * h + ns_clz32(~u_len)];
     const uint64_t a = T.w[go + v], b = T.w[go + min(v + 1u, n - 1u)];
@@ -147,7 +176,18 @@ NS_DEV void ev_push32(EvSink32 &s, int32_t pos, uint32_t type, int32_t len) {
 struct EList32 { int32_t l_new, middle_ref; };
 
 // error_list, S:1833-1916
-template <bool VU32>     // VU32: T is the LDS copy of the blob (integer thresholds, value edges as 32-bit integers); TG: the whole blob in global memory
+// VU32: T is the LDS copy of the blob (integer thresholds, value edges as 32-bit integers); TG: the whole blob in global memory.
+// VAR (bit mask, -DNS_CHAIN_VAR=..., 0 in the product build): formulations of the same iteration that are measured against each other
+// on the GPU (scripts/ab_run.sh) and held against the oracle on the CPU (tests/test_chain_host.py) — same events, bit for bit:
+//   1  ONE ev_push32 site for both branches of S:1875-1882 (the insertion's dict-key collision and the position update become
+//      selects): half the exec-mask regions of the event store
+//   2  run length by run_length_w: the three mixture weights stay in registers, the first two thresholds of the walk are fetched together
+//   4  the bin of the previous match and its segment range are looked up BEFORE the event is pushed (they depend on the previous
+//      iteration only): the LDS round trips of S:1891-1893 run under the event store instead of behind it
+//   8  the run-length table of (type, component) by its record in LDS (mix_record; blob layout 1) — found in the ISA of round 4:
+//      c.mix_cdf[type][comp] with a per-thread type is THREE global loads from the kernel-argument segment on every event's critical path
+//  32  chain_error_list_v2 below (blob layout 3)
+template <bool VU32, int VAR = 0>
 NS_DEV EList32 chain_error_list(const Tabs &T, const Tabs &TG, const ChainTab &c, int32_t m_ref, const ns_key &key,
                                                     uint32_t seg, uint32_t attempt, EvSink32 &s) {
     int32_t l_new = m_ref, pos = 0, middle_ref = m_ref;
@@ -164,13 +204,38 @@ NS_DEV EList32 chain_error_list(const Tabs &T, const Tabs &TG, const ChainTab &c
     const int32_t *bins = T.i(c.mm_bin);
     const uint32_t *seg_off = T.u(c.mm_seg_off);
     const uint8_t *bin_lut = reinterpret_cast<const uint8_t *>(T.w + c.mm_bin_lut);
+    uint64_t mw0 = 0, mw1 = 0, mw2 = 0;
+    if constexpr ((VAR & 2) != 0) { mw0 = T.q(c.mix_w)[0]; mw1 = T.q(c.mix_w)[1]; mw2 = T.q(c.mix_w)[2]; }
     u32x4 w_next = ns_draw(key, ST_EVENT, seg, attempt, 1, 0);
     while (pos < middle_ref) {                                                                     // S:1858
         w = w_next;
         w_next = ns_draw(key, ST_EVENT, seg, attempt, it + 1, 0);    // next iteration's draws do not depend on the chain state
         const int error = trans_pick_u(trans + 3 * state, w.x);                                   // S:1860-1864
-        int32_t step = run_length_t(T, c, error, w.y, w.z);                                       // S:1866-1873
+        uint32_t b = 0, o = 0, ncol = 0;
+        auto bin_of = [&]() {                                                                      // S:1891-1893
+            if ((uint32_t)prev_match < 256u) b = bin_lut[prev_match];
+            else {
+                for (b = 0; b < c.mm_nbins; ++b)
+                    if (bins[2 * b] <= prev_match && prev_match < bins[2 * b + 1]) break;
+                if (b >= c.mm_nbins) b = c.mm_nbins - 1;
+            }
+            o = seg_off[b]; ncol = seg_off[b + 1] - o;
+        };
+        if constexpr ((VAR & 4) != 0) bin_of();
+        int32_t step;                                                                              // S:1866-1873
+        if constexpr ((VAR & 2) != 0) step = run_length_w<(VAR & 8) != 0>(T, c, error, error == NS_MIS ? mw0 : error == NS_INS ? mw1 : mw2, w.y, w.z);
+        else step = run_length_t<(VAR & 8) != 0>(T, c, error, w.y, w.z);
         if (error == NS_INS) l_new += step; else if (error == NS_DEL) l_new -= step;
+        if constexpr ((VAR & 1) != 0) {
+            const bool ins = error == NS_INS;
+            const bool coll = ins && last_ins_pos == pos && s.n > 0;                               // dict key collision, S:1881-1882
+            s.n -= coll ? 1u : 0u; s.shift -= coll ? (int32_t)s.last_ins_len : 0;
+            ev_push32(s, pos, (uint32_t)error, step);
+            last_ins_pos = ins ? pos : last_ins_pos;
+            pos += ins ? 0 : step;                                                                 // S:1875-1880
+            const bool over = !ins && pos >= middle_ref;
+            l_new += over ? pos - middle_ref : 0; middle_ref = over ? pos : middle_ref;
+        } else
         if (error != NS_INS) {                                                                     // S:1875-1880
             ev_push32(s, pos, (uint32_t)error, step);
             pos += step;
@@ -181,17 +246,10 @@ NS_DEV EList32 chain_error_list(const Tabs &T, const Tabs &TG, const ChainTab &c
             last_ins_pos = pos;
         }
         state = NS_ST_MIS + error;                                                                 // S:1884
-        uint32_t b;                                                                                // S:1891-1893
-        if ((uint32_t)prev_match < 256u) b = bin_lut[prev_match];
-        else {
-            for (b = 0; b < c.mm_nbins; ++b)
-                if (bins[2 * b] <= prev_match && prev_match < bins[2 * b + 1]) break;
-            if (b >= c.mm_nbins) b = c.mm_nbins - 1;
-        }
-        const uint32_t o = seg_off[b];
-        if constexpr (VU32) step = ecdf_lookup_u(T.q(c.mm_g) + o, T.u(c.mm_vhi_u) + o, seg_off[b + 1] - o, T.h(c.mm_guide) + 256 * b, w.w, T.q(c.sub),
+        if constexpr ((VAR & 4) == 0) bin_of();
+        if constexpr (VU32) step = ecdf_lookup_u(T.q(c.mm_g) + o, T.u(c.mm_vhi_u) + o, ncol, T.h(c.mm_guide) + 256 * b, w.w, T.q(c.sub),
                                                  TG.d(c.mm_hi) + o, TG.d(c.mm_vhi) + o, T.d(c.mm_vlo0)[b]);
-        else step = ecdf_lookup_g(T.d(c.mm_hi) + o, T.d(c.mm_vhi) + o, seg_off[b + 1] - o, T.d(c.mm_vlo0)[b],
+        else step = ecdf_lookup_g(T.d(c.mm_hi) + o, T.d(c.mm_vhi) + o, ncol, T.d(c.mm_vlo0)[b],
                                   T.h(c.mm_guide) + 256 * b, w.w);
         if (prev_match == 0 && step == 0) step = 1;                                                // S:1900-1901
         prev_match = step;
@@ -203,6 +261,161 @@ NS_DEV EList32 chain_error_list(const Tabs &T, const Tabs &TG, const ChainTab &c
     }
     return EList32{l_new, middle_ref};
 }
+
+#ifdef NS_CHAIN_TABS2
+// ---- error_list on the one-word ECDF segments (NS_CHAIN_VAR & 32, blob layout 3; an experiment prepared in round 4, timed in round 5) ----
+// What the ISA and the counters of chain_error_list<true> show (profiles/r04): an event costs ~270 vector + ~180 scalar instructions and
+// eleven DEPENDENT look-ups — transition row, three loads from the kernel-argument segment, guide byte, one or two thresholds; bin byte,
+// segment range, guide, one or two thresholds, value edge — with four wavefronts per SIMD to hide them.  Here
+//   * a segment is ONE word (threshold, class, value: ns_pack_layout2), so the look-up ends with the threshold it stops at;
+//   * the column of the previous match comes from one word (pm_lut) instead of bin byte -> segment range;
+//   * the next match length depends on the previous match and the draw only: it is looked up FIRST, next to the run length, and both
+//     run ahead of the event store (whose LDS staging writes the compiler cannot move table reads across) — two chains of three reads
+//     side by side behind the transition row instead of eleven in a row;
+//   * one ev_push32 site (formulation 1) and the run-length record (formulation 8).
+// Same events as chain_error_list, bit for bit (tests/test_chain_host.py against the oracle).
+// ev_push32 with the bookkeeping behind the store as selects (no exec-mask regions for the type)
+NS_DEV void ev_push32s(EvSink32 &s, int32_t pos, uint32_t type, int32_t len) {
+    const uint32_t l = len > (int32_t)NS_EV_LEN_MAX ? NS_EV_LEN_MAX : (uint32_t)len;
+    if (len > (int32_t)NS_EV_LEN_MAX || !ev_shift_fits(s.shift)) s.range = true;
+    if (s.n < s.cap) {
+        ns_event e; e.pos = (uint32_t)pos; e.info = ns_ev_pack(l, type, s.shift);
+        if (s.stg) {
+            s.stg[(s.n & 3u) * NS_CHAIN_BLOCK] = make_uint2(e.pos, e.info);
+            if ((s.n & 3u) == 3u) ev_flush4(s, s.n - 3u);
+        } else s.ev[s.n] = e;
+    } else s.overflow = true;
+    s.shift += type == NS_INS ? (int32_t)l : type == NS_DEL ? -(int32_t)l : 0;
+    s.last_ins_len = type == NS_INS ? l : s.last_ins_len;
+    s.n++;
+}
+
+#define NS_GV_UNIT (1ull << 33)
+#define NS_GV_NARROW (1ull << 34)
+// the segment of draw u in a column of n one-word segments and the value it gives.  Straight-line for the common case — the guide's
+// segment or the next, one unit wide: the two words are read TOGETHER and unconditionally (GV[s + 1] behind the column's end is the next
+// table's first word: read, never used), the compares are arithmetic, nothing the compiler could sink a load into
+NS_DEV int32_t ecdf_lookup_gv(const uint64_t *__restrict__ GV, uint32_t n, const uint16_t *__restrict__ guide, uint32_t u,
+                              const uint64_t *__restrict__ sub2, const double *__restrict__ hi_g, const double *__restrict__ vhi_g, double vlo0) {
+    const uint32_t s0 = guide[u >> 24];
+    const uint64_t uu = u;
+    const uint32_t sc = min(s0, n - 1u);
+    const uint64_t g0 = GV[sc], g1 = GV[sc + 1u];
+    const uint32_t k0 = (s0 < n) & (uu >= NS_G_THR(g0)), k1 = k0 & (s0 + 1u < n) & (uu >= NS_G_THR(g1));
+    uint64_t g = k0 ? g1 : g0;
+    uint32_t s = s0 + k0 + k1;
+    if (k1) while (s < n) { g = GV[s]; if (uu < NS_G_THR(g)) break; ++s; }                  // (rare: three or more segments inside one guide cell)
+    if (s < n && (g & NS_GV_UNIT)) return (int32_t)(uint32_t)(g >> 35) - 1;
+    if (s < n && (g & NS_GV_NARROW)) {
+        const uint64_t *t = sub2 + (g >> 35);
+        const uint64_t h = t[0];
+        const uint32_t nt = (uint32_t)(h >> 32);
+        int32_t r = (int32_t)(uint32_t)h - (int32_t)nt;
+        for (uint32_t k = 1; k <= nt; ++k) r += uu >= t[k] ? 1 : 0;
+        return r;
+    }
+    double p = u32_to_p(u);                                  // a wide segment, or a draw above the last edge (clamped to it: frac = 1 -> vhi)
+    if (s >= n) { s = n - 1; p = hi_g[s]; }
+    const uint32_t sm = s ? s - 1 : 0;
+    const double hs = hi_g[s], plo = s ? hi_g[sm] : 0.0, vs = vhi_g[s], vlo = s ? vhi_g[sm] : vlo0;
+    return (int32_t)floor((p - plo) / (hs - plo) * (vs - vlo) + vlo);
+}
+
+// the generic look-up of the next match length (any previous match, any segment class): the fall-back of chain_error_list_v2's fast path
+NS_DEV int32_t next_match_gv(const Tabs &T, const Tabs &TG, const ChainTab &c, int32_t prev_match, uint32_t u) {
+    uint32_t b, o, ncol;
+    if ((uint32_t)prev_match < 256u) {
+        const uint64_t pe = T.q(c.pm_lut)[prev_match];
+        b = (uint32_t)(pe >> 56); o = (uint32_t)pe; ncol = (uint32_t)(pe >> 32) & 0xffffffu;
+    } else {                                                                                       // S:1891-1893
+        const int32_t *bins = T.i(c.mm_bin);
+        const uint32_t *seg_off = T.u(c.mm_seg_off);
+        for (b = 0; b < c.mm_nbins; ++b)
+            if (bins[2 * b] <= prev_match && prev_match < bins[2 * b + 1]) break;
+        if (b >= c.mm_nbins) b = c.mm_nbins - 1;
+        o = seg_off[b]; ncol = seg_off[b + 1] - o;
+    }
+    return ecdf_lookup_gv(T.q(c.mm_gv) + o, ncol, T.h(c.mm_guide) + 256u * b, u, T.q(c.sub2), TG.d(c.mm_hi) + o, TG.d(c.mm_vhi) + o, T.d(c.mm_vlo0)[b]);
+}
+
+NS_DEV EList32 chain_error_list_v2(const Tabs &T, const Tabs &TG, const ChainTab &c, int32_t m_ref, const ns_key &key,
+                                   uint32_t seg, uint32_t attempt, EvSink32 &s) {
+    int32_t l_new = m_ref, pos = 0, middle_ref = m_ref;
+    uint32_t state = NS_ST_START;
+    u32x4 w = ns_draw(key, ST_EVENT, seg, attempt, 0, 0);
+    int32_t prev_match = ecdf_lookup_gv(T.q(c.fm_gv), c.fm_n, T.h(c.fm_guide), w.x, T.q(c.sub2), TG.d(c.fm_hi), TG.d(c.fm_vhi), c.fm_vlo0);   // S:1843-1850
+    if (prev_match < 2) prev_match = 2;
+    pos += prev_match;
+    uint32_t it = 1;
+    int32_t last_ins_pos = -1;
+    const uint64_t *trans = T.q(c.trans);
+    const uint64_t *pm = T.q(c.pm_lut);
+    const uint64_t *rec = T.q(c.mix_rec);
+    const uint64_t *gv = T.q(c.mm_gv);
+    const uint16_t *guide = T.h(c.mm_guide);
+    const uint8_t *bytes = reinterpret_cast<const uint8_t *>(T.w);
+    const uint64_t mw0 = T.q(c.mix_w)[0], mw1 = T.q(c.mix_w)[1], mw2 = T.q(c.mix_w)[2];
+    u32x4 w_next = ns_draw(key, ST_EVENT, seg, attempt, 1, 0);
+    while (pos < middle_ref) {                                                                     // S:1858
+        w = w_next;
+        w_next = ns_draw(key, ST_EVENT, seg, attempt, it + 1, 0);    // next iteration's draws do not depend on the chain state
+        const uint64_t ux = w.x, uy = w.y, uz = w.z, uw = w.w;
+        // The iteration asks the tables two independent questions: the run length of this event (transition row -> record of (type,
+        // component) -> guide byte -> two thresholds) and the next match length, which depends on the PREVIOUS match and the draw only
+        // (column word -> guide -> two segment words).  Their reads are issued side by side, round by round, in one basic block; whatever
+        // does not fit the common case — a walk of more than two steps, a segment that is not one unit wide, a draw beyond the column, a
+        // previous match >= 256 — is recomputed by the generic functions behind it.
+        // ---- round 1: transition row (S:1860-1864); column of the previous match (S:1891-1893)
+        const uint64_t t0 = trans[3u * state], t1 = trans[3u * state + 1u];
+        const uint32_t small = (uint32_t)prev_match < 256u ? 1u : 0u;
+        const uint64_t pe = pm[small ? (uint32_t)prev_match : 0u];
+        const uint32_t e0 = ux >= t0 ? 1u : 0u, e1 = ux >= t1 ? 1u : 0u;
+        const uint32_t error = e0 + (e0 & e1);                                                     // mis [0, t0), ins [t0, t1), del: the rest (trans_pick_u)
+        const uint32_t b = (uint32_t)(pe >> 56), o = (uint32_t)pe, ncol = (uint32_t)(pe >> 32) & 0xffffffu;
+        // ---- round 2: record of the run-length table; guide of the column
+        const uint64_t mw = error == NS_MIS ? mw0 : error == NS_INS ? mw1 : mw2;
+        const uint32_t comp = uy >= mw ? 1u : 0u;                                                  // tmp_rand < weight, mm:44,54
+        const uint64_t r0 = rec[2u * (2u * error + comp)], r1 = rec[2u * (2u * error + comp) + 1u];
+        const uint32_t s0 = guide[256u * b + (w.w >> 24)];
+        // ---- round 3: guide byte of the threshold walk; the guide's segment and the next
+        const uint32_t go = (uint32_t)r0, rn = (uint32_t)(r0 >> 32);
+        uint32_t rv = bytes[8u * (uint32_t)r1 + ns_clz32(~w.z)];
+        const uint32_t sc = min(s0, ncol - 1u);
+        const uint64_t g0 = gv[o + sc], g1 = gv[o + sc + 1u];                                      // (a word behind a table is read, never used)
+        // ---- round 4: the first two thresholds of the walk
+        const uint64_t ra = T.w[go + rv], rb = T.w[go + rv + 1u];
+        // ---- answers
+        const uint32_t k0 = (s0 < ncol ? 1u : 0u) & (uw >= NS_G_THR(g0) ? 1u : 0u), k1 = k0 & (s0 + 1u < ncol ? 1u : 0u) & (uw >= NS_G_THR(g1) ? 1u : 0u);
+        const uint64_t g = k0 ? g1 : g0;
+        const uint32_t fast = small & (s0 + k0 < ncol ? 1u : 0u) & (k1 ^ 1u) & ((g & NS_GV_UNIT) ? 1u : 0u);
+        int32_t next = (int32_t)(uint32_t)(g >> 35) - 1;
+        const uint32_t c1 = (rv + 1u < rn ? 1u : 0u) & (uz >= ra ? 1u : 0u), c2 = c1 & (rv + 2u < rn ? 1u : 0u) & (uz >= rb ? 1u : 0u);
+        rv += c1 + c2;
+        if (c2) while (rv + 1u < rn && uz >= T.w[go + rv]) ++rv;                                   // (rare: a run longer than the guide's bound + 2)
+        if (!fast) next = next_match_gv(T, TG, c, prev_match, w.w);
+        const int32_t step = (int32_t)rv + 1;                                                      // S:1866-1873
+        if (prev_match == 0 && next == 0) next = 1;                                                // S:1900-1901
+        // ---- the event (S:1875-1882), one store site
+        const bool ins = error == NS_INS;
+        l_new += ins ? step : error == NS_DEL ? -step : 0;
+        const bool coll = ins && last_ins_pos == pos && s.n > 0;                                   // dict key collision
+        s.n -= coll ? 1u : 0u; s.shift -= coll ? (int32_t)s.last_ins_len : 0;
+        ev_push32s(s, pos, error, step);
+        last_ins_pos = ins ? pos : last_ins_pos;
+        pos += ins ? 0 : step;
+        const bool over = !ins && pos >= middle_ref;
+        l_new += over ? pos - middle_ref : 0; middle_ref = over ? pos : middle_ref;
+        state = NS_ST_MIS + error;                                                                 // S:1884
+        prev_match = next;
+        if (pos + prev_match > middle_ref) { l_new += pos + prev_match - middle_ref; middle_ref = pos + prev_match; }
+        pos += prev_match;
+        if (prev_match == 0) state += 3;                                                           // S:1913-1914
+        else last_ins_pos = -1;
+        ++it;
+    }
+    return EList32{l_new, middle_ref};
+}
+#endif
 
 // ---- error_list with its table look-ups side by side (round 4; -DNS_CHAIN_MLP: an experiment that did NOT pay) -------------------------
 // Measured on configs[1] (950 000 reads, same box): 3.76 ms against 3.28 ms for chain_error_list — the three-fold run-length look-ups and
@@ -306,6 +519,7 @@ __device__ __forceinline__ EList32 chain_error_list_mlp(const Tabs &T, const Tab
 }
 
 // unaligned_error_list, S:1784-1830, with the event rewrite of DESIGN.md §5.3
+template <bool MR = false>
 NS_DEV EList32 chain_unaligned_error_list(const Tabs &T, const ChainTab &c, int32_t m_ref, const ns_key &key,
                                                               uint32_t seg, uint32_t attempt, EvSink32 &s) {
     int32_t l_new = m_ref, pos = 0, middle_ref = m_ref;
@@ -323,7 +537,7 @@ NS_DEV EList32 chain_unaligned_error_list(const Tabs &T, const ChainTab &c, int3
         const uint64_t ut = w.x;                                                                     // (p < t  <=>  u < ns_thr_lt(t))
         const int type = (ut < ns_thr_lt(0.4)) ? 3 : (ut < ns_thr_lt(0.7)) ? NS_MIS : (ut < ns_thr_lt(0.85)) ? NS_INS : NS_DEL;   // S:1787
         int32_t step = 1;
-        if (type != 3) step = run_length_w(T, c, type, type == NS_MIS ? mw0 : type == NS_INS ? mw1 : mw2, w.y, w.z);
+        if (type != 3) step = run_length_w<MR>(T, c, type, type == NS_MIS ? mw0 : type == NS_INS ? mw1 : mw2, w.y, w.z);
         if (type == NS_INS) { pend_ins += step; l_new += step; continue; }                          // S:1808-1815
         if (type == NS_DEL) l_new -= step;
         const int32_t L = pend_ins; pend_ins = 0;
@@ -367,7 +581,7 @@ __device__ inline EList32 coop_unaligned_error_list(const Tabs &T, const ChainTa
         const uint64_t ut = w.x;                                     // (p < t  <=>  u < ns_thr_lt(t))
         type = (ut < ns_thr_lt(0.4)) ? 3 : (ut < ns_thr_lt(0.7)) ? NS_MIS : (ut < ns_thr_lt(0.85)) ? NS_INS : NS_DEL;
         step = 1;
-        if (type != 3) step = (uint32_t)run_length_t(T, c, type, w.y, w.z);
+        if (type != 3) step = (uint32_t)run_length_t<NS_MIX_REC>(T, c, type, w.y, w.z);
     };
     int type_n; uint32_t step_n;
     draw(lane, type_n, step_n);

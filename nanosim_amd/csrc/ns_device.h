@@ -19,6 +19,15 @@ struct ChainTab {                 // offsets are in 8-byte words from the start 
     uint32_t n_words_lds;            // the blob up to here goes to LDS (k_chain<LDS>); the fp64 value edges behind it stay in global memory
     uint32_t mm_nbins, mm_bin, mm_bin_lut, mm_seg_off, mm_hi, mm_vhi, mm_vlo0, mm_guide;
     double fm_vlo0;
+#ifdef NS_CHAIN_TABS2
+    // layout bit 1 (NS_CHAIN_VAR & 8): the run-length tables' (offset, length, guide) by 2 * type + component as records of two words
+    // {offset | length << 32, guide} in the LDS part — indexed by a per-thread type, mix_cdf / mix_n / mix_g2 above are fetched from the
+    // kernel-argument segment with three vector loads per event
+    uint32_t mix_rec;
+    // layout bit 2 (NS_CHAIN_VAR & 32): ONE word per ECDF segment instead of threshold + value edge (ecdf_lookup_gv), and the column of a
+    // previous match < 256 in one word {first segment | segments << 32 | bin << 56} instead of bin_lut -> seg_off
+    uint32_t fm_gv, mm_gv, pm_lut, sub2;
+#endif
 };
 
 struct DevModel {

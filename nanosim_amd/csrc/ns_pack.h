@@ -4,18 +4,28 @@
 #pragma once
 #include <math.h>
 #include <string.h>
+#include <utility>
 #include <vector>
 #include "ns_device.h"
 
 // nseg: number of segments of all match-length columns together (t->mm_seg_off[t->mm_nbins]).  whole: every value edge is a whole number
 // below 2^31 and the step lists fit their index field — the condition for the integer LDS image (k_chain<LDS>).
-static inline void ns_pack_chain_tables(const ns_model_tables *t, uint32_t nseg, ChainTab &ct, std::vector<uint64_t> &blob, bool &whole) {
+// layout (NS_CHAIN_LAYOUT; 0 in the product build): bit 0 adds the run-length records, bit 1 the one-word ECDF segments and the column
+// table (ChainTab, NS_CHAIN_TABS2) — ns_pack_layout2 below rearranges the image this function builds.
+#ifdef NS_CHAIN_TABS2
+static inline void ns_pack_layout2(ChainTab &ct, std::vector<uint64_t> &blob, bool &whole, uint32_t layout, uint32_t fm_n, uint32_t nseg,
+                                   const std::vector<std::pair<uint32_t, uint32_t>> &segs);
+#endif
+static inline void ns_pack_chain_tables(const ns_model_tables *t, uint32_t nseg, ChainTab &ct, std::vector<uint64_t> &blob, bool &whole,
+                                        uint32_t layout = 0) {
     blob.clear();
+    std::vector<std::pair<uint32_t, uint32_t>> segs;          // (first word, words) of every table, in blob order
     // ---- pack the chain tables into one blob of 8-byte words (its first part is copied to LDS by k_chain) ----
     auto put_d = [&](const double *src, size_t n) { uint32_t off = (uint32_t)blob.size(); blob.resize(off + n);
-                                                     memcpy(blob.data() + off, src, n * 8); return off; };
+                                                     memcpy(blob.data() + off, src, n * 8); segs.emplace_back(off, (uint32_t)n); return off; };
     auto put_raw = [&](const void *src, size_t bytes) { uint32_t off = (uint32_t)blob.size(); blob.resize(off + (bytes + 7) / 8, 0);
-                                                         memcpy(blob.data() + off, src, bytes); return off; };
+                                                         memcpy(blob.data() + off, src, bytes); segs.emplace_back(off, (uint32_t)((bytes + 7) / 8));
+                                                         return off; };
     auto guide = [&](const double *hi, uint32_t n) {          // g[i] = #{s : hi[s] < i/256}: lower bound of the segment of any p >= i/256
         std::vector<uint16_t> g(256);
         uint32_t sidx = 0;
@@ -30,6 +40,7 @@ static inline void ns_pack_chain_tables(const ns_model_tables *t, uint32_t nseg,
     auto put_thr = [&](const double *src, size_t n, bool gt) {
         uint32_t off = (uint32_t)blob.size(); blob.resize(off + n);
         for (size_t i = 0; i < n; ++i) blob[off + i] = gt ? ns_thr_gt(src[i]) : ns_thr_lt(src[i]);
+        segs.emplace_back(off, (uint32_t)n);
         return off; };
     ct.trans = put_thr(&t->trans[0][0], 21, false);          // p < a, p < a + b            (S:1860-1864)
     ct.mix_w = put_thr(t->mix_w, 3, false);                   // tmp_rand < weight           (mm:44, 54)
@@ -125,4 +136,81 @@ static inline void ns_pack_chain_tables(const ns_model_tables *t, uint32_t nseg,
     ct.fm_hi = put_d(t->fm_hi, t->fm_nseg); ct.mm_hi = put_d(t->mm_hi, nseg);      // fp64 tables: global memory (wide segments, cooperative chain)
     ct.fm_vhi = put_d(t->fm_vhi, t->fm_nseg); ct.mm_vhi = put_d(t->mm_vhi, nseg);
     ct.n_words = (uint32_t)blob.size();
+#ifdef NS_CHAIN_TABS2
+    ct.mix_rec = ct.fm_gv = ct.mm_gv = ct.pm_lut = ct.sub2 = 0;
+    if (layout) ns_pack_layout2(ct, blob, whole, layout, t->fm_nseg, nseg, segs);
+#else
+    (void)layout;
+#endif
 }
+
+#ifdef NS_CHAIN_TABS2
+// Layouts 1 and 3 (experiments, NS_CHAIN_VAR bits 8 and 32): the image of layout 0 with tables added to its LDS part and, for layout 3,
+// the threshold / value-edge / step tables of ecdf_lookup_u moved behind it (the one-word segments replace them in LDS).
+//   mix_rec   6 records {table offset | thresholds << 32, guide offset}, index 2 * type + component
+//   fm_gv, mm_gv   per ECDF segment ONE word: bits 0..32 the threshold ns_thr_gt(hi[s]); bit 33: one unit wide and every draw gives vlo —
+//             bits 35.. = vhi; bit 34: 2..15 units wide (or one unit with a step inside) — bits 35.. = index into sub2 of {vhi | steps << 32}
+//             followed by the step thresholds; neither bit: the fp64 formula on the global tables
+//   pm_lut    previous match v < 256 -> {first segment of its column | segments << 32 | bin << 56}
+static inline void ns_pack_layout2(ChainTab &ct, std::vector<uint64_t> &blob, bool &whole, uint32_t layout, uint32_t fm_n, uint32_t nseg,
+                                   const std::vector<std::pair<uint32_t, uint32_t>> &segs) {
+    std::vector<uint64_t> fm_gv, mm_gv, pm, sub2;
+    if (layout & 2u) {
+        auto conv = [&](uint32_t g_off, uint32_t v_off, uint32_t n, std::vector<uint64_t> &out) {
+            const uint32_t *vu = reinterpret_cast<const uint32_t *>(blob.data() + v_off);
+            for (uint32_t i = 0; i < n; ++i) {
+                const uint64_t g = blob[g_off + i], thr = g & 0x1ffffffffull;
+                const uint32_t nt = (uint32_t)(g >> 36) & 15u, v = vu[i];
+                if ((v & 0x7fffffffu) >= (1u << 29)) whole = false;
+                uint64_t word = thr;
+                if (v & 0x80000000u) word |= 1ull << 33 | (uint64_t)(v & 0x7fffffffu) << 35;
+                else if (nt) {
+                    word |= 1ull << 34 | (uint64_t)sub2.size() << 35;
+                    sub2.push_back((uint64_t)v | (uint64_t)nt << 32);
+                    for (uint32_t k = 0; k < nt; ++k) sub2.push_back(blob[ct.sub + (g >> 40) + k]);
+                }
+                out.push_back(word);
+            } };
+        conv(ct.fm_g, ct.fm_vhi_u, fm_n, fm_gv);
+        conv(ct.mm_g, ct.mm_vhi_u, nseg, mm_gv);
+        if (sub2.size() >= (1u << 28)) whole = false;
+        sub2.push_back(0);
+        const uint8_t *lut = reinterpret_cast<const uint8_t *>(blob.data() + ct.mm_bin_lut);
+        const uint32_t *so = reinterpret_cast<const uint32_t *>(blob.data() + ct.mm_seg_off);
+        for (uint32_t v = 0; v < 256; ++v) {
+            const uint32_t b = lut[v], o = so[b], nc = so[b + 1] - o;
+            if (nc >= (1u << 24)) whole = false;
+            pm.push_back((uint64_t)o | (uint64_t)(nc & 0xffffffu) << 32 | (uint64_t)b << 56);
+        }
+    }
+    const uint32_t n_lds1 = ct.n_words_lds;
+    auto moved = [&](uint32_t off) { return (layout & 2u) && (off == ct.fm_g || off == ct.mm_g || off == ct.fm_vhi_u || off == ct.mm_vhi_u || off == ct.sub); };
+    std::vector<uint64_t> nb;
+    std::vector<std::pair<uint32_t, uint32_t>> remap;          // old first word -> new first word
+    auto take = [&](const std::pair<uint32_t, uint32_t> &sg) {
+        remap.emplace_back(sg.first, (uint32_t)nb.size());
+        nb.insert(nb.end(), blob.begin() + sg.first, blob.begin() + sg.first + sg.second); };
+    auto add = [&](const std::vector<uint64_t> &v) { const uint32_t off = (uint32_t)nb.size(); nb.insert(nb.end(), v.begin(), v.end()); return off; };
+    for (const auto &sg : segs) if (sg.first < n_lds1 && !moved(sg.first)) take(sg);
+    uint32_t rec_at = 0;
+    if (layout & 1u) rec_at = add(std::vector<uint64_t>(12, 0));
+    if (layout & 2u) { ct.fm_gv = add(fm_gv); ct.mm_gv = add(mm_gv); ct.pm_lut = add(pm); ct.sub2 = add(sub2); }
+    const uint32_t n_lds = (uint32_t)nb.size();
+    for (const auto &sg : segs) if (sg.first < n_lds1 && moved(sg.first)) take(sg);
+    for (const auto &sg : segs) if (sg.first >= n_lds1) take(sg);
+    auto mv = [&](uint32_t &f) { for (const auto &r : remap) if (r.first == f) { f = r.second; return; } whole = false; };
+    mv(ct.trans); mv(ct.mix_w);
+    for (int ty = 0; ty < 3; ++ty) for (int c = 0; c < 2; ++c) { mv(ct.mix_cdf[ty][c]); mv(ct.mix_g2[ty][c]); }
+    mv(ct.fm_g); mv(ct.fm_guide); mv(ct.mm_bin); mv(ct.mm_bin_lut); mv(ct.mm_seg_off); mv(ct.mm_g); mv(ct.mm_vlo0); mv(ct.mm_guide);
+    mv(ct.fm_vhi_u); mv(ct.mm_vhi_u); mv(ct.sub); mv(ct.fm_hi); mv(ct.mm_hi); mv(ct.fm_vhi); mv(ct.mm_vhi);
+    if (layout & 1u) {
+        ct.mix_rec = rec_at;
+        for (uint32_t ty = 0; ty < 3; ++ty) for (uint32_t c = 0; c < 2; ++c) {
+            nb[rec_at + 2 * (2 * ty + c)] = (uint64_t)ct.mix_cdf[ty][c] | (uint64_t)ct.mix_n[ty][c] << 32;
+            nb[rec_at + 2 * (2 * ty + c) + 1] = ct.mix_g2[ty][c];
+        }
+    }
+    blob.swap(nb);
+    ct.n_words_lds = n_lds; ct.n_words = (uint32_t)blob.size();
+}
+#endif

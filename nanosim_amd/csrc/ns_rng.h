@@ -6,6 +6,16 @@
 #include <stdint.h>
 
 #define NS_HD __host__ __device__ __forceinline__
+// NS_CHAIN_VAR (bit mask, 0 in the product build): formulations of the event chains that are timed against each other on the GPU
+// (scripts/ab_run.sh) and held against the oracle on the CPU (tests/test_chain_host.py); ns_chain.h lists the bits.  Bits 8 and 32 add
+// tables to the packed blob (NS_CHAIN_TABS2: fields of ChainTab, ns_pack.h layouts 1 and 3); the CPU test build has them all.
+#ifndef NS_CHAIN_VAR
+#define NS_CHAIN_VAR 0
+#endif
+#if (NS_CHAIN_VAR & (8 | 32)) || defined(NS_HOST_TEST)
+#define NS_CHAIN_TABS2 1
+#endif
+#define NS_CHAIN_LAYOUT (((NS_CHAIN_VAR) & 32) ? 3u : ((NS_CHAIN_VAR) & 8) ? 1u : 0u)
 // NS_DEV: device code of the thread-per-read event chains (ns_chain.h).  The CPU test suite compiles the SAME source for the host
 // (tests/chain_host.hip, -DNS_HOST_TEST, host pass only) and holds it against the oracle without a GPU; in the product build the
 // qualifier is the plain device one.

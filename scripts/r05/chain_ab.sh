@@ -1,0 +1,22 @@
+#!/bin/bash
+# round 5, first GPU call: the formulations of the event chain prepared in round 4 (ns_chain.h, NS_CHAIN_VAR) against the product build.
+#   here (no GPU):  scripts/r05/chain_ab.sh build      -> nanosim_amd/_variants/*.so (they travel to the GPU box with the snapshot)
+#   on the GPU box: scripts/r05/chain_ab.sh            -> per variant: the bit-exact parity tests, then 3 bench steps with the kernel times
+# Every variant is held against the oracle on the CPU by tests/test_chain_host.py (same events, bit for bit); what the GPU adds is the
+# timing and the parity of the whole batch through k_chain.
+#   var1  one ev_push32 site            var2  run_length_w            var4  column looked up before the event store
+#   var8  run-length record in LDS instead of three kernel-argument loads per event (blob layout 1)
+#   v2    chain_error_list_v2: one-word ECDF segments, column word, reads issued round by round in one basic block (blob layout 3)
+cd "$(dirname "$0")/../.."
+if [ "$1" = build ]; then
+  exec scripts/ab_build.sh base:"" var1:"-DNS_CHAIN_VAR=1" var2:"-DNS_CHAIN_VAR=2" var4:"-DNS_CHAIN_VAR=4" var8:"-DNS_CHAIN_VAR=8" var9:"-DNS_CHAIN_VAR=9" \
+       var11:"-DNS_CHAIN_VAR=11" v2:"-DNS_CHAIN_VAR=40"
+fi
+O=gpurun_out/r05a; mkdir -p $O
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+for f in nanosim_amd/_variants/*.so; do
+  name=$(basename $f .so)
+  echo "== $name parity"; ( NANOSIM_AMD_LIB=$PWD/$f timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3 ) | tee $O/parity_$name.log
+done
+scripts/ab_run.sh 2>&1 | tee $O/ab_chain.log
+( timeout 300 python -m pytest tests/test_gpu_zz_characterize.py -m gpu -q 2>&1 | tail -5 ) | tee $O/pytest_characterize.log

@@ -16,10 +16,11 @@ struct ChainHost {
 
 extern "C" {
 
-void *chost_pack(const ns_model_tables *t) {
+// layout: 0 = the product's blob; 1 = + run-length records (NS_CHAIN_VAR & 8); 3 = + one-word ECDF segments, column table (NS_CHAIN_VAR & 32)
+void *chost_pack(const ns_model_tables *t, uint32_t layout) {
     ChainHost *h = new (std::nothrow) ChainHost;
     if (!h) return nullptr;
-    ns_pack_chain_tables(t, t->mm_seg_off[t->mm_nbins], h->ct, h->blob, h->whole);
+    ns_pack_chain_tables(t, t->mm_seg_off[t->mm_nbins], h->ct, h->blob, h->whole, layout);
     return h;
 }
 void chost_free(void *p) { delete static_cast<ChainHost *>(p); }
@@ -29,13 +30,21 @@ uint32_t chost_lds_words(const void *p) { return static_cast<const ChainHost *>(
 // variant 0: chain_error_list<true>  — the integer image k_chain<LDS> walks (T = the blob's first n_words_lds words, here the blob itself)
 //         1: chain_error_list<false> — the fp64 tables (models whose value edges are not whole numbers, tables too large for LDS)
 //         2: chain_unaligned_error_list
-//         3: chain_error_list_bf<true> (-DNS_CHAIN_BF), when the header has it
+//    10 + v: chain_error_list<true, v>, v = 1 .. 15 — the formulations of the iteration that -DNS_CHAIN_VAR=v selects in the engine
+//            (v & 8: run-length records, needs a blob of layout 1 or 3)
+//        30: chain_unaligned_error_list<true> (run-length records: layout 1 or 3)
+//        32: chain_error_list_v2 (layout 3)
+// T and TG: the LDS image is the first n_words_lds words of the blob — handing the chain a COPY of just those words as T checks that it
+// never reads a table of the LDS part behind them.
 // staged != 0: events go through the four-slot staging column (EvSink32::stg) as in k_chain<LDS> for single-piece reads; cap must then be
 // a multiple of four and ev 32-byte aligned.  Returns 0, or -1 for an unknown variant.
 int chost_error_list(const void *p, int variant, int staged, int32_t m_ref, uint64_t seed, uint64_t read, uint32_t seg, uint32_t attempt,
                      ns_event *ev, uint32_t cap, int32_t *l_new, int32_t *middle_ref, uint32_t *n_ev, int32_t *shift, int *overflow, int *range) {
     const ChainHost *h = static_cast<const ChainHost *>(p);
-    const Tabs T{h->blob.data()};
+    const Tabs TG{h->blob.data()};
+    std::vector<uint64_t> lds(h->blob.begin(), h->blob.begin() + h->ct.n_words_lds);      // (+ nothing: a read behind it is out of bounds)
+    const bool image = variant != 1;                                                        // the fp64 chain walks the whole blob (k_chain<false, .>)
+    const Tabs T{image ? lds.data() : h->blob.data()};
     const ns_key key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)read, (uint32_t)(read >> 32)};
     uint2 stage[4 * NS_CHAIN_BLOCK];
     EvSink32 s;
@@ -43,12 +52,26 @@ int chost_error_list(const void *p, int variant, int staged, int32_t m_ref, uint
     s.stg = staged ? stage : nullptr;
     EList32 e;
     switch (variant) {
-    case 0: e = chain_error_list<true>(T, T, h->ct, m_ref, key, seg, attempt, s); break;
-    case 1: e = chain_error_list<false>(T, T, h->ct, m_ref, key, seg, attempt, s); break;
+    case 0: e = chain_error_list<true>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
+    case 1: e = chain_error_list<false>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
     case 2: e = chain_unaligned_error_list(T, h->ct, m_ref, key, seg, attempt, s); break;
-#ifdef NS_CHAIN_BF
-    case 3: e = chain_error_list_bf(T, T, h->ct, m_ref, key, seg, attempt, s); break;
-#endif
+    case 18: e = chain_error_list<true, 8>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
+    case 19: e = chain_error_list<true, 9>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
+    case 20: e = chain_error_list<true, 10>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
+    case 21: e = chain_error_list<true, 11>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
+    case 22: e = chain_error_list<true, 12>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
+    case 23: e = chain_error_list<true, 13>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
+    case 24: e = chain_error_list<true, 14>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
+    case 25: e = chain_error_list<true, 15>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
+    case 30: e = chain_unaligned_error_list<true>(T, h->ct, m_ref, key, seg, attempt, s); break;
+    case 32: e = chain_error_list_v2(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
+    case 11: e = chain_error_list<true, 1>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
+    case 12: e = chain_error_list<true, 2>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
+    case 13: e = chain_error_list<true, 3>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
+    case 14: e = chain_error_list<true, 4>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
+    case 15: e = chain_error_list<true, 5>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
+    case 16: e = chain_error_list<true, 6>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
+    case 17: e = chain_error_list<true, 7>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
     default: return -1;
     }
     ev_flush_tail(s);

@@ -19,7 +19,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not found")
 
-VARIANT_LDS, VARIANT_FP64, VARIANT_UNALIGNED, VARIANT_BF = 0, 1, 2, 3
+VARIANT_LDS, VARIANT_FP64, VARIANT_UNALIGNED = 0, 1, 2
+# what -DNS_CHAIN_VAR=v builds into k_chain (ns_chain.h), per blob layout (ns_pack.h) it needs:
+FORMULATIONS = {0: tuple(range(11, 18)),                              # chain_error_list<true, 1 .. 7>
+                1: tuple(range(18, 26)) + (30,),                      # chain_error_list<true, 8 .. 15>, chain_unaligned_error_list<true>: run-length records
+                3: (32, 30, 1, 2)}                                    # chain_error_list_v2 (+ what else the engine runs on that blob)
 
 
 def _build(tmp, extra=()):
@@ -28,7 +32,7 @@ def _build(tmp, extra=()):
            *extra, "-shared", "-fPIC", "-o", out, os.path.join(ROOT, "tests", "chain_host.hip")]
     subprocess.check_call(cmd, cwd=ROOT, stderr=subprocess.DEVNULL)
     L = C.CDLL(out)
-    L.chost_pack.restype = C.c_void_p; L.chost_pack.argtypes = [C.POINTER(M.NsModelTables)]
+    L.chost_pack.restype = C.c_void_p; L.chost_pack.argtypes = [C.POINTER(M.NsModelTables), C.c_uint32]
     L.chost_free.restype = None; L.chost_free.argtypes = [C.c_void_p]
     L.chost_whole.restype = C.c_int; L.chost_whole.argtypes = [C.c_void_p]
     L.chost_lds_words.restype = C.c_uint32; L.chost_lds_words.argtypes = [C.c_void_p]
@@ -78,9 +82,9 @@ def same(h, o, what):
     assert h["ev"][:n].tobytes() == o["ev"][:n].tobytes(), what
 
 
-def sweep(L, mdl, variants, n_cases, seed, lengths):
+def sweep(L, mdl, variants, n_cases, seed, lengths, layout=0):
     t = mdl.to_c()
-    pk = L.chost_pack(C.byref(t))
+    pk = L.chost_pack(C.byref(t), layout)
     assert pk
     try:
         rng = np.random.default_rng(seed)
@@ -91,7 +95,7 @@ def sweep(L, mdl, variants, n_cases, seed, lengths):
             seg, att = int(rng.choice([0, 1, 5, 128, 130])), int(rng.integers(0, 1000))
             cap = 4 * ((2 * m_ref + 64) // 4)
             for v in variants:
-                o = oracle_list(t, v == VARIANT_UNALIGNED, m_ref, sd, rd, seg, att, cap)
+                o = oracle_list(t, v in (VARIANT_UNALIGNED, 30), m_ref, sd, rd, seg, att, cap)
                 same(host_list(L, pk, v, m_ref, sd, rd, seg, att, cap), o, (v, m_ref, sd, rd, seg, att))
                 if v != VARIANT_FP64:
                     same(host_list(L, pk, v, m_ref, sd, rd, seg, att, cap, staged=1), o, ("staged", v, m_ref, sd, rd))
@@ -126,17 +130,36 @@ def test_device_chains_on_models_that_take_the_other_look_up_paths(host, tmp_pat
         pk, n_ev = sweep(host, mdl, (VARIANT_LDS, VARIANT_FP64, VARIANT_UNALIGNED), 120, 2, (1, 4, 33, 900, 8000))
         assert host.chost_whole(pk) and n_ev > 20000, name
         host.chost_free(pk)
+        pk, n_ev = sweep(host, mdl, FORMULATIONS[3], 120, 2, (1, 4, 33, 900, 8000), layout=3)        # the one-word segments on the same tables
+        assert host.chost_whole(pk) and n_ev > 20000, name
+        host.chost_free(pk)
+
+
+def test_every_formulation_of_the_iteration_gives_the_same_events(host, small_model, tmp_path):
+    """chain_error_list<VU32, VAR>: the formulations that scripts/ab_run.sh times against each other on the GPU are the same function —
+    checked here against the oracle on the small model and on the dense one (insertions on top of each other, zero-length matches)."""
+    from nanosim_amd import synth
+    spec = synth.SynthModelSpec(n_train=3000, seed=7, aligned_median=2500.0, mis=(3.0, 0.0, 0.3, 0.5), ins=(8.0, 0.9, 0.12, 0.5),
+                                dele=(6.0, 0.95, 0.15, 0.5), mm_means=(2.0, 2.5, 3.0, 3.0, 3.5, 3.5, 4.0, 4.0),
+                                mm_zero=(0.0, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3), fm_mean=3.0)
+    prefix = str(tmp_path / "dense" / "training")
+    synth.write_model(prefix, spec, write_pkl=False)
+    for mdl in (small_model, M.load_model(prefix)):
+        for layout, variants in FORMULATIONS.items():
+            pk, n_ev = sweep(host, mdl, variants, 60, 3, (1, 2, 9, 300, 6000), layout=layout)
+            assert n_ev > 20000 and host.chost_whole(pk)
+            host.chost_free(pk)
 
 
 def test_event_capacity_overflow_and_range_flags(host, small_model):
     """A sink that is too small: the chain keeps counting, flags the overflow and never writes behind the capacity (k_chain re-plans the
     batch from the count); the same numbers as the oracle."""
     t = small_model.to_c()
-    pk = host.chost_pack(C.byref(t))
+    pk = host.chost_pack(C.byref(t), 0)
     try:
-        for v in (VARIANT_LDS, VARIANT_UNALIGNED):
+        for v in (VARIANT_LDS, VARIANT_UNALIGNED) + FORMULATIONS[0]:
             for staged in (0, 1):
-                full = oracle_list(t, v == VARIANT_UNALIGNED, 5000, 77, 5, 0, 0, 4096)
+                full = oracle_list(t, v in (VARIANT_UNALIGNED, 30), 5000, 77, 5, 0, 0, 4096)
                 assert full["n_ev"] > 40
                 cap = 16
                 ev = _aligned(cap + 8)
