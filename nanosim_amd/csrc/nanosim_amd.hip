@@ -290,6 +290,11 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #ifndef NS_CHAIN_MINW
 #define NS_CHAIN_MINW 4
 #endif
+#if NS_CHAIN_VAR & 32
+#define NS_UNALIGNED_LIST chain_unaligned_error_list_v2
+#else
+#define NS_UNALIGNED_LIST chain_unaligned_error_list<NS_MIX_REC>
+#endif
 template <bool LDS_TABLES, bool COOP>
 __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK, COOP ? 4 : NS_CHAIN_MINW) k_chain(GenArgs A) {
     extern __shared__ uint64_t lds_tbl[];
@@ -347,7 +352,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK, COOP ? 4 : NS_CHAI
                 }
                 EList32 e;
                 if (kind == NS_KIND_PERFECT) { e.l_new = e.middle_ref = m32; }
-                else if (p.kind) e = COOP ? coop_unaligned_error_list(T, ct, m32, key, sid, a, sink, lane) : chain_unaligned_error_list<NS_MIX_REC>(T, ct, m32, key, sid, a, sink);
+                else if (p.kind) e = COOP ? coop_unaligned_error_list(T, ct, m32, key, sid, a, sink, lane) : NS_UNALIGNED_LIST(T, ct, m32, key, sid, a, sink);
                 else if (COOP) e = coop_error_list(T, ct, m32, key, sid, a, sink, *coop, lane);
 #ifdef NS_CHAIN_MLP          // (round 4: measured SLOWER than the one-question-at-a-time chain, 3.76 against 3.28 ms — ns_chain.h)
                 else if constexpr (LDS_TABLES) e = chain_error_list_mlp(T, Tabs{A.m.chain_blob}, ct, m32, key, sid, a, sink);

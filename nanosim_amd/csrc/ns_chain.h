@@ -290,6 +290,22 @@ NS_DEV void ev_push32s(EvSink32 &s, int32_t pos, uint32_t type, int32_t len) {
     s.n++;
 }
 
+// run length (S:1866-1873 / S:1796-1806) by the record of (type, component): record -> guide byte -> the first two thresholds read
+// TOGETHER (the word behind a table is read, never used) -> arithmetic compares; a walk of more than two steps is the rare tail
+NS_DEV int32_t run_length_r(const Tabs &T, const ChainTab &c, uint32_t type, uint64_t weight_thr, uint32_t u_mix, uint32_t u_len) {
+    const uint32_t comp = (uint64_t)u_mix >= weight_thr ? 1u : 0u;                                 // tmp_rand < weight, mm:44,54
+    const uint64_t *r = T.w + c.mix_rec + 2u * (2u * type + comp);
+    const uint64_t r0 = r[0], r1 = r[1];
+    const uint32_t go = (uint32_t)r0, rn = (uint32_t)(r0 >> 32);
+    const uint64_t uz = u_len;
+    uint32_t rv = reinterpret_cast<const uint8_t *>(T.w)[8u * (uint32_t)r1 + ns_clz32(~u_len)];
+    const uint64_t ra = T.w[go + rv], rb = T.w[go + rv + 1u];
+    const uint32_t c1 = (rv + 1u < rn ? 1u : 0u) & (uz >= ra ? 1u : 0u), c2 = c1 & (rv + 2u < rn ? 1u : 0u) & (uz >= rb ? 1u : 0u);
+    rv += c1 + c2;
+    if (c2) while (rv + 1u < rn && uz >= T.w[go + rv]) ++rv;
+    return (int32_t)rv + 1;
+}
+
 #define NS_GV_UNIT (1ull << 33)
 #define NS_GV_NARROW (1ull << 34)
 // the segment of draw u in a column of n one-word segments and the value it gives.  Straight-line for the common case — the guide's
@@ -412,6 +428,47 @@ NS_DEV EList32 chain_error_list_v2(const Tabs &T, const Tabs &TG, const ChainTab
         if (prev_match == 0) state += 3;                                                           // S:1913-1914
         else last_ins_pos = -1;
         ++it;
+    }
+    return EList32{l_new, middle_ref};
+}
+
+// unaligned_error_list (S:1784-1830, event rewrite of DESIGN.md section 5.3) in the same style (NS_CHAIN_VAR & 32): the seven event-store
+// sites of chain_unaligned_error_list — one per case of (type, pending insertion) — become THREE slots filled by selects: A the
+// mismatch / deletion at pos, B the pending insertion behind it at pos + 1, C the rest of a mismatch run behind that insertion; an
+// insertion draws no event and does not advance (it waits in pend_ins), without leaving the iteration early.
+NS_DEV EList32 chain_unaligned_error_list_v2(const Tabs &T, const ChainTab &c, int32_t m_ref, const ns_key &key,
+                                             uint32_t seg, uint32_t attempt, EvSink32 &s) {
+    int32_t l_new = m_ref, pos = 0, middle_ref = m_ref;
+    int32_t pend_ins = 0;
+    if (m_ref <= 0) return EList32{l_new, middle_ref};
+    uint32_t it = 0;
+    u32x4 w_next = ns_draw(key, ST_UEVENT, seg, attempt, 0, 0);
+    const uint64_t mw0 = T.q(c.mix_w)[0], mw1 = T.q(c.mix_w)[1], mw2 = T.q(c.mix_w)[2];
+    while (pos < middle_ref) {
+        const u32x4 w = w_next;
+        ++it;
+        w_next = ns_draw(key, ST_UEVENT, seg, attempt, it, 0);
+        const uint64_t ut = w.x;                                                                     // (p < t  <=>  u < ns_thr_lt(t))
+        const uint32_t type = (ut < ns_thr_lt(0.4)) ? 3u : (ut < ns_thr_lt(0.7)) ? (uint32_t)NS_MIS : (ut < ns_thr_lt(0.85)) ? (uint32_t)NS_INS : (uint32_t)NS_DEL;   // S:1787
+        const uint32_t tt = type == 3u ? (uint32_t)NS_MIS : type;                                    // (a match asks the mismatch table and drops the answer)
+        const int32_t run = run_length_r(T, c, tt, tt == NS_MIS ? mw0 : tt == NS_INS ? mw1 : mw2, w.y, w.z);
+        const int32_t step = type == 3u ? 1 : run;
+        const bool is_ins = type == NS_INS, is_mis = type == NS_MIS, is_del = type == NS_DEL;
+        l_new += is_ins ? step : is_del ? -step : 0;                                                 // S:1808-1815
+        const int32_t L = is_ins ? 0 : pend_ins;
+        pend_ins = is_ins ? pend_ins + step : 0;
+        const bool va = is_mis || is_del;
+        int32_t dl = step - L; dl = dl < 1 ? 1 : dl;
+        const int32_t la = L == 0 ? step : is_mis ? 1 : dl;
+        const int32_t lb = is_del ? L - (step - 1) : L;
+        const bool vb = L > 0 && lb > 0;
+        const bool vc = is_mis && L > 0 && step - 1 > L;
+        if (va) ev_push32s(s, pos, type, la);
+        if (vb) ev_push32s(s, pos + 1, NS_INS, lb);
+        if (vc) ev_push32s(s, pos + 1, NS_MIS, step - 1 - L);
+        pos += is_ins ? 0 : step;
+        const bool over = pos > middle_ref;                                                          // S:1826-1828
+        l_new += over ? pos - middle_ref : 0; middle_ref = over ? pos : middle_ref;
     }
     return EList32{l_new, middle_ref};
 }

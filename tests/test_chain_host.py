@@ -23,7 +23,7 @@ VARIANT_LDS, VARIANT_FP64, VARIANT_UNALIGNED = 0, 1, 2
 # what -DNS_CHAIN_VAR=v builds into k_chain (ns_chain.h), per blob layout (ns_pack.h) it needs:
 FORMULATIONS = {0: tuple(range(11, 18)),                              # chain_error_list<true, 1 .. 7>
                 1: tuple(range(18, 26)) + (30,),                      # chain_error_list<true, 8 .. 15>, chain_unaligned_error_list<true>: run-length records
-                3: (32, 30, 1, 2)}                                    # chain_error_list_v2 (+ what else the engine runs on that blob)
+                3: (32, 31, 30, 1, 2)}                                    # chain_error_list_v2 (+ what else the engine runs on that blob)
 
 
 def _build(tmp, extra=()):
@@ -95,7 +95,7 @@ def sweep(L, mdl, variants, n_cases, seed, lengths, layout=0):
             seg, att = int(rng.choice([0, 1, 5, 128, 130])), int(rng.integers(0, 1000))
             cap = 4 * ((2 * m_ref + 64) // 4)
             for v in variants:
-                o = oracle_list(t, v in (VARIANT_UNALIGNED, 30), m_ref, sd, rd, seg, att, cap)
+                o = oracle_list(t, v in (VARIANT_UNALIGNED, 30, 31), m_ref, sd, rd, seg, att, cap)
                 same(host_list(L, pk, v, m_ref, sd, rd, seg, att, cap), o, (v, m_ref, sd, rd, seg, att))
                 if v != VARIANT_FP64:
                     same(host_list(L, pk, v, m_ref, sd, rd, seg, att, cap, staged=1), o, ("staged", v, m_ref, sd, rd))
@@ -159,7 +159,7 @@ def test_event_capacity_overflow_and_range_flags(host, small_model):
     try:
         for v in (VARIANT_LDS, VARIANT_UNALIGNED) + FORMULATIONS[0]:
             for staged in (0, 1):
-                full = oracle_list(t, v in (VARIANT_UNALIGNED, 30), 5000, 77, 5, 0, 0, 4096)
+                full = oracle_list(t, v in (VARIANT_UNALIGNED, 30, 31), 5000, 77, 5, 0, 0, 4096)
                 assert full["n_ev"] > 40
                 cap = 16
                 ev = _aligned(cap + 8)
