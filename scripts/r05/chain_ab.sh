@@ -7,10 +7,12 @@
 #   var1  one ev_push32 site            var2  run_length_w            var4  column looked up before the event store
 #   var8  run-length record in LDS instead of three kernel-argument loads per event (blob layout 1)
 #   v2    chain_error_list_v2: one-word ECDF segments, column word, reads issued round by round in one basic block (blob layout 3)
+#   v2m5  v2 compiled for five wavefronts per SIMD (96 VGPRs, 20 bytes of spills outside the loop): the bench model's LDS image is 24.1 KB
+#         in layout 3 (29.1 KB in layout 0), + 8 KB of event staging = five workgroups of 256 threads per CU instead of four
 cd "$(dirname "$0")/../.."
 if [ "$1" = build ]; then
   exec scripts/ab_build.sh base:"" var1:"-DNS_CHAIN_VAR=1" var2:"-DNS_CHAIN_VAR=2" var4:"-DNS_CHAIN_VAR=4" var8:"-DNS_CHAIN_VAR=8" var9:"-DNS_CHAIN_VAR=9" \
-       var11:"-DNS_CHAIN_VAR=11" v2:"-DNS_CHAIN_VAR=40"
+       var11:"-DNS_CHAIN_VAR=11" v2:"-DNS_CHAIN_VAR=40" v2m5:"-DNS_CHAIN_VAR=40 -DNS_CHAIN_MINW=5"
 fi
 O=gpurun_out/r05a; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
