@@ -274,17 +274,28 @@ NS_DEV EList32 chain_error_list(const Tabs &T, const Tabs &TG, const ChainTab &c
 //     side by side behind the transition row instead of eleven in a row;
 //   * one ev_push32 site (formulation 1) and the run-length record (formulation 8).
 // Same events as chain_error_list, bit for bit (tests/test_chain_host.py against the oracle).
-// ev_push32 with the bookkeeping behind the store as selects (no exec-mask regions for the type)
-NS_DEV void ev_push32s(EvSink32 &s, int32_t pos, uint32_t type, int32_t len) {
+// ev_push32 with the bookkeeping behind the store as selects (no exec-mask regions for the type) and the two flags as ARITHMETIC: the
+// longest run and the extremes of the shift at store time are tracked (three vector instructions) and turned into `range` / `overflow`
+// once per piece (ev_track_close) — kept as booleans they are lane masks the compiler updates with three scalar instructions per flag
+// and store site.  overflow == "n ended above the capacity": n never ends an iteration below where it started (the dict-key collision
+// pops one event and pushes one).
+struct EvTrack { int32_t max_len, smin, smax; };
+NS_DEV EvTrack ev_track_open(const EvSink32 &s) { return EvTrack{0, s.shift, s.shift}; }
+NS_DEV void ev_track_close(EvSink32 &s, const EvTrack &t) {
+    if (t.max_len > (int32_t)NS_EV_LEN_MAX || !ev_shift_fits(t.smin) || !ev_shift_fits(t.smax)) s.range = true;
+    if (s.n > s.cap) s.overflow = true;
+}
+NS_DEV void ev_push32s(EvSink32 &s, EvTrack &t, int32_t pos, uint32_t type, int32_t len) {
     const uint32_t l = len > (int32_t)NS_EV_LEN_MAX ? NS_EV_LEN_MAX : (uint32_t)len;
-    if (len > (int32_t)NS_EV_LEN_MAX || !ev_shift_fits(s.shift)) s.range = true;
+    t.max_len = len > t.max_len ? len : t.max_len;
+    t.smin = s.shift < t.smin ? s.shift : t.smin; t.smax = s.shift > t.smax ? s.shift : t.smax;
     if (s.n < s.cap) {
         ns_event e; e.pos = (uint32_t)pos; e.info = ns_ev_pack(l, type, s.shift);
         if (s.stg) {
             s.stg[(s.n & 3u) * NS_CHAIN_BLOCK] = make_uint2(e.pos, e.info);
             if ((s.n & 3u) == 3u) ev_flush4(s, s.n - 3u);
         } else s.ev[s.n] = e;
-    } else s.overflow = true;
+    }
     s.shift += type == NS_INS ? (int32_t)l : type == NS_DEL ? -(int32_t)l : 0;
     s.last_ins_len = type == NS_INS ? l : s.last_ins_len;
     s.n++;
@@ -372,6 +383,7 @@ NS_DEV EList32 chain_error_list_v2(const Tabs &T, const Tabs &TG, const ChainTab
     const uint8_t *bytes = reinterpret_cast<const uint8_t *>(T.w);
     const uint64_t mw0 = T.q(c.mix_w)[0], mw1 = T.q(c.mix_w)[1], mw2 = T.q(c.mix_w)[2];
     u32x4 w_next = ns_draw(key, ST_EVENT, seg, attempt, 1, 0);
+    EvTrack trk = ev_track_open(s);
     while (pos < middle_ref) {                                                                     // S:1858
         w = w_next;
         w_next = ns_draw(key, ST_EVENT, seg, attempt, it + 1, 0);    // next iteration's draws do not depend on the chain state
@@ -416,7 +428,7 @@ NS_DEV EList32 chain_error_list_v2(const Tabs &T, const Tabs &TG, const ChainTab
         l_new += ins ? step : error == NS_DEL ? -step : 0;
         const bool coll = ins && last_ins_pos == pos && s.n > 0;                                   // dict key collision
         s.n -= coll ? 1u : 0u; s.shift -= coll ? (int32_t)s.last_ins_len : 0;
-        ev_push32s(s, pos, error, step);
+        ev_push32s(s, trk, pos, error, step);
         last_ins_pos = ins ? pos : last_ins_pos;
         pos += ins ? 0 : step;
         const bool over = !ins && pos >= middle_ref;
@@ -429,6 +441,7 @@ NS_DEV EList32 chain_error_list_v2(const Tabs &T, const Tabs &TG, const ChainTab
         else last_ins_pos = -1;
         ++it;
     }
+    ev_track_close(s, trk);
     return EList32{l_new, middle_ref};
 }
 
@@ -444,6 +457,7 @@ NS_DEV EList32 chain_unaligned_error_list_v2(const Tabs &T, const ChainTab &c, i
     uint32_t it = 0;
     u32x4 w_next = ns_draw(key, ST_UEVENT, seg, attempt, 0, 0);
     const uint64_t mw0 = T.q(c.mix_w)[0], mw1 = T.q(c.mix_w)[1], mw2 = T.q(c.mix_w)[2];
+    EvTrack trk = ev_track_open(s);
     while (pos < middle_ref) {
         const u32x4 w = w_next;
         ++it;
@@ -463,13 +477,14 @@ NS_DEV EList32 chain_unaligned_error_list_v2(const Tabs &T, const ChainTab &c, i
         const int32_t lb = is_del ? L - (step - 1) : L;
         const bool vb = L > 0 && lb > 0;
         const bool vc = is_mis && L > 0 && step - 1 > L;
-        if (va) ev_push32s(s, pos, type, la);
-        if (vb) ev_push32s(s, pos + 1, NS_INS, lb);
-        if (vc) ev_push32s(s, pos + 1, NS_MIS, step - 1 - L);
+        if (va) ev_push32s(s, trk, pos, type, la);
+        if (vb) ev_push32s(s, trk, pos + 1, NS_INS, lb);
+        if (vc) ev_push32s(s, trk, pos + 1, NS_MIS, step - 1 - L);
         pos += is_ins ? 0 : step;
         const bool over = pos > middle_ref;                                                          // S:1826-1828
         l_new += over ? pos - middle_ref : 0; middle_ref = over ? pos : middle_ref;
     }
+    ev_track_close(s, trk);
     return EList32{l_new, middle_ref};
 }
 #endif

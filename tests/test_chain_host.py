@@ -151,22 +151,46 @@ def test_every_formulation_of_the_iteration_gives_the_same_events(host, small_mo
             host.chost_free(pk)
 
 
-def test_event_capacity_overflow_and_range_flags(host, small_model):
+def test_event_capacity_overflow_and_range_flags(host, small_model, tmp_path):
     """A sink that is too small: the chain keeps counting, flags the overflow and never writes behind the capacity (k_chain re-plans the
-    batch from the count); the same numbers as the oracle."""
+    batch from the count); a piece whose cumulative shift leaves the 18-bit field of the event record raises `range` (the batch then takes
+    the wide-event path) — the same numbers and flags as the oracle, in every formulation (the v2 lists track both flags arithmetically)."""
+    from nanosim_amd import synth
     t = small_model.to_c()
-    pk = host.chost_pack(C.byref(t), 0)
-    try:
-        for v in (VARIANT_LDS, VARIANT_UNALIGNED) + FORMULATIONS[0]:
-            for staged in (0, 1):
-                full = oracle_list(t, v in (VARIANT_UNALIGNED, 30, 31), 5000, 77, 5, 0, 0, 4096)
-                assert full["n_ev"] > 40
-                cap = 16
-                ev = _aligned(cap + 8)
-                ev["pos"] = 0xdeadbeef
-                out = [C.c_int32(), C.c_int32(), C.c_uint32(), C.c_int32(), C.c_int(), C.c_int()]
-                assert host.chost_error_list(pk, v, staged, 5000, 77, 5, 0, 0, ev.ctypes.data, cap, *[C.addressof(o) for o in out]) == 0
-                assert out[2].value == full["n_ev"] and out[4].value == 1 and (out[0].value, out[1].value) == (full["l_new"], full["middle_ref"])
-                assert ev[:cap].tobytes() == full["ev"][:cap].tobytes() and (ev["pos"][cap:] == 0xdeadbeef).all()
-    finally:
-        host.chost_free(pk)
+    for layout, variants in ((0, (VARIANT_LDS, VARIANT_UNALIGNED) + FORMULATIONS[0]), (3, (32, 31, 30))):
+        pk = host.chost_pack(C.byref(t), layout)
+        try:
+            for v in variants:
+                for staged in (0, 1):
+                    full = oracle_list(t, v in (VARIANT_UNALIGNED, 30, 31), 5000, 77, 5, 0, 0, 4096)
+                    assert full["n_ev"] > 40
+                    cap = 16
+                    ev = _aligned(cap + 8)
+                    ev["pos"] = 0xdeadbeef
+                    out = [C.c_int32(), C.c_int32(), C.c_uint32(), C.c_int32(), C.c_int(), C.c_int()]
+                    assert host.chost_error_list(pk, v, staged, 5000, 77, 5, 0, 0, ev.ctypes.data, cap, *[C.addressof(o) for o in out]) == 0
+                    assert out[2].value == full["n_ev"] and out[4].value == 1 and (out[0].value, out[1].value) == (full["l_new"], full["middle_ref"])
+                    assert ev[:cap].tobytes() == full["ev"][:cap].tobytes() and (ev["pos"][cap:] == 0xdeadbeef).all()
+        finally:
+            host.chost_free(pk)
+    # insertion-heavy tables: the shift of a long piece runs out of the field
+    spec = synth.SynthModelSpec(n_train=3000, seed=8, mis=(3.0, 0.0, 0.3, 0.5), ins=(12.0, 0.9, 0.12, 0.5), dele=(1.5, 0.95, 0.15, 0.5),
+                                mm_means=(3.0,) * 8, mm_zero=(0.0,) + (0.2,) * 7, fm_mean=3.0)
+    prefix = str(tmp_path / "ins" / "training")
+    synth.write_model(prefix, spec, write_pkl=False)
+    mdl = M.load_model(prefix)
+    t2 = mdl.to_c()
+    cap = 4 * 150000
+    seen = 0
+    for layout, variants in ((0, (VARIANT_LDS, VARIANT_UNALIGNED, 11)), (3, (32, 31))):
+        pk = host.chost_pack(C.byref(t2), layout)
+        try:
+            for v in variants:
+                m_ref = 400000 if v in (VARIANT_UNALIGNED, 30, 31) else 800000          # (shift per base: 0.45 unaligned, 0.18 aligned)
+                o = oracle_list(t2, v in (VARIANT_UNALIGNED, 30, 31), m_ref, 9, 1, 0, 0, cap)
+                h = host_list(host, pk, v, m_ref, 9, 1, 0, 0, cap, staged=1)
+                same(h, o, ("range", v))
+                seen += int(bool(o["range"]))
+        finally:
+            host.chost_free(pk)
+    assert seen == 5                                       # every case does leave the field (else the flag was never exercised)
