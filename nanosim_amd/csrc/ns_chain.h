@@ -764,7 +764,7 @@ __device__ inline EList32 coop_error_list(const Tabs &T, const ChainTab &c, int3
             for (int st = 0; st < 7; ++st) eb |= (uint32_t)trans_pick_u(trans + 3 * st, wi.x) << (2 * st);
             S.err_tab[lane] = eb;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) S.step_tab[lane][t] = (uint16_t)run_length_t(T, c, t, wi.y, wi.z);
+            for (int t = 0; t < 3; ++t) S.step_tab[lane][t] = (uint16_t)run_length_t<NS_MIX_REC>(T, c, t, wi.y, wi.z);
             for (uint32_t b = 0; b < c.mm_nbins; ++b) {
                 const uint32_t o = seg_off[b];
                 S.match_tab[lane][b] = (uint16_t)ecdf_lookup_g(T.d(c.mm_hi) + o, T.d(c.mm_vhi) + o, seg_off[b + 1] - o,
