@@ -34,6 +34,7 @@ uint32_t chost_lds_words(const void *p) { return static_cast<const ChainHost *>(
 //            (v & 8: run-length records, needs a blob of layout 1 or 3)
 //        30: chain_unaligned_error_list<true> (run-length records: layout 1 or 3)
 //        31: chain_unaligned_error_list_v2, 32: chain_error_list_v2 (layout 3)
+//        33: chain_error_list<false, 8> — what k_chain<false, .> runs under NS_CHAIN_VAR & (8 | 32): fp64 tables, run-length records
 // T and TG: the LDS image is the first n_words_lds words of the blob — handing the chain a COPY of just those words as T checks that it
 // never reads a table of the LDS part behind them.
 // staged != 0: events go through the four-slot staging column (EvSink32::stg) as in k_chain<LDS> for single-piece reads; cap must then be
@@ -63,6 +64,7 @@ int chost_error_list(const void *p, int variant, int staged, int32_t m_ref, uint
     case 23: e = chain_error_list<true, 13>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
     case 24: e = chain_error_list<true, 14>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
     case 25: e = chain_error_list<true, 15>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
+    case 33: e = chain_error_list<false, 8>(TG, TG, h->ct, m_ref, key, seg, attempt, s); break;
     case 30: e = chain_unaligned_error_list<true>(T, h->ct, m_ref, key, seg, attempt, s); break;
     case 31: e = chain_unaligned_error_list_v2(T, h->ct, m_ref, key, seg, attempt, s); break;
     case 32: e = chain_error_list_v2(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
