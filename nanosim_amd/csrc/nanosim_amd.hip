@@ -31,6 +31,7 @@
 #include "ns_ir.h"
 #include "ns_io.h"
 #include "ns_pack.h"
+#include "ns_errlog.h"
 #include "ns_cs_hist.h"
 
 // Reads per workgroup of the wave-per-read kernels.  One: read lengths vary by an order of magnitude inside a batch, and a wavefront
@@ -1534,6 +1535,31 @@ __global__ void __launch_bounds__(64) k_errlog(GenArgs A) {
                 w[len] = '\t';
                 w2[len] = '\n';
             };
+#ifdef NS_ERRLOG_V3         // (round 4: prepared and held against the oracle on the CPU, not yet timed — ns_errlog.h)
+            if (staged && nl >= 8u) {
+                uint8_t *q = buf + (incl - row);
+                if (active) errlog_tail_v3(q + nl, e, p.n_ev - 1 - k, pc, A.ref, key, a);
+                wave_sync();                                            // the last store of a row may run into the next row's name
+                if (active) {
+                    for (uint32_t i = 0; i + 8 <= nl; i += 8) { uint64_t v; __builtin_memcpy(&v, name_lds + i, 8); __builtin_memcpy(q + i, &v, 8); }
+                    if (nl & 7u) { uint64_t v; __builtin_memcpy(&v, name_lds + nl - 8, 8); __builtin_memcpy(q + nl - 8, &v, 8); }
+                }
+                wave_sync();
+                uint8_t *const dst0 = A.errlog + base;
+                const uint32_t mis = (uint32_t)(uintptr_t)dst0 & 15u;
+                uint8_t *const dstA = dst0 - mis;
+                for (uint32_t c = lane; 16u * c < mis + total; c += 64) {
+                    const int32_t lo = (int32_t)(16u * c) - (int32_t)mis;
+                    uint64_t v0, v1;
+                    __builtin_memcpy(&v0, buf + lo, 8); __builtin_memcpy(&v1, buf + lo + 8, 8);
+                    const uint32_t s0 = lo < 0 ? (uint32_t)(-lo) : 0u;
+                    const uint32_t e0 = min(16u, mis + total - 16u * c);
+                    if (s0 == 0 && e0 == 16u) { struct __attribute__((packed)) V { uint64_t a, b; } v{v0, v1}; __builtin_memcpy(dstA + 16u * c, &v, 16); }
+                    else { shift_down_bytes(v0, v1, s0); store16(dstA + 16u * c + s0, e0 - s0, v0, v1); }
+                }
+                wave_sync();
+            } else
+#endif
             if (staged) {
                 if (active) {
                     uint8_t *q = buf + (incl - row);

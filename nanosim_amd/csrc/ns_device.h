@@ -287,12 +287,12 @@ __device__ inline bool extract_pos_meta(const DevRef &ref, const uint32_t *__res
 }
 
 // ---- letters ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint8_t bases_atcg(uint32_t j) { return (uint8_t)(0x47435441u >> (8 * j)); }   // BASES, S:49
-__device__ __forceinline__ int base_rank(uint32_t c) { return c == 'A' ? 0 : c == 'T' ? 1 : c == 'C' ? 2 : c == 'G' ? 3 : -1; }
-__device__ __forceinline__ bool is_acgt(uint32_t c) { return ((1u << ((c - 65u) & 31u)) & 0x00080045u) != 0 && (c - 65u) < 26u; }
+NS_DEV uint8_t bases_atcg(uint32_t j) { return (uint8_t)(0x47435441u >> (8 * j)); }   // BASES, S:49
+NS_DEV int base_rank(uint32_t c) { return c == 'A' ? 0 : c == 'T' ? 1 : c == 'C' ? 2 : c == 'G' ? 3 : -1; }
+NS_DEV bool is_acgt(uint32_t c) { return ((1u << ((c - 65u) & 31u)) & 0x00080045u) != 0 && (c - 65u) < 26u; }
 
 // case_convert (S:743-755): members in the reference's list order, packed little-endian; count in the top byte index
-__device__ __forceinline__ uint32_t iupac_members(uint32_t c, uint32_t &n) {
+NS_DEV uint32_t iupac_members(uint32_t c, uint32_t &n) {
     switch (c) {
         case 'Y': n = 2; return 'C' | 'T' << 8;
         case 'R': n = 2; return 'A' | 'G' << 8;
@@ -310,7 +310,7 @@ __device__ __forceinline__ uint32_t iupac_members(uint32_t c, uint32_t &n) {
 }
 // device form of the reference: upper-case ASCII; IUPAC ambiguity codes (and anything else, as N) carry bit 7
 // so that "needs case_convert's random choice" is one AND per 4 bases
-__device__ __forceinline__ uint8_t normalise_base(uint32_t c) {
+NS_DEV uint8_t normalise_base(uint32_t c) {
     c &= 0x7fu;
     if (c >= 'a' && c <= 'z') c -= 32;
     uint32_t n;
@@ -318,7 +318,7 @@ __device__ __forceinline__ uint8_t normalise_base(uint32_t c) {
     iupac_members(c, n);
     return (uint8_t)((n ? c : (uint32_t)'N') | 0x80u);
 }
-__device__ __forceinline__ uint8_t resolve_base(uint32_t c, const ns_key &key, uint32_t seg, uint32_t attempt, uint32_t x) {
+NS_DEV uint8_t resolve_base(uint32_t c, const ns_key &key, uint32_t seg, uint32_t attempt, uint32_t x) {
     if (!(c & 0x80u)) return (uint8_t)c;
     c &= 0x7fu;
     uint32_t n, mem = iupac_members(c, n);
@@ -331,18 +331,18 @@ __device__ __forceinline__ uint8_t resolve_base(uint32_t c, const ns_key &key, u
 //   word(j, 0) = Philox(ST_SUB, seg, attempt, idx = j>>2).w[j&3]           (letters 0..15)
 //   word(j, c) = Philox(ST_INS, seg, attempt, idx = j, sub = c>>2).w[c&3]  (letters 16c..16c+15, c >= 1)
 // insertion letter i = 2-bit field (i&15); substitution letter i = (i&15)-th base-3 digit of the word as a fraction.
-__device__ __forceinline__ uint32_t payload_word(const ns_key &key, uint32_t seg, uint32_t attempt, uint32_t j, uint32_t c) {
+NS_DEV uint32_t payload_word(const ns_key &key, uint32_t seg, uint32_t attempt, uint32_t j, uint32_t c) {
     if (c == 0) { u32x4 w = ns_draw(key, ST_SUB, seg, attempt, j >> 2, 0); return ns_word(w, j & 3); }
     u32x4 w = ns_draw(key, ST_INS, seg, attempt, j, c >> 2);
     return ns_word(w, c & 3);
 }
-__device__ __forceinline__ uint8_t mis_from_digit(uint32_t cur, uint32_t dg) {      // S:1968-1972
+NS_DEV uint8_t mis_from_digit(uint32_t cur, uint32_t dg) {      // S:1968-1972
     int rc = base_rank(cur);
     uint32_t rk = dg + ((int)dg >= rc ? 1u : 0u);
     if (rc < 0) rk = dg;
     return bases_atcg(rk);
 }
-__device__ __forceinline__ uint32_t next_digit3(uint32_t &frac) {
+NS_DEV uint32_t next_digit3(uint32_t &frac) {
     uint64_t p = (uint64_t)frac * 3u;
     frac = (uint32_t)p;
     return (uint32_t)(p >> 32);
@@ -387,11 +387,11 @@ __device__ __forceinline__ uint8_t qual_at(const DevModel &m, int cls, const ns_
 
 // (32-bit values — positions, run lengths, lengths — take the 32-bit forms: a division of a 64-bit value by ten is a multi-instruction
 // sequence on this target, and k_errlen / k_errlog / the names format millions of numbers per batch)
-__device__ __forceinline__ uint32_t dec_digits(uint32_t v) {
+NS_DEV uint32_t dec_digits(uint32_t v) {
     return v < 10u ? 1u : v < 100u ? 2u : v < 1000u ? 3u : v < 10000u ? 4u : v < 100000u ? 5u : v < 1000000u ? 6u : v < 10000000u ? 7u :
            v < 100000000u ? 8u : v < 1000000000u ? 9u : 10u;
 }
-__device__ __forceinline__ uint8_t *put_dec(uint8_t *p, uint32_t v) {
+NS_DEV uint8_t *put_dec(uint8_t *p, uint32_t v) {
     const uint32_t n = dec_digits(v);
     for (uint32_t i = 0; i < n; ++i) { const uint32_t q = v / 10u; p[n - 1 - i] = (uint8_t)('0' + (v - 10u * q)); v = q; }
     return p + n;

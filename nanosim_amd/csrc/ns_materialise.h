@@ -268,7 +268,7 @@ __device__ __forceinline__ void cursor_seek(Cursor &c, const PieceCtx &pc, uint3
     c.j = lo;
     cursor_load(c, pc);
 }
-__device__ __forceinline__ uint8_t ref_base_at(const DevRef &ref, const PieceCtx &pc, uint32_t x) {
+NS_DEV uint8_t ref_base_at(const DevRef &ref, const PieceCtx &pc, uint32_t x) {
     uint64_t g = pc.pos + x;
     if (g >= pc.chrom_len) g -= pc.chrom_len;               // circular wrap (S:1757-1760)
     return ref.bases[pc.chrom_base + g];
@@ -291,7 +291,7 @@ __device__ __forceinline__ uint8_t piece_byte(const DevRef &ref, const PieceCtx 
     uint32_t x = c.cur_rp + (d - c.cur_pl);
     return resolve_base(ref_base_at(ref, pc, x), key, pc.sid, attempt, x);           // case_convert, S:743-755
 }
-__device__ __forceinline__ PieceCtx load_piece(const ns_event *events, const DevRef &ref, const ns_piece &p, uint32_t pi) {
+NS_DEV PieceCtx load_piece(const ns_event *events, const DevRef &ref, const ns_piece &p, uint32_t pi) {
     PieceCtx pc;
     pc.ev = events + p.ev_off; pc.wd = nullptr; pc.n_ev = p.n_ev; pc.out_len = p.out_len; pc.ref_len = p.ref_len;
     pc.chrom_base = ref.chrom_off[p.chrom];

@@ -7,12 +7,14 @@
 #   var1  one ev_push32 site            var2  run_length_w            var4  column looked up before the event store
 #   var8  run-length record in LDS instead of three kernel-argument loads per event (blob layout 1)
 #   v2    chain_error_list_v2: one-word ECDF segments, column word, reads issued round by round in one basic block (blob layout 3)
+#   errlog3  k_errlog with the packed row writer (ns_errlog.h: errlog_tail_v3; tests/test_errlog_host.py); all = v2 + errlog3
 #   v2m5  v2 compiled for five wavefronts per SIMD (96 VGPRs, 20 bytes of spills outside the loop): the bench model's LDS image is 24.1 KB
 #         in layout 3 (29.1 KB in layout 0), + 8 KB of event staging = five workgroups of 256 threads per CU instead of four
 cd "$(dirname "$0")/../.."
 if [ "$1" = build ]; then
   exec scripts/ab_build.sh base:"" var1:"-DNS_CHAIN_VAR=1" var2:"-DNS_CHAIN_VAR=2" var4:"-DNS_CHAIN_VAR=4" var8:"-DNS_CHAIN_VAR=8" var9:"-DNS_CHAIN_VAR=9" \
-       var11:"-DNS_CHAIN_VAR=11" v2:"-DNS_CHAIN_VAR=40" v2m5:"-DNS_CHAIN_VAR=40 -DNS_CHAIN_MINW=5"
+       var11:"-DNS_CHAIN_VAR=11" v2:"-DNS_CHAIN_VAR=40" v2m5:"-DNS_CHAIN_VAR=40 -DNS_CHAIN_MINW=5" \
+       errlog3:"-DNS_ERRLOG_V3" all:"-DNS_CHAIN_VAR=40 -DNS_ERRLOG_V3"
 fi
 O=gpurun_out/r05a; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -21,4 +23,8 @@ for f in nanosim_amd/_variants/*.so; do
   echo "== $name parity"; ( NANOSIM_AMD_LIB=$PWD/$f timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3 ) | tee $O/parity_$name.log
 done
 scripts/ab_run.sh 2>&1 | tee $O/ab_chain.log
+for name in base errlog3 all; do            # the error profile switched on: what k_errlog costs (bench.py's errlog_on object)
+  echo -n "$name errlog_on "; NANOSIM_AMD_LIB=$PWD/nanosim_amd/_variants/$name.so timeout 300 python bench.py --no-cpu-baseline --no-e2e --no-configs2 2>/dev/null | tail -1 | \
+    python -c "import json,sys; d=json.loads(sys.stdin.read()); e=d['errlog_on']; print(round(e['value']/1e6,1), 'M reads/s', e['ms_per_step'], 'ms/step, k_errlog', e['k_errlog_ms'], 'ms')"
+done 2>&1 | tee $O/ab_errlog.log
 ( timeout 300 python -m pytest tests/test_gpu_zz_characterize.py -m gpu -q 2>&1 | tail -5 ) | tee $O/pytest_characterize.log
