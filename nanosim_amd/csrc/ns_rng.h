@@ -56,14 +56,21 @@ NS_HD uint32_t ns_clz32(uint32_t x) {
 }
 
 // Philox4x32-10 (Salmon, Moraes, Dror, Shaw 2011)
+// -DNS_PHILOX_BITOP3 (prepared in round 4, not timed): the two three-way XORs of a round as ONE v_bitop3_b32 each (gfx950; truth table
+// 0x96) — the compiler emits two v_xor_b32 for a ^ b ^ c: 20 of the ~62 vector instructions of an evaluation
+#if defined(NS_PHILOX_BITOP3) && defined(__HIP_DEVICE_COMPILE__)
+#define NS_XOR3(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96)
+#else
+#define NS_XOR3(a, b, c) ((a) ^ (b) ^ (c))
+#endif
 NS_HD u32x4 philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n0 = NS_XOR3((uint32_t)(p1 >> 32), c1, k0);
         uint32_t n1 = (uint32_t)p1;
-        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n2 = NS_XOR3((uint32_t)(p0 >> 32), c3, k1);
         uint32_t n3 = (uint32_t)p0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
