@@ -64,6 +64,12 @@ NS_HD uint32_t ns_clz32(uint32_t x) {
 #define NS_XOR3(a, b, c) ((a) ^ (b) ^ (c))
 #endif
 NS_HD u32x4 philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+#if defined(NS_PHILOX_REKEY) && defined(__HIP_DEVICE_COMPILE__)
+    // the seed is wave-uniform: its ten round keys are loop-invariant, the compiler hoists all twenty words out of the kernels' loops and
+    // then spills some to VGPR lanes (v_readlane + hazard s_nop at every use).  The empty asm makes the key opaque per evaluation: the round
+    // keys are twenty s_add_i32 next to the vector work instead of twenty live SGPRs (prepared in round 4, not timed)
+    asm volatile("" : "+s"(k0), "+s"(k1));
+#endif
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
