@@ -528,7 +528,9 @@ def extra_legs(w, a, n, n_al, n_un, steps):
     out["serial"] = {"value": n * steps / dt, "unit": "reads/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
                      "aligned_device_ms": float(np.mean([st[0].ms_total for st in infos])),
                      "unaligned_device_ms": float(np.mean([st[1].ms_total for st in infos])) if n_un else None,
-                     "note": "one engine context, aligned then unaligned worker call (CLI: NS_SERIAL=1)"}
+                     "aligned_kernel_ms": {nm: float(np.mean([st[0].ms_kernel[k] for st in infos])) for k, nm in enumerate(w.engine.KERNEL_NAMES)},
+                     "unaligned_kernel_ms": {nm: float(np.mean([st[1].ms_kernel[k] for st in infos])) for k, nm in enumerate(w.engine.KERNEL_NAMES)} if n_un else None,
+                     "note": "one engine context, aligned then unaligned worker call (CLI: NS_SERIAL=1): each call's kernels run ALONE here"}
     infos, dt, _ = timed_steps(w, a, n, n_al, n_un, steps, 2, None, True, first_step=3000)    # (two warm-ups: both error-profile slots sized)
     al = [st[0] for st in infos]
     k_err = w.engine.KERNEL_NAMES.index("k_errlog")

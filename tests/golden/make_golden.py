@@ -870,12 +870,17 @@ def _trx_worker(args):
     return out
 
 
-def fixture_transcriptome_runs(prefix, workdir, n_reads=16000):
+def fixture_transcriptome_runs(prefix, workdir, n_reads=16000, per_worker=None, which=("aligned", "perfect"), seed_base=0):
+    """per_worker: reads per reference worker (= num_simulate of S:1080: the size of the worker's 2-D KDE sample); default n_reads / 8"""
     out = {}
     n_proc = min(8, os.cpu_count() or 1)
+    per_worker = per_worker or n_reads // n_proc
+    n_workers = max(1, n_reads // per_worker)
     for name, perfect, uracil in (("aligned", False, False), ("perfect", True, True)):
+        if name not in which:
+            continue
         with mp.get_context("fork").Pool(n_proc) as pool:
-            res = pool.map(_trx_worker, [(i, n_reads // n_proc, prefix, workdir, perfect, uracil) for i in range(n_proc)])
+            res = pool.map(_trx_worker, [(seed_base + i, per_worker, prefix, workdir, perfect, uracil) for i in range(n_workers)])
         lens = res[0]["seq_lens_of"]
         listed = set(res[0]["polya_listed"])
         trx = [t for r in res for t in r["trx"]]
@@ -1048,6 +1053,7 @@ def main():
     ap.add_argument("--skip-dist", action="store_true")
     ap.add_argument("--only-meta-perfect", action="store_true", help="add runs.perfect to reference_metagenome.json, keep the rest")
     ap.add_argument("--only-trx", action="store_true", help="write reference_transcriptome.json only")
+    ap.add_argument("--only-trx-sizes", action="store_true", help="write reference_transcriptome_sizes.json only: the transcriptome worker at 125, 1 000 and 50 000 reads per worker")
     ap.add_argument("--only-ir", action="store_true", help="write the intron-retention inputs and reference_ir.json only")
     ap.add_argument("--only-ir-splice", action="store_true", help="write reference_ir_splice.json only (the intron splice of the transcriptome worker)")
     ap.add_argument("--only-trx-walk", action="store_true", help="write reference_trx_walk.json only (the pick walk of the transcriptome worker as a tape)")
@@ -1088,6 +1094,23 @@ def main():
             with open(os.path.join(HERE, "reference_chimeric_dense.json"), "w") as f:
                 json.dump(fx, f)
             print("reference_chimeric_dense.json written:", fx["n_aligned"], "aligned reads,", sum(fx["nseg_hist"][2:]), "chimeric")
+            return
+        if a.only_trx_sizes:
+            # the sample-until-repeat rule of S:1080-1104 at worker sizes well away from the 12 000 of reference_transcriptome.json: the
+            # reference's worker keeps a sample of num_simulate = (reads of the worker) points, the restatement one of unbounded size per
+            # block of 1 024 read indices.  Same committed inputs; 64 workers x 125 reads, 8 x 1 000 (aligned and --perfect) and 8 x 50 000.
+            build_trx_inputs()
+            fx = {}
+            for tag, n, per, which, sb in (("w125", 8000, 125, ("aligned",), 100), ("w1000", 8000, 1000, ("aligned", "perfect"), 200),
+                                           ("w50000", 400000, 50000, ("aligned",), 300)):
+                runs = fixture_transcriptome_runs(prefix, workdir, n_reads=n, per_worker=per, which=which, seed_base=sb)
+                for name, r in runs.items():
+                    r["per_worker"] = per
+                    fx["%s_%s" % (tag, name)] = r
+                print(tag, "done", flush=True)
+            with open(os.path.join(HERE, "reference_transcriptome_sizes.json"), "w") as f:
+                json.dump(fx, f)
+            print("reference_transcriptome_sizes.json written")
             return
         if a.only_trx:
             build_trx_inputs()
