@@ -575,6 +575,7 @@ def main():
     ap.add_argument("--no-configs2", action="store_true", help="skip the configs[2] object (chr1-size reference, FASTQ, -hp -k 5)")
     ap.add_argument("--configs2-steps", type=int, default=3)
     ap.add_argument("--no-extras", action="store_true", help="skip the `serial` and `errlog_on` objects")
+    ap.add_argument("--no-solo-reference", action="store_true", help="N > 1: skip rank 0's single-rank repeat of the timed steps (multi_gpu.single_rank_reference)")
     ap.add_argument("--extras-steps", type=int, default=3)
     a = ap.parse_args()
     a.aligned_only = a.aligned_only or a.no_genome_run
@@ -634,13 +635,25 @@ def main():
         dist.all_gather(allr, mine)
         per_rank = [{"rank": r, "ms_per_step": float(x[0].item()), "aligned_device_ms": float(x[1].item())} for r, x in enumerate(allr)]
 
+    solo = None
+    if dist is not None and not a.no_solo_reference:
+        # the same binary, the same workload, ONE rank busy: rank 0 repeats the timed steps while the others wait at the barrier — what the
+        # N-rank value is an efficiency of (weak scaling: value / (N x this))
+        if rank == 0:
+            _, dt1, _ = timed_steps(w, a, n, n_al, n_un, a.steps, 1, None, a.errlog, first_step=5000)
+            solo = {"value": n * a.steps / dt1, "unit": "reads/s", "ms_per_step": dt1 / a.steps * 1e3, "steps": a.steps,
+                    "note": "rank 0 alone on its GPU, the other ranks idle at a barrier: same process, same engines, same reference copy"}
+        dist.barrier()
     if rank == 0:
         out = summarise(w, a, infos, dt, n, n_al, n_un, a.steps, a.warmup, world, tot_bases, a.errlog)
         if world > 1:
             out["multi_gpu"] = {"world_size": dist.get_world_size(), "backend": "RCCL (torch.distributed nccl)" if a.dist_backend == "nccl" else a.dist_backend,
+                                "backend_reported": dist.get_backend(),
                                 "reference_broadcast_ms": w.broadcast_ms, "reference_bytes": w.glen,
                                 "reference_broadcast_gb_per_s": w.glen / (w.broadcast_ms * 1e-3) / 1e9 if w.broadcast_ms else None,
                                 "per_rank": per_rank, "collectives_in_timed_region": 0,
+                                "single_rank_reference": solo,
+                                "scaling_efficiency": out["value"] / (world * solo["value"]) if solo else None,
                                 "ranks_on_one_gpu": os.environ.get("NS_BENCH_DEVICE") is not None}
         if world == 1 and not a.no_extras and w.eng_un is not None and n_un:
             try:

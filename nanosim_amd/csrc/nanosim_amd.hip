@@ -31,7 +31,6 @@
 #include "ns_ir.h"
 #include "ns_io.h"
 #include "ns_pack.h"
-#include "ns_errlog.h"
 #include "ns_cs_hist.h"
 
 // Reads per workgroup of the wave-per-read kernels.  One: read lengths vary by an order of magnitude inside a batch, and a wavefront
@@ -288,13 +287,11 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #ifndef NS_CHAIN_BLOCK
 #define NS_CHAIN_BLOCK 256     // threads per block of the thread-per-read chain (320 was measured slower: 4.56 vs 4.09 ms)
 #endif
+// Wavefronts per SIMD the thread-per-read chain is compiled for.  Five: 95 VGPRs without scratch, and the bench model's LDS image (24.1 KB)
+// + 8 KB of event staging fits five workgroups per CU (round 5, same box: aligned chain alone 2.94 -> 2.76 ms; four until round 4, when
+// the lists needed 104 VGPRs and the image 30 KB)
 #ifndef NS_CHAIN_MINW
-#define NS_CHAIN_MINW 4
-#endif
-#if NS_CHAIN_VAR & 32
-#define NS_UNALIGNED_LIST chain_unaligned_error_list_v2
-#else
-#define NS_UNALIGNED_LIST chain_unaligned_error_list<NS_MIX_REC>
+#define NS_CHAIN_MINW 5
 #endif
 template <bool LDS_TABLES, bool COOP>
 __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK, COOP ? 4 : NS_CHAIN_MINW) k_chain(GenArgs A) {
@@ -353,15 +350,10 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK, COOP ? 4 : NS_CHAI
                 }
                 EList32 e;
                 if (kind == NS_KIND_PERFECT) { e.l_new = e.middle_ref = m32; }
-                else if (p.kind) e = COOP ? coop_unaligned_error_list(T, ct, m32, key, sid, a, sink, lane) : NS_UNALIGNED_LIST(T, ct, m32, key, sid, a, sink);
+                else if (p.kind) e = COOP ? coop_unaligned_error_list(T, ct, m32, key, sid, a, sink, lane) : chain_unaligned_error_list(T, ct, m32, key, sid, a, sink);
                 else if (COOP) e = coop_error_list(T, ct, m32, key, sid, a, sink, *coop, lane);
-#ifdef NS_CHAIN_MLP          // (round 4: measured SLOWER than the one-question-at-a-time chain, 3.76 against 3.28 ms — ns_chain.h)
-                else if constexpr (LDS_TABLES) e = chain_error_list_mlp(T, Tabs{A.m.chain_blob}, ct, m32, key, sid, a, sink);
-#endif
-#if NS_CHAIN_VAR & 32       // (round 4: prepared and checked against the oracle on the CPU, not yet timed — ns_chain.h)
-                else if constexpr (LDS_TABLES) e = chain_error_list_v2(T, Tabs{A.m.chain_blob}, ct, m32, key, sid, a, sink);
-#endif
-                else e = chain_error_list<LDS_TABLES, (NS_CHAIN_VAR & 15)>(T, Tabs{A.m.chain_blob}, ct, m32, key, sid, a, sink);
+                else if constexpr (LDS_TABLES) e = chain_error_list(T, Tabs{A.m.chain_blob}, ct, m32, key, sid, a, sink);
+                else e = chain_error_list_g(T, ct, m32, key, sid, a, sink);
                 ev_flush_tail(sink);
                 p.ev_off = ev_off + evn;
                 p.ref_len = (uint32_t)(e.middle_ref < 0 ? 0 : e.middle_ref);
@@ -1535,31 +1527,6 @@ __global__ void __launch_bounds__(64) k_errlog(GenArgs A) {
                 w[len] = '\t';
                 w2[len] = '\n';
             };
-#ifdef NS_ERRLOG_V3         // (round 4: prepared and held against the oracle on the CPU, not yet timed — ns_errlog.h)
-            if (staged && nl >= 8u) {
-                uint8_t *q = buf + (incl - row);
-                if (active) errlog_tail_v3(q + nl, e, p.n_ev - 1 - k, pc, A.ref, key, a);
-                wave_sync();                                            // the last store of a row may run into the next row's name
-                if (active) {
-                    for (uint32_t i = 0; i + 8 <= nl; i += 8) { uint64_t v; __builtin_memcpy(&v, name_lds + i, 8); __builtin_memcpy(q + i, &v, 8); }
-                    if (nl & 7u) { uint64_t v; __builtin_memcpy(&v, name_lds + nl - 8, 8); __builtin_memcpy(q + nl - 8, &v, 8); }
-                }
-                wave_sync();
-                uint8_t *const dst0 = A.errlog + base;
-                const uint32_t mis = (uint32_t)(uintptr_t)dst0 & 15u;
-                uint8_t *const dstA = dst0 - mis;
-                for (uint32_t c = lane; 16u * c < mis + total; c += 64) {
-                    const int32_t lo = (int32_t)(16u * c) - (int32_t)mis;
-                    uint64_t v0, v1;
-                    __builtin_memcpy(&v0, buf + lo, 8); __builtin_memcpy(&v1, buf + lo + 8, 8);
-                    const uint32_t s0 = lo < 0 ? (uint32_t)(-lo) : 0u;
-                    const uint32_t e0 = min(16u, mis + total - 16u * c);
-                    if (s0 == 0 && e0 == 16u) { struct __attribute__((packed)) V { uint64_t a, b; } v{v0, v1}; __builtin_memcpy(dstA + 16u * c, &v, 16); }
-                    else { shift_down_bytes(v0, v1, s0); store16(dstA + 16u * c + s0, e0 - s0, v0, v1); }
-                }
-                wave_sync();
-            } else
-#endif
             if (staged) {
                 if (active) {
                     uint8_t *q = buf + (incl - row);
@@ -2016,7 +1983,7 @@ int ns_load_model(ns_ctx *ctx, const ns_model_tables *t) {
         std::vector<uint64_t> blob;
         ChainTab &ct = m.ct;
         bool whole = true;
-        ns_pack_chain_tables(t, nseg, ct, blob, whole, NS_CHAIN_LAYOUT);
+        ns_pack_chain_tables(t, nseg, ct, blob, whole);
         if ((rc = upload(ctx, pool, blob.data(), blob.size(), &m.chain_blob))) return rc;
         ctx->lds_bytes = (size_t)ct.n_words_lds * 8;
         ctx->lds_tables = whole && ctx->lds_bytes <= 40 * 1024;     // keep >= 4 workgroups of 256 threads per CU

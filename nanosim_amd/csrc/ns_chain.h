@@ -1,7 +1,13 @@
 // ns_chain.h — the error-event Markov chains of error_list (S:1833-1916) and unaligned_error_list
-// (S:1784-1830) on tables packed into ONE blob of 8-byte words that k_chain copies into LDS.
-// Same arithmetic as the generic functions of ns_device.h (fp64 compares + one fp64 interpolation),
-// but every search starts from a 256-entry guide index instead of a full binary search.
+// (S:1784-1830) on tables packed into ONE blob of 8-byte words (ns_pack.h) that k_chain copies into LDS.
+//   chain_error_list            thread per read on the LDS image: integer thresholds, one word per ECDF segment, the reads of an
+//                               iteration issued round by round in one basic block
+//   chain_error_list_g          thread per read on the fp64 tables in global memory (models whose value edges are not whole numbers or
+//                               whose image does not fit LDS): the reference's arithmetic as it is
+//   chain_unaligned_error_list  thread per read, unaligned reads and gaps
+//   coop_error_list, coop_unaligned_error_list   one read per wavefront (the longest reads of a batch; lane = loop iteration)
+// All produce the events of the oracle's error_list / unaligned_error_list bit for bit (tests/test_chain_host.py compiles this source
+// for the host; the -m gpu parity tests compare whole batches).
 #pragma once
 #include "ns_device.h"
 
@@ -36,100 +42,24 @@ NS_DEV int32_t ecdf_lookup_g(const double *__restrict__ hi, const V *__restrict_
     return (int32_t)floor((p - plo) / (hs - plo) * (vs - vlo) + vlo);
 }
 
-// The same look-up without floating point, for the LDS image (k_chain<LDS>).  The segment search compares the draw with integer
-// thresholds (bits 0..32 of G[s] = ns_thr_gt(hi[s]): p > hi[s] <=> u >= G[s], exactly).  Inside a segment (vlo, vhi] the interpolation
-// floor(frac * (vhi - vlo) + vlo) is a non-decreasing step function of the draw, and the host (ns_load_model) finds its steps with the
-// arithmetic of the fp64 formula:
-//   * bit 31 of the 32-bit value edge: the segment is one unit wide and every draw inside it gives vlo (the histograms read_analysis.py
-//     writes have bins one unit wide: all but the sparse tails and the first segment of a column, which S:216-221 stretches down);
-//   * else bits 36..39 of G[s]: w = vhi - vlo <= 15 and bits 40.. point at w thresholds t_1..t_w in `sub` (t_k: the smallest draw that
-//     gives vlo + k; 2^32: none): the result is vlo + #{k : u >= t_k};
-//   * else (wider segments: empty bins merged) the fp64 formula on the global tables.
-// A draw above the last edge is clamped to it (the reference would keep a stale value): frac = 1 exactly -> vhi.
-#define NS_G_THR(g) ((g) & 0x1ffffffffull)
-NS_DEV int32_t ecdf_lookup_u(const uint64_t *__restrict__ G, const uint32_t *__restrict__ vhi_u, uint32_t n,
-                                                 const uint16_t *__restrict__ guide, uint32_t u, const uint64_t *__restrict__ sub,
-                                                 const double *__restrict__ hi_g, const double *__restrict__ vhi_g, double vlo0) {
-    uint32_t s = guide[u >> 24];
-    const uint64_t uu = u;
-    if (s < n) {
-        const uint64_t g0 = G[s], g1 = G[min(s + 1, n - 1)];
-        if (uu >= NS_G_THR(g0)) {
-            ++s;
-            if (s < n && uu >= NS_G_THR(g1)) { ++s; while (s < n && uu >= NS_G_THR(G[s])) ++s; }
-        }
-    }
-    if (s >= n) return (int32_t)(vhi_u[n - 1] & 0x7fffffffu);
-    const uint32_t v = vhi_u[s];
-    if (v & 0x80000000u) return (int32_t)(v & 0x7fffffffu) - 1;
-    const uint64_t g = G[s];
-    const uint32_t nt = (uint32_t)(g >> 36) & 15u;
-    if (nt) {
-        const uint64_t *t = sub + (g >> 40);
-        int32_t r = (int32_t)v - (int32_t)nt;
-        for (uint32_t k = 0; k < nt; ++k) r += uu >= t[k] ? 1 : 0;
-        return r;
-    }
-    const double p = u32_to_p(u);
-    const uint32_t sm = s ? s - 1 : 0;
-    const double hs = hi_g[s], plo = s ? hi_g[sm] : 0.0, vs = vhi_g[s], vlo = s ? vhi_g[sm] : vlo0;
-    return (int32_t)floor((p - plo) / (hs - plo) * (vs - vlo) + vlo);
-}
-
 // mixture run length (mm:41-63) on integer thresholds: component by u_mix < T(weight), value = 1 + #{j : p > cdf[j]} by walking
-// G[j] = ns_thr_gt(cdf[j]) — no fp64 on the way
-// MR (NS_CHAIN_VAR & 8): offset, length and guide of the table come from the record 2 * type + component in the blob (one LDS read)
-// instead of ChainTab — indexed by a per-thread type, those are three vector loads from the kernel-argument segment per event
-#ifdef NS_CHAIN_TABS2
+// G[j] = ns_thr_gt(cdf[j]) — no fp64 on the way.  Offset, length and guide of the table of (type, component) come from its record in the
+// blob: ONE read (as fields of ChainTab indexed by a per-thread type they were three vector loads from the kernel-argument segment on
+// every event's critical path — found in the ISA of round 4).
 NS_DEV void mix_record(const Tabs &T, const ChainTab &c, uint32_t type, uint32_t comp, uint32_t &go, uint32_t &n, uint32_t &h) {
     const uint64_t *r = T.w + c.mix_rec + 2u * (2u * type + comp);
     const uint64_t r0 = r[0], r1 = r[1];
     go = (uint32_t)r0; n = (uint32_t)(r0 >> 32); h = (uint32_t)r1;
 }
-#endif
-constexpr bool NS_MIX_REC = (NS_CHAIN_VAR & (8 | 32)) != 0;
-template <bool MR = false>
 NS_DEV int32_t run_length_t(const Tabs &T, const ChainTab &c, int type, uint32_t u_mix, uint32_t u_len) {
     const int comp = ((uint64_t)u_mix < T.q(c.mix_w)[type]) ? 0 : 1;         // tmp_rand < weight, mm:44,54
-#ifdef NS_CHAIN_TABS2
-    if constexpr (MR) {
-        uint32_t go, n, h;
-        mix_record(T, c, (uint32_t)type, (uint32_t)comp, go, n, h);
-        const uint64_t u = u_len;
-        uint32_t v = reinterpret_cast<const uint8_t *>(T.w)[8u * h + ns_clz32(~u_len)];
-        while (v + 1 < n && u >= T.w[go + v]) ++v;
-        return (int32_t)v + 1;
-    }
-#endif
-    const uint64_t *G = T.q(c.mix_cdf[type][comp]);
-    const uint32_t n = c.mix_n[type][comp];
+    uint32_t go, n, h;
+    mix_record(T, c, (uint32_t)type, (uint32_t)comp, go, n, h);
     const uint64_t u = u_len;
     // == v = 0; while (v + 1 < n && p > cdf[v]) ++v — started at the guide's lower bound for draws with this many leading one bits
-    // (every threshold below it is <= the smallest such draw): zero to two steps instead of (run length - 1) dependent LDS reads
-    const uint8_t *g2 = reinterpret_cast<const uint8_t *>(T.w + c.mix_g2[type][comp]);
-    uint32_t v = g2[ns_clz32(~u_len)];                             // (__clz(0) == 32: the draw 0xffffffff)
-    while (v + 1 < n && u >= G[v]) ++v;
-    return (int32_t)v + 1;
-}
-
-// the same with the mixture weight handed in (the callers keep the three weights in registers) and the first TWO thresholds of the walk
-// fetched together: the walk starts at the guide's lower bound and almost always ends within two steps
-template <bool MR = false>
-NS_DEV int32_t run_length_w(const Tabs &T, const ChainTab &c, int type, uint64_t weight_thr, uint32_t u_mix, uint32_t u_len) {
-    const uint32_t comp = ((uint64_t)u_mix < weight_thr) ? 0u : 1u;                        // tmp_rand < weight, mm:44,54
-    uint32_t go, n, h;
-#ifdef NS_CHAIN_TABS2
-    if constexpr (MR) mix_record(T, c, (uint32_t)type, comp, go, n, h);
-    else
-#endif
-    {
-        go = comp ? c.mix_cdf[type][1] : c.mix_cdf[type][0]; n = comp ? c.mix_n[type][1] : c.mix_n[type][0];
-        h = comp ? c.mix_g2[type][1] : c.mix_g2[type][0];
-    }
-    const uint64_t u = u_len;
-    uint32_t v = reinterpret_cast<const uint8_t *>(T.w)[8u * h + ns_clz32(~u_len)];
-    const uint64_t a = T.w[go + v], b = T.w[go + min(v + 1u, n - 1u)];
-    if (v + 1u < n && u >= a) { ++v; if (v + 1u < n && u >= b) { ++v; while (v + 1u < n && u >= T.w[go + v]) ++v; } }
+    // (every threshold below it is <= the smallest such draw): zero to two steps instead of (run length - 1) dependent reads
+    uint32_t v = reinterpret_cast<const uint8_t *>(T.w)[8u * h + ns_clz32(~u_len)];        // (__clz(0) == 32: the draw 0xffffffff)
+    while (v + 1 < n && u >= T.w[go + v]) ++v;
     return (int32_t)v + 1;
 }
 
@@ -175,27 +105,13 @@ NS_DEV void ev_push32(EvSink32 &s, int32_t pos, uint32_t type, int32_t len) {
 
 struct EList32 { int32_t l_new, middle_ref; };
 
-// error_list, S:1833-1916
-// VU32: T is the LDS copy of the blob (integer thresholds, value edges as 32-bit integers); TG: the whole blob in global memory.
-// VAR (bit mask, -DNS_CHAIN_VAR=..., 0 in the product build): formulations of the same iteration that are measured against each other
-// on the GPU (scripts/ab_run.sh) and held against the oracle on the CPU (tests/test_chain_host.py) — same events, bit for bit:
-//   1  ONE ev_push32 site for both branches of S:1875-1882 (the insertion's dict-key collision and the position update become
-//      selects): half the exec-mask regions of the event store
-//   2  run length by run_length_w: the three mixture weights stay in registers, the first two thresholds of the walk are fetched together
-//   4  the bin of the previous match and its segment range are looked up BEFORE the event is pushed (they depend on the previous
-//      iteration only): the LDS round trips of S:1891-1893 run under the event store instead of behind it
-//   8  the run-length table of (type, component) by its record in LDS (mix_record; blob layout 1) — found in the ISA of round 4:
-//      c.mix_cdf[type][comp] with a per-thread type is THREE global loads from the kernel-argument segment on every event's critical path
-//  32  chain_error_list_v2 below (blob layout 3)
-template <bool VU32, int VAR = 0>
-NS_DEV EList32 chain_error_list(const Tabs &T, const Tabs &TG, const ChainTab &c, int32_t m_ref, const ns_key &key,
-                                                    uint32_t seg, uint32_t attempt, EvSink32 &s) {
+// error_list, S:1833-1916, on the fp64 tables (T = the whole blob in global memory): fp64 compares + the fp64 interpolation of the
+// reference, every search started from a 256-entry guide index instead of a full binary search
+NS_DEV EList32 chain_error_list_g(const Tabs &T, const ChainTab &c, int32_t m_ref, const ns_key &key, uint32_t seg, uint32_t attempt, EvSink32 &s) {
     int32_t l_new = m_ref, pos = 0, middle_ref = m_ref;
     int state = NS_ST_START;
     u32x4 w = ns_draw(key, ST_EVENT, seg, attempt, 0, 0);
-    int32_t prev_match;                                                                                           // S:1843-1850
-    if constexpr (VU32) prev_match = ecdf_lookup_u(T.q(c.fm_g), T.u(c.fm_vhi_u), c.fm_n, T.h(c.fm_guide), w.x, T.q(c.sub), TG.d(c.fm_hi), TG.d(c.fm_vhi), c.fm_vlo0);
-    else prev_match = ecdf_lookup_g(T.d(c.fm_hi), T.d(c.fm_vhi), c.fm_n, c.fm_vlo0, T.h(c.fm_guide), w.x);
+    int32_t prev_match = ecdf_lookup_g(T.d(c.fm_hi), T.d(c.fm_vhi), c.fm_n, c.fm_vlo0, T.h(c.fm_guide), w.x);          // S:1843-1850
     if (prev_match < 2) prev_match = 2;
     pos += prev_match;
     uint32_t it = 1;
@@ -204,38 +120,13 @@ NS_DEV EList32 chain_error_list(const Tabs &T, const Tabs &TG, const ChainTab &c
     const int32_t *bins = T.i(c.mm_bin);
     const uint32_t *seg_off = T.u(c.mm_seg_off);
     const uint8_t *bin_lut = reinterpret_cast<const uint8_t *>(T.w + c.mm_bin_lut);
-    uint64_t mw0 = 0, mw1 = 0, mw2 = 0;
-    if constexpr ((VAR & 2) != 0) { mw0 = T.q(c.mix_w)[0]; mw1 = T.q(c.mix_w)[1]; mw2 = T.q(c.mix_w)[2]; }
     u32x4 w_next = ns_draw(key, ST_EVENT, seg, attempt, 1, 0);
     while (pos < middle_ref) {                                                                     // S:1858
         w = w_next;
         w_next = ns_draw(key, ST_EVENT, seg, attempt, it + 1, 0);    // next iteration's draws do not depend on the chain state
         const int error = trans_pick_u(trans + 3 * state, w.x);                                   // S:1860-1864
-        uint32_t b = 0, o = 0, ncol = 0;
-        auto bin_of = [&]() {                                                                      // S:1891-1893
-            if ((uint32_t)prev_match < 256u) b = bin_lut[prev_match];
-            else {
-                for (b = 0; b < c.mm_nbins; ++b)
-                    if (bins[2 * b] <= prev_match && prev_match < bins[2 * b + 1]) break;
-                if (b >= c.mm_nbins) b = c.mm_nbins - 1;
-            }
-            o = seg_off[b]; ncol = seg_off[b + 1] - o;
-        };
-        if constexpr ((VAR & 4) != 0) bin_of();
-        int32_t step;                                                                              // S:1866-1873
-        if constexpr ((VAR & 2) != 0) step = run_length_w<(VAR & 8) != 0>(T, c, error, error == NS_MIS ? mw0 : error == NS_INS ? mw1 : mw2, w.y, w.z);
-        else step = run_length_t<(VAR & 8) != 0>(T, c, error, w.y, w.z);
+        int32_t step = run_length_t(T, c, error, w.y, w.z);                                        // S:1866-1873
         if (error == NS_INS) l_new += step; else if (error == NS_DEL) l_new -= step;
-        if constexpr ((VAR & 1) != 0) {
-            const bool ins = error == NS_INS;
-            const bool coll = ins && last_ins_pos == pos && s.n > 0;                               // dict key collision, S:1881-1882
-            s.n -= coll ? 1u : 0u; s.shift -= coll ? (int32_t)s.last_ins_len : 0;
-            ev_push32(s, pos, (uint32_t)error, step);
-            last_ins_pos = ins ? pos : last_ins_pos;
-            pos += ins ? 0 : step;                                                                 // S:1875-1880
-            const bool over = !ins && pos >= middle_ref;
-            l_new += over ? pos - middle_ref : 0; middle_ref = over ? pos : middle_ref;
-        } else
         if (error != NS_INS) {                                                                     // S:1875-1880
             ev_push32(s, pos, (uint32_t)error, step);
             pos += step;
@@ -246,11 +137,15 @@ NS_DEV EList32 chain_error_list(const Tabs &T, const Tabs &TG, const ChainTab &c
             last_ins_pos = pos;
         }
         state = NS_ST_MIS + error;                                                                 // S:1884
-        if constexpr ((VAR & 4) == 0) bin_of();
-        if constexpr (VU32) step = ecdf_lookup_u(T.q(c.mm_g) + o, T.u(c.mm_vhi_u) + o, ncol, T.h(c.mm_guide) + 256 * b, w.w, T.q(c.sub),
-                                                 TG.d(c.mm_hi) + o, TG.d(c.mm_vhi) + o, T.d(c.mm_vlo0)[b]);
-        else step = ecdf_lookup_g(T.d(c.mm_hi) + o, T.d(c.mm_vhi) + o, ncol, T.d(c.mm_vlo0)[b],
-                                  T.h(c.mm_guide) + 256 * b, w.w);
+        uint32_t b;                                                                                // S:1891-1893
+        if ((uint32_t)prev_match < 256u) b = bin_lut[prev_match];
+        else {
+            for (b = 0; b < c.mm_nbins; ++b)
+                if (bins[2 * b] <= prev_match && prev_match < bins[2 * b + 1]) break;
+            if (b >= c.mm_nbins) b = c.mm_nbins - 1;
+        }
+        const uint32_t o = seg_off[b], ncol = seg_off[b + 1] - o;
+        step = ecdf_lookup_g(T.d(c.mm_hi) + o, T.d(c.mm_vhi) + o, ncol, T.d(c.mm_vlo0)[b], T.h(c.mm_guide) + 256 * b, w.w);
         if (prev_match == 0 && step == 0) step = 1;                                                // S:1900-1901
         prev_match = step;
         if (pos + prev_match > middle_ref) { l_new += pos + prev_match - middle_ref; middle_ref = pos + prev_match; }
@@ -262,18 +157,19 @@ NS_DEV EList32 chain_error_list(const Tabs &T, const Tabs &TG, const ChainTab &c
     return EList32{l_new, middle_ref};
 }
 
-#ifdef NS_CHAIN_TABS2
-// ---- error_list on the one-word ECDF segments (NS_CHAIN_VAR & 32, blob layout 3; an experiment prepared in round 4, timed in round 5) ----
-// What the ISA and the counters of chain_error_list<true> show (profiles/r04): an event costs ~270 vector + ~180 scalar instructions and
+// ---- error_list on the LDS image ---------------------------------------------------------------------------------------------------
+// What the ISA and the counters of the round-3/4 chain showed (profiles/r04): an event cost ~270 vector + ~180 scalar instructions and
 // eleven DEPENDENT look-ups — transition row, three loads from the kernel-argument segment, guide byte, one or two thresholds; bin byte,
 // segment range, guide, one or two thresholds, value edge — with four wavefronts per SIMD to hide them.  Here
-//   * a segment is ONE word (threshold, class, value: ns_pack_layout2), so the look-up ends with the threshold it stops at;
+//   * a segment is ONE word (threshold, class, value: ns_pack.h), so the look-up ends with the threshold it stops at;
 //   * the column of the previous match comes from one word (pm_lut) instead of bin byte -> segment range;
 //   * the next match length depends on the previous match and the draw only: it is looked up FIRST, next to the run length, and both
 //     run ahead of the event store (whose LDS staging writes the compiler cannot move table reads across) — two chains of three reads
 //     side by side behind the transition row instead of eleven in a row;
-//   * one ev_push32 site (formulation 1) and the run-length record (formulation 8).
-// Same events as chain_error_list, bit for bit (tests/test_chain_host.py against the oracle).
+//   * one event-store site and the run-length record.
+// Round 5, same box (profiles/r05/ab_chain.log): aligned k_chain 3.28 -> 2.94 ms alone, the thread-per-read unaligned chain next to the
+// aligned call 8.8 -> 3.8 ms, whole step 11.3 -> 9.9 ms.
+//
 // ev_push32 with the bookkeeping behind the store as selects (no exec-mask regions for the type) and the two flags as ARITHMETIC: the
 // longest run and the extremes of the shift at store time are tracked (three vector instructions) and turned into `range` / `overflow`
 // once per piece (ev_track_close) — kept as booleans they are lane masks the compiler updates with three scalar instructions per flag
@@ -317,6 +213,7 @@ NS_DEV int32_t run_length_r(const Tabs &T, const ChainTab &c, uint32_t type, uin
     return (int32_t)rv + 1;
 }
 
+#define NS_G_THR(g) ((g) & 0x1ffffffffull)
 #define NS_GV_UNIT (1ull << 33)
 #define NS_GV_NARROW (1ull << 34)
 // the segment of draw u in a column of n one-word segments and the value it gives.  Straight-line for the common case — the guide's
@@ -348,7 +245,7 @@ NS_DEV int32_t ecdf_lookup_gv(const uint64_t *__restrict__ GV, uint32_t n, const
     return (int32_t)floor((p - plo) / (hs - plo) * (vs - vlo) + vlo);
 }
 
-// the generic look-up of the next match length (any previous match, any segment class): the fall-back of chain_error_list_v2's fast path
+// the generic look-up of the next match length (any previous match, any segment class): the fall-back of chain_error_list's fast path
 NS_DEV int32_t next_match_gv(const Tabs &T, const Tabs &TG, const ChainTab &c, int32_t prev_match, uint32_t u) {
     uint32_t b, o, ncol;
     if ((uint32_t)prev_match < 256u) {
@@ -365,8 +262,9 @@ NS_DEV int32_t next_match_gv(const Tabs &T, const Tabs &TG, const ChainTab &c, i
     return ecdf_lookup_gv(T.q(c.mm_gv) + o, ncol, T.h(c.mm_guide) + 256u * b, u, T.q(c.sub2), TG.d(c.mm_hi) + o, TG.d(c.mm_vhi) + o, T.d(c.mm_vlo0)[b]);
 }
 
-NS_DEV EList32 chain_error_list_v2(const Tabs &T, const Tabs &TG, const ChainTab &c, int32_t m_ref, const ns_key &key,
-                                   uint32_t seg, uint32_t attempt, EvSink32 &s) {
+// T: the LDS image (the first n_words_lds words of the blob); TG: the whole blob in global memory (fp64 tables of the wide segments)
+NS_DEV EList32 chain_error_list(const Tabs &T, const Tabs &TG, const ChainTab &c, int32_t m_ref, const ns_key &key,
+                                uint32_t seg, uint32_t attempt, EvSink32 &s) {
     int32_t l_new = m_ref, pos = 0, middle_ref = m_ref;
     uint32_t state = NS_ST_START;
     u32x4 w = ns_draw(key, ST_EVENT, seg, attempt, 0, 0);
@@ -445,12 +343,12 @@ NS_DEV EList32 chain_error_list_v2(const Tabs &T, const Tabs &TG, const ChainTab
     return EList32{l_new, middle_ref};
 }
 
-// unaligned_error_list (S:1784-1830, event rewrite of DESIGN.md section 5.3) in the same style (NS_CHAIN_VAR & 32): the seven event-store
-// sites of chain_unaligned_error_list — one per case of (type, pending insertion) — become THREE slots filled by selects: A the
+// unaligned_error_list (S:1784-1830, event rewrite of DESIGN.md section 5.3) in the same style: the seven event-store
+// sites a literal restatement has — one per case of (type, pending insertion) — are THREE slots filled by selects: A the
 // mismatch / deletion at pos, B the pending insertion behind it at pos + 1, C the rest of a mismatch run behind that insertion; an
 // insertion draws no event and does not advance (it waits in pend_ins), without leaving the iteration early.
-NS_DEV EList32 chain_unaligned_error_list_v2(const Tabs &T, const ChainTab &c, int32_t m_ref, const ns_key &key,
-                                             uint32_t seg, uint32_t attempt, EvSink32 &s) {
+NS_DEV EList32 chain_unaligned_error_list(const Tabs &T, const ChainTab &c, int32_t m_ref, const ns_key &key,
+                                          uint32_t seg, uint32_t attempt, EvSink32 &s) {
     int32_t l_new = m_ref, pos = 0, middle_ref = m_ref;
     int32_t pend_ins = 0;
     if (m_ref <= 0) return EList32{l_new, middle_ref};
@@ -487,154 +385,6 @@ NS_DEV EList32 chain_unaligned_error_list_v2(const Tabs &T, const ChainTab &c, i
     ev_track_close(s, trk);
     return EList32{l_new, middle_ref};
 }
-#endif
-
-// ---- error_list with its table look-ups side by side (round 4; -DNS_CHAIN_MLP: an experiment that did NOT pay) -------------------------
-// Measured on configs[1] (950 000 reads, same box): 3.76 ms against 3.28 ms for chain_error_list — the three-fold run-length look-ups and
-// the wider match look-up cost more LDS bandwidth and issue slots than the shorter dependency chain gives back; the chain is closer to
-// LDS- / issue-throughput bound than its serial shape suggests.  Kept as the documented negative result.
-// chain_error_list above asks the tables one question at a time: transition row -> run-length mixture -> guide -> threshold walk ->
-// event -> bin -> segment offsets -> guide -> thresholds -> value edge, each an LDS round trip the next one waits for — about fourteen per
-// event, ~3 000 dependent cycles, with four wavefronts per SIMD to hide them.  But an iteration's questions hardly depend on each other:
-//   * the next match length depends on the PREVIOUS match length (its bin) and on the draw, not on this iteration's error;
-//   * the run length depends on the error type only through which of three tables is asked — all three are asked;
-//   * a walk that starts at the guide's lower bound almost always ends within two steps — both thresholds are fetched at once.
-// So the look-ups are issued in three waves of independent LDS reads (straight-line code: the compiler batches them under one wait)
-// and the answers are selected afterwards; whatever does not fit the pattern (a walk of more than two steps, a draw beyond the last
-// edge, a segment that is not one unit wide, a previous match >= 256) falls back to the functions above.  Same events, bit for bit.
-struct RunPick { uint32_t v; bool more; uint32_t g_off, n; };
-__device__ __forceinline__ EList32 chain_error_list_mlp(const Tabs &T, const Tabs &TG, const ChainTab &c, int32_t m_ref, const ns_key &key,
-                                                        uint32_t seg, uint32_t attempt, EvSink32 &s) {
-    int32_t l_new = m_ref, pos = 0, middle_ref = m_ref;
-    int state = NS_ST_START;
-    u32x4 w = ns_draw(key, ST_EVENT, seg, attempt, 0, 0);
-    int32_t prev_match = ecdf_lookup_u(T.q(c.fm_g), T.u(c.fm_vhi_u), c.fm_n, T.h(c.fm_guide), w.x, T.q(c.sub), TG.d(c.fm_hi), TG.d(c.fm_vhi), c.fm_vlo0);   // S:1843-1850
-    if (prev_match < 2) prev_match = 2;
-    pos += prev_match;
-    uint32_t it = 1;
-    int32_t last_ins_pos = -1;
-    const uint64_t *trans = T.q(c.trans);
-    const int32_t *bins = T.i(c.mm_bin);
-    const uint32_t *seg_off = T.u(c.mm_seg_off);
-    const uint8_t *bin_lut = reinterpret_cast<const uint8_t *>(T.w + c.mm_bin_lut);
-    const uint64_t *mmG = T.q(c.mm_g);
-    const uint32_t *mmV = T.u(c.mm_vhi_u);
-    const uint16_t *mmGuide = T.h(c.mm_guide);
-    const uint8_t *wbytes = reinterpret_cast<const uint8_t *>(T.w);
-    // the three mixture weights are the same for every iteration: registers
-    const uint64_t mw0 = T.q(c.mix_w)[0], mw1 = T.q(c.mix_w)[1], mw2 = T.q(c.mix_w)[2];
-    u32x4 w_next = ns_draw(key, ST_EVENT, seg, attempt, 1, 0);
-    while (pos < middle_ref) {                                                                     // S:1858
-        w = w_next;
-        w_next = ns_draw(key, ST_EVENT, seg, attempt, it + 1, 0);    // next iteration's draws do not depend on the chain state
-        const uint64_t ux = w.x, uy = w.y, uz = w.z, uw = w.w;
-        // ---- wave 1: transition row, bin of the previous match, the walk's lower bound for each error type
-        const uint64_t t0 = trans[3 * state], t1 = trans[3 * state + 1];
-        const bool small = (uint32_t)prev_match < 256u;
-        const uint32_t b_l = bin_lut[small ? prev_match : 0];
-        const uint32_t lz = (uint32_t)__clz((int)~w.z);
-        const uint32_t c0 = uy < mw0 ? 0u : 1u, c1 = uy < mw1 ? 0u : 1u, c2 = uy < mw2 ? 0u : 1u;
-        const uint32_t go0 = c0 ? c.mix_cdf[0][1] : c.mix_cdf[0][0], go1 = c1 ? c.mix_cdf[1][1] : c.mix_cdf[1][0], go2 = c2 ? c.mix_cdf[2][1] : c.mix_cdf[2][0];
-        const uint32_t n0 = c0 ? c.mix_n[0][1] : c.mix_n[0][0], n1 = c1 ? c.mix_n[1][1] : c.mix_n[1][0], n2 = c2 ? c.mix_n[2][1] : c.mix_n[2][0];
-        const uint32_t h0 = c0 ? c.mix_g2[0][1] : c.mix_g2[0][0], h1 = c1 ? c.mix_g2[1][1] : c.mix_g2[1][0], h2 = c2 ? c.mix_g2[2][1] : c.mix_g2[2][0];
-        const uint32_t v0 = wbytes[8u * h0 + lz], v1 = wbytes[8u * h1 + lz], v2 = wbytes[8u * h2 + lz];
-        uint32_t b = b_l;
-        if (!small) {                                                                              // S:1891-1893 (rare: a match of >= 256 bases)
-            for (b = 0; b < c.mm_nbins; ++b)
-                if (bins[2 * b] <= prev_match && prev_match < bins[2 * b + 1]) break;
-            if (b >= c.mm_nbins) b = c.mm_nbins - 1;
-        }
-        // ---- wave 2: two thresholds of every run-length walk; segment range and guide of the match column
-        const uint64_t a0 = T.w[go0 + v0], b0 = T.w[go0 + min(v0 + 1u, n0 - 1u)];
-        const uint64_t a1 = T.w[go1 + v1], b1 = T.w[go1 + min(v1 + 1u, n1 - 1u)];
-        const uint64_t a2 = T.w[go2 + v2], b2 = T.w[go2 + min(v2 + 1u, n2 - 1u)];
-        const uint32_t o = seg_off[b], ncol = seg_off[b + 1] - o;
-        const uint32_t s0 = mmGuide[256u * b + (w.w >> 24)];
-        // ---- wave 3: three thresholds / value edges of the match column from the guide's segment on
-        const uint32_t sa = min(s0, ncol - 1u), sb = min(s0 + 1u, ncol - 1u), sc = min(s0 + 2u, ncol - 1u);
-        const uint64_t ga = mmG[o + sa], gb = mmG[o + sb], gc = mmG[o + sc];
-        const uint32_t va = mmV[o + sa], vb = mmV[o + sb], vc = mmV[o + sc];
-        // ---- the answers
-        const int error = ux < t0 ? NS_MIS : ux < t1 ? NS_INS : NS_DEL;                           // S:1860-1864 (trans_pick_u)
-        const uint32_t rv = error == NS_MIS ? v0 : error == NS_INS ? v1 : v2, rn = error == NS_MIS ? n0 : error == NS_INS ? n1 : n2;
-        const uint64_t ra = error == NS_MIS ? a0 : error == NS_INS ? a1 : a2, rb = error == NS_MIS ? b0 : error == NS_INS ? b1 : b2;
-        const uint32_t rg = error == NS_MIS ? go0 : error == NS_INS ? go1 : go2;
-        uint32_t rw = rv;                                                                          // == run_length_t's walk (S:1866-1873)
-        if (rw + 1u < rn && uz >= ra) { ++rw; if (rw + 1u < rn && uz >= rb) { ++rw; while (rw + 1u < rn && uz >= T.w[rg + rw]) ++rw; } }
-        int32_t step = (int32_t)rw + 1;
-        if (error == NS_INS) l_new += step; else if (error == NS_DEL) l_new -= step;
-        if (error != NS_INS) {                                                                     // S:1875-1880
-            ev_push32(s, pos, (uint32_t)error, step);
-            pos += step;
-            if (pos >= middle_ref) { l_new += pos - middle_ref; middle_ref = pos; }
-        } else {                                                                                   // S:1881-1882
-            if (last_ins_pos == pos && s.n > 0) { s.n--; s.shift -= (int32_t)s.last_ins_len; }    // dict key collision
-            ev_push32(s, pos, NS_INS, step);
-            last_ins_pos = pos;
-        }
-        state = NS_ST_MIS + error;                                                                 // S:1884
-        // next match length (S:1895-1898): the segment is the guide's, or one or two further on, and one unit wide — else the full look-up
-        const bool k0 = s0 < ncol && uw >= NS_G_THR(ga), k1 = k0 && s0 + 1u < ncol && uw >= NS_G_THR(gb), k2 = k1 && s0 + 2u < ncol && uw >= NS_G_THR(gc);
-        const uint32_t sv = k1 ? vc : k0 ? vb : va;
-        const bool in_col = (k1 ? s0 + 2u : k0 ? s0 + 1u : s0) < ncol;
-        if (!k2 && in_col && (sv & 0x80000000u)) step = (int32_t)(sv & 0x7fffffffu) - 1;
-        else step = ecdf_lookup_u(mmG + o, mmV + o, ncol, mmGuide + 256u * b, w.w, T.q(c.sub), TG.d(c.mm_hi) + o, TG.d(c.mm_vhi) + o, T.d(c.mm_vlo0)[b]);
-        if (prev_match == 0 && step == 0) step = 1;                                                // S:1900-1901
-        prev_match = step;
-        if (pos + prev_match > middle_ref) { l_new += pos + prev_match - middle_ref; middle_ref = pos + prev_match; }
-        pos += prev_match;
-        if (prev_match == 0) state += 3;                                                           // S:1913-1914
-        else last_ins_pos = -1;
-        ++it;
-    }
-    return EList32{l_new, middle_ref};
-}
-
-// unaligned_error_list, S:1784-1830, with the event rewrite of DESIGN.md §5.3
-template <bool MR = false>
-NS_DEV EList32 chain_unaligned_error_list(const Tabs &T, const ChainTab &c, int32_t m_ref, const ns_key &key,
-                                                              uint32_t seg, uint32_t attempt, EvSink32 &s) {
-    int32_t l_new = m_ref, pos = 0, middle_ref = m_ref;
-    int32_t pend_ins = 0;
-    if (m_ref <= 0) return EList32{l_new, middle_ref};
-    uint32_t it = 0;
-    // what iteration `it` draws does not depend on the state of the loop: the Philox block of the NEXT iteration is evaluated under this
-    // iteration's table walk, off the critical path (as thread-per-read work the loop is pure latency: ~2 000 dependent iterations per read)
-    u32x4 w_next = ns_draw(key, ST_UEVENT, seg, attempt, 0, 0);
-    const uint64_t mw0 = T.q(c.mix_w)[0], mw1 = T.q(c.mix_w)[1], mw2 = T.q(c.mix_w)[2];            // the mixture weights: registers
-    while (pos < middle_ref) {
-        const u32x4 w = w_next;
-        ++it;
-        w_next = ns_draw(key, ST_UEVENT, seg, attempt, it, 0);
-        const uint64_t ut = w.x;                                                                     // (p < t  <=>  u < ns_thr_lt(t))
-        const int type = (ut < ns_thr_lt(0.4)) ? 3 : (ut < ns_thr_lt(0.7)) ? NS_MIS : (ut < ns_thr_lt(0.85)) ? NS_INS : NS_DEL;   // S:1787
-        int32_t step = 1;
-        if (type != 3) step = run_length_w<MR>(T, c, type, type == NS_MIS ? mw0 : type == NS_INS ? mw1 : mw2, w.y, w.z);
-        if (type == NS_INS) { pend_ins += step; l_new += step; continue; }                          // S:1808-1815
-        if (type == NS_DEL) l_new -= step;
-        const int32_t L = pend_ins; pend_ins = 0;
-        if (type == 3) {
-            if (L) ev_push32(s, pos + 1, NS_INS, L);
-        } else if (type == NS_MIS) {
-            if (!L) ev_push32(s, pos, NS_MIS, step);
-            else {
-                ev_push32(s, pos, NS_MIS, 1);
-                ev_push32(s, pos + 1, NS_INS, L);
-                if (step - 1 > L) ev_push32(s, pos + 1, NS_MIS, step - 1 - L);
-            }
-        } else {
-            if (!L) ev_push32(s, pos, NS_DEL, step);
-            else {
-                int32_t dl = step - L; if (dl < 1) dl = 1;
-                ev_push32(s, pos, NS_DEL, dl);
-                if (L - (step - 1) > 0) ev_push32(s, pos + 1, NS_INS, L - (step - 1));
-            }
-        }
-        pos += step;
-        if (pos > middle_ref) { l_new += pos - middle_ref; middle_ref = pos; }                       // S:1826-1828
-    }
-    return EList32{l_new, middle_ref};
-}
 
 // ---- cooperative unaligned_error_list: one read (or gap) per wavefront, lane = loop iteration -------------------------
 // What iteration `it` of S:1797-1829 draws (type, run length) does not depend on the state of the loop, and the state is a running
@@ -653,7 +403,7 @@ __device__ inline EList32 coop_unaligned_error_list(const Tabs &T, const ChainTa
         const uint64_t ut = w.x;                                     // (p < t  <=>  u < ns_thr_lt(t))
         type = (ut < ns_thr_lt(0.4)) ? 3 : (ut < ns_thr_lt(0.7)) ? NS_MIS : (ut < ns_thr_lt(0.85)) ? NS_INS : NS_DEL;
         step = 1;
-        if (type != 3) step = (uint32_t)run_length_t<NS_MIX_REC>(T, c, type, w.y, w.z);
+        if (type != 3) step = (uint32_t)run_length_t(T, c, type, w.y, w.z);
     };
     int type_n; uint32_t step_n;
     draw(lane, type_n, step_n);
@@ -764,7 +514,7 @@ __device__ inline EList32 coop_error_list(const Tabs &T, const ChainTab &c, int3
             for (int st = 0; st < 7; ++st) eb |= (uint32_t)trans_pick_u(trans + 3 * st, wi.x) << (2 * st);
             S.err_tab[lane] = eb;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) S.step_tab[lane][t] = (uint16_t)run_length_t<NS_MIX_REC>(T, c, t, wi.y, wi.z);
+            for (int t = 0; t < 3; ++t) S.step_tab[lane][t] = (uint16_t)run_length_t(T, c, t, wi.y, wi.z);
             for (uint32_t b = 0; b < c.mm_nbins; ++b) {
                 const uint32_t o = seg_off[b];
                 S.match_tab[lane][b] = (uint16_t)ecdf_lookup_g(T.d(c.mm_hi) + o, T.d(c.mm_vhi) + o, seg_off[b + 1] - o,

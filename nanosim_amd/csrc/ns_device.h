@@ -5,29 +5,20 @@
 #include "ns_rng.h"
 #include "../../include/nanosim_amd.h"
 
-struct ChainTab {                 // offsets are in 8-byte words from the start of the blob
+struct ChainTab {                 // offsets are in 8-byte words from the start of the blob (ns_pack.h describes the image)
     uint32_t n_words;
-    uint32_t trans;               // 21 doubles: rows start,mis,ins,del,mis0,ins0,del0 x (a, a+b, 1-c)
-    uint32_t mix_w;               // 3 doubles
-    uint32_t mix_cdf[3][2], mix_n[3][2];
-    uint32_t mix_g2[3][2];        // per table: 33 bytes, guide of the threshold walk by the leading one bits of the draw (run_length_t)
+    uint32_t trans;               // 21 thresholds: rows start,mis,ins,del,mis0,ins0,del0 x (a, a+b, -)
+    uint32_t mix_w;               // 3 thresholds
+    uint32_t mix_rec;             // the run-length tables' (offset, length, guide) by 2 * type + component as records of two words
+                                  // {offset | length << 32, guide}: indexed by a per-thread type, three fields of this struct would be
+                                  // three vector loads from the kernel-argument segment per event
     uint32_t fm_hi, fm_vhi, fm_n, fm_guide;
-    uint32_t fm_vhi_u, mm_vhi_u;     // the value edges once more as 32-bit integers (they are whole numbers in every trained model): what the LDS copy holds;
-                                     // bit 31: the segment is one unit wide and no draw inside it rounds up to its upper edge (ecdf_lookup_u)
-    uint32_t fm_g, mm_g;             // the probability edges as integer thresholds of the 32-bit draw (ns_thr_gt), 8 bytes each: LDS copy
-    uint32_t sub;                    // the steps of the interpolation inside the narrow segments that are not flagged (ecdf_lookup_u)
-    uint32_t n_words_lds;            // the blob up to here goes to LDS (k_chain<LDS>); the fp64 value edges behind it stay in global memory
+    uint32_t fm_gv, mm_gv;        // ONE word per ECDF segment: threshold | class | value (ecdf_lookup_gv)
+    uint32_t pm_lut;              // the column of a previous match < 256 in one word {first segment | segments << 32 | bin << 56}
+    uint32_t sub2;                // the steps of the interpolation inside the narrow segments
+    uint32_t n_words_lds;         // the blob up to here goes to LDS (k_chain<LDS>); the fp64 tables behind it stay in global memory
     uint32_t mm_nbins, mm_bin, mm_bin_lut, mm_seg_off, mm_hi, mm_vhi, mm_vlo0, mm_guide;
     double fm_vlo0;
-#ifdef NS_CHAIN_TABS2
-    // layout bit 1 (NS_CHAIN_VAR & 8): the run-length tables' (offset, length, guide) by 2 * type + component as records of two words
-    // {offset | length << 32, guide} in the LDS part — indexed by a per-thread type, mix_cdf / mix_n / mix_g2 above are fetched from the
-    // kernel-argument segment with three vector loads per event
-    uint32_t mix_rec;
-    // layout bit 2 (NS_CHAIN_VAR & 32): ONE word per ECDF segment instead of threshold + value edge (ecdf_lookup_gv), and the column of a
-    // previous match < 256 in one word {first segment | segments << 32 | bin << 56} instead of bin_lut -> seg_off
-    uint32_t fm_gv, mm_gv, pm_lut, sub2;
-#endif
 };
 
 struct DevModel {

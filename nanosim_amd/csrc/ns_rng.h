@@ -6,16 +6,6 @@
 #include <stdint.h>
 
 #define NS_HD __host__ __device__ __forceinline__
-// NS_CHAIN_VAR (bit mask, 0 in the product build): formulations of the event chains that are timed against each other on the GPU
-// (scripts/ab_run.sh) and held against the oracle on the CPU (tests/test_chain_host.py); ns_chain.h lists the bits.  Bits 8 and 32 add
-// tables to the packed blob (NS_CHAIN_TABS2: fields of ChainTab, ns_pack.h layouts 1 and 3); the CPU test build has them all.
-#ifndef NS_CHAIN_VAR
-#define NS_CHAIN_VAR 0
-#endif
-#if (NS_CHAIN_VAR & (8 | 32)) || defined(NS_HOST_TEST)
-#define NS_CHAIN_TABS2 1
-#endif
-#define NS_CHAIN_LAYOUT (((NS_CHAIN_VAR) & 32) ? 3u : ((NS_CHAIN_VAR) & 8) ? 1u : 0u)
 // NS_DEV: device code of the thread-per-read event chains (ns_chain.h).  The CPU test suite compiles the SAME source for the host
 // (tests/chain_host.hip, -DNS_HOST_TEST, host pass only) and holds it against the oracle without a GPU; in the product build the
 // qualifier is the plain device one.
@@ -56,20 +46,14 @@ NS_HD uint32_t ns_clz32(uint32_t x) {
 }
 
 // Philox4x32-10 (Salmon, Moraes, Dror, Shaw 2011)
-// -DNS_PHILOX_BITOP3 (prepared in round 4, not timed): the two three-way XORs of a round as ONE v_bitop3_b32 each (gfx950; truth table
-// 0x96) — the compiler emits two v_xor_b32 for a ^ b ^ c: 20 of the ~62 vector instructions of an evaluation
-#if defined(NS_PHILOX_BITOP3) && defined(__HIP_DEVICE_COMPILE__)
+// The two three-way XORs of a round are ONE v_bitop3_b32 each on gfx950 (truth table 0x96 = a ^ b ^ c; the compiler emits two v_xor_b32):
+// 20 of the ~62 vector instructions of an evaluation, in every kernel (round 5, same-box A/B: profiles/r05/ab_chain.log)
+#if defined(__HIP_DEVICE_COMPILE__)
 #define NS_XOR3(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96)
 #else
 #define NS_XOR3(a, b, c) ((a) ^ (b) ^ (c))
 #endif
 NS_HD u32x4 philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
-#if defined(NS_PHILOX_REKEY) && defined(__HIP_DEVICE_COMPILE__)
-    // the seed is wave-uniform: its ten round keys are loop-invariant, the compiler hoists all twenty words out of the kernels' loops and
-    // then spills some to VGPR lanes (v_readlane + hazard s_nop at every use).  The empty asm makes the key opaque per evaluation: the round
-    // keys are twenty s_add_i32 next to the vector work instead of twenty live SGPRs (prepared in round 4, not timed)
-    asm volatile("" : "+s"(k0), "+s"(k1));
-#endif
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;

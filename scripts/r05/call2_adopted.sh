@@ -1,0 +1,32 @@
+#!/bin/bash
+# round 5, GPU call 2: the adopted build (v2 lists + bit-op Philox, five waves per SIMD) — the whole -m gpu suite, the default bench line,
+# the configs[3] / configs[4] lines, then the two knob sweeps the faster lists invite (share of reads on the wave-per-read lists).
+cd "$(dirname "$0")/../.."
+O=gpurun_out/r05b; mkdir -p $O
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+( timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 ) | tee $O/pytest_gpu.log
+timeout 400 python bench.py --steps 10 --warmup 3 2>$O/bench_default.err | tail -1 > $O/bench_ecoli_fasta.json
+python - $O/bench_ecoli_fasta.json <<'P' | tee $O/bench_default_summary.log
+import json,sys
+d=json.load(open(sys.argv[1])); r=lambda x:round(x,3)
+print("step", r(d["ms_per_step"]), "ms", r(d["value"]/1e6), "M reads/s | aligned", {k:r(v) for k,v in d["kernel_ms"].items() if v>0.01}, "| unaligned", {k:r(v) for k,v in d["unaligned_batch"]["kernel_ms"].items() if v>0.01})
+print("roofline", {k:(r(v) if isinstance(v,float) else v) for k,v in d["roofline"].items() if k in ("frac","frac_kernel_only_bytes","frac_counter_bytes","whole_aligned_batch_frac")})
+for k in ("serial","errlog_on"): print(k, {a:(r(b) if isinstance(b,float) else b) for a,b in d[k].items() if not isinstance(b,(dict,str))})
+c=d.get("configs2",{}); print("configs2", r(c.get("ms_per_step",0)), c.get("aligned_batch",{}).get("kernel_ms"), c.get("roofline",{}).get("frac"))
+print("cpu", d.get("cpu_baseline",{}).get("value"), "e2e", {k:(r(v.get("reads_per_s",0)/1e6) if isinstance(v,dict) and "reads_per_s" in v else None) for k,v in d.get("e2e",{}).items()})
+P
+timeout 400 python bench.py --genome grch38 --chimeric --steps 5 --warmup 2 --no-cpu-baseline --no-e2e 2>$O/bench_grch38.err | tail -1 > $O/bench_grch38_chimeric.json
+timeout 300 python bench.py --metagenome --steps 5 --warmup 2 --no-cpu-baseline --no-e2e 2>$O/bench_meta.err | tail -1 > $O/bench_zymo10_metagenome.json
+for f in bench_grch38_chimeric bench_zymo10_metagenome; do python -c "
+import json,sys
+d=json.load(open('$O/$f.json')); r=lambda x:round(x,3)
+print('$f', r(d['ms_per_step']), 'ms', r(d['value']/1e6), 'M reads/s', {k:r(v) for k,v in d['kernel_ms'].items() if v>0.01}, 'serial', r(d.get('serial',{}).get('ms_per_step',0)), 'errlog_on', r(d.get('errlog_on',{}).get('ms_per_step',0)), 'frac', r(d['roofline']['frac']))
+" | tee -a $O/bench_other_summary.log; done
+for sh in 2 4 5 6; do echo -n "NS_UCOOP_SHIFT=$sh "; NS_UCOOP_SHIFT=$sh timeout 120 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-e2e --no-configs2 --no-extras 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=lambda x:round(x,2)
+print(r(d['ms_per_step']), 'ms/step; aligned', r(d['aligned_batch']['device_ms']), 'chain', r(d['kernel_ms']['k_chain']), '; unaligned', r(d['unaligned_batch']['device_ms']), 'chain', r(d['unaligned_batch']['kernel_ms']['k_chain']))"; done 2>&1 | tee $O/sweep_ucoop.log
+for sh in 9 11 12; do echo -n "NS_COOP_SHIFT=$sh "; NS_COOP_SHIFT=$sh timeout 120 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-e2e --no-configs2 --no-extras 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=lambda x:round(x,2)
+print(r(d['ms_per_step']), 'ms/step; aligned', r(d['aligned_batch']['device_ms']), 'chain', r(d['kernel_ms']['k_chain']), '; unaligned', r(d['unaligned_batch']['device_ms']), 'chain', r(d['unaligned_batch']['kernel_ms']['k_chain']))"; done 2>&1 | tee $O/sweep_coop.log

@@ -1,5 +1,5 @@
 // chain_host.hip — TEST infrastructure: the thread-per-read event chains of the engine (nanosim_amd/csrc/ns_chain.h: chain_error_list,
-// chain_unaligned_error_list) and the table packing of ns_load_model (ns_pack.h) compiled for the HOST, so that `-m "not gpu"` tests can
+// chain_error_list_g, chain_unaligned_error_list) and the table packing of ns_load_model (ns_pack.h) compiled for the HOST, so that `-m "not gpu"` tests can
 // hold the device source against the oracle event by event (tests/test_chain_host.py).  Built by the test with
 //   hipcc --cuda-host-only -x hip -O2 -std=c++17 -ffp-contract=off -DNS_HOST_TEST -shared -fPIC
 // (host pass only: no device code, no HIP call).  Nothing of the product links or loads this file.
@@ -16,25 +16,19 @@ struct ChainHost {
 
 extern "C" {
 
-// layout: 0 = the product's blob; 1 = + run-length records (NS_CHAIN_VAR & 8); 3 = + one-word ECDF segments, column table (NS_CHAIN_VAR & 32)
-void *chost_pack(const ns_model_tables *t, uint32_t layout) {
+void *chost_pack(const ns_model_tables *t) {
     ChainHost *h = new (std::nothrow) ChainHost;
     if (!h) return nullptr;
-    ns_pack_chain_tables(t, t->mm_seg_off[t->mm_nbins], h->ct, h->blob, h->whole, layout);
+    ns_pack_chain_tables(t, t->mm_seg_off[t->mm_nbins], h->ct, h->blob, h->whole);
     return h;
 }
 void chost_free(void *p) { delete static_cast<ChainHost *>(p); }
 int chost_whole(const void *p) { return static_cast<const ChainHost *>(p)->whole ? 1 : 0; }
 uint32_t chost_lds_words(const void *p) { return static_cast<const ChainHost *>(p)->ct.n_words_lds; }
 
-// variant 0: chain_error_list<true>  — the integer image k_chain<LDS> walks (T = the blob's first n_words_lds words, here the blob itself)
-//         1: chain_error_list<false> — the fp64 tables (models whose value edges are not whole numbers, tables too large for LDS)
-//         2: chain_unaligned_error_list
-//    10 + v: chain_error_list<true, v>, v = 1 .. 15 — the formulations of the iteration that -DNS_CHAIN_VAR=v selects in the engine
-//            (v & 8: run-length records, needs a blob of layout 1 or 3)
-//        30: chain_unaligned_error_list<true> (run-length records: layout 1 or 3)
-//        31: chain_unaligned_error_list_v2, 32: chain_error_list_v2 (layout 3)
-//        33: chain_error_list<false, 8> — what k_chain<false, .> runs under NS_CHAIN_VAR & (8 | 32): fp64 tables, run-length records
+// variant 0: chain_error_list   — the integer image k_chain<LDS> walks (T = the blob's first n_words_lds words)
+//         1: chain_error_list_g — the fp64 tables (models whose value edges are not whole numbers, tables too large for LDS)
+//         2: chain_unaligned_error_list on the LDS image, 3: on the whole blob (k_chain<false, .>)
 // T and TG: the LDS image is the first n_words_lds words of the blob — handing the chain a COPY of just those words as T checks that it
 // never reads a table of the LDS part behind them.
 // staged != 0: events go through the four-slot staging column (EvSink32::stg) as in k_chain<LDS> for single-piece reads; cap must then be
@@ -44,8 +38,7 @@ int chost_error_list(const void *p, int variant, int staged, int32_t m_ref, uint
     const ChainHost *h = static_cast<const ChainHost *>(p);
     const Tabs TG{h->blob.data()};
     std::vector<uint64_t> lds(h->blob.begin(), h->blob.begin() + h->ct.n_words_lds);      // (+ nothing: a read behind it is out of bounds)
-    const bool image = variant != 1;                                                        // the fp64 chain walks the whole blob (k_chain<false, .>)
-    const Tabs T{image ? lds.data() : h->blob.data()};
+    const Tabs T{lds.data()};
     const ns_key key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)read, (uint32_t)(read >> 32)};
     uint2 stage[4 * NS_CHAIN_BLOCK];
     EvSink32 s;
@@ -53,28 +46,10 @@ int chost_error_list(const void *p, int variant, int staged, int32_t m_ref, uint
     s.stg = staged ? stage : nullptr;
     EList32 e;
     switch (variant) {
-    case 0: e = chain_error_list<true>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
-    case 1: e = chain_error_list<false>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
+    case 0: e = chain_error_list(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
+    case 1: e = chain_error_list_g(TG, h->ct, m_ref, key, seg, attempt, s); break;
     case 2: e = chain_unaligned_error_list(T, h->ct, m_ref, key, seg, attempt, s); break;
-    case 18: e = chain_error_list<true, 8>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
-    case 19: e = chain_error_list<true, 9>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
-    case 20: e = chain_error_list<true, 10>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
-    case 21: e = chain_error_list<true, 11>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
-    case 22: e = chain_error_list<true, 12>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
-    case 23: e = chain_error_list<true, 13>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
-    case 24: e = chain_error_list<true, 14>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
-    case 25: e = chain_error_list<true, 15>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
-    case 33: e = chain_error_list<false, 8>(TG, TG, h->ct, m_ref, key, seg, attempt, s); break;
-    case 30: e = chain_unaligned_error_list<true>(T, h->ct, m_ref, key, seg, attempt, s); break;
-    case 31: e = chain_unaligned_error_list_v2(T, h->ct, m_ref, key, seg, attempt, s); break;
-    case 32: e = chain_error_list_v2(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
-    case 11: e = chain_error_list<true, 1>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
-    case 12: e = chain_error_list<true, 2>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
-    case 13: e = chain_error_list<true, 3>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
-    case 14: e = chain_error_list<true, 4>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
-    case 15: e = chain_error_list<true, 5>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
-    case 16: e = chain_error_list<true, 6>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
-    case 17: e = chain_error_list<true, 7>(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
+    case 3: e = chain_unaligned_error_list(TG, h->ct, m_ref, key, seg, attempt, s); break;
     default: return -1;
     }
     ev_flush_tail(s);

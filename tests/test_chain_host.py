@@ -19,11 +19,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not found")
 
-VARIANT_LDS, VARIANT_FP64, VARIANT_UNALIGNED = 0, 1, 2
-# what -DNS_CHAIN_VAR=v builds into k_chain (ns_chain.h), per blob layout (ns_pack.h) it needs:
-FORMULATIONS = {0: tuple(range(11, 18)),                              # chain_error_list<true, 1 .. 7>
-                1: tuple(range(18, 26)) + (30, 33),                      # chain_error_list<true, 8 .. 15>, chain_unaligned_error_list<true>: run-length records
-                3: (32, 31, 30, 33, 1, 2)}                                    # chain_error_list_v2 (+ what else the engine runs on that blob)
+VARIANT_LDS, VARIANT_FP64, VARIANT_UNALIGNED, VARIANT_UNALIGNED_G = 0, 1, 2, 3
+UNALIGNED = (VARIANT_UNALIGNED, VARIANT_UNALIGNED_G)
+ALL = (VARIANT_LDS, VARIANT_FP64, VARIANT_UNALIGNED, VARIANT_UNALIGNED_G)
 
 
 def _build(tmp, extra=()):
@@ -32,7 +30,7 @@ def _build(tmp, extra=()):
            *extra, "-shared", "-fPIC", "-o", out, os.path.join(ROOT, "tests", "chain_host.hip")]
     subprocess.check_call(cmd, cwd=ROOT, stderr=subprocess.DEVNULL)
     L = C.CDLL(out)
-    L.chost_pack.restype = C.c_void_p; L.chost_pack.argtypes = [C.POINTER(M.NsModelTables), C.c_uint32]
+    L.chost_pack.restype = C.c_void_p; L.chost_pack.argtypes = [C.POINTER(M.NsModelTables)]
     L.chost_free.restype = None; L.chost_free.argtypes = [C.c_void_p]
     L.chost_whole.restype = C.c_int; L.chost_whole.argtypes = [C.c_void_p]
     L.chost_lds_words.restype = C.c_uint32; L.chost_lds_words.argtypes = [C.c_void_p]
@@ -82,9 +80,9 @@ def same(h, o, what):
     assert h["ev"][:n].tobytes() == o["ev"][:n].tobytes(), what
 
 
-def sweep(L, mdl, variants, n_cases, seed, lengths, layout=0):
+def sweep(L, mdl, variants, n_cases, seed, lengths):
     t = mdl.to_c()
-    pk = L.chost_pack(C.byref(t), layout)
+    pk = L.chost_pack(C.byref(t))
     assert pk
     try:
         rng = np.random.default_rng(seed)
@@ -95,9 +93,9 @@ def sweep(L, mdl, variants, n_cases, seed, lengths, layout=0):
             seg, att = int(rng.choice([0, 1, 5, 128, 130])), int(rng.integers(0, 1000))
             cap = 4 * ((2 * m_ref + 64) // 4)
             for v in variants:
-                o = oracle_list(t, v in (VARIANT_UNALIGNED, 30, 31), m_ref, sd, rd, seg, att, cap)
+                o = oracle_list(t, v in UNALIGNED, m_ref, sd, rd, seg, att, cap)
                 same(host_list(L, pk, v, m_ref, sd, rd, seg, att, cap), o, (v, m_ref, sd, rd, seg, att))
-                if v not in (VARIANT_FP64, 33):
+                if v != VARIANT_FP64:
                     same(host_list(L, pk, v, m_ref, sd, rd, seg, att, cap, staged=1), o, ("staged", v, m_ref, sd, rd))
                 n_events += o["n_ev"]
         return pk, n_events
@@ -107,7 +105,7 @@ def sweep(L, mdl, variants, n_cases, seed, lengths, layout=0):
 
 
 def test_device_chains_on_the_small_model(host, small_model):
-    pk, n_ev = sweep(host, small_model, (VARIANT_LDS, VARIANT_FP64, VARIANT_UNALIGNED), 400, 1, (1, 2, 3, 7, 50, 400, 3000, 20000))
+    pk, n_ev = sweep(host, small_model, ALL, 400, 1, (1, 2, 3, 7, 50, 400, 3000, 20000))
     assert host.chost_whole(pk) and host.chost_lds_words(pk) * 8 <= 40 * 1024 and n_ev > 100000       # the LDS image is what the GPU runs here
     host.chost_free(pk)
 
@@ -127,52 +125,32 @@ def test_device_chains_on_models_that_take_the_other_look_up_paths(host, tmp_pat
         prefix = str(tmp_path / name / "training")
         synth.write_model(prefix, spec, write_pkl=False)
         mdl = M.load_model(prefix)
-        pk, n_ev = sweep(host, mdl, (VARIANT_LDS, VARIANT_FP64, VARIANT_UNALIGNED), 120, 2, (1, 4, 33, 900, 8000))
+        pk, n_ev = sweep(host, mdl, ALL, 160, 2, (1, 2, 4, 9, 33, 300, 900, 8000))
         assert host.chost_whole(pk) and n_ev > 20000, name
         host.chost_free(pk)
-        pk, n_ev = sweep(host, mdl, FORMULATIONS[3], 120, 2, (1, 4, 33, 900, 8000), layout=3)        # the one-word segments on the same tables
-        assert host.chost_whole(pk) and n_ev > 20000, name
-        host.chost_free(pk)
-
-
-def test_every_formulation_of_the_iteration_gives_the_same_events(host, small_model, tmp_path):
-    """chain_error_list<VU32, VAR>: the formulations that scripts/ab_run.sh times against each other on the GPU are the same function —
-    checked here against the oracle on the small model and on the dense one (insertions on top of each other, zero-length matches)."""
-    from nanosim_amd import synth
-    spec = synth.SynthModelSpec(n_train=3000, seed=7, aligned_median=2500.0, mis=(3.0, 0.0, 0.3, 0.5), ins=(8.0, 0.9, 0.12, 0.5),
-                                dele=(6.0, 0.95, 0.15, 0.5), mm_means=(2.0, 2.5, 3.0, 3.0, 3.5, 3.5, 4.0, 4.0),
-                                mm_zero=(0.0, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3), fm_mean=3.0)
-    prefix = str(tmp_path / "dense" / "training")
-    synth.write_model(prefix, spec, write_pkl=False)
-    for mdl in (small_model, M.load_model(prefix)):
-        for layout, variants in FORMULATIONS.items():
-            pk, n_ev = sweep(host, mdl, variants, 60, 3, (1, 2, 9, 300, 6000), layout=layout)
-            assert n_ev > 20000 and host.chost_whole(pk)
-            host.chost_free(pk)
 
 
 def test_event_capacity_overflow_and_range_flags(host, small_model, tmp_path):
     """A sink that is too small: the chain keeps counting, flags the overflow and never writes behind the capacity (k_chain re-plans the
     batch from the count); a piece whose cumulative shift leaves the 18-bit field of the event record raises `range` (the batch then takes
-    the wide-event path) — the same numbers and flags as the oracle, in every formulation (the v2 lists track both flags arithmetically)."""
+    the wide-event path) — the same numbers and flags as the oracle (the lists on the LDS image track both flags arithmetically)."""
     from nanosim_amd import synth
     t = small_model.to_c()
-    for layout, variants in ((0, (VARIANT_LDS, VARIANT_UNALIGNED) + FORMULATIONS[0]), (3, (32, 31, 30))):
-        pk = host.chost_pack(C.byref(t), layout)
-        try:
-            for v in variants:
-                for staged in (0, 1):
-                    full = oracle_list(t, v in (VARIANT_UNALIGNED, 30, 31), 5000, 77, 5, 0, 0, 4096)
-                    assert full["n_ev"] > 40
-                    cap = 16
-                    ev = _aligned(cap + 8)
-                    ev["pos"] = 0xdeadbeef
-                    out = [C.c_int32(), C.c_int32(), C.c_uint32(), C.c_int32(), C.c_int(), C.c_int()]
-                    assert host.chost_error_list(pk, v, staged, 5000, 77, 5, 0, 0, ev.ctypes.data, cap, *[C.addressof(o) for o in out]) == 0
-                    assert out[2].value == full["n_ev"] and out[4].value == 1 and (out[0].value, out[1].value) == (full["l_new"], full["middle_ref"])
-                    assert ev[:cap].tobytes() == full["ev"][:cap].tobytes() and (ev["pos"][cap:] == 0xdeadbeef).all()
-        finally:
-            host.chost_free(pk)
+    pk = host.chost_pack(C.byref(t))
+    try:
+        for v in ALL:
+            for staged in ((0,) if v == VARIANT_FP64 else (0, 1)):
+                full = oracle_list(t, v in UNALIGNED, 5000, 77, 5, 0, 0, 4096)
+                assert full["n_ev"] > 40
+                cap = 16
+                ev = _aligned(cap + 8)
+                ev["pos"] = 0xdeadbeef
+                out = [C.c_int32(), C.c_int32(), C.c_uint32(), C.c_int32(), C.c_int(), C.c_int()]
+                assert host.chost_error_list(pk, v, staged, 5000, 77, 5, 0, 0, ev.ctypes.data, cap, *[C.addressof(o) for o in out]) == 0
+                assert out[2].value == full["n_ev"] and out[4].value == 1 and (out[0].value, out[1].value) == (full["l_new"], full["middle_ref"])
+                assert ev[:cap].tobytes() == full["ev"][:cap].tobytes() and (ev["pos"][cap:] == 0xdeadbeef).all()
+    finally:
+        host.chost_free(pk)
     # insertion-heavy tables: the shift of a long piece runs out of the field
     spec = synth.SynthModelSpec(n_train=3000, seed=8, mis=(3.0, 0.0, 0.3, 0.5), ins=(12.0, 0.9, 0.12, 0.5), dele=(1.5, 0.95, 0.15, 0.5),
                                 mm_means=(3.0,) * 8, mm_zero=(0.0,) + (0.2,) * 7, fm_mean=3.0)
@@ -182,15 +160,14 @@ def test_event_capacity_overflow_and_range_flags(host, small_model, tmp_path):
     t2 = mdl.to_c()
     cap = 4 * 150000
     seen = 0
-    for layout, variants in ((0, (VARIANT_LDS, VARIANT_UNALIGNED, 11)), (3, (32, 31))):
-        pk = host.chost_pack(C.byref(t2), layout)
-        try:
-            for v in variants:
-                m_ref = 400000 if v in (VARIANT_UNALIGNED, 30, 31) else 800000          # (shift per base: 0.45 unaligned, 0.18 aligned)
-                o = oracle_list(t2, v in (VARIANT_UNALIGNED, 30, 31), m_ref, 9, 1, 0, 0, cap)
-                h = host_list(host, pk, v, m_ref, 9, 1, 0, 0, cap, staged=1)
-                same(h, o, ("range", v))
-                seen += int(bool(o["range"]))
-        finally:
-            host.chost_free(pk)
-    assert seen == 5                                       # every case does leave the field (else the flag was never exercised)
+    pk = host.chost_pack(C.byref(t2))
+    try:
+        for v in ALL:
+            m_ref = 400000 if v in UNALIGNED else 800000          # (shift per base: 0.45 unaligned, 0.18 aligned)
+            o = oracle_list(t2, v in UNALIGNED, m_ref, 9, 1, 0, 0, cap)
+            h = host_list(host, pk, v, m_ref, 9, 1, 0, 0, cap, staged=0 if v == VARIANT_FP64 else 1)
+            same(h, o, ("range", v))
+            seen += int(bool(o["range"]))
+    finally:
+        host.chost_free(pk)
+    assert seen == 4                                       # every case does leave the field (else the flag was never exercised)

@@ -286,6 +286,10 @@ def test_bench_gpus_2_launches_its_own_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["multi_gpu"]["world_size"] == 2 and d["multi_gpu"]["collectives_in_timed_region"] == 0
     assert len(d["multi_gpu"]["per_rank"]) == 2 and d["multi_gpu"]["reference_broadcast_ms"] > 0
     assert d["value"] > 0 and d["scaling"] == "weak" and d["config"]["reads_per_step_per_gpu"] == 100000
+    # what a scaling run needs without interpretation: rank 0 alone with the same binary, and the ratio (two ranks on ONE GPU: about a half)
+    mg = d["multi_gpu"]
+    assert mg["backend_reported"] == "gloo" and mg["single_rank_reference"]["value"] > 0
+    assert abs(mg["scaling_efficiency"] - d["value"] / (2 * mg["single_rank_reference"]["value"])) < 1e-9 and 0.2 < mg["scaling_efficiency"] < 1.3
 
 
 def test_bench_metagenome_and_extras_objects():
