@@ -1459,12 +1459,29 @@ __global__ void __launch_bounds__(64 * NS_WPB) k_errlen(GenArgs A) {
 // touching 64 different cache lines: the kernel was bound by the memory pipeline's address handling (11.5 ms per 950 000 reads for
 // 17.7 KB of text per read = 0.18 of HBM), not by HBM.  A block of rows that does not fit the buffer (names beyond ~60 characters with
 // long payloads) takes the row-per-lane stores.
-#define NS_ERR_BUF 8192u          // bytes of rows staged per iteration
-#define NS_ERR_PAD 16u            // in front of the buffer: the copy-out reads 16 bytes from up to 15 bytes before the first row
-#define NS_ERR_NAME 256u          // the read name, once per read
+// Round 5: every DS access is ALIGNED.  The counters showed the LDS pipe 76 % busy at 19 LDS cycles per DS instruction (5.5 in the record
+// kernel), and scripts/microbench/lds_align.hip says why: a ds_write_b64 / ds_read_b64 / b32 / b16 whose address is not a multiple of
+// its size costs ~58 cycles per CU against ~7 (profiles/r05/microbench_lds_align.log) — and a row starts at any byte.  So
+//   * the block lies in LDS at the destination's offset inside its 16-byte chunk (buf + (dst & 15)): the copy-out is one aligned
+//     ds_read_b128 and one aligned 16-byte global store per lane (it was two ds_read_b64 at any offset);
+//   * the read name is kept FOUR times, copy s shifted by s bytes: a lane whose row starts s bytes behind a dword boundary copies
+//     aligned dwords from copy s (it was six ds_write_b64 at any offset per row); the bytes of a dword a row shares with its neighbours
+//     and the row's fields are byte stores (6.8 cycles each whatever the address).
+// Round 5, second step: the kernel is bound by how many wavefronts a SIMD holds (same-box A/B: an 8 KB block buffer = 4 wavefronts per
+// SIMD 8.63 ms, 4.5 KB = 6 wavefronts 7.46 ms), so the block buffer is a template parameter: BUF = 5 120 bytes when 64 average rows of the
+// batch fit with four bytes to spare each (the host knows the batch's bytes per row; a block that still does not fit takes the
+// row-per-lane stores), else 8 192.  What did not pay on top of it (profiles/r05/ab_errlog.log): staging a block that does not fit in lane
+// groups, and fetching the event of the NEXT iteration and the reference bases under this one before the LDS work — 83-84 VGPRs = five
+// wavefronts per SIMD: 7.63 ms; bounded to 80 VGPRs with 20 bytes of scratch: 7.7-7.9.
+#define NS_ERR_BUF_SMALL 5120u
+#define NS_ERR_BUF_LARGE 8192u
+#define NS_ERR_PAD 16u            // the block starts at the destination's offset inside its 16-byte chunk
+#define NS_ERR_NAME 256u          // the read name, once per read (four shifted copies)
+#define NS_ERR_NAME_ROW (NS_ERR_NAME + 8u)
+template <uint32_t BUF>
 __global__ void __launch_bounds__(64) k_errlog(GenArgs A) {
-    __shared__ __align__(16) uint8_t buf_lds[NS_ERR_PAD + NS_ERR_BUF + 16];
-    __shared__ __align__(16) uint8_t name_lds[NS_ERR_NAME];
+    __shared__ __align__(16) uint8_t buf_lds[NS_ERR_PAD + BUF + 16];
+    __shared__ __align__(16) uint8_t name_lds[4][NS_ERR_NAME_ROW];
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t r = blockIdx.x;
     if (r >= A.prm.n_reads) return;
@@ -1474,13 +1491,17 @@ __global__ void __launch_bounds__(64) k_errlog(GenArgs A) {
     const uint32_t a = rd.attempts;
     const uint32_t nl = A.name_len[r];
     const uint8_t *name = A.records + rd.rec_off + 1;
-    uint8_t *const buf = buf_lds + NS_ERR_PAD;
     const bool name_in_lds = nl <= NS_ERR_NAME;
     if (name_in_lds) {                                              // (k_names is done: ns_generate orders the kernels)
-        for (uint32_t i = lane * 4; i < nl; i += 256) {
-            uint32_t v = 0;
-            for (uint32_t b = 0; b < 4 && i + b < nl; ++b) v |= (uint32_t)name[i + b] << (8 * b);
-            *reinterpret_cast<uint32_t *>(name_lds + i) = v;
+        // copy s, dword j = name bytes 4 j - s .. 4 j - s + 3 (zero outside the name)
+        for (uint32_t j = lane; 4u * j < nl + 4u; j += 64) {
+            uint32_t v0 = 0;
+            for (uint32_t b = 0; b < 4; ++b) if (4u * j + b < nl) v0 |= (uint32_t)name[4u * j + b] << (8 * b);
+            const uint32_t vp = j ? (uint32_t)name[4u * j - 1] | (uint32_t)name[4u * j - 2] << 8 | (uint32_t)name[4u * j - 3] << 16 : 0u;   // bytes -1, -2, -3
+            *reinterpret_cast<uint32_t *>(&name_lds[0][4u * j]) = v0;
+            *reinterpret_cast<uint32_t *>(&name_lds[1][4u * j]) = v0 << 8 | (vp & 0xffu);
+            *reinterpret_cast<uint32_t *>(&name_lds[2][4u * j]) = v0 << 16 | (vp & 0xffu) << 8 | ((vp >> 8) & 0xffu);
+            *reinterpret_cast<uint32_t *>(&name_lds[3][4u * j]) = v0 << 24 | (vp & 0xffu) << 16 | ((vp >> 8) & 0xffu) << 8 | (vp >> 16);
         }
         wave_sync();
     }
@@ -1499,13 +1520,15 @@ __global__ void __launch_bounds__(64) k_errlog(GenArgs A) {
             const uint32_t row = active ? nl + tail : 0;
             const uint32_t incl = wave_incl_scan(row);                                      // row offsets: prefix sum over the wavefront
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            const bool staged = name_in_lds && total <= NS_ERR_BUF;                         // wave-uniform
-            auto fields = [&](uint8_t *w) {                          // the rest of the row at w
-                *w++ = '\t'; w = put_dec(w, e.pos); *w++ = '\t';
+            const bool staged = name_in_lds && total <= BUF;                               // wave-uniform
+            // (P: LdsBytes for the staged block — volatile, so that the compiler cannot merge neighbouring byte stores into a wide store at
+            // an odd address, and in the LDS address space by type, because volatile accesses are not inferred into it)
+            auto fields = [&](auto w) __attribute__((always_inline)) {                   // the rest of the row at w
+                *w++ = '\t'; w = put_dec_p(w, e.pos); *w++ = '\t';
                 const char *tn = ty == NS_MIS ? "mis" : ty == NS_INS ? "ins" : "del";
                 *w++ = (uint8_t)tn[0]; *w++ = (uint8_t)tn[1]; *w++ = (uint8_t)tn[2];
-                *w++ = '\t'; w = put_dec(w, len); *w++ = '\t';
-                uint8_t *w2 = w + len + 1;
+                *w++ = '\t'; w = put_dec_p(w, len); *w++ = '\t';
+                auto w2 = w + len + 1;
                 // the letters of the event come from ONE word per 16 (payload_word: 2-bit fields / successive base-3 digits) — drawn
                 // once per word here, not once per letter (ins_letter / mis_letter evaluate a Philox block per call)
                 uint32_t frac = 0;
@@ -1528,29 +1551,43 @@ __global__ void __launch_bounds__(64) k_errlog(GenArgs A) {
                 w2[len] = '\n';
             };
             if (staged) {
+                uint8_t *const dst0 = A.errlog + base;
+                const uint32_t mis = (uint32_t)(uintptr_t)dst0 & 15u;                        // block byte i lies at buf_lds[mis + i]: chunk-congruent with dst0
                 if (active) {
-                    uint8_t *q = buf + (incl - row);
-                    // the name: 8 bytes at a time from its LDS copy (every lane reads the same address: a broadcast), the last group
-                    // overlapping; the row starts at any byte
-                    if (nl >= 8) {
-                        for (uint32_t i = 0; i + 8 <= nl; i += 8) { uint64_t v; __builtin_memcpy(&v, name_lds + i, 8); __builtin_memcpy(q + i, &v, 8); }
-                        if (nl & 7u) { uint64_t v; __builtin_memcpy(&v, name_lds + nl - 8, 8); __builtin_memcpy(q + nl - 8, &v, 8); }
-                    } else for (uint32_t i = 0; i < nl; ++i) q[i] = name_lds[i];
+                    const uint32_t o = mis + (incl - row);                                  // the row starts at buf_lds[o]
+                    const uint32_t al = o & 3u;                                             // ... al bytes behind a dword boundary (buf_lds is 16-byte aligned)
+                    const LdsBytes q = (LdsBytes)buf_lds + o;
+                    const LdsBytes src = (LdsBytes)name_lds[al];                            // copy al: name byte i at src[al + i]
+                    const LdsWords qd = (LdsWords)((LdsBytes)buf_lds + (o - al));
+                    const uint32_t d1 = (al + nl) >> 2;                                     // dwords [d0, d1) of the row's grid hold name bytes only
+                    const uint32_t d0 = al ? 1u : 0u;
+                    if (d1 > d0) {
+                        const LdsWords sw = (LdsWords)src;
+                        const uint32_t w_head = sw[0], w_tail = sw[d1];                     // the dwords the row shares with its neighbours: byte stores
+                        for (uint32_t j = d0; j < d1; j += 4) {                             // four dwords in flight (volatile accesses keep their order)
+                            const uint32_t a0 = sw[j], a1 = sw[min(j + 1u, d1 - 1u)], a2 = sw[min(j + 2u, d1 - 1u)], a3 = sw[min(j + 3u, d1 - 1u)];
+                            qd[j] = a0;
+                            if (j + 1u < d1) qd[j + 1u] = a1;
+                            if (j + 2u < d1) qd[j + 2u] = a2;
+                            if (j + 3u < d1) qd[j + 3u] = a3;
+                        }
+                        for (uint32_t b = al; b < 4u && al; ++b) q[b - al] = (uint8_t)(w_head >> (8u * b));
+                        for (uint32_t b = 4u * d1; b < al + nl; ++b) q[b - al] = (uint8_t)(w_tail >> (8u * (b & 3u)));
+                    } else for (uint32_t i = 0; i < nl; ++i) q[i] = src[al + i];
                     fields(q + nl);
                 }
                 wave_sync();
-                // the block leaves: chunk c = the 16 bytes at errlog address (dst0 & ~15) + 16 c, i.e. buffer bytes [16 c - mis, 16 c - mis + 16)
-                uint8_t *const dst0 = A.errlog + base;
-                const uint32_t mis = (uint32_t)(uintptr_t)dst0 & 15u;
+                // the block leaves: lane c the 16 bytes at errlog address (dst0 - mis) + 16 c = buf_lds[16 c .. 16 c + 15]
                 uint8_t *const dstA = dst0 - mis;
                 for (uint32_t c = lane; 16u * c < mis + total; c += 64) {
-                    const int32_t lo = (int32_t)(16u * c) - (int32_t)mis;                      // >= -15: inside the pad
-                    uint64_t v0, v1;
-                    __builtin_memcpy(&v0, buf + lo, 8); __builtin_memcpy(&v1, buf + lo + 8, 8);
-                    const uint32_t s0 = lo < 0 ? (uint32_t)(-lo) : 0u;                          // bytes of the chunk in front of the block
+                    const uint4 v = *reinterpret_cast<const uint4 *>(buf_lds + 16u * c);
+                    const uint32_t s0 = c ? 0u : mis;                                           // bytes of the chunk in front of the block
                     const uint32_t e0 = min(16u, mis + total - 16u * c);                        // ... and where the block ends inside it
-                    if (s0 == 0 && e0 == 16u) { struct __attribute__((packed)) V { uint64_t a, b; } v{v0, v1}; __builtin_memcpy(dstA + 16u * c, &v, 16); }
-                    else { shift_down_bytes(v0, v1, s0); store16(dstA + 16u * c + s0, e0 - s0, v0, v1); }
+                    if (s0 == 0 && e0 == 16u) *reinterpret_cast<uint4 *>(dstA + 16u * c) = v;
+                    else {
+                        uint64_t v0 = (uint64_t)v.x | (uint64_t)v.y << 32, v1 = (uint64_t)v.z | (uint64_t)v.w << 32;
+                        shift_down_bytes(v0, v1, s0); store16(dstA + 16u * c + s0, e0 - s0, v0, v1);
+                    }
                 }
                 wave_sync();
             } else if (active) {
@@ -3114,7 +3151,11 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     if (side_names) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
     HIPCHK(hipEventRecord(ctx->evt[7], st));
     if (prm->emit_errlog && write_rec) {
-        k_errlog<<<dim3((unsigned)n), dim3(64), 0, st>>>(A);
+        // the block buffer of the kernel: the small one (six wavefronts per SIMD instead of four) when 64 average rows of this batch fit it
+        const uint64_t rows = stats[3] ? stats[3] : 1;
+        const bool small_buf = !getenv("NS_ERRLOG_BUF_LARGE") && (info->errlog_bytes / rows + 5) * 64 <= NS_ERR_BUF_SMALL;
+        if (small_buf) k_errlog<NS_ERR_BUF_SMALL><<<dim3((unsigned)n), dim3(64), 0, st>>>(A);
+        else k_errlog<NS_ERR_BUF_LARGE><<<dim3((unsigned)n), dim3(64), 0, st>>>(A);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ctx->evt[8], st));

@@ -387,6 +387,14 @@ NS_DEV uint8_t *put_dec(uint8_t *p, uint32_t v) {
     for (uint32_t i = 0; i < n; ++i) { const uint32_t q = v / 10u; p[n - 1 - i] = (uint8_t)('0' + (v - 10u * q)); v = q; }
     return p + n;
 }
+// the same through any pointer type (k_errlog: volatile LDS bytes — every digit stays ONE byte store; a merged store at an odd LDS
+// address costs eight byte stores)
+template <class P>
+NS_DEV P put_dec_p(P p, uint32_t v) {
+    const uint32_t n = dec_digits(v);
+    for (uint32_t i = 0; i < n; ++i) { const uint32_t q = v / 10u; p[n - 1 - i] = (uint8_t)('0' + (v - 10u * q)); v = q; }
+    return p + n;
+}
 __device__ __forceinline__ uint32_t dec_digits(uint64_t v) {
     uint32_t n = 1;
     while (v >= 10) { v /= 10; ++n; }

@@ -351,6 +351,34 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// LDS pointers by type: volatile, so that the compiler cannot merge neighbouring narrow stores into a wide one at an address that is not
+// a multiple of its size, and in the LDS address space explicitly (volatile accesses are not inferred into it).  A ds_write_b16 / b32 /
+// b64 (or read) at such an address costs ~58 LDS cycles per CU against ~7 aligned; a byte store costs ~7 wherever it lands
+// (scripts/microbench/lds_align.hip, profiles/r05/microbench_lds_align.log).
+typedef __attribute__((address_space(3))) volatile uint8_t *LdsBytes;
+typedef __attribute__((address_space(3))) volatile uint32_t *LdsWords;
+// the first cn <= 16 bytes of (x0, x1, x2, x3) to d, any alignment, with aligned stores only: byte stores up to the next dword boundary,
+// whole dwords, byte stores for the rest
+__device__ __forceinline__ void lds_put_bytes(LdsBytes d, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t cn) {
+    const uint32_t head = min(cn, (0u - (uint32_t)(uintptr_t)d) & 3u);
+    if (head > 0) d[0] = (uint8_t)x0;
+    if (head > 1) d[1] = (uint8_t)(x0 >> 8);
+    if (head > 2) d[2] = (uint8_t)(x0 >> 16);
+    const uint32_t sh = 8u * head;                       // the value moved down by the bytes that are out
+    const uint32_t y0 = __builtin_amdgcn_alignbit(x1, x0, sh), y1 = __builtin_amdgcn_alignbit(x2, x1, sh), y2 = __builtin_amdgcn_alignbit(x3, x2, sh), y3 = x3 >> sh;
+    const uint32_t rem = cn - head;
+    const LdsWords w = (LdsWords)(d + head);
+    if (rem >= 4u) w[0] = y0;
+    if (rem >= 8u) w[1] = y1;
+    if (rem >= 12u) w[2] = y2;
+    if (rem >= 16u) w[3] = y3;
+    const uint32_t yt = rem >= 12u ? y3 : rem >= 8u ? y2 : rem >= 4u ? y1 : y0, tail = rem & 3u;
+    const LdsBytes e = d + head + (rem & ~3u);
+    if (tail > 0) e[0] = (uint8_t)yt;
+    if (tail > 1) e[1] = (uint8_t)(yt >> 8);
+    if (tail > 2) e[2] = (uint8_t)(yt >> 16);
+}
+
 // ---- dense pieces: lane per event -----------------------------------------------------------------------------
 // Unaligned reads (S:1482-1549) and the gaps of chimeric reads carry ~0.55 events per base: an event owns two output bytes on
 // average — its letters, then the reference bases copied behind them up to the next event.  One lane per event (item 0 = the stretch
@@ -396,7 +424,7 @@ __device__ inline void dense_piece(const DevModel &m, const DevRef &ref, DenseLd
             const uint32_t cn = act && c_lo < hi ? hi - c_lo : 0u;                    // copied bases behind them
             const uint32_t x0 = rp + (c_lo - os - pl);                                // output byte mm <- segment position rp + (mm - os - pl)
             // ---- straight-line path: the letters four at a time (byte permutes, as the tiled kernel), the copied bases from one
-            // 16-byte load with <= 4 stores into the tile.  Items cut by the tile border, stretches of > 16 bases, IUPAC codes under
+            // 16-byte load, stored with aligned LDS stores (lds_put_bytes).  Items cut by the tile border, stretches of > 16 bases, IUPAC codes under
             // the copy and the origin of a circular chromosome take the per-byte walk below.
             const bool fast_l = n_let && os >= M0 && (ty == NS_INS || (uint64_t)pos + n_let <= lin);
             bool fast_c = cn && cn <= 16u && (uint64_t)x0 + 16u <= lin;
@@ -446,17 +474,7 @@ __device__ inline void dense_piece(const DevModel &m, const DevRef &ref, DenseLd
                     S.out[cnt > 2 ? o + 2 : dump] = (uint8_t)(letters >> 16); S.out[cnt > 3 ? o + 3 : dump] = (uint8_t)(letters >> 24);
                 }
             }
-            if (fast_c) {
-                uint8_t *d = &S.out[c_lo - M0];
-                uint64_t w = (uint64_t)f.x | (uint64_t)f.y << 32;
-                if (cn & 16u) { const uint64_t w2 = (uint64_t)f.z | (uint64_t)f.w << 32; __builtin_memcpy(d, &w, 8); __builtin_memcpy(d + 8, &w2, 8); }
-                else {
-                    if (cn & 8u) { __builtin_memcpy(d, &w, 8); d += 8; w = (uint64_t)f.z | (uint64_t)f.w << 32; }
-                    if (cn & 4u) { const uint32_t v = (uint32_t)w; __builtin_memcpy(d, &v, 4); d += 4; w >>= 32; }
-                    if (cn & 2u) { const uint16_t v = (uint16_t)w; __builtin_memcpy(d, &v, 2); d += 2; w >>= 16; }
-                    if (cn & 1u) *d = (uint8_t)w;
-                }
-            }
+            if (fast_c) lds_put_bytes((LdsBytes)&S.out[c_lo - M0], f.x, f.y, f.z, f.w, cn);
             if (act && ((n_let && !fast_l) || (cn && !fast_c))) {
                 // ---- per-byte walk.  Letters (mutate_read, S:1965-1995): letter i = field / digit i & 15 of word i >> 4
                 if (!fast_l) {
@@ -664,7 +682,7 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
     // (round 4: caching the letter words of 256 events per Philox evaluation — lane l keeps block l, tiles fetch theirs by ds_bpermute or
     // from 1 KB of LDS — was SLOWER in every variant: record kernel 5.72 ms without, 6.40 / 5.93 / 6.06 with (registers at 7 / 6 waves per
     // SIMD, LDS): the spills and cross-lane reads cost more than the Philox they save.  The word is drawn per tile: event_word.)
-    auto cached_word = [&](uint32_t j0) -> uint32_t { const uint32_t j = j0 + lane; return event_word<MODE>(pc, key, a, j < pc.n_ev ? j : 0u); };
+    auto cached_word = [&](uint32_t j0) -> uint32_t { if (dbg & 64u) return 0u; const uint32_t j = j0 + lane; return event_word<MODE>(pc, key, a, j < pc.n_ev ? j : 0u); };
     w_pre = cached_word(0u);
     // The tile whose bytes are complete in T.out and wait for their final pass (step 4): it runs UNDER the loads of the next tile
     bool have_prev = false;

@@ -1098,10 +1098,10 @@ def main():
         if a.only_trx_sizes:
             # the sample-until-repeat rule of S:1080-1104 at worker sizes well away from the 12 000 of reference_transcriptome.json: the
             # reference's worker keeps a sample of num_simulate = (reads of the worker) points, the restatement one of unbounded size per
-            # block of 1 024 read indices.  Same committed inputs; 64 workers x 125 reads, 8 x 1 000 (aligned and --perfect) and 8 x 50 000.
+            # block of 1 024 read indices.  Same committed inputs; 768 workers x 125 reads, 96 x 1 000 (aligned and --perfect) and 8 x 50 000.
             build_trx_inputs()
             fx = {}
-            for tag, n, per, which, sb in (("w125", 8000, 125, ("aligned",), 100), ("w1000", 8000, 1000, ("aligned", "perfect"), 200),
+            for tag, n, per, which, sb in (("w125", 96000, 125, ("aligned",), 1000), ("w1000", 96000, 1000, ("aligned", "perfect"), 2000),
                                            ("w50000", 400000, 50000, ("aligned",), 300)):
                 runs = fixture_transcriptome_runs(prefix, workdir, n_reads=n, per_worker=per, which=which, seed_base=sb)
                 for name, r in runs.items():
