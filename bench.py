@@ -181,9 +181,18 @@ class Workload:
         self.eng = engine.Engine(local_rank)
         # the unaligned worker call of a step runs next to the aligned one on its own engine context (own HIP streams and buffers on the
         # same GPU, own host thread): the schedule of the CLI (nanosim_amd/simulator.py: _run_phases)
-        self.eng_un = None if (aligned_only or serial) else engine.Engine(local_rank)
-        if self.eng_un is not None:
+        # default: ns_generate_step — the library runs the unaligned call on the engine's step companion (which shares reference and model)
+        # from its own worker thread; --python-threads: the round-2..4 form, a second Engine with its own copy of everything and a
+        # Python thread per step (kept for A/B runs)
+        self.python_threads = bool(getattr(a, "python_threads", False))
+        if aligned_only or serial:
+            self.eng_un = None
+        elif self.python_threads:
+            self.eng_un = engine.Engine(local_rank)
             self.eng_un.set_background(True)     # its kernels share the GPU with the aligned call's: few issue slots matter more than a short latency
+        else:
+            self.eng_un = self.eng.step_engine()
+        self.own_engs = [e for e in (self.eng, self.eng_un if self.python_threads else None) if e is not None]      # what this object sets up
         self.engs = [e for e in (self.eng, self.eng_un) if e is not None]
         self.broadcast_ms = None
         dev_ptr, self._keep = None, None
@@ -213,16 +222,16 @@ class Workload:
             abun = {sp: float(e) for sp, _, e, _ in synth.ZYMO10}                  # the "even" column of the abundance table
             infl = {sp: MG.inflate_abun(abun, sp, self.mdl.abun_inflation) for sp in abun} if self.chimeric else None
             self.eng.set_metagenome(self.mref, abun, infl, dev_ptr=dev_ptr)
-            if self.eng_un is not None:
+            if self.eng_un is not None and self.python_threads:
                 self.eng_un.set_metagenome(self.mref, dev_ptr=dev_ptr)
         else:
-            for e in self.engs:
+            for e in self.own_engs:
                 if dev_ptr is not None:
                     e.set_reference_device(dev_ptr, ref_meta)
                 else:
                     e.set_reference(ref)
         self._keep = None                          # (the engines hold their own normalised copies)
-        for e in self.engs:
+        for e in self.own_engs:
             e.load_model(self.mdl)
         self.max_len = min(int(np.diff(chrom_off.astype(np.int64)).max()), 1 << 30)
         self.unaligned_delay_s = max(0.0, getattr(a, "unaligned_delay_ms", 0.0)) * 1e-3
@@ -245,17 +254,19 @@ class Workload:
         base = (i * self.world + self.rank) * n
         out = [None, None]
 
+        p_al = engine.make_params(seed=SEED, first_read=base, n_reads=n_al, fastq=self.fastq, max_len=self.max_len, emit_errlog=errlog,
+                                  kmer_bias=self.kmer, emit_records=records, chimeric=self.chimeric, meta=self.meta)
+        p_un = engine.make_params(seed=SEED, first_read=base + n_al, n_reads=n_un, kind=engine.NS_KIND_UNALIGNED, fastq=self.fastq,
+                                  max_len=self.max_len, emit_records=records, meta=self.meta)
+
         def aligned():
-            b = self.eng.generate(engine.make_params(seed=SEED, first_read=base, n_reads=n_al, fastq=self.fastq, max_len=self.max_len,
-                                                     emit_errlog=errlog, kmer_bias=self.kmer, emit_records=records, chimeric=self.chimeric,
-                                                     meta=self.meta))
+            b = self.eng.generate(p_al)
             out[0] = b.info
             if after_aligned:
                 after_aligned(b)
 
         def unaligned(e):
-            b = e.generate(engine.make_params(seed=SEED, first_read=base + n_al, n_reads=n_un, kind=engine.NS_KIND_UNALIGNED,
-                                              fastq=self.fastq, max_len=self.max_len, emit_records=records, meta=self.meta))
+            b = e.generate(p_un)
             out[1] = b.info
             if after_unaligned:
                 after_unaligned(b)
@@ -264,6 +275,14 @@ class Workload:
             return out[:1]
         if self.eng_un is None or serial:                      # one engine, one call after the other
             aligned(); unaligned(self.eng)
+            return out
+        if not self.python_threads:                            # ONE library call per step (ns_generate_step)
+            b_al, b_un = self.eng.generate_step(p_al, p_un)
+            out[0], out[1] = b_al.info, b_un.info
+            if after_aligned:
+                after_aligned(b_al)
+            if after_unaligned:
+                after_unaligned(b_un)
             return out
         def late_unaligned():
             if self.unaligned_delay_s > 0:
@@ -274,7 +293,7 @@ class Workload:
         return out
 
     def close(self):
-        for e in self.engs:
+        for e in self.own_engs:
             e.close()
 
 
@@ -326,7 +345,8 @@ def summarise(w, a, infos, dt, n, n_al, n_un, steps, warmup, world, tot_bases, e
                                   "formatted by k_errlog only when asked for (--errlog; the CLI always asks): it is a file-format stage "
                                   "behind the path the metric names (SURVEY section 8 f-1); the e2e legs below time it",
                    "seed": SEED, "parallelism": "read-index sharding x%d, 1 RCCL broadcast of the reference" % world, "engines_per_gpu": len(w.engs),
-                   "engines_note": "aligned and unaligned worker call of a step run side by side on two engine contexts of the GPU, the unaligned one as a background context (ns_set_background) - the schedule of the CLI (nanosim_amd/simulator.py: _run_phases); the `serial` object / --serial: one after the other on one context (the CLI with NS_SERIAL=1)"},
+                   "engines_note": "one ns_generate_step call per step (include/nanosim_amd.h, ABI 6): the aligned worker call on the engine context, the unaligned one on its step companion (same reference and model, own streams and batch buffers, the library's worker thread) side by side on the GPU - the schedule of the CLI (nanosim_amd/simulator.py: StepPair); --python-threads: two independent Engine objects and a Python thread per step (rounds 2-4); the `serial` object / --serial: one after the other on one context (the CLI with NS_SERIAL=1)",
+                   "step_call": "python threads" if w.python_threads else "ns_generate_step"},
         "device_ms_per_step": device_ms,
         "aligned_batch": {"reads": n_al, "device_ms": float(np.mean([x.ms_total for x in al])),
                           "reads_per_s_device": n_al / (float(np.mean([x.ms_total for x in al])) * 1e-3), "kernel_ms": kms},
@@ -575,6 +595,8 @@ def main():
     ap.add_argument("--no-configs2", action="store_true", help="skip the configs[2] object (chr1-size reference, FASTQ, -hp -k 5)")
     ap.add_argument("--configs2-steps", type=int, default=3)
     ap.add_argument("--no-extras", action="store_true", help="skip the `serial` and `errlog_on` objects")
+    ap.add_argument("--python-threads", action="store_true", help="the round-2..4 schedule: a second Engine with its own copies and a Python thread per "
+                                                                  "step for the unaligned worker call, instead of ns_generate_step (A/B runs)")
     ap.add_argument("--no-solo-reference", action="store_true", help="N > 1: skip rank 0's single-rank repeat of the timed steps (multi_gpu.single_rank_reference)")
     ap.add_argument("--extras-steps", type=int, default=3)
     a = ap.parse_args()

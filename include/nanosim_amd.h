@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define NS_ABI_VERSION 5u
+#define NS_ABI_VERSION 6u
 
 /* error codes */
 #define NS_OK 0
@@ -287,6 +287,20 @@ int ns_load_model(ns_ctx *ctx, const ns_model_tables *tables);
  * (src/simulator.py:1266-1454, 1482-1549).  Results stay in HBM until the next ns_generate; the record and error-profile images
  * live in one of TWO result slots, so that a batch queued with ns_sink_write leaves the device while the next one is generated. */
 int ns_generate(ns_ctx *ctx, const ns_params *params, ns_batch_info *info);
+
+/* One STEP of simulation() (src/simulator.py:1571-1672): the aligned worker call (S:1601-1619 -> simulation_aligned_*) and the unaligned
+ * one (S:1657-1660 -> simulation_unaligned) of the same share of the run, side by side on this GPU.  The reference joins the aligned
+ * workers before it starts the unaligned ones (S:1621-1622); that order constrains the FILES only — the two calls write different files
+ * and a read is a function of (seed, read index) — so the library runs them next to each other: the aligned call on `ctx`, the unaligned
+ * one on the context's STEP COMPANION (own streams and batch buffers on the same device; it shares the reference, the model and the
+ * mode tables of `ctx` — nothing is uploaded twice) from a worker thread the library keeps, its thread-per-read chain filling the SIMD
+ * slots the aligned call's kernels leave (ns_set_background).  info[0] = the aligned batch, info[1] = the unaligned one; either params
+ * pointer may be NULL (that call is skipped and its info zeroed).  The bytes of both batches are those of two ns_generate calls.
+ * The unaligned batch's buffers belong to the companion: ns_step_context returns it (created on first use, owned and destroyed by
+ * `ctx`; never pass it to ns_destroy) for ns_copy_out / ns_device_ptr / ns_record_offsets / ns_sink_* / ns_io_counters.
+ * Added with ABI 6; ns_generate is unchanged. */
+int ns_generate_step(ns_ctx *ctx, const ns_params *aligned, const ns_params *unaligned, ns_batch_info info[2]);
+int ns_step_context(ns_ctx *ctx, ns_ctx **companion);
 
 /* copy a result buffer of the last batch to host memory; nbytes must not exceed the buffer size
  * (record_bytes, n_reads*sizeof(ns_read), n_pieces*sizeof(ns_piece), n_events*sizeof(ns_event), errlog_bytes) */

@@ -20,7 +20,10 @@
 #include <string.h>
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -1631,12 +1634,20 @@ struct CsAccDev {
     __device__ __forceinline__ void first(uint32_t i) { atomicAdd(&l[5u * 1001u + 18u + i], 1u); }
     __device__ __forceinline__ void skip() { atomicAdd(&H->misc[2], 1ull); }
 };
-__global__ void __launch_bounds__(256) k_cs_hist(const uint8_t *__restrict__ cs, const uint64_t *__restrict__ off, uint32_t n_aln, CsHistDev H) {
+__global__ void __launch_bounds__(256) k_cs_len(const uint64_t *__restrict__ off, uint32_t n_aln, uint32_t *__restrict__ key, uint32_t *__restrict__ idx) {
+    const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_aln) return;
+    const uint64_t n = off[a + 1] - off[a];
+    key[a] = n > 0xffffffffull ? 0xffffffffu : (uint32_t)n; idx[a] = a;
+}
+__global__ void __launch_bounds__(256) k_cs_hist(const uint8_t *__restrict__ cs, const uint64_t *__restrict__ off, uint32_t n_aln, CsHistDev H,
+                                                 const uint32_t *__restrict__ order) {
     __shared__ uint32_t cnt[NS_CSH_LDS_WORDS];
     for (uint32_t i = threadIdx.x; i < NS_CSH_LDS_WORDS; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
-    const uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (a < n_aln) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < n_aln) {
+        const uint64_t a = order ? order[tid] : tid;          // visited by descending length: the 64 walks of a wavefront have similar trip counts
         const uint8_t *s = cs + off[a];
         const uint64_t n = off[a + 1] - off[a];
         // prev_match is only read before this alignment assigns it when its first op is an error: then it is what the alignments in
@@ -1739,8 +1750,26 @@ struct ns_ctx {
     ns_batch_info last{};
     hipEvent_t evt[16]{};
     bool evt_ok = false;
+    // ns_generate_step: the companion context the unaligned worker call of a step runs on (it borrows this context's reference, model and
+    // mode tables) and the worker thread that makes that call
+    ns_ctx *companion = nullptr;
+    bool borrowed = false;            // this context IS a companion: the tables it points at belong to its owner
+    struct StepWorker;
+    StepWorker *step = nullptr;
+};
+struct ns_ctx::StepWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    const ns_params *prm = nullptr;   // the posted call (nullptr: none)
+    ns_batch_info *info = nullptr;
+    int rc = 0;
+    bool done = false, quit = false;
 };
 
+static int fail(ns_ctx *c, int code, const std::string &msg);
+// the tables of a step companion (ns_generate_step) are its owner's
+#define NS_NOT_ON_COMPANION(c) do { if ((c) && (c)->borrowed) return fail((c), NS_ESTATE, "this is a step companion: set reference, model and mode tables on the context that owns it"); } while (0)
 static int fail(ns_ctx *c, int code, const std::string &msg) {
     if (c) c->err = msg;
     return code;
@@ -1871,6 +1900,17 @@ static void free_pool(std::vector<void *> &pool) {
 
 void ns_destroy(ns_ctx *ctx) {
     if (!ctx) return;
+    if (ctx->step) {                                 // the step worker first: it may be inside a call on the companion
+        { std::lock_guard<std::mutex> lk(ctx->step->mu); ctx->step->quit = true; }
+        ctx->step->cv.notify_all();
+        if (ctx->step->th.joinable()) ctx->step->th.join();
+        delete ctx->step; ctx->step = nullptr;
+    }
+    if (ctx->companion) { ns_destroy(ctx->companion); ctx->companion = nullptr; }
+    if (ctx->borrowed) {                             // a companion frees its own batch buffers only
+        ctx->model_allocs.clear(); ctx->ref_allocs.clear(); ctx->ir_allocs.clear(); ctx->ref_bases_owned = nullptr;
+        ctx->species_chrom_off = DevBuf{}; ctx->trx_chrom = DevBuf{}; ctx->trx_cum = DevBuf{}; ctx->trx_polya = DevBuf{};
+    }
     hipError_t e = hipSetDevice(ctx->device); (void)e;
     if (ctx->io) { ctx->io->wait_all(); ctx->io->shutdown(); delete ctx->io; ctx->io = nullptr; }
     for (ns_sink *s : ctx->sinks) delete s;
@@ -1958,6 +1998,7 @@ static int install_reference(ns_ctx *ctx, const void *src, bool src_on_device, u
 
 int ns_set_reference(ns_ctx *ctx, const uint8_t *bases, uint64_t nbases, const uint64_t *chrom_off, uint32_t nchrom,
                      const uint8_t *circular, const char *names, uint64_t names_len) {
+    NS_NOT_ON_COMPANION(ctx);
     if (!ctx) return NS_EINVAL;
     if (!bases || !nbases) return fail(ctx, NS_EINVAL, "empty reference");
     return install_reference(ctx, bases, false, nbases, chrom_off, nchrom, circular, names, names_len);
@@ -1965,12 +2006,14 @@ int ns_set_reference(ns_ctx *ctx, const uint8_t *bases, uint64_t nbases, const u
 
 int ns_set_reference_device(ns_ctx *ctx, const void *bases_dev, uint64_t nbases, const uint64_t *chrom_off,
                             uint32_t nchrom, const uint8_t *circular, const char *names, uint64_t names_len) {
+    NS_NOT_ON_COMPANION(ctx);
     if (!ctx) return NS_EINVAL;
     if (!bases_dev || !nbases) return fail(ctx, NS_EINVAL, "empty reference");
     return install_reference(ctx, bases_dev, true, nbases, chrom_off, nchrom, circular, names, names_len);
 }
 
 int ns_load_model(ns_ctx *ctx, const ns_model_tables *t) {
+    NS_NOT_ON_COMPANION(ctx);
     if (!ctx) return NS_EINVAL;
     if (!t || t->abi_version != NS_ABI_VERSION) return fail(ctx, NS_EINVAL, "ns_model_tables: wrong abi_version");
     HIPCHK(hipSetDevice(ctx->device));
@@ -2242,6 +2285,7 @@ static int hp_stage1(ns_ctx *ctx, const ns_params *prm, GenArgs &A, size_t n, ui
 
 int ns_set_transcriptome(ns_ctx *ctx, uint32_t n_expr, const uint32_t *expr_chrom, const double *expr_cum, const uint8_t *polya,
                          double polya_scale) {
+    NS_NOT_ON_COMPANION(ctx);
     if (!ctx) return NS_EINVAL;
     if (!ctx->has_ref) return fail(ctx, NS_ESTATE, "ns_set_transcriptome before ns_set_reference");
     if (!n_expr || !expr_chrom || !expr_cum) return fail(ctx, NS_EINVAL, "empty expression table");
@@ -2267,6 +2311,7 @@ int ns_set_transcriptome(ns_ctx *ctx, uint32_t n_expr, const uint32_t *expr_chro
 }
 
 int ns_set_intron_retention(ns_ctx *ctx, const ns_ir_tables *t) {
+    NS_NOT_ON_COMPANION(ctx);
     if (!ctx) return NS_EINVAL;
     HIPCHK(hipSetDevice(ctx->device));
     ctx->has_ir = false;
@@ -2311,6 +2356,7 @@ int ns_set_intron_retention(ns_ctx *ctx, const ns_ir_tables *t) {
 }
 
 int ns_set_species(ns_ctx *ctx, uint32_t nspecies, const uint32_t *species_chrom_off) {
+    NS_NOT_ON_COMPANION(ctx);
     if (!ctx) return NS_EINVAL;
     if (!ctx->has_ref) return fail(ctx, NS_ESTATE, "ns_set_species before ns_set_reference");
     if (!nspecies || nspecies > 65535u || !species_chrom_off) return fail(ctx, NS_EINVAL, "bad species table");
@@ -2327,6 +2373,7 @@ int ns_set_species(ns_ctx *ctx, uint32_t nspecies, const uint32_t *species_chrom
 }
 
 int ns_set_abundance(ns_ctx *ctx, const double *abun, const double *abun_inflated) {
+    NS_NOT_ON_COMPANION(ctx);
     if (!ctx) return NS_EINVAL;
     if (!ctx->nspecies) return fail(ctx, NS_ESTATE, "ns_set_abundance before ns_set_species");
     if (!abun) return fail(ctx, NS_EINVAL, "null abundance table");
@@ -3178,6 +3225,78 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     return NS_OK;
 }
 
+// ---- ns_generate_step: the aligned and the unaligned worker call of one step side by side (include/nanosim_amd.h) ----
+// what the companion borrows from its owner: everything ns_generate reads that ns_set_* / ns_load_model fill (device pointers by value)
+static void lend_tables(const ns_ctx *ctx, ns_ctx *c) {
+    c->m = ctx->m; c->ref = ctx->ref; c->has_model = ctx->has_model; c->has_ref = ctx->has_ref;
+    c->cap_rate = ctx->cap_rate; c->ref_nbases = ctx->ref_nbases;
+    c->lds_tables = ctx->lds_tables; c->lds_bytes = ctx->lds_bytes; c->coop_ok = ctx->coop_ok;
+    c->nspecies = ctx->nspecies; c->species_chrom_off = ctx->species_chrom_off;      // (DevBuf by value: not freed by the companion)
+    c->tx = ctx->tx; c->has_trx = ctx->has_trx;
+    c->has_abun = false; c->has_inflated = false; c->has_ir = false;                   // (aligned workers only: S:814-1040, 1156-1192)
+}
+static void step_worker_main(ns_ctx *owner) {
+    ns_ctx::StepWorker *w = owner->step;
+    std::unique_lock<std::mutex> lk(w->mu);
+    for (;;) {
+        w->cv.wait(lk, [w] { return w->quit || (w->prm && !w->done); });
+        if (w->quit) return;
+        const ns_params *prm = w->prm; ns_batch_info *info = w->info;
+        lk.unlock();
+        const int rc = ns_generate(owner->companion, prm, info);
+        lk.lock();
+        w->rc = rc; w->done = true;
+        w->cv.notify_all();
+    }
+}
+int ns_step_context(ns_ctx *ctx, ns_ctx **out) {
+    if (!ctx) return NS_EINVAL;
+    if (!out) return fail(ctx, NS_EINVAL, "null output pointer");
+    *out = nullptr;
+    if (ctx->borrowed) return fail(ctx, NS_EINVAL, "a step companion has no companion of its own");
+    if (!ctx->companion) {
+        ns_ctx *c = nullptr;
+        const int rc = ns_create(ctx->device, &c);
+        if (rc) return fail(ctx, rc, "ns_generate_step: the companion context could not be created");
+        c->borrowed = true;
+        ns_set_background(c, 1);
+        ctx->companion = c;
+    }
+    lend_tables(ctx, ctx->companion);
+    *out = ctx->companion;
+    return NS_OK;
+}
+int ns_generate_step(ns_ctx *ctx, const ns_params *aligned, const ns_params *unaligned, ns_batch_info info[2]) {
+    if (!ctx) return NS_EINVAL;
+    if (!info) return fail(ctx, NS_EINVAL, "null info");
+    if (ctx->borrowed) return fail(ctx, NS_EINVAL, "ns_generate_step on a step companion");
+    if (aligned && aligned->kind == NS_KIND_UNALIGNED) return fail(ctx, NS_EINVAL, "ns_generate_step: the first call is the aligned (or perfect) worker call");
+    if (unaligned && unaligned->kind != NS_KIND_UNALIGNED) return fail(ctx, NS_EINVAL, "ns_generate_step: the second call is the unaligned worker call");
+    memset(info, 0, 2 * sizeof *info);
+    if (!unaligned) return aligned ? ns_generate(ctx, aligned, &info[0]) : NS_OK;
+    ns_ctx *c = nullptr;
+    int rc = ns_step_context(ctx, &c);                        // (creates the companion on first use; lends it the tables as they are now)
+    if (rc) return rc;
+    if (!aligned) {
+        rc = ns_generate(c, unaligned, &info[1]);
+        if (rc) ctx->err = "unaligned worker call: " + c->err;
+        return rc;
+    }
+    if (!ctx->step) {
+        ctx->step = new ns_ctx::StepWorker();
+        ctx->step->th = std::thread(step_worker_main, ctx);
+    }
+    ns_ctx::StepWorker *w = ctx->step;
+    { std::lock_guard<std::mutex> lk(w->mu); w->prm = unaligned; w->info = &info[1]; w->done = false; w->rc = 0; }
+    w->cv.notify_all();
+    const int rc_al = ns_generate(ctx, aligned, &info[0]);
+    int rc_un;
+    { std::unique_lock<std::mutex> lk(w->mu); w->cv.wait(lk, [w] { return w->done; }); rc_un = w->rc; w->prm = nullptr; w->info = nullptr; }
+    if (rc_al) return rc_al;
+    if (rc_un) { ctx->err = "unaligned worker call: " + c->err; return rc_un; }
+    return NS_OK;
+}
+
 static int result_buf(ns_ctx *ctx, int which, const void **p, uint64_t *size) {
     const ns_batch_info &b = ctx->last;
     switch (which) {
@@ -3349,8 +3468,8 @@ int ns_cs_histograms(ns_ctx *ctx, const uint8_t *cs, uint64_t nbytes, const uint
     h->max_match = h->n_match2d_overflow = h->n_skip = 0; h->ms_kernel = 0;
     if (!n_aln) { if (m2_host) memset(m2_host, 0, (size_t)cap * cap * 8); return NS_OK; }
     const size_t n_small = 5 * 1001 + 24 + 8;
-    void *d_cs = nullptr, *d_off = nullptr, *d_small = nullptr, *d_m2 = nullptr;
-    auto release = [&]() { for (void *p : {d_cs, d_off, d_small, d_m2}) if (p) { hipError_t e = hipFree(p); (void)e; } };
+    void *d_cs = nullptr, *d_off = nullptr, *d_small = nullptr, *d_m2 = nullptr, *d_key = nullptr, *d_tmp = nullptr;
+    auto release = [&]() { for (void *p : {d_cs, d_off, d_small, d_m2, d_key, d_tmp}) if (p) { hipError_t e = hipFree(p); (void)e; } };
     hipError_t e = hipMalloc(&d_cs, (size_t)nbytes + 16);
     if (e == hipSuccess) e = hipMalloc(&d_off, ((size_t)n_aln + 1) * 8);
     if (e == hipSuccess) e = hipMalloc(&d_small, n_small * 8);
@@ -3362,11 +3481,27 @@ int ns_cs_histograms(ns_ctx *ctx, const uint8_t *cs, uint64_t nbytes, const uint
     if (e == hipSuccess) e = hipMemsetAsync(d_small, 0, n_small * 8, st);
     if (e == hipSuccess && d_m2) e = hipMemsetAsync(d_m2, 0, (size_t)cap * cap * 8, st);
     if (e == hipSuccess) e = hipEventRecord(ctx->evt[14], st);
+    // Alignments of 1 kb .. 100 kb on neighbouring lanes diverge like the thread-per-read chain did before its length sort: the walks are
+    // visited by descending length of their cs strings (the counts are sums: any order gives the same tables).  NS_CS_NO_SORT=1: file order.
+    uint32_t *d_order = nullptr;
+    if (e == hipSuccess && n_aln > 64 && !getenv("NS_CS_NO_SORT")) {
+        size_t tmp = 0;
+        e = hipMalloc(&d_key, (size_t)n_aln * 16);                 // key, index, sorted key, sorted index
+        if (e == hipSuccess) {
+            uint32_t *key = (uint32_t *)d_key, *idx = key + n_aln, *key2 = idx + n_aln, *idx2 = key2 + n_aln;
+            k_cs_len<<<dim3((n_aln + 255u) / 256u), dim3(256), 0, st>>>((const uint64_t *)d_off, n_aln, key, idx);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp, key, key2, idx, idx2, (int)n_aln, 0, 32, st);
+            if (e == hipSuccess) e = hipMalloc(&d_tmp, tmp + 16);
+            if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairsDescending(d_tmp, tmp, key, key2, idx, idx2, (int)n_aln, 0, 32, st);
+            d_order = idx2;
+        }
+    }
     if (e == hipSuccess) {
         CsHistDev H;
         H.dic = (unsigned long long *)d_small; H.err = H.dic + 5 * 1001; H.misc = H.err + 24;
         H.m2 = (unsigned long long *)d_m2; H.cap2 = cap;
-        k_cs_hist<<<dim3((n_aln + 255u) / 256u), dim3(256), 0, st>>>((const uint8_t *)d_cs, (const uint64_t *)d_off, n_aln, H);
+        k_cs_hist<<<dim3((n_aln + 255u) / 256u), dim3(256), 0, st>>>((const uint8_t *)d_cs, (const uint64_t *)d_off, n_aln, H, d_order);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipEventRecord(ctx->evt[15], st);

@@ -24,7 +24,7 @@ EXPORTS = ("ns_abi_version", "ns_create", "ns_destroy", "ns_last_error", "ns_set
            "ns_set_species", "ns_set_abundance", "ns_species_bases", "ns_host_alloc", "ns_host_free",
            "ns_set_transcriptome", "ns_set_intron_retention", "ns_set_background",
            "ns_sink_open", "ns_sink_put", "ns_sink_write", "ns_sink_write_range", "ns_record_offsets", "ns_sink_drain",
-           "ns_sink_close", "ns_io_counters", "ns_cs_histograms")
+           "ns_sink_close", "ns_io_counters", "ns_cs_histograms", "ns_generate_step", "ns_step_context")
 
 
 class NsIoStats(C.Structure):
@@ -101,6 +101,10 @@ def load_library(path: str = LIB_PATH):
     L.ns_io_counters.argtypes = [C.c_void_p, C.POINTER(NsIoStats), C.c_int]
     L.ns_cs_histograms.restype = C.c_int
     L.ns_cs_histograms.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.ns_generate_step.restype = C.c_int
+    L.ns_generate_step.argtypes = [C.c_void_p, C.POINTER(NsParams), C.POINTER(NsParams), C.POINTER(NsBatchInfo)]
+    L.ns_step_context.restype = C.c_int
+    L.ns_step_context.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     _lib = L
     return L
 
@@ -207,6 +211,31 @@ class Engine:
         self._keep = []
         self._pinned = []
 
+    @classmethod
+    def _borrowed(cls, owner: "Engine", ctx: C.c_void_p) -> "Engine":
+        """an Engine over a context the library owns (the step companion of `owner`): every result call works on it, close() leaves it alone"""
+        e = cls.__new__(cls)
+        e.L, e.ctx, e._keep, e._pinned, e._owner = owner.L, ctx, [], [], owner
+        return e
+
+    def step_engine(self) -> "Engine":
+        """The context the UNALIGNED worker call of generate_step runs on (ns_step_context): it shares this engine's reference, model and
+        mode tables; its batch buffers, sinks and I/O counters are its own.  Owned by this engine (closed with it)."""
+        if getattr(self, "_step_engine", None) is None:
+            c = C.c_void_p()
+            self._check(self.L.ns_step_context(self.ctx, C.byref(c)))
+            self._step_engine = Engine._borrowed(self, c)
+        return self._step_engine
+
+    def generate_step(self, aligned: NsParams | None, unaligned: NsParams | None):
+        """One step of simulation() (S:1571-1672): the aligned and the unaligned worker call side by side on this GPU (ns_generate_step).
+        Returns (aligned Batch or None, unaligned Batch or None); the unaligned batch lives on step_engine()."""
+        info = (NsBatchInfo * 2)()
+        un_eng = self.step_engine() if unaligned is not None else None
+        self._check(self.L.ns_generate_step(self.ctx, C.byref(aligned) if aligned is not None else None,
+                                            C.byref(unaligned) if unaligned is not None else None, info))
+        return (Batch(self, info[0]) if aligned is not None else None, Batch(un_eng, info[1]) if unaligned is not None else None)
+
     def set_background(self, on: bool = True):
         """this context's worker calls run next to another context's on the same GPU (ns_set_background)"""
         self._check(self.L.ns_set_background(self.ctx, 1 if on else 0))
@@ -216,6 +245,13 @@ class Engine:
             for p in self._pinned:
                 self.L.ns_host_free(self.ctx, p)
             self._pinned = []
+            if getattr(self, "_owner", None) is not None:      # a step companion: its owner destroys it
+                self.ctx = C.c_void_p()
+                return
+            se = getattr(self, "_step_engine", None)
+            if se is not None:
+                se.close()
+                self._step_engine = None
             self.L.ns_destroy(self.ctx)
             self.ctx = C.c_void_p()
 

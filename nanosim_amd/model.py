@@ -14,7 +14,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-NS_ABI_VERSION = 5
+NS_ABI_VERSION = 6
 NS_KDE_ALIGNED, NS_KDE_HT, NS_KDE_RATIO, NS_KDE_UNALIGNED, NS_KDE_GAP, NS_KDE_COUNT = 0, 1, 2, 3, 4, 5
 NS_Q_NAMES = ("match", "mis", "ins", "ht", "unmapped")
 NS_QUAL_LEVELS = 128

@@ -35,6 +35,12 @@ def log(msg):
     sys.stdout.flush()
 
 
+NO_MERGE_HELP = ("Not in the reference: with -t K > 1 (or several ranks) keep the sub-files the workers wrote side by side and list them in "
+                 "<file>.subfiles (cat $(cat <file>.subfiles) = <file>) instead of concatenating them into one file as the reference does "
+                 "(S:1626-1639).  Writes into ONE inode serialise in the kernel (5.7 GB/s on the measured box): the merge, not the GPU, sets "
+                 "the wall clock of a large run.  NS_KEEP_SUBFILES=1 does the same")
+
+
 def build_parser():
     parser = argparse.ArgumentParser(
         description=dedent('''
@@ -69,6 +75,7 @@ def build_parser():
     g.add_argument('--fastq', action='store_true', default=False, help='Output fastq files instead of fasta files')
     g.add_argument('--chimeric', action='store_true', default=False, help='Simulate chimeric reads')
     g.add_argument('-t', '--num_threads', type=int, default=1, help='Number of threads for simulation (Default = 1)')
+    g.add_argument('--no-merge', dest='no_merge', action='store_true', default=False, help=NO_MERGE_HELP)
 
     t = sub.add_parser('transcriptome', help="Run the simulator on transcriptome mode")
     t.add_argument('-rt', '--ref_t', required=True)
@@ -90,6 +97,7 @@ def build_parser():
     t.add_argument('--polya', default=None)
     t.add_argument('--fastq', action='store_true', default=False)
     t.add_argument('-t', '--num_threads', type=int, default=1)
+    t.add_argument('--no-merge', dest='no_merge', action='store_true', default=False, help=NO_MERGE_HELP)
     t.add_argument('--uracil', action='store_true', default=False)
 
     mg = sub.add_parser('metagenome', help="Run the simulator on metagenome mode")
@@ -111,6 +119,7 @@ def build_parser():
     mg.add_argument('--fastq', action='store_true', default=False)
     mg.add_argument('--chimeric', action='store_true', default=False)
     mg.add_argument('-t', '--num_threads', type=int, default=1)
+    mg.add_argument('--no-merge', dest='no_merge', action='store_true', default=False, help=NO_MERGE_HELP)
     return parser, g, mg, t
 
 
@@ -176,9 +185,13 @@ def _serial_schedule() -> bool:
     return os.environ.get("NS_SERIAL", "0") != "0"
 
 
-def _background_engine(device, setup):
-    """The second engine context of this GPU: the unaligned worker calls run on it NEXT TO the aligned ones (ns_set_background: its
-    kernels are chosen for few issue slots, not for a short latency).  `setup(engine)` installs reference, mode tables and model."""
+def _background_engine(device, setup, owner=None):
+    """Where the unaligned worker calls of this GPU run, NEXT TO the aligned ones: by default the step companion of `owner`
+    (Engine.step_engine: it shares the owner's reference, model and mode tables, nothing is uploaded twice; the library runs it from
+    its own worker thread, ns_generate_step); NS_TWO_ENGINES=1: a second engine context of its own (the schedule of rounds 2-4: `setup`
+    installs reference, mode tables and model on it).  Returns (engine of the unaligned calls, owner of a StepPair or None)."""
+    if owner is not None and os.environ.get("NS_TWO_ENGINES", "0") == "0":
+        return owner.step_engine(), owner
     eng = E.Engine(device)
     try:
         eng.set_background(True)
@@ -186,20 +199,79 @@ def _background_engine(device, setup):
     except BaseException:
         eng.close()
         raise
-    return eng
+    return eng, None
 
 
-def _run_phases(aligned, unaligned, rank, n_done):
+class StepPair:
+    """Pairs the worker calls of the two phases of a run into steps: when the aligned phase asks for its next batch and the unaligned
+    phase is waiting with one, both go into ONE ns_generate_step call (include/nanosim_amd.h) — the aligned call on the engine, the
+    unaligned one on its step companion, side by side on the GPU; a phase whose partner has nothing to run (it is done, or busy
+    queueing its files) calls on its own.  The unaligned phase posts its next request only when it has queued the last batch for its
+    files, so the companion's buffers are never written under it."""
+
+    def __init__(self, eng):
+        import threading
+        self.eng, self.un_eng = eng, eng.step_engine()
+        self.cv = threading.Condition()
+        self.pending = None          # parameters of an unaligned call waiting for its step
+        self.result = None           # ("ok", Batch) | ("alone", None) for the waiting unaligned call
+        self.al_done = False
+        self.steps = self.alone = 0
+
+    def aligned(self, p):
+        with self.cv:
+            pu, self.pending = self.pending, None
+        if pu is None:
+            self.alone += 1
+            return self.eng.generate(p)
+        try:
+            b_al, b_un = self.eng.generate_step(p, pu)
+        except BaseException:
+            with self.cv:            # the unaligned call repeats on its own (and reports its own error, if it was its error)
+                self.result = ("alone", None)
+                self.cv.notify_all()
+            raise
+        with self.cv:
+            self.result = ("ok", b_un)
+            self.cv.notify_all()
+        self.steps += 1
+        return b_al
+
+    def unaligned(self, p):
+        with self.cv:
+            if not self.al_done:
+                self.pending = p
+                while self.result is None and not (self.al_done and self.pending is not None):
+                    self.cv.wait()
+                if self.result is not None:
+                    kind, b = self.result
+                    self.result = None
+                    if kind == "ok":
+                        return b
+                else:
+                    self.pending = None          # the aligned phase ended without taking it
+        return self.un_eng.generate(p)
+
+    def finish_aligned(self):
+        with self.cv:
+            self.al_done = True
+            self.cv.notify_all()
+
+
+def _run_phases(aligned, unaligned, rank, n_done, step_owner=None):
     """simulation() (S:1588-1672) starts the unaligned workers once the aligned ones are joined.  That order constrains the FILES only —
-    the two phases write different files and a read is a function of (seed, read index) — so here `unaligned` (a closure over the
-    background engine context) runs in a second host thread NEXT TO `aligned`: one GPU, two contexts, the schedule bench.py times.
+    the two phases write different files and a read is a function of (seed, read index) — so here `unaligned` runs in a second host
+    thread NEXT TO `aligned`: one GPU, the schedule bench.py times.  step_owner (an Engine): the two phases take their batches through a
+    StepPair of it — `aligned(gen)` / `unaligned(gen)` are then called with the pair's generate functions (one ns_generate_step per step);
+    None: they are called without arguments (closures over two engine contexts of their own).
     unaligned is None: nothing to run (--perfect).  The log keeps the reference's order."""
     import threading
     err = []
+    pair = StepPair(step_owner) if (step_owner is not None and unaligned is not None) else None
 
     def bg():
         try:
-            unaligned()
+            unaligned(pair.unaligned) if pair else unaligned()
         except BaseException as ex:                      # (SystemExit of a failed merge included: threading would swallow it)
             err.append(ex)
     t = None
@@ -207,14 +279,18 @@ def _run_phases(aligned, unaligned, rank, n_done):
         t = threading.Thread(target=bg, name="ns-unaligned")
         t.start()
     try:
-        aligned()
+        aligned(pair.aligned) if pair else aligned()
     finally:
+        if pair:
+            pair.finish_aligned()
         if t is not None:
             if rank == 0:
                 log("Start simulation of random reads")
             t.join()
     if err:
         raise err[0]
+    if pair and os.environ.get("NS_CLI_TRACE") is not None:
+        sys.stderr.write("[cli] %d steps through ns_generate_step, %d aligned worker calls on their own\n" % (pair.steps, pair.alone))
     if t is not None and rank == 0:
         sys.stdout.write(strftime("%Y-%m-%d %H:%M:%S") + ": Number of reads simulated >> " + str(n_done) + "\n")
         sys.stdout.flush()
@@ -229,7 +305,7 @@ def _batch_params(n, first, *, seed, kind, fastq, chimeric, min_len, max_len, me
 
 def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, chimeric, min_len, max_len, median_len,
                    sd_len, want_errlog, kmer_bias=0, meta=False, err_header=b"", trx=False, uracil=False, model_ir=False, dist=None, stripes=1,
-                   quiet=False, tag="", batch_reads=None):
+                   quiet=False, tag="", batch_reads=None, gen=None):
     """Reads [first, first + count) of this rank into out_path (and their error-profile rows into err_path), through the engine's output
     sinks (include/nanosim_amd.h: ns_sink_*): the images of batch i leave the GPU and reach the files while batch i + 1 is generated.
 
@@ -240,12 +316,13 @@ def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, 
     NS_KEEP_SUBFILES=1 skips that merge: the sub-files stay and `<file>.subfiles` lists them in order (cat $(cat x.subfiles) = x).
     Several ranks: a rank that is done publishes the list of its sub-files (shard.publish_parts); rank 0 appends them in rank order as they
     appear (shard.collect_parts) — no collective, and a rank that fails leaves a marker instead of a hanging peer.
-    quiet: no progress line on stdout (the worker call that runs on the background context, _run_phases)."""
+    quiet: no progress line on stdout (the worker call that runs on the background context, _run_phases).
+    gen: what generates a batch from its parameters (StepPair.aligned / .unaligned); None: eng.generate."""
     rank = dist.get_rank() if dist is not None else 0
     stripes = _cap_stripes(stripes, len([p for p in (out_path, err_path) if p]))
     world = dist.get_world_size() if dist is not None else 1
     trace = os.environ.get("NS_CLI_TRACE") is not None       # per-batch host timing on stderr
-    keep = os.environ.get("NS_KEEP_SUBFILES", "0") != "0"
+    keep = os.environ.get("NS_KEEP_SUBFILES", "0") != "0"      # (--no-merge sets it: main)
     kw = dict(seed=seed, kind=kind, fastq=fastq, chimeric=chimeric, min_len=min_len, max_len=max_len, median_len=median_len, sd_len=sd_len,
               want_errlog=err_path is not None, kmer_bias=kmer_bias, meta=meta, trx=trx, uracil=uracil, model_ir=model_ir)
     batch = min(getattr(eng, "_batch_reads", BATCH_READS), batch_reads or BATCH_READS)
@@ -289,7 +366,7 @@ def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, 
             n = min(batch, count - done)
             t0 = time.perf_counter()
             try:
-                b = eng.generate(_batch_params(n, first + done, **kw))
+                b = (gen or eng.generate)(_batch_params(n, first + done, **kw))
             except E.EngineError as ex:              # not enough free HBM for this batch size (shared GPU): halve it and go on
                 if getattr(ex, "code", 0) != E.NS_ENOMEM or n <= 1000 or meta:
                     raise                            # (metagenome workers: the batches are part of the result)
@@ -317,9 +394,11 @@ def _write_batches(eng, out_path, err_path, *, seed, first, count, kind, fastq, 
                 prev, open_now = open_now, []
             if trace:
                 c = eng.io_counters()
-                sys.stderr.write("[cli%s] batch %d reads: generate %.1f ms (device %.1f), %.2f GB queued; so far %.2f GB copied at %s GB/s (DMA), copier waited "
+                # device: first to last event of the worker call — it includes what the HOST does in between (the first-use hipMalloc of a result
+                # slot, the wait for a slot whose last batch is still crossing PCIe); kernels: the sum of the kernel phases alone
+                sys.stderr.write("[cli%s] batch %d reads: generate %.1f ms (device %.1f, kernels %.1f), %.2f GB queued; so far %.2f GB copied at %s GB/s (DMA), copier waited "
                                  "%.2f s for staging, writers %.2f s in pwrite\n"
-                                 % (tag, n, (t1 - t0) * 1e3, b.info.ms_total, (int(b.info.record_bytes) + int(b.info.errlog_bytes)) / 1e9, c["bytes"] / 1e9,
+                                 % (tag, n, (t1 - t0) * 1e3, b.info.ms_total, sum(float(x) for x in b.info.ms_kernel), (int(b.info.record_bytes) + int(b.info.errlog_bytes)) / 1e9, c["bytes"] / 1e9,
                                     "%.1f" % c["d2h_gbs"] if c["d2h_gbs"] else "-", c["wait_staging_s"], c["write_s"]))
             done += n
             if rank == 0 and not quiet:
@@ -418,21 +497,21 @@ def run_genome(a, parser_g):
         lo, hi = shard.partition(n_al, world)[rank]
         ulo, uhi = shard.partition(n_un, world)[rank]
         stripes = max(a.num_threads, 1)
-        eng_un = eng
+        eng_un, step_owner = eng, None
         if not a.perfect and not _serial_schedule():
-            eng_un = _background_engine(device, setup)
+            eng_un, step_owner = _background_engine(device, setup, eng)
         b_al, b_un = _step_batches(n_al, n_un) if eng_un is not eng else (None, None)
 
-        def aligned():
+        def aligned(gen=None):
             _write_batches(eng, outputs[0], outputs[1], seed=seed, first=lo, count=hi - lo, kind=kind,
                            fastq=a.fastq, chimeric=a.chimeric, min_len=a.min_len, max_len=max_len, median_len=a.median_len, sd_len=a.sd_len,
                            want_errlog=True, kmer_bias=a.KmerBias or 0, err_header=ERR_HEADER, dist=dist, stripes=stripes, tag=" aligned",
-                           batch_reads=b_al)
+                           batch_reads=b_al, gen=gen)
 
-        def unaligned(quiet):                                                                   # S:1642-1672
+        def unaligned(quiet, gen=None):                                                         # S:1642-1672
             _write_batches(eng_un, outputs[2], None, seed=seed, first=n_al + ulo, count=uhi - ulo, kind=E.NS_KIND_UNALIGNED,
                            fastq=a.fastq, chimeric=False, min_len=a.min_len, max_len=max_len, median_len=a.median_len, sd_len=a.sd_len,
-                           want_errlog=False, dist=dist, stripes=stripes, quiet=quiet, tag=" unaligned", batch_reads=b_un)
+                           want_errlog=False, dist=dist, stripes=stripes, quiet=quiet, tag=" unaligned", batch_reads=b_un, gen=gen)
         try:
             if a.perfect:
                 aligned()
@@ -442,7 +521,7 @@ def run_genome(a, parser_g):
                     log("Start simulation of random reads")
                 unaligned(False)
             else:
-                _run_phases(aligned, lambda: unaligned(True), rank, n_al + uhi)
+                _run_phases(aligned, lambda gen=None: unaligned(True, gen), rank, n_al + uhi, step_owner)
         finally:
             if eng_un is not eng:
                 eng_un.close()
@@ -510,9 +589,9 @@ def run_metagenome(a, parser_mg):
             e.set_metagenome(mref, dev_ptr=keep.data_ptr() if (dist is not None and bdev is not None) else None)
             e.load_model(mdl)
         setup(eng)
-        eng_un = eng
+        eng_un, step_owner = eng, None
         if not a.perfect and not _serial_schedule():
-            eng_un = _background_engine(device, setup)       # (unaligned reads and gaps take any species: no abundances needed, S:1708)
+            eng_un, step_owner = _background_engine(device, setup, eng)      # (unaligned reads and gaps take any species: no abundances needed, S:1708)
         max_len = a.max_len
         total_len = mref.total_len()
         first = 0
@@ -536,16 +615,17 @@ def run_metagenome(a, parser_mg):
                 lo, hi = shard.partition(n_al, world)[rank]
                 ulo, uhi = shard.partition(n_un, world)[rank]
 
-                def aligned(base=base, first=first, lo=lo, hi=hi, max_len=max_len):
+                def aligned(gen=None, base=base, first=first, lo=lo, hi=hi, max_len=max_len):
                     _write_batches(eng, base + "_aligned_reads" + ext, base + "_aligned_error_profile", seed=seed, first=first + lo,
                                    count=hi - lo, kind=E.NS_KIND_PERFECT if a.perfect else E.NS_KIND_ALIGNED, fastq=a.fastq, chimeric=a.chimeric,
                                    min_len=a.min_len, max_len=max_len, median_len=a.median_len, sd_len=a.sd_len, want_errlog=True, meta=True,
-                                   kmer_bias=0 if a.perfect else (a.KmerBias or 0), err_header=ERR_HEADER, dist=dist, tag=" aligned")
+                                   kmer_bias=0 if a.perfect else (a.KmerBias or 0), err_header=ERR_HEADER, dist=dist, tag=" aligned", gen=gen)
 
-                def unaligned(quiet, base=base, first=first, n_al=n_al, ulo=ulo, uhi=uhi, max_len=max_len):     # S:1642
+                def unaligned(quiet, gen=None, base=base, first=first, n_al=n_al, ulo=ulo, uhi=uhi, max_len=max_len):     # S:1642
                     _write_batches(eng_un, base + "_unaligned_reads" + ext, None, seed=seed, first=first + n_al + ulo, count=uhi - ulo,
                                    kind=E.NS_KIND_UNALIGNED, fastq=a.fastq, chimeric=False, min_len=a.min_len, max_len=max_len,
-                                   median_len=a.median_len, sd_len=a.sd_len, want_errlog=False, meta=True, dist=dist, quiet=quiet, tag=" unaligned")
+                                   median_len=a.median_len, sd_len=a.sd_len, want_errlog=False, meta=True, dist=dist, quiet=quiet, tag=" unaligned",
+                                   gen=gen)
                 if a.perfect:
                     aligned()
                 elif eng_un is eng:
@@ -554,7 +634,7 @@ def run_metagenome(a, parser_mg):
                         log("Start simulation of random reads")
                     unaligned(False)
                 else:
-                    _run_phases(aligned, lambda: unaligned(True), rank, first + n_al + uhi)
+                    _run_phases(aligned, lambda gen=None, un=unaligned: un(True, gen), rank, first + n_al + uhi, step_owner)
                 first += n_al + n_un            # samples draw from disjoint read-index ranges of the same seed
         finally:
             if eng_un is not eng:
@@ -651,22 +731,22 @@ def run_transcriptome(a, parser_t):
         lo, hi = shard.partition(n_al, world)[rank]
         ulo, uhi = shard.partition(n_un, world)[rank]
         stripes = max(a.num_threads, 1)
-        eng_un = eng
+        eng_un, step_owner = eng, None
         if not a.perfect and not _serial_schedule():
-            eng_un = _background_engine(device, lambda e: setup(e, with_ir=False))     # (S:1156: unaligned reads are never spliced)
+            eng_un, step_owner = _background_engine(device, lambda e: setup(e, with_ir=False), eng)     # (S:1156: unaligned reads are never spliced)
         b_al, b_un = _step_batches(n_al, n_un) if eng_un is not eng else (None, None)
 
-        def aligned():
+        def aligned(gen=None):
             _write_batches(eng, outputs[0], outputs[1], seed=seed, first=lo, count=hi - lo,
                            kind=E.NS_KIND_PERFECT if a.perfect else E.NS_KIND_ALIGNED, fastq=a.fastq, chimeric=False, min_len=a.min_len,
                            max_len=max_len, median_len=None, sd_len=None, want_errlog=True, trx=True, uracil=a.uracil, kmer_bias=a.KmerBias or 0,
-                           err_header=ERR_HEADER, model_ir=model_ir, dist=dist, stripes=stripes, tag=" aligned", batch_reads=b_al)
+                           err_header=ERR_HEADER, model_ir=model_ir, dist=dist, stripes=stripes, tag=" aligned", batch_reads=b_al, gen=gen)
 
-        def unaligned(quiet):                                                                     # S:1642-1672
+        def unaligned(quiet, gen=None):                                                           # S:1642-1672
             _write_batches(eng_un, outputs[2], None, seed=seed, first=n_al + ulo, count=uhi - ulo,
                            kind=E.NS_KIND_UNALIGNED, fastq=a.fastq, chimeric=False, min_len=a.min_len, max_len=max_len, median_len=None,
                            sd_len=None, want_errlog=False, trx=True, uracil=a.uracil, dist=dist, stripes=stripes, quiet=quiet, tag=" unaligned",
-                           batch_reads=b_un)
+                           batch_reads=b_un, gen=gen)
         try:
             if a.perfect:
                 aligned()
@@ -676,7 +756,7 @@ def run_transcriptome(a, parser_t):
                     log("Start simulation of random reads")
                 unaligned(False)
             else:
-                _run_phases(aligned, lambda: unaligned(True), rank, n_al + uhi)
+                _run_phases(aligned, lambda gen=None: unaligned(True, gen), rank, n_al + uhi, step_owner)
         finally:
             if eng_un is not eng:
                 eng_un.close()
@@ -693,6 +773,8 @@ def main(argv=None):
         parser.print_help(sys.stderr)
         sys.exit(1)
     a = parser.parse_args(argv)
+    if getattr(a, "no_merge", False):
+        os.environ["NS_KEEP_SUBFILES"] = "1"
     if a.mode == "genome":
         run_genome(a, parser_g)
     elif a.mode == "metagenome":

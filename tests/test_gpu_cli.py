@@ -254,16 +254,57 @@ def test_two_context_schedule_writes_the_files_of_the_serial_one(tmp_path, monke
     cwd = os.getcwd()
     os.chdir(ROOT)                               # (the metagenome genome list holds paths relative to the repo root)
     try:
-        simulator.main(argv + ["-o", str(tmp_path / "two" / "sim")])
+        simulator.main(argv + ["-o", str(tmp_path / "two" / "sim")])       # default: one ns_generate_step per step (StepPair, round 5)
+        monkeypatch.setenv("NS_TWO_ENGINES", "1")                            # two engine contexts of their own + a Python thread (rounds 2-4)
+        simulator.main(argv + ["-o", str(tmp_path / "two_engines" / "sim")])
+        monkeypatch.delenv("NS_TWO_ENGINES")
         monkeypatch.setenv("NS_SERIAL", "1")
         simulator.main(argv + ["-o", str(tmp_path / "one" / "sim")])
     finally:
         os.chdir(cwd)
     names = sorted(os.listdir(tmp_path / "one"))
-    assert names == sorted(os.listdir(tmp_path / "two")) and len(names) >= 3
+    assert names == sorted(os.listdir(tmp_path / "two")) == sorted(os.listdir(tmp_path / "two_engines")) and len(names) >= 3
     for f in names:
-        a, b = open(tmp_path / "one" / f, "rb").read(), open(tmp_path / "two" / f, "rb").read()
-        assert a == b and (len(a) > 0 or "unaligned" in f), f
+        a, b, c = (open(tmp_path / d / f, "rb").read() for d in ("one", "two", "two_engines"))
+        assert a == b == c and (len(a) > 0 or "unaligned" in f), f
+
+
+def test_generate_step_is_two_worker_calls_side_by_side(small_model, small_ref):
+    """VERDICT r4 item 2 / ABI 6: ns_generate_step runs the aligned worker call on the context and the unaligned one on its step companion
+    (same reference and model, own buffers, the library's worker thread).  Bytes of both batches == two ns_generate calls; either half
+    may be missing; the companion's results are reached through Engine.step_engine(); its tables cannot be set behind its owner's back."""
+    import numpy as np
+    from nanosim_amd import engine as E
+    eng, ref_eng = E.Engine(0), E.Engine(0)
+    try:
+        for e in (eng, ref_eng):
+            e.set_reference(small_ref); e.load_model(small_model)
+        for it, (n_al, n_un) in enumerate(((3000, 400), (1200, 1300), (257, 0), (0, 300), (3000, 400))):
+            p_al = E.make_params(seed=5, first_read=1000 * it, n_reads=n_al, max_len=small_ref.max_chrom, chimeric=True, fastq=True, emit_errlog=True) if n_al else None
+            p_un = E.make_params(seed=5, first_read=1000 * it + n_al, n_reads=n_un, kind=E.NS_KIND_UNALIGNED, max_len=small_ref.max_chrom, fastq=True) if n_un else None
+            b_al, b_un = eng.generate_step(p_al, p_un)
+            assert (b_al is None) == (p_al is None) and (b_un is None) == (p_un is None)
+            if p_al is not None:
+                exp = ref_eng.generate(p_al)
+                assert b_al.records().tobytes() == exp.records().tobytes() and b_al.errlog().tobytes() == exp.errlog().tobytes()
+                assert np.array_equal(b_al.reads(), exp.reads()) and int(b_al.info.n_reads) == n_al
+            if p_un is not None:
+                exp = ref_eng.generate(p_un)
+                assert b_un.eng is eng.step_engine() and b_un.records().tobytes() == exp.records().tobytes()
+                assert np.array_equal(b_un.reads(), exp.reads()) and int(b_un.info.record_bytes) == int(exp.info.record_bytes) > 0
+        # wrong halves, and the companion's tables belong to its owner
+        with pytest.raises(E.EngineError):
+            eng.generate_step(E.make_params(seed=5, first_read=0, n_reads=10, kind=E.NS_KIND_UNALIGNED, max_len=small_ref.max_chrom), None)
+        with pytest.raises(E.EngineError) as ei:
+            eng.step_engine().load_model(small_model)
+        assert ei.value.code == E.NS_ESTATE
+        # a new model on the owner reaches the companion with the next step
+        eng.load_model(small_model)
+        b_al, b_un = eng.generate_step(E.make_params(seed=6, first_read=0, n_reads=100, max_len=small_ref.max_chrom),
+                                       E.make_params(seed=6, first_read=100, n_reads=100, kind=E.NS_KIND_UNALIGNED, max_len=small_ref.max_chrom))
+        assert b_un.records().tobytes() == ref_eng.generate(E.make_params(seed=6, first_read=100, n_reads=100, kind=E.NS_KIND_UNALIGNED, max_len=small_ref.max_chrom)).records().tobytes()
+    finally:
+        eng.close(); ref_eng.close()
 
 
 def _bench_line(args, env_extra=None, timeout=900):

@@ -394,6 +394,64 @@ def test_run_phases_runs_both_worker_calls_side_by_side_and_reports_failures(cap
     assert done == [1, 2]
 
 
+class _StepFake:
+    """what StepPair uses of an Engine: generate / generate_step / step_engine, recording who served which request"""
+    def __init__(self, fail_step_at=None):
+        self.log, self.fail_step_at, self.n_steps = [], fail_step_at, 0
+        self.un = self
+    def step_engine(self):
+        return self
+    def generate(self, p):
+        self.log.append(("alone", p))
+        return ("batch", p)
+    def generate_step(self, pa, pu):
+        self.n_steps += 1
+        if self.fail_step_at == self.n_steps:
+            raise RuntimeError("step %d failed" % self.n_steps)
+        self.log.append(("step", pa, pu))
+        return ("batch", pa), ("batch", pu)
+
+
+@pytest.mark.parametrize("n_al,n_un", [(6, 6), (9, 3), (2, 7), (5, 0)])
+def test_step_pair_serves_every_request_once(n_al, n_un):
+    """the CLI takes its batches through ns_generate_step.  StepPair pairs the requests of the two phases; whatever the
+    counts and the timing, every request is answered exactly once with ITS batch, and nothing waits for a partner that is gone."""
+    import time
+    fake = _StepFake()
+    got = {"al": [], "un": []}
+
+    def aligned(gen):
+        for i in range(n_al):
+            got["al"].append(gen(("al", i)))
+            time.sleep(0.002)
+
+    def unaligned(gen):
+        for i in range(n_un):
+            got["un"].append(gen(("un", i)))
+    simulator._run_phases(aligned, unaligned, 1, 0, step_owner=fake)
+    assert got["al"] == [("batch", ("al", i)) for i in range(n_al)] and got["un"] == [("batch", ("un", i)) for i in range(n_un)]
+    served = [x for e in fake.log for x in e[1:]]
+    assert sorted(served) == sorted([("al", i) for i in range(n_al)] + [("un", i) for i in range(n_un)])
+    if n_al >= 6 and n_un >= 3:
+        assert any(e[0] == "step" for e in fake.log)          # (the waiting unaligned request is picked up by the next aligned call)
+
+
+def test_step_pair_failure_in_a_step_reaches_the_aligned_phase_and_frees_the_unaligned_one():
+    fake = _StepFake(fail_step_at=1)
+    got = []
+
+    def aligned(gen):
+        import time
+        time.sleep(0.05)                                       # (the unaligned request is waiting by now)
+        gen(("al", 0))
+
+    def unaligned(gen):
+        got.append(gen(("un", 0)))
+    with pytest.raises(RuntimeError, match="step 1 failed"):
+        simulator._run_phases(aligned, unaligned, 1, 0, step_owner=fake)
+    assert got == [("batch", ("un", 0))] and ("alone", ("un", 0)) in fake.log      # repeated on its own, not lost, not hung
+
+
 def test_failure_markers_cover_every_output_of_a_rank(tmp_path):
     """a rank > 0 that dies OUTSIDE _write_batches (engine, model, a later file) leaves a marker for every output"""
     outs = [str(tmp_path / "sim_aligned_reads.fasta"), str(tmp_path / "sim_unaligned_reads.fasta")]
