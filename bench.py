@@ -38,7 +38,7 @@ if ROOT not in sys.path:
 
 SEED = 20260926
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PROFILE_ROUNDS = ("r04", "r03", "r02")
+PROFILE_ROUNDS = ("r05", "r04", "r03", "r02")
 
 
 REFERENCE_PYTHON = {        # the reference itself (bcgsc/NanoSim v3.2.2, simulator.py -t 8), measured in the build container

@@ -9,6 +9,8 @@ from the event lists of reads the CPU oracle generates with the small test model
 errors next to each other (the mis0 / ins0 / del0 states), runs of mismatches, matches of every length.
 
     python tests/golden/make_hist_golden.py        -> tests/golden/reference_hist.json.gz
+    python tests/golden/make_hist_golden.py --maf  -> tests/golden/reference_hist_maf.json.gz: hist(prefix, "maf") (B:191-305) on the two
+                                                      `s` lines per alignment of a synthetic `<prefix>_besthit.maf`
 """
 import gzip
 import json
@@ -134,7 +136,90 @@ def run_reference(cs_list, workdir):
     return files, parsed, getcs
 
 
+def synthetic_maf(n_reads=450, seed=777):
+    """(reference line, query line) of pairwise alignments, as the two `s` lines of `<prefix>_besthit.maf` carry them (field 7), from oracle
+    reads: the events of every aligned piece column by column, plus hand-made cases for the corners of the MAF branch (B:191-305)"""
+    from nanosim_amd import engine as E
+    from nanosim_amd import model as M
+    from tests import oracle_lib as O
+    mdl = M.load_model(os.path.join(HERE, "model_small", "training"))
+    ref = M.read_fasta(os.path.join(HERE, "genome_small.fa"))
+    p = E.make_params(seed=seed, first_read=0, n_reads=n_reads, max_len=ref.max_chrom)
+    out = O.generate(mdl, ref, p)
+    rng = np.random.default_rng(seed)
+    L = "ACGT"
+    pairs = []
+    for pc in out["pieces"]:
+        if pc["kind"]:
+            continue
+        ev = out["events"][int(pc["ev_off"]):int(pc["ev_off"]) + int(pc["n_ev"])]
+        r, q, pos = [], [], 0
+
+        def match(n):
+            b = "".join(L[i] for i in rng.integers(0, 4, n))
+            r.append(b); q.append(b)
+        for e in ev:
+            epos, ln, ty = int(e["pos"]), int(e["info"]) & 0xfff, (int(e["info"]) >> 12) & 3
+            if epos > pos:
+                match(epos - pos); pos = epos
+            seq = [int(i) for i in rng.integers(0, 4, ln)]
+            if ty == 0:
+                r.append("".join(L[i] for i in seq)); q.append("".join(L[(i + 1 + int(rng.integers(0, 3))) % 4] for i in seq)); pos += ln
+            elif ty == 1:
+                r.append("-" * ln); q.append("".join(L[i] for i in seq))
+            else:
+                r.append("".join(L[i] for i in seq)); q.append("-" * ln); pos += ln
+        if int(pc["ref_len"]) > pos:
+            match(int(pc["ref_len"]) - pos)
+        rs, qs = "".join(r), "".join(q)
+        if rng.random() < 0.3:                                                 # soft-masked stretches: hist() upper-cases both lines
+            a = int(rng.integers(0, max(1, len(rs) - 1))); b = min(len(rs), a + int(rng.integers(1, 200)))
+            rs = rs[:a] + rs[a:b].lower() + rs[b:]
+            if rng.random() < 0.5:
+                qs = qs[:a] + qs[a:b].lower() + qs[b:]
+        pairs.append([rs, qs])
+    # corners: one match only; errors at both ends (pending counts at the end are dropped); a deletion directly in front of an insertion
+    # and the other way round (both counters pending: the `elif` chain flushes ONE per column); mismatch next to indels (mis0 / ins0 /
+    # del0); a match beyond 1 000 columns (add_dict drops it, add_match keeps it); lower against upper case; N against N
+    pairs += [["ACGTACGT", "ACGTACGT"], ["A-CGT", "ATCGA"], ["ACG--T", "A-GTTT"], ["AC-GT", "ACT-T"], ["ACCGT--A", "A--GTTTA"],
+              ["AAAA" + "C" * 1200 + "G-T", "AAAT" + "C" * 1200 + "GAT"], ["acgtNNac", "ACGTNNAC"], ["ACGT", "TGCA"], ["A-C", "AT-"],
+              ["ACGTT-GCA-", "AC-TTAGCAT"], ["-ACGT", "TACGT"], ["ACGT-", "ACGTA"], ["TTGA--CCA", "TT--GGCCA"], ["AC--GT", "ACTT-T"]]
+    return pairs
+
+
+def run_reference_maf(pairs, workdir):
+    for m in ("pysam",):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    sys.dont_write_bytecode = True
+    if REF_SRC not in sys.path:
+        sys.path.insert(0, REF_SRC)
+    import besthit_to_histogram as B
+    prefix = os.path.join(workdir, "training")
+    with open(prefix + "_besthit.maf", "w") as f:                              # two `s` lines per alignment, nothing else (B:192-201)
+        for i, (r, q) in enumerate(pairs):
+            f.write("s ref 0 %d + 1000000 %s\n" % (len(r.replace("-", "")), r))
+            f.write("s read%d 0 %d + %d %s\n" % (i, len(q.replace("-", "")), len(q.replace("-", "")), q))
+    B.hist(prefix, "maf")
+    files = {}
+    for name in ("_match.hist", "_mis.hist", "_ins.hist", "_del.hist", "_error_markov_model", "_match_markov_model", "_first_match.hist",
+                 "_error_rate.tsv"):
+        files[name] = open(prefix + name).read()
+    return files
+
+
 if __name__ == "__main__":
+    if "--maf" in sys.argv:
+        pairs = synthetic_maf()
+        work = tempfile.mkdtemp(prefix="nshistmaf_")
+        try:
+            files = run_reference_maf(pairs, work)
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+        out = os.path.join(HERE, "reference_hist_maf.json.gz")
+        with gzip.open(out, "wt", compresslevel=9) as f:
+            json.dump(dict(maf=pairs, files=files), f)
+        print("written", out, os.path.getsize(out), "bytes;", len(pairs), "alignments;", {k: len(v) for k, v in files.items()})
+        sys.exit(0)
     cs_list = synthetic_cs()
     work = tempfile.mkdtemp(prefix="nshist_")
     try:
