@@ -367,6 +367,13 @@ typedef struct ns_cs_hist {
 } ns_cs_hist;
 enum { NS_CSH_MATCH = 0, NS_CSH_FIRST_MATCH = 1, NS_CSH_MIS = 2, NS_CSH_INS = 3, NS_CSH_DEL = 4 };
 int ns_cs_histograms(ns_ctx *ctx, const uint8_t *cs, uint64_t nbytes, const uint64_t *aln_off, uint32_t n_aln, ns_cs_hist *h);
+/* The MAF branch of the same loop (B:187-305): <prefix>_besthit.maf carries two `s` lines per alignment, the aligned reference and query
+ * sequences with '-' for gaps.  ref_lines / query_lines: those lines (field 7) of all alignments back to back, alignment a at
+ * aln_off[a] .. aln_off[a + 1] of BOTH (the two lines of an alignment have the same length; nbytes = aln_off[n_aln]).  Same counters,
+ * same struct; per alignment the state of the reference's column walk (its four pending run lengths, prev_match and prev_error reset
+ * per alignment).  Added with ABI 6. */
+int ns_maf_histograms(ns_ctx *ctx, const uint8_t *ref_lines, const uint8_t *query_lines, uint64_t nbytes, const uint64_t *aln_off,
+                      uint32_t n_aln, ns_cs_hist *h);
 
 /* device address of a result buffer (for zero-copy consumers such as torch / RCCL); NULL if absent */
 const void *ns_device_ptr(ns_ctx *ctx, int which);

@@ -10,7 +10,9 @@ what is left: getting the cs strings out of a SAM file and formatting the refere
     eng = engine.Engine(0)
     characterize.hist("training", characterize.cs_from_sam("training_primary.sam"), eng)
 
-Not covered: BAM input (pysam is not a dependency here: convert with ``samtools view -h``) and the MAF branch of the reference (B:187-306).
+    characterize.hist("training", characterize.maf_pairs("training_besthit.maf"), eng, alnm_ftype="maf")      # hist(prefix, "maf"), B:187-305
+
+Not covered: BAM input (pysam is not a dependency here: convert with ``samtools view -h``).
 """
 from __future__ import annotations
 
@@ -123,6 +125,42 @@ def count(eng, cs_list, cap: int = 2048) -> dict:
                 first_error=np.ctypeslib.as_array(h.first_error).copy(), max_match=int(h.max_match), ms_kernel=float(h.ms_kernel))
 
 
+def maf_pairs(path: str):
+    """[(reference line, query line)] of `<prefix>_besthit.maf` as hist(prefix, "maf") reads it (B:192-202): the file holds two `s` lines
+    per alignment and nothing else; field 7 of each is the aligned sequence (the upper-casing is done by the counting walk)"""
+    out = []
+    with open(path) as f:
+        for line in f:
+            r = line.strip().split()
+            q = next(f).strip().split()
+            if len(r) < 7 or len(q) < 7 or len(r[6]) > len(q[6]):
+                raise ValueError("%s: not two `s` lines with an aligned sequence each (the reference would stop with an IndexError)" % path)
+            out.append((r[6], q[6][:len(r[6])]))                   # (the walk runs over len(ref), B:207)
+    return out
+
+
+def count_maf(eng, pairs, cap: int = 2048) -> dict:
+    """the counts of hist()'s MAF loop for these alignments, from the GPU (ns_maf_histograms)"""
+    rb = [a.encode() if isinstance(a, str) else bytes(a) for a, _ in pairs]
+    qb = [b.encode() if isinstance(b, str) else bytes(b) for _, b in pairs]
+    if any(len(a) != len(b) for a, b in zip(rb, qb)):
+        raise ValueError("the two lines of an alignment differ in length")
+    off = np.zeros(len(rb) + 1, dtype=np.uint64)
+    np.cumsum([len(b) for b in rb], out=off[1:])
+    ref = np.frombuffer(b"".join(rb) + b"\0", dtype=np.uint8)
+    qry = np.frombuffer(b"".join(qb) + b"\0", dtype=np.uint8)
+    while True:
+        h = NsCsHist()
+        m2 = np.zeros((cap, cap), dtype=np.uint64)
+        h.cap_match2d, h.match_list = cap, m2.ctypes.data
+        eng._check(eng.L.ns_maf_histograms(eng.ctx, ref.ctypes.data, qry.ctypes.data, int(off[-1]), off.ctypes.data, len(rb), C.byref(h)))
+        if not h.n_match2d_overflow:
+            break
+        cap = 1 << int(h.max_match).bit_length()
+    return dict(dic=np.ctypeslib.as_array(h.dic).copy(), match_list=m2, error_list=np.ctypeslib.as_array(h.error_list).copy().reshape(6, 3),
+                first_error=np.ctypeslib.as_array(h.first_error).copy(), max_match=int(h.max_match), ms_kernel=float(h.ms_kernel))
+
+
 def _dict_len(cnt, initial):
     nz = np.nonzero(cnt)[0]
     return max(initial, int(nz[-1]) + 1 if len(nz) else 0)
@@ -208,12 +246,13 @@ def format_tables(t: dict) -> dict:
     return out
 
 
-def hist(prefix: str, cs_list, eng) -> dict:
+def hist(prefix: str, alignments, eng, alnm_ftype: str = "bam") -> dict:
     """writes <prefix>_match.hist, _mis.hist, _ins.hist, _del.hist, _error_rate.tsv, _error_markov_model, _match_markov_model and
-    _first_match.hist like hist(prefix, "bam") (B:148-486; `prefix` may end in "_genome", B:150-151); returns the counts"""
+    _first_match.hist like hist(prefix, alnm_ftype) (B:148-486; `prefix` may end in "_genome", B:150-151); returns the counts.
+    alnm_ftype "bam" (or "sam"): alignments = cs strings (cs_from_sam); "maf": (reference line, query line) pairs (maf_pairs)"""
     if "_genome" in prefix:
         prefix = prefix[:-7]
-    t = count(eng, cs_list)
+    t = count_maf(eng, alignments) if alnm_ftype == "maf" else count(eng, alignments)
     for name, text in format_tables(t).items():
         with open(prefix + name, "w") as f:
             f.write(text)

@@ -1641,8 +1641,9 @@ __global__ void __launch_bounds__(256) k_cs_len(const uint64_t *__restrict__ off
     const uint64_t n = off[a + 1] - off[a];
     key[a] = n > 0xffffffffull ? 0xffffffffu : (uint32_t)n; idx[a] = a;
 }
+// qry != nullptr: the MAF branch — cs holds the reference lines, qry the query lines (maf_hist_alignment)
 __global__ void __launch_bounds__(256) k_cs_hist(const uint8_t *__restrict__ cs, const uint64_t *__restrict__ off, uint32_t n_aln, CsHistDev H,
-                                                 const uint32_t *__restrict__ order) {
+                                                 const uint32_t *__restrict__ order, const uint8_t *__restrict__ qry) {
     __shared__ uint32_t cnt[NS_CSH_LDS_WORDS];
     for (uint32_t i = threadIdx.x; i < NS_CSH_LDS_WORDS; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
@@ -1653,10 +1654,13 @@ __global__ void __launch_bounds__(256) k_cs_hist(const uint8_t *__restrict__ cs,
         const uint64_t n = off[a + 1] - off[a];
         // prev_match is only read before this alignment assigns it when its first op is an error: then it is what the alignments in
         // front of it left (the reference never resets it between alignments)
-        uint32_t pm = 0;
-        { CsCursor c; cs_cursor_init(c); int t; uint32_t l; if (cs_next_op(s, n, c, t, l) && t != CS_MATCH) pm = cs_carry_in(cs, off, a); }
         CsAccDev acc{cnt, &H, 0u};
-        cs_hist_alignment(s, n, pm, nullptr, acc);
+        if (qry) maf_hist_alignment(s, qry + off[a], n, acc);
+        else {
+            uint32_t pm = 0;
+            { CsCursor c; cs_cursor_init(c); int t; uint32_t l; if (cs_next_op(s, n, c, t, l) && t != CS_MATCH) pm = cs_carry_in(cs, off, a); }
+            cs_hist_alignment(s, n, pm, nullptr, acc);
+        }
         if (acc.mx) atomicMax(&cnt[NS_CSH_LDS_WORDS - 1u], acc.mx);
     }
     __syncthreads();
@@ -3470,7 +3474,15 @@ int ns_io_counters(ns_ctx *ctx, ns_io_stats *out, int reset) {
 }
 
 // the characterisation stage's counting loop (include/nanosim_amd.h: ns_cs_hist; src/besthit_to_histogram.py:308-355)
+static int histograms(ns_ctx *ctx, const uint8_t *cs, const uint8_t *qry, bool maf, uint64_t nbytes, const uint64_t *aln_off, uint32_t n_aln, ns_cs_hist *h);
 int ns_cs_histograms(ns_ctx *ctx, const uint8_t *cs, uint64_t nbytes, const uint64_t *aln_off, uint32_t n_aln, ns_cs_hist *h) {
+    return histograms(ctx, cs, nullptr, false, nbytes, aln_off, n_aln, h);
+}
+int ns_maf_histograms(ns_ctx *ctx, const uint8_t *ref_lines, const uint8_t *query_lines, uint64_t nbytes, const uint64_t *aln_off, uint32_t n_aln, ns_cs_hist *h) {
+    if (ctx && n_aln && nbytes && !query_lines) return fail(ctx, NS_EINVAL, "ns_maf_histograms: null argument");
+    return histograms(ctx, ref_lines, query_lines, true, nbytes, aln_off, n_aln, h);
+}
+static int histograms(ns_ctx *ctx, const uint8_t *cs, const uint8_t *qry, bool maf, uint64_t nbytes, const uint64_t *aln_off, uint32_t n_aln, ns_cs_hist *h) {
     if (!ctx) return NS_EINVAL;
     if (!h || (n_aln && (!aln_off || (!cs && nbytes)))) return fail(ctx, NS_EINVAL, "ns_cs_histograms: null argument");
     for (uint32_t a = 0; a < n_aln; ++a)
@@ -3483,15 +3495,17 @@ int ns_cs_histograms(ns_ctx *ctx, const uint8_t *cs, uint64_t nbytes, const uint
     h->max_match = h->n_match2d_overflow = h->n_skip = 0; h->ms_kernel = 0;
     if (!n_aln) { if (m2_host) memset(m2_host, 0, (size_t)cap * cap * 8); return NS_OK; }
     const size_t n_small = 5 * 1001 + 24 + 8;
-    void *d_cs = nullptr, *d_off = nullptr, *d_small = nullptr, *d_m2 = nullptr, *d_key = nullptr, *d_tmp = nullptr;
-    auto release = [&]() { for (void *p : {d_cs, d_off, d_small, d_m2, d_key, d_tmp}) if (p) { hipError_t e = hipFree(p); (void)e; } };
+    void *d_cs = nullptr, *d_off = nullptr, *d_small = nullptr, *d_m2 = nullptr, *d_key = nullptr, *d_tmp = nullptr, *d_qry = nullptr;
+    auto release = [&]() { for (void *p : {d_cs, d_off, d_small, d_m2, d_key, d_tmp, d_qry}) if (p) { hipError_t e = hipFree(p); (void)e; } };
     hipError_t e = hipMalloc(&d_cs, (size_t)nbytes + 16);
+    if (e == hipSuccess && maf) e = hipMalloc(&d_qry, (size_t)nbytes + 16);
     if (e == hipSuccess) e = hipMalloc(&d_off, ((size_t)n_aln + 1) * 8);
     if (e == hipSuccess) e = hipMalloc(&d_small, n_small * 8);
     if (e == hipSuccess && m2_host) e = hipMalloc(&d_m2, (size_t)cap * cap * 8);
     if (e != hipSuccess) { release(); (void)hipGetLastError(); return fail(ctx, NS_ENOMEM, std::string("ns_cs_histograms: hipMalloc: ") + hipGetErrorString(e)); }
     hipStream_t st = ctx->stream;
     e = hipMemcpyAsync(d_cs, cs, (size_t)nbytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && maf && nbytes) e = hipMemcpyAsync(d_qry, qry, (size_t)nbytes, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_off, aln_off, ((size_t)n_aln + 1) * 8, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(d_small, 0, n_small * 8, st);
     if (e == hipSuccess && d_m2) e = hipMemsetAsync(d_m2, 0, (size_t)cap * cap * 8, st);
@@ -3516,7 +3530,7 @@ int ns_cs_histograms(ns_ctx *ctx, const uint8_t *cs, uint64_t nbytes, const uint
         CsHistDev H;
         H.dic = (unsigned long long *)d_small; H.err = H.dic + 5 * 1001; H.misc = H.err + 24;
         H.m2 = (unsigned long long *)d_m2; H.cap2 = cap;
-        k_cs_hist<<<dim3((n_aln + 255u) / 256u), dim3(256), 0, st>>>((const uint8_t *)d_cs, (const uint64_t *)d_off, n_aln, H, d_order);
+        k_cs_hist<<<dim3((n_aln + 255u) / 256u), dim3(256), 0, st>>>((const uint8_t *)d_cs, (const uint64_t *)d_off, n_aln, H, d_order, (const uint8_t *)d_qry);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipEventRecord(ctx->evt[15], st);

@@ -118,3 +118,49 @@ NS_CSH uint32_t cs_carry_in(const uint8_t *cs, const uint64_t *off, uint64_t a) 
     }
     return 0;
 }
+
+// ---- the MAF branch of hist() (B:187-305): the two aligned lines of an alignment, column by column ------------------------------------
+// Same counters, another tokenizer: a column is a match (equal letters after upper()), an inserted base (reference '-'), a deleted base
+// (query '-') or a mismatch.  The reference keeps FOUR pending run lengths and flushes at most one of them per column through its
+// `elif` chains — so a deletion directly in front of an insertion leaves both pending, and the one that is tested later waits until the
+// earlier one has gone; prev_match and prev_error start afresh in every alignment; runs still pending behind the last column are
+// dropped, and a match that ends the alignment goes to match_list only (B:233-234).  All of that is the walk below.
+struct MafRuns { uint32_t match, mis, ins, del; };
+template <class Acc>
+NS_CSH void maf_hist_alignment(const uint8_t *ref, const uint8_t *qry, uint64_t n, Acc &acc) {
+    MafRuns run{0u, 0u, 0u, 0u};
+    uint32_t prev_match = 0, state = 0;           // state: the row of error_list the next error is counted in (mis ins del mis0 ins0 del0)
+    bool first = true;
+    auto upper = [](uint8_t c) -> uint8_t { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; };
+    // an error run of kind t (0 mis, 1 ins, 2 del) is over; zero: no match between it and the column that ends it
+    auto close_error = [&](uint32_t t, uint32_t len, bool zero) {
+        acc.d1(CSH_MIS + t, len);
+        if (zero) { acc.d1(CSH_MATCH, 0); acc.m2(prev_match, 0); prev_match = 0; }
+        if (first) { first = false; acc.first(t); } else acc.err(state * 3u + t);
+        state = t + (zero ? 3u : 0u);
+    };
+    auto close_match = [&]() {
+        if (first) acc.d1(CSH_FIRST, run.match);
+        else { acc.d1(CSH_MATCH, run.match); acc.m2(prev_match, run.match); }
+        prev_match = run.match; run.match = 0;
+    };
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint8_t r = upper(ref[i]), q = upper(qry[i]);
+        if (r == q) {                                                   // B:208-234
+            if (run.mis) { close_error(0, run.mis, false); run.mis = 0; }
+            else if (run.ins) { close_error(1, run.ins, false); run.ins = 0; }
+            else if (run.del) { close_error(2, run.del, false); run.del = 0; }
+            ++run.match;
+            if (i + 1 == n) acc.m2(prev_match, run.match);
+        } else if (r == '-' || q == '-') {                              // B:235-278: an indel column ends a match or a mismatch run
+            if (run.match) close_match();
+            else if (run.mis) { close_error(0, run.mis, true); run.mis = 0; }
+            if (r == '-') ++run.ins; else ++run.del;
+        } else {                                                        // B:279-305: a mismatch column ends a match or an indel run
+            if (run.match) close_match();
+            else if (run.ins) { close_error(1, run.ins, true); run.ins = 0; }
+            else if (run.del) { close_error(2, run.del, true); run.del = 0; }
+            ++run.mis;
+        }
+    }
+}

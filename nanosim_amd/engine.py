@@ -24,7 +24,7 @@ EXPORTS = ("ns_abi_version", "ns_create", "ns_destroy", "ns_last_error", "ns_set
            "ns_set_species", "ns_set_abundance", "ns_species_bases", "ns_host_alloc", "ns_host_free",
            "ns_set_transcriptome", "ns_set_intron_retention", "ns_set_background",
            "ns_sink_open", "ns_sink_put", "ns_sink_write", "ns_sink_write_range", "ns_record_offsets", "ns_sink_drain",
-           "ns_sink_close", "ns_io_counters", "ns_cs_histograms", "ns_generate_step", "ns_step_context")
+           "ns_sink_close", "ns_io_counters", "ns_cs_histograms", "ns_generate_step", "ns_step_context", "ns_maf_histograms")
 
 
 class NsIoStats(C.Structure):
@@ -101,6 +101,8 @@ def load_library(path: str = LIB_PATH):
     L.ns_io_counters.argtypes = [C.c_void_p, C.POINTER(NsIoStats), C.c_int]
     L.ns_cs_histograms.restype = C.c_int
     L.ns_cs_histograms.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.ns_maf_histograms.restype = C.c_int
+    L.ns_maf_histograms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
     L.ns_generate_step.restype = C.c_int
     L.ns_generate_step.argtypes = [C.c_void_p, C.POINTER(NsParams), C.POINTER(NsParams), C.POINTER(NsBatchInfo)]
     L.ns_step_context.restype = C.c_int

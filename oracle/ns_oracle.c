@@ -1771,3 +1771,72 @@ int nso_cs_hist(const uint8_t *cs, const uint64_t *off, uint32_t n_aln, uint32_t
     free(l.hist); free(l.op);
     return rc;
 }
+
+/* hist(), the MAF branch (B:187-305): the two aligned lines of every alignment of <prefix>_besthit.maf, column by column.
+ * ref / qry: the two lines of all alignments back to back (same offsets: the lines of an alignment have the same length).
+ * Same counters as nso_cs_hist.  The state of the reference's loop is kept as it is — four pending run counters of which the
+ * `elif` chains flush ONE per column, prev_match and prev_error reset per alignment (B:194-196), whatever is still pending
+ * behind the last column is dropped, only a final match reaches match_list (B:233-234).
+ * PARITY: pinned against the files the REAL hist(prefix, "maf") wrote (tests/golden/reference_hist_maf.json.gz,
+ * make_hist_golden.py --maf). */
+static uint8_t maf_upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }          /* str.upper(), B:199, 202 */
+int nso_maf_hist(const uint8_t *ref, const uint8_t *qry, const uint64_t *off, uint32_t n_aln, uint32_t cap2, uint64_t *dic, uint64_t *match_list,
+                 uint64_t *error_list, uint64_t *first_error, uint64_t *max_match, uint64_t *overflow) {
+    *max_match = 0; *overflow = 0;
+#define MAF_ADD_DICT(w, v) do { int64_t v_ = (v); if (v_ <= 1000) dic[(w) * 1001 + v_] += 1; } while (0)                 /* B:14-22 */
+#define MAF_ADD_MATCH(p, q) do { int64_t p_ = (p), q_ = (q), m_ = p_ > q_ ? p_ : q_; if ((uint64_t)m_ > *max_match) *max_match = (uint64_t)m_; \
+        if (match_list && m_ < (int64_t)cap2) match_list[(uint64_t)p_ * cap2 + (uint64_t)q_] += 1; else *overflow += 1; } while (0)
+    /* the bookkeeping every flushed error run shares (B:206-211 and its eleven copies): curr = 1 mis, 2 ins, 3 del; next_state = the
+     * prev_error it leaves (1..3, or 4..6 for mis0 / ins0 / del0) */
+#define MAF_TRANSITION(curr, next_state) do { if (flag) { flag = 0; first_error[(curr) - 1] += 1; } \
+        else { error_list[(prev_error - 1) * 3 + ((curr) - 1)] += 1; } \
+        prev_error = (next_state); } while (0)
+    /* a match run ends in front of an error column (B:236-243 and its two copies) */
+#define MAF_FLUSH_MATCH() do { if (flag) { MAF_ADD_DICT(1, match); prev_match = match; } \
+        else { MAF_ADD_DICT(0, match); MAF_ADD_MATCH(prev_match, match); prev_match = match; } match = 0; } while (0)
+    for (uint32_t a = 0; a < n_aln; ++a) {
+        const uint8_t *r = ref + off[a], *q = qry + off[a];
+        const uint64_t n = off[a + 1] - off[a];
+        int64_t prev_match = 0, match = 0, mismatch = 0, ins = 0, dele = 0;     /* B:194, 203-206 */
+        int prev_error = 0, flag = 1;                                          /* B:195-196 */
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint8_t rc = maf_upper(r[i]), qc = maf_upper(q[i]);
+            if (rc == qc) {                                                    /* B:208-234 */
+                if (mismatch != 0) { MAF_ADD_DICT(2, mismatch); mismatch = 0; MAF_TRANSITION(1, 1); }
+                else if (ins != 0) { MAF_ADD_DICT(3, ins); ins = 0; MAF_TRANSITION(2, 2); }
+                else if (dele != 0) { MAF_ADD_DICT(4, dele); dele = 0; MAF_TRANSITION(3, 3); }
+                match += 1;
+                if (i == n - 1 && match != 0) MAF_ADD_MATCH(prev_match, match);
+            } else if (rc == '-') {                                            /* B:235-256: an inserted base */
+                if (match != 0) MAF_FLUSH_MATCH();
+                else if (mismatch != 0) {
+                    MAF_ADD_DICT(2, mismatch); dic[0] += 1; MAF_ADD_MATCH(prev_match, 0); prev_match = 0; mismatch = 0;
+                    MAF_TRANSITION(1, 4);
+                }
+                ins += 1;
+            } else if (qc == '-') {                                            /* B:257-278: a deleted base */
+                if (match != 0) MAF_FLUSH_MATCH();
+                else if (mismatch != 0) {
+                    MAF_ADD_DICT(2, mismatch); dic[0] += 1; MAF_ADD_MATCH(prev_match, 0); prev_match = 0; mismatch = 0;
+                    MAF_TRANSITION(1, 4);
+                }
+                dele += 1;
+            } else {                                                           /* B:279-305: a mismatch */
+                if (match != 0) MAF_FLUSH_MATCH();
+                else if (ins != 0) {
+                    MAF_ADD_DICT(3, ins); MAF_ADD_DICT(0, match); MAF_ADD_MATCH(prev_match, 0); prev_match = 0; ins = 0;
+                    MAF_TRANSITION(2, 5);
+                } else if (dele != 0) {
+                    MAF_ADD_DICT(4, dele); MAF_ADD_DICT(0, match); MAF_ADD_MATCH(prev_match, 0); prev_match = 0; dele = 0;
+                    MAF_TRANSITION(3, 6);
+                }
+                mismatch += 1;
+            }
+        }
+    }
+#undef MAF_ADD_DICT
+#undef MAF_ADD_MATCH
+#undef MAF_TRANSITION
+#undef MAF_FLUSH_MATCH
+    return 0;
+}

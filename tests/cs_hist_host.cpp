@@ -31,3 +31,13 @@ extern "C" int csh_host_count(const uint8_t *cs, const uint64_t *off, uint32_t n
     }
     return 0;
 }
+
+// the MAF branch (maf_hist_alignment): the two lines of every alignment at the same offsets
+extern "C" int maf_host_count(const uint8_t *ref, const uint8_t *qry, const uint64_t *off, uint32_t n_aln, uint32_t cap2, uint64_t *dic, uint64_t *m2,
+                              uint64_t *err, uint64_t *first, uint64_t *misc) {
+    for (uint32_t a = 0; a < n_aln; ++a) {
+        HostAcc acc{dic, m2, err, first, misc, cap2};
+        maf_hist_alignment(ref + off[a], qry + off[a], off[a + 1] - off[a], acc);
+    }
+    return 0;
+}

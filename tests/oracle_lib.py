@@ -296,6 +296,35 @@ def cs_hist(cs_list, cap=2048):
     return dict(dic=dic, match_list=m2, error_list=err.reshape(6, 3), first_error=first, max_match=int(mx[0]))
 
 
+def _pack_maf(pairs):
+    """the two lines of every alignment back to back with ONE offset table (both lines of an alignment have the same length)"""
+    r = [a.encode() if isinstance(a, str) else bytes(a) for a, _ in pairs]
+    q = [b.encode() if isinstance(b, str) else bytes(b) for _, b in pairs]
+    assert all(len(a) == len(b) for a, b in zip(r, q))
+    off = np.zeros(len(r) + 1, dtype=np.uint64)
+    np.cumsum([len(a) for a in r], out=off[1:])
+    return np.frombuffer(b"".join(r) + b"\0", dtype=np.uint8), np.frombuffer(b"".join(q) + b"\0", dtype=np.uint8), off
+
+
+def maf_hist(pairs, cap=2048):
+    """hist(prefix, "maf") (src/besthit_to_histogram.py:187-305) through the oracle's column walk (nso_maf_hist); same dict as cs_hist"""
+    L = lib()
+    L.nso_maf_hist.restype = C.c_int
+    L.nso_maf_hist.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 6
+    r, q, off = _pack_maf(pairs)
+    while True:
+        dic = np.zeros((5, 1001), dtype=np.uint64); m2 = np.zeros((cap, cap), dtype=np.uint64)
+        err = np.zeros(18, dtype=np.uint64); first = np.zeros(3, dtype=np.uint64); mx = np.zeros(2, dtype=np.uint64)
+        rc = L.nso_maf_hist(r.ctypes.data, q.ctypes.data, off.ctypes.data, len(pairs), cap, dic.ctypes.data, m2.ctypes.data, err.ctypes.data,
+                            first.ctypes.data, mx[0:].ctypes.data, mx[1:].ctypes.data)
+        if rc:
+            raise RuntimeError("nso_maf_hist failed: %d" % rc)
+        if not mx[1]:
+            break
+        cap = 1 << int(mx[0]).bit_length()
+    return dict(dic=dic, match_list=m2, error_list=err.reshape(6, 3), first_error=first, max_match=int(mx[0]))
+
+
 def parse_cs(cs):
     """(list_hist, list_op) of the oracle's parse_cs restatement"""
     L = lib()

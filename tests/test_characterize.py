@@ -32,14 +32,23 @@ def host_walk():
     L = C.CDLL(so)
     L.csh_host_count.restype = C.c_int
     L.csh_host_count.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 5
+    L.maf_host_count.restype = C.c_int
+    L.maf_host_count.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 5
 
-    def run(cs_list, cap=2048):
-        data, off = O._pack_cs(cs_list)
+    def run(cs_list, cap=2048, maf=False):
+        if maf:
+            ref, qry, off = O._pack_maf(cs_list)
+        else:
+            data, off = O._pack_cs(cs_list)
         while True:
             dic = np.zeros((5, 1001), dtype=np.uint64); m2 = np.zeros((cap, cap), dtype=np.uint64)
             err = np.zeros(18, dtype=np.uint64); first = np.zeros(3, dtype=np.uint64); misc = np.zeros(4, dtype=np.uint64)
-            L.csh_host_count(data.ctypes.data, off.ctypes.data, len(cs_list), cap, dic.ctypes.data, m2.ctypes.data, err.ctypes.data,
-                             first.ctypes.data, misc.ctypes.data)
+            if maf:
+                L.maf_host_count(ref.ctypes.data, qry.ctypes.data, off.ctypes.data, len(cs_list), cap, dic.ctypes.data, m2.ctypes.data,
+                                 err.ctypes.data, first.ctypes.data, misc.ctypes.data)
+            else:
+                L.csh_host_count(data.ctypes.data, off.ctypes.data, len(cs_list), cap, dic.ctypes.data, m2.ctypes.data, err.ctypes.data,
+                                 first.ctypes.data, misc.ctypes.data)
             if not misc[1]:
                 break
             cap = 1 << int(misc[0]).bit_length()
@@ -103,3 +112,41 @@ def test_get_cs_and_sam_reader(fx, tmp_path):
     sam.write_text("@HD\tVN:1.6\nr1\t0\tchr\t1\t60\t10M\t*\t0\t0\tACGTACGTAC\t*\tcs:Z::4*ag:5\nr2\t0\tchr\t1\t60\t5M2I5M\t*\t0\t0\tACGTACGTACGT\t*\tMD:Z:10\n"
                    "r3\t4\t*\t0\t0\t*\t*\t0\t0\tACGT\t*\n")
     assert characterize.cs_from_sam(str(sam)) == [":4*ag:5", ":5+II:5"]
+
+
+# ---- the MAF branch (B:187-305) -------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def fx_maf():
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "reference_hist_maf.json.gz"), "rt") as f:
+        return json.load(f)
+
+
+def test_oracle_maf_counts_give_the_reference_files(fx_maf):
+    """VERDICT r4 "missing" 1: hist(prefix, "maf").  The oracle's column walk (nso_maf_hist) -> counts -> the host's formatting == every
+    file the REAL hist() wrote for the 464 alignments of the fixture (450 oracle reads as aligned line pairs with soft-masked stretches +
+    hand-made corners: a deletion in front of an insertion and the reverse, mismatches next to indels, errors at both ends, a match
+    beyond 1 000 columns), text for text"""
+    got = characterize.format_tables(O.maf_hist(fx_maf["maf"]))
+    assert sorted(got) == sorted(fx_maf["files"])
+    for name, text in fx_maf["files"].items():
+        assert got[name] == text, name
+
+
+def test_maf_walk_of_the_engine_equals_the_oracle(fx_maf, host_walk):
+    """maf_hist_alignment (nanosim_amd/csrc/ns_cs_hist.h: what k_cs_hist runs per thread on MAF input), compiled for the host"""
+    w = host_walk(fx_maf["maf"], maf=True)
+    same_counts(w, O.maf_hist(fx_maf["maf"]))
+    got = characterize.format_tables(w)
+    for name, text in fx_maf["files"].items():
+        assert got[name] == text, name
+    rng = np.random.default_rng(5)
+    for _ in range(40):                                   # random columns: every order of the four column classes, gaps on both lines at once
+        n = int(rng.integers(0, 60))
+        r = "".join(rng.choice(list("ACGTacgt-N"), n)); q = "".join(rng.choice(list("ACGTacgt-N"), n))
+        same_counts(host_walk([(r, q), ("ACGT", "ACGT")], cap=128, maf=True), O.maf_hist([(r, q), ("ACGT", "ACGT")], cap=128))
+
+
+def test_maf_reader(tmp_path):
+    p = tmp_path / "t_besthit.maf"
+    p.write_text("s ref 10 5 + 1000 AC-GT\ns read1 0 5 + 5 ACTGT\ns ref 20 3 + 1000 acg\ns read2 0 3 + 3 ACG\n")
+    assert characterize.maf_pairs(str(p)) == [("AC-GT", "ACTGT"), ("acg", "ACG")]

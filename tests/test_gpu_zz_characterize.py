@@ -67,3 +67,23 @@ def test_gpu_edge_cases_and_many_alignments(fx, eng):
     t = characterize.count(eng, many)
     same_counts(t, O.cs_hist(many))
     assert t["ms_kernel"] > 0
+
+
+def test_gpu_maf_counts_equal_the_oracle_and_the_reference_files(eng, tmp_path):
+    """the MAF branch (B:187-305) through ns_maf_histograms: GPU == oracle == the files the REAL hist(prefix, "maf") wrote"""
+    import gzip
+    import json
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "reference_hist_maf.json.gz"), "rt") as f:
+        fxm = json.load(f)
+    pairs = [tuple(p) for p in fxm["maf"]]
+    same_counts(characterize.count_maf(eng, pairs, cap=256), O.maf_hist(pairs))
+    maf = tmp_path / "training_besthit.maf"
+    with open(maf, "w") as f:
+        for i, (r, q) in enumerate(pairs):
+            f.write("s ref 0 %d + 1000000 %s\ns read%d 0 %d + %d %s\n" % (len(r), r, i, len(q), len(q), q))
+    characterize.hist(str(tmp_path / "training"), characterize.maf_pairs(str(maf)), eng, alnm_ftype="maf")
+    for name, text in fxm["files"].items():
+        assert open(str(tmp_path / "training") + name).read() == text, name
+    rng = np.random.default_rng(9)
+    many = [pairs[i] for i in rng.integers(0, len(pairs), 20 * len(pairs))] + [("", ""), ("A-C", "AT-")]
+    same_counts(characterize.count_maf(eng, many), O.maf_hist(many))
