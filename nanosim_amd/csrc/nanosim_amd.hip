@@ -2146,7 +2146,11 @@ static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fast
     hipStream_t st = ctx->stream;
     if (A.prm.kind == NS_KIND_UNALIGNED) {
         // work list: stretches per read + scan (list_b / list_c are free once the passes are done); the grid is bounded from the batch's
-        // total: every read adds at most one partial stretch
+        // total: every read adds at most one partial stretch.  (Round 5, next to an aligned worker call — ns_generate_step — the unaligned
+        // call ends ~0.75 ms after the aligned one: its dense kernel gets no wavefront slots while the record kernel's grid still has
+        // workgroups to start.  Neither fewer launches in this tail — plan + both scans as ONE single-workgroup kernel: 10.0-10.2 against
+        // 9.7 ms per step — nor the aligned record kernel as two launches on two streams (80 % + 20 %: 9.75-9.82 against 9.81-10.1, noise)
+        // nor stream priorities moved it: profiles/r05/ab_step_gate.log.)
         uint32_t *cnt = (uint32_t *)ctx->list_b.p, *seg_off = (uint32_t *)ctx->list_c.p;
         k_dense_plan<<<dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st>>>(A, cnt);
         HIPCHK(hipGetLastError());
@@ -3192,7 +3196,8 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     const uint64_t max_unaligned = prm->kind == NS_KIND_UNALIGNED ? stats[1] : 0;      // emitted bases of the batch (k_chain): bounds the dense kernel's grid
     HIPCHK(hipEventRecord(ctx->evt[5], st));
     const bool write_rec = prm->emit_records == 1u;            // (2 = NS_EMIT_SIZES: the sizes of the images only)
-    const bool side_names = !A.hp && write_rec;               // names + framing on the second stream, next to the record kernel
+    const bool side_names = write_rec;                        // names + framing on the second stream, next to the record kernel (round 5: also
+                                                              // next to the second record pass of -k: 0.37 ms per 950 000 reads on the main stream)
     if (side_names) {
         HIPCHK(hipEventRecord(ctx->ev_fork, st));
         HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
