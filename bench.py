@@ -234,7 +234,6 @@ class Workload:
         for e in self.own_engs:
             e.load_model(self.mdl)
         self.max_len = min(int(np.diff(chrom_off.astype(np.int64)).max()), 1 << 30)
-        self.unaligned_delay_s = max(0.0, getattr(a, "unaligned_delay_ms", 0.0)) * 1e-3
 
     def describe(self):
         mode = "metagenome mode" if self.meta else "genome mode"
@@ -284,11 +283,7 @@ class Workload:
             if after_unaligned:
                 after_unaligned(b_un)
             return out
-        def late_unaligned():
-            if self.unaligned_delay_s > 0:
-                time.sleep(self.unaligned_delay_s)
-            unaligned(self.eng_un)
-        t = threading.Thread(target=late_unaligned)      # (the C call releases the GIL)
+        t = threading.Thread(target=unaligned, args=(self.eng_un,))      # --python-threads (the C call releases the GIL)
         t.start(); aligned(); t.join()
         return out
 
@@ -588,7 +583,6 @@ def main():
     ap.add_argument("--no-genome-run", action="store_true", help="same as --aligned-only (kept for the profiling scripts)")
     ap.add_argument("--cpu-sample", type=int, default=5000, help="reads PER CORE of the CPU baseline sample (about 10 s with every core busy)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU test of the N>1 path)")
-    ap.add_argument("--unaligned-delay-ms", type=float, default=0.0, help="start the unaligned worker call of a step this long after the aligned one")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end legs (generation + D2H + file writes)")
     ap.add_argument("--e2e-steps", type=int, default=3)
     ap.add_argument("--e2e-dir", default="/dev/shm")

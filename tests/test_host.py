@@ -394,6 +394,20 @@ def test_run_phases_runs_both_worker_calls_side_by_side_and_reports_failures(cap
     assert done == [1, 2]
 
 
+def test_no_merge_flag_is_the_keep_subfiles_switch(monkeypatch):
+    """--no-merge (round 5; not in the reference): the -t K sub-files stay and <file>.subfiles lists them — what NS_KEEP_SUBFILES=1 did"""
+    seen = {}
+    monkeypatch.delenv("NS_KEEP_SUBFILES", raising=False)
+    for mode, runner in (("genome", "run_genome"), ("metagenome", "run_metagenome"), ("transcriptome", "run_transcriptome")):
+        monkeypatch.setattr(simulator, runner, lambda a, p, mode=mode: seen.__setitem__(mode, (a.no_merge, os.environ.get("NS_KEEP_SUBFILES"))))
+    simulator.main(["genome", "-rg", "r.fa", "-t", "4", "--no-merge"])
+    assert seen["genome"] == (True, "1")
+    monkeypatch.delenv("NS_KEEP_SUBFILES", raising=False)
+    simulator.main(["metagenome", "-gl", "g.tsv", "-a", "a.tsv", "-dl", "d.tsv"])
+    simulator.main(["transcriptome", "-rt", "t.fa", "-e", "e.tsv", "--no-merge"])
+    assert seen["metagenome"] == (False, None) and seen["transcriptome"][0] is True
+
+
 class _StepFake:
     """what StepPair uses of an Engine: generate / generate_step / step_engine, recording who served which request"""
     def __init__(self, fail_step_at=None):
