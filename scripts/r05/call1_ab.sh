@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, GPU call 1: the prepared variants (scripts/r05/chain_ab.sh build) timed FIRST — per variant one bench run whose line carries the
+# round 5, GPU call 1: the prepared variants (scripts/ab_build.sh with the flags of round 4; the flags and their code are gone since: DESIGN.md section 6) timed FIRST — per variant one bench run whose line carries the
 # two-context step, the serial step (each worker call's kernels alone), and errlog_on — then the bit-exact parity tests of each.
 cd "$(dirname "$0")/../.."
 O=gpurun_out/r05a; mkdir -p $O
