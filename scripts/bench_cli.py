@@ -15,7 +15,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("-n", type=int, default=2_000_000)
 ap.add_argument("--fastq", action="store_true")
 ap.add_argument("--dir", default="/dev/shm")
-ap.add_argument("-t", type=int, default=1, help="sub-files per batch (the CLI's -t); with NS_KEEP_SUBFILES=1 they are kept")
+ap.add_argument("-t", type=int, default=1, help="sub-files per batch (the CLI's -t)")
+ap.add_argument("--no-merge", action="store_true", help="keep the sub-files (the CLI's --no-merge)")
 a = ap.parse_args()
 d = tempfile.mkdtemp(prefix="nscli_", dir=a.dir)
 try:
@@ -24,7 +25,7 @@ try:
     fa = os.path.join(d, "ecoli_like.fa")
     synth.write_fasta(fa, [("ecoli-like", synth.synth_sequence(synth.ECOLI_LEN, 1, n_frac=0.0005, iupac_frac=0.0002, lower_frac=0.02, hp_boost=0.005))])
     out = os.path.join(d, "sim")
-    argv = ["genome", "-rg", fa, "-c", prefix, "-o", out, "-n", str(a.n), "--seed", "1", "-dna_type", "circular", "-t", str(a.t)] + (["--fastq"] if a.fastq else [])
+    argv = ["genome", "-rg", fa, "-c", prefix, "-o", out, "-n", str(a.n), "--seed", "1", "-dna_type", "circular", "-t", str(a.t)] + (["--fastq"] if a.fastq else []) + (["--no-merge"] if a.no_merge else [])
     so = sys.stdout
     sys.stdout = open(os.devnull, "w")
     t0 = time.perf_counter()
