@@ -3057,9 +3057,13 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         k_nseg<<<grid_t, blk, 0, st>>>(A);
         HIPCHK(hipGetLastError());
         if ((rc = scan_u32(ctx, A.n_pieces, A.piece_off, n + 1))) return rc;
-        uint32_t tp32 = 0;
-        if ((rc = read_small(ctx, st, &tp32, A.piece_off + n, 4))) return rc;
-        tot_pieces = tp32;
+        // one piece per read unless the batch is chimeric (k_nseg): the total is n then, without a read-back (one stream round trip less
+        // per worker call)
+        if (prm->kind == NS_KIND_ALIGNED && prm->chimeric) {
+            uint32_t tp32 = 0;
+            if ((rc = read_small(ctx, st, &tp32, A.piece_off + n, 4))) return rc;
+            tot_pieces = tp32;
+        } else tot_pieces = n;
         if ((rc = ensure(ctx, ctx->pieces, (size_t)tot_pieces * sizeof(ns_piece) + 64))) return rc;
         A.pieces = (ns_piece *)ctx->pieces.p;
         A.list = nullptr; A.list_n = (uint32_t)n; A.attempt = 0;
