@@ -343,11 +343,11 @@ typedef struct ns_io_stats {
 int ns_io_counters(ns_ctx *ctx, ns_io_stats *out, int reset);
 
 /* ---- training side: the histograms of the characterisation stage ---------------------------------------------------------------------
- * replaces the counting loop of src/besthit_to_histogram.py:hist() (B:308-355 over parse_cs, B:42-72): from the cs strings of the primary
+ * replaces the counting loop of src/besthit_to_histogram.py:hist() (B:316-365 over parse_cs, B:41-69): from the cs strings of the primary
  * alignments (minimap2's short form: `:N` match, `*xy` mismatch, `+seq` insertion, `-seq` deletion) to
  *   dic[0..4]    run-length histograms of add_dict (B:14-22; values above 1000 are not counted): matches between errors, the first
  *                match of every alignment, mismatch runs, insertions, deletions           -> _match.hist, _first_match.hist, _mis/_ins/_del.hist
- *   match_list   (previous match, next match) counts of add_match (B:25-39; no upper limit) -> _match_markov_model
+ *   match_list   (previous match, next match) counts of add_match (B:25-38; no upper limit) -> _match_markov_model
  *   error_list   error transitions, row = mis, ins, del, mis0, ins0, del0 (the previous error, "0": no match in between), column = mis,
  *                ins, del; first_error: the first error of every alignment                   -> _error_markov_model
  * cs: the strings back to back, aln_off[n_aln + 1] their offsets (host memory; copied to the device).  The tables the reference writes
@@ -367,7 +367,7 @@ typedef struct ns_cs_hist {
 } ns_cs_hist;
 enum { NS_CSH_MATCH = 0, NS_CSH_FIRST_MATCH = 1, NS_CSH_MIS = 2, NS_CSH_INS = 3, NS_CSH_DEL = 4 };
 int ns_cs_histograms(ns_ctx *ctx, const uint8_t *cs, uint64_t nbytes, const uint64_t *aln_off, uint32_t n_aln, ns_cs_hist *h);
-/* The MAF branch of the same loop (B:187-305): <prefix>_besthit.maf carries two `s` lines per alignment, the aligned reference and query
+/* The MAF branch of the same loop (B:188-315): <prefix>_besthit.maf carries two `s` lines per alignment, the aligned reference and query
  * sequences with '-' for gaps.  ref_lines / query_lines: those lines (field 7) of all alignments back to back, alignment a at
  * aln_off[a] .. aln_off[a + 1] of BOTH (the two lines of an alignment have the same length; nbytes = aln_off[n_aln]).  Same counters,
  * same struct; per alignment the state of the reference's column walk (its four pending run lengths, prev_match and prev_error reset

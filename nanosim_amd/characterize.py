@@ -1,8 +1,8 @@
 """Training side, the histogramming step of the characterisation stage (second half): a drop-in for
 ``hist(prefix, "bam")`` of src/besthit_to_histogram.py (B:148-486) from the cs strings of the primary alignments on.
 
-The reference walks every alignment in Python (parse_cs B:42-72, then the loop B:308-355) and fills dictionaries; the tables it writes
-afterwards (B:357-486) are what ``simulator.py`` reads back as the error model (``read_profile``, src/simulator.py:473-501).  Here the
+The reference walks every alignment in Python (parse_cs B:41-69, then the loop B:316-365) and fills dictionaries; the tables it writes
+afterwards (B:366-486) are what ``simulator.py`` reads back as the error model (``read_profile``, src/simulator.py:473-501).  Here the
 walk runs on the GPU through the C-ABI (``ns_cs_histograms``: one alignment per thread, include/nanosim_amd.h) and this module does
 what is left: getting the cs strings out of a SAM file and formatting the reference's files from the counts, text for text.
 
@@ -10,7 +10,7 @@ what is left: getting the cs strings out of a SAM file and formatting the refere
     eng = engine.Engine(0)
     characterize.hist("training", characterize.cs_from_sam("training_primary.sam"), eng)
 
-    characterize.hist("training", characterize.maf_pairs("training_besthit.maf"), eng, alnm_ftype="maf")      # hist(prefix, "maf"), B:187-305
+    characterize.hist("training", characterize.maf_pairs("training_besthit.maf"), eng, alnm_ftype="maf")      # hist(prefix, "maf"), B:188-315
 
 Not covered: BAM input (pysam is not a dependency here: convert with ``samtools view -h``).
 """
@@ -38,7 +38,7 @@ _CIGAR_TOKEN = re.compile(r'(\d+)([MIDSHX=])')          # (no N: introns are not
 
 
 def get_cs(cigar_str: str, md_str: str) -> str:
-    """The cs string the reference derives for an alignment that carries only CIGAR + MD (B:79-130).  It models indels and mismatches,
+    """The cs string the reference derives for an alignment that carries only CIGAR + MD (B:76-132).  It models indels and mismatches,
     not bases: a mismatch is always `*ab`, an inserted base `I`.  Written as a walk of the MD items over a cursor into the CIGAR; the
     reference's corner behaviour is kept because its histograms depend on it: an MD item that ends exactly where an M block ends closes
     the block as a MATCH of the remaining length (so a mismatch in the last column of a block counts as `:1`, and an item that starts at
@@ -80,7 +80,7 @@ def get_cs(cigar_str: str, md_str: str) -> str:
 
 
 def cs_from_sam(path: str):
-    """the cs string of every alignment of a SAM text file: the cs:Z tag, else from CIGAR + MD:Z (B:311-315)"""
+    """the cs string of every alignment of a SAM text file: the cs:Z tag, else from CIGAR + MD:Z (B:320-324)"""
     out = []
     with open(path) as f:
         for line in f:
@@ -126,7 +126,7 @@ def count(eng, cs_list, cap: int = 2048) -> dict:
 
 
 def maf_pairs(path: str):
-    """[(reference line, query line)] of `<prefix>_besthit.maf` as hist(prefix, "maf") reads it (B:192-202): the file holds two `s` lines
+    """[(reference line, query line)] of `<prefix>_besthit.maf` as hist(prefix, "maf") reads it (B:190-198): the file holds two `s` lines
     per alignment and nothing else; field 7 of each is the aligned sequence (the upper-casing is done by the counting walk)"""
     out = []
     with open(path) as f:
@@ -135,7 +135,7 @@ def maf_pairs(path: str):
             q = next(f).strip().split()
             if len(r) < 7 or len(q) < 7 or len(r[6]) > len(q[6]):
                 raise ValueError("%s: not two `s` lines with an aligned sequence each (the reference would stop with an IndexError)" % path)
-            out.append((r[6], q[6][:len(r[6])]))                   # (the walk runs over len(ref), B:207)
+            out.append((r[6], q[6][:len(r[6])]))                   # (the walk runs over len(ref), B:203)
     return out
 
 
@@ -167,7 +167,7 @@ def _dict_len(cnt, initial):
 
 
 def format_tables(t: dict) -> dict:
-    """{file suffix: text} exactly as hist() writes them (B:357-486) from the counts"""
+    """{file suffix: text} exactly as hist() writes them (B:366-486) from the counts"""
     dic, m2 = t["dic"], t["match_list"]
     out = {}
     totals = {}
@@ -186,7 +186,7 @@ def format_tables(t: dict) -> dict:
     out["_error_rate.tsv"] = ("Mismatch rate:\t" + str(total_mis * 1.0 / den) + '\n' + "Insertion rate:\t" + str(total_ins * 1.0 / den) + '\n' +
                               "Deletion rate:\t" + str(total_del * 1.0 / den) + '\n' +
                               "Total error rate:\t" + str((total_mis + total_ins + total_del) * 1.0 / den) + '\n')
-    # error Markov model (B:391-409)
+    # error Markov model (B:404-422)
     err = t["error_list"]
     first = [int(x) for x in t["first_error"]]
     num_first = sum(first)
@@ -198,7 +198,7 @@ def format_tables(t: dict) -> dict:
         for c in range(3):
             s += "\t" + ("0" if pred == 0 else str(int(err[r][c]) * 1.0 / pred))
     out["_error_markov_model"] = s
-    # match Markov model (B:411-466).  The previous-match lengths are cut into <= 15 consecutive bins of about total / 15 pairs each:
+    # match Markov model (B:424-476).  The previous-match lengths are cut into <= 15 consecutive bins of about total / 15 pairs each:
     # a bin takes rows while it is below the target and stops in front of a row that would carry it further from the target than it is
     # (never in front of its first row); rows left over behind the 15th bin are added to its counts (its label keeps the old end)
     n = max(150, t["max_match"] + 1)
@@ -234,7 +234,7 @@ def format_tables(t: dict) -> dict:
                 cells.append(str(running[j]))
         lines.append("\t".join(cells) + '\n')
     out["_match_markov_model"] = "".join(lines)
-    # first match profile (B:468-476)
+    # first match profile (B:478-486)
     nf = _dict_len(dic[1], 150)
     total_first = int(dic[1][:nf].sum())
     lines = ["bin\t0-50000\n"]

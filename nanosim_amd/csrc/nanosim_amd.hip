@@ -885,7 +885,7 @@ k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, co
     }
 }
 
-// k_qualities: the quality line of one read per wavefront (predict_base_qualities per class, bq:183-193; classes S:1421-1423, 1953-1955,
+// k_qualities: the quality line of one read per wavefront (predict_base_qualities per class, bq:120-130, the truncated log-normal of bq:9-20; classes S:1421-1423, 1953-1955,
 // 1564), from the class words k_materialise<true, .> left.  HPF: second record pass of -k (piece lengths after mutate_homo).
 template <bool HPF>
 __global__ void __launch_bounds__(64 * NS_MATQ_WAVES, NS_MATQ_MINW) k_qualities(GenArgs A, const uint32_t *order) {

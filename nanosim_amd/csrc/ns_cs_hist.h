@@ -3,11 +3,11 @@
 // alignment, the (previous match, next match) matrix behind _match_markov_model, and the error transitions behind _error_markov_model —
 // as ONE streaming pass per alignment.  B: = src/besthit_to_histogram.py of bcgsc/NanoSim v3.2.2.
 //
-// The reference works in two steps: parse_cs (B:42-72) turns the string into two lists (one entry per op, a run of `*xy` items folded
-// into one "mis" op that carries its count), then hist() walks the list with a little state (B:308-355): `flag` (no error seen yet in
+// The reference works in two steps: parse_cs (B:41-69) turns the string into two lists (one entry per op, a run of `*xy` items folded
+// into one "mis" op that carries its count), then hist() walks the list with a little state (B:316-365): `flag` (no error seen yet in
 // this alignment), prev_error, prev_match, and two looks sideways — the op BEFORE an error (Python's list[i - 1]: for the first op
 // that is the LAST op of the alignment) and whether a match is the last op.  Both looks are local, so the walk streams: the items are
-// tokenised on the fly (the regex of B:45), folded, and an op is accounted for when the op behind it is known.
+// tokenised on the fly (the regex of B:46), folded, and an op is accounted for when the op behind it is known.
 // The code below compiles for the device (k_cs_hist) and, unchanged, for the host (tests/cs_hist_host.cpp: the CPU tests run the very
 // same walk against the oracle's two-list restatement and the reference's files).
 #pragma once
@@ -19,11 +19,11 @@
 #define NS_CSH static inline
 #endif
 
-enum { CS_MATCH = 0, CS_MIS = 1, CS_INS = 2, CS_DEL = 3, CS_SKIP = 4 };         // conv_op_to_word (B:133-143)
+enum { CS_MATCH = 0, CS_MIS = 1, CS_INS = 2, CS_DEL = 3, CS_SKIP = 4 };         // conv_op_to_word (B:135-145)
 enum { CSH_MATCH = 0, CSH_FIRST = 1, CSH_MIS = 2, CSH_INS = 3, CSH_DEL = 4 };    // the five 1-D histograms (add_dict, B:14-22)
 #define NS_CS_DICT_MAX 1000u      // add_dict ignores values above it (B:15-16)
 
-// the next item of the cs string at or after i — re.findall('(:[0-9]+|\*[a-z][a-z]|[=\+\-][A-Za-z]+)') of B:45: what matches nothing
+// the next item of the cs string at or after i — re.findall('(:[0-9]+|\*[a-z][a-z]|[=\+\-][A-Za-z]+)') of B:46: what matches nothing
 // is skipped one character at a time
 NS_CSH bool cs_next_item(const uint8_t *s, uint64_t n, uint64_t &i, int &type, uint32_t &len) {
     while (i < n) {
@@ -52,7 +52,7 @@ NS_CSH bool cs_next_op(const uint8_t *s, uint64_t n, CsCursor &c, int &type, uin
     if (!c.have) { if (!cs_next_item(s, n, c.i, t, l)) return false; c.have = true; c.type = t; c.len = l; }
     type = c.type; len = c.len;
     c.have = false;
-    if (type == CS_MIS) {                                       // fold the mismatch items that follow (B:50-53, 66-67)
+    if (type == CS_MIS) {                                       // fold the mismatch items that follow (B:49-52, 64-65)
         while (cs_next_item(s, n, c.i, t, l)) {
             if (t != CS_MIS) { c.have = true; c.type = t; c.len = l; break; }
             ++len;
@@ -61,12 +61,12 @@ NS_CSH bool cs_next_op(const uint8_t *s, uint64_t n, CsCursor &c, int &type, uin
     return true;
 }
 
-// the walk of hist() over one alignment (B:320-355).  prev_match: in = the value the previous alignments left (the reference never
+// the walk of hist() over one alignment (B:328-365).  prev_match: in = the value the previous alignments left (the reference never
 // resets it), out = what this one leaves; *assigned: the alignment assigned it.  n_skip counts `=` items (long-form cs): the reference's
 // two lists fall out of step on them, the caller refuses such input.
 template <class Acc>
 NS_CSH void cs_hist_alignment(const uint8_t *s, uint64_t n, uint32_t &prev_match, bool *assigned, Acc &acc) {
-    // the type of the last op: what list_op_unique[i - 1] is for i = 0 (B:324)
+    // the type of the last op: what list_op_unique[i - 1] is for i = 0 (B:332)
     int last_type = CS_SKIP;
     { CsCursor c; cs_cursor_init(c); int t; uint32_t l; while (cs_next_op(s, n, c, t, l)) last_type = t; }
     CsCursor c; cs_cursor_init(c);
@@ -78,7 +78,7 @@ NS_CSH void cs_hist_alignment(const uint8_t *s, uint64_t n, uint32_t &prev_match
         int tn = CS_SKIP; uint32_t ln = 0;
         const bool has_next = cs_next_op(s, n, c, tn, ln);
         if (t == CS_SKIP) acc.skip();
-        else if (t != CS_MATCH) {                               // B:323-343
+        else if (t != CS_MATCH) {                               // B:331-352
             const bool zero = prev_type != CS_MATCH;            // exact_prev_op != "match": prev_error += "0"
             if (flag) { flag = false; acc.first((uint32_t)(t - CS_MIS)); }
             else acc.err((uint32_t)((prev_error - CS_MIS) + (zero ? 3 : 0)) * 3u + (uint32_t)(t - CS_MIS));
@@ -88,12 +88,12 @@ NS_CSH void cs_hist_alignment(const uint8_t *s, uint64_t n, uint32_t &prev_match
                 if (zero) { acc.d1(CSH_MATCH, 0); acc.m2(prev_match, 0); prev_match = 0; if (assigned) *assigned = true; }
             } else if (t == CS_DEL) acc.d1(CSH_DEL, l);
             else acc.d1(CSH_INS, l);
-        } else {                                                // B:344-355
+        } else {                                                // B:353-364
             if (flag) { acc.d1(CSH_FIRST, l); prev_match = l; if (assigned) *assigned = true; }
             else if (!has_next) acc.m2(prev_match, l);
             else { acc.d1(CSH_MATCH, l); acc.m2(prev_match, l); prev_match = l; if (assigned) *assigned = true; }
         }
-        if (t != CS_SKIP) prev_type = t;                        // (a `skip` op is not looked at by conv_op_to_word's callers: B:322)
+        if (t != CS_SKIP) prev_type = t;                        // (a `skip` op is not looked at by conv_op_to_word's callers: B:330-332)
         else prev_type = CS_SKIP;
         t = tn; l = ln; more = has_next;
     }
@@ -119,7 +119,7 @@ NS_CSH uint32_t cs_carry_in(const uint8_t *cs, const uint64_t *off, uint64_t a) 
     return 0;
 }
 
-// ---- the MAF branch of hist() (B:187-305): the two aligned lines of an alignment, column by column ------------------------------------
+// ---- the MAF branch of hist() (B:188-315): the two aligned lines of an alignment, column by column ------------------------------------
 // Same counters, another tokenizer: a column is a match (equal letters after upper()), an inserted base (reference '-'), a deleted base
 // (query '-') or a mismatch.  The reference keeps FOUR pending run lengths and flushes at most one of them per column through its
 // `elif` chains — so a deletion directly in front of an insertion leaves both pending, and the one that is tested later waits until the
@@ -146,17 +146,17 @@ NS_CSH void maf_hist_alignment(const uint8_t *ref, const uint8_t *qry, uint64_t 
     };
     for (uint64_t i = 0; i < n; ++i) {
         const uint8_t r = upper(ref[i]), q = upper(qry[i]);
-        if (r == q) {                                                   // B:208-234
+        if (r == q) {                                                   // B:204-234
             if (run.mis) { close_error(0, run.mis, false); run.mis = 0; }
             else if (run.ins) { close_error(1, run.ins, false); run.ins = 0; }
             else if (run.del) { close_error(2, run.del, false); run.del = 0; }
             ++run.match;
             if (i + 1 == n) acc.m2(prev_match, run.match);
-        } else if (r == '-' || q == '-') {                              // B:235-278: an indel column ends a match or a mismatch run
+        } else if (r == '-' || q == '-') {                              // B:235-280: an indel column ends a match or a mismatch run
             if (run.match) close_match();
             else if (run.mis) { close_error(0, run.mis, true); run.mis = 0; }
             if (r == '-') ++run.ins; else ++run.del;
-        } else {                                                        // B:279-305: a mismatch column ends a match or an indel run
+        } else {                                                        // B:281-315: a mismatch column ends a match or an indel run
             if (run.match) close_match();
             else if (run.ins) { close_error(1, run.ins, true); run.ins = 0; }
             else if (run.del) { close_error(2, run.del, true); run.del = 0; }

@@ -546,7 +546,7 @@ enum { MAT_REF = 0,          // the reference -> the record (qualities drawn her
        MAT_HP_SCRATCH = 1,   // -k, first pass: the reference -> the pre-homopolymer read in the scratch buffer (class bits kept, no qualities)
        MAT_HP_FINAL = 2 };   // -k, second pass: the scratch read + the homopolymer edits as its event list -> the record
 
-// ---- qualities (predict_base_qualities, bq:183-193; classes S:1421-1423, 1953-1955) --------------------------------------------------
+// ---- qualities (predict_base_qualities, bq:120-130, the truncated log-normal of bq:9-20; classes S:1421-1423, 1953-1955) --------------------------------------------------
 // The 16-bit draw of emitted piece position m is halfword m & 7 of Philox(ST_QUAL, sid, attempt, idx = m >> 3).
 __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t lane0_value, uint32_t v) {      // lane l gets v of lane l - 1, lane 0 gets lane0_value
     return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0_value, (int)v, 0x138, 0xf, 0xf, false);

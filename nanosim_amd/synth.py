@@ -56,7 +56,7 @@ class SynthModelSpec:
     mm_means: tuple = (24.0, 26.0, 28.0, 30.0, 31.0, 32.0, 34.0, 36.0)
     mm_zero: tuple = (0.0, 0.02, 0.03, 0.03, 0.03, 0.03, 0.03, 0.03)   # P(match length 0)
     fm_mean: float = 18.0
-    # base qualities: type -> (sd, loc, mu)   (src/model_base_qualities.py:146-159)
+    # base qualities: type -> (sd, loc, mu)   (src/model_base_qualities.py:82-96)
     quals: dict = field(default_factory=lambda: {
         "mis": (0.50, 0.0, 2.2), "ins": (0.48, 0.0, 2.3), "match": (0.35, 0.0, 3.2),
         "ht": (0.45, 0.0, 2.6), "unmapped": (0.42, 0.0, 2.4)})
@@ -168,7 +168,7 @@ def write_model(prefix: str, spec: SynthModelSpec | None = None, *, write_pkl: b
     with open(prefix + "_chimeric_info", "w") as f:           # src/get_primary_sam.py:472-475
         f.write("Mean segments for each aligned read:\t" + str(spec.segment_mean) + "\n")
         f.write("Shrinkage rate (beta):\t" + str(spec.abun_inflation) + "\n")
-    with open(prefix + "_base_qualities_model_parameters.tsv", "w") as f:   # src/model_base_qualities.py:146-159
+    with open(prefix + "_base_qualities_model_parameters.tsv", "w") as f:   # src/model_base_qualities.py:82-96
         f.write("type\tsd\tloc\tmu\n")
         for t in ("mis", "ins", "match", "ht", "unmapped"):
             sd, loc, mu = spec.quals[t]

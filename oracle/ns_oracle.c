@@ -1684,7 +1684,7 @@ static void cs_push_hist(nso_cs_lists *l, int64_t v) { if (l->n_hist + 1 > l->ca
 static void cs_push_op(nso_cs_lists *l, char c) { if (l->n_op + 1 > l->cap) { l->cap = 2 * l->cap + 64; l->hist = (int64_t *)realloc(l->hist, l->cap * sizeof(int64_t)); l->op = (char *)realloc(l->op, l->cap); } l->op[l->n_op++] = c; }
 static int cs_is_alpha(uint8_t c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); }
 
-/* parse_cs (B:42-72): items of re.findall('(:[0-9]+|\*[a-z][a-z]|[=\+\-][A-Za-z]+)') */
+/* parse_cs (B:41-69): items of re.findall('(:[0-9]+|\*[a-z][a-z]|[=\+\-][A-Za-z]+)') */
 static void nso_parse_cs(const uint8_t *s, uint64_t n, nso_cs_lists *l) {
     int64_t mis = 0;
     int prev_mis = 0;                                  /* prev_op == "mis" (prev_op starts as "start") */
@@ -1699,21 +1699,21 @@ static void nso_parse_cs(const uint8_t *s, uint64_t n, nso_cs_lists *l) {
         else if (c == '+' || c == '-' || c == '=') { while (j < n && cs_is_alpha(s[j])) ++j; ok = j > i + 1; }
         if (!ok) { ++i; continue; }
         const int is_mis = c == '*';
-        if (!is_mis) cs_push_op(l, (char)c);                                   /* B:50-51 */
-        else if (!prev_mis) cs_push_op(l, (char)c);                            /* B:52-53 */
+        if (!is_mis) cs_push_op(l, (char)c);                                   /* B:49-50 */
+        else if (!prev_mis) cs_push_op(l, (char)c);                            /* B:51-52 */
         prev_mis = is_mis;
-        if (c == '+' || c == '-') {                                            /* B:55-59 */
+        if (c == '+' || c == '-') {                                            /* B:54-58 */
             if (mis != 0) { cs_push_hist(l, mis); mis = 0; }
             cs_push_hist(l, (int64_t)(j - i - 1));
-        } else if (c == ':') {                                                 /* B:60-64 */
+        } else if (c == ':') {                                                 /* B:59-63 */
             if (mis != 0) { cs_push_hist(l, mis); mis = 0; }
             int64_t v = 0;
             for (uint64_t k = i + 1; k < j; ++k) { v = v * 10 + (s[k] - '0'); if (v > 0xffffffffll) v = 0xffffffffll; }
             cs_push_hist(l, v);
-        } else if (is_mis) mis += 1;                                           /* B:65-66 ("skip" items add nothing) */
+        } else if (is_mis) mis += 1;                                           /* B:64-65 ("skip" items add nothing) */
         i = j;
     }
-    if (mis != 0) cs_push_hist(l, mis);                                        /* B:68-69 */
+    if (mis != 0) cs_push_hist(l, mis);                                        /* B:67-68 */
 }
 int nso_parse_cs_lists(const uint8_t *s, uint64_t n, int64_t *hist, char *op, uint32_t cap, uint32_t *n_hist, uint32_t *n_op) {
     nso_cs_lists l; memset(&l, 0, sizeof l);
@@ -1727,8 +1727,8 @@ int nso_parse_cs_lists(const uint8_t *s, uint64_t n, int64_t *hist, char *op, ui
 
 static int cs_word(char op) { return op == ':' ? 0 : op == '*' ? 1 : op == '+' ? 2 : op == '-' ? 3 : 4; }   /* conv_op_to_word: match mis ins del skip */
 
-/* hist(), the bam branch (B:308-355).  dic: [5][1001] = dic_match, dic_first_match, dic_mis, dic_ins, dic_del (add_dict, B:14-22);
- * match_list: dense cap2 x cap2 (add_match, B:25-39); error_list: rows mis, ins, del, mis0, ins0, del0 x columns mis, ins, del.
+/* hist(), the bam branch (B:316-365).  dic: [5][1001] = dic_match, dic_first_match, dic_mis, dic_ins, dic_del (add_dict, B:14-22);
+ * match_list: dense cap2 x cap2 (add_match, B:25-38); error_list: rows mis, ins, del, mis0, ins0, del0 x columns mis, ins, del.
  * Returns 0; -2: list_hist shorter than list_op (an `=` item: the reference raises IndexError or counts garbage). */
 int nso_cs_hist(const uint8_t *cs, const uint64_t *off, uint32_t n_aln, uint32_t cap2, uint64_t *dic, uint64_t *match_list,
                 uint64_t *error_list, uint64_t *first_error, uint64_t *max_match, uint64_t *overflow) {
@@ -1740,13 +1740,13 @@ int nso_cs_hist(const uint8_t *cs, const uint64_t *off, uint32_t n_aln, uint32_t
 #define NSO_ADD_MATCH(p, q) do { int64_t p_ = (p), q_ = (q), m_ = p_ > q_ ? p_ : q_; if ((uint64_t)m_ > *max_match) *max_match = (uint64_t)m_; \
         if (match_list && m_ < (int64_t)cap2) match_list[(uint64_t)p_ * cap2 + (uint64_t)q_] += 1; else *overflow += 1; } while (0)
     for (uint32_t a = 0; a < n_aln && !rc; ++a) {
-        nso_parse_cs(cs + off[a], off[a + 1] - off[a], &l);                    /* B:316 */
-        int flag = 1;                                                          /* B:318 */
+        nso_parse_cs(cs + off[a], off[a + 1] - off[a], &l);                    /* B:325 */
+        int flag = 1;                                                          /* B:327 */
         for (size_t i = 0; i < l.n_op; ++i) {
-            const int curr = cs_word(l.op[i]);                                 /* B:320 */
-            if (curr == 4) continue;                                           /* B:321 */
+            const int curr = cs_word(l.op[i]);                                 /* B:329 */
+            if (curr == 4) continue;                                           /* B:330 */
             if (i >= l.n_hist) { rc = -2; break; }
-            if (curr != 0) {                                                   /* B:322-343 */
+            if (curr != 0) {                                                   /* B:331-352 */
                 const int exact_prev = cs_word(l.op[(i + l.n_op - 1) % l.n_op]);   /* list_op_unique[i - 1]: Python wraps for i = 0 */
                 int pe = prev_error;
                 if (exact_prev != 0) pe += 3;                                  /* prev_error += "0" */
@@ -1758,7 +1758,7 @@ int nso_cs_hist(const uint8_t *cs, const uint64_t *off, uint32_t n_aln, uint32_t
                     if (exact_prev != 0) { NSO_ADD_DICT(0, 0); NSO_ADD_MATCH(prev_match, 0); prev_match = 0; }
                 } else if (curr == 3) NSO_ADD_DICT(4, l.hist[i]);
                 else NSO_ADD_DICT(3, l.hist[i]);
-            } else {                                                           /* B:344-355 */
+            } else {                                                           /* B:353-364 */
                 const int64_t match = l.hist[i];
                 if (flag) { NSO_ADD_DICT(1, match); prev_match = match; }
                 else if (i == l.n_op - 1) NSO_ADD_MATCH(prev_match, match);
@@ -1772,56 +1772,56 @@ int nso_cs_hist(const uint8_t *cs, const uint64_t *off, uint32_t n_aln, uint32_t
     return rc;
 }
 
-/* hist(), the MAF branch (B:187-305): the two aligned lines of every alignment of <prefix>_besthit.maf, column by column.
+/* hist(), the MAF branch (B:188-315): the two aligned lines of every alignment of <prefix>_besthit.maf, column by column.
  * ref / qry: the two lines of all alignments back to back (same offsets: the lines of an alignment have the same length).
  * Same counters as nso_cs_hist.  The state of the reference's loop is kept as it is — four pending run counters of which the
- * `elif` chains flush ONE per column, prev_match and prev_error reset per alignment (B:194-196), whatever is still pending
+ * `elif` chains flush ONE per column, prev_match and prev_error reset per alignment (B:191-193), whatever is still pending
  * behind the last column is dropped, only a final match reaches match_list (B:233-234).
  * PARITY: pinned against the files the REAL hist(prefix, "maf") wrote (tests/golden/reference_hist_maf.json.gz,
  * make_hist_golden.py --maf). */
-static uint8_t maf_upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }          /* str.upper(), B:199, 202 */
+static uint8_t maf_upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }          /* str.upper(), B:195, 198 */
 int nso_maf_hist(const uint8_t *ref, const uint8_t *qry, const uint64_t *off, uint32_t n_aln, uint32_t cap2, uint64_t *dic, uint64_t *match_list,
                  uint64_t *error_list, uint64_t *first_error, uint64_t *max_match, uint64_t *overflow) {
     *max_match = 0; *overflow = 0;
 #define MAF_ADD_DICT(w, v) do { int64_t v_ = (v); if (v_ <= 1000) dic[(w) * 1001 + v_] += 1; } while (0)                 /* B:14-22 */
 #define MAF_ADD_MATCH(p, q) do { int64_t p_ = (p), q_ = (q), m_ = p_ > q_ ? p_ : q_; if ((uint64_t)m_ > *max_match) *max_match = (uint64_t)m_; \
         if (match_list && m_ < (int64_t)cap2) match_list[(uint64_t)p_ * cap2 + (uint64_t)q_] += 1; else *overflow += 1; } while (0)
-    /* the bookkeeping every flushed error run shares (B:206-211 and its eleven copies): curr = 1 mis, 2 ins, 3 del; next_state = the
+    /* the bookkeeping every flushed error run shares (B:205-213 and its eleven copies): curr = 1 mis, 2 ins, 3 del; next_state = the
      * prev_error it leaves (1..3, or 4..6 for mis0 / ins0 / del0) */
 #define MAF_TRANSITION(curr, next_state) do { if (flag) { flag = 0; first_error[(curr) - 1] += 1; } \
         else { error_list[(prev_error - 1) * 3 + ((curr) - 1)] += 1; } \
         prev_error = (next_state); } while (0)
-    /* a match run ends in front of an error column (B:236-243 and its two copies) */
+    /* a match run ends in front of an error column (B:236-244 and its two copies) */
 #define MAF_FLUSH_MATCH() do { if (flag) { MAF_ADD_DICT(1, match); prev_match = match; } \
         else { MAF_ADD_DICT(0, match); MAF_ADD_MATCH(prev_match, match); prev_match = match; } match = 0; } while (0)
     for (uint32_t a = 0; a < n_aln; ++a) {
         const uint8_t *r = ref + off[a], *q = qry + off[a];
         const uint64_t n = off[a + 1] - off[a];
-        int64_t prev_match = 0, match = 0, mismatch = 0, ins = 0, dele = 0;     /* B:194, 203-206 */
-        int prev_error = 0, flag = 1;                                          /* B:195-196 */
+        int64_t prev_match = 0, match = 0, mismatch = 0, ins = 0, dele = 0;     /* B:191, 199-202 */
+        int prev_error = 0, flag = 1;                                          /* B:192-193 */
         for (uint64_t i = 0; i < n; ++i) {
             const uint8_t rc = maf_upper(r[i]), qc = maf_upper(q[i]);
-            if (rc == qc) {                                                    /* B:208-234 */
+            if (rc == qc) {                                                    /* B:204-234 */
                 if (mismatch != 0) { MAF_ADD_DICT(2, mismatch); mismatch = 0; MAF_TRANSITION(1, 1); }
                 else if (ins != 0) { MAF_ADD_DICT(3, ins); ins = 0; MAF_TRANSITION(2, 2); }
                 else if (dele != 0) { MAF_ADD_DICT(4, dele); dele = 0; MAF_TRANSITION(3, 3); }
                 match += 1;
                 if (i == n - 1 && match != 0) MAF_ADD_MATCH(prev_match, match);
-            } else if (rc == '-') {                                            /* B:235-256: an inserted base */
+            } else if (rc == '-') {                                            /* B:235-257: an inserted base */
                 if (match != 0) MAF_FLUSH_MATCH();
                 else if (mismatch != 0) {
                     MAF_ADD_DICT(2, mismatch); dic[0] += 1; MAF_ADD_MATCH(prev_match, 0); prev_match = 0; mismatch = 0;
                     MAF_TRANSITION(1, 4);
                 }
                 ins += 1;
-            } else if (qc == '-') {                                            /* B:257-278: a deleted base */
+            } else if (qc == '-') {                                            /* B:258-280: a deleted base */
                 if (match != 0) MAF_FLUSH_MATCH();
                 else if (mismatch != 0) {
                     MAF_ADD_DICT(2, mismatch); dic[0] += 1; MAF_ADD_MATCH(prev_match, 0); prev_match = 0; mismatch = 0;
                     MAF_TRANSITION(1, 4);
                 }
                 dele += 1;
-            } else {                                                           /* B:279-305: a mismatch */
+            } else {                                                           /* B:281-315: a mismatch */
                 if (match != 0) MAF_FLUSH_MATCH();
                 else if (ins != 0) {
                     MAF_ADD_DICT(3, ins); MAF_ADD_DICT(0, match); MAF_ADD_MATCH(prev_match, 0); prev_match = 0; ins = 0;

@@ -9,7 +9,7 @@ from the event lists of reads the CPU oracle generates with the small test model
 errors next to each other (the mis0 / ins0 / del0 states), runs of mismatches, matches of every length.
 
     python tests/golden/make_hist_golden.py        -> tests/golden/reference_hist.json.gz
-    python tests/golden/make_hist_golden.py --maf  -> tests/golden/reference_hist_maf.json.gz: hist(prefix, "maf") (B:191-305) on the two
+    python tests/golden/make_hist_golden.py --maf  -> tests/golden/reference_hist_maf.json.gz: hist(prefix, "maf") (B:188-315) on the two
                                                       `s` lines per alignment of a synthetic `<prefix>_besthit.maf`
 """
 import gzip
@@ -132,13 +132,13 @@ def run_reference(cs_list, workdir):
         if rng.random() < 0.3:
             ops.append("%dS" % rng.integers(1, 30))
         cigar_md.append(("".join(ops), "".join(md)))
-    getcs = [[c, m, B.get_cs(c, m)] for c, m in cigar_md]                      # get_cs (B:79-130) by value
+    getcs = [[c, m, B.get_cs(c, m)] for c, m in cigar_md]                      # get_cs (B:76-132) by value
     return files, parsed, getcs
 
 
 def synthetic_maf(n_reads=450, seed=777):
     """(reference line, query line) of pairwise alignments, as the two `s` lines of `<prefix>_besthit.maf` carry them (field 7), from oracle
-    reads: the events of every aligned piece column by column, plus hand-made cases for the corners of the MAF branch (B:191-305)"""
+    reads: the events of every aligned piece column by column, plus hand-made cases for the corners of the MAF branch (B:188-315)"""
     from nanosim_amd import engine as E
     from nanosim_amd import model as M
     from tests import oracle_lib as O
@@ -195,7 +195,7 @@ def run_reference_maf(pairs, workdir):
         sys.path.insert(0, REF_SRC)
     import besthit_to_histogram as B
     prefix = os.path.join(workdir, "training")
-    with open(prefix + "_besthit.maf", "w") as f:                              # two `s` lines per alignment, nothing else (B:192-201)
+    with open(prefix + "_besthit.maf", "w") as f:                              # two `s` lines per alignment, nothing else (B:190-198)
         for i, (r, q) in enumerate(pairs):
             f.write("s ref 0 %d + 1000000 %s\n" % (len(r.replace("-", "")), r))
             f.write("s read%d 0 %d + %d %s\n" % (i, len(q.replace("-", "")), len(q.replace("-", "")), q))

@@ -101,7 +101,7 @@ def test_walk_edge_cases(host_walk):
 
 
 def test_get_cs_and_sam_reader(fx, tmp_path):
-    """cs from CIGAR + MD (B:79-130) — against the reference's own get_cs on recorded inputs — and the SAM reader"""
+    """cs from CIGAR + MD (B:76-132) — against the reference's own get_cs on recorded inputs — and the SAM reader"""
     for cigar, md, cs in fx["get_cs"]:
         assert characterize.get_cs(cigar, md) == cs, (cigar, md)
     assert characterize.get_cs("10M", "10") == ":10"
@@ -114,7 +114,7 @@ def test_get_cs_and_sam_reader(fx, tmp_path):
     assert characterize.cs_from_sam(str(sam)) == [":4*ag:5", ":5+II:5"]
 
 
-# ---- the MAF branch (B:187-305) -------------------------------------------------------------------------------------------------------
+# ---- the MAF branch (B:188-315) -------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def fx_maf():
     with gzip.open(os.path.join(ROOT, "tests", "golden", "reference_hist_maf.json.gz"), "rt") as f:

@@ -70,7 +70,7 @@ def test_gpu_edge_cases_and_many_alignments(fx, eng):
 
 
 def test_gpu_maf_counts_equal_the_oracle_and_the_reference_files(eng, tmp_path):
-    """the MAF branch (B:187-305) through ns_maf_histograms: GPU == oracle == the files the REAL hist(prefix, "maf") wrote"""
+    """the MAF branch (B:188-315) through ns_maf_histograms: GPU == oracle == the files the REAL hist(prefix, "maf") wrote"""
     import gzip
     import json
     with gzip.open(os.path.join(ROOT, "tests", "golden", "reference_hist_maf.json.gz"), "rt") as f:
