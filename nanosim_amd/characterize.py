@@ -72,7 +72,7 @@ def get_cs(cigar_str: str, md_str: str) -> str:
                 at += 1
                 continue
             elif op != 'S':                                 # (H, X, = : the reference never advances on these; minimap2 -a writes M/I/D/S)
-                raise ValueError("CIGAR operation %r is not handled by get_cs (src/besthit_to_histogram.py:99-127)" % op)
+                raise ValueError("CIGAR operation %r is not handled by get_cs (src/besthit_to_histogram.py:100-129)" % op)
             block_end += size
             md_pos += size
             at += 1
@@ -116,7 +116,7 @@ def count(eng, cs_list, cap: int = 2048) -> dict:
         eng._check(eng.L.ns_cs_histograms(eng.ctx, data.ctypes.data, int(off[-1]), off.ctypes.data, len(blobs), C.byref(h)))
         if h.n_skip:
             raise ValueError("long-form cs strings (`=` items) are not supported: the reference's parse_cs loses the pairing of its two "
-                             "lists on them (src/besthit_to_histogram.py:50-66)")
+                             "lists on them (src/besthit_to_histogram.py:49-65)")
         if not h.n_match2d_overflow:
             break
         cap = 1 << int(h.max_match).bit_length()                       # the matrix has to hold index max_match

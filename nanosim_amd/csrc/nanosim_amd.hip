@@ -1608,7 +1608,7 @@ __global__ void __launch_bounds__(64) k_errlog(GenArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_cs_hist: the counting loop of the characterisation stage (ns_cs_hist.h; src/besthit_to_histogram.py:308-355), one alignment per
+// k_cs_hist: the counting loop of the characterisation stage (ns_cs_hist.h; src/besthit_to_histogram.py:316-365), one alignment per
 // thread.  The 1-D histograms and the transition counters are privatised per workgroup in LDS (their hot bins — one-base mismatches,
 // short matches — would serialise millions of atomics on a few addresses) and flushed once; the (previous match, next match) matrix is
 // large and sparse: global atomics.
@@ -3482,7 +3482,7 @@ int ns_io_counters(ns_ctx *ctx, ns_io_stats *out, int reset) {
     return NS_OK;
 }
 
-// the characterisation stage's counting loop (include/nanosim_amd.h: ns_cs_hist; src/besthit_to_histogram.py:308-355)
+// the characterisation stage's counting loop (include/nanosim_amd.h: ns_cs_hist; src/besthit_to_histogram.py:316-365)
 static int histograms(ns_ctx *ctx, const uint8_t *cs, const uint8_t *qry, bool maf, uint64_t nbytes, const uint64_t *aln_off, uint32_t n_aln, ns_cs_hist *h);
 int ns_cs_histograms(ns_ctx *ctx, const uint8_t *cs, uint64_t nbytes, const uint64_t *aln_off, uint32_t n_aln, ns_cs_hist *h) {
     return histograms(ctx, cs, nullptr, false, nbytes, aln_off, n_aln, h);

@@ -3,7 +3,7 @@
 src/besthit_to_histogram.py:hist() is run in the build container on synthetic alignments and what it writes is committed as data.
 
 hist(prefix, "bam") reads `<prefix>_primary.bam` through pysam, which this image lacks; the only thing it uses of an alignment is
-`alnm.get_tag('cs')` (besthit_to_histogram.py:311-317), so the module is imported with a pysam stand-in whose AlignmentFile serves the
+`alnm.get_tag('cs')` (besthit_to_histogram.py:319-325), so the module is imported with a pysam stand-in whose AlignmentFile serves the
 synthetic cs strings.  The cs strings are minimap2's short form (`:N` match, `*xy` mismatch, `+seq` insertion, `-seq` deletion), built
 from the event lists of reads the CPU oracle generates with the small test model — so that they carry what real alignments carry:
 errors next to each other (the mis0 / ins0 / del0 states), runs of mismatches, matches of every length.

@@ -307,7 +307,7 @@ def _pack_maf(pairs):
 
 
 def maf_hist(pairs, cap=2048):
-    """hist(prefix, "maf") (src/besthit_to_histogram.py:187-305) through the oracle's column walk (nso_maf_hist); same dict as cs_hist"""
+    """hist(prefix, "maf") (src/besthit_to_histogram.py:188-315) through the oracle's column walk (nso_maf_hist); same dict as cs_hist"""
     L = lib()
     L.nso_maf_hist.restype = C.c_int
     L.nso_maf_hist.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 6
