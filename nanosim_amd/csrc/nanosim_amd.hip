@@ -301,10 +301,14 @@ template <bool LDS_TABLES, bool COOP>
 __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK, COOP ? 4 : NS_CHAIN_MINW) k_chain(GenArgs A) {
     extern __shared__ uint64_t lds_tbl[];
     CoopLds *coop = nullptr;
-    if constexpr (COOP) { __shared__ CoopLds coop_lds; coop = &coop_lds; }
+    if constexpr (COOP && !LDS_TABLES) { __shared__ CoopLds coop_lds; coop = &coop_lds; }
     Tabs T;
     if (LDS_TABLES) {
-        for (uint32_t i = threadIdx.x; i < A.m.ct.n_words_lds; i += blockDim.x) lds_tbl[i] = A.m.chain_blob[i];
+        // <true, true>: the wave-per-read UNALIGNED chain — all it reads is the front of the blob (n_words_mix words: the run-length
+        // tables), 2-5 KB per wavefront.  From global memory the four dependent table reads of a block of 64 iterations were its
+        // critical path (a 60 kb read: ~940 blocks of ~3 us set the duration of the batch's chain, 3.2 ms per 50 000 reads)
+        const uint32_t nw = COOP ? A.m.ct.n_words_mix : A.m.ct.n_words_lds;
+        for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x) lds_tbl[i] = A.m.chain_blob[i];
         __syncthreads();
         T.w = lds_tbl;
     } else T.w = A.m.chain_blob;
@@ -355,7 +359,8 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK, COOP ? 4 : NS_CHAI
                 EList32 e;
                 if (kind == NS_KIND_PERFECT) { e.l_new = e.middle_ref = m32; }
                 else if (p.kind) e = COOP ? coop_unaligned_error_list(T, ct, m32, key, sid, a, sink, lane) : chain_unaligned_error_list(T, ct, m32, key, sid, a, sink);
-                else if (COOP) e = coop_error_list(T, ct, m32, key, sid, a, sink, *coop, lane);
+                else if constexpr (COOP && LDS_TABLES) { e.l_new = e.middle_ref = m32; sink.range = true; }   // (not launched for aligned segments: their tables are not in this image)
+                else if constexpr (COOP) e = coop_error_list(T, ct, m32, key, sid, a, sink, *coop, lane);
                 else if constexpr (LDS_TABLES) e = chain_error_list(T, Tabs{A.m.chain_blob}, ct, m32, key, sid, a, sink);
                 else e = chain_error_list_g(T, ct, m32, key, sid, a, sink);
                 ev_flush_tail(sink);
@@ -1719,6 +1724,7 @@ struct ns_ctx {
     uint32_t dbg = 0;          // NS_DEBUG_SKIP: phase-ablation bits for profiling only (results are wrong when set)
     uint32_t coop_min = 16384, coop_shift = 10;  // cooperative chain for the longest n>>shift reads of batches >= min (env: NS_COOP_MIN, NS_COOP_SHIFT);
                                                  // 10^6 reads, chain ms at shift 9 / 10 / 11 / 12: 4.18 / 3.63 / 3.90 / 4.32
+    bool ucoop_lds = true;                       // ... with the run-length tables in LDS (k_chain<true, true>; env NS_UCOOP_LDS=0: from global memory, as until round 5)
     uint32_t ucoop_shift = 0;                    // unaligned reads: the longest n>>shift of a batch take the wave-per-read list, the rest the thread-per-read one (env: NS_UCOOP_SHIFT; 0: all)
     // planning + result buffers
     DevBuf l_cap, l_off, p_need, p_off;
@@ -1887,6 +1893,7 @@ int ns_create(int device, ns_ctx **out) {
     if (const char *d = getenv("NS_COOP_MIN")) ctx->coop_min = (uint32_t)atoi(d);
     if (const char *d = getenv("NS_COOP_SHIFT")) ctx->coop_shift = (uint32_t)atoi(d) & 31u;
     if (const char *d = getenv("NS_UCOOP_SHIFT")) ctx->ucoop_shift = (uint32_t)atoi(d) & 31u;
+    if (const char *d = getenv("NS_UCOOP_LDS")) ctx->ucoop_lds = atoi(d) != 0;
     *out = ctx;
     return NS_OK;
 }
@@ -3131,7 +3138,10 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
                 GenArgs B = A; B.list_n = n_coop;
                 HIPCHK(hipEventRecord(ctx->ev_fork, st));
                 HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-                k_chain<false, true><<<dim3(n_coop), dim3(64), 0, ctx->stream2>>>(B);
+                // unaligned reads: the run-length tables in LDS (k_chain<true, true>; the image must fit next to nothing else: 64 KB)
+                if (prm->kind == NS_KIND_UNALIGNED && ctx->lds_tables && ctx->ucoop_lds && (size_t)A.m.ct.n_words_mix * 8 <= 64u * 1024u)
+                    k_chain<true, true><<<dim3(n_coop), dim3(64), (size_t)A.m.ct.n_words_mix * 8, ctx->stream2>>>(B);
+                else k_chain<false, true><<<dim3(n_coop), dim3(64), 0, ctx->stream2>>>(B);
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
                 A.list = cur + n_coop; A.list_n = cur_n - n_coop;

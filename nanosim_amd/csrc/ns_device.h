@@ -17,6 +17,8 @@ struct ChainTab {                 // offsets are in 8-byte words from the start 
     uint32_t pm_lut;              // the column of a previous match < 256 in one word {first segment | segments << 32 | bin << 56}
     uint32_t sub2;                // the steps of the interpolation inside the narrow segments
     uint32_t n_words_lds;         // the blob up to here goes to LDS (k_chain<LDS>); the fp64 tables behind it stay in global memory
+    uint32_t n_words_mix;         // ... and up to here (trans, mix_w, the run-length tables, mix_rec) is all unaligned_error_list reads:
+                                  // the LDS image of the wave-per-read unaligned chain (k_chain<true, true>)
     uint32_t mm_nbins, mm_bin, mm_bin_lut, mm_seg_off, mm_hi, mm_vhi, mm_vlo0, mm_guide;
     double fm_vlo0;
 };

@@ -1,5 +1,5 @@
 // ns_pack.h — host side of ns_load_model: the tables of the event chains packed into ONE blob of 8-byte words (ns_chain.h reads it;
-// k_chain copies its first n_words_lds words to LDS).  Plain host code without a HIP call, so that the CPU test suite can pack a model and
+// k_chain copies its first n_words_lds words to LDS; the wave-per-read unaligned chain its first n_words_mix).  Plain host code without a HIP call, so that the CPU test suite can pack a model and
 // run the chain source compiled for the host against the oracle (tests/chain_host.hip).
 //
 // The image (offsets in ChainTab, ns_device.h).  LDS part:
@@ -72,6 +72,7 @@ static inline void ns_pack_chain_tables(const ns_model_tables *t, uint32_t nseg,
             rec[2 * (2 * ty + c) + 1] = gd;
         }
     ct.mix_rec = put_raw(rec, sizeof rec);
+    ct.n_words_mix = (uint32_t)blob.size();                   // everything unaligned_error_list reads lies in front of here
     ct.fm_n = t->fm_nseg; ct.fm_vlo0 = t->fm_vlo0;
     { auto g = guide(t->fm_hi, t->fm_nseg); ct.fm_guide = put_raw(g.data(), 512); }
     ct.mm_nbins = t->mm_nbins;
