@@ -1057,6 +1057,10 @@ def main():
     ap.add_argument("--only-ir", action="store_true", help="write the intron-retention inputs and reference_ir.json only")
     ap.add_argument("--only-ir-splice", action="store_true", help="write reference_ir_splice.json only (the intron splice of the transcriptome worker)")
     ap.add_argument("--only-trx-walk", action="store_true", help="write reference_trx_walk.json only (the pick walk of the transcriptome worker as a tape)")
+    ap.add_argument("--only-chimeric-sparse", action="store_true",
+                    help="write reference_chimeric_sparse.json only: genome mode --chimeric with the committed small model AS IT IS (1.05 segments "
+                         "per read, the share of the bench model) on --dist-reads reads — at 1 450 000 the fixture holds > 6 x 10^4 chimeric reads, "
+                         "enough for the 1 %% gate on the gap lengths that the 114 000-read run of reference_distributions.json cannot carry")
     ap.add_argument("--only-chimeric-dense", action="store_true",
                     help="write reference_chimeric_dense.json only: genome mode --chimeric with the small model at 2 segments per read on average, "
                          "so that the fixture holds > 10^5 chimeric reads (gap lengths and segment counts at the 1 %% gate)")
@@ -1084,6 +1088,12 @@ def main():
             with open(os.path.join(HERE, "reference_trx_walk.json"), "w") as f:
                 json.dump(fx, f, separators=(",", ":"))
             print("reference_trx_walk.json written:", len(fx["picks"]), "picks,", fx["n_samples"], "KDE samples,", len(fx["written"]), "reads")
+            return
+        if a.only_chimeric_sparse:
+            fx = fixture_distributions(prefix, fasta, workdir, a.dist_reads, False, chimeric=True, n_unaligned=8)
+            with open(os.path.join(HERE, "reference_chimeric_sparse.json"), "w") as f:
+                json.dump(fx, f)
+            print("reference_chimeric_sparse.json written:", fx["n_aligned"], "aligned reads,", sum(fx["nseg_hist"][2:]), "chimeric")
             return
         if a.only_chimeric_dense:
             spec = synth.SynthModelSpec(**SMALL_SPEC, segment_mean=CHIMERIC_DENSE_MEAN)       # the committed small model but for _chimeric_info

@@ -72,6 +72,37 @@ def oracle_batch(model, ref, **kw):
     return p, out
 
 
+_POOL_ARGS = None
+
+
+def _oracle_chunk(i):
+    model, ref, per, kw = _POOL_ARGS
+    p = E.make_params(seed=424242, first_read=i * per, n_reads=per, max_len=ref.max_chrom, **kw)
+    out = O.generate(model, ref, p, bytes_per_read=12000, events_per_read=2000)
+    rd = out["reads"]
+    used = int((rd["piece_off"].astype(np.int64) + rd["n_pieces"]).max())
+    return rd.copy(), out["pieces"][:used].copy()
+
+
+def oracle_batch_parallel(model, ref, n_reads, chunks=8, **kw):
+    """reads and pieces of one oracle run of n_reads read indices, generated as `chunks` index ranges side by side (forked workers: a read is
+    a function of (seed, read index), so the ranges ARE the run); no records, no events kept — for the million-read distribution gates"""
+    import multiprocessing as mp
+    import os
+    global _POOL_ARGS
+    per = n_reads // chunks
+    _POOL_ARGS = (model, ref, per, dict(kw, emit_records=False))
+    with mp.get_context("fork").Pool(min(chunks, os.cpu_count() or 1)) as pool:
+        parts = pool.map(_oracle_chunk, range(chunks))
+    _POOL_ARGS = None
+    reads, pieces, base = [], [], 0
+    for rd, pc in parts:
+        rd = rd.copy(); rd["piece_off"] = rd["piece_off"] + base
+        base += len(pc)
+        reads.append(rd); pieces.append(pc)
+    return np.concatenate(reads), np.concatenate(pieces)
+
+
 def test_oracle_aligned_distributions_match_reference(golden_distributions, small_model, small_ref):
     fx = golden_distributions["fasta"]
     p, out = oracle_batch(small_model, small_ref, n_reads=60000, emit_records=True)
@@ -175,6 +206,24 @@ def golden_chimeric_dense():
     import os
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_chimeric_dense.json")) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def golden_chimeric_sparse():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_chimeric_sparse.json")) as f:
+        return json.load(f)
+
+
+def test_oracle_sparse_chimeric_matches_reference_at_the_1_percent_gate(golden_chimeric_sparse, small_model, small_ref):
+    """genome mode --chimeric with the model AS IT IS (1.05 segments per read — the share of the bench model): 1.38 million reference reads,
+    > 6 x 10^4 of them chimeric (make_golden.py --only-chimeric-sparse), so the gap bases per chimeric read and the mean gap are held at
+    the 1 % gate here too (the 114 000-read run above has 5 578 chimeric reads: noise floor 0.02, gated at 0.03 / 6 %)"""
+    fx = golden_chimeric_sparse
+    assert sum(fx["nseg_hist"][2:]) > 60000
+    reads, pieces = oracle_batch_parallel(small_model, small_ref, 1000000, chunks=40, chimeric=True)
+    check_chimeric(reads, pieces, None, fx, "oracle-chimeric-sparse", gap_gate=KS_GATE, gap_mean_tol=0.01)
 
 
 def test_oracle_dense_chimeric_matches_reference_at_the_1_percent_gate(golden_chimeric_dense, small_model, small_ref):
@@ -281,6 +330,20 @@ def test_gpu_genome_chimeric_matches_reference(golden_distributions, small_model
         p = E.make_params(seed=31337, first_read=0, n_reads=300000, chimeric=True, max_len=small_ref.max_chrom, emit_records=False)
         b = eng.generate(p)
         check_chimeric(b.reads(), b.pieces(), b.events(), golden_distributions["chimeric"], "gpu-chimeric")
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_gpu_sparse_chimeric_matches_reference_at_the_1_percent_gate(golden_chimeric_sparse, small_model, small_ref):
+    """the 1.05-segment model on 3 million reads (~140 000 chimeric) against the 1.38-million-read reference run: gap bases at the 1 % gate"""
+    eng = E.Engine(0)
+    try:
+        eng.set_reference(small_ref)
+        eng.load_model(small_model)
+        p = E.make_params(seed=161803, first_read=0, n_reads=3000000, chimeric=True, max_len=small_ref.max_chrom, emit_records=False)
+        b = eng.generate(p)
+        check_chimeric(b.reads(), b.pieces(), None, golden_chimeric_sparse, "gpu-chimeric-sparse", gap_gate=KS_GATE, gap_mean_tol=0.01)
     finally:
         eng.close()
 
