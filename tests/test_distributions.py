@@ -76,25 +76,36 @@ _POOL_ARGS = None
 
 
 def _oracle_chunk(i):
-    model, ref, per, kw = _POOL_ARGS
+    model, ref, per, kw, sizes, what = _POOL_ARGS
     p = E.make_params(seed=424242, first_read=i * per, n_reads=per, max_len=ref.max_chrom, **kw)
-    out = O.generate(model, ref, p, bytes_per_read=12000, events_per_read=2000)
+    out = O.generate(model, ref, p, bytes_per_read=sizes[0], events_per_read=sizes[1])
     rd = out["reads"]
+    if what == "metrics":               # per-read metrics (+ the quality histogram of a FASTQ run) of the chunk: a few MB instead of its records
+        met = per_read_metrics(rd, out["pieces"], out["events"])
+        qh = qual_hist_from_records(out["records"], rd) if kw.get("fastq") else None
+        return {k: np.array(v) for k, v in met.items()}, qh
     used = int((rd["piece_off"].astype(np.int64) + rd["n_pieces"]).max())
     return rd.copy(), out["pieces"][:used].copy()
 
 
-def oracle_batch_parallel(model, ref, n_reads, chunks=8, **kw):
-    """reads and pieces of one oracle run of n_reads read indices, generated as `chunks` index ranges side by side (forked workers: a read is
-    a function of (seed, read index), so the ranges ARE the run); no records, no events kept — for the million-read distribution gates"""
+def _oracle_pool(model, ref, n_reads, chunks, kw, sizes, what):
     import multiprocessing as mp
     import os
     global _POOL_ARGS
-    per = n_reads // chunks
-    _POOL_ARGS = (model, ref, per, dict(kw, emit_records=False))
-    with mp.get_context("fork").Pool(min(chunks, os.cpu_count() or 1)) as pool:
-        parts = pool.map(_oracle_chunk, range(chunks))
-    _POOL_ARGS = None
+    assert n_reads % chunks == 0
+    _POOL_ARGS = (model, ref, n_reads // chunks, kw, sizes, what)
+    try:
+        with mp.get_context("fork").Pool(min(chunks, os.cpu_count() or 1)) as pool:
+            return pool.map(_oracle_chunk, range(chunks))
+    finally:
+        _POOL_ARGS = None
+
+
+def oracle_batch_parallel(model, ref, n_reads, chunks=8, bytes_per_read=12000, events_per_read=2000, **kw):
+    """reads and pieces of ONE oracle run of n_reads read indices, generated as `chunks` index ranges side by side (forked workers: a read is
+    a function of (seed, read index), so the ranges ARE the run — same arrays as oracle_batch but for the rebased piece offsets); no
+    records, no events kept.  (One call for 10^5 reads spent most of its time faulting in buffers sized for the longest possible read.)"""
+    parts = _oracle_pool(model, ref, n_reads, chunks, dict(kw, emit_records=False), (bytes_per_read, events_per_read), "pieces")
     reads, pieces, base = [], [], 0
     for rd, pc in parts:
         rd = rd.copy(); rd["piece_off"] = rd["piece_off"] + base
@@ -103,16 +114,23 @@ def oracle_batch_parallel(model, ref, n_reads, chunks=8, **kw):
     return np.concatenate(reads), np.concatenate(pieces)
 
 
+def oracle_metrics_parallel(model, ref, n_reads, chunks=8, bytes_per_read=30000, events_per_read=4000, **kw):
+    """per_read_metrics (and the quality histogram of a FASTQ run) of one oracle run, computed range by range in forked workers"""
+    parts = _oracle_pool(model, ref, n_reads, chunks, dict(kw), (bytes_per_read, events_per_read), "metrics")
+    met = {k: np.concatenate([m[k] for m, _ in parts]) for k in parts[0][0]}
+    qh = None if parts[0][1] is None else np.sum([q for _, q in parts], axis=0)
+    return met, qh
+
+
 def test_oracle_aligned_distributions_match_reference(golden_distributions, small_model, small_ref):
     fx = golden_distributions["fasta"]
-    p, out = oracle_batch(small_model, small_ref, n_reads=60000, emit_records=True)
-    check_aligned(per_read_metrics(out["reads"], out["pieces"], out["events"]), fx, "oracle")
+    met, _ = oracle_metrics_parallel(small_model, small_ref, 60000, emit_records=True)
+    check_aligned(met, fx, "oracle")
 
 
 def test_oracle_unaligned_distributions_match_reference(golden_distributions, small_model, small_ref):
     fx = golden_distributions["fasta"]
-    p, out = oracle_batch(small_model, small_ref, n_reads=100000, kind=E.NS_KIND_UNALIGNED, emit_records=False)
-    r = out["reads"]
+    r, _ = oracle_batch_parallel(small_model, small_ref, 100000, kind=E.NS_KIND_UNALIGNED)
     assert ks_vs_quantiles(r["seq_len"], fx["q_unaligned_len"]) <= KS_GATE
     assert abs(float(np.mean(r["reversed"])) - fx["unaligned_rev_frac"]) < 0.01
 
@@ -120,9 +138,9 @@ def test_oracle_unaligned_distributions_match_reference(golden_distributions, sm
 def test_oracle_homopolymer_mode_distributions_match_reference(golden_distributions, small_model, small_ref):
     """--fastq -hp -k 5 (114 000 reference reads): the events that survive the homopolymer filter, the lengths after mutate_homo"""
     fx = golden_distributions["hp"]
-    p, out = oracle_batch(small_model, small_ref, n_reads=60000, fastq=True, kmer_bias=5)
-    check_aligned(per_read_metrics(out["reads"], out["pieces"], out["events"]), fx, "oracle-hp")
-    h = qual_hist_from_records(out["records"], out["reads"]).astype(np.float64)
+    met, h = oracle_metrics_parallel(small_model, small_ref, 60000, fastq=True, kmer_bias=5)
+    check_aligned(met, fx, "oracle-hp")
+    h = h.astype(np.float64)
     ref_h = np.array(fx["qual_hist"], dtype=np.float64)
     assert np.max(np.abs(np.cumsum(h) / h.sum() - np.cumsum(ref_h) / ref_h.sum())) <= KS_GATE
 
@@ -168,8 +186,8 @@ def test_oracle_genome_chimeric_matches_reference(golden_distributions, small_mo
     """genome mode --chimeric (S:1276-1279, 1355-1358, 1406-1419, simulation_gap S:1552-1568): segments per read, gap bases, lengths"""
     import re
     fx = golden_distributions["chimeric"]
-    p, out = oracle_batch(small_model, small_ref, n_reads=100000, chimeric=True, emit_records=False)
-    check_chimeric(out["reads"], out["pieces"], out["events"], fx, "oracle-chimeric")
+    reads, pieces = oracle_batch_parallel(small_model, small_ref, 100000, chimeric=True)
+    check_chimeric(reads, pieces, None, fx, "oracle-chimeric")
     # name grammar of a chimeric read (S:1390-1402): ';'-joined positions, _chimeric tag, ';'-joined segment lengths
     name_re = re.compile(r"^[A-Za-z0-9\-]+_\d+(;[A-Za-z0-9\-]+_\d+)+_aligned_\d+_chimeric_[FR]_\d+_\d+(;\d+)+_\d+$")
     assert fx["first"]["chimeric_names"]
@@ -233,8 +251,8 @@ def test_oracle_dense_chimeric_matches_reference_at_the_1_percent_gate(golden_ch
     fx = golden_chimeric_dense
     assert sum(fx["nseg_hist"][2:]) > 100000
     m = dense_chimeric_model(small_model, fx)
-    p, out = oracle_batch(m, small_ref, n_reads=120000, chimeric=True, emit_records=False)
-    check_chimeric(out["reads"], out["pieces"], out["events"], fx, "oracle-chimeric-dense", gap_gate=KS_GATE, gap_mean_tol=0.01)
+    reads, pieces = oracle_batch_parallel(m, small_ref, 120000, bytes_per_read=30000, events_per_read=4000, chimeric=True)
+    check_chimeric(reads, pieces, None, fx, "oracle-chimeric-dense", gap_gate=KS_GATE, gap_mean_tol=0.01)
 
 
 def qual_hist_from_records(records, reads, name_len_total=None):
