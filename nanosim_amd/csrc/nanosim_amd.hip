@@ -1518,12 +1518,13 @@ __global__ void __launch_bounds__(64) k_errlog(GenArgs A) {
     for (uint32_t pi = 0; pi < rd.n_pieces; pi += 2) {
         const ns_piece p = A.pieces[rd.piece_off + pi];
         PieceCtx pc = load_piece(A.events, A.ref, p, pi);
+        ns_event e_nx; e_nx.pos = 0; e_nx.info = 0;             // the events of the iteration to come: rows are written from the LAST event to the first
+        if (lane < p.n_ev) e_nx = pc.ev[p.n_ev - 1 - lane];
         for (uint32_t j0 = 0; j0 < p.n_ev; j0 += 64) {
             // rows are written from the LAST event to the first
             const uint32_t k = j0 + lane;
             const bool active = k < p.n_ev;
-            ns_event e; e.pos = 0; e.info = 0;
-            if (active) e = pc.ev[p.n_ev - 1 - k];
+            const ns_event e = e_nx;                                                        // (loaded in front of the last copy-out)
             const uint32_t len = ns_ev_len(e.info), ty = ns_ev_type(e.info);
             const uint32_t tail = dec_digits(e.pos) + dec_digits(len) + 2u * len + 9u;      // "\t<pos>\t<type>\t<len>\t<ref>\t<new>\n"
             const uint32_t row = active ? nl + tail : 0;
@@ -1533,27 +1534,67 @@ __global__ void __launch_bounds__(64) k_errlog(GenArgs A) {
             // (P: LdsBytes for the staged block — volatile, so that the compiler cannot merge neighbouring byte stores into a wide store at
             // an odd address, and in the LDS address space by type, because volatile accesses are not inferred into it)
             auto fields = [&](auto w) __attribute__((always_inline)) {                   // the rest of the row at w
+                if (A.dbg & (1u << 17)) return;                           // (NS_DEBUG_SKIP, profiling only — 1 << 16: no name copy, 17: no fields, 18: no letter
+                                                                          // columns, 19: no copy-out; profiles/r05/ablate_errlog.log)
                 *w++ = '\t'; w = put_dec_p(w, e.pos); *w++ = '\t';
                 const char *tn = ty == NS_MIS ? "mis" : ty == NS_INS ? "ins" : "del";
                 *w++ = (uint8_t)tn[0]; *w++ = (uint8_t)tn[1]; *w++ = (uint8_t)tn[2];
                 *w++ = '\t'; w = put_dec_p(w, len); *w++ = '\t';
                 auto w2 = w + len + 1;
-                // the letters of the event come from ONE word per 16 (payload_word: 2-bit fields / successive base-3 digits) — drawn
-                // once per word here, not once per letter (ins_letter / mis_letter evaluate a Philox block per call)
-                uint32_t frac = 0;
-                // the reference bases under a substitution / deletion of <= 8 bases: ONE 8-byte load in front of the loop (the engine's
-                // copy of the reference is padded) instead of a dependent byte load per base; across the origin: the byte loads
-                uint64_t ref8 = 0;
-                const bool ref_fast = ty != NS_INS && len <= 8u && pc.pos + e.pos + 8ull <= pc.chrom_len;
-                if (ref_fast) __builtin_memcpy(&ref8, A.ref.bases + pc.chrom_base + pc.pos + e.pos, 8);
-                for (uint32_t i = 0; i < len; ++i) {
-                    if (ty != NS_DEL && !(i & 15u)) frac = payload_word(key, pc.sid, a, p.n_ev - 1 - k, i >> 4);
-                    if (ty == NS_INS) { w[i] = '-'; w2[i] = bases_atcg((frac >> (2u * (i & 15u))) & 3u); }
-                    else {
-                        uint32_t x = e.pos + i;
-                        uint8_t cur = resolve_base(ref_fast ? (uint32_t)(ref8 >> (8u * i)) & 0xffu : (uint32_t)ref_base_at(A.ref, pc, x), key, pc.sid, a, x);
-                        w[i] = cur;
-                        w2[i] = (ty == NS_MIS) ? mis_from_digit(cur, next_digit3(frac)) : (uint8_t)'-';
+                if (A.dbg & (1u << 18)) return;
+                // The two letter columns.  Round 5: as straight-line code for what all but one event in thousands is — <= 16 letters, plain
+                // bases under them, not across the origin: the 16 reference bytes in ONE unaligned load, the letters of the event from its
+                // ONE word (payload_word: 2-bit fields / successive base-3 digits) four at a time through byte permutes (the record kernel's
+                // forms: S:1990 / S:1968-1972), then one pass of byte stores that ends with the longest run of the WAVEFRONT.  The
+                // per-byte loop this replaces ran as often, but with ~200 instructions of divergent control flow per trip (the profile's
+                // 2 094 scalar instructions per read were its exec-mask bookkeeping); it stays for the events the fast form does not take.
+                const bool need_ref = ty != NS_INS;
+                const bool inside = pc.pos + e.pos + 16ull <= pc.chrom_len;
+                uint32_t r16[4] = {0x2d2d2d2du, 0x2d2d2d2du, 0x2d2d2d2du, 0x2d2d2d2du}, n16[4] = {0x2d2d2d2du, 0x2d2d2d2du, 0x2d2d2d2du, 0x2d2d2d2du};   // '-'
+                if (need_ref && inside) __builtin_memcpy(r16, A.ref.bases + pc.chrom_base + pc.pos + e.pos, 16);   // (the engine's copy of the reference is padded)
+                bool fast = len <= 16u && (!need_ref || inside);
+                if (fast && need_ref) {                                   // an IUPAC code under the event: case_convert draws its base (resolve_base)
+                    const uint32_t nb = 8u * (len & 3u), full = len >> 2;
+                    uint32_t amb = 0;
+#pragma unroll
+                    for (uint32_t g = 0; g < 4; ++g) amb |= r16[g] & (g < full ? 0x80808080u : g == full ? (0x80808080u & ((1u << nb) - 1u)) : 0u);
+                    fast = amb == 0;
+                }
+                if (ty != NS_DEL) {
+                    const uint32_t word = payload_word(key, pc.sid, a, p.n_ev - 1 - k, 0);
+                    uint32_t f3 = word;
+#pragma unroll
+                    for (uint32_t g = 0; g < 4; ++g) {
+                        if (ty == NS_INS) {
+                            const uint32_t x8 = (word >> (8u * g)) & 0xffu, t8 = (x8 | x8 << 12) & 0x000f000fu;
+                            n16[g] = __builtin_amdgcn_perm(0u, 0x47435441u, (t8 | t8 << 6) & 0x03030303u);                        // S:1990
+                        } else {
+                            const uint32_t d0 = next_digit3(f3), d1 = next_digit3(f3), d2 = next_digit3(f3), d3 = next_digit3(f3);
+                            const uint32_t d4 = d0 | d1 << 8 | d2 << 16 | d3 << 24;
+                            const uint32_t vv = (r16[g] >> 1) & 0x03030303u;                              // A 0, C 1, T 2, G 3
+                            const uint32_t rank4 = (vv & 0x01010101u) << 1 | ((vv >> 1) & 0x01010101u);  // rank in "ATCG": A 0, T 1, C 2, G 3
+                            const uint32_t ge = ((d4 | 0x80808080u) - rank4) & 0x80808080u;              // per byte: digit >= rank
+                            n16[g] = __builtin_amdgcn_perm(0u, 0x47435441u, d4 + (ge >> 7));                                       // S:1968-1972
+                        }
+                    }
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < 16; ++i) {
+                    const bool on = fast && i < len;
+                    if (!__ballot(on)) break;                             // (wave-uniform: no lane of the wavefront has a letter i; a ballot counts active lanes only)
+                    if (on) { w[i] = (uint8_t)(r16[i >> 2] >> (8u * (i & 3u))); w2[i] = (uint8_t)(n16[i >> 2] >> (8u * (i & 3u))); }
+                }
+                if (!fast) {
+                    uint32_t frac = 0;
+                    for (uint32_t i = 0; i < len; ++i) {
+                        if (ty != NS_DEL && !(i & 15u)) frac = payload_word(key, pc.sid, a, p.n_ev - 1 - k, i >> 4);
+                        if (ty == NS_INS) { w[i] = '-'; w2[i] = bases_atcg((frac >> (2u * (i & 15u))) & 3u); }
+                        else {
+                            uint32_t x = e.pos + i;
+                            uint8_t cur = resolve_base((uint32_t)ref_base_at(A.ref, pc, x), key, pc.sid, a, x);
+                            w[i] = cur;
+                            w2[i] = (ty == NS_MIS) ? mis_from_digit(cur, next_digit3(frac)) : (uint8_t)'-';
+                        }
                     }
                 }
                 w[len] = '\t';
@@ -1570,7 +1611,8 @@ __global__ void __launch_bounds__(64) k_errlog(GenArgs A) {
                     const LdsWords qd = (LdsWords)((LdsBytes)buf_lds + (o - al));
                     const uint32_t d1 = (al + nl) >> 2;                                     // dwords [d0, d1) of the row's grid hold name bytes only
                     const uint32_t d0 = al ? 1u : 0u;
-                    if (d1 > d0) {
+                    if (A.dbg & (1u << 16)) {}
+                    else if (d1 > d0) {
                         const LdsWords sw = (LdsWords)src;
                         const uint32_t w_head = sw[0], w_tail = sw[d1];                     // the dwords the row shares with its neighbours: byte stores
                         for (uint32_t j = d0; j < d1; j += 4) {                             // four dwords in flight (volatile accesses keep their order)
@@ -1588,11 +1630,14 @@ __global__ void __launch_bounds__(64) k_errlog(GenArgs A) {
                 wave_sync();
                 // the block leaves: lane c the 16 bytes at errlog address (dst0 - mis) + 16 c = buf_lds[16 c .. 16 c + 15]
                 uint8_t *const dstA = dst0 - mis;
-                for (uint32_t c = lane; 16u * c < mis + total; c += 64) {
+                // the NEXT iteration's events are asked for in front of the stores, not behind them (the load then does not queue up behind
+                // 4 KB of this wavefront's own writes: 6.34 -> 6.09 ms on top of the nontemporal stores, profiles/r05/ab_errlog_nt.log)
+                e_nx.pos = 0; e_nx.info = 0; if (k + 64u < p.n_ev) e_nx = pc.ev[p.n_ev - 1 - (k + 64u)];
+                for (uint32_t c = lane; 16u * c < mis + total && !(A.dbg & (1u << 19)); c += 64) {
                     const uint4 v = *reinterpret_cast<const uint4 *>(buf_lds + 16u * c);
                     const uint32_t s0 = c ? 0u : mis;                                           // bytes of the chunk in front of the block
                     const uint32_t e0 = min(16u, mis + total - 16u * c);                        // ... and where the block ends inside it
-                    if (s0 == 0 && e0 == 16u) *reinterpret_cast<uint4 *>(dstA + 16u * c) = v;
+                    if (s0 == 0 && e0 == 16u) __builtin_nontemporal_store(ns_v4u_any{v.x, v.y, v.z, v.w}, reinterpret_cast<ns_v4u_any *>(dstA + 16u * c));   // (store16)
                     else {
                         uint64_t v0 = (uint64_t)v.x | (uint64_t)v.y << 32, v1 = (uint64_t)v.z | (uint64_t)v.w << 32;
                         shift_down_bytes(v0, v1, s0); store16(dstA + 16u * c + s0, e0 - s0, v0, v1);
@@ -1607,6 +1652,7 @@ __global__ void __launch_bounds__(64) k_errlog(GenArgs A) {
                 } else for (uint32_t i = 0; i < nl; ++i) q[i] = name[i];
                 fields(q + nl);
             }
+            if (!staged) { e_nx.pos = 0; e_nx.info = 0; if (k + 64u < p.n_ev) e_nx = pc.ev[p.n_ev - 1 - (k + 64u)]; }
             base += total;
         }
     }

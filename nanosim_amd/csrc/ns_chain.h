@@ -81,6 +81,8 @@ struct EvSink32 {
 NS_DEV void ev_flush4(EvSink32 &s, uint32_t first) {       // staged slots 0..3 -> events first .. first + 3
     const uint2 e0 = s.stg[0], e1 = s.stg[NS_CHAIN_BLOCK], e2 = s.stg[2 * NS_CHAIN_BLOCK], e3 = s.stg[3 * NS_CHAIN_BLOCK];
     uint4 *dst = reinterpret_cast<uint4 *>(s.ev + first);
+    // (plain stores: as nontemporal stores these scattered 32-byte groups took the thread-per-read chain from 3.2 to 8.5 ms,
+    // profiles/r05/ab_nt_more.log — nontemporal pays for the wave-wide contiguous streams of the record and error-profile images)
     dst[0] = make_uint4(e0.x, e0.y, e1.x, e1.y); dst[1] = make_uint4(e2.x, e2.y, e3.x, e3.y);
 }
 // the events still staged when a piece is complete (slots behind the last event carry stale values: inside the capacity, never read)

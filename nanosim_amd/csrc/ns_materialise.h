@@ -70,10 +70,15 @@ __device__ __forceinline__ uint64_t t_to_u8(uint64_t x) {
     return x | (z >> 7);
 }
 
+// A full group leaves as a NONTEMPORAL store (round 5): the record image, the scratch image of -k and the error profile are streams
+// that are written once, wavefront-wide and contiguous, and not read back by the kernel that writes them — kept out of the L2 they no
+// longer evict the reference and the event lists the same kernel is reading (same box, profiles/r05/ab_nt_records.log: record kernel
+// 5.43 -> 5.09 ms, whole step 9.64 -> 9.27 ms; k_errlog 7.64 -> 6.34 ms, ab_errlog_nt.log)
+typedef uint32_t ns_v4u_any __attribute__((ext_vector_type(4), aligned(1)));      // 16 bytes at any address
 __device__ __forceinline__ void store16(uint8_t *dst, uint32_t count, uint64_t lo, uint64_t hi) {
     if (count == 16) {
-        struct __attribute__((packed)) V { uint64_t a, b; } v{lo, hi};
-        __builtin_memcpy(dst, &v, 16);
+        ns_v4u_any x = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+        __builtin_nontemporal_store(x, reinterpret_cast<ns_v4u_any *>(dst));
     } else {                             // 8 + 4 + 2 + 1: at most four (unaligned) stores instead of up to 15 byte stores
         if (count & 8u) { __builtin_memcpy(dst, &lo, 8); dst += 8; lo = hi; }
         if (count & 4u) { const uint32_t w = (uint32_t)lo; __builtin_memcpy(dst, &w, 4); dst += 4; lo >>= 32; }

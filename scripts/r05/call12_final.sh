@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 5, final GPU call (repeated on the last build: LDS image for the wave-per-read unaligned chain, sparse chimeric gate): the whole -m gpu suite on the final build, the default bench line, the configs[3] / configs[4] lines, the
+# round 5, final GPU call (repeated on the last build: nontemporal stores of the record, scratch and error-profile images, k_errlog with its next events loaded in front of the copy-out): the whole -m gpu suite on the final build, the default bench line, the configs[3] / configs[4] lines, the
 # transcriptome worker call, and the rocprofv3 passes (kernel stats + PMC, separate passes) behind the roofline numbers.
 cd "$(dirname "$0")/../.."
 export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$PWD}
-O=gpurun_out/r05o; mkdir -p $O
+O=gpurun_out/r05v; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 ( timeout 60 python -c 'import __graft_entry__ as g; g.smoke(); print("smoke OK")' 2>&1 | tail -2; timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 ) | tee $O/pytest_gpu.log
 timeout 400 python bench.py --steps 10 --warmup 3 2>$O/bench_default.err | tail -1 > $O/bench_ecoli_fasta.json
@@ -24,4 +24,4 @@ d=json.load(open('$O/$f.json')); r=lambda x:round(x,3)
 print('$f', r(d['ms_per_step']), 'ms', r(d['value']/1e6), 'M reads/s', {k:r(v) for k,v in d['kernel_ms'].items() if v>0.01}, 'serial', r(d.get('serial',{}).get('ms_per_step',0)), 'errlog_on', r(d.get('errlog_on',{}).get('ms_per_step',0)), r(d.get('errlog_on',{}).get('k_errlog_ms',0)), 'frac', r(d['roofline']['frac']))
 " | tee -a $O/bench_summary.log; done
 ( timeout 300 python scripts/bench_transcriptome.py 2>&1 | tail -3; timeout 300 python scripts/bench_transcriptome.py --model-ir 2>&1 | tail -3 ) | tee $O/bench_transcriptome.log
-SKIP_BENCH=1 CFGS="ecoli_fasta ecoli_fasta_errlog chr1_fastq_k5" bash scripts/profile_round.sh r05o 2>&1 | tail -3
+SKIP_BENCH=1 CFGS="ecoli_fasta ecoli_fasta_errlog chr1_fastq_k5" bash scripts/profile_round.sh r05v 2>&1 | tail -3
