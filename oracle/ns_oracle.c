@@ -15,7 +15,7 @@
  *   NSO_TAPE    uniforms / run lengths / normals are popped from tapes recorded while running the REAL
  *               reference (tests/golden/make_golden.py) — this is how the restatement is pinned.
  *
- * Parity status: pinned against outputs of the imported reference (tests/golden/*.json, reference_hist.json.gz);
+ * Parity status: pinned against outputs of the imported reference (the .json fixtures under tests/golden/, reference_hist.json.gz);
  * the reference itself has no tests.
  *
  * Build: make -C oracle   (gcc -O2 -ffp-contract=off; fma() only where written).
