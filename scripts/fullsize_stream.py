@@ -29,10 +29,9 @@ CONFIGS = {1: dict(genome="ecoli", fastq=False, kmer=0, chimeric=False, reads=10
 
 
 def ranges(lo, hi, parts):
-    """contiguous index ranges of [lo, hi): int(n / parts) each, the remainder to the last (S:1588, 1597-1598)"""
-    n = hi - lo
-    per = n // parts
-    return [(lo + k * per, lo + (k + 1) * per if k < parts - 1 else hi) for k in range(parts)]
+    """the contiguous index ranges of [lo, hi) that `parts` GPUs take (nanosim_amd/shard.py: partition)"""
+    from nanosim_amd import shard
+    return [(lo + a, lo + b) for a, b in shard.partition(hi - lo, parts)]
 
 
 def stream(w, kind, spans, batch, pin):
