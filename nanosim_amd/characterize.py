@@ -126,16 +126,25 @@ def count(eng, cs_list, cap: int = 2048) -> dict:
 
 
 def maf_pairs(path: str):
-    """[(reference line, query line)] of `<prefix>_besthit.maf` as hist(prefix, "maf") reads it (B:190-198): the file holds two `s` lines
-    per alignment and nothing else; field 7 of each is the aligned sequence (the upper-casing is done by the counting walk)"""
-    out = []
+    """[(reference line, query line)] of `<prefix>_besthit.maf` as hist(prefix, "maf") reads it (B:190-198): two `s` lines per alignment;
+    field 7 of each is the aligned sequence (the upper-casing is done by the counting walk).  The file get_besthit_maf writes holds `s`
+    lines only, and the reference assumes that; here everything else a MAF file may carry (`#` headers, `a score=` lines, blank
+    separators) is skipped, and an `s` line without its partner is a ValueError."""
+    out, pend = [], None
     with open(path) as f:
         for line in f:
-            r = line.strip().split()
-            q = next(f).strip().split()
+            if not line.startswith("s ") and not line.startswith("s\t"):
+                continue
+            r = line.split()
+            if pend is None:
+                pend = r
+                continue
+            r, q, pend = pend, r, None
             if len(r) < 7 or len(q) < 7 or len(r[6]) > len(q[6]):
                 raise ValueError("%s: not two `s` lines with an aligned sequence each (the reference would stop with an IndexError)" % path)
             out.append((r[6], q[6][:len(r[6])]))                   # (the walk runs over len(ref), B:203)
+    if pend is not None:
+        raise ValueError("%s: an `s` line without its partner (odd number of `s` lines)" % path)
     return out
 
 

@@ -841,7 +841,7 @@ template <bool FASTQ, int MODE>
 __global__ void __launch_bounds__(64, NS_MAT_WAVES)
 k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, const uint32_t *order) {
     constexpr bool CLSOUT = FASTQ && MODE != MAT_HP_SCRATCH;           // FASTQ: the bases here, the quality line in k_qualities
-    __shared__ TileLds6 T;
+    __shared__ TileLds7 T;
     const uint32_t lane = threadIdx.x;
     const uint64_t slot = blockIdx.x;
     if (slot >= A.prm.n_reads) return;
@@ -859,7 +859,7 @@ k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, co
         uint32_t q = 0;
         for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
             const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi, ev_word);
-            materialise_piece6<FASTQ, MODE>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, nullptr);
+            materialise_piece7<FASTQ, MODE>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, nullptr);
             q += pc.out_len;
         }
         return;
@@ -881,7 +881,7 @@ k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, co
             pc.sid = pc.kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
             q_in += pc.ref_len;
         } else pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi, ev_word);
-        materialise_piece6<FASTQ, MODE>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, CLSOUT ? cls + (q >> 4) + 2u * pi : nullptr);
+        materialise_piece7<FASTQ, MODE>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, CLSOUT ? cls + (q >> 4) + 2u * pi : nullptr);
         q += pc.out_len;                                 // (-k: k_hp_report files the emitted length in the piece once the record kernels are done)
     }
     if (A.polya) {                                                                          // transcriptome: polyA tail (S:1224-1225)
@@ -1811,6 +1811,7 @@ struct ns_ctx {
     // mode tables) and the worker thread that makes that call
     ns_ctx *companion = nullptr;
     bool borrowed = false;            // this context IS a companion: the tables it points at belong to its owner
+    ns_ctx *owner = nullptr;          // ... which is this one: every call on the companion takes the owner's tables as they are NOW (lend_tables)
     // the step gate: the companion holds its first chain launch until the owner's aligned call has launched its own chain — the aligned
     // call's planning kernels then run in 0.29 ms instead of 0.72 ms behind the unaligned chain's grid (same box: 9.9-10.1 -> 9.6-9.85 ms
     // per step, profiles/r05/ab_step_gate.log; NS_STEP_GATE=0: off).  Creating the companion's streams with the device's highest priority
@@ -2122,6 +2123,8 @@ int ns_load_model(ns_ctx *ctx, const ns_model_tables *t) {
         }
         double rate = 1.0 / (mean_match_min > 0.5 ? mean_match_min + 0.5 : 1.0);
         ctx->cap_rate = rate * 1.5 > 2.0 ? 2.0 : rate * 1.5;
+        // test knob (tests/test_gpu_parity.py): a planned rate below the model's forces the event-capacity overflow and its re-plan
+        if (const char *d = getenv("NS_CAP_RATE_SCALE")) { const double f = atof(d); if (f > 0.0) ctx->cap_rate *= f; }
 
         // ---- pack the chain tables into one blob of 8-byte words (its first part is copied to LDS by k_chain): ns_pack.h ----
         std::vector<uint64_t> blob;
@@ -2323,6 +2326,8 @@ static int hp_stage1(ns_ctx *ctx, const ns_params *prm, GenArgs &A, size_t n, ui
         uint32_t sh = 0;
         while (sh < 16 && rate * (double)(2u << sh) <= 1.0) ++sh;
         ctx->hp_shift = sh; ctx->hp_pad = 64; ctx->hp_cap_k = prm->kmer_bias;
+        // test knob: NS_HP_CAP_SHIFT=s plans 2^-s of that capacity and one slot of slack per piece, so that the stage's own overflow path runs
+        if (const char *d = getenv("NS_HP_CAP_SHIFT")) { const int s = atoi(d); if (s > 0) { ctx->hp_shift = std::min<uint32_t>(16u, sh + (uint32_t)s); ctx->hp_pad = 1; } }
     }
     for (int retry = 0;; ++retry) {
         A.hp_shift = ctx->hp_shift; A.hp_pad = ctx->hp_pad;
@@ -2982,9 +2987,13 @@ static int trx_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, Ge
     return NS_OK;
 }
 
+static void lend_tables(const ns_ctx *ctx, ns_ctx *c);
 int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     if (!ctx) return NS_EINVAL;
     if (!prm || !info) return fail(ctx, NS_EINVAL, "null params/info");
+    // a step companion called directly (include/nanosim_amd.h allows it): the owner may have loaded another model or reference since the
+    // tables were lent — the pointers the companion holds by value would be freed memory
+    if (ctx->borrowed && ctx->owner) lend_tables(ctx->owner, ctx);
     if (!ctx->has_model || !ctx->has_ref) return fail(ctx, NS_ESTATE, "ns_generate before ns_load_model/ns_set_reference");
     if (prm->kind > NS_KIND_PERFECT) return fail(ctx, NS_EINVAL, "bad kind");
     if (prm->emit_records > NS_EMIT_SIZES) return fail(ctx, NS_EINVAL, "bad emit_records");
@@ -3173,8 +3182,11 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
                 A.l_off = (const uint64_t *)ctx->l_off.p; A.l_base = used;
                 used += pass_cap;
             }
-            if (a == 0 && ctx->gate_wait)                                  // (bounded: the owner opens the gate on every way out of its call)
-                for (int spin = 0; spin < 2000 && !ctx->gate_wait->load(std::memory_order_acquire); ++spin) std::this_thread::sleep_for(std::chrono::microseconds(10));
+            if (a == 0 && ctx->gate_wait) {                                // (bounded: the owner opens the gate on every way out of its call; an owner
+                const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(3);   // that blocks in front of its chain — a first-use
+                while (!ctx->gate_wait->load(std::memory_order_acquire) && std::chrono::steady_clock::now() < t_end)   // hipMalloc, a result slot still
+                    std::this_thread::yield();                                                         // crossing PCIe — is not waited for: 3 ms)
+            }
             HIPCHK(hipEventRecord(ctx->evt[3], st));
             uint32_t n_coop = 0;
             if (prm->kind == NS_KIND_UNALIGNED)                           // its loop is a prefix sum (coop_unaligned_error_list); pass 0 visits the reads longest first
@@ -3337,7 +3349,7 @@ int ns_step_context(ns_ctx *ctx, ns_ctx **out) {
         ns_ctx *c = nullptr;
         const int rc = ns_create(ctx->device, &c);
         if (rc) return fail(ctx, rc, "ns_generate_step: the companion context could not be created");
-        c->borrowed = true;
+        c->borrowed = true; c->owner = ctx;
         ns_set_background(c, 1);
         ctx->companion = c;
     }

@@ -1,13 +1,14 @@
 // ns_materialise.h — the record kernels' device code: one read per wavefront, tiles of <= 2 KB of output whose 16-byte chunks are
-// aligned in the destination.  Per tile (materialise_piece below has the details):
+// aligned in the destination.  Per tile (materialise_piece7 below has the details):
 //   1. the events that start inside the tile (<= 63; lane = event, prefetched with their letter words) are staged in LDS;
-//   2. lane per event: substituted / inserted letters (mutate_read, S:1965-1995) go to an LDS payload tile at their output offsets;
-//   3. lane per 16-byte chunk: histogram + wavefront prefix sum -> the event in force at the chunk's first byte; one unaligned
-//      16-byte global load per event sub-run straight from the source (no source tile in LDS: neighbouring lanes hit the same
-//      lines in L1/L2), merged under byte masks; the payload tile on top; IUPAC codes resolved (case_convert, S:743-755);
-//   4. FASTQ: two Philox blocks per lane = the 16-bit quality draws of the chunk (the block that straddles the chunk start comes
-//      from the neighbouring lane by DPP), 16 look-ups in a bucket table held in LDS;
-//   5. complement / reverse in registers (S:1433-1435, 1675-1680), one aligned 16-byte store per line.
+//   2. lane per 16-byte chunk: histogram + wavefront prefix maximum -> the event in force at the chunk's first byte; the bytes copied
+//      under it come with ONE unaligned 16-byte global load straight from the source (no source tile in LDS: neighbouring lanes hit the
+//      same lines in L1/L2) and stay in the lane's registers;
+//   3. lane per event: the bytes copied behind an event that starts INSIDE a chunk (one more such load, masked) and the substituted /
+//      inserted letters (mutate_read, S:1965-1995) go to an LDS tile at their output offsets;
+//   4. lane per chunk again: own bytes | what the LDS tile holds, IUPAC codes resolved (case_convert, S:743-755), FASTQ: the quality class
+//      of every base leaves as two bits for k_qualities, complement / reverse in registers (S:1433-1435, 1675-1680), one aligned 16-byte
+//      nontemporal store per line.
 // The SOURCE of a piece is the reference (MAT_REF), or — second pass of -k — the pre-homopolymer read in the scratch buffer with
 // the homopolymer edits as its event list (MAT_HP_FINAL).  Tiles that straddle the origin of a circular chromosome take the generic
 // per-byte path (slow_piece_range).
@@ -626,37 +627,6 @@ __device__ __forceinline__ void qual_lut_load(uint16_t *lds, const DevModel &m, 
     for (uint32_t i = tid; i < NS_QLUT_SLOTS * 128u; i += nthreads) dst[i] = src[i];      // slot = class (NS_Q_*)
 }
 
-// ================================================================================================================================
-// Version 6 of the tile (round 3).  Same tiles, same events, same letters — a different COPY: instead of one lane per 16-byte chunk
-// that walks the events crossing its chunk (four predicated gathers per lane and iteration, paid by the whole wavefront whenever one
-// lane needs them), the tile's copy is cut into SUB-RUNS — maximal stretches of output bytes that lie in one chunk AND under one
-// event — and one lane copies one sub-run:
-//   * the sorted merge of the chunk starts and the event starts is never searched: chunk c is element c + (events that start at or
-//     before it), event k is element k + (chunks that start before it) — both counts fall out of the staging of the events;
-//   * element j covers [start_j, cut_{j+1}): ONE unaligned 16-byte load at the chunk's source position under the element's shift,
-//     masked to the sub-run's bytes and OR-ed into the zeroed output tile in LDS (ds_or_b64: no two sub-runs share a byte, so the
-//     OR is a store that needs no ordering); <= 128 + 63 elements = three passes of the wavefront per 2 KB tile;
-//   * the letters are byte stores into the same tile (no copy ever lies under a letter), so the final pass is: read the chunk,
-//     resolve IUPAC codes (rare), qualities, complement / reverse, one aligned 16-byte store.
-// Per tile ~250 wavefront instructions of copy machinery instead of ~590 (ablation of round 3: the copy loop was 53 % of the kernel).
-// ================================================================================================================================
-#define T6_NEL (64u * NS_TILE_CHUNKS + T_EV + 3u)
-struct __align__(16) TileLds6 {
-    uint32_t mlut[17][4];                       // mlut[i]: 16-byte mask with bytes >= i set; [16] empty
-    uint2 ent[T_EV + 1];                        // per staged event (0: the event in force at the tile start): x = first output offset copied
-                                                // under it, y = segment position minus output offset of those bytes
-    uint32_t hist[64 * NS_TILE_CHUNKS];         // build: last event at or before chunk c (+1); afterwards: the number of events at or before it
-    uint2 desc[T6_NEL];                         // elements: .x = (start - A0) | (cut - A0) << 16, .y = y
-    __align__(16) uint8_t out[T_OUT + 16 + 64]; // the tile's output bytes (zero where nothing has been written) + dump slots
-};
-__device__ __forceinline__ void tile_lds_init(TileLds6 &T, uint32_t lane) {
-    for (uint32_t c = lane * 16; c < T_OUT + 16 + 64; c += 64 * 16) *reinterpret_cast<uint4 *>(&T.out[c]) = make_uint4(0, 0, 0, 0);
-    if (lane < 17) {
-#pragma unroll
-        for (uint32_t k = 0; k < 4; ++k)
-            T.mlut[lane][k] = lane <= 4 * k ? 0xffffffffu : lane >= 4 * k + 4 ? 0u : 0xffffffffu << (8 * (lane - 4 * k));
-    }
-}
 __device__ __forceinline__ void lds_or64(uint8_t *p, uint64_t v) {
     __hip_atomic_fetch_or(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
@@ -669,8 +639,49 @@ __device__ __forceinline__ uint32_t event_word(const PieceCtx &pc, const ns_key 
     if constexpr (MODE == MAT_HP_FINAL) return pc.wd[j];
     else { const u32x4 w = ns_draw(key, ST_SUB, pc.sid, a, j >> 2, 0); return ns_word(w, j & 3u); }
 }
+// ================================================================================================================================
+// Version 7 of the tile (round 6).  The tile's copy is cut into SUB-RUNS — maximal stretches of output bytes that lie in one 16-byte chunk
+// AND under one event; a sub-run is ONE unaligned 16-byte load at the chunk's source position under the event's shift, masked to its bytes.
+// Version 6 (rounds 3-5) made every sub-run an element of a sorted list (chunk starts + event starts, <= 191 = three passes of the
+// wavefront per tile), loaded by the lane of its ELEMENT, OR-ed into the LDS tile and read back by the lane of its CHUNK.  Here the chunk
+// lane loads the sub-run that is in force at the chunk's first byte ITSELF and keeps it in registers — for a chunk no event starts in
+// (more than half of the chunks of an aligned read, 19 of 20 in the second pass of -k) that is the whole chunk: one load, complement /
+// reverse, one aligned store, no LDS round trip for the data.  Only the sub-runs that start INSIDE a chunk (one per event, lane = event,
+// one pass) and the letters go through the LDS tile; the chunk lane ORs its own bytes with what it finds there.  No element list, no
+// deferred final pass, 3.7 instead of 5.0 KB of LDS per wavefront.  Same-box A/B (profiles/r06/ab_tile_v7.log): record kernel 5.23 ->
+// 5.11 ms, bytes identical; other tile sizes / occupancies of v7 all lose (one chunk per lane at 8 waves 6.5 ms, four at 6 waves 6.8 ms,
+// two at 8 waves with 64 VGPRs — spills — 6.0 ms).
+// ================================================================================================================================
+struct __align__(16) TileLds7 {
+    uint32_t mlut[17][4];                       // mlut[i]: 16-byte mask with bytes >= i set; [16] empty
+    uint2 ent[T_EV + 1];                        // per staged event (0: the event in force at the tile start): x = first output offset copied
+                                                // under it, y = segment position minus output offset of those bytes
+    uint32_t eos[T_EV + 1];                     // first output offset of tile event k (0xffffffff behind the last)
+    uint32_t hist[64 * NS_TILE_CHUNKS];         // build: last event at or before chunk c (+1); afterwards: the number of events at or before it
+    __align__(16) uint8_t out[T_OUT + 16 + 64]; // letters and event sub-runs of the tile (zero where nothing has been written) + dump slots
+};
+__device__ __forceinline__ void tile_lds_init(TileLds7 &T, uint32_t lane) {
+    for (uint32_t c = lane * 16; c < T_OUT + 16 + 64; c += 64 * 16) *reinterpret_cast<uint4 *>(&T.out[c]) = make_uint4(0, 0, 0, 0);
+    if (lane < 17) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k)
+            T.mlut[lane][k] = lane <= 4 * k ? 0xffffffffu : lane >= 4 * k + 4 ? 0u : 0xffffffffu << (8 * (lane - 4 * k));
+    }
+}
+// IUPAC codes among the bytes [i0, i1) of a masked 16-byte group whose byte b lies at segment position x0 + b (case_convert, S:743-755: rare)
+__device__ __forceinline__ void resolve16(uint32_t &a0, uint32_t &a1, uint32_t &a2, uint32_t &a3, uint32_t i0, uint32_t i1, uint32_t x0,
+                                          const ns_key &key, uint32_t sid, uint32_t a) {
+    for (uint32_t b = i0; b < i1; ++b) {
+        uint32_t wk = b < 8 ? (b < 4 ? a0 : a1) : (b < 12 ? a2 : a3);
+        const uint32_t ch = (wk >> (8 * (b & 3))) & 0xff;
+        if (!(ch & 0x80u)) continue;
+        const uint32_t r = resolve_base(ch, key, sid, a, x0 + b);
+        wk = (wk & ~(0xffu << (8 * (b & 3)))) | r << (8 * (b & 3));
+        if (b < 4) a0 = wk; else if (b < 8) a1 = wk; else if (b < 12) a2 = wk; else a3 = wk;
+    }
+}
 template <bool FASTQ, int MODE>
-__device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, TileLds6 &T, const ReadOut &ro, const ns_key &key,
+__device__ inline void materialise_piece7(const DevModel &m, const DevRef &ref, TileLds7 &T, const ReadOut &ro, const ns_key &key,
                                           uint32_t a, const PieceCtx &pc, uint32_t pq, uint32_t lane, uint32_t dbg, const SlowQueue &sq,
                                           uint32_t read_idx, uint32_t piece_idx, uint32_t *__restrict__ cls) {
     constexpr bool CLSOUT = FASTQ && MODE != MAT_HP_SCRATCH;           // the class of every base leaves as 2 bits for k_qualities (cls: the piece's words)
@@ -684,56 +695,9 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
     const uint32_t phi = ro.reversed ? ((uint32_t)(uintptr_t)ro.seq + ro.seq_len - pq) & 15u : (0u - ((uint32_t)(uintptr_t)ro.seq + pq)) & 15u;
     ns_event e_pre; e_pre.pos = 0; e_pre.info = 0; uint32_t w_pre = 0;
     if (lane < pc.n_ev) e_pre = pc.ev[lane];
-    // (round 4: caching the letter words of 256 events per Philox evaluation — lane l keeps block l, tiles fetch theirs by ds_bpermute or
-    // from 1 KB of LDS — was SLOWER in every variant: record kernel 5.72 ms without, 6.40 / 5.93 / 6.06 with (registers at 7 / 6 waves per
-    // SIMD, LDS): the spills and cross-lane reads cost more than the Philox they save.  The word is drawn per tile: event_word.)
     auto cached_word = [&](uint32_t j0) -> uint32_t { if (dbg & 64u) return 0u; const uint32_t j = j0 + lane; return event_word<MODE>(pc, key, a, j < pc.n_ev ? j : 0u); };
     w_pre = cached_word(0u);
-    // The tile whose bytes are complete in T.out and wait for their final pass (step 4): it runs UNDER the loads of the next tile
-    bool have_prev = false;
-    uint32_t A0p = 0, M0p = 0, M1p = 0;
     uint32_t cls_carry = 0;                // class bits of the chunk the last tile ended in (tiles queued for the generic path: none)
-    // ---- 4. one lane per aligned 16-byte chunk of the tile [M0p, M1p): qualities, complement / reverse, one aligned 16-byte store
-    auto final_pass = [&]() {
-        if (!have_prev) return;
-        have_prev = false;
-#if NS_TILE_CHUNKS > 1
-#pragma nounroll
-#endif
-        for (uint32_t t = 0; t < NS_TILE_CHUNKS; ++t) {
-            const uint32_t ci = 64 * t + lane;
-            const uint32_t c0 = A0p + 16 * ci;                         // chunk origin (chunk 0 of a piece's first tile may start before M0)
-            const uint32_t lo_m = ci == 0 ? M0p : c0, hi_m = min(c0 + 16, M1p);
-            const bool active = (int32_t)(hi_m - lo_m) > 0 && !(dbg & 1);
-            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, cw = 0;
-            if (active) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(&T.out[16 * ci]);
-                *reinterpret_cast<uint4 *>(&T.out[16 * ci]) = make_uint4(0, 0, 0, 0);      // the tile is left clean for the next one
-                r0 = v.x; r1 = v.y; r2 = v.z; r3 = v.w;
-            }
-            if (active) {
-                uint64_t qlo = 0, qhi = 0;
-                uint32_t s0 = lo_m - c0, count = hi_m - lo_m;          // bytes [s0, s0 + count) of the chunk are this tile's
-                if constexpr (CLSOUT) {                                // chunk k of the piece covers its positions [16 k - g, 16 k - g + 16), g = -phi mod 16
-                    cw = cls_pack16(r0, r1, r2, r3);
-                    if (ci == 0) cw |= cls_carry;                      // (a tile cut inside a chunk: the bits of the part the last tile wrote)
-                    if (!pc.kind) cls[(c0 + ((0u - phi) & 15u)) >> 4] = cw;
-                    r0 &= NS_CLS_STRIP; r1 &= NS_CLS_STRIP; r2 &= NS_CLS_STRIP; r3 &= NS_CLS_STRIP;
-                }
-                uint64_t lo = (uint64_t)r0 | (uint64_t)r1 << 32, hi = (uint64_t)r2 | (uint64_t)r3 << 32;
-                if (s0) {                                              // front-partial chunk (first chunk of a piece): shift down
-                    const uint32_t sh = 8 * s0;
-                    if (sh < 64) { lo = (lo >> sh) | (hi << (64 - sh)); hi >>= sh; qlo = (qlo >> sh) | (qhi << (64 - sh)); qhi >>= sh; }
-                    else { lo = hi >> (sh - 64); hi = 0; qlo = qhi >> (sh - 64); qhi = 0; }
-                }
-                if (!(dbg & 16)) { PendingChunk pd = prep_chunk(ro, pq + lo_m, count, lo, hi, qlo, qhi); flush_chunk(ro, pd); }
-            }
-            if constexpr (CLSOUT) {                                    // the tile ends inside a chunk: its word goes on in the next tile's chunk 0
-                const uint32_t cl = (M1p - 1u - A0p) >> 4;
-                if (t == (cl >> 6)) cls_carry = (M1p < pc.out_len && ((M1p - A0p) & 15u)) ? (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)(cl & 63u)) : 0u;
-            }
-        }
-    };
     for (uint32_t M0 = 0; M0 < pc.out_len;) {
         const uint32_t A0 = M0 - ((M0 - phi) & 15u);             // aligned origin of the tile (<= M0; may be "negative" = wrapped)
         uint32_t M1 = min(A0 + T_OUT, pc.out_len);
@@ -744,18 +708,16 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
         const uint32_t os = ev_out_start(e), len = ns_ev_len(e.info), ty = ns_ev_type(e.info);
         const uint32_t e_pt = (ty == NS_DEL ? 0u : len) | ty << 12, e_rp = e.pos + (ty == NS_INS ? 0u : len);
         if (jb + 63 < pc.n_ev) {           // more events than lanes: the tile ends early — on a CHUNK boundary, so that the next tile starts on one
-            const uint32_t os63 = (uint32_t)__builtin_amdgcn_readlane((int)os, 63);     // (a tile cut inside a chunk gives this tile a partial last
-            if (os63 < M1) {                                                             // chunk and the next one a partial first chunk: the partial
-                const uint32_t cut = A0 + ((os63 - A0) & ~15u);                          // store path then runs in every iteration of the final pass)
+            const uint32_t os63 = (uint32_t)__builtin_amdgcn_readlane((int)os, 63);
+            if (os63 < M1) {
+                const uint32_t cut = A0 + ((os63 - A0) & ~15u);
                 M1 = (int32_t)(cut - M0) > 0 ? cut : os63;                                // (A0, and with it cut, may be "negative": wrapped)
             }
         }
         const bool take = valid && os < M1;
         const uint32_t cnt = (uint32_t)__popcll(__ballot(take));
         if (M1 <= M0) {                    // 64 events at one output offset (zero-length matches between deletions): not a case
-            final_pass();                  // for the tile machinery; the generic path takes the tile
-            cls_carry = 0;
-            wave_sync();
+            cls_carry = 0;                 // for the tile machinery; the generic path takes the tile
             M1 = min(M0 + T_OUT, pc.out_len);
             uint32_t j2 = jb;
             while (j2 < pc.n_ev && ev_out_start(pc.ev[j2]) < M1) ++j2;
@@ -776,19 +738,15 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
             continue;
         }
         const uint32_t nc = (M1 - A0 + 15u) >> 4;                 // chunks of the tile (chunk 0 starts at M0, chunk c > 0 at A0 + 16 c)
-        const uint32_t nel = nc + cnt;                            // elements: chunk starts + event starts
         // chunk an event sorts in front of: the first one that starts at or after it (an event AT a chunk start comes first, so the
         // chunk already copies under it)
         const uint32_t ekey = take ? (os <= M0 ? 0u : (os - A0 + 15u) >> 4) : 0xffffffffu;
+        const uint32_t s1 = os + (e_pt & 0xfffu), y1 = e_rp - s1;
         {
             const uint32_t s0 = L0_out + (L0_pt & 0xfffu);
             T.ent[0] = make_uint2(s0, L0_rp - s0);                // (every lane, same value)
-            if (take) {
-                const uint32_t s1 = os + (e_pt & 0xfffu), y1 = e_rp - s1;
-                T.ent[1 + lane] = make_uint2(s1, y1);
-                T.desc[lane + ekey] = make_uint2((min(s1, M1) - A0) | (os - A0) << 16, y1);
-            }
-            T.desc[nel] = make_uint2((M1 - A0) | (M1 - A0) << 16, 0u);          // sentinel: the last sub-run ends at M1
+            if (take) T.ent[1 + lane] = make_uint2(s1, y1);
+            T.eos[lane] = take ? os : 0xffffffffu;                // (cnt <= 63: slot cnt holds the end mark)
         }
 #pragma unroll
         for (uint32_t t = 0; t < NS_TILE_CHUNKS; ++t) T.hist[64 * t + lane] = 0;
@@ -797,6 +755,8 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
         if (M1 < pc.out_len && jb_next + lane < pc.n_ev) e_pre = pc.ev[jb_next + lane];       // prefetch for the next tile
         if (M1 < pc.out_len) w_pre = cached_word(jb_next);
         wave_sync();
+        // first output offset of the next event of the tile (the last one: none)
+        const uint32_t os_next = dpp_wave_shl1(0xffffffffu, take ? os : 0xffffffffu);
         {   // hist[c] = number of the tile's events sorted in front of chunk c — written by the LAST one (sorted events: lane l is event l + 1
             // of the tile), the chunks in between inherit it through a prefix maximum
             const uint32_t c_next = dpp_wave_shl1(0xffffffffu, ekey);
@@ -823,7 +783,6 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
             else if (x1 > wrap_at) fast = false;                   // tile straddles the origin
         }
         if (!fast) {
-            final_pass();
             cls_carry = 0;
             if (lane == 0) {
                 const uint32_t slot = atomicAdd(sq.count, 1u);
@@ -835,7 +794,9 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
             continue;
         }
         wave_sync();
-        // ---- 3a. the chunk elements: chunk c is element c + (events in front of it), it copies under the last of those events
+        // ---- 3a. lane per chunk: the sub-run in force at the chunk's first byte — [max(chunk start, first byte copied under the last event at
+        // or before it), min(next event, chunk end)) — is loaded HERE and stays in registers until the chunk leaves
+        uint4 f[NS_TILE_CHUNKS]; uint32_t fi[NS_TILE_CHUNKS], fy[NS_TILE_CHUNKS];
         {
             uint32_t scan_base = 0;
 #pragma unroll
@@ -843,34 +804,30 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
                 const uint32_t ci = 64 * t + lane;
                 const uint32_t incl = max(scan_base, wave_incl_max(T.hist[ci]));
                 scan_base = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                if (ci < nc && !(dbg & 8192u)) {
-                    const uint32_t p = ci == 0 ? M0 : A0 + 16u * ci;
+                f[t] = make_uint4(0, 0, 0, 0); fi[t] = 16u | 16u << 8; fy[t] = 0;
+                if (ci < nc && !(dbg & 1)) {
+                    const uint32_t cs = A0 + 16u * ci, p = ci == 0 ? M0 : cs;
                     const uint2 E = T.ent[incl];
-                    T.desc[ci + incl] = make_uint2((min(max(p, E.x), M1) - A0) | (p - A0) << 16, E.y);
+                    const uint32_t nx = T.eos[incl];
+                    const uint32_t st = max(p, E.x), en = min(nx, min(cs + 16u, M1));
+                    if ((int32_t)(en - st) > 0) {
+                        fi[t] = (st - cs) | (en - cs) << 8; fy[t] = E.y;
+                        __builtin_memcpy(&f[t], tb + (E.y + cs + 32u), 16);
+                    }
                 }
             }
         }
-        wave_sync();
-        // ---- 3b. one lane per sub-run: element j copies [start_j, cut_(j+1)).  All loads of the tile are issued here; they travel while
-        // the PREVIOUS tile gets its final pass and this tile its letters
-        uint4 f[3]; uint32_t i0[3], i1[3], oc[3];
-#pragma unroll
-        for (uint32_t ps = 0; ps < 3; ++ps) {
-            const uint32_t j = 64u * ps + lane;
-            f[ps] = make_uint4(0, 0, 0, 0); i0[ps] = 16; i1[ps] = 16; oc[ps] = 0;
-            if (!(dbg & 1) && 64u * ps < nel && j < nel) {
-                const uint2 d0 = T.desc[j];
-                const uint32_t nx = T.desc[j + 1].x;
-                const uint32_t st = d0.x & 0xffffu, en = nx >> 16;
-                if (en > st) {
-                    const uint32_t c = st >> 4;                          // (relative to A0: the chunk of the sub-run)
-                    oc[ps] = 16u * c; i0[ps] = st - 16u * c; i1[ps] = en - 16u * c;
-                    __builtin_memcpy(&f[ps], tb + (d0.y + A0 + 16u * c + 32u), 16);
-                }
+        // ---- 3b. lane per event: the sub-run that starts behind the event's letters, up to the next event or the end of its chunk — unless the
+        // chunk starts under this event (then the chunk lane has it)
+        uint4 fe = make_uint4(0, 0, 0, 0); uint32_t ei0 = 16, ei1 = 16, eoc = 0;
+        if (take && !(dbg & 1)) {
+            const uint32_t c = (s1 - A0) >> 4, ecs = A0 + 16u * c;
+            const uint32_t en = min(os_next, min(ecs + 16u, M1));
+            if ((int32_t)(en - s1) > 0 && ekey > c) {
+                eoc = 16u * c; ei0 = s1 - ecs; ei1 = en - ecs;
+                __builtin_memcpy(&fe, tb + (y1 + ecs + 32u), 16);
             }
         }
-        final_pass();                                              // the previous tile: reads and clears T.out
-        wave_sync();
         // ---- 2. letters: lane per event; lane 63 (never a taker) continues the payload of the event in force at M0
         if (!(dbg & 2)) {
             const bool cont = lane == 63 && L0_out + (L0_pt & 0xfffu) > M0;
@@ -880,8 +837,7 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
             const uint32_t b_pl = b_pt & 0xfffu, b_ty = b_pt >> 12;
             const bool on = (take || cont) && b_pl;
             const uint32_t xs = b_rp - b_pl;                      // segment position under the first substituted base
-            // fast path (branch-free): up to EIGHT letters, all inside the tile, plain bases under a substitution (with four, two tiles in
-            // five had an event for the per-byte loop below; run lengths beyond eight are one event in three hundred)
+            // fast path (branch-free): up to EIGHT letters, all inside the tile, plain bases under a substitution
             const bool mis = b_ty == NS_MIS;
             bool fast_l = on && b_pl <= 8 && b_os >= M0 && b_os + b_pl <= M1 && !wraps;
             uint2 cur8 = make_uint2(0x41414141u, 0x41414141u);
@@ -939,39 +895,63 @@ __device__ inline void materialise_piece6(const DevModel &m, const DevRef &ref, 
                     if (i >= i_lo) T.out[b_os + i - A0] = (uint8_t)b;
                 }
             }
-            // the dump slots collect predicated-off letter bytes: cleared so that the tile stays zero outside its bytes
         }
-        // ---- 3c. the sub-runs arrive: masked to their bytes, IUPAC codes resolved (case_convert, S:743-755: rare), OR-ed into the tile
+        // ---- 3c. the event sub-runs arrive: masked to their bytes, IUPAC codes resolved, OR-ed into the tile (no two sub-runs share a byte:
+        // the OR is a store that needs no ordering)
+        if (cnt && ei0 < 16u && !(dbg & 32u)) {
+            const uint4 m0 = *reinterpret_cast<const uint4 *>(&T.mlut[ei0][0]), m1 = *reinterpret_cast<const uint4 *>(&T.mlut[ei1][0]);
+            uint32_t a0 = fe.x & m0.x & ~m1.x, a1 = fe.y & m0.y & ~m1.y, a2 = fe.z & m0.z & ~m1.z, a3 = fe.w & m0.w & ~m1.w;
+            if constexpr (!HPF) {
+                if ((a0 | a1 | a2 | a3) & 0x80808080u) resolve16(a0, a1, a2, a3, ei0, ei1, A0 + eoc + y1, key, pc.sid, a);
+            }
+            lds_or64(&T.out[eoc], (uint64_t)a0 | (uint64_t)a1 << 32);
+            lds_or64(&T.out[eoc + 8], (uint64_t)a2 | (uint64_t)a3 << 32);
+        }
+        wave_sync();
+        // ---- 4. lane per aligned 16-byte chunk: own sub-run | what the tile holds; qualities classes, complement / reverse, one aligned store
+        // (unrolled: f[t] must stay in registers)
 #pragma unroll
-        for (uint32_t ps = 0; ps < 3; ++ps) {
-            if (64u * ps < nel && i0[ps] < 16u && !(dbg & 32u)) {
-                const uint4 m0 = *reinterpret_cast<const uint4 *>(&T.mlut[i0[ps]][0]), m1 = *reinterpret_cast<const uint4 *>(&T.mlut[i1[ps]][0]);
-                uint32_t a0 = f[ps].x & m0.x & ~m1.x, a1 = f[ps].y & m0.y & ~m1.y, a2 = f[ps].z & m0.z & ~m1.z, a3 = f[ps].w & m0.w & ~m1.w;
+        for (uint32_t t = 0; t < NS_TILE_CHUNKS; ++t) {
+            const uint32_t ci = 64 * t + lane;
+            const uint32_t c0 = A0 + 16 * ci;                         // chunk origin (chunk 0 of a piece's first tile may start before M0)
+            const uint32_t lo_m = ci == 0 ? M0 : c0, hi_m = min(c0 + 16, M1);
+            const bool active = (int32_t)(hi_m - lo_m) > 0 && !(dbg & 1);
+            uint32_t cw = 0;
+            if (active) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(&T.out[16 * ci]);
+                *reinterpret_cast<uint4 *>(&T.out[16 * ci]) = make_uint4(0, 0, 0, 0);      // the tile is left clean for the next one
+                const uint32_t i0 = fi[t] & 0xffu, i1 = fi[t] >> 8;
+                const uint4 m0 = *reinterpret_cast<const uint4 *>(&T.mlut[i0][0]), m1 = *reinterpret_cast<const uint4 *>(&T.mlut[i1][0]);
+                uint32_t a0 = f[t].x & m0.x & ~m1.x, a1 = f[t].y & m0.y & ~m1.y, a2 = f[t].z & m0.z & ~m1.z, a3 = f[t].w & m0.w & ~m1.w;
                 if constexpr (!HPF) {
-                    if ((a0 | a1 | a2 | a3) & 0x80808080u) {
-                        const uint32_t y = T.desc[64u * ps + lane].y;
-                        for (uint32_t b = i0[ps]; b < i1[ps]; ++b) {
-                            uint32_t wk = b < 8 ? (b < 4 ? a0 : a1) : (b < 12 ? a2 : a3);
-                            const uint32_t ch = (wk >> (8 * (b & 3))) & 0xff;
-                            if (!(ch & 0x80u)) continue;
-                            const uint32_t x = A0 + oc[ps] + b + y;              // segment position of the byte
-                            const uint32_t r = resolve_base(ch, key, pc.sid, a, x);
-                            wk = (wk & ~(0xffu << (8 * (b & 3)))) | r << (8 * (b & 3));
-                            if (b < 4) a0 = wk; else if (b < 8) a1 = wk; else if (b < 12) a2 = wk; else a3 = wk;
-                        }
-                    }
+                    if ((a0 | a1 | a2 | a3) & 0x80808080u) resolve16(a0, a1, a2, a3, i0, i1, c0 + fy[t], key, pc.sid, a);
                 }
-                lds_or64(&T.out[oc[ps]], (uint64_t)a0 | (uint64_t)a1 << 32);
-                lds_or64(&T.out[oc[ps] + 8], (uint64_t)a2 | (uint64_t)a3 << 32);
+                uint32_t r0 = v.x | a0, r1 = v.y | a1, r2 = v.z | a2, r3 = v.w | a3;
+                uint64_t qlo = 0, qhi = 0;
+                uint32_t s0 = lo_m - c0, count = hi_m - lo_m;          // bytes [s0, s0 + count) of the chunk are this tile's
+                if constexpr (CLSOUT) {                                // chunk k of the piece covers its positions [16 k - g, 16 k - g + 16), g = -phi mod 16
+                    cw = cls_pack16(r0, r1, r2, r3);
+                    if (ci == 0) cw |= cls_carry;                      // (a tile cut inside a chunk: the bits of the part the last tile wrote)
+                    if (!pc.kind) cls[(c0 + ((0u - phi) & 15u)) >> 4] = cw;
+                    r0 &= NS_CLS_STRIP; r1 &= NS_CLS_STRIP; r2 &= NS_CLS_STRIP; r3 &= NS_CLS_STRIP;
+                }
+                uint64_t lo = (uint64_t)r0 | (uint64_t)r1 << 32, hi = (uint64_t)r2 | (uint64_t)r3 << 32;
+                if (s0) {                                              // front-partial chunk (first chunk of a piece): shift down
+                    const uint32_t sh = 8 * s0;
+                    if (sh < 64) { lo = (lo >> sh) | (hi << (64 - sh)); hi >>= sh; }
+                    else { lo = hi >> (sh - 64); hi = 0; }
+                }
+                if (!(dbg & 16)) { PendingChunk pd = prep_chunk(ro, pq + lo_m, count, lo, hi, qlo, qhi); flush_chunk(ro, pd); }
+            }
+            if constexpr (CLSOUT) {                                    // the tile ends inside a chunk: its word goes on in the next tile's chunk 0
+                const uint32_t cl = (M1 - 1u - A0) >> 4;
+                if (t == (cl >> 6)) cls_carry = (M1 < pc.out_len && ((M1 - A0) & 15u)) ? (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)(cl & 63u)) : 0u;
             }
         }
         L0_out = osl; L0_rp = rpl; L0_pt = ptl; L0_wd = wdl; L0_j = jl;
-        have_prev = true; A0p = A0; M0p = M0; M1p = M1;
         jb = jb_next; M0 = M1;
         wave_sync();
     }
-    final_pass();
-    wave_sync();
 }
 
 // ---- the quality lines (k_qualities) ----------------------------------------------------------------------------------------------

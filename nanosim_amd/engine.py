@@ -234,8 +234,14 @@ class Engine:
         Returns (aligned Batch or None, unaligned Batch or None); the unaligned batch lives on step_engine()."""
         info = (NsBatchInfo * 2)()
         un_eng = self.step_engine() if unaligned is not None else None
-        self._check(self.L.ns_generate_step(self.ctx, C.byref(aligned) if aligned is not None else None,
-                                            C.byref(unaligned) if unaligned is not None else None, info))
+        try:
+            self._check(self.L.ns_generate_step(self.ctx, C.byref(aligned) if aligned is not None else None,
+                                                C.byref(unaligned) if unaligned is not None else None, info))
+        except EngineError as err:
+            # only the unaligned half failed (the library says which: "unaligned worker call: ..."): the aligned batch is complete
+            if aligned is not None and unaligned is not None and "unaligned worker call:" in str(err):
+                err.aligned_batch = Batch(self, info[0])
+            raise
         return (Batch(self, info[0]) if aligned is not None else None, Batch(un_eng, info[1]) if unaligned is not None else None)
 
     def set_background(self, on: bool = True):
@@ -249,6 +255,8 @@ class Engine:
             self._pinned = []
             if getattr(self, "_owner", None) is not None:      # a step companion: its owner destroys it
                 self.ctx = C.c_void_p()
+                if getattr(self._owner, "_step_engine", None) is self:      # ... and hands out a fresh wrapper on the next step_engine()
+                    self._owner._step_engine = None
                 return
             se = getattr(self, "_step_engine", None)
             if se is not None:

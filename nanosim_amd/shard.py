@@ -250,6 +250,14 @@ def collect_parts(path: str, world: int, own=None, keep: bool = False, timeout_s
     fd = None
     try:
         if not keep:
+            if world > 1:            # (--merge with several ranks: say what it will cost before it does)
+                try:
+                    own_bytes = sum(os.path.getsize(x) for x in own)
+                except OSError:
+                    own_bytes = 0
+                sys.stderr.write("merging %d ranks' parts of %s into one file: about %.1f GB through one inode at 6-10 GB/s = %.0f-%.0f s "
+                                 "(default without --merge: the parts stay, <file>.subfiles lists them)\n"
+                                 % (world, os.path.basename(path), own_bytes * world / 1e9, own_bytes * (world - 1) / 10e9, own_bytes * (world - 1) / 6e9))
             fd = os.open(path, os.O_WRONLY | os.O_CREAT, 0o644)          # (no O_APPEND: copy_file_range refuses such a descriptor)
             if final not in own:
                 os.ftruncate(fd, 0)

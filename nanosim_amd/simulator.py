@@ -35,6 +35,9 @@ def log(msg):
     sys.stdout.flush()
 
 
+MERGE_HELP = ("Not in the reference: with several ranks (one process per GPU) concatenate every rank's sub-files into ONE file per output, "
+              "as the reference's workers do (S:1626-1639).  Off by default when WORLD_SIZE > 1: rank 0 would append terabytes through one "
+              "inode at 6-10 GB/s after minutes of GPU work; <file>.subfiles lists the parts in order (cat $(cat <file>.subfiles) = <file>)")
 NO_MERGE_HELP = ("Not in the reference: with -t K > 1 (or several ranks) keep the sub-files the workers wrote side by side and list them in "
                  "<file>.subfiles (cat $(cat <file>.subfiles) = <file>) instead of concatenating them into one file as the reference does "
                  "(S:1626-1639).  Writes into ONE inode serialise in the kernel (5.7 GB/s on the measured box): the merge, not the GPU, sets "
@@ -76,6 +79,7 @@ def build_parser():
     g.add_argument('--chimeric', action='store_true', default=False, help='Simulate chimeric reads')
     g.add_argument('-t', '--num_threads', type=int, default=1, help='Number of threads for simulation (Default = 1)')
     g.add_argument('--no-merge', dest='no_merge', action='store_true', default=False, help=NO_MERGE_HELP)
+    g.add_argument('--merge', dest='merge', action='store_true', default=False, help=MERGE_HELP)
 
     t = sub.add_parser('transcriptome', help="Run the simulator on transcriptome mode")
     t.add_argument('-rt', '--ref_t', required=True)
@@ -98,6 +102,7 @@ def build_parser():
     t.add_argument('--fastq', action='store_true', default=False)
     t.add_argument('-t', '--num_threads', type=int, default=1)
     t.add_argument('--no-merge', dest='no_merge', action='store_true', default=False, help=NO_MERGE_HELP)
+    t.add_argument('--merge', dest='merge', action='store_true', default=False, help=MERGE_HELP)
     t.add_argument('--uracil', action='store_true', default=False)
 
     mg = sub.add_parser('metagenome', help="Run the simulator on metagenome mode")
@@ -120,6 +125,7 @@ def build_parser():
     mg.add_argument('--chimeric', action='store_true', default=False)
     mg.add_argument('-t', '--num_threads', type=int, default=1)
     mg.add_argument('--no-merge', dest='no_merge', action='store_true', default=False, help=NO_MERGE_HELP)
+    mg.add_argument('--merge', dest='merge', action='store_true', default=False, help=MERGE_HELP)
     return parser, g, mg, t
 
 
@@ -226,11 +232,14 @@ class StepPair:
             return self.eng.generate(p)
         try:
             b_al, b_un = self.eng.generate_step(p, pu)
-        except BaseException:
+        except BaseException as ex:
             with self.cv:            # the unaligned call repeats on its own (and reports its own error, if it was its error)
                 self.result = ("alone", None)
                 self.cv.notify_all()
-            raise
+            b_al = getattr(ex, "aligned_batch", None)
+            if b_al is None:
+                raise
+            return b_al              # only the unaligned half failed: the aligned batch is good and its phase keeps its batch size
         with self.cv:
             self.result = ("ok", b_un)
             self.cv.notify_all()
@@ -773,7 +782,14 @@ def main(argv=None):
         parser.print_help(sys.stderr)
         sys.exit(1)
     a = parser.parse_args(argv)
+    if getattr(a, "no_merge", False) and getattr(a, "merge", False):
+        sys.stderr.write("--merge and --no-merge exclude each other\n")
+        sys.exit(1)
+    world = int(os.environ.get("WORLD_SIZE", "1") or 1)
     if getattr(a, "no_merge", False):
+        os.environ["NS_KEEP_SUBFILES"] = "1"
+    elif world > 1 and not getattr(a, "merge", False) and "NS_KEEP_SUBFILES" not in os.environ:
+        # several ranks: the parts stay where the ranks wrote them unless --merge asks for the reference's single files (MERGE_HELP)
         os.environ["NS_KEEP_SUBFILES"] = "1"
     if a.mode == "genome":
         run_genome(a, parser_g)

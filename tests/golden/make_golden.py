@@ -926,13 +926,16 @@ def fixture_metagenome_runs(prefix, workdir, n_reads=24000):
     return out
 
 def _dist_worker(args):
+    dna_type = "linear"
+    if len(args) == 10:
+        args, dna_type = args[:9], args[9]
     idx, n_al, n_un, prefix, fasta, workdir, fastq, kmer, chimeric = args
     S = import_reference()
     devnull = open(os.devnull, "w")
     so = sys.stdout
     sys.stdout = devnull
     try:
-        S.read_profile(fasta, [n_al + n_un], prefix, False, "genome", None, dna_type="linear", chimeric=chimeric,
+        S.read_profile(fasta, [n_al + n_un], prefix, False, "genome", None, dna_type=dna_type, chimeric=chimeric,
                        homopolymer=bool(kmer), fastq=fastq)
     finally:
         sys.stdout = so
@@ -944,8 +947,8 @@ def _dist_worker(args):
     o_un = os.path.join(workdir, "un%d%s" % (idx, ext))
     sys.stdout = devnull
     try:
-        S.simulation_aligned_genome("linear", 50, S.max_chrom, None, None, o_reads, o_err, kmer, fastq, n_al, False, chimeric)
-        S.simulation_unaligned("linear", 50, S.max_chrom, None, None, o_un, fastq, n_un, False)
+        S.simulation_aligned_genome(dna_type, 50, S.max_chrom, None, None, o_reads, o_err, kmer, fastq, n_al, False, chimeric)
+        S.simulation_unaligned(dna_type, 50, S.max_chrom, None, None, o_un, fastq, n_un, False)
     finally:
         sys.stdout = so
     # per-read metrics
@@ -992,11 +995,11 @@ def quantiles(x, k=2048):
     return x[idx].tolist()
 
 
-def fixture_distributions(prefix, fasta, workdir, n_reads, fastq, kmer=None, chimeric=False, n_unaligned=None):
+def fixture_distributions(prefix, fasta, workdir, n_reads, fastq, kmer=None, chimeric=False, n_unaligned=None, dna_type="linear"):
     n_proc = min(8, os.cpu_count() or 1)
     n_al = int(round(n_reads * 19.0 / 20.0))
     n_un = n_reads - n_al if n_unaligned is None else n_unaligned
-    args = [(i, n_al // n_proc, max(1, n_un // n_proc), prefix, fasta, workdir, fastq, kmer, chimeric) for i in range(n_proc)]
+    args = [(i, n_al // n_proc, max(1, n_un // n_proc), prefix, fasta, workdir, fastq, kmer, chimeric, dna_type) for i in range(n_proc)]
     with mp.get_context("fork").Pool(n_proc) as pool:
         res = pool.map(_dist_worker, args)
     cat = lambda k: np.concatenate([np.asarray(r[k]) for r in res])
@@ -1047,6 +1050,25 @@ def write_distributions(prefix, fasta, workdir, n):
     print("reference_distributions.json written")
 
 
+HG002_SEED = 20260926          # bench.py's SEED: the model and the reference of the headline workload
+
+
+def write_hg002(workdir, n):
+    """The north-star gate on the north-star workload: the unmodified reference on the `hg002_like` model bench.py times (n_train 10^6 per
+    KDE, aligned regions of 8.4 kb on average) and its `ecoli_like` reference (4 641 652 bp, circular) — n aligned + 100 000 unaligned reads.
+    Neither input is committed (the tests rebuild both from nanosim_amd/synth.py by seed); the fixture is the quantile summary."""
+    prefix = os.path.join(workdir, "hg002", "training")
+    synth.write_model(prefix, synth.SynthModelSpec(n_train=1_000_000, seed=HG002_SEED), write_pkl=True, write_npz=False)
+    fasta = os.path.join(workdir, "ecoli_like.fa")
+    synth.write_fasta(fasta, [("ecoli-like", synth.synth_sequence(synth.ECOLI_LEN, HG002_SEED, n_frac=0.0005, iupac_frac=0.0002, lower_frac=0.02, hp_boost=0.005))])
+    d = fixture_distributions(prefix, fasta, workdir, int(round(n * 20.0 / 19.0)), False, n_unaligned=100000, dna_type="circular")
+    d["model"] = dict(spec="synth.SynthModelSpec(n_train=1_000_000, seed=%d)" % HG002_SEED,
+                      reference="synth.synth_sequence(ECOLI_LEN, %d, n_frac=0.0005, iupac_frac=0.0002, lower_frac=0.02, hp_boost=0.005), circular" % HG002_SEED)
+    with open(os.path.join(HERE, "reference_hg002.json"), "w") as f:
+        json.dump(d, f)
+    print("reference_hg002.json written: %d aligned, %d unaligned reads" % (d["n_aligned"], d["n_unaligned"]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dist-reads", type=int, default=100000)
@@ -1065,6 +1087,7 @@ def main():
                     help="write reference_chimeric_dense.json only: genome mode --chimeric with the small model at 2 segments per read on average, "
                          "so that the fixture holds > 10^5 chimeric reads (gap lengths and segment counts at the 1 %% gate)")
     ap.add_argument("--only-dist", action="store_true", help="write reference_distributions.json only (whole-run distribution pins)")
+    ap.add_argument("--only-hg002", action="store_true", help="write reference_hg002.json only: the bench-scale model (n_train 10^6, mean 8.4 kb) on the ecoli_like reference, --dist-reads aligned reads")
     ap.add_argument("--only-coverage", action="store_true", help="write reference_coverage.json only (-x / --coverage read counts)")
     ap.add_argument("--only-meta-runs", action="store_true", help="replace the whole-run part (runs) of reference_metagenome.json: 8 workers x 12 500 reads, plain and chimeric, + 8 x 6 000 perfect reads")
     a = ap.parse_args()
@@ -1075,6 +1098,9 @@ def main():
             with open(os.path.join(HERE, "reference_ir.json"), "w") as f:
                 json.dump(fixture_ir(import_reference()), f)
             print("reference_ir.json written")
+            return
+        if a.only_hg002:
+            write_hg002(workdir, a.dist_reads)
             return
         prefix, fasta, circ = build_inputs(workdir)
         if a.only_ir_splice:
@@ -1133,6 +1159,7 @@ def main():
         if a.only_dist:
             write_distributions(prefix, fasta, workdir, a.dist_reads)
             return
+
         if a.only_meta_runs:
             mg = json.load(open(os.path.join(HERE, "reference_metagenome.json")))
             mg["runs"] = fixture_metagenome_runs(prefix, workdir, n_reads=100000)

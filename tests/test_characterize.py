@@ -150,3 +150,9 @@ def test_maf_reader(tmp_path):
     p = tmp_path / "t_besthit.maf"
     p.write_text("s ref 10 5 + 1000 AC-GT\ns read1 0 5 + 5 ACTGT\ns ref 20 3 + 1000 acg\ns read2 0 3 + 3 ACG\n")
     assert characterize.maf_pairs(str(p)) == [("AC-GT", "ACTGT"), ("acg", "ACG")]
+    # what else a MAF file may carry is skipped; an `s` line without its partner is an error, not a StopIteration
+    p.write_text("##maf version=1\na score=12\ns ref 10 5 + 1000 AC-GT\ns read1 0 5 + 5 ACTGT\n\na score=3\ns ref 20 3 + 1000 acg\ns read2 0 3 + 3 ACG\n")
+    assert characterize.maf_pairs(str(p)) == [("AC-GT", "ACTGT"), ("acg", "ACG")]
+    p.write_text("s ref 10 5 + 1000 AC-GT\ns read1 0 5 + 5 ACTGT\ns ref 20 3 + 1000 acg\n")
+    with pytest.raises(ValueError):
+        characterize.maf_pairs(str(p))

@@ -377,3 +377,64 @@ def test_gpu_dense_chimeric_matches_reference_at_the_1_percent_gate(golden_chime
         check_chimeric(b.reads(), b.pieces(), b.events(), golden_chimeric_dense, "gpu-chimeric-dense", gap_gate=KS_GATE, gap_mean_tol=0.01)
     finally:
         eng.close()
+
+
+# ---- the north-star gate on the north-star workload ---------------------------------------------------------------------------------
+# tests/golden/reference_hg002.json (make_golden.py --only-hg002): 114 000 aligned + 100 000 unaligned reads of the UNMODIFIED reference
+# on the model and the reference bench.py times — `hg002_like` (n_train 10^6 per KDE, aligned regions of 8.4 kb on average) on the
+# `ecoli_like` 4 641 652 bp circular chromosome.  Neither input is committed: both are rebuilt here from nanosim_amd/synth.py by seed,
+# exactly as bench.py and make_golden.py build them.
+HG002_SEED = 20260926
+
+
+@pytest.fixture(scope="module")
+def golden_hg002():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_hg002.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def hg002_inputs(tmp_path_factory):
+    import os
+    from nanosim_amd import synth
+    d = tmp_path_factory.mktemp("hg002")
+    prefix = os.path.join(str(d), "hg002_like")
+    synth.write_model(prefix, synth.SynthModelSpec(n_train=1_000_000, seed=HG002_SEED), write_pkl=False)
+    mdl = M.load_model(prefix)
+    bases = synth.synth_sequence(synth.ECOLI_LEN, HG002_SEED, n_frac=0.0005, iupac_frac=0.0002, lower_frac=0.02, hp_boost=0.005)
+    ref = M.Reference(["ecoli-like"], bases, np.array([0, synth.ECOLI_LEN], dtype=np.uint64), np.array([1], dtype=np.uint8))
+    return mdl, ref
+
+
+def test_oracle_hg002_scale_distributions_match_reference(golden_hg002, hg002_inputs):
+    """read length, head, tail, reference length, per-type error counts and bases of 8.4 kb reads at KS <= 1 % against the reference"""
+    mdl, ref = hg002_inputs
+    assert golden_hg002["n_aligned"] >= 100000 and golden_hg002["n_unaligned"] >= 100000
+    met, _ = oracle_metrics_parallel(mdl, ref, 48000, chunks=16, bytes_per_read=200000, events_per_read=20000, emit_records=True)
+    rep = check_aligned(met, golden_hg002, "oracle-hg002")
+    print("KS distances oracle vs reference (hg002_like):", rep)
+    r, _ = oracle_batch_parallel(mdl, ref, 60000, bytes_per_read=200000, events_per_read=60000, kind=E.NS_KIND_UNALIGNED)
+    assert ks_vs_quantiles(r["seq_len"], golden_hg002["q_unaligned_len"]) <= KS_GATE
+    assert abs(float(np.mean(r["reversed"])) - golden_hg002["unaligned_rev_frac"]) < 0.01
+
+
+@pytest.mark.gpu
+def test_gpu_hg002_scale_distributions_match_reference(golden_hg002, hg002_inputs):
+    """the same on the HIP path: one launch of 200 000 aligned reads of the bench workload, 100 000 unaligned ones"""
+    mdl, ref = hg002_inputs
+    eng = E.Engine(0)
+    try:
+        eng.set_reference(ref)
+        eng.load_model(mdl)
+        p = E.make_params(seed=HG002_SEED, first_read=0, n_reads=200000, max_len=ref.max_chrom, emit_records=False)
+        b = eng.generate(p)
+        rep = check_aligned(per_read_metrics(b.reads(), b.pieces(), b.events()), golden_hg002, "gpu-hg002")
+        print("KS distances GPU vs reference (hg002_like):", rep)
+        p = E.make_params(seed=HG002_SEED, first_read=200000, n_reads=100000, kind=E.NS_KIND_UNALIGNED, max_len=ref.max_chrom, emit_records=False)
+        r = eng.generate(p).reads()
+        assert ks_vs_quantiles(r["seq_len"], golden_hg002["q_unaligned_len"]) <= KS_GATE
+    finally:
+        eng.close()
+

@@ -178,10 +178,17 @@ def test_genome_output_does_not_depend_on_the_number_of_ranks(tmp_path, flags):
     simulator.main(base + ["-o", one])
     for world in (2, 3):
         out = str(tmp_path / ("w%d" % world) / "sim")
-        _run_ranks(world, base + ["-o", out], tmp_path)
+        _run_ranks(world, base + ["-o", out, "--merge"], tmp_path)                                        # --merge: the reference's single files
         assert sorted(os.listdir(tmp_path / ("w%d" % world))) == sorted(os.listdir(tmp_path / "w1"))      # no sub-files left behind
         for f in ("_aligned_reads" + ext, "_aligned_error_profile", "_unaligned_reads" + ext):
             assert open(out + f, "rb").read() == open(one + f, "rb").read(), (world, f)
+    # the default with several ranks (round 6): the parts stay where the ranks wrote them, <file>.subfiles lists them in rank order
+    out = str(tmp_path / "w2keep" / "sim")
+    _run_ranks(2, base + ["-o", out], tmp_path)
+    for f in ("_aligned_reads" + ext, "_aligned_error_profile", "_unaligned_reads" + ext):
+        listed = open(out + f + ".subfiles").read().split()
+        assert len(listed) == 2 and listed[0] == os.path.abspath(out + f)                                 # rank 0 wrote the head of the final file
+        assert b"".join(open(x, "rb").read() for x in listed) == open(one + f, "rb").read(), f
 
 
 def test_transcriptome_output_does_not_depend_on_the_number_of_ranks(tmp_path):
@@ -191,7 +198,7 @@ def test_transcriptome_output_does_not_depend_on_the_number_of_ranks(tmp_path):
     one = str(tmp_path / "w1" / "sim")
     simulator.main(base + ["-o", one])
     out = str(tmp_path / "w2" / "sim")
-    _run_ranks(2, base + ["-o", out], tmp_path)
+    _run_ranks(2, base + ["-o", out, "--merge"], tmp_path)
     for f in ("_aligned_reads.fastq", "_aligned_error_profile", "_unaligned_reads.fastq"):
         assert open(out + f, "rb").read() == open(one + f, "rb").read(), f
 

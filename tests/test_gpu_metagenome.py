@@ -81,6 +81,26 @@ def test_gpu_metagenome_equals_oracle(setup, small_model, meta_ref, case):
             eng.load_model(small_model)
 
 
+def test_metagenome_event_capacity_overflow_replans_the_pass(small_model, meta_ref, monkeypatch):
+    """The metagenome worker's twin of the event-capacity re-plan (meta_passes: `P.cap_rate *= 2.0`), forced by NS_CAP_RATE_SCALE
+    (a test knob read by ns_load_model: it plans a twentieth of the model's event rate)."""
+    monkeypatch.setenv("NS_CAP_RATE_SCALE", "0.05")
+    _, samples = MG.read_abundance(os.path.join(META, "abundance.tsv"), meta_ref.species)
+    abun = samples[0]
+    infl = {sp: MG.inflate_abun(abun, sp, small_model.abun_inflation) for sp in abun}
+    e = E.Engine(0)
+    try:
+        e.set_metagenome(meta_ref, abun, infl)
+        e.load_model(small_model)
+        for kw in (dict(n_reads=400, emit_errlog=True), dict(n_reads=300, chimeric=True, fastq=True)):
+            p = E.make_params(seed=0xFEED5EED78, first_read=0, max_len=meta_ref.max_chrom, meta=True, **kw)
+            b = e.generate(p)
+            assert int(b.info.n_overflow) > 0, "the knob did not force a re-plan"
+            compare(b, O.generate_meta(small_model, meta_ref, abun, infl if p.chimeric else None, p), p)
+    finally:
+        e.close()
+
+
 def test_metagenome_batches_are_reproducible(setup, meta_ref):
     eng, abun, infl = setup
     p = E.make_params(seed=5, first_read=1000, n_reads=2000, chimeric=True, fastq=True, max_len=meta_ref.max_chrom, meta=True)

@@ -295,6 +295,44 @@ def test_later_attempt_outgrows_the_planned_event_capacity(tmp_path, small_ref):
         e.close()
 
 
+def test_event_capacity_overflow_replans_the_batch(small_model, small_ref, monkeypatch):
+    """The recovery path of ns_generate: the chain finds more events than the batch planned slots for, the batch is planned again
+    with twice the rate (nanosim_amd.hip: `cap_rate *= 2.0`).  NS_CAP_RATE_SCALE (a test knob read by ns_load_model) plans a
+    twentieth of the model's rate, so the first plans MUST overflow; the batch that comes out equals the oracle's."""
+    monkeypatch.setenv("NS_CAP_RATE_SCALE", "0.05")
+    e = E.Engine(0)
+    try:
+        e.set_reference(small_ref)
+        e.load_model(small_model)
+        for kw in (dict(n_reads=400, emit_errlog=True), dict(n_reads=300, chimeric=True, fastq=True, emit_errlog=True),
+                   dict(n_reads=300, kmer_bias=5, fastq=True, emit_errlog=True), dict(n_reads=300, min_len=3000, max_len=9000)):
+            args = dict(seed=777, first_read=3, max_len=small_ref.max_chrom)
+            args.update(kw)
+            p = E.make_params(**args)
+            b = e.generate(p)
+            assert int(b.info.n_overflow) > 0, "the knob did not force a re-plan"
+            compare(b, O.generate(small_model, small_ref, p), p)
+    finally:
+        e.close()
+
+
+def test_homopolymer_edit_capacity_overflow_repeats_the_stage(small_model, small_ref, monkeypatch):
+    """The recovery path of the -k stage: more homopolymer edits in a piece than its slots (hp_ev_slot) hold -> stats[7], the scan /
+    drain pair runs again with twice the capacity.  NS_HP_CAP_SHIFT plans 2^-8 of the usual capacity and one slot of slack."""
+    monkeypatch.setenv("NS_HP_CAP_SHIFT", "8")
+    e = E.Engine(0)
+    try:
+        e.set_reference(small_ref)
+        e.load_model(small_model)
+        for kw in (dict(n_reads=300, kmer_bias=5, fastq=True, emit_errlog=True), dict(n_reads=200, kmer_bias=3, chimeric=True)):
+            args = dict(seed=778, first_read=0, max_len=small_ref.max_chrom)
+            args.update(kw)
+            p = E.make_params(**args)
+            compare(e.generate(p), O.generate(small_model, small_ref, p), p)
+    finally:
+        e.close()
+
+
 def test_many_contig_reference(small_model):
     """A fragmented assembly (3 000 contigs of 0.5-40 kb, a few empty): the start-position walk of extract_read (S:1767-1780) is
     a bisection on the device; reads longer than most contigs are redrawn until they fit."""

@@ -111,7 +111,7 @@ def test_eight_ranks_on_one_gpu_genome_chimeric(tmp_path):
     one = str(tmp_path / "w1" / "sim")
     simulator.main(base + ["-o", one])
     out = str(tmp_path / "w8" / "sim")
-    _run_ranks(8, base + ["-o", out])
+    _run_ranks(8, base + ["-o", out, "--merge"])
     assert sorted(os.listdir(tmp_path / "w8")) == sorted(os.listdir(tmp_path / "w1"))
     for f in ("_aligned_reads.fasta", "_aligned_error_profile", "_unaligned_reads.fasta"):
         assert open(out + f, "rb").read() == open(one + f, "rb").read(), f
@@ -127,7 +127,7 @@ def test_eight_ranks_on_one_gpu_metagenome(tmp_path, small_model):
     out = str(tmp_path / "mg8" / "sim")
     _run_ranks(8, ["metagenome", "-gl", os.path.join(meta, "genome_list.tsv"), "-a", os.path.join(meta, "abundance.tsv"),
                    "-dl", os.path.join(meta, "dna_type_list.tsv"), "-c", os.path.join(GOLDEN, "model_small", "training"),
-                   "-o", out, "--seed", "777", "--chimeric"])
+                   "-o", out, "--seed", "777", "--chimeric", "--merge"])
     cwd = os.getcwd()
     os.chdir(ROOT)
     try:
@@ -182,7 +182,7 @@ def test_sub_files_of_minus_t_give_the_same_files(tmp_path, monkeypatch, flags):
         assert head in (b"", b">", b"@") or f == "_aligned_error_profile"                          # cut at read boundaries
     monkeypatch.delenv("NS_KEEP_SUBFILES")
     out = str(tmp_path / "w2" / "sim")
-    _run_ranks(2, base + ["-o", out, "-t", "3"])
+    _run_ranks(2, base + ["-o", out, "-t", "3", "--merge"])
     assert sorted(os.listdir(tmp_path / "w2")) == sorted(os.listdir(tmp_path / "t1"))
     for f in tails:
         assert open(out + f, "rb").read() == open(one + f, "rb").read(), f

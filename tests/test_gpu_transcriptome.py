@@ -62,6 +62,23 @@ def test_gpu_transcriptome_equals_oracle(trx_ref, case):
         e.close()
 
 
+def test_transcriptome_event_capacity_overflow_replans_the_batch(trx_ref, monkeypatch):
+    """The transcriptome worker's twin of the event-capacity re-plan, forced by NS_CAP_RATE_SCALE (test knob, ns_load_model)."""
+    monkeypatch.setenv("NS_CAP_RATE_SCALE", "0.05")
+    mdl = M.load_model(PREFIX, transcriptome=True, fastq=True, homopolymer=True)
+    e = E.Engine(0)
+    try:
+        e.set_transcriptome(trx_ref)
+        e.load_model(mdl)
+        for kw in (dict(n_reads=500, emit_errlog=True), dict(n_reads=300, kmer_bias=5, fastq=True)):
+            p = E.make_params(seed=0xABCD1235, first_read=0, max_len=10 ** 9, trx=True, **kw)
+            b = e.generate(p)
+            assert int(b.info.n_overflow) > 0, "the knob did not force a re-plan"
+            compare(b, O.generate_trx(mdl, trx_ref, p), p)
+    finally:
+        e.close()
+
+
 IR_CASES = [
     dict(n_reads=600, emit_errlog=True),
     dict(n_reads=500, fastq=True, uracil=True, emit_errlog=True),

@@ -406,6 +406,16 @@ def test_no_merge_flag_is_the_keep_subfiles_switch(monkeypatch):
     simulator.main(["metagenome", "-gl", "g.tsv", "-a", "a.tsv", "-dl", "d.tsv"])
     simulator.main(["transcriptome", "-rt", "t.fa", "-e", "e.tsv", "--no-merge"])
     assert seen["metagenome"] == (False, None) and seen["transcriptome"][0] is True
+    # several ranks (round 6): the parts stay unless --merge asks for the reference's single files
+    monkeypatch.delenv("NS_KEEP_SUBFILES", raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    simulator.main(["genome", "-rg", "r.fa"])
+    assert seen["genome"] == (False, "1")
+    monkeypatch.delenv("NS_KEEP_SUBFILES", raising=False)
+    simulator.main(["genome", "-rg", "r.fa", "--merge"])
+    assert seen["genome"] == (False, None)
+    with pytest.raises(SystemExit):
+        simulator.main(["genome", "-rg", "r.fa", "--merge", "--no-merge"])
 
 
 class _StepFake:
