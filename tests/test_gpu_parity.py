@@ -103,6 +103,29 @@ def test_gpu_circular_reference(small_model, circ_ref):
         # wrap-around reads exist in this sample
         pc = b.pieces()
         assert np.any(pc["pos"].astype(np.int64) + pc["ref_len"] > circ_ref.genome_len)
+        # -hp -k on reads across the origin (their tiles there take the generic kernel in both record passes)
+        for kw in (dict(n_reads=300, kmer_bias=5, fastq=True, emit_errlog=True), dict(n_reads=300, kmer_bias=3), dict(n_reads=200, kmer_bias=4, chimeric=True, fastq=True)):
+            p = E.make_params(seed=78, first_read=0, max_len=circ_ref.max_chrom, **kw)
+            b = e.generate(p)
+            compare(b, O.generate(small_model, circ_ref, p), p)
+            pc = b.pieces()
+            assert np.any(pc["pos"].astype(np.int64) + pc["ref_len"] > circ_ref.genome_len)
+    finally:
+        e.close()
+
+
+def test_homopolymer_stage_at_every_k(small_model, small_ref):
+    """mutate_homo's run scan and drain (S:627-705) at k = 2 .. 17 — the window logic of k_hp_scan changes with k (k < 4: runs straight to
+    the run buffer; k > 16: only the run closed by a chunk's first start) — with chimeric reads (pieces that start inside a 16-byte group
+    of the scratch image) and FASTQ class bits on the bases"""
+    e = E.Engine(0)
+    try:
+        e.set_reference(small_ref)
+        e.load_model(small_model)
+        for k in (2, 3, 4, 5, 7, 9, 16, 17):
+            for kw in (dict(n_reads=150, fastq=True, emit_errlog=True), dict(n_reads=100, chimeric=True)):
+                p = E.make_params(seed=9000 + k, first_read=0, max_len=small_ref.max_chrom, kmer_bias=k, **kw)
+                compare(e.generate(p), O.generate(small_model, small_ref, p), p)
     finally:
         e.close()
 

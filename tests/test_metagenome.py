@@ -148,7 +148,9 @@ def test_oracle_metagenome_batches_match_reference_runs(fx, meta_ref, chimeric):
     assert ks_vs_quantiles(lens, run["q_len"]) <= 0.01
     ref_chim = sum(wk["n_chim"] for wk in run["workers"])
     if chimeric:
-        assert 0.5 * ref_chim <= n_chim <= 2.0 * ref_chim + 10, (n_chim, ref_chim)
+        # ~4 800 chimeric reads among 100 000 on either side: one standard deviation of the difference of two such counts is ~100 (2 %).
+        # Measured at these seeds: oracle 4 704, reference 4 799 (ratio 0.980, one sigma).  Gate: 8 % = four sigma.
+        assert abs(n_chim / ref_chim - 1.0) <= 0.08, (n_chim, ref_chim)
     else:
         assert n_chim == 0
     # S:860: the strand is drawn once per pass, so workers that finish in one pass have a single strand
