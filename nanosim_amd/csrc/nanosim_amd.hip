@@ -864,7 +864,10 @@ k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, co
         }
         return;
     }
-    if (!(dbg & 8)) emit_head_tail(A.m, ro, key, a, rd.head, rd.tail, lane);                                             // S:1426-1427
+#ifdef NS_ABLATE
+    if (!(dbg & 8))
+#endif
+    emit_head_tail(A.m, ro, key, a, rd.head, rd.tail, lane);                                                              // S:1426-1427
     uint32_t q = rd.head;
     uint64_t q_in = MODE == MAT_HP_FINAL ? uni64(A.scr_off[r]) : 0;
     for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
@@ -1083,13 +1086,10 @@ __global__ void __launch_bounds__(256) k_hp_bitmap(const uint8_t *__restrict__ b
 
 // -k filter of mutate_read (S:1929-1947), one read per wavefront: lane per event (the homopolymer test of an event is independent of the others), ballot /
 // prefix-popcount compaction, exclusive wavefront prefix sum of the length changes for the shift field
-// (Compiled for six waves per SIMD: 80 VGPRs + 12 bytes of scratch instead of 82 VGPRs = five waves; the kernel waits for two dependent
-// loads per 64 events — the events, then their window of the bitmap.  Round 6, same box, profiles/r06/ab_hp_filter.log: -k stage 12.35 ->
-// 12.10 ms; asking for the next block's events and bitmap windows one iteration ahead instead — 89 VGPRs — bought 0.08 ms and is gone.)
-#ifndef NS_FILT_WAVES
-#define NS_FILT_WAVES 6
-#endif
-__global__ void __launch_bounds__(64 * NS_WPB, NS_FILT_WAVES) k_hp_filter_w(GenArgs A) {
+// (80 VGPRs = six waves per SIMD as it stands.  Round 6, profiles/r06/ab_hp_filter.log: asking for the next block's events and bitmap windows one
+// iteration ahead — the kernel waits for two dependent loads per 64 events — needs 89 VGPRs = five waves and bought 0.08 ms of 2.4; bounding the
+// kernel to six waves explicitly moves 12 bytes to scratch: 2.41 -> 2.60 ms.  Both gone again.)
+__global__ void __launch_bounds__(64 * NS_WPB) k_hp_filter_w(GenArgs A) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r > A.prm.n_reads) return;

@@ -557,6 +557,7 @@ enum { MAT_REF = 0,          // the reference -> the record (qualities drawn her
 __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t lane0_value, uint32_t v) {      // lane l gets v of lane l - 1, lane 0 gets lane0_value
     return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0_value, (int)v, 0x138, 0xf, 0xf, false);
 }
+typedef uint16_t ns_v2u16 __attribute__((ext_vector_type(2)));
 struct QualState {
     const uint16_t *lut;                 // LDS: NS_QLUT_SLOTS x 1024 bucket entries (see qual_value_lut), slot = class
 };
@@ -575,9 +576,16 @@ __device__ __forceinline__ void qual_lookup16(const QualState &Q, const DevModel
         const uint32_t a0 = and_or(d >> 5, 0x7feu, o0), a1 = and_or(d >> 21, 0x7feu, o1);        // byte address of entry [slot][h >> 6]
         uint32_t E;
         if (skip_lut) E = (a0 & 0x3f80u) | (a1 & 0x3f80u) << 16 | 0x00400040u;
-        else E = (uint32_t)*reinterpret_cast<const uint16_t *>(lut + a0) | (uint32_t)*reinterpret_cast<const uint16_t *>(lut + a1) << 16;
+        else {                               // (built as a two-halfword vector: one v_perm_b32 instead of shift + or)
+            ns_v2u16 e2;
+            e2.x = *reinterpret_cast<const uint16_t *>(lut + a0); e2.y = *reinterpret_cast<const uint16_t *>(lut + a1);
+            E = __builtin_bit_cast(uint32_t, e2);
+        }
         flags |= E;
-        Q2[k] = (((E & 0x7fff7fffu) + (d & 0x003f003fu)) >> 7) & 0x007f007fu;                   // see qual_value_lut
+        // see qual_value_lut — on both halfwords at once (packed 16-bit add and shift: no carry between the halves, nothing to mask; an
+        // entry with bit 15 set gives garbage here and is redone by the exact walk below)
+        const ns_v2u16 s2 = (__builtin_bit_cast(ns_v2u16, E) + __builtin_bit_cast(ns_v2u16, d & 0x003f003fu)) >> (uint16_t)7;
+        Q2[k] = __builtin_bit_cast(uint32_t, s2);
     }
     if (__ballot((flags & 0x80008000u) != 0)) {                        // a bucket with several thresholds (never with the loader's tables)
 #pragma unroll
@@ -627,6 +635,9 @@ __device__ __forceinline__ void qual_lut_load(uint16_t *lds, const DevModel &m, 
     for (uint32_t i = tid; i < NS_QLUT_SLOTS * 128u; i += nthreads) dst[i] = src[i];      // slot = class (NS_Q_*)
 }
 
+__device__ __forceinline__ void lds_or32(uint8_t *p, uint32_t v) {
+    __hip_atomic_fetch_or(reinterpret_cast<unsigned int *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
 __device__ __forceinline__ void lds_or64(uint8_t *p, uint64_t v) {
     __hip_atomic_fetch_or(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
@@ -680,6 +691,16 @@ __device__ __forceinline__ void resolve16(uint32_t &a0, uint32_t &a1, uint32_t &
         if (b < 4) a0 = wk; else if (b < 8) a1 = wk; else if (b < 12) a2 = wk; else a3 = wk;
     }
 }
+// Phase-ablation bits of the record kernel (NS_DEBUG_SKIP: 1 no chunk loads / final step, 2 no letters, 16 no stores, 32 no event sub-runs,
+// 64 no letter-word Philox): compiled in only with -DNS_ABLATE (scripts/ablate_materialise.sh builds that variant) — every test of a
+// run-time flag in the tile loop is a branch and a live SGPR in a kernel that spills ~80 of them.
+#ifdef NS_ABLATE
+#define NS_DBG(bit) (dbg & (bit))
+#else
+#define NS_DBG(bit) false
+#endif
+// a & b & ~c in one instruction (v_bitop3_b32, truth table 0x40 for inputs 0xF0, 0xCC, 0xAA; the compiler emits not + and + and)
+__device__ __forceinline__ uint32_t and_andn(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x40); }
 template <bool FASTQ, int MODE>
 __device__ inline void materialise_piece7(const DevModel &m, const DevRef &ref, TileLds7 &T, const ReadOut &ro, const ns_key &key,
                                           uint32_t a, const PieceCtx &pc, uint32_t pq, uint32_t lane, uint32_t dbg, const SlowQueue &sq,
@@ -695,7 +716,7 @@ __device__ inline void materialise_piece7(const DevModel &m, const DevRef &ref, 
     const uint32_t phi = ro.reversed ? ((uint32_t)(uintptr_t)ro.seq + ro.seq_len - pq) & 15u : (0u - ((uint32_t)(uintptr_t)ro.seq + pq)) & 15u;
     ns_event e_pre; e_pre.pos = 0; e_pre.info = 0; uint32_t w_pre = 0;
     if (lane < pc.n_ev) e_pre = pc.ev[lane];
-    auto cached_word = [&](uint32_t j0) -> uint32_t { if (dbg & 64u) return 0u; const uint32_t j = j0 + lane; return event_word<MODE>(pc, key, a, j < pc.n_ev ? j : 0u); };
+    auto cached_word = [&](uint32_t j0) -> uint32_t { if (NS_DBG(64u)) return 0u; const uint32_t j = j0 + lane; return event_word<MODE>(pc, key, a, j < pc.n_ev ? j : 0u); };
     w_pre = cached_word(0u);
     uint32_t cls_carry = 0;                // class bits of the chunk the last tile ended in (tiles queued for the generic path: none)
     for (uint32_t M0 = 0; M0 < pc.out_len;) {
@@ -805,7 +826,7 @@ __device__ inline void materialise_piece7(const DevModel &m, const DevRef &ref, 
                 const uint32_t incl = max(scan_base, wave_incl_max(T.hist[ci]));
                 scan_base = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                 f[t] = make_uint4(0, 0, 0, 0); fi[t] = 16u | 16u << 8; fy[t] = 0;
-                if (ci < nc && !(dbg & 1)) {
+                if (ci < nc && !NS_DBG(1u)) {
                     const uint32_t cs = A0 + 16u * ci, p = ci == 0 ? M0 : cs;
                     const uint2 E = T.ent[incl];
                     const uint32_t nx = T.eos[incl];
@@ -820,7 +841,7 @@ __device__ inline void materialise_piece7(const DevModel &m, const DevRef &ref, 
         // ---- 3b. lane per event: the sub-run that starts behind the event's letters, up to the next event or the end of its chunk — unless the
         // chunk starts under this event (then the chunk lane has it)
         uint4 fe = make_uint4(0, 0, 0, 0); uint32_t ei0 = 16, ei1 = 16, eoc = 0;
-        if (take && !(dbg & 1)) {
+        if (take && !NS_DBG(1u)) {
             const uint32_t c = (s1 - A0) >> 4, ecs = A0 + 16u * c;
             const uint32_t en = min(os_next, min(ecs + 16u, M1));
             if ((int32_t)(en - s1) > 0 && ekey > c) {
@@ -829,7 +850,7 @@ __device__ inline void materialise_piece7(const DevModel &m, const DevRef &ref, 
             }
         }
         // ---- 2. letters: lane per event; lane 63 (never a taker) continues the payload of the event in force at M0
-        if (!(dbg & 2)) {
+        if (!NS_DBG(2u)) {
             const bool cont = lane == 63 && L0_out + (L0_pt & 0xfffu) > M0;
             const uint32_t b_os = cont ? L0_out : os, b_pt = cont ? L0_pt : e_pt, b_rp = cont ? L0_rp : e_rp;
             const uint32_t b_j = cont ? L0_j : jb + lane;
@@ -844,8 +865,7 @@ __device__ inline void materialise_piece7(const DevModel &m, const DevRef &ref, 
             if (fast_l && mis) __builtin_memcpy(&cur8, seg0 + xs, 8);
             if constexpr (!HPF) fast_l = fast_l && !((cur8.x | cur8.y) & 0x80808080u);
             if (fast_l) {
-                uint32_t f3 = frac;
-                const uint32_t o = b_os - A0, dump = T_DUMP + lane;
+                uint32_t f3 = frac, L2[2];
 #pragma unroll
                 for (uint32_t g = 0; g < 2; ++g) {
                     const uint32_t cur4 = g ? cur8.y : cur8.x;
@@ -866,10 +886,17 @@ __device__ inline void materialise_piece7(const DevModel &m, const DevRef &ref, 
                         }
                         letters |= cls4;
                     }
-                    const uint32_t q0 = 4u * g;
-                    const uint32_t p0 = b_pl > q0 ? o + q0 : dump, p1 = b_pl > q0 + 1 ? o + q0 + 1 : dump, p2 = b_pl > q0 + 2 ? o + q0 + 2 : dump, p3 = b_pl > q0 + 3 ? o + q0 + 3 : dump;
-                    T.out[p0] = (uint8_t)letters; T.out[p1] = (uint8_t)(letters >> 8); T.out[p2] = (uint8_t)(letters >> 16); T.out[p3] = (uint8_t)(letters >> 24);
+                    L2[g] = letters;
                 }
+                // the <= 8 letters leave as three aligned dword ORs into the (zeroed) tile instead of eight predicated byte stores: no other
+                // sub-run or letter shares a byte with them, so the OR is a store
+                const uint64_t keep = b_pl >= 8u ? ~0ull : ~(~0ull << (8u * b_pl));
+                const uint64_t v = ((uint64_t)L2[0] | (uint64_t)L2[1] << 32) & keep;
+                const uint32_t o = b_os - A0, sh = 8u * (o & 3u);
+                const uint64_t lo64 = v << sh;
+                const uint32_t top = (uint32_t)(((v >> 32) << sh) >> 32);
+                uint8_t *w = &T.out[o & ~3u];
+                lds_or32(w, (uint32_t)lo64); lds_or32(w + 4, (uint32_t)(lo64 >> 32)); lds_or32(w + 8, top);
             }
             if (on && !fast_l) {                                  // long payloads, tile borders, IUPAC under a substitution, the origin
                 const uint32_t i_lo = b_os < M0 ? M0 - b_os : 0u;
@@ -898,9 +925,9 @@ __device__ inline void materialise_piece7(const DevModel &m, const DevRef &ref, 
         }
         // ---- 3c. the event sub-runs arrive: masked to their bytes, IUPAC codes resolved, OR-ed into the tile (no two sub-runs share a byte:
         // the OR is a store that needs no ordering)
-        if (cnt && ei0 < 16u && !(dbg & 32u)) {
+        if (cnt && ei0 < 16u && !NS_DBG(32u)) {
             const uint4 m0 = *reinterpret_cast<const uint4 *>(&T.mlut[ei0][0]), m1 = *reinterpret_cast<const uint4 *>(&T.mlut[ei1][0]);
-            uint32_t a0 = fe.x & m0.x & ~m1.x, a1 = fe.y & m0.y & ~m1.y, a2 = fe.z & m0.z & ~m1.z, a3 = fe.w & m0.w & ~m1.w;
+            uint32_t a0 = and_andn(fe.x, m0.x, m1.x), a1 = and_andn(fe.y, m0.y, m1.y), a2 = and_andn(fe.z, m0.z, m1.z), a3 = and_andn(fe.w, m0.w, m1.w);
             if constexpr (!HPF) {
                 if ((a0 | a1 | a2 | a3) & 0x80808080u) resolve16(a0, a1, a2, a3, ei0, ei1, A0 + eoc + y1, key, pc.sid, a);
             }
@@ -915,14 +942,14 @@ __device__ inline void materialise_piece7(const DevModel &m, const DevRef &ref, 
             const uint32_t ci = 64 * t + lane;
             const uint32_t c0 = A0 + 16 * ci;                         // chunk origin (chunk 0 of a piece's first tile may start before M0)
             const uint32_t lo_m = ci == 0 ? M0 : c0, hi_m = min(c0 + 16, M1);
-            const bool active = (int32_t)(hi_m - lo_m) > 0 && !(dbg & 1);
+            const bool active = (int32_t)(hi_m - lo_m) > 0 && !NS_DBG(1u);
             uint32_t cw = 0;
             if (active) {
                 const uint4 v = *reinterpret_cast<const uint4 *>(&T.out[16 * ci]);
                 *reinterpret_cast<uint4 *>(&T.out[16 * ci]) = make_uint4(0, 0, 0, 0);      // the tile is left clean for the next one
                 const uint32_t i0 = fi[t] & 0xffu, i1 = fi[t] >> 8;
                 const uint4 m0 = *reinterpret_cast<const uint4 *>(&T.mlut[i0][0]), m1 = *reinterpret_cast<const uint4 *>(&T.mlut[i1][0]);
-                uint32_t a0 = f[t].x & m0.x & ~m1.x, a1 = f[t].y & m0.y & ~m1.y, a2 = f[t].z & m0.z & ~m1.z, a3 = f[t].w & m0.w & ~m1.w;
+                uint32_t a0 = and_andn(f[t].x, m0.x, m1.x), a1 = and_andn(f[t].y, m0.y, m1.y), a2 = and_andn(f[t].z, m0.z, m1.z), a3 = and_andn(f[t].w, m0.w, m1.w);
                 if constexpr (!HPF) {
                     if ((a0 | a1 | a2 | a3) & 0x80808080u) resolve16(a0, a1, a2, a3, i0, i1, c0 + fy[t], key, pc.sid, a);
                 }
@@ -941,7 +968,7 @@ __device__ inline void materialise_piece7(const DevModel &m, const DevRef &ref, 
                     if (sh < 64) { lo = (lo >> sh) | (hi << (64 - sh)); hi >>= sh; }
                     else { lo = hi >> (sh - 64); hi = 0; }
                 }
-                if (!(dbg & 16)) { PendingChunk pd = prep_chunk(ro, pq + lo_m, count, lo, hi, qlo, qhi); flush_chunk(ro, pd); }
+                if (!NS_DBG(16u)) { PendingChunk pd = prep_chunk(ro, pq + lo_m, count, lo, hi, qlo, qhi); flush_chunk(ro, pd); }
             }
             if constexpr (CLSOUT) {                                    // the tile ends inside a chunk: its word goes on in the next tile's chunk 0
                 const uint32_t cl = (M1 - 1u - A0) >> 4;
