@@ -837,11 +837,22 @@ __device__ __forceinline__ bool load_read_uniform(const GenArgs &A, uint64_t r, 
 // the scratch buffer): a monotone function of both, so the slots of no two pieces overlap
 __device__ __forceinline__ uint64_t hp_ev_slot(const GenArgs &A, uint64_t pos, uint32_t piece) { return (pos >> A.hp_shift) + (uint64_t)A.hp_pad * piece; }
 
+// chunks per lane and tile: two (2 KB tiles) where a tile's ~63 events span about that much; the second pass of -k has an event every
+// ~300 bytes, so its tiles are byte-limited and a larger one amortises the per-tile work — by little: 4.78 ms with 2 KB tiles, 4.66 with
+// 3 KB, 4.70 with 4 KB at seven waves (8 bytes of scratch), 4.60 with 4 KB at six waves, 4.71 with 6 KB at four (same box, under
+// rocprofv3: profiles/r06/ab_final_pass_tiles.log).  What the pass costs is per chunk, not per tile.
+#ifndef NS_TILE_CHUNKS_FINAL
+#define NS_TILE_CHUNKS_FINAL 4u
+#endif
+#ifndef NS_MAT_WAVES_FINAL
+#define NS_MAT_WAVES_FINAL 6
+#endif
 template <bool FASTQ, int MODE>
-__global__ void __launch_bounds__(64, NS_MAT_WAVES)
+__global__ void __launch_bounds__(64, MODE == MAT_HP_FINAL ? NS_MAT_WAVES_FINAL : NS_MAT_WAVES)
 k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, const uint32_t *order) {
     constexpr bool CLSOUT = FASTQ && MODE != MAT_HP_SCRATCH;           // FASTQ: the bases here, the quality line in k_qualities
-    __shared__ TileLds7 T;
+    constexpr uint32_t TC = MODE == MAT_HP_FINAL ? NS_TILE_CHUNKS_FINAL : NS_TILE_CHUNKS;
+    __shared__ TileLds7<TC> T;
     const uint32_t lane = threadIdx.x;
     const uint64_t slot = blockIdx.x;
     if (slot >= A.prm.n_reads) return;
@@ -859,7 +870,7 @@ k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, co
         uint32_t q = 0;
         for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
             const PieceCtx pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi, ev_word);
-            materialise_piece7<FASTQ, MODE>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, nullptr);
+            materialise_piece7<FASTQ, MODE, TC>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, nullptr);
             q += pc.out_len;
         }
         return;
@@ -884,7 +895,7 @@ k_materialise(GenArgs A, const uint32_t *ev_word, uint32_t dbg, SlowQueue sq, co
             pc.sid = pc.kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
             q_in += pc.ref_len;
         } else pc = load_piece_uniform(A.events, A.ref, A.pieces[rd.piece_off + pi], pi, ev_word);
-        materialise_piece7<FASTQ, MODE>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, CLSOUT ? cls + (q >> 4) + 2u * pi : nullptr);
+        materialise_piece7<FASTQ, MODE, TC>(A.m, A.ref, T, ro, key, a, pc, q, lane, dbg, sq, (uint32_t)r, pi, CLSOUT ? cls + (q >> 4) + 2u * pi : nullptr);
         q += pc.out_len;                                 // (-k: k_hp_report files the emitted length in the piece once the record kernels are done)
     }
     if (A.polya) {                                                                          // transcriptome: polyA tail (S:1224-1225)
@@ -1282,7 +1293,12 @@ __global__ void __launch_bounds__(64 * NS_WPB) k_hp_scan(GenArgs A, uint2 *__res
                     // before its end (a start further back than the window leaves the test true: the run is then longer than 16)
                     uint32_t E = M << 16;
                     if (c == 0) E &= ~(1u << 16);
-                    if (k <= 16) { for (uint32_t sft = 1; sft < k; ++sft) E &= ~(W << sft); }
+                    if (k <= 16) {                                                   // E &= ~(W << 1 | ... | W << (k - 1)): the starts smeared upwards by doubling
+                        uint32_t sm = W, have = 1;                                   // (sm = W | W << 1 | ... | W << (have - 1); k - 1 shifts in ~log2 k steps)
+                        while (2u * have <= k - 1u) { sm |= sm << have; have *= 2u; }
+                        if (have < k - 1u) sm |= sm << (k - 1u - have);
+                        if (k > 1u) E &= ~(sm << 1);
+                    }
                     else E = (M && c && back + (uint32_t)__builtin_ctz(M) >= k) ? (M & (0u - M)) << 16 : 0u;   // only the run closed by the first start
                     // ---- the long runs that end in front of the window bits E go to the list
                     const uint32_t rc = (uint32_t)__builtin_popcount(E), incl = wave_incl_scan(rc);

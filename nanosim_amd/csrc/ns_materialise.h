@@ -28,12 +28,14 @@
 #define NS_CLS_STRIP 0xd7d7d7d7u
 // LDS copy of the quality bucket tables: slots 0..2 = match / mis / ins, slot 3 = unmapped (gaps of chimeric reads)
 #define NS_QLUT_SLOTS 5u
-// inclusive prefix sum over the wavefront with DPP row shifts / row broadcasts (6 VALU instructions)
+// inclusive prefix sum over the wavefront with DPP row shifts / row broadcasts: 6 VALU instructions — with bound_ctrl on the row shifts
+// (a lane without a source reads 0) every step folds into ONE v_add_u32_dpp; with bound_ctrl off the compiler emitted v_mov + v_mov_dpp +
+// v_add per step (18 instead of 6: round 6, the ISA of k_hp_scan)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);      // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);      // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);      // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);       // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);       // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);       // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);       // row_shr:8
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
     return v;
@@ -663,16 +665,19 @@ __device__ __forceinline__ uint32_t event_word(const PieceCtx &pc, const ns_key 
 // 5.11 ms, bytes identical; other tile sizes / occupancies of v7 all lose (one chunk per lane at 8 waves 6.5 ms, four at 6 waves 6.8 ms,
 // two at 8 waves with 64 VGPRs — spills — 6.0 ms).
 // ================================================================================================================================
+template <uint32_t TC>
 struct __align__(16) TileLds7 {
+    static constexpr uint32_t T_OUT_ = 1024u * TC;          // output bytes of a tile: TC 16-byte chunks per lane
     uint32_t mlut[17][4];                       // mlut[i]: 16-byte mask with bytes >= i set; [16] empty
     uint2 ent[T_EV + 1];                        // per staged event (0: the event in force at the tile start): x = first output offset copied
                                                 // under it, y = segment position minus output offset of those bytes
     uint32_t eos[T_EV + 1];                     // first output offset of tile event k (0xffffffff behind the last)
-    uint32_t hist[64 * NS_TILE_CHUNKS];         // build: last event at or before chunk c (+1); afterwards: the number of events at or before it
-    __align__(16) uint8_t out[T_OUT + 16 + 64]; // letters and event sub-runs of the tile (zero where nothing has been written) + dump slots
+    uint32_t hist[64 * TC];         // build: last event at or before chunk c (+1); afterwards: the number of events at or before it
+    __align__(16) uint8_t out[1024u * TC + 16 + 64]; // letters and event sub-runs of the tile (zero where nothing has been written) + dump slots
 };
-__device__ __forceinline__ void tile_lds_init(TileLds7 &T, uint32_t lane) {
-    for (uint32_t c = lane * 16; c < T_OUT + 16 + 64; c += 64 * 16) *reinterpret_cast<uint4 *>(&T.out[c]) = make_uint4(0, 0, 0, 0);
+template <uint32_t TC>
+__device__ __forceinline__ void tile_lds_init(TileLds7<TC> &T, uint32_t lane) {
+    for (uint32_t c = lane * 16; c < 1024u * TC + 16 + 64; c += 64 * 16) *reinterpret_cast<uint4 *>(&T.out[c]) = make_uint4(0, 0, 0, 0);
     if (lane < 17) {
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k)
@@ -701,12 +706,13 @@ __device__ __forceinline__ void resolve16(uint32_t &a0, uint32_t &a1, uint32_t &
 #endif
 // a & b & ~c in one instruction (v_bitop3_b32, truth table 0x40 for inputs 0xF0, 0xCC, 0xAA; the compiler emits not + and + and)
 __device__ __forceinline__ uint32_t and_andn(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x40); }
-template <bool FASTQ, int MODE>
-__device__ inline void materialise_piece7(const DevModel &m, const DevRef &ref, TileLds7 &T, const ReadOut &ro, const ns_key &key,
+template <bool FASTQ, int MODE, uint32_t TC>
+__device__ inline void materialise_piece7(const DevModel &m, const DevRef &ref, TileLds7<TC> &T, const ReadOut &ro, const ns_key &key,
                                           uint32_t a, const PieceCtx &pc, uint32_t pq, uint32_t lane, uint32_t dbg, const SlowQueue &sq,
                                           uint32_t read_idx, uint32_t piece_idx, uint32_t *__restrict__ cls) {
     constexpr bool CLSOUT = FASTQ && MODE != MAT_HP_SCRATCH;           // the class of every base leaves as 2 bits for k_qualities (cls: the piece's words)
     constexpr bool HPF = MODE == MAT_HP_FINAL;
+    constexpr uint32_t T_OUT_ = 1024u * TC;
     uint32_t jb = 0;                       // events with out_start < M0
     uint32_t L0_out = 0, L0_rp = 0, L0_pt = 3u << 12, L0_wd = 0, L0_j = 0;   // the event in force at M0 (synthetic start: no payload, copy from 0)
     const uint8_t *seg0 = ref.bases + pc.chrom_base + pc.pos;           // segment position 0
@@ -721,7 +727,7 @@ __device__ inline void materialise_piece7(const DevModel &m, const DevRef &ref, 
     uint32_t cls_carry = 0;                // class bits of the chunk the last tile ended in (tiles queued for the generic path: none)
     for (uint32_t M0 = 0; M0 < pc.out_len;) {
         const uint32_t A0 = M0 - ((M0 - phi) & 15u);             // aligned origin of the tile (<= M0; may be "negative" = wrapped)
-        uint32_t M1 = min(A0 + T_OUT, pc.out_len);
+        uint32_t M1 = min(A0 + T_OUT_, pc.out_len);
         // ---- 1. events of the tile
         const ns_event e = e_pre;
         const uint32_t e_wd = w_pre;
@@ -739,7 +745,7 @@ __device__ inline void materialise_piece7(const DevModel &m, const DevRef &ref, 
         const uint32_t cnt = (uint32_t)__popcll(__ballot(take));
         if (M1 <= M0) {                    // 64 events at one output offset (zero-length matches between deletions): not a case
             cls_carry = 0;                 // for the tile machinery; the generic path takes the tile
-            M1 = min(M0 + T_OUT, pc.out_len);
+            M1 = min(M0 + T_OUT_, pc.out_len);
             uint32_t j2 = jb;
             while (j2 < pc.n_ev && ev_out_start(pc.ev[j2]) < M1) ++j2;
             if (lane == 0) {
@@ -770,7 +776,7 @@ __device__ inline void materialise_piece7(const DevModel &m, const DevRef &ref, 
             T.eos[lane] = take ? os : 0xffffffffu;                // (cnt <= 63: slot cnt holds the end mark)
         }
 #pragma unroll
-        for (uint32_t t = 0; t < NS_TILE_CHUNKS; ++t) T.hist[64 * t + lane] = 0;
+        for (uint32_t t = 0; t < TC; ++t) T.hist[64 * t + lane] = 0;
         const uint32_t jb_next = jb + cnt;
         e_pre.pos = 0; e_pre.info = 0; w_pre = 0;
         if (M1 < pc.out_len && jb_next + lane < pc.n_ev) e_pre = pc.ev[jb_next + lane];       // prefetch for the next tile
@@ -781,7 +787,7 @@ __device__ inline void materialise_piece7(const DevModel &m, const DevRef &ref, 
         {   // hist[c] = number of the tile's events sorted in front of chunk c — written by the LAST one (sorted events: lane l is event l + 1
             // of the tile), the chunks in between inherit it through a prefix maximum
             const uint32_t c_next = dpp_wave_shl1(0xffffffffu, ekey);
-            if (ekey < 64 * NS_TILE_CHUNKS && ekey != c_next) T.hist[ekey] = lane + 1u;
+            if (ekey < 64 * TC && ekey != c_next) T.hist[ekey] = lane + 1u;
         }
         // ---- the event in force at M1 (wave-uniform): the last one taken, straight from its lane's registers
         uint32_t osl = L0_out, ptl = L0_pt, rpl = L0_rp, wdl = L0_wd, jl = L0_j;
@@ -817,11 +823,11 @@ __device__ inline void materialise_piece7(const DevModel &m, const DevRef &ref, 
         wave_sync();
         // ---- 3a. lane per chunk: the sub-run in force at the chunk's first byte — [max(chunk start, first byte copied under the last event at
         // or before it), min(next event, chunk end)) — is loaded HERE and stays in registers until the chunk leaves
-        uint4 f[NS_TILE_CHUNKS]; uint32_t fi[NS_TILE_CHUNKS], fy[NS_TILE_CHUNKS];
+        uint4 f[TC]; uint32_t fi[TC], fy[TC];
         {
             uint32_t scan_base = 0;
 #pragma unroll
-            for (uint32_t t = 0; t < NS_TILE_CHUNKS; ++t) {
+            for (uint32_t t = 0; t < TC; ++t) {
                 const uint32_t ci = 64 * t + lane;
                 const uint32_t incl = max(scan_base, wave_incl_max(T.hist[ci]));
                 scan_base = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -938,7 +944,7 @@ __device__ inline void materialise_piece7(const DevModel &m, const DevRef &ref, 
         // ---- 4. lane per aligned 16-byte chunk: own sub-run | what the tile holds; qualities classes, complement / reverse, one aligned store
         // (unrolled: f[t] must stay in registers)
 #pragma unroll
-        for (uint32_t t = 0; t < NS_TILE_CHUNKS; ++t) {
+        for (uint32_t t = 0; t < TC; ++t) {
             const uint32_t ci = 64 * t + lane;
             const uint32_t c0 = A0 + 16 * ci;                         // chunk origin (chunk 0 of a piece's first tile may start before M0)
             const uint32_t lo_m = ci == 0 ? M0 : c0, hi_m = min(c0 + 16, M1);
