@@ -696,8 +696,8 @@ __device__ __forceinline__ void resolve16(uint32_t &a0, uint32_t &a1, uint32_t &
         if (b < 4) a0 = wk; else if (b < 8) a1 = wk; else if (b < 12) a2 = wk; else a3 = wk;
     }
 }
-// Phase-ablation bits of the record kernel (NS_DEBUG_SKIP: 1 no chunk loads / final step, 2 no letters, 16 no stores, 32 no event sub-runs,
-// 64 no letter-word Philox): compiled in only with -DNS_ABLATE (scripts/ablate_materialise.sh builds that variant) — every test of a
+// Phase-ablation bits of the record kernel (NS_DEBUG_SKIP: 1 no chunk loads / final step, 2 no letters, 16 no stores, 32 no event sub-run merge,
+// 64 no letter-word Philox, 128 no event sub-run loads, 256 no chunk-lane look-ups and loads): compiled in only with -DNS_ABLATE (scripts/ablate_materialise.sh builds that variant) — every test of a
 // run-time flag in the tile loop is a branch and a live SGPR in a kernel that spills ~80 of them.
 #ifdef NS_ABLATE
 #define NS_DBG(bit) (dbg & (bit))
@@ -832,7 +832,7 @@ __device__ inline void materialise_piece7(const DevModel &m, const DevRef &ref, 
                 const uint32_t incl = max(scan_base, wave_incl_max(T.hist[ci]));
                 scan_base = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                 f[t] = make_uint4(0, 0, 0, 0); fi[t] = 16u | 16u << 8; fy[t] = 0;
-                if (ci < nc && !NS_DBG(1u)) {
+                if (ci < nc && !NS_DBG(1u) && !NS_DBG(256u)) {
                     const uint32_t cs = A0 + 16u * ci, p = ci == 0 ? M0 : cs;
                     const uint2 E = T.ent[incl];
                     const uint32_t nx = T.eos[incl];
@@ -847,7 +847,7 @@ __device__ inline void materialise_piece7(const DevModel &m, const DevRef &ref, 
         // ---- 3b. lane per event: the sub-run that starts behind the event's letters, up to the next event or the end of its chunk — unless the
         // chunk starts under this event (then the chunk lane has it)
         uint4 fe = make_uint4(0, 0, 0, 0); uint32_t ei0 = 16, ei1 = 16, eoc = 0;
-        if (take && !NS_DBG(1u)) {
+        if (take && !NS_DBG(1u) && !NS_DBG(128u)) {
             const uint32_t c = (s1 - A0) >> 4, ecs = A0 + 16u * c;
             const uint32_t en = min(os_next, min(ecs + 16u, M1));
             if ((int32_t)(en - s1) > 0 && ekey > c) {
@@ -959,6 +959,7 @@ __device__ inline void materialise_piece7(const DevModel &m, const DevRef &ref, 
                 if constexpr (!HPF) {
                     if ((a0 | a1 | a2 | a3) & 0x80808080u) resolve16(a0, a1, a2, a3, i0, i1, c0 + fy[t], key, pc.sid, a);
                 }
+                if (NS_DBG(512u)) { a0 = a1 = a2 = a3 = 0x41414141u; }
                 uint32_t r0 = v.x | a0, r1 = v.y | a1, r2 = v.z | a2, r3 = v.w | a3;
                 uint64_t qlo = 0, qhi = 0;
                 uint32_t s0 = lo_m - c0, count = hi_m - lo_m;          // bytes [s0, s0 + count) of the chunk are this tile's
