@@ -182,9 +182,19 @@ class Workload:
         self.engine, self.genome, self.fastq, self.kmer, self.rank, self.world = engine, genome, fastq, kmer, rank, world
         self.meta = genome == "zymo10"
         self.chimeric = bool(chimeric)
-        prefix = os.path.join(tmp, "hg002_like")
+        self.trained_shape = bool(getattr(a, "trained_shape", False))
+        prefix = os.path.join(tmp, "hg002_like" + ("_trained_shape" if self.trained_shape else ""))
         if not os.path.exists(prefix + "_kde.npz"):
-            synth.write_model(prefix, synth.SynthModelSpec(n_train=1_000_000, seed=SEED), write_pkl=False)
+            spec = synth.SynthModelSpec(n_train=1_000_000, seed=SEED)
+            if self.trained_shape:
+                # the table SHAPE of a model read_analysis.py trains (README.md:41: the published ones are not in this image): 15 previous-match
+                # bins and 1 500-row ECDFs — ~360 KB of chain tables, far beyond the LDS image, so k_chain reads them from global memory
+                # (k_chain<false, false>, ns_chain.h: chain_error_list_g).  Same error rates as hg002_like.
+                bins = ((0, 1), (1, 2), (2, 3), (3, 5), (5, 7), (7, 10), (10, 14), (14, 19), (19, 25), (25, 33), (33, 45), (45, 60),
+                        (60, 90), (90, 150), (150, 1500))
+                means = (24.0, 25.0, 26.0, 27.0, 28.0, 29.0, 30.0, 31.0, 31.0, 32.0, 33.0, 34.0, 35.0, 36.0, 36.0)
+                spec = synth.SynthModelSpec(n_train=1_000_000, seed=SEED, ecdf_rows=1500, mm_bins=bins, mm_means=means, mm_zero=(0.0,) + (0.03,) * 14)
+            synth.write_model(prefix, spec, write_pkl=False)
         self.mdl = model.load_model(prefix, fastq=fastq, homopolymer=kmer > 0, chimeric=self.chimeric)
         names, chrom_off, circular = reference_layout(genome)
         self.glen = glen = int(chrom_off[-1])
@@ -248,7 +258,8 @@ class Workload:
 
     def describe(self):
         mode = "metagenome mode" if self.meta else "genome mode"
-        return (WORKLOADS[self.genome] + ", hg002_like error model" + ("" if self.meta else ", " + mode) + ", " + ("FASTQ" if self.fastq else "FASTA") +
+        return (WORKLOADS[self.genome] + ", hg002_like error model" + (" in the table shape of a trained model (15 bins x 1 500 rows: chain tables in global memory)" if self.trained_shape else "") +
+                ("" if self.meta else ", " + mode) + ", " + ("FASTQ" if self.fastq else "FASTA") +
                 (", -hp -k %d" % self.kmer if self.kmer else "") + (", --chimeric" if self.chimeric else ""))
 
     def split(self, n, aligned_only):
@@ -590,6 +601,8 @@ def main():
     ap.add_argument("--chimeric", action="store_true", help="chimeric reads (S:1276-1299; configs[3] and, optionally, configs[4])")
     ap.add_argument("--metagenome", action="store_true", help="configs[4]: zymo10-like community, one metagenome worker call per step (S:814-1040)")
     ap.add_argument("--errlog", action="store_true", help="also format the error profile on the device")
+    ap.add_argument("--trained-shape", action="store_true", help="the hg002_like rates in the table shape of a model read_analysis.py trains (15 previous-match bins, "
+                                                                 "1 500-row ECDFs): the chain reads its tables from global memory")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-genome-run", action="store_true", help="same as --aligned-only (kept for the profiling scripts)")
     ap.add_argument("--cpu-sample", type=int, default=5000, help="reads PER CORE of the CPU baseline sample (about 10 s with every core busy)")
@@ -607,7 +620,7 @@ def main():
     a = ap.parse_args()
     a.aligned_only = a.aligned_only or a.no_genome_run
     genome = "zymo10" if a.metagenome else a.genome
-    default_cfg = genome == "ecoli" and not a.fastq and not a.kmer_bias and not a.aligned_only and not a.serial and not a.chimeric
+    default_cfg = genome == "ecoli" and not a.fastq and not a.kmer_bias and not a.aligned_only and not a.serial and not a.chimeric and not a.trained_shape
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a)                                         # (does not return)
 

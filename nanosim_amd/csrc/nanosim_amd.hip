@@ -291,6 +291,12 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #ifndef NS_CHAIN_BLOCK
 #define NS_CHAIN_BLOCK 256     // threads per block of the thread-per-read chain (320 was measured slower: 4.56 vs 4.09 ms)
 #endif
+// ... and when the LDS image is large (a trained model's hot prefixes: ~43 KB): 512 threads share one image — 43 + 16 KB of staging fit a
+// CU twice = four waves per SIMD, where 256-thread workgroups (43 + 8 KB each) reach 2.6 (measured: profiles/r06/chain_pmc_trained_shape.log).
+// (640 threads — ten waves, 3 + 3 + 2 + 2 over the SIMDs — would make five on paper, but two such workgroups rarely find their slots: 2.3.)
+#ifndef NS_CHAIN_BLOCK_BIG
+#define NS_CHAIN_BLOCK_BIG 512
+#endif
 // Wavefronts per SIMD the thread-per-read chain is compiled for.  Five: 95 VGPRs without scratch, and the bench model's LDS image (24.1 KB)
 // + 8 KB of event staging fits five workgroups per CU (round 5, same box: aligned chain alone 2.94 -> 2.76 ms; four until round 4, when
 // the lists needed 104 VGPRs and the image 30 KB)
@@ -298,7 +304,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #define NS_CHAIN_MINW 5
 #endif
 template <bool LDS_TABLES, bool COOP>
-__global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK, COOP ? 4 : NS_CHAIN_MINW) k_chain(GenArgs A) {
+__global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? 4 : NS_CHAIN_MINW) k_chain(GenArgs A) {
     extern __shared__ uint64_t lds_tbl[];
     CoopLds *coop = nullptr;
     if constexpr (COOP && !LDS_TABLES) { __shared__ CoopLds coop_lds; coop = &coop_lds; }
@@ -343,7 +349,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK, COOP ? 4 : NS_CHAI
             const uint64_t ev_off = A.l_off ? A.l_base + A.l_off[tid] : A.ev_base + A.ev_off[r];
             const uint64_t ev_cap64 = A.l_off ? A.l_off[tid + 1] - A.l_off[tid] : A.ev_off[r + 1] - A.ev_off[r];
             const uint32_t ev_cap = ev_cap64 > 0xffffffffull ? 0xffffffffu : (uint32_t)ev_cap64;
-            EvSink32 sink; sink.last_ins_len = 0; sink.overflow = false; sink.range = false;
+            EvSink32 sink; sink.last_ins_len = 0; sink.overflow = false; sink.range = false; sink.stride = blockDim.x;
             int64_t total = (int64_t)rd.head + rd.tail;
             uint32_t evn = 0;
             const uint32_t trx_chrom = trx_al ? pc[0].pos : 0u;      // planned by k_lengths
@@ -362,6 +368,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK, COOP ? 4 : NS_CHAI
                 else if constexpr (COOP && LDS_TABLES) { e.l_new = e.middle_ref = m32; sink.range = true; }   // (not launched for aligned segments: their tables are not in this image)
                 else if constexpr (COOP) e = coop_error_list(T, ct, m32, key, sid, a, sink, *coop, lane);
                 else if constexpr (LDS_TABLES) e = chain_error_list(T, Tabs{A.m.chain_blob}, ct, m32, key, sid, a, sink);
+                else if (ct.int_image) e = chain_error_list(T, T, ct, m32, key, sid, a, sink);      // the integer image, from global memory (it does not fit LDS)
                 else e = chain_error_list_g(T, ct, m32, key, sid, a, sink);
                 ev_flush_tail(sink);
                 p.ev_off = ev_off + evn;
@@ -1824,6 +1831,7 @@ struct ns_ctx {
     bool has_abun = false, has_inflated = false, has_key_pos = false;
     std::vector<double> abun, abun_inflated, last_species_bases;
     bool lds_tables = false, coop_ok = false;
+    uint32_t chain_block = NS_CHAIN_BLOCK;     // threads per workgroup of k_chain<LDS> (ns_load_model: 256, or 640 for a large image)
     size_t lds_bytes = 0;
     uint32_t hp_bm_k = 0;                // -k: the k the bitmap hp_bm was built for (0: none)
     ns_batch_info last{};
@@ -2152,10 +2160,18 @@ int ns_load_model(ns_ctx *ctx, const ns_model_tables *t) {
         std::vector<uint64_t> blob;
         ChainTab &ct = m.ct;
         bool whole = true;
-        ns_pack_chain_tables(t, nseg, ct, blob, whole);
+        uint32_t force_bits = 0;
+        if (const char *d = getenv("NS_TAIL_BITS")) force_bits = (uint32_t)atoi(d) & 31u;
+        ns_pack_chain_tables(t, nseg, ct, blob, whole, force_bits);
         if ((rc = upload(ctx, pool, blob.data(), blob.size(), &m.chain_blob))) return rc;
         ctx->lds_bytes = (size_t)ct.n_words_lds * 8;
-        ctx->lds_tables = whole && ctx->lds_bytes <= 40 * 1024;     // keep >= 4 workgroups of 256 threads per CU
+        // (the packer sizes the image — hot prefixes of the match-length columns — for 24 / 32 / 45 KB: five / four / three workgroups of 256
+        // threads per CU next to their 8 KB of event staging; a model whose image is larger still keeps its tables in global memory)
+        ctx->lds_tables = whole && ctx->lds_bytes <= 44 * 1024;
+        // workgroup size of the thread-per-read chain: 256 threads while five workgroups (image + 8 KB of staging) fit a CU's 160 KB, else
+        // NS_CHAIN_BLOCK_BIG threads on one image while image + staging stays inside the 64 KB a launch may ask for
+        ctx->chain_block = (ctx->lds_bytes + 8192 <= 32768 || ctx->lds_bytes + NS_CHAIN_BLOCK_BIG * 32u > 65536) ? NS_CHAIN_BLOCK : NS_CHAIN_BLOCK_BIG;
+        if (const char *d = getenv("NS_CHAIN_BLOCK")) { const int v = atoi(d); if (v >= 64 && v <= NS_CHAIN_BLOCK_BIG && v % 64 == 0) ctx->chain_block = (uint32_t)v; }
         double vmax = 0;
         for (uint32_t k2 = 0; k2 < nseg; ++k2) if (t->mm_vhi[k2] > vmax) vmax = t->mm_vhi[k2];
         ctx->coop_ok = t->mm_nbins <= COOP_MAX_BINS && vmax < 65535.0;   // the cooperative chain keeps match lengths in 16 bits
@@ -2806,8 +2822,9 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
             HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
             Q.list_base = n_coop; Q.list_n = (uint32_t)np - n_coop;
         }
-        const dim3 grid_pc((unsigned)((Q.list_n + NS_CHAIN_BLOCK - 1) / NS_CHAIN_BLOCK)), blk_c(NS_CHAIN_BLOCK);
-        if (lds) k_chain<true, false><<<grid_pc, blk_c, ctx->lds_bytes + (Q.ev_stage ? NS_CHAIN_BLOCK * 32u : 0u), st>>>(Q);
+        const uint32_t cb = lds ? ctx->chain_block : NS_CHAIN_BLOCK;
+        const dim3 grid_pc((unsigned)((Q.list_n + cb - 1) / cb)), blk_c(cb);
+        if (lds) k_chain<true, false><<<grid_pc, blk_c, ctx->lds_bytes + (Q.ev_stage ? cb * 32u : 0u), st>>>(Q);
         else k_chain<false, false><<<grid_pc, blk_c, 0, st>>>(Q);
         HIPCHK(hipGetLastError());
         if (n_coop) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
@@ -2973,8 +2990,9 @@ static int trx_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, Ge
             A.events = P.events = (ns_event *)ctx->events.p;
             P.list = (const uint32_t *)ctx->list_b.p;
             HIPCHK(hipEventRecord(ctx->evt[3], st));
-            const dim3 grid_c((unsigned)((np + NS_CHAIN_BLOCK - 1) / NS_CHAIN_BLOCK)), blk_c(NS_CHAIN_BLOCK);
-            if (lds) k_chain<true, false><<<grid_c, blk_c, ctx->lds_bytes + (P.ev_stage ? NS_CHAIN_BLOCK * 32u : 0u), st>>>(P);
+            const uint32_t cb = lds ? ctx->chain_block : NS_CHAIN_BLOCK;
+            const dim3 grid_c((unsigned)((np + cb - 1) / cb)), blk_c(cb);
+            if (lds) k_chain<true, false><<<grid_c, blk_c, ctx->lds_bytes + (P.ev_stage ? cb * 32u : 0u), st>>>(P);
             else k_chain<false, false><<<grid_c, blk_c, 0, st>>>(P);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(ctx->evt[4], st));
@@ -3070,7 +3088,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     A.key_first = A.name_first = prm->first_read;
     A.cap_gap_mul = 2;
     // events of the thread-per-read chain staged four at a time in LDS, when the tables leave room for it next to four workgroups per CU
-    A.ev_stage = (ctx->lds_tables && ctx->lds_bytes + NS_CHAIN_BLOCK * 32u <= 40u * 1024u && !getenv("NS_NO_EV_STAGE")) ? (uint32_t)ctx->lds_bytes : 0u;
+    A.ev_stage = (ctx->lds_tables && ctx->lds_bytes + ctx->chain_block * 32u <= 64u * 1024u && !getenv("NS_NO_EV_STAGE")) ? (uint32_t)ctx->lds_bytes : 0u;
     A.n_pieces = (uint32_t *)ctx->n_pieces.p; A.piece_off = (uint32_t *)ctx->piece_off.p;
     A.ev_cap = (uint64_t *)ctx->ev_cap.p; A.ev_off = (uint64_t *)ctx->ev_off.p; A.l_cap = (uint64_t *)ctx->l_cap.p;
     A.rec_len = (uint64_t *)ctx->rec_len.p; A.rec_off = (uint64_t *)ctx->rec_off.p;
@@ -3226,9 +3244,10 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
                 HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
                 A.list = cur + n_coop; A.list_n = cur_n - n_coop;
             }
-            const dim3 grid_c((A.list_n + NS_CHAIN_BLOCK - 1) / NS_CHAIN_BLOCK), blk_c(NS_CHAIN_BLOCK);
+            const uint32_t cb = lds ? ctx->chain_block : NS_CHAIN_BLOCK;
+            const dim3 grid_c((A.list_n + cb - 1) / cb), blk_c(cb);
             if (!A.list_n) {}
-            else if (lds) k_chain<true, false><<<grid_c, blk_c, ctx->lds_bytes + (A.ev_stage ? NS_CHAIN_BLOCK * 32u : 0u), st>>>(A);
+            else if (lds) k_chain<true, false><<<grid_c, blk_c, ctx->lds_bytes + (A.ev_stage ? cb * 32u : 0u), st>>>(A);
             else k_chain<false, false><<<grid_c, blk_c, 0, st>>>(A);
             HIPCHK(hipGetLastError());
             if (n_coop) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
@@ -3343,7 +3362,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
 static void lend_tables(const ns_ctx *ctx, ns_ctx *c) {
     c->m = ctx->m; c->ref = ctx->ref; c->has_model = ctx->has_model; c->has_ref = ctx->has_ref;
     c->cap_rate = ctx->cap_rate; c->ref_nbases = ctx->ref_nbases;
-    c->lds_tables = ctx->lds_tables; c->lds_bytes = ctx->lds_bytes; c->coop_ok = ctx->coop_ok;
+    c->lds_tables = ctx->lds_tables; c->lds_bytes = ctx->lds_bytes; c->coop_ok = ctx->coop_ok; c->chain_block = ctx->chain_block;
     c->nspecies = ctx->nspecies; c->species_chrom_off = ctx->species_chrom_off;      // (DevBuf by value: not freed by the companion)
     c->tx = ctx->tx; c->has_trx = ctx->has_trx;
     c->has_abun = false; c->has_inflated = false; c->has_ir = false;                   // (aligned workers only: S:814-1040, 1156-1192)

@@ -70,16 +70,17 @@ struct EvSink32 {
     uint32_t last_ins_len;
     bool overflow;
     bool range;          // an event does not fit the 8-byte record: run longer than NS_EV_LEN_MAX, or |shift| >= NS_EV_SHIFT_BIAS
-    // thread-per-read chain: LDS column of this thread, four slots NS_CHAIN_BLOCK apart (nullptr: events are stored one by one).
+    // thread-per-read chain: LDS column of this thread, four slots `stride` (= threads of the workgroup) apart (nullptr: events are stored one by one).
     // A thread's scattered 8-byte stores cost a 32-byte memory write each (WRITE_SIZE 10.3 KB per read for 2.1 KB of events); staged,
     // four events leave as one aligned 32-byte group (ev and cap are multiples of four events then)
     uint2 *stg;
+    uint32_t stride;
 };
 #ifndef NS_CHAIN_BLOCK
 #define NS_CHAIN_BLOCK 256
 #endif
 NS_DEV void ev_flush4(EvSink32 &s, uint32_t first) {       // staged slots 0..3 -> events first .. first + 3
-    const uint2 e0 = s.stg[0], e1 = s.stg[NS_CHAIN_BLOCK], e2 = s.stg[2 * NS_CHAIN_BLOCK], e3 = s.stg[3 * NS_CHAIN_BLOCK];
+    const uint2 e0 = s.stg[0], e1 = s.stg[s.stride], e2 = s.stg[2u * s.stride], e3 = s.stg[3u * s.stride];
     uint4 *dst = reinterpret_cast<uint4 *>(s.ev + first);
     // (plain stores: as nontemporal stores these scattered 32-byte groups took the thread-per-read chain from 3.2 to 8.5 ms,
     // profiles/r05/ab_nt_more.log — nontemporal pays for the wave-wide contiguous streams of the record and error-profile images)
@@ -97,7 +98,7 @@ NS_DEV void ev_push32(EvSink32 &s, int32_t pos, uint32_t type, int32_t len) {
     if (s.n < s.cap) {
         ns_event e; e.pos = (uint32_t)pos; e.info = ns_ev_pack(l, type, s.shift);
         if (s.stg) {
-            s.stg[(s.n & 3u) * NS_CHAIN_BLOCK] = make_uint2(e.pos, e.info);
+            s.stg[(s.n & 3u) * s.stride] = make_uint2(e.pos, e.info);
             if ((s.n & 3u) == 3u) ev_flush4(s, s.n - 3u);
         } else s.ev[s.n] = e;
     } else s.overflow = true;
@@ -190,7 +191,7 @@ NS_DEV void ev_push32s(EvSink32 &s, EvTrack &t, int32_t pos, uint32_t type, int3
     if (s.n < s.cap) {
         ns_event e; e.pos = (uint32_t)pos; e.info = ns_ev_pack(l, type, s.shift);
         if (s.stg) {
-            s.stg[(s.n & 3u) * NS_CHAIN_BLOCK] = make_uint2(e.pos, e.info);
+            s.stg[(s.n & 3u) * s.stride] = make_uint2(e.pos, e.info);
             if ((s.n & 3u) == 3u) ev_flush4(s, s.n - 3u);
         } else s.ev[s.n] = e;
     }
@@ -247,11 +248,37 @@ NS_DEV int32_t ecdf_lookup_gv(const uint64_t *__restrict__ GV, uint32_t n, const
     return (int32_t)floor((p - plo) / (hs - plo) * (vs - vlo) + vlo);
 }
 
-// the generic look-up of the next match length (any previous match, any segment class): the fall-back of chain_error_list's fast path
+// the same walk on the PREFIX of a column (the LDS image, ns_pack.h): answers for a unit-wide or narrow segment inside the prefix; false: the
+// draw lies behind the prefix, or in a wide segment (fp64 formula) — the full column decides
+NS_DEV bool ecdf_lookup_pre(const uint64_t *__restrict__ GV, uint32_t n, const uint16_t *__restrict__ guide, uint32_t u,
+                            const uint64_t *__restrict__ sub2, int32_t &out) {
+    const uint64_t uu = u;
+    uint32_t s = guide[u >> 24];
+    uint64_t g = 0;
+    while (s < n) { g = GV[s]; if (uu < NS_G_THR(g)) break; ++s; }
+    if (s >= n) return false;
+    if (g & NS_GV_UNIT) { out = (int32_t)(uint32_t)(g >> 35) - 1; return true; }
+    if (g & NS_GV_NARROW) {
+        const uint64_t *t = sub2 + (g >> 35);
+        const uint64_t h = t[0];
+        const uint32_t nt = (uint32_t)(h >> 32);
+        int32_t r = (int32_t)(uint32_t)h - (int32_t)nt;
+        for (uint32_t k = 1; k <= nt; ++k) r += uu >= t[k] ? 1 : 0;
+        out = r;
+        return true;
+    }
+    return false;
+}
+// the generic look-up of the next match length (any previous match, any segment class, any draw): the fall-back of chain_error_list's fast
+// path.  The prefix column in the LDS image first (a walk of more than two segments, a narrow segment: a few percent of the events); the
+// FULL column in global memory for what the prefix cannot answer (a draw behind it: one in 2^tail_bits; a wide segment; a previous match >= 256)
 NS_DEV int32_t next_match_gv(const Tabs &T, const Tabs &TG, const ChainTab &c, int32_t prev_match, uint32_t u) {
     uint32_t b, o, ncol;
     if ((uint32_t)prev_match < 256u) {
-        const uint64_t pe = T.q(c.pm_lut)[prev_match];
+        const uint64_t pp = T.q(c.pm_lut)[prev_match];
+        int32_t r;
+        if (ecdf_lookup_pre(T.q(c.mm_gv) + (uint32_t)pp, (uint32_t)(pp >> 32) & 0xffffffu, T.h(c.mm_guide) + 256u * (uint32_t)(pp >> 56), u, T.q(c.sub2), r)) return r;
+        const uint64_t pe = TG.q(c.pm_full)[prev_match];
         b = (uint32_t)(pe >> 56); o = (uint32_t)pe; ncol = (uint32_t)(pe >> 32) & 0xffffffu;
     } else {                                                                                       // S:1891-1893
         const int32_t *bins = T.i(c.mm_bin);
@@ -261,7 +288,7 @@ NS_DEV int32_t next_match_gv(const Tabs &T, const Tabs &TG, const ChainTab &c, i
         if (b >= c.mm_nbins) b = c.mm_nbins - 1;
         o = seg_off[b]; ncol = seg_off[b + 1] - o;
     }
-    return ecdf_lookup_gv(T.q(c.mm_gv) + o, ncol, T.h(c.mm_guide) + 256u * b, u, T.q(c.sub2), TG.d(c.mm_hi) + o, TG.d(c.mm_vhi) + o, T.d(c.mm_vlo0)[b]);
+    return ecdf_lookup_gv(TG.q(c.mm_gv_full) + o, ncol, T.h(c.mm_guide) + 256u * b, u, TG.q(c.sub2_full), TG.d(c.mm_hi) + o, TG.d(c.mm_vhi) + o, T.d(c.mm_vlo0)[b]);
 }
 
 // T: the LDS image (the first n_words_lds words of the blob); TG: the whole blob in global memory (fp64 tables of the wide segments)
@@ -270,7 +297,7 @@ NS_DEV EList32 chain_error_list(const Tabs &T, const Tabs &TG, const ChainTab &c
     int32_t l_new = m_ref, pos = 0, middle_ref = m_ref;
     uint32_t state = NS_ST_START;
     u32x4 w = ns_draw(key, ST_EVENT, seg, attempt, 0, 0);
-    int32_t prev_match = ecdf_lookup_gv(T.q(c.fm_gv), c.fm_n, T.h(c.fm_guide), w.x, T.q(c.sub2), TG.d(c.fm_hi), TG.d(c.fm_vhi), c.fm_vlo0);   // S:1843-1850
+    int32_t prev_match = ecdf_lookup_gv(TG.q(c.fm_gv), c.fm_n, T.h(c.fm_guide), w.x, TG.q(c.sub2_full), TG.d(c.fm_hi), TG.d(c.fm_vhi), c.fm_vlo0);   // S:1843-1850 (once per piece: global memory)
     if (prev_match < 2) prev_match = 2;
     pos += prev_match;
     uint32_t it = 1;

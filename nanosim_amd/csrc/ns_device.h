@@ -13,10 +13,16 @@ struct ChainTab {                 // offsets are in 8-byte words from the start 
                                   // {offset | length << 32, guide}: indexed by a per-thread type, three fields of this struct would be
                                   // three vector loads from the kernel-argument segment per event
     uint32_t fm_hi, fm_vhi, fm_n, fm_guide;
-    uint32_t fm_gv, mm_gv;        // ONE word per ECDF segment: threshold | class | value (ecdf_lookup_gv)
-    uint32_t pm_lut;              // the column of a previous match < 256 in one word {first segment | segments << 32 | bin << 56}
-    uint32_t sub2;                // the steps of the interpolation inside the narrow segments
-    uint32_t n_words_lds;         // the blob up to here goes to LDS (k_chain<LDS>); the fp64 tables behind it stay in global memory
+    uint32_t mm_gv;               // ONE word per ECDF segment: threshold | class | value (ecdf_lookup_gv) — in the LDS part the HOT PREFIX of every
+                                  // match-length column (round 6): the segments a draw reaches with probability >= 1 - 2^-tail_bits; a draw beyond
+                                  // them takes the full column in global memory (mm_gv_full): a trained model's 15 x 1 500 segments are 180 KB
+    uint32_t pm_lut;              // the (prefix) column of a previous match < 256 in one word {first segment | segments << 32 | bin << 56}
+    uint32_t sub2;                // the steps of the interpolation inside the narrow segments (of the prefix columns)
+    uint32_t n_words_lds;         // the blob up to here goes to LDS (k_chain<LDS>); what lies behind it stays in global memory:
+    uint32_t fm_gv, mm_gv_full, pm_full, sub2_full;   // the first-match column (one look-up per piece), the FULL match-length columns, their
+                                  // {first segment | segments | bin} words and step lists; then the fp64 tables
+    uint32_t int_image;           // every value edge is a whole number: the integer image is valid (chain_error_list), in LDS or not
+    uint32_t tail_bits;           // the prefix columns end where 2^-tail_bits of the probability is left (0: they are the full columns)
     uint32_t n_words_mix;         // ... and up to here (trans, mix_w, the run-length tables, mix_rec) is all unaligned_error_list reads:
                                   // the LDS image of the wave-per-read unaligned chain (k_chain<true, true>)
     uint32_t mm_nbins, mm_bin, mm_bin_lut, mm_seg_off, mm_hi, mm_vhi, mm_vlo0, mm_guide;

@@ -11,7 +11,8 @@
 //              per-lane indexed kernel-argument loads
 //   fm_guide, mm_guide   256-entry guides of the ECDF columns: g[i] = #{s : hi[s] < i/256}
 //   mm_bin, mm_bin_lut, mm_seg_off, mm_vlo0   bins of the previous match length (S:1891-1893), the bin of a length < 256, the columns' ranges
-//   fm_gv, mm_gv   per ECDF segment ONE word: bits 0..32 the threshold ns_thr_gt(hi[s]) (p > hi[s] <=> u >= thr, exactly); bit 33: the
+//   mm_gv      (LDS: the hot prefix of every column, ns_device.h; the full columns mm_gv_full and the first-match column fm_gv lie in the global part)
+//              per ECDF segment ONE word: bits 0..32 the threshold ns_thr_gt(hi[s]) (p > hi[s] <=> u >= thr, exactly); bit 33: the
 //              segment is one unit wide and every draw inside it gives vlo — bits 35.. = vhi; bit 34: 1..15 units wide with steps inside —
 //              bits 35.. = index into sub2 of {vhi | steps << 32} followed by the step thresholds; neither bit: the fp64 formula on the
 //              global tables
@@ -20,13 +21,15 @@
 // Global part (wide segments, the cooperative chain, models whose image does not fit LDS): fm_hi, mm_hi, fm_vhi, mm_vhi as fp64.
 #pragma once
 #include <math.h>
+#define NS_PACK_THR(g) ((g) & 0x1ffffffffull)        // the threshold field of a segment word (NS_G_THR of ns_chain.h)
 #include <string.h>
 #include <vector>
 #include "ns_device.h"
 
 // nseg: number of segments of all match-length columns together (t->mm_seg_off[t->mm_nbins]).  whole: every value edge is a whole number
 // that fits its field and the step lists fit their index field — the condition for the integer LDS image (k_chain<LDS>).
-static inline void ns_pack_chain_tables(const ns_model_tables *t, uint32_t nseg, ChainTab &ct, std::vector<uint64_t> &blob, bool &whole) {
+static inline void ns_pack_chain_tables(const ns_model_tables *t, uint32_t nseg, ChainTab &ct, std::vector<uint64_t> &blob, bool &whole,
+                                        uint32_t force_tail_bits = 0) {
     blob.clear();
     auto put_d = [&](const double *src, size_t n) { uint32_t off = (uint32_t)blob.size(); blob.resize(off + n);
                                                      memcpy(blob.data() + off, src, n * 8); return off; };
@@ -102,8 +105,7 @@ static inline void ns_pack_chain_tables(const ns_model_tables *t, uint32_t nseg,
     // inside a segment (vlo, vhi] the interpolation floor((p - plo) / (hs - plo) * (vs - vlo) + vlo) of S:1847 / S:1897 is a
     // non-decreasing step function of the draw: its steps are found here with the arithmetic of the fp64 formula (this file is compiled
     // with -ffp-contract=off, like the device code and the oracle) — ecdf_lookup_gv resolves a draw without floating point.
-    std::vector<uint64_t> sub2;
-    auto segments = [&](const double *hi, const double *src, size_t n, double vlo0, std::vector<uint64_t> &out) {
+    auto segments = [&](const double *hi, const double *src, size_t n, double vlo0, std::vector<uint64_t> &out, std::vector<uint64_t> &sub2) {
         for (size_t i = 0; i < n; ++i) {
             if (!(src[i] >= 0 && src[i] < 536870912.0 && src[i] == floor(src[i]))) whole = false;       // (29 bits behind the flags)
             const uint32_t e = (uint32_t)(src[i] < 0 ? 0 : src[i] >= 2147483647.0 ? 2147483647.0 : src[i]);
@@ -128,24 +130,75 @@ static inline void ns_pack_chain_tables(const ns_model_tables *t, uint32_t nseg,
             }
             out.push_back(word);
         } };
-    std::vector<uint64_t> fm_gv, mm_gv;
-    segments(t->fm_hi, t->fm_vhi, t->fm_nseg, t->fm_vlo0, fm_gv);
+    // ---- the FULL columns (global memory) ----
+    std::vector<uint64_t> fm_gv, mm_full, sub2_full;
+    segments(t->fm_hi, t->fm_vhi, t->fm_nseg, t->fm_vlo0, fm_gv, sub2_full);
     for (uint32_t b = 0; b < t->mm_nbins; ++b) {               // per column: its first segment starts at the column's vlo0
         const uint32_t o = t->mm_seg_off[b];
-        segments(t->mm_hi + o, t->mm_vhi + o, t->mm_seg_off[b + 1] - o, t->mm_vlo0[b], mm_gv);
+        segments(t->mm_hi + o, t->mm_vhi + o, t->mm_seg_off[b + 1] - o, t->mm_vlo0[b], mm_full, sub2_full);
     }
-    if (sub2.size() >= (1u << 28)) whole = false;
-    sub2.push_back(0);
-    std::vector<uint64_t> pm(256);
+    if (sub2_full.size() >= (1u << 28)) whole = false;
+    sub2_full.push_back(0);
+    std::vector<uint64_t> pm_full(256);
     for (uint32_t v = 0; v < 256; ++v) {
         const uint32_t b = lut[v], o = t->mm_seg_off[b], nc = t->mm_seg_off[b + 1] - o;
         if (nc >= (1u << 24)) whole = false;
-        pm[v] = (uint64_t)o | (uint64_t)(nc & 0xffffffu) << 32 | (uint64_t)b << 56;
+        pm_full[v] = (uint64_t)o | (uint64_t)(nc & 0xffffffu) << 32 | (uint64_t)b << 56;
     }
-    // (ecdf_lookup_gv reads the word behind a column's last segment and never uses it: every table below is followed by another one)
-    ct.fm_gv = put_q(fm_gv); ct.mm_gv = put_q(mm_gv); ct.pm_lut = put_q(pm); ct.sub2 = put_q(sub2);
+    // ---- the HOT PREFIX of every match-length column (the LDS part) ----
+    // A column of a trained model has as many rows as the longest match in the training data (1 500 x 15 bins x 8 bytes = 180 KB: more than a
+    // CU's LDS), but a draw lands behind row r with the probability the column has left there.  The prefix of a column ends at its first
+    // segment whose threshold leaves <= 2^-tail_bits; the chain's fast path only accepts a segment INSIDE the prefix (it tests s < ncol with
+    // the prefix length), everything else — one draw in 2^tail_bits — goes through next_match_gv on the full column: same thresholds, same
+    // answer.  tail_bits: the largest of 14 .. 10 whose image fits 24 KB (five 256-thread workgroups with their 8 KB of event staging in a CU's
+    // 160 KB) or 44 KB (two 512-thread workgroups with 16 KB each: four waves per SIMD); 0 = the prefixes are the full columns (small models: the image of the bench model is 24 KB either way).
+    const size_t head_words = blob.size();
+    auto prefix_len = [&](uint32_t b, uint32_t bits) {
+        const uint32_t o = t->mm_seg_off[b], nc = t->mm_seg_off[b + 1] - o;
+        if (!bits) return nc;
+        const uint64_t cut = (1ull << 32) - (1ull << (32 - bits));
+        uint32_t r = 0;
+        while (r < nc && NS_PACK_THR(mm_full[o + r]) < cut) ++r;    // segments whose upper edge is still below the cut ...
+        return r < nc ? r + 1 : nc;                                   // ... and the one that crosses it
+    };
+    auto image_words = [&](uint32_t tb) {                     // (+ the prefixes' step lists: at most the full ones)
+        size_t n = head_words + 256 + 64 + sub2_full.size();
+        for (uint32_t b = 0; b < t->mm_nbins; ++b) n += prefix_len(b, tb);
+        return n; };
+    uint32_t bits = 0;
+    if (image_words(0) * 8 > 24 * 1024) {
+        bits = 10;
+        for (uint32_t limit : {24u * 1024u, 44u * 1024u}) {
+            uint32_t best = 0;
+            for (uint32_t tb = 14; tb >= 10; --tb) if (image_words(tb) * 8 <= limit) { best = tb; break; }
+            if (best) { bits = best; break; }
+        }
+    }
+    if (force_tail_bits) bits = force_tail_bits;              // (NS_TAIL_BITS: A/B runs)
+#ifdef NS_PACK_TAIL_BITS
+    bits = NS_PACK_TAIL_BITS;                                 // test builds (tests/test_chain_host.py): short prefixes, so that the full-column path is taken often
+#endif
+    ct.tail_bits = bits;
+    std::vector<uint64_t> mm_gv, sub2;
+    std::vector<uint32_t> pre_off(t->mm_nbins + 1, 0);
+    for (uint32_t b = 0; b < t->mm_nbins; ++b) {
+        const uint32_t o = t->mm_seg_off[b], r = prefix_len(b, bits);
+        pre_off[b] = (uint32_t)mm_gv.size();
+        segments(t->mm_hi + o, t->mm_vhi + o, r, t->mm_vlo0[b], mm_gv, sub2);
+    }
+    pre_off[t->mm_nbins] = (uint32_t)mm_gv.size();
+    std::vector<uint64_t> pm(256);
+    for (uint32_t v = 0; v < 256; ++v) {
+        const uint32_t b = lut[v];
+        pm[v] = (uint64_t)pre_off[b] | (uint64_t)((pre_off[b + 1] - pre_off[b]) & 0xffffffu) << 32 | (uint64_t)b << 56;
+    }
+    // (the chain reads the word behind a column's last segment and never uses it: every table below is followed by another one)
+    sub2.push_back(0);
+    ct.mm_gv = put_q(mm_gv); ct.pm_lut = put_q(pm); ct.sub2 = put_q(sub2);
     ct.n_words_lds = (uint32_t)blob.size();
-    ct.fm_hi = put_d(t->fm_hi, t->fm_nseg); ct.mm_hi = put_d(t->mm_hi, nseg);      // fp64 tables: global memory (wide segments, cooperative chain)
+    ct.fm_gv = put_q(fm_gv); ct.mm_gv_full = put_q(mm_full); ct.pm_full = put_q(pm_full); ct.sub2_full = put_q(sub2_full);
+    ct.fm_hi = put_d(t->fm_hi, t->fm_nseg); ct.mm_hi = put_d(t->mm_hi, nseg);      // fp64 tables: wide segments, cooperative chain, chain_error_list_g
     ct.fm_vhi = put_d(t->fm_vhi, t->fm_nseg); ct.mm_vhi = put_d(t->mm_vhi, nseg);
+    ct.int_image = whole ? 1u : 0u;
     ct.n_words = (uint32_t)blob.size();
 }

@@ -1,0 +1,23 @@
+#!/bin/bash
+# round 6, GPU call 13: the hg002_like rates in the table shape of a TRAINED model (15 previous-match bins x 1 500-row ECDFs: ~240 KB of chain
+# tables, k_chain from global memory — the path a real human_giab_hg002 model takes) against the LDS-image path, same box
+cd "$(dirname "$0")/../.."
+export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$PWD}
+O=gpurun_out/r06m; mkdir -p $O
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+for tag in lds trained lds trained; do
+  if [ $tag = trained ]; then X="--trained-shape"; else X=""; fi
+  timeout 300 python bench.py $X --steps 6 --warmup 2 --no-cpu-baseline --no-e2e --no-configs2 --extras-steps 3 2>$O/err_$tag.log | tail -1 > $O/bench_$tag.json
+  python - $tag $O/bench_$tag.json <<'P' | tee -a $O/ab.log
+import json,sys
+name,p=sys.argv[1:3]
+try:
+    d=json.load(open(p))
+except Exception as ex:
+    print(name,"FAILED",ex); sys.exit(0)
+r=lambda x:round(x,2)
+s=d.get("serial",{})
+print(name,"step",r(d["ms_per_step"]),"ms",r(d["value"]/1e6),"M/s | aligned",{k:r(v) for k,v in d["kernel_ms"].items() if v>0.01},"frac",r(d["roofline"]["frac"]),
+      "| serial",r(s.get("ms_per_step",0)),"al",{k:r(v) for k,v in (s.get("aligned_kernel_ms") or {}).items() if v>0.01}, "|", d["config"]["workload"][:150])
+P
+done

@@ -1,0 +1,24 @@
+#!/bin/bash
+# round 6, GPU call 14: the LDS image with the HOT PREFIX of every match-length column (a trained model's 15 x 1 500-row columns no longer
+# push the chain to global memory): parity, then bench.py --trained-shape against the default model, alternating
+cd "$(dirname "$0")/../.."
+export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$PWD}
+O=gpurun_out/r06n; mkdir -p $O
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+( timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_metagenome.py tests/test_gpu_transcriptome.py -m gpu -x -q 2>&1 | tail -4 ) | tee $O/pytest_parity.log
+for tag in lds trained lds trained; do
+  if [ $tag = trained ]; then X="--trained-shape"; else X=""; fi
+  timeout 300 python bench.py $X --steps 6 --warmup 2 --no-cpu-baseline --no-e2e --no-configs2 --extras-steps 3 2>$O/err_$tag.log | tail -1 > $O/bench_$tag.json
+  python - $tag $O/bench_$tag.json <<'P' | tee -a $O/ab.log
+import json,sys
+name,p=sys.argv[1:3]
+try:
+    d=json.load(open(p))
+except Exception as ex:
+    print(name,"FAILED",ex); sys.exit(0)
+r=lambda x:round(x,2)
+s=d.get("serial",{})
+print(name,"step",r(d["ms_per_step"]),"ms",r(d["value"]/1e6),"M/s | aligned",{k:r(v) for k,v in d["kernel_ms"].items() if v>0.01},"frac",r(d["roofline"]["frac"]),
+      "| serial",r(s.get("ms_per_step",0)),"al",{k:r(v) for k,v in (s.get("aligned_kernel_ms") or {}).items() if v>0.01})
+P
+done

@@ -25,10 +25,12 @@ void *chost_pack(const ns_model_tables *t) {
 void chost_free(void *p) { delete static_cast<ChainHost *>(p); }
 int chost_whole(const void *p) { return static_cast<const ChainHost *>(p)->whole ? 1 : 0; }
 uint32_t chost_lds_words(const void *p) { return static_cast<const ChainHost *>(p)->ct.n_words_lds; }
+uint32_t chost_tail_bits(const void *p) { return static_cast<const ChainHost *>(p)->ct.tail_bits; }
 
 // variant 0: chain_error_list   — the integer image k_chain<LDS> walks (T = the blob's first n_words_lds words)
 //         1: chain_error_list_g — the fp64 tables (models whose value edges are not whole numbers, tables too large for LDS)
 //         2: chain_unaligned_error_list on the LDS image, 3: on the whole blob (k_chain<false, .>)
+//         4: chain_error_list with the whole blob as its image (an integer image that does not fit LDS)
 // T and TG: the LDS image is the first n_words_lds words of the blob — handing the chain a COPY of just those words as T checks that it
 // never reads a table of the LDS part behind them.
 // staged != 0: events go through the four-slot staging column (EvSink32::stg) as in k_chain<LDS> for single-piece reads; cap must then be
@@ -43,13 +45,14 @@ int chost_error_list(const void *p, int variant, int staged, int32_t m_ref, uint
     uint2 stage[4 * NS_CHAIN_BLOCK];
     EvSink32 s;
     s.ev = ev; s.cap = cap; s.n = 0; s.shift = 0; s.last_ins_len = 0; s.overflow = false; s.range = false;
-    s.stg = staged ? stage : nullptr;
+    s.stg = staged ? stage : nullptr; s.stride = NS_CHAIN_BLOCK;
     EList32 e;
     switch (variant) {
     case 0: e = chain_error_list(T, TG, h->ct, m_ref, key, seg, attempt, s); break;
     case 1: e = chain_error_list_g(TG, h->ct, m_ref, key, seg, attempt, s); break;
     case 2: e = chain_unaligned_error_list(T, h->ct, m_ref, key, seg, attempt, s); break;
     case 3: e = chain_unaligned_error_list(TG, h->ct, m_ref, key, seg, attempt, s); break;
+    case 4: e = chain_error_list(TG, TG, h->ct, m_ref, key, seg, attempt, s); break;     // the integer image read from global memory (k_chain<false, false>)
     default: return -1;
     }
     ev_flush_tail(s);

@@ -19,9 +19,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not found")
 
-VARIANT_LDS, VARIANT_FP64, VARIANT_UNALIGNED, VARIANT_UNALIGNED_G = 0, 1, 2, 3
+VARIANT_LDS, VARIANT_FP64, VARIANT_UNALIGNED, VARIANT_UNALIGNED_G, VARIANT_INT_GLOBAL = 0, 1, 2, 3, 4
 UNALIGNED = (VARIANT_UNALIGNED, VARIANT_UNALIGNED_G)
-ALL = (VARIANT_LDS, VARIANT_FP64, VARIANT_UNALIGNED, VARIANT_UNALIGNED_G)
+ALL = (VARIANT_LDS, VARIANT_FP64, VARIANT_UNALIGNED, VARIANT_UNALIGNED_G, VARIANT_INT_GLOBAL)
 
 
 def _build(tmp, extra=()):
@@ -34,6 +34,7 @@ def _build(tmp, extra=()):
     L.chost_free.restype = None; L.chost_free.argtypes = [C.c_void_p]
     L.chost_whole.restype = C.c_int; L.chost_whole.argtypes = [C.c_void_p]
     L.chost_lds_words.restype = C.c_uint32; L.chost_lds_words.argtypes = [C.c_void_p]
+    L.chost_tail_bits.restype = C.c_uint32; L.chost_tail_bits.argtypes = [C.c_void_p]
     L.chost_error_list.restype = C.c_int
     L.chost_error_list.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32] + \
                                   [C.c_void_p] * 6
@@ -121,13 +122,25 @@ def test_device_chains_on_models_that_take_the_other_look_up_paths(host, tmp_pat
                  dense=synth.SynthModelSpec(n_train=3000, seed=7, aligned_median=2500.0, mis=(3.0, 0.0, 0.3, 0.5), ins=(8.0, 0.9, 0.12, 0.5),
                                             dele=(6.0, 0.95, 0.15, 0.5), mm_means=(2.0, 2.5, 3.0, 3.0, 3.5, 3.5, 4.0, 4.0),
                                             mm_zero=(0.0, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3), fm_mean=3.0))
+    short = _build(str(tmp_path), extra=("-DNS_PACK_TAIL_BITS=3",))      # prefixes that end where 1/8 of the probability is left
     for name, spec in specs.items():
         prefix = str(tmp_path / name / "training")
         synth.write_model(prefix, spec, write_pkl=False)
         mdl = M.load_model(prefix)
         pk, n_ev = sweep(host, mdl, ALL, 160, 2, (1, 2, 4, 9, 33, 300, 900, 8000))
         assert host.chost_whole(pk) and n_ev > 20000, name
+        if name == "big":
+            # round 6: the LDS image holds the HOT PREFIX of every match-length column (15 x 1 500 segments are 180 KB); a draw behind a
+            # prefix takes the full column in global memory.  The image fits three workgroups per CU next to their event staging.
+            assert 10 <= host.chost_tail_bits(pk) <= 14 and host.chost_lds_words(pk) * 8 <= 45 * 1024
+        else:
+            assert host.chost_lds_words(pk) * 8 <= 32 * 1024
         host.chost_free(pk)
+        # the same with prefixes so short that one draw in eight leaves them: the full-column path under load (T is a COPY of the LDS words
+        # only: a read of a prefix table behind its end would be out of bounds)
+        pk, n_ev = sweep(short, mdl, (VARIANT_LDS, VARIANT_INT_GLOBAL), 120, 3, (1, 2, 4, 9, 33, 300, 900, 8000))
+        assert short.chost_tail_bits(pk) == 3 and n_ev > 10000, name
+        short.chost_free(pk)
 
 
 def test_event_capacity_overflow_and_range_flags(host, small_model, tmp_path):
@@ -170,4 +183,4 @@ def test_event_capacity_overflow_and_range_flags(host, small_model, tmp_path):
             seen += int(bool(o["range"]))
     finally:
         host.chost_free(pk)
-    assert seen == 4                                       # every case does leave the field (else the flag was never exercised)
+    assert seen == len(ALL)                                # every case does leave the field (else the flag was never exercised)

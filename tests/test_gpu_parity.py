@@ -237,9 +237,12 @@ def test_background_context_gives_the_same_unaligned_reads(small_model, small_re
             e.close()
 
 
-def test_large_tables_take_the_global_memory_path(tmp_path, small_ref, monkeypatch):
-    """A model shaped like a real trained one (15 previous-match bins, 1500-row ECDFs): the chain tables (~360 KB) do not
-    fit the LDS budget, so k_chain reads them from global memory; the cooperative chain is forced on as well."""
+def test_large_tables_of_a_trained_model_shape(tmp_path, small_ref, monkeypatch):
+    """A model shaped like a real trained one (15 previous-match bins, 1500-row ECDFs: ~360 KB of chain tables).  Round 6: the LDS image
+    holds the HOT PREFIX of every match-length column (the segments a draw reaches with probability >= 1 - 2^-12: ~43 KB, 512-thread
+    workgroups), a draw behind a prefix takes the full column in global memory.  The same reads with prefixes cut at 1/8 of the probability
+    (NS_TAIL_BITS=3: the full-column path under load), with 256-thread workgroups, and with the whole integer image read from global
+    memory (an image forced out of LDS); the cooperative chain is forced on as well."""
     from nanosim_amd import synth
     bins = ((0, 1), (1, 2), (2, 3), (3, 5), (5, 7), (7, 10), (10, 14), (14, 19), (19, 25), (25, 33), (33, 45), (45, 60),
             (60, 90), (90, 150), (150, 1500))
@@ -251,17 +254,25 @@ def test_large_tables_take_the_global_memory_path(tmp_path, small_ref, monkeypat
     assert sum(len(c.hi) for c in mdl.match_markov) * 16 > 64 * 1024
     monkeypatch.setenv("NS_COOP_MIN", "1")
     monkeypatch.setenv("NS_COOP_SHIFT", "2")
-    e = E.Engine(0)
-    try:
-        e.set_reference(small_ref)
-        e.load_model(mdl)
-        for kw in (dict(n_reads=600, emit_errlog=True), dict(n_reads=300, fastq=True, chimeric=True, kmer_bias=5)):
-            args = dict(seed=4242, first_read=0, max_len=small_ref.max_chrom)
-            args.update(kw)
-            p = E.make_params(**args)
-            compare(e.generate(p), O.generate(mdl, small_ref, p), p)
-    finally:
-        e.close()
+    exp = {}
+    for env in ({}, {"NS_TAIL_BITS": "3"}, {"NS_CHAIN_BLOCK": "256"}, {"NS_TAIL_BITS": "31"}):      # 31 bits: prefixes = (nearly) the full columns, no LDS
+        for k in ("NS_TAIL_BITS", "NS_CHAIN_BLOCK"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = E.Engine(0)
+        try:
+            e.set_reference(small_ref)
+            e.load_model(mdl)
+            for i, kw in enumerate((dict(n_reads=600, emit_errlog=True), dict(n_reads=300, fastq=True, chimeric=True, kmer_bias=5))):
+                args = dict(seed=4242, first_read=0, max_len=small_ref.max_chrom)
+                args.update(kw)
+                p = E.make_params(**args)
+                if i not in exp:
+                    exp[i] = O.generate(mdl, small_ref, p)
+                compare(e.generate(p), exp[i], p)
+        finally:
+            e.close()
 
 
 def test_dense_events_and_long_payloads(tmp_path, small_ref, circ_ref):
