@@ -119,6 +119,11 @@ def test_device_chains_on_models_that_take_the_other_look_up_paths(host, tmp_pat
     specs = dict(hg002=synth.SynthModelSpec(n_train=20000, seed=5),
                  big=synth.SynthModelSpec(n_train=3000, seed=99, ecdf_rows=1500, mm_bins=bins, mm_means=tuple(20.0 + 2 * i for i in range(15)),
                                           mm_zero=(0.0,) + (0.02,) * 14, fm_mean=25.0),
+                 # matches of hundreds of bases (a low-error model): previous matches >= 256 are the rule — pm_lut's cells of sixteen lengths, with bin
+                 # edges inside a cell (700, 1001) and on a cell border (256, 2048)
+                 long=synth.SynthModelSpec(n_train=3000, seed=11, ecdf_rows=3000, fm_mean=150.0,
+                                           mm_bins=((0, 40), (40, 120), (120, 256), (256, 700), (700, 1001), (1001, 2048), (2048, 3000)),
+                                           mm_means=(150.0, 200.0, 260.0, 320.0, 380.0, 430.0, 480.0), mm_zero=(0.0,) + (0.01,) * 6),
                  dense=synth.SynthModelSpec(n_train=3000, seed=7, aligned_median=2500.0, mis=(3.0, 0.0, 0.3, 0.5), ins=(8.0, 0.9, 0.12, 0.5),
                                             dele=(6.0, 0.95, 0.15, 0.5), mm_means=(2.0, 2.5, 3.0, 3.0, 3.5, 3.5, 4.0, 4.0),
                                             mm_zero=(0.0, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3), fm_mean=3.0))
@@ -127,9 +132,11 @@ def test_device_chains_on_models_that_take_the_other_look_up_paths(host, tmp_pat
         prefix = str(tmp_path / name / "training")
         synth.write_model(prefix, spec, write_pkl=False)
         mdl = M.load_model(prefix)
-        pk, n_ev = sweep(host, mdl, ALL, 160, 2, (1, 2, 4, 9, 33, 300, 900, 8000))
-        assert host.chost_whole(pk) and n_ev > 20000, name
-        if name == "big":
+        pk, n_ev = sweep(host, mdl, ALL, 160, 2, (1, 2, 4, 9, 33, 300, 900, 8000) if name != "long" else (5, 700, 9000, 60000))
+        assert host.chost_whole(pk) and n_ev > (20000 if name != "long" else 5000), name
+        if name == "long":
+            assert host.chost_lds_words(pk) * 8 > 44 * 1024      # (even its shortest prefixes do not fit: on the GPU this model reads its image from global memory)
+        elif name == "big":
             # round 6: the LDS image holds the HOT PREFIX of every match-length column (15 x 1 500 segments are 180 KB); a draw behind a
             # prefix takes the full column in global memory.  The image fits three workgroups per CU next to their event staging.
             assert 10 <= host.chost_tail_bits(pk) <= 14 and host.chost_lds_words(pk) * 8 <= 45 * 1024
@@ -138,8 +145,8 @@ def test_device_chains_on_models_that_take_the_other_look_up_paths(host, tmp_pat
         host.chost_free(pk)
         # the same with prefixes so short that one draw in eight leaves them: the full-column path under load (T is a COPY of the LDS words
         # only: a read of a prefix table behind its end would be out of bounds)
-        pk, n_ev = sweep(short, mdl, (VARIANT_LDS, VARIANT_INT_GLOBAL), 120, 3, (1, 2, 4, 9, 33, 300, 900, 8000))
-        assert short.chost_tail_bits(pk) == 3 and n_ev > 10000, name
+        pk, n_ev = sweep(short, mdl, (VARIANT_LDS, VARIANT_INT_GLOBAL), 120, 3, (1, 2, 4, 9, 33, 300, 900, 8000) if name != "long" else (5, 700, 9000, 60000))
+        assert short.chost_tail_bits(pk) == 3 and n_ev > (10000 if name != "long" else 3000), name
         short.chost_free(pk)
 
 
