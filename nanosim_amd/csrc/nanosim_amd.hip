@@ -292,7 +292,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #define NS_CHAIN_BLOCK 256     // threads per block of the thread-per-read chain (320 was measured slower: 4.56 vs 4.09 ms)
 #endif
 // ... and when the LDS image is large (a trained model's hot prefixes: ~43 KB): 512 threads share one image — 43 + 16 KB of staging fit a
-// CU twice = four waves per SIMD, where 256-thread workgroups (43 + 8 KB each) reach 2.6 (measured: profiles/r06/chain_pmc_trained_shape.log).
+// CU twice = four waves per SIMD, where 256-thread workgroups (43 + 8 KB each) reach 2.6 (measured: profiles/r06/chain_trained_shape.log).
 // (640 threads — ten waves, 3 + 3 + 2 + 2 over the SIMDs — would make five on paper, but two such workgroups rarely find their slots: 2.3.)
 #ifndef NS_CHAIN_BLOCK_BIG
 #define NS_CHAIN_BLOCK_BIG 512
