@@ -286,6 +286,11 @@ NS_DEV int32_t next_match_gv(const Tabs &T, const Tabs &TG, const ChainTab &c, i
         for (b = 0; b < c.mm_nbins; ++b)
             if (bins[2 * b] <= prev_match && prev_match < bins[2 * b + 1]) break;
         if (b >= c.mm_nbins) b = c.mm_nbins - 1;
+        // (a trained model's matches run to thousands of bases: one event in a few thousand follows a match >= 256 — one iteration in fifty
+        // of a wavefront; its prefix column answers from LDS like any other)
+        const uint64_t pp = T.q(c.pm_bin)[b];
+        int32_t r;
+        if (ecdf_lookup_pre(T.q(c.mm_gv) + (uint32_t)pp, (uint32_t)(pp >> 32) & 0xffffffu, T.h(c.mm_guide) + 256u * b, u, T.q(c.sub2), r)) return r;
         o = seg_off[b]; ncol = seg_off[b + 1] - o;
     }
     return ecdf_lookup_gv(TG.q(c.mm_gv_full) + o, ncol, T.h(c.mm_guide) + 256u * b, u, TG.q(c.sub2_full), TG.d(c.mm_hi) + o, TG.d(c.mm_vhi) + o, T.d(c.mm_vlo0)[b]);

@@ -18,6 +18,7 @@ struct ChainTab {                 // offsets are in 8-byte words from the start 
                                   // them takes the full column in global memory (mm_gv_full): a trained model's 15 x 1 500 segments are 180 KB
     uint32_t pm_lut;              // the (prefix) column of a previous match < 256 in one word {first segment | segments << 32 | bin << 56}
     uint32_t sub2;                // the steps of the interpolation inside the narrow segments (of the prefix columns)
+    uint32_t pm_bin;              // the prefix column of every bin, same word format (previous matches >= 256 find their bin by the walk of S:1891-1893)
     uint32_t n_words_lds;         // the blob up to here goes to LDS (k_chain<LDS>); what lies behind it stays in global memory:
     uint32_t fm_gv, mm_gv_full, pm_full, sub2_full;   // the first-match column (one look-up per piece), the FULL match-length columns, their
                                   // {first segment | segments | bin} words and step lists; then the fp64 tables

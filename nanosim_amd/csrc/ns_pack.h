@@ -162,7 +162,7 @@ static inline void ns_pack_chain_tables(const ns_model_tables *t, uint32_t nseg,
         return r < nc ? r + 1 : nc;                                   // ... and the one that crosses it
     };
     auto image_words = [&](uint32_t tb) {                     // (+ the prefixes' step lists: at most the full ones)
-        size_t n = head_words + 256 + 64 + sub2_full.size();
+        size_t n = head_words + 256 + 64 + t->mm_nbins + sub2_full.size();
         for (uint32_t b = 0; b < t->mm_nbins; ++b) n += prefix_len(b, tb);
         return n; };
     uint32_t bits = 0;
@@ -194,7 +194,9 @@ static inline void ns_pack_chain_tables(const ns_model_tables *t, uint32_t nseg,
     }
     // (the chain reads the word behind a column's last segment and never uses it: every table below is followed by another one)
     sub2.push_back(0);
-    ct.mm_gv = put_q(mm_gv); ct.pm_lut = put_q(pm); ct.sub2 = put_q(sub2);
+    std::vector<uint64_t> pmb(t->mm_nbins);
+    for (uint32_t b = 0; b < t->mm_nbins; ++b) pmb[b] = (uint64_t)pre_off[b] | (uint64_t)((pre_off[b + 1] - pre_off[b]) & 0xffffffu) << 32 | (uint64_t)b << 56;
+    ct.mm_gv = put_q(mm_gv); ct.pm_lut = put_q(pm); ct.pm_bin = put_q(pmb); ct.sub2 = put_q(sub2);
     ct.n_words_lds = (uint32_t)blob.size();
     ct.fm_gv = put_q(fm_gv); ct.mm_gv_full = put_q(mm_full); ct.pm_full = put_q(pm_full); ct.sub2_full = put_q(sub2_full);
     ct.fm_hi = put_d(t->fm_hi, t->fm_nseg); ct.mm_hi = put_d(t->mm_hi, nseg);      // fp64 tables: wide segments, cooperative chain, chain_error_list_g
