@@ -150,8 +150,9 @@ static inline void ns_pack_chain_tables(const ns_model_tables *t, uint32_t nseg,
     // CU's LDS), but a draw lands behind row r with the probability the column has left there.  The prefix of a column ends at its first
     // segment whose threshold leaves <= 2^-tail_bits; the chain's fast path only accepts a segment INSIDE the prefix (it tests s < ncol with
     // the prefix length), everything else — one draw in 2^tail_bits — goes through next_match_gv on the full column: same thresholds, same
-    // answer.  tail_bits: the largest of 14 .. 10 whose image fits 24 KB (five 256-thread workgroups with their 8 KB of event staging in a CU's
-    // 160 KB) or 44 KB (two 512-thread workgroups with 16 KB each: four waves per SIMD); 0 = the prefixes are the full columns (small models: the image of the bench model is 24 KB either way).
+    // answer.  tail_bits: the largest of 14 .. 12 whose image fits 24 KB (five 256-thread workgroups with their 8 KB of event staging in a CU's
+    // 160 KB), else of 14 .. 8 that fits 44 KB (two 512-thread workgroups with 16 KB each: four waves per SIMD; a model of very long matches
+    // gives up coverage for a place in LDS); 0 = the prefixes are the full columns (small models: the image of the bench model is 24 KB either way).
     const size_t head_words = blob.size();
     auto prefix_len = [&](uint32_t b, uint32_t bits) {
         const uint32_t o = t->mm_seg_off[b], nc = t->mm_seg_off[b + 1] - o;
@@ -167,10 +168,10 @@ static inline void ns_pack_chain_tables(const ns_model_tables *t, uint32_t nseg,
         return n; };
     uint32_t bits = 0;
     if (image_words(0) * 8 > 24 * 1024) {
-        bits = 10;
+        bits = 8;
         for (uint32_t limit : {24u * 1024u, 44u * 1024u}) {
             uint32_t best = 0;
-            for (uint32_t tb = 14; tb >= 10; --tb) if (image_words(tb) * 8 <= limit) { best = tb; break; }
+            for (uint32_t tb = 14; tb >= (limit == 24u * 1024u ? 12u : 8u); --tb) if (image_words(tb) * 8 <= limit) { best = tb; break; }
             if (best) { bits = best; break; }
         }
     }
