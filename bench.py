@@ -718,11 +718,15 @@ def main():
         # on the same GPU, same protocol: BASELINE configs[2] (chr1-size linear reference, FASTQ + base qualities + homopolymers), and the
         # headline's FASTA workload on that reference — 249 Mb do not fit the L2 / Infinity Cache the 4.6 Mb of configs[1] live in, so this
         # is the record kernel's roofline with its source bytes coming from HBM
-        for key, fq, km in (("configs2", True, 5), ("chr1_fasta", False, 0)):
+        import copy
+        a_tr = copy.copy(a); a_tr.trained_shape = True
+        # ... and the headline workload with its chain tables in the SHAPE read_analysis.py gives a trained model (15 previous-match bins x
+        # 1 500-row ECDFs: --trained-shape): the hot prefixes of the columns in LDS, the rest in global memory
+        for key, gen, fq, km, aa in (("configs2", "chr1", True, 5, a), ("chr1_fasta", "chr1", False, 0, a), ("trained_shape", "ecoli", False, 0, a_tr)):
             try:
-                w2 = Workload(a, "chr1", fq, km, local_rank, rank, world, None, False, False, tmp)
-                infos2, dt2, _ = timed_steps(w2, a, n, n_al, n_un, a.configs2_steps, 1, None, False)
-                c2 = summarise(w2, a, infos2, dt2, n, n_al, n_un, a.configs2_steps, 1, 1, sum(int(x.total_bases) for st in infos2 for x in st), False)
+                w2 = Workload(aa, gen, fq, km, local_rank, rank, world, None, False, False, tmp)
+                infos2, dt2, _ = timed_steps(w2, a, n, n_al, n_un, a.configs2_steps, 2, None, False)
+                c2 = summarise(w2, a, infos2, dt2, n, n_al, n_un, a.configs2_steps, 2, 1, sum(int(x.total_bases) for st in infos2 for x in st), False)
                 out[key] = {k: c2[k] for k in ("value", "unit", "bases_per_s", "steps", "warmup", "ms_per_step", "config", "device_ms_per_step",
                                                "aligned_batch", "roofline", "unaligned_batch")}
                 w2.close()

@@ -12,7 +12,7 @@ d=json.load(open(sys.argv[1])); r=lambda x:round(x,3)
 print("step", r(d["ms_per_step"]), "ms", r(d["value"]/1e6), "M reads/s | aligned", r(d["aligned_batch"]["device_ms"]), {k:r(v) for k,v in d["kernel_ms"].items() if v>0.01}, "| unaligned", r(d["unaligned_batch"]["device_ms"]), {k:r(v) for k,v in d["unaligned_batch"]["kernel_ms"].items() if v>0.01})
 print("roofline", {k:(r(v) if isinstance(v,float) else v) for k,v in d["roofline"].items() if k in ("frac","frac_kernel_only_bytes","frac_counter_bytes","whole_aligned_batch_frac","traffic_source")})
 for k in ("serial","errlog_on"): print(k, {a:(r(b) if isinstance(b,float) else b) for a,b in d[k].items() if not isinstance(b,(dict,str))})
-for key in ("configs2","chr1_fasta"):
+for key in ("configs2","chr1_fasta","trained_shape"):
     c=d.get(key,{}); print(key, r(c.get("ms_per_step",0)), r(c.get("value",0)/1e6), "M reads/s", {k:r(v) for k,v in (c.get("aligned_batch",{}).get("kernel_ms") or {}).items() if v>0.01}, "frac", c.get("roofline",{}).get("frac"), "batch frac", c.get("roofline",{}).get("whole_aligned_batch_frac"), c.get("roofline",{}).get("traffic_source"))
 print("cpu", d.get("cpu_baseline",{}).get("value"), d.get("cpu_baseline",{}).get("cores"), "e2e", {k:(r(v.get("reads_per_s",0)/1e6) if isinstance(v,dict) and "reads_per_s" in v else None) for k,v in d.get("e2e",{}).items()})
 P
