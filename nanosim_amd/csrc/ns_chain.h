@@ -231,7 +231,12 @@ NS_DEV int32_t ecdf_lookup_gv(const uint64_t *__restrict__ GV, uint32_t n, const
     const uint32_t k0 = (s0 < n) & (uu >= NS_G_THR(g0)), k1 = k0 & (s0 + 1u < n) & (uu >= NS_G_THR(g1));
     uint64_t g = k0 ? g1 : g0;
     uint32_t s = s0 + k0 + k1;
-    if (k1) while (s < n) { g = GV[s]; if (uu < NS_G_THR(g)) break; ++s; }                  // (rare: three or more segments inside one guide cell)
+    if (k1) {                                     // three or more segments inside one guide cell: bisection between the guide's bounds — the
+        const uint32_t cell = u >> 24;            // last cells of a trained model's column hold hundreds of segments (its tail rows), and in the
+        uint32_t hi2 = cell < 255u ? min((uint32_t)guide[cell + 1u], n) : n;      // full column every step of a walk is a global-memory read
+        while (s < hi2) { const uint32_t mid = (s + hi2) >> 1; if (uu >= NS_G_THR(GV[mid])) s = mid + 1u; else hi2 = mid; }
+        if (s < n) g = GV[s];
+    }
     if (s < n && (g & NS_GV_UNIT)) return (int32_t)(uint32_t)(g >> 35) - 1;
     if (s < n && (g & NS_GV_NARROW)) {
         const uint64_t *t = sub2 + (g >> 35);
@@ -253,10 +258,11 @@ NS_DEV int32_t ecdf_lookup_gv(const uint64_t *__restrict__ GV, uint32_t n, const
 NS_DEV bool ecdf_lookup_pre(const uint64_t *__restrict__ GV, uint32_t n, const uint16_t *__restrict__ guide, uint32_t u,
                             const uint64_t *__restrict__ sub2, int32_t &out) {
     const uint64_t uu = u;
-    uint32_t s = guide[u >> 24];
-    uint64_t g = 0;
-    while (s < n) { g = GV[s]; if (uu < NS_G_THR(g)) break; ++s; }
+    const uint32_t cell = u >> 24;
+    uint32_t s = guide[cell], hi2 = cell < 255u ? min((uint32_t)guide[cell + 1u], n) : n;       // first segment with u < threshold: bisection
+    while (s < hi2) { const uint32_t mid = (s + hi2) >> 1; if (uu >= NS_G_THR(GV[mid])) s = mid + 1u; else hi2 = mid; }   // between the guide's bounds
     if (s >= n) return false;
+    const uint64_t g = GV[s];
     if (g & NS_GV_UNIT) { out = (int32_t)(uint32_t)(g >> 35) - 1; return true; }
     if (g & NS_GV_NARROW) {
         const uint64_t *t = sub2 + (g >> 35);

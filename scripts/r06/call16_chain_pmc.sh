@@ -3,7 +3,7 @@
 export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06p; mkdir -p $O; cd /tmp; export TMPDIR=/tmp; ulimit -c 0
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-for tag in default trained trained256 trained384; do
+for tag in default trained; do
   X=""; E=""
   [ $tag = trained ] && X="--trained-shape"
   [ $tag = trained256 ] && X="--trained-shape" && export NS_CHAIN_BLOCK=256
@@ -15,7 +15,7 @@ for tag in default trained trained256 trained384; do
 done
 python3 - <<'P' | tee $O/chain_pmc.log
 import csv,glob,collections
-for tag in ("default","trained","trained256","trained384"):
+for tag in ("default","trained"):
     acc=collections.defaultdict(list); dur=[]
     for d in ("c1","c2"):
         for f in glob.glob('/tmp/%s_%s/**/*counter_collection.csv'%(d,tag), recursive=True):

@@ -3,7 +3,7 @@
 # default / trained-shape lines alternating, then workgroup sizes for the trained shape
 cd "$(dirname "$0")/../.."
 export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$PWD}
-O=gpurun_out/r06s; mkdir -p $O
+O=gpurun_out/r06t; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 ( timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_metagenome.py tests/test_gpu_transcriptome.py -m gpu -x -q 2>&1 | tail -4 ) | tee $O/pytest_parity.log
 run() { tag=$1; shift
@@ -24,4 +24,4 @@ P
 X=""; run default Y=1
 X="--trained-shape"; run trained Y=1
 X=""; run default Y=1
-X="--trained-shape"; run trained Y=1; run trained_tb13 NS_TAIL_BITS=13; run trained_tb11 NS_TAIL_BITS=11
+X="--trained-shape"; run trained Y=1; run trained_256 NS_CHAIN_BLOCK=256; run trained_tb14 NS_TAIL_BITS=14; run trained_tb10 NS_TAIL_BITS=10; run trained_global NS_TAIL_BITS=31
