@@ -555,6 +555,43 @@ __device__ inline EList32 coop_error_list(const Tabs &T, const ChainTab &c, int3
             S.err_tab[lane] = eb;
 #pragma unroll
             for (int t = 0; t < 3; ++t) S.step_tab[lane][t] = (uint16_t)run_length_t(T, c, t, wi.y, wi.z);
+            if (c.int_image) {
+                // Round 6: the next match length of EVERY column on the one-word segments of the full columns, four columns at a time, their
+                // reads side by side: 65 536-cell guide -> the guide's segment and the next -> (unit-wide, no third segment in the cell:
+                // all but a few draws in ten thousand) the value.  Two dependent global reads per group of four columns; the fp64 loop below
+                // made two to four per COLUMN, one column after the other — and the chain phase of a call waits for the wave that walks
+                // its longest read (profiles/r06/chain_trained_shape.log).  Same thresholds, same values as ecdf_lookup_g.
+                const uint16_t *g16 = T.h(c.mm_g16);
+                const uint64_t *gvf = T.q(c.mm_gv_full);
+                const uint32_t cell = wi.w >> 16, nb = c.mm_nbins;
+                const uint64_t uu = wi.w;
+                for (uint32_t b0 = 0; b0 < nb; b0 += 4) {
+                    uint32_t o[4], nc[4], s0[4];
+                    uint64_t ga[4], gb[4];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        const uint32_t b = min(b0 + k, nb - 1u);
+                        o[k] = seg_off[b]; nc[k] = seg_off[b + 1] - o[k];
+                        s0[k] = g16[(size_t)b * 65536u + cell];
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        const uint32_t sc = min(s0[k], nc[k] ? nc[k] - 1u : 0u);
+                        ga[k] = gvf[o[k] + sc]; gb[k] = gvf[o[k] + sc + 1u];                       // (the word behind a column is read, never used)
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        const uint32_t b = min(b0 + k, nb - 1u);
+                        const uint32_t k0 = (s0[k] < nc[k] ? 1u : 0u) & (uu >= NS_G_THR(ga[k]) ? 1u : 0u);
+                        const uint32_t k1 = k0 & (s0[k] + 1u < nc[k] ? 1u : 0u) & (uu >= NS_G_THR(gb[k]) ? 1u : 0u);
+                        const uint64_t g = k0 ? gb[k] : ga[k];
+                        int32_t v = (int32_t)(uint32_t)(g >> 35) - 1;
+                        if (!((s0[k] + k0 < nc[k]) && !k1 && (g & NS_GV_UNIT)))
+                            v = ecdf_lookup_gv(gvf + o[k], nc[k], T.h(c.mm_guide) + 256u * b, wi.w, T.q(c.sub2_full), T.d(c.mm_hi) + o[k], T.d(c.mm_vhi) + o[k], T.d(c.mm_vlo0)[b]);
+                        if (b0 + k < nb) S.match_tab[lane][b0 + k] = (uint16_t)v;
+                    }
+                }
+            } else
             for (uint32_t b = 0; b < c.mm_nbins; ++b) {
                 const uint32_t o = seg_off[b];
                 S.match_tab[lane][b] = (uint16_t)ecdf_lookup_g(T.d(c.mm_hi) + o, T.d(c.mm_vhi) + o, seg_off[b + 1] - o,

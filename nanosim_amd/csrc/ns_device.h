@@ -22,6 +22,9 @@ struct ChainTab {                 // offsets are in 8-byte words from the start 
     uint32_t n_words_lds;         // the blob up to here goes to LDS (k_chain<LDS>); what lies behind it stays in global memory:
     uint32_t fm_gv, mm_gv_full, pm_full, sub2_full;   // the first-match column (one look-up per piece), the FULL match-length columns, their
                                   // {first segment | segments | bin} words and step lists; then the fp64 tables
+    uint32_t mm_g16;              // per match-length column a 65 536-cell guide over its FULL one-word segments (uint16: segments passed by the
+                                  // smallest draw of the cell) — the wave-per-read chain evaluates every column for every future iteration
+                                  // (coop_error_list): guide -> two segment words, two dependent reads per column instead of a walk
     uint32_t int_image;           // every value edge is a whole number: the integer image is valid (chain_error_list), in LDS or not
     uint32_t tail_bits;           // the prefix columns end where 2^-tail_bits of the probability is left (0: they are the full columns)
     uint32_t n_words_mix;         // ... and up to here (trans, mix_w, the run-length tables, mix_rec) is all unaligned_error_list reads:

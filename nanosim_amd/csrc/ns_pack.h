@@ -200,6 +200,19 @@ static inline void ns_pack_chain_tables(const ns_model_tables *t, uint32_t nseg,
     ct.mm_gv = put_q(mm_gv); ct.pm_lut = put_q(pm); ct.pm_bin = put_q(pmb); ct.sub2 = put_q(sub2);
     ct.n_words_lds = (uint32_t)blob.size();
     ct.fm_gv = put_q(fm_gv); ct.mm_gv_full = put_q(mm_full); ct.pm_full = put_q(pm_full); ct.sub2_full = put_q(sub2_full);
+    {   // the 65 536-cell guides of the full columns (coop_error_list): g[i] = #{s : thr(s) <= i << 16}
+        std::vector<uint16_t> g16((size_t)t->mm_nbins * 65536u);
+        for (uint32_t b = 0; b < t->mm_nbins; ++b) {
+            const uint32_t o = t->mm_seg_off[b], nc = t->mm_seg_off[b + 1] - o;
+            uint32_t sidx = 0;
+            for (uint32_t i = 0; i < 65536u; ++i) {
+                const uint64_t lo_u = (uint64_t)i << 16;
+                while (sidx < nc && NS_PACK_THR(mm_full[o + sidx]) <= lo_u) ++sidx;
+                g16[(size_t)b * 65536u + i] = (uint16_t)(sidx > 65535u ? 65535u : sidx);
+            }
+        }
+        ct.mm_g16 = put_raw(g16.data(), g16.size() * 2);
+    }
     ct.fm_hi = put_d(t->fm_hi, t->fm_nseg); ct.mm_hi = put_d(t->mm_hi, nseg);      // fp64 tables: wide segments, cooperative chain, chain_error_list_g
     ct.fm_vhi = put_d(t->fm_vhi, t->fm_nseg); ct.mm_vhi = put_d(t->mm_vhi, nseg);
     ct.int_image = whole ? 1u : 0u;
