@@ -48,6 +48,7 @@
 // ---------------------------------------------------------------------------------------------------------
 struct GenArgs {
     uint32_t ev_stage;               // k_chain<LDS>: byte offset of the event staging area behind the tables in dynamic LDS (0: none)
+    uint32_t coop_mix;               // k_chain<false, true>: the launch carries n_words_mix words of dynamic LDS for the front of the blob
     ns_params prm;
     DevModel m;
     DevRef ref;
@@ -318,6 +319,16 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? 4 : NS_
         __syncthreads();
         T.w = lds_tbl;
     } else T.w = A.m.chain_blob;
+    Tabs TM = T;                           // the front of the blob (transition rows, run-length tables)
+    if constexpr (COOP && !LDS_TABLES) {
+        // the wave-per-read ALIGNED chain: its future iterations' run lengths come from the front of the blob — three look-ups of three to four
+        // dependent reads per block of 64 iterations: from an LDS copy when the launch made room for it (A.coop_mix: n_words_mix words)
+        if (A.coop_mix) {
+            for (uint32_t i = threadIdx.x; i < A.m.ct.n_words_mix; i += blockDim.x) lds_tbl[i] = A.m.chain_blob[i];
+            __syncthreads();
+            TM.w = lds_tbl;
+        }
+    }
     const ChainTab &ct = A.m.ct;
     // COOP: the whole wavefront works on ONE read (blockIdx.x-th entry of the list); lane 0 does the bookkeeping stores
     const uint32_t lane = threadIdx.x & 63u;
@@ -364,9 +375,9 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? 4 : NS_
                 }
                 EList32 e;
                 if (kind == NS_KIND_PERFECT) { e.l_new = e.middle_ref = m32; }
-                else if (p.kind) e = COOP ? coop_unaligned_error_list(T, ct, m32, key, sid, a, sink, lane) : chain_unaligned_error_list(T, ct, m32, key, sid, a, sink);
+                else if (p.kind) e = COOP ? coop_unaligned_error_list(TM, ct, m32, key, sid, a, sink, lane) : chain_unaligned_error_list(T, ct, m32, key, sid, a, sink);
                 else if constexpr (COOP && LDS_TABLES) { e.l_new = e.middle_ref = m32; sink.range = true; }   // (not launched for aligned segments: their tables are not in this image)
-                else if constexpr (COOP) e = coop_error_list(T, ct, m32, key, sid, a, sink, *coop, lane);
+                else if constexpr (COOP) e = coop_error_list(TM, T, ct, m32, key, sid, a, sink, *coop, lane);
                 else if constexpr (LDS_TABLES) e = chain_error_list(T, Tabs{A.m.chain_blob}, ct, m32, key, sid, a, sink);
                 else if (ct.int_image) e = chain_error_list(T, T, ct, m32, key, sid, a, sink);      // the integer image, from global memory (it does not fit LDS)
                 else e = chain_error_list_g(T, ct, m32, key, sid, a, sink);
@@ -2817,7 +2828,8 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
             GenArgs B = P; B.list_n = n_coop; B.list_base = 0;
             HIPCHK(hipEventRecord(ctx->ev_fork, st));
             HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-            k_chain<false, true><<<dim3(n_coop), dim3(64), 0, ctx->stream2>>>(B);
+            B.coop_mix = (size_t)B.m.ct.n_words_mix * 8 <= 32u * 1024u ? 1u : 0u;
+            k_chain<false, true><<<dim3(n_coop), dim3(64), B.coop_mix ? (size_t)B.m.ct.n_words_mix * 8 : 0, ctx->stream2>>>(B);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
             Q.list_base = n_coop; Q.list_n = (uint32_t)np - n_coop;
@@ -3239,7 +3251,8 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
                 // unaligned reads: the run-length tables in LDS (k_chain<true, true>; the image must fit next to nothing else: 64 KB)
                 if (prm->kind == NS_KIND_UNALIGNED && ctx->lds_tables && ctx->ucoop_lds && (size_t)A.m.ct.n_words_mix * 8 <= 64u * 1024u)
                     k_chain<true, true><<<dim3(n_coop), dim3(64), (size_t)A.m.ct.n_words_mix * 8, ctx->stream2>>>(B);
-                else k_chain<false, true><<<dim3(n_coop), dim3(64), 0, ctx->stream2>>>(B);
+                else { B.coop_mix = (size_t)B.m.ct.n_words_mix * 8 <= 32u * 1024u ? 1u : 0u;
+                       k_chain<false, true><<<dim3(n_coop), dim3(64), B.coop_mix ? (size_t)B.m.ct.n_words_mix * 8 : 0, ctx->stream2>>>(B); }
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
                 A.list = cur + n_coop; A.list_n = cur_n - n_coop;

@@ -527,11 +527,13 @@ __device__ inline EList32 coop_unaligned_error_list(const Tabs &T, const ChainTa
 struct CoopLds {
     uint32_t err_tab[64];                 // 2 bits per Markov state
     uint16_t step_tab[64][4];             // run length per error type
-    uint16_t match_tab[64][COOP_MAX_BINS];
+    uint32_t match_tab[64][COOP_MAX_BINS];   // next match length | the bin IT falls into << 16 (what the iteration after needs: round 6 — the bin used
+                                          // to come from a global-memory byte table inside the sequential walk, one dependent read per event)
     ns_event ev_buf[64];
 };
 
-__device__ inline EList32 coop_error_list(const Tabs &T, const ChainTab &c, int32_t m_ref, const ns_key &key, uint32_t seg,
+// TM: the front of the blob (transition rows, run-length tables: n_words_mix words) — the wavefront's LDS copy when the launch gave it room
+__device__ inline EList32 coop_error_list(const Tabs &TM, const Tabs &T, const ChainTab &c, int32_t m_ref, const ns_key &key, uint32_t seg,
                                           uint32_t attempt, EvSink32 &s, CoopLds &S, uint32_t lane) {
     int32_t l_new = m_ref, pos = 0, middle_ref = m_ref;
     int state = NS_ST_START;
@@ -541,10 +543,18 @@ __device__ inline EList32 coop_error_list(const Tabs &T, const ChainTab &c, int3
     pos += prev_match;
     uint32_t it0 = 1;
     int32_t last_ins_pos = -1;
-    const uint64_t *trans = T.q(c.trans);
+    const uint64_t *trans = TM.q(c.trans);
     const int32_t *bins = T.i(c.mm_bin);
     const uint32_t *seg_off = T.u(c.mm_seg_off);
     const uint8_t *bin_lut = reinterpret_cast<const uint8_t *>(T.w + c.mm_bin_lut);
+    auto bin_of = [&](int32_t v) -> uint32_t {                                                     // S:1891-1893
+        if ((uint32_t)v < 256u) return bin_lut[v];
+        uint32_t b = 0;
+        for (; b < c.mm_nbins; ++b)
+            if (bins[2 * b] <= v && v < bins[2 * b + 1]) break;
+        return b >= c.mm_nbins ? c.mm_nbins - 1 : b;
+    };
+    uint32_t pbin = bin_of(prev_match);                                                            // bin of the previous match (wave-uniform)
     while (pos < middle_ref) {                                                                     // S:1858
         // ---- parallel: lane evaluates iteration it0+lane for every state / type / bin
         {
@@ -554,7 +564,7 @@ __device__ inline EList32 coop_error_list(const Tabs &T, const ChainTab &c, int3
             for (int st = 0; st < 7; ++st) eb |= (uint32_t)trans_pick_u(trans + 3 * st, wi.x) << (2 * st);
             S.err_tab[lane] = eb;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) S.step_tab[lane][t] = (uint16_t)run_length_t(T, c, t, wi.y, wi.z);
+            for (int t = 0; t < 3; ++t) S.step_tab[lane][t] = (uint16_t)run_length_t(TM, c, t, wi.y, wi.z);
             if (c.int_image) {
                 // Round 6: the next match length of EVERY column on the one-word segments of the full columns, four columns at a time, their
                 // reads side by side: 65 536-cell guide -> the guide's segment and the next -> (unit-wide, no third segment in the cell:
@@ -588,14 +598,15 @@ __device__ inline EList32 coop_error_list(const Tabs &T, const ChainTab &c, int3
                         int32_t v = (int32_t)(uint32_t)(g >> 35) - 1;
                         if (!((s0[k] + k0 < nc[k]) && !k1 && (g & NS_GV_UNIT)))
                             v = ecdf_lookup_gv(gvf + o[k], nc[k], T.h(c.mm_guide) + 256u * b, wi.w, T.q(c.sub2_full), T.d(c.mm_hi) + o[k], T.d(c.mm_vhi) + o[k], T.d(c.mm_vlo0)[b]);
-                        if (b0 + k < nb) S.match_tab[lane][b0 + k] = (uint16_t)v;
+                        // (the value as the walk will use it — "no two 0-matches", S:1900-1901, is decided there — and the bin of either outcome)
+                        if (b0 + k < nb) S.match_tab[lane][b0 + k] = (uint32_t)(uint16_t)v | bin_of(v) << 16 | bin_of(v == 0 ? 1 : v) << 24;
                     }
                 }
             } else
             for (uint32_t b = 0; b < c.mm_nbins; ++b) {
                 const uint32_t o = seg_off[b];
-                S.match_tab[lane][b] = (uint16_t)ecdf_lookup_g(T.d(c.mm_hi) + o, T.d(c.mm_vhi) + o, seg_off[b + 1] - o,
-                                                               T.d(c.mm_vlo0)[b], T.h(c.mm_guide) + 256 * b, wi.w);
+                const int32_t v = ecdf_lookup_g(T.d(c.mm_hi) + o, T.d(c.mm_vhi) + o, seg_off[b + 1] - o, T.d(c.mm_vlo0)[b], T.h(c.mm_guide) + 256 * b, wi.w);
+                S.match_tab[lane][b] = (uint32_t)(uint16_t)v | bin_of(v) << 16 | bin_of(v == 0 ? 1 : v) << 24;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -627,15 +638,10 @@ __device__ inline EList32 coop_error_list(const Tabs &T, const ChainTab &c, int3
                 if (error == NS_INS) { s.shift += (int32_t)l; s.last_ins_len = l; } else if (error == NS_DEL) s.shift -= (int32_t)l;
             }
             state = NS_ST_MIS + error;                                                             // S:1884
-            uint32_t b;                                                                            // S:1891-1893
-            if ((uint32_t)prev_match < 256u) b = bin_lut[prev_match];
-            else {
-                for (b = 0; b < c.mm_nbins; ++b)
-                    if (bins[2 * b] <= prev_match && prev_match < bins[2 * b + 1]) break;
-                if (b >= c.mm_nbins) b = c.mm_nbins - 1;
-            }
-            step = S.match_tab[i][b];
-            if (prev_match == 0 && step == 0) step = 1;                                            // S:1900-1901
+            const uint32_t me = S.match_tab[i][pbin];                                              // S:1891-1898: the column of the previous match's bin
+            step = (int32_t)(me & 0xffffu);
+            pbin = (me >> 16) & 0xffu;
+            if (prev_match == 0 && step == 0) { step = 1; pbin = me >> 24; }                       // S:1900-1901
             prev_match = step;
             if (pos + prev_match > middle_ref) { l_new += pos + prev_match - middle_ref; middle_ref = pos + prev_match; }
             pos += prev_match;

@@ -3,10 +3,10 @@
 # full columns with a 65 536-cell guide, four columns' reads side by side, against the fp64 loop (one column after the other): parity, then A/B
 cd "$(dirname "$0")/../.."
 export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$PWD}
-O=gpurun_out/r06y; mkdir -p $O
+O=gpurun_out/r06y2; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 ( timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_metagenome.py tests/test_gpu_transcriptome.py -m gpu -x -q 2>&1 | tail -4 ) | tee $O/pytest_parity.log
-for rep in 1 2; do for name in base coopg16; do for X in "" "--trained-shape"; do
+for rep in 1 2; do for name in base coop2; do for X in "" "--trained-shape"; do
   f=nanosim_amd/_variants/$name.so
   NANOSIM_AMD_LIB=$PWD/$f timeout 300 python bench.py $X --steps 6 --warmup 2 --no-cpu-baseline --no-e2e --no-configs2 --extras-steps 4 2>$O/err.log | tail -1 > $O/b.json
   python - "$name$X" $O/b.json <<'P' | tee -a $O/ab.log
