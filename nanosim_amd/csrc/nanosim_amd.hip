@@ -48,6 +48,7 @@
 // ---------------------------------------------------------------------------------------------------------
 struct GenArgs {
     uint32_t ev_stage;               // k_chain<LDS>: byte offset of the event staging area behind the tables in dynamic LDS (0: none)
+    uint32_t coop_k1;                // wave-per-read unaligned chain with one iteration per lane (NS_UCOOP_K=1: the form until round 6)
     uint32_t coop_mix;               // k_chain<false, true>: the launch carries n_words_mix words of dynamic LDS for the front of the blob
     ns_params prm;
     DevModel m;
@@ -185,7 +186,11 @@ __global__ void __launch_bounds__(256) k_replan(GenArgs A, uint32_t *need) {
 // (KDE, inverse normal, 10^x) lives here; k_chain is integer/table work only.  Pass 0 visits every read and
 // also sizes the event buffer; later passes visit only the reads whose previous attempt was rejected.
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_lengths(GenArgs A) {
+// SMALL: the retry passes (a handful of reads).  175 VGPRs do not fit between the wavefronts of another call's record kernel (7 x 72 of a
+// SIMD's 512): next to it such a launch waited 2 ms for room (round 6, profiles/r06/step_timeline.log).  One wavefront per workgroup within
+// 72 registers (the rest spills: irrelevant for a few reads) goes wherever a record wavefront has left.
+template <bool SMALL>
+__global__ void __launch_bounds__(SMALL ? 64 : 256, SMALL ? 7 : 1) k_lengths(GenArgs A) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= A.list_n) return;
     const uint64_t r = A.list ? A.list[tid] : tid;
@@ -289,6 +294,8 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     return v;
 }
 
+#define NS_STATS_WAYS 64u    // copies of the chain counters (k_chain -> k_stats_fold); == the threads of k_stats_fold
+#define NS_STATS_BYTES ((8u + 8u * NS_STATS_WAYS) * sizeof(unsigned long long))
 #ifndef NS_CHAIN_BLOCK
 #define NS_CHAIN_BLOCK 256     // threads per block of the thread-per-read chain (320 was measured slower: 4.56 vs 4.09 ms)
 #endif
@@ -370,18 +377,31 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? 4 : NS_
                 const uint32_t sid = p.kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
                 sink.ev = A.events + ev_off + evn; sink.cap = ev_cap > evn ? ev_cap - evn : 0; sink.n = 0; sink.shift = 0;
                 sink.stg = nullptr;
+#ifdef NS_ABLATE
+                if (COOP && LDS_TABLES && (A.dbg & (1u << 21))) sink.cap = 0;                       // (profiling: no event stores)
+#endif
                 if constexpr (LDS_TABLES && !COOP) {      // single-piece reads: events leave in groups of four (32-byte stores), staged in LDS
                     if (A.ev_stage && n_pieces == 1) sink.stg = reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(lds_tbl) + A.ev_stage) + threadIdx.x;
                 }
                 EList32 e;
+#ifdef NS_ABLATE
+                if (COOP && LDS_TABLES && (A.dbg & (1u << 20))) { e.l_new = e.middle_ref = m32; } else   // (profiling: no error list)
+#endif
                 if (kind == NS_KIND_PERFECT) { e.l_new = e.middle_ref = m32; }
-                else if (p.kind) e = COOP ? coop_unaligned_error_list(TM, ct, m32, key, sid, a, sink, lane) : chain_unaligned_error_list(T, ct, m32, key, sid, a, sink);
+                else if (p.kind) {
+                    if constexpr (COOP && LDS_TABLES) e = A.coop_k1 ? coop_unaligned_error_list(TM, ct, m32, key, sid, a, sink, lane)
+                                                                           : coopk_unaligned_error_list<4>(TM, ct, m32, key, sid, a, sink, lane);
+                    else e = COOP ? coop_unaligned_error_list(TM, ct, m32, key, sid, a, sink, lane) : chain_unaligned_error_list(T, ct, m32, key, sid, a, sink);
+                }
                 else if constexpr (COOP && LDS_TABLES) { e.l_new = e.middle_ref = m32; sink.range = true; }   // (not launched for aligned segments: their tables are not in this image)
                 else if constexpr (COOP) e = coop_error_list(TM, T, ct, m32, key, sid, a, sink, *coop, lane);
                 else if constexpr (LDS_TABLES) e = chain_error_list(T, Tabs{A.m.chain_blob}, ct, m32, key, sid, a, sink);
                 else if (ct.int_image) e = chain_error_list(T, T, ct, m32, key, sid, a, sink);      // the integer image, from global memory (it does not fit LDS)
                 else e = chain_error_list_g(T, ct, m32, key, sid, a, sink);
                 ev_flush_tail(sink);
+#ifdef NS_ABLATE
+                if (COOP && LDS_TABLES && (A.dbg & (1u << 21))) { sink.overflow = false; sink.n = 0; }
+#endif
                 p.ev_off = ev_off + evn;
                 p.ref_len = (uint32_t)(e.middle_ref < 0 ? 0 : e.middle_ref);
                 p.out_len = (uint32_t)((e.middle_ref < 0 ? 0 : e.middle_ref) + sink.shift);
@@ -522,10 +542,32 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? 4 : NS_
     // one atomic per wavefront and counter
     st_over = wave_sum(st_over); st_bases = wave_sum(st_bases); st_ref = wave_sum(st_ref); st_ev = wave_sum(st_ev);
     if (A.prm.kind == NS_KIND_UNALIGNED) for (int off = 32; off > 0; off >>= 1) st_max = max(st_max, (uint32_t)__shfl_xor((int)st_max, off));
+    // ... into one of NS_STATS_WAYS copies of the counters (k_stats_fold adds them up behind the chain kernels).  On ONE set of counters the
+    // 200 000 atomics of a wave-per-read launch over 50 000 unaligned reads were executed one after the other at the memory side, ~12 ns
+    // each: they, not the error lists, were the 2.6 ms of that kernel (round 6: the kernel without its lists took 2.44 ms)
     if ((threadIdx.x & 63) == 0) {
-        if (st_over) atomicAdd(&A.stats[0], st_over);
-        atomicAdd(&A.stats[1], st_bases); atomicAdd(&A.stats[2], st_ref); atomicAdd(&A.stats[3], st_ev);
-        if (A.prm.kind == NS_KIND_UNALIGNED && st_max) atomicMax(&A.stats[4], (unsigned long long)st_max);
+        unsigned long long *S = A.stats + 8u + 8u * (blockIdx.x & (NS_STATS_WAYS - 1u));
+        if (st_over) atomicAdd(&S[0], st_over);
+        if (st_bases) atomicAdd(&S[1], st_bases);
+        if (st_ref) atomicAdd(&S[2], st_ref);
+        if (st_ev) atomicAdd(&S[3], st_ev);
+        if (A.prm.kind == NS_KIND_UNALIGNED && st_max) atomicMax(&S[4], (unsigned long long)st_max);
+    }
+}
+
+// the NS_STATS_WAYS copies of the chain counters -> stats[0..4]; the copies are left zeroed for the next launch
+__global__ void __launch_bounds__(64) k_stats_fold(unsigned long long *stats) {
+    unsigned long long *S = stats + 8u + 8u * threadIdx.x;
+    unsigned long long v[5];
+    #pragma unroll
+    for (int k = 0; k < 5; ++k) { v[k] = S[k]; S[k] = 0; }
+    #pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = wave_sum(v[k]);
+    for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(v[4], off); v[4] = o > v[4] ? o : v[4]; }
+    if (threadIdx.x == 0) {
+        #pragma unroll
+        for (int k = 0; k < 4; ++k) if (v[k]) atomicAdd(&stats[k], v[k]);
+        if (v[4]) atomicMax(&stats[4], v[4]);
     }
 }
 
@@ -1953,7 +1995,20 @@ int ns_set_background(ns_ctx *ctx, int on) {
     return NS_OK;
 }
 
-int ns_create(int device, ns_ctx **out) {
+// prio: 0 = the default stream priority, 1 / -1 = the highest / lowest the device offers (NS_STEP_PRIO, for the step companion's streams:
+// an A/B knob).  Streams of another priority come from another pool of hardware queues — the runtime shares GPU_MAX_HW_QUEUES = 4 among the
+// streams of ONE priority, so with the companion's streams on top of the owner's the two chain kernels of its call share a queue and run one
+// after the other.  Measured (profiles/r06/ab_step_companion.log): high priority ends the unaligned call a millisecond earlier and the
+// aligned one as much later, low priority starves it, eight queues at the default priority change nothing: the default stays.
+static int create_stream(hipStream_t *s, int prio) {
+    int least = 0, greatest = 0;
+    if (prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least &&
+        hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio > 0 ? greatest : least) == hipSuccess) return 0;
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess ? 0 : -1;
+}
+static int create_ctx(int device, ns_ctx **out, int prio);
+int ns_create(int device, ns_ctx **out) { return create_ctx(device, out, 0); }
+static int create_ctx(int device, ns_ctx **out, int prio) {
     if (!out) return NS_EINVAL;
     *out = nullptr;
     int n = 0;
@@ -1962,7 +2017,7 @@ int ns_create(int device, ns_ctx **out) {
     ns_ctx *ctx = new ns_ctx();
     ctx->device = device;
     // (ns_destroy releases whatever exists of a half-built context: null handles are skipped)
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess || create_stream(&ctx->stream, prio)) {
         ctx->stream = nullptr;
         ns_destroy(ctx);
         return NS_EHIP;
@@ -1972,7 +2027,7 @@ int ns_create(int device, ns_ctx **out) {
     for (auto &e : ctx->evt)
         if (ok && hipEventCreate(&e) != hipSuccess) { e = nullptr; ok = false; }
     ctx->evt_ok = true;              // (the events that exist are destroyed with the context)
-    if (!ok || hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+    if (!ok || create_stream(&ctx->stream2, prio) ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { ns_destroy(ctx); return NS_EHIP; }
     if (hipHostMalloc((void **)&ctx->pin_small, 1024, hipHostMallocDefault) != hipSuccess) { ctx->pin_small = nullptr; ns_destroy(ctx); return NS_ENOMEM; }
@@ -2662,7 +2717,7 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
     const dim3 blk(256);
     int rc;
     float ms = 0;
-    HIPCHK(hipMemsetAsync(ctx->stats.p, 0, 8 * sizeof(unsigned long long), st));
+    HIPCHK(hipMemsetAsync(ctx->stats.p, 0, NS_STATS_BYTES, st));
     HIPCHK(hipEventRecord(ctx->evt[1], st));
     k_nseg<<<dim3((unsigned)((n + 1 + 255) / 256)), blk, 0, st>>>(A);       // num_segment (S:825-828); zeroes the scan sentinels
     HIPCHK(hipGetLastError());
@@ -2811,7 +2866,7 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
         const dim3 grid_p((unsigned)((np + 255) / 256));
         uint64_t pass_cap = 0;
         for (int retry = 0;; ++retry) {
-        k_lengths<<<grid_p, blk, 0, st>>>(P);                                      // gaps, head/tail, planned pieces (S:872, 898-903)
+        k_lengths<false><<<grid_p, blk, 0, st>>>(P);                                      // gaps, head/tail, planned pieces (S:872, 898-903)
         HIPCHK(hipGetLastError());
         if ((rc = scan_u64(ctx, P.ev_cap, P.ev_off, np + 1))) return rc;
         if ((rc = read_small(ctx, st, &pass_cap, P.ev_off + np, 8))) return rc;     // also: the host vectors above are free to change again
@@ -2841,6 +2896,7 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
         HIPCHK(hipGetLastError());
         if (n_coop) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
         HIPCHK(hipEventRecord(ctx->evt[4], st));
+        k_stats_fold<<<dim3(1), dim3(64), 0, st>>>((unsigned long long *)ctx->stats.p);
         if ((rc = read_small(ctx, st, stats, ctx->stats.p, 8 * sizeof(unsigned long long)))) return rc;
         HIPCHK(hipEventElapsedTime(&ms, ctx->evt[3], ctx->evt[4])); ms_chain += ms;
         if (!(stats[0] & NS_OVER_MASK)) break;
@@ -2979,13 +3035,13 @@ static int trx_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, Ge
         const dim3 grid_p((unsigned)((np + 255) / 256));
         uint64_t cap = 0;
         for (int retry = 0;; ++retry) {
-            HIPCHK(hipMemsetAsync(ctx->stats.p, 0, 8 * sizeof(unsigned long long), st));
+            HIPCHK(hipMemsetAsync(ctx->stats.p, 0, NS_STATS_BYTES, st));
             HIPCHK(hipMemsetAsync(P.accept, 0, (np + 1) * 8, st));
             HIPCHK(hipMemsetAsync(P.polya, 0, (np + 1) * 2, st));
             if (P.ir_need) HIPCHK(hipMemsetAsync(P.ir_need, 0, (np + 1) * 8, st));
             HIPCHK(hipMemsetAsync(P.ev_cap + np, 0, 8, st));
             P.list = nullptr;
-            k_lengths<<<grid_p, blk, 0, st>>>(P);
+            k_lengths<false><<<grid_p, blk, 0, st>>>(P);
             HIPCHK(hipGetLastError());
             if ((rc = scan_u64(ctx, P.ev_cap, P.ev_off, np + 1))) return rc;
             {   // candidates by descending length: the 64 chains of a wavefront then have similar trip counts
@@ -3008,6 +3064,7 @@ static int trx_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, Ge
             else k_chain<false, false><<<grid_c, blk_c, 0, st>>>(P);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(ctx->evt[4], st));
+            k_stats_fold<<<dim3(1), dim3(64), 0, st>>>((unsigned long long *)ctx->stats.p);
             if ((rc = read_small(ctx, st, stats, ctx->stats.p, 8 * sizeof(unsigned long long)))) return rc;
             HIPCHK(hipEventElapsedTime(&ms, ctx->evt[3], ctx->evt[4])); ms_chain += ms;
             if (!(stats[0] & NS_OVER_MASK)) break;
@@ -3086,7 +3143,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         (rc = ensure(ctx, ctx->rec_len, (n + 1) * 8)) || (rc = ensure(ctx, ctx->rec_off, (n + 1) * 8)) ||
         (rc = ensure(ctx, ctx->err_len, (n + 1) * 8)) || (rc = ensure(ctx, ctx->err_off, (n + 1) * 8)) ||
         (rc = ensure(ctx, ctx->name_len, (n + 1) * 2)) || (rc = ensure(ctx, ctx->reads, n * sizeof(ns_read))) ||
-        (rc = ensure(ctx, ctx->stats, 8 * sizeof(unsigned long long))) ||
+        (rc = ensure(ctx, ctx->stats, NS_STATS_BYTES)) ||
         (rc = ensure(ctx, ctx->sort_key, (n + 1) * 4)) || (rc = ensure(ctx, ctx->sort_idx, (n + 1) * 4)) ||
         (rc = ensure(ctx, ctx->sort_key_out, (n + 1) * 4)) || (rc = ensure(ctx, ctx->order, (n + 1) * 4)) ||
         (rc = ensure(ctx, ctx->list_b, (n + 1) * 4)) || (rc = ensure(ctx, ctx->list_c, (n + 1) * 4)) || (rc = ensure(ctx, ctx->rstate, (n + 1) * 4)) ||
@@ -3165,7 +3222,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     for (int hp_round = 0; !meta_al && !trx_tab; ++hp_round) {
     for (int retry = 0;; ++retry) {
         A.cap_rate = cap_rate;
-        HIPCHK(hipMemsetAsync(ctx->stats.p, 0, 8 * sizeof(unsigned long long), st));
+        HIPCHK(hipMemsetAsync(ctx->stats.p, 0, NS_STATS_BYTES, st));
         // ---- plan: pieces, lengths of attempt 0, event capacity, visiting order ----
         HIPCHK(hipEventRecord(ctx->evt[1], st));
         k_nseg<<<grid_t, blk, 0, st>>>(A);
@@ -3181,7 +3238,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         if ((rc = ensure(ctx, ctx->pieces, (size_t)tot_pieces * sizeof(ns_piece) + 64))) return rc;
         A.pieces = (ns_piece *)ctx->pieces.p;
         A.list = nullptr; A.list_n = (uint32_t)n; A.attempt = 0;
-        k_lengths<<<grid_t, blk, 0, st>>>(A);
+        k_lengths<false><<<grid_t, blk, 0, st>>>(A);
         HIPCHK(hipGetLastError());
         if ((rc = scan_u64(ctx, A.ev_cap, A.ev_off, n + 1))) return rc;
         {   // visit reads by descending length: the 64 chains of a wavefront then have similar trip counts
@@ -3223,7 +3280,8 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
                         tot_pieces += extra;
                     }
                 }
-                k_lengths<<<grid_p, blk, 0, st>>>(A);
+                if (cur_n <= 4096u) k_lengths<true><<<dim3((cur_n + 63) / 64), dim3(64), 0, st>>>(A);
+                else k_lengths<false><<<grid_p, blk, 0, st>>>(A);
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipMemsetAsync(A.l_cap + cur_n, 0, 8, st));
                 if ((rc = scan_u64(ctx, A.l_cap, (uint64_t *)ctx->l_off.p, (size_t)cur_n + 1))) return rc;
@@ -3246,6 +3304,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
             else if (a == 0 && ctx->coop_ok && prm->kind == NS_KIND_ALIGNED && cur_n >= ctx->coop_min) n_coop = cur_n >> ctx->coop_shift;   // longest 0.1 %
             if (n_coop) {      // wave-per-read for the head of the (length-sorted) list, thread-per-read for the rest
                 GenArgs B = A; B.list_n = n_coop;
+                { const char *d = getenv("NS_UCOOP_K"); B.coop_k1 = d && atoi(d) == 1 ? 1u : 0u; }
                 HIPCHK(hipEventRecord(ctx->ev_fork, st));
                 HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
                 // unaligned reads: the run-length tables in LDS (k_chain<true, true>; the image must fit next to nothing else: 64 KB)
@@ -3266,6 +3325,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
             if (n_coop) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
             HIPCHK(hipEventRecord(ctx->evt[4], st));
             if (ctx->gate_signal) ctx->gate_signal->store(1, std::memory_order_release);
+            k_stats_fold<<<dim3(1), dim3(64), 0, st>>>((unsigned long long *)ctx->stats.p);
             if ((rc = read_small(ctx, st, stats, ctx->stats.p, sizeof stats))) return rc;
             HIPCHK(hipEventElapsedTime(&ms, ctx->evt[3], ctx->evt[4]));
             ms_chain += ms;
@@ -3401,7 +3461,8 @@ int ns_step_context(ns_ctx *ctx, ns_ctx **out) {
     if (ctx->borrowed) return fail(ctx, NS_EINVAL, "a step companion has no companion of its own");
     if (!ctx->companion) {
         ns_ctx *c = nullptr;
-        const int rc = ns_create(ctx->device, &c);
+        const char *pe = getenv("NS_STEP_PRIO");
+        const int rc = create_ctx(ctx->device, &c, pe ? atoi(pe) : 0);
         if (rc) return fail(ctx, rc, "ns_generate_step: the companion context could not be created");
         c->borrowed = true; c->owner = ctx;
         ns_set_background(c, 1);

@@ -516,6 +516,139 @@ __device__ inline EList32 coop_unaligned_error_list(const Tabs &T, const ChainTa
     return EList32{l_new, middle_ref};
 }
 
+// ---- the same with K consecutive iterations per lane (a round = 64 * K iterations) -------------------------------------------------
+// One iteration per lane leaves a wavefront with ~460 instructions in one long dependent chain per block (Philox, the table walk, three
+// prefix sums, two cross-lane reads: 3 us per block alone, 7 us next to others — 13 % of the issue slots used, 50 000 reads in 2.6 ms:
+// round 6, profiles/r06/ucoop_pmc.log).  With K iterations per lane the K Philox blocks and table walks are independent instruction
+// streams, the prefix sums run once per round over the lanes' totals, and the state that crosses lanes is a fold of four numbers
+// per lane: {positions advanced, insertions drawn, whether it has a non-insertion iteration, the insertions behind its last one}.
+// Same events, same order, same sink state as coop_unaligned_error_list.
+template <int K>
+__device__ inline EList32 coopk_unaligned_error_list(const Tabs &T, const ChainTab &c, int32_t m_ref, const ns_key &key, uint32_t seg,
+                                                     uint32_t attempt, EvSink32 &s, uint32_t lane) {
+    int32_t l_new = m_ref, middle_ref = m_ref;
+    if (m_ref <= 0) return EList32{l_new, middle_ref};
+    uint32_t pos0 = 0, pend0 = 0;                                // position / pending insertion length in front of the round
+    auto draw = [&](uint32_t it, int &type, uint32_t &step) {    // what iteration `it` does (S:1787, 1799-1818)
+        const u32x4 w = ns_draw(key, ST_UEVENT, seg, attempt, it, 0);
+        const uint64_t ut = w.x;
+        type = (ut < ns_thr_lt(0.4)) ? 3 : (ut < ns_thr_lt(0.7)) ? NS_MIS : (ut < ns_thr_lt(0.85)) ? NS_INS : NS_DEL;
+        step = 1;
+        if (type != 3) step = (uint32_t)run_length_t(T, c, type, w.y, w.z);
+    };
+    int type_n[K]; uint32_t step_n[K];
+    #pragma unroll
+    for (int k = 0; k < K; ++k) draw(lane * K + k, type_n[k], step_n[k]);
+    bool bad = false;
+    for (uint32_t it0 = 0;; it0 += 64u * K) {
+        int type[K]; uint32_t step[K];
+        #pragma unroll
+        for (int k = 0; k < K; ++k) { type[k] = type_n[k]; step[k] = step_n[k]; }
+        #pragma unroll
+        for (int k = 0; k < K; ++k) draw(it0 + 64u * K + lane * K + k, type_n[k], step_n[k]);     // the next round's draws run under this round's sums
+        // positions: lane-local prefix + one prefix sum over the lanes' totals
+        uint32_t a_loc[K], a_lane = 0;
+        #pragma unroll
+        for (int k = 0; k < K; ++k) { a_loc[k] = a_lane; a_lane += type[k] == NS_INS ? 0u : step[k]; }
+        const uint32_t a_incl = wave_incl_scan(a_lane);
+        const uint32_t pos_l = pos0 + a_incl - a_lane;
+        // the iterations that still run (a prefix of the round), their insertions / deletions; within the lane: the insertions pending in
+        // front of every non-insertion iteration since the previous one of the LANE (L_loc), whether it is the lane's first (`first`)
+        bool exec[K], nonins[K], first[K];
+        uint32_t L_loc[K], i_loc[K], d_loc[K], run = 0, i_lane = 0, d_lane = 0, a_exec = 0, n_exec_l = 0;
+        bool seen = false;
+        #pragma unroll
+        for (int k = 0; k < K; ++k) {
+            exec[k] = pos_l + a_loc[k] < (uint32_t)m_ref;
+            if (!exec[k]) { step[k] = 0; type[k] = 3; }
+            nonins[k] = exec[k] && type[k] != NS_INS;
+            const uint32_t ins = (exec[k] && type[k] == NS_INS) ? step[k] : 0u, del = (exec[k] && type[k] == NS_DEL) ? step[k] : 0u;
+            i_loc[k] = i_lane; d_loc[k] = d_lane;
+            i_lane += ins; d_lane += del;
+            run += ins;
+            L_loc[k] = nonins[k] ? run : 0u;
+            first[k] = nonins[k] && !seen;
+            if (nonins[k]) { run = 0; seen = true; }
+            a_exec += (exec[k] && type[k] != NS_INS) ? step[k] : 0u;
+            n_exec_l += exec[k] ? 1u : 0u;
+        }
+        const uint32_t i_incl = wave_incl_scan(i_lane);
+        const uint64_t HAS = __ballot(seen);
+        const uint64_t below = HAS & ((1ull << lane) - 1ull);
+        const int jb = below ? 63 - __clzll((long long)below) : (int)lane;
+        const uint32_t tail_b = (uint32_t)__shfl((int)run, jb), incl_b = (uint32_t)__shfl((int)i_incl, jb);
+        const uint32_t pend_l = below ? tail_b + (i_incl - i_lane) - incl_b : pend0 + (i_incl - i_lane);       // pending in front of this lane
+        // the events of every iteration, at most three each
+        uint32_t ty[K][3], ln[K][3], ps[K][3], n_ev[K], n_loc[K], L[K], n_lane = 0;
+        #pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t pos = pos_l + a_loc[k], st = step[k];
+            L[k] = nonins[k] ? L_loc[k] + (first[k] ? pend_l : 0u) : 0u;
+            const uint32_t Lk = L[k];
+            ty[k][0] = ty[k][1] = ty[k][2] = 0; ln[k][0] = ln[k][1] = ln[k][2] = 0; ps[k][0] = pos; ps[k][1] = ps[k][2] = pos + 1;
+            uint32_t ne = 0;
+            if (nonins[k]) {
+                if (type[k] == 3) { if (Lk) { ty[k][0] = NS_INS; ln[k][0] = Lk; ps[k][0] = pos + 1; ne = 1; } }
+                else if (type[k] == NS_MIS) {
+                    if (!Lk) { ty[k][0] = NS_MIS; ln[k][0] = st; ne = 1; }
+                    else {
+                        ty[k][0] = NS_MIS; ln[k][0] = 1; ty[k][1] = NS_INS; ln[k][1] = Lk; ne = 2;
+                        if (st - 1 > Lk) { ty[k][2] = NS_MIS; ln[k][2] = st - 1 - Lk; ne = 3; }
+                    }
+                } else {
+                    if (!Lk) { ty[k][0] = NS_DEL; ln[k][0] = st; ne = 1; }
+                    else {
+                        ty[k][0] = NS_DEL; ln[k][0] = st > Lk ? st - Lk : 1u; ne = 1;
+                        if (Lk > st - 1) { ty[k][1] = NS_INS; ln[k][1] = Lk - (st - 1); ne = 2; }
+                    }
+                }
+            }
+            bad |= ln[k][0] > NS_EV_LEN_MAX || ln[k][1] > NS_EV_LEN_MAX || ln[k][2] > NS_EV_LEN_MAX;      // (a merged insertion of > 4095 bases)
+            ln[k][0] = min(ln[k][0], NS_EV_LEN_MAX); ln[k][1] = min(ln[k][1], NS_EV_LEN_MAX); ln[k][2] = min(ln[k][2], NS_EV_LEN_MAX);
+            n_ev[k] = ne; n_loc[k] = n_lane; n_lane += ne;
+        }
+        // deleted bases; event counts (<= 3 K per lane) and the iterations that ran (<= K) in one prefix sum
+        const uint32_t d_incl = wave_incl_scan(d_lane);
+        const uint32_t ne_incl = wave_incl_scan(n_lane | n_exec_l << 16);
+        const uint32_t d_front = d_incl - d_lane, n_front = (ne_incl & 0xffffu) - n_lane;
+        auto dsh = [](uint32_t t, uint32_t l) { return t == NS_INS ? l : t == NS_DEL ? 0u - l : 0u; };
+        #pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (!n_ev[k]) continue;
+            // the shift in front of the iteration's events: the insertions filed so far - the deletions so far
+            const uint32_t sh = (uint32_t)s.shift + (pend0 + (i_incl - i_lane) + i_loc[k] - L[k]) - (d_front + d_loc[k]);
+            const uint32_t d0 = dsh(ty[k][0], ln[k][0]), d1 = n_ev[k] > 1 ? dsh(ty[k][1], ln[k][1]) : 0u;
+            if (!ev_shift_fits((int32_t)sh) || (n_ev[k] > 1 && !ev_shift_fits((int32_t)(sh + d0))) || (n_ev[k] > 2 && !ev_shift_fits((int32_t)(sh + d0 + d1)))) bad = true;
+            const uint32_t slot = s.n + n_front + n_loc[k];
+            if (slot < s.cap) { ns_event e; e.pos = ps[k][0]; e.info = ns_ev_pack(ln[k][0], ty[k][0], (int32_t)sh); s.ev[slot] = e; }
+            if (n_ev[k] > 1 && slot + 1 < s.cap) { ns_event e; e.pos = ps[k][1]; e.info = ns_ev_pack(ln[k][1], ty[k][1], (int32_t)(sh + d0)); s.ev[slot + 1] = e; }
+            if (n_ev[k] > 2 && slot + 2 < s.cap) { ns_event e; e.pos = ps[k][2]; e.info = ns_ev_pack(ln[k][2], ty[k][2], (int32_t)(sh + d0 + d1)); s.ev[slot + 2] = e; }
+        }
+        // ---- the state behind the round
+        const uint32_t ne_tot = (uint32_t)__builtin_amdgcn_readlane((int)ne_incl, 63);
+        const uint32_t n_blk = ne_tot & 0xffffu, n_ran = ne_tot >> 16;
+        const uint32_t del_tot = (uint32_t)__builtin_amdgcn_readlane((int)d_incl, 63), ins_tot = (uint32_t)__builtin_amdgcn_readlane((int)i_incl, 63);
+        // positions advanced by the iterations that ran: all of the round's, except in the round where the loop ends
+        uint32_t adv_tot = (uint32_t)__builtin_amdgcn_readlane((int)a_incl, 63);
+        if (n_ran < 64u * K) adv_tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(a_exec), 63);
+        if (s.n + n_blk > s.cap) s.overflow = true;
+        s.n += n_blk;
+        l_new += (int32_t)ins_tot - (int32_t)del_tot;                                                          // S:1808-1815, 1820
+        uint32_t pend1 = pend0 + ins_tot;                          // pending behind the last non-insertion iteration of the round
+        if (HAS) {
+            const int jl = 63 - __clzll((long long)HAS);
+            pend1 = (uint32_t)__shfl((int)run, jl) + ins_tot - (uint32_t)__shfl((int)i_incl, jl);
+        }
+        s.shift = (int32_t)((uint32_t)s.shift + (pend0 + ins_tot - pend1) - del_tot);
+        pend0 = pend1;
+        pos0 += adv_tot;
+        if (n_ran < 64u * K || pos0 >= (uint32_t)m_ref) break;
+    }
+    if (__ballot(bad)) s.range = true;
+    if ((int32_t)pos0 > middle_ref) { l_new += (int32_t)pos0 - middle_ref; middle_ref = (int32_t)pos0; }      // S:1826-1828
+    return EList32{l_new, middle_ref};
+}
+
 // ---- cooperative error_list: one read per wavefront, for the few longest reads of a batch ---------------------
 // The chain is sequential, but what an iteration draws depends on very little state: the error type on the Markov
 // state (7 rows), the run length on the error type (3), the next match length on the bin of the previous match

@@ -237,6 +237,28 @@ def test_background_context_gives_the_same_unaligned_reads(small_model, small_re
             e.close()
 
 
+@pytest.mark.parametrize("k, background", [(4, False), (4, True), (1, False)])
+def test_wave_per_read_unaligned_chain_equals_oracle(small_model, small_ref, circ_ref, monkeypatch, k, background):
+    """The wave-per-read unaligned chain with four loop iterations of S:1797-1829 per lane (256 per round; round 6) and with one (NS_UCOOP_K=1,
+    the form until then): reads of a few hundred bases end inside the first round (most lanes idle), 20-80 kb reads run hundreds of rounds;
+    on a background context the longest eighth only, the rest thread per read."""
+    monkeypatch.setenv("NS_COOP_MIN", "1")
+    monkeypatch.setenv("NS_UCOOP_K", str(k))
+    for ref in (small_ref, circ_ref):
+        e = E.Engine(0)
+        try:
+            if background:
+                e.set_background(True)
+            e.set_reference(ref)
+            e.load_model(small_model)
+            for kw in (dict(n_reads=700, fastq=True), dict(n_reads=200, median_len=20000, sd_len=0.5), dict(n_reads=400, min_len=500, max_len=4000),
+                       dict(n_reads=3, median_len=60000, sd_len=0.1), dict(n_reads=300, median_len=150, sd_len=0.8)):
+                p = E.make_params(seed=161803, first_read=5, kind=E.NS_KIND_UNALIGNED, **{**dict(max_len=ref.max_chrom), **kw})
+                compare(e.generate(p), O.generate(small_model, ref, p, bytes_per_read=400000, events_per_read=80000), p)
+        finally:
+            e.close()
+
+
 def test_large_tables_of_a_trained_model_shape(tmp_path, small_ref, monkeypatch):
     """A model shaped like a real trained one (15 previous-match bins, 1500-row ECDFs: ~360 KB of chain tables).  Round 6: the LDS image
     holds the HOT PREFIX of every match-length column (the segments a draw reaches with probability >= 1 - 2^-12: ~43 KB, 512-thread
