@@ -48,6 +48,8 @@
 // ---------------------------------------------------------------------------------------------------------
 struct GenArgs {
     uint32_t ev_stage;               // k_chain<LDS>: byte offset of the event staging area behind the tables in dynamic LDS (0: none)
+    uint32_t defer_tail;             // metagenome pass: k_chain stops in front of the positions (the species are not known yet: the host is still walking the
+                                     // quotas of assign_species, S:758-811, while the lists run) and marks the read pending; k_meta_tail goes on from there
     uint32_t coop_k1;                // wave-per-read unaligned chain with one iteration per lane (NS_UCOOP_K=1: the form until round 6)
     uint32_t coop_mix;               // k_chain<false, true>: the launch carries n_words_mix words of dynamic LDS for the front of the blob
     ns_params prm;
@@ -433,6 +435,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? 4 : NS_
                 if (kind != NS_KIND_UNALIGNED && ++fails >= NS_EPOCH_FAILS) { ++epoch; fails = 0; }
                 break;
             }
+            if (A.defer_tail) { if (lead) A.accept[r] = 2ull | (uint64_t)evn << 32; break; }      // pending: k_meta_tail
             // ---- positions (S:1388-1389, 1510, 1557) ----
             bool pos_ok = true;
             int64_t seq_len = (int64_t)rd.head + rd.tail;
@@ -568,6 +571,73 @@ __global__ void __launch_bounds__(64) k_stats_fold(unsigned long long *stats) {
         #pragma unroll
         for (int k = 0; k < 4; ++k) if (v[k]) atomicAdd(&stats[k], v[k]);
         if (v[4]) atomicMax(&stats[4], v[4]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_meta_tail: what k_chain does behind the error lists, for the reads of a metagenome pass it left pending (A.defer_tail): the start
+// positions in the species assign_species gave the segments (extract_read, S:1704-1749), the final length check (S:1023-1024), the name
+// and record sizes, the pass's acceptance flag.  Thread per pass position.  The pass launches its lists BEFORE the host has walked the
+// quotas (the lists do not depend on the species): the walk — sequential by definition, ~3 ms per 10^6 reads — then runs next to the
+// chain kernels instead of in front of them.  (The statements are those of k_chain's metagenome branch; change both.)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_meta_tail(GenArgs A) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const ns_params &prm = A.prm;
+    unsigned long long st_bases = 0, st_ref = 0, st_ev = 0;
+    const uint64_t pend = r < A.list_n ? A.accept[r] : 0ull;
+    if ((pend & 3ull) == 2ull) {
+        const uint32_t evn = (uint32_t)(pend >> 32), a = A.attempt;
+        const ns_key key = make_key(A, r);
+        ns_read rd = A.reads[r];
+        const uint32_t n_pieces = rd.n_pieces;
+        ns_piece *pc = A.pieces + rd.piece_off;
+        bool pos_ok = true;
+        int64_t seq_len = (int64_t)rd.head + rd.tail;
+        uint64_t ref_bases = 0;
+        for (uint32_t pi = 0; pi < n_pieces; ++pi) {
+            ns_piece p = pc[pi];
+            const uint32_t sid = p.kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
+            uint32_t chrom = 0; uint64_t pos = 0;
+            if (p.chrom == 1u && p.kind) { p.ref_len = 0; p.out_len = 0; p.n_ev = 0; }
+            else {                                           // species of the segment; gaps: any species
+                const int sp = !p.kind ? (int)A.m_species[A.m_segptr[r] + (pi >> 1)] : -1;
+                if (!extract_pos_meta(A.ref, A.species_chrom_off, A.nspecies, p.ref_len, sp, key, sid, a, chrom, pos)) { pos_ok = false; break; }
+            }
+            p.chrom = chrom; p.pos = (uint32_t)pos;
+            p.ref_gpos = A.ref.chrom_off[chrom] + pos;
+            pc[pi] = p;
+            seq_len += p.out_len;
+            ref_bases += p.ref_len;
+        }
+        uint64_t acc = 0;
+        if (pos_ok && (A.hp || (seq_len >= prm.min_len && seq_len <= prm.max_len))) {      // S:1023-1024; with -k the length is only final after k_hp_drain
+            rd.flags = 0; rd.seq_len = (uint32_t)seq_len; rd.attempts = a;
+            uint32_t nl = 0; bool first = true;                                              // name length (S:965-985)
+            for (uint32_t pi = 0; pi < n_pieces; ++pi) {
+                const ns_piece p = pc[pi];
+                if (p.kind && prm.kind == NS_KIND_ALIGNED) { nl += 5 + dec_digits(p.out_len); continue; }      // ";gap_<len>" (S:970-971)
+                if (!first) nl += 2;
+                first = false;
+                nl += (A.ref.name_off[p.chrom + 1] - A.ref.name_off[p.chrom] - 1) + 1 + dec_digits(p.pos) + dec_digits(p.ref_len);
+            }
+            nl += 9u;                                        // (the number of the read: k_meta_commit, once the accepted reads of the pass are counted)
+            if (prm.kind == NS_KIND_ALIGNED && n_pieces > 1) nl += 9;
+            nl += 2 /*_F*/ + 1 + dec_digits(rd.head) + 1 + 1 + dec_digits(rd.tail);
+            A.name_len[r] = (uint16_t)nl;
+            A.rec_len[r] = prm.emit_records ? (uint64_t)nl + 2 + (uint64_t)seq_len + 1 + (prm.fastq ? (uint64_t)seq_len + 3 : 0) : 0;
+            A.err_len[r] = 0;                                // (k_errlen / k_hp_filter_w)
+            A.sort_key[r] = evn;                             // (event count: taken back if -k rejects the read)
+            acc = 1ull | (uint64_t)n_pieces << 32;
+            st_bases = A.hp ? 0ull : (unsigned long long)seq_len; st_ref = ref_bases; st_ev = evn;
+        }
+        A.accept[r] = acc;
+        A.reads[r] = rd;
+    }
+    st_bases = wave_sum(st_bases); st_ref = wave_sum(st_ref); st_ev = wave_sum(st_ev);
+    if ((threadIdx.x & 63) == 0 && (st_bases | st_ref | st_ev)) {
+        unsigned long long *S = A.stats + 8u + 8u * (blockIdx.x & (NS_STATS_WAYS - 1u));
+        atomicAdd(&S[1], st_bases); atomicAdd(&S[2], st_ref); atomicAdd(&S[3], st_ev);
     }
 }
 
@@ -2817,7 +2887,8 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
         for (uint32_t v = 2; v <= NS_MAX_SEG; ++v) chim += (uint64_t)v * hist[v];  // S:761: the first `chim` lengths keep their order
         if (chim > V) chim = V;
         HIPCHK(hipMemcpyAsync(h_draw, d_sel, V * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipEventRecord(ctx->ev_fork, st));
+        hipEvent_t ev_draws = ctx->evt[11];                                        // (the filtered draws have reached the host)
+        HIPCHK(hipEventRecord(ev_draws, st));
         if (chim) HIPCHK(hipMemcpyAsync(d_sorted, d_sel, chim * 8, hipMemcpyDeviceToDevice, st));
         if (V > chim) {                                                            // S:764-765
             size_t tmp = 0;
@@ -2831,82 +2902,115 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
         uint2 *h_words = (uint2 *)ctx->pin_c.p;
         HIPCHK(hipMemcpyAsync(h_sorted, d_sorted, V * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(h_words, ctx->meta_words.p, V * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipEventSynchronize(ctx->ev_fork));
-        double to_add = 0;
-        for (uint64_t j = 0; j < V; ++j) to_add += h_draw[j];                      // S:767 (one dependent add per value: ~1 ms per 10^6)
-        lap("sum(length_list)", tt);
-        HIPCHK(hipStreamSynchronize(st));
-        lap("sort + words", tt);
-        uint16_t *h_species = (uint16_t *)h_draw;                                  // the draws are no longer needed: reuse the staging
-        uint64_t np64 = 0;
-        const uint64_t P_seg = assign_species_host(ctx, h_sorted, V, to_add, h_words, hist, cur_bases, h_species, &np64);   // S:866-867
-        lap("assign_species", tt);
         P.m_reversed = u32_to_p(ns_draw(bkey, ST_STRAND, 0, p, 0, 0).x) > ctx->m.strandness_rate ? 1u : 0u;   // S:860
-        // S:862-865: the reads that still get their lengths are the first np of the descending order; their first segment / first piece
-        // are closed forms of the histogram (k_meta_layout): no host loop over the reads, no upload of two 4 MB arrays
-        size_t np = (size_t)std::min<uint64_t>(np64, m);
-        if (!np) continue;
-        MetaHist H;
-        uint64_t left = np, sp = 0, po = 0;
-        H.cnt[0] = 0;
-        for (int v = (int)NS_MAX_SEG; v >= 1; --v) {
-            const uint64_t c = std::min<uint64_t>(hist[v], left);
-            H.cnt[v] = (uint32_t)c; left -= c; sp += c * (uint64_t)v; po += c * (2ull * (uint64_t)v - 1ull);
-        }
-        (void)P_seg;
-        k_meta_layout<<<dim3((unsigned)((np + 1 + 255) / 256)), blk, 0, st>>>(H, (uint32_t)np, (uint32_t *)ctx->m_segptr.p, (uint32_t *)ctx->piece_off.p);
-        HIPCHK(hipGetLastError());
-        k_meta_round<<<dim3((unsigned)((sp + 255) / 256)), blk, 0, st>>>(d_sorted, (int32_t *)ctx->m_len.p, sp);   // S:871: int(round(length))
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(ctx->m_species.p, h_species, sp * 2, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemsetAsync(P.accept, 0, (np + 1) * 8, st));
-        HIPCHK(hipMemsetAsync(P.ev_cap + np, 0, 8, st));
-        lap("arrays + upload", tt);
-        P.list_n = (uint32_t)np;
-        const dim3 grid_p((unsigned)((np + 255) / 256));
-        uint64_t pass_cap = 0;
+        // S:862-865: the reads that get their lengths are the first np of the descending segment-count order; their first segment / first
+        // piece are closed forms of the histogram (k_meta_layout).  The error lists of a read do not depend on its species, so the pass
+        // launches them NOW, for the reads the V lengths cover (np_spec: all that assign_species can reach, S:781-782), and the host walks the
+        // quotas (sum(length_list) + assign_species: ~3 ms per 10^6 reads, sequential by definition) while they run; k_meta_tail then takes
+        // the reads the walk did assign (np <= np_spec: fewer only when every quota is used up) through positions and acceptance.
+        uint64_t np_spec = 0;
+        { uint64_t ptr = 0; bool stop = false;
+          for (int v = (int)NS_MAX_SEG; v >= 1 && !stop; --v) {
+              const uint64_t fit = (V - ptr) / (uint64_t)v, c = std::min<uint64_t>(hist[v], fit);
+              np_spec += c; ptr += c * (uint64_t)v;
+              if (c < hist[v]) stop = true;
+          } }
+        np_spec = std::min<uint64_t>(np_spec, m);
+        auto layout = [&](uint64_t np_l, MetaHist &H, uint64_t &sp, uint64_t &po) {
+            uint64_t left = np_l; sp = 0; po = 0;
+            H.cnt[0] = 0;
+            for (int v = (int)NS_MAX_SEG; v >= 1; --v) {
+                const uint64_t c = std::min<uint64_t>(hist[v], left);
+                H.cnt[v] = (uint32_t)c; left -= c; sp += c * (uint64_t)v; po += c * (2ull * (uint64_t)v - 1ull);
+            }
+        };
+        uint64_t pass_cap = 0, np64 = 0, sp = 0, po = 0;
+        double to_add = 0;
+        size_t np = 0;
+        bool walked = false;
+        uint16_t *h_species = (uint16_t *)h_draw;                                  // (once the sum is taken the draws are no longer needed: reuse the staging)
         for (int retry = 0;; ++retry) {
-        k_lengths<false><<<grid_p, blk, 0, st>>>(P);                                      // gaps, head/tail, planned pieces (S:872, 898-903)
-        HIPCHK(hipGetLastError());
-        if ((rc = scan_u64(ctx, P.ev_cap, P.ev_off, np + 1))) return rc;
-        if ((rc = read_small(ctx, st, &pass_cap, P.ev_off + np, 8))) return rc;     // also: the host vectors above are free to change again
-        if ((rc = ensure_keep(ctx, ctx->events, (size_t)(ev_base + pass_cap) * sizeof(ns_event) + 64, (size_t)ev_base * sizeof(ns_event)))) return rc;
-        P.events = (ns_event *)ctx->events.p; P.ev_base = ev_base;
-        P.m_passed = (uint32_t)passed; P.m_pieces_passed = (uint32_t)pieces_passed;
-        HIPCHK(hipEventRecord(ctx->evt[3], st));
-        if (first_pass && retry == 0) { HIPCHK(hipEventRecord(ctx->evt[2], st)); first_pass = false; }
-        // the pass positions are (nearly) sorted by descending length: the head of the list goes to the cooperative chain
-        uint32_t n_coop = 0;
-        if (ctx->coop_ok && !perfect && np >= ctx->coop_min) n_coop = (uint32_t)(np >> ctx->coop_shift);
-        GenArgs Q = P;
-        if (n_coop) {
-            GenArgs B = P; B.list_n = n_coop; B.list_base = 0;
-            HIPCHK(hipEventRecord(ctx->ev_fork, st));
-            HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-            B.coop_mix = (size_t)B.m.ct.n_words_mix * 8 <= 32u * 1024u ? 1u : 0u;
-            k_chain<false, true><<<dim3(n_coop), dim3(64), B.coop_mix ? (size_t)B.m.ct.n_words_mix * 8 : 0, ctx->stream2>>>(B);
+            const size_t np_l = walked ? np : (size_t)np_spec;                     // the reads of this launch
+            if (!np_l) break;
+            MetaHist H;
+            uint64_t sp_l, po_l;
+            layout(np_l, H, sp_l, po_l);
+            k_meta_layout<<<dim3((unsigned)((np_l + 1 + 255) / 256)), blk, 0, st>>>(H, (uint32_t)np_l, (uint32_t *)ctx->m_segptr.p, (uint32_t *)ctx->piece_off.p);
             HIPCHK(hipGetLastError());
-            HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
-            Q.list_base = n_coop; Q.list_n = (uint32_t)np - n_coop;
+            k_meta_round<<<dim3((unsigned)((sp_l + 255) / 256)), blk, 0, st>>>(d_sorted, (int32_t *)ctx->m_len.p, sp_l);   // S:871: int(round(length))
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemsetAsync(P.accept, 0, (np_l + 1) * 8, st));
+            HIPCHK(hipMemsetAsync(P.ev_cap + np_l, 0, 8, st));
+            P.list_n = (uint32_t)np_l;
+            P.defer_tail = 1;
+            const dim3 grid_l((unsigned)((np_l + 255) / 256));
+            k_lengths<false><<<grid_l, blk, 0, st>>>(P);                           // gaps, head/tail, planned pieces (S:872, 898-903)
+            HIPCHK(hipGetLastError());
+            if ((rc = scan_u64(ctx, P.ev_cap, P.ev_off, np_l + 1))) return rc;
+            if (!walked) {               // S:767: sum(length_list), left to right as Python adds (~1 ms per 10^6 values) — while the device sorts and plans
+                HIPCHK(hipEventSynchronize(ev_draws));
+                for (uint64_t j = 0; j < V; ++j) to_add += h_draw[j];
+                lap("sum(length_list)", tt);
+            }
+            if ((rc = read_small(ctx, st, &pass_cap, P.ev_off + np_l, 8))) return rc;   // also: the sorted lengths and the words have reached the host
+            if ((rc = ensure_keep(ctx, ctx->events, (size_t)(ev_base + pass_cap) * sizeof(ns_event) + 64, (size_t)ev_base * sizeof(ns_event)))) return rc;
+            P.events = (ns_event *)ctx->events.p; P.ev_base = ev_base;
+            P.m_passed = (uint32_t)passed; P.m_pieces_passed = (uint32_t)pieces_passed;
+            HIPCHK(hipEventRecord(ctx->evt[3], st));
+            if (first_pass && retry == 0) { HIPCHK(hipEventRecord(ctx->evt[2], st)); first_pass = false; }
+            // the pass positions are (nearly) sorted by descending length: the head of the list goes to the cooperative chain
+            uint32_t n_coop = 0;
+            if (ctx->coop_ok && !perfect && np_l >= ctx->coop_min) n_coop = (uint32_t)(np_l >> ctx->coop_shift);
+            GenArgs Q = P;
+            if (n_coop) {
+                GenArgs B = P; B.list_n = n_coop; B.list_base = 0;
+                HIPCHK(hipEventRecord(ctx->ev_fork, st));
+                HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+                B.coop_mix = (size_t)B.m.ct.n_words_mix * 8 <= 32u * 1024u ? 1u : 0u;
+                k_chain<false, true><<<dim3(n_coop), dim3(64), B.coop_mix ? (size_t)B.m.ct.n_words_mix * 8 : 0, ctx->stream2>>>(B);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+                Q.list_base = n_coop; Q.list_n = (uint32_t)np_l - n_coop;
+            }
+            const uint32_t cb = lds ? ctx->chain_block : NS_CHAIN_BLOCK;
+            const dim3 grid_pc((unsigned)((Q.list_n + cb - 1) / cb)), blk_c(cb);
+            if (lds) k_chain<true, false><<<grid_pc, blk_c, ctx->lds_bytes + (Q.ev_stage ? cb * 32u : 0u), st>>>(Q);
+            else k_chain<false, false><<<grid_pc, blk_c, 0, st>>>(Q);
+            HIPCHK(hipGetLastError());
+            if (n_coop) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
+            HIPCHK(hipEventRecord(ctx->evt[4], st));
+            if (!walked) {               // ---- the host's walk over the quotas, next to the chain kernels
+                const uint64_t P_seg = assign_species_host(ctx, h_sorted, V, to_add, h_words, hist, cur_bases, h_species, &np64);   // S:866-867
+                (void)P_seg;
+                lap("assign_species", tt);
+                np = (size_t)std::min<uint64_t>(np64, m);
+                walked = true;
+                if (np > np_l) return fail(ctx, NS_ESTATE, "metagenome pass: assign_species reached more reads than the pass planned");
+            }
+            if (!np) {                   // every quota is used up: nothing of this launch counts
+                k_stats_fold<<<dim3(1), dim3(64), 0, st>>>((unsigned long long *)ctx->stats.p);
+                HIPCHK(hipMemcpyAsync(ctx->stats.p, good_stats, 8 * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+                break;
+            }
+            MetaHist Hn;
+            layout(np, Hn, sp, po);                          // (the first np reads of the launch: the layout of a prefix is a prefix of the layout)
+            HIPCHK(hipMemcpyAsync(ctx->m_species.p, h_species, sp * 2, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemsetAsync(P.accept + np, 0, 8, st)); // (a read beyond np that the launch left pending is not a read of this pass)
+            P.list_n = (uint32_t)np;
+            k_meta_tail<<<dim3((unsigned)((np + 255) / 256)), blk, 0, st>>>(P);
+            HIPCHK(hipGetLastError());
+            k_stats_fold<<<dim3(1), dim3(64), 0, st>>>((unsigned long long *)ctx->stats.p);
+            if ((rc = read_small(ctx, st, stats, ctx->stats.p, 8 * sizeof(unsigned long long)))) return rc;
+            HIPCHK(hipEventElapsedTime(&ms, ctx->evt[3], ctx->evt[4])); ms_chain += ms;
+            if (!(stats[0] & NS_OVER_MASK)) break;
+            // a read outgrew its event capacity (rare): the lists of the pass are repeated with twice the capacity
+            info->n_overflow += stats[0] & NS_OVER_MASK;
+            if (retry >= 6) return fail(ctx, NS_ENOMEM, "event capacity overflow persists after 6 retries");
+            P.cap_rate *= 2.0; P.cap_gap_mul *= 2;
+            HIPCHK(hipMemcpyAsync(ctx->stats.p, good_stats, 8 * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
         }
-        const uint32_t cb = lds ? ctx->chain_block : NS_CHAIN_BLOCK;
-        const dim3 grid_pc((unsigned)((Q.list_n + cb - 1) / cb)), blk_c(cb);
-        if (lds) k_chain<true, false><<<grid_pc, blk_c, ctx->lds_bytes + (Q.ev_stage ? cb * 32u : 0u), st>>>(Q);
-        else k_chain<false, false><<<grid_pc, blk_c, 0, st>>>(Q);
-        HIPCHK(hipGetLastError());
-        if (n_coop) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
-        HIPCHK(hipEventRecord(ctx->evt[4], st));
-        k_stats_fold<<<dim3(1), dim3(64), 0, st>>>((unsigned long long *)ctx->stats.p);
-        if ((rc = read_small(ctx, st, stats, ctx->stats.p, 8 * sizeof(unsigned long long)))) return rc;
-        HIPCHK(hipEventElapsedTime(&ms, ctx->evt[3], ctx->evt[4])); ms_chain += ms;
-        if (!(stats[0] & NS_OVER_MASK)) break;
-        // a read outgrew its event capacity (rare): the pass is repeated with twice the capacity
-        info->n_overflow += stats[0] & NS_OVER_MASK;
-        if (retry >= 6) return fail(ctx, NS_ENOMEM, "event capacity overflow persists after 6 retries");
-        P.cap_rate *= 2.0; P.cap_gap_mul *= 2;
-        HIPCHK(hipMemcpyAsync(ctx->stats.p, good_stats, 8 * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemsetAsync(P.accept, 0, (np + 1) * 8, st));
-        }
+        if (!np) continue;
+        const dim3 grid_p((unsigned)((np + 255) / 256));
         if (P.hp) {            // -k: the homopolymer stage decides the final length, and with it whether the pass accepts the read (S:1023-1024)
             GenArgs H = P;
             H.prm.n_reads = np;                      // bound of the thread-per-read kernels of the stage
