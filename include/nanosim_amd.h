@@ -224,10 +224,9 @@ void ns_destroy(ns_ctx *ctx);
 const char *ns_last_error(const ns_ctx *ctx);
 uint32_t ns_abi_version(void);
 /* A context whose worker calls run NEXT TO another context's on the same GPU (the reference runs its workers side by side, -t,
- * S:1588-1605; bench.py runs the unaligned worker call of a step like that): with on != 0 the engine prefers kernels that
- * take few issue slots over kernels with a short latency — only the longest eighth of a batch of unaligned reads goes through
- * the wave-per-read error list, the rest through the thread-per-read one (six times fewer instructions, several times the latency).
- * The reads are the same either way. */
+ * S:1588-1605; the unaligned worker call of a step runs like that).  A scheduling hint only — the reads are the same either way.
+ * Until ABI 6 / round 5 it sent all but the longest eighth of a batch of unaligned reads through the thread-per-read error list;
+ * since round 6 every unaligned read takes the wave-per-read one on either kind of context (NS_UCOOP_SHIFT=3 restores the split). */
 int ns_set_background(ns_ctx *ctx, int on);
 
 /* reference genome: replaces seq_dict/seq_len/genome_len (src/simulator.py:279-353).  `bases` is the
@@ -293,8 +292,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *params, ns_batch_info *info);
  * workers before it starts the unaligned ones (S:1621-1622); that order constrains the FILES only — the two calls write different files
  * and a read is a function of (seed, read index) — so the library runs them next to each other: the aligned call on `ctx`, the unaligned
  * one on the context's STEP COMPANION (own streams and batch buffers on the same device; it shares the reference, the model and the
- * mode tables of `ctx` — nothing is uploaded twice) from a worker thread the library keeps, its thread-per-read chain filling the SIMD
- * slots the aligned call's kernels leave (ns_set_background).  info[0] = the aligned batch, info[1] = the unaligned one; either params
+ * mode tables of `ctx` — nothing is uploaded twice) from a worker thread the library keeps.  info[0] = the aligned batch, info[1] = the unaligned one; either params
  * pointer may be NULL (that call is skipped and its info zeroed).  The bytes of both batches are those of two ns_generate calls.
  * The unaligned batch's buffers belong to the companion: ns_step_context returns it (created on first use, owned and destroyed by
  * `ctx`; never pass it to ns_destroy) for ns_copy_out / ns_device_ptr / ns_record_offsets / ns_sink_* / ns_io_counters.

@@ -2058,9 +2058,14 @@ extern "C" {
 
 uint32_t ns_abi_version(void) { return NS_ABI_VERSION; }
 
+// (Until round 6 a background context sent all but the longest eighth of its unaligned reads to the thread-per-read chain: the wave-per-read
+// one was 2.65 ms of serialized atomics then and slowed the other call's chain.  At 1.45 ms it ends the unaligned call of a step after 3.6
+// instead of 7.7 ms and leaves the record kernel alone — 0.53 instead of 0.48 of the roofline inside a step, the step itself 2 % longer:
+// profiles/r06/ab_step_companion.log, call 39.  NS_UCOOP_SHIFT=3 brings the split back.)
 int ns_set_background(ns_ctx *ctx, int on) {
     if (!ctx) return NS_EINVAL;
-    ctx->ucoop_shift = on ? 3u : 0u;
+    (void)on;
+    ctx->ucoop_shift = 0u;
     if (const char *d = getenv("NS_UCOOP_SHIFT")) ctx->ucoop_shift = (uint32_t)atoi(d) & 31u;
     return NS_OK;
 }

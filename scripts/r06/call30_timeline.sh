@@ -3,7 +3,7 @@
 export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06ag; mkdir -p $O; cd /tmp; export TMPDIR=/tmp; ulimit -c 0
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-export NS_UWIDE_SHIFT=${NS_UWIDE_SHIFT:-31}
+
 rm -rf /tmp/tl
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -o p -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-e2e --no-configs2 --no-extras > $O/bench.json 2>$O/err.log
 python3 - <<'P' | tee $O/timeline.log

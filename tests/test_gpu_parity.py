@@ -221,9 +221,10 @@ def test_cooperative_chain_equals_oracle(small_model, small_ref, monkeypatch):
 
 
 def test_background_context_gives_the_same_unaligned_reads(small_model, small_ref, circ_ref, monkeypatch):
-    """ns_set_background: all but the longest eighth of a batch of unaligned reads take the thread-per-read error list instead of
-    the wave-per-read one — same reads, byte for byte"""
+    """NS_UCOOP_SHIFT=3 (the split of a background context until round 6): all but the longest eighth of a batch of unaligned reads take
+    the thread-per-read error list instead of the wave-per-read one — same reads, byte for byte"""
     monkeypatch.setenv("NS_COOP_MIN", "1")
+    monkeypatch.setenv("NS_UCOOP_SHIFT", "3")
     for ref in (small_ref, circ_ref):
         e = E.Engine(0)
         try:
@@ -241,9 +242,11 @@ def test_background_context_gives_the_same_unaligned_reads(small_model, small_re
 def test_wave_per_read_unaligned_chain_equals_oracle(small_model, small_ref, circ_ref, monkeypatch, k, background):
     """The wave-per-read unaligned chain with four loop iterations of S:1797-1829 per lane (256 per round; round 6) and with one (NS_UCOOP_K=1,
     the form until then): reads of a few hundred bases end inside the first round (most lanes idle), 20-80 kb reads run hundreds of rounds;
-    on a background context the longest eighth only, the rest thread per read."""
+    with NS_UCOOP_SHIFT=3 the longest eighth only, the rest thread per read."""
     monkeypatch.setenv("NS_COOP_MIN", "1")
     monkeypatch.setenv("NS_UCOOP_K", str(k))
+    if background:
+        monkeypatch.setenv("NS_UCOOP_SHIFT", "3")
     for ref in (small_ref, circ_ref):
         e = E.Engine(0)
         try:
