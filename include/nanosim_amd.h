@@ -211,7 +211,9 @@ typedef struct ns_batch_info {
                                * read drew new lengths, as after a failed final length check (S:1429-1430) */
 } ns_batch_info;
 
-enum { NS_K_LENGTHS = 0, NS_K_EVENTS = 1, NS_K_SCAN = 2, NS_K_MATERIALISE = 3, NS_K_HP = 4, NS_K_ERRLOG = 5 };
+enum { NS_K_LENGTHS = 0, NS_K_EVENTS = 1, NS_K_SCAN = 2, NS_K_MATERIALISE = 3, NS_K_HP = 4, NS_K_ERRLOG = 5,
+       NS_K_RECORD_KERNEL = 6 };   /* 6: the record kernel alone (k_materialise; with -k: its last pass) — NS_K_MATERIALISE is the record STAGE:
+                                    * that kernel, the generic kernel for the tiles it queued, the quality lines, the join with k_names */
 enum { NS_BUF_RECORDS = 0, NS_BUF_READS = 1, NS_BUF_PIECES = 2, NS_BUF_EVENTS = 3, NS_BUF_ERRLOG = 4,
        NS_BUF_POLYA = 5 /* uint16 per read: polyA tail length of a transcriptome batch */,
        NS_BUF_SPLICED = 6 /* intron retention: the spliced stretches (transcript orientation, device form of the bases) */ };

@@ -1959,6 +1959,7 @@ struct ns_ctx {
     uint32_t hp_bm_k = 0;                // -k: the k the bitmap hp_bm was built for (0: none)
     ns_batch_info last{};
     hipEvent_t evt[16]{};
+    bool rec_timed = false;                      // evt[12] / evt[13] bracket the record kernel of this call
     bool evt_ok = false;
     // ns_generate_step: the companion context the unaligned worker call of a step runs on (it borrows this context's reference, model and
     // mode tables) and the worker thread that makes that call
@@ -2420,6 +2421,7 @@ static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fast
         if (ctx->dbg & 1024u) order = nullptr;          // (profiling: reads in index order)
         const dim3 grid_q((unsigned)((n + NS_MATQ_WAVES - 1) / NS_MATQ_WAVES)), blk_q(64 * NS_MATQ_WAVES), grid_1((unsigned)n), blk_1(64);
         const uint32_t *order_b = (ctx->dbg & 2048u) ? order : nullptr;      // (the record kernel: reads in index order)
+        if (round == 0) HIPCHK(hipEventRecord(ctx->evt[12], st));            // the record kernel itself (ns_batch_info.ms_kernel[NS_K_RECORD_KERNEL])
         if (mode == MAT_REF) {
             if (fastq) k_materialise<true, MAT_REF><<<grid_1, blk_1, 0, st>>>(A, wd, ctx->dbg, sq, order_b);
             else k_materialise<false, MAT_REF><<<grid_1, blk_1, 0, st>>>(A, wd, ctx->dbg, sq, order_b);
@@ -2431,6 +2433,7 @@ static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fast
             else k_materialise<false, MAT_HP_FINAL><<<grid_1, blk_1, 0, st>>>(A, wd, ctx->dbg, sq, nullptr);
         }
         HIPCHK(hipGetLastError());
+        if (round == 0) { HIPCHK(hipEventRecord(ctx->evt[13], st)); ctx->rec_timed = true; }
         // FASTQ: the quality lines, from the class words the record kernel left (before the generic kernel below: a tile queued for it
         // has no class words, and its qualities are that kernel's)
         if (fastq && mode != MAT_HP_SCRATCH && round == 0) {
@@ -3301,6 +3304,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     double cap_rate = ctx->cap_rate;
     const bool lds = ctx->lds_tables && prm->kind != NS_KIND_PERFECT;
     float ms = 0;
+    ctx->rec_timed = false;
     HIPCHK(hipEventRecord(ctx->evt[0], st));
     double ms_hp = 0;
     const bool trx_tab = prm->trx && prm->kind != NS_KIND_UNALIGNED;        // transcript + aligned length per block walk (trx_passes)
@@ -3526,6 +3530,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
     HIPCHK(hipEventElapsedTime(&ms, ctx->evt[5], ctx->evt[6])); info->ms_kernel[NS_K_SCAN] = ms;      // names/framing
     HIPCHK(hipEventElapsedTime(&ms, ctx->evt[6], ctx->evt[7])); info->ms_kernel[NS_K_MATERIALISE] = ms;
     HIPCHK(hipEventElapsedTime(&ms, ctx->evt[7], ctx->evt[8])); info->ms_kernel[NS_K_ERRLOG] = ms;
+    if (ctx->rec_timed) { HIPCHK(hipEventElapsedTime(&ms, ctx->evt[12], ctx->evt[13])); info->ms_kernel[NS_K_RECORD_KERNEL] = ms; }
     info->ms_kernel[NS_K_HP] = ms_hp;
     info->n_reads = n; info->n_pieces = tot_pieces; info->n_events = tot_cap;
     info->total_bases = stats[1]; info->total_ref_bases = stats[2]; info->events_used = stats[3];
