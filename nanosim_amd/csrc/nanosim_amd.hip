@@ -296,6 +296,13 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     return v;
 }
 
+// loop iterations per lane of the wave-per-read unaligned chain (coopk_unaligned_error_list): 4 = 116 VGPRs, 3 = 98, 2 = 82
+#ifndef NS_UCOOP_ITER
+#define NS_UCOOP_ITER 3
+#endif
+#ifndef NS_UCOOP_MINW
+#define NS_UCOOP_MINW 4      // wavefronts per SIMD that kernel is compiled for
+#endif
 #define NS_STATS_WAYS 64u    // copies of the chain counters (k_chain -> k_stats_fold); == the threads of k_stats_fold
 #define NS_STATS_BYTES ((8u + 8u * NS_STATS_WAYS) * sizeof(unsigned long long))
 #ifndef NS_CHAIN_BLOCK
@@ -314,7 +321,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #define NS_CHAIN_MINW 5
 #endif
 template <bool LDS_TABLES, bool COOP>
-__global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? 4 : NS_CHAIN_MINW) k_chain(GenArgs A) {
+__global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? (LDS_TABLES ? NS_UCOOP_MINW : 4) : NS_CHAIN_MINW) k_chain(GenArgs A) {
     extern __shared__ uint64_t lds_tbl[];
     CoopLds *coop = nullptr;
     if constexpr (COOP && !LDS_TABLES) { __shared__ CoopLds coop_lds; coop = &coop_lds; }
@@ -392,7 +399,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? 4 : NS_
                 if (kind == NS_KIND_PERFECT) { e.l_new = e.middle_ref = m32; }
                 else if (p.kind) {
                     if constexpr (COOP && LDS_TABLES) e = A.coop_k1 ? coop_unaligned_error_list(TM, ct, m32, key, sid, a, sink, lane)
-                                                                           : coopk_unaligned_error_list<4>(TM, ct, m32, key, sid, a, sink, lane);
+                                                                           : coopk_unaligned_error_list<NS_UCOOP_ITER>(TM, ct, m32, key, sid, a, sink, lane);
                     else e = COOP ? coop_unaligned_error_list(TM, ct, m32, key, sid, a, sink, lane) : chain_unaligned_error_list(T, ct, m32, key, sid, a, sink);
                 }
                 else if constexpr (COOP && LDS_TABLES) { e.l_new = e.middle_ref = m32; sink.range = true; }   // (not launched for aligned segments: their tables are not in this image)

@@ -238,9 +238,10 @@ def test_background_context_gives_the_same_unaligned_reads(small_model, small_re
             e.close()
 
 
-@pytest.mark.parametrize("k, background", [(4, False), (4, True), (1, False)])
+@pytest.mark.parametrize("k, background", [(0, False), (0, True), (1, False)])
 def test_wave_per_read_unaligned_chain_equals_oracle(small_model, small_ref, circ_ref, monkeypatch, k, background):
-    """The wave-per-read unaligned chain with four loop iterations of S:1797-1829 per lane (256 per round; round 6) and with one (NS_UCOOP_K=1,
+    """The wave-per-read unaligned chain with several loop iterations of S:1797-1829 per lane (NS_UCOOP_ITER of the build: 192 per round; round 6)
+    and with one (NS_UCOOP_K=1,
     the form until then): reads of a few hundred bases end inside the first round (most lanes idle), 20-80 kb reads run hundreds of rounds;
     with NS_UCOOP_SHIFT=3 the longest eighth only, the rest thread per read."""
     monkeypatch.setenv("NS_COOP_MIN", "1")
