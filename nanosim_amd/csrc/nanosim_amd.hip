@@ -5,6 +5,7 @@
 //   scans, radix sort   rocPRIM       piece / event offsets; visiting order by descending length
 //   k_chain             thread/read   error_list / unaligned_error_list, acceptance, positions   (S:1283-1402, 1833-1916, 1784-1830,
 //                       (+ wave/read for the longest reads, the unaligned reads and the gaps)      1694-1781); one pass per attempt
+//   k_stats_fold        1 wave        the chain kernels' counters: 64 copies -> one (one set of counters serialises their atomics)
 //   k_ir_splice         wave/read     transcriptome: retained introns spliced into the read's slot of an arena (S:1156-1192)
 //   -k: k_hp_filter_w, k_materialise<., MAT_HP_SCRATCH>, k_hp_scan, k_hp_drain, k_hp_finalize  (ns_hp.h; S:1920-1947, 618-705)
 //   scans               rocPRIM       record / error-profile offsets
@@ -12,7 +13,8 @@
 //   k_materialise       wave/read     case_convert + mutate_read + head/tail + revcomp (+ qualities)   (S:743-755, 1919-2015, 1421-1435)
 //   k_materialise_dense wave/segment  the same for unaligned reads and gaps (0.55 events per base)
 //   k_errlog            wave/read     _aligned_error_profile rows                           (S:2006-2008)
-// Metagenome worker calls run k_lengths / k_chain per PASS of the reference's while loop (S:844-1040) with k_meta_* around them.
+// Metagenome worker calls run k_lengths / k_chain per PASS of the reference's while loop (S:844-1040) with k_meta_* around them; the lists of a
+// pass are launched before the host has walked the species quotas (assign_species), k_meta_tail does positions + acceptance afterwards.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdio.h>

@@ -5,7 +5,8 @@
 //   chain_error_list_g          thread per read on the fp64 tables in global memory (models whose value edges are not whole numbers or
 //                               whose image does not fit LDS): the reference's arithmetic as it is
 //   chain_unaligned_error_list  thread per read, unaligned reads and gaps
-//   coop_error_list, coop_unaligned_error_list   one read per wavefront (the longest reads of a batch; lane = loop iteration)
+//   coop_error_list, coop_unaligned_error_list   one read per wavefront (the longest aligned reads of a batch, gaps; lane = loop iteration)
+//   coopk_unaligned_error_list  one unaligned read per wavefront, K loop iterations per lane (all unaligned reads)
 // All produce the events of the oracle's error_list / unaligned_error_list bit for bit (tests/test_chain_host.py compiles this source
 // for the host; the -m gpu parity tests compare whole batches).
 #pragma once
