@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the workgroup-per-read kernel and NS_UWIDE_SHIFT were removed again: commit a56cb35 has the log)
 # round 6, GPU call 25: the longest unaligned reads of a batch on a workgroup of 16 wavefronts each (NS_UWIDE_SHIFT; 31 = off = the build before):
 # parity, then the step with the share at several values
 cd "$(dirname "$0")/../.."

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs a build with NS_UCOOP_WPB: commit 89c8eb7 describes it; the macro is not in the tree any more)
 # round 6, GPU call 37: reads per workgroup of the wave-per-read unaligned chain (1 / 4 / 8 wavefronts sharing the LDS tables): parity, the call
 # alone, the kernel without its lists (floor), the step
 cd "$(dirname "$0")/../.."

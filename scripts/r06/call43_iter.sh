@@ -1,4 +1,6 @@
 #!/bin/bash
+# (variants first, here: scripts/ab_build.sh k4:"-DNS_UCOOP_ITER=4" k3:"-DNS_UCOOP_ITER=3" k2:"-DNS_UCOOP_ITER=2" — second run: k3 k3w5:"-DNS_UCOOP_ITER=3 -DNS_UCOOP_MINW=5"
+#  k4w5:"-DNS_UCOOP_ITER=4 -DNS_UCOOP_MINW=5" k2w6:"-DNS_UCOOP_ITER=2 -DNS_UCOOP_MINW=6")
 # round 6, GPU call 43: loop iterations per lane of the wave-per-read unaligned chain (4 / 3 / 2: 116 / 98 / 82 VGPRs) — alone and inside the step
 cd "$(dirname "$0")/../.."
 export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$PWD}
