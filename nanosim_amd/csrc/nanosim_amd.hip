@@ -568,7 +568,10 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? (LDS_TA
 }
 
 // the NS_STATS_WAYS copies of the chain counters -> stats[0..4]; the copies are left zeroed for the next launch
-__global__ void __launch_bounds__(64) k_stats_fold(unsigned long long *stats) {
+// zero_me: the counter of the record kernel's slow-tile queue (a 4-byte hipMemsetAsync in front of that kernel is a launch of its own that waits
+// for room next to the other call's kernels: 0.1 ms in the timeline of a step)
+__global__ void __launch_bounds__(64) k_stats_fold(unsigned long long *stats, uint32_t *zero_me) {
+    if (threadIdx.x == 0 && zero_me) *zero_me = 0;
     unsigned long long *S = stats + 8u + 8u * threadIdx.x;
     unsigned long long v[5];
     #pragma unroll
@@ -1968,6 +1971,7 @@ struct ns_ctx {
     uint32_t hp_bm_k = 0;                // -k: the k the bitmap hp_bm was built for (0: none)
     ns_batch_info last{};
     hipEvent_t evt[16]{};
+    bool sq_zeroed = false;                      // k_stats_fold has zeroed the slow-tile queue's counter and nothing has used the queue since
     bool rec_timed = false;                      // evt[12] / evt[13] bracket the record kernel of this call
     bool evt_ok = false;
     // ns_generate_step: the companion context the unaligned worker call of a step runs on (it borrows this context's reference, model and
@@ -2129,6 +2133,11 @@ static int create_ctx(int device, ns_ctx **out, int prio) {
 // Scalar read-backs of a call (totals of the scans, the counters): device -> page-locked slot -> destination, with the stream
 // synchronised in between.  (hipMemcpyAsync into pageable memory goes through a staging blit kernel; next to another context's
 // kernels on the same GPU that costs hundreds of microseconds per read-back.)
+static void fold_stats(ns_ctx *ctx, hipStream_t st) {
+    uint32_t *z = ctx->slow_q.cap >= 16 ? (uint32_t *)ctx->slow_q.p : nullptr;
+    k_stats_fold<<<dim3(1), dim3(64), 0, st>>>((unsigned long long *)ctx->stats.p, z);
+    ctx->sq_zeroed = z != nullptr;
+}
 static int read_small(ns_ctx *ctx, hipStream_t st, void *dst, const void *src, size_t n, void *dst2 = nullptr, const void *src2 = nullptr, size_t n2 = 0) {
     if (n > (dst2 ? 512u : 1024u) || n2 > 512) return fail(ctx, NS_EINVAL, "read_small: too large");
     HIPCHK(hipMemcpyAsync(ctx->pin_small, src, n, hipMemcpyDeviceToHost, st));
@@ -2425,7 +2434,8 @@ static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fast
         SlowQueue sq;
         sq.count = (uint32_t *)ctx->slow_q.p; sq.items = (SlowTile *)((uint8_t *)ctx->slow_q.p + 16);
         sq.cap = (uint32_t)(cap > 0xffffffffull ? 0xffffffffull : cap);
-        HIPCHK(hipMemsetAsync(sq.count, 0, 4, st));
+        if (!(ctx->sq_zeroed && round == 0 && sq.count == (uint32_t *)ctx->slow_q.p)) HIPCHK(hipMemsetAsync(sq.count, 0, 4, st));
+        ctx->sq_zeroed = false;
         const uint32_t *wd = nullptr;               // (MAT_HP_FINAL reads A.hp_wd; the other modes draw the letter words: event_word)
         if (ctx->dbg & 1024u) order = nullptr;          // (profiling: reads in index order)
         const dim3 grid_q((unsigned)((n + NS_MATQ_WAVES - 1) / NS_MATQ_WAVES)), blk_q(64 * NS_MATQ_WAVES), grid_1((unsigned)n), blk_1(64);
@@ -3005,7 +3015,7 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
                 if (np > np_l) return fail(ctx, NS_ESTATE, "metagenome pass: assign_species reached more reads than the pass planned");
             }
             if (!np) {                   // every quota is used up: nothing of this launch counts
-                k_stats_fold<<<dim3(1), dim3(64), 0, st>>>((unsigned long long *)ctx->stats.p);
+                fold_stats(ctx, st);
                 HIPCHK(hipMemcpyAsync(ctx->stats.p, good_stats, 8 * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
                 break;
             }
@@ -3016,7 +3026,7 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
             P.list_n = (uint32_t)np;
             k_meta_tail<<<dim3((unsigned)((np + 255) / 256)), blk, 0, st>>>(P);
             HIPCHK(hipGetLastError());
-            k_stats_fold<<<dim3(1), dim3(64), 0, st>>>((unsigned long long *)ctx->stats.p);
+            fold_stats(ctx, st);
             if ((rc = read_small(ctx, st, stats, ctx->stats.p, 8 * sizeof(unsigned long long)))) return rc;
             HIPCHK(hipEventElapsedTime(&ms, ctx->evt[3], ctx->evt[4])); ms_chain += ms;
             if (!(stats[0] & NS_OVER_MASK)) break;
@@ -3185,7 +3195,7 @@ static int trx_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, Ge
             else k_chain<false, false><<<grid_c, blk_c, 0, st>>>(P);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(ctx->evt[4], st));
-            k_stats_fold<<<dim3(1), dim3(64), 0, st>>>((unsigned long long *)ctx->stats.p);
+            fold_stats(ctx, st);
             if ((rc = read_small(ctx, st, stats, ctx->stats.p, 8 * sizeof(unsigned long long)))) return rc;
             HIPCHK(hipEventElapsedTime(&ms, ctx->evt[3], ctx->evt[4])); ms_chain += ms;
             if (!(stats[0] & NS_OVER_MASK)) break;
@@ -3384,7 +3394,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         for (uint32_t a = 0;; ++a) {
             A.list = cur; A.list_n = cur_n; A.attempt = a; A.next_list = nxt;
             A.l_off = nullptr; A.l_base = 0;
-            HIPCHK(hipMemsetAsync(A.next_n, 0, 4, st));
+            if (a > 0) HIPCHK(hipMemsetAsync(A.next_n, 0, 4, st));      // (pass 0: the counters were zeroed as a whole at the top of the retry loop)
             const dim3 grid_p((cur_n + 255) / 256);
             A.p_need = nullptr; A.p_off = nullptr; A.p_base = 0;
             if (a > 0) {          // new lengths for the reads still open; their events go to a fresh region behind the earlier passes
@@ -3447,7 +3457,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
             if (n_coop) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
             HIPCHK(hipEventRecord(ctx->evt[4], st));
             if (ctx->gate_signal) ctx->gate_signal->store(1, std::memory_order_release);
-            k_stats_fold<<<dim3(1), dim3(64), 0, st>>>((unsigned long long *)ctx->stats.p);
+            fold_stats(ctx, st);
             if ((rc = read_small(ctx, st, stats, ctx->stats.p, sizeof stats))) return rc;
             HIPCHK(hipEventElapsedTime(&ms, ctx->evt[3], ctx->evt[4]));
             ms_chain += ms;
