@@ -853,59 +853,91 @@ __global__ void __launch_bounds__(256) k_trx_commit(GenArgs A, uint64_t n_pos, u
 // ---------------------------------------------------------------------------------------------------------
 // k_names: record framing and read name, one thread per read
 // ---------------------------------------------------------------------------------------------------------
+// The header line of a read (">name\n") is composed by its thread in a row of LDS and leaves in contiguous stores — lane = byte, one read of
+// the wavefront after the other.  Written by the composing thread straight into the record image (until round 6) it was ~50 single-byte
+// stores per read, every store instruction of a wavefront touching 64 different cache lines of an image the record kernel is filling at the
+// same time on the other stream: the step was 0.2-0.3 ms longer with k_names than without it (profiles/r06/ab_names.log).  A header
+// longer than a row (chimeric reads with many segments) is written the old way.
+#define NS_NAME_ROW 128u
 __global__ void __launch_bounds__(256) k_names(GenArgs A) {
-    uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= A.prm.n_reads) return;
-    ns_read rd = A.reads[r];
-    rd.rec_off = A.rec_off[r];
-    A.reads[r].rec_off = rd.rec_off;
-    if (rd.flags || A.prm.emit_records != 1u) return;
-    const int kind = (int)A.prm.kind;
-    const ns_piece *pc = A.pieces + rd.piece_off;
-    uint8_t *p = A.records + rd.rec_off;
-    *p++ = A.prm.fastq ? '@' : '>';
-    bool first = true;
-    for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
-        if (pc[pi].kind && kind == NS_KIND_ALIGNED) {
-            if (A.meta) { const char *g = ";gap_"; while (*g) *p++ = (uint8_t)*g++; p = put_dec(p, pc[pi].out_len); }   // S:970-971
-            continue;
+    __shared__ uint8_t rows[256][NS_NAME_ROW];
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint64_t rec_off = 0;
+    uint32_t hdr = 0;                        // bytes of the header in this thread's row (0: nothing to copy)
+    if (r < A.prm.n_reads) {
+        ns_read rd = A.reads[r];
+        rd.rec_off = A.rec_off[r];
+        A.reads[r].rec_off = rd.rec_off;
+        rec_off = rd.rec_off;
+        if (!rd.flags && A.prm.emit_records == 1u) {
+            const int kind = (int)A.prm.kind;
+            const ns_piece *pc = A.pieces + rd.piece_off;
+            const uint32_t name_len = A.name_len[r];                   // without '>' and '\n' (k_chain / k_meta_commit)
+            const bool in_row = name_len + 2u <= NS_NAME_ROW;
+            uint8_t *const p0 = in_row ? rows[threadIdx.x] : A.records + rd.rec_off;
+            uint8_t *p = p0;
+            *p++ = A.prm.fastq ? '@' : '>';
+            bool first = true;
+            for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
+                if (pc[pi].kind && kind == NS_KIND_ALIGNED) {
+                    if (A.meta) { const char *g = ";gap_"; while (*g) *p++ = (uint8_t)*g++; p = put_dec(p, pc[pi].out_len); }   // S:970-971
+                    continue;
+                }
+                if (!first) *p++ = ';';
+                first = false;
+                const char *cn = A.ref.names + A.ref.name_off[pc[pi].chrom];
+                while (*cn) *p++ = (uint8_t)*cn++;
+                *p++ = '_';
+                p = put_dec(p, pc[pi].pos);
+            }
+            const char *tag = kind == NS_KIND_ALIGNED ? "_aligned_" : kind == NS_KIND_PERFECT ? "_perfect_" : "_unaligned_";
+            while (*tag) *p++ = (uint8_t)*tag++;
+            p = put_dec(p, A.name_first + r);
+            if (kind == NS_KIND_ALIGNED && rd.n_pieces > 1) { const char *c = "_chimeric"; while (*c) *p++ = (uint8_t)*c++; }
+            if (pc[0].ref_gpos >= NS_SPLICED_BASE) {                          // "_RetainedIntron_<start>-<end>;..." (S:1189-1192)
+                const uint32_t trx = pc[0].chrom;
+                const uint32_t trx_len = (uint32_t)(A.ref.chrom_off[trx + 1] - A.ref.chrom_off[trx]);
+                bool open = false;
+                ir_walk(A.ir, trx, pc[0].ref_len, trx_len, read_key(A, r), rd.attempts, [&](uint32_t, uint32_t, uint32_t start, uint32_t end, bool retained) {
+                    if (!retained) return;
+                    if (!open) { const char *c = "_RetainedIntron_"; while (*c) *p++ = (uint8_t)*c++; open = true; }
+                    p = put_dec(p, start); *p++ = '-'; p = put_dec(p, end); *p++ = ';';
+                });
+            }
+            *p++ = '_'; *p++ = rd.reversed ? 'R' : 'F';
+            *p++ = '_'; p = put_dec(p, rd.head);
+            *p++ = '_';
+            first = true;
+            for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
+                if (pc[pi].kind && kind == NS_KIND_ALIGNED) continue;
+                if (!first) *p++ = ';';
+                first = false;
+                p = put_dec(p, pc[pi].ref_len);
+            }
+            *p++ = '_'; p = put_dec(p, rd.tail + (A.polya ? A.polya[r] : 0u));
+            *p++ = '\n';
+            const uint32_t len = (uint32_t)(p - p0);
+            if (in_row) hdr = len;
+            // the framing behind the bases (and the qualities): single bytes far from the header
+            uint8_t *g = A.records + rd.rec_off + len + rd.seq_len;
+            *g++ = '\n';
+            if (A.prm.fastq) { *g++ = '+'; *g++ = '\n'; g += rd.seq_len; *g++ = '\n'; }
         }
-        if (!first) *p++ = ';';
-        first = false;
-        const char *cn = A.ref.names + A.ref.name_off[pc[pi].chrom];
-        while (*cn) *p++ = (uint8_t)*cn++;
-        *p++ = '_';
-        p = put_dec(p, pc[pi].pos);
     }
-    const char *tag = kind == NS_KIND_ALIGNED ? "_aligned_" : kind == NS_KIND_PERFECT ? "_perfect_" : "_unaligned_";
-    while (*tag) *p++ = (uint8_t)*tag++;
-    p = put_dec(p, A.name_first + r);
-    if (kind == NS_KIND_ALIGNED && rd.n_pieces > 1) { const char *c = "_chimeric"; while (*c) *p++ = (uint8_t)*c++; }
-    if (pc[0].ref_gpos >= NS_SPLICED_BASE) {                          // "_RetainedIntron_<start>-<end>;..." (S:1189-1192)
-        const uint32_t trx = pc[0].chrom;
-        const uint32_t trx_len = (uint32_t)(A.ref.chrom_off[trx + 1] - A.ref.chrom_off[trx]);
-        bool open = false;
-        ir_walk(A.ir, trx, pc[0].ref_len, trx_len, read_key(A, r), rd.attempts, [&](uint32_t, uint32_t, uint32_t start, uint32_t end, bool retained) {
-            if (!retained) return;
-            if (!open) { const char *c = "_RetainedIntron_"; while (*c) *p++ = (uint8_t)*c++; open = true; }
-            p = put_dec(p, start); *p++ = '-'; p = put_dec(p, end); *p++ = ';';
-        });
+    // copy-out: the 64 rows of this wavefront, one after the other, lane = byte
+    __syncthreads();                         // (the rows were written through generic pointers by other lanes: wait for them)
+    const uint32_t row0 = threadIdx.x & ~63u;
+    uint64_t todo = __ballot(hdr != 0);
+    while (todo) {
+        const int j = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint32_t n = (uint32_t)__shfl((int)hdr, j);
+        const uint64_t off = (uint64_t)(uint32_t)__shfl((int)(uint32_t)rec_off, j) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)(rec_off >> 32), j) << 32;
+        uint8_t *dst = A.records + off;
+        const uint8_t *src = rows[row0 + (uint32_t)j];
+        for (uint32_t b = lane; b < n; b += 64u) dst[b] = src[b];
     }
-    *p++ = '_'; *p++ = rd.reversed ? 'R' : 'F';
-    *p++ = '_'; p = put_dec(p, rd.head);
-    *p++ = '_';
-    first = true;
-    for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
-        if (pc[pi].kind && kind == NS_KIND_ALIGNED) continue;
-        if (!first) *p++ = ';';
-        first = false;
-        p = put_dec(p, pc[pi].ref_len);
-    }
-    *p++ = '_'; p = put_dec(p, rd.tail + (A.polya ? A.polya[r] : 0u));
-    *p++ = '\n';
-    p += rd.seq_len;
-    *p++ = '\n';
-    if (A.prm.fastq) { *p++ = '+'; *p++ = '\n'; p += rd.seq_len; *p++ = '\n'; }
 }
 
 // ---------------------------------------------------------------------------------------------------------
