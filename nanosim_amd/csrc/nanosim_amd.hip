@@ -587,6 +587,55 @@ __global__ void __launch_bounds__(64) k_stats_fold(unsigned long long *stats, ui
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The visiting order of a batch: reads by descending planned work, so that the 64 chains of a wavefront have similar trip counts and the
+// longest reads come first.  Nothing depends on the order beyond that (a read is a function of its index), so it need not be a sort: the
+// reads are dealt into 1 024 bins of their key on a logarithmic scale (32 bins per octave: keys of a bin differ by at most 3 %), bins in
+// descending order, reads inside a bin in whatever order they arrive.  Three small kernels instead of rocPRIM's merge sort of 10^6 pairs
+// (a block sort + 15 merge passes, ~0.16 of the 0.28 ms of a call's planning phase).
+// ---------------------------------------------------------------------------------------------------------
+#define NS_ORD_BINS 1024u
+__device__ __forceinline__ uint32_t ord_bin(uint32_t key) {
+    uint32_t v = key;                                        // keys below 32: one bin each
+    if (key >= 32u) { const uint32_t e = 31u - (uint32_t)__clz((int)key); v = (e - 4u) * 32u + ((key >> (e - 5u)) & 31u); }   // <= 895
+    return NS_ORD_BINS - 1u - v;                             // descending
+}
+__global__ void __launch_bounds__(1024) k_order_hist(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ hist) {
+    __shared__ uint32_t h[NS_ORD_BINS];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < n; i += gridDim.x * 1024u) atomicAdd(&h[ord_bin(keys[i])], 1u);
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+// exclusive scan of the bins -> the cursor of every bin; the histogram is left zeroed for the next batch
+__global__ void __launch_bounds__(1024) k_order_scan(uint32_t *__restrict__ hist, uint32_t *__restrict__ cursor) {
+    __shared__ uint32_t wsum[16];
+    const uint32_t c = hist[threadIdx.x];
+    hist[threadIdx.x] = 0;
+    const uint32_t incl = wave_incl_scan(c);
+    if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) base += wsum[w];
+    cursor[threadIdx.x] = base + incl - c;
+}
+// a workgroup deals 1 024 consecutive reads: ranks inside the workgroup from LDS counters, ONE global atomic per bin the workgroup touches
+__global__ void __launch_bounds__(1024) k_order_deal(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ cursor, uint32_t *__restrict__ list) {
+    __shared__ uint32_t cnt[NS_ORD_BINS];
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t r = blockIdx.x * 1024u + threadIdx.x;
+    uint32_t b = 0, rank = 0;
+    if (r < n) { b = ord_bin(keys[r]); rank = atomicAdd(&cnt[b], 1u); }
+    __syncthreads();
+    const uint32_t mine = cnt[threadIdx.x];
+    __syncthreads();
+    if (mine) cnt[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], mine);      // (now: where this workgroup's reads of the bin start)
+    __syncthreads();
+    if (r < n) list[cnt[b] + rank] = r;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // k_meta_tail: what k_chain does behind the error lists, for the reads of a metagenome pass it left pending (A.defer_tail): the start
 // positions in the species assign_species gave the segments (extract_read, S:1704-1749), the final length check (S:1023-1024), the name
 // and record sizes, the pass's acceptance flag.  Thread per pass position.  The pass launches its lists BEFORE the host has walked the
@@ -1976,6 +2025,7 @@ struct ns_ctx {
     int slot = 0;                      // slot of the last batch
     IoEngine *io = nullptr;            // copy stream, staging slices, writer threads (created by the first ns_sink_open)
     std::vector<ns_sink *> sinks;
+    DevBuf ord_bins;                 // k_order_*: histogram + cursors of the visiting-order bins
     DevBuf sort_key, sort_idx, sort_key_out, order, list_b, list_c, rstate, att_base, scr, scr_len, scr_off, hp_len, hp_nev, hp_ev, hp_wd, hp_runs, hp_nrun, slow_q, cls, hp_bm, hp_pcnt, hp_pord;
     uint32_t hp_shift = 5, hp_pad = 64, hp_cap_k = 0;       // -k: event capacity of a piece (hp_ev_slot), planned for kmer_bias hp_cap_k
     // metagenome: species view of the reference, abundances of the sample, per-pass scratch
@@ -2165,6 +2215,30 @@ static int create_ctx(int device, ns_ctx **out, int prio) {
 // Scalar read-backs of a call (totals of the scans, the counters): device -> page-locked slot -> destination, with the stream
 // synchronised in between.  (hipMemcpyAsync into pageable memory goes through a staging blit kernel; next to another context's
 // kernels on the same GPU that costs hundreds of microseconds per read-back.)
+// the visiting order of a batch: reads by descending key (planned work) — bins of the key, 3 % wide (k_order_*); NS_EXACT_ORDER=1: a full sort (A/B)
+static int visiting_order(ns_ctx *ctx, const uint32_t *keys, const uint32_t *idx, size_t n, uint32_t *list) {
+    hipStream_t st = ctx->stream;
+    int rc;
+    if (getenv("NS_EXACT_ORDER")) {
+        size_t tmp = 0;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp, keys, (uint32_t *)ctx->sort_key_out.p, idx, list, (int)n, 0, 32, st));
+        if ((rc = ensure(ctx, ctx->scan_tmp, tmp))) return rc;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(ctx->scan_tmp.p, tmp, keys, (uint32_t *)ctx->sort_key_out.p, idx, list, (int)n, 0, 32, st));
+        return NS_OK;
+    }
+    if (!ctx->ord_bins.p) {
+        if ((rc = ensure(ctx, ctx->ord_bins, 2 * NS_ORD_BINS * 4))) return rc;
+        HIPCHK(hipMemsetAsync(ctx->ord_bins.p, 0, 2 * NS_ORD_BINS * 4, st));
+    }
+    uint32_t *hist = (uint32_t *)ctx->ord_bins.p, *cursor = hist + NS_ORD_BINS;
+    const unsigned tiles = (unsigned)((n + 1023) / 1024);
+    if (!tiles) return NS_OK;
+    k_order_hist<<<dim3(std::min(tiles, 256u)), dim3(1024), 0, st>>>(keys, (uint32_t)n, hist);
+    k_order_scan<<<dim3(1), dim3(1024), 0, st>>>(hist, cursor);
+    k_order_deal<<<dim3(tiles), dim3(1024), 0, st>>>(keys, (uint32_t)n, cursor, list);
+    HIPCHK(hipGetLastError());
+    return NS_OK;
+}
 static void fold_stats(ns_ctx *ctx, hipStream_t st) {
     uint32_t *z = ctx->slow_q.cap >= 16 ? (uint32_t *)ctx->slow_q.p : nullptr;
     k_stats_fold<<<dim3(1), dim3(64), 0, st>>>((unsigned long long *)ctx->stats.p, z);
@@ -2212,7 +2286,7 @@ void ns_destroy(ns_ctx *ctx) {
     if (ctx->ref_bases_owned) e = hipFree(ctx->ref_bases_owned);
     DevBuf *bufs[] = {&ctx->n_pieces, &ctx->piece_off, &ctx->ev_cap, &ctx->ev_off, &ctx->rec_len, &ctx->rec_off,
                       &ctx->err_len, &ctx->err_off, &ctx->name_len, &ctx->reads, &ctx->pieces, &ctx->events,
-                      &ctx->rec_slot[0], &ctx->rec_slot[1], &ctx->err_slot[0], &ctx->err_slot[1], &ctx->stats, &ctx->scan_tmp, &ctx->sort_key, &ctx->sort_idx,
+                      &ctx->rec_slot[0], &ctx->rec_slot[1], &ctx->err_slot[0], &ctx->err_slot[1], &ctx->stats, &ctx->scan_tmp, &ctx->sort_key, &ctx->sort_idx, &ctx->ord_bins,
                       &ctx->sort_key_out, &ctx->order, &ctx->list_b, &ctx->list_c, &ctx->rstate, &ctx->att_base, &ctx->scr, &ctx->hp_nev, &ctx->hp_ev, &ctx->hp_wd, &ctx->hp_runs, &ctx->hp_nrun,
                       &ctx->scr_len, &ctx->scr_off, &ctx->hp_len, &ctx->slow_q, &ctx->l_cap, &ctx->l_off, &ctx->species_chrom_off, &ctx->t_reads, &ctx->t_pieces,
                       &ctx->t_name_len, &ctx->t_rec_len, &ctx->t_err_len, &ctx->accept, &ctx->accept_scan, &ctx->key_pos,
@@ -3207,14 +3281,7 @@ static int trx_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, Ge
             k_lengths<false><<<grid_p, blk, 0, st>>>(P);
             HIPCHK(hipGetLastError());
             if ((rc = scan_u64(ctx, P.ev_cap, P.ev_off, np + 1))) return rc;
-            {   // candidates by descending length: the 64 chains of a wavefront then have similar trip counts
-                size_t tmp = 0;
-                HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp, P.sort_key, (uint32_t *)ctx->sort_key_out.p, P.sort_idx,
-                                                                    (uint32_t *)ctx->list_b.p, (int)np, 0, 32, st));
-                if ((rc = ensure(ctx, ctx->scan_tmp, tmp))) return rc;
-                HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(ctx->scan_tmp.p, tmp, P.sort_key, (uint32_t *)ctx->sort_key_out.p, P.sort_idx,
-                                                                    (uint32_t *)ctx->list_b.p, (int)np, 0, 32, st));
-            }
+            if ((rc = visiting_order(ctx, P.sort_key, P.sort_idx, np, (uint32_t *)ctx->list_b.p))) return rc;      // candidates by descending length
             if (!planned) { HIPCHK(hipEventRecord(ctx->evt[2], st)); planned = true; }
             if ((rc = read_small(ctx, st, &cap, P.ev_off + np, 8))) return rc;
             if ((rc = ensure(ctx, ctx->events, (size_t)cap * sizeof(ns_event) + 64))) return rc;
@@ -3405,14 +3472,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         k_lengths<false><<<grid_t, blk, 0, st>>>(A);
         HIPCHK(hipGetLastError());
         if ((rc = scan_u64(ctx, A.ev_cap, A.ev_off, n + 1))) return rc;
-        {   // visit reads by descending length: the 64 chains of a wavefront then have similar trip counts
-            size_t tmp = 0;
-            HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp, A.sort_key, (uint32_t *)ctx->sort_key_out.p,
-                                                                A.sort_idx, list_a, (int)n, 0, 32, st));
-            if ((rc = ensure(ctx, ctx->scan_tmp, tmp))) return rc;
-            HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(ctx->scan_tmp.p, tmp, A.sort_key, (uint32_t *)ctx->sort_key_out.p,
-                                                                A.sort_idx, list_a, (int)n, 0, 32, st));
-        }
+        if ((rc = visiting_order(ctx, A.sort_key, A.sort_idx, n, list_a))) return rc;
         HIPCHK(hipEventRecord(ctx->evt[2], st));
         if ((rc = read_small(ctx, st, &tot_cap, A.ev_off + n, 8))) return rc;
         if ((rc = ensure(ctx, ctx->events, (size_t)tot_cap * sizeof(ns_event) + 64))) return rc;
