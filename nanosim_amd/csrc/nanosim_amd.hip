@@ -781,7 +781,9 @@ __global__ void __launch_bounds__(256) k_meta_commit(GenArgs A) {
                 }
             }
         }
-        wave_add_by_key(A.species_bases, sp, bases);
+        // (one of NS_STATS_WAYS copies of the species counters, summed by the host: on one copy the ~150 000 atomics of a 10^6-read pass —
+        // one per wavefront and species — were executed one after the other: 1.1 of this kernel's 1.2 ms, profiles/r06/ab_meta_commit.log)
+        wave_add_by_key(A.species_bases + (size_t)(blockIdx.x & (NS_STATS_WAYS - 1u)) * A.nspecies, sp, bases);
     }
     if (!on) return;
     const uint64_t slot = A.m_passed + (uint32_t)sc;
@@ -2957,9 +2959,9 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
         (rc = ensure(ctx, ctx->accept, (n + 1) * 8)) || (rc = ensure(ctx, ctx->accept_scan, (n + 1) * 8)) ||
         (rc = ensure(ctx, ctx->key_pos, (n + 1) * 4)) || (rc = ensure(ctx, ctx->draw_x, (tot_seg + 1) * 8)) ||
         (rc = ensure(ctx, ctx->m_segptr, (n + 1) * 4)) || (rc = ensure(ctx, ctx->m_len, (tot_seg + 1) * 4)) ||
-        (rc = ensure(ctx, ctx->m_species, (tot_seg + 1) * 2)) || (rc = ensure(ctx, ctx->species_bases, (size_t)ns * 8)))
+        (rc = ensure(ctx, ctx->m_species, (tot_seg + 1) * 2)) || (rc = ensure(ctx, ctx->species_bases, (size_t)ns * 8 * NS_STATS_WAYS)))
         return rc;
-    HIPCHK(hipMemsetAsync(ctx->species_bases.p, 0, (size_t)ns * 8, st));
+    HIPCHK(hipMemsetAsync(ctx->species_bases.p, 0, (size_t)ns * 8 * NS_STATS_WAYS, st));
     lap("nseg loop + buffers", tt);
     // final arrays (what the record kernels read) and the per-pass views of the same kernels
     A.f_reads = (ns_read *)ctx->reads.p; A.f_pieces = (ns_piece *)ctx->pieces.p; A.f_name_len = (uint16_t *)ctx->name_len.p;
@@ -2978,7 +2980,7 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
     const bool perfect = prm->kind == NS_KIND_PERFECT;      // S:838-842, 879-910: no errors, no head/tail, the quotas are never updated
     const ns_key bkey{(uint32_t)prm->seed, (uint32_t)(prm->seed >> 32), (uint32_t)prm->first_read, (uint32_t)(prm->first_read >> 32)};
     std::vector<double> cur_bases(ns, 0.0);
-    std::vector<unsigned long long> sb(ns);
+    std::vector<unsigned long long> sb((size_t)ns * NS_STATS_WAYS);
     uint64_t passed = 0, pieces_passed = 0, ev_base = 0;
     double ms_chain = 0;
     unsigned long long good_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // counters after the last complete pass
@@ -3170,10 +3172,14 @@ static int meta_passes(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info, G
         HIPCHK(hipGetLastError());
         uint64_t acc = 0;
         HIPCHK(hipMemcpyAsync(&acc, P.accept_scan + np, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(sb.data(), ctx->species_bases.p, (size_t)ns * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(sb.data(), ctx->species_bases.p, (size_t)ns * 8 * NS_STATS_WAYS, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         lap("plan/chain/commit", tt);
-        for (uint32_t s = 0; s < ns && !perfect; ++s) cur_bases[s] = (double)sb[s];
+        for (uint32_t s = 0; s < ns && !perfect; ++s) {
+            unsigned long long tot = 0;
+            for (uint32_t w = 0; w < NS_STATS_WAYS; ++w) tot += sb[(size_t)w * ns + s];
+            cur_bases[s] = (double)tot;
+        }
         passed += acc & 0xffffffffull; pieces_passed += acc >> 32;
         ev_base += pass_cap;
     }
