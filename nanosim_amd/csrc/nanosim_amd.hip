@@ -929,50 +929,54 @@ __global__ void __launch_bounds__(256) k_names(GenArgs A) {
             const ns_piece *pc = A.pieces + rd.piece_off;
             const uint32_t name_len = A.name_len[r];                   // without '>' and '\n' (k_chain / k_meta_commit)
             const bool in_row = name_len + 2u <= NS_NAME_ROW;
-            uint8_t *const p0 = in_row ? rows[threadIdx.x] : A.records + rd.rec_off;
-            uint8_t *p = p0;
-            *p++ = A.prm.fastq ? '@' : '>';
-            bool first = true;
-            for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
-                if (pc[pi].kind && kind == NS_KIND_ALIGNED) {
-                    if (A.meta) { const char *g = ";gap_"; while (*g) *p++ = (uint8_t)*g++; p = put_dec(p, pc[pi].out_len); }   // S:970-971
-                    continue;
+            // (a lambda inlined at two call sites: behind each the compiler knows the address space of `p` — LDS stores for the row, global
+            // stores for the image; through one pointer that may be either they were flat stores, several times slower)
+            auto compose = [&](uint8_t *p) -> uint8_t * {
+                *p++ = A.prm.fastq ? '@' : '>';
+                bool first = true;
+                for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
+                    if (pc[pi].kind && kind == NS_KIND_ALIGNED) {
+                        if (A.meta) { const char *g = ";gap_"; while (*g) *p++ = (uint8_t)*g++; p = put_dec(p, pc[pi].out_len); }   // S:970-971
+                        continue;
+                    }
+                    if (!first) *p++ = ';';
+                    first = false;
+                    const char *cn = A.ref.names + A.ref.name_off[pc[pi].chrom];
+                    while (*cn) *p++ = (uint8_t)*cn++;
+                    *p++ = '_';
+                    p = put_dec(p, pc[pi].pos);
                 }
-                if (!first) *p++ = ';';
-                first = false;
-                const char *cn = A.ref.names + A.ref.name_off[pc[pi].chrom];
-                while (*cn) *p++ = (uint8_t)*cn++;
+                const char *tag = kind == NS_KIND_ALIGNED ? "_aligned_" : kind == NS_KIND_PERFECT ? "_perfect_" : "_unaligned_";
+                while (*tag) *p++ = (uint8_t)*tag++;
+                p = put_dec(p, A.name_first + r);
+                if (kind == NS_KIND_ALIGNED && rd.n_pieces > 1) { const char *c = "_chimeric"; while (*c) *p++ = (uint8_t)*c++; }
+                if (pc[0].ref_gpos >= NS_SPLICED_BASE) {                          // "_RetainedIntron_<start>-<end>;..." (S:1189-1192)
+                    const uint32_t trx = pc[0].chrom;
+                    const uint32_t trx_len = (uint32_t)(A.ref.chrom_off[trx + 1] - A.ref.chrom_off[trx]);
+                    bool open = false;
+                    ir_walk(A.ir, trx, pc[0].ref_len, trx_len, read_key(A, r), rd.attempts, [&](uint32_t, uint32_t, uint32_t start, uint32_t end, bool retained) {
+                        if (!retained) return;
+                        if (!open) { const char *c = "_RetainedIntron_"; while (*c) *p++ = (uint8_t)*c++; open = true; }
+                        p = put_dec(p, start); *p++ = '-'; p = put_dec(p, end); *p++ = ';';
+                    });
+                }
+                *p++ = '_'; *p++ = rd.reversed ? 'R' : 'F';
+                *p++ = '_'; p = put_dec(p, rd.head);
                 *p++ = '_';
-                p = put_dec(p, pc[pi].pos);
-            }
-            const char *tag = kind == NS_KIND_ALIGNED ? "_aligned_" : kind == NS_KIND_PERFECT ? "_perfect_" : "_unaligned_";
-            while (*tag) *p++ = (uint8_t)*tag++;
-            p = put_dec(p, A.name_first + r);
-            if (kind == NS_KIND_ALIGNED && rd.n_pieces > 1) { const char *c = "_chimeric"; while (*c) *p++ = (uint8_t)*c++; }
-            if (pc[0].ref_gpos >= NS_SPLICED_BASE) {                          // "_RetainedIntron_<start>-<end>;..." (S:1189-1192)
-                const uint32_t trx = pc[0].chrom;
-                const uint32_t trx_len = (uint32_t)(A.ref.chrom_off[trx + 1] - A.ref.chrom_off[trx]);
-                bool open = false;
-                ir_walk(A.ir, trx, pc[0].ref_len, trx_len, read_key(A, r), rd.attempts, [&](uint32_t, uint32_t, uint32_t start, uint32_t end, bool retained) {
-                    if (!retained) return;
-                    if (!open) { const char *c = "_RetainedIntron_"; while (*c) *p++ = (uint8_t)*c++; open = true; }
-                    p = put_dec(p, start); *p++ = '-'; p = put_dec(p, end); *p++ = ';';
-                });
-            }
-            *p++ = '_'; *p++ = rd.reversed ? 'R' : 'F';
-            *p++ = '_'; p = put_dec(p, rd.head);
-            *p++ = '_';
-            first = true;
-            for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
-                if (pc[pi].kind && kind == NS_KIND_ALIGNED) continue;
-                if (!first) *p++ = ';';
-                first = false;
-                p = put_dec(p, pc[pi].ref_len);
-            }
-            *p++ = '_'; p = put_dec(p, rd.tail + (A.polya ? A.polya[r] : 0u));
-            *p++ = '\n';
-            const uint32_t len = (uint32_t)(p - p0);
-            if (in_row) hdr = len;
+                first = true;
+                for (uint32_t pi = 0; pi < rd.n_pieces; ++pi) {
+                    if (pc[pi].kind && kind == NS_KIND_ALIGNED) continue;
+                    if (!first) *p++ = ';';
+                    first = false;
+                    p = put_dec(p, pc[pi].ref_len);
+                }
+                *p++ = '_'; p = put_dec(p, rd.tail + (A.polya ? A.polya[r] : 0u));
+                *p++ = '\n';
+                return p;
+            };
+            uint32_t len;
+            if (in_row) { uint8_t *row = rows[threadIdx.x]; len = (uint32_t)(compose(row) - row); hdr = len; }
+            else { uint8_t *img = A.records + rd.rec_off; len = (uint32_t)(compose(img) - img); }
             // the framing behind the bases (and the qualities): single bytes far from the header
             uint8_t *g = A.records + rd.rec_off + len + rd.seq_len;
             *g++ = '\n';
