@@ -50,6 +50,10 @@
 // ---------------------------------------------------------------------------------------------------------
 struct GenArgs {
     uint32_t ev_stage;               // k_chain<LDS>: byte offset of the event staging area behind the tables in dynamic LDS (0: none)
+    uint32_t hole_at, hole_len;      // k_chain over a list with a hole: entries [hole_at, hole_at + hole_len) belong to another launch (the wave-per-read list of a
+                                     // chimeric batch: the longest single-segment reads, which sit behind the reads of several pieces in the visiting order)
+    const uint32_t *prio_thr;        // k_chain, thread per read, over a batch with reads of several pieces: [1..3] = the planned work from which a wavefront takes
+                                     // issue priority 3, 2, 1 (k_order_scan; nullptr: by position in the list, which is then one descending order)
     uint32_t defer_tail;             // metagenome pass: k_chain stops in front of the positions (the species are not known yet: the host is still walking the
                                      // quotas of assign_species, S:758-811, while the lists run) and marks the read pending; k_meta_tail goes on from there
     uint32_t coop_k1;                // wave-per-read unaligned chain with one iteration per lane (NS_UCOOP_K=1: the form until round 6)
@@ -162,6 +166,14 @@ __device__ __forceinline__ uint32_t read_nseg(const GenArgs &A, const ns_key &ke
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// planned work on a scale of 32 steps, four per octave from 2^9 to 2^17 (clamped outside): the visiting order of the reads of several pieces
+__device__ __forceinline__ uint32_t ord_coarse(uint64_t w) {
+    if (w < 512ull) return 0u;
+    if (w >= (1ull << 17)) return 31u;
+    const uint32_t v = (uint32_t)w, e = 31u - (uint32_t)__clz((int)v);      // 9 .. 16
+    return (e - 9u) * 4u + ((v >> (e - 2u)) & 3u);
+}
+__device__ __forceinline__ uint32_t ord_coarse_floor(uint32_t b) { return b ? (4u + (b & 3u)) << ((b >> 2) + 7u) : 0u; }   // the smallest work of step b
 // k_nseg: pieces per read (S:1276-1279)
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_nseg(GenArgs A) {
@@ -214,7 +226,7 @@ __global__ void __launch_bounds__(SMALL ? 64 : 256, SMALL ? 7 : 1) k_lengths(Gen
     }
     ns_piece *pc = A.pieces + piece_off;
     bool ok = true;
-    uint64_t cap = 0, work = 0;
+    uint64_t cap = 0, work = 0, work0 = 0;
     for (uint32_t pi = 0; pi < n_pieces; ++pi) {
         const bool is_gap = (kind == NS_KIND_UNALIGNED) || (pi & 1);
         int64_t mlen = 0;
@@ -241,6 +253,8 @@ __global__ void __launch_bounds__(SMALL ? 64 : 256, SMALL ? 7 : 1) k_lengths(Gen
         if (kind == NS_KIND_PERFECT) continue;
         if (is_gap) { cap += l * A.cap_gap_mul + 64; work += 20 * l; }    // a gap base costs ~20x an aligned base
         else { cap += (uint64_t)((double)l * A.cap_rate) + 64; work += l; }
+        if (n_pieces > 1u) cap += 4;                                      // (k_chain starts every piece on a group of four events)
+        if (pi == 0) work0 = work;
     }
     int32_t remainder = 0; double ratio = 0;
     if (prm.trx && kind == NS_KIND_ALIGNED) {                                          // S:1073-1076, 1203-1204: one draw per read, no filter
@@ -282,7 +296,13 @@ __global__ void __launch_bounds__(SMALL ? 64 : 256, SMALL ? 7 : 1) k_lengths(Gen
     if (A.attempt > 0 && !meta_al && !trx_tab) A.l_cap[tid] = cap;
     if (A.attempt == 0 || meta_al || trx_tab) {
         A.ev_cap[r] = cap;
-        A.sort_key[r] = work > 0xffffffffull ? 0xffffffffu : (uint32_t)work;
+        // bit 31: a read of several pieces (chimeric) — those are visited first, together (visiting_order): a thread walks its pieces one
+        // after the other, so ONE two-segment read among 64 made its whole wavefront run the second segment's trip count on top of the
+        // first's (5 % chimeric reads: 96 % of the wavefronts; the chain of a chimeric batch took 4.6 instead of 2.0 ms).  Among themselves
+        // they are ordered by (planned work, work of the FIRST piece), both on a coarse logarithmic scale (ord_coarse): the wavefront runs
+        // max(first pieces) + max(the rest), and reads of equal total alone have those two anywhere.
+        if (n_pieces > 1u) A.sort_key[r] = 0x80000000u | ord_coarse(work) << 5 | ord_coarse(work0);
+        else A.sort_key[r] = work > 0x7fffffffull ? 0x7fffffffu : (uint32_t)work;
         A.sort_idx[r] = (uint32_t)r;
     }
 }
@@ -322,6 +342,9 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #ifndef NS_CHAIN_MINW
 #define NS_CHAIN_MINW 5
 #endif
+#ifdef NS_CHAIN_CLOCK
+__device__ unsigned long long g_chain_clock[16];      // [multi ? 4 : 0] + {max, sum, waves, max trip proxy}: thread-per-read chain, per wavefront (100 MHz ticks)
+#endif
 template <bool LDS_TABLES, bool COOP>
 __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? (LDS_TABLES ? NS_UCOOP_MINW : 4) : NS_CHAIN_MINW) k_chain(GenArgs A) {
     extern __shared__ uint64_t lds_tbl[];
@@ -356,13 +379,32 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? (LDS_TA
     // The list is sorted by descending length, so the first workgroups carry the longest chains and set the makespan
     // (a 120 kb read is ~3800 dependent iterations): give them issue priority over the short-read waves they share a
     // SIMD with.
-    if (COOP || blockIdx.x < (gridDim.x >> 6)) __builtin_amdgcn_s_setprio(3);
+    // A batch with reads of several pieces is visited in TWO descending orders, those reads first (k_lengths): there the priority goes by
+    // the planned work of the wavefront's reads against the work at ranks n/64, n/16, n/4 of the single-segment reads (prio_thr) —
+    // by position, the reads of several pieces (5 % of the batch, 2-4 mean lengths each) held priorities 3 and 2 and the longest
+    // single-segment reads ran at 1: their wavefronts took 2.0 ms instead of 0.5 (profiles/r06/ab_chimeric_order.log)
+    if (!COOP && A.prio_thr) {
+        uint32_t w = 0;
+        if (tid < A.list_n) {
+            const uint32_t k = A.sort_key[A.list[tid + (tid >= A.hole_at ? A.hole_len : 0u)]];
+            w = (k >> 31) ? ord_coarse_floor((k >> 5) & 31u) : k;
+        }
+        for (int off = 32; off > 0; off >>= 1) w = max(w, (uint32_t)__shfl_xor((int)w, off));
+        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+        if (w >= A.prio_thr[1]) __builtin_amdgcn_s_setprio(3);
+        else if (w >= A.prio_thr[2]) __builtin_amdgcn_s_setprio(2);
+        else if (w >= A.prio_thr[3]) __builtin_amdgcn_s_setprio(1);
+    }
+    else if (COOP || blockIdx.x < (gridDim.x >> 6)) __builtin_amdgcn_s_setprio(3);
     else if (blockIdx.x < (gridDim.x >> 4)) __builtin_amdgcn_s_setprio(2);
     else if (blockIdx.x < (gridDim.x >> 2)) __builtin_amdgcn_s_setprio(1);
+#ifdef NS_CHAIN_CLOCK
+    const unsigned long long clk0 = wall_clock64(); uint32_t clk_multi = 0; unsigned long long clk_al = 0, clk_gap = 0, clk_pos = 0;
+#endif
     unsigned long long st_over = 0, st_bases = 0, st_ref = 0, st_ev = 0;
     uint32_t st_max = 0;
     if (tid < A.list_n) {
-        const uint64_t r = A.list ? A.list[tid] : A.list_base + tid;
+        const uint64_t r = A.list ? A.list[tid + (tid >= A.hole_at ? A.hole_len : 0u)] : A.list_base + tid;      // (hole: the entries another launch takes)
         const int kind = (int)prm.kind;
         const bool trx_al = prm.trx && kind != NS_KIND_UNALIGNED;       // r is then a position of the candidate table (one try each)
         const bool meta_al = (A.meta && kind != NS_KIND_UNALIGNED) || trx_al;      // ... or of a metagenome pass
@@ -370,6 +412,9 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? (LDS_TA
         const uint32_t a = trx_al ? trx_attempt(A, r) : meta_al ? A.attempt : A.att_base[r] + A.attempt;
         ns_read rd = A.reads[r];
         const uint32_t n_pieces = rd.n_pieces;
+#ifdef NS_CHAIN_CLOCK
+        clk_multi = n_pieces > 1u;
+#endif
         ns_piece *pc = A.pieces + rd.piece_off;
         uint32_t epoch = meta_al ? 0u : A.rstate[r] & 0xffffu, fails = meta_al ? 0u : A.rstate[r] >> 16;
         bool accepted = false, overflow = false;
@@ -380,21 +425,27 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? (LDS_TA
             const uint32_t ev_cap = ev_cap64 > 0xffffffffull ? 0xffffffffu : (uint32_t)ev_cap64;
             EvSink32 sink; sink.last_ins_len = 0; sink.overflow = false; sink.range = false; sink.stride = blockDim.x;
             int64_t total = (int64_t)rd.head + rd.tail;
-            uint32_t evn = 0;
+            uint32_t evn = 0, evp = 0;                               // events of the read so far / where the next piece's events start (below)
             const uint32_t trx_chrom = trx_al ? pc[0].pos : 0u;      // planned by k_lengths
             for (uint32_t pi = 0; pi < n_pieces; ++pi) {
                 ns_piece p = pc[pi];
                 const int32_t m32 = (int32_t)p.ref_len;                // planned length from k_lengths
                 const uint32_t sid = p.kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
-                sink.ev = A.events + ev_off + evn; sink.cap = ev_cap > evn ? ev_cap - evn : 0; sink.n = 0; sink.shift = 0;
+                sink.ev = A.events + ev_off + evp; sink.cap = ev_cap > evp ? ev_cap - evp : 0; sink.n = 0; sink.shift = 0;
                 sink.stg = nullptr;
 #ifdef NS_ABLATE
                 if (COOP && LDS_TABLES && (A.dbg & (1u << 21))) sink.cap = 0;                       // (profiling: no event stores)
 #endif
-                if constexpr (LDS_TABLES && !COOP) {      // single-piece reads: events leave in groups of four (32-byte stores), staged in LDS
-                    if (A.ev_stage && n_pieces == 1) sink.stg = reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(lds_tbl) + A.ev_stage) + threadIdx.x;
+                if constexpr (LDS_TABLES && !COOP) {      // events leave in groups of four (32-byte stores), staged in LDS.  A read of several
+                    // pieces starts every piece on a group boundary (up to three unused slots behind a piece: k_lengths plans them; every
+                    // consumer goes by ns_piece.ev_off / n_ev).  Until round 6 such reads stored their events one by one, which made them
+                    // ~2.2 times slower per base on top of being twice as long: the tail of a chimeric batch's chain launch (3.6 against 2.0 ms)
+                    if (A.ev_stage) sink.stg = reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(lds_tbl) + A.ev_stage) + threadIdx.x;
                 }
                 EList32 e;
+#ifdef NS_CHAIN_CLOCK
+                const unsigned long long clk_p = wall_clock64();
+#endif
 #ifdef NS_ABLATE
                 if (COOP && LDS_TABLES && (A.dbg & (1u << 20))) { e.l_new = e.middle_ref = m32; } else   // (profiling: no error list)
 #endif
@@ -410,16 +461,20 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? (LDS_TA
                 else if (ct.int_image) e = chain_error_list(T, T, ct, m32, key, sid, a, sink);      // the integer image, from global memory (it does not fit LDS)
                 else e = chain_error_list_g(T, ct, m32, key, sid, a, sink);
                 ev_flush_tail(sink);
+#ifdef NS_CHAIN_CLOCK
+                if (p.kind) clk_gap += wall_clock64() - clk_p; else clk_al += wall_clock64() - clk_p;
+#endif
 #ifdef NS_ABLATE
                 if (COOP && LDS_TABLES && (A.dbg & (1u << 21))) { sink.overflow = false; sink.n = 0; }
 #endif
-                p.ev_off = ev_off + evn;
+                p.ev_off = ev_off + evp;
                 p.ref_len = (uint32_t)(e.middle_ref < 0 ? 0 : e.middle_ref);
                 p.out_len = (uint32_t)((e.middle_ref < 0 ? 0 : e.middle_ref) + sink.shift);
                 p.n_ev = sink.n;
                 p.chrom = (p.kind && kind == NS_KIND_ALIGNED && m32 == 0) ? 1u : 0u;   // empty gap marker (S:1553-1554)
                 pc[pi] = p;          // COOP: every lane stores the same value (and later reads back its own store)
                 evn += sink.n;
+                evp += sink.stg ? (sink.n + 3u) & ~3u : sink.n;
                 if (!p.kind) total += e.l_new;                                           // S:1362
                 if (kind == NS_KIND_UNALIGNED) total = e.middle_ref;                     // S:1503
             }
@@ -446,6 +501,9 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? (LDS_TA
             }
             if (A.defer_tail) { if (lead) A.accept[r] = 2ull | (uint64_t)evn << 32; break; }      // pending: k_meta_tail
             // ---- positions (S:1388-1389, 1510, 1557) ----
+#ifdef NS_CHAIN_CLOCK
+            clk_pos = wall_clock64();
+#endif
             bool pos_ok = true;
             int64_t seq_len = (int64_t)rd.head + rd.tail;
             uint64_t ref_bases = 0;
@@ -551,6 +609,15 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? (LDS_TA
             }
         }
     }
+#ifdef NS_CHAIN_CLOCK
+    if (!COOP && A.attempt == 0) {
+        const unsigned long long dt = wall_clock64() - clk0;
+        const bool any_multi = __ballot(clk_multi != 0) != 0;
+        if ((threadIdx.x & 63) == 0) { unsigned long long *C = g_chain_clock + (any_multi ? 4 : 0); atomicMax(&C[0], dt); atomicAdd(&C[1], dt); atomicAdd(&C[2], 1ull);
+                                       atomicMax(&C[3], (unsigned long long)blockIdx.x << 32 | dt);
+                                       if (any_multi) { atomicAdd(&g_chain_clock[8], clk_al); atomicAdd(&g_chain_clock[9], clk_gap); atomicAdd(&g_chain_clock[10], clk_pos ? wall_clock64() - clk_pos : 0ull); } }
+    }
+#endif
     // one atomic per wavefront and counter
     st_over = wave_sum(st_over); st_bases = wave_sum(st_bases); st_ref = wave_sum(st_ref); st_ev = wave_sum(st_ev);
     if (A.prm.kind == NS_KIND_UNALIGNED) for (int off = 32; off > 0; off >>= 1) st_max = max(st_max, (uint32_t)__shfl_xor((int)st_max, off));
@@ -590,47 +657,70 @@ __global__ void __launch_bounds__(64) k_stats_fold(unsigned long long *stats, ui
 // The visiting order of a batch: reads by descending planned work, so that the 64 chains of a wavefront have similar trip counts and the
 // longest reads come first.  Nothing depends on the order beyond that (a read is a function of its index), so it need not be a sort: the
 // reads are dealt into 1 024 bins of their key on a logarithmic scale (32 bins per octave: keys of a bin differ by at most 3 %), bins in
-// descending order, reads inside a bin in whatever order they arrive.  Three small kernels instead of rocPRIM's merge sort of 10^6 pairs
+// descending order, reads inside a bin in whatever order they arrive — twice: the reads of several pieces (chimeric) first, then the rest.  Three small kernels instead of rocPRIM's merge sort of 10^6 pairs
 // (a block sort + 15 merge passes, ~0.16 of the 0.28 ms of a call's planning phase).
 // ---------------------------------------------------------------------------------------------------------
-#define NS_ORD_BINS 1024u
-__device__ __forceinline__ uint32_t ord_bin(uint32_t key) {
+#define NS_ORD_BINS 2048u                                     // [0, 1024): reads of several pieces (key bit 31), [1024, 2048): the others
+__device__ __forceinline__ uint32_t ord_bin(uint32_t key31) {
+    if (key31 >> 31) return 1023u - (key31 & 1023u);         // several pieces: k_lengths made the two coarse bins, descending
+    const uint32_t key = key31;
     uint32_t v = key;                                        // keys below 32: one bin each
-    if (key >= 32u) { const uint32_t e = 31u - (uint32_t)__clz((int)key); v = (e - 4u) * 32u + ((key >> (e - 5u)) & 31u); }   // <= 895
-    return NS_ORD_BINS - 1u - v;                             // descending
+    if (key >= 32u) { const uint32_t e = 31u - (uint32_t)__clz((int)key); v = (e - 4u) * 32u + ((key >> (e - 5u)) & 31u); }   // <= 863
+    return 1024u + 1023u - v;                                // descending
 }
 __global__ void __launch_bounds__(1024) k_order_hist(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ hist) {
     __shared__ uint32_t h[NS_ORD_BINS];
-    h[threadIdx.x] = 0;
+    h[threadIdx.x] = 0; h[threadIdx.x + 1024u] = 0;
     __syncthreads();
     for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < n; i += gridDim.x * 1024u) atomicAdd(&h[ord_bin(keys[i])], 1u);
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+    if (h[threadIdx.x + 1024u]) atomicAdd(&hist[threadIdx.x + 1024u], h[threadIdx.x + 1024u]);
 }
-// exclusive scan of the bins -> the cursor of every bin; the histogram is left zeroed for the next batch
+// exclusive scan of the bins -> the cursor of every bin; cursor[NS_ORD_BINS] = the reads of several pieces; the histogram is left zeroed
 __global__ void __launch_bounds__(1024) k_order_scan(uint32_t *__restrict__ hist, uint32_t *__restrict__ cursor) {
     __shared__ uint32_t wsum[16];
-    const uint32_t c = hist[threadIdx.x];
-    hist[threadIdx.x] = 0;
+    const uint32_t c0 = hist[2u * threadIdx.x], c1 = hist[2u * threadIdx.x + 1u];     // thread t: bins 2t, 2t + 1
+    hist[2u * threadIdx.x] = 0; hist[2u * threadIdx.x + 1u] = 0;
+    const uint32_t c = c0 + c1;
     const uint32_t incl = wave_incl_scan(c);
     if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = incl;
     __syncthreads();
     uint32_t base = 0;
     for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) base += wsum[w];
-    cursor[threadIdx.x] = base + incl - c;
+    base += incl - c;
+    cursor[2u * threadIdx.x] = base; cursor[2u * threadIdx.x + 1u] = base + c0;
+    if (threadIdx.x == 512u) cursor[NS_ORD_BINS] = base;     // (bin 1024 starts here)
+    // cursor[NS_ORD_BINS + 1 .. 3]: the work of the single-segment read at ranks n/64, n/16, n/4 of their order (k_chain's issue priorities)
+    __shared__ uint32_t n_multi_s, n_all_s;
+    if (threadIdx.x == 512u) n_multi_s = base;
+    if (threadIdx.x == 1023u) n_all_s = base + c;
+    __syncthreads();
+    if (threadIdx.x >= 512u && c) {
+        const uint32_t n_single = n_all_s - n_multi_s, lo = base - n_multi_s;       // ranks [lo, lo + c) of the single-segment reads
+#pragma unroll
+        for (uint32_t j = 0; j < 3; ++j) {
+            const uint32_t rank = n_single >> (6u - 2u * j);
+            if (lo <= rank && rank < lo + c) {
+                const uint32_t bin = 2u * threadIdx.x + (rank < lo + c0 ? 0u : 1u), v = 2047u - bin;     // ord_bin backwards: the smallest key of the bin
+                cursor[NS_ORD_BINS + 1u + j] = v < 32u ? v : (32u + (v & 31u)) << ((v >> 5) - 1u);
+            }
+        }
+    }
 }
 // a workgroup deals 1 024 consecutive reads: ranks inside the workgroup from LDS counters, ONE global atomic per bin the workgroup touches
 __global__ void __launch_bounds__(1024) k_order_deal(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ cursor, uint32_t *__restrict__ list) {
     __shared__ uint32_t cnt[NS_ORD_BINS];
-    cnt[threadIdx.x] = 0;
+    cnt[threadIdx.x] = 0; cnt[threadIdx.x + 1024u] = 0;
     __syncthreads();
     const uint32_t r = blockIdx.x * 1024u + threadIdx.x;
     uint32_t b = 0, rank = 0;
     if (r < n) { b = ord_bin(keys[r]); rank = atomicAdd(&cnt[b], 1u); }
     __syncthreads();
-    const uint32_t mine = cnt[threadIdx.x];
+    const uint32_t m0 = cnt[threadIdx.x], m1 = cnt[threadIdx.x + 1024u];
     __syncthreads();
-    if (mine) cnt[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], mine);      // (now: where this workgroup's reads of the bin start)
+    if (m0) cnt[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], m0);                   // (now: where this workgroup's reads of the bin start)
+    if (m1) cnt[threadIdx.x + 1024u] = atomicAdd(&cursor[threadIdx.x + 1024u], m1);
     __syncthreads();
     if (r < n) list[cnt[b] + rank] = r;
 }
@@ -2236,8 +2326,8 @@ static int visiting_order(ns_ctx *ctx, const uint32_t *keys, const uint32_t *idx
         return NS_OK;
     }
     if (!ctx->ord_bins.p) {
-        if ((rc = ensure(ctx, ctx->ord_bins, 2 * NS_ORD_BINS * 4))) return rc;
-        HIPCHK(hipMemsetAsync(ctx->ord_bins.p, 0, 2 * NS_ORD_BINS * 4, st));
+        if ((rc = ensure(ctx, ctx->ord_bins, (2 * NS_ORD_BINS + 16) * 4))) return rc;
+        HIPCHK(hipMemsetAsync(ctx->ord_bins.p, 0, (2 * NS_ORD_BINS + 16) * 4, st));
     }
     uint32_t *hist = (uint32_t *)ctx->ord_bins.p, *cursor = hist + NS_ORD_BINS;
     const unsigned tiles = (unsigned)((n + 1023) / 1024);
@@ -3488,7 +3578,10 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         if ((rc = scan_u64(ctx, A.ev_cap, A.ev_off, n + 1))) return rc;
         if ((rc = visiting_order(ctx, A.sort_key, A.sort_idx, n, list_a))) return rc;
         HIPCHK(hipEventRecord(ctx->evt[2], st));
-        if ((rc = read_small(ctx, st, &tot_cap, A.ev_off + n, 8))) return rc;
+        uint32_t n_multi = 0;                 // reads of several pieces: the head of the visiting order (visiting_order; 0 with NS_EXACT_ORDER)
+        if (prm->chimeric && prm->kind == NS_KIND_ALIGNED && ctx->ord_bins.p && !getenv("NS_EXACT_ORDER")) {
+            if ((rc = read_small(ctx, st, &tot_cap, A.ev_off + n, 8, &n_multi, (uint32_t *)ctx->ord_bins.p + 2 * NS_ORD_BINS, 4))) return rc;
+        } else if ((rc = read_small(ctx, st, &tot_cap, A.ev_off + n, 8))) return rc;
         if ((rc = ensure(ctx, ctx->events, (size_t)tot_cap * sizeof(ns_event) + 64))) return rc;
         A.events = (ns_event *)ctx->events.p;
         // ---- passes: pass a generates attempt a of every read still without an accepted attempt ----
@@ -3498,7 +3591,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
         double ms_chain = 0;
         uint64_t used = tot_cap;                  // event slots handed out so far
         for (uint32_t a = 0;; ++a) {
-            A.list = cur; A.list_n = cur_n; A.attempt = a; A.next_list = nxt;
+            A.list = cur; A.list_n = cur_n; A.attempt = a; A.next_list = nxt; A.hole_at = 0; A.hole_len = 0; A.prio_thr = nullptr;
             A.l_off = nullptr; A.l_base = 0;
             if (a > 0) HIPCHK(hipMemsetAsync(A.next_n, 0, 4, st));      // (pass 0: the counters were zeroed as a whole at the top of the retry loop)
             const dim3 grid_p((cur_n + 255) / 256);
@@ -3539,21 +3632,34 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
             uint32_t n_coop = 0;
             if (prm->kind == NS_KIND_UNALIGNED)                           // its loop is a prefix sum (coop_unaligned_error_list); pass 0 visits the reads longest first
                 n_coop = (a == 0 && lds && cur_n >= ctx->coop_min) ? std::max(cur_n >> ctx->ucoop_shift, 1u) : cur_n;
-            else if (a == 0 && ctx->coop_ok && prm->kind == NS_KIND_ALIGNED && cur_n >= ctx->coop_min) n_coop = cur_n >> ctx->coop_shift;   // longest 0.1 %
+            else if (a == 0 && ctx->coop_ok && prm->kind == NS_KIND_ALIGNED && cur_n >= ctx->coop_min)    // longest 0.1 % (of the single-segment reads)
+                n_coop = (cur_n - std::min(cur_n, n_multi)) >> ctx->coop_shift;
+            const uint32_t coop_at = (a == 0 && prm->kind == NS_KIND_ALIGNED) ? std::min(cur_n, n_multi) : 0u;     // where that list starts in the visiting order
+            // ... and the longest of the reads of several pieces (the head of the order): their chains are the sum of their pieces', so more of them
+            // lie beyond the length at which a thread-per-read chain becomes the tail of the launch (NS_COOP_MULTI_SHIFT, default: 32 times the share = 3 %; same-box sweep in profiles/r06/ab_chimeric_order.log)
+            uint32_t m_coop = 0;
+            if (coop_at && n_coop) {
+                uint32_t sh = ctx->coop_shift > 5u ? ctx->coop_shift - 5u : 0u;
+                if (const char *d = getenv("NS_COOP_MULTI_SHIFT")) sh = (uint32_t)atoi(d) & 31u;
+                m_coop = std::min(coop_at, std::max(coop_at >> sh, 64u));
+            }
             if (n_coop) {      // wave-per-read for the head of the (length-sorted) list, thread-per-read for the rest
-                GenArgs B = A; B.list_n = n_coop;
+                GenArgs B = A; B.list_n = n_coop + m_coop; B.list = cur + (m_coop ? 0u : coop_at);
+                if (m_coop) { B.hole_at = m_coop; B.hole_len = coop_at - m_coop; }      // [0, m_coop) and [coop_at, coop_at + n_coop) of the order
                 { const char *d = getenv("NS_UCOOP_K"); B.coop_k1 = d && atoi(d) == 1 ? 1u : 0u; }
                 HIPCHK(hipEventRecord(ctx->ev_fork, st));
                 HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
                 // unaligned reads: the run-length tables in LDS (k_chain<true, true>; the image must fit next to nothing else: 64 KB)
                 if (prm->kind == NS_KIND_UNALIGNED && ctx->lds_tables && ctx->ucoop_lds && (size_t)A.m.ct.n_words_mix * 8 <= 64u * 1024u)
-                    k_chain<true, true><<<dim3(n_coop), dim3(64), (size_t)A.m.ct.n_words_mix * 8, ctx->stream2>>>(B);
+                    k_chain<true, true><<<dim3(B.list_n), dim3(64), (size_t)A.m.ct.n_words_mix * 8, ctx->stream2>>>(B);
                 else { B.coop_mix = (size_t)B.m.ct.n_words_mix * 8 <= 32u * 1024u ? 1u : 0u;
-                       k_chain<false, true><<<dim3(n_coop), dim3(64), B.coop_mix ? (size_t)B.m.ct.n_words_mix * 8 : 0, ctx->stream2>>>(B); }
+                       k_chain<false, true><<<dim3(B.list_n), dim3(64), B.coop_mix ? (size_t)B.m.ct.n_words_mix * 8 : 0, ctx->stream2>>>(B); }
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
-                A.list = cur + n_coop; A.list_n = cur_n - n_coop;
+                if (coop_at) { A.list = cur + m_coop; A.hole_at = coop_at - m_coop; A.hole_len = n_coop; } else A.list = cur + n_coop;
+                A.list_n = cur_n - n_coop - m_coop;
             }
+            if (a == 0 && n_multi && prm->kind == NS_KIND_ALIGNED && !getenv("NS_PRIO_BY_POSITION")) A.prio_thr = (const uint32_t *)ctx->ord_bins.p + 2 * NS_ORD_BINS;
             const uint32_t cb = lds ? ctx->chain_block : NS_CHAIN_BLOCK;
             const dim3 grid_c((A.list_n + cb - 1) / cb), blk_c(cb);
             if (!A.list_n) {}
@@ -3577,6 +3683,12 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
             cur = nxt; nxt = cur == list_b ? list_c : list_b;      // (list_a keeps the length-sorted order of the batch for the record kernels)
         }
         info->ms_kernel[NS_K_EVENTS] = ms_chain;
+#ifdef NS_CHAIN_CLOCK
+        if (prm->kind == NS_KIND_ALIGNED) { unsigned long long c[16], z[16] = {0}; HIPCHK(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_chain_clock), sizeof c)); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_chain_clock), z, sizeof z));
+          fprintf(stderr, "chain clock: lane 0 of the multi waves: aligned pieces %.3f ms, gaps %.3f ms, behind the lists %.3f ms (means) | ", c[6] ? c[8] * 1e-5 / c[6] : 0.0, c[6] ? c[9] * 1e-5 / c[6] : 0.0, c[6] ? c[10] * 1e-5 / c[6] : 0.0);
+          fprintf(stderr, "chain clock: single waves %llu max %.3f ms mean %.3f ms (slowest at block %llu) | multi waves %llu max %.3f ms mean %.3f ms (slowest at block %llu) | ms_chain %.3f\n",
+              c[2], c[0] * 1e-5, c[2] ? c[1] * 1e-5 / c[2] : 0.0, c[3] >> 32, c[6], c[4] * 1e-5, c[6] ? c[5] * 1e-5 / c[6] : 0.0, c[7] >> 32, ms_chain); }
+#endif
         if (!overflow) break;
         info->n_overflow += stats[0] & NS_OVER_MASK;
         if (retry >= 6) return fail(ctx, NS_ENOMEM, "event capacity overflow persists after 6 retries");
