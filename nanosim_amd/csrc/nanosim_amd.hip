@@ -2053,8 +2053,9 @@ __global__ void __launch_bounds__(256) k_cs_hist(const uint8_t *__restrict__ cs,
         if (qry) maf_hist_alignment(s, qry + off[a], n, acc);
         else {
             uint32_t pm = 0;
-            { CsCursor c; cs_cursor_init(c); int t; uint32_t l; if (cs_next_op(s, n, c, t, l) && t != CS_MATCH) pm = cs_carry_in(cs, off, a); }
-            cs_hist_alignment(s, n, pm, nullptr, acc);
+            CsBytes sb(s);                                   // (an 8-byte register window over the thread's string: ns_cs_hist.h)
+            { CsCursor c; cs_cursor_init(c); int t; uint32_t l; if (cs_next_op(sb, n, c, t, l) && t != CS_MATCH) pm = cs_carry_in(cs, off, a); }
+            cs_hist_alignment(sb, n, pm, nullptr, acc);
         }
         if (acc.mx) atomicMax(&cnt[NS_CSH_LDS_WORDS - 1u], acc.mx);
     }

@@ -23,9 +23,27 @@ enum { CS_MATCH = 0, CS_MIS = 1, CS_INS = 2, CS_DEL = 3, CS_SKIP = 4 };         
 enum { CSH_MATCH = 0, CSH_FIRST = 1, CSH_MIS = 2, CSH_INS = 3, CSH_DEL = 4 };    // the five 1-D histograms (add_dict, B:14-22)
 #define NS_CS_DICT_MAX 1000u      // add_dict ignores values above it (B:15-16)
 
+// Where the bytes of a string come from: `const uint8_t *` (host, MAF branch) or CsBytes (k_cs_hist) — the walks only index it.
+// CsBytes keeps the aligned 8 bytes around the last position in a register pair: a thread walks its own string, so a byte load of a
+// wavefront touches 64 cache lines, and that, not the arithmetic, is what the kernel waits for (one load per 8 bytes instead of one per
+// byte; the strings are allocated with 16 bytes to spare, so the last window may reach beyond a string's end).
+#if defined(__HIPCC__)
+struct CsBytes {
+    const uint8_t *p;
+    uint64_t w; uintptr_t at;
+    __device__ __forceinline__ explicit CsBytes(const uint8_t *q) : p(q), w(0), at(~(uintptr_t)0) {}
+    __device__ __forceinline__ uint8_t operator[](uint64_t i) {
+        const uintptr_t a = (uintptr_t)p + i, al = a & ~(uintptr_t)7;
+        if (al != at) { w = *reinterpret_cast<const uint64_t *>(al); at = al; }
+        return (uint8_t)(w >> (8u * (uint32_t)(a & 7u)));
+    }
+};
+#endif
+
 // the next item of the cs string at or after i — re.findall('(:[0-9]+|\*[a-z][a-z]|[=\+\-][A-Za-z]+)') of B:46: what matches nothing
 // is skipped one character at a time
-NS_CSH bool cs_next_item(const uint8_t *s, uint64_t n, uint64_t &i, int &type, uint32_t &len) {
+template <class S>
+NS_CSH bool cs_next_item(S &s, uint64_t n, uint64_t &i, int &type, uint32_t &len) {
     while (i < n) {
         const uint8_t c = s[i];
         if (c == ':') {
@@ -47,7 +65,8 @@ NS_CSH bool cs_next_item(const uint8_t *s, uint64_t n, uint64_t &i, int &type, u
 // the next op of the FOLDED list (list_op / list_hist of parse_cs): a run of mismatch items is one op whose length is their number
 struct CsCursor { uint64_t i; bool have; int type; uint32_t len; };
 NS_CSH void cs_cursor_init(CsCursor &c) { c.i = 0; c.have = false; c.type = CS_SKIP; c.len = 0; }
-NS_CSH bool cs_next_op(const uint8_t *s, uint64_t n, CsCursor &c, int &type, uint32_t &len) {
+template <class S>
+NS_CSH bool cs_next_op(S &s, uint64_t n, CsCursor &c, int &type, uint32_t &len) {
     int t; uint32_t l;
     if (!c.have) { if (!cs_next_item(s, n, c.i, t, l)) return false; c.have = true; c.type = t; c.len = l; }
     type = c.type; len = c.len;
@@ -64,16 +83,17 @@ NS_CSH bool cs_next_op(const uint8_t *s, uint64_t n, CsCursor &c, int &type, uin
 // the walk of hist() over one alignment (B:328-365).  prev_match: in = the value the previous alignments left (the reference never
 // resets it), out = what this one leaves; *assigned: the alignment assigned it.  n_skip counts `=` items (long-form cs): the reference's
 // two lists fall out of step on them, the caller refuses such input.
-template <class Acc>
-NS_CSH void cs_hist_alignment(const uint8_t *s, uint64_t n, uint32_t &prev_match, bool *assigned, Acc &acc) {
-    // the type of the last op: what list_op_unique[i - 1] is for i = 0 (B:332)
-    int last_type = CS_SKIP;
-    { CsCursor c; cs_cursor_init(c); int t; uint32_t l; while (cs_next_op(s, n, c, t, l)) last_type = t; }
+template <class Acc, class S>
+NS_CSH void cs_hist_alignment(S &s, uint64_t n, uint32_t &prev_match, bool *assigned, Acc &acc) {
     CsCursor c; cs_cursor_init(c);
     bool flag = true;
-    int prev_type = last_type, prev_error = CS_MIS;             // (prev_error: only read after an error of this alignment has set it)
+    int prev_error = CS_MIS;                                    // (only read after an error of this alignment has set it)
     int t; uint32_t l;
     bool more = cs_next_op(s, n, c, t, l);
+    // the type of the last op: what list_op_unique[i - 1] is for i = 0 (B:332) — looked at only when the FIRST op is an error, so only
+    // then is the string walked for it (until round 6 every alignment was walked twice)
+    int prev_type = CS_SKIP;
+    if (more && t != CS_MATCH && t != CS_SKIP) { CsCursor c2; cs_cursor_init(c2); int t2; uint32_t l2; while (cs_next_op(s, n, c2, t2, l2)) prev_type = t2; }
     while (more) {
         int tn = CS_SKIP; uint32_t ln = 0;
         const bool has_next = cs_next_op(s, n, c, tn, ln);
@@ -113,7 +133,12 @@ NS_CSH uint32_t cs_carry_in(const uint8_t *cs, const uint64_t *off, uint64_t a) 
     while (a > 0) {
         --a;
         uint32_t pm = 0; bool assigned = false; CsAccNull z;
-        cs_hist_alignment(cs + off[a], off[a + 1] - off[a], pm, &assigned, z);
+#if defined(__HIP_DEVICE_COMPILE__)
+        CsBytes s(cs + off[a]);
+#else
+        const uint8_t *s = cs + off[a];
+#endif
+        cs_hist_alignment(s, off[a + 1] - off[a], pm, &assigned, z);
         if (assigned) return pm;
     }
     return 0;
