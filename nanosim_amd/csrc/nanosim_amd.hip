@@ -52,6 +52,9 @@ struct GenArgs {
     uint32_t ev_stage;               // k_chain<LDS>: byte offset of the event staging area behind the tables in dynamic LDS (0: none)
     uint32_t hole_at, hole_len;      // k_chain over a list with a hole: entries [hole_at, hole_at + hole_len) belong to another launch (the wave-per-read list of a
                                      // chimeric batch: the longest single-segment reads, which sit behind the reads of several pieces in the visiting order)
+    uint32_t piece_mode;             // k_chain, thread per read, pass 0 of a chimeric batch: 1 = a thread per PIECE of the reads of several pieces (slot s of
+                                     // NS_PIECE_SLOTS takes piece s, the last slot all pieces from there on): the error list only, left in the piece record;
+                                     // 2 = the reads themselves, their lists done (acceptance, positions, name); 0 = a read's lists and the rest in one thread
     const uint32_t *prio_thr;        // k_chain, thread per read, over a batch with reads of several pieces: [1..3] = the planned work from which a wavefront takes
                                      // issue priority 3, 2, 1 (k_order_scan; nullptr: by position in the list, which is then one descending order)
     uint32_t defer_tail;             // metagenome pass: k_chain stops in front of the positions (the species are not known yet: the host is still walking the
@@ -246,7 +249,8 @@ __global__ void __launch_bounds__(SMALL ? 64 : 256, SMALL ? 7 : 1) k_lengths(Gen
         else if (!seg_length(A.m, prm, key, pi >> 1, epoch, mlen)) { ok = false; mlen = 0; }   // S:1285-1296
         const int32_t m32 = mlen > 0x3fffffff ? 0x3fffffff : mlen < -1 ? -1 : (int32_t)mlen;
         ns_piece p;
-        p.ref_gpos = 0; p.ev_off = 0; p.chrom = 0; p.pos = plan_chrom; p.ref_len = (uint32_t)m32; p.out_len = 0; p.n_ev = 0;   // (pos: the planned transcript until k_chain draws the start)
+        cap = (cap + 3ull) & ~3ull;                                                     // every piece starts on a group of four event slots
+        p.ref_gpos = 0; p.ev_off = cap /* RELATIVE until k_chain has run: its piece mode goes by it */; p.chrom = 0; p.pos = plan_chrom; p.ref_len = (uint32_t)m32; p.out_len = 0; p.n_ev = 0;   // (pos: the planned transcript until k_chain draws the start)
         p.kind = is_gap ? 1u : 0u;
         pc[pi] = p;
         const uint64_t l = m32 > 0 ? (uint64_t)m32 : 0;
@@ -336,6 +340,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #ifndef NS_CHAIN_BLOCK_BIG
 #define NS_CHAIN_BLOCK_BIG 512
 #endif
+#define NS_PIECE_SLOTS 6u          // k_chain's piece mode: threads per read of several pieces (five pieces = three segments one each; the sixth takes the rest)
 // Wavefronts per SIMD the thread-per-read chain is compiled for.  Five: 95 VGPRs without scratch, and the bench model's LDS image (24.1 KB)
 // + 8 KB of event staging fits five workgroups per CU (round 5, same box: aligned chain alone 2.94 -> 2.76 ms; four until round 4, when
 // the lists needed 104 VGPRs and the image 30 KB)
@@ -345,7 +350,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #ifdef NS_CHAIN_CLOCK
 __device__ unsigned long long g_chain_clock[16];      // [multi ? 4 : 0] + {max, sum, waves, max trip proxy}: thread-per-read chain, per wavefront (100 MHz ticks)
 #endif
-template <bool LDS_TABLES, bool COOP>
+template <bool LDS_TABLES, bool COOP, bool PIECES = false>       // PIECES: the piece modes (GenArgs.piece_mode) are compiled in
 __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? (LDS_TABLES ? NS_UCOOP_MINW : 4) : NS_CHAIN_MINW) k_chain(GenArgs A) {
     extern __shared__ uint64_t lds_tbl[];
     CoopLds *coop = nullptr;
@@ -395,7 +400,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? (LDS_TA
         else if (w >= A.prio_thr[2]) __builtin_amdgcn_s_setprio(2);
         else if (w >= A.prio_thr[3]) __builtin_amdgcn_s_setprio(1);
     }
-    else if (COOP || blockIdx.x < (gridDim.x >> 6)) __builtin_amdgcn_s_setprio(3);
+    else if (COOP || (PIECES && A.piece_mode == 1u) || blockIdx.x < (gridDim.x >> 6)) __builtin_amdgcn_s_setprio(3);
     else if (blockIdx.x < (gridDim.x >> 4)) __builtin_amdgcn_s_setprio(2);
     else if (blockIdx.x < (gridDim.x >> 2)) __builtin_amdgcn_s_setprio(1);
 #ifdef NS_CHAIN_CLOCK
@@ -403,8 +408,11 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? (LDS_TA
 #endif
     unsigned long long st_over = 0, st_bases = 0, st_ref = 0, st_ev = 0;
     uint32_t st_max = 0;
-    if (tid < A.list_n) {
-        const uint64_t r = A.list ? A.list[tid + (tid >= A.hole_at ? A.hole_len : 0u)] : A.list_base + tid;      // (hole: the entries another launch takes)
+    const bool piece_only = PIECES && !COOP && A.piece_mode == 1u;      // thread (slot, i): piece `slot` of the i-th read of the list
+    const uint32_t slot = piece_only ? (uint32_t)(tid / A.list_n) : 0u;
+    const uint64_t li = piece_only ? tid % A.list_n : tid;
+    if (piece_only ? slot < NS_PIECE_SLOTS : tid < A.list_n) {
+        const uint64_t r = A.list ? A.list[li + (li >= A.hole_at ? A.hole_len : 0u)] : A.list_base + li;      // (hole: the entries another launch takes)
         const int kind = (int)prm.kind;
         const bool trx_al = prm.trx && kind != NS_KIND_UNALIGNED;       // r is then a position of the candidate table (one try each)
         const bool meta_al = (A.meta && kind != NS_KIND_UNALIGNED) || trx_al;      // ... or of a metagenome pass
@@ -427,11 +435,29 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? (LDS_TA
             int64_t total = (int64_t)rd.head + rd.tail;
             uint32_t evn = 0, evp = 0;                               // events of the read so far / where the next piece's events start (below)
             const uint32_t trx_chrom = trx_al ? pc[0].pos : 0u;      // planned by k_lengths
-            for (uint32_t pi = 0; pi < n_pieces; ++pi) {
+            const uint32_t pi_lo = piece_only ? slot : 0u, pi_hi = (piece_only && slot + 1u < NS_PIECE_SLOTS) ? min(slot + 1u, n_pieces) : n_pieces;
+            for (uint32_t pi = pi_lo; pi < pi_hi; ++pi) {
                 ns_piece p = pc[pi];
+                if (PIECES && !COOP && A.piece_mode == 2u) {                     // the list is done (piece mode 1): what it left in the record
+                    const uint32_t fl = (uint32_t)(p.ref_gpos >> 32);
+                    if (fl & 1u) sink.range = true;
+                    if (fl & 2u) sink.overflow = true;
+                    p.ev_off = ev_off + p.ev_off;
+                    pc[pi] = p;
+                    evn += p.n_ev;
+                    if (!p.kind) total += (int64_t)(int32_t)(uint32_t)p.ref_gpos;            // e.l_new, S:1362
+                    continue;
+                }
+                if (piece_only) {                                      // the piece's own share of the read's capacity (k_lengths)
+                    evp = (uint32_t)p.ev_off;
+                    const uint32_t end = pi + 1u < n_pieces ? (uint32_t)pc[pi + 1u].ev_off : ev_cap;
+                    sink.range = false; sink.overflow = false;
+                    sink.ev = A.events + ev_off + evp; sink.cap = end > evp ? end - evp : 0u;
+                }
                 const int32_t m32 = (int32_t)p.ref_len;                // planned length from k_lengths
                 const uint32_t sid = p.kind ? NS_GAP_SEG + (pi >> 1) : (pi >> 1);
-                sink.ev = A.events + ev_off + evp; sink.cap = ev_cap > evp ? ev_cap - evp : 0; sink.n = 0; sink.shift = 0;
+                if (!piece_only) { sink.ev = A.events + ev_off + evp; sink.cap = ev_cap > evp ? ev_cap - evp : 0; }
+                sink.n = 0; sink.shift = 0;
                 sink.stg = nullptr;
 #ifdef NS_ABLATE
                 if (COOP && LDS_TABLES && (A.dbg & (1u << 21))) sink.cap = 0;                       // (profiling: no event stores)
@@ -467,7 +493,8 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? (LDS_TA
 #ifdef NS_ABLATE
                 if (COOP && LDS_TABLES && (A.dbg & (1u << 21))) { sink.overflow = false; sink.n = 0; }
 #endif
-                p.ev_off = ev_off + evp;
+                if (!piece_only) p.ev_off = ev_off + evp;
+                else p.ref_gpos = (uint64_t)(uint32_t)e.l_new | (sink.range ? 1ull << 32 : 0ull) | (sink.overflow ? 2ull << 32 : 0ull);
                 p.ref_len = (uint32_t)(e.middle_ref < 0 ? 0 : e.middle_ref);
                 p.out_len = (uint32_t)((e.middle_ref < 0 ? 0 : e.middle_ref) + sink.shift);
                 p.n_ev = sink.n;
@@ -482,6 +509,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? (LDS_TA
             // beyond the 18-bit shift field: multi-megabase reads only): this ATTEMPT is dropped like one that fails the final length
             // check (S:1429-1430) and the read draws new lengths; counted in stats[0] >> 40 (ns_batch_info.n_range_redraws).  The
             // reference keeps Python integers (S:1875-1882) and would emit the read: a documented limit of the record format.
+            if (piece_only) break;
             if (sink.range) { if (lead) st_over = 1ull << 40; if (!meta_al) { ++epoch; fails = 0; } break; }
             if (sink.overflow) { overflow = true; break; }
             int64_t trx_len = 0;
@@ -598,7 +626,7 @@ __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? (LDS_TA
             }
             accepted = true;
         } while (false);
-        if (lead) {
+        if (lead && !piece_only) {
             if (overflow) st_over += 1;
             A.reads[r] = rd;
             if (meta_al) { /* a rejected read is re-planned by the next pass */ }
@@ -2102,7 +2130,8 @@ struct DevBuf {
 struct ns_ctx {
     int device = 0;
     hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: cooperative chain of the longest reads, concurrent with the bulk
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t stream3 = nullptr;                     // chimeric batches: the reads of several pieces, a thread per piece, next to both (created at first use)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
     std::string err;
     bool has_model = false, has_ref = false, has_batch = false;
     DevModel m{};
@@ -2378,6 +2407,8 @@ void ns_destroy(ns_ctx *ctx) {
     ctx->sinks.clear();
     if (ctx->stream) { e = hipStreamSynchronize(ctx->stream); e = hipStreamDestroy(ctx->stream); }
     if (ctx->stream2) { e = hipStreamSynchronize(ctx->stream2); e = hipStreamDestroy(ctx->stream2); }
+    if (ctx->stream3) { e = hipStreamSynchronize(ctx->stream3); e = hipStreamDestroy(ctx->stream3); }
+    if (ctx->ev_join3) e = hipEventDestroy(ctx->ev_join3);
     if (ctx->ev_fork) e = hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) e = hipEventDestroy(ctx->ev_join);
     free_pool(ctx->model_allocs);
@@ -3637,10 +3668,12 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
                 n_coop = (cur_n - std::min(cur_n, n_multi)) >> ctx->coop_shift;
             const uint32_t coop_at = (a == 0 && prm->kind == NS_KIND_ALIGNED) ? std::min(cur_n, n_multi) : 0u;     // where that list starts in the visiting order
             // ... and the longest of the reads of several pieces (the head of the order): their chains are the sum of their pieces', so more of them
-            // lie beyond the length at which a thread-per-read chain becomes the tail of the launch (NS_COOP_MULTI_SHIFT, default: 32 times the share = 3 %; same-box sweep in profiles/r06/ab_chimeric_order.log)
+            // lie beyond the length at which a thread-per-read chain becomes the tail of the launch (NS_COOP_MULTI_SHIFT; same-box sweeps in profiles/r06/ab_chimeric_order.log)
             uint32_t m_coop = 0;
             if (coop_at && n_coop) {
-                uint32_t sh = ctx->coop_shift > 5u ? ctx->coop_shift - 5u : 0u;
+                // (a thread per piece for the rest — below — leaves few of them too long for that side: 1/512; one thread per read: 1/32)
+                const bool piece_threads = lds && !getenv("NS_NO_PIECE_THREADS");
+                uint32_t sh = piece_threads ? (ctx->coop_shift > 1u ? ctx->coop_shift - 1u : 0u) : (ctx->coop_shift > 5u ? ctx->coop_shift - 5u : 0u);
                 if (const char *d = getenv("NS_COOP_MULTI_SHIFT")) sh = (uint32_t)atoi(d) & 31u;
                 m_coop = std::min(coop_at, std::max(coop_at >> sh, 64u));
             }
@@ -3660,14 +3693,37 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
                 if (coop_at) { A.list = cur + m_coop; A.hole_at = coop_at - m_coop; A.hole_len = n_coop; } else A.list = cur + n_coop;
                 A.list_n = cur_n - n_coop - m_coop;
             }
-            if (a == 0 && n_multi && prm->kind == NS_KIND_ALIGNED && !getenv("NS_PRIO_BY_POSITION")) A.prio_thr = (const uint32_t *)ctx->ord_bins.p + 2 * NS_ORD_BINS;
             const uint32_t cb = lds ? ctx->chain_block : NS_CHAIN_BLOCK;
+            // The reads of several pieces that stay on the thread-per-read side: a thread per PIECE (k_chain's piece mode 1: the error lists, each into
+            // its piece's own share of the read's event slots), then a thread per read for what follows the lists (mode 2) — on a third stream, next
+            // to the launch of the single-segment reads.  A thread that walks all pieces of its read has 2-4 times the trip count of any other, and
+            // the slowest wavefront is what a chain launch waits for (profiles/r06/ab_chimeric_order.log).  NS_NO_PIECE_THREADS=1: one thread per read.
+            uint32_t n_pt = 0;
+            if (a == 0 && lds && n_coop && coop_at > m_coop && !getenv("NS_NO_PIECE_THREADS")) {
+                if (!ctx->stream3) {
+                    HIPCHK(hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
+                    HIPCHK(hipEventCreateWithFlags(&ctx->ev_join3, hipEventDisableTiming));
+                }
+                n_pt = coop_at - m_coop;
+                GenArgs P = A; P.list = cur + m_coop; P.list_n = n_pt; P.hole_at = 0; P.hole_len = 0; P.prio_thr = nullptr;
+                const size_t lds_p = ctx->lds_bytes + (P.ev_stage ? cb * 32u : 0u);
+                HIPCHK(hipStreamWaitEvent(ctx->stream3, ctx->ev_fork, 0));
+                P.piece_mode = 1;
+                k_chain<true, false, true><<<dim3((unsigned)(((uint64_t)n_pt * NS_PIECE_SLOTS + cb - 1) / cb)), dim3(cb), lds_p, ctx->stream3>>>(P);
+                P.piece_mode = 2;
+                k_chain<true, false, true><<<dim3((n_pt + cb - 1) / cb), dim3(cb), lds_p, ctx->stream3>>>(P);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipEventRecord(ctx->ev_join3, ctx->stream3));
+                A.list = cur + coop_at + n_coop; A.hole_at = 0; A.hole_len = 0; A.list_n = cur_n - coop_at - n_coop;
+            }
+            if (a == 0 && n_multi && !n_pt && prm->kind == NS_KIND_ALIGNED && !getenv("NS_PRIO_BY_POSITION")) A.prio_thr = (const uint32_t *)ctx->ord_bins.p + 2 * NS_ORD_BINS;
             const dim3 grid_c((A.list_n + cb - 1) / cb), blk_c(cb);
             if (!A.list_n) {}
             else if (lds) k_chain<true, false><<<grid_c, blk_c, ctx->lds_bytes + (A.ev_stage ? cb * 32u : 0u), st>>>(A);
             else k_chain<false, false><<<grid_c, blk_c, 0, st>>>(A);
             HIPCHK(hipGetLastError());
             if (n_coop) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
+            if (n_pt) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join3, 0));
             HIPCHK(hipEventRecord(ctx->evt[4], st));
             if (ctx->gate_signal) ctx->gate_signal->store(1, std::memory_order_release);
             fold_stats(ctx, st);

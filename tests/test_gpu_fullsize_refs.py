@@ -135,11 +135,13 @@ def test_grch38_like_chimeric(hg002_model):
         eng.close()
 
 
-def test_chimeric_batch_on_both_chain_lists_equals_small_batches(hg002_model):
+@pytest.mark.parametrize("n,extra", [(131_072, dict(emit_errlog=True)), (32_768, dict(fastq=True, kmer_bias=5, emit_errlog=True))])
+def test_chimeric_batch_on_both_chain_lists_equals_small_batches(hg002_model, n, extra):
     """A chimeric batch large enough for the wave-per-read lists (>= 16 384 reads: the reads of several pieces are visited first, the longest
-    3 % of them and the longest 0.1 % of the others on the wave-per-read list, the thread-per-read launch over the list with a hole, its issue
-    priorities from the planned work) against the SAME reads generated in batches of 4 096 (thread-per-read chain only, the path the oracle
-    parity tests cover): records and error-profile rows byte for byte — a read is a function of (seed, index) (S:1276-1299, 1833-1916)"""
+    of them and the longest 0.1 % of the others on the wave-per-read list, the rest of them as a thread per PIECE — k_chain's piece modes —
+    next to the thread-per-read launch of the others) against the SAME reads generated in batches of 4 096 (one thread per read, the path
+    the oracle parity tests cover): records and error-profile rows byte for byte, also through the -k stage — a read is a function of
+    (seed, index) (S:1276-1299, 1833-1916)"""
     mdl = hg002_model
     bases = synth.synth_sequence(synth.ECOLI_LEN, SEED, n_frac=0.0005, iupac_frac=0.0002, lower_frac=0.02, hp_boost=0.005)
     ref = M.Reference(["ecoli-like"], bases, np.array([0, synth.ECOLI_LEN], dtype=np.uint64), np.array([1], dtype=np.uint8))
@@ -147,8 +149,8 @@ def test_chimeric_batch_on_both_chain_lists_equals_small_batches(hg002_model):
     try:
         eng.set_reference(ref)
         eng.load_model(mdl)
-        n, chunk = 131_072, 4_096
-        kw = dict(seed=SEED + 11, chimeric=True, emit_errlog=True, max_len=ref.max_chrom)
+        chunk = 4_096
+        kw = dict(seed=SEED + 11, chimeric=True, max_len=ref.max_chrom, **extra)
         b = eng.generate(E.make_params(first_read=0, n_reads=n, **kw))
         reads = b.reads()
         assert np.all(reads["flags"] == 0)
@@ -165,10 +167,11 @@ def test_chimeric_batch_on_both_chain_lists_equals_small_batches(hg002_model):
             assert np.array_equal(ce, err[e_at:e_at + len(ce)]), f
             r_at += len(cr); e_at += len(ce)
         assert r_at == len(rec) and e_at == len(err)
-        # ... and a handful of the longest reads of several pieces (the wave-per-read list's) against the oracle itself
+        # ... and reads of several pieces from both sides — the longest (the wave-per-read list's) and three of the middle (a thread per
+        # piece) — against the oracle itself
         multi = np.nonzero(nseg > 1)[0]
-        longest = multi[np.argsort(seq_len[multi])[-3:]]
-        for r in (int(x) for x in longest):
+        by_len = multi[np.argsort(seq_len[multi])]
+        for r in (int(x) for x in np.concatenate([by_len[-3:], by_len[len(by_len) // 2:len(by_len) // 2 + 3]])):
             exp = O.generate(mdl, ref, E.make_params(first_read=r, n_reads=1, **kw), bytes_per_read=2_000_000, events_per_read=200_000)
             lo = int(reads["rec_off"][r]); hi = int(reads["rec_off"][r + 1]) if r + 1 < n else len(rec)
             assert rec[lo:hi].tobytes() == exp["records"].tobytes(), r
