@@ -2,9 +2,10 @@
 //
 // Pipeline of one ns_generate() call (one worker call of the reference, S:1266-1454 / S:1482-1549):
 //   k_nseg, k_lengths   thread/read   segment count (S:1276-1299), lengths of the attempt, strand, head / tail, event capacity
-//   scans, radix sort   rocPRIM       piece / event offsets; visiting order by descending length
+//   scans, k_order_*    rocPRIM / own piece / event offsets; visiting order by descending planned work (1 024 bins; reads of several pieces first)
 //   k_chain             thread/read   error_list / unaligned_error_list, acceptance, positions   (S:1283-1402, 1833-1916, 1784-1830,
 //                       (+ wave/read for the longest reads, the unaligned reads and the gaps)      1694-1781); one pass per attempt
+//                       (+ thread/PIECE for the reads of several pieces of a chimeric batch: piece modes 1 + 2, GenArgs.piece_mode)
 //   k_stats_fold        1 wave        the chain kernels' counters: 64 copies -> one (one set of counters serialises their atomics)
 //   k_ir_splice         wave/read     transcriptome: retained introns spliced into the read's slot of an arena (S:1156-1192)
 //   -k: k_hp_filter_w, k_materialise<., MAT_HP_SCRATCH>, k_hp_scan, k_hp_drain, k_hp_finalize  (ns_hp.h; S:1920-1947, 618-705)
