@@ -135,8 +135,10 @@ def test_grch38_like_chimeric(hg002_model):
         eng.close()
 
 
-@pytest.mark.parametrize("n,extra", [(131_072, dict(emit_errlog=True)), (32_768, dict(fastq=True, kmer_bias=5, emit_errlog=True))])
-def test_chimeric_batch_on_both_chain_lists_equals_small_batches(hg002_model, n, extra):
+@pytest.mark.parametrize("n,extra,env", [(131_072, dict(emit_errlog=True), {}), (32_768, dict(fastq=True, kmer_bias=5, emit_errlog=True), {}),
+                                         (32_768, dict(emit_errlog=True), {"NS_NO_PIECE_THREADS": "1"}),      # one thread per read over the list with a hole
+                                         (32_768, dict(emit_errlog=True), {"NS_TAIL_BITS": "31"})])           # ... with the chain tables in global memory
+def test_chimeric_batch_on_both_chain_lists_equals_small_batches(hg002_model, monkeypatch, n, extra, env):
     """A chimeric batch large enough for the wave-per-read lists (>= 16 384 reads: the reads of several pieces are visited first, the longest
     of them and the longest 0.1 % of the others on the wave-per-read list, the rest of them as a thread per PIECE — k_chain's piece modes —
     next to the thread-per-read launch of the others) against the SAME reads generated in batches of 4 096 (one thread per read, the path
@@ -145,6 +147,8 @@ def test_chimeric_batch_on_both_chain_lists_equals_small_batches(hg002_model, n,
     mdl = hg002_model
     bases = synth.synth_sequence(synth.ECOLI_LEN, SEED, n_frac=0.0005, iupac_frac=0.0002, lower_frac=0.02, hp_boost=0.005)
     ref = M.Reference(["ecoli-like"], bases, np.array([0, synth.ECOLI_LEN], dtype=np.uint64), np.array([1], dtype=np.uint8))
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     eng = E.Engine(0)
     try:
         eng.set_reference(ref)
