@@ -2668,11 +2668,13 @@ static int launch_materialise(ns_ctx *ctx, const GenArgs &A, size_t n, bool fast
             int rc = ensure(ctx, ctx->slow_q, 16 + (n / 4 + 4096) * sizeof(SlowTile));
             if (rc) return rc;
             cap = (ctx->slow_q.cap - 16) / sizeof(SlowTile);
-        }
+            ctx->sq_zeroed = false;                 // a NEW buffer: k_stats_fold zeroed the counter of the one just freed.  (Until the last day of round 6 the
+        }                                           // launch went ahead on whatever the new allocation held — a batch larger than all before it, on recycled device
+                                                    // memory, queued `garbage` tiles: a memory fault in the generic kernel; scripts/parity_chimeric_big.py found it)
         SlowQueue sq;
         sq.count = (uint32_t *)ctx->slow_q.p; sq.items = (SlowTile *)((uint8_t *)ctx->slow_q.p + 16);
         sq.cap = (uint32_t)(cap > 0xffffffffull ? 0xffffffffull : cap);
-        if (!(ctx->sq_zeroed && round == 0 && sq.count == (uint32_t *)ctx->slow_q.p)) HIPCHK(hipMemsetAsync(sq.count, 0, 4, st));
+        if (!(ctx->sq_zeroed && round == 0)) HIPCHK(hipMemsetAsync(sq.count, 0, 4, st));
         ctx->sq_zeroed = false;
         const uint32_t *wd = nullptr;               // (MAT_HP_FINAL reads A.hp_wd; the other modes draw the letter words: event_word)
         if (ctx->dbg & 1024u) order = nullptr;          // (profiling: reads in index order)

@@ -183,6 +183,38 @@ def test_chimeric_batch_on_both_chain_lists_equals_small_batches(hg002_model, mo
         eng.close()
 
 
+def test_batches_growing_on_one_engine(hg002_model):
+    """Worker calls of growing size on ONE engine, a -k FASTQ call between them (what a CLI run with a changing batch size does): every buffer
+    that grows is a new allocation on recycled device memory, and nothing may rely on what an earlier launch left in the old one — the
+    slow-tile queue's counter did (zeroed by k_stats_fold in the buffer that the record stage then replaced): this sequence ended in a
+    GPU memory fault until the last day of round 6.  The last batch equals the same reads in batches of 4 096."""
+    mdl = hg002_model
+    bases = synth.synth_sequence(synth.ECOLI_LEN, SEED, n_frac=0.0005, iupac_frac=0.0002, lower_frac=0.02, hp_boost=0.005)
+    ref = M.Reference(["ecoli-like"], bases, np.array([0, synth.ECOLI_LEN], dtype=np.uint64), np.array([1], dtype=np.uint8))
+    eng = E.Engine(0)
+    try:
+        eng.set_reference(ref)
+        eng.load_model(mdl)
+        kw = dict(seed=SEED + 100, chimeric=True, max_len=ref.max_chrom)
+        for seed_off in (0, 1):
+            for n, extra in ((16_384, dict(emit_errlog=True)), (40_000, dict(emit_errlog=True, fastq=True, kmer_bias=5)), (70_000, dict(emit_errlog=True))):
+                b = eng.generate(E.make_params(first_read=7 + seed_off, n_reads=n, **kw, **extra))
+                assert np.all(b.reads()["flags"] == 0)
+                for f in range(0, n, 4096):                    # (the small calls in between, as scripts/parity_chimeric_big.py makes them)
+                    eng.generate(E.make_params(first_read=7 + seed_off + f, n_reads=min(4096, n - f), **kw, **extra))
+        n = 70_000
+        b = eng.generate(E.make_params(first_read=7, n_reads=n, emit_errlog=True, **kw))
+        rec = b.records().copy()
+        at = 0
+        for f in range(0, n, 4096):
+            cr = eng.generate(E.make_params(first_read=7 + f, n_reads=min(4096, n - f), emit_errlog=True, **kw)).records()
+            assert np.array_equal(cr, rec[at:at + len(cr)]), f
+            at += len(cr)
+        assert at == len(rec)
+    finally:
+        eng.close()
+
+
 def test_reference_beyond_4gb(hg002_model):
     """three linear chromosomes of 1.6 Gb: the third lies behind offset 2^32 of the concatenated reference (64-bit offsets everywhere)"""
     mdl = hg002_model
