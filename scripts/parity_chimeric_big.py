@@ -16,9 +16,12 @@ from nanosim_amd import engine as E, model as M, synth  # noqa: E402
 
 SEED = 20260926
 bad = 0
-for seg_mean in (1.05, 2.5, 1.002):
+# the table shape of a trained model (15 previous-match bins x 1 500-row ECDFs: the LDS image holds the hot prefixes only, 512-thread workgroups)
+TRAINED = dict(ecdf_rows=1500, mm_bins=((0, 1), (1, 2), (2, 3), (3, 5), (5, 7), (7, 10), (10, 14), (14, 19), (19, 25), (25, 33), (33, 45), (45, 60), (60, 90), (90, 150), (150, 1500)),
+               mm_means=(24.0, 25.0, 26.0, 27.0, 28.0, 29.0, 30.0, 31.0, 31.0, 32.0, 33.0, 34.0, 35.0, 36.0, 36.0), mm_zero=(0.0,) + (0.03,) * 14)
+for seg_mean in (1.05, 2.5, 1.002, -1.05):                      # (negative: the trained table shape)
     prefix = os.path.join(tempfile.mkdtemp(prefix="nschim_"), "training")
-    synth.write_model(prefix, synth.SynthModelSpec(n_train=200_000, seed=SEED, segment_mean=seg_mean), write_pkl=False)
+    synth.write_model(prefix, synth.SynthModelSpec(n_train=200_000, seed=SEED, segment_mean=abs(seg_mean), **(TRAINED if seg_mean < 0 else {})), write_pkl=False)
     mdl = M.load_model(prefix, fastq=True, homopolymer=True, chimeric=True)
     bases = synth.synth_sequence(synth.ECOLI_LEN, SEED, n_frac=0.0005, iupac_frac=0.0002, lower_frac=0.02, hp_boost=0.005)
     for circ in (1, 0):
