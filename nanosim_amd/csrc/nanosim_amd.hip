@@ -349,7 +349,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #define NS_CHAIN_MINW 5
 #endif
 #ifdef NS_CHAIN_CLOCK
-__device__ unsigned long long g_chain_clock[16];      // [multi ? 4 : 0] + {max, sum, waves, max trip proxy}: thread-per-read chain, per wavefront (100 MHz ticks)
+__device__ unsigned long long g_chain_clock[16];      // [multi ? 4 : 0] + {max, sum, waves, last block << 32 | its ticks}, [8..10] lane 0 of the multi wavefronts: aligned pieces, gaps, behind the lists: thread-per-read chain, per wavefront (100 MHz ticks; -DNS_CHAIN_CLOCK builds only)
 #endif
 template <bool LDS_TABLES, bool COOP, bool PIECES = false>       // PIECES: the piece modes (GenArgs.piece_mode) are compiled in
 __global__ void __launch_bounds__(COOP ? 64 : NS_CHAIN_BLOCK_BIG, COOP ? (LDS_TABLES ? NS_UCOOP_MINW : 4) : NS_CHAIN_MINW) k_chain(GenArgs A) {
@@ -3746,7 +3746,7 @@ int ns_generate(ns_ctx *ctx, const ns_params *prm, ns_batch_info *info) {
 #ifdef NS_CHAIN_CLOCK
         if (prm->kind == NS_KIND_ALIGNED) { unsigned long long c[16], z[16] = {0}; HIPCHK(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_chain_clock), sizeof c)); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_chain_clock), z, sizeof z));
           fprintf(stderr, "chain clock: lane 0 of the multi waves: aligned pieces %.3f ms, gaps %.3f ms, behind the lists %.3f ms (means) | ", c[6] ? c[8] * 1e-5 / c[6] : 0.0, c[6] ? c[9] * 1e-5 / c[6] : 0.0, c[6] ? c[10] * 1e-5 / c[6] : 0.0);
-          fprintf(stderr, "chain clock: single waves %llu max %.3f ms mean %.3f ms (slowest at block %llu) | multi waves %llu max %.3f ms mean %.3f ms (slowest at block %llu) | ms_chain %.3f\n",
+          fprintf(stderr, "chain clock: single waves %llu max %.3f ms mean %.3f ms (the group's last block: %llu) | multi waves %llu max %.3f ms mean %.3f ms (the group's last block: %llu) | ms_chain %.3f\n",
               c[2], c[0] * 1e-5, c[2] ? c[1] * 1e-5 / c[2] : 0.0, c[3] >> 32, c[6], c[4] * 1e-5, c[6] ? c[5] * 1e-5 / c[6] : 0.0, c[7] >> 32, ms_chain); }
 #endif
         if (!overflow) break;
